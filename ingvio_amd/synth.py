@@ -1,0 +1,368 @@
+"""Deterministic synthetic stereo-MSCKF workloads (BASELINE.json configs 2-5).
+
+This is harness code shared by tests and bench.py: it only produces *inputs* (IMU samples,
+clone poses, feature observations, index tables).  All filter arithmetic is delegated to the two
+callables the caller passes in:
+
+* ``transition(R, p, v, bg, ba, gyro, acc, gravity, dt) -> (R', p', v', Phi, G)`` — the analytic
+  IMU transition (ImuPropagator.cpp:98-162); the product one lives in libingvio_host.so
+  (``ingvio_amd.host.imu_transition``), tests may pass the oracle's.
+* a covariance engine with ``propagate / augment / append_independent / marginalize`` and ``n`` —
+  ``ingvio_amd.capi.DeviceCov`` (HIP) or ``oracle.oracle.Cov`` (CPU checker).
+
+Values follow the shipped sports-field stereo configuration
+(config/sportsfield/ingvio_stereo.yaml, stereo_{left,right}_config.yaml); only numbers, no code.
+"""
+import math
+
+import numpy as np
+
+# config/sportsfield/ingvio_stereo.yaml
+PARAMS = dict(
+    noise_g=0.004, noise_a=0.08, noise_bg=0.0002, noise_ba=0.008,
+    # quirk Q1 (State.cpp:51-52): _noise_clockbias <- noise_cb_rw param (0.2), _noise_cb_rw stays 0.2
+    sigma_cb=0.2, sigma_rw=0.2,
+    init_cov_rot=0.0, init_cov_pos=0.0, init_cov_vel=0.25, init_cov_bg=0.01, init_cov_ba=0.01,
+    init_cov_ext_rot=1.8e-2, init_cov_ext_pos=2e-3,
+    init_cov_cb=2.0, init_cov_fs=1.0, init_cov_yof=0.015,
+    gravity=9.8, visual_noise=0.08, chi2_thres=0.95, chi2_max_dof=150,
+)
+# stereo_left_config.yaml / stereo_right_config.yaml: R^{imu}_{cam}, t^{imu}_{cam}
+R_CL2I = np.array([[0.9999890386957373, -0.0043227774403168, 0.0017989117755288],
+                   [0.0043276579084841, 0.9999869417854389, -0.0027180205355500],
+                   [-0.0017871388870994, 0.0027257758172719, 0.9999946881262878]])
+T_CL2I = np.array([-0.0759472920952561, -0.0039320527565750, -0.0016395029500217])
+R_CR2I = np.array([[0.9999014076382304, -0.0133731297219721, 0.0042818692791948],
+                   [0.0133731003056063, 0.9999105754655292, 0.0000355022536769],
+                   [-0.0042819611512717, 0.0000217631139403, 0.9999908321255077]])
+T_CR2I = np.array([0.0341738532732442, -0.0032623030537933, -0.0017782029037505])
+
+
+def t_cl2cr():
+    """T_cl2cr = T_cr2i^-1 * T_cl2i (State.cpp:33)."""
+    R = R_CR2I.T @ R_CL2I
+    t = R_CR2I.T @ (T_CL2I - T_CR2I)
+    return R, t
+
+
+def chi2_table(max_dof=150, p=0.95):
+    """chi2_table[d] = 0.95-quantile of chi^2_d, d = 1..max_dof; [0] unused (Update.cpp:27-34).
+    Wilson-Hilferty start + Newton on the regularised lower incomplete gamma: self-contained, equals
+    scipy.stats.chi2.ppf to 1e-10 (tests/test_oracle_golden.py)."""
+    out = np.zeros(max_dof + 1)
+    for k in range(1, max_dof + 1):
+        out[k] = _chi2_ppf(p, k)
+    return out
+
+
+def _gammainc_lower_reg(a, x):
+    if x <= 0:
+        return 0.0
+    if x < a + 1.0:  # series
+        term = 1.0 / a
+        s = term
+        n = a
+        for _ in range(10000):
+            n += 1.0
+            term *= x / n
+            s += term
+            if abs(term) < abs(s) * 1e-17:
+                break
+        return s * math.exp(-x + a * math.log(x) - math.lgamma(a))
+    # continued fraction (Lentz) for Q
+    tiny = 1e-300
+    b = x + 1.0 - a
+    c = 1.0 / tiny
+    d = 1.0 / b
+    h = d
+    for i in range(1, 10000):
+        an = -i * (i - a)
+        b += 2.0
+        d = an * d + b
+        if abs(d) < tiny:
+            d = tiny
+        c = b + an / c
+        if abs(c) < tiny:
+            c = tiny
+        d = 1.0 / d
+        delta = d * c
+        h *= delta
+        if abs(delta - 1.0) < 1e-16:
+            break
+    q = math.exp(-x + a * math.log(x) - math.lgamma(a)) * h
+    return 1.0 - q
+
+
+def _chi2_ppf(p, k):
+    a = 0.5 * k
+    # Wilson-Hilferty
+    z = 1.6448536269514722 if abs(p - 0.95) < 1e-15 else _norm_ppf(p)
+    x = k * (1.0 - 2.0 / (9.0 * k) + z * math.sqrt(2.0 / (9.0 * k))) ** 3
+    x = max(x, 1e-8)
+    for _ in range(100):
+        f = _gammainc_lower_reg(a, 0.5 * x) - p
+        pdf = math.exp((a - 1.0) * math.log(0.5 * x) - 0.5 * x - math.lgamma(a)) * 0.5
+        step = f / pdf
+        xn = x - step
+        if xn <= 0:
+            xn = 0.5 * x
+        if abs(xn - x) < 1e-14 * max(1.0, x):
+            x = xn
+            break
+        x = xn
+    return x
+
+
+def _norm_ppf(p):  # Acklam, refined by one Newton step; only used when p != 0.95
+    a = [-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02,
+         1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00]
+    b = [-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02,
+         6.680131188771972e+01, -1.328068155288572e+01]
+    q = p - 0.5
+    r = q * q
+    x = (((((a[0] * r + a[1]) * r + a[2]) * r + a[3]) * r + a[4]) * r + a[5]) * q / \
+        (((((b[0] * r + b[1]) * r + b[2]) * r + b[3]) * r + b[4]) * r + 1.0)
+    e = 0.5 * math.erfc(-x / math.sqrt(2.0)) - p
+    x -= e * math.sqrt(2.0 * math.pi) * math.exp(0.5 * x * x)
+    return x
+
+
+# ---------------------------------------------------------------------------------------------
+# trajectory: circle r = 5 m at 2 m/s, camera looking along the direction of travel
+# ---------------------------------------------------------------------------------------------
+RADIUS, SPEED, HEIGHT = 5.0, 2.0, 1.0
+OMEGA = SPEED / RADIUS
+IMU_DT, IMU_PER_FRAME = 0.005, 10
+
+
+def true_pose(t):
+    """(R_i2w, p, v) of the IMU at time t.  Body axes: x radial-out, y down, z forward."""
+    c, s = math.cos(OMEGA * t), math.sin(OMEGA * t)
+    p = np.array([RADIUS * c, RADIUS * s, HEIGHT])
+    v = SPEED * np.array([-s, c, 0.0])
+    R = np.array([[c, 0.0, -s],
+                  [s, 0.0, c],
+                  [0.0, -1.0, 0.0]])
+    return R, p, v
+
+
+def true_imu(t):
+    """Noise-free body-frame (gyro, accel specific force) at time t."""
+    R, _, _ = true_pose(t)
+    c, s = math.cos(OMEGA * t), math.sin(OMEGA * t)
+    a_w = -OMEGA * OMEGA * RADIUS * np.array([c, s, 0.0])
+    g_w = np.array([0.0, 0.0, -PARAMS["gravity"]])
+    return R.T @ np.array([0.0, 0.0, OMEGA]), R.T @ (a_w - g_w)
+
+
+def skew(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0.0]])
+
+
+class Filter:
+    """Minimal host-side bookkeeping for the synthetic runs: nominal IMU state, the
+    Type::idx()/size() table (State.cpp:62-88, StateManager.cpp:155-231,253-296) and the window of
+    clones.  Covariance arithmetic goes to ``cov`` (engine), nominal propagation to ``transition``."""
+
+    def __init__(self, cov_factory, transition, t0=0.0, n_gnss=0, n_landmarks=0, rng=None):
+        pr = PARAMS
+        self.transition = transition
+        self.t = t0
+        R, p, v = true_pose(t0)
+        self.R, self.p, self.v = R.copy(), p.copy(), v.copy()
+        self.bg = np.zeros(3)
+        self.ba = np.zeros(3)
+        self.gravity = np.array([0.0, 0.0, -pr["gravity"]])
+        # State ctor + initStateAndCov (State.cpp:60-91,126-167)
+        d = np.full(21, 1e-6)
+        d[0:3] = pr["init_cov_rot"] ** 2
+        d[3:6] = pr["init_cov_pos"] ** 2
+        d[6:9] = pr["init_cov_vel"] ** 2
+        d[9:12] = pr["init_cov_bg"] ** 2
+        d[12:15] = pr["init_cov_ba"] ** 2
+        d[15:18] = pr["init_cov_ext_rot"] ** 2
+        d[18:21] = pr["init_cov_ext_pos"] ** 2
+        self.cov = cov_factory(np.diag(d))
+        self.vars = [("SE23", 0, 9), ("bg", 9, 3), ("ba", 12, 3), ("ext", 15, 6)]
+        self.gnss_idx = [-1] * 5          # GPS, GLO, GAL, BDS, FS
+        self.idx_yof = -1
+        self.enable_gnss = 1 if n_gnss else 0
+        if n_gnss:
+            # addGNSSVariable (StateManager.cpp:216-231) in arrival order
+            for g, var in ((0, pr["init_cov_cb"] ** 2), (3, pr["init_cov_cb"] ** 2),
+                           (2, pr["init_cov_cb"] ** 2), (1, pr["init_cov_cb"] ** 2),
+                           (4, pr["init_cov_fs"] ** 2)):
+                self.gnss_idx[g] = self._append("gnss%d" % g, np.array([[var]]))
+            self.idx_yof = self._append("yof", np.array([[pr["init_cov_yof"] ** 2]]))
+        for i in range(n_landmarks):      # addAnchoredLandmarkInState (StateManager.cpp:298-314), padding
+            self._append("lm%d" % i, np.eye(3))
+        self.clones = []                  # dicts: name, t, R_c2w, p_c (estimated)
+
+    # -- index bookkeeping ---------------------------------------------------------------
+    def _append(self, name, blk):
+        idx = self.cov.append_independent(blk)
+        self.vars.append((name, idx, blk.shape[0]))
+        return idx
+
+    def idx_of(self, name):
+        for nm, i, s in self.vars:
+            if nm == name:
+                return i
+        raise KeyError(name)
+
+    def marginalize(self, name):
+        """StateManager.cpp:155-192: delete rows/cols, shift later idx by -size."""
+        k = [nm for nm, _, _ in self.vars].index(name)
+        _, idx, size = self.vars[k]
+        self.cov.marginalize(idx, size)
+        self.vars = [(nm, i - size if i > idx else i, s) for nm, i, s in self.vars if nm != name]
+        for g in range(5):
+            if self.gnss_idx[g] > idx:
+                self.gnss_idx[g] -= size
+        if self.idx_yof > idx:
+            self.idx_yof -= size
+        self.clones = [c for c in self.clones if c["name"] != name]
+
+    # -- IMU ---------------------------------------------------------------------------------
+    def imu_steps(self, rng, k=IMU_PER_FRAME, dt=IMU_DT):
+        """k noisy IMU steps ending at t + k*dt; returns the per-step (Phi, G, dt) list and advances
+        the nominal state (ImuPropagator.cpp:232-292 with one sample per step)."""
+        pr = PARAMS
+        steps = []
+        for _ in range(k):
+            gyro, acc = true_imu(self.t + dt)
+            gyro = gyro + rng.normal(0.0, pr["noise_g"], 3)
+            acc = acc + rng.normal(0.0, pr["noise_a"], 3)
+            self.R, self.p, self.v, Phi, G = self.transition(self.R, self.p, self.v, self.bg, self.ba,
+                                                             gyro, acc, self.gravity, dt)
+            self.t += dt
+            steps.append((np.asarray(Phi), np.asarray(G), dt))
+        return steps
+
+    def sigma(self):
+        pr = PARAMS
+        return [pr["noise_g"], pr["noise_a"], pr["noise_bg"], pr["noise_ba"]]
+
+    def propagate_cov(self, steps):
+        pr = PARAMS
+        for Phi, G, dt in steps:
+            self.cov.propagate(Phi, G, dt, self.sigma(), self.enable_gnss, self.gnss_idx,
+                               pr["sigma_cb"], pr["sigma_rw"])
+
+    def clone(self):
+        """augmentSlidingWindowPose (StateManager.cpp:253-296): value T_i2w * T_cl2i, idx = old N."""
+        idx = self.cov.augment(self.R)
+        name = "clone@%.6f" % self.t
+        self.vars.append((name, idx, 6))
+        self.clones.append(dict(name=name, t=self.t, R=self.R @ R_CL2I, p=self.p + self.R @ T_CL2I))
+        return idx
+
+    def step_dict(self, steps, marg_name=None):
+        pr = PARAMS
+        return dict(Phi=[s[0] for s in steps], G=[s[1] for s in steps], dt=[s[2] for s in steps],
+                    sigma=self.sigma(), enable_gnss=self.enable_gnss, gnss_idx=list(self.gnss_idx),
+                    sigma_cb=pr["sigma_cb"], sigma_rw=pr["sigma_rw"], R_i2w=self.R.copy(),
+                    marg_idx=-1 if marg_name is None else self.idx_of(marg_name))
+
+
+def true_cam_pose(t):
+    R, p, _ = true_pose(t)
+    return R @ R_CL2I, p + R @ T_CL2I
+
+
+def make_features(rng, clone_times, F, noise_px=1e-3, outlier_every=20, stereo=True, pf_sigma=0.02):
+    """F landmarks visible from every clone; observations from the TRUE camera poses + pixel noise;
+    every ``outlier_every``-th feature gets +0.5 on u0 at its middle observation.
+    Returns (pf_est[F,3], uv[F,C,4], outlier[F])."""
+    C = len(clone_times)
+    Rm, pm = true_cam_pose(clone_times[C // 2])
+    Rlr, tlr = t_cl2cr()
+    pf = np.zeros((F, 3))
+    uv = np.zeros((F, C, 4))
+    poses = [true_cam_pose(t) for t in clone_times]
+    j = 0
+    while j < F:
+        depth = rng.uniform(2.0, 20.0)
+        x = rng.uniform(-0.5, 0.5) * depth
+        y = rng.uniform(-0.35, 0.35) * depth
+        pw = Rm @ np.array([x, y, depth]) + pm
+        ok = True
+        obs = np.zeros((C, 4))
+        for c, (Rc, pc) in enumerate(poses):
+            q = Rc.T @ (pw - pc)
+            qr = Rlr @ q + tlr
+            if q[2] < 0.5 or qr[2] < 0.5 or abs(q[0] / q[2]) > 1.2 or abs(q[1] / q[2]) > 1.0:
+                ok = False
+                break
+            obs[c] = [q[0] / q[2], q[1] / q[2], qr[0] / qr[2], qr[1] / qr[2]]
+        if not ok:
+            continue
+        pf[j] = pw
+        uv[j] = obs
+        j += 1
+    uv += rng.normal(0.0, noise_px, uv.shape)
+    outlier = np.zeros(F, dtype=bool)
+    if outlier_every:
+        for j in range(outlier_every - 1, F, outlier_every):
+            uv[j, C // 2, 0] += 0.5
+            outlier[j] = True
+    pf_est = pf + rng.normal(0.0, pf_sigma, pf.shape)
+    if not stereo:
+        uv[:, :, 2:] = 0.0
+    return pf_est, uv, outlier
+
+
+def frame_from_filter(flt, pf, uv, obs_mask=None, anchor=None, dof=None, stereo=True, noise=None,
+                      table=None):
+    """Flatten the window + features into the FeatSoA/ClonePose form of the C ABI."""
+    C = len(flt.clones)
+    F = pf.shape[0]
+    Rlr, tlr = t_cl2cr()
+    if obs_mask is None:
+        obs_mask = np.full(F, (1 << C) - 1, dtype=np.uint64)
+    if anchor is None:
+        anchor = np.zeros(F, dtype=np.int32)
+    if dof is None:  # RemoveLost: #obs - 1 (RemoveLostUpdate.cpp:332-333)
+        dof = np.array([bin(int(m)).count("1") - 1 for m in obs_mask], dtype=np.int32)
+    return dict(
+        clone_idx=np.array([flt.idx_of(c["name"]) for c in flt.clones], dtype=np.int32),
+        clone_R=np.stack([c["R"] for c in flt.clones]), clone_p=np.stack([c["p"] for c in flt.clones]),
+        pf=np.ascontiguousarray(pf), anchor=np.asarray(anchor, dtype=np.int32),
+        obs_mask=np.asarray(obs_mask, dtype=np.uint64), uv=np.ascontiguousarray(uv),
+        dof=np.asarray(dof, dtype=np.int32), stereo=1 if stereo else 0, R_cl2cr=Rlr, t_cl2cr=tlr,
+        noise=PARAMS["visual_noise"] if noise is None else noise,
+        chi2_table=chi2_table() if table is None else table)
+
+
+def build_case(cov_factory, transition, seed=0, F=150, C=11, n_gnss=6, n_landmarks=52, stereo=True,
+               outlier_every=20, table=None):
+    """Config-2 style case.  Runs C-1 propagate+clone cycles to create a realistic prior, then
+    prepares the measured frame: k IMU steps, clone #C, F features seen by all C clones, marginalise
+    the oldest clone afterwards.  Returns (flt, step, frame, info) with the covariance engine inside
+    ``flt.cov`` holding the PRIOR (N = 21 + n_gnss + 3*n_landmarks + 6*(C-1))."""
+    rng = np.random.default_rng(0x1A6F10 + seed)
+    flt = Filter(cov_factory, transition, t0=0.1 * seed, n_gnss=n_gnss, n_landmarks=n_landmarks)
+    for _ in range(C - 1):
+        flt.propagate_cov(flt.imu_steps(rng))
+        flt.clone()
+    # the measured frame: nominal propagation now, covariance work left to the caller
+    steps = flt.imu_steps(rng)
+    t_new = flt.t
+    clone_times = [c["t"] for c in flt.clones] + [t_new]
+    oldest = flt.clones[0]["name"]
+    step = flt.step_dict(steps, marg_name=oldest)
+    # frame inputs need the new clone's pose and idx (= N after propagate, i.e. current n)
+    new_idx = flt.cov.n
+    pf, uv, outlier = make_features(rng, clone_times, F, stereo=stereo, outlier_every=outlier_every)
+    clones = flt.clones + [dict(name="clone@%.6f" % t_new, t=t_new, R=flt.R @ R_CL2I, p=flt.p + flt.R @ T_CL2I)]
+    Rlr, tlr = t_cl2cr()
+    frame = dict(
+        clone_idx=np.array([flt.idx_of(c["name"]) for c in flt.clones] + [new_idx], dtype=np.int32),
+        clone_R=np.stack([c["R"] for c in clones]), clone_p=np.stack([c["p"] for c in clones]),
+        pf=pf, anchor=np.zeros(F, dtype=np.int32), obs_mask=np.full(F, (1 << C) - 1, dtype=np.uint64),
+        uv=uv, dof=np.full(F, C - 1, dtype=np.int32), stereo=1 if stereo else 0,
+        R_cl2cr=Rlr, t_cl2cr=tlr, noise=PARAMS["visual_noise"],
+        chi2_table=chi2_table() if table is None else table)
+    info = dict(outlier=outlier, N_prior=flt.cov.n, N_update=flt.cov.n + 6, new_idx=new_idx,
+                marg_idx=step["marg_idx"])
+    return flt, step, frame, info
