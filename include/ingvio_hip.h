@@ -1,0 +1,191 @@
+/*
+ * ingvio_hip.h — C ABI of libingvio_hip.so: the MI355X (gfx950) covariance engine that replaces
+ * the Eigen + SuiteSparse path behind InGVIO's StateManager / UpdateBase seam.
+ *
+ * The reference has no FFI today; its seam is the static API of `StateManager`
+ * (ingvio_estimator/src/StateManager.h:38-127, sole friend of State::_cov, State.h:129-135) plus
+ * the per-feature helpers of the Update classes.  Each export below names the reference
+ * function(s) it replaces.  INTEGRATION.md shows the C++ shim a maintainer adds on the reference
+ * side (ingvio_amd/csrc/host/ is that shim, ROS-free).
+ *
+ * Data model
+ *   - A context owns `batch` independent filters on one GPU.  Filter b's covariance lives in HBM
+ *     as an FP64 column-major n_b x n_b matrix inside an ldp x ldp buffer (ldp = n_max rounded up
+ *     to 16), i.e. exactly Eigen::MatrixXd's layout (State.h:133) so `Eigen::Map` + `cov_set/get`
+ *     is a plain strided copy.  The host keeps the typed nominal values and the Type::idx()/size()
+ *     table (VecState.h:32-54); only integers and small parameter blocks cross the boundary.
+ *   - All pointer arguments are HOST pointers unless the name ends in `_dev`.  Inputs are read
+ *     during the call only; outputs are written before the call returns (calls that return
+ *     results synchronise the context's stream; pure state mutations are asynchronous).
+ *   - Every call returns 0 on success, <0 for the reference's fatal conditions / API misuse
+ *     (the host shim turns these back into the reference's std::exit(EXIT_FAILURE) paths),
+ *     >0 for soft conditions (e.g. INGVIO_NO_ROWS: nothing accepted, state untouched).
+ *   - Thread-compatible per context, no globals (the reference is single-threaded,
+ *     IngvioNode.cpp:36).
+ *   - 3x3 rotations and T_cl2cr are row-major double[9] (+ double[3]); Phi (15x15), G (15x12),
+ *     H and covariance blocks are column-major with explicit leading dimensions.
+ */
+#ifndef INGVIO_HIP_H
+#define INGVIO_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INGVIO_OK 0
+#define INGVIO_NO_ROWS 1             /* soft: no measurement rows survived gating              */
+#define INGVIO_NEG_DIAG 2            /* soft: negative diagonal after update (StateManager.cpp:413-421, assert only) */
+#define INGVIO_E_ARG (-1)            /* bad argument / out of range                            */
+#define INGVIO_E_CAPACITY (-2)       /* n_max / c_max / f_max / m_max exceeded                 */
+#define INGVIO_E_HIP (-3)            /* HIP runtime error, see ingvio_last_error               */
+#define INGVIO_E_NOT_IN_STATE (-4)   /* StateManager.cpp:157-161 "Marg is not in the current state" */
+#define INGVIO_E_UNSUPPORTED (-5)
+
+typedef struct ingvio_ctx ingvio_ctx;
+
+typedef struct {
+    int batch;      /* independent filters held by this context (>= 1)                          */
+    int n_max;      /* max state dimension N (21 + gnss + 6C + 3L)                               */
+    int c_max;      /* max clones in the sliding window (<= 21 in this build)     */
+    int f_max;      /* max features per MSCKF update                                             */
+    int m_max;      /* max rows of a generic ekf_update (<= 128 in this build)                   */
+    int device;     /* HIP device ordinal                                                        */
+    void* stream;   /* hipStream_t to run on, or NULL to create a private non-blocking stream    */
+} ingvio_ctx_desc;
+
+/* State ctor (State.cpp:60-91): allocates P (batch x ldp^2 FP64, two ping-pong buffers) + workspaces. */
+int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out);
+int ingvio_ctx_destroy(ingvio_ctx* ctx);
+int ingvio_sync(ingvio_ctx* ctx);
+void* ingvio_ctx_stream(ingvio_ctx* ctx);             /* the hipStream_t all kernels are launched on */
+const char* ingvio_last_error(ingvio_ctx* ctx);
+int ingvio_ldp(ingvio_ctx* ctx);                      /* leading dimension of the device P buffers  */
+
+/* initStateAndCov / getFullCov (State.cpp:126-167, StateManager.cpp:121-126). cov_get synchronises. */
+int ingvio_cov_set(ingvio_ctx* ctx, int b, const double* P, int ld, int n);
+int ingvio_cov_get(ingvio_ctx* ctx, int b, double* P, int ld);
+int ingvio_get_n(ingvio_ctx* ctx, int b, int* n);
+/* getMarginalCov (StateManager.cpp:128-153): out is ns x ns column-major, ns = sum(vsize). */
+int ingvio_cov_get_marginal(ingvio_ctx* ctx, int b, const int* vidx, const int* vsize, int k, double* out);
+/* device-to-device snapshot / restore of all filters' covariances and dims (benchmark hygiene). */
+int ingvio_cov_snapshot(ingvio_ctx* ctx);
+int ingvio_cov_restore(ingvio_ctx* ctx);
+
+/* propagateStateCov (StateManager.cpp:42-119) for filters [b0, b0+nb).  Phi [nb][225], G [nb][180]
+ * (column-major 15x15 / 15x12), dt [nb]; sigma = {noise_g, noise_a, noise_bg, noise_ba};
+ * gnss_idx [nb][5] = state idx of {GPS, GLO, GAL, BDS, FS} or -1 (NULL: none);
+ * sigma_cb / sigma_rw = StateParams::_noise_clockbias / _noise_cb_rw after quirk Q1. */
+int ingvio_propagate(ingvio_ctx* ctx, int b0, int nb, const double* Phi, const double* G, const double* dt,
+                     const double sigma[4], int enable_gnss, const int* gnss_idx,
+                     double sigma_cb, double sigma_rw);
+/* The k-step loop of ImuPropagator::propagateUntil (ImuPropagator.cpp:246-289) in ONE launch:
+ * Phi [nb][k][225], G [nb][k][180], dt [nb][k].  The kernel composes the k transitions in LDS and
+ * touches the covariance strip once (same result up to FP64 rounding). */
+int ingvio_propagate_fused(ingvio_ctx* ctx, int b0, int nb, int k, const double* Phi, const double* G,
+                           const double* dt, const double sigma[4], int enable_gnss, const int* gnss_idx,
+                           double sigma_cb, double sigma_rw);
+
+/* augmentSlidingWindowPose, covariance part (StateManager.cpp:279-293). R_i2w [nb][9] row-major.
+ * new_idx [nb] receives the clone's idx == old N (bit-exact, StateManager.cpp:274). */
+int ingvio_augment_clone(ingvio_ctx* ctx, int b0, int nb, const double* R_i2w, int* new_idx);
+/* marginalize, covariance part (StateManager.cpp:163-177). idx [nb]. */
+int ingvio_marginalize(ingvio_ctx* ctx, int b0, int nb, const int* idx, int size);
+/* addVariableIndependent (StateManager.cpp:194-214). blk [nb][size*size] column-major. */
+int ingvio_append_independent(ingvio_ctx* ctx, int b0, int nb, int size, const double* blk, int* new_idx);
+
+/* noise kinds for the generic update */
+#define INGVIO_R_SCALAR 0   /* R = (*R) * I                                                     */
+#define INGVIO_R_DIAG 1     /* R = diag(R[0..m))     (GNSS, GnssUpdate.cpp:195,264)             */
+#define INGVIO_R_FULL 2     /* R m x m column-major                                             */
+
+/* ekfUpdate minus boxPlus (StateManager.cpp:359-423) on filter b: var_order as (vidx, vsize)[k],
+ * H m x sum(vsize) column-major (ldh), res [m].  dx_out [N] = K res; the host applies boxPlus. */
+int ingvio_ekf_update(ingvio_ctx* ctx, int b, const int* vidx, const int* vsize, int k,
+                      const double* H, int ldh, int m, const double* res,
+                      const double* R, int r_kind, double* dx_out);
+/* whitenResidual (Update.cpp:36-79): gamma = res^T (H Pcc H^T + R)^-1 res. */
+int ingvio_chi2_gamma(ingvio_ctx* ctx, int b, const int* vidx, const int* vsize, int k,
+                      const double* H, int ldh, int m, const double* res,
+                      const double* R, int r_kind, double* gamma);
+
+/* ---- MSCKF visual update: K3-K11 ----------------------------------------------------------
+ * One frame of flattened MapServer data for one filter (FeatureInfo/_stereo_obs/_landmark,
+ * MapServer.h:69-134, flattened by the host shim).  Clones in ascending timestamp. */
+typedef struct {
+    int n_clones;                        /* C: clones in the window (State::_sw_camleft_poses)    */
+    const int* clone_idx;                /* [C] Type::idx() of each clone                         */
+    const double* clone_R;               /* [C][9] valueLinearAsMat(), row-major                  */
+    const double* clone_p;               /* [C][3] valueTrans()                                   */
+    int n_feat;                          /* F                                                     */
+    const double* pf;                    /* [F][3] _landmark->valuePosXyz()                       */
+    const int* anchor;                   /* [F] window slot of getAnchoredPose()                  */
+    const unsigned long long* obs_mask;  /* [F] bit s: observation at slot s takes part           */
+    const double* uv;                    /* [F][C][4] StereoMeas::asVec() (mono: [0..1])          */
+    const int* dof;                      /* [F] dof passed to testChiSquared (Q4)                 */
+} ingvio_msckf_frame;
+
+typedef struct {
+    int stereo;               /* 1: calcResJacobian...StereoObs, 0: ...MonoObs                      */
+    double R_cl2cr[9];        /* StateParams::_T_cl2cr linear part, row-major                       */
+    double t_cl2cr[3];
+    double noise;             /* _visual_noise (sigma)                                              */
+    const double* chi2_table; /* chi2_table[d], d = 0..chi2_len-1 (UpdateBase::_chi_squared_table)  */
+    int chi2_len;
+    int max_accept;           /* RemoveLostUpdate::_max_valid_ids (20); <= 0: no cap                */
+    int compress_rule;        /* 0 as_written (RemoveLost keeps all rows, Q2), 1 top_n.  The GPU    */
+                              /* always compresses to n rows: the two are the same posterior.       */
+    int selected_variant;     /* 0 RemoveLost form, 1 SwMarg/Keyframe form (anchor block assigned,  */
+                              /* quirk Q10, SwMargUpdate.cpp:302)                                   */
+} ingvio_msckf_opts;
+
+/* RemoveLostUpdate::updateState{Mono,Stereo} (RemoveLostUpdate.cpp:40-167,276-405),
+ * SwMargUpdate::updateState* (SwMargUpdate.cpp:42-189,216-365), KeyframeUpdate::updateState*
+ * (KeyframeUpdate.cpp:438-735) after triangulation, for filters [b0, b0+nb):
+ * Jacobians + nullspace (K3,K4), chi2 gate on the prior (K5), accepted-feature cap, TSQR
+ * compression (K6,K7) and the Kalman update (K8-K11).
+ * dx_out [nb][ldp]; accepted [nb][f_max] (1/0); gamma [nb][f_max] (may be NULL);
+ * rows_out [nb] = rows handed to the Kalman update (0: none accepted, state untouched). */
+int ingvio_msckf_update(ingvio_ctx* ctx, int b0, int nb, const ingvio_msckf_frame* frames,
+                        const ingvio_msckf_opts* opts, double* dx_out, int* accepted, double* gamma,
+                        int* rows_out);
+
+/* Stacked-QR compression on its own (the SPQR call sites RemoveLostUpdate.cpp:376-397,
+ * SwMargUpdate.cpp:336-357, KeyframeUpdate.cpp:707-728): H m x n (ldh) column-major, res [m] ->
+ * H_thin n x n upper triangular (ldt) and r_thin [n] with H_thin^T H_thin = H^T H,
+ * H_thin^T r_thin = H^T res.  n <= 6*c_max. */
+int ingvio_qr_compress(ingvio_ctx* ctx, const double* H, int ldh, int m, int n, const double* res,
+                       double* H_thin, int ldt, double* r_thin);
+
+/* ---- one benchmark "update" for the whole batch ------------------------------
+ * k-step propagation + clone + MSCKF update + marginalise one clone, all filters, no host
+ * synchronisation between the stages.  stage() uploads inputs (outside any timed region),
+ * run() only enqueues kernels, fetch() synchronises and downloads. */
+typedef struct {
+    int k;                    /* IMU steps                                                          */
+    const double* Phi;        /* [k][225]                                                           */
+    const double* G;          /* [k][180]                                                           */
+    const double* dt;         /* [k]                                                                */
+    int gnss_idx[5];
+    double R_i2w[9];          /* IMU rotation at clone time                                         */
+    int marg_idx;             /* idx of the clone to marginalise afterwards, -1: none               */
+} ingvio_frame_step;
+
+int ingvio_frame_stage(ingvio_ctx* ctx, int b0, int nb, const ingvio_frame_step* steps,
+                       const ingvio_msckf_frame* frames, const ingvio_msckf_opts* opts,
+                       const double sigma[4], int enable_gnss, double sigma_cb, double sigma_rw);
+int ingvio_frame_run(ingvio_ctx* ctx, int restore_prior);
+int ingvio_frame_fetch(ingvio_ctx* ctx, int b0, int nb, double* dx_out, int* accepted, int* rows_out);
+
+/* per-kernel device time, measured with hipEvents on the context's stream.  enable=1 brackets
+ * every kernel launch with events (adds launch-side overhead, off by default). */
+int ingvio_profile_enable(ingvio_ctx* ctx, int enable);
+int ingvio_profile_reset(ingvio_ctx* ctx);
+/* names: array of `cap` char* receiving static strings; ms/calls: [cap]; returns number of entries */
+int ingvio_profile_get(ingvio_ctx* ctx, const char** names, double* ms, int* calls, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

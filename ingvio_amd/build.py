@@ -1,0 +1,76 @@
+"""Builds libingvio_hip.so (hipcc, gfx950) and libingvio_host.so (g++) in-tree under ingvio_amd/lib/.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so files
+travel to the GPU box with the repository snapshot (they are git-ignored, not gpurun-ignored)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib")
+HIP_SOURCES = ["kernels_cov.hip", "kernels_msckf.hip", "kernels_ekf.hip", "capi.hip"]
+HIP_LIB = os.path.join(LIB, "libingvio_hip.so")
+HOST_LIB = os.path.join(LIB, "libingvio_host.so")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _all_deps(dirs):
+    out = []
+    for d in dirs:
+        for root, _, files in os.walk(d):
+            out += [os.path.join(root, f) for f in files if f.endswith((".hip", ".h", ".cpp", ".hpp"))]
+    return out
+
+
+def build_hip(force=False, verbose=False):
+    os.makedirs(LIB, exist_ok=True)
+    deps = _all_deps([CSRC, os.path.join(os.path.dirname(HERE), "include")])
+    objs = []
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    for src in HIP_SOURCES:
+        obj = os.path.join(LIB, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(obj, deps):
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+                   "-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    if force or _newer(HIP_LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs
+        subprocess.check_call(cmd)
+    return HIP_LIB
+
+
+def build_host(force=False, verbose=False):
+    host_dir = os.path.join(CSRC, "host")
+    if not os.path.isdir(host_dir):
+        return None
+    srcs = sorted(os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".cpp"))
+    if not srcs:
+        return None
+    deps = _all_deps([host_dir, os.path.join(os.path.dirname(HERE), "include")])
+    if force or _newer(HOST_LIB, deps):
+        cmd = ["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-I", os.path.join(os.path.dirname(HERE), "include"),
+               "-o", HOST_LIB] + srcs + ["-L", LIB, "-lingvio_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HOST_LIB
+
+
+def build_all(force=False, verbose=False):
+    a = build_hip(force, verbose)
+    b = build_host(force, verbose)
+    return a, b
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

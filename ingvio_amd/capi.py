@@ -1,0 +1,345 @@
+"""ctypes binding of the C ABI (include/ingvio_hip.h) — thin plumbing, no arithmetic.
+
+There is no CPU fallback: importing works anywhere (so the symbol table can be checked without a
+GPU), but creating a context raises if libingvio_hip.so is missing or no MI355X is visible.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libingvio_hip.so")
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+c_up = C.POINTER(C.c_ulonglong)
+
+OK, NO_ROWS, NEG_DIAG = 0, 1, 2
+E_ARG, E_CAPACITY, E_HIP, E_NOT_IN_STATE, E_UNSUPPORTED = -1, -2, -3, -4, -5
+R_SCALAR, R_DIAG, R_FULL = 0, 1, 2
+
+EXPORTS = [
+    "ingvio_ctx_create", "ingvio_ctx_destroy", "ingvio_sync", "ingvio_ctx_stream", "ingvio_last_error", "ingvio_ldp",
+    "ingvio_cov_set", "ingvio_cov_get", "ingvio_get_n", "ingvio_cov_get_marginal", "ingvio_cov_snapshot",
+    "ingvio_cov_restore", "ingvio_propagate", "ingvio_propagate_fused", "ingvio_augment_clone", "ingvio_marginalize",
+    "ingvio_append_independent", "ingvio_ekf_update", "ingvio_chi2_gamma", "ingvio_msckf_update", "ingvio_qr_compress",
+    "ingvio_frame_stage", "ingvio_frame_run", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_reset",
+    "ingvio_profile_get",
+]
+
+
+class CtxDesc(C.Structure):
+    _fields_ = [("batch", C.c_int), ("n_max", C.c_int), ("c_max", C.c_int), ("f_max", C.c_int), ("m_max", C.c_int),
+                ("device", C.c_int), ("stream", C.c_void_p)]
+
+
+class MsckfFrame(C.Structure):
+    _fields_ = [("n_clones", C.c_int), ("clone_idx", c_ip), ("clone_R", c_dp), ("clone_p", c_dp), ("n_feat", C.c_int),
+                ("pf", c_dp), ("anchor", c_ip), ("obs_mask", c_up), ("uv", c_dp), ("dof", c_ip)]
+
+
+class MsckfOpts(C.Structure):
+    _fields_ = [("stereo", C.c_int), ("R_cl2cr", C.c_double * 9), ("t_cl2cr", C.c_double * 3), ("noise", C.c_double),
+                ("chi2_table", c_dp), ("chi2_len", C.c_int), ("max_accept", C.c_int), ("compress_rule", C.c_int),
+                ("selected_variant", C.c_int)]
+
+
+class FrameStep(C.Structure):
+    _fields_ = [("k", C.c_int), ("Phi", c_dp), ("G", c_dp), ("dt", c_dp), ("gnss_idx", C.c_int * 5),
+                ("R_i2w", C.c_double * 9), ("marg_idx", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libingvio_hip.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`"
+                               % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.ingvio_last_error.restype = C.c_char_p
+        _lib.ingvio_ctx_stream.restype = C.c_void_p
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(c_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(c_ip)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class IngvioError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("ingvio_hip error %d %s" % (code, msg))
+        self.code = code
+
+
+def make_frame(fr):
+    keep = dict(clone_idx=i32(fr["clone_idx"]), clone_R=f64(fr["clone_R"]), clone_p=f64(fr["clone_p"]), pf=f64(fr["pf"]),
+                anchor=i32(fr["anchor"]), obs_mask=np.ascontiguousarray(fr["obs_mask"], dtype=np.uint64),
+                uv=f64(fr["uv"]), dof=i32(fr["dof"]))
+    f = MsckfFrame()
+    f.n_clones = len(keep["clone_idx"]); f.clone_idx = _i(keep["clone_idx"]); f.clone_R = _d(keep["clone_R"])
+    f.clone_p = _d(keep["clone_p"]); f.n_feat = keep["pf"].shape[0] if keep["pf"].size else 0; f.pf = _d(keep["pf"])
+    f.anchor = _i(keep["anchor"]); f.obs_mask = keep["obs_mask"].ctypes.data_as(c_up); f.uv = _d(keep["uv"])
+    f.dof = _i(keep["dof"])
+    return f, keep
+
+
+def make_opts(fr, max_accept=0, compress_rule=1, selected_variant=0):
+    chi2 = f64(fr["chi2_table"])
+    o = MsckfOpts()
+    o.stereo = int(fr.get("stereo", 1))
+    o.R_cl2cr = (C.c_double * 9)(*np.asarray(fr["R_cl2cr"], dtype=np.float64).reshape(9))
+    o.t_cl2cr = (C.c_double * 3)(*np.asarray(fr["t_cl2cr"], dtype=np.float64).reshape(3))
+    o.noise = float(fr["noise"]); o.chi2_table = _d(chi2); o.chi2_len = len(chi2)
+    o.max_accept = int(max_accept); o.compress_rule = int(compress_rule); o.selected_variant = int(selected_variant)
+    return o, chi2
+
+
+def make_step(step):
+    k = len(step["dt"])
+    keep = dict(Phi=f64(np.stack([np.asarray(p).reshape(15, 15).T for p in step["Phi"]])),
+                G=f64(np.stack([np.asarray(g).reshape(15, 12).T for g in step["G"]])), dt=f64(step["dt"]))
+    s = FrameStep()
+    s.k = k; s.Phi = _d(keep["Phi"]); s.G = _d(keep["G"]); s.dt = _d(keep["dt"])
+    s.gnss_idx = (C.c_int * 5)(*[int(x) for x in step.get("gnss_idx", (-1,) * 5)])
+    s.R_i2w = (C.c_double * 9)(*np.asarray(step["R_i2w"], dtype=np.float64).reshape(9))
+    s.marg_idx = int(step.get("marg_idx", -1))
+    return s, keep
+
+
+class Context:
+    """A batch of independent filters on one GPU (ingvio_ctx)."""
+
+    def __init__(self, batch=1, n_max=256, c_max=11, f_max=160, m_max=64, device=0, stream=None):
+        self.L = lib()
+        d = CtxDesc(batch, n_max, c_max, f_max, m_max, device, stream)
+        self.h = C.c_void_p()
+        rc = self.L.ingvio_ctx_create(C.byref(d), C.byref(self.h))
+        if rc != 0:
+            msg = self.L.ingvio_last_error(self.h).decode() if self.h else "no HIP device / library"
+            raise IngvioError(rc, msg)
+        self.batch, self.n_max, self.c_max, self.f_max = batch, n_max, c_max, f_max
+        self.ldp = self.L.ingvio_ldp(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.ingvio_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, soft_ok=True):
+        if rc < 0 or (rc > 0 and not soft_ok):
+            raise IngvioError(rc, self.L.ingvio_last_error(self.h).decode())
+        return rc
+
+    def sync(self):
+        self._chk(self.L.ingvio_sync(self.h))
+
+    def stream(self):
+        return self.L.ingvio_ctx_stream(self.h)
+
+    # ---- covariance I/O -----------------------------------------------------------------
+    def cov_set(self, b, P):
+        P = np.asfortranarray(P, dtype=np.float64)
+        n = P.shape[0]
+        self._chk(self.L.ingvio_cov_set(self.h, b, _d(P), max(n, 1), n))
+
+    def n(self, b=0):
+        v = C.c_int(0)
+        self._chk(self.L.ingvio_get_n(self.h, b, C.byref(v)))
+        return v.value
+
+    def cov_get(self, b=0):
+        n = self.n(b)
+        P = np.zeros((n, n), order="F")
+        self._chk(self.L.ingvio_cov_get(self.h, b, _d(P), max(n, 1)))
+        return P
+
+    def marginal(self, b, vidx, vsize):
+        ns = int(np.sum(vsize))
+        out = np.zeros((ns, ns), order="F")
+        self._chk(self.L.ingvio_cov_get_marginal(self.h, b, _i(i32(vidx)), _i(i32(vsize)), len(vidx), _d(out)))
+        return out
+
+    def snapshot(self):
+        self._chk(self.L.ingvio_cov_snapshot(self.h))
+
+    def restore(self):
+        self._chk(self.L.ingvio_cov_restore(self.h))
+
+    # ---- structure + propagation (batched over [b0, b0+nb)) ------------------------------
+    def propagate(self, b0, Phi, G, dt, sigma, enable_gnss=0, gnss_idx=None, sigma_cb=0.0, sigma_rw=0.0, fused=False):
+        """Phi [nb,k,15,15] (row-major numpy), G [nb,k,15,12], dt [nb,k]."""
+        Phi = np.asarray(Phi, dtype=np.float64); G = np.asarray(G, dtype=np.float64); dt = np.asarray(dt, dtype=np.float64)
+        if Phi.ndim == 2:
+            Phi = Phi[None, None]; G = G[None, None]; dt = dt.reshape(1, 1)
+        elif Phi.ndim == 3:
+            Phi = Phi[None]; G = G[None]; dt = dt.reshape(1, -1)
+        nb, k = Phi.shape[0], Phi.shape[1]
+        PhiC = f64(np.swapaxes(Phi, -1, -2)); GC = f64(np.swapaxes(G, -1, -2)); dt = f64(dt)
+        gi = None if gnss_idx is None else i32(np.asarray(gnss_idx).reshape(nb, 5))
+        sig = f64(sigma)
+        if fused or k > 1:
+            rc = self.L.ingvio_propagate_fused(self.h, b0, nb, k, _d(PhiC), _d(GC), _d(dt), _d(sig), int(enable_gnss),
+                                               _i(gi) if gi is not None else None, C.c_double(sigma_cb), C.c_double(sigma_rw))
+        else:
+            rc = self.L.ingvio_propagate(self.h, b0, nb, _d(PhiC), _d(GC), _d(dt), _d(sig), int(enable_gnss),
+                                         _i(gi) if gi is not None else None, C.c_double(sigma_cb), C.c_double(sigma_rw))
+        self._chk(rc)
+
+    def augment(self, b0, R_i2w):
+        R = f64(np.asarray(R_i2w).reshape(-1, 9))
+        nb = R.shape[0]
+        idx = np.zeros(nb, dtype=np.int32)
+        self._chk(self.L.ingvio_augment_clone(self.h, b0, nb, _d(R), _i(idx)))
+        return idx
+
+    def marginalize(self, b0, idx, size):
+        idx = i32(np.atleast_1d(idx))
+        self._chk(self.L.ingvio_marginalize(self.h, b0, len(idx), _i(idx), int(size)))
+
+    def append_independent(self, b0, blk):
+        blk = np.asarray(blk, dtype=np.float64)
+        if blk.ndim == 2:
+            blk = blk[None]
+        nb, s = blk.shape[0], blk.shape[1]
+        b = f64(np.swapaxes(blk, -1, -2))
+        idx = np.zeros(nb, dtype=np.int32)
+        self._chk(self.L.ingvio_append_independent(self.h, b0, nb, s, _d(b), _i(idx)))
+        return idx
+
+    # ---- updates ----------------------------------------------------------------------------
+    @staticmethod
+    def _R(R, m):
+        R = np.asarray(R, dtype=np.float64)
+        if R.ndim == 0 or (R.size == 1 and m != 1):
+            return f64(R.reshape(1)), R_SCALAR
+        if R.ndim == 1:
+            return f64(R), R_DIAG
+        return np.asfortranarray(R), R_FULL
+
+    def ekf_update(self, b, vidx, vsize, H, res, R):
+        H = np.asfortranarray(np.atleast_2d(H), dtype=np.float64)
+        m = H.shape[0]
+        Rb, kind = self._R(R, m)
+        dx = np.zeros(self.n(b))
+        rc = self.L.ingvio_ekf_update(self.h, b, _i(i32(vidx)), _i(i32(vsize)), len(vidx), _d(H), m, m, _d(f64(res)),
+                                      _d(Rb), kind, _d(dx))
+        return dx, self._chk(rc)
+
+    def chi2_gamma(self, b, vidx, vsize, H, res, R):
+        H = np.asfortranarray(np.atleast_2d(H), dtype=np.float64)
+        m = H.shape[0]
+        Rb, kind = self._R(R, m)
+        g = C.c_double(0.0)
+        self._chk(self.L.ingvio_chi2_gamma(self.h, b, _i(i32(vidx)), _i(i32(vsize)), len(vidx), _d(H), m, m, _d(f64(res)),
+                                           _d(Rb), kind, C.byref(g)))
+        return g.value
+
+    def msckf_update(self, b0, frames, max_accept=0, compress_rule=1, selected_variant=0):
+        """frames: list of frame dicts (one per filter).  Returns (dx[nb,n], accepted[nb,F], gamma[nb,F], rows[nb])."""
+        if isinstance(frames, dict):
+            frames = [frames]
+        nb = len(frames)
+        arr = (MsckfFrame * nb)()
+        keeps = []
+        for i, fr in enumerate(frames):
+            f, k = make_frame(fr)
+            arr[i] = f; keeps.append(k)
+        o, chi2 = make_opts(frames[0], max_accept, compress_rule, selected_variant)
+        dx = np.zeros((nb, self.ldp)); acc = np.zeros((nb, self.f_max), dtype=np.int32)
+        gam = np.zeros((nb, self.f_max)); rows = np.zeros(nb, dtype=np.int32)
+        rc = self.L.ingvio_msckf_update(self.h, b0, nb, arr, C.byref(o), _d(dx), _i(acc), _d(gam), _i(rows))
+        self._chk(rc)
+        return dx, acc, gam, rows
+
+    def qr_compress(self, H, res):
+        H = np.asfortranarray(H, dtype=np.float64)
+        m, n = H.shape
+        Ht = np.zeros((n, n), order="F"); rt = np.zeros(n)
+        self._chk(self.L.ingvio_qr_compress(self.h, _d(H), m, m, n, _d(f64(res)), _d(Ht), n, _d(rt)))
+        return Ht, rt
+
+    # ---- whole-batch frame (bench) ------------------------------------------------------------
+    def frame_stage(self, b0, steps, frames, sigma, enable_gnss=0, sigma_cb=0.0, sigma_rw=0.0, max_accept=0,
+                    compress_rule=1, selected_variant=0):
+        nb = len(steps)
+        sa = (FrameStep * nb)(); fa = (MsckfFrame * nb)()
+        keeps = []
+        for i in range(nb):
+            s, k1 = make_step(steps[i]); f, k2 = make_frame(frames[i])
+            sa[i] = s; fa[i] = f; keeps.append((k1, k2))
+        o, chi2 = make_opts(frames[0], max_accept, compress_rule, selected_variant)
+        self._chk(self.L.ingvio_frame_stage(self.h, b0, nb, sa, fa, C.byref(o), _d(f64(sigma)), int(enable_gnss),
+                                            C.c_double(sigma_cb), C.c_double(sigma_rw)))
+
+    def frame_run(self, restore_prior=False):
+        self._chk(self.L.ingvio_frame_run(self.h, 1 if restore_prior else 0))
+
+    def frame_fetch(self, b0=0, nb=None):
+        nb = self.batch if nb is None else nb
+        dx = np.zeros((nb, self.ldp)); acc = np.zeros((nb, self.f_max), dtype=np.int32); rows = np.zeros(nb, dtype=np.int32)
+        self._chk(self.L.ingvio_frame_fetch(self.h, b0, nb, _d(dx), _i(acc), _i(rows)))
+        return dx, acc, rows
+
+    # ---- profiling ---------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._chk(self.L.ingvio_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._chk(self.L.ingvio_profile_reset(self.h))
+
+    def profile_get(self):
+        cap = 16
+        names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); calls = (C.c_int * cap)()
+        k = self.L.ingvio_profile_get(self.h, names, ms, calls, cap)
+        return {names[i].decode(): (ms[i], calls[i]) for i in range(k)}
+
+
+class DeviceCov:
+    """Single-filter covariance engine with the same surface as oracle.Cov, backed by filter `b`
+    of a Context (so ingvio_amd.synth can build scenarios on the GPU)."""
+
+    def __init__(self, ctx, b, P):
+        self.ctx, self.b = ctx, b
+        ctx.cov_set(b, P)
+
+    @property
+    def n(self):
+        return self.ctx.n(self.b)
+
+    @property
+    def P(self):
+        return np.array(self.ctx.cov_get(self.b))
+
+    def propagate(self, Phi, G, dt, sigma, enable_gnss=0, gnss_idx=(-1,) * 5, sigma_cb=0.0, sigma_rw=0.0):
+        self.ctx.propagate(self.b, Phi, G, dt, sigma, enable_gnss, gnss_idx if enable_gnss else None, sigma_cb, sigma_rw)
+
+    def augment(self, R_i2w):
+        return int(self.ctx.augment(self.b, R_i2w)[0])
+
+    def marginalize(self, idx, size):
+        self.ctx.marginalize(self.b, [idx], size)
+
+    def append_independent(self, blk):
+        return int(self.ctx.append_independent(self.b, np.atleast_2d(blk))[0])

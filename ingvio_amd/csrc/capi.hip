@@ -1,0 +1,704 @@
+// capi.hip — the C ABI of libingvio_hip.so (include/ingvio_hip.h): context, staging, launches.
+// Host code only; kernels live in kernels_{cov,msckf,ekf}.hip.  gfx950 only, no CPU fallback:
+// every entry point fails with INGVIO_E_HIP if the HIP runtime has no device.
+#include "../../include/ingvio_hip.h"
+#include "dev_common.h"
+#include "launch_ekf.h"
+#include "launch_msckf.h"
+
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#define KMAX 64            // IMU steps per fused propagation call
+#define CHI2_CAP 1024
+
+namespace {
+
+enum ProfId { PF_RESTORE, PF_PROPAGATE, PF_AUGMENT, PF_GATE, PF_FOLD, PF_MERGE, PF_EKF_CORE, PF_DOWNDATE, PF_MARG, PF_COUNT };
+const char* kProfNames[PF_COUNT] = { "restore", "k_propagate", "k_augment", "k_msckf_gate", "k_msckf_fold",
+                                     "k_msckf_merge", "k_ekf_core", "k_downdate", "k_marginalize" };
+struct ProfRec { int id; hipEvent_t a, b; };
+
+}  // namespace
+
+struct ingvio_ctx {
+    ingvio_ctx_desc d;
+    int ldp, mld, nc_cap, G, rstride, hstride, cstride, ystride;
+    int cls;                       // CMAX class of the MSCKF kernels
+    hipStream_t st;
+    bool own_stream;
+    std::string err;
+    // covariances
+    double *Pbase, *Psnap;
+    int *d_cur, *d_n, *d_n_snap;
+    std::vector<int> h_n, h_cur, h_n_snap;
+    bool has_snap;
+    // propagation / structure staging
+    double *d_Phi, *d_G, *d_dt, *d_R, *d_blk;
+    int *d_gnss, *d_idx;
+    // frame staging
+    int *d_clone_idx, *d_nclones, *d_nfeat, *d_anchor, *d_dof;
+    double *d_clone_R, *d_clone_p, *d_pf, *d_uv, *d_chi2;
+    unsigned long long* d_mask;
+    // msckf / ekf workspaces
+    double *d_gamma, *d_Rpart, *d_H, *d_res, *d_noise, *d_noise1, *d_Y, *d_dx;
+    int *d_accept, *d_used, *d_chunk_used, *d_colmap, *d_m, *d_nc, *d_status;
+    // staged frame state
+    int st_k, st_stereo, st_enable_gnss, st_fmax_used;
+    double st_sigma[4], st_scb, st_srw;
+    MsckfOpts st_op;
+    std::vector<int> st_marg;      // per filter marg idx
+    bool staged;
+    // profiling
+    bool prof;
+    std::vector<ProfRec> recs;
+    double prof_ms[PF_COUNT];
+    int prof_calls[PF_COUNT];
+};
+
+namespace {
+
+#define HIPCHK(ctx, expr)                                                                       \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                    \
+            return INGVIO_E_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+template <class T>
+int dalloc(ingvio_ctx* c, T** p, size_t count)
+{
+    HIPCHK(c, hipMalloc((void**)p, sizeof(T) * (count ? count : 1)));
+    HIPCHK(c, hipMemsetAsync(*p, 0, sizeof(T) * (count ? count : 1), c->st));
+    return 0;
+}
+
+CovView view(ingvio_ctx* c)
+{
+    CovView v;
+    v.Pbase = c->Pbase; v.cur = c->d_cur; v.n = c->d_n; v.ldp = c->ldp; v.B = c->d.batch;
+    return v;
+}
+
+FrameView fview(ingvio_ctx* c)
+{
+    FrameView f;
+    f.clone_idx = c->d_clone_idx; f.clone_R = c->d_clone_R; f.clone_p = c->d_clone_p;
+    f.n_clones = c->d_nclones; f.n_feat = c->d_nfeat; f.pf = c->d_pf; f.anchor = c->d_anchor;
+    f.obs_mask = c->d_mask; f.uv = c->d_uv; f.dof = c->d_dof; f.cmax = c->d.c_max; f.fmax = c->d.f_max;
+    return f;
+}
+
+struct ProfScope {
+    ingvio_ctx* c; int id; hipEvent_t a, b; bool on;
+    ProfScope(ingvio_ctx* c_, int id_) : c(c_), id(id_), on(c_->prof)
+    {
+        if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->st); }
+    }
+    ~ProfScope()
+    {
+        if (on) { hipEventRecord(b, c->st); c->recs.push_back({ id, a, b }); }
+    }
+};
+
+int check_range(ingvio_ctx* c, int b0, int nb)
+{
+    if (!c || b0 < 0 || nb < 1 || b0 + nb > c->d.batch) return INGVIO_E_ARG;
+    return 0;
+}
+
+int up(ingvio_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) return 0;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->st));
+    return 0;
+}
+
+int down_sync(ingvio_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (bytes) HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return 0;
+}
+
+int last_launch(ingvio_ctx* c)
+{
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// uploads frames [b0, b0+nb) into the SoA staging; returns max F in *fmax_used
+int stage_frames(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* fr, int* fmax_used)
+{
+    const int cm = c->d.c_max, fm = c->d.f_max;
+    std::vector<int> cidx((size_t)nb * cm, 0), ncl(nb), nft(nb), anc((size_t)nb * fm, 0), dof((size_t)nb * fm, 0);
+    std::vector<double> cR((size_t)nb * cm * 9, 0.0), cp((size_t)nb * cm * 3, 0.0), pf((size_t)nb * fm * 3, 0.0),
+        uv((size_t)nb * fm * cm * 4, 0.0);
+    std::vector<unsigned long long> mk((size_t)nb * fm, 0ULL);
+    int fmx = 0;
+    for (int i = 0; i < nb; ++i) {
+        const ingvio_msckf_frame& f = fr[i];
+        if (f.n_clones < 0 || f.n_clones > cm || f.n_feat < 0 || f.n_feat > fm) return INGVIO_E_CAPACITY;
+        ncl[i] = f.n_clones; nft[i] = f.n_feat;
+        if (f.n_feat > fmx) fmx = f.n_feat;
+        for (int s = 0; s < f.n_clones; ++s) {
+            cidx[(size_t)i * cm + s] = f.clone_idx[s];
+            if (f.clone_idx[s] < 0 || f.clone_idx[s] + 6 > c->d.n_max) return INGVIO_E_ARG;
+            memcpy(&cR[((size_t)i * cm + s) * 9], f.clone_R + 9 * s, 72);
+            memcpy(&cp[((size_t)i * cm + s) * 3], f.clone_p + 3 * s, 24);
+        }
+        for (int j = 0; j < f.n_feat; ++j) {
+            memcpy(&pf[((size_t)i * fm + j) * 3], f.pf + 3 * j, 24);
+            anc[(size_t)i * fm + j] = f.anchor[j];
+            if (f.anchor[j] < 0 || f.anchor[j] >= f.n_clones) return INGVIO_E_ARG;
+            mk[(size_t)i * fm + j] = f.obs_mask[j] & (f.n_clones >= 64 ? ~0ULL : ((1ULL << f.n_clones) - 1ULL));
+            dof[(size_t)i * fm + j] = f.dof[j];
+            for (int s = 0; s < f.n_clones; ++s)
+                memcpy(&uv[(((size_t)i * fm + j) * cm + s) * 4], f.uv + ((size_t)j * f.n_clones + s) * 4, 32);
+        }
+    }
+    int rc = 0;
+    rc |= up(c, c->d_clone_idx + (size_t)b0 * cm, cidx.data(), sizeof(int) * cidx.size());
+    rc |= up(c, c->d_nclones + b0, ncl.data(), sizeof(int) * nb);
+    rc |= up(c, c->d_nfeat + b0, nft.data(), sizeof(int) * nb);
+    rc |= up(c, c->d_anchor + (size_t)b0 * fm, anc.data(), sizeof(int) * anc.size());
+    rc |= up(c, c->d_dof + (size_t)b0 * fm, dof.data(), sizeof(int) * dof.size());
+    rc |= up(c, c->d_clone_R + (size_t)b0 * cm * 9, cR.data(), 8 * cR.size());
+    rc |= up(c, c->d_clone_p + (size_t)b0 * cm * 3, cp.data(), 8 * cp.size());
+    rc |= up(c, c->d_pf + (size_t)b0 * fm * 3, pf.data(), 8 * pf.size());
+    rc |= up(c, c->d_uv + (size_t)b0 * fm * cm * 4, uv.data(), 8 * uv.size());
+    rc |= up(c, c->d_mask + (size_t)b0 * fm, mk.data(), 8 * mk.size());
+    if (rc) return INGVIO_E_HIP;
+    HIPCHK(c, hipStreamSynchronize(c->st));      // host vectors die at scope exit
+    *fmax_used = fmx;
+    return 0;
+}
+
+int make_opts(ingvio_ctx* c, const ingvio_msckf_opts* o, MsckfOpts* op)
+{
+    if (!o || !o->chi2_table || o->chi2_len < 2 || o->chi2_len > CHI2_CAP) return INGVIO_E_ARG;
+    memcpy(op->R_lr, o->R_cl2cr, 72);
+    memcpy(op->t_lr, o->t_cl2cr, 24);
+    op->var = o->noise * o->noise;
+    op->max_accept = o->max_accept;
+    op->selected_variant = o->selected_variant;
+    op->chi2 = c->d_chi2;
+    op->chi2_len = o->chi2_len;
+    int rc = up(c, c->d_chi2, o->chi2_table, 8 * (size_t)o->chi2_len);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return 0;
+}
+
+// K3..K11 for filters [b0, b0+nb) using the staged frames; asynchronous.
+int run_msckf(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int stereo, int fmax_used)
+{
+    MsckfLaunch L;
+    memset(&L, 0, sizeof L);
+    L.stereo = stereo; L.cv = view(c); L.fv = fview(c); L.op = op; L.b0 = b0; L.nb = nb;
+    L.fmax_used = fmax_used > 0 ? fmax_used : 1;
+    L.gamma = c->d_gamma; L.accept = c->d_accept; L.used = c->d_used;
+    L.Rpart = c->d_Rpart + (size_t)b0 * c->G * c->rstride; L.chunk_used = c->d_chunk_used + (size_t)b0 * c->G;
+    L.G = c->G; L.rstride = c->rstride;
+    L.Hout = c->d_H + (size_t)b0 * c->hstride; L.res_out = c->d_res + (size_t)b0 * c->mld;
+    L.colmap = c->d_colmap + (size_t)b0 * c->cstride; L.m_out = c->d_m + b0; L.nc_out = c->d_nc + b0;
+    L.mld = c->mld; L.hstride = c->hstride; L.cstride = c->cstride;
+    { ProfScope p(c, PF_GATE); L.stage = 0; if (launch_msckf(L, c->st)) return INGVIO_E_UNSUPPORTED; }
+    { ProfScope p(c, PF_FOLD); L.stage = 1; launch_msckf(L, c->st); }
+    { ProfScope p(c, PF_MERGE); L.stage = 2; launch_msckf(L, c->st); }
+    EkfLaunch E;
+    memset(&E, 0, sizeof E);
+    E.cv = view(c); E.b0 = b0; E.nb = nb; E.H = L.Hout; E.res = L.res_out; E.colmap = L.colmap; E.m = L.m_out; E.nc = L.nc_out;
+    E.noise = c->d_noise + b0; E.r_kind = 0; E.mld = c->mld; E.hstride = c->hstride; E.cstride = c->cstride; E.nstride = 1;
+    E.Y = c->d_Y + (size_t)b0 * c->ystride; E.ystride = c->ystride; E.dx = c->d_dx; E.status = c->d_status;
+    E.m_cap = 6 * c->d.c_max; E.nc_cap = c->nc_cap;
+    { ProfScope p(c, PF_EKF_CORE); launch_ekf_core(E, c->st); }
+    { ProfScope p(c, PF_DOWNDATE); launch_downdate(E, c->d.n_max, c->st); }
+    return last_launch(c);
+}
+
+int fill_noise_scalar(ingvio_ctx* c, int b0, int nb, double var)
+{
+    std::vector<double> v(nb, var);
+    int rc = up(c, c->d_noise + b0, v.data(), 8 * (size_t)nb);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
+{
+    if (!desc || !out || desc->batch < 1 || desc->n_max < 21 || desc->c_max < 1 || desc->f_max < 1) return INGVIO_E_ARG;
+    if (msckf_cmax_class(desc->c_max) < 0 || desc->c_max > 64) return INGVIO_E_CAPACITY;
+    if (desc->m_max > 128) return INGVIO_E_CAPACITY;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= desc->device) return INGVIO_E_HIP;
+    ingvio_ctx* c = new ingvio_ctx();
+    c->d = *desc;
+    if (c->d.m_max < 1) c->d.m_max = 32;
+    c->err.clear();
+    if (hipSetDevice(desc->device) != hipSuccess) { delete c; return INGVIO_E_HIP; }
+    c->own_stream = desc->stream == nullptr;
+    if (c->own_stream) {
+        if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) { delete c; return INGVIO_E_HIP; }
+    } else c->st = (hipStream_t)desc->stream;
+    const int B = desc->batch;
+    c->ldp = (desc->n_max + 15) & ~15;
+    const int mcap = c->d.m_max > 6 * desc->c_max ? c->d.m_max : 6 * desc->c_max;
+    c->mld = (mcap + 15) & ~15;
+    c->nc_cap = mcap;
+    c->G = 2048 / B; if (c->G > 16) c->G = 16; if (c->G < 2) c->G = 2;
+    c->cls = msckf_cmax_class(desc->c_max);
+    const int ncm = 6 * desc->c_max;
+    c->rstride = ncm * (ncm + 1);
+    c->hstride = c->mld * c->nc_cap;
+    c->cstride = c->nc_cap;
+    c->ystride = c->ldp * (c->mld + 4);
+    c->has_snap = false; c->staged = false; c->prof = false;
+    memset(c->prof_ms, 0, sizeof c->prof_ms); memset(c->prof_calls, 0, sizeof c->prof_calls);
+    c->h_n.assign(B, 0); c->h_cur.assign(B, 0); c->h_n_snap.assign(B, 0); c->st_marg.assign(B, -1);
+    const size_t pp = (size_t)c->ldp * c->ldp;
+    const int cm = desc->c_max, fm = desc->f_max;
+    int rc = 0;
+    rc |= dalloc(c, &c->Pbase, 2 * (size_t)B * pp);
+    rc |= dalloc(c, &c->Psnap, (size_t)B * pp);
+    rc |= dalloc(c, &c->d_cur, B); rc |= dalloc(c, &c->d_n, B); rc |= dalloc(c, &c->d_n_snap, B);
+    rc |= dalloc(c, &c->d_Phi, (size_t)B * KMAX * 225); rc |= dalloc(c, &c->d_G, (size_t)B * KMAX * 180);
+    rc |= dalloc(c, &c->d_dt, (size_t)B * KMAX); rc |= dalloc(c, &c->d_R, (size_t)B * 9);
+    rc |= dalloc(c, &c->d_blk, (size_t)B * 36); rc |= dalloc(c, &c->d_gnss, (size_t)B * 5); rc |= dalloc(c, &c->d_idx, B);
+    rc |= dalloc(c, &c->d_clone_idx, (size_t)B * cm); rc |= dalloc(c, &c->d_nclones, B); rc |= dalloc(c, &c->d_nfeat, B);
+    rc |= dalloc(c, &c->d_anchor, (size_t)B * fm); rc |= dalloc(c, &c->d_dof, (size_t)B * fm);
+    rc |= dalloc(c, &c->d_clone_R, (size_t)B * cm * 9); rc |= dalloc(c, &c->d_clone_p, (size_t)B * cm * 3);
+    rc |= dalloc(c, &c->d_pf, (size_t)B * fm * 3); rc |= dalloc(c, &c->d_uv, (size_t)B * fm * cm * 4);
+    rc |= dalloc(c, &c->d_chi2, CHI2_CAP); rc |= dalloc(c, &c->d_mask, (size_t)B * fm);
+    rc |= dalloc(c, &c->d_gamma, (size_t)B * fm); rc |= dalloc(c, &c->d_accept, (size_t)B * fm); rc |= dalloc(c, &c->d_used, (size_t)B * fm);
+    rc |= dalloc(c, &c->d_Rpart, (size_t)B * c->G * c->rstride); rc |= dalloc(c, &c->d_chunk_used, (size_t)B * c->G);
+    rc |= dalloc(c, &c->d_H, (size_t)B * c->hstride); rc |= dalloc(c, &c->d_res, (size_t)B * c->mld);
+    rc |= dalloc(c, &c->d_colmap, (size_t)B * c->cstride); rc |= dalloc(c, &c->d_m, B); rc |= dalloc(c, &c->d_nc, B);
+    rc |= dalloc(c, &c->d_noise, B); rc |= dalloc(c, &c->d_noise1, (size_t)c->mld * c->mld);
+    rc |= dalloc(c, &c->d_Y, (size_t)B * c->ystride); rc |= dalloc(c, &c->d_dx, (size_t)B * c->ldp);
+    rc |= dalloc(c, &c->d_status, B);
+    if (rc || hipStreamSynchronize(c->st) != hipSuccess) { *out = c; return INGVIO_E_HIP; }
+    *out = c;
+    return INGVIO_OK;
+}
+
+int ingvio_ctx_destroy(ingvio_ctx* c)
+{
+    if (!c) return INGVIO_E_ARG;
+    hipStreamSynchronize(c->st);
+    void* ptrs[] = { c->Pbase, c->Psnap, c->d_cur, c->d_n, c->d_n_snap, c->d_Phi, c->d_G, c->d_dt, c->d_R, c->d_blk, c->d_gnss,
+                     c->d_idx, c->d_clone_idx, c->d_nclones, c->d_nfeat, c->d_anchor, c->d_dof, c->d_clone_R, c->d_clone_p,
+                     c->d_pf, c->d_uv, c->d_chi2, c->d_mask, c->d_gamma, c->d_accept, c->d_used, c->d_Rpart, c->d_chunk_used,
+                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_dx, c->d_status };
+    for (void* p : ptrs) if (p) hipFree(p);
+    for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    if (c->own_stream) hipStreamDestroy(c->st);
+    delete c;
+    return INGVIO_OK;
+}
+
+int ingvio_sync(ingvio_ctx* c)
+{
+    if (!c) return INGVIO_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipGetLastError());
+    return INGVIO_OK;
+}
+void* ingvio_ctx_stream(ingvio_ctx* c) { return c ? (void*)c->st : nullptr; }
+const char* ingvio_last_error(ingvio_ctx* c) { return c ? c->err.c_str() : "null context"; }
+int ingvio_ldp(ingvio_ctx* c) { return c ? c->ldp : 0; }
+
+int ingvio_cov_set(ingvio_ctx* c, int b, const double* P, int ld, int n)
+{
+    if (check_range(c, b, 1) || !P || n < 0 || n > c->d.n_max || ld < n) return INGVIO_E_ARG;
+    double* dst = c->Pbase + ((size_t)c->h_cur[b] * c->d.batch + b) * (size_t)c->ldp * c->ldp;
+    if (n) HIPCHK(c, hipMemcpy2DAsync(dst, 8 * (size_t)c->ldp, P, 8 * (size_t)ld, 8 * (size_t)n, n, hipMemcpyHostToDevice, c->st));
+    c->h_n[b] = n;
+    HIPCHK(c, hipMemcpyAsync(c->d_n + b, &c->h_n[b], sizeof(int), hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return INGVIO_OK;
+}
+
+int ingvio_cov_get(ingvio_ctx* c, int b, double* P, int ld)
+{
+    if (check_range(c, b, 1) || !P) return INGVIO_E_ARG;
+    const int n = c->h_n[b];
+    if (ld < n) return INGVIO_E_ARG;
+    const double* src = c->Pbase + ((size_t)c->h_cur[b] * c->d.batch + b) * (size_t)c->ldp * c->ldp;
+    if (n) HIPCHK(c, hipMemcpy2DAsync(P, 8 * (size_t)ld, src, 8 * (size_t)c->ldp, 8 * (size_t)n, n, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipGetLastError());
+    return INGVIO_OK;
+}
+
+int ingvio_get_n(ingvio_ctx* c, int b, int* n)
+{
+    if (check_range(c, b, 1) || !n) return INGVIO_E_ARG;
+    *n = c->h_n[b];
+    return INGVIO_OK;
+}
+
+int ingvio_cov_get_marginal(ingvio_ctx* c, int b, const int* vidx, const int* vsize, int k, double* out)
+{
+    if (check_range(c, b, 1) || !vidx || !vsize || !out || k < 1) return INGVIO_E_ARG;
+    const int n = c->h_n[b];
+    std::vector<double> P((size_t)n * n);
+    int rc = ingvio_cov_get(c, b, P.data(), n);
+    if (rc) return rc;
+    int ns = 0;
+    for (int i = 0; i < k; ++i) { if (vidx[i] < 0 || vidx[i] + vsize[i] > n) return INGVIO_E_NOT_IN_STATE; ns += vsize[i]; }
+    int r0 = 0;
+    for (int a = 0; a < k; ++a) {
+        int c0 = 0;
+        for (int bb = 0; bb < k; ++bb) {
+            for (int j = 0; j < vsize[bb]; ++j) for (int i = 0; i < vsize[a]; ++i)
+                out[(size_t)(c0 + j) * ns + r0 + i] = P[(size_t)(vidx[bb] + j) * n + vidx[a] + i];
+            c0 += vsize[bb];
+        }
+        r0 += vsize[a];
+    }
+    return INGVIO_OK;
+}
+
+int ingvio_cov_snapshot(ingvio_ctx* c)
+{
+    if (!c) return INGVIO_E_ARG;
+    launch_snapshot(view(c), c->d.n_max, c->Psnap, c->d_n_snap, c->st);
+    c->h_n_snap = c->h_n;
+    c->has_snap = true;
+    return last_launch(c);
+}
+
+int ingvio_cov_restore(ingvio_ctx* c)
+{
+    if (!c || !c->has_snap) return INGVIO_E_ARG;
+    launch_restore(view(c), c->d.n_max, c->Psnap, c->d_n_snap, c->st);
+    c->h_n = c->h_n_snap;
+    std::fill(c->h_cur.begin(), c->h_cur.end(), 0);
+    return last_launch(c);
+}
+
+int ingvio_propagate_fused(ingvio_ctx* c, int b0, int nb, int k, const double* Phi, const double* G, const double* dt,
+                           const double sigma[4], int enable_gnss, const int* gnss_idx, double scb, double srw)
+{
+    if (check_range(c, b0, nb) || k < 1 || k > KMAX || !Phi || !G || !dt || !sigma) return INGVIO_E_ARG;
+    for (int i = 0; i < nb; ++i) if (c->h_n[b0 + i] < 15) return INGVIO_E_ARG;
+    int rc = up(c, c->d_Phi, Phi, 8 * (size_t)nb * k * 225);
+    rc |= up(c, c->d_G, G, 8 * (size_t)nb * k * 180);
+    rc |= up(c, c->d_dt, dt, 8 * (size_t)nb * k);
+    if (enable_gnss && gnss_idx) rc |= up(c, c->d_gnss, gnss_idx, sizeof(int) * (size_t)nb * 5);
+    if (rc) return INGVIO_E_HIP;
+    {
+        ProfScope p(c, PF_PROPAGATE);
+        launch_propagate(view(c), b0, nb, c->d.n_max, c->d_Phi, c->d_G, c->d_dt, k, (enable_gnss && gnss_idx) ? c->d_gnss : nullptr,
+                         sigma, enable_gnss, scb, srw, c->st);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->st));     // staging buffers are shared: keep the API re-entrant
+    return last_launch(c);
+}
+
+int ingvio_propagate(ingvio_ctx* c, int b0, int nb, const double* Phi, const double* G, const double* dt,
+                     const double sigma[4], int enable_gnss, const int* gnss_idx, double scb, double srw)
+{
+    return ingvio_propagate_fused(c, b0, nb, 1, Phi, G, dt, sigma, enable_gnss, gnss_idx, scb, srw);
+}
+
+int ingvio_augment_clone(ingvio_ctx* c, int b0, int nb, const double* R, int* new_idx)
+{
+    if (check_range(c, b0, nb) || !R) return INGVIO_E_ARG;
+    for (int i = 0; i < nb; ++i) {
+        if (c->h_n[b0 + i] < 21) return INGVIO_E_ARG;
+        if (c->h_n[b0 + i] + 6 > c->d.n_max) return INGVIO_E_CAPACITY;
+    }
+    if (up(c, c->d_R, R, 8 * (size_t)nb * 9)) return INGVIO_E_HIP;
+    { ProfScope p(c, PF_AUGMENT); launch_augment(view(c), b0, nb, c->d_R, c->st); }
+    for (int i = 0; i < nb; ++i) { if (new_idx) new_idx[i] = c->h_n[b0 + i]; c->h_n[b0 + i] += 6; }
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return last_launch(c);
+}
+
+int ingvio_marginalize(ingvio_ctx* c, int b0, int nb, const int* idx, int size)
+{
+    if (check_range(c, b0, nb) || !idx || size < 1) return INGVIO_E_ARG;
+    for (int i = 0; i < nb; ++i)
+        if (idx[i] >= 0 && idx[i] + size > c->h_n[b0 + i]) return INGVIO_E_NOT_IN_STATE;
+    if (up(c, c->d_idx, idx, sizeof(int) * (size_t)nb)) return INGVIO_E_HIP;
+    { ProfScope p(c, PF_MARG); launch_marginalize(view(c), b0, nb, c->d.n_max, c->d_idx, size, c->st); }
+    for (int i = 0; i < nb; ++i) if (idx[i] >= 0) { c->h_n[b0 + i] -= size; c->h_cur[b0 + i] ^= 1; }
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return last_launch(c);
+}
+
+int ingvio_append_independent(ingvio_ctx* c, int b0, int nb, int size, const double* blk, int* new_idx)
+{
+    if (check_range(c, b0, nb) || !blk || size < 1 || size > 6) return INGVIO_E_ARG;
+    for (int i = 0; i < nb; ++i) if (c->h_n[b0 + i] + size > c->d.n_max) return INGVIO_E_CAPACITY;
+    if (up(c, c->d_blk, blk, 8 * (size_t)nb * size * size)) return INGVIO_E_HIP;
+    launch_append(view(c), b0, nb, size, c->d_blk, c->st);
+    for (int i = 0; i < nb; ++i) { if (new_idx) new_idx[i] = c->h_n[b0 + i]; c->h_n[b0 + i] += size; }
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return last_launch(c);
+}
+
+static int stage_generic(ingvio_ctx* c, int b, const int* vidx, const int* vsize, int k, const double* H, int ldh, int m,
+                         const double* res, const double* R, int r_kind, int* nc_out)
+{
+    if (check_range(c, b, 1) || !vidx || !vsize || !H || !res || !R || k < 1 || m < 1 || ldh < m) return INGVIO_E_ARG;
+    if (r_kind < 0 || r_kind > 2) return INGVIO_E_ARG;
+    if (m > c->d.m_max && m > 6 * c->d.c_max) return INGVIO_E_CAPACITY;
+    int nc = 0;
+    std::vector<int> cm;
+    for (int i = 0; i < k; ++i) {
+        if (vidx[i] < 0 || vidx[i] + vsize[i] > c->h_n[b]) return INGVIO_E_NOT_IN_STATE;      // checkSubOrder
+        for (int j = 0; j < vsize[i]; ++j) cm.push_back(vidx[i] + j);
+        nc += vsize[i];
+    }
+    if (nc > c->nc_cap) return INGVIO_E_CAPACITY;
+    std::vector<double> Hp((size_t)c->mld * nc, 0.0);
+    for (int cc = 0; cc < nc; ++cc) memcpy(&Hp[(size_t)cc * c->mld], H + (size_t)cc * ldh, 8 * (size_t)m);
+    int rc = up(c, c->d_H + (size_t)b * c->hstride, Hp.data(), 8 * Hp.size());
+    rc |= up(c, c->d_res + (size_t)b * c->mld, res, 8 * (size_t)m);
+    rc |= up(c, c->d_colmap + (size_t)b * c->cstride, cm.data(), sizeof(int) * (size_t)nc);
+    rc |= up(c, c->d_m + b, &m, sizeof(int));
+    rc |= up(c, c->d_nc + b, &nc, sizeof(int));
+    rc |= up(c, c->d_noise1, R, 8 * (size_t)(r_kind == 0 ? 1 : (r_kind == 1 ? m : m * m)));
+    if (rc) return INGVIO_E_HIP;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    *nc_out = nc;
+    return 0;
+}
+
+int ingvio_ekf_update(ingvio_ctx* c, int b, const int* vidx, const int* vsize, int k, const double* H, int ldh, int m,
+                      const double* res, const double* R, int r_kind, double* dx_out)
+{
+    int nc = 0;
+    int rc = stage_generic(c, b, vidx, vsize, k, H, ldh, m, res, R, r_kind, &nc);
+    if (rc) return rc;
+    int zero = 0;
+    if (up(c, c->d_status + b, &zero, sizeof(int))) return INGVIO_E_HIP;
+    EkfLaunch E;
+    memset(&E, 0, sizeof E);
+    E.cv = view(c); E.b0 = b; E.nb = 1; E.H = c->d_H + (size_t)b * c->hstride; E.res = c->d_res + (size_t)b * c->mld;
+    E.colmap = c->d_colmap + (size_t)b * c->cstride; E.m = c->d_m + b; E.nc = c->d_nc + b;
+    E.noise = c->d_noise1; E.r_kind = r_kind; E.mld = c->mld; E.hstride = c->hstride; E.cstride = c->cstride;
+    E.nstride = c->mld * c->mld; E.Y = c->d_Y + (size_t)b * c->ystride; E.ystride = c->ystride; E.dx = c->d_dx;
+    E.status = c->d_status; E.m_cap = m; E.nc_cap = nc;
+    { ProfScope p(c, PF_EKF_CORE); launch_ekf_core(E, c->st); }
+    { ProfScope p(c, PF_DOWNDATE); launch_downdate(E, c->h_n[b], c->st); }
+    int status = 0;
+    if (dx_out && down_sync(c, dx_out, c->d_dx + (size_t)b * c->ldp, 8 * (size_t)c->h_n[b])) return INGVIO_E_HIP;
+    if (down_sync(c, &status, c->d_status + b, sizeof(int))) return INGVIO_E_HIP;
+    rc = last_launch(c);
+    if (rc) return rc;
+    return (status & 2) ? INGVIO_NEG_DIAG : INGVIO_OK;
+}
+
+int ingvio_chi2_gamma(ingvio_ctx* c, int b, const int* vidx, const int* vsize, int k, const double* H, int ldh, int m,
+                      const double* res, const double* R, int r_kind, double* gamma)
+{
+    if (!gamma) return INGVIO_E_ARG;
+    int nc = 0;
+    int rc = stage_generic(c, b, vidx, vsize, k, H, ldh, m, res, R, r_kind, &nc);
+    if (rc) return rc;
+    if ((size_t)8 * ((size_t)nc * m + (size_t)(m + 1) * (m + 1)) > 150 * 1024) return INGVIO_E_CAPACITY;
+    launch_gamma(view(c), b, c->d_H + (size_t)b * c->hstride, c->d_res + (size_t)b * c->mld, c->d_colmap + (size_t)b * c->cstride,
+                 m, nc, c->d_noise1, r_kind, c->mld, c->d_gamma + (size_t)b * c->d.f_max, c->st);
+    if (down_sync(c, gamma, c->d_gamma + (size_t)b * c->d.f_max, 8)) return INGVIO_E_HIP;
+    return last_launch(c);
+}
+
+int ingvio_msckf_update(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* frames, const ingvio_msckf_opts* opts,
+                        double* dx_out, int* accepted, double* gamma, int* rows_out)
+{
+    if (check_range(c, b0, nb) || !frames || !opts) return INGVIO_E_ARG;
+    MsckfOpts op;
+    int rc = make_opts(c, opts, &op);
+    if (rc) return rc;
+    int fmx = 0;
+    rc = stage_frames(c, b0, nb, frames, &fmx);
+    if (rc) return rc;
+    rc = fill_noise_scalar(c, b0, nb, op.var);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_status + b0, 0, sizeof(int) * (size_t)nb, c->st));
+    rc = run_msckf(c, b0, nb, op, opts->stereo, fmx);
+    if (rc) return rc;
+    const int fm = c->d.f_max;
+    if (dx_out) HIPCHK(c, hipMemcpyAsync(dx_out, c->d_dx + (size_t)b0 * c->ldp, 8 * (size_t)nb * c->ldp, hipMemcpyDeviceToHost, c->st));
+    if (accepted) HIPCHK(c, hipMemcpyAsync(accepted, c->d_used + (size_t)b0 * fm, sizeof(int) * (size_t)nb * fm, hipMemcpyDeviceToHost, c->st));
+    if (gamma) HIPCHK(c, hipMemcpyAsync(gamma, c->d_gamma + (size_t)b0 * fm, 8 * (size_t)nb * fm, hipMemcpyDeviceToHost, c->st));
+    std::vector<int> rows(nb), status(nb);
+    HIPCHK(c, hipMemcpyAsync(rows.data(), c->d_m + b0, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(status.data(), c->d_status + b0, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    rc = last_launch(c);
+    if (rc) return rc;
+    int soft = INGVIO_OK;
+    for (int i = 0; i < nb; ++i) {
+        if (rows_out) rows_out[i] = rows[i];
+        if (rows[i] == 0 && soft == INGVIO_OK) soft = INGVIO_NO_ROWS;
+        if (status[i] & 2) soft = INGVIO_NEG_DIAG;
+    }
+    return nb == 1 ? soft : (soft == INGVIO_NEG_DIAG ? soft : INGVIO_OK);
+}
+
+int ingvio_qr_compress(ingvio_ctx* c, const double* H, int ldh, int m, int n, const double* res, double* Ht, int ldt, double* rt)
+{
+    if (!c || !H || !res || !Ht || !rt || m < 1 || n < 1 || ldh < m || ldt < n) return INGVIO_E_ARG;
+    if (n > 6 * c->d.c_max) return INGVIO_E_CAPACITY;
+    double *dH = nullptr, *dres = nullptr;
+    HIPCHK(c, hipMalloc((void**)&dH, 8 * (size_t)ldh * n));
+    HIPCHK(c, hipMalloc((void**)&dres, 8 * (size_t)m));
+    int rc = up(c, dH, H, 8 * (size_t)ldh * n) | up(c, dres, res, 8 * (size_t)m);
+    if (rc) { hipFree(dH); hipFree(dres); return INGVIO_E_HIP; }
+    // leaf: G chunks of row blocks -> partial factors in filter 0's Rpart slots
+    MsckfLaunch L;
+    memset(&L, 0, sizeof L);
+    L.stage = 3; L.stereo = 1; L.fv = fview(c); L.G = c->G; L.rstride = c->rstride; L.Rpart = c->d_Rpart;
+    L.chunk_used = c->d_chunk_used; L.dH = dH; L.dres = dres; L.ldh = ldh; L.m = m; L.ncol = n;
+    { ProfScope p(c, PF_FOLD); launch_msckf(L, c->st); }
+    // merge needs n_clones-independent ncol: reuse k_msckf_merge through a 1-filter FrameView whose n_clones = n/6
+    if (n % 6 != 0) { hipStreamSynchronize(c->st); hipFree(dH); hipFree(dres); return INGVIO_E_UNSUPPORTED; }
+    int ncl = n / 6, zero = 0;
+    std::vector<int> keep(2);
+    HIPCHK(c, hipMemcpyAsync(&keep[0], c->d_nclones, sizeof(int), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    rc = up(c, c->d_nclones, &ncl, sizeof(int));
+    (void)zero;
+    L.stage = 2; L.b0 = 0; L.nb = 1; L.Hout = c->d_H; L.res_out = c->d_res; L.colmap = c->d_colmap; L.m_out = c->d_m;
+    L.nc_out = c->d_nc; L.mld = c->mld; L.hstride = c->hstride; L.cstride = c->cstride;
+    { ProfScope p(c, PF_MERGE); launch_msckf(L, c->st); }
+    std::vector<double> Hh((size_t)c->mld * n), rh(c->mld);
+    HIPCHK(c, hipMemcpyAsync(Hh.data(), c->d_H, 8 * Hh.size(), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(rh.data(), c->d_res, 8 * (size_t)n, hipMemcpyDeviceToHost, c->st));
+    rc |= up(c, c->d_nclones, &keep[0], sizeof(int));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    hipFree(dH); hipFree(dres);
+    if (rc) return INGVIO_E_HIP;
+    for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) Ht[(size_t)j * ldt + i] = (i <= j) ? Hh[(size_t)j * c->mld + i] : 0.0;
+    for (int i = 0; i < n; ++i) rt[i] = rh[i];
+    return last_launch(c);
+}
+
+int ingvio_frame_stage(ingvio_ctx* c, int b0, int nb, const ingvio_frame_step* steps, const ingvio_msckf_frame* frames,
+                       const ingvio_msckf_opts* opts, const double sigma[4], int enable_gnss, double scb, double srw)
+{
+    if (check_range(c, b0, nb) || !steps || !frames || !opts || !sigma) return INGVIO_E_ARG;
+    const int k = steps[0].k;
+    if (k < 1 || k > KMAX) return INGVIO_E_ARG;
+    std::vector<double> Phi((size_t)nb * k * 225), G((size_t)nb * k * 180), dt((size_t)nb * k), R((size_t)nb * 9);
+    std::vector<int> gi((size_t)nb * 5), mi(nb);
+    for (int i = 0; i < nb; ++i) {
+        if (steps[i].k != k) return INGVIO_E_ARG;
+        memcpy(&Phi[(size_t)i * k * 225], steps[i].Phi, 8 * (size_t)k * 225);
+        memcpy(&G[(size_t)i * k * 180], steps[i].G, 8 * (size_t)k * 180);
+        memcpy(&dt[(size_t)i * k], steps[i].dt, 8 * (size_t)k);
+        memcpy(&R[(size_t)i * 9], steps[i].R_i2w, 72);
+        for (int g = 0; g < 5; ++g) gi[(size_t)i * 5 + g] = steps[i].gnss_idx[g];
+        mi[i] = steps[i].marg_idx;
+        c->st_marg[b0 + i] = steps[i].marg_idx;
+    }
+    int rc = up(c, c->d_Phi + (size_t)b0 * k * 225, Phi.data(), 8 * Phi.size());
+    rc |= up(c, c->d_G + (size_t)b0 * k * 180, G.data(), 8 * G.size());
+    rc |= up(c, c->d_dt + (size_t)b0 * k, dt.data(), 8 * dt.size());
+    rc |= up(c, c->d_R + (size_t)b0 * 9, R.data(), 8 * R.size());
+    rc |= up(c, c->d_gnss + (size_t)b0 * 5, gi.data(), sizeof(int) * gi.size());
+    rc |= up(c, c->d_idx + b0, mi.data(), sizeof(int) * (size_t)nb);
+    if (rc) return INGVIO_E_HIP;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    rc = make_opts(c, opts, &c->st_op);
+    if (rc) return rc;
+    int fmx = 0;
+    rc = stage_frames(c, b0, nb, frames, &fmx);
+    if (rc) return rc;
+    rc = fill_noise_scalar(c, b0, nb, c->st_op.var);
+    if (rc) return rc;
+    c->st_k = k; c->st_stereo = opts->stereo; c->st_enable_gnss = enable_gnss; c->st_scb = scb; c->st_srw = srw;
+    memcpy(c->st_sigma, sigma, 32);
+    if (!c->staged || fmx > c->st_fmax_used) c->st_fmax_used = fmx;
+    c->staged = true;
+    return INGVIO_OK;
+}
+
+int ingvio_frame_run(ingvio_ctx* c, int restore_prior)
+{
+    if (!c || !c->staged) return INGVIO_E_ARG;
+    const int B = c->d.batch;
+    if (restore_prior) {
+        if (!c->has_snap) return INGVIO_E_ARG;
+        ProfScope p(c, PF_RESTORE);
+        launch_restore(view(c), c->d.n_max, c->Psnap, c->d_n_snap, c->st);
+        c->h_n = c->h_n_snap;
+        std::fill(c->h_cur.begin(), c->h_cur.end(), 0);
+    }
+    for (int b = 0; b < B; ++b) if (c->h_n[b] + 6 > c->d.n_max) return INGVIO_E_CAPACITY;
+    hipMemsetAsync(c->d_status, 0, sizeof(int) * (size_t)B, c->st);
+    {
+        ProfScope p(c, PF_PROPAGATE);
+        launch_propagate(view(c), 0, B, c->d.n_max, c->d_Phi, c->d_G, c->d_dt, c->st_k, c->st_enable_gnss ? c->d_gnss : nullptr,
+                         c->st_sigma, c->st_enable_gnss, c->st_scb, c->st_srw, c->st);
+    }
+    { ProfScope p(c, PF_AUGMENT); launch_augment(view(c), 0, B, c->d_R, c->st); }
+    for (int b = 0; b < B; ++b) c->h_n[b] += 6;
+    int rc = run_msckf(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used);
+    if (rc) return rc;
+    { ProfScope p(c, PF_MARG); launch_marginalize(view(c), 0, B, c->d.n_max, c->d_idx, 6, c->st); }
+    for (int b = 0; b < B; ++b) if (c->st_marg[b] >= 0) { c->h_n[b] -= 6; c->h_cur[b] ^= 1; }
+    return INGVIO_OK;
+}
+
+int ingvio_frame_fetch(ingvio_ctx* c, int b0, int nb, double* dx_out, int* accepted, int* rows_out)
+{
+    if (check_range(c, b0, nb)) return INGVIO_E_ARG;
+    const int fm = c->d.f_max;
+    if (dx_out) HIPCHK(c, hipMemcpyAsync(dx_out, c->d_dx + (size_t)b0 * c->ldp, 8 * (size_t)nb * c->ldp, hipMemcpyDeviceToHost, c->st));
+    if (accepted) HIPCHK(c, hipMemcpyAsync(accepted, c->d_used + (size_t)b0 * fm, sizeof(int) * (size_t)nb * fm, hipMemcpyDeviceToHost, c->st));
+    if (rows_out) HIPCHK(c, hipMemcpyAsync(rows_out, c->d_m + b0, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return last_launch(c);
+}
+
+int ingvio_profile_enable(ingvio_ctx* c, int enable)
+{
+    if (!c) return INGVIO_E_ARG;
+    c->prof = enable != 0;
+    return INGVIO_OK;
+}
+
+static void prof_collect(ingvio_ctx* c)
+{
+    hipStreamSynchronize(c->st);
+    for (auto& r : c->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->prof_ms[r.id] += ms; c->prof_calls[r.id] += 1; }
+        hipEventDestroy(r.a); hipEventDestroy(r.b);
+    }
+    c->recs.clear();
+}
+
+int ingvio_profile_reset(ingvio_ctx* c)
+{
+    if (!c) return INGVIO_E_ARG;
+    prof_collect(c);
+    memset(c->prof_ms, 0, sizeof c->prof_ms); memset(c->prof_calls, 0, sizeof c->prof_calls);
+    return INGVIO_OK;
+}
+
+int ingvio_profile_get(ingvio_ctx* c, const char** names, double* ms, int* calls, int cap)
+{
+    if (!c || !names || !ms || !calls) return INGVIO_E_ARG;
+    prof_collect(c);
+    int k = 0;
+    for (int i = 0; i < PF_COUNT && k < cap; ++i) { names[k] = kProfNames[i]; ms[k] = c->prof_ms[i]; calls[k] = c->prof_calls[i]; ++k; }
+    return k;
+}
+
+}  // extern "C"

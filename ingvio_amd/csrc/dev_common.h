@@ -1,0 +1,57 @@
+// dev_common.h — shared declarations of libingvio_hip.so's device side (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WAVE 64
+
+// Device view of a context: B filters, two ping-pong covariance buffers per filter.
+// Filter b's current covariance = Pbase + (cur[b] * B + b) * ldp * ldp, column-major, ld = ldp.
+struct CovView {
+    double* Pbase;
+    int* cur;     // [B] 0/1: which ping-pong half is live
+    int* n;       // [B] current state dimension
+    int ldp;
+    int B;
+};
+
+__device__ __forceinline__ double* cov_ptr(const CovView& v, int b)
+{
+    return v.Pbase + ((size_t)v.cur[b] * v.B + b) * (size_t)v.ldp * v.ldp;
+}
+__device__ __forceinline__ double* cov_alt_ptr(const CovView& v, int b)
+{
+    return v.Pbase + ((size_t)(1 - v.cur[b]) * v.B + b) * (size_t)v.ldp * v.ldp;
+}
+
+// MSCKF frame inputs, SoA over the batch (strides are the context maxima).
+struct FrameView {
+    const int* clone_idx;               // [B][cmax]
+    const double* clone_R;              // [B][cmax][9]
+    const double* clone_p;              // [B][cmax][3]
+    const int* n_clones;                // [B]
+    const int* n_feat;                  // [B]
+    const double* pf;                   // [B][fmax][3]
+    const int* anchor;                  // [B][fmax]
+    const unsigned long long* obs_mask; // [B][fmax]
+    const double* uv;                   // [B][fmax][cmax][4]
+    const int* dof;                     // [B][fmax]
+    int cmax, fmax;
+};
+
+struct MsckfOpts {
+    double R_lr[9];
+    double t_lr[3];
+    double var;            // visual_noise^2
+    int max_accept;
+    int selected_variant;
+    const double* chi2;    // device table
+    int chi2_len;
+};
+
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, WAVE);
+    return x;
+}

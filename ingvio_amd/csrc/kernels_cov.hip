@@ -1,0 +1,326 @@
+// kernels_cov.hip — covariance strip kernels: K1 (fused IMU propagation), K2 (clone augmentation),
+// K12 (marginalisation), addVariableIndependent.  All are HBM/latency bound: each touches the
+// 15(+gnss)-wide strip or the N^2 matrix exactly once, coalesced along the column-major leading
+// dimension.  gfx950 only.
+#include "dev_common.h"
+
+#define PROP_THREADS 256
+#define NA_MAX 20      // 15 IMU + 4 clock biases + clock drift
+
+// ---------------------------------------------------------------------------------------------
+// K1: StateManager::propagateStateCov (StateManager.cpp:42-119), k IMU steps fused.
+// Every workgroup composes Phi_tot = Phi_k..Phi_1 and Q_tot = sum Phi_{k..s+1} Q_s Phi_{k..s+1}^T
+// in LDS (15x15 work, redundantly per row tile), then applies
+//     P[r, A] <- P[r, A] Phi_A^T          for rows r outside the active set A
+//     P[A, A] <- Phi_A P[A, A] Phi_A^T + Q_A, symmetrised
+// where A = {0..14} + the GNSS clock states (clock-bias <- clock-drift coupling, :56-86, and the
+// clock process noise, :99-116).  grid = (row tiles, nb).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PROP_THREADS) void k_propagate(
+    CovView cv, int b0, const double* __restrict__ Phi, const double* __restrict__ G,
+    const double* __restrict__ dts, int k, const int* __restrict__ gnss_idx,
+    double sg0, double sg1, double sg2, double sg3, int enable_gnss, double scb, double srw)
+{
+    const int bl = blockIdx.y, b = b0 + bl, tid = threadIdx.x;
+    const int n = cv.n[b], ld = cv.ldp;
+    double* P = cov_ptr(cv, b);
+
+    __shared__ double sPhi[225], sQ[225], sStep[225], sG[180], sPG[180], sT1[225], sT2[225];
+    __shared__ double sPhiA[NA_MAX * NA_MAX], sQA[NA_MAX * NA_MAX], sX[NA_MAX * NA_MAX], sY[NA_MAX * NA_MAX];
+    __shared__ int sA[NA_MAX];
+    __shared__ int sNA;
+
+    const double sig[4] = { sg0, sg1, sg2, sg3 };
+    if (tid < 225) { sPhi[tid] = (tid % 15 == tid / 15) ? 1.0 : 0.0; sQ[tid] = 0.0; }
+    const double* PhiB = Phi + (size_t)bl * k * 225;
+    const double* GB = G + (size_t)bl * k * 180;
+    const double* dtB = dts + (size_t)bl * k;
+    __syncthreads();
+    for (int s = 0; s < k; ++s) {
+        if (tid < 225) sStep[tid] = PhiB[s * 225 + tid];
+        if (tid < 180) sG[tid] = GB[s * 180 + tid] * sig[(tid / 15) / 3];   // G_tmp, :92-96
+        __syncthreads();
+        const double dt = dtB[s];
+        const int i = tid % 15, j = tid / 15;
+        if (tid < 180) {
+            double a = 0.0;
+            for (int l = 0; l < 15; ++l) a += sStep[i + 15 * l] * sG[l + 15 * j];
+            sPG[tid] = a;                                                   // Phi * G_tmp
+        }
+        if (tid < 225) {
+            double a = 0.0, c = 0.0;
+            for (int l = 0; l < 15; ++l) { a += sStep[i + 15 * l] * sQ[l + 15 * j]; c += sStep[i + 15 * l] * sPhi[l + 15 * j]; }
+            sT1[tid] = a; sT2[tid] = c;
+        }
+        __syncthreads();
+        if (tid < 225) {
+            double a = 0.0, q = 0.0;
+            for (int l = 0; l < 15; ++l) a += sT1[i + 15 * l] * sStep[j + 15 * l];
+            for (int l = 0; l < 12; ++l) q += sPG[i + 15 * l] * sPG[j + 15 * l];
+            sQ[tid] = a + dt * q;                                           // :51 + :97 composed
+            sPhi[tid] = sT2[tid];
+        }
+        __syncthreads();
+    }
+    // active set + GNSS clock block (thread 0, <= 5x5 work)
+    if (tid == 0) {
+        int gi[5], na = 15;
+        for (int g = 0; g < 5; ++g) gi[g] = (enable_gnss && gnss_idx) ? gnss_idx[bl * 5 + g] : -1;
+        for (int a = 0; a < 15; ++a) sA[a] = a;
+        int loc[5];
+        for (int g = 0; g < 5; ++g) { loc[g] = -1; if (gi[g] >= 0) { loc[g] = na; sA[na++] = gi[g]; } }
+        sNA = na;
+        for (int a = 0; a < NA_MAX * NA_MAX; ++a) { sPhiA[a] = 0.0; sQA[a] = 0.0; }
+        for (int a = 0; a < 15; ++a) for (int c = 0; c < 15; ++c) {
+            sPhiA[a * NA_MAX + c] = sPhi[a + 15 * c];
+            sQA[a * NA_MAX + c] = sQ[a + 15 * c];
+        }
+        double qg[5][5];
+        for (int a = 0; a < 5; ++a) for (int c = 0; c < 5; ++c) qg[a][c] = 0.0;
+        double T = 0.0;
+        const bool has_fs = gi[4] >= 0;
+        for (int s = 0; s < k; ++s) {
+            const double dt = dtB[s];
+            if (has_fs) {
+                T += dt;
+                for (int g = 0; g < 4; ++g) if (gi[g] >= 0) for (int c = 0; c < 5; ++c) qg[g][c] += dt * qg[4][c];
+                for (int g = 0; g < 4; ++g) if (gi[g] >= 0) for (int r = 0; r < 5; ++r) qg[r][g] += dt * qg[r][4];
+            }
+            for (int a = 0; a < 5; ++a) {
+                if (gi[a] < 0) continue;
+                for (int c = 0; c < 5; ++c) {
+                    if (gi[c] < 0) continue;
+                    if (a != 4 && c != 4) qg[a][c] += dt * scb * scb + dt * dt * dt * srw * srw;   // :110
+                    else if (a == 4 && c == 4) qg[a][c] += dt * srw * srw;                         // :112
+                    else qg[a][c] += dt * dt * srw * srw;                                          // :114
+                }
+            }
+        }
+        for (int a = 0; a < 5; ++a) {
+            if (loc[a] < 0) continue;
+            sPhiA[loc[a] * NA_MAX + loc[a]] = 1.0;
+            if (a < 4 && has_fs) sPhiA[loc[a] * NA_MAX + loc[4]] = T;
+            for (int c = 0; c < 5; ++c) if (loc[c] >= 0) sQA[loc[a] * NA_MAX + loc[c]] = qg[a][c];
+        }
+    }
+    __syncthreads();
+    const int na = sNA;
+    // strip rows outside A
+    const int r = blockIdx.x * PROP_THREADS + tid;
+    bool inA = r < 15;
+    for (int a = 15; a < na; ++a) inA |= (sA[a] == r);
+    if (r < n && !inA) {
+        double s[NA_MAX], o[NA_MAX];
+#pragma unroll
+        for (int a = 0; a < NA_MAX; ++a) s[a] = (a < na) ? P[r + (size_t)sA[a] * ld] : 0.0;
+#pragma unroll
+        for (int a = 0; a < NA_MAX; ++a) {
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < NA_MAX; ++c) acc += s[c] * sPhiA[a * NA_MAX + c];
+            o[a] = acc;
+        }
+#pragma unroll
+        for (int a = 0; a < NA_MAX; ++a) if (a < na) {
+            P[r + (size_t)sA[a] * ld] = o[a];
+            P[sA[a] + (size_t)r * ld] = o[a];        // :89 upper strip = transpose
+        }
+    }
+    // A x A block, tile 0 only
+    if (blockIdx.x == 0) {
+        for (int e = tid; e < na * na; e += PROP_THREADS) {
+            const int a = e / na, c = e % na;
+            sX[a * NA_MAX + c] = P[sA[a] + (size_t)sA[c] * ld];
+        }
+        __syncthreads();
+        for (int e = tid; e < na * na; e += PROP_THREADS) {
+            const int a = e / na, c = e % na;
+            double acc = 0.0;
+            for (int l = 0; l < na; ++l) acc += sPhiA[a * NA_MAX + l] * sX[l * NA_MAX + c];
+            sY[a * NA_MAX + c] = acc;
+        }
+        __syncthreads();
+        for (int e = tid; e < na * na; e += PROP_THREADS) {
+            const int a = e / na, c = e % na;
+            double acc = 0.0;
+            for (int l = 0; l < na; ++l) acc += sY[a * NA_MAX + l] * sPhiA[c * NA_MAX + l];
+            sX[a * NA_MAX + c] = acc + sQA[a * NA_MAX + c];
+        }
+        __syncthreads();
+        for (int e = tid; e < na * na; e += PROP_THREADS) {
+            const int a = e / na, c = e % na;
+            P[sA[a] + (size_t)sA[c] * ld] = 0.5 * (sX[a * NA_MAX + c] + sX[c * NA_MAX + a]);   // :118
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: StateManager::augmentSlidingWindowPose covariance part (StateManager.cpp:279-293).
+// One workgroup per filter; the 6 new rows/cols are J*P[0:21,:], read through the symmetric
+// counterpart P[c, 0:21] so consecutive lanes read consecutive addresses.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_augment(CovView cv, int b0, const double* __restrict__ Rs)
+{
+    const int bl = blockIdx.x, b = b0 + bl, tid = threadIdx.x;
+    const int n = cv.n[b], ld = cv.ldp;
+    double* P = cov_ptr(cv, b);
+    __shared__ double sJP[6][21];
+    double R[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = Rs[bl * 9 + i];
+    for (int c = tid; c < n; c += 256) {
+        double e[6], q[6], jp[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { e[j] = P[c + (size_t)j * ld]; q[j] = P[c + (size_t)(15 + j) * ld]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            jp[i] = e[i] + R[3 * i] * q[0] + R[3 * i + 1] * q[1] + R[3 * i + 2] * q[2];
+            jp[3 + i] = e[3 + i] + R[3 * i] * q[3] + R[3 * i + 1] * q[4] + R[3 * i + 2] * q[5];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            P[c + (size_t)(n + i) * ld] = jp[i];
+            P[(n + i) + (size_t)c * ld] = jp[i];
+            if (c < 21) sJP[i][c] = jp[i];
+        }
+    }
+    __syncthreads();
+    if (tid < 36) {
+        const int i = tid / 6, i2 = tid % 6;
+        auto X = [&](int a, int c) {            // (J P J^T)[a][c] = JP[a][:21] . J[c][:]
+            const int off = c < 3 ? 15 : 18, rr = c % 3;
+            return sJP[a][c] + R[3 * rr] * sJP[a][off] + R[3 * rr + 1] * sJP[a][off + 1] + R[3 * rr + 2] * sJP[a][off + 2];
+        };
+        P[(n + i) + (size_t)(n + i2) * ld] = 0.5 * (X(i, i2) + X(i2, i));      // :293
+    }
+    __syncthreads();
+    if (tid == 0) cv.n[b] = n + 6;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K12: StateManager::marginalize covariance part (StateManager.cpp:163-177), out of place into
+// the filter's other ping-pong buffer; k_post then flips `cur` and shrinks n.  grid = (col tiles, nb)
+// ---------------------------------------------------------------------------------------------
+#define MARG_COLS 8
+__global__ __launch_bounds__(256) void k_marginalize(CovView cv, int b0, const int* __restrict__ idxs, int size)
+{
+    const int bl = blockIdx.y, b = b0 + bl, tid = threadIdx.x;
+    const int idx = idxs[bl];
+    if (idx < 0) return;
+    const int n = cv.n[b], ld = cv.ldp, nn = n - size;
+    const double* src = cov_ptr(cv, b);
+    double* dst = cov_alt_ptr(cv, b);
+    for (int jj = 0; jj < MARG_COLS; ++jj) {
+        const int j = blockIdx.x * MARG_COLS + jj;
+        if (j >= nn) break;
+        const int sj = j < idx ? j : j + size;
+        for (int i = tid; i < nn; i += 256) {
+            const int si = i < idx ? i : i + size;
+            dst[i + (size_t)j * ld] = src[si + (size_t)sj * ld];
+        }
+    }
+}
+
+__global__ void k_post_marg(CovView cv, int b0, int nb, const int* __restrict__ idxs, int size)
+{
+    const int bl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bl >= nb) return;
+    if (idxs[bl] < 0) return;
+    const int b = b0 + bl;
+    cv.cur[b] ^= 1;
+    cv.n[b] -= size;
+}
+
+// StateManager::addVariableIndependent (StateManager.cpp:194-214). One workgroup per filter.
+__global__ __launch_bounds__(256) void k_append(CovView cv, int b0, int size, const double* __restrict__ blk)
+{
+    const int bl = blockIdx.x, b = b0 + bl, tid = threadIdx.x;
+    const int n = cv.n[b], ld = cv.ldp;
+    double* P = cov_ptr(cv, b);
+    for (int e = tid; e < (n + size) * size; e += 256) {
+        const int c = e / size, j = e % size;
+        P[c + (size_t)(n + j) * ld] = 0.0;
+        P[(n + j) + (size_t)c * ld] = 0.0;
+    }
+    __syncthreads();
+    for (int e = tid; e < size * size; e += 256) {
+        const int i = e % size, j = e / size;
+        P[(n + i) + (size_t)(n + j) * ld] = blk[(size_t)bl * size * size + e];
+    }
+    __syncthreads();
+    if (tid == 0) cv.n[b] = n + size;
+}
+
+// device-to-device snapshot of n / cur (the covariances are copied with hipMemcpyAsync)
+__global__ void k_copy_ints(int* dst, const int* src, int count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = src[i];
+}
+
+// snapshot / restore of every filter's live covariance (benchmark hygiene: each timed step starts
+// from the same prior).  grid = (col tiles, B).
+__global__ __launch_bounds__(256) void k_snapshot(CovView cv, double* __restrict__ snap, int* __restrict__ n_snap)
+{
+    const int b = blockIdx.y, tid = threadIdx.x, n = cv.n[b], ld = cv.ldp;
+    const double* src = cov_ptr(cv, b);
+    double* dst = snap + (size_t)b * ld * ld;
+    for (int jj = 0; jj < MARG_COLS; ++jj) {
+        const int j = blockIdx.x * MARG_COLS + jj;
+        if (j >= n) break;
+        for (int i = tid; i < n; i += 256) dst[i + (size_t)j * ld] = src[i + (size_t)j * ld];
+    }
+    if (blockIdx.x == 0 && tid == 0) n_snap[b] = n;
+}
+__global__ __launch_bounds__(256) void k_restore(CovView cv, const double* __restrict__ snap, const int* __restrict__ n_snap)
+{
+    const int b = blockIdx.y, tid = threadIdx.x, n = n_snap[b], ld = cv.ldp;
+    const double* src = snap + (size_t)b * ld * ld;
+    double* dst = cv.Pbase + (size_t)b * ld * ld;          // half 0
+    for (int jj = 0; jj < MARG_COLS; ++jj) {
+        const int j = blockIdx.x * MARG_COLS + jj;
+        if (j >= n) break;
+        for (int i = tid; i < n; i += 256) dst[i + (size_t)j * ld] = src[i + (size_t)j * ld];
+    }
+}
+__global__ void k_post_restore(CovView cv, const int* __restrict__ n_snap)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < cv.B) { cv.cur[b] = 0; cv.n[b] = n_snap[b]; }
+}
+
+// ---------------------------------------------------------------------------------------------
+#include "launch_ekf.h"
+void launch_propagate(CovView cv, int b0, int nb, int n_cap, const double* Phi, const double* G, const double* dt, int k,
+                      const int* gnss_idx, const double sigma[4], int enable_gnss, double scb, double srw, hipStream_t st)
+{
+    const int tiles = (n_cap + PROP_THREADS - 1) / PROP_THREADS;
+    hipLaunchKernelGGL(k_propagate, dim3(tiles, nb), dim3(PROP_THREADS), 0, st, cv, b0, Phi, G, dt, k, gnss_idx,
+                       sigma[0], sigma[1], sigma[2], sigma[3], enable_gnss, scb, srw);
+}
+void launch_augment(CovView cv, int b0, int nb, const double* R, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_augment, dim3(nb), dim3(256), 0, st, cv, b0, R);
+}
+void launch_marginalize(CovView cv, int b0, int nb, int n_cap, const int* idx, int size, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_marginalize, dim3((n_cap + MARG_COLS - 1) / MARG_COLS, nb), dim3(256), 0, st, cv, b0, idx, size);
+    hipLaunchKernelGGL(k_post_marg, dim3((nb + 255) / 256), dim3(256), 0, st, cv, b0, nb, idx, size);
+}
+void launch_append(CovView cv, int b0, int nb, int size, const double* blk, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_append, dim3(nb), dim3(256), 0, st, cv, b0, size, blk);
+}
+void launch_copy_ints(int* dst, const int* src, int count, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_copy_ints, dim3((count + 255) / 256), dim3(256), 0, st, dst, src, count);
+}
+void launch_snapshot(CovView cv, int n_cap, double* snap, int* n_snap, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_snapshot, dim3((n_cap + MARG_COLS - 1) / MARG_COLS, cv.B), dim3(256), 0, st, cv, snap, n_snap);
+}
+void launch_restore(CovView cv, int n_cap, const double* snap, const int* n_snap, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_restore, dim3((n_cap + MARG_COLS - 1) / MARG_COLS, cv.B), dim3(256), 0, st, cv, snap, n_snap);
+    hipLaunchKernelGGL(k_post_restore, dim3((cv.B + 255) / 256), dim3(256), 0, st, cv, n_snap);
+}

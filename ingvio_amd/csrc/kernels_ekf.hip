@@ -1,0 +1,225 @@
+// kernels_ekf.hip — K8-K11: StateManager::ekfUpdate (StateManager.cpp:359-423) and
+// UpdateBase::whitenResidual (Update.cpp:36-79).
+//
+//   k_ekf_core  (one workgroup per filter):  PH^T = P[:, cols] H^T  (K8, :381-397)
+//                                            S = H Pcc H^T + R      (K9, :399-403) in LDS
+//                                            Cholesky S = L L^T, Y = PH^T L^-T, z = L^-1 res
+//                                            dx = Y z (= K res, :423)
+//   k_downdate  (MFMA FP64 16x16x4 tiles):   P <- P - Y Y^T  (= P - K (PH^T)^T, :407-411), lower
+//                                            tiles computed once and mirrored, which is the
+//                                            reference's 0.5 (P + P^T) without a second pass.
+// S is SPD (R is positive definite), so Cholesky + triangular solves give the same K as the
+// reference's general LU `S.inverse()`.  gfx950 only.
+#include "dev_common.h"
+#include "launch_ekf.h"
+
+#define EKF_THREADS 512
+#define IB 16
+
+__global__ __launch_bounds__(EKF_THREADS) void k_ekf_core(
+    CovView cv, int b0, const double* __restrict__ Hall, const double* __restrict__ res_all,
+    const int* __restrict__ colmap_all, const int* __restrict__ m_all, const int* __restrict__ nc_all,
+    const double* __restrict__ noise_all, int r_kind, int mld, int hstride, int cstride, int nstride,
+    double* __restrict__ Yall, int ystride, double* __restrict__ dx_all, int* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* sS = reinterpret_cast<double*>(smem_raw);
+    const int bl = blockIdx.x, b = b0 + bl, tid = threadIdx.x;
+    const int m = m_all[bl], nc = nc_all[bl];
+    const int n = cv.n[b], ld = cv.ldp;
+    double* dx = dx_all + (size_t)b * ld;
+    if (m == 0) {
+        for (int r = tid; r < n; r += EKF_THREADS) dx[r] = 0.0;
+        return;
+    }
+    const double* P = cov_ptr(cv, b);
+    const double* H = Hall + (size_t)bl * hstride;
+    const double* res = res_all + (size_t)bl * mld;
+    const int* cm = colmap_all + (size_t)bl * cstride;
+    const double* noise = noise_all + (size_t)bl * nstride;
+    double* Y = Yall + (size_t)bl * ystride;
+    const int LS = m + 1;
+    int* sCol = reinterpret_cast<int*>(sS + (size_t)(m + 1) * LS);
+
+    for (int c = tid; c < nc; c += EKF_THREADS) sCol[c] = cm[c];
+    __syncthreads();
+    // ---- K8: PH^T -> Y (n x m, column-major, ld) ------------------------------------------
+    for (int r = tid; r < n; r += EKF_THREADS) {
+        for (int ib = 0; ib < m; ib += IB) {
+            double acc[IB];
+#pragma unroll
+            for (int ii = 0; ii < IB; ++ii) acc[ii] = 0.0;
+            for (int c = 0; c < nc; ++c) {
+                const double p = P[r + (size_t)sCol[c] * ld];
+                const double* hc = H + (size_t)c * mld + ib;      // rows ib.. of column c (zero padded to mld)
+#pragma unroll
+                for (int ii = 0; ii < IB; ++ii) acc[ii] += p * hc[ii];
+            }
+#pragma unroll
+            for (int ii = 0; ii < IB; ++ii) if (ib + ii < m) Y[r + (size_t)(ib + ii) * ld] = acc[ii];
+        }
+    }
+    __syncthreads();
+    // ---- K9: S = H * PHT[cols, :] + R, lower triangle, bordered by res ---------------------
+    for (int e = tid; e < m * m; e += EKF_THREADS) {
+        const int i = e % m, i2 = e / m;
+        if (i < i2) continue;
+        double acc = 0.0;
+        for (int c = 0; c < nc; ++c) acc += H[i + (size_t)c * mld] * Y[sCol[c] + (size_t)i2 * ld];
+        if (r_kind == 0) { if (i == i2) acc += noise[0]; }
+        else if (r_kind == 1) { if (i == i2) acc += noise[i]; }
+        else acc += noise[i + (size_t)i2 * m];
+        sS[i * LS + i2] = acc;
+    }
+    for (int e = tid; e <= m; e += EKF_THREADS) sS[m * LS + e] = (e < m) ? res[e] : 0.0;
+    __syncthreads();
+    // ---- right-looking elimination (unscaled columns), one barrier per column --------------
+    for (int j = 0; j < m; ++j) {
+        const double inv = 1.0 / sS[j * LS + j];
+        const int w = m - j;
+        for (int e = tid; e < w * w; e += EKF_THREADS) {
+            const int i = j + 1 + e % w, k = j + 1 + e / w;
+            if (k > i) continue;
+            sS[i * LS + k] -= sS[i * LS + j] * sS[k * LS + j] * inv;
+        }
+        __syncthreads();
+    }
+    // scale: L[i][j] = S^(j)[i][j] / sqrt(S^(j)[j][j]);  row m becomes z = L^-1 res
+    bool bad = false;
+    for (int e = tid; e < (m + 1) * m; e += EKF_THREADS) {
+        const int i = e / m, j = e % m;
+        if (i <= j) continue;
+        const double d = sS[j * LS + j];
+        if (!(d > 0.0)) bad = true;
+        sS[i * LS + j] = sS[i * LS + j] / sqrt(d);
+    }
+    __syncthreads();
+    for (int j = tid; j < m; j += EKF_THREADS) sS[j * LS + j] = sqrt(sS[j * LS + j]);
+    __syncthreads();
+    if (bad) atomicOr(&status[b], 4);
+    // ---- Y = PHT L^-T (row-wise forward substitution), dx = Y z -----------------------------
+    for (int r = tid; r < n; r += EKF_THREADS) {
+        double d = 0.0;
+        for (int j = 0; j < m; ++j) {
+            double x = Y[r + (size_t)j * ld];
+            for (int k = 0; k < j; ++k) x -= sS[j * LS + k] * Y[r + (size_t)k * ld];
+            x /= sS[j * LS + j];
+            Y[r + (size_t)j * ld] = x;
+            d += x * sS[m * LS + j];
+        }
+        dx[r] = d;
+        for (int j = m; j < ((m + 3) & ~3); ++j) Y[r + (size_t)j * ld] = 0.0;      // pad K dim for MFMA
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K10: P <- P - Y Y^T with v_mfma_f64_16x16x4_f64.  One wave per 16x16 tile of the lower
+// triangle; A[i][k] = Y[ri+i][k], B[k][j] = Y[rj+j][k] are read straight from L2 (Y is N x m,
+// <= 130 KB per filter).  f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg.
+// ---------------------------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_downdate(CovView cv, int b0, const double* __restrict__ Yall,
+                                                  const int* __restrict__ m_all, int ystride, int* __restrict__ status)
+{
+    const int bl = blockIdx.y, b = b0 + bl;
+    const int m = m_all[bl];
+    if (m == 0) return;
+    const int n = cv.n[b], ld = cv.ldp;
+    const int nt = (n + 15) >> 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= nt * (nt + 1) / 2) return;
+    int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    double* P = cov_ptr(cv, b);
+    const double* Y = Yall + (size_t)bl * ystride;
+    const int ra = ti * 16 + (lane & 15), rb = tj * 16 + (lane & 15), kq = lane >> 4;
+    const bool va = ra < n, vb = rb < n;
+    double4_t acc = { 0.0, 0.0, 0.0, 0.0 };
+    const int mp = (m + 3) & ~3;
+    for (int k0 = 0; k0 < mp; k0 += 4) {
+        const double a = va ? Y[ra + (size_t)(k0 + kq) * ld] : 0.0;
+        const double bb = vb ? Y[rb + (size_t)(k0 + kq) * ld] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+    }
+    const int col = tj * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = ti * 16 + (lane >> 4) + 4 * r;
+        if (row < n && col < n && row >= col) {
+            // read through the mirrored (coalesced) address; P is symmetric on entry
+            const double v = P[col + (size_t)row * ld] - acc[r];
+            P[col + (size_t)row * ld] = v;
+            P[row + (size_t)col * ld] = v;
+            if (row == col && v < 0.0) atomicOr(&status[b], 2);          // StateManager.cpp:413-421
+        }
+    }
+}
+
+// whitenResidual for small blocks (GNSS per-row / block gating): one workgroup, m <= 32.
+__global__ __launch_bounds__(256) void k_gamma(CovView cv, int b, const double* __restrict__ H, const double* __restrict__ res,
+                                               const int* __restrict__ colmap, int m, int nc, const double* __restrict__ noise,
+                                               int r_kind, int mld, double* __restrict__ gamma_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* sT = reinterpret_cast<double*>(smem_raw);          // nc x m : Pcc H^T
+    double* sS = sT + (size_t)nc * m;                           // (m+1) x (m+1)
+    const int tid = threadIdx.x, ld = cv.ldp, LS = m + 1;
+    const double* P = cov_ptr(cv, b);
+    for (int e = tid; e < nc * m; e += 256) {
+        const int c = e % nc, i = e / nc;
+        double acc = 0.0;
+        for (int c2 = 0; c2 < nc; ++c2) acc += P[colmap[c] + (size_t)colmap[c2] * ld] * H[i + (size_t)c2 * mld];
+        sT[c + (size_t)i * nc] = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < m * m; e += 256) {
+        const int i = e % m, i2 = e / m;
+        if (i < i2) continue;
+        double acc = 0.0;
+        for (int c = 0; c < nc; ++c) acc += H[i + (size_t)c * mld] * sT[c + (size_t)i2 * nc];
+        if (r_kind == 0) { if (i == i2) acc += noise[0]; }
+        else if (r_kind == 1) { if (i == i2) acc += noise[i]; }
+        else acc += noise[i + (size_t)i2 * m];
+        sS[i * LS + i2] = acc;
+    }
+    for (int e = tid; e <= m; e += 256) sS[m * LS + e] = (e < m) ? res[e] : 0.0;
+    __syncthreads();
+    for (int j = 0; j < m; ++j) {
+        const double inv = 1.0 / sS[j * LS + j];
+        const int w = m - j;
+        for (int e = tid; e < w * w; e += 256) {
+            const int i = j + 1 + e % w, k = j + 1 + e / w;
+            if (k > i) continue;
+            sS[i * LS + k] -= sS[i * LS + j] * sS[k * LS + j] * inv;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *gamma_out = -sS[m * LS + m];
+}
+
+void launch_ekf_core(const EkfLaunch& L, hipStream_t st)
+{
+    const size_t sm = sizeof(double) * (size_t)(L.m_cap + 1) * (L.m_cap + 1) + sizeof(int) * (size_t)L.nc_cap + 16;
+    hipFuncSetAttribute((const void*)k_ekf_core, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(k_ekf_core, dim3(L.nb), dim3(EKF_THREADS), sm, st, L.cv, L.b0, L.H, L.res, L.colmap, L.m, L.nc,
+                       L.noise, L.r_kind, L.mld, L.hstride, L.cstride, L.nstride, L.Y, L.ystride, L.dx, L.status);
+}
+
+void launch_downdate(const EkfLaunch& L, int n_cap, hipStream_t st)
+{
+    const int nt = (n_cap + 15) / 16;
+    const int tiles = nt * (nt + 1) / 2;
+    hipLaunchKernelGGL(k_downdate, dim3((tiles + 3) / 4, L.nb), dim3(256), 0, st, L.cv, L.b0, L.Y, L.m, L.ystride, L.status);
+}
+
+void launch_gamma(CovView cv, int b, const double* H, const double* res, const int* colmap, int m, int nc,
+                  const double* noise, int r_kind, int mld, double* gamma_out, hipStream_t st)
+{
+    const size_t sm = sizeof(double) * ((size_t)nc * m + (size_t)(m + 1) * (m + 1));
+    hipFuncSetAttribute((const void*)k_gamma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(k_gamma, dim3(1), dim3(256), sm, st, cv, b, H, res, colmap, m, nc, noise, r_kind, mld, gamma_out);
+}

@@ -1,0 +1,35 @@
+// launch_ekf.h — host-side launch descriptors of kernels_ekf.hip / kernels_cov.hip.
+#pragma once
+#include "dev_common.h"
+
+struct EkfLaunch {
+    CovView cv;
+    int b0, nb;
+    const double* H;        // [nb][hstride], column-major ld = mld
+    const double* res;      // [nb][mld]
+    const int* colmap;      // [nb][cstride]
+    const int* m;           // [nb]
+    const int* nc;          // [nb]
+    const double* noise;    // [nb][nstride]
+    int r_kind, mld, hstride, cstride, nstride;
+    double* Y;              // [nb][ystride]
+    int ystride;
+    double* dx;             // [B][ldp]
+    int* status;            // [B]
+    int m_cap, nc_cap;      // LDS sizing
+};
+
+void launch_ekf_core(const EkfLaunch& L, hipStream_t st);
+void launch_downdate(const EkfLaunch& L, int n_cap, hipStream_t st);
+void launch_gamma(CovView cv, int b, const double* H, const double* res, const int* colmap, int m, int nc,
+                  const double* noise, int r_kind, int mld, double* gamma_out, hipStream_t st);
+
+// kernels_cov.hip
+void launch_propagate(CovView cv, int b0, int nb, int n_cap, const double* Phi, const double* G, const double* dt, int k,
+                      const int* gnss_idx, const double sigma[4], int enable_gnss, double scb, double srw, hipStream_t st);
+void launch_augment(CovView cv, int b0, int nb, const double* R, hipStream_t st);
+void launch_marginalize(CovView cv, int b0, int nb, int n_cap, const int* idx, int size, hipStream_t st);
+void launch_append(CovView cv, int b0, int nb, int size, const double* blk, hipStream_t st);
+void launch_copy_ints(int* dst, const int* src, int count, hipStream_t st);
+void launch_snapshot(CovView cv, int n_cap, double* snap, int* n_snap, hipStream_t st);
+void launch_restore(CovView cv, int n_cap, const double* snap, const int* n_snap, hipStream_t st);
