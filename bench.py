@@ -1,0 +1,313 @@
+#!/usr/bin/env python3
+"""bench.py — EKF updates/s on synthetic stereo MSCKF frames (BASELINE.json metric).
+
+One *step* = one pass of the hot path over one batch: every filter of the batch does
+k=10-step covariance propagation (K1) + clone augmentation (K2) + 150-feature MSCKF update
+(Jacobians K3, nullspace K4, chi^2 gate K5, TSQR compression K6/K7, Kalman update K8-K11) +
+marginalisation of the oldest clone (K12) — SURVEY.md §8(d) "one update".  Inputs (IMU transitions,
+clone poses, feature tracks, the prior covariances) are resident in HBM before the timed region;
+each step restores the same prior device-to-device so the work per step is stationary.
+
+N = 1 workload: BASELINE.json configs[1] (150 feats x 11 clones, N = 249), `--batch` independent
+filters per GPU (default 512 = configs[3]'s 4096 frames / 8 GPUs).  N > 1: weak scaling, each rank
+owns its own `--batch` filters, no data-path collective; RCCL only for the timing
+barrier / max and one end-of-run gather of per-rank summaries.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector == FP64 MFMA peak (datasheet)
+HBM_PEAK_GBS = 8000.0
+
+
+class LazyCov:
+    """Index bookkeeping + deferred covariance ops so that `synth.Filter` can drive B filters in
+    lockstep and the arithmetic is done by ONE batched C-ABI call per stage.  While `host_init`
+    is set, append_independent assembles the block-diagonal prior on the host (data assembly only)."""
+
+    def __init__(self, P):
+        self.M = np.array(P, dtype=np.float64)
+        self.n = self.M.shape[0]
+        self.host_init = True
+        self.pending_steps = None
+        self.pending_R = None
+
+    def append_independent(self, blk):
+        assert self.host_init
+        n, s = self.n, blk.shape[0]
+        M = np.zeros((n + s, n + s)); M[:n, :n] = self.M; M[n:, n:] = blk
+        self.M = M; self.n = n + s
+        return n
+
+    def propagate(self, Phi, G, dt, *a, **k):
+        self.pending_steps.append((Phi, G, dt))
+
+    def augment(self, R):
+        self.pending_R = np.array(R)
+        self.n += 6
+        return self.n - 6
+
+
+def build_batch(ctx, B, seed0, F, C, n_gnss, n_landmarks):
+    """Creates B config-2 cases; priors are produced by the HIP path itself (batched propagate+clone)."""
+    from ingvio_amd import host, synth
+    pr = synth.PARAMS
+    filters, rngs = [], []
+    for b in range(B):
+        rng = np.random.default_rng(0x1A6F10 + seed0 + b)
+        flt = synth.Filter(LazyCov, host.imu_transition, t0=0.1 * ((seed0 + b) % 997), n_gnss=n_gnss, n_landmarks=n_landmarks)
+        flt.cov.host_init = False
+        ctx.cov_set(b, flt.cov.M)
+        filters.append(flt); rngs.append(rng)
+    sigma = filters[0].sigma()
+    for cyc in range(C - 1):
+        Phi = np.zeros((B, synth.IMU_PER_FRAME, 15, 15)); G = np.zeros((B, synth.IMU_PER_FRAME, 15, 12))
+        dt = np.zeros((B, synth.IMU_PER_FRAME)); R = np.zeros((B, 3, 3)); gi = np.zeros((B, 5), dtype=np.int32)
+        for b, flt in enumerate(filters):
+            flt.cov.pending_steps = []
+            flt.propagate_cov(flt.imu_steps(rngs[b]))
+            for s, (p, g, d) in enumerate(flt.cov.pending_steps):
+                Phi[b, s], G[b, s], dt[b, s] = p, g, d
+            flt.clone()
+            R[b] = flt.cov.pending_R
+            gi[b] = flt.gnss_idx
+        ctx.propagate(0, Phi, G, dt, sigma, filters[0].enable_gnss, gi if filters[0].enable_gnss else None,
+                      pr["sigma_cb"], pr["sigma_rw"], fused=True)
+        idx = ctx.augment(0, R)
+        assert all(int(idx[b]) == filters[b].cov.n - 6 for b in range(B))
+    steps, frames, infos = [], [], []
+    table = synth.chi2_table()
+    Rlr, tlr = synth.t_cl2cr()
+    for b, flt in enumerate(filters):
+        rng = rngs[b]
+        flt.cov.pending_steps = []
+        st = flt.imu_steps(rng)
+        t_new = flt.t
+        clone_times = [c["t"] for c in flt.clones] + [t_new]
+        step = flt.step_dict(st, marg_name=flt.clones[0]["name"])
+        new_idx = flt.cov.n
+        pf, uv, outlier = synth.make_features(rng, clone_times, F)
+        clones = flt.clones + [dict(R=flt.R @ synth.R_CL2I, p=flt.p + flt.R @ synth.T_CL2I)]
+        frames.append(dict(
+            clone_idx=np.array([flt.idx_of(c["name"]) for c in flt.clones] + [new_idx], dtype=np.int32),
+            clone_R=np.stack([c["R"] for c in clones]), clone_p=np.stack([c["p"] for c in clones]), pf=pf,
+            anchor=np.zeros(F, dtype=np.int32), obs_mask=np.full(F, (1 << C) - 1, dtype=np.uint64), uv=uv,
+            dof=np.full(F, C - 1, dtype=np.int32), stereo=1, R_cl2cr=Rlr, t_cl2cr=tlr, noise=pr["visual_noise"],
+            chi2_table=table))
+        steps.append(step)
+        infos.append(dict(outlier=outlier, n_prior=flt.cov.n))
+    return filters, steps, frames, infos
+
+
+def algorithmic_flops(F_used, F, C, N, k):
+    """SURVEY.md §8(d) formula block, per update, split by the kernel that carries the term."""
+    n = 6 * C; rho = 4 * C - 3; m = F_used * rho
+    k4 = 12.0 * (4 * C) * (n + 1)
+    k5 = 2.0 * rho * n * n + 2.0 * rho * rho * n + rho ** 3 / 3.0 + 2.0 * rho * rho
+    k7 = 2.0 * m * n * n - (2.0 / 3.0) * n ** 3 + 4.0 * m * n
+    k8_9_11 = 2.0 * N * n * n + 2.0 * n ** 3 + n ** 3 / 3.0 + 2.0 * N * n * n + 2.0 * N * n
+    k10 = 2.0 * N * N * n
+    k1 = k * (2.0 * 15 * 15 * (N - 15) + 4.0 * 15 ** 3)
+    k2 = 2.0 * 6 * 21 * N
+    per_kernel = {
+        "k_propagate": k1, "k_augment": k2, "k_msckf_gate": F * (k4 + k5), "k_msckf_fold": F_used * k4 + k7,
+        "k_msckf_merge": 0.0, "k_ekf_core": k8_9_11, "k_downdate": k10, "k_marginalize": 0.0, "restore": 0.0}
+    total = F * (k4 + k5) + k7 + k8_9_11 + k10 + k1 + k2
+    return per_kernel, total
+
+
+def algorithmic_bytes(N):
+    """HBM-bound strip kernels: bytes each must move once (FP64)."""
+    return {"k_propagate": 2 * 2 * 20 * N * 8.0, "k_augment": (12 + 2 * 6) * N * 8.0, "k_marginalize": 2.0 * N * N * 8,
+            "restore": 2.0 * N * N * 8}
+
+
+def cpu_baseline(ctx, steps, frames, n_prior, target_s=12.0):
+    """Times the oracle (C port of the reference algorithm, OpenMP one-filter-per-thread) on a
+    bounded sample of the same workload, and cross-checks the GPU posterior on that sample."""
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    S = min(len(steps), cores)
+    ld = 256
+    ctx.restore(); ctx.sync()
+    P0 = np.zeros((S, ld, ld))
+    for b in range(S):
+        P0[b, :n_prior, :n_prior] = ctx.cov_get(b)
+    n0 = np.full(S, n_prior, dtype=np.int32)
+    # warm-up + timed rounds
+    orc.frame_update_batch(P0.copy(), n0, ld, steps[:S], frames[:S], threads=cores, max_accept=0, compress_rule=1)
+    rounds, t0 = 0, time.perf_counter()
+    while True:
+        P1, n1, dx1, acc1 = orc.frame_update_batch(P0.copy(), n0, ld, steps[:S], frames[:S], threads=cores,
+                                                   max_accept=0, compress_rule=1)
+        rounds += 1
+        el = time.perf_counter() - t0
+        if el >= target_s or rounds >= 200:
+            break
+    # 1-thread figure on a few frames (the reference itself is single-threaded)
+    s1 = min(S, 4)
+    t1 = time.perf_counter()
+    orc.frame_update_batch(P0[:s1].copy(), n0[:s1], ld, steps[:s1], frames[:s1], threads=1, max_accept=0, compress_rule=1)
+    one = (time.perf_counter() - t1) / s1
+    return dict(value=rounds * S / el, unit="updates/s", cores=cores, kind="port",
+                sample="%d rounds x %d of the bench's own frames (150 feats x 11 clones, top_n compression), "
+                       "oracle/ingvio_oracle.c with OpenMP one-filter-per-thread; 1-thread: %.1f ms/update"
+                       % (rounds, S, one * 1e3),
+                ms_per_update_1thread=one * 1e3), (P1, n1, dx1, acc1, S)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=512, help="independent filters per GPU")
+    ap.add_argument("--feats", type=int, default=150)
+    ap.add_argument("--clones", type=int, default=11)
+    ap.add_argument("--literal", action="store_true", help="N=87 (no GNSS / landmark padding) instead of N=249")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from ingvio_amd import capi
+    B, F, C = args.batch, args.feats, args.clones
+    n_gnss, n_lm = (0, 0) if args.literal else (6, 52)
+    N = 21 + n_gnss + 3 * n_lm + 6 * C
+    ctx = capi.Context(batch=B, n_max=((N + 15) // 16) * 16, c_max=C, f_max=F, m_max=64, device=local_rank)
+    t_build = time.perf_counter()
+    filters, steps, frames, infos = build_batch(ctx, B, rank * B, F, C, n_gnss, n_lm)
+    ctx.snapshot()
+    from ingvio_amd import synth
+    pr = synth.PARAMS
+    ctx.frame_stage(0, steps, frames, filters[0].sigma(), filters[0].enable_gnss, pr["sigma_cb"], pr["sigma_rw"],
+                    max_accept=0, compress_rule=1)
+    ctx.sync()
+    t_build = time.perf_counter() - t_build
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.frame_run(restore_prior=True)
+    barrier()
+    ctx.profile_reset()
+    ctx.profile_enable(not args.no_profile)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.frame_run(restore_prior=True)
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    prof = ctx.profile_get()
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
+        elapsed = float(t.item())
+
+    dx, acc, rows = ctx.frame_fetch()
+    n_acc = acc[:, :F].sum(axis=1)
+    ok = bool(np.isfinite(dx).all() and (rows == 6 * C).all())
+    if dist is not None:      # one end-of-run gather of per-rank summaries
+        import torch
+        summ = torch.tensor([float(n_acc.sum()), float(np.abs(dx).sum()), float(ok)], device="cuda", dtype=torch.float64)
+        outl = [torch.zeros_like(summ) for _ in range(world)]
+        dist.all_gather(outl, summ)
+        torch.cuda.synchronize()
+        ok = all(bool(o[2].item()) for o in outl)
+
+    if rank == 0:
+        F_used = float(n_acc.mean())
+        per_kernel, total_flops = algorithmic_flops(F_used, F, C, N, synth.IMU_PER_FRAME)
+        bytes_k = algorithmic_bytes(N)
+        kernels = {}
+        dom, dom_ms = None, -1.0
+        for name, (ms, calls) in prof.items():
+            if calls == 0:
+                continue
+            avg = ms / calls
+            e = dict(avg_ms=avg, calls=calls)
+            if per_kernel.get(name, 0.0) > 0:
+                e["algorithmic_flops_per_launch"] = per_kernel[name] * B
+                e["tflops"] = per_kernel[name] * B / (avg * 1e-3) / 1e12
+                e["frac_fp64_peak"] = e["tflops"] / FP64_PEAK_TFLOPS
+            if name in bytes_k:
+                e["algorithmic_bytes_per_launch"] = bytes_k[name] * B
+                e["gbs"] = bytes_k[name] * B / (avg * 1e-3) / 1e9
+                e["frac_hbm_peak"] = e["gbs"] / HBM_PEAK_GBS
+            kernels[name] = e
+            if avg > dom_ms and (per_kernel.get(name, 0.0) > 0 or name in bytes_k):
+                dom, dom_ms = name, avg
+        roofline = None
+        if dom is not None:
+            if per_kernel.get(dom, 0.0) > 0:
+                a = kernels[dom]["tflops"]
+                roofline = dict(kernel=dom, bound="mfma", achieved=a, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
+                                frac=a / FP64_PEAK_TFLOPS, traffic=None, avg_launch_ms=dom_ms,
+                                note="FP64: vector and MFMA peaks coincide on MI355X (78.6 TFLOP/s); algorithmic "
+                                     "FLOPs per SURVEY.md 8(d) x filters per launch")
+            elif dom in bytes_k:
+                a = kernels[dom]["gbs"]
+                roofline = dict(kernel=dom, bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
+                                frac=a / HBM_PEAK_GBS, traffic=None, avg_launch_ms=dom_ms)
+        cpu, parity = None, None
+        if world == 1 and not args.no_cpu:
+            cpu, (P1, n1, dx1, acc1, S) = cpu_baseline(ctx, steps, frames, infos[0]["n_prior"])
+            ctx.frame_run(restore_prior=True)
+            dxg, accg, rowsg = ctx.frame_fetch(0, S)
+            errs = []
+            for b in range(S):
+                Pg = ctx.cov_get(b); nb = Pg.shape[0]
+                Po = P1[b, :nb, :nb]
+                errs.append(float(np.linalg.norm(Pg - Po) / np.linalg.norm(Po)))
+            parity = dict(sample=S, max_rel_cov_err=max(errs), accept_mask_equal=bool(np.array_equal(accg[:, :F], acc1[:, :F])),
+                          max_rel_dx_err=float(max(np.linalg.norm(dxg[b, :N] - dx1[b, :N]) / max(np.linalg.norm(dx1[b, :N]), 1e-300)
+                                                   for b in range(S))))
+        updates = B * world * args.steps
+        out = dict(
+            metric="ekf_updates_per_sec", value=updates / elapsed, unit="updates/s", n_gpus=world, steps=args.steps,
+            warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak",
+            vs_baseline=None, dtype="f64", data="synthetic",
+            config=dict(workload="synthetic stereo MSCKF, %d feats x %d clones, state dim N=%d (update at N), "
+                                 "%d independent filters per GPU; step = propagate(k=10)+clone+MSCKF update+marginalise"
+                                 % (F, C, N, B), filters_per_gpu=B, feats=F, clones=C, state_dim=N, imu_steps=synth.IMU_PER_FRAME,
+                        parallelism="independent filters, %d rank(s), no data-path collective" % world),
+            ms_per_update=elapsed / args.steps * 1e3 / B, accepted_per_filter=F_used, results_finite=ok,
+            algorithmic_flops_per_update=total_flops,
+            whole_step_fp64_frac=total_flops * B / (elapsed / args.steps) / 1e12 / FP64_PEAK_TFLOPS,
+            roofline=roofline, cpu_baseline=cpu, parity_vs_oracle=parity, kernels=kernels, setup_s=t_build)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -196,10 +196,10 @@ __device__ __forceinline__ int build_feature(const FrameView& fv, const MsckfOpt
     for (int k = 0; k < 3; ++k) {
         double w = 0.0;
 #pragma unroll
-        for (int i = 0; i < RR; ++i) if (i < rows) w += sh.V[k][i] * B[i];
+        for (int i = 0; i < RR; ++i) w += sh.V[k][i] * B[i];      // rows >= `rows` are zero in both
         w *= sh.tau[k];
 #pragma unroll
-        for (int i = 0; i < RR; ++i) if (i < rows) B[i] -= w * sh.V[k][i];
+        for (int i = 0; i < RR; ++i) B[i] -= w * sh.V[k][i];
     }
     return rows;
 }
@@ -314,19 +314,19 @@ struct FoldShared {
     double tau[2];
 };
 
-// Folds register rows [lo, hi) of the column-owner block B into the packed R (Householder
-// "append rows" update, one barrier per column).  All NT lanes must call.
+// Folds the column-owner block B (all RR register rows; unused rows must be zero) into the packed
+// R (Householder "append rows" update, one barrier per column).  All NT lanes must call.
 template <int RR>
-__device__ __forceinline__ void fold_rows(double (&B)[RR], int lo, int hi, int ncol, double* sR, FoldShared<RR>& fs)
+__device__ __forceinline__ void fold_rows(double (&B)[RR], int ncol, double* sR, FoldShared<RR>& fs, int k0 = 0)
 {
     const int tid = threadIdx.x;
-    for (int k = 0; k < ncol; ++k) {
+    for (int k = k0; k < ncol; ++k) {     // columns < k0 of the block are known to be zero
         const int buf = k & 1;
         const int rk = roff(k, ncol);
         if (tid == k) {
             double nrm2 = 0.0;
 #pragma unroll
-            for (int i = 0; i < RR; ++i) if (i >= lo && i < hi) nrm2 += B[i] * B[i];
+            for (int i = 0; i < RR; ++i) nrm2 += B[i] * B[i];
             double tau = 0.0;
             if (nrm2 > 0.0) {
                 const double x0 = sR[rk];
@@ -336,7 +336,7 @@ __device__ __forceinline__ void fold_rows(double (&B)[RR], int lo, int hi, int n
                 tau = -v0 / alpha;
                 const double iv0 = 1.0 / v0;
 #pragma unroll
-                for (int i = 0; i < RR; ++i) if (i >= lo && i < hi) { fs.v[buf][i] = B[i] * iv0; B[i] = 0.0; }
+                for (int i = 0; i < RR; ++i) { fs.v[buf][i] = B[i] * iv0; B[i] = 0.0; }
                 sR[rk] = alpha;
             }
             fs.tau[buf] = tau;
@@ -346,11 +346,11 @@ __device__ __forceinline__ void fold_rows(double (&B)[RR], int lo, int hi, int n
         if (tau != 0.0 && tid > k && tid <= ncol) {
             double w = sR[rk + tid - k];
 #pragma unroll
-            for (int i = 0; i < RR; ++i) if (i >= lo && i < hi) w += fs.v[buf][i] * B[i];
+            for (int i = 0; i < RR; ++i) w += fs.v[buf][i] * B[i];
             w *= tau;
             sR[rk + tid - k] -= w;
 #pragma unroll
-            for (int i = 0; i < RR; ++i) if (i >= lo && i < hi) B[i] -= w * fs.v[buf][i];
+            for (int i = 0; i < RR; ++i) B[i] -= w * fs.v[buf][i];
         }
     }
     __syncthreads();
@@ -403,8 +403,9 @@ __global__ __launch_bounds__((FeatCfg<CMAX, STEREO>::NT)) void k_msckf_fold(
     int nused = 0;
     for (int j = g; j < F; j += G) {
         if (!sUse[j]) continue;                                  // uniform
-        const int rows = build_feature<CMAX, STEREO>(fv, op, b, j, C, sh.f, B);
-        fold_rows<RR>(B, 3, rows, ncol, sR, sh.fs);
+        build_feature<CMAX, STEREO>(fv, op, b, j, C, sh.f, B);
+        B[0] = 0.0; B[1] = 0.0; B[2] = 0.0;                      // rows 0..2 span range(Hf): projected out
+        fold_rows<RR>(B, ncol, sR, sh.fs);
         ++nused;
     }
     double* out = Rpart + ((size_t)bl * G + g) * rstride;
@@ -456,7 +457,7 @@ __global__ __launch_bounds__((FeatCfg<CMAX, STEREO>::NT)) void k_msckf_merge(
 #pragma unroll
             for (int i = 0; i < RR; ++i)
                 B[i] = (i < cnt && tid <= ncol) ? part[(size_t)(rb + i) * (ncol + 1) + tid] : 0.0;
-            fold_rows<RR>(B, 0, cnt, ncol, sR, fs);
+            fold_rows<RR>(B, ncol, sR, fs, rb);                  // partial factors are upper triangular
         }
     }
     double* H = Hout + (size_t)bl * hstride;
@@ -498,7 +499,7 @@ __global__ __launch_bounds__((FeatCfg<CMAX, STEREO>::NT)) void k_fold_dense(
             }
             B[i] = val;
         }
-        fold_rows<RR>(B, 0, cnt, ncol, sR, fs);
+        fold_rows<RR>(B, ncol, sR, fs);
         ++nblk;
     }
     double* out = Rpart + (size_t)g * rstride;
