@@ -123,7 +123,9 @@ def algorithmic_flops(F_used, F, C, N, k):
     k2 = 2.0 * 6 * 21 * N
     per_kernel = {
         "k_propagate": k1, "k_augment": k2, "k_msckf_gate": F * (k4 + k5), "k_msckf_fold": F_used * k4 + k7,
-        "k_msckf_merge": 0.0, "k_ekf_core": k8_9_11, "k_downdate": k10, "k_marginalize": 0.0, "restore": 0.0}
+        "k_msckf_merge": 0.0, "k_ekf_core": k8_9_11, "k_downdate": k10, "k_marginalize": 0.0, "restore": 0.0,
+        # factored path: same algorithmic work, different kernels
+        "k_feat_gate2": F * (k4 + k5), "k_feat_gram": F_used * k4 + k7, "k_info_update": k8_9_11}
     total = F * (k4 + k5) + k7 + k8_9_11 + k10 + k1 + k2
     return per_kernel, total
 
@@ -179,6 +181,7 @@ def main():
     ap.add_argument("--literal", action="store_true", help="N=87 (no GNSS / landmark padding) instead of N=249")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--method", default="factored", choices=["factored", "dense"])
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -195,6 +198,7 @@ def main():
     n_gnss, n_lm = (0, 0) if args.literal else (6, 52)
     N = 21 + n_gnss + 3 * n_lm + 6 * C
     ctx = capi.Context(batch=B, n_max=((N + 15) // 16) * 16, c_max=C, f_max=F, m_max=64, device=local_rank)
+    ctx.set_method(args.method)
     t_build = time.perf_counter()
     filters, steps, frames, infos = build_batch(ctx, B, rank * B, F, C, n_gnss, n_lm)
     ctx.snapshot()
@@ -301,7 +305,7 @@ def main():
             ms_per_update=elapsed / args.steps * 1e3 / B, accepted_per_filter=F_used, results_finite=ok,
             algorithmic_flops_per_update=total_flops,
             whole_step_fp64_frac=total_flops * B / (elapsed / args.steps) / 1e12 / FP64_PEAK_TFLOPS,
-            roofline=roofline, cpu_baseline=cpu, parity_vs_oracle=parity, kernels=kernels, setup_s=t_build)
+            method=args.method, roofline=roofline, cpu_baseline=cpu, parity_vs_oracle=parity, kernels=kernels, setup_s=t_build)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -151,6 +151,15 @@ int ingvio_msckf_update(ingvio_ctx* ctx, int b0, int nb, const ingvio_msckf_fram
                         const ingvio_msckf_opts* opts, double* dx_out, int* accepted, double* gamma,
                         int* rows_out);
 
+/* Selects how ingvio_msckf_update / ingvio_frame_run evaluate K4-K11 (same posterior to FP64 rounding):
+ *   0 dense    — literal: projected blocks H_j, dense S_j, Householder TSQR of the stacked H,
+ *                Cholesky Kalman update (kernels_msckf.hip, kernels_ekf.hip)
+ *   1 factored — default: exploits H_x = Gblk*D (per-observation 4x3 factors times a sparse
+ *                selection), the projector identity for gamma, R^T R accumulated as 6x6 clone-pair
+ *                blocks and the information-form update (kernels_factored.hip); see DESIGN.md.
+ * Also settable at context creation through the environment: INGVIO_MSCKF_METHOD=dense|factored. */
+int ingvio_set_msckf_method(ingvio_ctx* ctx, int method);
+
 /* Stacked-QR compression on its own (the SPQR call sites RemoveLostUpdate.cpp:376-397,
  * SwMargUpdate.cpp:336-357, KeyframeUpdate.cpp:707-728): H m x n (ldh) column-major, res [m] ->
  * H_thin n x n upper triangular (ldt) and r_thin [n] with H_thin^T H_thin = H^T H,

@@ -5,8 +5,10 @@
 #include "dev_common.h"
 #include "launch_ekf.h"
 #include "launch_msckf.h"
+#include "launch_factored.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -16,9 +18,11 @@
 
 namespace {
 
-enum ProfId { PF_RESTORE, PF_PROPAGATE, PF_AUGMENT, PF_GATE, PF_FOLD, PF_MERGE, PF_EKF_CORE, PF_DOWNDATE, PF_MARG, PF_COUNT };
+enum ProfId { PF_RESTORE, PF_PROPAGATE, PF_AUGMENT, PF_GATE, PF_FOLD, PF_MERGE, PF_EKF_CORE, PF_DOWNDATE, PF_MARG,
+              PF_GATE2, PF_GRAM, PF_INFO, PF_COUNT };
 const char* kProfNames[PF_COUNT] = { "restore", "k_propagate", "k_augment", "k_msckf_gate", "k_msckf_fold",
-                                     "k_msckf_merge", "k_ekf_core", "k_downdate", "k_marginalize" };
+                                     "k_msckf_merge", "k_ekf_core", "k_downdate", "k_marginalize",
+                                     "k_feat_gate2", "k_feat_gram", "k_info_update" };
 struct ProfRec { int id; hipEvent_t a, b; };
 
 }  // namespace
@@ -43,7 +47,8 @@ struct ingvio_ctx {
     double *d_clone_R, *d_clone_p, *d_pf, *d_uv, *d_chi2;
     unsigned long long* d_mask;
     // msckf / ekf workspaces
-    double *d_gamma, *d_Rpart, *d_H, *d_res, *d_noise, *d_noise1, *d_Y, *d_dx;
+    double *d_gamma, *d_Rpart, *d_H, *d_res, *d_noise, *d_noise1, *d_Y, *d_Yc, *d_dx;
+    int method;                    // 0 dense TSQR path, 1 factored (information-form) path
     int *d_accept, *d_used, *d_chunk_used, *d_colmap, *d_m, *d_nc, *d_status;
     // staged frame state
     int st_k, st_stereo, st_enable_gnss, st_fmax_used;
@@ -195,8 +200,30 @@ int make_opts(ingvio_ctx* c, const ingvio_msckf_opts* o, MsckfOpts* op)
 }
 
 // K3..K11 for filters [b0, b0+nb) using the staged frames; asynchronous.
+int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int stereo, int fmax_used)
+{
+    FactoredLaunch L;
+    memset(&L, 0, sizeof L);
+    L.stereo = stereo; L.cv = view(c); L.fv = fview(c); L.op = op; L.b0 = b0; L.nb = nb;
+    L.fmax_used = fmax_used > 0 ? fmax_used : 1;
+    L.gamma = c->d_gamma; L.accept = c->d_accept; L.used = c->d_used;
+    L.Apart = c->d_Rpart + (size_t)b0 * c->G * c->rstride; L.chunk_used = c->d_chunk_used + (size_t)b0 * c->G;
+    L.G = c->G; L.rstride = c->rstride; L.noise = c->d_noise + b0;
+    L.T = c->d_Y + (size_t)b0 * c->ystride; L.Pc = c->d_Yc + (size_t)b0 * c->ystride; L.ystride = c->ystride;
+    L.dx = c->d_dx; L.m_out = c->d_m + b0; L.nc_out = c->d_nc + b0; L.status = c->d_status;
+    { ProfScope p(c, PF_GATE2); L.stage = 0; if (launch_factored(L, c->st)) return INGVIO_E_UNSUPPORTED; }
+    { ProfScope p(c, PF_GRAM); L.stage = 1; launch_factored(L, c->st); }
+    { ProfScope p(c, PF_INFO); L.stage = 2; launch_factored(L, c->st); }
+    EkfLaunch E;
+    memset(&E, 0, sizeof E);
+    E.cv = view(c); E.b0 = b0; E.nb = nb; E.m = L.m_out; E.Y = L.T; E.ystride = c->ystride; E.status = c->d_status;
+    { ProfScope p(c, PF_DOWNDATE); launch_downdate(E, c->d.n_max, c->st, L.Pc); }
+    return last_launch(c);
+}
+
 int run_msckf(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int stereo, int fmax_used)
 {
+    if (c->method == 1) return run_msckf_factored(c, b0, nb, op, stereo, fmax_used);
     MsckfLaunch L;
     memset(&L, 0, sizeof L);
     L.stereo = stereo; L.cv = view(c); L.fv = fview(c); L.op = op; L.b0 = b0; L.nb = nb;
@@ -263,6 +290,10 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     c->cstride = c->nc_cap;
     c->ystride = c->ldp * (c->mld + 4);
     c->has_snap = false; c->staged = false; c->prof = false;
+    {
+        const char* e = getenv("INGVIO_MSCKF_METHOD");
+        c->method = (e && (!strcmp(e, "dense") || !strcmp(e, "0"))) ? 0 : 1;
+    }
     memset(c->prof_ms, 0, sizeof c->prof_ms); memset(c->prof_calls, 0, sizeof c->prof_calls);
     c->h_n.assign(B, 0); c->h_cur.assign(B, 0); c->h_n_snap.assign(B, 0); c->st_marg.assign(B, -1);
     const size_t pp = (size_t)c->ldp * c->ldp;
@@ -284,7 +315,8 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     rc |= dalloc(c, &c->d_H, (size_t)B * c->hstride); rc |= dalloc(c, &c->d_res, (size_t)B * c->mld);
     rc |= dalloc(c, &c->d_colmap, (size_t)B * c->cstride); rc |= dalloc(c, &c->d_m, B); rc |= dalloc(c, &c->d_nc, B);
     rc |= dalloc(c, &c->d_noise, B); rc |= dalloc(c, &c->d_noise1, (size_t)c->mld * c->mld);
-    rc |= dalloc(c, &c->d_Y, (size_t)B * c->ystride); rc |= dalloc(c, &c->d_dx, (size_t)B * c->ldp);
+    rc |= dalloc(c, &c->d_Y, (size_t)B * c->ystride); rc |= dalloc(c, &c->d_Yc, (size_t)B * c->ystride);
+    rc |= dalloc(c, &c->d_dx, (size_t)B * c->ldp);
     rc |= dalloc(c, &c->d_status, B);
     if (rc || hipStreamSynchronize(c->st) != hipSuccess) { *out = c; return INGVIO_E_HIP; }
     *out = c;
@@ -298,7 +330,7 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
     void* ptrs[] = { c->Pbase, c->Psnap, c->d_cur, c->d_n, c->d_n_snap, c->d_Phi, c->d_G, c->d_dt, c->d_R, c->d_blk, c->d_gnss,
                      c->d_idx, c->d_clone_idx, c->d_nclones, c->d_nfeat, c->d_anchor, c->d_dof, c->d_clone_R, c->d_clone_p,
                      c->d_pf, c->d_uv, c->d_chi2, c->d_mask, c->d_gamma, c->d_accept, c->d_used, c->d_Rpart, c->d_chunk_used,
-                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_dx, c->d_status };
+                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_status };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (c->own_stream) hipStreamDestroy(c->st);
@@ -664,6 +696,13 @@ int ingvio_frame_fetch(ingvio_ctx* c, int b0, int nb, double* dx_out, int* accep
     if (rows_out) HIPCHK(c, hipMemcpyAsync(rows_out, c->d_m + b0, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
     return last_launch(c);
+}
+
+int ingvio_set_msckf_method(ingvio_ctx* c, int method)
+{
+    if (!c || method < 0 || method > 1) return INGVIO_E_ARG;
+    c->method = method;
+    return INGVIO_OK;
 }
 
 int ingvio_profile_enable(ingvio_ctx* c, int enable)

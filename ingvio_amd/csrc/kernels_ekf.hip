@@ -113,13 +113,15 @@ __global__ __launch_bounds__(EKF_THREADS) void k_ekf_core(
 }
 
 // ---------------------------------------------------------------------------------------------
-// K10: P <- P - Y Y^T with v_mfma_f64_16x16x4_f64.  One wave per 16x16 tile of the lower
+// K10: P <- P - Y Yb^T (Yb == Y: the symmetric Cholesky form; Yb = Pc: the information form) with
+// v_mfma_f64_16x16x4_f64.  One wave per 16x16 tile of the lower
 // triangle; A[i][k] = Y[ri+i][k], B[k][j] = Y[rj+j][k] are read straight from L2 (Y is N x m,
 // <= 130 KB per filter).  f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg.
 // ---------------------------------------------------------------------------------------------
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void k_downdate(CovView cv, int b0, const double* __restrict__ Yall,
+                                                  const double* __restrict__ Yball,
                                                   const int* __restrict__ m_all, int ystride, int* __restrict__ status)
 {
     const int bl = blockIdx.y, b = b0 + bl;
@@ -136,13 +138,14 @@ __global__ __launch_bounds__(256) void k_downdate(CovView cv, int b0, const doub
     const int tj = t - ti * (ti + 1) / 2;
     double* P = cov_ptr(cv, b);
     const double* Y = Yall + (size_t)bl * ystride;
+    const double* Yb = Yball + (size_t)bl * ystride;      // == Y for the symmetric Y Y^T form
     const int ra = ti * 16 + (lane & 15), rb = tj * 16 + (lane & 15), kq = lane >> 4;
     const bool va = ra < n, vb = rb < n;
     double4_t acc = { 0.0, 0.0, 0.0, 0.0 };
     const int mp = (m + 3) & ~3;
     for (int k0 = 0; k0 < mp; k0 += 4) {
         const double a = va ? Y[ra + (size_t)(k0 + kq) * ld] : 0.0;
-        const double bb = vb ? Y[rb + (size_t)(k0 + kq) * ld] : 0.0;
+        const double bb = vb ? Yb[rb + (size_t)(k0 + kq) * ld] : 0.0;
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
     }
     const int col = tj * 16 + (lane & 15);
@@ -209,11 +212,11 @@ void launch_ekf_core(const EkfLaunch& L, hipStream_t st)
                        L.noise, L.r_kind, L.mld, L.hstride, L.cstride, L.nstride, L.Y, L.ystride, L.dx, L.status);
 }
 
-void launch_downdate(const EkfLaunch& L, int n_cap, hipStream_t st)
+void launch_downdate(const EkfLaunch& L, int n_cap, hipStream_t st, const double* Yb)
 {
     const int nt = (n_cap + 15) / 16;
     const int tiles = nt * (nt + 1) / 2;
-    hipLaunchKernelGGL(k_downdate, dim3((tiles + 3) / 4, L.nb), dim3(256), 0, st, L.cv, L.b0, L.Y, L.m, L.ystride, L.status);
+    hipLaunchKernelGGL(k_downdate, dim3((tiles + 3) / 4, L.nb), dim3(256), 0, st, L.cv, L.b0, L.Y, Yb ? Yb : L.Y, L.m, L.ystride, L.status);
 }
 
 void launch_gamma(CovView cv, int b, const double* H, const double* res, const int* colmap, int m, int nc,

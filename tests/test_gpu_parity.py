@@ -12,10 +12,12 @@ TOL_COV = 1e-6          # BASELINE.json: "<= 1e-6 relative covariance error vs r
 TIGHT = 1e-11           # what FP64 actually delivers; regressions show up here first
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=["factored", "dense"])
+def ctx(request):
+    """Both evaluation strategies of K4-K11 must reproduce the reference posterior."""
     from ingvio_amd import capi
     c = capi.Context(batch=4, n_max=256, c_max=11, f_max=160, m_max=64)
+    c.set_method(request.param)
     yield c
     c.close()
 
@@ -208,11 +210,13 @@ def test_config2_frame_golden(ctx):
         assert rel_err(ctx.cov_get(b), z["P_final"]) < TIGHT and rel_err(dx[b, :87], z["dx"]) < 1e-9
 
 
-def test_full_n249_batch_vs_oracle(orc):
+@pytest.mark.parametrize("method", ["factored", "dense"])
+def test_full_n249_batch_vs_oracle(orc, method):
     """Config 2 at the BASELINE nominal size: N=249 (6 GNSS scalars + 52 landmark blocks), 8
     different filters in one batch, prior built by the HIP path itself, vs the oracle."""
     from ingvio_amd import capi, host, synth
     ctx2 = capi.Context(batch=8, n_max=256, c_max=11, f_max=150, m_max=64)
+    ctx2.set_method(method)
     cases = []
     for b in range(8):
         flt, step, frame, info = synth.build_case(lambda P, b=b: capi.DeviceCov(ctx2, b, P), host.imu_transition, seed=b)
