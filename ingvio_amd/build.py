@@ -66,9 +66,27 @@ def build_host(force=False, verbose=False):
     return HOST_LIB
 
 
+def build_cpp_tests(force=False, verbose=False):
+    """tests/cpp/test_host_shim.cpp -> ingvio_amd/lib/test_host_shim (run by pytest -m gpu)."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tests", "cpp", "test_host_shim.cpp")
+    exe = os.path.join(LIB, "test_host_shim")
+    if not os.path.exists(src) or not os.path.exists(HOST_LIB):
+        return None
+    deps = _all_deps([os.path.join(CSRC, "host"), os.path.join(root, "include")]) + [src, HOST_LIB]
+    if force or _newer(exe, deps):
+        cmd = ["g++", "-O1", "-std=c++14", "-I", os.path.join(root, "include"), src, "-o", exe, "-L", LIB,
+               "-lingvio_host", "-lingvio_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return exe
+
+
 def build_all(force=False, verbose=False):
     a = build_hip(force, verbose)
     b = build_host(force, verbose)
+    build_cpp_tests(force, verbose)
     return a, b
 
 

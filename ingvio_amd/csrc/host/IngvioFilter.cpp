@@ -1,0 +1,111 @@
+#include "IngvioFilter.h"
+
+#include "StateManager.h"
+
+namespace ingvio {
+
+IngvioFilter::IngvioFilter(const IngvioParams& params, std::shared_ptr<Triangulator> tri) : _filter_params(params)
+{
+    _state = std::make_shared<State>(_filter_params);                                   // IngvioFilter.cpp:76-98
+    _imu_propa = std::make_shared<ImuPropagator>(_filter_params);
+    _tri = tri ? tri : std::make_shared<Triangulator>();
+    _map_server = std::make_shared<MapServer>();
+    _remove_lost_update = std::make_shared<RemoveLostUpdate>(_filter_params);
+    _sw_marg_update = std::make_shared<SwMargUpdate>(_filter_params);
+    _keyframe_update = std::make_shared<KeyframeUpdate>(_filter_params);
+}
+
+void IngvioFilter::callbackIMU(const ImuMsg& m)
+{
+    _imu_propa->storeImu(ImuCtrl(m.stamp, Vec3d(m.accel), Vec3d(m.gyro)));
+    if (!_hasInitState && _imu_propa->isInit()) {                                       // :396-406
+        _state->initStateAndCov(m.stamp, _imu_propa->getInitQuat());
+        _hasInitState = true;
+    }
+}
+
+void IngvioFilter::collectStereoMeas(const StereoFrameMsg& f)
+{
+    const auto anchor = _state->_sw_camleft_poses.at(_state->_timestamp);
+    for (const auto& o : f.stereo_meas) {
+        auto it = _map_server->find(o.id);
+        if (it == _map_server->end()) {                                                 // new id: MSCKF feature anchored at the current clone
+            auto fi = std::make_shared<FeatureInfo>();
+            fi->_id = o.id; fi->_ftype = FeatureInfo::MSCKF;
+            fi->_landmark->resetAnchoredPose(anchor);
+            it = _map_server->insert({ o.id, fi }).first;
+        }
+        auto sm = std::make_shared<StereoMeas>();
+        sm->_u0 = o.u0; sm->_v0 = o.v0; sm->_u1 = o.u1; sm->_v1 = o.v1;
+        it->second->_stereo_obs[f.stamp] = sm;
+    }
+}
+
+void IngvioFilter::collectMonoMeas(const MonoFrameMsg& f)
+{
+    const auto anchor = _state->_sw_camleft_poses.at(_state->_timestamp);
+    for (const auto& o : f.mono_meas) {
+        auto it = _map_server->find(o.id);
+        if (it == _map_server->end()) {
+            auto fi = std::make_shared<FeatureInfo>();
+            fi->_id = o.id; fi->_ftype = FeatureInfo::MSCKF;
+            fi->_landmark->resetAnchoredPose(anchor);
+            it = _map_server->insert({ o.id, fi }).first;
+        }
+        auto mm = std::make_shared<MonoMeas>();
+        mm->_u0 = o.u0; mm->_v0 = o.v0;
+        it->second->_mono_obs[f.stamp] = mm;
+    }
+}
+
+void IngvioFilter::callbackStereoFrame(const StereoFrameMsg& frame)
+{
+    if (!_hasImageCome) { _hasImageCome = true; return; }                               // :257-261
+    if (!_hasInitState) return;
+    const double target_time = frame.stamp;
+    if (_state->_timestamp >= target_time) return;                                      // :267
+    _imu_propa->propagateAugmentAtEnd(_state, target_time);
+    if (_state->_timestamp < target_time) return;                                       // :273
+    collectStereoMeas(frame);
+    _remove_lost_update->updateStateStereo(_state, _map_server, _tri);
+    if (_filter_params._is_key_frame) {
+        _keyframe_update->updateStateStereo(_state, _map_server, _tri);
+        _keyframe_update->cleanStereoObsAtMargTime(_state, _map_server);
+        _keyframe_update->changeMSCKFAnchor(_state, _map_server);
+        _keyframe_update->margSwPose(_state);
+    } else {
+        _sw_marg_update->updateStateStereo(_state, _map_server, _tri);
+        _sw_marg_update->cleanStereoObsAtMargTime(_state, _map_server);
+        _sw_marg_update->changeMSCKFAnchor(_state, _map_server);
+        _sw_marg_update->margSwPose(_state);
+    }
+    eraseInvalidFeatures(_map_server, _state);
+    ++_frames;
+}
+
+void IngvioFilter::callbackMonoFrame(const MonoFrameMsg& frame)
+{
+    if (!_hasImageCome) { _hasImageCome = true; return; }
+    if (!_hasInitState) return;
+    const double target_time = frame.stamp;
+    if (_state->_timestamp >= target_time) return;
+    _imu_propa->propagateAugmentAtEnd(_state, target_time);
+    if (_state->_timestamp < target_time) return;
+    collectMonoMeas(frame);
+    _remove_lost_update->updateStateMono(_state, _map_server, _tri);
+    if (_filter_params._is_key_frame) {
+        _keyframe_update->updateStateMono(_state, _map_server, _tri);
+        _keyframe_update->cleanMonoObsAtMargTime(_state, _map_server);
+        _keyframe_update->changeMSCKFAnchor(_state, _map_server);
+        _keyframe_update->margSwPose(_state);
+    } else {
+        _sw_marg_update->updateStateMono(_state, _map_server, _tri);
+        _sw_marg_update->cleanMonoObsAtMargTime(_state, _map_server);
+        _sw_marg_update->changeMSCKFAnchor(_state, _map_server);
+        _sw_marg_update->margSwPose(_state);
+    }
+    eraseInvalidFeatures(_map_server, _state);
+    ++_frames;
+}
+
+}  // namespace ingvio

@@ -1,0 +1,53 @@
+// IngvioFilter.h — ROS-free mirror of the callback surface of ingvio_estimator/src/IngvioFilter.{h,cpp}
+// (IngvioFilter.cpp:252-407): callbackIMU / callbackStereoFrame / callbackMonoFrame with POD
+// messages shaped like sensor_msgs/Imu and feature_tracker/{Mono,Stereo}Frame, same early-return logic
+// and the same per-frame orchestration (propagate+clone -> collect -> RemoveLost -> Keyframe|SwMarg ->
+// clean / re-anchor / marginalise -> erase invalid).  ROS, tf, publishers and the GNSS
+// sync/aligner plumbing (IngvioFilter.cpp:50-122, 329-498) are out of scope.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "GnssUpdate.h"
+#include "ImuPropagator.h"
+#include "IngvioParams.h"
+#include "MapServer.h"
+#include "MsckfUpdates.h"
+#include "State.h"
+
+namespace ingvio {
+
+struct ImuMsg { double stamp; double gyro[3]; double accel[3]; };                       // sensor_msgs/Imu subset
+struct StereoObsMsg { int id; double u0, v0, u1, v1; };                                 // feature_tracker/StereoMeas
+struct StereoFrameMsg { double stamp; std::vector<StereoObsMsg> stereo_meas; };         // feature_tracker/StereoFrame
+struct MonoObsMsg { int id; double u0, v0; };
+struct MonoFrameMsg { double stamp; std::vector<MonoObsMsg> mono_meas; };
+
+class IngvioFilter {
+public:
+    IngvioFilter(const IngvioParams& params, std::shared_ptr<Triangulator> tri = nullptr);
+    void callbackIMU(const ImuMsg& imu_msg);                                            // IngvioFilter.cpp:381-407
+    void callbackStereoFrame(const StereoFrameMsg& stereo_frame);                       // :252-379
+    void callbackMonoFrame(const MonoFrameMsg& mono_frame);                             // :124-250
+
+    std::shared_ptr<State> state() { return _state; }
+    std::shared_ptr<MapServer> mapServer() { return _map_server; }
+    std::shared_ptr<ImuPropagator> imuPropagator() { return _imu_propa; }
+    int framesProcessed() const { return _frames; }
+
+protected:
+    void collectStereoMeas(const StereoFrameMsg& f);                                    // MapServerManager.cpp:147-217
+    void collectMonoMeas(const MonoFrameMsg& f);
+    IngvioParams _filter_params;
+    std::shared_ptr<State> _state;
+    std::shared_ptr<ImuPropagator> _imu_propa;
+    std::shared_ptr<Triangulator> _tri;
+    std::shared_ptr<MapServer> _map_server;
+    std::shared_ptr<RemoveLostUpdate> _remove_lost_update;
+    std::shared_ptr<SwMargUpdate> _sw_marg_update;
+    std::shared_ptr<KeyframeUpdate> _keyframe_update;
+    bool _hasImageCome = false, _hasInitState = false;
+    int _frames = 0;
+};
+
+}  // namespace ingvio

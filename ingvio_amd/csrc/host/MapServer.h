@@ -1,0 +1,34 @@
+// MapServer.h — mirrors the data model of ingvio_estimator/src/MapServer.h:30-134 (MonoMeas, StereoMeas,
+// FeatureInfo, MapServer).  The pointer-chasing bookkeeping of MapServerManager stays host-side and out
+// of scope; the Update classes flatten this structure into the SoA of the C ABI.
+#pragma once
+#include <map>
+#include <memory>
+
+#include "AnchoredLandmark.h"
+
+namespace ingvio {
+
+struct MonoMeas { double _u0 = 0, _v0 = 0; };
+struct StereoMeas { double _u0 = 0, _v0 = 0, _u1 = 0, _v1 = 0; };
+
+class FeatureInfo {
+public:
+    enum FeatureType { MSCKF = 0, SLAM };
+    FeatureInfo() : _id(-1), _ftype(MSCKF), _isToMarg(false), _isTri(false), _numOfTri(0) { _landmark = std::make_shared<AnchoredLandmark>(); }
+    int numOfMonoFrames() const { return (int)_mono_obs.size(); }
+    int numOfStereoFrames() const { return (int)_stereo_obs.size(); }
+    const std::shared_ptr<SE3> anchor() const { return _landmark->getAnchoredPose(); }
+    int _id;
+    FeatureType _ftype;
+    bool _isToMarg;
+    bool _isTri;
+    int _numOfTri;
+    std::shared_ptr<AnchoredLandmark> _landmark;
+    std::map<double, std::shared_ptr<MonoMeas>> _mono_obs;
+    std::map<double, std::shared_ptr<StereoMeas>> _stereo_obs;
+};
+
+typedef std::map<int, std::shared_ptr<FeatureInfo>> MapServer;
+
+}  // namespace ingvio

@@ -1,0 +1,345 @@
+#include "MsckfUpdates.h"
+
+#include <cstdlib>
+#include <iostream>
+#include <unordered_set>
+
+#include "IngvioParams.h"
+#include "StateManager.h"
+
+namespace ingvio {
+
+bool Triangulator::triangulate(std::shared_ptr<FeatureInfo> fi, const std::shared_ptr<State>, bool)
+{
+    if (!fi->_isTri || fi->_landmark->getAnchoredPose() == nullptr) return false;
+    const auto anchor = fi->_landmark->getAnchoredPose();
+    const Vec3d body = anchor->valueLinearAsMat().transpose() * (fi->_landmark->valuePosXyz() - anchor->valueTrans());
+    if (body.z() <= 0) return false;                                                          // MapServerManager.cpp:325
+    ++fi->_numOfTri;
+    return true;
+}
+
+namespace {
+
+// The sliding window + a list of features flattened into the SoA of the C ABI.
+struct FlatFrame {
+    std::vector<double> times;
+    std::vector<std::shared_ptr<SE3>> poses;
+    std::vector<int> clone_idx, anchor, dof;
+    std::vector<double> clone_R, clone_p, pf, uv;
+    std::vector<unsigned long long> mask;
+    int C = 0, F = 0;
+
+    explicit FlatFrame(const std::shared_ptr<State>& state)
+    {
+        for (const auto& item : state->_sw_camleft_poses) {          // std::map: ascending timestamp
+            times.push_back(item.first);
+            poses.push_back(item.second);
+            clone_idx.push_back(item.second->idx());
+            const Mat3d& R = item.second->valueLinearAsMat();      // current values, not FEJ (Q7)
+            clone_R.insert(clone_R.end(), R.m, R.m + 9);
+            const Vec3d& p = item.second->valueTrans();
+            clone_p.insert(clone_p.end(), p.v, p.v + 3);
+        }
+        C = (int)times.size();
+    }
+    int slotOfPose(const std::shared_ptr<SE3>& p) const
+    {
+        for (int s = 0; s < C; ++s) if (poses[s] == p) return s;
+        return -1;
+    }
+    // `sel`: nullptr = every observation inside the window (RemoveLost), else only these stamps
+    bool add(const std::shared_ptr<FeatureInfo>& fi, bool stereo, const std::vector<double>* sel, int dof_value)
+    {
+        const int a = slotOfPose(fi->_landmark->getAnchoredPose());
+        if (a < 0) return false;
+        unsigned long long m = 0ULL;
+        std::vector<double> row((size_t)C * 4, 0.0);
+        for (int s = 0; s < C; ++s) {
+            if (sel) { bool in = false; for (double t : *sel) if (t == times[s]) in = true; if (!in) continue; }
+            if (stereo) {
+                auto it = fi->_stereo_obs.find(times[s]);
+                if (it == fi->_stereo_obs.end()) continue;
+                row[4 * s] = it->second->_u0; row[4 * s + 1] = it->second->_v0; row[4 * s + 2] = it->second->_u1; row[4 * s + 3] = it->second->_v1;
+            } else {
+                auto it = fi->_mono_obs.find(times[s]);
+                if (it == fi->_mono_obs.end()) continue;
+                row[4 * s] = it->second->_u0; row[4 * s + 1] = it->second->_v0;
+            }
+            m |= 1ULL << s;
+        }
+        if (!m) return false;
+        const Vec3d& p = fi->_landmark->valuePosXyz();
+        pf.insert(pf.end(), p.v, p.v + 3);
+        uv.insert(uv.end(), row.begin(), row.end());
+        anchor.push_back(a); mask.push_back(m); dof.push_back(dof_value);
+        ++F;
+        return true;
+    }
+    ingvio_msckf_frame view() const
+    {
+        ingvio_msckf_frame f;
+        f.n_clones = C; f.clone_idx = clone_idx.data(); f.clone_R = clone_R.data(); f.clone_p = clone_p.data();
+        f.n_feat = F; f.pf = pf.data(); f.anchor = anchor.data(); f.obs_mask = mask.data(); f.uv = uv.data(); f.dof = dof.data();
+        return f;
+    }
+};
+
+ingvio_msckf_opts makeOpts(const std::shared_ptr<State>& state, bool stereo, double noise, const std::vector<double>& table,
+                           int max_accept, int compress_rule, int selected_variant)
+{
+    ingvio_msckf_opts o;
+    o.stereo = stereo ? 1 : 0;
+    for (int i = 0; i < 9; ++i) o.R_cl2cr[i] = state->_state_params._T_cl2cr.R.m[i];
+    for (int i = 0; i < 3; ++i) o.t_cl2cr[i] = state->_state_params._T_cl2cr.t[i];
+    o.noise = noise; o.chi2_table = table.data(); o.chi2_len = (int)table.size();
+    o.max_accept = max_accept; o.compress_rule = compress_rule; o.selected_variant = selected_variant;
+    return o;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+RemoveLostUpdate::RemoveLostUpdate(const IngvioParams& fp)
+    : UpdateBase(fp._chi2_max_dof, fp._chi2_thres), _max_valid_ids(20), _noise(fp._visual_noise) {}
+
+void RemoveLostUpdate::updateStateMono(std::shared_ptr<State> s, std::shared_ptr<MapServer> m, std::shared_ptr<Triangulator> t) { update(s, m, t, false); }
+void RemoveLostUpdate::updateStateStereo(std::shared_ptr<State> s, std::shared_ptr<MapServer> m, std::shared_ptr<Triangulator> t) { update(s, m, t, true); }
+
+void RemoveLostUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri, bool stereo)
+{
+    _last_rows = 0; _last_accepted = 0;
+    // MapServerManager::mark{Mono,Stereo}Features (MapServerManager.cpp:219-273), MSCKF part
+    for (auto& item : *map_server) {
+        const bool has = stereo ? item.second->_stereo_obs.count(state->_timestamp) > 0 : item.second->_mono_obs.count(state->_timestamp) > 0;
+        if (!has) item.second->_isToMarg = true;
+    }
+    std::vector<int> update_ids, direct_marg_ids;
+    for (auto& item : *map_server)
+        if (item.second->_ftype == FeatureInfo::MSCKF && item.second->_isToMarg) {
+            const bool enough = stereo ? item.second->numOfStereoFrames() >= 3 : item.second->numOfMonoFrames() >= 4;   // :287 / :51
+            if (tri->triangulate(item.second, state, stereo) && enough) update_ids.push_back(item.first);
+            else direct_marg_ids.push_back(item.first);
+        }
+    for (const auto& id : direct_marg_ids) map_server->erase(id);
+    if (update_ids.size() == 0) return;
+    FlatFrame ff(state);
+    int max_dof = 1;
+    for (int id : update_ids) {
+        const auto& fi = map_server->at(id);
+        const int dof = (stereo ? (int)fi->_stereo_obs.size() : (int)fi->_mono_obs.size()) - 1;       // :332-333 (Q4)
+        ff.add(fi, stereo, nullptr, dof);
+        if (dof > max_dof) max_dof = dof;
+    }
+    if (ff.F > 0) {
+        const std::vector<double> table = chi2TableDense(max_dof + 1);
+        const ingvio_msckf_frame fr = ff.view();
+        const ingvio_msckf_opts op = makeOpts(state, stereo, _noise, table, _max_valid_ids, 0 /* as written, Q2 */, 0);
+        std::vector<int> acc;
+        _last_rows = StateManager::msckfUpdate(state, fr, op, &acc);
+        for (int a : acc) _last_accepted += a;
+    }
+    for (const auto& id : update_ids) map_server->erase(id);                                          // :402-403
+}
+
+// ---------------------------------------------------------------------------------------------
+SwMargUpdate::SwMargUpdate(const IngvioParams& fp)
+    : UpdateBase(fp._chi2_max_dof, fp._chi2_thres), _noise(fp._visual_noise), _frame_select_interval(fp._frame_select_interval) {}
+
+void SwMargUpdate::selectSwTimestamps(const std::map<double, std::shared_ptr<SE3>>& sw_poses, const double& marg_time,
+                                      std::vector<double>& selected_timestamps)
+{
+    selected_timestamps.clear();
+    if (marg_time == INFINITY || sw_poses.find(marg_time) == sw_poses.end()) return;
+    int cnt = 1;
+    selected_timestamps.push_back(marg_time);
+    for (const auto& item : sw_poses) {
+        if (item.first <= marg_time) continue;
+        if (cnt % _frame_select_interval == 0) selected_timestamps.push_back(item.first);
+        ++cnt;
+    }
+}
+
+void SwMargUpdate::updateStateMono(std::shared_ptr<State> s, std::shared_ptr<MapServer> m, std::shared_ptr<Triangulator> t) { update(s, m, t, false); }
+void SwMargUpdate::updateStateStereo(std::shared_ptr<State> s, std::shared_ptr<MapServer> m, std::shared_ptr<Triangulator> t) { update(s, m, t, true); }
+
+static int selectedUpdate(UpdateBase& base, std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server,
+                          std::shared_ptr<Triangulator> tri, bool stereo, const std::vector<double>& sel, int dof, double noise)
+{
+    // features observed at every selected stamp (SwMargUpdate.cpp:236-257 / KeyframeUpdate.cpp:607-628)
+    FlatFrame ff(state);
+    for (const auto& item : *map_server) {
+        const auto& fi = item.second;
+        if (fi->_ftype != FeatureInfo::MSCKF) continue;
+        bool miss = false;
+        for (double ts : sel)
+            if (stereo ? fi->_stereo_obs.find(ts) == fi->_stereo_obs.end() : fi->_mono_obs.find(ts) == fi->_mono_obs.end()) { miss = true; break; }
+        if (miss) continue;
+        if (tri->triangulate(fi, state, stereo)) ff.add(fi, stereo, &sel, dof);
+    }
+    if (ff.F == 0) return 0;
+    const std::vector<double> table = base.chi2TableDense(dof + 1);
+    const ingvio_msckf_frame fr = ff.view();
+    const ingvio_msckf_opts op = makeOpts(state, stereo, noise, table, 0, 1 /* top_n, SwMargUpdate.cpp:350-351 */, 1 /* Q10 */);
+    return StateManager::msckfUpdate(state, fr, op, nullptr);
+}
+
+void SwMargUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri, bool stereo)
+{
+    _last_rows = 0;
+    const double marg_time = state->nextMargTime();
+    if (marg_time == INFINITY) return;
+    std::vector<double> selected_timestamps;
+    this->selectSwTimestamps(state->_sw_camleft_poses, marg_time, selected_timestamps);
+    for (double ts : selected_timestamps)
+        if (state->_sw_camleft_poses.find(ts) == state->_sw_camleft_poses.end()) {
+            std::cout << "[SwMargUpdate]: selected timestamp not in sw!" << std::endl;                // :462-466
+            std::exit(EXIT_FAILURE);
+        }
+    _last_rows = selectedUpdate(*this, state, map_server, tri, stereo, selected_timestamps, (int)selected_timestamps.size() - 1, _noise);
+}
+
+template <bool STEREO>
+static void cleanObsAt(std::shared_ptr<MapServer> map_server, const std::vector<double>& stamps)
+{
+    std::vector<int> ids_to_clean;
+    for (auto& item : *map_server)
+        for (double t : stamps) {
+            if (STEREO) { item.second->_stereo_obs.erase(t); if (item.second->_stereo_obs.empty()) ids_to_clean.push_back(item.first); }
+            else { item.second->_mono_obs.erase(t); if (item.second->_mono_obs.empty()) ids_to_clean.push_back(item.first); }
+        }
+    for (int id : ids_to_clean) map_server->erase(id);
+}
+
+void SwMargUpdate::cleanMonoObsAtMargTime(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server)
+{
+    const double marg_time = state->nextMargTime();
+    if (marg_time == INFINITY) return;
+    cleanObsAt<false>(map_server, { marg_time });
+}
+void SwMargUpdate::cleanStereoObsAtMargTime(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server)
+{
+    const double marg_time = state->nextMargTime();
+    if (marg_time == INFINITY) return;
+    cleanObsAt<true>(map_server, { marg_time });
+}
+
+static void changeAnchor(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server,
+                         const std::unordered_set<std::shared_ptr<SE3>>& old_anchor_set, double min_depth)
+{
+    const std::shared_ptr<SE3> new_anchor = state->_sw_camleft_poses.rbegin()->second;
+    std::vector<int> ids_to_marg;
+    for (auto& item : *map_server) {
+        if (item.second->_ftype != FeatureInfo::MSCKF) continue;
+        if (old_anchor_set.find(item.second->_landmark->getAnchoredPose()) != old_anchor_set.end()) {
+            if (item.second->_isTri) {
+                const Vec3d pf = item.second->_landmark->valuePosXyz();
+                const Vec3d body = new_anchor->valueLinearAsMat().transpose() * (pf - new_anchor->valueTrans());
+                if (body.z() <= min_depth) { ids_to_marg.push_back(item.first); continue; }
+                item.second->_landmark->resetAnchoredPose(new_anchor, true);
+            } else
+                ids_to_marg.push_back(item.first);
+        }
+    }
+    for (const int& id : ids_to_marg) map_server->erase(id);
+}
+
+void SwMargUpdate::changeMSCKFAnchor(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server)
+{
+    const double marg_time = state->nextMargTime();
+    if (marg_time == INFINITY || state->_sw_camleft_poses.find(marg_time) == state->_sw_camleft_poses.end()) return;
+    changeAnchor(state, map_server, { state->_sw_camleft_poses.at(marg_time) }, 0.0);               // :395 (body.z() <= 0)
+}
+
+void SwMargUpdate::margSwPose(std::shared_ptr<State> state)
+{
+    const double marg_time = state->nextMargTime();
+    if (marg_time == INFINITY) return;
+    StateManager::margSlidingWindowPose(state, marg_time);
+}
+
+// ---------------------------------------------------------------------------------------------
+KeyframeUpdate::KeyframeUpdate(const IngvioParams& fp)
+    : UpdateBase(fp._chi2_max_dof, fp._chi2_thres), _noise(fp._visual_noise), _max_sw_poses(fp._max_sw_clones) {}
+
+void KeyframeUpdate::getMargKfs(const std::shared_ptr<State> state, std::vector<double>& marg_kfs)
+{
+    if ((int)state->_sw_camleft_poses.size() < _max_sw_poses || _max_sw_poses < 3) { marg_kfs.clear(); return; }
+    if (state->_timestamp == _timestamp && _kfs.size() > 0) { marg_kfs = _kfs; return; }
+    if ((int)state->_sw_camleft_poses.size() > _max_sw_poses) {
+        std::cout << "[KeyframeUpdate]: Current sw poses larger than max size!" << std::endl;        // :60-64
+        std::exit(EXIT_FAILURE);
+    }
+    _timestamp = state->_timestamp;
+    _kfs.clear();
+    const int rem = _max_sw_poses - 2;
+    const int idx1 = 2 + _select_cnt;
+    ++_select_cnt;
+    _select_cnt = _select_cnt % rem;
+    auto item1 = state->_sw_camleft_poses.rbegin();
+    for (int i = 0; i < idx1; ++i) ++item1;
+    auto item2 = state->_sw_camleft_poses.rbegin();
+    ++item2;
+    _kfs.push_back(item1->first);
+    _kfs.push_back(item2->first);
+    marg_kfs = _kfs;
+}
+
+void KeyframeUpdate::updateStateMono(std::shared_ptr<State> s, std::shared_ptr<MapServer> m, std::shared_ptr<Triangulator> t) { update(s, m, t, false); }
+void KeyframeUpdate::updateStateStereo(std::shared_ptr<State> s, std::shared_ptr<MapServer> m, std::shared_ptr<Triangulator> t) { update(s, m, t, true); }
+
+void KeyframeUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri, bool stereo)
+{
+    _last_rows = 0;
+    std::vector<double> selected_timestamps;
+    this->getMargKfs(state, selected_timestamps);
+    if (selected_timestamps.size() == 0) return;
+    _last_rows = selectedUpdate(*this, state, map_server, tri, stereo, selected_timestamps, 2 /* KeyframeUpdate.cpp:675-676 */, _noise);
+}
+
+void KeyframeUpdate::cleanMonoObsAtMargTime(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server)
+{
+    std::vector<double> marg_kfs;
+    this->getMargKfs(state, marg_kfs);
+    cleanObsAt<false>(map_server, marg_kfs);
+}
+void KeyframeUpdate::cleanStereoObsAtMargTime(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server)
+{
+    std::vector<double> marg_kfs;
+    this->getMargKfs(state, marg_kfs);
+    cleanObsAt<true>(map_server, marg_kfs);
+}
+
+void KeyframeUpdate::changeMSCKFAnchor(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server)
+{
+    std::vector<double> marg_kfs;
+    this->getMargKfs(state, marg_kfs);
+    if (marg_kfs.size() == 0) return;
+    std::unordered_set<std::shared_ptr<SE3>> old_anchor_set;
+    for (const double& marg_time : marg_kfs) old_anchor_set.insert(state->_sw_camleft_poses.at(marg_time));
+    changeAnchor(state, map_server, old_anchor_set, 0.3);                                            // :311
+}
+
+void KeyframeUpdate::margSwPose(std::shared_ptr<State> state)
+{
+    std::vector<double> marg_kfs;
+    this->getMargKfs(state, marg_kfs);
+    if (marg_kfs.size() == 0) return;
+    for (const double& marg_time : marg_kfs) StateManager::margSlidingWindowPose(state, marg_time);
+}
+
+void eraseInvalidFeatures(std::shared_ptr<MapServer> map_server, std::shared_ptr<State>)
+{
+    std::vector<int> ids_to_remove;
+    for (const auto& item : *map_server) {
+        const auto& fi = item.second;
+        if (!fi->_isTri) continue;
+        if (fi->_landmark->getAnchoredPose() == nullptr) { ids_to_remove.push_back(item.first); continue; }
+        const auto anchor_ptr = fi->_landmark->getAnchoredPose();
+        const Vec3d body = anchor_ptr->valueLinearAsMat().transpose() * (fi->_landmark->valuePosXyz() - anchor_ptr->valueTrans());
+        if (body.z() <= 0.2) ids_to_remove.push_back(item.first);
+    }
+    for (const int& id : ids_to_remove) map_server->erase(id);
+}
+
+}  // namespace ingvio

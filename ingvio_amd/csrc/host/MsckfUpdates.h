@@ -1,0 +1,92 @@
+// MsckfUpdates.h — mirrors the three MSCKF update policies of the reference:
+//   RemoveLostUpdate  (RemoveLostUpdate.h:30-75, .cpp:40-167,276-405)
+//   SwMargUpdate      (SwMargUpdate.h, .cpp:42-189,216-497)
+//   KeyframeUpdate    (KeyframeUpdate.h, .cpp:43-129,280-328,438-761)
+// "Who/what to update" (selection, anchor changes, observation cleaning, marginalisation order) is
+// restated here on the host; the per-feature Jacobians, nullspace, chi^2 gate, stacking, compression
+// and the Kalman update are ONE call into libingvio_hip.so (StateManager::msckfUpdate) on a
+// flattened copy of the MapServer.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "MapServer.h"
+#include "Update.h"
+
+namespace ingvio {
+
+class IngvioParams;
+class State;
+
+// Triangulation is the "next" row f-1 of SURVEY.md §8(f); the policies only need this interface.
+// The default accepts features whose landmark position was already set (feature->_isTri) and applies
+// the depth test of MapServerManager.cpp:309-341.
+class Triangulator {
+public:
+    virtual ~Triangulator() {}
+    virtual bool triangulate(std::shared_ptr<FeatureInfo> feature_info, const std::shared_ptr<State> state, bool stereo);
+};
+
+class RemoveLostUpdate : public UpdateBase {
+public:
+    RemoveLostUpdate(const IngvioParams& filter_params);
+    void updateStateMono(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri);
+    void updateStateStereo(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri);
+    int lastRows() const { return _last_rows; }
+    int lastAccepted() const { return _last_accepted; }
+    void setMaxValidIds(int n) { _max_valid_ids = n; }      // RemoveLostUpdate.h:38 (20)
+
+protected:
+    void update(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri, bool stereo);
+    int _max_valid_ids;
+    double _noise;
+    int _last_rows = 0, _last_accepted = 0;
+};
+
+class SwMargUpdate : public UpdateBase {
+public:
+    SwMargUpdate(const IngvioParams& filter_params);
+    void updateStateMono(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri);
+    void updateStateStereo(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri);
+    void cleanMonoObsAtMargTime(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server);      // SwMargUpdate.cpp:191-214
+    void cleanStereoObsAtMargTime(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server);    // :421-444
+    void changeMSCKFAnchor(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server);           // :367-410
+    void margSwPose(std::shared_ptr<State> state);                                                         // :412-419
+    void selectSwTimestamps(const std::map<double, std::shared_ptr<SE3>>& sw_poses, const double& marg_time,
+                            std::vector<double>& selected_timestamps);                                     // :475-497
+    int lastRows() const { return _last_rows; }
+
+protected:
+    void update(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri, bool stereo);
+    double _noise;
+    int _frame_select_interval;
+    int _last_rows = 0;
+};
+
+class KeyframeUpdate : public UpdateBase {
+public:
+    KeyframeUpdate(const IngvioParams& filter_params);
+    void getMargKfs(const std::shared_ptr<State> state, std::vector<double>& marg_kfs);                    // KeyframeUpdate.cpp:43-116
+    void updateStateMono(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri);
+    void updateStateStereo(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri);
+    void cleanMonoObsAtMargTime(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server);
+    void cleanStereoObsAtMargTime(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server);    // :737-761
+    void changeMSCKFAnchor(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server);           // :280-328
+    void margSwPose(std::shared_ptr<State> state);                                                         // :118-129
+    int lastRows() const { return _last_rows; }
+
+protected:
+    void update(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri, bool stereo);
+    double _noise;
+    int _max_sw_poses;
+    // the reference keeps this counter as a process-global static (KeyframeUpdate.cpp:41); per filter here
+    int _select_cnt = 0;
+    double _timestamp = -1;
+    std::vector<double> _kfs;
+    int _last_rows = 0;
+};
+
+// MapServerManager::eraseInvalidFeatures (MapServerManager.cpp:454-490), MSCKF part
+void eraseInvalidFeatures(std::shared_ptr<MapServer> map_server, std::shared_ptr<State> state);
+
+}  // namespace ingvio

@@ -1,0 +1,278 @@
+#include "StateManager.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <iostream>
+
+namespace ingvio {
+
+void StateManager::fatal(const std::shared_ptr<State>& state, const char* what, int rc)
+{
+    std::cout << "[StateManager]: " << what << " failed on the device (" << rc << "): " << ingvio_last_error(state->_ctx) << std::endl;
+    std::exit(EXIT_FAILURE);
+}
+
+bool StateManager::checkStateContinuity(const std::shared_ptr<State> state)
+{
+    int idx = 0;
+    for (size_t i = 0; i < state->_err_variables.size(); ++i)
+        if (state->_err_variables[i]->idx() == idx) idx += state->_err_variables[i]->size();
+        else return false;
+    return state->curr_cov_size() == idx;
+}
+
+static void gnssIdx(const std::shared_ptr<State>& state, int gi[5])
+{
+    for (int g = 0; g < 5; ++g) {
+        auto it = state->_gnss.find(g);
+        gi[g] = it == state->_gnss.end() ? -1 : it->second->idx();
+    }
+}
+
+void StateManager::propagateStateCov(std::shared_ptr<State> state, const double Phi_imu[225], const double G_imu[180], double dt)
+{
+    propagateStateCovFused(state, 1, Phi_imu, G_imu, &dt);
+}
+
+void StateManager::propagateStateCovFused(std::shared_ptr<State> state, int k, const double* Phi, const double* G, const double* dt)
+{
+    const StateParams& sp = state->_state_params;
+    const double sigma[4] = { sp._noise_g, sp._noise_a, sp._noise_bg, sp._noise_ba };
+    int gi[5];
+    gnssIdx(state, gi);
+    const int rc = ingvio_propagate_fused(state->_ctx, state->_b, 1, k, Phi, G, dt, sigma, sp._enable_gnss ? 1 : 0, gi,
+                                          sp._noise_clockbias, sp._noise_cb_rw);
+    if (rc != INGVIO_OK) fatal(state, "propagateStateCov", rc);
+}
+
+MatXd StateManager::getFullCov(std::shared_ptr<State> state)
+{
+    const int n = state->curr_cov_size();
+    MatXd cov(n, n);
+    const int rc = ingvio_cov_get(state->_ctx, state->_b, cov.data(), n);
+    if (rc != INGVIO_OK) fatal(state, "getFullCov", rc);
+    return cov;
+}
+
+static void orderOf(const std::vector<std::shared_ptr<Type>>& vars, std::vector<int>& vidx, std::vector<int>& vsize)
+{
+    vidx.clear(); vsize.clear();
+    for (const auto& v : vars) { vidx.push_back(v->idx()); vsize.push_back(v->size()); }
+}
+
+MatXd StateManager::getMarginalCov(std::shared_ptr<State> state, const std::vector<std::shared_ptr<Type>>& small_variables)
+{
+    std::vector<int> vidx, vsize;
+    orderOf(small_variables, vidx, vsize);
+    const int ns = calcSubVarSize(small_variables);
+    MatXd small_cov(ns, ns);
+    const int rc = ingvio_cov_get_marginal(state->_ctx, state->_b, vidx.data(), vsize.data(), (int)vidx.size(), small_cov.data());
+    if (rc != INGVIO_OK) fatal(state, "getMarginalCov", rc);
+    return small_cov;
+}
+
+void StateManager::marginalize(std::shared_ptr<State> state, std::shared_ptr<Type> marg)
+{
+    if (std::find(state->_err_variables.begin(), state->_err_variables.end(), marg) == state->_err_variables.end()) {
+        std::cout << "[StateManager]: Marg is not in the current state!" << std::endl;      // :157-161
+        std::exit(EXIT_FAILURE);
+    }
+    const int marg_size = marg->size(), marg_start = marg->idx();
+    const int rc = ingvio_marginalize(state->_ctx, state->_b, 1, &marg_start, marg_size);
+    if (rc != INGVIO_OK) fatal(state, "marginalize", rc);
+    std::vector<std::shared_ptr<Type>> remaining_variables;                                 // :179-191
+    for (size_t i = 0; i < state->_err_variables.size(); ++i)
+        if (state->_err_variables[i] != marg) {
+            if (state->_err_variables[i]->idx() > marg_start)
+                state->_err_variables[i]->set_cov_idx(state->_err_variables[i]->idx() - marg_size);
+            remaining_variables.push_back(state->_err_variables[i]);
+        }
+    marg->set_cov_idx(-1);
+    state->_err_variables = remaining_variables;
+}
+
+void StateManager::addVariableIndependent(std::shared_ptr<State> state, std::shared_ptr<Type> new_state, const MatXd& blk)
+{
+    int new_idx = -1;
+    const int rc = ingvio_append_independent(state->_ctx, state->_b, 1, new_state->size(), blk.data(), &new_idx);
+    if (rc != INGVIO_OK) fatal(state, "addVariableIndependent", rc);
+    new_state->set_cov_idx(new_idx);                                                        // :208 (== old_cov_size)
+    state->_err_variables.push_back(new_state);
+}
+
+void StateManager::addGNSSVariable(std::shared_ptr<State> state, const State::GNSSType& gtype, double value, double cov)
+{
+    if (state->_gnss.find(gtype) != state->_gnss.end())
+        std::cout << "[StateManager]: GNSS variable already in the state, adding operation will rewrite such var!" << std::endl;
+    state->_gnss[gtype] = std::make_shared<Scalar>();
+    state->_gnss[gtype]->setValue(value);
+    MatXd scalar_cov(1, 1);
+    scalar_cov(0, 0) = cov;
+    addVariableIndependent(state, state->_gnss[gtype], scalar_cov);
+}
+
+void StateManager::margGNSSVariable(std::shared_ptr<State> state, const State::GNSSType& gtype)
+{
+    if (state->_gnss.find(gtype) == state->_gnss.end())
+        std::cout << "[StateManager]: GNSS variable not in the state, no need to marg!" << std::endl;
+    marginalize(state, state->_gnss.at(gtype));
+    state->_gnss.erase(gtype);
+}
+
+void StateManager::boxPlus(std::shared_ptr<State> state, const VecXd& dx)
+{
+    for (size_t i = 0; i < state->_err_variables.size(); ++i) state->_err_variables[i]->update(dx);
+}
+
+void StateManager::augmentSlidingWindowPose(std::shared_ptr<State> state)
+{
+    if (state->_sw_camleft_poses.find(state->_timestamp) != state->_sw_camleft_poses.end()) {
+        std::cout << "[StateManager]: Curr pose already in the sw, cannot clone!" << std::endl;
+        return;
+    }
+    std::shared_ptr<SE3> clone(new SE3());
+    const Mat3d& R_i2w = state->_extended_pose->valueLinearAsMat();
+    const Mat3d Rc = R_i2w * state->_camleft_imu_extrinsics->valueLinearAsMat();           // T_i2w * T_cl2i, :263-272
+    const Vec3d pc = R_i2w * state->_camleft_imu_extrinsics->valueTrans() + state->_extended_pose->valueTrans1();
+    clone->setValue(Rc, pc);
+    clone->setFej(Rc, pc);
+    int new_idx = -1;
+    const int rc = ingvio_augment_clone(state->_ctx, state->_b, 1, R_i2w.m, &new_idx);
+    if (rc != INGVIO_OK) fatal(state, "augmentSlidingWindowPose", rc);
+    clone->set_cov_idx(new_idx);                                                            // :274
+    state->_sw_camleft_poses[state->_timestamp] = clone;
+    state->_err_variables.push_back(clone);
+}
+
+void StateManager::addAnchoredLandmarkInState(std::shared_ptr<State> state, std::shared_ptr<AnchoredLandmark> lm, int lm_id, const MatXd& cov)
+{
+    if (state->_anchored_landmarks.find(lm_id) != state->_anchored_landmarks.end()) {
+        std::cout << "[StateManager]: Landmark already in the state, cannot add!" << std::endl;
+        return;
+    }
+    state->_anchored_landmarks[lm_id] = lm;
+    addVariableIndependent(state, lm, cov);
+}
+
+void StateManager::margSlidingWindowPose(std::shared_ptr<State> state, double marg_time)
+{
+    if (state->_sw_camleft_poses.find(marg_time) == state->_sw_camleft_poses.end())
+        std::cout << "[StateManager]: Marg pose time not exists! Cannot marg!" << std::endl;
+    marginalize(state, state->_sw_camleft_poses.at(marg_time));
+    state->_sw_camleft_poses.erase(marg_time);
+}
+
+void StateManager::margSlidingWindowPose(std::shared_ptr<State> state)
+{
+    const double marg_time = state->nextMargTime();
+    if (marg_time == INFINITY) {
+        std::cout << "[StateManager]: Auto marg pose gives inf time! Cannot marg!" << std::endl;
+        return;
+    }
+    margSlidingWindowPose(state, marg_time);
+}
+
+void StateManager::margAnchoredLandmarkInState(std::shared_ptr<State> state, int lm_id)
+{
+    if (state->_anchored_landmarks.find(lm_id) == state->_anchored_landmarks.end()) {
+        std::cout << "[StateManager]: Landmark id not exists in state! Cannot marg!" << std::endl;
+        return;
+    }
+    marginalize(state, state->_anchored_landmarks.at(lm_id));
+    state->_anchored_landmarks.erase(lm_id);
+}
+
+// classifies R as scalar*I / diagonal / full so the device can skip the dense noise block
+static int classifyR(const MatXd& R, std::vector<double>& out)
+{
+    const int m = R.rows();
+    bool diag = true, scalar = true;
+    for (int j = 0; j < m && diag; ++j)
+        for (int i = 0; i < m; ++i)
+            if (i != j && R(i, j) != 0.0) { diag = false; break; }
+    if (diag) for (int i = 1; i < m; ++i) if (R(i, i) != R(0, 0)) { scalar = false; break; }
+    if (diag && scalar && m > 1) { out.assign(1, R(0, 0)); return INGVIO_R_SCALAR; }
+    if (diag) { out.resize(m); for (int i = 0; i < m; ++i) out[i] = R(i, i); return INGVIO_R_DIAG; }
+    out.assign(R.data(), R.data() + (size_t)m * m);
+    return INGVIO_R_FULL;
+}
+
+void StateManager::ekfUpdate(std::shared_ptr<State> state, const std::vector<std::shared_ptr<Type>>& var_order,
+                             const MatXd& H, const VecXd& res, const MatXd& R)
+{
+    if (!checkSubOrder(state, var_order)) std::exit(EXIT_FAILURE);      // assert(checkSubOrder), :369
+    std::vector<int> vidx, vsize;
+    orderOf(var_order, vidx, vsize);
+    std::vector<double> Rv;
+    const int kind = classifyR(R, Rv);
+    VecXd dx(state->curr_cov_size(), 0.0);
+    const int rc = ingvio_ekf_update(state->_ctx, state->_b, vidx.data(), vsize.data(), (int)vidx.size(), H.data(), H.rows(),
+                                     H.rows(), res.data(), Rv.data(), kind, dx.data());
+    if (rc < 0) fatal(state, "ekfUpdate", rc);
+    if (rc == INGVIO_NEG_DIAG)
+        std::cout << "[StateManager]: EKF Update and found negative diag cov elements! " << std::endl;      // :418
+    boxPlus(state, dx);                                                                      // :425
+}
+
+bool StateManager::checkSubOrder(std::shared_ptr<State> state, const std::vector<std::shared_ptr<Type>>& sub_order)
+{
+    for (const auto& item : sub_order)
+        if (std::find(state->_err_variables.begin(), state->_err_variables.end(), item) == state->_err_variables.end()) {
+            std::cout << "[StateManager]: Existing sub order var not in state! " << std::endl;
+            return false;
+        }
+    return true;
+}
+
+int StateManager::calcSubVarSize(const std::vector<std::shared_ptr<Type>>& sub_var)
+{
+    int total_size = 0;
+    for (const auto& item : sub_var) if (item != nullptr) total_size += item->size();
+    return total_size;
+}
+
+double StateManager::whitenResidual(std::shared_ptr<State> state, const VecXd& res, const MatXd& H,
+                                    const std::vector<std::shared_ptr<Type>>& var_order, const MatXd& R)
+{
+    std::vector<int> vidx, vsize;
+    orderOf(var_order, vidx, vsize);
+    std::vector<double> Rv;
+    const int kind = classifyR(R, Rv);
+    double gamma = 0.0;
+    const int rc = ingvio_chi2_gamma(state->_ctx, state->_b, vidx.data(), vsize.data(), (int)vidx.size(), H.data(), H.rows(),
+                                     H.rows(), res.data(), Rv.data(), kind, &gamma);
+    if (rc != INGVIO_OK) fatal(state, "whitenResidual", rc);
+    return gamma;
+}
+
+double StateManager::whitenResidual(std::shared_ptr<State> state, const VecXd& res, const MatXd& H,
+                                    const std::vector<std::shared_ptr<Type>>& var_order, double noise)
+{
+    std::vector<int> vidx, vsize;
+    orderOf(var_order, vidx, vsize);
+    const double var = noise * noise;                                                        // Update.cpp:53
+    double gamma = 0.0;
+    const int rc = ingvio_chi2_gamma(state->_ctx, state->_b, vidx.data(), vsize.data(), (int)vidx.size(), H.data(), H.rows(),
+                                     H.rows(), res.data(), &var, INGVIO_R_SCALAR, &gamma);
+    if (rc != INGVIO_OK) fatal(state, "whitenResidual", rc);
+    return gamma;
+}
+
+int StateManager::msckfUpdate(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_msckf_opts& opts,
+                              std::vector<int>* accepted)
+{
+    const int ldp = ingvio_ldp(state->_ctx);
+    VecXd dx(ldp, 0.0);
+    std::vector<int> acc(opts.chi2_len > 0 ? 4096 : 4096, 0);
+    int rows = 0;
+    const int rc = ingvio_msckf_update(state->_ctx, state->_b, 1, &frame, &opts, dx.data(), acc.data(), nullptr, &rows);
+    if (rc < 0) fatal(state, "msckfUpdate", rc);
+    if (accepted) accepted->assign(acc.begin(), acc.begin() + frame.n_feat);
+    if (rows > 0) {
+        dx.resize(state->curr_cov_size());
+        boxPlus(state, dx);
+    }
+    return rows;
+}
+
+}  // namespace ingvio

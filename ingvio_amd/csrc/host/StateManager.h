@@ -1,0 +1,61 @@
+// StateManager.h — mirrors ingvio_estimator/src/StateManager.h:38-127: the sole friend of the
+// state's covariance.  Every static function keeps the reference's name and argument meaning and
+// forwards the covariance arithmetic to libingvio_hip.so; the Type::idx() bookkeeping is done here
+// exactly as StateManager.cpp does (append at the end, shift later indices on marginalise).
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "MatX.h"
+#include "State.h"
+
+namespace ingvio {
+
+class StateManager {
+public:
+    StateManager() = delete;
+
+    static bool checkStateContinuity(const std::shared_ptr<State> state);                    // StateManager.cpp:27-40
+    static void propagateStateCov(std::shared_ptr<State> state, const double Phi_imu[225],   // :42-119
+                                  const double G_imu[180], double dt);
+    // k steps of propagateStateCov in one launch (the loop of ImuPropagator.cpp:246-289)
+    static void propagateStateCovFused(std::shared_ptr<State> state, int k, const double* Phi, const double* G, const double* dt);
+    static MatXd getFullCov(std::shared_ptr<State> state);                                   // :121-126
+    static MatXd getMarginalCov(std::shared_ptr<State> state,                                // :128-153
+                                const std::vector<std::shared_ptr<Type>>& small_variables);
+    static void marginalize(std::shared_ptr<State> state, std::shared_ptr<Type> marg);       // :155-192
+    static void addVariableIndependent(std::shared_ptr<State> state, std::shared_ptr<Type> new_state,
+                                       const MatXd& new_state_cov_block);                    // :194-214
+    static void addGNSSVariable(std::shared_ptr<State> state, const State::GNSSType& gtype, double value, double cov);   // :216-231
+    static void margGNSSVariable(std::shared_ptr<State> state, const State::GNSSType& gtype);                            // :233-242
+    static void boxPlus(std::shared_ptr<State> state, const VecXd& dx);                      // :244-251
+    static void augmentSlidingWindowPose(std::shared_ptr<State> state);                      // :253-296
+    static void addAnchoredLandmarkInState(std::shared_ptr<State> state, std::shared_ptr<AnchoredLandmark> anchored_landmark,
+                                           int lm_id, const MatXd& cov);                     // :298-314
+    static void margSlidingWindowPose(std::shared_ptr<State> state, double marg_time);       // :316-326
+    static void margSlidingWindowPose(std::shared_ptr<State> state);                         // :328-338
+    static void margAnchoredLandmarkInState(std::shared_ptr<State> state, int lm_id);        // :340-353
+    // R: m x m (the reference's signature).  Diagonal / scalar*I matrices are detected and sent as such.
+    static void ekfUpdate(std::shared_ptr<State> state, const std::vector<std::shared_ptr<Type>>& var_order,
+                          const MatXd& H, const VecXd& res, const MatXd& R);                 // :359-426
+    static bool checkSubOrder(std::shared_ptr<State> state, const std::vector<std::shared_ptr<Type>>& sub_order);   // :428-445
+    static int calcSubVarSize(const std::vector<std::shared_ptr<Type>>& sub_var);            // :447-456
+
+    // whitenResidual's arithmetic (Update.cpp:36-79) lives with the covariance on the device
+    static double whitenResidual(std::shared_ptr<State> state, const VecXd& res, const MatXd& H,
+                                 const std::vector<std::shared_ptr<Type>>& var_order, const MatXd& R);
+    static double whitenResidual(std::shared_ptr<State> state, const VecXd& res, const MatXd& H,
+                                 const std::vector<std::shared_ptr<Type>>& var_order, double noise);
+
+    // MSCKF update on flattened MapServer data + boxPlus; returns rows handed to the Kalman update.
+    static int msckfUpdate(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_msckf_opts& opts,
+                           std::vector<int>* accepted = nullptr);
+
+    static ingvio_ctx* ctx(const std::shared_ptr<State>& state) { return state->_ctx; }
+    static int filterIndex(const std::shared_ptr<State>& state) { return state->_b; }
+
+private:
+    static void fatal(const std::shared_ptr<State>& state, const char* what, int rc);
+};
+
+}  // namespace ingvio

@@ -1,6 +1,7 @@
 // facade.cpp — small extern "C" surface of libingvio_host.so for the Python harness (bench.py,
 // tests): lets Python drive the C++ host shim without a C++ test runner.  Not part of the HIP ABI.
 #include "ImuTransition.h"
+#include "Update.h"
 
 extern "C" {
 
@@ -23,5 +24,7 @@ void ingvio_host_gamma(const double* vec, int m, double* out)
     const ingvio::Mat3d g = ingvio::GammaFunc(ingvio::Vec3d(vec), m);
     for (int i = 0; i < 9; ++i) out[i] = g.m[i];
 }
+
+double ingvio_host_chi2_quantile(int dof, double p) { return ingvio::chi2Quantile(dof, p); }
 
 }  // extern "C"

@@ -17,6 +17,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libingvio_host.so not built; run __graft_entry__.build()")
         _lib = C.CDLL(LIB_PATH)
+        _lib.ingvio_host_chi2_quantile.restype = C.c_double
     return _lib
 
 
@@ -41,3 +42,8 @@ def imu_transition(R, p, v, bg, ba, gyro, acc, gravity, dt):
     lib().ingvio_host_imu_transition(_d(R), _d(p), _d(v), _d(_f(bg)), _d(_f(ba)), _d(_f(gyro)), _d(_f(acc)),
                                      _d(_f(gravity)), C.c_double(dt), _d(Phi), _d(G))
     return R, p, v, Phi.reshape(15, 15, order="F"), G.reshape(15, 12, order="F")
+
+
+def chi2_quantile(dof, p=0.95):
+    """UpdateBase's table entry: boost::math::quantile(chi_squared(dof), p) without Boost."""
+    return lib().ingvio_host_chi2_quantile(C.c_int(dof), C.c_double(p))
