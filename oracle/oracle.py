@@ -278,6 +278,27 @@ def frame_update(cov, step, frame, **kw):
     return dx[:n_upd].copy(), acc[:F].copy(), gam[:F].copy(), m
 
 
+class PreparedBatch:
+    """C structs for orc_frame_update_batch built once, so a timed loop measures the C code only."""
+
+    def __init__(self, steps, frames, **kw):
+        self.B = len(steps)
+        self.frs = (FrameIn * self.B)(); self.mss = (MsckfIn * self.B)()
+        self.keeps = []
+        self.fmax = 1
+        for b in range(self.B):
+            fr, k1 = make_frame_in(steps[b]); ms, k2 = make_msckf_in(frames[b], **kw)
+            self.frs[b] = fr; self.mss[b] = ms; self.keeps.append((k1, k2, fr, ms))
+            self.fmax = max(self.fmax, ms.n_feat)
+
+    def run(self, P, n, ld, threads=0):
+        """P [B, ld, ld] float64 C-contiguous (modified in place), n [B] int32 (modified in place)."""
+        dx = np.zeros((self.B, ld)); acc = np.zeros((self.B, self.fmax), dtype=np.int32)
+        lib().orc_frame_update_batch(C.c_int(self.B), C.c_int(threads), _d(P), _i(n), C.c_int(ld), self.frs, self.mss,
+                                     _d(dx), _i(acc), C.c_int(self.fmax))
+        return dx, acc
+
+
 def frame_update_batch(P, n, ld, steps, frames, threads=0, **kw):
     """P: [B, ld, ld] (each column-major => pass array with P[b] = buf.T contiguous, i.e. shape
     [B, ld, ld] C-order holding the TRANSPOSE; symmetric so equivalent).  Returns (dx[B,ld], acc)."""
