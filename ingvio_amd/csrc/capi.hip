@@ -47,7 +47,7 @@ struct ingvio_ctx {
     double *d_clone_R, *d_clone_p, *d_pf, *d_uv, *d_chi2;
     unsigned long long* d_mask;
     // msckf / ekf workspaces
-    double *d_gamma, *d_Rpart, *d_H, *d_res, *d_noise, *d_noise1, *d_Y, *d_Yc, *d_dx;
+    double *d_gamma, *d_Rpart, *d_H, *d_res, *d_noise, *d_noise1, *d_Y, *d_Yc, *d_dx, *d_rec;
     int method;                    // 0 dense TSQR path, 1 factored (information-form) path
     int *d_accept, *d_used, *d_chunk_used, *d_colmap, *d_m, *d_nc, *d_status;
     // staged frame state
@@ -206,7 +206,7 @@ int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int s
     memset(&L, 0, sizeof L);
     L.stereo = stereo; L.cv = view(c); L.fv = fview(c); L.op = op; L.b0 = b0; L.nb = nb;
     L.fmax_used = fmax_used > 0 ? fmax_used : 1;
-    L.gamma = c->d_gamma; L.accept = c->d_accept; L.used = c->d_used;
+    L.gamma = c->d_gamma; L.accept = c->d_accept; L.used = c->d_used; L.rec = c->d_rec;
     L.Apart = c->d_Rpart + (size_t)b0 * c->G * c->rstride; L.chunk_used = c->d_chunk_used + (size_t)b0 * c->G;
     L.G = c->G; L.rstride = c->rstride; L.noise = c->d_noise + b0;
     L.T = c->d_Y + (size_t)b0 * c->ystride; L.Pc = c->d_Yc + (size_t)b0 * c->ystride; L.ystride = c->ystride;
@@ -317,6 +317,7 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     rc |= dalloc(c, &c->d_noise, B); rc |= dalloc(c, &c->d_noise1, (size_t)c->mld * c->mld);
     rc |= dalloc(c, &c->d_Y, (size_t)B * c->ystride); rc |= dalloc(c, &c->d_Yc, (size_t)B * c->ystride);
     rc |= dalloc(c, &c->d_dx, (size_t)B * c->ldp);
+    rc |= dalloc(c, &c->d_rec, (size_t)B * fm * factored_rec_size(desc->c_max));
     rc |= dalloc(c, &c->d_status, B);
     if (rc || hipStreamSynchronize(c->st) != hipSuccess) { *out = c; return INGVIO_E_HIP; }
     *out = c;
@@ -330,7 +331,7 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
     void* ptrs[] = { c->Pbase, c->Psnap, c->d_cur, c->d_n, c->d_n_snap, c->d_Phi, c->d_G, c->d_dt, c->d_R, c->d_blk, c->d_gnss,
                      c->d_idx, c->d_clone_idx, c->d_nclones, c->d_nfeat, c->d_anchor, c->d_dof, c->d_clone_R, c->d_clone_p,
                      c->d_pf, c->d_uv, c->d_chi2, c->d_mask, c->d_gamma, c->d_accept, c->d_used, c->d_Rpart, c->d_chunk_used,
-                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_status };
+                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (c->own_stream) hipStreamDestroy(c->st);

@@ -45,41 +45,102 @@ __device__ __forceinline__ void mulXt(const double M[9], double x, double y, dou
 
 // ---------------------------------------------------------------------------------------------
 // K3 + K5, one workgroup per (feature, filter).
+//
+// The bordered matrix [[S, Y], [Y^T, 0]] (S = Gblk Su Gblk^T + s^2 I, Y = [r | Hf]) is held as 4x4
+// register blocks of its lower triangle.  For a stereo feature block (bi, bk) IS the observation
+// pair (o, o'): its owner lane builds it straight from nine 3x3 blocks of the prior P
+// (Su[o][o'] = D_o Pcc D_o'^T), so nothing but the per-observation 4x3 factors G_o passes through
+// LDS (~5 KB per workgroup: occupancy is bounded by waves, not LDS).  Right-looking elimination
+// of the first `rows` pivots leaves -Y^T S^-1 Y in the border block.
+// The kernel also writes the feature's compact record (N_o = G_o^T G_o, h_o = G_o^T r_o, slots,
+// flags, p_f) consumed by k_feat_gram.
 // ---------------------------------------------------------------------------------------------
-#define GATE2_NT 128
+#define GATE_NT 128
+#define REC_HDR 5
+#define REC_OBS 15          // slot, cna, pfl, N(9), h(3)
+
+__host__ __device__ constexpr int rec_size(int cmax) { return REC_HDR + REC_OBS * cmax; }
 
 template <int CMAX, bool STEREO>
-struct Gate2Shared {
+struct GateShared {
     using Cfg = FeatCfg<CMAX, STEREO>;
-    static constexpr int NU = 3 * CMAX;
     static constexpr int NB = Cfg::RR + 4;                 // S bordered by [r | Hf]
     static constexpr int NBB = (NB + 3) / 4;               // 4x4 register blocks per side
     static constexpr int NBLK = NBB * (NBB + 1) / 2;
-    static constexpr int BPT = (NBLK + GATE2_NT - 1) / GATE2_NT;
+    static constexpr int BPT = (NBLK + GATE_NT - 1) / GATE_NT;
     FeatShared<CMAX, STEREO> f;
     int cna[CMAX];                                 // obs slot != anchor
     int pfl[CMAX];                                 // obs keeps its -I block (false only under Q10)
-    union {
-        double PD[Cfg::NCOLMAX][NU];               // Pcc D^T
-        double T2[NU][Cfg::RR + 4];                // Su Gblk^T
-    } u;
-    double Su[NU][NU + 1];
     double col[2][4 * NBB];                        // published pivot column, double buffered
     double W4[16];
 };
 
+// Su[o][o'] = D_o Pcc D_o'^T from nine 3x3 blocks of P (row-major 3x3 out)
+__device__ __forceinline__ void su_pair(const double* __restrict__ P, int ld, int gc, int gc2, int ga, bool cn, bool cn2,
+                                        bool pl, bool pl2, double px, double py, double pz, double out[9])
+{
+    auto blk = [&](int r0, int c0, double M[9]) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) M[3 * m + q] = P[(r0 + m) + (size_t)(c0 + q) * ld];
+    };
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out[i] = 0.0;
+    double A[9], T[9], U[9];
+    if (cn && cn2) {                                  // X (Ptt' - Pta - Pat' + Paa) X^T
+        blk(gc, gc2, A);
+        blk(gc, ga, T);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) A[i] -= T[i];
+        blk(ga, gc2, T);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) A[i] -= T[i];
+        blk(ga, ga, T);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) A[i] += T[i];
+        mulXt(A, px, py, pz, T);                      // X^T A = -X A
+        mulX(T, px, py, pz, U);                       // (X^T A) X = X A X^T
+#pragma unroll
+        for (int i = 0; i < 9; ++i) out[i] += U[i];
+    }
+    if (cn && pl2) {                                  // -X (Ptp' - Pap')  = +X^T (.)
+        blk(gc, gc2 + 3, A);
+        blk(ga, gc2 + 3, T);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) A[i] -= T[i];
+        mulXt(A, px, py, pz, T);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) out[i] += T[i];
+    }
+    if (pl && cn2) {                                  // -(Ppt' - Ppa) X^T = +(.) X
+        blk(gc + 3, gc2, A);
+        blk(gc + 3, ga, T);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) A[i] -= T[i];
+        mulX(A, px, py, pz, T);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) out[i] += T[i];
+    }
+    if (pl && pl2) {
+        blk(gc + 3, gc2 + 3, A);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) out[i] += A[i];
+    }
+}
+
 template <int CMAX, bool STEREO>
-__global__ __launch_bounds__(GATE2_NT) void k_feat_gate2(
-    CovView cv, FrameView fv, MsckfOpts op, int b0, double* __restrict__ gamma_out, int* __restrict__ accept_out)
+__global__ __launch_bounds__(GATE_NT) void k_feat_gate2(
+    CovView cv, FrameView fv, MsckfOpts op, int b0, double* __restrict__ gamma_out, int* __restrict__ accept_out,
+    double* __restrict__ rec_out)
 {
     using Cfg = FeatCfg<CMAX, STEREO>;
-    using SH = Gate2Shared<CMAX, STEREO>;
-    constexpr int RPO = Cfg::RPO, NT = GATE2_NT, BPT = SH::BPT;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    SH& sh = *reinterpret_cast<SH*>(smem_raw);
+    using SH = GateShared<CMAX, STEREO>;
+    constexpr int RPO = Cfg::RPO, NT = GATE_NT, BPT = SH::BPT, OPB = 4 / RPO;      // observations per block side
+    __shared__ SH sh;
     const int b = b0 + blockIdx.y, j = blockIdx.x, tid = threadIdx.x;
     if (j >= fv.n_feat[b]) return;
-    const int C = fv.n_clones[b], ncol = 6 * C, ld = cv.ldp;
+    const int C = fv.n_clones[b], ld = cv.ldp;
     const double* P = cov_ptr(cv, b);
     const size_t oidx = (size_t)b * fv.fmax + j;
     const int a = fv.anchor[oidx];
@@ -87,73 +148,39 @@ __global__ __launch_bounds__(GATE2_NT) void k_feat_gate2(
     const double px = pf[0], py = pf[1], pz = pf[2];
     load_gidx<CMAX, STEREO>(fv, b, C, sh.f);
     const int rows = feat_phase1<CMAX, STEREO>(fv, op, b, j, C, sh.f);
-    const int nobs = sh.f.nobs, nu = 3 * nobs, rho = rows - 3;
+    const int nobs = sh.f.nobs, rho = rows - 3;
+    double* rec = rec_out + oidx * rec_size(CMAX);
     if (rho <= 0) {
-        if (tid == 0) { gamma_out[oidx] = __builtin_nan(""); accept_out[oidx] = 0; }
+        if (tid == 0) { gamma_out[oidx] = __builtin_nan(""); accept_out[oidx] = 0; rec[0] = 0.0; }
         return;
     }
     if (tid < nobs) {
         const int so = sh.f.slot[tid];
-        sh.cna[tid] = so != a;
-        sh.pfl[tid] = !(op.selected_variant && so == a);
-    }
-    __syncthreads();
-    const int tx = tid & 31, ty = tid >> 5;               // 32 x 4 item grid for the small products
-    // PD[r][3o..3o+2] = Pcc[r,:] D_o^T  (rows of P read through the symmetric counterpart: coalesced)
-    const int ga0 = sh.f.gidx[6 * a];
-    for (int o = 0; o < nobs; ++o) {
-        const int gc = sh.f.gidx[6 * sh.f.slot[o]];
-        const bool cn = sh.cna[o], pl = sh.pfl[o];
-        for (int r = tid; r < ncol; r += NT) {
-            const int gr = sh.f.gidx[r];
-            double dth[3] = { 0.0, 0.0, 0.0 }, pp[3] = { 0.0, 0.0, 0.0 }, cr[3];
-            if (cn) {
+        const bool cn = so != a, pl = !(op.selected_variant && so == a);
+        sh.cna[tid] = cn;
+        sh.pfl[tid] = pl;
+        double* ro = rec + REC_HDR + REC_OBS * tid;
+        ro[0] = so; ro[1] = cn ? 1.0 : 0.0; ro[2] = pl ? 1.0 : 0.0;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) dth[q] = P[gr + (size_t)(gc + q) * ld] - P[gr + (size_t)(ga0 + q) * ld];
+        for (int m = 0; m < 3; ++m) {
+#pragma unroll
+            for (int m2 = 0; m2 < 3; ++m2) {
+                double s = 0.0;
+#pragma unroll
+                for (int t = 0; t < RPO; ++t) s += sh.f.G[tid][t][m] * sh.f.G[tid][t][m2];
+                ro[3 + 3 * m + m2] = s;
             }
-            if (pl) {
+            double hh = 0.0;
 #pragma unroll
-                for (int m = 0; m < 3; ++m) pp[m] = P[gr + (size_t)(gc + 3 + m) * ld];
-            }
-            cross3(px, py, pz, dth, cr);
-#pragma unroll
-            for (int m = 0; m < 3; ++m) sh.u.PD[r][3 * o + m] = cr[m] - pp[m];
+            for (int t = 0; t < RPO; ++t) hh += sh.f.G[tid][t][m] * sh.f.res[tid][t];
+            ro[12 + m] = hh;
         }
     }
+    if (tid == 0) { rec[0] = nobs; rec[1] = a; rec[2] = px; rec[3] = py; rec[4] = pz; }
     __syncthreads();
-    // Su = D (Pcc D^T)
-    for (int o = ty; o < nobs; o += 4) {
-        const int rc = 6 * sh.f.slot[o], ra = 6 * a;
-        const bool cn = sh.cna[o], pl = sh.pfl[o];
-        for (int jj = tx; jj < nu; jj += 32) {
-            double dth[3] = { 0.0, 0.0, 0.0 }, pp[3] = { 0.0, 0.0, 0.0 }, cr[3];
-            if (cn) {
-#pragma unroll
-                for (int q = 0; q < 3; ++q) dth[q] = sh.u.PD[rc + q][jj] - sh.u.PD[ra + q][jj];
-            }
-            if (pl) {
-#pragma unroll
-                for (int m = 0; m < 3; ++m) pp[m] = sh.u.PD[rc + 3 + m][jj];
-            }
-            cross3(px, py, pz, dth, cr);
-#pragma unroll
-            for (int m = 0; m < 3; ++m) sh.Su[3 * o + m][jj] = cr[m] - pp[m];
-        }
-    }
-    __syncthreads();
-    // T2 = Su Gblk^T (aliases PD, which is dead now)
-    for (int o2 = ty; o2 < nobs; o2 += 4) {
-        for (int u = tx; u < nu; u += 32) {
-            const double s0 = sh.Su[u][3 * o2], s1 = sh.Su[u][3 * o2 + 1], s2 = sh.Su[u][3 * o2 + 2];
-#pragma unroll
-            for (int t = 0; t < RPO; ++t)
-                sh.u.T2[u][RPO * o2 + t] = s0 * sh.f.G[o2][t][0] + s1 * sh.f.G[o2][t][1] + s2 * sh.f.G[o2][t][2];
-        }
-    }
-    __syncthreads();
-    // S = Gblk T2 + s^2 I, bordered by [r | Hf], held as 4x4 register blocks of the lower triangle;
-    // right-looking elimination of the first `rows` pivots leaves -Y^T S^-1 Y in the border block.
+
     const int nb = rows + 4, nbb = (nb + 3) >> 2, nblk = nbb * (nbb + 1) / 2;
+    const int ga = sh.f.gidx[6 * a];
     double val[BPT][4][4];
     int bi_[BPT], bk_[BPT];
 #pragma unroll
@@ -168,23 +195,48 @@ __global__ __launch_bounds__(GATE2_NT) void k_feat_gate2(
         }
         bi_[s] = bi; bk_[s] = bk;
 #pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) val[s][r][c] = 0.0;
+        if (bi < 0) continue;
+        // S part: observation pairs covered by this block
+#pragma unroll
+        for (int u = 0; u < OPB; ++u) {
+            const int o = OPB * bi + u;
+            if (o >= nobs) continue;
+#pragma unroll
+            for (int w = 0; w < OPB; ++w) {
+                const int o2 = OPB * bk + w;
+                if (o2 >= nobs || o2 > o) continue;
+                double Su[9];
+                su_pair(P, ld, sh.f.gidx[6 * sh.f.slot[o]], sh.f.gidx[6 * sh.f.slot[o2]], ga, sh.cna[o], sh.cna[o2],
+                        sh.pfl[o], sh.pfl[o2], px, py, pz, Su);
+                double GS[RPO][3];
+#pragma unroll
+                for (int t = 0; t < RPO; ++t)
+#pragma unroll
+                    for (int m2 = 0; m2 < 3; ++m2)
+                        GS[t][m2] = sh.f.G[o][t][0] * Su[m2] + sh.f.G[o][t][1] * Su[3 + m2] + sh.f.G[o][t][2] * Su[6 + m2];
+#pragma unroll
+                for (int t = 0; t < RPO; ++t)
+#pragma unroll
+                    for (int t2 = 0; t2 < RPO; ++t2) {
+                        double v = GS[t][0] * sh.f.G[o2][t2][0] + GS[t][1] * sh.f.G[o2][t2][1] + GS[t][2] * sh.f.G[o2][t2][2];
+                        if (o == o2 && t == t2) v += op.var;
+                        val[s][RPO * u + t][RPO * w + t2] = v;
+                    }
+            }
+        }
+        // border rows: [r | Hf]^T
+#pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * bi + r;
+            if (i < rows || i >= nb) continue;
+            const int kb = i - rows;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int k = 4 * bk + c;
-                double v = 0.0;
-                if (bi >= 0 && i < nb && k <= i) {
-                    if (i < rows) {
-                        const int o = i / RPO, t = i % RPO;
-                        v = sh.f.G[o][t][0] * sh.u.T2[3 * o][k] + sh.f.G[o][t][1] * sh.u.T2[3 * o + 1][k] +
-                            sh.f.G[o][t][2] * sh.u.T2[3 * o + 2][k] + (i == k ? op.var : 0.0);
-                    } else if (k < rows) {
-                        const int kb = i - rows;
-                        v = (kb == 0) ? sh.f.res[k / RPO][k % RPO] : sh.f.G[k / RPO][k % RPO][kb - 1];
-                    }
-                }
-                val[s][r][c] = v;
+                if (k < rows) val[s][r][c] = (kb == 0) ? sh.f.res[k / RPO][k % RPO] : sh.f.G[k / RPO][k % RPO][kb - 1];
             }
         }
     }
@@ -251,32 +303,43 @@ __global__ __launch_bounds__(GATE2_NT) void k_feat_gate2(
 // K4 + K6/K7 in Gram form.  grid = (G chunks, nb); chunk g accumulates A_g = sum H_j^T H_j and
 // b_g = sum H_j^T r_j over its used features j = g, g+G, ...; lane (c, c') owns the 6x6 block of
 // window-slot pair (c, c') in registers for the whole chunk (deterministic, no atomics).
+// With N_o = G_o^T G_o, h_o = G_o^T r_o (from the gate kernel's record), Ns = sum N_o = Hf^T Hf:
+//   W[o][o'] = [o == o'] N_o - N_o Ns^-1 N_o'        (= Gblk^T (I - Hf (Hf^T Hf)^-1 Hf^T) Gblk)
+//   g_o      = h_o - N_o Ns^-1 sum_o h_o
+// i.e. the left-nullspace projection K4 without ever forming the 4C x (4C-3) basis.
 // ---------------------------------------------------------------------------------------------
-template <int CMAX, bool STEREO>
+template <int CMAX>
 struct GramShared {
-    using Cfg = FeatCfg<CMAX, STEREO>;
-    static constexpr int NU = 3 * CMAX;
     static constexpr int NT = ((CMAX * CMAX + 63) / 64) * 64;
-    FeatShared<CMAX, STEREO> f;
-    int cna[CMAX], pfl[CMAX], obs_of_slot[CMAX];
-    double U[Cfg::RR][3];
-    double rp[Cfg::RR];
-    double Z[NU][3];
-    double g[NU];
-    double W[NU][NU + 1];
-    double Wa[3][NU + 1];
-    double Waa[9];
-    double ga[3];
+    static constexpr int REC = REC_HDR + REC_OBS * CMAX;
+    double rec[2][REC];           // double-buffered feature record
+    double sums[2][24];           // Ns(9) hs(3) Nsa(9) hsa(3)
 };
 
-template <int CMAX, bool STEREO>
-__global__ __launch_bounds__((GramShared<CMAX, STEREO>::NT)) void k_feat_gram(
-    FrameView fv, MsckfOpts op, int b0, const int* __restrict__ accept_in, int* __restrict__ used_out,
-    double* __restrict__ Apart, int* __restrict__ chunk_used, int G, int rstride)
+__device__ __forceinline__ void inv3sym(const double N[9], double out[9])
 {
-    using Cfg = FeatCfg<CMAX, STEREO>;
-    using SH = GramShared<CMAX, STEREO>;
-    constexpr int RPO = Cfg::RPO, RR = Cfg::RR, NT = SH::NT;
+    const double a = N[0], b = N[1], c = N[2], d = N[4], e = N[5], f = N[8];
+    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+    const double det = a * c00 + b * c01 + c * c02, id = 1.0 / det;
+    out[0] = c00 * id; out[1] = c01 * id; out[2] = c02 * id;
+    out[3] = out[1]; out[4] = (a * f - c * c) * id; out[5] = (b * c - a * e) * id;
+    out[6] = out[2]; out[7] = out[5]; out[8] = (a * d - b * b) * id;
+}
+__device__ __forceinline__ void mul33(const double A[9], const double B[9], double C[9])
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) C[3 * i + k] = A[3 * i] * B[k] + A[3 * i + 1] * B[3 + k] + A[3 * i + 2] * B[6 + k];
+}
+
+template <int CMAX, bool STEREO>
+__global__ __launch_bounds__((GramShared<CMAX>::NT)) void k_feat_gram(
+    FrameView fv, MsckfOpts op, int b0, const int* __restrict__ accept_in, int* __restrict__ used_out,
+    const double* __restrict__ rec_in, double* __restrict__ Apart, int* __restrict__ chunk_used, int G, int rstride)
+{
+    using SH = GramShared<CMAX>;
+    constexpr int NT = SH::NT, REC = SH::REC;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SH& sh = *reinterpret_cast<SH*>(smem_raw);
     int* sUse = reinterpret_cast<int*>(smem_raw + ((sizeof(SH) + 15) / 16) * 16);
@@ -304,127 +367,56 @@ __global__ __launch_bounds__((GramShared<CMAX, STEREO>::NT)) void k_feat_gram(
     for (int i = 0; i < 6; ++i) bacc[i] = 0.0;
     int nused = 0;
 
-    for (int j = g; j < F; j += G) {
-        if (!sUse[j]) continue;
-        const size_t oidx = (size_t)b * fv.fmax + j;
-        const int a = fv.anchor[oidx];
-        const double* pf = fv.pf + oidx * 3;
-        const double px = pf[0], py = pf[1], pz = pf[2];
-        const int rows = feat_phase1<CMAX, STEREO>(fv, op, b, j, C, sh.f);
-        const int nobs = sh.f.nobs, nu = 3 * nobs;
-        feat_phase2<CMAX, STEREO>(sh.f, rows);
-        if (tid < C) sh.obs_of_slot[tid] = -1;
-        __syncthreads();
-        if (tid < nobs) {
-            const int so = sh.f.slot[tid];
-            sh.obs_of_slot[so] = tid;
-            sh.cna[tid] = so != a;
-            sh.pfl[tid] = !(op.selected_variant && so == a);
+    // software pipeline: the record of the next used feature is fetched while the current one is reduced
+    int jn = g;
+    while (jn < F && !sUse[jn]) jn += G;
+    int buf = 0;
+    if (jn < F) for (int e = tid; e < REC; e += NT) sh.rec[0][e] = rec_in[((size_t)b * fv.fmax + jn) * REC + e];
+    __syncthreads();
+    while (jn < F) {
+        const int j = jn;
+        jn += G;
+        while (jn < F && !sUse[jn]) jn += G;
+        double pre[(REC + NT - 1) / NT];
+        if (jn < F) {
+#pragma unroll
+            for (int u = 0; u < (REC + NT - 1) / NT; ++u) { const int e = tid + u * NT; pre[u] = e < REC ? rec_in[((size_t)b * fv.fmax + jn) * REC + e] : 0.0; }
         }
-        // U = Q[:, 0:3] = H1 H2 H3 e_k ;  rp = (I - U U^T) r      (wave 0, registers)
-        if (tid < WAVE) {
-            constexpr int PER = (RR + WAVE - 1) / WAVE;
-            double ucol[3][PER], rr[PER];
-#pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                const int i = tid + u * WAVE;
-                rr[u] = (i < rows) ? sh.f.res[i / RPO][i % RPO] : 0.0;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) ucol[k][u] = (i == k) ? 1.0 : 0.0;
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-#pragma unroll
-                for (int q = 2; q >= 0; --q) {
-                    double w = 0.0;
-#pragma unroll
-                    for (int u = 0; u < PER; ++u) { const int i = tid + u * WAVE; w += (i < RR ? sh.f.V[q][i] : 0.0) * ucol[k][u]; }
-                    w = wave_sum(w) * sh.f.tau[q];
-#pragma unroll
-                    for (int u = 0; u < PER; ++u) { const int i = tid + u * WAVE; ucol[k][u] -= w * (i < RR ? sh.f.V[q][i] : 0.0); }
-                }
-            }
-            double c3[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                double w = 0.0;
-#pragma unroll
-                for (int u = 0; u < PER; ++u) w += ucol[k][u] * rr[u];
-                c3[k] = wave_sum(w);
-            }
-#pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                const int i = tid + u * WAVE;
-                if (i < RR) {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) sh.U[i][k] = (i < rows) ? ucol[k][u] : 0.0;
-                    sh.rp[i] = rr[u] - (ucol[0][u] * c3[0] + ucol[1][u] * c3[1] + ucol[2][u] * c3[2]);
-                }
-            }
-        }
-        __syncthreads();
-        // Z = Gblk^T U, g = Gblk^T rp
-        for (int it = tid; it < nu * 4; it += NT) {
-            const int u = it >> 2, k = it & 3, o = u / 3, m = u - 3 * o;
+        const double* rc = sh.rec[buf];
+        const int nobs = (int)rc[0], a = (int)rc[1];
+        const double px = rc[2], py = rc[3], pz = rc[4];
+        // sums over observations: Ns, hs (all), Nsa, hsa (obs != anchor)
+        if (tid < 24) {
+            const int comp = tid % 12, anch = tid / 12;
             double s = 0.0;
-            if (k < 3) {
-#pragma unroll
-                for (int t = 0; t < RPO; ++t) s += sh.f.G[o][t][m] * sh.U[RPO * o + t][k];
-                sh.Z[u][k] = s;
-            } else {
-#pragma unroll
-                for (int t = 0; t < RPO; ++t) s += sh.f.G[o][t][m] * sh.rp[RPO * o + t];
-                sh.g[u] = s;
+            for (int o = 0; o < nobs; ++o) {
+                const double* ro = rc + REC_HDR + REC_OBS * o;
+                if (!anch || ro[1] != 0.0) s += ro[3 + comp];
             }
+            sh.sums[buf][tid] = s;
         }
         __syncthreads();
-        // W = blockdiag(G_o^T G_o) - Z Z^T
-        for (int u = tid >> 5; u < nu; u += NT / 32) {
-            for (int u2 = tid & 31; u2 < nu; u2 += 32) {
-                double s = -(sh.Z[u][0] * sh.Z[u2][0] + sh.Z[u][1] * sh.Z[u2][1] + sh.Z[u][2] * sh.Z[u2][2]);
-                const int o = u / 3, o2 = u2 / 3;
-                if (o == o2) {
-                    const int m = u - 3 * o, m2 = u2 - 3 * o2;
-#pragma unroll
-                    for (int t = 0; t < RPO; ++t) s += sh.f.G[o][t][m] * sh.f.G[o][t][m2];
-                }
-                sh.W[u][u2] = s;
-            }
-        }
-        __syncthreads();
-        // anchor sums: Wa = sum_{o != anchor} W[o-block, :],  ga likewise
-        for (int u2 = tid; u2 < nu + 1; u2 += NT) {
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                double s = 0.0;
-                if (u2 < nu) { for (int o = 0; o < nobs; ++o) if (sh.cna[o]) s += sh.W[3 * o + m][u2]; sh.Wa[m][u2] = s; }
-                else { for (int o = 0; o < nobs; ++o) if (sh.cna[o]) s += sh.g[3 * o + m]; sh.ga[m] = s; }
-            }
-        }
-        __syncthreads();
-        if (tid < 9) {
-            const int m = tid / 3, m2 = tid - 3 * m;
-            double s = 0.0;
-            for (int o = 0; o < nobs; ++o) if (sh.cna[o]) s += sh.Wa[m][3 * o + m2];
-            sh.Waa[tid] = s;
-        }
-        __syncthreads();
-        // slot-pair blocks
         if (pair) {
-            const int o = sh.obs_of_slot[c], o2 = sh.obs_of_slot[c2];
+            const double* sm = sh.sums[buf];
+            double Nsi[9];
+            inv3sym(sm, Nsi);
+            int o = -1, o2 = -1;
+            for (int q = 0; q < nobs; ++q) { const int sl = (int)rc[REC_HDR + REC_OBS * q]; if (sl == c) o = q; if (sl == c2) o2 = q; }
+            const double* ro = rc + REC_HDR + REC_OBS * (o >= 0 ? o : 0);
+            const double* ro2 = rc + REC_HDR + REC_OBS * (o2 >= 0 ? o2 : 0);
             if (o >= 0 && o2 >= 0) {
-                double Wb[9], WX[9], XtW[9], XtWX[9];
+                double Y2[9], NY[9], Wb[9], WX[9], XtW[9], XtWX[9];
+                mul33(Nsi, ro2 + 3, Y2);                       // Ns^-1 N_o'
+                mul33(ro + 3, Y2, NY);                         // N_o Ns^-1 N_o'
 #pragma unroll
-                for (int m = 0; m < 3; ++m)
-#pragma unroll
-                    for (int m2 = 0; m2 < 3; ++m2) Wb[3 * m + m2] = sh.W[3 * o + m][3 * o2 + m2];
+                for (int i = 0; i < 9; ++i) Wb[i] = (o == o2 ? ro[3 + i] : 0.0) - NY[i];
                 mulX(Wb, px, py, pz, WX);
                 mulXt(Wb, px, py, pz, XtW);
                 mulXt(WX, px, py, pz, XtWX);
-                const double stt = (sh.cna[o] && sh.cna[o2]) ? 1.0 : 0.0;
-                const double stp = (sh.cna[o] && sh.pfl[o2]) ? -1.0 : 0.0;
-                const double spt = (sh.pfl[o] && sh.cna[o2]) ? -1.0 : 0.0;
-                const double spp = (sh.pfl[o] && sh.pfl[o2]) ? 1.0 : 0.0;
+                const double stt = (ro[1] != 0.0 && ro2[1] != 0.0) ? 1.0 : 0.0;
+                const double stp = (ro[1] != 0.0 && ro2[2] != 0.0) ? -1.0 : 0.0;
+                const double spt = (ro[2] != 0.0 && ro2[1] != 0.0) ? -1.0 : 0.0;
+                const double spp = (ro[2] != 0.0 && ro2[2] != 0.0) ? 1.0 : 0.0;
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -435,54 +427,74 @@ __global__ __launch_bounds__((GramShared<CMAX, STEREO>::NT)) void k_feat_gram(
                         acc[6 * (3 + q) + 3 + q2] += spp * Wb[3 * q + q2];
                     }
             }
-            if (c == a && o2 >= 0) {              // rows theta_anchor: -X^T Wa[:, o2] [cna X, -pfl I]
-                double M[9], XtM[9], XtMX[9];
+            if (c == a && o2 >= 0) {              // rows theta_anchor: -X^T Wa_o' [cna X, -pfl I],  Wa_o' = cna N_o' - Nsa Ns^-1 N_o'
+                double Y2[9], M[9], XtM[9], XtMX[9];
+                mul33(Nsi, ro2 + 3, Y2);
+                mul33(sm + 12, Y2, M);
 #pragma unroll
-                for (int m = 0; m < 3; ++m)
-#pragma unroll
-                    for (int m2 = 0; m2 < 3; ++m2) M[3 * m + m2] = sh.Wa[m][3 * o2 + m2];
+                for (int i = 0; i < 9; ++i) M[i] = (ro2[1] != 0.0 ? ro2[3 + i] : 0.0) - M[i];
                 mulXt(M, px, py, pz, XtM);
                 mulX(XtM, px, py, pz, XtMX);
-                const double s1 = sh.cna[o2] ? -1.0 : 0.0, s2 = sh.pfl[o2] ? 1.0 : 0.0;
+                const double s1 = ro2[1] != 0.0 ? -1.0 : 0.0, s2 = ro2[2] != 0.0 ? 1.0 : 0.0;
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
 #pragma unroll
                     for (int q2 = 0; q2 < 3; ++q2) { acc[6 * q + q2] += s1 * XtMX[3 * q + q2]; acc[6 * q + 3 + q2] += s2 * XtM[3 * q + q2]; }
             }
-            if (c2 == a && o >= 0) {              // cols theta_anchor: [cna X, -pfl I]^T Wa[:, o]^T (-X)
-                double M[9], MX[9], XtMX[9];
+            if (c2 == a && o >= 0) {              // cols theta_anchor: transpose of the above with o
+                double Y1[9], M[9], Mt[9], MX[9], XtMX[9];
+                mul33(Nsi, ro + 3, Y1);
+                mul33(sm + 12, Y1, M);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) M[i] = (ro[1] != 0.0 ? ro[3 + i] : 0.0) - M[i];      // Wa_o (3x3)
 #pragma unroll
                 for (int m = 0; m < 3; ++m)
 #pragma unroll
-                    for (int m2 = 0; m2 < 3; ++m2) M[3 * m + m2] = sh.Wa[m2][3 * o + m];
-                mulX(M, px, py, pz, MX);
+                    for (int m2 = 0; m2 < 3; ++m2) Mt[3 * m + m2] = M[3 * m2 + m];
+                mulX(Mt, px, py, pz, MX);
                 mulXt(MX, px, py, pz, XtMX);
-                const double s1 = sh.cna[o] ? -1.0 : 0.0, s2 = sh.pfl[o] ? 1.0 : 0.0;
+                const double s1 = ro[1] != 0.0 ? -1.0 : 0.0, s2 = ro[2] != 0.0 ? 1.0 : 0.0;
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
 #pragma unroll
                     for (int q2 = 0; q2 < 3; ++q2) { acc[6 * q + q2] += s1 * XtMX[3 * q + q2]; acc[6 * (3 + q) + q2] += s2 * MX[3 * q + q2]; }
             }
-            if (c == a && c2 == a) {
-                double MX[9], XtMX[9];
-                mulX(sh.Waa, px, py, pz, MX);
+            if (c == a && c2 == a) {              // Waa = Nsa - Nsa Ns^-1 Nsa
+                double Y[9], M[9], MX[9], XtMX[9];
+                mul33(Nsi, sm + 12, Y);
+                mul33(sm + 12, Y, M);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) M[i] = sm[12 + i] - M[i];
+                mulX(M, px, py, pz, MX);
                 mulXt(MX, px, py, pz, XtMX);
 #pragma unroll
                 for (int q = 0; q < 9; ++q) acc[6 * (q / 3) + q % 3] += XtMX[q];
             }
             if (c == c2) {
+                double gy[3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) gy[m] = Nsi[3 * m] * sm[9] + Nsi[3 * m + 1] * sm[10] + Nsi[3 * m + 2] * sm[11];
                 if (o >= 0) {
-                    const double g0 = sh.g[3 * o], g1 = sh.g[3 * o + 1], g2 = sh.g[3 * o + 2];
-                    if (sh.cna[o]) { bacc[0] += pz * g1 - py * g2; bacc[1] += -pz * g0 + px * g2; bacc[2] += py * g0 - px * g1; }
-                    if (sh.pfl[o]) { bacc[3] -= g0; bacc[4] -= g1; bacc[5] -= g2; }
+                    double go[3];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) go[m] = ro[12 + m] - (ro[3 + 3 * m] * gy[0] + ro[3 + 3 * m + 1] * gy[1] + ro[3 + 3 * m + 2] * gy[2]);
+                    if (ro[1] != 0.0) { bacc[0] += pz * go[1] - py * go[2]; bacc[1] += -pz * go[0] + px * go[2]; bacc[2] += py * go[0] - px * go[1]; }
+                    if (ro[2] != 0.0) { bacc[3] -= go[0]; bacc[4] -= go[1]; bacc[5] -= go[2]; }
                 }
                 if (c == a) {
-                    const double g0 = sh.ga[0], g1 = sh.ga[1], g2 = sh.ga[2];
-                    bacc[0] -= pz * g1 - py * g2; bacc[1] -= -pz * g0 + px * g2; bacc[2] -= py * g0 - px * g1;
+                    double gaa[3];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) gaa[m] = sm[21 + m] - (sm[12 + 3 * m] * gy[0] + sm[12 + 3 * m + 1] * gy[1] + sm[12 + 3 * m + 2] * gy[2]);
+                    bacc[0] -= pz * gaa[1] - py * gaa[2]; bacc[1] -= -pz * gaa[0] + px * gaa[2]; bacc[2] -= py * gaa[0] - px * gaa[1];
                 }
             }
         }
         ++nused;
+        if (jn < F) {
+#pragma unroll
+            for (int u = 0; u < (REC + NT - 1) / NT; ++u) { const int e = tid + u * NT; if (e < REC) sh.rec[buf ^ 1][e] = pre[u]; }
+        }
+        buf ^= 1;
         __syncthreads();
     }
     double* out = Apart + ((size_t)bl * G + g) * rstride;      // [ncol][ncol+1] row-major, b in the last column
@@ -606,16 +618,19 @@ template <int CMAX, bool STEREO>
 static void launch_ft(const FactoredLaunch& L, hipStream_t st)
 {
     if (L.stage == 0) {
-        const size_t sm = sizeof(Gate2Shared<CMAX, STEREO>);
-        hipFuncSetAttribute((const void*)k_feat_gate2<CMAX, STEREO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        hipLaunchKernelGGL((k_feat_gate2<CMAX, STEREO>), dim3(L.fmax_used, L.nb), dim3(GATE2_NT), sm, st,
-                           L.cv, L.fv, L.op, L.b0, L.gamma, L.accept);
+        hipLaunchKernelGGL((k_feat_gate2<CMAX, STEREO>), dim3(L.fmax_used, L.nb), dim3(GATE_NT), 0, st,
+                           L.cv, L.fv, L.op, L.b0, L.gamma, L.accept, L.rec);
     } else {
-        const size_t sm = ((sizeof(GramShared<CMAX, STEREO>) + 15) / 16) * 16 + sizeof(int) * (size_t)L.fv.fmax;
-        hipFuncSetAttribute((const void*)k_feat_gram<CMAX, STEREO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        hipLaunchKernelGGL((k_feat_gram<CMAX, STEREO>), dim3(L.G, L.nb), dim3(GramShared<CMAX, STEREO>::NT), sm, st,
-                           L.fv, L.op, L.b0, L.accept, L.used, L.Apart, L.chunk_used, L.G, L.rstride);
+        const size_t sm = ((sizeof(GramShared<CMAX>) + 15) / 16) * 16 + sizeof(int) * (size_t)L.fv.fmax;
+        hipLaunchKernelGGL((k_feat_gram<CMAX, STEREO>), dim3(L.G, L.nb), dim3(GramShared<CMAX>::NT), sm, st,
+                           L.fv, L.op, L.b0, L.accept, L.used, L.rec, L.Apart, L.chunk_used, L.G, L.rstride);
     }
+}
+
+int factored_rec_size(int cmax)
+{
+    const int cls = cmax <= 6 ? 6 : (cmax <= 11 ? 11 : (cmax <= 16 ? 16 : -1));
+    return cls < 0 ? 0 : rec_size(cls);
 }
 
 int launch_factored(const FactoredLaunch& L, hipStream_t st)

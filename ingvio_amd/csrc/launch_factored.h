@@ -12,6 +12,7 @@ struct FactoredLaunch {
     double* gamma;
     int* accept;
     int* used;
+    double* rec;          // [B][fmax][rec_size] per-feature records (gate -> gram)
     double* Apart;
     int* chunk_used;
     int G, rstride;
@@ -26,3 +27,4 @@ struct FactoredLaunch {
 };
 
 int launch_factored(const FactoredLaunch& L, hipStream_t st);
+int factored_rec_size(int cmax);
