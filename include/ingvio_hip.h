@@ -187,6 +187,9 @@ int ingvio_frame_stage(ingvio_ctx* ctx, int b0, int nb, const ingvio_frame_step*
 int ingvio_frame_run(ingvio_ctx* ctx, int restore_prior);
 int ingvio_frame_fetch(ingvio_ctx* ctx, int b0, int nb, double* dx_out, int* accepted, int* rows_out);
 
+/* debug: shader-clock stamps written by block (0,0) of the instrumented kernels (see dev_common.h) */
+int ingvio_debug_read(ingvio_ctx* ctx, long long* out, int n);
+
 /* per-kernel device time, measured with hipEvents on the context's stream.  enable=1 brackets
  * every kernel launch with events (adds launch-side overhead, off by default). */
 int ingvio_profile_enable(ingvio_ctx* ctx, int enable);

@@ -25,7 +25,7 @@ EXPORTS = [
     "ingvio_cov_restore", "ingvio_propagate", "ingvio_propagate_fused", "ingvio_augment_clone", "ingvio_marginalize",
     "ingvio_append_independent", "ingvio_ekf_update", "ingvio_chi2_gamma", "ingvio_msckf_update", "ingvio_qr_compress",
     "ingvio_frame_stage", "ingvio_frame_run", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_reset",
-    "ingvio_profile_get", "ingvio_set_msckf_method",
+    "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_debug_read",
 ]
 
 
@@ -158,6 +158,11 @@ class Context:
     def set_method(self, method):
         """'dense' (literal TSQR path) or 'factored' (default, structure-exploiting information form)."""
         self._chk(self.L.ingvio_set_msckf_method(self.h, {"dense": 0, "factored": 1}[method]))
+
+    def debug_read(self, n=32):
+        out = (C.c_longlong * n)()
+        self._chk(self.L.ingvio_debug_read(self.h, out, n))
+        return list(out)
 
     def stream(self):
         return self.L.ingvio_ctx_stream(self.h)

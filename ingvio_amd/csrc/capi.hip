@@ -19,10 +19,10 @@
 namespace {
 
 enum ProfId { PF_RESTORE, PF_PROPAGATE, PF_AUGMENT, PF_GATE, PF_FOLD, PF_MERGE, PF_EKF_CORE, PF_DOWNDATE, PF_MARG,
-              PF_GATE2, PF_GRAM, PF_INFO, PF_COUNT };
+              PF_GATE2, PF_GRAM, PF_INFO, PF_APPLY, PF_COUNT };
 const char* kProfNames[PF_COUNT] = { "restore", "k_propagate", "k_augment", "k_msckf_gate", "k_msckf_fold",
                                      "k_msckf_merge", "k_ekf_core", "k_downdate", "k_marginalize",
-                                     "k_feat_gate2", "k_feat_gram", "k_info_update" };
+                                     "k_feat_gate2", "k_feat_gram", "k_info_update", "k_info_apply" };
 struct ProfRec { int id; hipEvent_t a, b; };
 
 }  // namespace
@@ -213,11 +213,9 @@ int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int s
     L.dx = c->d_dx; L.m_out = c->d_m + b0; L.nc_out = c->d_nc + b0; L.status = c->d_status;
     { ProfScope p(c, PF_GATE2); L.stage = 0; if (launch_factored(L, c->st)) return INGVIO_E_UNSUPPORTED; }
     { ProfScope p(c, PF_GRAM); L.stage = 1; launch_factored(L, c->st); }
+    L.mstride = c->ystride; L.n_cap = c->d.n_max;
     { ProfScope p(c, PF_INFO); L.stage = 2; launch_factored(L, c->st); }
-    EkfLaunch E;
-    memset(&E, 0, sizeof E);
-    E.cv = view(c); E.b0 = b0; E.nb = nb; E.m = L.m_out; E.Y = L.T; E.ystride = c->ystride; E.status = c->d_status;
-    { ProfScope p(c, PF_DOWNDATE); launch_downdate(E, c->d.n_max, c->st, L.Pc); }
+    { ProfScope p(c, PF_APPLY); L.stage = 3; launch_factored(L, c->st); }
     return last_launch(c);
 }
 
@@ -703,6 +701,16 @@ int ingvio_set_msckf_method(ingvio_ctx* c, int method)
 {
     if (!c || method < 0 || method > 1) return INGVIO_E_ARG;
     c->method = method;
+    return INGVIO_OK;
+}
+
+int ingvio_debug_read(ingvio_ctx* c, long long* out, int n)
+{
+    if (!c || !out || n < 1 || n > 64) return INGVIO_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    long long a[64], bq[64];
+    if (dbg_read_factored(a, 64) || dbg_read_cov(bq, 64)) return INGVIO_E_HIP;
+    for (int i = 0; i < n; ++i) out[i] = i < 16 ? a[i] : bq[i];
     return INGVIO_OK;
 }
 

@@ -55,3 +55,14 @@ __device__ __forceinline__ double wave_sum(double x)
     for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, WAVE);
     return x;
 }
+
+// phase-timing probes (debug): block (0,0) lane 0 stamps the shader clock; read with ingvio_debug_read
+static __device__ long long g_dbg[64];      // one copy per translation unit (no -fgpu-rdc)
+__device__ __forceinline__ void dbg_stamp(int slot)
+{
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_dbg[slot] = clock64();
+}
+static inline int dbg_read_local(long long* out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(long long) * n);
+}

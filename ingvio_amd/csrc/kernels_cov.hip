@@ -6,6 +6,7 @@
 
 #define PROP_THREADS 256
 #define NA_MAX 20      // 15 IMU + 4 clock biases + clock drift
+#define PROP_KCH 10    // IMU steps staged in LDS per fetch
 
 // ---------------------------------------------------------------------------------------------
 // K1: StateManager::propagateStateCov (StateManager.cpp:42-119), k IMU steps fused.
@@ -25,21 +26,30 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
     const int n = cv.n[b], ld = cv.ldp;
     double* P = cov_ptr(cv, b);
 
-    __shared__ double sPhi[225], sQ[225], sStep[225], sG[180], sPG[180], sT1[225], sT2[225];
+    __shared__ double sPhi[225], sQ[225], sPG[180], sT1[225], sT2[225];
+    __shared__ double sAll[PROP_KCH * 405];      // a chunk of steps' (Phi, G~) fetched at once: one memory latency per chunk
     __shared__ double sPhiA[NA_MAX * NA_MAX], sQA[NA_MAX * NA_MAX], sX[NA_MAX * NA_MAX], sY[NA_MAX * NA_MAX];
     __shared__ int sA[NA_MAX];
     __shared__ int sNA;
 
     const double sig[4] = { sg0, sg1, sg2, sg3 };
+    dbg_stamp(16);
     if (tid < 225) { sPhi[tid] = (tid % 15 == tid / 15) ? 1.0 : 0.0; sQ[tid] = 0.0; }
     const double* PhiB = Phi + (size_t)bl * k * 225;
     const double* GB = G + (size_t)bl * k * 180;
     const double* dtB = dts + (size_t)bl * k;
     __syncthreads();
     for (int s = 0; s < k; ++s) {
-        if (tid < 225) sStep[tid] = PhiB[s * 225 + tid];
-        if (tid < 180) sG[tid] = GB[s * 180 + tid] * sig[(tid / 15) / 3];   // G_tmp, :92-96
-        __syncthreads();
+        if (s % PROP_KCH == 0) {
+            const int cnt = min(PROP_KCH, k - s);
+            for (int e = tid; e < cnt * 405; e += PROP_THREADS) {
+                const int q = e / 405, w = e - q * 405;
+                sAll[e] = w < 225 ? PhiB[(s + q) * 225 + w] : GB[(s + q) * 180 + (w - 225)] * sig[((w - 225) / 15) / 3];   // G_tmp, :92-96
+            }
+            __syncthreads();
+        }
+        const double* sStep = sAll + (s % PROP_KCH) * 405;
+        const double* sG = sStep + 225;
         const double dt = dtB[s];
         const int i = tid % 15, j = tid / 15;
         if (tid < 180) {
@@ -62,6 +72,7 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
         }
         __syncthreads();
     }
+    dbg_stamp(17);
     // active set + GNSS clock block (thread 0, <= 5x5 work)
     if (tid == 0) {
         int gi[5], na = 15;
@@ -104,6 +115,7 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
         }
     }
     __syncthreads();
+    dbg_stamp(18);
     const int na = sNA;
     // strip rows outside A
     const int r = blockIdx.x * PROP_THREADS + tid;
@@ -126,6 +138,7 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
             P[sA[a] + (size_t)r * ld] = o[a];        // :89 upper strip = transpose
         }
     }
+    dbg_stamp(19);
     // A x A block, tile 0 only
     if (blockIdx.x == 0) {
         for (int e = tid; e < na * na; e += PROP_THREADS) {
@@ -152,6 +165,7 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
             P[sA[a] + (size_t)sA[c] * ld] = 0.5 * (sX[a * NA_MAX + c] + sX[c * NA_MAX + a]);   // :118
         }
     }
+    dbg_stamp(20);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -324,3 +338,5 @@ void launch_restore(CovView cv, int n_cap, const double* snap, const int* n_snap
     hipLaunchKernelGGL(k_restore, dim3((n_cap + MARG_COLS - 1) / MARG_COLS, cv.B), dim3(256), 0, st, cv, snap, n_snap);
     hipLaunchKernelGGL(k_post_restore, dim3((cv.B + 255) / 256), dim3(256), 0, st, cv, n_snap);
 }
+
+int dbg_read_cov(long long* out, int n) { return dbg_read_local(out, n); }

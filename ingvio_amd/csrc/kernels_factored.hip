@@ -146,8 +146,10 @@ __global__ __launch_bounds__(GATE_NT) void k_feat_gate2(
     const int a = fv.anchor[oidx];
     const double* pf = fv.pf + oidx * 3;
     const double px = pf[0], py = pf[1], pz = pf[2];
+    dbg_stamp(8);
     load_gidx<CMAX, STEREO>(fv, b, C, sh.f);
     const int rows = feat_phase1<CMAX, STEREO>(fv, op, b, j, C, sh.f);
+    dbg_stamp(9);
     const int nobs = sh.f.nobs, rho = rows - 3;
     double* rec = rec_out + oidx * rec_size(CMAX);
     if (rho <= 0) {
@@ -240,6 +242,7 @@ __global__ __launch_bounds__(GATE_NT) void k_feat_gate2(
             }
         }
     }
+    dbg_stamp(10);
     for (int jj = 0; jj < rows; ++jj) {
         const int buf = jj & 1, bj = jj >> 2, rj = jj & 3;
 #pragma unroll
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(GATE_NT) void k_feat_gate2(
             }
     }
     __syncthreads();
+    dbg_stamp(11);
     if (tid == 0) {
         // -border = Y^T S^-1 Y, Y = [r | Hf];  gamma = W00 - f^T Wff^-1 f
         double W[4][4];
@@ -515,18 +519,23 @@ __global__ __launch_bounds__((GramShared<CMAX>::NT)) void k_feat_gram(
 //   T = Pc M (-> Tout), Pc copy (-> Pcout), dx = Pc t.   P <- P - T Pc^T is done by k_downdate.
 // ---------------------------------------------------------------------------------------------
 #define INFO_NT 512
+
+// The solve always runs at the compile-time size NC = 6 * (c_max class): clones missing from the
+// window are zero rows/columns of A, for which K1 = s^2 I and M = 0 (harmless), so no loop needs a
+// runtime guard and every register array is fully used.
+template <int NC>
 __global__ __launch_bounds__(INFO_NT) void k_info_update(
     CovView cv, FrameView fv, int b0, const double* __restrict__ Apart, const int* __restrict__ chunk_used, int G, int rstride,
-    const double* __restrict__ noise_all, double* __restrict__ Tall, double* __restrict__ Pcall, int ystride,
+    const double* __restrict__ noise_all, double* __restrict__ Mall, int mstride, double* __restrict__ Pcall, int ystride,
     double* __restrict__ dx_all, int* __restrict__ m_out, int* __restrict__ nc_out, int* __restrict__ status)
 {
+    constexpr int LA = 2 * NC + 1, MP = (NC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* aug = reinterpret_cast<double*>(smem_raw);
+    int* sCol = reinterpret_cast<int*>(aug + (size_t)NC * LA);
+    __shared__ unsigned long long sBest[2];
     const int bl = blockIdx.x, b = b0 + bl, tid = threadIdx.x;
     const int C = fv.n_clones[b], ncol = 6 * C, n = cv.n[b], ld = cv.ldp;
-    const int LA = 2 * ncol + 1;
-    int* sCol = reinterpret_cast<int*>(aug + (size_t)ncol * LA);
-    __shared__ int sPiv;
     double* dx = dx_all + (size_t)b * ld;
     int total = 0;
     for (int g = 0; g < G; ++g) total += chunk_used[bl * G + g];
@@ -537,80 +546,227 @@ __global__ __launch_bounds__(INFO_NT) void k_info_update(
     }
     const double* P = cov_ptr(cv, b);
     const double var = noise_all[bl];
-    for (int c = tid; c < ncol; c += INFO_NT) sCol[c] = fv.clone_idx[(size_t)b * fv.cmax + c / 6] + c % 6;
+    dbg_stamp(0);
+    for (int c = tid; c < NC; c += INFO_NT) { const int cc = c < ncol ? c : 0; sCol[c] = fv.clone_idx[(size_t)b * fv.cmax + cc / 6] + cc % 6; }
+    if (tid < 2) sBest[tid] = 0ULL;
     const int tx = tid & 63, ty = tid >> 6;               // 64 x 8 thread grid: no runtime div/mod in the loops
-    for (int i = ty; i < ncol; i += INFO_NT / 64) {
-        for (int j = tx; j <= ncol; j += 64) {
-            const size_t e = (size_t)i * (ncol + 1) + j;
+    for (int i = ty; i < NC; i += INFO_NT / 64) {
+        for (int j = tx; j <= NC; j += 64) {
             double s = 0.0;
-            for (int g = 0; g < G; ++g)
-                if (chunk_used[bl * G + g]) s += Apart[((size_t)bl * G + g) * rstride + e];
-            aug[i * LA + ncol + j] = s;
+            const int jj = j == NC ? ncol : j;                  // b lives in column ncol of the partials
+            if (i < ncol && (j < ncol || j == NC)) {
+                const size_t e = (size_t)i * (ncol + 1) + jj;
+                for (int g = 0; g < G; ++g)
+                    if (chunk_used[bl * G + g]) s += Apart[((size_t)bl * G + g) * rstride + e];
+            }
+            aug[i * LA + NC + j] = s;
         }
     }
     __syncthreads();
-    for (int i = ty; i < ncol; i += INFO_NT / 64) {
-        for (int j = tx; j < ncol; j += 64) {              // consecutive lanes: consecutive j -> coalesced P rows
-            double s = (i == j) ? var : 0.0;
+    dbg_stamp(1);
+    // K1 = A Pcc + s^2 I.  Lane j keeps column j of Pcc in registers (NC independent, coalesced loads: one
+    // memory latency instead of a dependent chain); KG row groups share the rows.
+    {
+        constexpr int KG = INFO_NT / NC;
+        const int j = tid % NC, g = tid / NC;
+        if (g < KG) {
+            double pc[NC];
             const int gj = sCol[j];
-            for (int k = 0; k < ncol; ++k) s += aug[i * LA + ncol + k] * P[gj + (size_t)sCol[k] * ld];   // Pcc[k][j] = P[gj, gk]
-            aug[i * LA + j] = s;
-        }
-    }
-    __syncthreads();
-    for (int k = 0; k < ncol; ++k) {
-        if (tid < WAVE) {                                   // partial pivoting
-            double best = -1.0; int bi = k;
-            for (int i = k + tid; i < ncol; i += WAVE) { const double v = fabs(aug[i * LA + k]); if (v > best) { best = v; bi = i; } }
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ob = __shfl_xor(best, off, WAVE); const int oi = __shfl_xor(bi, off, WAVE);
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            for (int k = 0; k < NC; ++k) pc[k] = P[gj + (size_t)sCol[k] * ld];      // Pcc[k][j] = P[gj, gk]
+            for (int i = g; i < NC; i += KG) {
+                double s = (i == j) ? var : 0.0;
+                const double* arow = aug + i * LA + NC;
+#pragma unroll
+                for (int k = 0; k < NC; ++k) s += arow[k] * pc[k];
+                aug[i * LA + j] = s;
             }
-            if (tid == 0) { sPiv = bi; if (!(best > 0.0)) atomicOr(&status[b], 4); }
         }
-        __syncthreads();
-        const int p = sPiv;
-        if (p != k) {
-            for (int j = k + tid; j < LA; j += INFO_NT) { const double t = aug[k * LA + j]; aug[k * LA + j] = aug[p * LA + j]; aug[p * LA + j] = t; }
-            __syncthreads();
-        }
-        const double inv = 1.0 / aug[k * LA + k];
-        for (int i = ty; i < ncol; i += INFO_NT / 64) {
-            if (i == k) continue;
-            const double f = aug[i * LA + k] * inv;
-            for (int j = k + 1 + tx; j < LA; j += 64) aug[i * LA + j] -= f * aug[k * LA + j];
-        }
-        __syncthreads();
-    }
-    for (int i = ty; i < ncol; i += INFO_NT / 64) {
-        const double d = 1.0 / aug[i * LA + i];
-        for (int j = tx; j <= ncol; j += 64) aug[i * LA + ncol + j] *= d;
     }
     __syncthreads();
-    double* T = Tall + (size_t)bl * ystride;
+    dbg_stamp(2);
+    // Gauss-Jordan with implicit partial pivoting, the augmented matrix [K1 | A | b] in REGISTERS:
+    // lane (tx, ty) owns columns {tx, tx + TXN} of rows {ty, ty + TYN, ...}.  Per step only the pivot
+    // row and the pivot column pass through LDS; the next pivot is found by the owners of column
+    // k+1 with an LDS atomicMax on (|value| bits, row).  No row is ever moved: perm[k] = pivot row.
+    constexpr int TXN = (LA + 1) / 2, TYN = INFO_NT / TXN, RPT = (NC + TYN - 1) / TYN;
+    double* rowbuf = aug;                      // LA      (LDS is free again once the registers are loaded)
+    double* colbuf = aug + LA + 1;             // NC
+    double* sPivVal = colbuf + NC;             // NC
+    int* sInv = reinterpret_cast<int*>(sPivVal + NC);      // NC : row -> solution index
+    const int gx = tid % TXN, gy = tid / TXN;
+    const bool active = gy < TYN;
+    const int j0 = gx, j1 = gx + TXN;
+    double v[RPT][2];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int i = gy + TYN * q;
+        v[q][0] = (active && i < NC) ? aug[i * LA + j0] : 0.0;
+        v[q][1] = (active && i < NC && j1 < LA) ? aug[i * LA + j1] : 0.0;
+        if (active && j0 == 0 && i < NC) {
+            const unsigned long long key = ((unsigned long long)__double_as_longlong(fabs(v[q][0])) & ~0xFFULL) | (unsigned long long)(255 - i);
+            atomicMax(&sBest[0], key);
+        }
+    }
+    unsigned usedmask = 0u;
+    __syncthreads();
+    for (int k = 0; k < NC; ++k) {
+        const unsigned long long best = sBest[k & 1];
+        const int p = 255 - (int)(best & 0xFFULL);
+        if (active) {
+            if (gy == p % TYN) {                           // owner of the pivot row publishes it
+                const int qp = p / TYN;
+                double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) if (q == qp) { r0 = v[q][0]; r1 = v[q][1]; }
+                rowbuf[j0] = r0;
+                if (j1 < LA) rowbuf[j1] = r1;
+                usedmask |= 1u << qp;
+            }
+            const int kc = k >= TXN ? 1 : 0;
+            if (gx == k - kc * TXN) {                      // owner of column k publishes it
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) { const int i = gy + TYN * q; if (i < NC) colbuf[i] = kc ? v[q][1] : v[q][0]; }
+            }
+        }
+        if (tid == 0) { sBest[(k + 1) & 1] = 0ULL; sInv[p] = k; if ((best >> 8) == 0ULL) atomicOr(&status[b], 4); }
+        __syncthreads();
+        if (active) {
+            const double piv = rowbuf[k];
+            if (tid == 0) sPivVal[k] = piv;
+            const double inv = 1.0 / piv;
+            const double r0 = rowbuf[j0], r1 = j1 < LA ? rowbuf[j1] : 0.0;
+            const int kn = k + 1, knc = kn >= TXN ? 1 : 0;
+            const bool own_next = kn < NC && gx == kn - knc * TXN;
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int i = gy + TYN * q;
+                if (i < NC && i != p) {
+                    const double f = colbuf[i] * inv;
+                    v[q][0] -= f * r0;
+                    v[q][1] -= f * r1;
+                    if (own_next && !((usedmask >> q) & 1u)) {
+                        const double nv = knc ? v[q][1] : v[q][0];
+                        const unsigned long long key = ((unsigned long long)__double_as_longlong(fabs(nv)) & ~0xFFULL) | (unsigned long long)(255 - i);
+                        atomicMax(&sBest[kn & 1], key);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // solution: row i holds component k = sInv[i], scaled by its pivot; stage [M | t] back into LDS rows
+    double* sol = aug + LA + 1 + 3 * NC + 8;           // NC x (NC + 1), past the small buffers
+    if (active) {
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int i = gy + TYN * q;
+            if (i < NC) {
+                const int ks = sInv[i];
+                const double d = 1.0 / sPivVal[ks];
+                if (j0 >= NC) sol[ks * (NC + 1) + (j0 - NC)] = v[q][0] * d;
+                if (j1 >= NC && j1 < LA) sol[ks * (NC + 1) + (j1 - NC)] = v[q][1] * d;
+            }
+        }
+    }
+    __syncthreads();
+    dbg_stamp(3);
+    // publish M (row-major MP x MP, zero padded) and t for the apply kernel; save Pc = P[:, clone cols]
+    // (the apply kernel updates P in place and must read the PRE-update columns)
+    double* Mg = Mall + (size_t)bl * mstride;
+    for (int i = ty; i < MP; i += INFO_NT / 64)
+        for (int j = tx; j < MP; j += 64) Mg[(size_t)i * MP + j] = (i < NC && j < NC) ? sol[i * (NC + 1) + j] : 0.0;
+    for (int i = tid; i < MP; i += INFO_NT) Mg[(size_t)MP * MP + i] = i < NC ? sol[i * (NC + 1) + NC] : 0.0;
     double* Pc = Pcall + (size_t)bl * ystride;
-    const int mp = (ncol + 3) & ~3;
-    for (int r = tid; r < n; r += INFO_NT) {
-        double d = 0.0;
-        for (int jb = 0; jb < ncol; jb += 16) {
-            double acc[16];
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj) acc[jj] = 0.0;
-            for (int k = 0; k < ncol; ++k) {
-                const double p = P[r + (size_t)sCol[k] * ld];
-                if (jb == 0) { Pc[r + (size_t)k * ld] = p; d += p * aug[k * LA + 2 * ncol]; }
-                const double* mrow = aug + k * LA + ncol + jb;
-#pragma unroll
-                for (int jj = 0; jj < 16; ++jj) if (jb + jj < ncol) acc[jj] += p * mrow[jj];
-            }
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj) if (jb + jj < ncol) T[r + (size_t)(jb + jj) * ld] = acc[jj];
-        }
-        dx[r] = d;
-        for (int j = ncol; j < mp; ++j) { T[r + (size_t)j * ld] = 0.0; Pc[r + (size_t)j * ld] = 0.0; }
+    for (int k = ty; k < MP; k += INFO_NT / 64) {
+        const int gk = k < NC ? sCol[k] : 0;
+        const bool real = k < ncol;
+        for (int r = tx; r < n; r += 64) Pc[r + (size_t)k * ld] = real ? P[r + (size_t)gk * ld] : 0.0;
     }
+    dbg_stamp(4);
     if (tid == 0) { m_out[bl] = ncol; nc_out[bl] = ncol; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8 + K10 + K11, MFMA FP64: one wave per 16-row tile ri of the state.
+//   T_ri = Pc[ri,:] M                      (16 x n, v_mfma_f64_16x16x4_f64, M streamed from L2)
+//   dx[ri] = Pc[ri,:] t
+//   P[ri, rj] -= T_ri Pc[rj,:]^T  for every 16-column tile rj <= ri, mirrored into the upper
+//   triangle (the reference's 0.5 (P + P^T), StateManager.cpp:411, without a second pass).
+// T_ri goes through LDS once to turn the MFMA C/D layout into the A-operand layout.
+// K4 = MP / 4 is a compile-time constant: all operand loads of a tile are issued before its MFMAs.
+// grid = (ceil(nt / 4), nb), 4 waves per workgroup.
+// ---------------------------------------------------------------------------------------------
+typedef double double4_f __attribute__((ext_vector_type(4)));
+
+template <int NC>
+__global__ __launch_bounds__(256) void k_info_apply(CovView cv, int b0, const double* __restrict__ Mall, int mstride,
+                                                    const double* __restrict__ Pcall, int ystride, const int* __restrict__ m_all,
+                                                    double* __restrict__ dx_all, int* __restrict__ status)
+{
+    constexpr int MP = (NC + 3) & ~3, K4 = MP / 4, JT = (MP + 15) / 16;
+    __shared__ double sT[4][16][MP + 2];
+    const int bl = blockIdx.y, b = b0 + bl;
+    if (m_all[bl] == 0) return;
+    const int n = cv.n[b], ld = cv.ldp, nt = (n + 15) >> 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ti = blockIdx.x * 4 + wave;
+    if (ti >= nt) return;
+    double* P = cov_ptr(cv, b);
+    const double* Pc = Pcall + (size_t)bl * ystride;
+    const double* M = Mall + (size_t)bl * mstride;
+    const double* tvec = M + (size_t)MP * MP;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int ra = min(ti * 16 + l15, n - 1);                    // clamped: rows >= n are computed but never stored
+    double afrag[K4];
+#pragma unroll
+    for (int k4 = 0; k4 < K4; ++k4) afrag[k4] = Pc[ra + (size_t)(4 * k4 + kq) * ld];
+    {
+        double d = 0.0;
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) d += afrag[k4] * tvec[4 * k4 + kq];
+        d += __shfl_xor(d, 16, WAVE);
+        d += __shfl_xor(d, 32, WAVE);
+        if (kq == 0 && ti * 16 + l15 < n) dx_all[(size_t)b * ld + ra] = d;
+    }
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
+        const int jc = min(jt * 16 + l15, MP - 1);
+        double bfrag[K4];
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) bfrag[k4] = M[(size_t)(4 * k4 + kq) * MP + jc];      // B[k][j] = M[k][j]
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[k4], bfrag[k4], acc, 0, 0, 0);
+        if (jt * 16 + l15 < MP) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sT[wave][kq + 4 * r][jc] = acc[r];      // C/D: col = lane&15, row = (lane>>4)+4r
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    double tfrag[K4];
+#pragma unroll
+    for (int k4 = 0; k4 < K4; ++k4) tfrag[k4] = sT[wave][l15][4 * k4 + kq];      // A[i][k] = T[i][k]
+    for (int tj = 0; tj <= ti; ++tj) {
+        const int rb = min(tj * 16 + l15, n - 1);
+        double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
+        double bfrag[K4];
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) bfrag[k4] = Pc[rb + (size_t)(4 * k4 + kq) * ld];      // B[k][j] = Pc[rj + j][k]
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tfrag[k4], bfrag[k4], acc, 0, 0, 0);
+        const int col = tj * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = ti * 16 + kq + 4 * r;
+            if (row < n && col < n && row >= col) {
+                const double v = P[col + (size_t)row * ld] - acc[r];      // read through the mirrored (coalesced) address
+                P[col + (size_t)row * ld] = v;
+                P[row + (size_t)col * ld] = v;
+                if (row == col && v < 0.0) atomicOr(&status[b], 2);      // StateManager.cpp:413-421
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -635,12 +791,26 @@ int factored_rec_size(int cmax)
 
 int launch_factored(const FactoredLaunch& L, hipStream_t st)
 {
+    const int ncm = 6 * L.fv.cmax;
+    if (L.stage == 3) {
+        const int nt = (L.n_cap + 15) / 16;
+#define APPLY_DISPATCH(NC)                                                                                            \
+        hipLaunchKernelGGL(k_info_apply<NC>, dim3((nt + 3) / 4, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, \
+                           L.ystride, L.m_out, L.dx, L.status);
+        if (ncm <= 36) { APPLY_DISPATCH(36) } else if (ncm <= 66) { APPLY_DISPATCH(66) } else { APPLY_DISPATCH(96) }
+#undef APPLY_DISPATCH
+        return 0;
+    }
     if (L.stage == 2) {
-        const int ncm = 6 * L.fv.cmax;
-        const size_t sm = sizeof(double) * (size_t)ncm * (2 * ncm + 1) + sizeof(int) * (size_t)ncm + 16;
-        hipFuncSetAttribute((const void*)k_info_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        hipLaunchKernelGGL(k_info_update, dim3(L.nb), dim3(INFO_NT), sm, st, L.cv, L.fv, L.b0, L.Apart, L.chunk_used, L.G, L.rstride,
-                           L.noise, L.T, L.Pc, L.ystride, L.dx, L.m_out, L.nc_out, L.status);
+#define INFO_DISPATCH(NC)                                                                                                   \
+        {                                                                                                                   \
+            const size_t sm = sizeof(double) * (size_t)NC * (2 * NC + 1) + sizeof(int) * (size_t)NC + 16;                     \
+            hipFuncSetAttribute((const void*)k_info_update<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);         \
+            hipLaunchKernelGGL(k_info_update<NC>, dim3(L.nb), dim3(INFO_NT), sm, st, L.cv, L.fv, L.b0, L.Apart, L.chunk_used, \
+                               L.G, L.rstride, L.noise, L.T, L.mstride, L.Pc, L.ystride, L.dx, L.m_out, L.nc_out, L.status);  \
+        }
+        if (ncm <= 36) { INFO_DISPATCH(36) } else if (ncm <= 66) { INFO_DISPATCH(66) } else { INFO_DISPATCH(96) }
+#undef INFO_DISPATCH
         return 0;
     }
     const int cm = L.fv.cmax;
@@ -654,3 +824,5 @@ int launch_factored(const FactoredLaunch& L, hipStream_t st)
 #undef DISPATCH
     return -1;
 }
+
+int dbg_read_factored(long long* out, int n) { return dbg_read_local(out, n); }

@@ -33,3 +33,4 @@ void launch_append(CovView cv, int b0, int nb, int size, const double* blk, hipS
 void launch_copy_ints(int* dst, const int* src, int count, hipStream_t st);
 void launch_snapshot(CovView cv, int n_cap, double* snap, int* n_snap, hipStream_t st);
 void launch_restore(CovView cv, int n_cap, const double* snap, const int* n_snap, hipStream_t st);
+int dbg_read_cov(long long* out, int n);

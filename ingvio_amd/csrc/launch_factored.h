@@ -3,7 +3,7 @@
 #include "dev_common.h"
 
 struct FactoredLaunch {
-    int stage;            // 0 gate2, 1 gram, 2 info update
+    int stage;            // 0 gate, 1 gram, 2 info solve, 3 info apply (+ downdate)
     int stereo;
     CovView cv;
     FrameView fv;
@@ -17,7 +17,8 @@ struct FactoredLaunch {
     int* chunk_used;
     int G, rstride;
     const double* noise;
-    double* T;
+    double* T;            // M (ncol x mp row-major) followed by t, per filter
+    int mstride, n_cap;
     double* Pc;
     int ystride;
     double* dx;
@@ -28,3 +29,4 @@ struct FactoredLaunch {
 
 int launch_factored(const FactoredLaunch& L, hipStream_t st);
 int factored_rec_size(int cmax);
+int dbg_read_factored(long long* out, int n);

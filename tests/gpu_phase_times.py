@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Shader-clock phase breakdown of the instrumented kernels (block (0,0) only); debugging aid."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import bench
+from ingvio_amd import capi, synth
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+ctx = capi.Context(batch=B, n_max=256, c_max=11, f_max=150, m_max=64)
+filters, steps, frames, infos = bench.build_batch(ctx, B, 0, 150, 11, 6, 52)
+ctx.snapshot(); pr = synth.PARAMS
+ctx.frame_stage(0, steps, frames, filters[0].sigma(), 1, pr["sigma_cb"], pr["sigma_rw"])
+for _ in range(3):
+    ctx.frame_run(restore_prior=True)
+d = ctx.debug_read(32)
+def seg(name, idx):
+    print(name, [d[b] - d[a] for a, b in zip(idx[:-1], idx[1:])], "total", d[idx[-1]] - d[idx[0]])
+seg("info_update [assemble,K1,GJ,T]", [0, 1, 2, 3, 4])
+seg("gate [phase1,blockinit,elim]", [8, 9, 10, 11])
+seg("propagate [compose,gnss,strip,AA]", [16, 17, 18, 19, 20])
