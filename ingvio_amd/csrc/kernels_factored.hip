@@ -17,6 +17,15 @@
 #include "feat_build.h"
 #include "launch_factored.h"
 
+// 1/x to full FP64 precision: v_rcp_f64 + two Newton steps (the IEEE division expands to ~3x the latency)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 __device__ __forceinline__ void cross3(double ax, double ay, double az, const double v[3], double out[3])
 {
     out[0] = ay * v[2] - az * v[1];
@@ -71,7 +80,9 @@ struct GateShared {
     FeatShared<CMAX, STEREO> f;
     int cna[CMAX];                                 // obs slot != anchor
     int pfl[CMAX];                                 // obs keeps its -I block (false only under Q10)
-    double col[2][4 * NBB];                        // published pivot column, double buffered
+    alignas(16) double X[4 * NBB][4];              // published panel L_ij D (blocked LDL^T)
+    double L[4][4];
+    double Dinv[4];
     double W4[16];
 };
 
@@ -130,7 +141,7 @@ __device__ __forceinline__ void su_pair(const double* __restrict__ P, int ld, in
 }
 
 template <int CMAX, bool STEREO>
-__global__ __launch_bounds__(GATE_NT) void k_feat_gate2(
+__global__ __launch_bounds__(GATE_NT, (GateShared<CMAX, STEREO>::BPT == 1 ? 5 : 3)) void k_feat_gate2(
     CovView cv, FrameView fv, MsckfOpts op, int b0, double* __restrict__ gamma_out, int* __restrict__ accept_out,
     double* __restrict__ rec_out)
 {
@@ -181,7 +192,8 @@ __global__ __launch_bounds__(GATE_NT) void k_feat_gate2(
     if (tid == 0) { rec[0] = nobs; rec[1] = a; rec[2] = px; rec[3] = py; rec[4] = pz; }
     __syncthreads();
 
-    const int nb = rows + 4, nbb = (nb + 3) >> 2, nblk = nbb * (nbb + 1) / 2;
+    const int rowsp = (rows + 3) & ~3;          // pivots padded to whole 4x4 blocks (mono with odd nobs): identity rows
+    const int nb = rowsp + 4, nbb = nb >> 2, nblk = nbb * (nbb + 1) / 2;
     const int ga = sh.f.gidx[6 * a];
     double val[BPT][4][4];
     int bi_[BPT], bk_[BPT];
@@ -229,12 +241,13 @@ __global__ __launch_bounds__(GATE_NT) void k_feat_gate2(
                     }
             }
         }
-        // border rows: [r | Hf]^T
+        // padding rows (decoupled unit pivots) and border rows [r | Hf]^T
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * bi + r;
-            if (i < rows || i >= nb) continue;
-            const int kb = i - rows;
+            if (i >= rows && i < rowsp && bi == bk) val[s][r][r] = 1.0;
+            if (i < rowsp || i >= nb) continue;
+            const int kb = i - rowsp;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int k = 4 * bk + c;
@@ -243,30 +256,69 @@ __global__ __launch_bounds__(GATE_NT) void k_feat_gate2(
         }
     }
     dbg_stamp(10);
-    for (int jj = 0; jj < rows; ++jj) {
-        const int buf = jj & 1, bj = jj >> 2, rj = jj & 3;
+    // Blocked LDL^T, 4 pivots per panel, 2 barriers per panel:
+    //   1. the owner of diagonal block (bj,bj) factorises it in registers, publishes L_jj and D^-1
+    //   2. panel blocks (bi,bj), bi > bj: X = S_ij L_jj^-T (= L_ij D), published to LDS
+    //   3. trailing blocks (bi,bk), bk > bj: S_ik -= X_i D^-1 X_k^T
+    // Only the first `rows` (a multiple of 4 here) rows/cols are pivots; the border block ends as -Y^T S^-1 Y.
+    const int npan = rowsp >> 2;
+    for (int bj = 0; bj < npan; ++bj) {
 #pragma unroll
         for (int s = 0; s < BPT; ++s) {
-            if (bk_[s] == bj) {
+            if (bi_[s] == bj && bk_[s] == bj) {
+                double (&Bq)[4][4] = val[s];
+                double dinv[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double v = rj == 0 ? val[s][r][0] : (rj == 1 ? val[s][r][1] : (rj == 2 ? val[s][r][2] : val[s][r][3]));
-                    sh.col[buf][4 * bi_[s] + r] = v;
+                for (int c = 0; c < 4; ++c) {
+                    dinv[c] = fast_rcp(Bq[c][c]);
+#pragma unroll
+                    for (int r = c + 1; r < 4; ++r) {
+                        const double l = Bq[r][c] * dinv[c];
+#pragma unroll
+                        for (int c2 = c + 1; c2 <= r; ++c2) Bq[r][c2] -= l * Bq[c2][c];
+                        sh.L[r][c] = l;
+                    }
+                    sh.Dinv[c] = dinv[c];
                 }
             }
         }
         __syncthreads();
-        const double inv = 1.0 / sh.col[buf][jj];
+        const double L10 = sh.L[1][0], L20 = sh.L[2][0], L21 = sh.L[2][1], L30 = sh.L[3][0], L31 = sh.L[3][1], L32 = sh.L[3][2];
 #pragma unroll
         for (int s = 0; s < BPT; ++s) {
-            if (bk_[s] >= bj) {                   // block still has columns > jj (or is the pivot block)
-                double ci[4], ck[4];
+            if (bk_[s] == bj && bi_[s] > bj) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { ci[r] = sh.col[buf][4 * bi_[s] + r] * inv; ck[r] = sh.col[buf][4 * bk_[s] + r]; }
+                for (int r = 0; r < 4; ++r) {
+                    const double x0 = val[s][r][0];
+                    const double x1 = val[s][r][1] - L10 * x0;
+                    const double x2 = val[s][r][2] - L20 * x0 - L21 * x1;
+                    const double x3 = val[s][r][3] - L30 * x0 - L31 * x1 - L32 * x2;
+                    double2* xr = reinterpret_cast<double2*>(sh.X[4 * bi_[s] + r]);
+                    xr[0] = make_double2(x0, x1); xr[1] = make_double2(x2, x3);
+                }
+            }
+        }
+        __syncthreads();
+        const double d0 = sh.Dinv[0], d1 = sh.Dinv[1], d2 = sh.Dinv[2], d3 = sh.Dinv[3];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+        for (int s = 0; s < BPT; ++s) {
+            if (bk_[s] > bj) {
+                // X_i rows (scaled by D^-1) preloaded with 16-byte LDS reads, X_k rows streamed
+                double a[4][4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) val[s][r][c] -= ci[r] * ck[c];
+                for (int r = 0; r < 4; ++r) {
+                    const double2* xr = reinterpret_cast<const double2*>(sh.X[4 * bi_[s] + r]);
+                    const double2 u0 = xr[0], u1 = xr[1];
+                    a[r][0] = u0.x * d0; a[r][1] = u0.y * d1; a[r][2] = u1.x * d2; a[r][3] = u1.y * d3;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double2* xc = reinterpret_cast<const double2*>(sh.X[4 * bk_[s] + c]);
+                    const double2 w0 = xc[0], w1 = xc[1];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        val[s][r][c] -= a[r][0] * w0.x + a[r][1] * w0.y + a[r][2] * w1.x + a[r][3] * w1.y;
+                }
             }
         }
     }
@@ -278,7 +330,7 @@ __global__ __launch_bounds__(GATE_NT) void k_feat_gate2(
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int i = 4 * bi_[s] + r, k = 4 * bk_[s] + c;
-                if (i >= rows && i < nb && k >= rows && k <= i) sh.W4[(i - rows) * 4 + (k - rows)] = val[s][r][c];
+                if (i >= rowsp && i < nb && k >= rowsp && k <= i) sh.W4[(i - rowsp) * 4 + (k - rowsp)] = val[s][r][c];
             }
     }
     __syncthreads();
