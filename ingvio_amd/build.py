@@ -40,6 +40,8 @@ def build_hip(force=False, verbose=False):
         if force or _newer(obj, deps):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
                    "-c", os.path.join(CSRC, src), "-o", obj]
+            if os.environ.get("INGVIO_DBG_STAMPS"):
+                cmd.insert(1, "-DINGVIO_DBG_STAMPS")
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -60,7 +60,11 @@ __device__ __forceinline__ double wave_sum(double x)
 static __device__ long long g_dbg[64];      // one copy per translation unit (no -fgpu-rdc)
 __device__ __forceinline__ void dbg_stamp(int slot)
 {
+#ifdef INGVIO_DBG_STAMPS      // build with INGVIO_DBG_STAMPS=1 python ingvio_amd/build.py --force (tests/gpu_phase_times.py)
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_dbg[slot] = clock64();
+#else
+    (void)slot;
+#endif
 }
 static inline int dbg_read_local(long long* out, int n)
 {

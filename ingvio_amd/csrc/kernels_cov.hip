@@ -31,6 +31,8 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
     __shared__ double sPhiA[NA_MAX * NA_MAX], sQA[NA_MAX * NA_MAX], sX[NA_MAX * NA_MAX], sY[NA_MAX * NA_MAX];
     __shared__ int sA[NA_MAX];
     __shared__ int sNA;
+    __shared__ double sDt[64];
+    __shared__ double sStrip[NA_MAX][PROP_THREADS + 1];      // new strip, transposed through LDS for the row-wise store
 
     const double sig[4] = { sg0, sg1, sg2, sg3 };
     dbg_stamp(16);
@@ -73,6 +75,9 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
         __syncthreads();
     }
     dbg_stamp(17);
+    for (int a = tid; a < NA_MAX * NA_MAX; a += PROP_THREADS) { sPhiA[a] = 0.0; sQA[a] = 0.0; }
+    for (int s = tid; s < k; s += PROP_THREADS) sDt[s] = dtB[s];
+    __syncthreads();
     // active set + GNSS clock block (thread 0, <= 5x5 work)
     if (tid == 0) {
         int gi[5], na = 15;
@@ -81,17 +86,13 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
         int loc[5];
         for (int g = 0; g < 5; ++g) { loc[g] = -1; if (gi[g] >= 0) { loc[g] = na; sA[na++] = gi[g]; } }
         sNA = na;
-        for (int a = 0; a < NA_MAX * NA_MAX; ++a) { sPhiA[a] = 0.0; sQA[a] = 0.0; }
-        for (int a = 0; a < 15; ++a) for (int c = 0; c < 15; ++c) {
-            sPhiA[a * NA_MAX + c] = sPhi[a + 15 * c];
-            sQA[a * NA_MAX + c] = sQ[a + 15 * c];
-        }
+        for (int a = na; a < NA_MAX; ++a) sA[a] = 0;      // padding: loads stay unconditional, Phi_A rows/cols there are zero
         double qg[5][5];
         for (int a = 0; a < 5; ++a) for (int c = 0; c < 5; ++c) qg[a][c] = 0.0;
         double T = 0.0;
         const bool has_fs = gi[4] >= 0;
         for (int s = 0; s < k; ++s) {
-            const double dt = dtB[s];
+            const double dt = sDt[s];
             if (has_fs) {
                 T += dt;
                 for (int g = 0; g < 4; ++g) if (gi[g] >= 0) for (int c = 0; c < 5; ++c) qg[g][c] += dt * qg[4][c];
@@ -114,6 +115,11 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
             for (int c = 0; c < 5; ++c) if (loc[c] >= 0) sQA[loc[a] * NA_MAX + loc[c]] = qg[a][c];
         }
     }
+    if (tid < 225) {
+        const int a = tid % 15, c = tid / 15;
+        sPhiA[a * NA_MAX + c] = sPhi[a + 15 * c];
+        sQA[a * NA_MAX + c] = sQ[a + 15 * c];
+    }
     __syncthreads();
     dbg_stamp(18);
     const int na = sNA;
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
     if (r < n && !inA) {
         double s[NA_MAX], o[NA_MAX];
 #pragma unroll
-        for (int a = 0; a < NA_MAX; ++a) s[a] = (a < na) ? P[r + (size_t)sA[a] * ld] : 0.0;
+        for (int a = 0; a < NA_MAX; ++a) s[a] = P[r + (size_t)sA[a] * ld];      // 20 independent loads in flight
 #pragma unroll
         for (int a = 0; a < NA_MAX; ++a) {
             double acc = 0.0;
@@ -135,7 +141,22 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
 #pragma unroll
         for (int a = 0; a < NA_MAX; ++a) if (a < na) {
             P[r + (size_t)sA[a] * ld] = o[a];
-            P[sA[a] + (size_t)r * ld] = o[a];        // :89 upper strip = transpose
+            sStrip[a][tid] = o[a];
+        }
+    }
+    __syncthreads();
+    // upper strip = transpose (:89): lanes run along the active index a so that each store instruction
+    // covers 16-element row segments instead of 64 different columns
+    {
+        const int a = tid & 15, rr0 = tid >> 4;
+        for (int rr = rr0; rr < PROP_THREADS; rr += PROP_THREADS / 16) {
+            const int r2 = blockIdx.x * PROP_THREADS + rr;
+            bool in2 = r2 < 15;
+            for (int q = 15; q < na; ++q) in2 |= (sA[q] == r2);
+            if (r2 < n && !in2) {
+                if (a < na) P[sA[a] + (size_t)r2 * ld] = sStrip[a][rr];
+                if (a + 16 < na) P[sA[a + 16] + (size_t)r2 * ld] = sStrip[a + 16][rr];
+            }
         }
     }
     dbg_stamp(19);

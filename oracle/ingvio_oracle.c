@@ -10,6 +10,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <malloc.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -850,6 +851,11 @@ void orc_frame_update_batch(int B, int threads, double* P, int* n_io, int ld,
                             const orc_frame_in* fr, const orc_msckf_in* ms,
                             double* dx, int* accepted, int fmax)
 {
+    /* the restatement allocates its N x N temporaries per call like the reference's Eigen code does;
+     * keep them in the per-thread malloc arenas instead of mmap/munmap so that many threads do not
+     * serialise in the kernel (a fair multi-core baseline) */
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
 #pragma omp parallel for schedule(dynamic, 1)
