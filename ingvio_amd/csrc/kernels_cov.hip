@@ -27,14 +27,15 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
     double* P = cov_ptr(cv, b);
 
     __shared__ double sPhi[225], sQ[225], sPG[180], sT1[225], sT2[225];
-    __shared__ double sAll[PROP_KCH * 405];      // a chunk of steps' (Phi, G~) fetched at once: one memory latency per chunk
-    __shared__ double sPhiA[NA_MAX * NA_MAX], sQA[NA_MAX * NA_MAX], sX[NA_MAX * NA_MAX], sY[NA_MAX * NA_MAX];
+    // a chunk of steps' (Phi, G~) fetched at once (one memory latency per chunk); after the composition the
+    // same LDS holds the new strip, transposed for the row-wise store
+    __shared__ __attribute__((aligned(16))) double sAll[NA_MAX * (PROP_THREADS + 1) > PROP_KCH * 405 ? NA_MAX * (PROP_THREADS + 1) : PROP_KCH * 405];
+    double* const sStrip = sAll;
+    __shared__ __attribute__((aligned(16))) double sPhiA[NA_MAX * NA_MAX], sQA[NA_MAX * NA_MAX], sX[NA_MAX * NA_MAX], sY[NA_MAX * NA_MAX];
     __shared__ int sA[NA_MAX];
     __shared__ int sNA;
     __shared__ double sDt[64];
-    __shared__ double sStrip[NA_MAX][PROP_THREADS + 1];      // new strip, transposed through LDS for the row-wise store
 
-    const double sig[4] = { sg0, sg1, sg2, sg3 };
     dbg_stamp(16);
     if (tid < 225) { sPhi[tid] = (tid % 15 == tid / 15) ? 1.0 : 0.0; sQ[tid] = 0.0; }
     const double* PhiB = Phi + (size_t)bl * k * 225;
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
             const int cnt = min(PROP_KCH, k - s);
             for (int e = tid; e < cnt * 405; e += PROP_THREADS) {
                 const int q = e / 405, w = e - q * 405;
-                sAll[e] = w < 225 ? PhiB[(s + q) * 225 + w] : GB[(s + q) * 180 + (w - 225)] * sig[((w - 225) / 15) / 3];   // G_tmp, :92-96
+                sAll[e] = w < 225 ? PhiB[(s + q) * 225 + w] : GB[(s + q) * 180 + (w - 225)] * (w < 225 + 45 ? sg0 : w < 225 + 90 ? sg1 : w < 225 + 135 ? sg2 : sg3);   // G_tmp, :92-96
             }
             __syncthreads();
         }
@@ -128,20 +129,20 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
     bool inA = r < 15;
     for (int a = 15; a < na; ++a) inA |= (sA[a] == r);
     if (r < n && !inA) {
-        double s[NA_MAX], o[NA_MAX];
+        double s[NA_MAX];
 #pragma unroll
         for (int a = 0; a < NA_MAX; ++a) s[a] = P[r + (size_t)sA[a] * ld];      // 20 independent loads in flight
+        // one output column at a time: keeps the live set at s[] + one row of Phi_A (the fully unrolled
+        // 20x20 form hoists all 400 LDS reads and spills)
+#pragma unroll 1
+        for (int a = 0; a < na; ++a) {
+            const double2* ph = reinterpret_cast<const double2*>(sPhiA + a * NA_MAX);
+            double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-        for (int a = 0; a < NA_MAX; ++a) {
-            double acc = 0.0;
-#pragma unroll
-            for (int c = 0; c < NA_MAX; ++c) acc += s[c] * sPhiA[a * NA_MAX + c];
-            o[a] = acc;
-        }
-#pragma unroll
-        for (int a = 0; a < NA_MAX; ++a) if (a < na) {
-            P[r + (size_t)sA[a] * ld] = o[a];
-            sStrip[a][tid] = o[a];
+            for (int c = 0; c < NA_MAX / 2; ++c) { const double2 w = ph[c]; acc0 += s[2 * c] * w.x; acc1 += s[2 * c + 1] * w.y; }
+            const double o = acc0 + acc1;
+            P[r + (size_t)sA[a] * ld] = o;
+            sStrip[a * (PROP_THREADS + 1) + tid] = o;
         }
     }
     __syncthreads();
@@ -154,8 +155,8 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
             bool in2 = r2 < 15;
             for (int q = 15; q < na; ++q) in2 |= (sA[q] == r2);
             if (r2 < n && !in2) {
-                if (a < na) P[sA[a] + (size_t)r2 * ld] = sStrip[a][rr];
-                if (a + 16 < na) P[sA[a + 16] + (size_t)r2 * ld] = sStrip[a + 16][rr];
+                if (a < na) P[sA[a] + (size_t)r2 * ld] = sStrip[a * (PROP_THREADS + 1) + rr];
+                if (a + 16 < na) P[sA[a + 16] + (size_t)r2 * ld] = sStrip[(a + 16) * (PROP_THREADS + 1) + rr];
             }
         }
     }
