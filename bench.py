@@ -125,7 +125,7 @@ def algorithmic_flops(F_used, F, C, N, k):
         "k_propagate": k1, "k_augment": k2, "k_msckf_gate": F * (k4 + k5), "k_msckf_fold": F_used * k4 + k7,
         "k_msckf_merge": 0.0, "k_ekf_core": k8_9_11, "k_downdate": k10, "k_marginalize": 0.0, "restore": 0.0,
         # factored path: same algorithmic work, different kernels
-        "k_feat_gate2": F * (k4 + k5), "k_feat_gram": F_used * k4 + k7, "k_info_update": k8_9_11}
+        "k_feat_gate3": F * (k4 + k5), "k_feat_gram": F_used * k4 + k7, "k_info_update": k8_9_11}
     total = F * (k4 + k5) + k7 + k8_9_11 + k10 + k1 + k2
     return per_kernel, total
 

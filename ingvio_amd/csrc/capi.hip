@@ -22,7 +22,7 @@ enum ProfId { PF_RESTORE, PF_PROPAGATE, PF_AUGMENT, PF_GATE, PF_FOLD, PF_MERGE, 
               PF_GATE2, PF_GRAM, PF_INFO, PF_APPLY, PF_COUNT };
 const char* kProfNames[PF_COUNT] = { "restore", "k_propagate", "k_augment", "k_msckf_gate", "k_msckf_fold",
                                      "k_msckf_merge", "k_ekf_core", "k_downdate", "k_marginalize",
-                                     "k_feat_gate2", "k_feat_gram", "k_info_update", "k_info_apply" };
+                                     "k_feat_gate3", "k_feat_gram", "k_info_update", "k_info_apply" };
 struct ProfRec { int id; hipEvent_t a, b; };
 
 }  // namespace
@@ -710,7 +710,7 @@ int ingvio_debug_read(ingvio_ctx* c, long long* out, int n)
     HIPCHK(c, hipStreamSynchronize(c->st));
     long long a[64], bq[64];
     if (dbg_read_factored(a, 64) || dbg_read_cov(bq, 64)) return INGVIO_E_HIP;
-    for (int i = 0; i < n; ++i) out[i] = i < 16 ? a[i] : bq[i];
+    for (int i = 0; i < n; ++i) out[i] = (i < 16 || i >= 24) ? a[i] : bq[i];
     return INGVIO_OK;
 }
 

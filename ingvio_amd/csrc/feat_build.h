@@ -26,6 +26,56 @@ struct FeatShared {
     int nobs;
 };
 
+// One observation of one feature: q = R^T(p_f - p), projection Jacobians G = Pi~ R^T (RPO x 3) and the
+// residual (RemoveLostUpdate.cpp:435-506).  Returns false when the reference would skip it (NaN guard, :486).
+template <bool STEREO>
+__device__ __forceinline__ bool feat_obs(const double* R, const double* p, const double z[4], double pfx, double pfy,
+                                         double pfz, const MsckfOpts& op, double (*Gm)[3], double* rs)
+{
+    constexpr int RPO = STEREO ? 4 : 2;
+    const double dx = pfx - p[0], dy = pfy - p[1], dz = pfz - p[2];
+    double q[3], Rt[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        q[i] = R[i] * dx + R[3 + i] * dy + R[6 + i] * dz;                 // R^T (p_f - p), :448
+        Rt[3 * i] = R[i]; Rt[3 * i + 1] = R[3 + i]; Rt[3 * i + 2] = R[6 + i];
+    }
+    const double iz = 1.0 / q[2];
+    const double hp02 = -q[0] / (q[2] * q[2]), hp12 = -q[1] / (q[2] * q[2]);   // :452-456
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        Gm[0][m] = iz * Rt[m] + hp02 * Rt[6 + m];
+        Gm[1][m] = iz * Rt[3 + m] + hp12 * Rt[6 + m];
+    }
+    rs[0] = z[0] - q[0] / q[2];
+    rs[1] = z[1] - q[1] / q[2];
+    bool nan = (iz != iz) || (hp02 != hp02) || (hp12 != hp12);                 // :486
+#pragma unroll
+    for (int i = 0; i < 9; ++i) nan |= (R[i] != R[i]);
+    nan |= (pfx != pfx) || (pfy != pfy) || (pfz != pfz);
+    if (STEREO) {
+        double qr[3], M[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            qr[i] = op.R_lr[3 * i] * q[0] + op.R_lr[3 * i + 1] * q[1] + op.R_lr[3 * i + 2] * q[2] + op.t_lr[i];   // :450
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                M[3 * i + m] = op.R_lr[3 * i] * Rt[m] + op.R_lr[3 * i + 1] * Rt[3 + m] + op.R_lr[3 * i + 2] * Rt[6 + m];
+        const double izr = 1.0 / qr[2];
+        const double h02 = -qr[0] / (qr[2] * qr[2]), h12 = -qr[1] / (qr[2] * qr[2]);     // :458-462
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            Gm[RPO - 2][m] = izr * M[m] + h02 * M[6 + m];
+            Gm[RPO - 1][m] = izr * M[3 + m] + h12 * M[6 + m];
+        }
+        rs[RPO - 2] = z[2] - qr[0] / qr[2];
+        rs[RPO - 1] = z[3] - qr[1] / qr[2];                                             // :503
+    }
+    return !nan;
+}
+
 // phase 1 (wave 0, one lane per window slot): q = R^T(p_f - p), projection Jacobians, residuals.
 // Fills sh.G (= Pi~ R^T, also the rows of Hf), sh.GX (= G [p_f]x), sh.res, sh.slot, sh.nobs.
 // RemoveLostUpdate.cpp:435-506.  Ends with a workgroup barrier.  Returns rows = RPO * nobs.
@@ -48,47 +98,9 @@ __device__ __forceinline__ int feat_phase1(const FrameView& fv, const MsckfOpts&
             const double* R = fv.clone_R + ((size_t)b * fv.cmax + s) * 9;
             const double* p = fv.clone_p + ((size_t)b * fv.cmax + s) * 3;
             const double* z = fv.uv + (((size_t)b * fv.fmax + j) * fv.cmax + s) * 4;
-            const double dx = pfx - p[0], dy = pfy - p[1], dz = pfz - p[2];
-            double q[3], Rt[9];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                q[i] = R[i] * dx + R[3 + i] * dy + R[6 + i] * dz;                 // R^T (p_f - p), :448
-                Rt[3 * i] = R[i]; Rt[3 * i + 1] = R[3 + i]; Rt[3 * i + 2] = R[6 + i];
-            }
-            const double iz = 1.0 / q[2];
-            const double hp02 = -q[0] / (q[2] * q[2]), hp12 = -q[1] / (q[2] * q[2]);   // :452-456
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                Gm[0][m] = iz * Rt[m] + hp02 * Rt[6 + m];
-                Gm[1][m] = iz * Rt[3 + m] + hp12 * Rt[6 + m];
-            }
-            rs[0] = z[0] - q[0] / q[2];
-            rs[1] = z[1] - q[1] / q[2];
-            bool nan = (iz != iz) || (hp02 != hp02) || (hp12 != hp12);                 // :486
-#pragma unroll
-            for (int i = 0; i < 9; ++i) nan |= (R[i] != R[i]);
-            nan |= (pfx != pfx) || (pfy != pfy) || (pfz != pfz);
-            if (STEREO) {
-                double qr[3], M[9];
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    qr[i] = op.R_lr[3 * i] * q[0] + op.R_lr[3 * i + 1] * q[1] + op.R_lr[3 * i + 2] * q[2] + op.t_lr[i];   // :450
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int m = 0; m < 3; ++m)
-                        M[3 * i + m] = op.R_lr[3 * i] * Rt[m] + op.R_lr[3 * i + 1] * Rt[3 + m] + op.R_lr[3 * i + 2] * Rt[6 + m];
-                const double izr = 1.0 / qr[2];
-                const double h02 = -qr[0] / (qr[2] * qr[2]), h12 = -qr[1] / (qr[2] * qr[2]);     // :458-462
-#pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    Gm[RPO - 2][m] = izr * M[m] + h02 * M[6 + m];
-                    Gm[RPO - 1][m] = izr * M[3 + m] + h12 * M[6 + m];
-                }
-                rs[RPO - 2] = z[2] - qr[0] / qr[2];
-                rs[RPO - 1] = z[3] - qr[1] / qr[2];                                             // :503
-            }
-            valid = !nan;
+            double zz[4] = { z[0], z[1], 0.0, 0.0 };
+            if (STEREO) { zz[2] = z[2]; zz[3] = z[3]; }
+            valid = feat_obs<STEREO>(R, p, zz, pfx, pfy, pfz, op, Gm, rs);
         }
         const unsigned long long vm = __ballot(valid);
         if (valid) {

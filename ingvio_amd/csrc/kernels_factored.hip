@@ -14,6 +14,7 @@
 //   K8-K11  K H = Pc (A Pcc + s^2 I)^-1 A  (push-through identity; A may be singular, rank n-6):
 //        P <- P - (Pc M) Pc^T,  dx = Pc (A Pcc + s^2 I)^-1 b,  Pc = P[:, clone cols].
 // gfx950 only.
+#include <algorithm>
 #include "feat_build.h"
 #include "launch_factored.h"
 
@@ -24,6 +25,23 @@ __device__ __forceinline__ double fast_rcp(double x)
     r = fma(fma(-x, r, 1.0), r, r);
     r = fma(fma(-x, r, 1.0), r, r);
     return r;
+}
+
+__device__ __forceinline__ void inv3sym(const double N[9], double out[9])
+{
+    const double a = N[0], b = N[1], c = N[2], d = N[4], e = N[5], f = N[8];
+    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+    const double det = a * c00 + b * c01 + c * c02, id = 1.0 / det;
+    out[0] = c00 * id; out[1] = c01 * id; out[2] = c02 * id;
+    out[3] = out[1]; out[4] = (a * f - c * c) * id; out[5] = (b * c - a * e) * id;
+    out[6] = out[2]; out[7] = out[5]; out[8] = (a * d - b * b) * id;
+}
+__device__ __forceinline__ void mul33(const double A[9], const double B[9], double C[9])
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) C[3 * i + k] = A[3 * i] * B[k] + A[3 * i + 1] * B[3 + k] + A[3 * i + 2] * B[6 + k];
 }
 
 __device__ __forceinline__ void cross3(double ax, double ay, double az, const double v[3], double out[3])
@@ -53,38 +71,13 @@ __device__ __forceinline__ void mulXt(const double M[9], double x, double y, dou
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3 + K5, one workgroup per (feature, filter).
-//
-// The bordered matrix [[S, Y], [Y^T, 0]] (S = Gblk Su Gblk^T + s^2 I, Y = [r | Hf]) is held as 4x4
-// register blocks of its lower triangle.  For a stereo feature block (bi, bk) IS the observation
-// pair (o, o'): its owner lane builds it straight from nine 3x3 blocks of the prior P
-// (Su[o][o'] = D_o Pcc D_o'^T), so nothing but the per-observation 4x3 factors G_o passes through
-// LDS (~5 KB per workgroup: occupancy is bounded by waves, not LDS).  Right-looking elimination
-// of the first `rows` pivots leaves -Y^T S^-1 Y in the border block.
-// The kernel also writes the feature's compact record (N_o = G_o^T G_o, h_o = G_o^T r_o, slots,
-// flags, p_f) consumed by k_feat_gram.
+// Per-feature record written by the gate kernel and consumed by k_feat_gram:
+//   {nobs, anchor slot, p_f(3)} then per observation {slot, cna, pfl, N_o = G_o^T G_o (9), h_o = G_o^T r_o (3)}
 // ---------------------------------------------------------------------------------------------
-#define GATE_NT 128
 #define REC_HDR 5
 #define REC_OBS 15          // slot, cna, pfl, N(9), h(3)
 
 __host__ __device__ constexpr int rec_size(int cmax) { return REC_HDR + REC_OBS * cmax; }
-
-template <int CMAX, bool STEREO>
-struct GateShared {
-    using Cfg = FeatCfg<CMAX, STEREO>;
-    static constexpr int NB = Cfg::RR + 4;                 // S bordered by [r | Hf]
-    static constexpr int NBB = (NB + 3) / 4;               // 4x4 register blocks per side
-    static constexpr int NBLK = NBB * (NBB + 1) / 2;
-    static constexpr int BPT = (NBLK + GATE_NT - 1) / GATE_NT;
-    FeatShared<CMAX, STEREO> f;
-    int cna[CMAX];                                 // obs slot != anchor
-    int pfl[CMAX];                                 // obs keeps its -I block (false only under Q10)
-    alignas(16) double X[4 * NBB][4];              // published panel L_ij D (blocked LDL^T)
-    double L[4][4];
-    double Dinv[4];
-    double W4[16];
-};
 
 // Su[o][o'] = D_o Pcc D_o'^T from nine 3x3 blocks of P (row-major 3x3 out)
 __device__ __forceinline__ void su_pair(const double* __restrict__ P, int ld, int gc, int gc2, int ga, bool cn, bool cn2,
@@ -140,16 +133,60 @@ __device__ __forceinline__ void su_pair(const double* __restrict__ P, int ld, in
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K3 + K5, one WAVE per (feature, filter): "column-owner" LDL^T in the reduced observation space.
+//
+// Stereo (G_o is 4x3, full column rank): by Woodbury on S = s^2 I + Gblk Su Gblk^T,
+//     S^-1 = s^-2 (I - Gblk N^-1 Gblk^T) + Gblk N^-1 K^-1 N^-1 Gblk^T,   K = Su + s^2 N^-1,  N = blockdiag(G_o^T G_o)
+// so  Y^T S^-1 Y = W^T K^-1 W + s^-2 |r_perp|^2 e0 e0^T  with  W = N^-1 Gblk^T [r | Hf] = [u | 1],
+//     u_o = N_o^-1 G_o^T r_o,  |r_perp|^2 = sum_o (|r_o|^2 - h_o^T u_o)   (Hf = Gblk 1, so its residual part is 0):
+// a (3 nobs)-dimensional SPD system instead of the (4 nobs)-dimensional S, and no G_o products on Su.
+// Mono (G_o is 2x3): K = s^2 I + Gblk Su Gblk^T itself (2 nobs), W = [r | Hf].
+//
+// Lane j holds column j of the bordered matrix [[0, W^T], [W, K]] (border FIRST: indices 0..3) in
+// registers; pivot p broadcasts column p with v_readlane (lane index and register index are compile-time
+// constants after unrolling), every lane updates its own column: no LDS traffic, no barriers, the wave
+// runs D*nobs pivots back to back and leaves -W^T K^-1 W in the 4x4 border.
+// The 3x3 (2x2) blocks of K are built one observation pair per lane from nine 3x3 blocks of P
+// and exchanged once through LDS.  Also writes the feature's compact record for k_feat_gram.
+// ---------------------------------------------------------------------------------------------
 template <int CMAX, bool STEREO>
-__global__ __launch_bounds__(GATE_NT, (GateShared<CMAX, STEREO>::BPT == 1 ? 5 : 3)) void k_feat_gate2(
-    CovView cv, FrameView fv, MsckfOpts op, int b0, double* __restrict__ gamma_out, int* __restrict__ accept_out,
-    double* __restrict__ rec_out)
+struct Gate3Shared {
+    static constexpr int D = STEREO ? 3 : 2;
+    static constexpr int DIM = 4 + D * CMAX;
+    static constexpr int NPAIR = CMAX * (CMAX + 1) / 2;
+    FeatShared<CMAX, STEREO> f;
+    int cna[CMAX];
+    int pfl[CMAX];
+    double Ninv[CMAX][9];
+    double u[CMAX][3];
+    double rperp[CMAX];
+    double blk[NPAIR][D * D];
+};
+
+__device__ __forceinline__ double bcast_lane(double x, int lane)      // lane must be a compile-time constant
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <int CMAX, bool STEREO>
+__global__ __launch_bounds__(WAVE) void k_feat_gate3(
+    CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out,
+    int* __restrict__ accept_out, double* __restrict__ rec_out)
 {
     using Cfg = FeatCfg<CMAX, STEREO>;
-    using SH = GateShared<CMAX, STEREO>;
-    constexpr int RPO = Cfg::RPO, NT = GATE_NT, BPT = SH::BPT, OPB = 4 / RPO;      // observations per block side
+    using SH = Gate3Shared<CMAX, STEREO>;
+    constexpr int RPO = Cfg::RPO, D = SH::D, DIM = SH::DIM;
+    static_assert(DIM <= WAVE, "one lane per column");
     __shared__ SH sh;
-    const int b = b0 + blockIdx.y, j = blockIdx.x, tid = threadIdx.x;
+    // XCD-aware mapping: consecutive workgroups go round-robin to the 8 XCDs, so give every XCD whole filters
+    // (a filter's P blocks then live in one L2 instead of eight)
+    const int w = blockIdx.x, xcd = w & 7, t = w >> 3;
+    const int bl = xcd + 8 * (t / fmax_used), j = t % fmax_used;
+    if (bl >= nb) return;
+    const int b = b0 + bl, tid = threadIdx.x;
     if (j >= fv.n_feat[b]) return;
     const int C = fv.n_clones[b], ld = cv.ldp;
     const double* P = cov_ptr(cv, b);
@@ -157,10 +194,8 @@ __global__ __launch_bounds__(GATE_NT, (GateShared<CMAX, STEREO>::BPT == 1 ? 5 : 
     const int a = fv.anchor[oidx];
     const double* pf = fv.pf + oidx * 3;
     const double px = pf[0], py = pf[1], pz = pf[2];
-    dbg_stamp(8);
     load_gidx<CMAX, STEREO>(fv, b, C, sh.f);
     const int rows = feat_phase1<CMAX, STEREO>(fv, op, b, j, C, sh.f);
-    dbg_stamp(9);
     const int nobs = sh.f.nobs, rho = rows - 3;
     double* rec = rec_out + oidx * rec_size(CMAX);
     if (rho <= 0) {
@@ -174,171 +209,152 @@ __global__ __launch_bounds__(GATE_NT, (GateShared<CMAX, STEREO>::BPT == 1 ? 5 : 
         sh.pfl[tid] = pl;
         double* ro = rec + REC_HDR + REC_OBS * tid;
         ro[0] = so; ro[1] = cn ? 1.0 : 0.0; ro[2] = pl ? 1.0 : 0.0;
+        double N[9], h[3];
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
 #pragma unroll
             for (int m2 = 0; m2 < 3; ++m2) {
-                double s = 0.0;
+                double sN = 0.0;
 #pragma unroll
-                for (int t = 0; t < RPO; ++t) s += sh.f.G[tid][t][m] * sh.f.G[tid][t][m2];
-                ro[3 + 3 * m + m2] = s;
+                for (int q = 0; q < RPO; ++q) sN += sh.f.G[tid][q][m] * sh.f.G[tid][q][m2];
+                N[3 * m + m2] = sN;
+                ro[3 + 3 * m + m2] = sN;
             }
             double hh = 0.0;
 #pragma unroll
-            for (int t = 0; t < RPO; ++t) hh += sh.f.G[tid][t][m] * sh.f.res[tid][t];
+            for (int q = 0; q < RPO; ++q) hh += sh.f.G[tid][q][m] * sh.f.res[tid][q];
+            h[m] = hh;
             ro[12 + m] = hh;
+        }
+        if (STEREO) {
+            double Ni[9];
+            inv3sym(N, Ni);
+            double rr = 0.0;
+#pragma unroll
+            for (int q = 0; q < RPO; ++q) rr += sh.f.res[tid][q] * sh.f.res[tid][q];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const double um = Ni[3 * m] * h[0] + Ni[3 * m + 1] * h[1] + Ni[3 * m + 2] * h[2];
+                sh.u[tid][m] = um;
+                rr -= h[m] * um;
+#pragma unroll
+                for (int m2 = 0; m2 < 3; ++m2) sh.Ninv[tid][3 * m + m2] = Ni[3 * m + m2];
+            }
+            sh.rperp[tid] = rr;
         }
     }
     if (tid == 0) { rec[0] = nobs; rec[1] = a; rec[2] = px; rec[3] = py; rec[4] = pz; }
     __syncthreads();
-
-    const int rowsp = (rows + 3) & ~3;          // pivots padded to whole 4x4 blocks (mono with odd nobs): identity rows
-    const int nb = rowsp + 4, nbb = nb >> 2, nblk = nbb * (nbb + 1) / 2;
+    // ---- pair blocks: lane q -> observation pair (o >= o2) ------------------------------------
     const int ga = sh.f.gidx[6 * a];
-    double val[BPT][4][4];
-    int bi_[BPT], bk_[BPT];
+    const int npair = nobs * (nobs + 1) / 2;
+    for (int q = tid; q < npair; q += WAVE) {
+        int o = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
+        while ((o + 1) * (o + 2) / 2 <= q) ++o;
+        while (o * (o + 1) / 2 > q) --o;
+        const int o2 = q - o * (o + 1) / 2;
+        double Su[9];
+        su_pair(P, ld, sh.f.gidx[6 * sh.f.slot[o]], sh.f.gidx[6 * sh.f.slot[o2]], ga, sh.cna[o], sh.cna[o2],
+                sh.pfl[o], sh.pfl[o2], px, py, pz, Su);
+        if (STEREO) {
+            if (o == o2) {
 #pragma unroll
-    for (int s = 0; s < BPT; ++s) {
-        const int bq = tid + s * NT;
-        int bi = -1, bk = -1;
-        if (bq < nblk) {
-            bi = (int)((sqrtf(8.0f * bq + 1.0f) - 1.0f) * 0.5f);
-            while ((bi + 1) * (bi + 2) / 2 <= bq) ++bi;
-            while (bi * (bi + 1) / 2 > bq) --bi;
-            bk = bq - bi * (bi + 1) / 2;
-        }
-        bi_[s] = bi; bk_[s] = bk;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) val[s][r][c] = 0.0;
-        if (bi < 0) continue;
-        // S part: observation pairs covered by this block
-#pragma unroll
-        for (int u = 0; u < OPB; ++u) {
-            const int o = OPB * bi + u;
-            if (o >= nobs) continue;
-#pragma unroll
-            for (int w = 0; w < OPB; ++w) {
-                const int o2 = OPB * bk + w;
-                if (o2 >= nobs || o2 > o) continue;
-                double Su[9];
-                su_pair(P, ld, sh.f.gidx[6 * sh.f.slot[o]], sh.f.gidx[6 * sh.f.slot[o2]], ga, sh.cna[o], sh.cna[o2],
-                        sh.pfl[o], sh.pfl[o2], px, py, pz, Su);
-                double GS[RPO][3];
-#pragma unroll
-                for (int t = 0; t < RPO; ++t)
-#pragma unroll
-                    for (int m2 = 0; m2 < 3; ++m2)
-                        GS[t][m2] = sh.f.G[o][t][0] * Su[m2] + sh.f.G[o][t][1] * Su[3 + m2] + sh.f.G[o][t][2] * Su[6 + m2];
-#pragma unroll
-                for (int t = 0; t < RPO; ++t)
-#pragma unroll
-                    for (int t2 = 0; t2 < RPO; ++t2) {
-                        double v = GS[t][0] * sh.f.G[o2][t2][0] + GS[t][1] * sh.f.G[o2][t2][1] + GS[t][2] * sh.f.G[o2][t2][2];
-                        if (o == o2 && t == t2) v += op.var;
-                        val[s][RPO * u + t][RPO * w + t2] = v;
-                    }
+                for (int i = 0; i < 9; ++i) Su[i] += op.var * sh.Ninv[o][i];
             }
-        }
-        // padding rows (decoupled unit pivots) and border rows [r | Hf]^T
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = 4 * bi + r;
-            if (i >= rows && i < rowsp && bi == bk) val[s][r][r] = 1.0;
-            if (i < rowsp || i >= nb) continue;
-            const int kb = i - rowsp;
+            for (int i = 0; i < 9; ++i) sh.blk[q][i] = Su[i];
+        } else {
+            double GS[2][3];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int k = 4 * bk + c;
-                if (k < rows) val[s][r][c] = (kb == 0) ? sh.f.res[k / RPO][k % RPO] : sh.f.G[k / RPO][k % RPO][kb - 1];
-            }
-        }
-    }
-    dbg_stamp(10);
-    // Blocked LDL^T, 4 pivots per panel, 2 barriers per panel:
-    //   1. the owner of diagonal block (bj,bj) factorises it in registers, publishes L_jj and D^-1
-    //   2. panel blocks (bi,bj), bi > bj: X = S_ij L_jj^-T (= L_ij D), published to LDS
-    //   3. trailing blocks (bi,bk), bk > bj: S_ik -= X_i D^-1 X_k^T
-    // Only the first `rows` (a multiple of 4 here) rows/cols are pivots; the border block ends as -Y^T S^-1 Y.
-    const int npan = rowsp >> 2;
-    for (int bj = 0; bj < npan; ++bj) {
+            for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int s = 0; s < BPT; ++s) {
-            if (bi_[s] == bj && bk_[s] == bj) {
-                double (&Bq)[4][4] = val[s];
-                double dinv[4];
+                for (int m2 = 0; m2 < 3; ++m2)
+                    GS[r][m2] = sh.f.G[o][r][0] * Su[m2] + sh.f.G[o][r][1] * Su[3 + m2] + sh.f.G[o][r][2] * Su[6 + m2];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    dinv[c] = fast_rcp(Bq[c][c]);
+            for (int r = 0; r < 2; ++r)
 #pragma unroll
-                    for (int r = c + 1; r < 4; ++r) {
-                        const double l = Bq[r][c] * dinv[c];
-#pragma unroll
-                        for (int c2 = c + 1; c2 <= r; ++c2) Bq[r][c2] -= l * Bq[c2][c];
-                        sh.L[r][c] = l;
-                    }
-                    sh.Dinv[c] = dinv[c];
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    double v = GS[r][0] * sh.f.G[o2][r2][0] + GS[r][1] * sh.f.G[o2][r2][1] + GS[r][2] * sh.f.G[o2][r2][2];
+                    if (o == o2 && r == r2) v += op.var;
+                    sh.blk[q][(D * r + r2) % (D * D)] = v;
                 }
-            }
         }
-        __syncthreads();
-        const double L10 = sh.L[1][0], L20 = sh.L[2][0], L21 = sh.L[2][1], L30 = sh.L[3][0], L31 = sh.L[3][1], L32 = sh.L[3][2];
-#pragma unroll
-        for (int s = 0; s < BPT; ++s) {
-            if (bk_[s] == bj && bi_[s] > bj) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double x0 = val[s][r][0];
-                    const double x1 = val[s][r][1] - L10 * x0;
-                    const double x2 = val[s][r][2] - L20 * x0 - L21 * x1;
-                    const double x3 = val[s][r][3] - L30 * x0 - L31 * x1 - L32 * x2;
-                    double2* xr = reinterpret_cast<double2*>(sh.X[4 * bi_[s] + r]);
-                    xr[0] = make_double2(x0, x1); xr[1] = make_double2(x2, x3);
-                }
-            }
-        }
-        __syncthreads();
-        const double d0 = sh.Dinv[0], d1 = sh.Dinv[1], d2 = sh.Dinv[2], d3 = sh.Dinv[3];
-#pragma unroll
-        for (int s = 0; s < BPT; ++s) {
-            if (bk_[s] > bj) {
-                // X_i rows (scaled by D^-1) preloaded with 16-byte LDS reads, X_k rows streamed
-                double a[4][4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double2* xr = reinterpret_cast<const double2*>(sh.X[4 * bi_[s] + r]);
-                    const double2 u0 = xr[0], u1 = xr[1];
-                    a[r][0] = u0.x * d0; a[r][1] = u0.y * d1; a[r][2] = u1.x * d2; a[r][3] = u1.y * d3;
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const double2* xc = reinterpret_cast<const double2*>(sh.X[4 * bk_[s] + c]);
-                    const double2 w0 = xc[0], w1 = xc[1];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        val[s][r][c] -= a[r][0] * w0.x + a[r][1] * w0.y + a[r][2] * w1.x + a[r][3] * w1.y;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < BPT; ++s) {
-        if (bi_[s] < 0) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int i = 4 * bi_[s] + r, k = 4 * bk_[s] + c;
-                if (i >= rowsp && i < nb && k >= rowsp && k <= i) sh.W4[(i - rowsp) * 4 + (k - rowsp)] = val[s][r][c];
-            }
     }
     __syncthreads();
-    dbg_stamp(11);
+    // ---- gather own column -------------------------------------------------------------------
+    double col[DIM];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) col[i] = 0.0;
+    const int jo = (tid - 4) / D, jc = (tid - 4) - D * jo;      // own observation / component (lanes >= 4)
+    const bool kcol = tid >= 4 && jo < nobs;
+    if (kcol) {
+        // border rows of a K column = W[j][0..3]
+        if (STEREO) {
+            col[0] = sh.u[jo][jc];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) col[1 + m] = (jc == m) ? 1.0 : 0.0;
+        } else {
+            col[0] = sh.f.res[jo][jc];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) col[1 + m] = sh.f.G[jo][jc][m];
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < CMAX; ++o) {
+        if (o < nobs) {
+            if (kcol) {
+                const bool low = o >= jo;                    // block (o, jo) stored, else (jo, o) transposed
+                const int q = low ? o * (o + 1) / 2 + jo : jo * (jo + 1) / 2 + o;
+#pragma unroll
+                for (int c = 0; c < D; ++c) col[4 + D * o + c] = sh.blk[q][low ? D * c + jc : D * jc + c];
+            } else if (tid < 4) {
+                // border columns: W[3o+c][tid]
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    double v;
+                    if (STEREO) v = tid == 0 ? sh.u[o][c] : (tid - 1 == c ? 1.0 : 0.0);
+                    else v = tid == 0 ? sh.f.res[o][c] : sh.f.G[o][c][(tid + 2) % 3];   // tid-1 for tid in 1..3
+                    col[4 + D * o + c] = v;
+                }
+            }
+        }
+    }
+    // ---- LDL^T, D*nobs pivots ----------------------------------------------------------------
+#pragma unroll
+    for (int po = 0; po < CMAX; ++po) {
+        if (po < nobs) {
+#pragma unroll
+            for (int pc = 0; pc < D; ++pc) {
+                constexpr int dummy = 0; (void)dummy;
+                const int p = 4 + D * po + pc;
+                const double dp = bcast_lane(col[p], p);
+                const double f = col[p] * fast_rcp(dp);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) col[i] = fma(-bcast_lane(col[i], p), f, col[i]);
+#pragma unroll
+                for (int c2 = pc + 1; c2 < D; ++c2) col[4 + D * po + c2] = fma(-bcast_lane(col[4 + D * po + c2], p), f, col[4 + D * po + c2]);
+#pragma unroll
+                for (int o2 = po + 1; o2 < CMAX; ++o2) {
+                    if (o2 < nobs) {
+#pragma unroll
+                        for (int c2 = 0; c2 < D; ++c2) col[4 + D * o2 + c2] = fma(-bcast_lane(col[4 + D * o2 + c2], p), f, col[4 + D * o2 + c2]);
+                    }
+                }
+            }
+        }
+    }
+    // ---- gamma from the border: Z = W^T K^-1 W (+ residual part), gamma = Z00 - f^T Zff^-1 f -----
+    double W[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) W[i][q] = -bcast_lane(col[i], q);
+    if (STEREO) {
+        double rp = 0.0;
+        for (int o = 0; o < nobs; ++o) rp += sh.rperp[o];
+        W[0][0] += rp / op.var;
+    }
     if (tid == 0) {
-        // -border = Y^T S^-1 Y, Y = [r | Hf];  gamma = W00 - f^T Wff^-1 f
-        double W[4][4];
-        for (int p = 0; p < 4; ++p) for (int q = 0; q <= p; ++q) { W[p][q] = -sh.W4[p * 4 + q]; W[q][p] = W[p][q]; }
         const double l00 = sqrt(W[1][1]);
         const double l10 = W[2][1] / l00, l20 = W[3][1] / l00;
         const double l11 = sqrt(W[2][2] - l10 * l10);
@@ -371,23 +387,6 @@ struct GramShared {
     double rec[2][REC];           // double-buffered feature record
     double sums[2][24];           // Ns(9) hs(3) Nsa(9) hsa(3)
 };
-
-__device__ __forceinline__ void inv3sym(const double N[9], double out[9])
-{
-    const double a = N[0], b = N[1], c = N[2], d = N[4], e = N[5], f = N[8];
-    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
-    const double det = a * c00 + b * c01 + c * c02, id = 1.0 / det;
-    out[0] = c00 * id; out[1] = c01 * id; out[2] = c02 * id;
-    out[3] = out[1]; out[4] = (a * f - c * c) * id; out[5] = (b * c - a * e) * id;
-    out[6] = out[2]; out[7] = out[5]; out[8] = (a * d - b * b) * id;
-}
-__device__ __forceinline__ void mul33(const double A[9], const double B[9], double C[9])
-{
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) C[3 * i + k] = A[3 * i] * B[k] + A[3 * i + 1] * B[3 + k] + A[3 * i + 2] * B[6 + k];
-}
 
 template <int CMAX, bool STEREO>
 __global__ __launch_bounds__((GramShared<CMAX>::NT)) void k_feat_gram(
@@ -826,8 +825,9 @@ template <int CMAX, bool STEREO>
 static void launch_ft(const FactoredLaunch& L, hipStream_t st)
 {
     if (L.stage == 0) {
-        hipLaunchKernelGGL((k_feat_gate2<CMAX, STEREO>), dim3(L.fmax_used, L.nb), dim3(GATE_NT), 0, st,
-                           L.cv, L.fv, L.op, L.b0, L.gamma, L.accept, L.rec);
+        const int nb8 = (L.nb + 7) / 8 * 8;
+        hipLaunchKernelGGL((k_feat_gate3<CMAX, STEREO>), dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st,
+                           L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
     } else {
         const size_t sm = ((sizeof(GramShared<CMAX>) + 15) / 16) * 16 + sizeof(int) * (size_t)L.fv.fmax;
         hipLaunchKernelGGL((k_feat_gram<CMAX, STEREO>), dim3(L.G, L.nb), dim3(GramShared<CMAX>::NT), sm, st,

@@ -15,5 +15,5 @@ d = ctx.debug_read(32)
 def seg(name, idx):
     print(name, [d[b] - d[a] for a, b in zip(idx[:-1], idx[1:])], "total", d[idx[-1]] - d[idx[0]])
 seg("info_update [assemble,K1,GJ,T]", [0, 1, 2, 3, 4])
-seg("gate [phase1,blockinit,elim]", [8, 9, 10, 11])
+seg("gate3 [phase1,record,pairs,gather,ldl,gamma]", [24, 25, 26, 27, 28, 29, 30])
 seg("propagate [compose,gnss,strip,AA]", [16, 17, 18, 19, 20])
