@@ -200,7 +200,8 @@ int make_opts(ingvio_ctx* c, const ingvio_msckf_opts* o, MsckfOpts* op)
 }
 
 // K3..K11 for filters [b0, b0+nb) using the staged frames; asynchronous.
-int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int stereo, int fmax_used)
+int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int stereo, int fmax_used,
+                       const int* marg_idx = nullptr, int marg_size = 0)
 {
     FactoredLaunch L;
     memset(&L, 0, sizeof L);
@@ -215,6 +216,7 @@ int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int s
     { ProfScope p(c, PF_GRAM); L.stage = 1; launch_factored(L, c->st); }
     L.mstride = c->ystride; L.n_cap = c->d.n_max;
     { ProfScope p(c, PF_INFO); L.stage = 2; launch_factored(L, c->st); }
+    L.marg_idx = marg_idx; L.marg_size = marg_size;
     { ProfScope p(c, PF_APPLY); L.stage = 3; launch_factored(L, c->st); }
     return last_launch(c);
 }
@@ -679,9 +681,17 @@ int ingvio_frame_run(ingvio_ctx* c, int restore_prior)
     }
     { ProfScope p(c, PF_AUGMENT); launch_augment(view(c), 0, B, c->d_R, c->st); }
     for (int b = 0; b < B; ++b) c->h_n[b] += 6;
-    int rc = run_msckf(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used);
+    // factored path: the marginalisation of the oldest clone rides on the update's write-back (k_info_apply
+    // stores the updated covariance compacted into the other ping-pong half); dense path: separate kernel
+    const bool fuse = c->method == 1;
+    int rc = fuse ? run_msckf_factored(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used, c->d_idx, 6)
+                  : run_msckf(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used);
     if (rc) return rc;
-    { ProfScope p(c, PF_MARG); launch_marginalize(view(c), 0, B, c->d.n_max, c->d_idx, 6, c->st); }
+    {
+        ProfScope p(c, PF_MARG);
+        if (fuse) launch_post_marg(view(c), 0, B, c->d_idx, 6, c->st);
+        else launch_marginalize(view(c), 0, B, c->d.n_max, c->d_idx, 6, c->st);
+    }
     for (int b = 0; b < B; ++b) if (c->st_marg[b] >= 0) { c->h_n[b] -= 6; c->h_cur[b] ^= 1; }
     return INGVIO_OK;
 }

@@ -343,6 +343,10 @@ void launch_marginalize(CovView cv, int b0, int nb, int n_cap, const int* idx, i
     hipLaunchKernelGGL(k_marginalize, dim3((n_cap + MARG_COLS - 1) / MARG_COLS, nb), dim3(256), 0, st, cv, b0, idx, size);
     hipLaunchKernelGGL(k_post_marg, dim3((nb + 255) / 256), dim3(256), 0, st, cv, b0, nb, idx, size);
 }
+void launch_post_marg(CovView cv, int b0, int nb, const int* idx, int size, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_post_marg, dim3((nb + 255) / 256), dim3(256), 0, st, cv, b0, nb, idx, size);
+}
 void launch_append(CovView cv, int b0, int nb, int size, const double* blk, hipStream_t st)
 {
     hipLaunchKernelGGL(k_append, dim3(nb), dim3(256), 0, st, cv, b0, size, blk);

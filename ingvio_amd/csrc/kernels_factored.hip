@@ -18,6 +18,8 @@
 #include "feat_build.h"
 #include "launch_factored.h"
 
+typedef double double4_f __attribute__((ext_vector_type(4)));
+
 // 1/x to full FP64 precision: v_rcp_f64 + two Newton steps (the IEEE division expands to ~3x the latency)
 __device__ __forceinline__ double fast_rcp(double x)
 {
@@ -72,9 +74,9 @@ __device__ __forceinline__ void mulXt(const double M[9], double x, double y, dou
 
 // ---------------------------------------------------------------------------------------------
 // Per-feature record written by the gate kernel and consumed by k_feat_gram:
-//   {nobs, anchor slot, p_f(3)} then per observation {slot, cna, pfl, N_o = G_o^T G_o (9), h_o = G_o^T r_o (3)}
+//   {nobs, anchor slot, p_f(3), window-slot mask} then per observation (ascending slot) {slot, cna, pfl, N_o = G_o^T G_o (9), h_o = G_o^T r_o (3)}
 // ---------------------------------------------------------------------------------------------
-#define REC_HDR 5
+#define REC_HDR 6
 #define REC_OBS 15          // slot, cna, pfl, N(9), h(3)
 
 __host__ __device__ constexpr int rec_size(int cmax) { return REC_HDR + REC_OBS * cmax; }
@@ -243,7 +245,11 @@ __global__ __launch_bounds__(WAVE) void k_feat_gate3(
             sh.rperp[tid] = rr;
         }
     }
-    if (tid == 0) { rec[0] = nobs; rec[1] = a; rec[2] = px; rec[3] = py; rec[4] = pz; }
+    if (tid == 0) {
+        unsigned sm = 0;
+        for (int o = 0; o < nobs; ++o) sm |= 1u << sh.f.slot[o];
+        rec[0] = nobs; rec[1] = a; rec[2] = px; rec[3] = py; rec[4] = pz; rec[5] = (double)sm;
+    }
     __syncthreads();
     // ---- pair blocks: lane q -> observation pair (o >= o2) ------------------------------------
     const int ga = sh.f.gidx[6 * a];
@@ -369,6 +375,300 @@ __global__ __launch_bounds__(WAVE) void k_feat_gate3(
         gamma_out[oidx] = g;
         accept_out[oidx] = ok ? 1 : 0;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4 + K6/K7 in Gram form, second generation: block-sparse part + rank-3 MFMA part.
+//
+// With D_o = [cn X | -pl I | -cn X] on (theta_c, p_c, theta_anchor) (X = [p_f]x, c = slot of obs o),
+// N = blockdiag(N_o), Ns = sum_o N_o (= Hf^T Hf) the nullspace-projected information of one feature is
+//     H_j^T H_j = D^T (N - N 1 Ns^-1 1^T N) D = sum_o D_o^T N_o D_o  -  B^T Ns^-1 B,     B = sum_o N_o D_o  (3 x 6C)
+//     H_j^T r_j = sum_o D_o^T h_o - B^T Ns^-1 hs,                                      hs = sum_o h_o
+// i.e. a block-sparse term (6x6 at the observing clone, couplings to the anchor's theta block) minus a
+// RANK-3 term.  Summed over a chunk's features the rank-3 terms are one GEMM  Y^T [B | hs]  with
+// Y = Ns^-1 B stacked over features (3 rows each): it runs on the matrix cores
+// (v_mfma_f64_16x16x4, 4 stacked rows per instruction), no per-pair 3x3 algebra at all.
+// The sparse term only needs, per (observing slot c, anchor slot a), the running sums of
+// cn X^T N X, cn pl N X, pl N, cn X^T h, pl h: lane (c, a) keeps them in registers and the chunk's
+// 6C x (6C+1) partial [A | b] is assembled once at the end.
+// grid = (G chunks, nb); a workgroup walks its chunk in batches of GRAM_NB features.
+// ---------------------------------------------------------------------------------------------
+#define GRAM_NB 8
+#define GRAM_NT 256
+template <int CMAX>
+struct Gram2Cfg {
+    static constexpr int NC = 6 * CMAX;
+    static constexpr int TI = (NC + 15) / 16;              // tiles over rows of A (columns of Y)
+    static constexpr int TJ = (NC + 1 + 15) / 16;          // tiles over columns of [A | b]
+    static constexpr int LDW = 16 * TJ;
+    static constexpr int NTILE = TI * TJ;
+    static constexpr int TPW = (NTILE + 3) / 4;            // tiles per wave
+    static constexpr int REC = REC_HDR + REC_OBS * CMAX;
+    static constexpr int KR = 3 * GRAM_NB;                 // stacked rows per batch
+    static constexpr int SPW = 24;                         // per (feature, slot) sparse scratch: S1(9) NXs(9) s4(3) flag
+};
+template <int CMAX>
+struct Gram2Batch {
+    using Cfg = Gram2Cfg<CMAX>;
+    double rec[GRAM_NB][Cfg::REC];
+    double sums[GRAM_NB][24];                // Ns(9) hs(3) Nsa(9) hsa(3)
+    double Bm[Cfg::KR][Cfg::LDW];
+    double Ym[Cfg::KR][Cfg::LDW];
+    double sp[GRAM_NB][CMAX][Cfg::SPW];
+};
+template <int CMAX>
+struct Gram2Out {
+    using Cfg = Gram2Cfg<CMAX>;
+    double A2[Cfg::NC][Cfg::NC + 2];         // rank-3 part (+ hs column), row stride NC+2
+    double S[CMAX][CMAX][34];                // per (slot, anchor) sparse sums: S1 NXs S3 s4 s5
+};
+
+template <int CMAX>
+__global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
+    FrameView fv, MsckfOpts op, int b0, const int* __restrict__ accept_in, int* __restrict__ used_out,
+    const double* __restrict__ rec_in, double* __restrict__ Apart, int* __restrict__ chunk_used, int G, int rstride)
+{
+    using Cfg = Gram2Cfg<CMAX>;
+    constexpr int NC = Cfg::NC, TJ = Cfg::TJ, LDW = Cfg::LDW, NTILE = Cfg::NTILE, TPW = Cfg::TPW, REC = Cfg::REC, KR = Cfg::KR;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Gram2Batch<CMAX>& sb = *reinterpret_cast<Gram2Batch<CMAX>*>(smem_raw);
+    Gram2Out<CMAX>& so = *reinterpret_cast<Gram2Out<CMAX>*>(smem_raw);             // epilogue view of the same LDS
+    constexpr size_t UNI = sizeof(Gram2Batch<CMAX>) > sizeof(Gram2Out<CMAX>) ? sizeof(Gram2Batch<CMAX>) : sizeof(Gram2Out<CMAX>);
+    int* sUse = reinterpret_cast<int*>(smem_raw + ((UNI + 15) / 16) * 16);
+    int* sList = sUse + fv.fmax;
+    __shared__ int sNu;
+    const int bl = blockIdx.y, b = b0 + bl, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int F = fv.n_feat[b], C = fv.n_clones[b], ncol = 6 * C;
+
+    dbg_stamp(32);
+    for (int j = tid; j < F; j += GRAM_NT) {                    // RemoveLostUpdate.cpp:357-359
+        int use = accept_in[(size_t)b * fv.fmax + j];
+        if (use && op.max_accept > 0) {
+            int rank = 0;
+            for (int q = 0; q < j; ++q) rank += accept_in[(size_t)b * fv.fmax + q];
+            if (rank >= op.max_accept) use = 0;
+        }
+        sUse[j] = use;
+        if (g == 0) used_out[(size_t)b * fv.fmax + j] = use;
+    }
+    // zero the operand panels once: padding columns (and rows of a short last batch) stay zero
+    for (int e = tid; e < KR * LDW; e += GRAM_NT) { (&sb.Bm[0][0])[e] = 0.0; (&sb.Ym[0][0])[e] = 0.0; }
+    __syncthreads();
+    if (wave == 0) {                                            // ordered list of the used features
+        int cnt = 0;
+        for (int base = 0; base < F; base += WAVE) {
+            const int j = base + lane;
+            const bool u = j < F && sUse[j];
+            const unsigned long long m = __ballot(u);
+            if (u) sList[cnt + __popcll(m & ((1ULL << lane) - 1ULL))] = j;
+            cnt += __popcll(m);
+        }
+        if (lane == 0) sNu = cnt;
+    }
+    __syncthreads();
+    const int nu = sNu, per = (nu + G - 1) / G;
+    const int q0 = g * per, q1 = min(nu, q0 + per);
+
+    dbg_stamp(33);
+    // MFMA accumulators: wave w owns tiles t = w, w+4, ...
+    double4_f acc[TPW];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) acc[u] = double4_f{ 0.0, 0.0, 0.0, 0.0 };
+    // sparse accumulators of lane (c, a)
+    const int pc = tid / CMAX, pa = tid - pc * CMAX;
+    const bool pairlane = tid < CMAX * CMAX;
+    double sS1[9], sNX[9], sS3[9], s4[3], s5[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { sS1[i] = 0.0; sNX[i] = 0.0; sS3[i] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { s4[i] = 0.0; s5[i] = 0.0; }
+    const int kq = lane >> 4, l15 = lane & 15;
+
+    for (int qb = q0; qb < q1; qb += GRAM_NB) {
+        const int nbf = min(GRAM_NB, q1 - qb);
+        dbg_stamp(34);
+        // ---- P0: records ---------------------------------------------------------------------
+        for (int e = tid; e < nbf * REC; e += GRAM_NT) {
+            const int f = e / REC, w = e - f * REC;
+            sb.rec[f][w] = rec_in[((size_t)b * fv.fmax + sList[qb + f]) * REC + w];
+        }
+        if (nbf < GRAM_NB) {                                   // short last batch: clear the unused stacked rows
+            for (int e = tid; e < (KR - 3 * nbf) * LDW; e += GRAM_NT) { (&sb.Bm[3 * nbf][0])[e] = 0.0; (&sb.Ym[3 * nbf][0])[e] = 0.0; }
+        }
+        __syncthreads();
+        dbg_stamp(35);
+        // ---- P1: per-feature sums over the observations -------------------------------------------
+        if (tid < nbf * 24) {
+            const int f = tid / 24, comp = tid - 24 * f, anch = comp >= 12, cc = comp - 12 * anch;
+            const double* rc = sb.rec[f];
+            const int nobs = (int)rc[0];
+            double s = 0.0;
+            for (int o = 0; o < nobs; ++o) {
+                const double* ro = rc + REC_HDR + REC_OBS * o;
+                if (!anch || ro[1] != 0.0) s += ro[3 + cc];
+            }
+            sb.sums[f][comp] = s;
+        }
+        __syncthreads();
+        dbg_stamp(36);
+        // ---- P2: operand rows B, Y = Ns^-1 B and the sparse scratch, lane = (feature, window slot) -----
+        if (tid < nbf * 16) {
+            const int f = tid >> 4, c = tid & 15;
+            if (c < C) {
+                const double* rc = sb.rec[f];
+                const int a = (int)rc[1];
+                const double px = rc[2], py = rc[3], pz = rc[4];
+                const unsigned mask = (unsigned)rc[5];
+                const bool obs = (mask >> c) & 1u;
+                const int o = __popc(mask & ((1u << c) - 1u));
+                const double* ro = rc + REC_HDR + REC_OBS * (obs ? o : 0);
+                const double* sm = sb.sums[f];
+                double Nsi[9];
+                inv3sym(sm, Nsi);
+                double Bt[9], Bp[9], NX[9];
+                const double cn = (obs && ro[1] != 0.0) ? 1.0 : 0.0, pl = (obs && ro[2] != 0.0) ? 1.0 : 0.0;
+                mulX(ro + 3, px, py, pz, NX);                       // N_o X
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { Bt[i] = cn * NX[i]; Bp[i] = -pl * ro[3 + i]; }
+                if (c == a) {                                       // theta_anchor block: -Nsa X   (the anchor's own cn is 0)
+                    double T[9];
+                    mulX(sm + 12, px, py, pz, T);
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) Bt[i] = -T[i];
+                }
+                double Yt[9], Yp[9];
+                mul33(Nsi, Bt, Yt);
+                mul33(Nsi, Bp, Yp);
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        sb.Bm[3 * f + k][6 * c + q] = Bt[3 * k + q];
+                        sb.Bm[3 * f + k][6 * c + 3 + q] = Bp[3 * k + q];
+                        sb.Ym[3 * f + k][6 * c + q] = Yt[3 * k + q];
+                        sb.Ym[3 * f + k][6 * c + 3 + q] = Yp[3 * k + q];
+                    }
+                if (c == 0) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) sb.Bm[3 * f + k][NC] = sm[9 + k];      // extra column: hs
+                }
+                // sparse scratch
+                double* sp = sb.sp[f][c < CMAX ? c : 0];
+                double S1[9];
+                mulXt(NX, px, py, pz, S1);                          // X^T N X
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { sp[i] = cn * S1[i]; sp[9 + i] = cn * pl * NX[i]; }
+                sp[18] = cn * (pz * ro[13] - py * ro[14]);          // X^T h_o = h_o x p_f
+                sp[19] = cn * (px * ro[14] - pz * ro[12]);
+                sp[20] = cn * (py * ro[12] - px * ro[13]);
+                sp[21] = obs ? 1.0 : 0.0;
+                sp[22] = pl;
+                sp[23] = (double)o;
+            }
+        }
+        __syncthreads();
+        dbg_stamp(37);
+        // ---- P3a: rank-3 part on the matrix cores ------------------------------------------------
+        const int nst = (3 * nbf + 3) >> 2;
+        for (int st = 0; st < nst; ++st) {
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
+                const int t = wave + 4 * u;
+                if (t < NTILE) {
+                    const int ti = t / TJ, tj = t - ti * TJ;
+                    const double af = sb.Ym[4 * st + kq][16 * ti + l15];      // A[i][k] = Y[k][i]
+                    const double bf = sb.Bm[4 * st + kq][16 * tj + l15];      // B[k][j]
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[u], 0, 0, 0);
+                }
+            }
+        }
+        dbg_stamp(38);
+        // ---- P3b: sparse part, lane (c, a) ----------------------------------------------------------
+        if (pairlane) {
+            for (int f = 0; f < nbf; ++f) {
+                const double* rc = sb.rec[f];
+                if ((int)rc[1] != pa) continue;
+                const double* sp = sb.sp[f][pc];
+                if (sp[21] == 0.0) continue;
+                const double pl = sp[22];
+                const double* ro = rc + REC_HDR + REC_OBS * (int)sp[23];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { sS1[i] += sp[i]; sNX[i] += sp[9 + i]; sS3[i] += pl * ro[3 + i]; }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { s4[i] += sp[18 + i]; s5[i] += pl * ro[12 + i]; }
+            }
+        }
+        __syncthreads();
+    }
+
+    dbg_stamp(39);
+    // ---- epilogue: assemble [A | b] of the chunk ---------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const int t = wave + 4 * u;
+        if (t < NTILE) {
+            const int ti = t / TJ, tj = t - ti * TJ;
+            const int jc = 16 * tj + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ti + kq + 4 * r;      // C/D: col = lane&15, row = (lane>>4)+4r
+                if (i < NC && jc <= NC) so.A2[i][jc] = acc[u][r];
+            }
+        }
+    }
+    if (pairlane) {
+        double* S = so.S[pc][pa];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { S[i] = sS1[i]; S[9 + i] = sNX[i]; S[18 + i] = sS3[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { S[27 + i] = s4[i]; S[30 + i] = s5[i]; }
+    }
+    __syncthreads();
+    double* out = Apart + ((size_t)bl * G + g) * rstride;      // [ncol][ncol+1] row-major, b in the last column
+    if (pairlane && pc < C && pa < C) {
+        const int c = pc, c2 = pa;
+        double blk[36];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) blk[i] = 0.0;
+        double bb[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+        if (c == c2) {
+            for (int a = 0; a < C; ++a) {
+                const double* S = so.S[c][a];          // obs at slot c, anchor a
+                const double* Sa = so.S[a][c];         // obs at slot a, anchor c  -> (theta_c, theta_c) += S1
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int q2 = 0; q2 < 3; ++q2) {
+                        blk[6 * q + q2] += S[3 * q + q2] + Sa[3 * q + q2];
+                        blk[6 * q + 3 + q2] -= S[9 + 3 * q2 + q];            // (theta,p) = -NXs^T
+                        blk[6 * (3 + q) + q2] -= S[9 + 3 * q + q2];          // (p,theta) = -NXs
+                        blk[6 * (3 + q) + 3 + q2] += S[18 + 3 * q + q2];
+                    }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { bb[q] += S[27 + q] - Sa[27 + q]; bb[3 + q] -= S[30 + q]; }
+            }
+        } else {
+            const double* S = so.S[c][c2];             // obs at slot c, anchor c2
+            const double* St = so.S[c2][c];            // obs at slot c2, anchor c
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int q2 = 0; q2 < 3; ++q2) {
+                    blk[6 * q + q2] = -S[3 * q + q2] - St[3 * q + q2];       // S1 is symmetric
+                    blk[6 * (3 + q) + q2] = S[9 + 3 * q + q2];               // (p_c, theta_a) = +NXs
+                    blk[6 * q + 3 + q2] = St[9 + 3 * q2 + q];                // (theta_a, p_c') = +NXs^T
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+#pragma unroll
+            for (int q2 = 0; q2 < 6; ++q2)
+                out[(size_t)(6 * c + q) * (ncol + 1) + 6 * c2 + q2] = blk[6 * q + q2] - so.A2[6 * c + q][6 * c2 + q2];
+            if (c == c2) out[(size_t)(6 * c + q) * (ncol + 1) + ncol] = bb[q] - so.A2[6 * c + q][NC];
+        }
+    }
+    if (tid == 0) chunk_used[bl * G + g] = max(0, q1 - q0);
+    dbg_stamp(40);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -748,75 +1048,99 @@ __global__ __launch_bounds__(INFO_NT) void k_info_update(
 // K4 = MP / 4 is a compile-time constant: all operand loads of a tile are issued before its MFMAs.
 // grid = (ceil(nt / 4), nb), 4 waves per workgroup.
 // ---------------------------------------------------------------------------------------------
-typedef double double4_f __attribute__((ext_vector_type(4)));
 
 template <int NC>
 __global__ __launch_bounds__(256) void k_info_apply(CovView cv, int b0, const double* __restrict__ Mall, int mstride,
                                                     const double* __restrict__ Pcall, int ystride, const int* __restrict__ m_all,
-                                                    double* __restrict__ dx_all, int* __restrict__ status)
+                                                    double* __restrict__ dx_all, int* __restrict__ status,
+                                                    const int* __restrict__ marg_idx, int msize)
 {
     constexpr int MP = (NC + 3) & ~3, K4 = MP / 4, JT = (MP + 15) / 16;
     __shared__ double sT[4][16][MP + 2];
+    __shared__ double sV[4][16][17];
     const int bl = blockIdx.y, b = b0 + bl;
-    if (m_all[bl] == 0) return;
+    const bool upd = m_all[bl] != 0;
+    const int midx = marg_idx ? marg_idx[bl] : -1;            // fused StateManager::marginalize of [midx, midx+msize)
+    const bool fused = midx >= 0;
+    if (!upd && !fused) return;
     const int n = cv.n[b], ld = cv.ldp, nt = (n + 15) >> 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ti = blockIdx.x * 4 + wave;
     if (ti >= nt) return;
-    double* P = cov_ptr(cv, b);
+    const double* P = cov_ptr(cv, b);
+    double* dst = fused ? cov_alt_ptr(cv, b) : cov_ptr(cv, b);
     const double* Pc = Pcall + (size_t)bl * ystride;
     const double* M = Mall + (size_t)bl * mstride;
     const double* tvec = M + (size_t)MP * MP;
     const int l15 = lane & 15, kq = lane >> 4;
-    const int ra = min(ti * 16 + l15, n - 1);                    // clamped: rows >= n are computed but never stored
-    double afrag[K4];
-#pragma unroll
-    for (int k4 = 0; k4 < K4; ++k4) afrag[k4] = Pc[ra + (size_t)(4 * k4 + kq) * ld];
-    {
-        double d = 0.0;
-#pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) d += afrag[k4] * tvec[4 * k4 + kq];
-        d += __shfl_xor(d, 16, WAVE);
-        d += __shfl_xor(d, 32, WAVE);
-        if (kq == 0 && ti * 16 + l15 < n) dx_all[(size_t)b * ld + ra] = d;
-    }
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt) {
-        double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
-        const int jc = min(jt * 16 + l15, MP - 1);
-        double bfrag[K4];
-#pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) bfrag[k4] = M[(size_t)(4 * k4 + kq) * MP + jc];      // B[k][j] = M[k][j]
-#pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[k4], bfrag[k4], acc, 0, 0, 0);
-        if (jt * 16 + l15 < MP) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sT[wave][kq + 4 * r][jc] = acc[r];      // C/D: col = lane&15, row = (lane>>4)+4r
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
     double tfrag[K4];
+    if (upd) {
+        const int ra = min(ti * 16 + l15, n - 1);                    // clamped: rows >= n are computed but never stored
+        double afrag[K4];
 #pragma unroll
-    for (int k4 = 0; k4 < K4; ++k4) tfrag[k4] = sT[wave][l15][4 * k4 + kq];      // A[i][k] = T[i][k]
+        for (int k4 = 0; k4 < K4; ++k4) afrag[k4] = Pc[ra + (size_t)(4 * k4 + kq) * ld];
+        {
+            double d = 0.0;
+#pragma unroll
+            for (int k4 = 0; k4 < K4; ++k4) d += afrag[k4] * tvec[4 * k4 + kq];
+            d += __shfl_xor(d, 16, WAVE);
+            d += __shfl_xor(d, 32, WAVE);
+            if (kq == 0 && ti * 16 + l15 < n) dx_all[(size_t)b * ld + ra] = d;
+        }
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
+            const int jc = min(jt * 16 + l15, MP - 1);
+            double bfrag[K4];
+#pragma unroll
+            for (int k4 = 0; k4 < K4; ++k4) bfrag[k4] = M[(size_t)(4 * k4 + kq) * MP + jc];      // B[k][j] = M[k][j]
+#pragma unroll
+            for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[k4], bfrag[k4], acc, 0, 0, 0);
+            if (jt * 16 + l15 < MP) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sT[wave][kq + 4 * r][jc] = acc[r];      // C/D: col = lane&15, row = (lane>>4)+4r
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) tfrag[k4] = sT[wave][l15][4 * k4 + kq];      // A[i][k] = T[i][k]
+    }
+    // index map of the fused marginalisation (identity when not fused)
+    auto alive = [&](int i) { return !(fused && i >= midx && i < midx + msize); };
+    auto remap = [&](int i) { return (fused && i >= midx) ? i - msize : i; };
     for (int tj = 0; tj <= ti; ++tj) {
-        const int rb = min(tj * 16 + l15, n - 1);
         double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
-        double bfrag[K4];
+        if (upd) {
+            const int rb = min(tj * 16 + l15, n - 1);
+            double bfrag[K4];
 #pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) bfrag[k4] = Pc[rb + (size_t)(4 * k4 + kq) * ld];      // B[k][j] = Pc[rj + j][k]
+            for (int k4 = 0; k4 < K4; ++k4) bfrag[k4] = Pc[rb + (size_t)(4 * k4 + kq) * ld];      // B[k][j] = Pc[rj + j][k]
 #pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tfrag[k4], bfrag[k4], acc, 0, 0, 0);
+            for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tfrag[k4], bfrag[k4], acc, 0, 0, 0);
+        }
+        // element (row, col), row >= col, of the lower tile: read and stored through the mirrored address (col fastest,
+        // coalesced); its transpose goes through LDS so that the second store runs along rows, coalesced as well
         const int col = tj * 16 + l15;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = ti * 16 + kq + 4 * r;
+            double v = 0.0;
             if (row < n && col < n && row >= col) {
-                const double v = P[col + (size_t)row * ld] - acc[r];      // read through the mirrored (coalesced) address
-                P[col + (size_t)row * ld] = v;
-                P[row + (size_t)col * ld] = v;
-                if (row == col && v < 0.0) atomicOr(&status[b], 2);      // StateManager.cpp:413-421
+                v = P[col + (size_t)row * ld] - acc[r];
+                if (alive(row) && alive(col)) dst[remap(col) + (size_t)remap(row) * ld] = v;
+                if (upd && row == col && v < 0.0) atomicOr(&status[b], 2);      // StateManager.cpp:413-421
             }
+            sV[wave][kq + 4 * r][l15] = v;
         }
+        __builtin_amdgcn_wave_barrier();
+        const int row2 = ti * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col2 = tj * 16 + kq + 4 * r;
+            if (row2 < n && col2 < n && row2 > col2 && alive(row2) && alive(col2))
+                dst[remap(row2) + (size_t)remap(col2) * ld] = sV[wave][l15][kq + 4 * r];
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -829,8 +1153,14 @@ static void launch_ft(const FactoredLaunch& L, hipStream_t st)
         hipLaunchKernelGGL((k_feat_gate3<CMAX, STEREO>), dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st,
                            L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
     } else {
-        const size_t sm = ((sizeof(GramShared<CMAX>) + 15) / 16) * 16 + sizeof(int) * (size_t)L.fv.fmax;
-        hipLaunchKernelGGL((k_feat_gram<CMAX, STEREO>), dim3(L.G, L.nb), dim3(GramShared<CMAX>::NT), sm, st,
+        constexpr size_t uni = sizeof(Gram2Batch<CMAX>) > sizeof(Gram2Out<CMAX>) ? sizeof(Gram2Batch<CMAX>) : sizeof(Gram2Out<CMAX>);
+        const size_t sm = ((uni + 15) / 16) * 16 + 2 * sizeof(int) * (size_t)L.fv.fmax;
+        static size_t attr_sm = 0;
+        if (sm > attr_sm) {
+            hipFuncSetAttribute((const void*)k_feat_gram2<CMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            attr_sm = sm;
+        }
+        hipLaunchKernelGGL((k_feat_gram2<CMAX>), dim3(L.G, L.nb), dim3(GRAM_NT), sm, st,
                            L.fv, L.op, L.b0, L.accept, L.used, L.rec, L.Apart, L.chunk_used, L.G, L.rstride);
     }
 }
@@ -848,7 +1178,7 @@ int launch_factored(const FactoredLaunch& L, hipStream_t st)
         const int nt = (L.n_cap + 15) / 16;
 #define APPLY_DISPATCH(NC)                                                                                            \
         hipLaunchKernelGGL(k_info_apply<NC>, dim3((nt + 3) / 4, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, \
-                           L.ystride, L.m_out, L.dx, L.status);
+                           L.ystride, L.m_out, L.dx, L.status, L.marg_idx, L.marg_size);
         if (ncm <= 36) { APPLY_DISPATCH(36) } else if (ncm <= 66) { APPLY_DISPATCH(66) } else { APPLY_DISPATCH(96) }
 #undef APPLY_DISPATCH
         return 0;

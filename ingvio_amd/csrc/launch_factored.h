@@ -25,6 +25,8 @@ struct FactoredLaunch {
     int* m_out;
     int* nc_out;
     int* status;
+    const int* marg_idx;  // stage 3: fused StateManager::marginalize, per filter state index or -1 (nullptr: none)
+    int marg_size;
 };
 
 int launch_factored(const FactoredLaunch& L, hipStream_t st);
