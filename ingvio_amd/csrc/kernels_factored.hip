@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(INFO_NT) void k_info_update(
 // ---------------------------------------------------------------------------------------------
 
 template <int NC>
-__global__ __launch_bounds__(256) void k_info_apply(CovView cv, int b0, const double* __restrict__ Mall, int mstride,
+__global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int nb, int wgpf, const double* __restrict__ Mall, int mstride,
                                                     const double* __restrict__ Pcall, int ystride, const int* __restrict__ m_all,
                                                     double* __restrict__ dx_all, int* __restrict__ status,
                                                     const int* __restrict__ marg_idx, int msize)
@@ -1058,89 +1058,117 @@ __global__ __launch_bounds__(256) void k_info_apply(CovView cv, int b0, const do
     constexpr int MP = (NC + 3) & ~3, K4 = MP / 4, JT = (MP + 15) / 16;
     __shared__ double sT[4][16][MP + 2];
     __shared__ double sV[4][16][17];
-    const int bl = blockIdx.y, b = b0 + bl;
+    // XCD-aware order: the workgroups of one filter share an L2 (they all stream the same Pc and M)
+    const int wg = blockIdx.x, xcd = wg & 7, tq = wg >> 3;
+    const int bl = xcd + 8 * (tq / wgpf), part = tq % wgpf;
+    if (bl >= nb) return;
+    const int b = b0 + bl;
     const bool upd = m_all[bl] != 0;
     const int midx = marg_idx ? marg_idx[bl] : -1;            // fused StateManager::marginalize of [midx, midx+msize)
     const bool fused = midx >= 0;
     if (!upd && !fused) return;
     const int n = cv.n[b], ld = cv.ldp, nt = (n + 15) >> 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ti = blockIdx.x * 4 + wave;
-    if (ti >= nt) return;
+    const int pw = part * 4 + wave;                           // this wave owns tile rows pw and nt-1-pw: nt+1 tiles, balanced
+    if (2 * pw >= nt) return;
     const double* P = cov_ptr(cv, b);
     double* dst = fused ? cov_alt_ptr(cv, b) : cov_ptr(cv, b);
     const double* Pc = Pcall + (size_t)bl * ystride;
     const double* M = Mall + (size_t)bl * mstride;
     const double* tvec = M + (size_t)MP * MP;
     const int l15 = lane & 15, kq = lane >> 4;
-    double tfrag[K4];
-    if (upd) {
-        const int ra = min(ti * 16 + l15, n - 1);                    // clamped: rows >= n are computed but never stored
-        double afrag[K4];
-#pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) afrag[k4] = Pc[ra + (size_t)(4 * k4 + kq) * ld];
-        {
-            double d = 0.0;
-#pragma unroll
-            for (int k4 = 0; k4 < K4; ++k4) d += afrag[k4] * tvec[4 * k4 + kq];
-            d += __shfl_xor(d, 16, WAVE);
-            d += __shfl_xor(d, 32, WAVE);
-            if (kq == 0 && ti * 16 + l15 < n) dx_all[(size_t)b * ld + ra] = d;
-        }
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
-            const int jc = min(jt * 16 + l15, MP - 1);
-            double bfrag[K4];
-#pragma unroll
-            for (int k4 = 0; k4 < K4; ++k4) bfrag[k4] = M[(size_t)(4 * k4 + kq) * MP + jc];      // B[k][j] = M[k][j]
-#pragma unroll
-            for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[k4], bfrag[k4], acc, 0, 0, 0);
-            if (jt * 16 + l15 < MP) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sT[wave][kq + 4 * r][jc] = acc[r];      // C/D: col = lane&15, row = (lane>>4)+4r
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int k4 = 0; k4 < K4; ++k4) tfrag[k4] = sT[wave][l15][4 * k4 + kq];      // A[i][k] = T[i][k]
-    }
-    // index map of the fused marginalisation (identity when not fused)
     auto alive = [&](int i) { return !(fused && i >= midx && i < midx + msize); };
     auto remap = [&](int i) { return (fused && i >= midx) ? i - msize : i; };
-    for (int tj = 0; tj <= ti; ++tj) {
-        double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
+
+    for (int half = 0; half < 2; ++half) {
+        const int ti = half == 0 ? pw : nt - 1 - pw;
+        if (half == 1 && ti == pw) break;
+        double tfrag[K4];
         if (upd) {
-            const int rb = min(tj * 16 + l15, n - 1);
-            double bfrag[K4];
+            const int ra = min(ti * 16 + l15, n - 1);                    // clamped: rows >= n are computed but never stored
+            double afrag[K4];
 #pragma unroll
-            for (int k4 = 0; k4 < K4; ++k4) bfrag[k4] = Pc[rb + (size_t)(4 * k4 + kq) * ld];      // B[k][j] = Pc[rj + j][k]
+            for (int k4 = 0; k4 < K4; ++k4) afrag[k4] = (Pc + (size_t)(4 * k4) * ld)[ra + kq * ld];      // uniform base + one lane offset
+            {
+                double d = 0.0;
 #pragma unroll
-            for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tfrag[k4], bfrag[k4], acc, 0, 0, 0);
-        }
-        // element (row, col), row >= col, of the lower tile: read and stored through the mirrored address (col fastest,
-        // coalesced); its transpose goes through LDS so that the second store runs along rows, coalesced as well
-        const int col = tj * 16 + l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = ti * 16 + kq + 4 * r;
-            double v = 0.0;
-            if (row < n && col < n && row >= col) {
-                v = P[col + (size_t)row * ld] - acc[r];
-                if (alive(row) && alive(col)) dst[remap(col) + (size_t)remap(row) * ld] = v;
-                if (upd && row == col && v < 0.0) atomicOr(&status[b], 2);      // StateManager.cpp:413-421
+                for (int k4 = 0; k4 < K4; ++k4) d += afrag[k4] * tvec[4 * k4 + kq];
+                d += __shfl_xor(d, 16, WAVE);
+                d += __shfl_xor(d, 32, WAVE);
+                if (kq == 0 && ti * 16 + l15 < n) dx_all[(size_t)b * ld + ra] = d;
             }
-            sV[wave][kq + 4 * r][l15] = v;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int row2 = ti * 16 + l15;
+#pragma unroll 1
+            for (int jt = 0; jt < JT; ++jt) {
+                double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
+                const int jc = min(jt * 16 + l15, MP - 1);
+                double bfrag[K4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int col2 = tj * 16 + kq + 4 * r;
-            if (row2 < n && col2 < n && row2 > col2 && alive(row2) && alive(col2))
-                dst[remap(row2) + (size_t)remap(col2) * ld] = sV[wave][l15][kq + 4 * r];
+                for (int k4 = 0; k4 < K4; ++k4) bfrag[k4] = (M + (size_t)(4 * k4) * MP)[kq * MP + jc];      // B[k][j] = M[k][j]
+#pragma unroll
+                for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[k4], bfrag[k4], acc, 0, 0, 0);
+                if (jt * 16 + l15 < MP) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sT[wave][kq + 4 * r][jc] = acc[r];      // C/D: col = lane&15, row = (lane>>4)+4r
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k4 = 0; k4 < K4; ++k4) tfrag[k4] = sT[wave][l15][4 * k4 + kq];      // A[i][k] = T[i][k]
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
+        // tiles (ti, 0..ti); the Pc fragment and the P values of the next tile are in flight during this tile's MFMAs
+        double bcur[K4], pcur[4];
+        auto load_tile = [&](int tj, double (&bf)[K4], double (&pv)[4]) {
+            const int rb = min(tj * 16 + l15, n - 1);
+            if (upd) {
+#pragma unroll
+                for (int k4 = 0; k4 < K4; ++k4) bf[k4] = (Pc + (size_t)(4 * k4) * ld)[rb + kq * ld];      // B[k][j] = Pc[rj + j][k]
+            }
+            const int col = tj * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = ti * 16 + kq + 4 * r;
+                pv[r] = (row < n && col < n && row >= col) ? P[col + (size_t)row * ld] : 0.0;      // mirrored (coalesced) address
+            }
+        };
+        load_tile(0, bcur, pcur);
+        for (int tj = 0; tj <= ti; ++tj) {
+            double bnext[K4], pnext[4];
+            if (tj < ti) load_tile(tj + 1, bnext, pnext);
+            double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
+            if (upd) {
+#pragma unroll
+                for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tfrag[k4], bcur[k4], acc, 0, 0, 0);
+            }
+            // element (row, col), row >= col: stored through the mirrored address (col fastest, coalesced); its transpose
+            // goes through LDS so that the second store runs along rows, coalesced as well
+            const int col = tj * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = ti * 16 + kq + 4 * r;
+                const double v = pcur[r] - acc[r];
+                if (row < n && col < n && row >= col) {
+                    if (alive(row) && alive(col)) dst[remap(col) + (size_t)remap(row) * ld] = v;
+                    if (upd && row == col && v < 0.0) atomicOr(&status[b], 2);      // StateManager.cpp:413-421
+                }
+                sV[wave][kq + 4 * r][l15] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int row2 = ti * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col2 = tj * 16 + kq + 4 * r;
+                if (row2 < n && col2 < n && row2 > col2 && alive(row2) && alive(col2))
+                    dst[remap(row2) + (size_t)remap(col2) * ld] = sV[wave][l15][kq + 4 * r];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (tj < ti) {
+#pragma unroll
+                for (int k4 = 0; k4 < K4; ++k4) bcur[k4] = bnext[k4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pcur[r] = pnext[r];
+            }
+        }
     }
 }
 
@@ -1175,9 +1203,9 @@ int launch_factored(const FactoredLaunch& L, hipStream_t st)
 {
     const int ncm = 6 * L.fv.cmax;
     if (L.stage == 3) {
-        const int nt = (L.n_cap + 15) / 16;
+        const int nt = (L.n_cap + 15) / 16, wgpf = ((nt + 1) / 2 + 3) / 4, nb8 = (L.nb + 7) / 8 * 8;
 #define APPLY_DISPATCH(NC)                                                                                            \
-        hipLaunchKernelGGL(k_info_apply<NC>, dim3((nt + 3) / 4, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, \
+        hipLaunchKernelGGL(k_info_apply<NC>, dim3(nb8 * wgpf), dim3(256), 0, st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride, L.Pc, \
                            L.ystride, L.m_out, L.dx, L.status, L.marg_idx, L.marg_size);
         if (ncm <= 36) { APPLY_DISPATCH(36) } else if (ncm <= 66) { APPLY_DISPATCH(66) } else { APPLY_DISPATCH(96) }
 #undef APPLY_DISPATCH
