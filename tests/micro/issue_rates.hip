@@ -33,6 +33,11 @@ __global__ void k(double* out, long long* cyc, int iters)
                 }
                 if (MODE == 3) x[i] = fma(lds[(u * 8 + i) & 1023], 1e-12, x[i]);                         // LDS broadcast read + FMA
                 if (MODE == 4) acc[i & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[i], x[(i + 1) & 7], acc[i & 3], 0, 0, 0);
+                if (MODE == 7) {                                                                         // 2x 32-bit DPP row_newbcast + FMA
+                    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x[(i + 1) & 7]), 0x150 + 5, 0xf, 0xf, false);
+                    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x[(i + 1) & 7]), 0x150 + 5, 0xf, 0xf, false);
+                    x[i] = fma(__hiloint2double(hi, lo), 1e-12, x[i]);
+                }
                 if (MODE == 5) {                                                                         // DPP quad broadcast + FMA
                     const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x[(i + 1) & 7]), 0x55, 0xf, 0xf, true);
                     const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x[(i + 1) & 7]), 0x55, 0xf, 0xf, true);
@@ -77,5 +82,6 @@ int main()
     run<3>("ds_read_b64 bcast + fma");
     run<4>("mfma_f64_16x16x4");
     run<5>("2 dpp quad bcast + fma");
+    run<7>("2 dpp32 row_newbcast + fma");
     return 0;
 }
