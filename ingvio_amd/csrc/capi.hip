@@ -49,7 +49,7 @@ struct ingvio_ctx {
     // msckf / ekf workspaces
     double *d_gamma, *d_Rpart, *d_H, *d_res, *d_noise, *d_noise1, *d_Y, *d_Yc, *d_dx, *d_rec;
     int method;                    // 0 dense TSQR path, 1 factored (information-form) path
-    int *d_accept, *d_used, *d_chunk_used, *d_colmap, *d_m, *d_nc, *d_status;
+    int *d_accept, *d_used, *d_chunk_used, *d_colmap, *d_m, *d_nc, *d_status, *d_pcbase;
     // staged frame state
     int st_k, st_stereo, st_enable_gnss, st_fmax_used;
     double st_sigma[4], st_scb, st_srw;
@@ -215,8 +215,8 @@ int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int s
     { ProfScope p(c, PF_GATE2); L.stage = 0; if (launch_factored(L, c->st)) return INGVIO_E_UNSUPPORTED; }
     { ProfScope p(c, PF_GRAM); L.stage = 1; launch_factored(L, c->st); }
     L.mstride = c->ystride; L.n_cap = c->d.n_max;
+    L.marg_idx = marg_idx; L.marg_size = marg_size; L.pc_base = c->d_pcbase + b0;
     { ProfScope p(c, PF_INFO); L.stage = 2; launch_factored(L, c->st); }
-    L.marg_idx = marg_idx; L.marg_size = marg_size;
     { ProfScope p(c, PF_APPLY); L.stage = 3; launch_factored(L, c->st); }
     return last_launch(c);
 }
@@ -313,7 +313,7 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     rc |= dalloc(c, &c->d_gamma, (size_t)B * fm); rc |= dalloc(c, &c->d_accept, (size_t)B * fm); rc |= dalloc(c, &c->d_used, (size_t)B * fm);
     rc |= dalloc(c, &c->d_Rpart, (size_t)B * c->G * c->rstride); rc |= dalloc(c, &c->d_chunk_used, (size_t)B * c->G);
     rc |= dalloc(c, &c->d_H, (size_t)B * c->hstride); rc |= dalloc(c, &c->d_res, (size_t)B * c->mld);
-    rc |= dalloc(c, &c->d_colmap, (size_t)B * c->cstride); rc |= dalloc(c, &c->d_m, B); rc |= dalloc(c, &c->d_nc, B);
+    rc |= dalloc(c, &c->d_colmap, (size_t)B * c->cstride); rc |= dalloc(c, &c->d_m, B); rc |= dalloc(c, &c->d_nc, B); rc |= dalloc(c, &c->d_pcbase, B);
     rc |= dalloc(c, &c->d_noise, B); rc |= dalloc(c, &c->d_noise1, (size_t)c->mld * c->mld);
     rc |= dalloc(c, &c->d_Y, (size_t)B * c->ystride); rc |= dalloc(c, &c->d_Yc, (size_t)B * c->ystride);
     rc |= dalloc(c, &c->d_dx, (size_t)B * c->ldp);
@@ -331,7 +331,7 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
     void* ptrs[] = { c->Pbase, c->Psnap, c->d_cur, c->d_n, c->d_n_snap, c->d_Phi, c->d_G, c->d_dt, c->d_R, c->d_blk, c->d_gnss,
                      c->d_idx, c->d_clone_idx, c->d_nclones, c->d_nfeat, c->d_anchor, c->d_dof, c->d_clone_R, c->d_clone_p,
                      c->d_pf, c->d_uv, c->d_chi2, c->d_mask, c->d_gamma, c->d_accept, c->d_used, c->d_Rpart, c->d_chunk_used,
-                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status };
+                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (c->own_stream) hipStreamDestroy(c->st);

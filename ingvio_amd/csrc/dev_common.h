@@ -56,6 +56,15 @@ __device__ __forceinline__ double wave_sum(double x)
     return x;
 }
 
+// 1/x to full FP64 precision: v_rcp_f64 + two Newton steps (the IEEE division expands to ~3x the latency)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 // phase-timing probes (debug): block (0,0) lane 0 stamps the shader clock; read with ingvio_debug_read
 static __device__ long long g_dbg[64];      // one copy per translation unit (no -fgpu-rdc)
 __device__ __forceinline__ void dbg_stamp(int slot)

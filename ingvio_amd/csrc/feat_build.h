@@ -40,15 +40,16 @@ __device__ __forceinline__ bool feat_obs(const double* R, const double* p, const
         q[i] = R[i] * dx + R[3 + i] * dy + R[6 + i] * dz;                 // R^T (p_f - p), :448
         Rt[3 * i] = R[i]; Rt[3 * i + 1] = R[3 + i]; Rt[3 * i + 2] = R[6 + i];
     }
-    const double iz = 1.0 / q[2];
-    const double hp02 = -q[0] / (q[2] * q[2]), hp12 = -q[1] / (q[2] * q[2]);   // :452-456
+    // reciprocal by v_rcp_f64 + Newton (~1 ulp); q_z == 0 keeps the IEEE result so the guard below sees inf/NaN as the reference does
+    const double iz = q[2] == 0.0 ? __builtin_copysign(__builtin_inf(), q[2]) : fast_rcp(q[2]);
+    const double hp02 = -q[0] * (iz * iz), hp12 = -q[1] * (iz * iz);   // :452-456
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         Gm[0][m] = iz * Rt[m] + hp02 * Rt[6 + m];
         Gm[1][m] = iz * Rt[3 + m] + hp12 * Rt[6 + m];
     }
-    rs[0] = z[0] - q[0] / q[2];
-    rs[1] = z[1] - q[1] / q[2];
+    rs[0] = z[0] - q[0] * iz;
+    rs[1] = z[1] - q[1] * iz;
     bool nan = (iz != iz) || (hp02 != hp02) || (hp12 != hp12);                 // :486
 #pragma unroll
     for (int i = 0; i < 9; ++i) nan |= (R[i] != R[i]);
@@ -63,15 +64,15 @@ __device__ __forceinline__ bool feat_obs(const double* R, const double* p, const
 #pragma unroll
             for (int m = 0; m < 3; ++m)
                 M[3 * i + m] = op.R_lr[3 * i] * Rt[m] + op.R_lr[3 * i + 1] * Rt[3 + m] + op.R_lr[3 * i + 2] * Rt[6 + m];
-        const double izr = 1.0 / qr[2];
-        const double h02 = -qr[0] / (qr[2] * qr[2]), h12 = -qr[1] / (qr[2] * qr[2]);     // :458-462
+        const double izr = qr[2] == 0.0 ? __builtin_copysign(__builtin_inf(), qr[2]) : fast_rcp(qr[2]);
+        const double h02 = -qr[0] * (izr * izr), h12 = -qr[1] * (izr * izr);     // :458-462
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
             Gm[RPO - 2][m] = izr * M[m] + h02 * M[6 + m];
             Gm[RPO - 1][m] = izr * M[3 + m] + h12 * M[6 + m];
         }
-        rs[RPO - 2] = z[2] - qr[0] / qr[2];
-        rs[RPO - 1] = z[3] - qr[1] / qr[2];                                             // :503
+        rs[RPO - 2] = z[2] - qr[0] * izr;
+        rs[RPO - 1] = z[3] - qr[1] * izr;                                               // :503
     }
     return !nan;
 }

@@ -20,20 +20,11 @@
 
 typedef double double4_f __attribute__((ext_vector_type(4)));
 
-// 1/x to full FP64 precision: v_rcp_f64 + two Newton steps (the IEEE division expands to ~3x the latency)
-__device__ __forceinline__ double fast_rcp(double x)
-{
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-}
-
 __device__ __forceinline__ void inv3sym(const double N[9], double out[9])
 {
     const double a = N[0], b = N[1], c = N[2], d = N[4], e = N[5], f = N[8];
     const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
-    const double det = a * c00 + b * c01 + c * c02, id = 1.0 / det;
+    const double det = a * c00 + b * c01 + c * c02, id = fast_rcp(det);
     out[0] = c00 * id; out[1] = c01 * id; out[2] = c02 * id;
     out[3] = out[1]; out[4] = (a * f - c * c) * id; out[5] = (b * c - a * e) * id;
     out[6] = out[2]; out[7] = out[5]; out[8] = (a * d - b * b) * id;
@@ -349,27 +340,23 @@ __global__ __launch_bounds__(WAVE) void k_feat_gate3(
             }
         }
     }
-    // ---- gamma from the border: Z = W^T K^-1 W (+ residual part), gamma = Z00 - f^T Zff^-1 f -----
-    double W[4][4];
+    // ---- gamma: three more pivots on the Hf border rows (indices 1..3) leave -(Z00 - f^T Zff^-1 f) at (0,0),
+    //      Z = W^T K^-1 W; the part of r outside range(Gblk) adds |r_perp|^2 / s^2 (stereo) ---------------
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int p = 1; p < 4; ++p) {
+        const double dp = bcast_lane(col[p], p);
+        const double f = col[p] * fast_rcp(dp);
+        col[0] = fma(-bcast_lane(col[0], p), f, col[0]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) W[i][q] = -bcast_lane(col[i], q);
-    if (STEREO) {
-        double rp = 0.0;
-        for (int o = 0; o < nobs; ++o) rp += sh.rperp[o];
-        W[0][0] += rp / op.var;
+        for (int i = p + 1; i < 4; ++i) col[i] = fma(-bcast_lane(col[i], p), f, col[i]);
     }
     if (tid == 0) {
-        const double l00 = sqrt(W[1][1]);
-        const double l10 = W[2][1] / l00, l20 = W[3][1] / l00;
-        const double l11 = sqrt(W[2][2] - l10 * l10);
-        const double l21 = (W[3][2] - l20 * l10) / l11;
-        const double l22 = sqrt(W[3][3] - l20 * l20 - l21 * l21);
-        const double y0 = W[1][0] / l00;
-        const double y1 = (W[2][0] - l10 * y0) / l11;
-        const double y2 = (W[3][0] - l20 * y0 - l21 * y1) / l22;
-        const double g = W[0][0] - (y0 * y0 + y1 * y1 + y2 * y2);
+        double g = -col[0];
+        if (STEREO) {
+            double rp = 0.0;
+            for (int o = 0; o < nobs; ++o) rp += sh.rperp[o];
+            g += rp / op.var;
+        }
         const int dof = fv.dof[oidx];
         const bool ok = dof >= 1 && dof < op.chi2_len && g < op.chi2[dof];      // Update.cpp:120
         gamma_out[oidx] = g;
@@ -875,10 +862,11 @@ __global__ __launch_bounds__((GramShared<CMAX>::NT)) void k_feat_gram(
 // window are zero rows/columns of A, for which K1 = s^2 I and M = 0 (harmless), so no loop needs a
 // runtime guard and every register array is fully used.
 template <int NC>
-__global__ __launch_bounds__(INFO_NT) void k_info_update(
+__global__ __launch_bounds__(INFO_NT, 2) void k_info_update(
     CovView cv, FrameView fv, int b0, const double* __restrict__ Apart, const int* __restrict__ chunk_used, int G, int rstride,
     const double* __restrict__ noise_all, double* __restrict__ Mall, int mstride, double* __restrict__ Pcall, int ystride,
-    double* __restrict__ dx_all, int* __restrict__ m_out, int* __restrict__ nc_out, int* __restrict__ status)
+    double* __restrict__ dx_all, int* __restrict__ m_out, int* __restrict__ nc_out, int* __restrict__ status,
+    const int* __restrict__ marg_idx, int* __restrict__ pc_base_out)
 {
     constexpr int LA = 2 * NC + 1, MP = (NC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -892,7 +880,7 @@ __global__ __launch_bounds__(INFO_NT) void k_info_update(
     for (int g = 0; g < G; ++g) total += chunk_used[bl * G + g];
     if (total == 0) {
         for (int r = tid; r < n; r += INFO_NT) dx[r] = 0.0;
-        if (tid == 0) { m_out[bl] = 0; nc_out[bl] = ncol; }
+        if (tid == 0) { m_out[bl] = 0; nc_out[bl] = ncol; pc_base_out[bl] = -1; }
         return;
     }
     const double* P = cov_ptr(cv, b);
@@ -902,35 +890,55 @@ __global__ __launch_bounds__(INFO_NT) void k_info_update(
     if (tid < 2) sBest[tid] = 0ULL;
     const int tx = tid & 63, ty = tid >> 6;               // 64 x 8 thread grid: no runtime div/mod in the loops
     for (int i = ty; i < NC; i += INFO_NT / 64) {
-        for (int j = tx; j <= NC; j += 64) {
-            double s = 0.0;
+#pragma unroll
+        for (int jq = 0; jq < (NC + 1 + 63) / 64; ++jq) {
+            const int j = tx + 64 * jq;
+            if (j > NC) continue;
             const int jj = j == NC ? ncol : j;                  // b lives in column ncol of the partials
+            double s = 0.0;
             if (i < ncol && (j < ncol || j == NC)) {
                 const size_t e = (size_t)i * (ncol + 1) + jj;
-                for (int g = 0; g < G; ++g)
-                    if (chunk_used[bl * G + g]) s += Apart[((size_t)bl * G + g) * rstride + e];
+                for (int g0 = 0; g0 < G; g0 += 4) {             // four partial loads in flight
+                    double t[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int g = g0 + u;
+                        t[u] = (g < G && chunk_used[bl * G + g]) ? Apart[((size_t)bl * G + g) * rstride + e] : 0.0;
+                    }
+                    s += (t[0] + t[1]) + (t[2] + t[3]);
+                }
             }
             aug[i * LA + NC + j] = s;
         }
     }
     __syncthreads();
     dbg_stamp(1);
+    // zero-copy operand for k_info_apply: when the update is written out of place (fused marginalisation) and the
+    // window's clones are one contiguous column block, Pc is P itself and the copy below is skipped
+    const bool fused = marg_idx && marg_idx[bl] >= 0;
+    const int contig = __syncthreads_and(tid >= ncol || sCol[tid < NC ? tid : 0] == sCol[0] + tid);
+    const bool zero_copy = fused && contig && sCol[0] + ((NC + 3) & ~3) <= ld;
     // K1 = A Pcc + s^2 I.  Lane j keeps column j of Pcc in registers (NC independent, coalesced loads: one
     // memory latency instead of a dependent chain); KG row groups share the rows.
     {
         constexpr int KG = INFO_NT / NC;
         const int j = tid % NC, g = tid / NC;
         if (g < KG) {
-            double pc[NC];
+            constexpr int NH = (NC + 1) / 2;                   // two halves of the k range: half the registers
             const int gj = sCol[j];
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                const int k0 = h * NH;
+                double pc[NH];
 #pragma unroll
-            for (int k = 0; k < NC; ++k) pc[k] = P[gj + (size_t)sCol[k] * ld];      // Pcc[k][j] = P[gj, gk]
-            for (int i = g; i < NC; i += KG) {
-                double s = (i == j) ? var : 0.0;
-                const double* arow = aug + i * LA + NC;
+                for (int k = 0; k < NH; ++k) pc[k] = (k0 + k < NC) ? P[gj + (size_t)sCol[k0 + k < NC ? k0 + k : 0] * ld] : 0.0;
+                for (int i = g; i < NC; i += KG) {
+                    double s = h == 0 ? ((i == j) ? var : 0.0) : aug[i * LA + j];
+                    const double* arow = aug + i * LA + NC + k0;
 #pragma unroll
-                for (int k = 0; k < NC; ++k) s += arow[k] * pc[k];
-                aug[i * LA + j] = s;
+                    for (int k = 0; k < NH; ++k) s += (k0 + k < NC ? arow[k] : 0.0) * pc[k];
+                    aug[i * LA + j] = s;
+                }
             }
         }
     }
@@ -985,7 +993,7 @@ __global__ __launch_bounds__(INFO_NT) void k_info_update(
         if (active) {
             const double piv = rowbuf[k];
             if (tid == 0) sPivVal[k] = piv;
-            const double inv = 1.0 / piv;
+            const double inv = fast_rcp(piv);
             const double r0 = rowbuf[j0], r1 = j1 < LA ? rowbuf[j1] : 0.0;
             const int kn = k + 1, knc = kn >= TXN ? 1 : 0;
             const bool own_next = kn < NC && gx == kn - knc * TXN;
@@ -1014,7 +1022,7 @@ __global__ __launch_bounds__(INFO_NT) void k_info_update(
             const int i = gy + TYN * q;
             if (i < NC) {
                 const int ks = sInv[i];
-                const double d = 1.0 / sPivVal[ks];
+                const double d = fast_rcp(sPivVal[ks]);
                 if (j0 >= NC) sol[ks * (NC + 1) + (j0 - NC)] = v[q][0] * d;
                 if (j1 >= NC && j1 < LA) sol[ks * (NC + 1) + (j1 - NC)] = v[q][1] * d;
             }
@@ -1029,13 +1037,14 @@ __global__ __launch_bounds__(INFO_NT) void k_info_update(
         for (int j = tx; j < MP; j += 64) Mg[(size_t)i * MP + j] = (i < NC && j < NC) ? sol[i * (NC + 1) + j] : 0.0;
     for (int i = tid; i < MP; i += INFO_NT) Mg[(size_t)MP * MP + i] = i < NC ? sol[i * (NC + 1) + NC] : 0.0;
     double* Pc = Pcall + (size_t)bl * ystride;
+    if (!zero_copy)
     for (int k = ty; k < MP; k += INFO_NT / 64) {
         const int gk = k < NC ? sCol[k] : 0;
         const bool real = k < ncol;
         for (int r = tx; r < n; r += 64) Pc[r + (size_t)k * ld] = real ? P[r + (size_t)gk * ld] : 0.0;
     }
     dbg_stamp(4);
-    if (tid == 0) { m_out[bl] = ncol; nc_out[bl] = ncol; }
+    if (tid == 0) { m_out[bl] = ncol; nc_out[bl] = ncol; pc_base_out[bl] = zero_copy ? sCol[0] : -1; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1053,7 +1062,7 @@ template <int NC>
 __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int nb, int wgpf, const double* __restrict__ Mall, int mstride,
                                                     const double* __restrict__ Pcall, int ystride, const int* __restrict__ m_all,
                                                     double* __restrict__ dx_all, int* __restrict__ status,
-                                                    const int* __restrict__ marg_idx, int msize)
+                                                    const int* __restrict__ marg_idx, int msize, const int* __restrict__ pc_base)
 {
     constexpr int MP = (NC + 3) & ~3, K4 = MP / 4, JT = (MP + 15) / 16;
     __shared__ double sT[4][16][MP + 2];
@@ -1073,7 +1082,10 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     if (2 * pw >= nt) return;
     const double* P = cov_ptr(cv, b);
     double* dst = fused ? cov_alt_ptr(cv, b) : cov_ptr(cv, b);
-    const double* Pc = Pcall + (size_t)bl * ystride;
+    // pc_base >= 0: the clone columns are a contiguous block of the (untouched, out-of-place) prior itself; columns
+    // past the window only meet zero rows of M
+    const int pcb = upd ? pc_base[bl] : -1;
+    const double* Pc = pcb >= 0 ? P + (size_t)pcb * ld : Pcall + (size_t)bl * ystride;
     const double* M = Mall + (size_t)bl * mstride;
     const double* tvec = M + (size_t)MP * MP;
     const int l15 = lane & 15, kq = lane >> 4;
@@ -1206,7 +1218,7 @@ int launch_factored(const FactoredLaunch& L, hipStream_t st)
         const int nt = (L.n_cap + 15) / 16, wgpf = ((nt + 1) / 2 + 3) / 4, nb8 = (L.nb + 7) / 8 * 8;
 #define APPLY_DISPATCH(NC)                                                                                            \
         hipLaunchKernelGGL(k_info_apply<NC>, dim3(nb8 * wgpf), dim3(256), 0, st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride, L.Pc, \
-                           L.ystride, L.m_out, L.dx, L.status, L.marg_idx, L.marg_size);
+                           L.ystride, L.m_out, L.dx, L.status, L.marg_idx, L.marg_size, L.pc_base);
         if (ncm <= 36) { APPLY_DISPATCH(36) } else if (ncm <= 66) { APPLY_DISPATCH(66) } else { APPLY_DISPATCH(96) }
 #undef APPLY_DISPATCH
         return 0;
@@ -1217,7 +1229,8 @@ int launch_factored(const FactoredLaunch& L, hipStream_t st)
             const size_t sm = sizeof(double) * (size_t)NC * (2 * NC + 1) + sizeof(int) * (size_t)NC + 16;                     \
             hipFuncSetAttribute((const void*)k_info_update<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);         \
             hipLaunchKernelGGL(k_info_update<NC>, dim3(L.nb), dim3(INFO_NT), sm, st, L.cv, L.fv, L.b0, L.Apart, L.chunk_used, \
-                               L.G, L.rstride, L.noise, L.T, L.mstride, L.Pc, L.ystride, L.dx, L.m_out, L.nc_out, L.status);  \
+                               L.G, L.rstride, L.noise, L.T, L.mstride, L.Pc, L.ystride, L.dx, L.m_out, L.nc_out, L.status,  \
+                               L.marg_idx, L.pc_base);                                                                      \
         }
         if (ncm <= 36) { INFO_DISPATCH(36) } else if (ncm <= 66) { INFO_DISPATCH(66) } else { INFO_DISPATCH(96) }
 #undef INFO_DISPATCH

@@ -27,6 +27,7 @@ struct FactoredLaunch {
     int* status;
     const int* marg_idx;  // stage 3: fused StateManager::marginalize, per filter state index or -1 (nullptr: none)
     int marg_size;
+    int* pc_base;         // [nb] stage 2 -> 3: first clone column when Pc is read straight from P, else -1
 };
 
 int launch_factored(const FactoredLaunch& L, hipStream_t st);
