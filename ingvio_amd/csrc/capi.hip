@@ -282,7 +282,8 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     const int mcap = c->d.m_max > 6 * desc->c_max ? c->d.m_max : 6 * desc->c_max;
     c->mld = (mcap + 15) & ~15;
     c->nc_cap = mcap;
-    c->G = 2048 / B; if (c->G > 16) c->G = 16; if (c->G < 2) c->G = 2;
+    c->G = 512 / B; if (c->G > 16) c->G = 16; if (c->G < 1) c->G = 1;      // ~2 resident gram workgroups per CU
+    if (const char* e = getenv("INGVIO_GRAM_CHUNKS")) { const int g = atoi(e); if (g >= 1 && g <= 16) c->G = g; }
     c->cls = msckf_cmax_class(desc->c_max);
     const int ncm = 6 * desc->c_max;
     c->rstride = ncm * (ncm + 1);

@@ -65,9 +65,10 @@ __device__ __forceinline__ void mulXt(const double M[9], double x, double y, dou
 
 // ---------------------------------------------------------------------------------------------
 // Per-feature record written by the gate kernel and consumed by k_feat_gram:
-//   {nobs, anchor slot, p_f(3), window-slot mask} then per observation (ascending slot) {slot, cna, pfl, N_o = G_o^T G_o (9), h_o = G_o^T r_o (3)}
+//   {nobs, anchor slot, p_f(3), window-slot mask, Ns^-1 (9), hs (3), Nsa (9)} then per observation (ascending slot);
+//   Ns = sum_o N_o, hs = sum_o h_o, Nsa = sum over the observations whose clone is not the anchor {slot, cna, pfl, N_o = G_o^T G_o (9), h_o = G_o^T r_o (3)}
 // ---------------------------------------------------------------------------------------------
-#define REC_HDR 6
+#define REC_HDR 27
 #define REC_OBS 15          // slot, cna, pfl, N(9), h(3)
 
 __host__ __device__ constexpr int rec_size(int cmax) { return REC_HDR + REC_OBS * cmax; }
@@ -154,7 +155,10 @@ struct Gate3Shared {
     double Ninv[CMAX][9];
     double u[CMAX][3];
     double rperp[CMAX];
-    double blk[NPAIR][D * D];
+    union {
+        double blk[NPAIR][D * D];     // pair blocks
+        double nh[CMAX * 12 + 24];    // before they are built: N_o | h_o per observation and the record's 21 sums
+    };
 };
 
 __device__ __forceinline__ double bcast_lane(double x, int lane)      // lane must be a compile-time constant
@@ -195,6 +199,8 @@ __global__ __launch_bounds__(WAVE) void k_feat_gate3(
         if (tid == 0) { gamma_out[oidx] = __builtin_nan(""); accept_out[oidx] = 0; rec[0] = 0.0; }
         return;
     }
+    double* const Nh = sh.nh;
+    double* const sums = Nh + CMAX * 12;
     if (tid < nobs) {
         const int so = sh.f.slot[tid];
         const bool cn = so != a, pl = !(op.selected_variant && so == a);
@@ -218,7 +224,10 @@ __global__ __launch_bounds__(WAVE) void k_feat_gate3(
             for (int q = 0; q < RPO; ++q) hh += sh.f.G[tid][q][m] * sh.f.res[tid][q];
             h[m] = hh;
             ro[12 + m] = hh;
+            Nh[tid * 12 + 9 + m] = hh;
         }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Nh[tid * 12 + i] = N[i];
         if (STEREO) {
             double Ni[9];
             inv3sym(N, Ni);
@@ -240,6 +249,24 @@ __global__ __launch_bounds__(WAVE) void k_feat_gate3(
         unsigned sm = 0;
         for (int o = 0; o < nobs; ++o) sm |= 1u << sh.f.slot[o];
         rec[0] = nobs; rec[1] = a; rec[2] = px; rec[3] = py; rec[4] = pz; rec[5] = (double)sm;
+    }
+    __syncthreads();
+    // sums for k_feat_gram2 (this kernel is VALU-bound, the gram kernel latency-bound: the reduction is cheaper here)
+    if (tid < 21) {
+        const int anch = tid >= 12, comp = anch ? tid - 12 : tid;
+        double t[CMAX];
+#pragma unroll
+        for (int o = 0; o < CMAX; ++o) t[o] = (o < nobs && (!anch || sh.cna[o])) ? Nh[o * 12 + comp] : 0.0;      // all loads in flight
+        double sacc = 0.0;
+#pragma unroll
+        for (int o = 0; o < CMAX; ++o) sacc += t[o];
+        sums[tid] = sacc;
+    }
+    __syncthreads();
+    if (tid < 21) {
+        double v = sums[tid];
+        if (tid < 9) { double Nsi[9]; inv3sym(sums, Nsi); v = Nsi[tid]; }
+        rec[6 + tid] = v;
     }
     __syncthreads();
     // ---- pair blocks: lane q -> observation pair (o >= o2) ------------------------------------
@@ -389,7 +416,9 @@ struct Gram2Cfg {
     static constexpr int TJ = (NC + 1 + 15) / 16;          // tiles over columns of [A | b]
     static constexpr int LDW = 16 * TJ;
     static constexpr int NTILE = TI * TJ;
-    static constexpr int TPW = (NTILE + 3) / 4;            // tiles per wave
+    static constexpr int NUP = TI * TJ - TI * (TI - 1) / 2;   // tiles (ti <= tj): the rank-3 Gram is symmetric
+    static constexpr int TPW = (NUP + 3) / 4;              // accumulator tiles per wave
+    static constexpr int PRE = (GRAM_NB * (REC_HDR + REC_OBS * CMAX) + GRAM_NT - 1) / GRAM_NT;
     static constexpr int REC = REC_HDR + REC_OBS * CMAX;
     static constexpr int KR = 3 * GRAM_NB;                 // stacked rows per batch
     static constexpr int SPW = 24;                         // per (feature, slot) sparse scratch: S1(9) NXs(9) s4(3) flag
@@ -398,7 +427,6 @@ template <int CMAX>
 struct Gram2Batch {
     using Cfg = Gram2Cfg<CMAX>;
     double rec[GRAM_NB][Cfg::REC];
-    double sums[GRAM_NB][24];                // Ns(9) hs(3) Nsa(9) hsa(3)
     double Bm[Cfg::KR][Cfg::LDW];
     double Ym[Cfg::KR][Cfg::LDW];
     double sp[GRAM_NB][CMAX][Cfg::SPW];
@@ -417,6 +445,7 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
 {
     using Cfg = Gram2Cfg<CMAX>;
     constexpr int NC = Cfg::NC, TJ = Cfg::TJ, LDW = Cfg::LDW, NTILE = Cfg::NTILE, TPW = Cfg::TPW, REC = Cfg::REC, KR = Cfg::KR;
+    constexpr int NUP = Cfg::NUP, TI = Cfg::TI, PRE = Cfg::PRE;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Gram2Batch<CMAX>& sb = *reinterpret_cast<Gram2Batch<CMAX>*>(smem_raw);
     Gram2Out<CMAX>& so = *reinterpret_cast<Gram2Out<CMAX>*>(smem_raw);             // epilogue view of the same LDS
@@ -457,7 +486,14 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
     const int q0 = g * per, q1 = min(nu, q0 + per);
 
     dbg_stamp(33);
-    // MFMA accumulators: wave w owns tiles t = w, w+4, ...
+    // MFMA accumulators: wave w owns the upper tiles t = w, w+4, ... (row-major over ti <= tj)
+    int tiA[TPW], tjA[TPW];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        int t = wave + 4 * u, ti = 0;
+        while (ti < TI - 1 && t >= TJ - ti) { t -= TJ - ti; ++ti; }
+        tiA[u] = ti; tjA[u] = ti + t;                          // t >= NUP gives tj >= TJ: never launched
+    }
     double4_f acc[TPW];
 #pragma unroll
     for (int u = 0; u < TPW; ++u) acc[u] = double4_f{ 0.0, 0.0, 0.0, 0.0 };
@@ -471,33 +507,26 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
     for (int i = 0; i < 3; ++i) { s4[i] = 0.0; s5[i] = 0.0; }
     const int kq = lane >> 4, l15 = lane & 15;
 
+    double pre[PRE];
+    auto fetch = [&](int qb) {                                  // this thread's share of a batch's records
+        const int nbf = min(GRAM_NB, q1 - qb);
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) {
+            const int e = tid + u * GRAM_NT, f = e / REC, w = e - f * REC;
+            pre[u] = (qb < q1 && e < nbf * REC) ? rec_in[((size_t)b * fv.fmax + sList[qb + f]) * REC + w] : 0.0;
+        }
+    };
+    fetch(q0);
     for (int qb = q0; qb < q1; qb += GRAM_NB) {
         const int nbf = min(GRAM_NB, q1 - qb);
         dbg_stamp(34);
-        // ---- P0: records ---------------------------------------------------------------------
-        for (int e = tid; e < nbf * REC; e += GRAM_NT) {
-            const int f = e / REC, w = e - f * REC;
-            sb.rec[f][w] = rec_in[((size_t)b * fv.fmax + sList[qb + f]) * REC + w];
-        }
+        // ---- P0: records (prefetched into registers during the previous batch's MFMA phase) ---------------
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) { const int e = tid + u * GRAM_NT; if (e < nbf * REC) (&sb.rec[0][0])[e] = pre[u]; }
         if (nbf < GRAM_NB) {                                   // short last batch: clear the unused stacked rows
             for (int e = tid; e < (KR - 3 * nbf) * LDW; e += GRAM_NT) { (&sb.Bm[3 * nbf][0])[e] = 0.0; (&sb.Ym[3 * nbf][0])[e] = 0.0; }
         }
         __syncthreads();
-        dbg_stamp(35);
-        // ---- P1: per-feature sums over the observations -------------------------------------------
-        if (tid < nbf * 24) {
-            const int f = tid / 24, comp = tid - 24 * f, anch = comp >= 12, cc = comp - 12 * anch;
-            const double* rc = sb.rec[f];
-            const int nobs = (int)rc[0];
-            double s = 0.0;
-            for (int o = 0; o < nobs; ++o) {
-                const double* ro = rc + REC_HDR + REC_OBS * o;
-                if (!anch || ro[1] != 0.0) s += ro[3 + cc];
-            }
-            sb.sums[f][comp] = s;
-        }
-        __syncthreads();
-        dbg_stamp(36);
         // ---- P2: operand rows B, Y = Ns^-1 B and the sparse scratch, lane = (feature, window slot) -----
         if (tid < nbf * 16) {
             const int f = tid >> 4, c = tid & 15;
@@ -509,9 +538,9 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
                 const bool obs = (mask >> c) & 1u;
                 const int o = __popc(mask & ((1u << c) - 1u));
                 const double* ro = rc + REC_HDR + REC_OBS * (obs ? o : 0);
-                const double* sm = sb.sums[f];
-                double Nsi[9];
-                inv3sym(sm, Nsi);
+                const double* Nsi = rc + 6;                          // Ns^-1, hs, Nsa from the gate kernel
+                const double* hs = rc + 15;
+                const double* Nsa = rc + 18;
                 double Bt[9], Bp[9], NX[9];
                 const double cn = (obs && ro[1] != 0.0) ? 1.0 : 0.0, pl = (obs && ro[2] != 0.0) ? 1.0 : 0.0;
                 mulX(ro + 3, px, py, pz, NX);                       // N_o X
@@ -519,7 +548,7 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
                 for (int i = 0; i < 9; ++i) { Bt[i] = cn * NX[i]; Bp[i] = -pl * ro[3 + i]; }
                 if (c == a) {                                       // theta_anchor block: -Nsa X   (the anchor's own cn is 0)
                     double T[9];
-                    mulX(sm + 12, px, py, pz, T);
+                    mulX(Nsa, px, py, pz, T);
 #pragma unroll
                     for (int i = 0; i < 9; ++i) Bt[i] = -T[i];
                 }
@@ -537,7 +566,7 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
                     }
                 if (c == 0) {
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) sb.Bm[3 * f + k][NC] = sm[9 + k];      // extra column: hs
+                    for (int k = 0; k < 3; ++k) sb.Bm[3 * f + k][NC] = hs[k];      // extra column: hs
                 }
                 // sparse scratch
                 double* sp = sb.sp[f][c < CMAX ? c : 0];
@@ -555,21 +584,20 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
         }
         __syncthreads();
         dbg_stamp(37);
-        // ---- P3a: rank-3 part on the matrix cores ------------------------------------------------
+        // ---- P3a: rank-3 part on the matrix cores (next batch's records are fetched meanwhile) -------------
+        fetch(qb + GRAM_NB);
         const int nst = (3 * nbf + 3) >> 2;
         for (int st = 0; st < nst; ++st) {
 #pragma unroll
             for (int u = 0; u < TPW; ++u) {
-                const int t = wave + 4 * u;
-                if (t < NTILE) {
-                    const int ti = t / TJ, tj = t - ti * TJ;
+                if (wave + 4 * u < NUP) {
+                    const int ti = tiA[u], tj = tjA[u];
                     const double af = sb.Ym[4 * st + kq][16 * ti + l15];      // A[i][k] = Y[k][i]
                     const double bf = sb.Bm[4 * st + kq][16 * tj + l15];      // B[k][j]
                     acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[u], 0, 0, 0);
                 }
             }
         }
-        dbg_stamp(38);
         // ---- P3b: sparse part, lane (c, a) ----------------------------------------------------------
         if (pairlane) {
             for (int f = 0; f < nbf; ++f) {
@@ -592,9 +620,8 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
     // ---- epilogue: assemble [A | b] of the chunk ---------------------------------------------------
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
-        const int t = wave + 4 * u;
-        if (t < NTILE) {
-            const int ti = t / TJ, tj = t - ti * TJ;
+        if (wave + 4 * u < NUP) {
+            const int ti = tiA[u], tj = tjA[u];
             const int jc = 16 * tj + l15;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -650,205 +677,17 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
         for (int q = 0; q < 6; ++q) {
 #pragma unroll
             for (int q2 = 0; q2 < 6; ++q2)
-                out[(size_t)(6 * c + q) * (ncol + 1) + 6 * c2 + q2] = blk[6 * q + q2] - so.A2[6 * c + q][6 * c2 + q2];
+                {
+                const int ri = 6 * c + q, rj = 6 * c2 + q2;
+                // only tiles ti <= tj were accumulated: element (ri, rj) with ri/16 > rj/16 is read from its mirror
+                const double a2 = (ri >> 4) <= (rj >> 4) ? so.A2[ri][rj] : so.A2[rj][ri];
+                out[(size_t)ri * (ncol + 1) + rj] = blk[6 * q + q2] - a2;
+            }
             if (c == c2) out[(size_t)(6 * c + q) * (ncol + 1) + ncol] = bb[q] - so.A2[6 * c + q][NC];
         }
     }
     if (tid == 0) chunk_used[bl * G + g] = max(0, q1 - q0);
     dbg_stamp(40);
-}
-
-// ---------------------------------------------------------------------------------------------
-// K4 + K6/K7 in Gram form.  grid = (G chunks, nb); chunk g accumulates A_g = sum H_j^T H_j and
-// b_g = sum H_j^T r_j over its used features j = g, g+G, ...; lane (c, c') owns the 6x6 block of
-// window-slot pair (c, c') in registers for the whole chunk (deterministic, no atomics).
-// With N_o = G_o^T G_o, h_o = G_o^T r_o (from the gate kernel's record), Ns = sum N_o = Hf^T Hf:
-//   W[o][o'] = [o == o'] N_o - N_o Ns^-1 N_o'        (= Gblk^T (I - Hf (Hf^T Hf)^-1 Hf^T) Gblk)
-//   g_o      = h_o - N_o Ns^-1 sum_o h_o
-// i.e. the left-nullspace projection K4 without ever forming the 4C x (4C-3) basis.
-// ---------------------------------------------------------------------------------------------
-template <int CMAX>
-struct GramShared {
-    static constexpr int NT = ((CMAX * CMAX + 63) / 64) * 64;
-    static constexpr int REC = REC_HDR + REC_OBS * CMAX;
-    double rec[2][REC];           // double-buffered feature record
-    double sums[2][24];           // Ns(9) hs(3) Nsa(9) hsa(3)
-};
-
-template <int CMAX, bool STEREO>
-__global__ __launch_bounds__((GramShared<CMAX>::NT)) void k_feat_gram(
-    FrameView fv, MsckfOpts op, int b0, const int* __restrict__ accept_in, int* __restrict__ used_out,
-    const double* __restrict__ rec_in, double* __restrict__ Apart, int* __restrict__ chunk_used, int G, int rstride)
-{
-    using SH = GramShared<CMAX>;
-    constexpr int NT = SH::NT, REC = SH::REC;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    SH& sh = *reinterpret_cast<SH*>(smem_raw);
-    int* sUse = reinterpret_cast<int*>(smem_raw + ((sizeof(SH) + 15) / 16) * 16);
-    const int bl = blockIdx.y, b = b0 + bl, g = blockIdx.x, tid = threadIdx.x;
-    const int F = fv.n_feat[b], C = fv.n_clones[b], ncol = 6 * C;
-
-    for (int j = tid; j < F; j += NT) {                    // RemoveLostUpdate.cpp:357-359
-        int use = accept_in[(size_t)b * fv.fmax + j];
-        if (use && op.max_accept > 0) {
-            int rank = 0;
-            for (int q = 0; q < j; ++q) rank += accept_in[(size_t)b * fv.fmax + q];
-            if (rank >= op.max_accept) use = 0;
-        }
-        sUse[j] = use;
-        if (g == 0) used_out[(size_t)b * fv.fmax + j] = use;
-    }
-    __syncthreads();
-
-    const int c = tid / C, c2 = tid - c * C;
-    const bool pair = tid < C * C;
-    double acc[36], bacc[6];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) bacc[i] = 0.0;
-    int nused = 0;
-
-    // software pipeline: the record of the next used feature is fetched while the current one is reduced
-    int jn = g;
-    while (jn < F && !sUse[jn]) jn += G;
-    int buf = 0;
-    if (jn < F) for (int e = tid; e < REC; e += NT) sh.rec[0][e] = rec_in[((size_t)b * fv.fmax + jn) * REC + e];
-    __syncthreads();
-    while (jn < F) {
-        const int j = jn;
-        jn += G;
-        while (jn < F && !sUse[jn]) jn += G;
-        double pre[(REC + NT - 1) / NT];
-        if (jn < F) {
-#pragma unroll
-            for (int u = 0; u < (REC + NT - 1) / NT; ++u) { const int e = tid + u * NT; pre[u] = e < REC ? rec_in[((size_t)b * fv.fmax + jn) * REC + e] : 0.0; }
-        }
-        const double* rc = sh.rec[buf];
-        const int nobs = (int)rc[0], a = (int)rc[1];
-        const double px = rc[2], py = rc[3], pz = rc[4];
-        // sums over observations: Ns, hs (all), Nsa, hsa (obs != anchor)
-        if (tid < 24) {
-            const int comp = tid % 12, anch = tid / 12;
-            double s = 0.0;
-            for (int o = 0; o < nobs; ++o) {
-                const double* ro = rc + REC_HDR + REC_OBS * o;
-                if (!anch || ro[1] != 0.0) s += ro[3 + comp];
-            }
-            sh.sums[buf][tid] = s;
-        }
-        __syncthreads();
-        if (pair) {
-            const double* sm = sh.sums[buf];
-            double Nsi[9];
-            inv3sym(sm, Nsi);
-            int o = -1, o2 = -1;
-            for (int q = 0; q < nobs; ++q) { const int sl = (int)rc[REC_HDR + REC_OBS * q]; if (sl == c) o = q; if (sl == c2) o2 = q; }
-            const double* ro = rc + REC_HDR + REC_OBS * (o >= 0 ? o : 0);
-            const double* ro2 = rc + REC_HDR + REC_OBS * (o2 >= 0 ? o2 : 0);
-            if (o >= 0 && o2 >= 0) {
-                double Y2[9], NY[9], Wb[9], WX[9], XtW[9], XtWX[9];
-                mul33(Nsi, ro2 + 3, Y2);                       // Ns^-1 N_o'
-                mul33(ro + 3, Y2, NY);                         // N_o Ns^-1 N_o'
-#pragma unroll
-                for (int i = 0; i < 9; ++i) Wb[i] = (o == o2 ? ro[3 + i] : 0.0) - NY[i];
-                mulX(Wb, px, py, pz, WX);
-                mulXt(Wb, px, py, pz, XtW);
-                mulXt(WX, px, py, pz, XtWX);
-                const double stt = (ro[1] != 0.0 && ro2[1] != 0.0) ? 1.0 : 0.0;
-                const double stp = (ro[1] != 0.0 && ro2[2] != 0.0) ? -1.0 : 0.0;
-                const double spt = (ro[2] != 0.0 && ro2[1] != 0.0) ? -1.0 : 0.0;
-                const double spp = (ro[2] != 0.0 && ro2[2] != 0.0) ? 1.0 : 0.0;
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-#pragma unroll
-                    for (int q2 = 0; q2 < 3; ++q2) {
-                        acc[6 * q + q2] += stt * XtWX[3 * q + q2];
-                        acc[6 * q + 3 + q2] += stp * XtW[3 * q + q2];
-                        acc[6 * (3 + q) + q2] += spt * WX[3 * q + q2];
-                        acc[6 * (3 + q) + 3 + q2] += spp * Wb[3 * q + q2];
-                    }
-            }
-            if (c == a && o2 >= 0) {              // rows theta_anchor: -X^T Wa_o' [cna X, -pfl I],  Wa_o' = cna N_o' - Nsa Ns^-1 N_o'
-                double Y2[9], M[9], XtM[9], XtMX[9];
-                mul33(Nsi, ro2 + 3, Y2);
-                mul33(sm + 12, Y2, M);
-#pragma unroll
-                for (int i = 0; i < 9; ++i) M[i] = (ro2[1] != 0.0 ? ro2[3 + i] : 0.0) - M[i];
-                mulXt(M, px, py, pz, XtM);
-                mulX(XtM, px, py, pz, XtMX);
-                const double s1 = ro2[1] != 0.0 ? -1.0 : 0.0, s2 = ro2[2] != 0.0 ? 1.0 : 0.0;
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-#pragma unroll
-                    for (int q2 = 0; q2 < 3; ++q2) { acc[6 * q + q2] += s1 * XtMX[3 * q + q2]; acc[6 * q + 3 + q2] += s2 * XtM[3 * q + q2]; }
-            }
-            if (c2 == a && o >= 0) {              // cols theta_anchor: transpose of the above with o
-                double Y1[9], M[9], Mt[9], MX[9], XtMX[9];
-                mul33(Nsi, ro + 3, Y1);
-                mul33(sm + 12, Y1, M);
-#pragma unroll
-                for (int i = 0; i < 9; ++i) M[i] = (ro[1] != 0.0 ? ro[3 + i] : 0.0) - M[i];      // Wa_o (3x3)
-#pragma unroll
-                for (int m = 0; m < 3; ++m)
-#pragma unroll
-                    for (int m2 = 0; m2 < 3; ++m2) Mt[3 * m + m2] = M[3 * m2 + m];
-                mulX(Mt, px, py, pz, MX);
-                mulXt(MX, px, py, pz, XtMX);
-                const double s1 = ro[1] != 0.0 ? -1.0 : 0.0, s2 = ro[2] != 0.0 ? 1.0 : 0.0;
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-#pragma unroll
-                    for (int q2 = 0; q2 < 3; ++q2) { acc[6 * q + q2] += s1 * XtMX[3 * q + q2]; acc[6 * (3 + q) + q2] += s2 * MX[3 * q + q2]; }
-            }
-            if (c == a && c2 == a) {              // Waa = Nsa - Nsa Ns^-1 Nsa
-                double Y[9], M[9], MX[9], XtMX[9];
-                mul33(Nsi, sm + 12, Y);
-                mul33(sm + 12, Y, M);
-#pragma unroll
-                for (int i = 0; i < 9; ++i) M[i] = sm[12 + i] - M[i];
-                mulX(M, px, py, pz, MX);
-                mulXt(MX, px, py, pz, XtMX);
-#pragma unroll
-                for (int q = 0; q < 9; ++q) acc[6 * (q / 3) + q % 3] += XtMX[q];
-            }
-            if (c == c2) {
-                double gy[3];
-#pragma unroll
-                for (int m = 0; m < 3; ++m) gy[m] = Nsi[3 * m] * sm[9] + Nsi[3 * m + 1] * sm[10] + Nsi[3 * m + 2] * sm[11];
-                if (o >= 0) {
-                    double go[3];
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) go[m] = ro[12 + m] - (ro[3 + 3 * m] * gy[0] + ro[3 + 3 * m + 1] * gy[1] + ro[3 + 3 * m + 2] * gy[2]);
-                    if (ro[1] != 0.0) { bacc[0] += pz * go[1] - py * go[2]; bacc[1] += -pz * go[0] + px * go[2]; bacc[2] += py * go[0] - px * go[1]; }
-                    if (ro[2] != 0.0) { bacc[3] -= go[0]; bacc[4] -= go[1]; bacc[5] -= go[2]; }
-                }
-                if (c == a) {
-                    double gaa[3];
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) gaa[m] = sm[21 + m] - (sm[12 + 3 * m] * gy[0] + sm[12 + 3 * m + 1] * gy[1] + sm[12 + 3 * m + 2] * gy[2]);
-                    bacc[0] -= pz * gaa[1] - py * gaa[2]; bacc[1] -= -pz * gaa[0] + px * gaa[2]; bacc[2] -= py * gaa[0] - px * gaa[1];
-                }
-            }
-        }
-        ++nused;
-        if (jn < F) {
-#pragma unroll
-            for (int u = 0; u < (REC + NT - 1) / NT; ++u) { const int e = tid + u * NT; if (e < REC) sh.rec[buf ^ 1][e] = pre[u]; }
-        }
-        buf ^= 1;
-        __syncthreads();
-    }
-    double* out = Apart + ((size_t)bl * G + g) * rstride;      // [ncol][ncol+1] row-major, b in the last column
-    if (pair) {
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-#pragma unroll
-            for (int q2 = 0; q2 < 6; ++q2) out[(size_t)(6 * c + q) * (ncol + 1) + 6 * c2 + q2] = acc[6 * q + q2];
-            if (c == c2) out[(size_t)(6 * c + q) * (ncol + 1) + ncol] = bacc[q];
-        }
-    }
-    if (tid == 0) chunk_used[bl * G + g] = nused;
 }
 
 // ---------------------------------------------------------------------------------------------
