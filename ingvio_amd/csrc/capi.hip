@@ -39,6 +39,10 @@ struct ingvio_ctx {
     int *d_cur, *d_n, *d_n_snap;
     std::vector<int> h_n, h_cur, h_n_snap;
     bool has_snap;
+    // partial restore: valid while half 0 still equals the snapshot outside the propagation strips, i.e. right after a
+    // fused frame step that began with a restore; any other use of the covariance (view()) invalidates it
+    bool strip_ok = false;
+    unsigned long long mut_seq = 0, strip_seq = 0;
     // propagation / structure staging
     double *d_Phi, *d_G, *d_dt, *d_R, *d_blk;
     int *d_gnss, *d_idx;
@@ -86,6 +90,7 @@ CovView view(ingvio_ctx* c)
 {
     CovView v;
     v.Pbase = c->Pbase; v.cur = c->d_cur; v.n = c->d_n; v.ldp = c->ldp; v.B = c->d.batch;
+    ++c->mut_seq;
     return v;
 }
 
@@ -628,6 +633,7 @@ int ingvio_frame_stage(ingvio_ctx* c, int b0, int nb, const ingvio_frame_step* s
     if (check_range(c, b0, nb) || !steps || !frames || !opts || !sigma) return INGVIO_E_ARG;
     const int k = steps[0].k;
     if (k < 1 || k > KMAX) return INGVIO_E_ARG;
+    c->strip_ok = false;                          // new clock-state indices: the next restore is a full one
     std::vector<double> Phi((size_t)nb * k * 225), G((size_t)nb * k * 180), dt((size_t)nb * k), R((size_t)nb * 9);
     std::vector<int> gi((size_t)nb * 5), mi(nb);
     for (int i = 0; i < nb; ++i) {
@@ -669,7 +675,9 @@ int ingvio_frame_run(ingvio_ctx* c, int restore_prior)
     if (restore_prior) {
         if (!c->has_snap) return INGVIO_E_ARG;
         ProfScope p(c, PF_RESTORE);
-        launch_restore(view(c), c->d.n_max, c->Psnap, c->d_n_snap, c->st);
+        const bool strips = c->strip_ok && c->mut_seq == c->strip_seq;
+        if (strips) launch_restore_strips(view(c), c->d.n_max, c->Psnap, c->d_n_snap, c->st_enable_gnss ? c->d_gnss : nullptr, c->st);
+        else launch_restore(view(c), c->d.n_max, c->Psnap, c->d_n_snap, c->st);
         c->h_n = c->h_n_snap;
         std::fill(c->h_cur.begin(), c->h_cur.end(), 0);
     }
@@ -693,7 +701,10 @@ int ingvio_frame_run(ingvio_ctx* c, int restore_prior)
         if (fuse) launch_post_marg(view(c), 0, B, c->d_idx, 6, c->st);
         else launch_marginalize(view(c), 0, B, c->d.n_max, c->d_idx, 6, c->st);
     }
-    for (int b = 0; b < B; ++b) if (c->st_marg[b] >= 0) { c->h_n[b] -= 6; c->h_cur[b] ^= 1; }
+    bool all_marg = true;
+    for (int b = 0; b < B; ++b) { if (c->st_marg[b] >= 0) { c->h_n[b] -= 6; c->h_cur[b] ^= 1; } else all_marg = false; }
+    c->strip_ok = fuse && all_marg && restore_prior;
+    c->strip_seq = c->mut_seq;
     return INGVIO_OK;
 }
 

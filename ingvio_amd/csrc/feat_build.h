@@ -12,14 +12,16 @@ struct FeatCfg {
     static constexpr int NT = ((NCOLMAX + 1 + 63) / 64) * 64;
 };
 
-// LDS scratch of the per-feature builder
-template <int CMAX, bool STEREO>
+// LDS scratch of the per-feature builder.  LEAN drops what only the dense path needs (G [p_f]x and the
+// nullspace reflectors): the factored gate kernel is occupancy-bound by LDS.
+template <int CMAX, bool STEREO, bool LEAN = false>
 struct FeatShared {
     using Cfg = FeatCfg<CMAX, STEREO>;
+    static constexpr bool kLean = LEAN;
     double G[CMAX][Cfg::RPO][3];      // Pi~ * R^T per observation  (also the Hf rows)
-    double GX[CMAX][Cfg::RPO][3];     // (Pi~ * R^T) [p_f]x
+    double GX[LEAN ? 1 : CMAX][Cfg::RPO][3];     // (Pi~ * R^T) [p_f]x
     double res[CMAX][Cfg::RPO];
-    double V[3][Cfg::RR];             // the three nullspace reflectors
+    double V[3][LEAN ? 1 : Cfg::RR];  // the three nullspace reflectors
     double tau[3];
     int slot[CMAX];                   // window slot of dense observation o
     int gidx[Cfg::NCOLMAX];           // state index of every column
@@ -80,9 +82,9 @@ __device__ __forceinline__ bool feat_obs(const double* R, const double* p, const
 // phase 1 (wave 0, one lane per window slot): q = R^T(p_f - p), projection Jacobians, residuals.
 // Fills sh.G (= Pi~ R^T, also the rows of Hf), sh.GX (= G [p_f]x), sh.res, sh.slot, sh.nobs.
 // RemoveLostUpdate.cpp:435-506.  Ends with a workgroup barrier.  Returns rows = RPO * nobs.
-template <int CMAX, bool STEREO>
+template <int CMAX, bool STEREO, bool LEAN = false>
 __device__ __forceinline__ int feat_phase1(const FrameView& fv, const MsckfOpts& op, int b, int j, int C,
-                                           FeatShared<CMAX, STEREO>& sh)
+                                           FeatShared<CMAX, STEREO, LEAN>& sh)
 {
     using Cfg = FeatCfg<CMAX, STEREO>;
     constexpr int RPO = Cfg::RPO;
@@ -111,9 +113,11 @@ __device__ __forceinline__ int feat_phase1(const FrameView& fv, const MsckfOpts&
             for (int t = 0; t < RPO; ++t) {
 #pragma unroll
                 for (int m = 0; m < 3; ++m) sh.G[od][t][m] = Gm[t][m];
-                sh.GX[od][t][0] = Gm[t][1] * pfz - Gm[t][2] * pfy;       // G * skew(p_f)
-                sh.GX[od][t][1] = -Gm[t][0] * pfz + Gm[t][2] * pfx;
-                sh.GX[od][t][2] = Gm[t][0] * pfy - Gm[t][1] * pfx;
+                if constexpr (!LEAN) {
+                    sh.GX[od][t][0] = Gm[t][1] * pfz - Gm[t][2] * pfy;       // G * skew(p_f)
+                    sh.GX[od][t][1] = -Gm[t][0] * pfz + Gm[t][2] * pfx;
+                    sh.GX[od][t][2] = Gm[t][0] * pfy - Gm[t][1] * pfx;
+                }
                 sh.res[od][t] = rs[t];
             }
         }
@@ -179,8 +183,8 @@ __device__ __forceinline__ void feat_phase2(FeatShared<CMAX, STEREO>& sh, int ro
 
 }
 
-template <int CMAX, bool STEREO>
-__device__ __forceinline__ void load_gidx(const FrameView& fv, int b, int C, FeatShared<CMAX, STEREO>& sh)
+template <int CMAX, bool STEREO, bool LEAN = false>
+__device__ __forceinline__ void load_gidx(const FrameView& fv, int b, int C, FeatShared<CMAX, STEREO, LEAN>& sh)
 {
     for (int c = threadIdx.x; c < 6 * C; c += blockDim.x)
         sh.gidx[c] = fv.clone_idx[(size_t)b * fv.cmax + c / 6] + c % 6;

@@ -319,6 +319,32 @@ __global__ __launch_bounds__(256) void k_restore(CovView cv, const double* __res
         for (int i = tid; i < n; i += 256) dst[i + (size_t)j * ld] = src[i + (size_t)j * ld];
     }
 }
+// Partial restore after a fused frame step (propagate + clone + out-of-place update/marginalise): half 0 still holds
+// the snapshot except for the rows/columns of the propagation's active set A = {0..14} + clock states (the six clone
+// rows/cols lie beyond n_snap).  grid = (ceil(n_cap/256), B), thread = row/column index.
+__global__ __launch_bounds__(256) void k_restore_strips(CovView cv, const double* __restrict__ snap, const int* __restrict__ n_snap,
+                                                        const int* __restrict__ gnss_idx)
+{
+    const int b = blockIdx.y, n = n_snap[b], ld = cv.ldp;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const double* src = snap + (size_t)b * ld * ld;
+    double* dst = cv.Pbase + (size_t)b * ld * ld;          // half 0
+    int A[NA_MAX], na = 15;
+#pragma unroll
+    for (int a = 0; a < 15; ++a) A[a] = a;
+#pragma unroll
+    for (int g = 0; g < 5; ++g) { const int gi = gnss_idx ? gnss_idx[b * 5 + g] : -1; A[15 + g] = gi >= 0 ? gi : 0; if (gi >= 0) na = 16 + g; }
+    double v[NA_MAX];
+#pragma unroll
+    for (int a = 0; a < NA_MAX; ++a) v[a] = src[r + (size_t)A[a] * ld];
+#pragma unroll
+    for (int a = 0; a < NA_MAX; ++a) if (a < na) dst[r + (size_t)A[a] * ld] = v[a];
+#pragma unroll
+    for (int a = 0; a < NA_MAX; ++a) v[a] = src[A[a] + (size_t)r * ld];
+#pragma unroll
+    for (int a = 0; a < NA_MAX; ++a) if (a < na) dst[A[a] + (size_t)r * ld] = v[a];
+}
 __global__ void k_post_restore(CovView cv, const int* __restrict__ n_snap)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -358,6 +384,11 @@ void launch_copy_ints(int* dst, const int* src, int count, hipStream_t st)
 void launch_snapshot(CovView cv, int n_cap, double* snap, int* n_snap, hipStream_t st)
 {
     hipLaunchKernelGGL(k_snapshot, dim3((n_cap + MARG_COLS - 1) / MARG_COLS, cv.B), dim3(256), 0, st, cv, snap, n_snap);
+}
+void launch_restore_strips(CovView cv, int n_cap, const double* snap, const int* n_snap, const int* gnss_idx, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_restore_strips, dim3((n_cap + 255) / 256, cv.B), dim3(256), 0, st, cv, snap, n_snap, gnss_idx);
+    hipLaunchKernelGGL(k_post_restore, dim3((cv.B + 255) / 256), dim3(256), 0, st, cv, n_snap);
 }
 void launch_restore(CovView cv, int n_cap, const double* snap, const int* n_snap, hipStream_t st)
 {

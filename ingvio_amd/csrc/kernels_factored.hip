@@ -149,17 +149,28 @@ struct Gate3Shared {
     static constexpr int D = STEREO ? 3 : 2;
     static constexpr int DIM = 4 + D * CMAX;
     static constexpr int NPAIR = CMAX * (CMAX + 1) / 2;
-    FeatShared<CMAX, STEREO> f;
+    FeatShared<CMAX, STEREO, true> f;
     int cna[CMAX];
     int pfl[CMAX];
+    double recbuf[REC_HDR + REC_OBS * CMAX];      // the feature record, staged: stored once, coalesced, at the very end
     double Ninv[CMAX][9];
     double u[CMAX][3];
     double rperp[CMAX];
-    union {
+    static constexpr int NTL = (D * CMAX + 12 + 15) / 16;      // 16x16 tile rows of the bordered matrix (MFMA back end)
+    static constexpr int KP = 16 * NTL - 12;                   // K padded with unit pivots to KP, border rows KP..KP+3
+    union alignas(16) {
         double blk[NPAIR][D * D];     // pair blocks
         double nh[CMAX * 12 + 24];    // before they are built: N_o | h_o per observation and the record's 21 sums
+        double pan[16 * NTL][4];      // after the tiles are built: panel exchange of the MFMA elimination
     };
+    double bz[16];
 };
+
+__device__ __forceinline__ void wave_sync()      // LDS hand-over between the lanes of ONE wave
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 __device__ __forceinline__ double bcast_lane(double x, int lane)      // lane must be a compile-time constant
 {
@@ -168,7 +179,7 @@ __device__ __forceinline__ double bcast_lane(double x, int lane)      // lane mu
     return __hiloint2double(hi, lo);
 }
 
-template <int CMAX, bool STEREO>
+template <int CMAX, bool STEREO, bool MFMA_LDL>
 __global__ __launch_bounds__(WAVE) void k_feat_gate3(
     CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out,
     int* __restrict__ accept_out, double* __restrict__ rec_out)
@@ -191,14 +202,17 @@ __global__ __launch_bounds__(WAVE) void k_feat_gate3(
     const int a = fv.anchor[oidx];
     const double* pf = fv.pf + oidx * 3;
     const double px = pf[0], py = pf[1], pz = pf[2];
-    load_gidx<CMAX, STEREO>(fv, b, C, sh.f);
-    const int rows = feat_phase1<CMAX, STEREO>(fv, op, b, j, C, sh.f);
+    dbg_stamp(24);
+    load_gidx<CMAX, STEREO, true>(fv, b, C, sh.f);
+    const int rows = feat_phase1<CMAX, STEREO, true>(fv, op, b, j, C, sh.f);
     const int nobs = sh.f.nobs, rho = rows - 3;
-    double* rec = rec_out + oidx * rec_size(CMAX);
+    double* const rec = sh.recbuf;                // global stores wait in vmcnt with the loads (gfx9): keep them off the critical path
+    double* const rec_g = rec_out + oidx * rec_size(CMAX);
     if (rho <= 0) {
-        if (tid == 0) { gamma_out[oidx] = __builtin_nan(""); accept_out[oidx] = 0; rec[0] = 0.0; }
+        if (tid == 0) { gamma_out[oidx] = __builtin_nan(""); accept_out[oidx] = 0; rec_g[0] = 0.0; }
         return;
     }
+    dbg_stamp(25);
     double* const Nh = sh.nh;
     double* const sums = Nh + CMAX * 12;
     if (tid < nobs) {
@@ -269,6 +283,7 @@ __global__ __launch_bounds__(WAVE) void k_feat_gate3(
         rec[6 + tid] = v;
     }
     __syncthreads();
+    dbg_stamp(26);
     // ---- pair blocks: lane q -> observation pair (o >= o2) ------------------------------------
     const int ga = sh.f.gidx[6 * a];
     const int npair = nobs * (nobs + 1) / 2;
@@ -305,6 +320,132 @@ __global__ __launch_bounds__(WAVE) void k_feat_gate3(
         }
     }
     __syncthreads();
+    dbg_stamp(27);
+    if constexpr (MFMA_LDL) {
+        // ---- blocked LDL^T on the matrix cores --------------------------------------------------------
+        // The bordered matrix (K padded with unit pivots to KP rows, then the 4 rows of W^T) is held as 16x16
+        // lower tiles in the MFMA C/D layout: lane (kq = lane>>4, l15 = lane&15), register r of tile (ti,tj)
+        // holds element (16 ti + kq + 4r, 16 tj + l15).  A panel of 4 pivots: its columns go through LDS once
+        // ([row][4] layout), every lane reads the 4x4 diagonal block (uniform) and the 4 panel entries of "its"
+        // rows, forms X = R L^-T for them and feeds X (A operand) and -X D^-1 (B operand) to one
+        // v_mfma_f64_16x16x4 per trailing tile: no per-element broadcasts at all.
+        constexpr int NTL = SH::NTL, KP = SH::KP, NLT = NTL * (NTL + 1) / 2;
+        const int np = D * nobs, npan = (np + 3) >> 2;
+        const int kq = tid >> 4, l15 = tid & 15;
+        auto kval = [&](int i, int o, int c, int jcol, int o2, int c2) -> double {
+            if (jcol >= np) return (i == jcol && i < KP) ? 1.0 : 0.0;
+            if (i < np) {
+                const bool low = o >= o2;
+                const int q = low ? o * (o + 1) / 2 + o2 : o2 * (o2 + 1) / 2 + o;
+                return sh.blk[q][low ? D * c + c2 : D * c2 + c];
+            }
+            const int bi = i - KP;
+            if (bi < 0 || bi >= 4) return 0.0;
+            if (STEREO) return bi == 0 ? sh.u[o2][c2] : (bi - 1 == c2 ? 1.0 : 0.0);
+            return bi == 0 ? sh.f.res[o2][c2] : sh.f.G[o2][c2][(bi + 2) % 3];
+        };
+        double4_f T[NLT];
+        int jo[NTL], jc[NTL];
+#pragma unroll
+        for (int tj = 0; tj < NTL; ++tj) { const int jj = min(16 * tj + l15, np > 0 ? np - 1 : 0); jo[tj] = jj / D; jc[tj] = jj - D * jo[tj]; }
+#pragma unroll
+        for (int ti = 0; ti < NTL; ++ti) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ti + kq + 4 * r;
+                const int ic = min(i, np > 0 ? np - 1 : 0), io = ic / D, icc = ic - D * io;
+#pragma unroll
+                for (int tj = 0; tj <= ti; ++tj) T[ti * (ti + 1) / 2 + tj][r] = kval(i, io, icc, 16 * tj + l15, jo[tj], jc[tj]);
+            }
+        }
+        dbg_stamp(28);
+        wave_sync();                              // blk is dead from here on: its LDS becomes the panel buffer
+#pragma unroll
+        for (int k = 0; k < KP / 4; ++k) {
+            if (k < npan) {
+                constexpr int dummy_ = 0; (void)dummy_;
+                const int tj0 = k >> 2, cb = 4 * (k & 3);
+                if (l15 >= cb && l15 < cb + 4) {
+#pragma unroll
+                    for (int ti = tj0; ti < NTL; ++ti)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sh.pan[16 * ti + kq + 4 * r][l15 - cb] = T[ti * (ti + 1) / 2 + tj0][r];
+                }
+                wave_sync();
+                double a[4][4];
+#pragma unroll
+                for (int ra = 0; ra < 4; ++ra) {
+                    const double2* pr = reinterpret_cast<const double2*>(sh.pan[4 * k + ra]);
+                    const double2 u0 = pr[0], u1 = pr[1];
+                    a[ra][0] = u0.x; a[ra][1] = u0.y; a[ra][2] = u1.x; a[ra][3] = u1.y;
+                }
+                double m[NTL][4];
+#pragma unroll
+                for (int t = tj0; t < NTL; ++t) {
+                    const double2* pr = reinterpret_cast<const double2*>(sh.pan[16 * t + l15]);
+                    const double2 u0 = pr[0], u1 = pr[1];
+                    m[t][0] = u0.x; m[t][1] = u0.y; m[t][2] = u1.x; m[t][3] = u1.y;
+                }
+                // 4x4 LDL^T of the diagonal block (every lane, uniform data)
+                const double r0 = fast_rcp(a[0][0]);
+                const double l10 = a[1][0] * r0, l20 = a[2][0] * r0, l30 = a[3][0] * r0;
+                const double r1 = fast_rcp(a[1][1] - l10 * a[1][0]);
+                const double t21 = a[2][1] - l20 * a[1][0], t31 = a[3][1] - l30 * a[1][0];
+                const double l21 = t21 * r1, l31 = t31 * r1;
+                const double r2 = fast_rcp(a[2][2] - l20 * a[2][0] - l21 * t21);
+                const double t32 = a[3][2] - l30 * a[2][0] - l31 * t21;
+                const double l32 = t32 * r2;
+                const double r3 = fast_rcp(a[3][3] - l30 * a[3][0] - l31 * t31 - l32 * t32);
+                const double dsel = kq == 0 ? r0 : (kq == 1 ? r1 : (kq == 2 ? r2 : r3));
+                double A[NTL], B[NTL];
+#pragma unroll
+                for (int t = tj0; t < NTL; ++t) {
+                    const double x0 = m[t][0];
+                    const double x1 = m[t][1] - l10 * x0;
+                    const double x2 = m[t][2] - l20 * x0 - l21 * x1;
+                    const double x3 = m[t][3] - l30 * x0 - l31 * x1 - l32 * x2;
+                    double xs = kq == 0 ? x0 : (kq == 1 ? x1 : (kq == 2 ? x2 : x3));
+                    if (16 * t + l15 <= 4 * k + 3) xs = 0.0;              // pivot rows and everything above: finished
+                    A[t] = xs;
+                    B[t] = -xs * dsel;
+                }
+#pragma unroll
+                for (int ti = tj0; ti < NTL; ++ti)
+#pragma unroll
+                    for (int tj = tj0; tj <= ti; ++tj)
+                        T[ti * (ti + 1) / 2 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ti], B[tj], T[ti * (ti + 1) / 2 + tj], 0, 0, 0);
+                wave_sync();
+            }
+        }
+        dbg_stamp(29);
+        // border block: tile (NTL-1, NTL-1), rows KP..KP+3 = local 4..7 -> r = 1, kq = 0..3; cols local 4..7
+        if (l15 >= 4 && l15 < 8) sh.bz[kq * 4 + (l15 - 4)] = T[NLT - 1][1];
+        wave_sync();
+        if (tid == 0) {
+            double W[4][4];
+            for (int p = 0; p < 4; ++p) for (int q = 0; q <= p; ++q) W[p][q] = -sh.bz[p * 4 + q];
+            const double r1 = fast_rcp(W[1][1]);
+            const double l21 = W[2][1] * r1, l31 = W[3][1] * r1;
+            const double r2 = fast_rcp(W[2][2] - l21 * W[2][1]);
+            const double t32 = W[3][2] - l31 * W[2][1];
+            const double l32 = t32 * r2;
+            const double r3 = fast_rcp(W[3][3] - l31 * W[3][1] - l32 * t32);
+            const double y1 = W[1][0], y2 = W[2][0] - l21 * y1, y3 = W[3][0] - l31 * y1 - l32 * y2;
+            double g = W[0][0] - (y1 * y1 * r1 + y2 * y2 * r2 + y3 * y3 * r3);
+            if (STEREO) {
+                double rp = 0.0;
+                for (int o = 0; o < nobs; ++o) rp += sh.rperp[o];
+                g += rp / op.var;
+            }
+            const int dof = fv.dof[oidx];
+            const bool ok = dof >= 1 && dof < op.chi2_len && g < op.chi2[dof];      // Update.cpp:120
+            gamma_out[oidx] = g;
+            accept_out[oidx] = ok ? 1 : 0;
+        }
+        dbg_stamp(30);
+        for (int e = tid; e < REC_HDR + REC_OBS * nobs; e += WAVE) rec_g[e] = rec[e];
+        return;
+    }
     // ---- gather own column -------------------------------------------------------------------
     double col[DIM];
 #pragma unroll
@@ -389,6 +530,7 @@ __global__ __launch_bounds__(WAVE) void k_feat_gate3(
         gamma_out[oidx] = g;
         accept_out[oidx] = ok ? 1 : 0;
     }
+    for (int e = tid; e < REC_HDR + REC_OBS * nobs; e += WAVE) rec_g[e] = rec[e];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1029,8 +1171,13 @@ static void launch_ft(const FactoredLaunch& L, hipStream_t st)
 {
     if (L.stage == 0) {
         const int nb8 = (L.nb + 7) / 8 * 8;
-        hipLaunchKernelGGL((k_feat_gate3<CMAX, STEREO>), dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st,
-                           L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
+        static const bool mfma_ldl = !(getenv("INGVIO_GATE_LDL") && atoi(getenv("INGVIO_GATE_LDL")) == 0);
+        if (mfma_ldl)
+            hipLaunchKernelGGL((k_feat_gate3<CMAX, STEREO, true>), dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st,
+                               L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
+        else
+            hipLaunchKernelGGL((k_feat_gate3<CMAX, STEREO, false>), dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st,
+                               L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
     } else {
         constexpr size_t uni = sizeof(Gram2Batch<CMAX>) > sizeof(Gram2Out<CMAX>) ? sizeof(Gram2Batch<CMAX>) : sizeof(Gram2Out<CMAX>);
         const size_t sm = ((uni + 15) / 16) * 16 + 2 * sizeof(int) * (size_t)L.fv.fmax;

@@ -236,6 +236,13 @@ def test_full_n249_batch_vs_oracle(orc, method):
         P = ctx2.cov_get(b)
         assert rel_err(P, oc.P) < TIGHT and rel_err(dx[b, :249], dxo) < 1e-9
         assert np.array_equal(P, P.T) and np.diag(P).min() > 0
+    # repeatability: the second of two back-to-back restores only rewrites the propagation strips (incl. the GNSS
+    # clock rows/columns) of the untouched ping-pong half; the result must be bit-identical
+    P_first = [ctx2.cov_get(b) for b in range(8)]
+    ctx2.frame_run(restore_prior=True)
+    ctx2.frame_run(restore_prior=True)
+    for b in range(8):
+        assert np.array_equal(ctx2.cov_get(b), P_first[b])
     ctx2.close()
 
 
