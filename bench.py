@@ -125,9 +125,20 @@ def algorithmic_flops(F_used, F, C, N, k):
         "k_propagate": k1, "k_augment": k2, "k_msckf_gate": F * (k4 + k5), "k_msckf_fold": F_used * k4 + k7,
         "k_msckf_merge": 0.0, "k_ekf_core": k8_9_11, "k_downdate": k10, "k_marginalize": 0.0, "restore": 0.0,
         # factored path: same algorithmic work, different kernels
-        "k_feat_gate3": F * (k4 + k5), "k_feat_gram": F_used * k4 + k7, "k_info_update": k8_9_11}
+        # factored path: same algorithmic work, different kernels (K8/K9 -> k_info_update; K10/K11 and the
+        # P H^T / K products -> k_info_apply)
+        "k_feat_gate3": F * (k4 + k5), "k_feat_gram2": F_used * k4 + k7, "k_info_update": 2.0 * n ** 3 + n ** 3 / 3.0,
+        "k_info_apply": k10 + 4.0 * N * n * n + 2.0 * N * n}
     total = F * (k4 + k5) + k7 + k8_9_11 + k10 + k1 + k2
     return per_kernel, total
+
+
+# HBM bytes per launch of the 512-filter config-2 workload, from the committed rocprofv3 PMC passes
+# (profiles/r01_rocprofv3_pmc_hbm_traffic.csv: FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE calibrated x1 on the
+# pure copy k_restore); a static annotation, bench.py cannot collect PMC counters itself
+TRAFFIC_MIB = {"k_feat_gate3": (49.6 + 113.4) * 2 ** 20, "k_feat_gram2": (112.9 + 22.6) * 2 ** 20,
+               "k_info_update": (38.5 + 18.4) * 2 ** 20, "k_info_apply": (371.3 + 246.3) * 2 ** 20,
+               "k_propagate": (38.9 + 40.9) * 2 ** 20}
 
 
 def algorithmic_bytes(N):
@@ -213,16 +224,32 @@ def main():
 
     for _ in range(args.warmup):
         ctx.frame_run(restore_prior=True)
+    # Per-kernel table: a separate UNTIMED pass of 3 steps with a HIP-event pair around every launch (an event pair
+    # per launch costs ~6 % of the step, so the timed region below only brackets the dominant kernel).
+    prof, dom_name = {}, None
+    if not args.no_profile:
+        ctx.profile_select(None); ctx.profile_reset(); ctx.profile_enable(True)
+        for _ in range(3):
+            ctx.frame_run(restore_prior=True)
+        ctx.sync(); ctx.profile_enable(False)
+        prof = ctx.profile_get()
+        pk0, _ = algorithmic_flops(float(F), F, C, N, synth.IMU_PER_FRAME)
+        bk0 = algorithmic_bytes(N)
+        cand = [(ms / calls, name) for name, (ms, calls) in prof.items() if calls and (pk0.get(name, 0.0) > 0 or name in bk0)]
+        dom_name = max(cand)[1] if cand else None
+        ctx.profile_select(dom_name)
+
     barrier()
     ctx.profile_reset()
-    ctx.profile_enable(not args.no_profile)
+    ctx.profile_enable(dom_name is not None)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ctx.frame_run(restore_prior=True)
     ctx.sync()
     elapsed = time.perf_counter() - t0
     ctx.profile_enable(False)
-    prof = ctx.profile_get()
+    if dom_name is not None:
+        prof[dom_name] = ctx.profile_get()[dom_name]      # the dominant kernel: measured live inside the timed region
     elapsed = grp.max_over_ranks(elapsed)
 
     dx, acc, rows = ctx.frame_fetch()
@@ -259,13 +286,17 @@ def main():
             if per_kernel.get(dom, 0.0) > 0:
                 a = kernels[dom]["tflops"]
                 roofline = dict(kernel=dom, bound="mfma", achieved=a, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
-                                frac=a / FP64_PEAK_TFLOPS, traffic=None, avg_launch_ms=dom_ms,
-                                note="FP64: vector and MFMA peaks coincide on MI355X (78.6 TFLOP/s); algorithmic "
-                                     "FLOPs per SURVEY.md 8(d) x filters per launch")
+                                frac=a / FP64_PEAK_TFLOPS, traffic=TRAFFIC_MIB.get(dom), avg_launch_ms=dom_ms,
+                                launches_timed=kernels[dom]["calls"],
+                                note="FP64: vector and MFMA peaks coincide on MI355X (78.6 TFLOP/s); achieved = SURVEY.md "
+                                     "8(d) ALGORITHMIC FLOPs (the reference's dense formulation) x filters per launch / "
+                                     "HIP-event time inside the timed region; the kernel executes far fewer operations "
+                                     "(Woodbury-reduced system), hence frac can exceed 1; traffic = HBM bytes per launch "
+                                     "(rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_rocprofv3_pmc_hbm_traffic.csv)")
             elif dom in bytes_k:
                 a = kernels[dom]["gbs"]
                 roofline = dict(kernel=dom, bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
-                                frac=a / HBM_PEAK_GBS, traffic=None, avg_launch_ms=dom_ms)
+                                frac=a / HBM_PEAK_GBS, traffic=TRAFFIC_MIB.get(dom), avg_launch_ms=dom_ms)
         cpu, parity = None, None
         if world == 1 and not args.no_cpu:
             cpu, (P1, n1, dx1, acc1, S) = cpu_baseline(ctx, steps, frames, infos[0]["n_prior"])
@@ -291,7 +322,9 @@ def main():
             ms_per_update=elapsed / args.steps * 1e3 / B, accepted_per_filter=F_used, results_finite=ok,
             algorithmic_flops_per_update=total_flops,
             whole_step_fp64_frac=total_flops * B / (elapsed / args.steps) / 1e12 / FP64_PEAK_TFLOPS,
-            method=args.method, roofline=roofline, cpu_baseline=cpu, parity_vs_oracle=parity, kernels=kernels, setup_s=t_build)
+            method=args.method, roofline=roofline, cpu_baseline=cpu, parity_vs_oracle=parity, kernels=kernels,
+            kernels_note="per-kernel avg_ms: separate untimed pass of 3 steps with an event pair around every launch; the "
+                         "roofline kernel's avg_ms is from the timed region", setup_s=t_build)
         print(json.dumps(out))
     grp.close()
     ctx.close()

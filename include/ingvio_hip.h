@@ -193,6 +193,9 @@ int ingvio_debug_read(ingvio_ctx* ctx, long long* out, int n);
 /* per-kernel device time, measured with hipEvents on the context's stream.  enable=1 brackets
  * every kernel launch with events (adds launch-side overhead, off by default). */
 int ingvio_profile_enable(ingvio_ctx* ctx, int enable);
+/* restrict the event pairs to one kernel (name as returned by ingvio_profile_get; NULL or "" = every kernel): the
+ * timed region of bench.py brackets only the dominant kernel, an event pair around every launch costs ~6 % */
+int ingvio_profile_select(ingvio_ctx* ctx, const char* kernel_name);
 int ingvio_profile_reset(ingvio_ctx* ctx);
 /* names: array of `cap` char* receiving static strings; ms/calls: [cap]; returns number of entries */
 int ingvio_profile_get(ingvio_ctx* ctx, const char** names, double* ms, int* calls, int cap);

@@ -24,7 +24,8 @@ EXPORTS = [
     "ingvio_cov_set", "ingvio_cov_get", "ingvio_get_n", "ingvio_cov_get_marginal", "ingvio_cov_snapshot",
     "ingvio_cov_restore", "ingvio_propagate", "ingvio_propagate_fused", "ingvio_augment_clone", "ingvio_marginalize",
     "ingvio_append_independent", "ingvio_ekf_update", "ingvio_chi2_gamma", "ingvio_msckf_update", "ingvio_qr_compress",
-    "ingvio_frame_stage", "ingvio_frame_run", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_reset",
+    "ingvio_frame_stage", "ingvio_frame_run", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_select",
+    "ingvio_profile_reset",
     "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_debug_read",
 ]
 
@@ -314,6 +315,9 @@ class Context:
     # ---- profiling ---------------------------------------------------------------------------
     def profile_enable(self, on=True):
         self._chk(self.L.ingvio_profile_enable(self.h, 1 if on else 0))
+
+    def profile_select(self, name=None):
+        self._chk(self.L.ingvio_profile_select(self.h, name.encode() if name else None))
 
     def profile_reset(self):
         self._chk(self.L.ingvio_profile_reset(self.h))

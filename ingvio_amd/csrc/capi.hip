@@ -22,7 +22,7 @@ enum ProfId { PF_RESTORE, PF_PROPAGATE, PF_AUGMENT, PF_GATE, PF_FOLD, PF_MERGE, 
               PF_GATE2, PF_GRAM, PF_INFO, PF_APPLY, PF_COUNT };
 const char* kProfNames[PF_COUNT] = { "restore", "k_propagate", "k_augment", "k_msckf_gate", "k_msckf_fold",
                                      "k_msckf_merge", "k_ekf_core", "k_downdate", "k_marginalize",
-                                     "k_feat_gate3", "k_feat_gram", "k_info_update", "k_info_apply" };
+                                     "k_feat_gate3", "k_feat_gram2", "k_info_update", "k_info_apply" };
 struct ProfRec { int id; hipEvent_t a, b; };
 
 }  // namespace
@@ -41,6 +41,7 @@ struct ingvio_ctx {
     bool has_snap;
     // partial restore: valid while half 0 still equals the snapshot outside the propagation strips, i.e. right after a
     // fused frame step that began with a restore; any other use of the covariance (view()) invalidates it
+    int prof_only = -1;          // >= 0: only this kernel id is bracketed by events (ingvio_profile_select)
     bool strip_ok = false;
     unsigned long long mut_seq = 0, strip_seq = 0;
     // propagation / structure staging
@@ -105,7 +106,7 @@ FrameView fview(ingvio_ctx* c)
 
 struct ProfScope {
     ingvio_ctx* c; int id; hipEvent_t a, b; bool on;
-    ProfScope(ingvio_ctx* c_, int id_) : c(c_), id(id_), on(c_->prof)
+    ProfScope(ingvio_ctx* c_, int id_) : c(c_), id(id_), on(c_->prof && (c_->prof_only < 0 || c_->prof_only == id_))
     {
         if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->st); }
     }
@@ -682,13 +683,12 @@ int ingvio_frame_run(ingvio_ctx* c, int restore_prior)
         std::fill(c->h_cur.begin(), c->h_cur.end(), 0);
     }
     for (int b = 0; b < B; ++b) if (c->h_n[b] + 6 > c->d.n_max) return INGVIO_E_CAPACITY;
-    hipMemsetAsync(c->d_status, 0, sizeof(int) * (size_t)B, c->st);
     {
+        // one launch: status reset + K1 (k composed IMU steps) + K2 (clone) when a workgroup owns a whole filter
         ProfScope p(c, PF_PROPAGATE);
         launch_propagate(view(c), 0, B, c->d.n_max, c->d_Phi, c->d_G, c->d_dt, c->st_k, c->st_enable_gnss ? c->d_gnss : nullptr,
-                         c->st_sigma, c->st_enable_gnss, c->st_scb, c->st_srw, c->st);
+                         c->st_sigma, c->st_enable_gnss, c->st_scb, c->st_srw, c->st, c->d_R, c->d_status);
     }
-    { ProfScope p(c, PF_AUGMENT); launch_augment(view(c), 0, B, c->d_R, c->st); }
     for (int b = 0; b < B; ++b) c->h_n[b] += 6;
     // factored path: the marginalisation of the oldest clone rides on the update's write-back (k_info_apply
     // stores the updated covariance compacted into the other ping-pong half); dense path: separate kernel
@@ -734,6 +734,15 @@ int ingvio_debug_read(ingvio_ctx* c, long long* out, int n)
     if (dbg_read_factored(a, 64) || dbg_read_cov(bq, 64)) return INGVIO_E_HIP;
     for (int i = 0; i < n; ++i) out[i] = (i < 16 || i >= 24) ? a[i] : bq[i];
     return INGVIO_OK;
+}
+
+int ingvio_profile_select(ingvio_ctx* c, const char* kernel_name)
+{
+    if (!c) return INGVIO_E_ARG;
+    c->prof_only = -1;
+    if (!kernel_name || !*kernel_name) return INGVIO_OK;
+    for (int i = 0; i < PF_COUNT; ++i) if (!strcmp(kernel_name, kProfNames[i])) { c->prof_only = i; return INGVIO_OK; }
+    return INGVIO_E_ARG;
 }
 
 int ingvio_profile_enable(ingvio_ctx* c, int enable)

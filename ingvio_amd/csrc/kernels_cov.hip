@@ -17,12 +17,53 @@
 // where A = {0..14} + the GNSS clock states (clock-bias <- clock-drift coupling, :56-86, and the
 // clock process noise, :99-116).  grid = (row tiles, nb).
 // ---------------------------------------------------------------------------------------------
+// body of K2 for one filter, executed by a whole workgroup of NT threads (ends with the size bump by thread 0)
+template <int NT>
+__device__ __forceinline__ void augment_filter(CovView cv, int b, const double* __restrict__ Rp, double (*sJP)[21])
+{
+    const int tid = threadIdx.x;
+    const int n = cv.n[b], ld = cv.ldp;
+    double* P = cov_ptr(cv, b);
+    double R[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = Rp[i];
+    for (int c = tid; c < n; c += NT) {
+        double e[6], q[6], jp[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { e[j] = P[c + (size_t)j * ld]; q[j] = P[c + (size_t)(15 + j) * ld]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            jp[i] = e[i] + R[3 * i] * q[0] + R[3 * i + 1] * q[1] + R[3 * i + 2] * q[2];
+            jp[3 + i] = e[3 + i] + R[3 * i] * q[3] + R[3 * i + 1] * q[4] + R[3 * i + 2] * q[5];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            P[c + (size_t)(n + i) * ld] = jp[i];
+            P[(n + i) + (size_t)c * ld] = jp[i];
+            if (c < 21) sJP[i][c] = jp[i];
+        }
+    }
+    __syncthreads();
+    if (tid < 36) {
+        const int i = tid / 6, i2 = tid % 6;
+        auto X = [&](int a, int c) {            // (J P J^T)[a][c] = JP[a][:21] . J[c][:]
+            const int off = c < 3 ? 15 : 18, rr = c % 3;
+            return sJP[a][c] + R[3 * rr] * sJP[a][off] + R[3 * rr + 1] * sJP[a][off + 1] + R[3 * rr + 2] * sJP[a][off + 2];
+        };
+        P[(n + i) + (size_t)(n + i2) * ld] = 0.5 * (X(i, i2) + X(i2, i));      // :293
+    }
+    __syncthreads();
+    if (tid == 0) cv.n[b] = n + 6;
+}
+
 __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
     CovView cv, int b0, const double* __restrict__ Phi, const double* __restrict__ G,
     const double* __restrict__ dts, int k, const int* __restrict__ gnss_idx,
-    double sg0, double sg1, double sg2, double sg3, int enable_gnss, double scb, double srw)
+    double sg0, double sg1, double sg2, double sg3, int enable_gnss, double scb, double srw,
+    const double* __restrict__ augR, int* __restrict__ status_clear)
 {
     const int bl = blockIdx.y, b = b0 + bl, tid = threadIdx.x;
+    if (status_clear && blockIdx.x == 0 && tid == 0) status_clear[b] = 0;
     const int n = cv.n[b], ld = cv.ldp;
     double* P = cov_ptr(cv, b);
 
@@ -188,6 +229,13 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
         }
     }
     dbg_stamp(20);
+    // fused K2 (single-tile launches only: this workgroup owns the whole filter): the clone's rows/columns are built
+    // from the just-propagated P[0:21, :]
+    if (augR) {
+        __syncthreads();
+        double (*sJP)[21] = reinterpret_cast<double (*)[21]>(sAll);
+        augment_filter<PROP_THREADS>(cv, b, augR + bl * 9, sJP);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -197,40 +245,8 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_augment(CovView cv, int b0, const double* __restrict__ Rs)
 {
-    const int bl = blockIdx.x, b = b0 + bl, tid = threadIdx.x;
-    const int n = cv.n[b], ld = cv.ldp;
-    double* P = cov_ptr(cv, b);
     __shared__ double sJP[6][21];
-    double R[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) R[i] = Rs[bl * 9 + i];
-    for (int c = tid; c < n; c += 256) {
-        double e[6], q[6], jp[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) { e[j] = P[c + (size_t)j * ld]; q[j] = P[c + (size_t)(15 + j) * ld]; }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            jp[i] = e[i] + R[3 * i] * q[0] + R[3 * i + 1] * q[1] + R[3 * i + 2] * q[2];
-            jp[3 + i] = e[3 + i] + R[3 * i] * q[3] + R[3 * i + 1] * q[4] + R[3 * i + 2] * q[5];
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            P[c + (size_t)(n + i) * ld] = jp[i];
-            P[(n + i) + (size_t)c * ld] = jp[i];
-            if (c < 21) sJP[i][c] = jp[i];
-        }
-    }
-    __syncthreads();
-    if (tid < 36) {
-        const int i = tid / 6, i2 = tid % 6;
-        auto X = [&](int a, int c) {            // (J P J^T)[a][c] = JP[a][:21] . J[c][:]
-            const int off = c < 3 ? 15 : 18, rr = c % 3;
-            return sJP[a][c] + R[3 * rr] * sJP[a][off] + R[3 * rr + 1] * sJP[a][off + 1] + R[3 * rr + 2] * sJP[a][off + 2];
-        };
-        P[(n + i) + (size_t)(n + i2) * ld] = 0.5 * (X(i, i2) + X(i2, i));      // :293
-    }
-    __syncthreads();
-    if (tid == 0) cv.n[b] = n + 6;
+    augment_filter<256>(cv, b0 + blockIdx.x, Rs + blockIdx.x * 9, sJP);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -327,6 +343,7 @@ __global__ __launch_bounds__(256) void k_restore_strips(CovView cv, const double
 {
     const int b = blockIdx.y, n = n_snap[b], ld = cv.ldp;
     const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r == 0) { cv.cur[b] = 0; cv.n[b] = n; }           // nothing in this kernel reads cur / n
     if (r >= n) return;
     const double* src = snap + (size_t)b * ld * ld;
     double* dst = cv.Pbase + (size_t)b * ld * ld;          // half 0
@@ -354,11 +371,14 @@ __global__ void k_post_restore(CovView cv, const int* __restrict__ n_snap)
 // ---------------------------------------------------------------------------------------------
 #include "launch_ekf.h"
 void launch_propagate(CovView cv, int b0, int nb, int n_cap, const double* Phi, const double* G, const double* dt, int k,
-                      const int* gnss_idx, const double sigma[4], int enable_gnss, double scb, double srw, hipStream_t st)
+                      const int* gnss_idx, const double sigma[4], int enable_gnss, double scb, double srw, hipStream_t st,
+                      const double* augR, int* status_clear)
 {
     const int tiles = (n_cap + PROP_THREADS - 1) / PROP_THREADS;
+    const bool fuse = augR && tiles == 1;
     hipLaunchKernelGGL(k_propagate, dim3(tiles, nb), dim3(PROP_THREADS), 0, st, cv, b0, Phi, G, dt, k, gnss_idx,
-                       sigma[0], sigma[1], sigma[2], sigma[3], enable_gnss, scb, srw);
+                       sigma[0], sigma[1], sigma[2], sigma[3], enable_gnss, scb, srw, fuse ? augR : nullptr, status_clear);
+    if (augR && !fuse) hipLaunchKernelGGL(k_augment, dim3(nb), dim3(256), 0, st, cv, b0, augR);
 }
 void launch_augment(CovView cv, int b0, int nb, const double* R, hipStream_t st)
 {
@@ -388,7 +408,6 @@ void launch_snapshot(CovView cv, int n_cap, double* snap, int* n_snap, hipStream
 void launch_restore_strips(CovView cv, int n_cap, const double* snap, const int* n_snap, const int* gnss_idx, hipStream_t st)
 {
     hipLaunchKernelGGL(k_restore_strips, dim3((n_cap + 255) / 256, cv.B), dim3(256), 0, st, cv, snap, n_snap, gnss_idx);
-    hipLaunchKernelGGL(k_post_restore, dim3((cv.B + 255) / 256), dim3(256), 0, st, cv, n_snap);
 }
 void launch_restore(CovView cv, int n_cap, const double* snap, const int* n_snap, hipStream_t st)
 {

@@ -26,7 +26,8 @@ void launch_gamma(CovView cv, int b, const double* H, const double* res, const i
 
 // kernels_cov.hip
 void launch_propagate(CovView cv, int b0, int nb, int n_cap, const double* Phi, const double* G, const double* dt, int k,
-                      const int* gnss_idx, const double sigma[4], int enable_gnss, double scb, double srw, hipStream_t st);
+                      const int* gnss_idx, const double sigma[4], int enable_gnss, double scb, double srw, hipStream_t st,
+                      const double* augR = nullptr, int* status_clear = nullptr);      // optional fused K2 / status reset
 void launch_augment(CovView cv, int b0, int nb, const double* R, hipStream_t st);
 void launch_marginalize(CovView cv, int b0, int nb, int n_cap, const int* idx, int size, hipStream_t st);
 void launch_post_marg(CovView cv, int b0, int nb, const int* idx, int size, hipStream_t st);
