@@ -73,60 +73,6 @@ __device__ __forceinline__ void mulXt(const double M[9], double x, double y, dou
 
 __host__ __device__ constexpr int rec_size(int cmax) { return REC_HDR + REC_OBS * cmax; }
 
-// Su[o][o'] = D_o Pcc D_o'^T from nine 3x3 blocks of P (row-major 3x3 out)
-__device__ __forceinline__ void su_pair(const double* __restrict__ P, int ld, int gc, int gc2, int ga, bool cn, bool cn2,
-                                        bool pl, bool pl2, double px, double py, double pz, double out[9])
-{
-    auto blk = [&](int r0, int c0, double M[9]) {
-#pragma unroll
-        for (int m = 0; m < 3; ++m)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) M[3 * m + q] = P[(r0 + m) + (size_t)(c0 + q) * ld];
-    };
-#pragma unroll
-    for (int i = 0; i < 9; ++i) out[i] = 0.0;
-    double A[9], T[9], U[9];
-    if (cn && cn2) {                                  // X (Ptt' - Pta - Pat' + Paa) X^T
-        blk(gc, gc2, A);
-        blk(gc, ga, T);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) A[i] -= T[i];
-        blk(ga, gc2, T);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) A[i] -= T[i];
-        blk(ga, ga, T);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) A[i] += T[i];
-        mulXt(A, px, py, pz, T);                      // X^T A = -X A
-        mulX(T, px, py, pz, U);                       // (X^T A) X = X A X^T
-#pragma unroll
-        for (int i = 0; i < 9; ++i) out[i] += U[i];
-    }
-    if (cn && pl2) {                                  // -X (Ptp' - Pap')  = +X^T (.)
-        blk(gc, gc2 + 3, A);
-        blk(ga, gc2 + 3, T);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) A[i] -= T[i];
-        mulXt(A, px, py, pz, T);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) out[i] += T[i];
-    }
-    if (pl && cn2) {                                  // -(Ppt' - Ppa) X^T = +(.) X
-        blk(gc + 3, gc2, A);
-        blk(gc + 3, ga, T);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) A[i] -= T[i];
-        mulX(A, px, py, pz, T);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) out[i] += T[i];
-    }
-    if (pl && pl2) {
-        blk(gc + 3, gc2 + 3, A);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) out[i] += A[i];
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // K3 + K5, one WAVE per (feature, filter): "column-owner" LDL^T in the reduced observation space.
 //
@@ -164,6 +110,8 @@ struct Gate3Shared {
         double pan[16 * NTL][4];      // after the tiles are built: panel exchange of the MFMA elimination
     };
     double bz[16];
+    double Rb[CMAX][9];               // per-observation part of Su: R_o = cn X P(th_o,th_a) X^T + pl P(p_o,th_a) X
+    double Qb[9];                     // X P(th_a,th_a) X^T
 };
 
 __device__ __forceinline__ void wave_sync()      // LDS hand-over between the lanes of ONE wave
@@ -179,15 +127,14 @@ __device__ __forceinline__ double bcast_lane(double x, int lane)      // lane mu
     return __hiloint2double(hi, lo);
 }
 
-template <int CMAX, bool STEREO, bool MFMA_LDL>
+template <int CMAX, bool STEREO>
 __global__ __launch_bounds__(WAVE) void k_feat_gate3(
     CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out,
     int* __restrict__ accept_out, double* __restrict__ rec_out)
 {
     using Cfg = FeatCfg<CMAX, STEREO>;
     using SH = Gate3Shared<CMAX, STEREO>;
-    constexpr int RPO = Cfg::RPO, D = SH::D, DIM = SH::DIM;
-    static_assert(DIM <= WAVE, "one lane per column");
+    constexpr int RPO = Cfg::RPO, D = SH::D;
     __shared__ SH sh;
     // XCD-aware mapping: consecutive workgroups go round-robin to the 8 XCDs, so give every XCD whole filters
     // (a filter's P blocks then live in one L2 instead of eight)
@@ -284,17 +231,22 @@ __global__ __launch_bounds__(WAVE) void k_feat_gate3(
     }
     __syncthreads();
     dbg_stamp(26);
-    // ---- pair blocks: lane q -> observation pair (o >= o2) ------------------------------------
+    // ---- Su = D Pcc D^T in 3x3 blocks.  With U_o = P(th_o, th_a), V_o = P(p_o, th_a):
+    //        Su[o][o'] = T_oo' - cn' R_o - cn R_o'^T + cn cn' Q
+    //        T_oo' = cn cn' X P(th_o,th_o') X^T + cn pl' X^T P(th_o,p_o') + pl cn' P(p_o,th_o') X + pl pl' P(p_o,p_o')
+    //        R_o = cn X U_o X^T + pl V_o X   (per observation),   Q = X P(th_a,th_a) X^T   (per feature)
+    //      so a pair needs 4 blocks of P instead of 9.  Pairs with the anchor's own observation (cn' = 0) only keep the
+    //      p-column terms; they are built in the per-observation pass, which leaves nobs-1 choose 2 (+diag) <= 55
+    //      generic pairs: ONE round of the wave for an 11-clone window instead of two.
     const int ga = sh.f.gidx[6 * a];
-    const int npair = nobs * (nobs + 1) / 2;
-    for (int q = tid; q < npair; q += WAVE) {
-        int o = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
-        while ((o + 1) * (o + 2) / 2 <= q) ++o;
-        while (o * (o + 1) / 2 > q) --o;
-        const int o2 = q - o * (o + 1) / 2;
-        double Su[9];
-        su_pair(P, ld, sh.f.gidx[6 * sh.f.slot[o]], sh.f.gidx[6 * sh.f.slot[o2]], ga, sh.cna[o], sh.cna[o2],
-                sh.pfl[o], sh.pfl[o2], px, py, pz, Su);
+    auto ldblk = [&](int r0, int c0, double M[9]) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) M[3 * m + q] = P[(r0 + m) + (size_t)(c0 + q) * ld];
+    };
+    auto finish_pair = [&](int o, int o2, double Su[9]) {        // o >= o2: K block (stereo: + s^2 N^-1 on the diagonal)
+        const int q = o * (o + 1) / 2 + o2;
         if (STEREO) {
             if (o == o2) {
 #pragma unroll
@@ -318,10 +270,82 @@ __global__ __launch_bounds__(WAVE) void k_feat_gate3(
                     sh.blk[q][(D * r + r2) % (D * D)] = v;
                 }
         }
+    };
+    const unsigned long long amask = __ballot(tid < nobs && sh.f.slot[tid < nobs ? tid : 0] == a);
+    const int oa = amask ? __ffsll((long long)amask) - 1 : -1;          // the anchor clone's own observation, if any
+    if (tid < nobs) {
+        const int o = tid, gc = sh.f.gidx[6 * sh.f.slot[o]];
+        const double cn = sh.cna[o] ? 1.0 : 0.0, pl = sh.pfl[o] ? 1.0 : 0.0;
+        double U[9], V[9], Paa[9], T1[9], T2[9];
+        ldblk(gc, ga, U);
+        ldblk(gc + 3, ga, V);
+        ldblk(ga, ga, Paa);
+        double B1[9], B2[9], Bp[9];
+        if (oa >= 0) { ldblk(gc, ga + 3, B1); ldblk(ga, ga + 3, B2); ldblk(gc + 3, ga + 3, Bp); }
+        mulXt(U, px, py, pz, T1);
+        mulX(T1, px, py, pz, T2);                 // X U X^T
+        mulX(V, px, py, pz, T1);                  // V X
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sh.Rb[o][i] = cn * T2[i] + pl * T1[i];
+        mulXt(Paa, px, py, pz, T1);
+        mulX(T1, px, py, pz, T2);
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) sh.Qb[i] = T2[i];
+        }
+        if (oa >= 0) {                            // pair (o, anchor obs): cn' = 0
+            const double pl2 = sh.pfl[oa] ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) B1[i] -= B2[i];
+            mulXt(B1, px, py, pz, T1);            // X^T (P(th_o,p_a) - P(th_a,p_a))
+            double Su[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Su[i] = cn * pl2 * T1[i] + pl * pl2 * Bp[i];
+            if (o >= oa) finish_pair(o, oa, Su);
+            else {
+                double St[9];
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) St[3 * m + q] = Su[3 * q + m];
+                finish_pair(oa, o, St);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int nred = oa >= 0 ? nobs - 1 : nobs, npair = nred * (nred + 1) / 2;
+        for (int q = tid; q < npair; q += WAVE) {
+            int i = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
+            while ((i + 1) * (i + 2) / 2 <= q) ++i;
+            while (i * (i + 1) / 2 > q) --i;
+            const int i2 = q - i * (i + 1) / 2;
+            const int o = i + ((oa >= 0 && i >= oa) ? 1 : 0), o2 = i2 + ((oa >= 0 && i2 >= oa) ? 1 : 0);
+            const int gc = sh.f.gidx[6 * sh.f.slot[o]], gc2 = sh.f.gidx[6 * sh.f.slot[o2]];
+            const double cn = sh.cna[o] ? 1.0 : 0.0, cn2 = sh.cna[o2] ? 1.0 : 0.0;
+            const double pl = sh.pfl[o] ? 1.0 : 0.0, pl2 = sh.pfl[o2] ? 1.0 : 0.0;
+            double Att[9], Atp[9], Apt[9], App[9], T1[9], T2[9], Su[9];
+            ldblk(gc, gc2, Att);
+            ldblk(gc, gc2 + 3, Atp);
+            ldblk(gc + 3, gc2, Apt);
+            ldblk(gc + 3, gc2 + 3, App);
+            mulXt(Att, px, py, pz, T1);
+            mulX(T1, px, py, pz, T2);             // X Ptt' X^T
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Su[k] = cn * cn2 * (T2[k] + sh.Qb[k]) + pl * pl2 * App[k];
+            mulXt(Atp, px, py, pz, T1);
+            mulX(Apt, px, py, pz, T2);
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    Su[3 * m + k] += cn * pl2 * T1[3 * m + k] + pl * cn2 * T2[3 * m + k] - cn2 * sh.Rb[o][3 * m + k] - cn * sh.Rb[o2][3 * k + m];
+            finish_pair(o, o2, Su);
+        }
     }
     __syncthreads();
     dbg_stamp(27);
-    if constexpr (MFMA_LDL) {
+    {
         // ---- blocked LDL^T on the matrix cores --------------------------------------------------------
         // The bordered matrix (K padded with unit pivots to KP rows, then the 4 rows of W^T) is held as 16x16
         // lower tiles in the MFMA C/D layout: lane (kq = lane>>4, l15 = lane&15), register r of tile (ti,tj)
@@ -446,91 +470,6 @@ __global__ __launch_bounds__(WAVE) void k_feat_gate3(
         for (int e = tid; e < REC_HDR + REC_OBS * nobs; e += WAVE) rec_g[e] = rec[e];
         return;
     }
-    // ---- gather own column -------------------------------------------------------------------
-    double col[DIM];
-#pragma unroll
-    for (int i = 0; i < DIM; ++i) col[i] = 0.0;
-    const int jo = (tid - 4) / D, jc = (tid - 4) - D * jo;      // own observation / component (lanes >= 4)
-    const bool kcol = tid >= 4 && jo < nobs;
-    if (kcol) {
-        // border rows of a K column = W[j][0..3]
-        if (STEREO) {
-            col[0] = sh.u[jo][jc];
-#pragma unroll
-            for (int m = 0; m < 3; ++m) col[1 + m] = (jc == m) ? 1.0 : 0.0;
-        } else {
-            col[0] = sh.f.res[jo][jc];
-#pragma unroll
-            for (int m = 0; m < 3; ++m) col[1 + m] = sh.f.G[jo][jc][m];
-        }
-    }
-#pragma unroll
-    for (int o = 0; o < CMAX; ++o) {
-        if (o < nobs) {
-            if (kcol) {
-                const bool low = o >= jo;                    // block (o, jo) stored, else (jo, o) transposed
-                const int q = low ? o * (o + 1) / 2 + jo : jo * (jo + 1) / 2 + o;
-#pragma unroll
-                for (int c = 0; c < D; ++c) col[4 + D * o + c] = sh.blk[q][low ? D * c + jc : D * jc + c];
-            } else if (tid < 4) {
-                // border columns: W[3o+c][tid]
-#pragma unroll
-                for (int c = 0; c < D; ++c) {
-                    double v;
-                    if (STEREO) v = tid == 0 ? sh.u[o][c] : (tid - 1 == c ? 1.0 : 0.0);
-                    else v = tid == 0 ? sh.f.res[o][c] : sh.f.G[o][c][(tid + 2) % 3];   // tid-1 for tid in 1..3
-                    col[4 + D * o + c] = v;
-                }
-            }
-        }
-    }
-    // ---- LDL^T, D*nobs pivots ----------------------------------------------------------------
-#pragma unroll
-    for (int po = 0; po < CMAX; ++po) {
-        if (po < nobs) {
-#pragma unroll
-            for (int pc = 0; pc < D; ++pc) {
-                constexpr int dummy = 0; (void)dummy;
-                const int p = 4 + D * po + pc;
-                const double dp = bcast_lane(col[p], p);
-                const double f = col[p] * fast_rcp(dp);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) col[i] = fma(-bcast_lane(col[i], p), f, col[i]);
-#pragma unroll
-                for (int c2 = pc + 1; c2 < D; ++c2) col[4 + D * po + c2] = fma(-bcast_lane(col[4 + D * po + c2], p), f, col[4 + D * po + c2]);
-#pragma unroll
-                for (int o2 = po + 1; o2 < CMAX; ++o2) {
-                    if (o2 < nobs) {
-#pragma unroll
-                        for (int c2 = 0; c2 < D; ++c2) col[4 + D * o2 + c2] = fma(-bcast_lane(col[4 + D * o2 + c2], p), f, col[4 + D * o2 + c2]);
-                    }
-                }
-            }
-        }
-    }
-    // ---- gamma: three more pivots on the Hf border rows (indices 1..3) leave -(Z00 - f^T Zff^-1 f) at (0,0),
-    //      Z = W^T K^-1 W; the part of r outside range(Gblk) adds |r_perp|^2 / s^2 (stereo) ---------------
-#pragma unroll
-    for (int p = 1; p < 4; ++p) {
-        const double dp = bcast_lane(col[p], p);
-        const double f = col[p] * fast_rcp(dp);
-        col[0] = fma(-bcast_lane(col[0], p), f, col[0]);
-#pragma unroll
-        for (int i = p + 1; i < 4; ++i) col[i] = fma(-bcast_lane(col[i], p), f, col[i]);
-    }
-    if (tid == 0) {
-        double g = -col[0];
-        if (STEREO) {
-            double rp = 0.0;
-            for (int o = 0; o < nobs; ++o) rp += sh.rperp[o];
-            g += rp / op.var;
-        }
-        const int dof = fv.dof[oidx];
-        const bool ok = dof >= 1 && dof < op.chi2_len && g < op.chi2[dof];      // Update.cpp:120
-        gamma_out[oidx] = g;
-        accept_out[oidx] = ok ? 1 : 0;
-    }
-    for (int e = tid; e < REC_HDR + REC_OBS * nobs; e += WAVE) rec_g[e] = rec[e];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1171,13 +1110,8 @@ static void launch_ft(const FactoredLaunch& L, hipStream_t st)
 {
     if (L.stage == 0) {
         const int nb8 = (L.nb + 7) / 8 * 8;
-        static const bool mfma_ldl = !(getenv("INGVIO_GATE_LDL") && atoi(getenv("INGVIO_GATE_LDL")) == 0);
-        if (mfma_ldl)
-            hipLaunchKernelGGL((k_feat_gate3<CMAX, STEREO, true>), dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st,
-                               L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
-        else
-            hipLaunchKernelGGL((k_feat_gate3<CMAX, STEREO, false>), dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st,
-                               L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
+        hipLaunchKernelGGL((k_feat_gate3<CMAX, STEREO>), dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st,
+                           L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
     } else {
         constexpr size_t uni = sizeof(Gram2Batch<CMAX>) > sizeof(Gram2Out<CMAX>) ? sizeof(Gram2Batch<CMAX>) : sizeof(Gram2Out<CMAX>);
         const size_t sm = ((uni + 15) / 16) * 16 + 2 * sizeof(int) * (size_t)L.fv.fmax;
