@@ -12,19 +12,26 @@ struct FeatCfg {
     static constexpr int NT = ((NCOLMAX + 1 + 63) / 64) * 64;
 };
 
-// LDS scratch of the per-feature builder.  LEAN drops what only the dense path needs (G [p_f]x and the
-// nullspace reflectors): the factored gate kernel is occupancy-bound by LDS.
+// LDS scratch of the per-feature builder.  LEAN drops what only the dense path needs (G [p_f]x, the nullspace
+// reflectors, the per-column index table): the factored gate kernel's occupancy is bounded by LDS.
+template <int CMAX, bool STEREO, bool LEAN>
+struct FeatDenseOnly {
+    using Cfg = FeatCfg<CMAX, STEREO>;
+    double GX[CMAX][Cfg::RPO][3];     // (Pi~ * R^T) [p_f]x
+    double V[3][Cfg::RR];             // the three nullspace reflectors
+    double tau[3];
+};
+template <int CMAX, bool STEREO>
+struct FeatDenseOnly<CMAX, STEREO, true> {};
+
 template <int CMAX, bool STEREO, bool LEAN = false>
-struct FeatShared {
+struct FeatShared : FeatDenseOnly<CMAX, STEREO, LEAN> {
     using Cfg = FeatCfg<CMAX, STEREO>;
     static constexpr bool kLean = LEAN;
     double G[CMAX][Cfg::RPO][3];      // Pi~ * R^T per observation  (also the Hf rows)
-    double GX[LEAN ? 1 : CMAX][Cfg::RPO][3];     // (Pi~ * R^T) [p_f]x
     double res[CMAX][Cfg::RPO];
-    double V[3][LEAN ? 1 : Cfg::RR];  // the three nullspace reflectors
-    double tau[3];
     int slot[CMAX];                   // window slot of dense observation o
-    int gidx[Cfg::NCOLMAX];           // state index of every column
+    int gidx[LEAN ? CMAX : Cfg::NCOLMAX];   // state index of every column (LEAN: of every clone's first column)
     int nobs;
 };
 
@@ -186,7 +193,11 @@ __device__ __forceinline__ void feat_phase2(FeatShared<CMAX, STEREO>& sh, int ro
 template <int CMAX, bool STEREO, bool LEAN = false>
 __device__ __forceinline__ void load_gidx(const FrameView& fv, int b, int C, FeatShared<CMAX, STEREO, LEAN>& sh)
 {
-    for (int c = threadIdx.x; c < 6 * C; c += blockDim.x)
-        sh.gidx[c] = fv.clone_idx[(size_t)b * fv.cmax + c / 6] + c % 6;
+    if constexpr (LEAN) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) sh.gidx[c] = fv.clone_idx[(size_t)b * fv.cmax + c];
+    } else {
+        for (int c = threadIdx.x; c < 6 * C; c += blockDim.x)
+            sh.gidx[c] = fv.clone_idx[(size_t)b * fv.cmax + c / 6] + c % 6;
+    }
 }
 

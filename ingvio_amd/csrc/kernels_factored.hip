@@ -108,8 +108,8 @@ struct Gate3Shared {
         double blk[NPAIR][D * D];     // pair blocks
         double nh[CMAX * 12 + 24];    // before they are built: N_o | h_o per observation and the record's 21 sums
         double pan[16 * NTL][4];      // after the tiles are built: panel exchange of the MFMA elimination
+        double bz[16];                // finally: the 4x4 border block
     };
-    double bz[16];
     double Rb[CMAX][9];               // per-observation part of Su: R_o = cn X P(th_o,th_a) X^T + pl P(p_o,th_a) X
     double Qb[9];                     // X P(th_a,th_a) X^T
 };
@@ -128,7 +128,7 @@ __device__ __forceinline__ double bcast_lane(double x, int lane)      // lane mu
 }
 
 template <int CMAX, bool STEREO>
-__global__ __launch_bounds__(WAVE) void k_feat_gate3(
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_feat_gate3(
     CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out,
     int* __restrict__ accept_out, double* __restrict__ rec_out)
 {
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(WAVE) void k_feat_gate3(
     //      so a pair needs 4 blocks of P instead of 9.  Pairs with the anchor's own observation (cn' = 0) only keep the
     //      p-column terms; they are built in the per-observation pass, which leaves nobs-1 choose 2 (+diag) <= 55
     //      generic pairs: ONE round of the wave for an 11-clone window instead of two.
-    const int ga = sh.f.gidx[6 * a];
+    const int ga = sh.f.gidx[a];
     auto ldblk = [&](int r0, int c0, double M[9]) {
 #pragma unroll
         for (int m = 0; m < 3; ++m)
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(WAVE) void k_feat_gate3(
     const unsigned long long amask = __ballot(tid < nobs && sh.f.slot[tid < nobs ? tid : 0] == a);
     const int oa = amask ? __ffsll((long long)amask) - 1 : -1;          // the anchor clone's own observation, if any
     if (tid < nobs) {
-        const int o = tid, gc = sh.f.gidx[6 * sh.f.slot[o]];
+        const int o = tid, gc = sh.f.gidx[sh.f.slot[o]];
         const double cn = sh.cna[o] ? 1.0 : 0.0, pl = sh.pfl[o] ? 1.0 : 0.0;
         double U[9], V[9], Paa[9], T1[9], T2[9];
         ldblk(gc, ga, U);
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(WAVE) void k_feat_gate3(
             while (i * (i + 1) / 2 > q) --i;
             const int i2 = q - i * (i + 1) / 2;
             const int o = i + ((oa >= 0 && i >= oa) ? 1 : 0), o2 = i2 + ((oa >= 0 && i2 >= oa) ? 1 : 0);
-            const int gc = sh.f.gidx[6 * sh.f.slot[o]], gc2 = sh.f.gidx[6 * sh.f.slot[o2]];
+            const int gc = sh.f.gidx[sh.f.slot[o]], gc2 = sh.f.gidx[sh.f.slot[o2]];
             const double cn = sh.cna[o] ? 1.0 : 0.0, cn2 = sh.cna[o2] ? 1.0 : 0.0;
             const double pl = sh.pfl[o] ? 1.0 : 0.0, pl2 = sh.pfl[o2] ? 1.0 : 0.0;
             double Att[9], Atp[9], Apt[9], App[9], T1[9], T2[9], Su[9];
