@@ -356,33 +356,55 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 4))) vo
         constexpr int NTL = SH::NTL, KP = SH::KP, NLT = NTL * (NTL + 1) / 2;
         const int np = D * nobs, npan = (np + 3) >> 2;
         const int kq = tid >> 4, l15 = tid & 15;
-        auto kval = [&](int i, int o, int c, int jcol, int o2, int c2) -> double {
-            if (jcol >= np) return (i == jcol && i < KP) ? 1.0 : 0.0;
-            if (i < np) {
-                const bool low = o >= o2;
-                const int q = low ? o * (o + 1) / 2 + o2 : o2 * (o2 + 1) / 2 + o;
-                return sh.blk[q][low ? D * c + c2 : D * c2 + c];
-            }
-            const int bi = i - KP;
-            if (bi < 0 || bi >= 4) return 0.0;
-            if (STEREO) return bi == 0 ? sh.u[o2][c2] : (bi - 1 == c2 ? 1.0 : 0.0);
-            return bi == 0 ? sh.f.res[o2][c2] : sh.f.G[o2][c2][(bi + 2) % 3];
-        };
+        // Tile fill, branch-free: one (clamped) LDS read + selects per element.  Row classes are compile-time:
+        // i = 16 ti + kq + 4 r is a border row exactly for (ti, r) = (NTL-1, 1) (then i - KP = kq), rows past the
+        // border (ti = NTL-1, r >= 2) are zero; whether a K row/column is real (< np) or a unit pad is a lane select.
         double4_f T[NLT];
         int jo[NTL], jc[NTL];
+        bool jreal[NTL];
 #pragma unroll
-        for (int tj = 0; tj < NTL; ++tj) { const int jj = min(16 * tj + l15, np > 0 ? np - 1 : 0); jo[tj] = jj / D; jc[tj] = jj - D * jo[tj]; }
+        for (int tj = 0; tj < NTL; ++tj) {
+            const int j = 16 * tj + l15;
+            jreal[tj] = j < np;
+            const int jj = jreal[tj] ? j : 0;
+            jo[tj] = jj / D; jc[tj] = jj - D * jo[tj];
+        }
 #pragma unroll
         for (int ti = 0; ti < NTL; ++ti) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * ti + kq + 4 * r;
-                const int ic = min(i, np > 0 ? np - 1 : 0), io = ic / D, icc = ic - D * io;
+                if (ti == NTL - 1 && r >= 2) {
 #pragma unroll
-                for (int tj = 0; tj <= ti; ++tj) T[ti * (ti + 1) / 2 + tj][r] = kval(i, io, icc, 16 * tj + l15, jo[tj], jc[tj]);
+                    for (int tj = 0; tj <= ti; ++tj) T[ti * (ti + 1) / 2 + tj][r] = 0.0;
+                } else if (ti == NTL - 1 && r == 1) {                 // border row kq: W[j][kq]
+#pragma unroll
+                    for (int tj = 0; tj <= ti; ++tj) {
+                        double v;
+                        if (STEREO) {
+                            const double uv = sh.u[jo[tj]][jc[tj]];
+                            v = kq == 0 ? uv : (kq - 1 == jc[tj] ? 1.0 : 0.0);
+                        } else {
+                            const double rv = sh.f.res[jo[tj]][jc[tj]], gv = sh.f.G[jo[tj]][jc[tj]][(kq + 2) % 3];
+                            v = kq == 0 ? rv : gv;
+                        }
+                        T[ti * (ti + 1) / 2 + tj][r] = jreal[tj] ? v : 0.0;
+                    }
+                } else {
+                    const bool ireal = i < np;
+                    const int ii = ireal ? i : 0, io = ii / D, ic = ii - D * io;
+#pragma unroll
+                    for (int tj = 0; tj <= ti; ++tj) {
+                        const int o2 = jo[tj], c2 = jc[tj];
+                        const bool low = io >= o2;
+                        const int q = low ? io * (io + 1) / 2 + o2 : o2 * (o2 + 1) / 2 + io;
+                        const double bv = sh.blk[q][low ? D * ic + c2 : D * c2 + ic];
+                        const double idv = (i == 16 * tj + l15) ? 1.0 : 0.0;      // unit pivots on the padding rows
+                        T[ti * (ti + 1) / 2 + tj][r] = (ireal && jreal[tj]) ? bv : ((!ireal && !jreal[tj]) ? idv : 0.0);
+                    }
+                }
             }
         }
-        dbg_stamp(28);
         wave_sync();                              // blk is dead from here on: its LDS becomes the panel buffer
 #pragma unroll
         for (int k = 0; k < KP / 4; ++k) {
