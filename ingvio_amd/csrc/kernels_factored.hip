@@ -524,7 +524,7 @@ struct Gram2Cfg {
     static constexpr int PRE = (GRAM_NB * (REC_HDR + REC_OBS * CMAX) + GRAM_NT - 1) / GRAM_NT;
     static constexpr int REC = REC_HDR + REC_OBS * CMAX;
     static constexpr int KR = 3 * GRAM_NB;                 // stacked rows per batch
-    static constexpr int SPW = 24;                         // per (feature, slot) sparse scratch: S1(9) NXs(9) s4(3) flag
+    static constexpr int SPW = 34;                         // per (feature, slot) sparse scratch: S1 NXs S3 (9 each) s4 s5 (3 each) key
 };
 template <int CMAX>
 struct Gram2Batch {
@@ -630,6 +630,7 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
             for (int e = tid; e < (KR - 3 * nbf) * LDW; e += GRAM_NT) { (&sb.Bm[3 * nbf][0])[e] = 0.0; (&sb.Ym[3 * nbf][0])[e] = 0.0; }
         }
         __syncthreads();
+        dbg_stamp(35);
         // ---- P2: operand rows B, Y = Ns^-1 B and the sparse scratch, lane = (feature, window slot) -----
         if (tid < nbf * 16) {
             const int f = tid >> 4, c = tid & 15;
@@ -680,9 +681,11 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
                 sp[18] = cn * (pz * ro[13] - py * ro[14]);          // X^T h_o = h_o x p_f
                 sp[19] = cn * (px * ro[14] - pz * ro[12]);
                 sp[20] = cn * (py * ro[12] - px * ro[13]);
-                sp[21] = obs ? 1.0 : 0.0;
-                sp[22] = pl;
-                sp[23] = (double)o;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) sp[21 + i] = pl * ro[3 + i];                 // pl N_o
+#pragma unroll
+                for (int i = 0; i < 3; ++i) sp[30 + i] = pl * ro[12 + i];                // pl h_o
+                sp[33] = obs ? (double)a : -1.0;                       // key: the anchor slot this contribution belongs to
             }
         }
         __syncthreads();
@@ -690,32 +693,36 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
         // ---- P3a: rank-3 part on the matrix cores (next batch's records are fetched meanwhile) -------------
         fetch(qb + GRAM_NB);
         const int nst = (3 * nbf + 3) >> 2;
-        for (int st = 0; st < nst; ++st) {
 #pragma unroll
-            for (int u = 0; u < TPW; ++u) {
-                if (wave + 4 * u < NUP) {
-                    const int ti = tiA[u], tj = tjA[u];
-                    const double af = sb.Ym[4 * st + kq][16 * ti + l15];      // A[i][k] = Y[k][i]
-                    const double bf = sb.Bm[4 * st + kq][16 * tj + l15];      // B[k][j]
-                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[u], 0, 0, 0);
+        for (int st = 0; st < KR / 4; ++st) {                // fully unrolled: the fragment reads of the later steps are
+            if (st < nst) {                                  // issued while the earlier MFMAs run
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    if (wave + 4 * u < NUP) {
+                        const int ti = tiA[u], tj = tjA[u];
+                        const double af = sb.Ym[4 * st + kq][16 * ti + l15];      // A[i][k] = Y[k][i]
+                        const double bf = sb.Bm[4 * st + kq][16 * tj + l15];      // B[k][j]
+                        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[u], 0, 0, 0);
+                    }
                 }
             }
         }
-        // ---- P3b: sparse part, lane (c, a) ----------------------------------------------------------
+        dbg_stamp(38);
+        // ---- P3b: sparse part, lane (c, a): branch-free, one level of LDS reads (the key says whose anchor it is) ----
         if (pairlane) {
-            for (int f = 0; f < nbf; ++f) {
-                const double* rc = sb.rec[f];
-                if ((int)rc[1] != pa) continue;
-                const double* sp = sb.sp[f][pc];
-                if (sp[21] == 0.0) continue;
-                const double pl = sp[22];
-                const double* ro = rc + REC_HDR + REC_OBS * (int)sp[23];
 #pragma unroll
-                for (int i = 0; i < 9; ++i) { sS1[i] += sp[i]; sNX[i] += sp[9 + i]; sS3[i] += pl * ro[3 + i]; }
+            for (int f = 0; f < GRAM_NB; ++f) {
+                if (f < nbf) {
+                    const double* sp = sb.sp[f][pc];
+                    const double m = sp[33] == (double)pa ? 1.0 : 0.0;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) { s4[i] += sp[18 + i]; s5[i] += pl * ro[12 + i]; }
+                    for (int i = 0; i < 9; ++i) { sS1[i] = fma(m, sp[i], sS1[i]); sNX[i] = fma(m, sp[9 + i], sNX[i]); sS3[i] = fma(m, sp[21 + i], sS3[i]); }
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { s4[i] = fma(m, sp[18 + i], s4[i]); s5[i] = fma(m, sp[30 + i], s5[i]); }
+                }
             }
         }
+        dbg_stamp(41);
         __syncthreads();
     }
 
