@@ -1009,12 +1009,17 @@ __global__ __launch_bounds__(INFO_NT, 2) void k_info_update(
 
 template <int NC>
 __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int nb, int wgpf, const double* __restrict__ Mall, int mstride,
-                                                    const double* __restrict__ Pcall, int ystride, const int* __restrict__ m_all,
-                                                    double* __restrict__ dx_all, int* __restrict__ status,
-                                                    const int* __restrict__ marg_idx, int msize, const int* __restrict__ pc_base)
+                                                       const double* __restrict__ Pcall, int ystride, const int* __restrict__ m_all,
+                                                       double* __restrict__ dx_all, int* __restrict__ status,
+                                                       const int* __restrict__ marg_idx, int msize, const int* __restrict__ pc_base)
 {
     constexpr int MP = (NC + 3) & ~3, K4 = MP / 4, JT = (MP + 15) / 16;
-    __shared__ double sT[4][16][MP + 2];
+    // sT (layout change of T, first phase) and sB (B-operand tile Pc[16 tj .. +16][0..MP), staged once per workgroup
+    // per step, second phase) share their LDS
+    constexpr int ST_DOUBLES = 4 * 16 * (MP + 2), SB_DOUBLES = 2 * MP * 16;
+    __shared__ __attribute__((aligned(16))) double sTB[ST_DOUBLES > SB_DOUBLES ? ST_DOUBLES : SB_DOUBLES];
+    double (*sT)[16][MP + 2] = reinterpret_cast<double (*)[16][MP + 2]>(sTB);
+    double (*sB)[MP][16] = reinterpret_cast<double (*)[MP][16]>(sTB);
     __shared__ double sV[4][16][17];
     // XCD-aware order: the workgroups of one filter share an L2 (they all stream the same Pc and M)
     const int wg = blockIdx.x, xcd = wg & 7, tq = wg >> 3;
@@ -1026,9 +1031,13 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     const bool fused = midx >= 0;
     if (!upd && !fused) return;
     const int n = cv.n[b], ld = cv.ldp, nt = (n + 15) >> 4;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (2 * part * 4 >= nt) return;                           // whole workgroup idle (uniform)
     const int pw = part * 4 + wave;                           // this wave owns tile rows pw and nt-1-pw: nt+1 tiles, balanced
-    if (2 * pw >= nt) return;
+    const bool wave_on = 2 * pw < nt;
+    const int tiR[2] = { pw, nt - 1 - pw };
+    const int nrows = !wave_on ? 0 : (tiR[1] > tiR[0] ? 2 : 1);
+    const int tjmax = nt - 1 - part * 4;                      // the workgroup's longest row
     const double* P = cov_ptr(cv, b);
     double* dst = fused ? cov_alt_ptr(cv, b) : cov_ptr(cv, b);
     // pc_base >= 0: the clone columns are a contiguous block of the (untouched, out-of-place) prior itself; columns
@@ -1041,95 +1050,131 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     auto alive = [&](int i) { return !(fused && i >= midx && i < midx + msize); };
     auto remap = [&](int i) { return (fused && i >= midx) ? i - msize : i; };
 
-    for (int half = 0; half < 2; ++half) {
-        const int ti = half == 0 ? pw : nt - 1 - pw;
-        if (half == 1 && ti == pw) break;
-        double tfrag[K4];
-        if (upd) {
-            const int ra = min(ti * 16 + l15, n - 1);                    // clamped: rows >= n are computed but never stored
-            double afrag[K4];
+    // ---- T rows of this wave's (up to) two tile rows, kept as A-operand fragments ------------------------------
+    double tfrag[2][K4];
+    if (upd) {
 #pragma unroll
-            for (int k4 = 0; k4 < K4; ++k4) afrag[k4] = (Pc + (size_t)(4 * k4) * ld)[ra + kq * ld];      // uniform base + one lane offset
-            {
-                double d = 0.0;
+        for (int h = 0; h < 2; ++h) {
+            if (h < nrows) {
+                const int ti = tiR[h];
+                const int ra = min(ti * 16 + l15, n - 1);                    // clamped: rows >= n are computed but never stored
+                double afrag[K4];
 #pragma unroll
-                for (int k4 = 0; k4 < K4; ++k4) d += afrag[k4] * tvec[4 * k4 + kq];
-                d += __shfl_xor(d, 16, WAVE);
-                d += __shfl_xor(d, 32, WAVE);
-                if (kq == 0 && ti * 16 + l15 < n) dx_all[(size_t)b * ld + ra] = d;
-            }
-#pragma unroll 1
-            for (int jt = 0; jt < JT; ++jt) {
-                double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
-                const int jc = min(jt * 16 + l15, MP - 1);
-                double bfrag[K4];
+                for (int k4 = 0; k4 < K4; ++k4) afrag[k4] = (Pc + (size_t)(4 * k4) * ld)[ra + kq * ld];      // uniform base + one lane offset
+                {
+                    double d = 0.0;
 #pragma unroll
-                for (int k4 = 0; k4 < K4; ++k4) bfrag[k4] = (M + (size_t)(4 * k4) * MP)[kq * MP + jc];      // B[k][j] = M[k][j]
-#pragma unroll
-                for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[k4], bfrag[k4], acc, 0, 0, 0);
-                if (jt * 16 + l15 < MP) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sT[wave][kq + 4 * r][jc] = acc[r];      // C/D: col = lane&15, row = (lane>>4)+4r
+                    for (int k4 = 0; k4 < K4; ++k4) d += afrag[k4] * tvec[4 * k4 + kq];
+                    d += __shfl_xor(d, 16, WAVE);
+                    d += __shfl_xor(d, 32, WAVE);
+                    if (kq == 0 && ti * 16 + l15 < n) dx_all[(size_t)b * ld + ra] = d;
                 }
-            }
-            __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+                for (int jt = 0; jt < JT; ++jt) {
+                    double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
+                    const int jc = min(jt * 16 + l15, MP - 1);
+                    double bfrag[K4];
 #pragma unroll
-            for (int k4 = 0; k4 < K4; ++k4) tfrag[k4] = sT[wave][l15][4 * k4 + kq];      // A[i][k] = T[i][k]
-            __builtin_amdgcn_wave_barrier();
+                    for (int k4 = 0; k4 < K4; ++k4) bfrag[k4] = (M + (size_t)(4 * k4) * MP)[kq * MP + jc];      // B[k][j] = M[k][j]
+#pragma unroll
+                    for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[k4], bfrag[k4], acc, 0, 0, 0);
+                    if (jt * 16 + l15 < MP) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sT[wave][kq + 4 * r][jc] = acc[r];      // C/D: col = lane&15, row = (lane>>4)+4r
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k4 = 0; k4 < K4; ++k4) tfrag[h][k4] = sT[wave][l15][4 * k4 + kq];      // A[i][k] = T[i][k]
+                __builtin_amdgcn_wave_barrier();
+            }
         }
-        // tiles (ti, 0..ti); the Pc fragment and the P values of the next tile are in flight during this tile's MFMAs
-        double bcur[K4], pcur[4];
-        auto load_tile = [&](int tj, double (&bf)[K4], double (&pv)[4]) {
-            const int rb = min(tj * 16 + l15, n - 1);
-            if (upd) {
+    }
+
+    // ---- tiles (ti, tj): all waves walk tj together; the B tile is staged in LDS once for the four waves ----------
+    constexpr int STG = (MP * 16 + 255) / 256;
+    double stg[STG];
+    auto stage_load = [&](int tj) {                            // element e = k * 16 + r  ->  Pc[16 tj + r][k]
 #pragma unroll
-                for (int k4 = 0; k4 < K4; ++k4) bf[k4] = (Pc + (size_t)(4 * k4) * ld)[rb + kq * ld];      // B[k][j] = Pc[rj + j][k]
-            }
-            const int col = tj * 16 + l15;
+        for (int u = 0; u < STG; ++u) {
+            const int e = tid + 256 * u, k = e >> 4, r = e & 15;
+            stg[u] = (upd && e < MP * 16) ? Pc[min(16 * tj + r, n - 1) + (size_t)k * ld] : 0.0;
+        }
+    };
+    auto stage_store = [&](int buf) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = ti * 16 + kq + 4 * r;
-                pv[r] = (row < n && col < n && row >= col) ? P[col + (size_t)row * ld] : 0.0;      // mirrored (coalesced) address
+        for (int u = 0; u < STG; ++u) { const int e = tid + 256 * u; if (e < MP * 16) (&sB[buf][0][0])[e] = stg[u]; }
+    };
+    auto store_tile = [&](int ti, int tj, const double4_f& acc, const double (&pv)[4]) {
+        // element (row, col), row >= col: stored through the mirrored address (col fastest, coalesced); its transpose
+        // goes through LDS so that the second store runs along rows, coalesced as well
+        const int col = tj * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = ti * 16 + kq + 4 * r;
+            const double v = pv[r] - acc[r];
+            if (row < n && col < n && row >= col) {
+                if (alive(row) && alive(col)) dst[remap(col) + (size_t)remap(row) * ld] = v;
+                if (upd && row == col && v < 0.0) atomicOr(&status[b], 2);      // StateManager.cpp:413-421
             }
-        };
-        load_tile(0, bcur, pcur);
-        for (int tj = 0; tj <= ti; ++tj) {
-            double bnext[K4], pnext[4];
-            if (tj < ti) load_tile(tj + 1, bnext, pnext);
+            sV[wave][kq + 4 * r][l15] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int row2 = ti * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col2 = tj * 16 + kq + 4 * r;
+            if (row2 < n && col2 < n && row2 > col2 && alive(row2) && alive(col2))
+                dst[remap(row2) + (size_t)remap(col2) * ld] = sV[wave][l15][kq + 4 * r];
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto load_p = [&](int ti, int tj, double (&pv)[4]) {
+        const int col = tj * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = ti * 16 + kq + 4 * r;
+            pv[r] = (row < n && col < n && row >= col) ? P[col + (size_t)row * ld] : 0.0;      // mirrored (coalesced) address
+        }
+    };
+    stage_load(0);
+    __syncthreads();                                           // every wave is done with sT
+    stage_store(0);
+    __syncthreads();
+    double pv0[4], pv1[4], pn0[4], pn1[4];
+    if (nrows > 0) load_p(tiR[0], 0, pv0);
+    if (nrows > 1) load_p(tiR[1], 0, pv1);
+    for (int tj = 0; tj <= tjmax; ++tj) {
+        const int buf = tj & 1;
+        if (tj < tjmax) stage_load(tj + 1);                    // next B tile and next P values in flight during this step's MFMAs
+        const bool do0 = nrows > 0 && tj <= tiR[0], do1 = nrows > 1 && tj <= tiR[1];
+        if (nrows > 0 && tj + 1 <= tiR[0]) load_p(tiR[0], tj + 1, pn0);
+        if (nrows > 1 && tj + 1 <= tiR[1]) load_p(tiR[1], tj + 1, pn1);
+        double bfrag[K4];
+        if (upd && (do0 || do1)) {
+#pragma unroll
+            for (int k4 = 0; k4 < K4; ++k4) bfrag[k4] = sB[buf][4 * k4 + kq][l15];      // B[k][j] = Pc[16 tj + j][k]
+        }
+        if (do0) {
             double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
             if (upd) {
 #pragma unroll
-                for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tfrag[k4], bcur[k4], acc, 0, 0, 0);
+                for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tfrag[0][k4], bfrag[k4], acc, 0, 0, 0);
             }
-            // element (row, col), row >= col: stored through the mirrored address (col fastest, coalesced); its transpose
-            // goes through LDS so that the second store runs along rows, coalesced as well
-            const int col = tj * 16 + l15;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = ti * 16 + kq + 4 * r;
-                const double v = pcur[r] - acc[r];
-                if (row < n && col < n && row >= col) {
-                    if (alive(row) && alive(col)) dst[remap(col) + (size_t)remap(row) * ld] = v;
-                    if (upd && row == col && v < 0.0) atomicOr(&status[b], 2);      // StateManager.cpp:413-421
-                }
-                sV[wave][kq + 4 * r][l15] = v;
-            }
-            __builtin_amdgcn_wave_barrier();
-            const int row2 = ti * 16 + l15;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int col2 = tj * 16 + kq + 4 * r;
-                if (row2 < n && col2 < n && row2 > col2 && alive(row2) && alive(col2))
-                    dst[remap(row2) + (size_t)remap(col2) * ld] = sV[wave][l15][kq + 4 * r];
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (tj < ti) {
-#pragma unroll
-                for (int k4 = 0; k4 < K4; ++k4) bcur[k4] = bnext[k4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pcur[r] = pnext[r];
-            }
+            store_tile(tiR[0], tj, acc, pv0);
         }
+        if (do1) {
+            double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
+            if (upd) {
+#pragma unroll
+                for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tfrag[1][k4], bfrag[k4], acc, 0, 0, 0);
+            }
+            store_tile(tiR[1], tj, acc, pv1);
+        }
+        if (tj < tjmax) stage_store(buf ^ 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pv0[r] = pn0[r]; pv1[r] = pn1[r]; }
+        __syncthreads();
     }
 }
 
