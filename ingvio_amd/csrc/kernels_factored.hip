@@ -946,6 +946,7 @@ __global__ __launch_bounds__(INFO_NT, 2) void k_info_update(
             const double r0 = rowbuf[j0], r1 = j1 < LA ? rowbuf[j1] : 0.0;
             const int kn = k + 1, knc = kn >= TXN ? 1 : 0;
             const bool own_next = kn < NC && gx == kn - knc * TXN;
+            unsigned long long mykey = 0ULL;                   // this thread's best candidate: one LDS atomic per owner
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
                 const int i = gy + TYN * q;
@@ -956,10 +957,11 @@ __global__ __launch_bounds__(INFO_NT, 2) void k_info_update(
                     if (own_next && !((usedmask >> q) & 1u)) {
                         const double nv = knc ? v[q][1] : v[q][0];
                         const unsigned long long key = ((unsigned long long)__double_as_longlong(fabs(nv)) & ~0xFFULL) | (unsigned long long)(255 - i);
-                        atomicMax(&sBest[kn & 1], key);
+                        mykey = key > mykey ? key : mykey;
                     }
                 }
             }
+            if (mykey) atomicMax(&sBest[kn & 1], mykey);
         }
         __syncthreads();
     }
