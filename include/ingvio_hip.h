@@ -48,7 +48,7 @@ typedef struct ingvio_ctx ingvio_ctx;
 typedef struct {
     int batch;      /* independent filters held by this context (>= 1)                          */
     int n_max;      /* max state dimension N (21 + gnss + 6C + 3L)                               */
-    int c_max;      /* max clones in the sliding window (<= 21 in this build)     */
+    int c_max;      /* max clones in the sliding window (<= 16 in this build)     */
     int f_max;      /* max features per MSCKF update                                             */
     int m_max;      /* max rows of a generic ekf_update (<= 128 in this build)                   */
     int device;     /* HIP device ordinal                                                        */
@@ -62,6 +62,7 @@ int ingvio_sync(ingvio_ctx* ctx);
 void* ingvio_ctx_stream(ingvio_ctx* ctx);             /* the hipStream_t all kernels are launched on */
 const char* ingvio_last_error(ingvio_ctx* ctx);
 int ingvio_ldp(ingvio_ctx* ctx);                      /* leading dimension of the device P buffers  */
+int ingvio_f_max(ingvio_ctx* ctx);                    /* feature capacity: length of the accepted[] arrays */
 
 /* initStateAndCov / getFullCov (State.cpp:126-167, StateManager.cpp:121-126). cov_get synchronises. */
 int ingvio_cov_set(ingvio_ctx* ctx, int b, const double* P, int ld, int n);

@@ -356,6 +356,7 @@ int ingvio_sync(ingvio_ctx* c)
 void* ingvio_ctx_stream(ingvio_ctx* c) { return c ? (void*)c->st : nullptr; }
 const char* ingvio_last_error(ingvio_ctx* c) { return c ? c->err.c_str() : "null context"; }
 int ingvio_ldp(ingvio_ctx* c) { return c ? c->ldp : 0; }
+int ingvio_f_max(ingvio_ctx* c) { return c ? c->d.f_max : 0; }
 
 int ingvio_cov_set(ingvio_ctx* c, int b, const double* P, int ld, int n)
 {

@@ -263,7 +263,7 @@ int StateManager::msckfUpdate(std::shared_ptr<State> state, const ingvio_msckf_f
 {
     const int ldp = ingvio_ldp(state->_ctx);
     VecXd dx(ldp, 0.0);
-    std::vector<int> acc(opts.chi2_len > 0 ? 4096 : 4096, 0);
+    std::vector<int> acc(std::max(ingvio_f_max(state->_ctx), frame.n_feat), 0);      // the ABI writes f_max entries per filter
     int rows = 0;
     const int rc = ingvio_msckf_update(state->_ctx, state->_b, 1, &frame, &opts, dx.data(), acc.data(), nullptr, &rows);
     if (rc < 0) fatal(state, "msckfUpdate", rc);

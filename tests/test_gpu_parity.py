@@ -246,6 +246,43 @@ def test_full_n249_batch_vs_oracle(orc, method):
     ctx2.close()
 
 
+@pytest.mark.parametrize("stereo", [True, False])
+def test_full_size_ragged_random_anchor_vs_oracle(orc, stereo):
+    """Full-size frames (150 features, 11 clones, N=249) with RAGGED observation sets and RANDOM anchors (an anchor
+    need not be one of the observing clones), stereo and mono: whole frame pipeline vs the oracle."""
+    from ingvio_amd import capi, host, synth
+    nb = 4
+    ctx2 = capi.Context(batch=nb, n_max=256, c_max=11, f_max=150, m_max=64)
+    cases = []
+    for b in range(nb):
+        flt, step, frame, info = synth.build_case(lambda P, b=b: capi.DeviceCov(ctx2, b, P), host.imu_transition,
+                                                  seed=40 + b, stereo=stereo)
+        rng = np.random.default_rng(1000 + b)
+        F, C = 150, 11
+        mask = np.zeros(F, dtype=np.uint64); dof = np.zeros(F, dtype=np.int32)
+        for j in range(F):
+            k = int(rng.integers(5, C + 1))                       # 5..11 observing clones
+            obs = np.sort(rng.choice(C, size=k, replace=False))
+            mask[j] = np.uint64(sum(1 << int(o) for o in obs)); dof[j] = k - 1
+        frame = dict(frame); frame["obs_mask"] = mask; frame["dof"] = dof
+        frame["anchor"] = rng.integers(0, C, size=F).astype(np.int32)
+        cases.append((flt, step, frame, info))
+    priors = [ctx2.cov_get(b) for b in range(nb)]
+    ctx2.snapshot()
+    ctx2.frame_stage(0, [c[1] for c in cases], [c[2] for c in cases], cases[0][1]["sigma"], 1, 0.2, 0.2)
+    ctx2.frame_run(restore_prior=True)
+    dx, acc, rows = ctx2.frame_fetch()
+    for b in range(nb):
+        flt, step, frame, info = cases[b]
+        oc = orc.Cov(priors[b], ld=256)
+        dxo, acco, gamo, m = orc.frame_update(oc, step, frame, max_accept=0, compress_rule=1)
+        assert np.array_equal(acc[b, :150], acco) and 0 < acco.sum()
+        P = ctx2.cov_get(b)
+        assert ctx2.n(b) == 243 and rel_err(P, oc.P) < TIGHT and rel_err(dx[b, :249], dxo) < 1e-8
+        assert np.array_equal(P, P.T)
+    ctx2.close()
+
+
 def test_qr_compress(ctx):
     """K7 on an explicit H_large (the SPQR call sites): H_thin^T H_thin == H^T H, H_thin upper triangular;
     also on a rank-deficient matrix (Q9: rank n-6)."""
