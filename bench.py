@@ -136,9 +136,9 @@ def algorithmic_flops(F_used, F, C, N, k):
 # HBM bytes per launch of the 512-filter config-2 workload, from the committed rocprofv3 PMC passes
 # (profiles/r01_rocprofv3_pmc_hbm_traffic.csv: FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE calibrated x1 on the
 # pure copy k_restore); a static annotation, bench.py cannot collect PMC counters itself
-TRAFFIC_MIB = {"k_feat_gate3": (49.6 + 113.4) * 2 ** 20, "k_feat_gram2": (112.9 + 22.6) * 2 ** 20,
-               "k_info_update": (38.5 + 18.4) * 2 ** 20, "k_info_apply": (371.3 + 246.3) * 2 ** 20,
-               "k_propagate": (38.9 + 40.9) * 2 ** 20}
+TRAFFIC_MIB = {"k_feat_gate3": (46.2 + 113.4) * 2 ** 20, "k_feat_gram2": (113.5 + 23.1) * 2 ** 20,
+               "k_info_update": (38.5 + 18.4) * 2 ** 20, "k_info_apply": (244.6 + 239.6) * 2 ** 20,
+               "k_propagate": (47.5 + 58.3) * 2 ** 20}
 
 
 def algorithmic_bytes(N):

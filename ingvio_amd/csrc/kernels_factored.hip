@@ -405,6 +405,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 4))) vo
                 }
             }
         }
+        dbg_stamp(28);
         wave_sync();                              // blk is dead from here on: its LDS becomes the panel buffer
 #pragma unroll
         for (int k = 0; k < KP / 4; ++k) {
