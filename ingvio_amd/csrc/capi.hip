@@ -285,7 +285,11 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     } else c->st = (hipStream_t)desc->stream;
     const int B = desc->batch;
     c->ldp = (desc->n_max + 15) & ~15;
-    const int mcap = c->d.m_max > 6 * desc->c_max ? c->d.m_max : 6 * desc->c_max;
+    // the factored kernels run at the padded width of their window class (6 / 11 / 16 clones): size the row/column
+    // workspaces (M, the Pc copy) for the class, not for c_max itself
+    const int cls0 = msckf_cmax_class(desc->c_max);
+    const int cpad = cls0 > desc->c_max ? cls0 : desc->c_max;
+    const int mcap = c->d.m_max > 6 * cpad ? c->d.m_max : 6 * cpad;
     c->mld = (mcap + 15) & ~15;
     c->nc_cap = mcap;
     c->G = 512 / B; if (c->G > 16) c->G = 16; if (c->G < 1) c->G = 1;      // ~2 resident gram workgroups per CU

@@ -283,6 +283,48 @@ def test_full_size_ragged_random_anchor_vs_oracle(orc, stereo):
     ctx2.close()
 
 
+@pytest.mark.parametrize("C,stereo,method", [(16, True, "factored"), (16, False, "factored"), (6, True, "factored"),
+                                             (6, False, "factored"), (13, True, "factored"), (4, True, "factored"),
+                                             (13, True, "dense"), (16, False, "dense"), (4, False, "dense")])
+def test_window_size_classes_vs_oracle(orc, C, stereo, method):
+    """The kernels are instantiated for window classes 6 / 11 / 16 clones: run whole frames at the class maxima and
+    at in-between sizes (13 -> class 16, 4 -> class 6), ragged observations, vs the oracle."""
+    from ingvio_amd import capi, host, synth
+    nb, F = 3, 60
+    n_gnss, n_lm = 6, 10
+    N = 21 + n_gnss + 3 * n_lm + 6 * C
+    ctx2 = capi.Context(batch=nb, n_max=((N + 15) // 16) * 16, c_max=C, f_max=F, m_max=64)
+    ctx2.set_method(method)
+    cases = []
+    for b in range(nb):
+        flt, step, frame, info = synth.build_case(lambda P, b=b: capi.DeviceCov(ctx2, b, P), host.imu_transition,
+                                                  seed=70 + b, F=F, C=C, n_gnss=n_gnss, n_landmarks=n_lm, stereo=stereo)
+        rng = np.random.default_rng(2000 + b)
+        kmin = min(C, 5 if not stereo else 3)
+        mask = np.zeros(F, dtype=np.uint64); dof = np.zeros(F, dtype=np.int32)
+        for j in range(F):
+            k = int(rng.integers(kmin, C + 1))
+            obs = np.sort(rng.choice(C, size=k, replace=False))
+            mask[j] = np.uint64(sum(1 << int(o) for o in obs)); dof[j] = k - 1
+        frame = dict(frame); frame["obs_mask"] = mask; frame["dof"] = dof
+        frame["anchor"] = rng.integers(0, C, size=F).astype(np.int32)
+        cases.append((flt, step, frame, info))
+    ld = ctx2.ldp
+    priors = [ctx2.cov_get(b) for b in range(nb)]
+    ctx2.snapshot()
+    ctx2.frame_stage(0, [c[1] for c in cases], [c[2] for c in cases], cases[0][1]["sigma"], 1, 0.2, 0.2)
+    ctx2.frame_run(restore_prior=True)
+    dx, acc, rows = ctx2.frame_fetch()
+    for b in range(nb):
+        flt, step, frame, info = cases[b]
+        oc = orc.Cov(priors[b], ld=ld)
+        dxo, acco, gamo, m = orc.frame_update(oc, step, frame, max_accept=0, compress_rule=1)
+        assert np.array_equal(acc[b, :F], acco)
+        P = ctx2.cov_get(b)
+        assert P.shape == oc.P.shape and rel_err(P, oc.P) < TIGHT and rel_err(dx[b, :N], dxo) < 1e-8
+    ctx2.close()
+
+
 def test_qr_compress(ctx):
     """K7 on an explicit H_large (the SPQR call sites): H_thin^T H_thin == H^T H, H_thin upper triangular;
     also on a rank-deficient matrix (Q9: rank n-6)."""
