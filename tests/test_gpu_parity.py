@@ -325,6 +325,59 @@ def test_window_size_classes_vs_oracle(orc, C, stereo, method):
     ctx2.close()
 
 
+def test_consecutive_frames_without_restore(orc):
+    """Three frame steps in a row WITHOUT restoring the prior: the ping-pong halves alternate, so the fused
+    update+marginalise and the zero-copy clone columns run from either half, and the covariance evolves; the oracle
+    applies the same three frames sequentially."""
+    from ingvio_amd import capi, host, synth
+    nb, F, C = 3, 80, 11
+    ctx2 = capi.Context(batch=nb, n_max=256, c_max=C, f_max=F, m_max=64)
+    cases = []
+    for b in range(nb):
+        flt, step, frame, info = synth.build_case(lambda P, b=b: capi.DeviceCov(ctx2, b, P), host.imu_transition,
+                                                  seed=90 + b, F=F, C=C)
+        cases.append((flt, step, frame, info))
+    ocs = [orc.Cov(ctx2.cov_get(b), ld=256) for b in range(nb)]
+    ctx2.frame_stage(0, [c[1] for c in cases], [c[2] for c in cases], cases[0][1]["sigma"], 1, 0.2, 0.2)
+    for it in range(3):
+        ctx2.frame_run(restore_prior=False)
+        dx, acc, rows = ctx2.frame_fetch()
+        for b in range(nb):
+            dxo, acco, gamo, m = orc.frame_update(ocs[b], cases[b][1], cases[b][2], max_accept=0, compress_rule=1)
+            assert np.array_equal(acc[b, :F], acco), (it, b)
+            assert ctx2.n(b) == 243 and rel_err(ctx2.cov_get(b), ocs[b].P) < 1e-10, (it, b)
+            assert rel_err(dx[b, :249], dxo) < 1e-7
+    ctx2.close()
+
+
+def test_frame_without_marginalisation_in_batch(orc):
+    """One filter of the batch keeps its oldest clone (marg_idx = -1): it takes the in-place update path while its
+    neighbours take the fused out-of-place one."""
+    from ingvio_amd import capi, host, synth
+    nb, F, C = 3, 80, 11
+    ctx2 = capi.Context(batch=nb, n_max=256, c_max=C, f_max=F, m_max=64)
+    cases = []
+    for b in range(nb):
+        flt, step, frame, info = synth.build_case(lambda P, b=b: capi.DeviceCov(ctx2, b, P), host.imu_transition,
+                                                  seed=95 + b, F=F, C=C)
+        step = dict(step)
+        if b == 1:
+            step["marg_idx"] = -1
+        cases.append((flt, step, frame, info))
+    ocs = [orc.Cov(ctx2.cov_get(b), ld=256) for b in range(nb)]
+    ctx2.snapshot()
+    ctx2.frame_stage(0, [c[1] for c in cases], [c[2] for c in cases], cases[0][1]["sigma"], 1, 0.2, 0.2)
+    for it in range(2):                                   # twice: the second restore must be a full one here
+        ctx2.frame_run(restore_prior=True)
+    dx, acc, rows = ctx2.frame_fetch()
+    for b in range(nb):
+        dxo, acco, gamo, m = orc.frame_update(ocs[b], cases[b][1], cases[b][2], max_accept=0, compress_rule=1)
+        assert np.array_equal(acc[b, :F], acco)
+        assert ctx2.n(b) == (249 if b == 1 else 243)
+        assert rel_err(ctx2.cov_get(b), ocs[b].P) < TIGHT and rel_err(dx[b, :249], dxo) < 1e-8
+    ctx2.close()
+
+
 def test_qr_compress(ctx):
     """K7 on an explicit H_large (the SPQR call sites): H_thin^T H_thin == H^T H, H_thin upper triangular;
     also on a rank-deficient matrix (Q9: rank n-6)."""
