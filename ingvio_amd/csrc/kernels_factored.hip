@@ -1,18 +1,17 @@
-// kernels_factored.hip — the structure-exploiting MSCKF path (same posterior as the dense
-// K3..K11 path of kernels_msckf.hip / kernels_ekf.hip to FP64 rounding, ~7x fewer FLOPs).
+// kernels_factored.hip — the structure-exploiting MSCKF path (same posterior as the dense K3..K11 path of
+// kernels_msckf.hip / kernels_ekf.hip to FP64 rounding, at about a quarter of the FLOPs).
 //
 // Per feature the stacked Jacobian factors as  Hx = Gblk * D  (RemoveLostUpdate.cpp:474-501):
 //   Gblk = blockdiag(G_o), G_o = Pi~_o R_o^T  (rows-per-obs x 3; stack(G_o) is also Hf)
 //   D    = [3*nobs x 6C] sparse: row block o has [p_f]x at theta_o, -I at p_o, -[p_f]x at theta_anchor
 // so, with V the left-nullspace basis of Hf (H_j = V^T Hx, r_j = V^T r):
-//   K5   S_j = V^T (Gblk Su Gblk^T + s^2 I) V,  Su = D Pcc D^T  (3nobs x 3nobs), and by the
-//        projector identity  V (V^T S V)^-1 V^T = S^-1 - S^-1 Hf (Hf^T S^-1 Hf)^-1 Hf^T S^-1 :
-//        gamma = r^T S^-1 r - b^T (Hf^T S^-1 Hf)^-1 b,  b = Hf^T S^-1 r   (one bordered elimination)
-//   K7   H_j^T H_j = D^T W D,  W = Gblk^T (I - U U^T) Gblk,  U = orthonormal basis of range(Hf);
-//        the stacked-QR factor R only enters the update through A = R^T R = sum_j H_j^T H_j and
-//        z-term b = sum_j H_j^T r_j, accumulated here as 6x6 slot-pair blocks in registers.
-//   K8-K11  K H = Pc (A Pcc + s^2 I)^-1 A  (push-through identity; A may be singular, rank n-6):
-//        P <- P - (Pc M) Pc^T,  dx = Pc (A Pcc + s^2 I)^-1 b,  Pc = P[:, clone cols].
+//   K5   k_feat_gate3: S_j = V^T (Gblk Su Gblk^T + s^2 I) V,  Su = D Pcc D^T; projector identity
+//        V (V^T S V)^-1 V^T = S^-1 - S^-1 Hf (Hf^T S^-1 Hf)^-1 Hf^T S^-1  and Woodbury down to the SPD matrix
+//        K = Su + s^2 N^-1 of dimension 3 nobs (N = blockdiag(G_o^T G_o)); one bordered blocked LDL^T per feature.
+//   K7   k_feat_gram2: the stacked-QR factor R only enters the update through A = R^T R = sum_j H_j^T H_j and
+//        b = sum_j H_j^T r_j;  H_j^T H_j = sum_o D_o^T N_o D_o - B^T Ns^-1 B  (block-sparse minus rank 3, MFMA GEMM).
+//   K8-K11  k_info_update / k_info_apply:  K H = Pc (A Pcc + s^2 I)^-1 A  (push-through identity; A may be singular,
+//        rank n-6):  P <- P - (Pc M) Pc^T,  dx = Pc (A Pcc + s^2 I)^-1 b,  Pc = P[:, clone cols].
 // gfx950 only.
 #include <algorithm>
 #include "feat_build.h"
@@ -37,12 +36,6 @@ __device__ __forceinline__ void mul33(const double A[9], const double B[9], doub
         for (int k = 0; k < 3; ++k) C[3 * i + k] = A[3 * i] * B[k] + A[3 * i + 1] * B[3 + k] + A[3 * i + 2] * B[6 + k];
 }
 
-__device__ __forceinline__ void cross3(double ax, double ay, double az, const double v[3], double out[3])
-{
-    out[0] = ay * v[2] - az * v[1];
-    out[1] = az * v[0] - ax * v[2];
-    out[2] = ax * v[1] - ay * v[0];
-}
 // (M X)[r][q] and (X^T M)[q][c] for X = skew(p), M row-major 3x3
 __device__ __forceinline__ void mulX(const double M[9], double x, double y, double z, double out[9])
 {
@@ -93,7 +86,6 @@ __host__ __device__ constexpr int rec_size(int cmax) { return REC_HDR + REC_OBS 
 template <int CMAX, bool STEREO>
 struct Gate3Shared {
     static constexpr int D = STEREO ? 3 : 2;
-    static constexpr int DIM = 4 + D * CMAX;
     static constexpr int NPAIR = CMAX * (CMAX + 1) / 2;
     FeatShared<CMAX, STEREO, true> f;
     int cna[CMAX];
@@ -410,7 +402,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 4))) vo
 #pragma unroll
         for (int k = 0; k < KP / 4; ++k) {
             if (k < npan) {
-                constexpr int dummy_ = 0; (void)dummy_;
                 const int tj0 = k >> 2, cb = 4 * (k & 3);
                 if (l15 >= cb && l15 < cb + 4) {
 #pragma unroll
