@@ -147,7 +147,7 @@ def algorithmic_bytes(N):
             "restore": 2.0 * N * N * 8}
 
 
-def cpu_baseline(ctx, steps, frames, n_prior, target_s=12.0):
+def cpu_baseline(ctx, steps, frames, n_prior, target_s=10.0):
     """Times the oracle (C port of the reference algorithm, OpenMP one-filter-per-thread) on a
     bounded sample of the same workload, and cross-checks the GPU posterior on that sample.
     Only the C call is inside the timed loop (structs are prepared once)."""
@@ -161,14 +161,27 @@ def cpu_baseline(ctx, steps, frames, n_prior, target_s=12.0):
         P0[b, :n_prior, :n_prior] = ctx.cov_get(b)
     n0 = np.full(S, n_prior, dtype=np.int32)
     prep = orc.PreparedBatch(steps[:S], frames[:S], max_accept=0, compress_rule=1)
-    prep.run(P0.copy(), n0.copy(), ld, threads=cores)                       # warm-up
-    rounds, el = 0, 0.0
-    while el < target_s and rounds < 500:
-        P1, n1 = P0.copy(), n0.copy()
-        t0 = time.perf_counter()
-        dx1, acc1 = prep.run(P1, n1, ld, threads=cores)
-        el += time.perf_counter() - t0
-        rounds += 1
+    # The container may be CPU-throttled (cgroup quota) well below os.cpu_count(): more threads than the quota makes the
+    # baseline SLOWER, so probe a few thread counts and keep the best one (the thread count used is reported as `cores`).
+    def rate(th, min_s):
+        prep.run(P0.copy(), n0.copy(), ld, threads=th)
+        r, e = 0, 0.0
+        last = None
+        while e < min_s and r < 500:
+            Pw, nw = P0.copy(), n0.copy()
+            t0 = time.perf_counter()
+            last = prep.run(Pw, nw, ld, threads=th)
+            e += time.perf_counter() - t0
+            r += 1
+        return r * S / e, r, (Pw, nw) + tuple(last)
+    probes = {}
+    for th in sorted({cores, min(cores, 64), min(cores, 32), min(cores, 16), min(cores, 8)}, reverse=True):
+        probes[th] = rate(th, 1.5)[0]
+    best = max(probes, key=probes.get)
+    val, rounds, (P1, n1, dx1, acc1) = rate(best, target_s)
+    el = rounds * S / val
+    host_cpus = cores
+    cores = best
     # 1-thread figure on a few frames (the reference itself is single-threaded, IngvioNode.cpp:36)
     s1 = min(S, 4)
     prep1 = orc.PreparedBatch(steps[:s1], frames[:s1], max_accept=0, compress_rule=1)
@@ -188,9 +201,10 @@ def cpu_baseline(ctx, steps, frames, n_prior, target_s=12.0):
     return dict(value=rounds * S / el, unit="updates/s", cores=cores, kind="port",
                 as_written_cap20_ms_per_update_1thread=one_aw * 1e3,
                 sample="%d rounds x %d of the bench's own frames (150 feats x 11 clones, N=249, top_n compression), "
-                       "oracle/ingvio_oracle.c, OpenMP one filter per thread on %d threads; "
-                       "single thread (the reference is single-threaded): %.1f ms/update = %.1f updates/s"
-                       % (rounds, S, cores, one * 1e3, 1.0 / one),
+                       "oracle/ingvio_oracle.c, OpenMP one filter per thread on %d threads (best of the probed thread counts "
+                       "%s on a host reporting %d CPUs); single thread (the reference is single-threaded): "
+                       "%.1f ms/update = %.1f updates/s"
+                       % (rounds, S, cores, {k: round(v) for k, v in sorted(probes.items())}, host_cpus, one * 1e3, 1.0 / one),
                 ms_per_update_1thread=one * 1e3, updates_per_s_1thread=1.0 / one), (P1, n1, dx1, acc1, S)
 
 
