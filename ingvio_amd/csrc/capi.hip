@@ -55,6 +55,7 @@ struct ingvio_ctx {
     double *d_gamma, *d_Rpart, *d_H, *d_res, *d_noise, *d_noise1, *d_Y, *d_Yc, *d_dx, *d_rec;
     int method;                    // 0 dense TSQR path, 1 factored (information-form) path
     int *d_accept, *d_used, *d_chunk_used, *d_colmap, *d_m, *d_nc, *d_status, *d_pcbase;
+    double *d_big_sg, *d_big_wk;        // large-window workspaces (c_max > 16)
     // staged frame state
     int st_k, st_stereo, st_enable_gnss, st_fmax_used;
     double st_sigma[4], st_scb, st_srw;
@@ -218,6 +219,8 @@ int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int s
     L.G = c->G; L.rstride = c->rstride; L.noise = c->d_noise + b0;
     L.T = c->d_Y + (size_t)b0 * c->ystride; L.Pc = c->d_Yc + (size_t)b0 * c->ystride; L.ystride = c->ystride;
     L.dx = c->d_dx; L.m_out = c->d_m + b0; L.nc_out = c->d_nc + b0; L.status = c->d_status;
+    L.big_sg = c->d_big_sg ? c->d_big_sg + (size_t)b0 * bigwin_sg_doubles(c->G) : nullptr;
+    L.big_wk = c->d_big_wk ? c->d_big_wk + (size_t)b0 * bigwin_wk_doubles() : nullptr;
     { ProfScope p(c, PF_GATE2); L.stage = 0; if (launch_factored(L, c->st)) return INGVIO_E_UNSUPPORTED; }
     { ProfScope p(c, PF_GRAM); L.stage = 1; launch_factored(L, c->st); }
     L.mstride = c->ystride; L.n_cap = c->d.n_max;
@@ -270,7 +273,7 @@ extern "C" {
 int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
 {
     if (!desc || !out || desc->batch < 1 || desc->n_max < 21 || desc->c_max < 1 || desc->f_max < 1) return INGVIO_E_ARG;
-    if (msckf_cmax_class(desc->c_max) < 0 || desc->c_max > 64) return INGVIO_E_CAPACITY;
+    if (desc->c_max > bigwin_cmax()) return INGVIO_E_CAPACITY;      // 17..36 clones: factored path only (kernels_bigwin.hip)
     if (desc->m_max > 128) return INGVIO_E_CAPACITY;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= desc->device) return INGVIO_E_HIP;
@@ -287,7 +290,7 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     c->ldp = (desc->n_max + 15) & ~15;
     // the factored kernels run at the padded width of their window class (6 / 11 / 16 clones): size the row/column
     // workspaces (M, the Pc copy) for the class, not for c_max itself
-    const int cls0 = msckf_cmax_class(desc->c_max);
+    const int cls0 = desc->c_max > 16 ? bigwin_cmax() : msckf_cmax_class(desc->c_max);
     const int cpad = cls0 > desc->c_max ? cls0 : desc->c_max;
     const int mcap = c->d.m_max > 6 * cpad ? c->d.m_max : 6 * cpad;
     c->mld = (mcap + 15) & ~15;
@@ -299,7 +302,7 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     c->rstride = ncm * (ncm + 1);
     c->hstride = c->mld * c->nc_cap;
     c->cstride = c->nc_cap;
-    c->ystride = c->ldp * (c->mld + 4);
+    c->ystride = std::max(c->ldp * (c->mld + 4), c->mld * (c->mld + 1));      // Pc copy (ldp x MP) or M | t (MP x MP + MP)
     c->has_snap = false; c->staged = false; c->prof = false;
     {
         const char* e = getenv("INGVIO_MSCKF_METHOD");
@@ -325,6 +328,10 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     rc |= dalloc(c, &c->d_Rpart, (size_t)B * c->G * c->rstride); rc |= dalloc(c, &c->d_chunk_used, (size_t)B * c->G);
     rc |= dalloc(c, &c->d_H, (size_t)B * c->hstride); rc |= dalloc(c, &c->d_res, (size_t)B * c->mld);
     rc |= dalloc(c, &c->d_colmap, (size_t)B * c->cstride); rc |= dalloc(c, &c->d_m, B); rc |= dalloc(c, &c->d_nc, B); rc |= dalloc(c, &c->d_pcbase, B);
+    c->d_big_sg = nullptr; c->d_big_wk = nullptr;
+    if (desc->c_max > 16) {
+        rc |= dalloc(c, &c->d_big_sg, (size_t)B * bigwin_sg_doubles(c->G)); rc |= dalloc(c, &c->d_big_wk, (size_t)B * bigwin_wk_doubles());
+    }
     rc |= dalloc(c, &c->d_noise, B); rc |= dalloc(c, &c->d_noise1, (size_t)c->mld * c->mld);
     rc |= dalloc(c, &c->d_Y, (size_t)B * c->ystride); rc |= dalloc(c, &c->d_Yc, (size_t)B * c->ystride);
     rc |= dalloc(c, &c->d_dx, (size_t)B * c->ldp);
@@ -342,7 +349,7 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
     void* ptrs[] = { c->Pbase, c->Psnap, c->d_cur, c->d_n, c->d_n_snap, c->d_Phi, c->d_G, c->d_dt, c->d_R, c->d_blk, c->d_gnss,
                      c->d_idx, c->d_clone_idx, c->d_nclones, c->d_nfeat, c->d_anchor, c->d_dof, c->d_clone_R, c->d_clone_p,
                      c->d_pf, c->d_uv, c->d_chi2, c->d_mask, c->d_gamma, c->d_accept, c->d_used, c->d_Rpart, c->d_chunk_used,
-                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase };
+                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (c->own_stream) hipStreamDestroy(c->st);

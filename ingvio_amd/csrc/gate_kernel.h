@@ -1,0 +1,468 @@
+// gate_kernel.h — shared device code of the factored MSCKF path: small 3x3 helpers, the per-feature record layout and
+// the body of the gate kernel (K3 + K5).  Included by kernels_factored.hip (window classes 6 / 11 / 16, tuned for
+// occupancy) and kernels_bigwin.hip (windows up to 36 clones, one wave per SIMD).  gfx950 only.
+#pragma once
+#include "feat_build.h"
+
+typedef double double4_f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void inv3sym(const double N[9], double out[9])
+{
+    const double a = N[0], b = N[1], c = N[2], d = N[4], e = N[5], f = N[8];
+    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+    const double det = a * c00 + b * c01 + c * c02, id = fast_rcp(det);
+    out[0] = c00 * id; out[1] = c01 * id; out[2] = c02 * id;
+    out[3] = out[1]; out[4] = (a * f - c * c) * id; out[5] = (b * c - a * e) * id;
+    out[6] = out[2]; out[7] = out[5]; out[8] = (a * d - b * b) * id;
+}
+__device__ __forceinline__ void mul33(const double A[9], const double B[9], double C[9])
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) C[3 * i + k] = A[3 * i] * B[k] + A[3 * i + 1] * B[3 + k] + A[3 * i + 2] * B[6 + k];
+}
+
+// (M X)[r][q] and (X^T M)[q][c] for X = skew(p), M row-major 3x3
+__device__ __forceinline__ void mulX(const double M[9], double x, double y, double z, double out[9])
+{
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        out[3 * r + 0] = M[3 * r + 1] * z - M[3 * r + 2] * y;
+        out[3 * r + 1] = -M[3 * r + 0] * z + M[3 * r + 2] * x;
+        out[3 * r + 2] = M[3 * r + 0] * y - M[3 * r + 1] * x;
+    }
+}
+__device__ __forceinline__ void mulXt(const double M[9], double x, double y, double z, double out[9])
+{
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        out[0 + c] = z * M[3 + c] - y * M[6 + c];
+        out[3 + c] = -z * M[0 + c] + x * M[6 + c];
+        out[6 + c] = y * M[0 + c] - x * M[3 + c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-feature record written by the gate kernel and consumed by k_feat_gram:
+//   {nobs, anchor slot, p_f(3), window-slot mask, Ns^-1 (9), hs (3), Nsa (9)} then per observation (ascending slot);
+//   Ns = sum_o N_o, hs = sum_o h_o, Nsa = sum over the observations whose clone is not the anchor {slot, cna, pfl, N_o = G_o^T G_o (9), h_o = G_o^T r_o (3)}
+// ---------------------------------------------------------------------------------------------
+#define REC_HDR 27
+#define REC_OBS 15          // slot, cna, pfl, N(9), h(3)
+
+__host__ __device__ constexpr int rec_size(int cmax) { return REC_HDR + REC_OBS * cmax; }
+
+// ---------------------------------------------------------------------------------------------
+// K3 + K5, one WAVE per (feature, filter): "column-owner" LDL^T in the reduced observation space.
+//
+// Stereo (G_o is 4x3, full column rank): by Woodbury on S = s^2 I + Gblk Su Gblk^T,
+//     S^-1 = s^-2 (I - Gblk N^-1 Gblk^T) + Gblk N^-1 K^-1 N^-1 Gblk^T,   K = Su + s^2 N^-1,  N = blockdiag(G_o^T G_o)
+// so  Y^T S^-1 Y = W^T K^-1 W + s^-2 |r_perp|^2 e0 e0^T  with  W = N^-1 Gblk^T [r | Hf] = [u | 1],
+//     u_o = N_o^-1 G_o^T r_o,  |r_perp|^2 = sum_o (|r_o|^2 - h_o^T u_o)   (Hf = Gblk 1, so its residual part is 0):
+// a (3 nobs)-dimensional SPD system instead of the (4 nobs)-dimensional S, and no G_o products on Su.
+// Mono (G_o is 2x3): K = s^2 I + Gblk Su Gblk^T itself (2 nobs), W = [r | Hf].
+//
+// Lane j holds column j of the bordered matrix [[0, W^T], [W, K]] (border FIRST: indices 0..3) in
+// registers; pivot p broadcasts column p with v_readlane (lane index and register index are compile-time
+// constants after unrolling), every lane updates its own column: no LDS traffic, no barriers, the wave
+// runs D*nobs pivots back to back and leaves -W^T K^-1 W in the 4x4 border.
+// The 3x3 (2x2) blocks of K are built one observation pair per lane from nine 3x3 blocks of P
+// and exchanged once through LDS.  Also writes the feature's compact record for k_feat_gram.
+// ---------------------------------------------------------------------------------------------
+template <int CMAX, bool STEREO>
+struct Gate3Shared {
+    static constexpr int D = STEREO ? 3 : 2;
+    static constexpr int NPAIR = CMAX * (CMAX + 1) / 2;
+    FeatShared<CMAX, STEREO, true> f;
+    int cna[CMAX];
+    int pfl[CMAX];
+    double recbuf[REC_HDR + REC_OBS * CMAX];      // the feature record, staged: stored once, coalesced, at the very end
+    double Ninv[CMAX][9];
+    double u[CMAX][3];
+    double rperp[CMAX];
+    static constexpr int NTL = (D * CMAX + 12 + 15) / 16;      // 16x16 tile rows of the bordered matrix (MFMA back end)
+    static constexpr int KP = 16 * NTL - 12;                   // K padded with unit pivots to KP, border rows KP..KP+3
+    union alignas(16) {
+        double blk[NPAIR][D * D];     // pair blocks
+        double nh[CMAX * 12 + 24];    // before they are built: N_o | h_o per observation and the record's 21 sums
+        double pan[16 * NTL][4];      // after the tiles are built: panel exchange of the MFMA elimination
+        double bz[16];                // finally: the 4x4 border block
+    };
+    double Rb[CMAX][9];               // per-observation part of Su: R_o = cn X P(th_o,th_a) X^T + pl P(p_o,th_a) X
+    double Qb[9];                     // X P(th_a,th_a) X^T
+};
+
+__device__ __forceinline__ void wave_sync()      // LDS hand-over between the lanes of ONE wave
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int CMAX, bool STEREO>
+__device__ __forceinline__ void gate3_body(
+    CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out,
+    int* __restrict__ accept_out, double* __restrict__ rec_out)
+{
+    using Cfg = FeatCfg<CMAX, STEREO>;
+    using SH = Gate3Shared<CMAX, STEREO>;
+    constexpr int RPO = Cfg::RPO, D = SH::D;
+    __shared__ SH sh;
+    // XCD-aware mapping: consecutive workgroups go round-robin to the 8 XCDs, so give every XCD whole filters
+    // (a filter's P blocks then live in one L2 instead of eight)
+    const int w = blockIdx.x, xcd = w & 7, t = w >> 3;
+    const int bl = xcd + 8 * (t / fmax_used), j = t % fmax_used;
+    if (bl >= nb) return;
+    const int b = b0 + bl, tid = threadIdx.x;
+    if (j >= fv.n_feat[b]) return;
+    const int C = fv.n_clones[b], ld = cv.ldp;
+    const double* P = cov_ptr(cv, b);
+    const size_t oidx = (size_t)b * fv.fmax + j;
+    const int a = fv.anchor[oidx];
+    const double* pf = fv.pf + oidx * 3;
+    const double px = pf[0], py = pf[1], pz = pf[2];
+    dbg_stamp(24);
+    load_gidx<CMAX, STEREO, true>(fv, b, C, sh.f);
+    const int rows = feat_phase1<CMAX, STEREO, true>(fv, op, b, j, C, sh.f);
+    const int nobs = sh.f.nobs, rho = rows - 3;
+    double* const rec = sh.recbuf;                // global stores wait in vmcnt with the loads (gfx9): keep them off the critical path
+    double* const rec_g = rec_out + oidx * rec_size(CMAX);
+    if (rho <= 0) {
+        if (tid == 0) { gamma_out[oidx] = __builtin_nan(""); accept_out[oidx] = 0; rec_g[0] = 0.0; }
+        return;
+    }
+    dbg_stamp(25);
+    double* const Nh = sh.nh;
+    double* const sums = Nh + CMAX * 12;
+    if (tid < nobs) {
+        const int so = sh.f.slot[tid];
+        const bool cn = so != a, pl = !(op.selected_variant && so == a);
+        sh.cna[tid] = cn;
+        sh.pfl[tid] = pl;
+        double* ro = rec + REC_HDR + REC_OBS * tid;
+        ro[0] = so; ro[1] = cn ? 1.0 : 0.0; ro[2] = pl ? 1.0 : 0.0;
+        double N[9], h[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+#pragma unroll
+            for (int m2 = 0; m2 < 3; ++m2) {
+                double sN = 0.0;
+#pragma unroll
+                for (int q = 0; q < RPO; ++q) sN += sh.f.G[tid][q][m] * sh.f.G[tid][q][m2];
+                N[3 * m + m2] = sN;
+                ro[3 + 3 * m + m2] = sN;
+            }
+            double hh = 0.0;
+#pragma unroll
+            for (int q = 0; q < RPO; ++q) hh += sh.f.G[tid][q][m] * sh.f.res[tid][q];
+            h[m] = hh;
+            ro[12 + m] = hh;
+            Nh[tid * 12 + 9 + m] = hh;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Nh[tid * 12 + i] = N[i];
+        if (STEREO) {
+            double Ni[9];
+            inv3sym(N, Ni);
+            double rr = 0.0;
+#pragma unroll
+            for (int q = 0; q < RPO; ++q) rr += sh.f.res[tid][q] * sh.f.res[tid][q];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const double um = Ni[3 * m] * h[0] + Ni[3 * m + 1] * h[1] + Ni[3 * m + 2] * h[2];
+                sh.u[tid][m] = um;
+                rr -= h[m] * um;
+#pragma unroll
+                for (int m2 = 0; m2 < 3; ++m2) sh.Ninv[tid][3 * m + m2] = Ni[3 * m + m2];
+            }
+            sh.rperp[tid] = rr;
+        }
+    }
+    if (tid == 0) {
+        unsigned long long sm = 0ULL;
+        for (int o = 0; o < nobs; ++o) sm |= 1ULL << sh.f.slot[o];
+        rec[0] = nobs; rec[1] = a; rec[2] = px; rec[3] = py; rec[4] = pz; rec[5] = (double)sm;
+    }
+    __syncthreads();
+    // sums for k_feat_gram2 (this kernel is VALU-bound, the gram kernel latency-bound: the reduction is cheaper here)
+    if (tid < 21) {
+        const int anch = tid >= 12, comp = anch ? tid - 12 : tid;
+        double t[CMAX];
+#pragma unroll
+        for (int o = 0; o < CMAX; ++o) t[o] = (o < nobs && (!anch || sh.cna[o])) ? Nh[o * 12 + comp] : 0.0;      // all loads in flight
+        double sacc = 0.0;
+#pragma unroll
+        for (int o = 0; o < CMAX; ++o) sacc += t[o];
+        sums[tid] = sacc;
+    }
+    __syncthreads();
+    if (tid < 21) {
+        double v = sums[tid];
+        if (tid < 9) { double Nsi[9]; inv3sym(sums, Nsi); v = Nsi[tid]; }
+        rec[6 + tid] = v;
+    }
+    __syncthreads();
+    dbg_stamp(26);
+    // ---- Su = D Pcc D^T in 3x3 blocks.  With U_o = P(th_o, th_a), V_o = P(p_o, th_a):
+    //        Su[o][o'] = T_oo' - cn' R_o - cn R_o'^T + cn cn' Q
+    //        T_oo' = cn cn' X P(th_o,th_o') X^T + cn pl' X^T P(th_o,p_o') + pl cn' P(p_o,th_o') X + pl pl' P(p_o,p_o')
+    //        R_o = cn X U_o X^T + pl V_o X   (per observation),   Q = X P(th_a,th_a) X^T   (per feature)
+    //      so a pair needs 4 blocks of P instead of 9.  Pairs with the anchor's own observation (cn' = 0) only keep the
+    //      p-column terms; they are built in the per-observation pass, which leaves nobs-1 choose 2 (+diag) <= 55
+    //      generic pairs: ONE round of the wave for an 11-clone window instead of two.
+    const int ga = sh.f.gidx[a];
+    auto ldblk = [&](int r0, int c0, double M[9]) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) M[3 * m + q] = P[(r0 + m) + (size_t)(c0 + q) * ld];
+    };
+    auto finish_pair = [&](int o, int o2, double Su[9]) {        // o >= o2: K block (stereo: + s^2 N^-1 on the diagonal)
+        const int q = o * (o + 1) / 2 + o2;
+        if (STEREO) {
+            if (o == o2) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Su[i] += op.var * sh.Ninv[o][i];
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) sh.blk[q][i] = Su[i];
+        } else {
+            double GS[2][3];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int m2 = 0; m2 < 3; ++m2)
+                    GS[r][m2] = sh.f.G[o][r][0] * Su[m2] + sh.f.G[o][r][1] * Su[3 + m2] + sh.f.G[o][r][2] * Su[6 + m2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    double v = GS[r][0] * sh.f.G[o2][r2][0] + GS[r][1] * sh.f.G[o2][r2][1] + GS[r][2] * sh.f.G[o2][r2][2];
+                    if (o == o2 && r == r2) v += op.var;
+                    sh.blk[q][(D * r + r2) % (D * D)] = v;
+                }
+        }
+    };
+    const unsigned long long amask = __ballot(tid < nobs && sh.f.slot[tid < nobs ? tid : 0] == a);
+    const int oa = amask ? __ffsll((long long)amask) - 1 : -1;          // the anchor clone's own observation, if any
+    if (tid < nobs) {
+        const int o = tid, gc = sh.f.gidx[sh.f.slot[o]];
+        const double cn = sh.cna[o] ? 1.0 : 0.0, pl = sh.pfl[o] ? 1.0 : 0.0;
+        double U[9], V[9], Paa[9], T1[9], T2[9];
+        ldblk(gc, ga, U);
+        ldblk(gc + 3, ga, V);
+        ldblk(ga, ga, Paa);
+        double B1[9], B2[9], Bp[9];
+        if (oa >= 0) { ldblk(gc, ga + 3, B1); ldblk(ga, ga + 3, B2); ldblk(gc + 3, ga + 3, Bp); }
+        mulXt(U, px, py, pz, T1);
+        mulX(T1, px, py, pz, T2);                 // X U X^T
+        mulX(V, px, py, pz, T1);                  // V X
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sh.Rb[o][i] = cn * T2[i] + pl * T1[i];
+        mulXt(Paa, px, py, pz, T1);
+        mulX(T1, px, py, pz, T2);
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) sh.Qb[i] = T2[i];
+        }
+        if (oa >= 0) {                            // pair (o, anchor obs): cn' = 0
+            const double pl2 = sh.pfl[oa] ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) B1[i] -= B2[i];
+            mulXt(B1, px, py, pz, T1);            // X^T (P(th_o,p_a) - P(th_a,p_a))
+            double Su[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Su[i] = cn * pl2 * T1[i] + pl * pl2 * Bp[i];
+            if (o >= oa) finish_pair(o, oa, Su);
+            else {
+                double St[9];
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) St[3 * m + q] = Su[3 * q + m];
+                finish_pair(oa, o, St);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int nred = oa >= 0 ? nobs - 1 : nobs, npair = nred * (nred + 1) / 2;
+        for (int q = tid; q < npair; q += WAVE) {
+            int i = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
+            while ((i + 1) * (i + 2) / 2 <= q) ++i;
+            while (i * (i + 1) / 2 > q) --i;
+            const int i2 = q - i * (i + 1) / 2;
+            const int o = i + ((oa >= 0 && i >= oa) ? 1 : 0), o2 = i2 + ((oa >= 0 && i2 >= oa) ? 1 : 0);
+            const int gc = sh.f.gidx[sh.f.slot[o]], gc2 = sh.f.gidx[sh.f.slot[o2]];
+            const double cn = sh.cna[o] ? 1.0 : 0.0, cn2 = sh.cna[o2] ? 1.0 : 0.0;
+            const double pl = sh.pfl[o] ? 1.0 : 0.0, pl2 = sh.pfl[o2] ? 1.0 : 0.0;
+            double Att[9], Atp[9], Apt[9], App[9], T1[9], T2[9], Su[9];
+            ldblk(gc, gc2, Att);
+            ldblk(gc, gc2 + 3, Atp);
+            ldblk(gc + 3, gc2, Apt);
+            ldblk(gc + 3, gc2 + 3, App);
+            mulXt(Att, px, py, pz, T1);
+            mulX(T1, px, py, pz, T2);             // X Ptt' X^T
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Su[k] = cn * cn2 * (T2[k] + sh.Qb[k]) + pl * pl2 * App[k];
+            mulXt(Atp, px, py, pz, T1);
+            mulX(Apt, px, py, pz, T2);
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    Su[3 * m + k] += cn * pl2 * T1[3 * m + k] + pl * cn2 * T2[3 * m + k] - cn2 * sh.Rb[o][3 * m + k] - cn * sh.Rb[o2][3 * k + m];
+            finish_pair(o, o2, Su);
+        }
+    }
+    __syncthreads();
+    dbg_stamp(27);
+    {
+        // ---- blocked LDL^T on the matrix cores --------------------------------------------------------
+        // The bordered matrix (K padded with unit pivots to KP rows, then the 4 rows of W^T) is held as 16x16
+        // lower tiles in the MFMA C/D layout: lane (kq = lane>>4, l15 = lane&15), register r of tile (ti,tj)
+        // holds element (16 ti + kq + 4r, 16 tj + l15).  A panel of 4 pivots: its columns go through LDS once
+        // ([row][4] layout), every lane reads the 4x4 diagonal block (uniform) and the 4 panel entries of "its"
+        // rows, forms X = R L^-T for them and feeds X (A operand) and -X D^-1 (B operand) to one
+        // v_mfma_f64_16x16x4 per trailing tile: no per-element broadcasts at all.
+        constexpr int NTL = SH::NTL, KP = SH::KP, NLT = NTL * (NTL + 1) / 2;
+        const int np = D * nobs, npan = (np + 3) >> 2;
+        const int kq = tid >> 4, l15 = tid & 15;
+        // Tile fill, branch-free: one (clamped) LDS read + selects per element.  Row classes are compile-time:
+        // i = 16 ti + kq + 4 r is a border row exactly for (ti, r) = (NTL-1, 1) (then i - KP = kq), rows past the
+        // border (ti = NTL-1, r >= 2) are zero; whether a K row/column is real (< np) or a unit pad is a lane select.
+        double4_f T[NLT];
+        int jo[NTL], jc[NTL];
+        bool jreal[NTL];
+#pragma unroll
+        for (int tj = 0; tj < NTL; ++tj) {
+            const int j = 16 * tj + l15;
+            jreal[tj] = j < np;
+            const int jj = jreal[tj] ? j : 0;
+            jo[tj] = jj / D; jc[tj] = jj - D * jo[tj];
+        }
+#pragma unroll
+        for (int ti = 0; ti < NTL; ++ti) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ti + kq + 4 * r;
+                if (ti == NTL - 1 && r >= 2) {
+#pragma unroll
+                    for (int tj = 0; tj <= ti; ++tj) T[ti * (ti + 1) / 2 + tj][r] = 0.0;
+                } else if (ti == NTL - 1 && r == 1) {                 // border row kq: W[j][kq]
+#pragma unroll
+                    for (int tj = 0; tj <= ti; ++tj) {
+                        double v;
+                        if (STEREO) {
+                            const double uv = sh.u[jo[tj]][jc[tj]];
+                            v = kq == 0 ? uv : (kq - 1 == jc[tj] ? 1.0 : 0.0);
+                        } else {
+                            const double rv = sh.f.res[jo[tj]][jc[tj]], gv = sh.f.G[jo[tj]][jc[tj]][(kq + 2) % 3];
+                            v = kq == 0 ? rv : gv;
+                        }
+                        T[ti * (ti + 1) / 2 + tj][r] = jreal[tj] ? v : 0.0;
+                    }
+                } else {
+                    const bool ireal = i < np;
+                    const int ii = ireal ? i : 0, io = ii / D, ic = ii - D * io;
+#pragma unroll
+                    for (int tj = 0; tj <= ti; ++tj) {
+                        const int o2 = jo[tj], c2 = jc[tj];
+                        const bool low = io >= o2;
+                        const int q = low ? io * (io + 1) / 2 + o2 : o2 * (o2 + 1) / 2 + io;
+                        const double bv = sh.blk[q][low ? D * ic + c2 : D * c2 + ic];
+                        const double idv = (i == 16 * tj + l15) ? 1.0 : 0.0;      // unit pivots on the padding rows
+                        T[ti * (ti + 1) / 2 + tj][r] = (ireal && jreal[tj]) ? bv : ((!ireal && !jreal[tj]) ? idv : 0.0);
+                    }
+                }
+            }
+        }
+        dbg_stamp(28);
+        wave_sync();                              // blk is dead from here on: its LDS becomes the panel buffer
+#pragma unroll
+        for (int k = 0; k < KP / 4; ++k) {
+            if (k < npan) {
+                const int tj0 = k >> 2, cb = 4 * (k & 3);
+                if (l15 >= cb && l15 < cb + 4) {
+#pragma unroll
+                    for (int ti = tj0; ti < NTL; ++ti)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sh.pan[16 * ti + kq + 4 * r][l15 - cb] = T[ti * (ti + 1) / 2 + tj0][r];
+                }
+                wave_sync();
+                double a[4][4];
+#pragma unroll
+                for (int ra = 0; ra < 4; ++ra) {
+                    const double2* pr = reinterpret_cast<const double2*>(sh.pan[4 * k + ra]);
+                    const double2 u0 = pr[0], u1 = pr[1];
+                    a[ra][0] = u0.x; a[ra][1] = u0.y; a[ra][2] = u1.x; a[ra][3] = u1.y;
+                }
+                double m[NTL][4];
+#pragma unroll
+                for (int t = tj0; t < NTL; ++t) {
+                    const double2* pr = reinterpret_cast<const double2*>(sh.pan[16 * t + l15]);
+                    const double2 u0 = pr[0], u1 = pr[1];
+                    m[t][0] = u0.x; m[t][1] = u0.y; m[t][2] = u1.x; m[t][3] = u1.y;
+                }
+                // 4x4 LDL^T of the diagonal block (every lane, uniform data)
+                const double r0 = fast_rcp(a[0][0]);
+                const double l10 = a[1][0] * r0, l20 = a[2][0] * r0, l30 = a[3][0] * r0;
+                const double r1 = fast_rcp(a[1][1] - l10 * a[1][0]);
+                const double t21 = a[2][1] - l20 * a[1][0], t31 = a[3][1] - l30 * a[1][0];
+                const double l21 = t21 * r1, l31 = t31 * r1;
+                const double r2 = fast_rcp(a[2][2] - l20 * a[2][0] - l21 * t21);
+                const double t32 = a[3][2] - l30 * a[2][0] - l31 * t21;
+                const double l32 = t32 * r2;
+                const double r3 = fast_rcp(a[3][3] - l30 * a[3][0] - l31 * t31 - l32 * t32);
+                const double dsel = kq == 0 ? r0 : (kq == 1 ? r1 : (kq == 2 ? r2 : r3));
+                double A[NTL], B[NTL];
+#pragma unroll
+                for (int t = tj0; t < NTL; ++t) {
+                    const double x0 = m[t][0];
+                    const double x1 = m[t][1] - l10 * x0;
+                    const double x2 = m[t][2] - l20 * x0 - l21 * x1;
+                    const double x3 = m[t][3] - l30 * x0 - l31 * x1 - l32 * x2;
+                    double xs = kq == 0 ? x0 : (kq == 1 ? x1 : (kq == 2 ? x2 : x3));
+                    if (16 * t + l15 <= 4 * k + 3) xs = 0.0;              // pivot rows and everything above: finished
+                    A[t] = xs;
+                    B[t] = -xs * dsel;
+                }
+#pragma unroll
+                for (int ti = tj0; ti < NTL; ++ti)
+#pragma unroll
+                    for (int tj = tj0; tj <= ti; ++tj)
+                        T[ti * (ti + 1) / 2 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ti], B[tj], T[ti * (ti + 1) / 2 + tj], 0, 0, 0);
+                wave_sync();
+            }
+        }
+        dbg_stamp(29);
+        // border block: tile (NTL-1, NTL-1), rows KP..KP+3 = local 4..7 -> r = 1, kq = 0..3; cols local 4..7
+        if (l15 >= 4 && l15 < 8) sh.bz[kq * 4 + (l15 - 4)] = T[NLT - 1][1];
+        wave_sync();
+        if (tid == 0) {
+            double W[4][4];
+            for (int p = 0; p < 4; ++p) for (int q = 0; q <= p; ++q) W[p][q] = -sh.bz[p * 4 + q];
+            const double r1 = fast_rcp(W[1][1]);
+            const double l21 = W[2][1] * r1, l31 = W[3][1] * r1;
+            const double r2 = fast_rcp(W[2][2] - l21 * W[2][1]);
+            const double t32 = W[3][2] - l31 * W[2][1];
+            const double l32 = t32 * r2;
+            const double r3 = fast_rcp(W[3][3] - l31 * W[3][1] - l32 * t32);
+            const double y1 = W[1][0], y2 = W[2][0] - l21 * y1, y3 = W[3][0] - l31 * y1 - l32 * y2;
+            double g = W[0][0] - (y1 * y1 * r1 + y2 * y2 * r2 + y3 * y3 * r3);
+            if (STEREO) {
+                double rp = 0.0;
+                for (int o = 0; o < nobs; ++o) rp += sh.rperp[o];
+                g += rp / op.var;
+            }
+            const int dof = fv.dof[oidx];
+            const bool ok = dof >= 1 && dof < op.chi2_len && g < op.chi2[dof];      // Update.cpp:120
+            gamma_out[oidx] = g;
+            accept_out[oidx] = ok ? 1 : 0;
+        }
+        dbg_stamp(30);
+        for (int e = tid; e < REC_HDR + REC_OBS * nobs; e += WAVE) rec_g[e] = rec[e];
+        return;
+    }
+}
+

@@ -1,0 +1,572 @@
+// kernels_bigwin.hip — the factored MSCKF path (K3..K11) for LARGE sliding windows, 17..36 clones (the reference's
+// shipped configs use 21..35, config/*/ingvio_{stereo,mono}.yaml: max_sliding_window_poses).  Same mathematics as
+// kernels_factored.hip (see its header and gate_kernel.h); what no longer fits LDS / registers at 6C = 216 columns
+// lives in L2-resident global workspaces:
+//   k_feat_gate3_big     the shared gate body, one wave per SIMD (16x16 tiles in VGPRs + AGPRs)
+//   k_feat_gram_big      rank-3 part on the matrix cores (105 upper tiles over 8 waves); the block-sparse sums
+//                        per (observing slot, anchor slot) accumulate in a global array, slot c always by the same
+//                        threads (no atomics, deterministic)
+//   k_info_update_big    [A Pcc + s^2 I | A | b] in global memory: K1 by MFMA, Gauss-Jordan with implicit partial
+//                        pivoting, one workgroup of 1024 threads per filter
+//   k_info_apply_big     T = Pc M kept in LDS, K = 216 streamed in MFMA steps of 4
+// Correct and parallel, not tuned: the batched config-2 benchmark never takes this path.  gfx950 only.
+#include <algorithm>
+#include "launch_factored.h"
+#include "gate_kernel.h"
+
+#define BIG_CMAX 36
+#define BIG_NC (6 * BIG_CMAX)
+
+template <bool STEREO>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_feat_gate3_big(
+    CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out,
+    int* __restrict__ accept_out, double* __restrict__ rec_out)
+{
+    gate3_body<BIG_CMAX, STEREO>(cv, fv, op, b0, nb, fmax_used, gamma_out, accept_out, rec_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4 + K6/K7 (see k_feat_gram2): grid = (G chunks, nb), 8 waves, batches of 4 features.
+// ---------------------------------------------------------------------------------------------
+#define GB_NB 4
+#define GB_NT 512
+#define GB_SW 34                                           // per (slot, anchor): S1(9) NXs(9) s4(3) S3(9) s5(3) + pad
+struct GBCfg {
+    static constexpr int CMAX = BIG_CMAX, NC = BIG_NC;
+    static constexpr int TI = (NC + 15) / 16, TJ = (NC + 1 + 15) / 16, LDW = 16 * TJ;
+    static constexpr int NUP = TI * TJ - TI * (TI - 1) / 2;
+    static constexpr int NW = GB_NT / WAVE, TPW = (NUP + NW - 1) / NW;
+    static constexpr int REC = REC_HDR + REC_OBS * CMAX;
+    static constexpr int KR = 3 * GB_NB;
+    static constexpr int PRE = (GB_NB * REC + GB_NT - 1) / GB_NT;
+};
+struct GBBatch {
+    double rec[GB_NB][GBCfg::REC];
+    double Bm[GBCfg::KR][GBCfg::LDW];
+    double Ym[GBCfg::KR][GBCfg::LDW];
+    double sp[GB_NB][GBCfg::CMAX][GB_SW];
+};
+
+__global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
+    FrameView fv, MsckfOpts op, int b0, const int* __restrict__ accept_in, int* __restrict__ used_out,
+    const double* __restrict__ rec_in, double* __restrict__ Apart, int* __restrict__ chunk_used, int G, int rstride,
+    double* __restrict__ Sg_all)
+{
+    using Cfg = GBCfg;
+    constexpr int CMAX = Cfg::CMAX, NC = Cfg::NC, TI = Cfg::TI, TJ = Cfg::TJ, LDW = Cfg::LDW, NUP = Cfg::NUP, NW = Cfg::NW;
+    constexpr int TPW = Cfg::TPW, REC = Cfg::REC, KR = Cfg::KR, PRE = Cfg::PRE;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    GBBatch& sb = *reinterpret_cast<GBBatch*>(smem_raw);
+    int* sUse = reinterpret_cast<int*>(smem_raw + ((sizeof(GBBatch) + 15) / 16) * 16);
+    int* sList = sUse + fv.fmax;
+    __shared__ int sNu;
+    const int bl = blockIdx.y, b = b0 + bl, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int F = fv.n_feat[b], C = fv.n_clones[b], ncol = 6 * C;
+    double* Sg = Sg_all + ((size_t)bl * G + g) * (size_t)CMAX * CMAX * GB_SW;
+
+    for (int j = tid; j < F; j += GB_NT) {                      // RemoveLostUpdate.cpp:357-359
+        int use = accept_in[(size_t)b * fv.fmax + j];
+        if (use && op.max_accept > 0) {
+            int rank = 0;
+            for (int q = 0; q < j; ++q) rank += accept_in[(size_t)b * fv.fmax + q];
+            if (rank >= op.max_accept) use = 0;
+        }
+        sUse[j] = use;
+        if (g == 0) used_out[(size_t)b * fv.fmax + j] = use;
+    }
+    for (int e = tid; e < KR * LDW; e += GB_NT) { (&sb.Bm[0][0])[e] = 0.0; (&sb.Ym[0][0])[e] = 0.0; }
+    for (int e = tid; e < CMAX * CMAX * GB_SW; e += GB_NT) Sg[e] = 0.0;
+    __syncthreads();
+    if (wave == 0) {                                            // ordered list of the used features
+        int cnt = 0;
+        for (int base = 0; base < F; base += WAVE) {
+            const int j = base + lane;
+            const bool u = j < F && sUse[j];
+            const unsigned long long m = __ballot(u);
+            if (u) sList[cnt + __popcll(m & ((1ULL << lane) - 1ULL))] = j;
+            cnt += __popcll(m);
+        }
+        if (lane == 0) sNu = cnt;
+    }
+    __syncthreads();
+    const int nu = sNu, per = (nu + G - 1) / G;
+    const int q0 = g * per, q1 = min(nu, q0 + per);
+
+    int tiA[TPW], tjA[TPW];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        int t = wave + NW * u, ti = 0;
+        while (ti < TI - 1 && t >= TJ - ti) { t -= TJ - ti; ++ti; }
+        tiA[u] = ti; tjA[u] = ti + t;
+    }
+    double4_f acc[TPW];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) acc[u] = double4_f{ 0.0, 0.0, 0.0, 0.0 };
+    const int kq = lane >> 4, l15 = lane & 15;
+
+    double pre[PRE];
+    auto fetch = [&](int qb) {
+        const int nbf = min(GB_NB, q1 - qb);
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) {
+            const int e = tid + u * GB_NT, f = e / REC, w = e - f * REC;
+            pre[u] = (qb < q1 && e < nbf * REC) ? rec_in[((size_t)b * fv.fmax + sList[qb + f]) * REC + w] : 0.0;
+        }
+    };
+    fetch(q0);
+    for (int qb = q0; qb < q1; qb += GB_NB) {
+        const int nbf = min(GB_NB, q1 - qb);
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) { const int e = tid + u * GB_NT; if (e < nbf * REC) (&sb.rec[0][0])[e] = pre[u]; }
+        if (nbf < GB_NB) {
+            for (int e = tid; e < (KR - 3 * nbf) * LDW; e += GB_NT) { (&sb.Bm[3 * nbf][0])[e] = 0.0; (&sb.Ym[3 * nbf][0])[e] = 0.0; }
+        }
+        __syncthreads();
+        // operand rows B, Y = Ns^-1 B and the sparse scratch, lane = (feature, window slot)
+        if (tid < nbf * WAVE) {
+            const int f = tid >> 6, c = tid & 63;
+            if (c < C) {
+                const double* rc = sb.rec[f];
+                const int a = (int)rc[1];
+                const double px = rc[2], py = rc[3], pz = rc[4];
+                const unsigned long long mask = (unsigned long long)rc[5];
+                const bool obs = (mask >> c) & 1ULL;
+                const int o = __popcll(mask & ((1ULL << c) - 1ULL));
+                const double* ro = rc + REC_HDR + REC_OBS * (obs ? o : 0);
+                const double* Nsi = rc + 6;
+                const double* hs = rc + 15;
+                const double* Nsa = rc + 18;
+                double Bt[9], Bp[9], NX[9];
+                const double cn = (obs && ro[1] != 0.0) ? 1.0 : 0.0, pl = (obs && ro[2] != 0.0) ? 1.0 : 0.0;
+                mulX(ro + 3, px, py, pz, NX);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { Bt[i] = cn * NX[i]; Bp[i] = -pl * ro[3 + i]; }
+                if (c == a) {
+                    double T[9];
+                    mulX(Nsa, px, py, pz, T);
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) Bt[i] = -T[i];
+                }
+                double Yt[9], Yp[9];
+                mul33(Nsi, Bt, Yt);
+                mul33(Nsi, Bp, Yp);
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        sb.Bm[3 * f + k][6 * c + q] = Bt[3 * k + q];
+                        sb.Bm[3 * f + k][6 * c + 3 + q] = Bp[3 * k + q];
+                        sb.Ym[3 * f + k][6 * c + q] = Yt[3 * k + q];
+                        sb.Ym[3 * f + k][6 * c + 3 + q] = Yp[3 * k + q];
+                    }
+                if (c == 0) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) sb.Bm[3 * f + k][NC] = hs[k];
+                }
+                double* sp = sb.sp[f][c];
+                double S1[9];
+                mulXt(NX, px, py, pz, S1);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { sp[i] = cn * S1[i]; sp[9 + i] = cn * pl * NX[i]; sp[21 + i] = pl * ro[3 + i]; }
+                sp[18] = cn * (pz * ro[13] - py * ro[14]);
+                sp[19] = cn * (px * ro[14] - pz * ro[12]);
+                sp[20] = cn * (py * ro[12] - px * ro[13]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) sp[30 + i] = pl * ro[12 + i];
+                sp[33] = obs ? (double)a : -1.0;
+            }
+        }
+        __syncthreads();
+        fetch(qb + GB_NB);
+        const int nst = (3 * nbf + 3) >> 2;
+#pragma unroll
+        for (int st = 0; st < KR / 4; ++st) {
+            if (st < nst) {
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    if (wave + NW * u < NUP) {
+                        const int ti = tiA[u], tj = tjA[u];
+                        const double af = sb.Ym[4 * st + kq][16 * ti + l15];
+                        const double bf = sb.Bm[4 * st + kq][16 * tj + l15];
+                        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[u], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // sparse sums: slot c is always handled by the same 8 threads (part = which of the 33 values), features in order
+        if (tid < CMAX * 8) {
+            const int c = tid >> 3, part = tid & 7;
+            if (c < C) {
+                for (int f = 0; f < nbf; ++f) {
+                    const double* sp = sb.sp[f][c];
+                    const double key = sp[33];
+                    if (key >= 0.0) {
+                        double* S = Sg + ((size_t)c * CMAX + (int)key) * GB_SW;
+                        for (int v = part; v < 33; v += 8) S[v] += sp[v];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: [A | b] of the chunk = sparse part - rank-3 part, assembled in global memory ---------------------
+    double* out = Apart + ((size_t)bl * G + g) * rstride;      // [ncol][ncol+1] row-major, b in the last column
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        if (wave + NW * u < NUP) {
+            const int ti = tiA[u], tj = tjA[u];
+            const int jc = 16 * tj + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ti + kq + 4 * r;
+                if (i < ncol) {
+                    if (jc < ncol) {
+                        out[(size_t)i * (ncol + 1) + jc] = -acc[u][r];
+                        if (ti != tj) out[(size_t)jc * (ncol + 1) + i] = -acc[u][r];
+                    } else if (jc == NC) {
+                        out[(size_t)i * (ncol + 1) + ncol] = -acc[u][r];
+                    }
+                }
+            }
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    for (int q = tid; q < C * C; q += GB_NT) {
+        const int c = q / C, c2 = q - c * C;
+        double blk[36];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) blk[i] = 0.0;
+        double bb[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+        if (c == c2) {
+            for (int a = 0; a < C; ++a) {
+                const double* S = Sg + ((size_t)c * CMAX + a) * GB_SW;          // obs at slot c, anchor a
+                const double* Sa = Sg + ((size_t)a * CMAX + c) * GB_SW;         // obs at slot a, anchor c
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        blk[6 * m + k] += S[3 * m + k] + Sa[3 * m + k];
+                        blk[6 * m + 3 + k] -= S[9 + 3 * k + m];            // (theta,p) = -NXs^T
+                        blk[6 * (3 + m) + k] -= S[9 + 3 * m + k];          // (p,theta) = -NXs
+                        blk[6 * (3 + m) + 3 + k] += S[21 + 3 * m + k];
+                    }
+#pragma unroll
+                for (int m = 0; m < 3; ++m) { bb[m] += S[18 + m] - Sa[18 + m]; bb[3 + m] -= S[30 + m]; }
+            }
+        } else {
+            const double* S = Sg + ((size_t)c * CMAX + c2) * GB_SW;             // obs at slot c, anchor c2
+            const double* St = Sg + ((size_t)c2 * CMAX + c) * GB_SW;            // obs at slot c2, anchor c
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    blk[6 * m + k] = -S[3 * m + k] - St[3 * m + k];
+                    blk[6 * (3 + m) + k] = S[9 + 3 * m + k];
+                    blk[6 * m + 3 + k] = St[9 + 3 * k + m];
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) out[(size_t)(6 * c + m) * (ncol + 1) + 6 * c2 + k] += blk[6 * m + k];
+            if (c == c2) out[(size_t)(6 * c + m) * (ncol + 1) + ncol] += bb[m];
+        }
+    }
+    if (tid == 0) chunk_used[bl * G + g] = max(0, q1 - q0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8/K9/K11 (see k_info_update): [K1 | A | b], K1 = A Pcc + s^2 I, in the global workspace Wk (NC x LA row-major).
+// One workgroup of 1024 threads per filter.
+// ---------------------------------------------------------------------------------------------
+#define IB_NT 1024
+__global__ __launch_bounds__(IB_NT, 1) void k_info_update_big(
+    CovView cv, FrameView fv, int b0, const double* __restrict__ Apart, const int* __restrict__ chunk_used, int G, int rstride,
+    const double* __restrict__ noise_all, double* __restrict__ Mall, int mstride, double* __restrict__ Pcall, int ystride,
+    double* __restrict__ dx_all, int* __restrict__ m_out, int* __restrict__ nc_out, int* __restrict__ status,
+    const int* __restrict__ marg_idx, int* __restrict__ pc_base_out, double* __restrict__ Wk_all)
+{
+    constexpr int NC = BIG_NC, LA = 2 * NC + 1, MP = NC;
+    __shared__ int sCol[NC];
+    __shared__ int sInv[NC];
+    __shared__ int sUsed[NC];
+    __shared__ double sPivVal[NC];
+    __shared__ double rowbuf[LA];
+    __shared__ double colbuf[NC];
+    __shared__ unsigned long long sBest[2];
+    const int bl = blockIdx.x, b = b0 + bl, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = fv.n_clones[b], ncol = 6 * C, n = cv.n[b], ld = cv.ldp;
+    double* dx = dx_all + (size_t)b * ld;
+    double* Wk = Wk_all + (size_t)bl * NC * LA;
+    int total = 0;
+    for (int g = 0; g < G; ++g) total += chunk_used[bl * G + g];
+    if (total == 0) {
+        for (int r = tid; r < n; r += IB_NT) dx[r] = 0.0;
+        if (tid == 0) { m_out[bl] = 0; nc_out[bl] = ncol; pc_base_out[bl] = -1; }
+        return;
+    }
+    const double* P = cov_ptr(cv, b);
+    const double var = noise_all[bl];
+    for (int c = tid; c < NC; c += IB_NT) {
+        const int cc = c < ncol ? c : 0;
+        sCol[c] = fv.clone_idx[(size_t)b * fv.cmax + cc / 6] + cc % 6;
+        sUsed[c] = 0;
+    }
+    if (tid < 2) sBest[tid] = 0ULL;
+    // [A | b] from the chunk partials
+    for (int e = tid; e < NC * (NC + 1); e += IB_NT) {
+        const int i = e / (NC + 1), j = e - i * (NC + 1);
+        double s = 0.0;
+        if (i < ncol && (j < ncol || j == NC)) {
+            const size_t src = (size_t)i * (ncol + 1) + (j == NC ? ncol : j);
+            for (int g = 0; g < G; ++g)
+                if (chunk_used[bl * G + g]) s += Apart[((size_t)bl * G + g) * rstride + src];
+        }
+        Wk[(size_t)i * LA + NC + j] = s;
+    }
+    __syncthreads();
+    const bool fused = marg_idx && marg_idx[bl] >= 0;
+    bool contig_t = true;
+    for (int c = tid; c < ncol; c += IB_NT) contig_t = contig_t && (sCol[c] == sCol[0] + c);
+    const int contig = __syncthreads_and(contig_t);
+    const bool zero_copy = fused && contig && sCol[0] + MP <= ld;
+    // K1 = A Pcc + s^2 I on the matrix cores: wave w owns tiles t = w, w + 16, ...
+    {
+        constexpr int TT = (NC + 15) / 16, NWV = IB_NT / WAVE;
+        const int kq = lane >> 4, l15 = lane & 15;
+        for (int t = wave; t < TT * TT; t += NWV) {
+            const int ti = t / TT, tj = t - ti * TT;
+            const int ia = min(16 * ti + l15, NC - 1), jb = min(16 * tj + l15, NC - 1);
+            const size_t gjb = (size_t)sCol[jb] * ld;
+            double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
+            for (int s4 = 0; s4 < NC / 4; ++s4) {
+                const int k = 4 * s4 + kq;
+                const double af = Wk[(size_t)ia * LA + NC + k];               // A[i][k]
+                const double bf = P[sCol[k] + gjb];                           // Pcc[k][j]
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+            }
+            const int j = 16 * tj + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ti + kq + 4 * r;
+                if (i < NC && j < NC) Wk[(size_t)i * LA + j] = acc[r] + (i == j ? var : 0.0);
+            }
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    // Gauss-Jordan with implicit partial pivoting on the global workspace; only columns > k are updated
+    // (the pivot row is zero in the columns of the earlier pivots)
+    for (int k = 0; k < NC; ++k) {
+        if (tid < 256) {                                                  // NC <= 256 candidates, 4 waves
+            unsigned long long key = 0ULL;
+            if (tid < NC && !sUsed[tid]) {
+                const double v = Wk[(size_t)tid * LA + k];
+                key = ((unsigned long long)__double_as_longlong(fabs(v)) & ~0xFFULL) | (unsigned long long)(255 - tid);
+                colbuf[tid] = v;
+            } else if (tid < NC) {
+                colbuf[tid] = Wk[(size_t)tid * LA + k];
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(key, off, WAVE); key = o > key ? o : key; }
+            if (lane == 0 && key) atomicMax(&sBest[k & 1], key);
+        }
+        __syncthreads();
+        const unsigned long long best = sBest[k & 1];
+        const int p = 255 - (int)(best & 0xFFULL);
+        for (int j = tid; j < LA; j += IB_NT) rowbuf[j] = Wk[(size_t)p * LA + j];
+        if (tid == 0) {
+            sBest[(k + 1) & 1] = 0ULL; sInv[p] = k; sUsed[p] = 1; sPivVal[k] = colbuf[p];
+            if ((best >> 8) == 0ULL) atomicOr(&status[b], 4);
+        }
+        __syncthreads();
+        {
+            const double inv = fast_rcp(colbuf[p]);
+            const int tx = tid & 255, ty = tid >> 8;
+            for (int i = ty; i < NC; i += IB_NT / 256) {
+                if (i == p) continue;
+                const double f = colbuf[i] * inv;
+                double* wr = Wk + (size_t)i * LA;
+                for (int j = k + 1 + tx; j < LA; j += 256) wr[j] -= f * rowbuf[j];
+            }
+        }
+        __threadfence();
+        __syncthreads();
+    }
+    // solution rows: row i holds component ks = sInv[i], scaled by its pivot
+    double* Mg = Mall + (size_t)bl * mstride;
+    for (int e = tid; e < NC * (NC + 1); e += IB_NT) {
+        const int i = e / (NC + 1), j = e - i * (NC + 1);
+        const int ks = sInv[i];
+        const double v = Wk[(size_t)i * LA + NC + j] * fast_rcp(sPivVal[ks]);
+        if (j < NC) Mg[(size_t)ks * MP + j] = v;
+        else Mg[(size_t)MP * MP + ks] = v;
+    }
+    double* Pc = Pcall + (size_t)bl * ystride;
+    if (!zero_copy) {
+        for (int k = wave; k < MP; k += IB_NT / WAVE) {
+            const int gk = sCol[k];
+            const bool real = k < ncol;
+            for (int r = lane; r < n; r += WAVE) Pc[r + (size_t)k * ld] = real ? P[r + (size_t)gk * ld] : 0.0;
+        }
+    }
+    if (tid == 0) { m_out[bl] = ncol; nc_out[bl] = ncol; pc_base_out[bl] = zero_copy ? sCol[0] : -1; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K10 (+ fused K12), see k_info_apply: one wave per 16-row tile row, T row in LDS, K streamed.
+// ---------------------------------------------------------------------------------------------
+struct ABShared {
+    static constexpr int MP = BIG_NC;
+    double sT[4][16][MP + 2];
+    double sB[MP][16];
+    double sV[4][16][17];
+};
+
+__global__ __launch_bounds__(256, 1) void k_info_apply_big(
+    CovView cv, int b0, int nb, int wgpf, const double* __restrict__ Mall, int mstride, const double* __restrict__ Pcall,
+    int ystride, const int* __restrict__ m_all, double* __restrict__ dx_all, int* __restrict__ status,
+    const int* __restrict__ marg_idx, int msize, const int* __restrict__ pc_base)
+{
+    constexpr int MP = BIG_NC, K4 = MP / 4, JT = (MP + 15) / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    ABShared& sh = *reinterpret_cast<ABShared*>(smem_raw);
+    const int wg = blockIdx.x, xcd = wg & 7, tq = wg >> 3;
+    const int bl = xcd + 8 * (tq / wgpf), part = tq % wgpf;
+    if (bl >= nb) return;
+    const int b = b0 + bl;
+    const bool upd = m_all[bl] != 0;
+    const int midx = marg_idx ? marg_idx[bl] : -1;
+    const bool fused = midx >= 0;
+    if (!upd && !fused) return;
+    const int n = cv.n[b], ld = cv.ldp, nt = (n + 15) >> 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (part * 4 >= nt) return;
+    const int ti = part * 4 + wave;
+    const bool wave_on = ti < nt;
+    const int tjmax = min(nt - 1, part * 4 + 3);
+    const double* P = cov_ptr(cv, b);
+    double* dst = fused ? cov_alt_ptr(cv, b) : cov_ptr(cv, b);
+    const int pcb = upd ? pc_base[bl] : -1;
+    const double* Pc = pcb >= 0 ? P + (size_t)pcb * ld : Pcall + (size_t)bl * ystride;
+    const double* M = Mall + (size_t)bl * mstride;
+    const double* tvec = M + (size_t)MP * MP;
+    const int l15 = lane & 15, kq = lane >> 4;
+    auto alive = [&](int i) { return !(fused && i >= midx && i < midx + msize); };
+    auto remap = [&](int i) { return (fused && i >= midx) ? i - msize : i; };
+
+    if (upd && wave_on) {
+        const int ra = min(ti * 16 + l15, n - 1);
+        double afrag[K4];
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) afrag[k4] = (Pc + (size_t)(4 * k4) * ld)[ra + kq * ld];
+        {
+            double d = 0.0;
+#pragma unroll
+            for (int k4 = 0; k4 < K4; ++k4) d += afrag[k4] * tvec[4 * k4 + kq];
+            d += __shfl_xor(d, 16, WAVE);
+            d += __shfl_xor(d, 32, WAVE);
+            if (kq == 0 && ti * 16 + l15 < n) dx_all[(size_t)b * ld + ra] = d;
+        }
+#pragma unroll 1
+        for (int jt = 0; jt < JT; ++jt) {
+            double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
+            const int jc = min(jt * 16 + l15, MP - 1);
+#pragma unroll
+            for (int k4 = 0; k4 < K4; ++k4) {
+                const double bf = (M + (size_t)(4 * k4) * MP)[kq * MP + jc];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[k4], bf, acc, 0, 0, 0);
+            }
+            if (jt * 16 + l15 < MP) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sh.sT[wave][kq + 4 * r][jc] = acc[r];
+            }
+        }
+    }
+    __syncthreads();
+    for (int tj = 0; tj <= tjmax; ++tj) {
+        // stage the B tile Pc[16 tj .. +16][0..MP) once for the four waves
+        if (upd) {
+            for (int e = tid; e < MP * 16; e += 256) {
+                const int k = e >> 4, r = e & 15;
+                sh.sB[k][r] = Pc[min(16 * tj + r, n - 1) + (size_t)k * ld];
+            }
+        }
+        __syncthreads();
+        if (wave_on && tj <= ti) {
+            double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
+            if (upd) {
+#pragma unroll 6
+                for (int k4 = 0; k4 < K4; ++k4)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.sT[wave][l15][4 * k4 + kq], sh.sB[4 * k4 + kq][l15], acc, 0, 0, 0);
+            }
+            const int col = tj * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = ti * 16 + kq + 4 * r;
+                double v = 0.0;
+                if (row < n && col < n && row >= col) {
+                    v = P[col + (size_t)row * ld] - acc[r];
+                    if (alive(row) && alive(col)) dst[remap(col) + (size_t)remap(row) * ld] = v;
+                    if (upd && row == col && v < 0.0) atomicOr(&status[b], 2);
+                }
+                sh.sV[wave][kq + 4 * r][l15] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int row2 = ti * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col2 = tj * 16 + kq + 4 * r;
+                if (row2 < n && col2 < n && row2 > col2 && alive(row2) && alive(col2))
+                    dst[remap(row2) + (size_t)remap(col2) * ld] = sh.sV[wave][l15][kq + 4 * r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+size_t bigwin_sg_doubles(int G) { return (size_t)G * BIG_CMAX * BIG_CMAX * GB_SW; }
+size_t bigwin_wk_doubles() { return (size_t)BIG_NC * (2 * BIG_NC + 1); }
+int bigwin_rec_size() { return rec_size(BIG_CMAX); }
+int bigwin_cmax() { return BIG_CMAX; }
+
+int launch_bigwin(const FactoredLaunch& L, hipStream_t st)
+{
+    if (L.fv.cmax > BIG_CMAX) return -1;
+    if (L.stage == 0) {
+        const int nb8 = (L.nb + 7) / 8 * 8;
+        if (L.stereo)
+            hipLaunchKernelGGL(k_feat_gate3_big<true>, dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st,
+                               L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
+        else
+            hipLaunchKernelGGL(k_feat_gate3_big<false>, dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st,
+                               L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
+        return 0;
+    }
+    if (L.stage == 1) {
+        const size_t sm = ((sizeof(GBBatch) + 15) / 16) * 16 + 2 * sizeof(int) * (size_t)L.fv.fmax;
+        static size_t attr_sm = 0;
+        if (sm > attr_sm) { hipFuncSetAttribute((const void*)k_feat_gram_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_sm = sm; }
+        hipLaunchKernelGGL(k_feat_gram_big, dim3(L.G, L.nb), dim3(GB_NT), sm, st, L.fv, L.op, L.b0, L.accept, L.used, L.rec,
+                           L.Apart, L.chunk_used, L.G, L.rstride, L.big_sg);
+        return 0;
+    }
+    if (L.stage == 2) {
+        hipLaunchKernelGGL(k_info_update_big, dim3(L.nb), dim3(IB_NT), 0, st, L.cv, L.fv, L.b0, L.Apart, L.chunk_used, L.G,
+                           L.rstride, L.noise, L.T, L.mstride, L.Pc, L.ystride, L.dx, L.m_out, L.nc_out, L.status, L.marg_idx,
+                           L.pc_base, L.big_wk);
+        return 0;
+    }
+    const int nt = (L.n_cap + 15) / 16, wgpf = (nt + 3) / 4, nb8 = (L.nb + 7) / 8 * 8;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)k_info_apply_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ABShared));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_info_apply_big, dim3(nb8 * wgpf), dim3(256), sizeof(ABShared), st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride,
+                       L.Pc, L.ystride, L.m_out, L.dx, L.status, L.marg_idx, L.marg_size, L.pc_base);
+    return 0;
+}

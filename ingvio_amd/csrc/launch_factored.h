@@ -28,8 +28,17 @@ struct FactoredLaunch {
     const int* marg_idx;  // stage 3: fused StateManager::marginalize, per filter state index or -1 (nullptr: none)
     int marg_size;
     int* pc_base;         // [nb] stage 2 -> 3: first clone column when Pc is read straight from P, else -1
+    double* big_sg;       // large-window path: [nb][G][36][36][34] sparse sums (kernels_bigwin.hip)
+    double* big_wk;       // large-window path: [nb][216][433] Gauss-Jordan workspace
 };
 
 int launch_factored(const FactoredLaunch& L, hipStream_t st);
 int factored_rec_size(int cmax);
 int dbg_read_factored(long long* out, int n);
+
+// kernels_bigwin.hip: windows of 17..36 clones
+int launch_bigwin(const FactoredLaunch& L, hipStream_t st);
+size_t bigwin_sg_doubles(int G);
+size_t bigwin_wk_doubles();
+int bigwin_rec_size();
+int bigwin_cmax();

@@ -378,6 +378,46 @@ def test_frame_without_marginalisation_in_batch(orc):
     ctx2.close()
 
 
+@pytest.mark.parametrize("C,stereo", [(20, True), (30, True), (35, False), (17, False), (36, True)])
+def test_large_window_vs_oracle(orc, C, stereo):
+    """Windows of 17..36 clones (the reference's shipped configs: 21..35) take the large-window kernels
+    (kernels_bigwin.hip): whole frames, ragged observations, random anchors, vs the oracle."""
+    from ingvio_amd import capi, host, synth
+    nb, F = 2, 48
+    n_gnss, n_lm = 6, 4
+    N = 21 + n_gnss + 3 * n_lm + 6 * C
+    ctx2 = capi.Context(batch=nb, n_max=((N + 15) // 16) * 16, c_max=C, f_max=F, m_max=64)
+    cases = []
+    for b in range(nb):
+        flt, step, frame, info = synth.build_case(lambda P, b=b: capi.DeviceCov(ctx2, b, P), host.imu_transition,
+                                                  seed=300 + b, F=F, C=C, n_gnss=n_gnss, n_landmarks=n_lm, stereo=stereo)
+        rng = np.random.default_rng(3000 + b)
+        mask = np.zeros(F, dtype=np.uint64); dof = np.zeros(F, dtype=np.int32)
+        for j in range(F):
+            k = int(rng.integers(5, C + 1))
+            obs = np.sort(rng.choice(C, size=k, replace=False))
+            mask[j] = np.uint64(sum(1 << int(o) for o in obs)); dof[j] = k - 1
+        frame = dict(frame); frame["obs_mask"] = mask; frame["dof"] = dof
+        frame["anchor"] = rng.integers(0, C, size=F).astype(np.int32)
+        cases.append((flt, step, frame, info))
+    ld = ctx2.ldp
+    priors = [ctx2.cov_get(b) for b in range(nb)]
+    ctx2.snapshot()
+    ctx2.frame_stage(0, [c[1] for c in cases], [c[2] for c in cases], cases[0][1]["sigma"], 1, 0.2, 0.2)
+    for _ in range(2):
+        ctx2.frame_run(restore_prior=True)
+    dx, acc, rows = ctx2.frame_fetch()
+    for b in range(nb):
+        flt, step, frame, info = cases[b]
+        oc = orc.Cov(priors[b], ld=ld)
+        dxo, acco, gamo, m = orc.frame_update(oc, step, frame, max_accept=0, compress_rule=1)
+        assert np.array_equal(acc[b, :F], acco) and acco.sum() > 0
+        P = ctx2.cov_get(b)
+        assert rows[b] == 6 * C and P.shape == oc.P.shape
+        assert rel_err(P, oc.P) < 1e-10 and rel_err(dx[b, :N], dxo) < 1e-7 and np.array_equal(P, P.T)
+    ctx2.close()
+
+
 def test_qr_compress(ctx):
     """K7 on an explicit H_large (the SPQR call sites): H_thin^T H_thin == H^T H, H_thin upper triangular;
     also on a rank-deficient matrix (Q9: rank n-6)."""
