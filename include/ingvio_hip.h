@@ -48,7 +48,8 @@ typedef struct ingvio_ctx ingvio_ctx;
 typedef struct {
     int batch;      /* independent filters held by this context (>= 1)                          */
     int n_max;      /* max state dimension N (21 + gnss + 6C + 3L)                               */
-    int c_max;      /* max clones in the sliding window (<= 16 in this build)     */
+    int c_max;      /* max clones in the sliding window: <= 36; windows above 16 take the large-window kernels (factored path
+                     * only: no dense method, no ingvio_qr_compress), see DESIGN.md                */
     int f_max;      /* max features per MSCKF update                                             */
     int m_max;      /* max rows of a generic ekf_update (<= 128 in this build)                   */
     int device;     /* HIP device ordinal                                                        */

@@ -418,6 +418,31 @@ def test_large_window_vs_oracle(orc, C, stereo):
     ctx2.close()
 
 
+@pytest.mark.parametrize("n_lm", [0, 200])
+def test_config5_stress_vs_oracle(orc, n_lm):
+    """BASELINE config 5: 300 features x 30 clones, stereo (rho = 117 rows per feature, n = 180 columns), at the
+    literal state size (N = 207 with the six GNSS scalars) and at the nominal N ~ 800 (+200 landmark blocks):
+    whole frame vs the oracle, incl. propagation over several 256-row tiles."""
+    from ingvio_amd import capi, host, synth
+    C, F, n_gnss = 30, 300, 6
+    N = 21 + n_gnss + 3 * n_lm + 6 * C
+    ctx2 = capi.Context(batch=1, n_max=((N + 15) // 16) * 16, c_max=C, f_max=F, m_max=64)
+    flt, step, frame, info = synth.build_case(lambda P: capi.DeviceCov(ctx2, 0, P), host.imu_transition, seed=5, F=F, C=C,
+                                              n_gnss=n_gnss, n_landmarks=n_lm, stereo=True)
+    prior = ctx2.cov_get(0)
+    oc = orc.Cov(prior, ld=ctx2.ldp)
+    dxo, acco, gamo, m = orc.frame_update(oc, step, frame, max_accept=0, compress_rule=1)
+    ctx2.snapshot()
+    ctx2.frame_stage(0, [step], [frame], step["sigma"], 1, 0.2, 0.2)
+    for _ in range(2):
+        ctx2.frame_run(restore_prior=True)
+    dx, acc, rows = ctx2.frame_fetch()
+    P = ctx2.cov_get(0)
+    assert np.array_equal(acc[0, :F], acco) and rows[0] == 6 * C and ctx2.n(0) == N - 6
+    assert rel_err(P, oc.P) < 1e-10 and rel_err(dx[0, :N], dxo) < 1e-7 and np.array_equal(P, P.T)
+    ctx2.close()
+
+
 def test_qr_compress(ctx):
     """K7 on an explicit H_large (the SPQR call sites): H_thin^T H_thin == H^T H, H_thin upper triangular;
     also on a rank-deficient matrix (Q9: rank n-6)."""
