@@ -65,7 +65,7 @@ State::State(const IngvioParams& filter_params) : _state_params(filter_params)
 {
     ingvio_ctx_desc d;
     d.batch = 1; d.n_max = filter_params._hip_n_max;
-    d.c_max = filter_params._max_sw_clones + 1 > 16 ? 16 : filter_params._max_sw_clones + 1;
+    d.c_max = filter_params._max_sw_clones + 1;                     // <= 36: the ABI refuses larger windows (INGVIO_E_CAPACITY)
     d.f_max = filter_params._hip_f_max; d.m_max = 64; d.device = filter_params._hip_device; d.stream = nullptr;
     if (ingvio_ctx_create(&d, &_ctx) != INGVIO_OK) {
         std::cout << "[State]: libingvio_hip: no MI355X context (" << (_ctx ? ingvio_last_error(_ctx) : "no device") << ")" << std::endl;

@@ -318,10 +318,14 @@ struct TruthTri : public Triangulator {
 
 static void testFilterEndToEnd()
 {
-    for (int keyframe = 1; keyframe >= 0; --keyframe) {
+    // {key-frame mode, window}: the two update policies at the 11-clone window of BASELINE config 2, then the window of
+    // the reference's shipped stereo config (config/fw_zed2i_f9p/ingvio_stereo.yaml: 21 poses -> large-window kernels)
+    const int runs[3][3] = { { 1, 11, 7 }, { 0, 11, 7 }, { 0, 21, 16 } };
+    for (int run = 0; run < 3; ++run) {
+        const int keyframe = runs[run][0], window = runs[run][1], life = runs[run][2];
         IngvioParams fp = params();
-        fp._enable_gnss = 0; fp._max_sw_clones = 11; fp._is_key_frame = keyframe; fp._frame_select_interval = 4;
-        fp._init_imu_buffer_sp = -1; fp._visual_noise = 0.08; fp._hip_f_max = 64; fp._hip_n_max = 112;
+        fp._enable_gnss = 0; fp._max_sw_clones = window; fp._is_key_frame = keyframe; fp._frame_select_interval = 4;
+        fp._init_imu_buffer_sp = -1; fp._visual_noise = 0.08; fp._hip_f_max = 64; fp._hip_n_max = 21 + 6 * (window + 2) + 16;
         fp._init_cov_rot = 0.01; fp._init_cov_pos = 0.01;
         auto tri = std::make_shared<TruthTri>();
         IngvioFilter filter(fp, tri);
@@ -352,7 +356,7 @@ static void testFilterEndToEnd()
             const Vec3d pc = Truth::p(t) + Truth::R(t) * fp._T_cl2i.t;
             // retire old features, spawn new ones in the frustum
             std::vector<Live> keep;
-            for (auto& l : live) if (f - l.born < 7) keep.push_back(l);
+            for (auto& l : live) if (f - l.born < life) keep.push_back(l);
             live = keep;
             while ((int)live.size() < 40) {
                 const double d = 3.0 + 10.0 * std::fabs(urand());
@@ -381,7 +385,7 @@ static void testFilterEndToEnd()
         ASSERT_TRUE(dmin > 0.0);
         const double perr = (state->_extended_pose->valueTrans1() - Truth::p(t)).norm();
         const double rerr = (state->_extended_pose->valueLinearAsMat() - Truth::R(t)).norm();
-        std::printf("  %s mode: N=%d clones=%zu |dp|=%.4f m |dR|=%.4f features=%zu\n", keyframe ? "keyframe" : "sw-marg",
+        std::printf("  %s mode, window %d: N=%d clones=%zu |dp|=%.4f m |dR|=%.4f features=%zu\n", keyframe ? "keyframe" : "sw-marg", window,
                     state->curr_cov_size(), state->_sw_camleft_poses.size(), perr, rerr, filter.mapServer()->size());
         ASSERT_TRUE(perr < 0.2);          // 2 s of 200 Hz consumer-grade IMU would drift further without the updates
         ASSERT_TRUE(rerr < 0.05);
