@@ -231,7 +231,6 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
             }
         }
     }
-    __threadfence();
     __syncthreads();
     for (int q = tid; q < C * C; q += GB_NT) {
         const int c = q / C, c2 = q - c * C;
@@ -293,8 +292,9 @@ __global__ __launch_bounds__(IB_NT, 1) void k_info_update_big(
     __shared__ int sInv[NC];
     __shared__ int sUsed[NC];
     __shared__ double sPivVal[NC];
-    __shared__ double rowbuf[LA];
-    __shared__ double colbuf[NC];
+    __shared__ double Pan[NC][9];                      // the current panel's 8 columns (+1 pad)
+    __shared__ double Fm[8][NC];                       // multipliers of the panel's pivots
+    __shared__ double Rw[8][LA];                       // the panel's pivot rows, right of the panel
     __shared__ unsigned long long sBest[2];
     const int bl = blockIdx.x, b = b0 + bl, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C = fv.n_clones[b], ncol = 6 * C, n = cv.n[b], ld = cv.ldp;
@@ -355,44 +355,77 @@ __global__ __launch_bounds__(IB_NT, 1) void k_info_update_big(
             }
         }
     }
-    __threadfence();
     __syncthreads();
-    // Gauss-Jordan with implicit partial pivoting on the global workspace; only columns > k are updated
-    // (the pivot row is zero in the columns of the earlier pivots)
-    for (int k = 0; k < NC; ++k) {
-        if (tid < 256) {                                                  // NC <= 256 candidates, 4 waves
-            unsigned long long key = 0ULL;
-            if (tid < NC && !sUsed[tid]) {
-                const double v = Wk[(size_t)tid * LA + k];
-                key = ((unsigned long long)__double_as_longlong(fabs(v)) & ~0xFFULL) | (unsigned long long)(255 - tid);
-                colbuf[tid] = v;
-            } else if (tid < NC) {
-                colbuf[tid] = Wk[(size_t)tid * LA + k];
-            }
+    // Blocked Gauss-Jordan with implicit partial pivoting, panels of PB pivots.  The panel's columns live in LDS only
+    // (nothing left of the current pivot is ever read again); the columns right of the panel are read and written ONCE
+    // per panel:  W[i][j] -= sum_k F[k][i] R_k[j], with F[k][i] the multipliers of pivot k (0 at its own pivot row) and
+    // R_k the pivot row as it stands when it is used (corrected for the earlier pivots of the panel).
+    constexpr int PB = 8;
+    static_assert(NC % PB == 0, "panel width");
+    for (int k0 = 0; k0 < NC; k0 += PB) {
+        for (int e = tid; e < NC * PB; e += IB_NT) { const int i = e / PB, jj = e - i * PB; Pan[i][jj] = Wk[(size_t)i * LA + k0 + jj]; }
+        __syncthreads();
+        for (int kk = 0; kk < PB; ++kk) {
+            const int k = k0 + kk;
+            if (tid < 256) {                                                  // NC <= 256 candidates, 4 waves
+                unsigned long long key = 0ULL;
+                if (tid < NC && !sUsed[tid])
+                    key = ((unsigned long long)__double_as_longlong(fabs(Pan[tid][kk])) & ~0xFFULL) | (unsigned long long)(255 - tid);
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(key, off, WAVE); key = o > key ? o : key; }
-            if (lane == 0 && key) atomicMax(&sBest[k & 1], key);
+                for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(key, off, WAVE); key = o > key ? o : key; }
+                if (lane == 0 && key) atomicMax(&sBest[k & 1], key);
+            }
+            __syncthreads();
+            const unsigned long long best = sBest[k & 1];
+            const int p = 255 - (int)(best & 0xFFULL);
+            const double piv = Pan[p][kk];
+            if (tid < NC) Fm[kk][tid] = tid == p ? 0.0 : Pan[tid][kk] * fast_rcp(piv);
+            for (int j = k0 + PB + tid; j < LA; j += IB_NT) {                  // pivot row, right of the panel
+                double r = Wk[(size_t)p * LA + j];
+                for (int kp = 0; kp < kk; ++kp) r -= Fm[kp][p] * Rw[kp][j];
+                Rw[kk][j] = r;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                sBest[(k + 1) & 1] = 0ULL; sInv[p] = k; sUsed[p] = 1; sPivVal[k] = piv;
+                if ((best >> 8) == 0ULL) atomicOr(&status[b], 4);
+            }
+            for (int e = tid; e < NC * PB; e += IB_NT) {                        // the panel's own later columns, in LDS
+                const int i = e / PB, jj = e - i * PB;
+                if (jj > kk && i != p) Pan[i][jj] -= Fm[kk][i] * Pan[p][jj];
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        const unsigned long long best = sBest[k & 1];
-        const int p = 255 - (int)(best & 0xFFULL);
-        for (int j = tid; j < LA; j += IB_NT) rowbuf[j] = Wk[(size_t)p * LA + j];
-        if (tid == 0) {
-            sBest[(k + 1) & 1] = 0ULL; sInv[p] = k; sUsed[p] = 1; sPivVal[k] = colbuf[p];
-            if ((best >> 8) == 0ULL) atomicOr(&status[b], 4);
-        }
-        __syncthreads();
         {
-            const double inv = fast_rcp(colbuf[p]);
             const int tx = tid & 255, ty = tid >> 8;
-            for (int i = ty; i < NC; i += IB_NT / 256) {
-                if (i == p) continue;
-                const double f = colbuf[i] * inv;
-                double* wr = Wk + (size_t)i * LA;
-                for (int j = k + 1 + tx; j < LA; j += 256) wr[j] -= f * rowbuf[j];
+            const int j0 = k0 + PB + tx, j1 = j0 + 256;
+            double r0[PB], r1[PB];
+#pragma unroll
+            for (int kk = 0; kk < PB; ++kk) { r0[kk] = j0 < LA ? Rw[kk][j0] : 0.0; r1[kk] = j1 < LA ? Rw[kk][j1] : 0.0; }
+            constexpr int RG = IB_NT / 256;
+            for (int ib = ty; ib < NC; ib += 4 * RG) {
+                double w0[4], w1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = ib + RG * u;
+                    const double* wr = Wk + (size_t)(i < NC ? i : 0) * LA;
+                    w0[u] = (i < NC && j0 < LA) ? wr[j0] : 0.0;
+                    w1[u] = (i < NC && j1 < LA) ? wr[j1] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = ib + RG * u;
+                    if (i < NC) {
+                        double a0 = w0[u], a1 = w1[u];
+#pragma unroll
+                        for (int kk = 0; kk < PB; ++kk) { const double f = Fm[kk][i]; a0 -= f * r0[kk]; a1 -= f * r1[kk]; }
+                        double* wr = Wk + (size_t)i * LA;
+                        if (j0 < LA) wr[j0] = a0;
+                        if (j1 < LA) wr[j1] = a1;
+                    }
+                }
             }
         }
-        __threadfence();
         __syncthreads();
     }
     // solution rows: row i holds component ks = sInv[i], scaled by its pivot
