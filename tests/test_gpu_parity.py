@@ -443,6 +443,36 @@ def test_config5_stress_vs_oracle(orc, n_lm):
     ctx2.close()
 
 
+@pytest.mark.parametrize("C,stereo,cap", [(24, True, 0), (27, False, 0), (22, True, 12)])
+def test_large_window_selected_variant_and_cap(orc, C, stereo, cap):
+    """Large windows with the Selected-timestamp quirk Q10 (anchor block assigned) and the accepted-feature cap,
+    two consecutive frames without restore (both ping-pong halves), vs the oracle."""
+    from ingvio_amd import capi, host, synth
+    F, n_gnss, n_lm = 40, 6, 3
+    N = 21 + n_gnss + 3 * n_lm + 6 * C
+    ctx2 = capi.Context(batch=1, n_max=((N + 15) // 16) * 16, c_max=C, f_max=F, m_max=64)
+    flt, step, frame, info = synth.build_case(lambda P: capi.DeviceCov(ctx2, 0, P), host.imu_transition, seed=77, F=F, C=C,
+                                              n_gnss=n_gnss, n_landmarks=n_lm, stereo=stereo)
+    rng = np.random.default_rng(77)
+    mask = np.zeros(F, dtype=np.uint64); dof = np.zeros(F, dtype=np.int32)
+    for j in range(F):
+        k = int(rng.integers(6, C + 1))
+        obs = np.sort(rng.choice(C, size=k, replace=False))
+        mask[j] = np.uint64(sum(1 << int(o) for o in obs)); dof[j] = k - 1
+    frame = dict(frame); frame["obs_mask"] = mask; frame["dof"] = dof
+    frame["anchor"] = np.array([int(np.sort([o for o in range(C) if (int(mask[j]) >> o) & 1])[j % 3]) if j % 2 else int(rng.integers(0, C))
+                                for j in range(F)], dtype=np.int32)          # half the anchors are observing clones
+    oc = orc.Cov(ctx2.cov_get(0), ld=ctx2.ldp)
+    ctx2.frame_stage(0, [step], [frame], step["sigma"], 1, 0.2, 0.2, max_accept=cap, compress_rule=1, selected_variant=1)
+    for it in range(2):
+        ctx2.frame_run(restore_prior=False)
+        dx, acc, rows = ctx2.frame_fetch()
+        dxo, acco, gamo, m = orc.frame_update(oc, step, frame, max_accept=cap, compress_rule=1, selected_variant=1)
+        assert np.array_equal(acc[0, :F], acco) and (cap == 0 or acco.sum() <= cap)
+        assert rel_err(ctx2.cov_get(0), oc.P) < 1e-10 and rel_err(dx[0, :N], dxo) < 1e-7
+    ctx2.close()
+
+
 def test_qr_compress(ctx):
     """K7 on an explicit H_large (the SPQR call sites): H_thin^T H_thin == H^T H, H_thin upper triangular;
     also on a rank-deficient matrix (Q9: rank n-6)."""
