@@ -91,6 +91,7 @@ struct Gate3Shared {
     };
     double Rb[CMAX][9];               // per-observation part of Su: R_o = cn X P(th_o,th_a) X^T + pl P(p_o,th_a) X
     double Qb[9];                     // X P(th_a,th_a) X^T
+    int oa;                           // observation index of the anchor clone itself, or -1
 };
 
 __device__ __forceinline__ void wave_sync()      // LDS hand-over between the lanes of ONE wave
@@ -99,125 +100,38 @@ __device__ __forceinline__ void wave_sync()      // LDS hand-over between the la
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int CMAX, bool STEREO>
+// FPW = features per workgroup (= waves per workgroup).  The FRONT of the kernel (projection Jacobians, the record,
+// the per-observation terms) only has one lane of work per window slot / observation; with FPW = 4 wave 0 runs it for
+// four features at once, 16 lanes each (window classes up to 16 clones), instead of four waves issuing the same
+// instructions for 11 lanes each.  The BACK (pair blocks, tile fill, blocked LDL^T) is one wave per feature.
+template <int CMAX, bool STEREO, int FPW>
 __device__ __forceinline__ void gate3_body(
     CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out,
     int* __restrict__ accept_out, double* __restrict__ rec_out)
 {
     using Cfg = FeatCfg<CMAX, STEREO>;
     using SH = Gate3Shared<CMAX, STEREO>;
-    constexpr int RPO = Cfg::RPO, D = SH::D;
-    __shared__ SH sh;
+    constexpr int RPO = Cfg::RPO, D = SH::D, GS = WAVE / FPW;
+    static_assert(FPW == 1 || CMAX <= GS, "a lane group must cover the window");
+    __shared__ SH sh4[FPW];
     // XCD-aware mapping: consecutive workgroups go round-robin to the 8 XCDs, so give every XCD whole filters
     // (a filter's P blocks then live in one L2 instead of eight)
+    const int nblk = (fmax_used + FPW - 1) / FPW;
     const int w = blockIdx.x, xcd = w & 7, t = w >> 3;
-    const int bl = xcd + 8 * (t / fmax_used), j = t % fmax_used;
+    const int bl = xcd + 8 * (t / nblk), jbase = (t % nblk) * FPW;
     if (bl >= nb) return;
-    const int b = b0 + bl, tid = threadIdx.x;
-    if (j >= fv.n_feat[b]) return;
+    const int b = b0 + bl, wave = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
+    const int F = fv.n_feat[b];
+    if (jbase >= F) return;
     const int C = fv.n_clones[b], ld = cv.ldp;
     const double* P = cov_ptr(cv, b);
-    const size_t oidx = (size_t)b * fv.fmax + j;
-    const int a = fv.anchor[oidx];
-    const double* pf = fv.pf + oidx * 3;
-    const double px = pf[0], py = pf[1], pz = pf[2];
-    dbg_stamp(24);
-    load_gidx<CMAX, STEREO, true>(fv, b, C, sh.f);
-    const int rows = feat_phase1<CMAX, STEREO, true>(fv, op, b, j, C, sh.f);
-    const int nobs = sh.f.nobs, rho = rows - 3;
-    double* const rec = sh.recbuf;                // global stores wait in vmcnt with the loads (gfx9): keep them off the critical path
-    double* const rec_g = rec_out + oidx * rec_size(CMAX);
-    if (rho <= 0) {
-        if (tid == 0) { gamma_out[oidx] = __builtin_nan(""); accept_out[oidx] = 0; rec_g[0] = 0.0; }
-        return;
-    }
-    dbg_stamp(25);
-    double* const Nh = sh.nh;
-    double* const sums = Nh + CMAX * 12;
-    if (tid < nobs) {
-        const int so = sh.f.slot[tid];
-        const bool cn = so != a, pl = !(op.selected_variant && so == a);
-        sh.cna[tid] = cn;
-        sh.pfl[tid] = pl;
-        double* ro = rec + REC_HDR + REC_OBS * tid;
-        ro[0] = so; ro[1] = cn ? 1.0 : 0.0; ro[2] = pl ? 1.0 : 0.0;
-        double N[9], h[3];
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-#pragma unroll
-            for (int m2 = 0; m2 < 3; ++m2) {
-                double sN = 0.0;
-#pragma unroll
-                for (int q = 0; q < RPO; ++q) sN += sh.f.G[tid][q][m] * sh.f.G[tid][q][m2];
-                N[3 * m + m2] = sN;
-                ro[3 + 3 * m + m2] = sN;
-            }
-            double hh = 0.0;
-#pragma unroll
-            for (int q = 0; q < RPO; ++q) hh += sh.f.G[tid][q][m] * sh.f.res[tid][q];
-            h[m] = hh;
-            ro[12 + m] = hh;
-            Nh[tid * 12 + 9 + m] = hh;
-        }
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Nh[tid * 12 + i] = N[i];
-        if (STEREO) {
-            double Ni[9];
-            inv3sym(N, Ni);
-            double rr = 0.0;
-#pragma unroll
-            for (int q = 0; q < RPO; ++q) rr += sh.f.res[tid][q] * sh.f.res[tid][q];
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const double um = Ni[3 * m] * h[0] + Ni[3 * m + 1] * h[1] + Ni[3 * m + 2] * h[2];
-                sh.u[tid][m] = um;
-                rr -= h[m] * um;
-#pragma unroll
-                for (int m2 = 0; m2 < 3; ++m2) sh.Ninv[tid][3 * m + m2] = Ni[3 * m + m2];
-            }
-            sh.rperp[tid] = rr;
-        }
-    }
-    if (tid == 0) {
-        unsigned long long sm = 0ULL;
-        for (int o = 0; o < nobs; ++o) sm |= 1ULL << sh.f.slot[o];
-        rec[0] = nobs; rec[1] = a; rec[2] = px; rec[3] = py; rec[4] = pz; rec[5] = (double)sm;
-    }
-    __syncthreads();
-    // sums for k_feat_gram2 (this kernel is VALU-bound, the gram kernel latency-bound: the reduction is cheaper here)
-    if (tid < 21) {
-        const int anch = tid >= 12, comp = anch ? tid - 12 : tid;
-        double t[CMAX];
-#pragma unroll
-        for (int o = 0; o < CMAX; ++o) t[o] = (o < nobs && (!anch || sh.cna[o])) ? Nh[o * 12 + comp] : 0.0;      // all loads in flight
-        double sacc = 0.0;
-#pragma unroll
-        for (int o = 0; o < CMAX; ++o) sacc += t[o];
-        sums[tid] = sacc;
-    }
-    __syncthreads();
-    if (tid < 21) {
-        double v = sums[tid];
-        if (tid < 9) { double Nsi[9]; inv3sym(sums, Nsi); v = Nsi[tid]; }
-        rec[6 + tid] = v;
-    }
-    __syncthreads();
-    dbg_stamp(26);
-    // ---- Su = D Pcc D^T in 3x3 blocks.  With U_o = P(th_o, th_a), V_o = P(p_o, th_a):
-    //        Su[o][o'] = T_oo' - cn' R_o - cn R_o'^T + cn cn' Q
-    //        T_oo' = cn cn' X P(th_o,th_o') X^T + cn pl' X^T P(th_o,p_o') + pl cn' P(p_o,th_o') X + pl pl' P(p_o,p_o')
-    //        R_o = cn X U_o X^T + pl V_o X   (per observation),   Q = X P(th_a,th_a) X^T   (per feature)
-    //      so a pair needs 4 blocks of P instead of 9.  Pairs with the anchor's own observation (cn' = 0) only keep the
-    //      p-column terms; they are built in the per-observation pass, which leaves nobs-1 choose 2 (+diag) <= 55
-    //      generic pairs: ONE round of the wave for an 11-clone window instead of two.
-    const int ga = sh.f.gidx[a];
     auto ldblk = [&](int r0, int c0, double M[9]) {
 #pragma unroll
         for (int m = 0; m < 3; ++m)
 #pragma unroll
             for (int q = 0; q < 3; ++q) M[3 * m + q] = P[(r0 + m) + (size_t)(c0 + q) * ld];
     };
-    auto finish_pair = [&](int o, int o2, double Su[9]) {        // o >= o2: K block (stereo: + s^2 N^-1 on the diagonal)
+    auto finish_pair = [&](SH& sh, int o, int o2, double Su[9]) {        // o >= o2: K block (stereo: + s^2 N^-1 on the diagonal)
         const int q = o * (o + 1) / 2 + o2;
         if (STEREO) {
             if (o == o2) {
@@ -227,64 +141,206 @@ __device__ __forceinline__ void gate3_body(
 #pragma unroll
             for (int i = 0; i < 9; ++i) sh.blk[q][i] = Su[i];
         } else {
-            double GS[2][3];
+            double GSm[2][3];
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int m2 = 0; m2 < 3; ++m2)
-                    GS[r][m2] = sh.f.G[o][r][0] * Su[m2] + sh.f.G[o][r][1] * Su[3 + m2] + sh.f.G[o][r][2] * Su[6 + m2];
+                    GSm[r][m2] = sh.f.G[o][r][0] * Su[m2] + sh.f.G[o][r][1] * Su[3 + m2] + sh.f.G[o][r][2] * Su[6 + m2];
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int r2 = 0; r2 < 2; ++r2) {
-                    double v = GS[r][0] * sh.f.G[o2][r2][0] + GS[r][1] * sh.f.G[o2][r2][1] + GS[r][2] * sh.f.G[o2][r2][2];
+                    double v = GSm[r][0] * sh.f.G[o2][r2][0] + GSm[r][1] * sh.f.G[o2][r2][1] + GSm[r][2] * sh.f.G[o2][r2][2];
                     if (o == o2 && r == r2) v += op.var;
                     sh.blk[q][(D * r + r2) % (D * D)] = v;
                 }
         }
     };
-    const unsigned long long amask = __ballot(tid < nobs && sh.f.slot[tid < nobs ? tid : 0] == a);
-    const int oa = amask ? __ffsll((long long)amask) - 1 : -1;          // the anchor clone's own observation, if any
-    if (tid < nobs) {
-        const int o = tid, gc = sh.f.gidx[sh.f.slot[o]];
-        const double cn = sh.cna[o] ? 1.0 : 0.0, pl = sh.pfl[o] ? 1.0 : 0.0;
-        double U[9], V[9], Paa[9], T1[9], T2[9];
-        ldblk(gc, ga, U);
-        ldblk(gc + 3, ga, V);
-        ldblk(ga, ga, Paa);
-        double B1[9], B2[9], Bp[9];
-        if (oa >= 0) { ldblk(gc, ga + 3, B1); ldblk(ga, ga + 3, B2); ldblk(gc + 3, ga + 3, Bp); }
-        mulXt(U, px, py, pz, T1);
-        mulX(T1, px, py, pz, T2);                 // X U X^T
-        mulX(V, px, py, pz, T1);                  // V X
-#pragma unroll
-        for (int i = 0; i < 9; ++i) sh.Rb[o][i] = cn * T2[i] + pl * T1[i];
-        mulXt(Paa, px, py, pz, T1);
-        mulX(T1, px, py, pz, T2);
-        if (tid == 0) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) sh.Qb[i] = T2[i];
+
+    // ================= FRONT: wave 0, lane group f = lane / GS handles feature jbase + f =================
+    if (wave == 0) {
+        const int f = lane / GS, sl = lane - GS * f;               // feature of this lane group, lane within the group
+        const unsigned long long gmask = GS == 64 ? ~0ULL : ((1ULL << GS) - 1ULL);
+        SH& sh = sh4[f];
+        const int j = jbase + f;
+        const bool jok = j < F;
+        const size_t oidx = (size_t)b * fv.fmax + (jok ? j : 0);
+        const int a = fv.anchor[oidx];
+        const double* pf = fv.pf + oidx * 3;
+        const double px = pf[0], py = pf[1], pz = pf[2];
+        const unsigned long long mask = jok ? fv.obs_mask[oidx] : 0ULL;
+        if (sl < C) sh.f.gidx[sl] = fv.clone_idx[(size_t)b * fv.cmax + sl];
+        // ---- per window slot: q = R^T(p_f - p), projection Jacobians, residuals (RemoveLostUpdate.cpp:435-506) --------
+        bool valid = false;
+        double Gm[RPO][3], rs[RPO];
+        if (sl < C && ((mask >> sl) & 1ULL)) {
+            const double* R = fv.clone_R + ((size_t)b * fv.cmax + sl) * 9;
+            const double* pp = fv.clone_p + ((size_t)b * fv.cmax + sl) * 3;
+            const double* z = fv.uv + (oidx * fv.cmax + sl) * 4;
+            double zz[4] = { z[0], z[1], 0.0, 0.0 };
+            if (STEREO) { zz[2] = z[2]; zz[3] = z[3]; }
+            valid = feat_obs<STEREO>(R, pp, zz, px, py, pz, op, Gm, rs);
         }
-        if (oa >= 0) {                            // pair (o, anchor obs): cn' = 0
-            const double pl2 = sh.pfl[oa] ? 1.0 : 0.0;
+        const unsigned long long vm = (__ballot(valid) >> (GS * f)) & gmask;
+        const int nobs = __popcll(vm);
+        if (valid) {
+            const int od = __popcll(vm & ((1ULL << sl) - 1ULL));
+            sh.f.slot[od] = sl;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) B1[i] -= B2[i];
-            mulXt(B1, px, py, pz, T1);            // X^T (P(th_o,p_a) - P(th_a,p_a))
-            double Su[9];
+            for (int q = 0; q < RPO; ++q) {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) Su[i] = cn * pl2 * T1[i] + pl * pl2 * Bp[i];
-            if (o >= oa) finish_pair(o, oa, Su);
-            else {
-                double St[9];
+                for (int m = 0; m < 3; ++m) sh.f.G[od][q][m] = Gm[q][m];
+                sh.f.res[od][q] = rs[q];
+            }
+        }
+        const bool fok = jok && RPO * nobs - 3 > 0;
+        double* const rec = sh.recbuf;            // global stores wait in vmcnt with the loads (gfx9): the record is staged
+        if (sl == 0) {
+            sh.f.nobs = fok ? nobs : 0;
+            if (jok && !fok) { gamma_out[oidx] = __builtin_nan(""); accept_out[oidx] = 0; rec_out[oidx * rec_size(CMAX)] = 0.0; }
+        }
+        wave_sync();
+        double* const Nh = sh.nh;
+        double* const sums = Nh + CMAX * 12;
+        if (fok && sl < nobs) {
+            const int so = sh.f.slot[sl];
+            const bool cn = so != a, pl = !(op.selected_variant && so == a);
+            sh.cna[sl] = cn;
+            sh.pfl[sl] = pl;
+            double* ro = rec + REC_HDR + REC_OBS * sl;
+            ro[0] = so; ro[1] = cn ? 1.0 : 0.0; ro[2] = pl ? 1.0 : 0.0;
+            double N[9], h[3];
 #pragma unroll
-                for (int m = 0; m < 3; ++m)
+            for (int m = 0; m < 3; ++m) {
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) St[3 * m + q] = Su[3 * q + m];
-                finish_pair(oa, o, St);
+                for (int m2 = 0; m2 < 3; ++m2) {
+                    double sN = 0.0;
+#pragma unroll
+                    for (int q = 0; q < RPO; ++q) sN += sh.f.G[sl][q][m] * sh.f.G[sl][q][m2];
+                    N[3 * m + m2] = sN;
+                    ro[3 + 3 * m + m2] = sN;
+                }
+                double hh = 0.0;
+#pragma unroll
+                for (int q = 0; q < RPO; ++q) hh += sh.f.G[sl][q][m] * sh.f.res[sl][q];
+                h[m] = hh;
+                ro[12 + m] = hh;
+                Nh[sl * 12 + 9 + m] = hh;
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Nh[sl * 12 + i] = N[i];
+            if (STEREO) {
+                double Ni[9];
+                inv3sym(N, Ni);
+                double rr = 0.0;
+#pragma unroll
+                for (int q = 0; q < RPO; ++q) rr += sh.f.res[sl][q] * sh.f.res[sl][q];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const double um = Ni[3 * m] * h[0] + Ni[3 * m + 1] * h[1] + Ni[3 * m + 2] * h[2];
+                    sh.u[sl][m] = um;
+                    rr -= h[m] * um;
+#pragma unroll
+                    for (int m2 = 0; m2 < 3; ++m2) sh.Ninv[sl][3 * m + m2] = Ni[3 * m + m2];
+                }
+                sh.rperp[sl] = rr;
+            }
+        }
+        if (fok && sl == 0) {
+            unsigned long long sm = 0ULL;
+            for (int o = 0; o < nobs; ++o) sm |= 1ULL << sh.f.slot[o];
+            rec[0] = nobs; rec[1] = a; rec[2] = px; rec[3] = py; rec[4] = pz; rec[5] = (double)sm;
+        }
+        wave_sync();
+        // sums for k_feat_gram2 (this kernel is VALU-bound, the gram kernel latency-bound: the reduction is cheaper here)
+        if (fok) {
+            for (int cmp = sl; cmp < 21; cmp += GS) {
+                const int anch = cmp >= 12, comp = anch ? cmp - 12 : cmp;
+                double tt[CMAX];
+#pragma unroll
+                for (int o = 0; o < CMAX; ++o) tt[o] = (o < nobs && (!anch || sh.cna[o])) ? Nh[o * 12 + comp] : 0.0;      // all loads in flight
+                double sacc = 0.0;
+#pragma unroll
+                for (int o = 0; o < CMAX; ++o) sacc += tt[o];
+                sums[cmp] = sacc;
+            }
+        }
+        wave_sync();
+        if (fok) {
+            for (int cmp = sl; cmp < 21; cmp += GS) {
+                double v = sums[cmp];
+                if (cmp < 9) { double Nsi[9]; inv3sym(sums, Nsi); v = Nsi[cmp]; }
+                rec[6 + cmp] = v;
+            }
+        }
+        wave_sync();
+        // ---- Su = D Pcc D^T in 3x3 blocks.  With U_o = P(th_o, th_a), V_o = P(p_o, th_a):
+        //        Su[o][o'] = T_oo' - cn' R_o - cn R_o'^T + cn cn' Q
+        //        T_oo' = cn cn' X P(th_o,th_o') X^T + cn pl' X^T P(th_o,p_o') + pl cn' P(p_o,th_o') X + pl pl' P(p_o,p_o')
+        //        R_o = cn X U_o X^T + pl V_o X   (per observation),   Q = X P(th_a,th_a) X^T   (per feature)
+        //      so a pair needs 4 blocks of P instead of 9.  Pairs with the anchor's own observation (cn' = 0) only keep
+        //      the p-column terms; they are built here, in the per-observation pass, which leaves nobs-1 choose 2 (+diag)
+        //      <= 55 generic pairs for the back end: ONE round of the wave for an 11-clone window instead of two.
+        const bool olane = fok && sl < nobs;
+        const unsigned long long amask = (__ballot(olane && sh.f.slot[olane ? sl : 0] == a) >> (GS * f)) & gmask;
+        const int oa = amask ? __ffsll((long long)amask) - 1 : -1;          // the anchor clone's own observation, if any
+        if (sl == 0) sh.oa = oa;
+        if (olane) {
+            const int ga = sh.f.gidx[a];
+            const int o = sl, gc = sh.f.gidx[sh.f.slot[o]];
+            const double cn = sh.cna[o] ? 1.0 : 0.0, pl = sh.pfl[o] ? 1.0 : 0.0;
+            double U[9], V[9], Paa[9], T1[9], T2[9];
+            ldblk(gc, ga, U);
+            ldblk(gc + 3, ga, V);
+            ldblk(ga, ga, Paa);
+            double B1[9], B2[9], Bp[9];
+            if (oa >= 0) { ldblk(gc, ga + 3, B1); ldblk(ga, ga + 3, B2); ldblk(gc + 3, ga + 3, Bp); }
+            mulXt(U, px, py, pz, T1);
+            mulX(T1, px, py, pz, T2);                 // X U X^T
+            mulX(V, px, py, pz, T1);                  // V X
+#pragma unroll
+            for (int i = 0; i < 9; ++i) sh.Rb[o][i] = cn * T2[i] + pl * T1[i];
+            mulXt(Paa, px, py, pz, T1);
+            mulX(T1, px, py, pz, T2);
+            if (sl == 0) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) sh.Qb[i] = T2[i];
+            }
+            if (oa >= 0) {                            // pair (o, anchor obs): cn' = 0
+                const double pl2 = sh.pfl[oa] ? 1.0 : 0.0;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) B1[i] -= B2[i];
+                mulXt(B1, px, py, pz, T1);            // X^T (P(th_o,p_a) - P(th_a,p_a))
+                double Su[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Su[i] = cn * pl2 * T1[i] + pl * pl2 * Bp[i];
+                if (o >= oa) finish_pair(sh, o, oa, Su);
+                else {
+                    double St[9];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) St[3 * m + q] = Su[3 * q + m];
+                    finish_pair(sh, oa, o, St);
+                }
             }
         }
     }
     __syncthreads();
+
+    // ================= BACK: wave w finishes feature jbase + w =================
+    SH& sh = sh4[wave];
+    const int tid = lane;
+    const int j = jbase + wave;
+    if (j >= F) return;
+    const int nobs = sh.f.nobs;
+    if (nobs == 0) return;                            // nothing to gate (reported by the front)
+    const size_t oidx = (size_t)b * fv.fmax + j;
+    double* const rec = sh.recbuf;
+    double* const rec_g = rec_out + oidx * rec_size(CMAX);
+    const double px = rec[2], py = rec[3], pz = rec[4];
+    const int oa = sh.oa;
     {
         const int nred = oa >= 0 ? nobs - 1 : nobs, npair = nred * (nred + 1) / 2;
         for (int q = tid; q < npair; q += WAVE) {
@@ -312,11 +368,10 @@ __device__ __forceinline__ void gate3_body(
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
                     Su[3 * m + k] += cn * pl2 * T1[3 * m + k] + pl * cn2 * T2[3 * m + k] - cn2 * sh.Rb[o][3 * m + k] - cn * sh.Rb[o2][3 * k + m];
-            finish_pair(o, o2, Su);
+            finish_pair(sh, o, o2, Su);
         }
     }
-    __syncthreads();
-    dbg_stamp(27);
+    wave_sync();
     {
         // ---- blocked LDL^T on the matrix cores --------------------------------------------------------
         // The bordered matrix (K padded with unit pivots to KP rows, then the 4 rows of W^T) is held as 16x16
@@ -377,7 +432,6 @@ __device__ __forceinline__ void gate3_body(
                 }
             }
         }
-        dbg_stamp(28);
         wave_sync();                              // blk is dead from here on: its LDS becomes the panel buffer
 #pragma unroll
         for (int k = 0; k < KP / 4; ++k) {
@@ -435,7 +489,6 @@ __device__ __forceinline__ void gate3_body(
                 wave_sync();
             }
         }
-        dbg_stamp(29);
         // border block: tile (NTL-1, NTL-1), rows KP..KP+3 = local 4..7 -> r = 1, kq = 0..3; cols local 4..7
         if (l15 >= 4 && l15 < 8) sh.bz[kq * 4 + (l15 - 4)] = T[NLT - 1][1];
         wave_sync();
@@ -460,7 +513,6 @@ __device__ __forceinline__ void gate3_body(
             gamma_out[oidx] = g;
             accept_out[oidx] = ok ? 1 : 0;
         }
-        dbg_stamp(30);
         for (int e = tid; e < REC_HDR + REC_OBS * nobs; e += WAVE) rec_g[e] = rec[e];
         return;
     }

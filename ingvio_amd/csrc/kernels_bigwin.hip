@@ -22,7 +22,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1))) vo
     CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out,
     int* __restrict__ accept_out, double* __restrict__ rec_out)
 {
-    gate3_body<BIG_CMAX, STEREO>(cv, fv, op, b0, nb, fmax_used, gamma_out, accept_out, rec_out);
+    gate3_body<BIG_CMAX, STEREO, 1>(cv, fv, op, b0, nb, fmax_used, gamma_out, accept_out, rec_out);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -18,14 +18,17 @@
 
 #include "gate_kernel.h"
 
-// K3 + K5 for the window classes 6 / 11 / 16: one wave per (feature, filter), see gate_kernel.h.  Tiles in VGPRs
-// (no AGPR copies), 4 waves per SIMD.
+// K3 + K5 for the window classes 6 / 11 / 16, see gate_kernel.h: workgroups of GATE_FPW waves = GATE_FPW features of one
+// filter; with GATE_FPW > 1 wave 0 runs the per-observation front for all of them (64 / GATE_FPW lanes each), then one
+// wave per feature.  Measured on MI355X (config 2): 1 -> 0.435 ms, 2 -> 0.435 ms, 4 -> 0.466 ms (the front is bound by
+// the latency of its loads, not by issue slots), hence 1.  Tiles in VGPRs (no AGPR copies), 4 waves per SIMD.
+#define GATE_FPW 1
 template <int CMAX, bool STEREO>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_feat_gate3(
+__global__ __launch_bounds__(GATE_FPW * WAVE) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_feat_gate3(
     CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out,
     int* __restrict__ accept_out, double* __restrict__ rec_out)
 {
-    gate3_body<CMAX, STEREO>(cv, fv, op, b0, nb, fmax_used, gamma_out, accept_out, rec_out);
+    gate3_body<CMAX, STEREO, GATE_FPW>(cv, fv, op, b0, nb, fmax_used, gamma_out, accept_out, rec_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -720,7 +723,7 @@ static void launch_ft(const FactoredLaunch& L, hipStream_t st)
 {
     if (L.stage == 0) {
         const int nb8 = (L.nb + 7) / 8 * 8;
-        hipLaunchKernelGGL((k_feat_gate3<CMAX, STEREO>), dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st,
+        hipLaunchKernelGGL((k_feat_gate3<CMAX, STEREO>), dim3(nb8 * ((L.fmax_used + GATE_FPW - 1) / GATE_FPW)), dim3(GATE_FPW * WAVE), 0, st,
                            L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
     } else {
         constexpr size_t uni = sizeof(Gram2Batch<CMAX>) > sizeof(Gram2Out<CMAX>) ? sizeof(Gram2Batch<CMAX>) : sizeof(Gram2Out<CMAX>);
