@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Shader-clock phase breakdown of the instrumented kernels (block (0,0) only); debugging aid."""
+"""Shader-clock phase breakdown of the instrumented kernels (block (0,0) lane 0 only: the oldest wave of its SIMD, i.e.
+un-contended latency, not throughput); debugging aid.  Needs a build with INGVIO_DBG_STAMPS=1."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import bench
@@ -15,5 +16,5 @@ d = ctx.debug_read(48)
 def seg(name, idx):
     print(name, [d[b] - d[a] for a, b in zip(idx[:-1], idx[1:])], "total", d[idx[-1]] - d[idx[0]])
 seg("info_update [assemble,K1,GJ,T]", [0, 1, 2, 3, 4])
-seg("gate3 [phase1, record+sums, pairs, build, panels, gamma]", [24, 25, 26, 27, 28, 29, 30]); seg("gram2 prologue", [32, 33]); seg("gram2 last batch [P0(store+barrier),P2,P3a,P3b]", [34, 35, 37, 38, 41]); seg("gram2 epilogue", [39, 40]); seg("gram2 total", [32, 40])
+seg("gram2 prologue", [32, 33]); seg("gram2 last batch [P0(store+barrier),P2,P3a,P3b]", [34, 35, 37, 38, 41]); seg("gram2 epilogue", [39, 40]); seg("gram2 total", [32, 40])
 seg("propagate [compose,gnss,strip,AA]", [16, 17, 18, 19, 20])
