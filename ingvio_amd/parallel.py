@@ -21,6 +21,7 @@ class Group:
         self.dist = None
         self.device = None
         if self.world > 1:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL)
             import torch
             import torch.distributed as dist
             if backend is None:
