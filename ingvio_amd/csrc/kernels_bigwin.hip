@@ -309,6 +309,7 @@ __global__ __launch_bounds__(IB_NT, 1) void k_info_update_big(
     }
     const double* P = cov_ptr(cv, b);
     const double var = noise_all[bl];
+    dbg_stamp(48);
     for (int c = tid; c < NC; c += IB_NT) {
         const int cc = c < ncol ? c : 0;
         sCol[c] = fv.clone_idx[(size_t)b * fv.cmax + cc / 6] + cc % 6;
@@ -321,12 +322,20 @@ __global__ __launch_bounds__(IB_NT, 1) void k_info_update_big(
         double s = 0.0;
         if (i < ncol && (j < ncol || j == NC)) {
             const size_t src = (size_t)i * (ncol + 1) + (j == NC ? ncol : j);
-            for (int g = 0; g < G; ++g)
-                if (chunk_used[bl * G + g]) s += Apart[((size_t)bl * G + g) * rstride + src];
+            for (int g0 = 0; g0 < G; g0 += 8) {                               // eight partial loads in flight
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int g = g0 + u;
+                    t[u] = (g < G && chunk_used[bl * G + g]) ? Apart[((size_t)bl * G + g) * rstride + src] : 0.0;
+                }
+                s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+            }
         }
         Wk[(size_t)i * LA + NC + j] = s;
     }
     __syncthreads();
+    dbg_stamp(49);
     const bool fused = marg_idx && marg_idx[bl] >= 0;
     bool contig_t = true;
     for (int c = tid; c < ncol; c += IB_NT) contig_t = contig_t && (sCol[c] == sCol[0] + c);
@@ -341,11 +350,18 @@ __global__ __launch_bounds__(IB_NT, 1) void k_info_update_big(
             const int ia = min(16 * ti + l15, NC - 1), jb = min(16 * tj + l15, NC - 1);
             const size_t gjb = (size_t)sCol[jb] * ld;
             double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
-            for (int s4 = 0; s4 < NC / 4; ++s4) {
-                const int k = 4 * s4 + kq;
-                const double af = Wk[(size_t)ia * LA + NC + k];               // A[i][k]
-                const double bf = P[sCol[k] + gjb];                           // Pcc[k][j]
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+            constexpr int UF = 9;                                             // operand loads of 9 steps in flight
+            static_assert((NC / 4) % UF == 0, "unroll factor");
+            for (int s0 = 0; s0 < NC / 4; s0 += UF) {
+                double af[UF], bf[UF];
+#pragma unroll
+                for (int u = 0; u < UF; ++u) {
+                    const int k = 4 * (s0 + u) + kq;
+                    af[u] = Wk[(size_t)ia * LA + NC + k];                     // A[i][k]
+                    bf[u] = P[sCol[k] + gjb];                                 // Pcc[k][j]
+                }
+#pragma unroll
+                for (int u = 0; u < UF; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u], bf[u], acc, 0, 0, 0);
             }
             const int j = 16 * tj + l15;
 #pragma unroll
@@ -356,6 +372,7 @@ __global__ __launch_bounds__(IB_NT, 1) void k_info_update_big(
         }
     }
     __syncthreads();
+    dbg_stamp(50);
     // Blocked Gauss-Jordan with implicit partial pivoting, panels of PB pivots.  The panel's columns live in LDS only
     // (nothing left of the current pivot is ever read again); the columns right of the panel are read and written ONCE
     // per panel:  W[i][j] -= sum_k F[k][i] R_k[j], with F[k][i] the multipliers of pivot k (0 at its own pivot row) and
@@ -402,18 +419,18 @@ __global__ __launch_bounds__(IB_NT, 1) void k_info_update_big(
             double r0[PB], r1[PB];
 #pragma unroll
             for (int kk = 0; kk < PB; ++kk) { r0[kk] = j0 < LA ? Rw[kk][j0] : 0.0; r1[kk] = j1 < LA ? Rw[kk][j1] : 0.0; }
-            constexpr int RG = IB_NT / 256;
-            for (int ib = ty; ib < NC; ib += 4 * RG) {
-                double w0[4], w1[4];
+            constexpr int RG = IB_NT / 256, RF = 4;                           // rows in flight per thread (measured: 4 beats 8 and 14)
+            for (int ib = ty; ib < NC; ib += RF * RG) {
+                double w0[RF], w1[RF];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < RF; ++u) {
                     const int i = ib + RG * u;
                     const double* wr = Wk + (size_t)(i < NC ? i : 0) * LA;
                     w0[u] = (i < NC && j0 < LA) ? wr[j0] : 0.0;
                     w1[u] = (i < NC && j1 < LA) ? wr[j1] : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < RF; ++u) {
                     const int i = ib + RG * u;
                     if (i < NC) {
                         double a0 = w0[u], a1 = w1[u];
@@ -428,6 +445,7 @@ __global__ __launch_bounds__(IB_NT, 1) void k_info_update_big(
         }
         __syncthreads();
     }
+    dbg_stamp(51);
     // solution rows: row i holds component ks = sInv[i], scaled by its pivot
     double* Mg = Mall + (size_t)bl * mstride;
     for (int e = tid; e < NC * (NC + 1); e += IB_NT) {
@@ -446,6 +464,7 @@ __global__ __launch_bounds__(IB_NT, 1) void k_info_update_big(
         }
     }
     if (tid == 0) { m_out[bl] = ncol; nc_out[bl] = ncol; pc_base_out[bl] = zero_copy ? sCol[0] : -1; }
+    dbg_stamp(52);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -561,6 +580,7 @@ __global__ __launch_bounds__(256, 1) void k_info_apply_big(
 }
 
 // ---------------------------------------------------------------------------------------------
+int dbg_read_bigwin(long long* out, int n) { return dbg_read_local(out, n); }
 size_t bigwin_sg_doubles(int G) { return (size_t)G * BIG_CMAX * BIG_CMAX * GB_SW; }
 size_t bigwin_wk_doubles() { return (size_t)BIG_NC * (2 * BIG_NC + 1); }
 int bigwin_rec_size() { return rec_size(BIG_CMAX); }

@@ -42,3 +42,4 @@ size_t bigwin_sg_doubles(int G);
 size_t bigwin_wk_doubles();
 int bigwin_rec_size();
 int bigwin_cmax();
+int dbg_read_bigwin(long long* out, int n);
