@@ -341,14 +341,16 @@ __global__ __launch_bounds__(IB_NT, 1) void k_info_update_big(
     for (int c = tid; c < ncol; c += IB_NT) contig_t = contig_t && (sCol[c] == sCol[0] + c);
     const int contig = __syncthreads_and(contig_t);
     const bool zero_copy = fused && contig && sCol[0] + MP <= ld;
-    // K1 = A Pcc + s^2 I on the matrix cores: wave w owns tiles t = w, w + 16, ...
+    // K1 = A Pcc + s^2 I on the matrix cores: wave w owns tiles t = w, w + 16, ...  Computed as K1^T = Pcc A (both
+    // symmetric) so that both operand loads run along the fast index (A-operand: 16 consecutive clone columns of P,
+    // B-operand: 16 consecutive entries of a row of A); only the tile store is strided.
     {
         constexpr int TT = (NC + 15) / 16, NWV = IB_NT / WAVE;
         const int kq = lane >> 4, l15 = lane & 15;
         for (int t = wave; t < TT * TT; t += NWV) {
             const int ti = t / TT, tj = t - ti * TT;
             const int ia = min(16 * ti + l15, NC - 1), jb = min(16 * tj + l15, NC - 1);
-            const size_t gjb = (size_t)sCol[jb] * ld;
+            const int gia = sCol[ia];
             double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
             constexpr int UF = 9;                                             // operand loads of 9 steps in flight
             static_assert((NC / 4) % UF == 0, "unroll factor");
@@ -357,17 +359,17 @@ __global__ __launch_bounds__(IB_NT, 1) void k_info_update_big(
 #pragma unroll
                 for (int u = 0; u < UF; ++u) {
                     const int k = 4 * (s0 + u) + kq;
-                    af[u] = Wk[(size_t)ia * LA + NC + k];                     // A[i][k]
-                    bf[u] = P[sCol[k] + gjb];                                 // Pcc[k][j]
+                    af[u] = P[gia + (size_t)sCol[k] * ld];                    // Pcc[i][k]
+                    bf[u] = Wk[(size_t)k * LA + NC + jb];                     // A[k][j]
                 }
 #pragma unroll
                 for (int u = 0; u < UF; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u], bf[u], acc, 0, 0, 0);
             }
-            const int j = 16 * tj + l15;
+            const int jc = 16 * tj + l15;                                     // acc[r] = K1^T[16 ti + kq + 4r][jc] = K1[jc][..]
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * ti + kq + 4 * r;
-                if (i < NC && j < NC) Wk[(size_t)i * LA + j] = acc[r] + (i == j ? var : 0.0);
+                if (i < NC && jc < NC) Wk[(size_t)jc * LA + i] = acc[r] + (i == jc ? var : 0.0);
             }
         }
     }
