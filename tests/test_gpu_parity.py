@@ -473,6 +473,36 @@ def test_large_window_selected_variant_and_cap(orc, C, stereo, cap):
     ctx2.close()
 
 
+@pytest.mark.parametrize("C,stereo", [(22, True), (28, False)])
+def test_large_window_update_in_place(orc, C, stereo):
+    """Large window without marginalisation (marg_idx = -1): the update runs IN PLACE and needs the copy of the clone
+    columns; one of the two filters of the batch, the other takes the fused out-of-place path.  Vs the oracle."""
+    from ingvio_amd import capi, host, synth
+    nb, F, n_gnss, n_lm = 2, 40, 6, 2
+    N = 21 + n_gnss + 3 * n_lm + 6 * C
+    ctx2 = capi.Context(batch=nb, n_max=((N + 15) // 16) * 16, c_max=C, f_max=F, m_max=64)
+    cases = []
+    for b in range(nb):
+        flt, step, frame, info = synth.build_case(lambda P, b=b: capi.DeviceCov(ctx2, b, P), host.imu_transition,
+                                                  seed=500 + b, F=F, C=C, n_gnss=n_gnss, n_landmarks=n_lm, stereo=stereo)
+        step = dict(step)
+        if b == 0:
+            step["marg_idx"] = -1
+        cases.append((flt, step, frame, info))
+    ocs = [orc.Cov(ctx2.cov_get(b), ld=ctx2.ldp) for b in range(nb)]
+    ctx2.snapshot()
+    ctx2.frame_stage(0, [c[1] for c in cases], [c[2] for c in cases], cases[0][1]["sigma"], 1, 0.2, 0.2)
+    for _ in range(2):
+        ctx2.frame_run(restore_prior=True)
+    dx, acc, rows = ctx2.frame_fetch()
+    for b in range(nb):
+        dxo, acco, gamo, m = orc.frame_update(ocs[b], cases[b][1], cases[b][2], max_accept=0, compress_rule=1)
+        assert np.array_equal(acc[b, :F], acco) and rows[b] == 6 * C
+        assert ctx2.n(b) == (N if b == 0 else N - 6)
+        assert rel_err(ctx2.cov_get(b), ocs[b].P) < 1e-10 and rel_err(dx[b, :N], dxo) < 1e-7
+    ctx2.close()
+
+
 def test_qr_compress(ctx):
     """K7 on an explicit H_large (the SPQR call sites): H_thin^T H_thin == H^T H, H_thin upper triangular;
     also on a rank-deficient matrix (Q9: rank n-6)."""
