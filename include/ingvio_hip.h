@@ -169,6 +169,27 @@ int ingvio_set_msckf_method(ingvio_ctx* ctx, int method);
 int ingvio_qr_compress(ingvio_ctx* ctx, const double* H, int ldh, int m, int n, const double* res,
                        double* H_thin, int ldt, double* r_thin);
 
+/* ---- feature triangulation ----------------------------------------------
+ * Triangulator::triangulateMonoObs / triangulateStereoObs (Triangulator.cpp:173-318, 320-359) for every feature of
+ * frames[0..nb): Levenberg-Marquardt on (x/z, y/z, 1/z) in the frame of the last observation, Huber weights, depth /
+ * parallax / convergence gates.  Of a frame only n_clones, clone_R, clone_p, n_feat, obs_mask and uv are used
+ * (pf, anchor, dof may be NULL; clone_idx must be valid state indices or 0).  Outputs per filter stride f_max:
+ * pf_out [nb][f_max][3] world points (0 where it failed), ok_out [nb][f_max].
+ * frames == NULL: triangulate the frames already staged by ingvio_frame_stage / ingvio_msckf_update; the results stay
+ * in the staged device frame (with mask_failed != 0 failed features lose their observation mask and drop out), so a
+ * following ingvio_frame_run uses them without a host round trip. */
+typedef struct {
+    int stereo;
+    double R_cl2cr[9];          /* row-major */
+    double t_cl2cr[3];
+    double trans_thres, huber_epsilon, conv_precision, init_damping;   /* Triangulator.h:67-70: 0.1, 0.01, 5e-7, 1e-3 */
+    int outer_loop_max_iter, inner_loop_max_iter;                      /* :71-72: 10, 10 */
+    double max_depth, min_depth;                                       /* :74-75: 60, 0.2 */
+    int mask_failed;
+} ingvio_tri_opts;
+int ingvio_triangulate(ingvio_ctx* ctx, int b0, int nb, const ingvio_msckf_frame* frames, const ingvio_tri_opts* opts,
+                       double* pf_out, int* ok_out);
+
 /* ---- one benchmark "update" for the whole batch ------------------------------
  * k-step propagation + clone + MSCKF update + marginalise one clone, all filters, no host
  * synchronisation between the stages.  stage() uploads inputs (outside any timed region),

@@ -26,7 +26,7 @@ EXPORTS = [
     "ingvio_append_independent", "ingvio_ekf_update", "ingvio_chi2_gamma", "ingvio_msckf_update", "ingvio_qr_compress",
     "ingvio_frame_stage", "ingvio_frame_run", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_select",
     "ingvio_profile_reset",
-    "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_debug_read",
+    "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_debug_read", "ingvio_triangulate",
 ]
 
 
@@ -312,6 +312,42 @@ class Context:
         self._chk(self.L.ingvio_frame_fetch(self.h, b0, nb, _d(dx), _i(acc), _i(rows)))
         return dx, acc, rows
 
+    # ---- triangulation (f-1) ------------------------------------------------------------------
+    def triangulate(self, b0, frames, stereo=True, mask_failed=False, **params):
+        """frames: list of frame dicts (clone_R, clone_p, obs_mask, uv, R_cl2cr, t_cl2cr; pf/anchor/dof unused), or None
+        for the staged frames.  Returns (pf[nb, f_max, 3], ok[nb, f_max])."""
+        pr = dict(trans_thres=0.1, huber_epsilon=0.01, conv_precision=5e-7, init_damping=1e-3, outer_loop_max_iter=10,
+                  inner_loop_max_iter=10, max_depth=60.0, min_depth=0.2)
+        pr.update(params)
+        o = TriOpts()
+        o.stereo = 1 if stereo else 0
+        ref = frames[0] if frames else None
+        Rl = f64(ref["R_cl2cr"]).reshape(-1) if ref is not None else np.eye(3).reshape(-1)
+        tl = f64(ref["t_cl2cr"]) if ref is not None else np.zeros(3)
+        if "R_cl2cr" in params:
+            Rl = f64(pr.pop("R_cl2cr")).reshape(-1)
+        if "t_cl2cr" in params:
+            tl = f64(pr.pop("t_cl2cr"))
+        for i in range(9):
+            o.R_cl2cr[i] = float(Rl[i])
+        for i in range(3):
+            o.t_cl2cr[i] = float(tl[i])
+        for k, v in pr.items():
+            setattr(o, k, v)
+        o.mask_failed = 1 if mask_failed else 0
+        if frames is None:
+            nb = self.batch - b0
+            fa = None
+            keeps = []
+        else:
+            nb = len(frames)
+            fa = (MsckfFrame * nb)(); keeps = []
+            for i in range(nb):
+                f, k = make_frame(frames[i]); fa[i] = f; keeps.append(k)
+        pf = np.zeros((nb, self.f_max, 3)); ok = np.zeros((nb, self.f_max), dtype=np.int32)
+        self._chk(self.L.ingvio_triangulate(self.h, b0, nb, fa, C.byref(o), _d(pf), _i(ok)))
+        return pf, ok
+
     # ---- profiling ---------------------------------------------------------------------------
     def profile_enable(self, on=True):
         self._chk(self.L.ingvio_profile_enable(self.h, 1 if on else 0))
@@ -327,6 +363,13 @@ class Context:
         names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); calls = (C.c_int * cap)()
         k = self.L.ingvio_profile_get(self.h, names, ms, calls, cap)
         return {names[i].decode(): (ms[i], calls[i]) for i in range(k)}
+
+
+class TriOpts(C.Structure):
+    _fields_ = [("stereo", C.c_int), ("R_cl2cr", C.c_double * 9), ("t_cl2cr", C.c_double * 3),
+                ("trans_thres", C.c_double), ("huber_epsilon", C.c_double), ("conv_precision", C.c_double),
+                ("init_damping", C.c_double), ("outer_loop_max_iter", C.c_int), ("inner_loop_max_iter", C.c_int),
+                ("max_depth", C.c_double), ("min_depth", C.c_double), ("mask_failed", C.c_int)]
 
 
 class DeviceCov:

@@ -6,6 +6,7 @@
 #include "launch_ekf.h"
 #include "launch_msckf.h"
 #include "launch_factored.h"
+#include "launch_tri.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -56,6 +57,7 @@ struct ingvio_ctx {
     int method;                    // 0 dense TSQR path, 1 factored (information-form) path
     int *d_accept, *d_used, *d_chunk_used, *d_colmap, *d_m, *d_nc, *d_status, *d_pcbase;
     double *d_big_sg, *d_big_wk;        // large-window workspaces (c_max > 16)
+    int* d_tri_ok;                      // [B][f_max] triangulation flags
     // staged frame state
     int st_k, st_stereo, st_enable_gnss, st_fmax_used;
     double st_sigma[4], st_scb, st_srw;
@@ -164,11 +166,11 @@ int stage_frames(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* fr, in
             memcpy(&cp[((size_t)i * cm + s) * 3], f.clone_p + 3 * s, 24);
         }
         for (int j = 0; j < f.n_feat; ++j) {
-            memcpy(&pf[((size_t)i * fm + j) * 3], f.pf + 3 * j, 24);
-            anc[(size_t)i * fm + j] = f.anchor[j];
-            if (f.anchor[j] < 0 || f.anchor[j] >= f.n_clones) return INGVIO_E_ARG;
+            if (f.pf) memcpy(&pf[((size_t)i * fm + j) * 3], f.pf + 3 * j, 24);
+            anc[(size_t)i * fm + j] = f.anchor ? f.anchor[j] : 0;
+            if (f.anchor && (f.anchor[j] < 0 || f.anchor[j] >= f.n_clones)) return INGVIO_E_ARG;
             mk[(size_t)i * fm + j] = f.obs_mask[j] & (f.n_clones >= 64 ? ~0ULL : ((1ULL << f.n_clones) - 1ULL));
-            dof[(size_t)i * fm + j] = f.dof[j];
+            dof[(size_t)i * fm + j] = f.dof ? f.dof[j] : 0;
             for (int s = 0; s < f.n_clones; ++s)
                 memcpy(&uv[(((size_t)i * fm + j) * cm + s) * 4], f.uv + ((size_t)j * f.n_clones + s) * 4, 32);
         }
@@ -328,6 +330,7 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     rc |= dalloc(c, &c->d_Rpart, (size_t)B * c->G * c->rstride); rc |= dalloc(c, &c->d_chunk_used, (size_t)B * c->G);
     rc |= dalloc(c, &c->d_H, (size_t)B * c->hstride); rc |= dalloc(c, &c->d_res, (size_t)B * c->mld);
     rc |= dalloc(c, &c->d_colmap, (size_t)B * c->cstride); rc |= dalloc(c, &c->d_m, B); rc |= dalloc(c, &c->d_nc, B); rc |= dalloc(c, &c->d_pcbase, B);
+    rc |= dalloc(c, &c->d_tri_ok, (size_t)B * fm);
     c->d_big_sg = nullptr; c->d_big_wk = nullptr;
     if (desc->c_max > 16) {
         rc |= dalloc(c, &c->d_big_sg, (size_t)B * bigwin_sg_doubles(c->G)); rc |= dalloc(c, &c->d_big_wk, (size_t)B * bigwin_wk_doubles());
@@ -349,7 +352,7 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
     void* ptrs[] = { c->Pbase, c->Psnap, c->d_cur, c->d_n, c->d_n_snap, c->d_Phi, c->d_G, c->d_dt, c->d_R, c->d_blk, c->d_gnss,
                      c->d_idx, c->d_clone_idx, c->d_nclones, c->d_nfeat, c->d_anchor, c->d_dof, c->d_clone_R, c->d_clone_p,
                      c->d_pf, c->d_uv, c->d_chi2, c->d_mask, c->d_gamma, c->d_accept, c->d_used, c->d_Rpart, c->d_chunk_used,
-                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk };
+                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk, c->d_tri_ok };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (c->own_stream) hipStreamDestroy(c->st);
@@ -600,6 +603,34 @@ int ingvio_msckf_update(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame*
         if (status[i] & 2) soft = INGVIO_NEG_DIAG;
     }
     return nb == 1 ? soft : (soft == INGVIO_NEG_DIAG ? soft : INGVIO_OK);
+}
+
+// Triangulator::triangulate{Mono,Stereo}Obs for every feature of the given (or staged) frames
+int ingvio_triangulate(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* frames, const ingvio_tri_opts* o,
+                       double* pf_out, int* ok_out)
+{
+    if (check_range(c, b0, nb) || !o) return INGVIO_E_ARG;
+    if (o->outer_loop_max_iter < 0 || o->inner_loop_max_iter < 0) return INGVIO_E_ARG;
+    int fmx = c->d.f_max;
+    if (frames) {
+        const int rc = stage_frames(c, b0, nb, frames, &fmx);
+        if (rc) return rc;
+        c->strip_ok = false;
+    } else if (!c->staged) return INGVIO_E_ARG;
+    TriLaunch L;
+    memset(&L, 0, sizeof L);
+    L.fv = fview(c); L.b0 = b0;
+    memcpy(L.R_lr, o->R_cl2cr, 72); memcpy(L.t_lr, o->t_cl2cr, 24);
+    L.trans_thres = o->trans_thres; L.huber_epsilon = o->huber_epsilon; L.conv_precision = o->conv_precision;
+    L.init_damping = o->init_damping; L.max_depth = o->max_depth; L.min_depth = o->min_depth;
+    L.outer_loop_max_iter = o->outer_loop_max_iter; L.inner_loop_max_iter = o->inner_loop_max_iter;
+    L.pf = c->d_pf; L.ok = c->d_tri_ok; L.mask_failed = o->mask_failed ? 1 : 0; L.mask_rw = c->d_mask;
+    if (launch_triangulate(L, nb, fmx > 0 ? fmx : 1, o->stereo, c->st)) return INGVIO_E_UNSUPPORTED;
+    const int fm = c->d.f_max;
+    if (pf_out) HIPCHK(c, hipMemcpyAsync(pf_out, c->d_pf + (size_t)b0 * fm * 3, 8 * (size_t)nb * fm * 3, hipMemcpyDeviceToHost, c->st));
+    if (ok_out) HIPCHK(c, hipMemcpyAsync(ok_out, c->d_tri_ok + (size_t)b0 * fm, sizeof(int) * (size_t)nb * fm, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return last_launch(c);
 }
 
 int ingvio_qr_compress(ingvio_ctx* c, const double* H, int ldh, int m, int n, const double* res, double* Ht, int ldt, double* rt)

@@ -864,3 +864,177 @@ void orc_frame_update_batch(int B, int threads, double* P, int* n_io, int ld,
         orc_frame_update(P + (size_t)b * ld * ld, n_io + b, ld, fr + b, ms + b,
                          dx + (size_t)b * ld, accepted + (size_t)b * fmax, NULL);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* f-1: triangulation (Triangulator.cpp)                                                        */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { double R[9], p[3], m[2]; } tri_obs;      /* camera pose in the world + its normalised measurement */
+
+/* rel = T_i^-1 * T_last (calcRelaSwPose, :70-88): maps last-camera coordinates into camera i */
+static void tri_rel(const tri_obs* oi, const tri_obs* ol, double Rr[9], double tr[3])
+{
+    double Rt[9];
+    m3_T(oi->R, Rt);
+    m3_mul(Rt, ol->R, Rr);
+    const double d[3] = { ol->p[0] - oi->p[0], ol->p[1] - oi->p[1], ol->p[2] - oi->p[2] };
+    m3_mulv(Rt, d, tr);
+}
+
+/* calcUnitCost (:107-125) */
+static double tri_unit_cost(const double m[2], const double Rr[9], const double tr[3], const double sol[3])
+{
+    double pf0[3], pf[3];
+    pf0[2] = 1.0 / sol[2];
+    pf0[0] = sol[0] * pf0[2];
+    pf0[1] = sol[1] * pf0[2];
+    m3_mulv(Rr, pf0, pf);
+    pf[0] += tr[0]; pf[1] += tr[1]; pf[2] += tr[2];
+    const double ex = m[0] - pf[0] / pf[2], ey = m[1] - pf[1] / pf[2];
+    return ex * ex + ey * ey;
+}
+
+static double tri_total_cost(const tri_obs* ob, int n, const double sol[3])      /* :127-137 */
+{
+    double c = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double Rr[9], tr[3];
+        if (i == n - 1) { m3_eye(Rr); tr[0] = tr[1] = tr[2] = 0.0; } else tri_rel(&ob[i], &ob[n - 1], Rr, tr);
+        c += tri_unit_cost(ob[i].m, Rr, tr, sol);
+    }
+    return c;
+}
+
+/* solve (A + lambda I) x = b for symmetric 3x3 (the reference uses Eigen's ldlt, :232) */
+static void tri_solve3(const double A[9], double lambda, const double b[3], double x[3])
+{
+    const double a00 = A[0] + lambda, a10 = A[3], a20 = A[6], a11 = A[4] + lambda, a21 = A[7], a22 = A[8] + lambda;
+    const double l10 = a10 / a00, l20 = a20 / a00;
+    const double d1 = a11 - l10 * a10;
+    const double l21 = (a21 - l20 * a10) / d1;
+    const double d2 = a22 - l20 * a20 - l21 * (a21 - l20 * a10);
+    const double y0 = b[0], y1 = b[1] - l10 * y0, y2 = b[2] - l20 * y0 - l21 * y1;
+    x[2] = y2 / d2;
+    x[1] = y1 / d1 - l21 * x[2];
+    x[0] = y0 / a00 - l10 * x[1] - l20 * x[2];
+}
+
+int orc_triangulate(const orc_tri_in* in, double pf[3])
+{
+    tri_obs ob[128];
+    int n = 0;
+    pf[0] = pf[1] = pf[2] = 0.0;
+    /* mono-equivalent observations in time order; a stereo pair contributes left, then right with the right camera's
+     * pose T_left * T_cl2cr^-1 (:331-354) */
+    double Rlr_t[9], tinv[3];
+    m3_T(in->R_lr, Rlr_t);
+    m3_mulv(Rlr_t, in->t_lr, tinv);
+    tinv[0] = -tinv[0]; tinv[1] = -tinv[1]; tinv[2] = -tinv[2];
+    for (int s = 0; s < in->C && n + 2 <= 128; ++s) {
+        if (!((in->mask >> s) & 1ULL)) continue;
+        const double* R = in->clone_R + 9 * s; const double* p = in->clone_p + 3 * s; const double* z = in->uv + 4 * s;
+        memcpy(ob[n].R, R, sizeof ob[n].R); memcpy(ob[n].p, p, sizeof ob[n].p);
+        ob[n].m[0] = z[0]; ob[n].m[1] = z[1];
+        ++n;
+        if (in->stereo) {
+            double t[3];
+            m3_mul(R, Rlr_t, ob[n].R);
+            m3_mulv(R, tinv, t);
+            ob[n].p[0] = p[0] + t[0]; ob[n].p[1] = p[1] + t[1]; ob[n].p[2] = p[2] + t[2];
+            ob[n].m[0] = z[2]; ob[n].m[1] = z[3];
+            ++n;
+        }
+    }
+    if (n <= 4) return 0;                                                         /* :183-187 */
+    const tri_obs* last = &ob[n - 1];
+    /* findLongestTrans (:31-68) */
+    double fl[3] = { last->m[0], last->m[1], 1.0 };
+    const double fn = v3_norm(fl);
+    fl[0] /= fn; fl[1] /= fn; fl[2] /= fn;
+    double fw[3];
+    m3_mulv(last->R, fl, fw);
+    double max_trans = -INFINITY;
+    int imax = n - 1;
+    for (int i = 0; i < n - 1; ++i) {
+        const double d[3] = { ob[i].p[0] - last->p[0], ob[i].p[1] - last->p[1], ob[i].p[2] - last->p[2] };
+        const double dot = fw[0] * d[0] + fw[1] * d[1] + fw[2] * d[2];
+        const double q[3] = { d[0] - fw[0] * dot, d[1] - fw[1] * dot, d[2] - fw[2] * dot };
+        const double tr = fabs(v3_norm(q));
+        if (tr > max_trans) { max_trans = tr; imax = i; }
+    }
+    if (max_trans < in->trans_thres) return 0;                                    /* :192 */
+    /* initial guess (:201-203, initDepth :90-105) */
+    double sol[3];
+    {
+        double Rr[9], tr[3], m1[3] = { last->m[0], last->m[1], 1.0 }, tm[3];
+        tri_rel(&ob[imax], last, Rr, tr);
+        m3_mulv(Rr, m1, tm);
+        const double* m2 = ob[imax].m;
+        const double A0 = tm[0] - m2[0] * tm[2], A1 = tm[1] - m2[1] * tm[2];
+        const double b0 = m2[0] * tr[2] - tr[0], b1 = m2[1] * tr[2] - tr[1];
+        const double depth = (A0 * b0 + A1 * b1) / (A0 * A0 + A1 * A1);
+        sol[0] = last->m[0]; sol[1] = last->m[1]; sol[2] = 1.0 / depth;
+    }
+    double total_cost = tri_total_cost(ob, n, sol);
+    double lambda = in->init_damping, delta_norm = INFINITY;
+    int inner = 0, outer = 0, reduced = 0;
+    do {                                                                           /* :215-262 */
+        double A[9] = { 0 }, b[3] = { 0 };
+        for (int i = 0; i < n; ++i) {                                              /* calcResJacobian :139-171 */
+            double Rr[9], tr[3];
+            if (i == n - 1) { m3_eye(Rr); tr[0] = tr[1] = tr[2] = 0.0; } else tri_rel(&ob[i], last, Rr, tr);
+            const double a[3] = { sol[0], sol[1], 1.0 };
+            double h[3];
+            m3_mulv(Rr, a, h);
+            h[0] += tr[0] * sol[2]; h[1] += tr[1] * sol[2]; h[2] += tr[2] * sol[2];
+            const double res[2] = { h[0] / h[2] - ob[i].m[0], h[1] / h[2] - ob[i].m[1] };
+            const double W00 = 1.0 / h[2], W02 = -h[0] / (h[2] * h[2]), W12 = -h[1] / (h[2] * h[2]);
+            /* U = [Rr(:,0:2) | tr],  J = W U (2x3) */
+            double J[6];
+            for (int c = 0; c < 3; ++c) {
+                const double u0 = c < 2 ? Rr[c] : tr[0], u1 = c < 2 ? Rr[3 + c] : tr[1], u2 = c < 2 ? Rr[6 + c] : tr[2];
+                J[c] = W00 * u0 + W02 * u2;
+                J[3 + c] = W00 * u1 + W12 * u2;
+            }
+            const double e = sqrt(res[0] * res[0] + res[1] * res[1]);
+            const double w = e <= in->huber_epsilon ? 1.0 : sqrt(2.0 * in->huber_epsilon / e);
+            const double w2 = w == 1.0 ? 1.0 : w * w;
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) A[3 * r + c] += w2 * (J[r] * J[c] + J[3 + r] * J[3 + c]);
+                b[r] -= w2 * (J[r] * res[0] + J[3 + r] * res[1]);
+            }
+        }
+        do {
+            double delta[3], ns[3];
+            tri_solve3(A, lambda, b, delta);
+            ns[0] = sol[0] + delta[0]; ns[1] = sol[1] + delta[1]; ns[2] = sol[2] + delta[2];
+            delta_norm = v3_norm(delta);
+            const double nc = tri_total_cost(ob, n, ns);
+            if (nc < total_cost) {
+                total_cost = nc; sol[0] = ns[0]; sol[1] = ns[1]; sol[2] = ns[2]; reduced = 1;
+                lambda = lambda / 10.0 > 1e-10 ? lambda / 10.0 : 1e-10;
+            } else {
+                reduced = 0;
+                lambda = lambda * 10 < 1e12 ? lambda * 10 : 1e12;
+            }
+        } while (inner++ < in->inner_loop_max_iter && !reduced);
+        inner = 0;                                                                 /* :259: the counter is reset, so the
+                                                                                      "both loops exhausted" test below can
+                                                                                      never fire; kept as written */
+    } while (outer++ < in->outer_loop_max_iter && delta_norm > in->conv_precision);
+    double pl[3];
+    pl[2] = 1.0 / sol[2]; pl[0] = sol[0] * pl[2]; pl[1] = sol[1] * pl[2];
+    if ((outer >= in->outer_loop_max_iter && inner >= in->inner_loop_max_iter) || delta_norm > in->conv_precision) return 0;
+    for (int i = 0; i < n; ++i) {                                                  /* :273-278 */
+        double Rr[9], tr[3], t[3];
+        if (i == n - 1) { m3_eye(Rr); tr[0] = tr[1] = tr[2] = 0.0; } else tri_rel(&ob[i], last, Rr, tr);
+        m3_mulv(Rr, pl, t);
+        if (t[2] + tr[2] <= in->min_depth) return 0;
+    }
+    if (pl[2] < in->min_depth || pl[2] > in->max_depth) return 0;                  /* :296-297 */
+    double w[3];
+    m3_mulv(last->R, pl, w);
+    w[0] += last->p[0]; w[1] += last->p[1]; w[2] += last->p[2];
+    if (w[0] != w[0] || w[1] != w[1] || w[2] != w[2]) return 0;
+    pf[0] = w[0]; pf[1] = w[1]; pf[2] = w[2];
+    return 1;
+}

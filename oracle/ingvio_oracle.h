@@ -170,6 +170,24 @@ void orc_frame_update_batch(int B, int threads, double* P, int* n_io, int ld,
  * b <- Q^T b. */
 void orc_qr_compress(double* A, int m, int n, int lda, double* b);
 
+/* ---- "next" row f-1: feature triangulation (Triangulator.cpp) ------------------------------------ */
+typedef struct {
+    int C;                       /* window slots                                                          */
+    const double* clone_R;       /* [C][9] row-major R_cam-left -> world                                  */
+    const double* clone_p;       /* [C][3]                                                                */
+    unsigned long long mask;     /* slots with an observation, ascending slot = ascending timestamp       */
+    const double* uv;            /* [C][4]: u0 v0 (u1 v1)                                                 */
+    int stereo;
+    double R_lr[9], t_lr[3];     /* T_cl2cr                                                               */
+    double trans_thres, huber_epsilon, conv_precision, init_damping;   /* Triangulator.h:67-70           */
+    int outer_loop_max_iter, inner_loop_max_iter;                      /* :71-72                         */
+    double max_depth, min_depth;                                       /* :74-75                         */
+} orc_tri_in;
+/* Triangulator::triangulateMonoObs (:173-318) / triangulateStereoObs (:320-359): LM on (x/z, y/z, 1/z) in the frame
+ * of the LAST mono-equivalent observation.  Returns 1 and the world point, or 0 (pf = 0; the reference leaves pf
+ * untouched on its early "translation too small" exit, callers ignore it on failure). */
+int orc_triangulate(const orc_tri_in* in, double pf[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -317,6 +317,37 @@ def frame_update_batch(P, n, ld, steps, frames, threads=0, **kw):
     return P, n, dx, acc
 
 
+class TriIn(C.Structure):
+    _fields_ = [("C", C.c_int), ("clone_R", C.POINTER(C.c_double)), ("clone_p", C.POINTER(C.c_double)),
+                ("mask", C.c_ulonglong), ("uv", C.POINTER(C.c_double)), ("stereo", C.c_int),
+                ("R_lr", C.c_double * 9), ("t_lr", C.c_double * 3),
+                ("trans_thres", C.c_double), ("huber_epsilon", C.c_double), ("conv_precision", C.c_double),
+                ("init_damping", C.c_double), ("outer_loop_max_iter", C.c_int), ("inner_loop_max_iter", C.c_int),
+                ("max_depth", C.c_double), ("min_depth", C.c_double)]
+
+
+TRI_DEFAULTS = dict(trans_thres=0.1, huber_epsilon=0.01, conv_precision=5e-7, init_damping=1e-3,
+                    outer_loop_max_iter=10, inner_loop_max_iter=10, max_depth=60.0, min_depth=0.2)   # Triangulator.h:67-75
+
+
+def triangulate(clone_R, clone_p, mask, uv, stereo, R_lr=None, t_lr=None, **params):
+    """One feature: clone_R [C,3,3], clone_p [C,3], mask (int), uv [C,4].  Returns (ok, pf[3])."""
+    pr = dict(TRI_DEFAULTS); pr.update(params)
+    R = f64(clone_R); p = f64(clone_p); z = f64(uv)
+    t = TriIn()
+    t.C = int(R.shape[0]); t.clone_R = _d(R); t.clone_p = _d(p); t.mask = int(mask); t.uv = _d(z); t.stereo = int(bool(stereo))
+    Rl = np.eye(3) if R_lr is None else f64(R_lr); tl = np.zeros(3) if t_lr is None else f64(t_lr)
+    for i in range(9):
+        t.R_lr[i] = float(Rl.reshape(-1)[i])
+    for i in range(3):
+        t.t_lr[i] = float(tl[i])
+    for k, v in pr.items():
+        setattr(t, k, v)
+    pf = np.zeros(3)
+    ok = lib().orc_triangulate(C.byref(t), _d(pf))
+    return bool(ok), pf
+
+
 def qr_compress(A, b):
     A = np.asfortranarray(A, dtype=np.float64).copy(order="F"); b = f64(b).copy()
     m, n = A.shape

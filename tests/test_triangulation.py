@@ -1,0 +1,168 @@
+"""f-1: feature triangulation.  CPU part: the oracle against the identities the reference's own gtest
+asserts (ingvio_estimator/test/TestTriangulator.cpp:133-177: result within 0.05 m / 0.15 m of the truth, flag true, on
+the two camera constellations of its fixture :35-93, measurement noise 0.02 in normalised coordinates)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+PF = np.array([1.0, 2.0, 3.0])
+T_LR = np.array([0.001, -0.12, 0.003])          # TestTriangulator.cpp:37-38, rotation identity
+
+
+def rot_z(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+
+
+def rot_from_two(a, b):
+    """Eigen::Quaterniond::FromTwoVectors(a, b) as a matrix (shortest arc; antiparallel -> pi about an orthogonal axis)."""
+    a = a / np.linalg.norm(a); b = b / np.linalg.norm(b)
+    c = float(a @ b)
+    if c > 1 - 1e-12:
+        return np.eye(3)
+    if c < -1 + 1e-12:
+        ax = np.cross(a, [1.0, 0, 0])
+        if np.linalg.norm(ax) < 1e-9:
+            ax = np.cross(a, [0, 1.0, 0])
+        ax /= np.linalg.norm(ax)
+        return 2 * np.outer(ax, ax) - np.eye(3)
+    v = np.cross(a, b); K = np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+    return np.eye(3) + K + K @ K / (1 + c)
+
+
+def fixture(which, rng, noise=0.02):
+    if which == 1:                                                            # :40-52
+        R = [rot_z(rng.normal(0, 0.1)) for _ in range(10)]
+        p = [np.array([2 * i - 9.0, 2 * i - 9.0, 0.0]) for i in range(10)]
+    else:                                                                     # :54-88
+        z = np.array([0, 0, 1.0])
+        dirs = [(0, 0, 1), (0, -1, 0), (0, 0, -1), (0, 1, 0), (-1, 0, 0), (1, 0, 0)]
+        pos = [(0, 0, 0), (0, 5, 0), (0, 0, 8), (0, -6, 0), (5.5, 0, 0), (-10, 0, 0)]
+        R = [rot_from_two(z, np.array(d, dtype=float)) for d in dirs]
+        p = [np.array(q, dtype=float) for q in pos]
+    uv = np.zeros((len(R), 4))
+    for i, (Ri, pi) in enumerate(zip(R, p)):
+        bl = Ri.T @ (PF - pi); br = bl + T_LR                                 # calcStereoMeas :117-130
+        uv[i] = [bl[0] / bl[2], bl[1] / bl[2], br[0] / br[2], br[1] / br[2]] + rng.normal(0, noise, 4)
+    return np.stack(R), np.stack(p), uv
+
+
+@pytest.mark.parametrize("stereo", [False, True])
+@pytest.mark.parametrize("which,tol", [(1, 0.05), (2, 0.15)])
+def test_oracle_triangulation_reference_identities(which, tol, stereo):
+    """The reference asserts |pf - truth| < tol and flag == true on ONE noisy draw of its fixture.  Its noise (0.02) is
+    above the Huber threshold (0.01, Triangulator.h:68) while the accept test uses the unweighted cost (:240-246), so
+    a fraction of draws does not reach conv_precision within the 10 outer iterations and is (correctly, as written)
+    reported as failed: the identity checked here is the bound on every draw that converges, a majority converging, and
+    exact recovery without noise."""
+    errs, oks = [], 0
+    for seed in range(40):
+        R, p, uv = fixture(which, np.random.default_rng(seed))
+        ok, pf = orc.triangulate(R, p, (1 << len(R)) - 1, uv, stereo, np.eye(3), T_LR)
+        oks += ok
+        if ok:
+            errs.append(np.linalg.norm(pf - PF))
+    assert oks >= 24 and np.median(errs) < tol and max(errs) < 2.5 * tol
+    R, p, uv = fixture(which, np.random.default_rng(0), noise=0.0)
+    ok, pf = orc.triangulate(R, p, (1 << len(R)) - 1, uv, stereo, np.eye(3), T_LR)
+    assert ok and np.linalg.norm(pf - PF) < 1e-6
+
+
+def test_oracle_triangulation_gates():
+    rng = np.random.default_rng(1)
+    R, p, uv = fixture(1, rng)
+    ok, pf = orc.triangulate(R[:4], p[:4], 0b1111, uv[:4], False)              # <= 4 mono observations (:183)
+    assert not ok and not pf.any()
+    ok, pf = orc.triangulate(R[:2], p[:2], 0b11, uv[:2], True, np.eye(3), T_LR)  # stereo: 2 frames = 4 mono-equivalent
+    assert not ok
+    p2 = np.tile(p[0], (10, 1)) + 1e-4 * rng.standard_normal((10, 3))         # no parallax (:192)
+    ok, pf = orc.triangulate(R, p2, (1 << 10) - 1, uv, False)
+    assert not ok
+    ok, pf = orc.triangulate(R, p, (1 << 10) - 1, uv, False, max_depth=2.0)    # depth gate (:296)
+    assert not ok
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GPU: ingvio_triangulate through the C ABI vs the oracle, feature by feature
+# ------------------------------------------------------------------------------------------------------------------
+def _frames(stereo, C, F, nb, ragged, noise_px, seed0):
+    from ingvio_amd import capi, host, synth
+    ctx = capi.Context(batch=nb, n_max=((21 + 6 * C + 15) // 16) * 16, c_max=C, f_max=F, m_max=32)
+    frames = []
+    for b in range(nb):
+        flt, step, frame, info = synth.build_case(lambda P, b=b: capi.DeviceCov(ctx, b, P), host.imu_transition, seed=seed0 + b,
+                                                  F=F, C=C, n_gnss=0, n_landmarks=0, stereo=stereo)
+        frame = dict(frame)
+        rng = np.random.default_rng(seed0 + 100 + b)
+        frame["uv"] = frame["uv"] + rng.normal(0, noise_px, frame["uv"].shape)
+        if ragged:
+            mask = np.zeros(F, dtype=np.uint64)
+            for j in range(F):
+                k = int(rng.integers(1, C + 1))                      # also too-few-observation features
+                obs = np.sort(rng.choice(C, size=k, replace=False))
+                mask[j] = np.uint64(sum(1 << int(o) for o in obs))
+            frame["obs_mask"] = mask
+        frames.append(frame)
+    return ctx, frames
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stereo,C,ragged,noise", [(True, 11, False, 0.0), (True, 11, True, 2e-3), (False, 11, True, 2e-3),
+                                                     (True, 30, True, 5e-3), (False, 6, False, 0.03)])
+def test_gpu_triangulation_vs_oracle(stereo, C, ragged, noise):
+    F, nb = 96, 2
+    ctx, frames = _frames(stereo, C, F, nb, ragged, noise, 900)
+    pf, ok = ctx.triangulate(0, frames, stereo=stereo)
+    n_ok = 0
+    for b in range(nb):
+        fr = frames[b]
+        for j in range(F):
+            oko, pfo = orc.triangulate(fr["clone_R"], fr["clone_p"], int(fr["obs_mask"][j]), fr["uv"][j], stereo,
+                                       fr["R_cl2cr"], fr["t_cl2cr"])
+            assert bool(ok[b, j]) == oko, (b, j)
+            # same operation order on both sides, so the iteration paths coincide; what remains is FMA contraction
+            # (gcc vs hipcc) amplified by an iteration that stops at conv_precision = 5e-7: tolerance 5e-7 relative
+            assert np.linalg.norm(pf[b, j] - pfo) <= 5e-7 * max(1.0, np.linalg.norm(pfo)), (b, j, pf[b, j], pfo)
+            n_ok += oko
+    assert n_ok > 0.3 * nb * F                      # the case is not degenerate
+    if noise == 0.0:                                 # synth's own 1e-3 pixel noise only: close to the generator's points
+        near = np.linalg.norm(pf[0, :F] - frames[0]["pf"], axis=1)[ok[0, :F] == 1]
+        assert np.median(near) < 0.2
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_triangulate_staged_then_update():
+    """frames == NULL: triangulate the staged frame on the device, failed features drop out, and the following frame
+    step uses the device-resident points: same posterior as staging the oracle's points from the host."""
+    from ingvio_amd import capi, host, synth
+    F, C = 64, 11
+    ctx, frames = _frames(True, C, F, 1, True, 1e-3, 950)
+    flt, step, frame, info = synth.build_case(lambda P: capi.DeviceCov(ctx, 0, P), host.imu_transition, seed=950, F=F, C=C,
+                                              n_gnss=0, n_landmarks=0, stereo=True)
+    frame = dict(frame); frame["obs_mask"] = frames[0]["obs_mask"]; frame["uv"] = frames[0]["uv"]
+    frame["dof"] = np.array([max(1, bin(int(m)).count("1") - 1) for m in frame["obs_mask"]], dtype=np.int32)
+    prior = ctx.cov_get(0)
+    # host reference: oracle triangulation, failed features removed, then the oracle frame update
+    fr_o = dict(frame); pfo = np.zeros((F, 3)); mko = frame["obs_mask"].copy()
+    for j in range(F):
+        okj, p = orc.triangulate(frame["clone_R"], frame["clone_p"], int(frame["obs_mask"][j]), frame["uv"][j], True,
+                                 frame["R_cl2cr"], frame["t_cl2cr"])
+        pfo[j] = p
+        if not okj:
+            mko[j] = np.uint64(0)
+    fr_o["pf"] = pfo; fr_o["obs_mask"] = mko
+    oc = orc.Cov(prior, ld=ctx.ldp)
+    dxo, acco, gamo, m = orc.frame_update(oc, step, fr_o, max_accept=0, compress_rule=1)
+    # device: stage the frame with garbage points, triangulate in place, run
+    fr_d = dict(frame); fr_d["pf"] = np.full((F, 3), 123.0)
+    ctx.snapshot()
+    ctx.frame_stage(0, [step], [fr_d], step["sigma"])
+    pf, ok = ctx.triangulate(0, None, stereo=True, mask_failed=True, R_cl2cr=frame["R_cl2cr"], t_cl2cr=frame["t_cl2cr"])
+    ctx.frame_run(restore_prior=True)
+    dx, acc, rows = ctx.frame_fetch()
+    assert np.array_equal(ok[0, :F] == 1, mko != 0) and np.array_equal(acc[0, :F], acco)
+    P = ctx.cov_get(0)
+    assert np.linalg.norm(P - oc.P) / np.linalg.norm(oc.P) < 1e-9
+    ctx.close()
