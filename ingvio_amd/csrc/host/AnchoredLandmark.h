@@ -30,9 +30,12 @@ public:
     const std::shared_ptr<SE3> getAnchoredPose() const { return _anchored_pose; }
     const Vec3d& valuePosXyz() const { return _pos_xyz; }
     void setValuePosXyz(const Vec3d& xyz_world) { _pos_xyz = xyz_world; }
+    // first-estimate copy (AnchoredLandmark.cpp: setFejPosXyz); stored, the Jacobians use current values (quirk Q7)
+    const Vec3d& fejPosXyz() const { return _pos_xyz_fej; }
+    void setFejPosXyz(const Vec3d& xyz_world) { _pos_xyz_fej = xyz_world; }
 
 protected:
-    Vec3d _pos_xyz;
+    Vec3d _pos_xyz, _pos_xyz_fej;
     std::shared_ptr<SE3> _anchored_pose;
 };
 

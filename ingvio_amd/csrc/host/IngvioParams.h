@@ -29,6 +29,9 @@ public:
     double _init_gravity = 9.8;
     int _max_imu_buffer_size = 3000, _init_imu_buffer_sp = 300;
     double _trans_thres = 0.25;
+    // triangulation (IngvioParams.cpp:78-85, config/*/ingvio_*.yaml)
+    double _huber_epsilon = 0.01, _conv_precision = 5e-07, _init_damping = 1e-03, _max_depth = 40.0, _min_depth = 0.2;
+    int _outer_loop_max_iter = 10, _inner_loop_max_iter = 10;
     int _chi2_max_dof = 150;
     double _chi2_thres = 0.95;
     double _visual_noise = 0.18;

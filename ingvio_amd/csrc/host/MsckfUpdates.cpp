@@ -1,4 +1,6 @@
 #include "MsckfUpdates.h"
+#include <cstring>
+#include <iostream>
 
 #include <cstdlib>
 #include <iostream>
@@ -9,13 +11,82 @@
 
 namespace ingvio {
 
-bool Triangulator::triangulate(std::shared_ptr<FeatureInfo> fi, const std::shared_ptr<State>, bool)
+// common timestamps of the window and the observations, in time order (Triangulator.h filterCommonTimestamp), one
+// feature, through the C ABI
+bool Triangulator::run(const std::shared_ptr<State> state, const std::map<double, std::shared_ptr<SE3>>& sw_poses,
+                       const std::vector<double>& stamps, const std::vector<double>& uv4, bool stereo, const Iso3& T_cl2cr,
+                       Vec3d& pf) const
 {
-    if (!fi->_isTri || fi->_landmark->getAnchoredPose() == nullptr) return false;
-    const auto anchor = fi->_landmark->getAnchoredPose();
-    const Vec3d body = anchor->valueLinearAsMat().transpose() * (fi->_landmark->valuePosXyz() - anchor->valueTrans());
-    if (body.z() <= 0) return false;                                                          // MapServerManager.cpp:325
+    std::vector<double> cR, cp, uv;
+    std::vector<int> cidx;
+    for (size_t k = 0; k < stamps.size(); ++k) {
+        const auto it = sw_poses.find(stamps[k]);
+        if (it == sw_poses.end()) continue;
+        const Mat3d& R = it->second->valueLinearAsMat();
+        const Vec3d& p = it->second->valueTrans();
+        cR.insert(cR.end(), R.m, R.m + 9);
+        cp.insert(cp.end(), p.v, p.v + 3);
+        uv.insert(uv.end(), uv4.begin() + 4 * k, uv4.begin() + 4 * k + 4);
+        cidx.push_back(0);
+    }
+    const int C = (int)cidx.size();
+    pf = Vec3d();
+    if (C == 0) return false;
+    const unsigned long long mask = C >= 64 ? ~0ULL : ((1ULL << C) - 1ULL);
+    ingvio_msckf_frame fr;
+    std::memset(&fr, 0, sizeof fr);
+    fr.n_clones = C; fr.clone_idx = cidx.data(); fr.clone_R = cR.data(); fr.clone_p = cp.data();
+    fr.n_feat = 1; fr.obs_mask = &mask; fr.uv = uv.data();
+    ingvio_tri_opts o;
+    std::memset(&o, 0, sizeof o);
+    o.stereo = stereo ? 1 : 0;
+    std::memcpy(o.R_cl2cr, T_cl2cr.R.m, sizeof o.R_cl2cr);
+    std::memcpy(o.t_cl2cr, T_cl2cr.t.v, sizeof o.t_cl2cr);
+    o.trans_thres = _trans_thres; o.huber_epsilon = _huber_epsilon; o.conv_precision = _conv_precision;
+    o.init_damping = _init_damping; o.outer_loop_max_iter = _outer_loop_max_iter; o.inner_loop_max_iter = _inner_loop_max_iter;
+    o.max_depth = _max_depth; o.min_depth = _min_depth;
+    return StateManager::triangulateOne(state, fr, o, pf);
+}
+
+bool Triangulator::triangulateMonoObs(const std::shared_ptr<State> state, const std::map<double, std::shared_ptr<MonoMeas>>& mono_obs,
+                                      const std::map<double, std::shared_ptr<SE3>>& sw_poses, Vec3d& pf) const
+{
+    std::vector<double> stamps, uv4;
+    for (const auto& item : mono_obs) { stamps.push_back(item.first); uv4.insert(uv4.end(), { item.second->_u0, item.second->_v0, 0.0, 0.0 }); }
+    return run(state, sw_poses, stamps, uv4, false, Iso3(), pf);
+}
+
+bool Triangulator::triangulateStereoObs(const std::shared_ptr<State> state,
+                                        const std::map<double, std::shared_ptr<StereoMeas>>& stereo_obs,
+                                        const std::map<double, std::shared_ptr<SE3>>& sw_poses, const Iso3& T_cl2cr, Vec3d& pf) const
+{
+    std::vector<double> stamps, uv4;
+    for (const auto& item : stereo_obs) {
+        stamps.push_back(item.first);
+        uv4.insert(uv4.end(), { item.second->_u0, item.second->_v0, item.second->_u1, item.second->_v1 });
+    }
+    return run(state, sw_poses, stamps, uv4, true, T_cl2cr, pf);
+}
+
+// FeatureInfoManager::triangulateFeatureInfoMono / Stereo (MapServerManager.cpp:274-341)
+bool Triangulator::triangulate(std::shared_ptr<FeatureInfo> fi, const std::shared_ptr<State> state, bool stereo)
+{
+    Vec3d pf;
+    const bool flag = stereo ? triangulateStereoObs(state, fi->_stereo_obs, state->_sw_camleft_poses, state->_state_params._T_cl2cr, pf)
+                             : triangulateMonoObs(state, fi->_mono_obs, state->_sw_camleft_poses, pf);
+    if (!flag || pf[0] != pf[0] || pf[1] != pf[1] || pf[2] != pf[2]) return false;
     ++fi->_numOfTri;
+    const auto anchor = fi->_landmark->getAnchoredPose();
+    if (anchor == nullptr) return false;
+    const Vec3d body = anchor->valueLinearAsMat().transpose() * (pf - anchor->valueTrans());
+    if (body.z() <= 0) return false;                                                          // :290, :325
+    if (!fi->_isTri) {
+        fi->_landmark->setFejPosXyz(pf);
+        fi->_landmark->setValuePosXyz(pf);
+        fi->_isTri = true;
+        return true;
+    }
+    fi->_landmark->setValuePosXyz(pf);
     return true;
 }
 

@@ -10,21 +10,40 @@
 #include <memory>
 #include <vector>
 
+#include <map>
+
+#include "IngvioParams.h"
 #include "MapServer.h"
 #include "Update.h"
 
 namespace ingvio {
 
-class IngvioParams;
 class State;
 
-// Triangulation is the "next" row f-1 of SURVEY.md §8(f); the policies only need this interface.
-// The default accepts features whose landmark position was already set (feature->_isTri) and applies
-// the depth test of MapServerManager.cpp:309-341.
+// Triangulator (Triangulator.h:30-120) on the device: the LM iteration of triangulateMonoObs / triangulateStereoObs runs
+// in ingvio_triangulate (kernels_tri.hip).  triangulate() is FeatureInfoManager::triangulateFeatureInfo{Mono,Stereo}
+// (MapServerManager.cpp:274-341): count the attempt, reject points behind their anchor, set value (and FEJ the first time).
 class Triangulator {
 public:
+    Triangulator() {}
+    explicit Triangulator(const IngvioParams& filter_params)
+        : _trans_thres(filter_params._trans_thres), _huber_epsilon(filter_params._huber_epsilon),
+          _conv_precision(filter_params._conv_precision), _init_damping(filter_params._init_damping),
+          _outer_loop_max_iter(filter_params._outer_loop_max_iter), _inner_loop_max_iter(filter_params._inner_loop_max_iter),
+          _max_depth(filter_params._max_depth), _min_depth(filter_params._min_depth) {}
     virtual ~Triangulator() {}
+    bool triangulateMonoObs(const std::shared_ptr<State> state, const std::map<double, std::shared_ptr<MonoMeas>>& mono_obs,
+                            const std::map<double, std::shared_ptr<SE3>>& sw_poses, Vec3d& pf) const;
+    bool triangulateStereoObs(const std::shared_ptr<State> state, const std::map<double, std::shared_ptr<StereoMeas>>& stereo_obs,
+                              const std::map<double, std::shared_ptr<SE3>>& sw_poses, const Iso3& T_cl2cr, Vec3d& pf) const;
     virtual bool triangulate(std::shared_ptr<FeatureInfo> feature_info, const std::shared_ptr<State> state, bool stereo);
+
+protected:
+    bool run(const std::shared_ptr<State> state, const std::map<double, std::shared_ptr<SE3>>& sw_poses,
+             const std::vector<double>& stamps, const std::vector<double>& uv4, bool stereo, const Iso3& T_cl2cr, Vec3d& pf) const;
+    double _trans_thres = 0.1, _huber_epsilon = 0.01, _conv_precision = 5e-7, _init_damping = 1e-3;      // Triangulator.h:67-75
+    int _outer_loop_max_iter = 10, _inner_loop_max_iter = 10;
+    double _max_depth = 60.0, _min_depth = 0.2;
 };
 
 class RemoveLostUpdate : public UpdateBase {

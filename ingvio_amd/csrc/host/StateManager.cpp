@@ -258,6 +258,17 @@ double StateManager::whitenResidual(std::shared_ptr<State> state, const VecXd& r
     return gamma;
 }
 
+bool StateManager::triangulateOne(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_tri_opts& opts, Vec3d& pf)
+{
+    const int fm = std::max(ingvio_f_max(state->_ctx), 1);
+    std::vector<double> pfo(3 * (size_t)fm, 0.0);
+    std::vector<int> ok((size_t)fm, 0);
+    const int rc = ingvio_triangulate(state->_ctx, state->_b, 1, &frame, &opts, pfo.data(), ok.data());
+    if (rc < 0) fatal(state, "triangulate", rc);
+    pf = Vec3d(pfo[0], pfo[1], pfo[2]);
+    return ok[0] != 0;
+}
+
 int StateManager::msckfUpdate(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_msckf_opts& opts,
                               std::vector<int>* accepted)
 {

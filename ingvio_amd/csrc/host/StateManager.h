@@ -48,6 +48,8 @@ public:
                                  const std::vector<std::shared_ptr<Type>>& var_order, double noise);
 
     // MSCKF update on flattened MapServer data + boxPlus; returns rows handed to the Kalman update.
+    // f-1: Triangulator::triangulate{Mono,Stereo}Obs of ONE feature on the device (ingvio_triangulate)
+    static bool triangulateOne(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_tri_opts& opts, Vec3d& pf);
     static int msckfUpdate(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_msckf_opts& opts,
                            std::vector<int>* accepted = nullptr);
 
