@@ -1,10 +1,11 @@
 // kernels_tri.hip — SURVEY.md §8(f) row f-1: batched feature triangulation on the device.
 // Triangulator::triangulateMonoObs (Triangulator.cpp:173-318) and its stereo wrapper (:320-359): Levenberg-Marquardt on
 // (x/z, y/z, 1/z) in the frame of the LAST mono-equivalent observation, Huber-weighted normal equations, accept test
-// on the unweighted cost, depth / parallax / convergence gates.  One LANE per feature (the iteration is inherently
-// sequential and features are independent); the window's camera poses (left, and right = left * T_cl2cr^-1) are
-// staged once per workgroup in LDS.  Operation order follows the restatement in oracle/ingvio_oracle.c so that both
-// walk the same iteration path.  gfx950 only.
+// on the unweighted cost, depth / parallax / convergence gates.  One DPP QUAD per feature: the iteration is sequential,
+// but each cost / normal-equation pass is a sum over observations, dealt round-robin to the four lanes and reduced
+// with two quad_perm exchanges; 16 features per wave, 32 per workgroup.  The window's camera poses (left, and right = left * T_cl2cr^-1) are
+// staged once per workgroup in LDS.  Per-observation arithmetic follows the restatement in oracle/ingvio_oracle.c; only the order of
+// the sums over observations differs (4 partial sums), which the parity tolerance (5e-7 relative) covers.  gfx950 only.
 #include "dev_common.h"
 #include "launch_tri.h"
 
@@ -36,16 +37,15 @@ __device__ __forceinline__ void eye_pose(double Rr[9], double tr[3])
     tr[0] = tr[1] = tr[2] = 0.0;
 }
 
-// calcUnitCost (:107-125)
-__device__ __forceinline__ double unit_cost(double mx, double my, const double Rr[9], const double tr[3], const double sol[3])
+// calcUnitCost (:107-125); pf0 = (x/z, y/z, 1)/rho is the same for every observation of a pass and comes in precomputed.
+// One reciprocal instead of the two divisions of the reference (last-bit rounding only, inside the parity tolerance).
+__device__ __forceinline__ double unit_cost(double mx, double my, const double Rr[9], const double tr[3], const double pf0[3])
 {
-    double pf0[3], pf[3];
-    pf0[2] = 1.0 / sol[2];
-    pf0[0] = sol[0] * pf0[2];
-    pf0[1] = sol[1] * pf0[2];
+    double pf[3];
     m3mulv(Rr, pf0, pf);
     pf[0] += tr[0]; pf[1] += tr[1]; pf[2] += tr[2];
-    const double ex = mx - pf[0] / pf[2], ey = my - pf[1] / pf[2];
+    const double r = fast_rcp(pf[2]);
+    const double ex = mx - pf[0] * r, ey = my - pf[1] * r;
     return ex * ex + ey * ey;
 }
 
@@ -64,18 +64,72 @@ __device__ __forceinline__ void solve3(const double A[9], double lambda, const d
 }
 
 #define TRI_CMAX 64
+#define TRI_LPF 4                      // lanes per feature (one DPP quad)
+#define TRI_NT 128                     // 32 features per workgroup
+#define TRI_NOBS 6                     // register path: up to 24 mono-equivalent observations per feature
 
+// quad_perm DPP: full-rate lane exchange inside a quad (0xB1 = lanes ^1, 0x4E = lanes ^2)
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(double x)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_quad_i(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xf, 0xf, true); }
+// butterfly: a+b is commutative, so all four lanes end with the SAME bits and the quad's control flow stays uniform
+__device__ __forceinline__ double quad_sum(double x)
+{
+    x += dpp_quad<0xB1>(x);
+    x += dpp_quad<0x4E>(x);
+    return x;
+}
+__device__ __forceinline__ int quad_or(int x)
+{
+    x |= dpp_quad_i<0xB1>(x);
+    x |= dpp_quad_i<0x4E>(x);
+    return x;
+}
+
+// The mono-equivalent observations of a feature in the reference's order (clone ascending, left eye before right) are
+// dealt round-robin to the four lanes of a quad: lane q owns observations q, q+4, q+8, ...  Stereo: that is every second
+// observing clone starting at the (q>>1)-th, always eye q&1; mono: every fourth starting at the q-th.
 template <bool STEREO>
-__global__ __launch_bounds__(WAVE) void k_triangulate(TriLaunch L)
+struct ObsCursor {
+    unsigned long long m;
+    __device__ __forceinline__ ObsCursor(unsigned long long mask, int q)
+    {
+        m = mask;
+        const int skip = STEREO ? (q >> 1) : q;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < skip) m &= m - 1ULL;
+    }
+    __device__ __forceinline__ bool valid() const { return m != 0ULL; }
+    __device__ __forceinline__ int slot() const { return __ffsll((long long)m) - 1; }
+    __device__ __forceinline__ void next()
+    {
+#pragma unroll
+        for (int i = 0; i < (STEREO ? 2 : 4); ++i) m &= m - 1ULL;
+    }
+};
+
+// NOBS > 0: a lane keeps its (at most NOBS) observations - clone slot and measurement - in registers and every pass is a
+// fully unrolled, branch-free loop over them (independent observations interleave, nothing is re-read from global
+// memory).  NOBS == 0: any number of observations, walked with the cursor and read from global memory in every pass.
+template <bool STEREO, int NOBS>
+__global__ __launch_bounds__(TRI_NT) void k_triangulate(TriLaunch L)
 {
     constexpr int EYES = STEREO ? 2 : 1;
+    constexpr int NREG = NOBS > 0 ? NOBS : 1;
     __shared__ double sR[EYES][TRI_CMAX][9];
     __shared__ double sP[EYES][TRI_CMAX][3];
     const int bl = blockIdx.y, b = L.b0 + bl, tid = threadIdx.x;
     const FrameView& fv = L.fv;
     const int C = fv.n_clones[b], F = fv.n_feat[b];
     // camera poses of the window: left as given, right = left * T_cl2cr^-1 (:349-354)
-    for (int s = tid; s < C; s += WAVE) {
+    for (int s = tid; s < C; s += TRI_NT) {
         const double* R = fv.clone_R + ((size_t)b * fv.cmax + s) * 9;
         const double* p = fv.clone_p + ((size_t)b * fv.cmax + s) * 3;
 #pragma unroll
@@ -95,16 +149,19 @@ __global__ __launch_bounds__(WAVE) void k_triangulate(TriLaunch L)
         }
     }
     __syncthreads();
-    const int j = blockIdx.x * WAVE + tid;
-    if (j >= F) return;
+    const int q = tid & (TRI_LPF - 1), eq = STEREO ? (q & 1) : 0;
+    const int j = blockIdx.x * (TRI_NT / TRI_LPF) + (tid >> 2);
+    if (j >= F) return;                                                             // whole quads leave together
     const size_t oidx = (size_t)b * fv.fmax + j;
     const unsigned long long mask = fv.obs_mask[oidx] & (C >= 64 ? ~0ULL : ((1ULL << C) - 1ULL));
     const double* uv = fv.uv + oidx * fv.cmax * 4;
     double* pf_out = L.pf + oidx * 3;
     auto fail = [&]() {
-        pf_out[0] = pf_out[1] = pf_out[2] = 0.0;
-        L.ok[oidx] = 0;
-        if (L.mask_failed) L.mask_rw[oidx] = 0ULL;
+        if (q == 0) {
+            pf_out[0] = pf_out[1] = pf_out[2] = 0.0;
+            L.ok[oidx] = 0;
+            if (L.mask_failed) L.mask_rw[oidx] = 0ULL;
+        }
     };
     const int n = EYES * __popcll(mask);
     if (n <= 4) { fail(); return; }                                                 // :183-187
@@ -112,8 +169,42 @@ __global__ __launch_bounds__(WAVE) void k_triangulate(TriLaunch L)
     const double* Rl = sR[EYES - 1][s_last];
     const double* pl = sP[EYES - 1][s_last];
     const double ml0 = uv[4 * s_last + 2 * (EYES - 1)], ml1 = uv[4 * s_last + 2 * (EYES - 1) + 1];
-    // findLongestTrans (:31-68)
-    int smax = s_last, emax = EYES - 1;
+    int sl[NREG], cnt = 0;
+    double mu[NREG], mv[NREG];
+    if (NOBS > 0) {
+        ObsCursor<STEREO> oc(mask, q);
+#pragma unroll
+        for (int t = 0; t < NREG; ++t) {
+            const bool v = oc.valid();
+            const int s = v ? oc.slot() : s_last;                                  // padding entries: a valid address, result masked
+            sl[t] = s; mu[t] = uv[4 * s + 2 * eq]; mv[t] = uv[4 * s + 2 * eq + 1];
+            cnt += v ? 1 : 0;
+            oc.next();
+        }
+    }
+    // body(s, u, v, t, live): live == false only for padding entries of the register path (compute, then discard)
+    auto each_obs = [&](auto&& body) {
+        if constexpr (NOBS > 0) {
+#pragma unroll
+            for (int t = 0; t < NREG; ++t) {
+                int s = sl[t];
+                asm volatile("" : "+v"(s));        // opaque per pass: keeps the 6 x 12 relative-pose values out of loop-invariant registers
+                if (t < cnt) body(s, mu[t], mv[t], t, true);
+            }
+        } else {
+            int t = 0;
+            for (ObsCursor<STEREO> oc(mask, q); oc.valid(); oc.next(), ++t) {
+                const int s = oc.slot();
+                body(s, uv[4 * s + 2 * eq], uv[4 * s + 2 * eq + 1], t, true);
+            }
+        }
+    };
+    // relative pose of observation (s, eq) to the last one; the last one itself is the exact identity (:215-221)
+    auto rel = [&](int s, double Rr[9], double tr[3]) {
+        if (s == s_last && eq == EYES - 1) eye_pose(Rr, tr); else rel_pose(sR[eq][s], sP[eq][s], Rl, pl, Rr, tr);
+    };
+    // findLongestTrans (:31-68): first maximum in observation order = maximum with the lowest observation number
+    int smax, emax;
     {
         double fl[3] = { ml0, ml1, 1.0 };
         const double fn = sqrt(fl[0] * fl[0] + fl[1] * fl[1] + fl[2] * fl[2]);
@@ -121,20 +212,24 @@ __global__ __launch_bounds__(WAVE) void k_triangulate(TriLaunch L)
         double fw[3];
         m3mulv(Rl, fl, fw);
         double max_trans = -__builtin_inf();
-        for (int s = 0; s <= s_last; ++s) {
-            if (!((mask >> s) & 1ULL)) continue;
-#pragma unroll
-            for (int e = 0; e < EYES; ++e) {
-                if (s == s_last && e == EYES - 1) continue;
-                const double* pi = sP[e][s];
-                const double d[3] = { pi[0] - pl[0], pi[1] - pl[1], pi[2] - pl[2] };
-                const double dot = fw[0] * d[0] + fw[1] * d[1] + fw[2] * d[2];
-                const double q[3] = { d[0] - fw[0] * dot, d[1] - fw[1] * dot, d[2] - fw[2] * dot };
-                const double tr = fabs(sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]));
-                if (tr > max_trans) { max_trans = tr; smax = s; emax = e; }
-            }
+        int kmax = 0x7fffffff;
+        each_obs([&](int s, double, double, int t, bool live) {
+            const int k = q + TRI_LPF * t;
+            const double* pi = sP[eq][s];
+            const double d[3] = { pi[0] - pl[0], pi[1] - pl[1], pi[2] - pl[2] };
+            const double dot = fw[0] * d[0] + fw[1] * d[1] + fw[2] * d[2];
+            const double qv[3] = { d[0] - fw[0] * dot, d[1] - fw[1] * dot, d[2] - fw[2] * dot };
+            const double tr = fabs(sqrt(qv[0] * qv[0] + qv[1] * qv[1] + qv[2] * qv[2]));
+            if (live && !(s == s_last && eq == EYES - 1) && tr > max_trans) { max_trans = tr; kmax = (k << 8) | (s << 1) | eq; }
+        });
+        {
+            double ot = dpp_quad<0xB1>(max_trans); int ok_ = dpp_quad_i<0xB1>(kmax);
+            if (ot > max_trans || (ot == max_trans && ok_ < kmax)) { max_trans = ot; kmax = ok_; }
+            ot = dpp_quad<0x4E>(max_trans); ok_ = dpp_quad_i<0x4E>(kmax);
+            if (ot > max_trans || (ot == max_trans && ok_ < kmax)) { max_trans = ot; kmax = ok_; }
         }
         if (max_trans < L.trans_thres) { fail(); return; }                          // :192
+        smax = (kmax >> 1) & 127; emax = kmax & 1;
     }
     // initial guess (:201-203, initDepth :90-105)
     double sol[3];
@@ -150,57 +245,62 @@ __global__ __launch_bounds__(WAVE) void k_triangulate(TriLaunch L)
         sol[0] = ml0; sol[1] = ml1; sol[2] = 1.0 / depth;
     }
     auto total_cost_of = [&](const double s3[3]) {                                  // calcTotalCost :127-137
-        double c = 0.0;
-        for (int s = 0; s <= s_last; ++s) {
-            if (!((mask >> s) & 1ULL)) continue;
-#pragma unroll
-            for (int e = 0; e < EYES; ++e) {
-                double Rr[9], tr[3];
-                if (s == s_last && e == EYES - 1) eye_pose(Rr, tr); else rel_pose(sR[e][s], sP[e][s], Rl, pl, Rr, tr);
-                c += unit_cost(uv[4 * s + 2 * e], uv[4 * s + 2 * e + 1], Rr, tr, s3);
-            }
-        }
-        return c;
+        double c = 0.0, pf0[3];
+        pf0[2] = 1.0 / s3[2];
+        pf0[0] = s3[0] * pf0[2];
+        pf0[1] = s3[1] * pf0[2];
+        each_obs([&](int s, double u, double v, int, bool live) {
+            double Rr[9], tr[3];
+            rel(s, Rr, tr);
+            const double uc = unit_cost(u, v, Rr, tr, pf0);
+            c += live ? uc : 0.0;
+        });
+        return quad_sum(c);
     };
+    const double eps2 = L.huber_epsilon * L.huber_epsilon, two_eps = 2.0 * L.huber_epsilon;
     double total_cost = total_cost_of(sol);
     double lambda = L.init_damping, delta_norm = __builtin_inf();
     int inner = 0, outer = 0;
     bool reduced = false;
     do {                                                                             // :215-262
-        double A[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, bv[3] = { 0, 0, 0 };
-        for (int s = 0; s <= s_last; ++s) {
-            if (!((mask >> s) & 1ULL)) continue;
+        double A[6] = { 0, 0, 0, 0, 0, 0 }, bv[3] = { 0, 0, 0 };                     // A: 00 01 02 11 12 22
+        each_obs([&](int s, double mu_, double mv_, int, bool live) {                // calcResJacobian :139-171
+            double Rr[9], tr[3];
+            rel(s, Rr, tr);
+            const double a3[3] = { sol[0], sol[1], 1.0 };
+            double h[3];
+            m3mulv(Rr, a3, h);
+            h[0] += tr[0] * sol[2]; h[1] += tr[1] * sol[2]; h[2] += tr[2] * sol[2];
+            // one reciprocal for the five divisions by h_z / h_z^2 of :150-158
+            const double W00 = fast_rcp(h[2]), hx = h[0] * W00, hy = h[1] * W00;
+            const double res0 = hx - mu_, res1 = hy - mv_;
+            const double W02 = -hx * W00, W12 = -hy * W00;
+            double J[6];
 #pragma unroll
-            for (int e = 0; e < EYES; ++e) {                                        // calcResJacobian :139-171
-                double Rr[9], tr[3];
-                if (s == s_last && e == EYES - 1) eye_pose(Rr, tr); else rel_pose(sR[e][s], sP[e][s], Rl, pl, Rr, tr);
-                const double a3[3] = { sol[0], sol[1], 1.0 };
-                double h[3];
-                m3mulv(Rr, a3, h);
-                h[0] += tr[0] * sol[2]; h[1] += tr[1] * sol[2]; h[2] += tr[2] * sol[2];
-                const double res0 = h[0] / h[2] - uv[4 * s + 2 * e], res1 = h[1] / h[2] - uv[4 * s + 2 * e + 1];
-                const double W00 = 1.0 / h[2], W02 = -h[0] / (h[2] * h[2]), W12 = -h[1] / (h[2] * h[2]);
-                double J[6];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const double u0 = c < 2 ? Rr[c] : tr[0], u1 = c < 2 ? Rr[3 + c] : tr[1], u2 = c < 2 ? Rr[6 + c] : tr[2];
-                    J[c] = W00 * u0 + W02 * u2;
-                    J[3 + c] = W00 * u1 + W12 * u2;
-                }
-                const double en = sqrt(res0 * res0 + res1 * res1);
-                const double w = en <= L.huber_epsilon ? 1.0 : sqrt(2.0 * L.huber_epsilon / en);
-                const double w2 = w == 1.0 ? 1.0 : w * w;
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) A[3 * r + c] += w2 * (J[r] * J[c] + J[3 + r] * J[3 + c]);
-                    bv[r] -= w2 * (J[r] * res0 + J[3 + r] * res1);
-                }
+            for (int c = 0; c < 3; ++c) {
+                const double u0 = c < 2 ? Rr[c] : tr[0], u1 = c < 2 ? Rr[3 + c] : tr[1], u2 = c < 2 ? Rr[6 + c] : tr[2];
+                J[c] = W00 * u0 + W02 * u2;
+                J[3 + c] = W00 * u1 + W12 * u2;
             }
-        }
+            // Huber (:161-166): w = sqrt(2 eps / |res|) enters only as w^2 = 2 eps / |res|
+            const double e2 = res0 * res0 + res1 * res1;
+            const double w2 = !live ? 0.0 : (e2 <= eps2 ? 1.0 : two_eps * rsqrt(e2));
+            int t = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c = r; c < 3; ++c) A[t++] += w2 * (J[r] * J[c] + J[3 + r] * J[3 + c]);
+                bv[r] -= w2 * (J[r] * res0 + J[3 + r] * res1);
+            }
+        });
+#pragma unroll
+        for (int t = 0; t < 6; ++t) A[t] = quad_sum(A[t]);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bv[t] = quad_sum(bv[t]);
+        const double Af[9] = { A[0], A[1], A[2], A[1], A[3], A[4], A[2], A[4], A[5] };
         do {
             double delta[3], ns[3];
-            solve3(A, lambda, bv, delta);
+            solve3(Af, lambda, bv, delta);
             ns[0] = sol[0] + delta[0]; ns[1] = sol[1] + delta[1]; ns[2] = sol[2] + delta[2];
             delta_norm = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
             const double nc = total_cost_of(ns);
@@ -217,23 +317,23 @@ __global__ __launch_bounds__(WAVE) void k_triangulate(TriLaunch L)
     double plast[3];
     plast[2] = 1.0 / sol[2]; plast[0] = sol[0] * plast[2]; plast[1] = sol[1] * plast[2];
     if ((outer >= L.outer_loop_max_iter && inner >= L.inner_loop_max_iter) || delta_norm > L.conv_precision) { fail(); return; }
-    for (int s = 0; s <= s_last; ++s) {                                              // :273-278
-        if (!((mask >> s) & 1ULL)) continue;
-#pragma unroll
-        for (int e = 0; e < EYES; ++e) {
-            double Rr[9], tr[3], t3[3];
-            if (s == s_last && e == EYES - 1) eye_pose(Rr, tr); else rel_pose(sR[e][s], sP[e][s], Rl, pl, Rr, tr);
-            m3mulv(Rr, plast, t3);
-            if (t3[2] + tr[2] <= L.min_depth) { fail(); return; }
-        }
-    }
+    int behind = 0;
+    each_obs([&](int s, double, double, int, bool live) {                            // :273-278
+        double Rr[9], tr[3], t3[3];
+        rel(s, Rr, tr);
+        m3mulv(Rr, plast, t3);
+        behind |= (live && t3[2] + tr[2] <= L.min_depth) ? 1 : 0;
+    });
+    if (quad_or(behind)) { fail(); return; }
     if (plast[2] < L.min_depth || plast[2] > L.max_depth) { fail(); return; }        // :296-297
     double w3[3];
     m3mulv(Rl, plast, w3);
     w3[0] += pl[0]; w3[1] += pl[1]; w3[2] += pl[2];
     if (w3[0] != w3[0] || w3[1] != w3[1] || w3[2] != w3[2]) { fail(); return; }
-    pf_out[0] = w3[0]; pf_out[1] = w3[1]; pf_out[2] = w3[2];
-    L.ok[oidx] = 1;
+    if (q == 0) {
+        pf_out[0] = w3[0]; pf_out[1] = w3[1]; pf_out[2] = w3[2];
+        L.ok[oidx] = 1;
+    }
 }
 
 }  // namespace
@@ -241,8 +341,15 @@ __global__ __launch_bounds__(WAVE) void k_triangulate(TriLaunch L)
 int launch_triangulate(const TriLaunch& L, int nb, int fmax_used, int stereo, hipStream_t st)
 {
     if (L.fv.cmax > TRI_CMAX) return -1;
-    const dim3 grid((fmax_used + WAVE - 1) / WAVE, nb);
-    if (stereo) hipLaunchKernelGGL(k_triangulate<true>, grid, dim3(WAVE), 0, st, L);
-    else hipLaunchKernelGGL(k_triangulate<false>, grid, dim3(WAVE), 0, st, L);
+    const int fpb = TRI_NT / TRI_LPF;
+    const dim3 grid((fmax_used + fpb - 1) / fpb, nb);
+    const bool regs = (stereo ? 2 : 1) * L.fv.cmax <= TRI_LPF * TRI_NOBS;          // every lane's share fits the register path
+    if (stereo) {
+        if (regs) hipLaunchKernelGGL((k_triangulate<true, TRI_NOBS>), grid, dim3(TRI_NT), 0, st, L);
+        else hipLaunchKernelGGL((k_triangulate<true, 0>), grid, dim3(TRI_NT), 0, st, L);
+    } else {
+        if (regs) hipLaunchKernelGGL((k_triangulate<false, TRI_NOBS>), grid, dim3(TRI_NT), 0, st, L);
+        else hipLaunchKernelGGL((k_triangulate<false, 0>), grid, dim3(TRI_NT), 0, st, L);
+    }
     return 0;
 }
