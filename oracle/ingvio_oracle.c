@@ -1038,3 +1038,222 @@ int orc_triangulate(const orc_tri_in* in, double pf[3])
     pf[0] = w[0]; pf[1] = w[1]; pf[2] = w[2];
     return 1;
 }
+
+/* ========================================================================================== */
+/* SLAM-landmark path                                                  */
+/*   StateManager::addVariableDelayedInvertible (StateManager.cpp:461-543)                     */
+/*   StateManager::addVariableDelayed           (:549-637)                                     */
+/*   StateManager::replaceVarLinear             (:639-693)                                     */
+/*   LandmarkUpdate::calcResJacobianSingleLandmark{Mono,Stereo} (LandmarkUpdate.cpp:521-626,   */
+/*   :628-686 and the sliding-window-pose twins)                                               */
+/* ========================================================================================== */
+void orc_add_variable_delayed_invertible(double* P, int n, int ld, const int* vidx, const int* vsize, int k,
+                                         const double* H_old, int ldh, const double* H_new, int ldn, int s, double noise)
+{
+    /* :490-505  PH^T over the measured variables */
+    double* PHT = dalloc((size_t)n * s);
+    int hc = 0;
+    for (int a = 0; a < k; ++a) {
+        gemm(n, s, vsize[a], P + (size_t)vidx[a] * ld, ld, H_old + (size_t)hc * ldh, ldh, 1, PHT, n, 1);
+        hc += vsize[a];
+    }
+    /* :507-514  S = H small_cov H^T + noise^2 I */
+    double var = noise * noise;
+    double* S = form_S(P, ld, vidx, vsize, k, H_old, ldh, s, &var, 0, NULL);
+    /* :516  H_new^-1 */
+    double* Hn = dalloc((size_t)s * s);
+    double* Hinv = dalloc((size_t)s * s);
+    for (int j = 0; j < s; ++j) for (int i = 0; i < s; ++i) CM(Hn, s, i, j) = CM(H_new, ldn, i, j);
+    lu_inverse(Hn, s, Hinv);
+    /* :518  cov_newnew = Hinv S Hinv^T */
+    double* T = dalloc((size_t)s * s);
+    double* Cnn = dalloc((size_t)s * s);
+    gemm(s, s, s, Hinv, s, S, s, 0, T, s, 0);
+    gemm(s, s, s, T, s, Hinv, s, 1, Cnn, s, 0);
+    /* :526  cross = -PH^T Hinv^T */
+    double* X = dalloc((size_t)n * s);
+    gemm(n, s, s, PHT, n, Hinv, s, 1, X, n, 0);
+    for (int j = 0; j < s; ++j) {
+        for (int i = 0; i < n; ++i) { CM(P, ld, i, n + j) = -CM(X, n, i, j); CM(P, ld, n + j, i) = -CM(X, n, i, j); }
+        for (int i = 0; i < s; ++i) CM(P, ld, n + i, n + j) = CM(Cnn, s, i, j);
+    }
+    symmetrize(P, n + s, ld);                                           /* :534 */
+    free(PHT); free(S); free(Hn); free(Hinv); free(T); free(Cnn); free(X);
+}
+
+/* Eigen::JacobiRotation::makeGivens for reals (Jacobi.h) */
+static void make_givens(double p, double q, double* c, double* s)
+{
+    if (q == 0.0) { *c = p < 0.0 ? -1.0 : 1.0; *s = 0.0; }
+    else if (p == 0.0) { *c = 0.0; *s = q < 0.0 ? 1.0 : -1.0; }
+    else if (fabs(p) > fabs(q)) {
+        double t = q / p, u = sqrt(1.0 + t * t);
+        if (p < 0.0) u = -u;
+        *c = 1.0 / u; *s = -t * *c;
+    } else {
+        double t = p / q, u = sqrt(1.0 + t * t);
+        if (q < 0.0) u = -u;
+        *s = -1.0 / u; *c = -t * *s;
+    }
+}
+
+/* rows (r-1, r) of A(:, c0..c1) <- G^* applied on the left: x' = c x - s y, y' = s x + c y */
+static void rot_rows(double* A, int lda, int r, int c0, int c1, double c, double s)
+{
+    for (int j = c0; j < c1; ++j) {
+        double x = CM(A, lda, r - 1, j), y = CM(A, lda, r, j);
+        CM(A, lda, r - 1, j) = c * x - s * y;
+        CM(A, lda, r, j) = s * x + c * y;
+    }
+}
+
+int orc_add_variable_delayed(double* P, int* n_io, int ld, const int* vidx, const int* vsize, int k,
+                             double* H_old, int ldh, double* H_new, int ldn, int m, int s, double* res,
+                             double noise, double chi2_mult, int do_chi2, double chi2_check, double* dx, double* chi2_out)
+{
+    int n = *n_io, nc = 0;
+    for (int a = 0; a < k; ++a) nc += vsize[a];
+    if (m <= s) return 0;                                               /* :571-575 */
+    /* :577-589 Givens: H_new -> upper triangular, same rotations on res and H_old */
+    for (int col = 0; col < s; ++col)
+        for (int r = m - 1; r > col; --r) {
+            double c, sn;
+            make_givens(CM(H_new, ldn, r - 1, col), CM(H_new, ldn, r, col), &c, &sn);
+            rot_rows(H_new, ldn, r, col, s, c, sn);
+            rot_rows(res, m > 0 ? m : 1, r, 0, 1, c, sn);
+            rot_rows(H_old, ldh, r, 0, nc, c, sn);
+        }
+    /* :591-599 split; :601-608 chi2 on the lower part */
+    const int mu = m - s;
+    double var = noise * noise;
+    double chi2 = orc_whiten_residual(P, ld, vidx, vsize, k, H_old + s, ldh, mu, res + s, &var, 0);
+    if (chi2_out) *chi2_out = chi2;
+    if (chi2 > chi2_mult * chi2_check && do_chi2) return 0;             /* :614-618 */
+    orc_add_variable_delayed_invertible(P, n, ld, vidx, vsize, k, H_old, ldh, H_new, ldn, s, noise);
+    *n_io = n + s;
+    for (int i = 0; i < n + s; ++i) dx[i] = 0.0;
+    if (mu > 0) orc_ekf_update(P, n + s, ld, vidx, vsize, k, H_old + s, ldh, mu, res + s, &var, 0, dx);   /* :623-624 */
+    return 1;
+}
+
+void orc_replace_var_linear(double* P, int n, int ld, int tidx, int tsize, const int* vidx, const int* vsize, int k,
+                            const double* H, int ldh)
+{
+    double* PHT = dalloc((size_t)n * tsize);
+    int hc = 0;
+    for (int a = 0; a < k; ++a) {
+        gemm(n, tsize, vsize[a], P + (size_t)vidx[a] * ld, ld, H + (size_t)hc * ldh, ldh, 1, PHT, n, 1);
+        hc += vsize[a];
+    }
+    double zero = 0.0;
+    double* HPH = form_S(P, ld, vidx, vsize, k, H, ldh, tsize, &zero, 0, NULL);          /* :683-685 */
+    for (int j = 0; j < tsize; ++j) for (int i = 0; i < n; ++i) CM(P, ld, i, tidx + j) = CM(PHT, n, i, j);      /* :687 */
+    for (int j = 0; j < tsize; ++j) for (int i = 0; i < n; ++i) CM(P, ld, tidx + j, i) = CM(PHT, n, i, j);      /* :689 */
+    for (int j = 0; j < tsize; ++j) for (int i = 0; i < tsize; ++i) CM(P, ld, tidx + i, tidx + j) = CM(HPH, tsize, i, j);   /* :691 */
+    free(PHT); free(HPH);
+}
+
+/* H (rows x 24 col-major, ld = 4): [epose 9 | ext 6 | anchor 6 | pf 3]; rows = 2 (mono) / 4 (stereo).
+ * LandmarkUpdate.cpp:521-572 (mono), :628-686 (stereo).  Quirk Q12 (as written, :682): the right-camera rows of the
+ * anchor block are -H_proj_r * R_cl2cr * skew(pf_w), without the R_w2cl factor the left rows carry. */
+int orc_landmark_rows_epose(const double R_i2w[9], const double p_i2w[3], const double R_cl2i[9], const double p_c2i[3],
+                            const double pf[3], const double* uv, int stereo, const double R_lr[9], const double t_lr[3],
+                            double* H, double* res)
+{
+    const int rows = stereo ? 4 : 2;
+    double d[3], pf_i[3], d2[3], pf_cl[3], pf_cr[3];
+    for (int i = 0; i < 3; ++i) d[i] = pf[i] - p_i2w[i];
+    m3_tmulv(R_i2w, d, pf_i);
+    for (int i = 0; i < 3; ++i) d2[i] = pf_i[i] - p_c2i[i];
+    m3_tmulv(R_cl2i, d2, pf_cl);
+    double RiT[9], RcT[9], Rw2cl[9], Sk[9], Ski[9];
+    m3_T(R_i2w, RiT); m3_T(R_cl2i, RcT);
+    m3_mul(RcT, RiT, Rw2cl);
+    orc_skew(pf, Sk); orc_skew(pf_i, Ski);
+    memset(H, 0, sizeof(double) * 4 * 24);
+    for (int eye = 0; eye < (stereo ? 2 : 1); ++eye) {
+        double q[3], Hp[6], L[9];
+        if (eye == 0) { memcpy(q, pf_cl, sizeof q); m3_eye(L); }
+        else {
+            m3_mulv(R_lr, pf_cl, pf_cr);
+            for (int i = 0; i < 3; ++i) pf_cr[i] += t_lr[i];
+            memcpy(q, pf_cr, sizeof q); memcpy(L, R_lr, sizeof L);
+        }
+        proj_jac(q, Hp);
+        res[2 * eye] = uv[2 * eye] - q[0] / q[2];
+        res[2 * eye + 1] = uv[2 * eye + 1] - q[1] / q[2];
+        double HL[6];                                   /* H_proj * L (2x3 row-major) */
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c)
+            HL[3 * r + c] = Hp[3 * r] * L[c] + Hp[3 * r + 1] * L[3 + c] + Hp[3 * r + 2] * L[6 + c];
+        double A[6], B[6], Cc[6], D[6], E[6];
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) {
+            double a = 0, b = 0, cc = 0, dd = 0, e = 0;
+            for (int l = 0; l < 3; ++l) {
+                a += HL[3 * r + l] * Rw2cl[3 * l + c];          /* HL R_w2cl            */
+                cc += HL[3 * r + l] * RcT[3 * l + c];           /* HL R_cl2i^T          */
+                e += HL[3 * r + l] * Sk[3 * l + c];             /* HL skew(pf_w)  (Q12) */
+            }
+            A[3 * r + c] = a; Cc[3 * r + c] = cc; E[3 * r + c] = e; (void)b; (void)dd;
+        }
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) {
+            double b = 0, dd = 0;
+            for (int l = 0; l < 3; ++l) { b += A[3 * r + l] * Sk[3 * l + c]; dd += Cc[3 * r + l] * Ski[3 * l + c]; }
+            B[3 * r + c] = b; D[3 * r + c] = dd;
+        }
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) {
+            const int row = 2 * eye + r;
+            CM(H, 4, row, c) = B[3 * r + c];                    /* epose theta:  H_proj (L) R_w2cl skew(pf_w) */
+            CM(H, 4, row, 3 + c) = -A[3 * r + c];               /* epose p                                   */
+            CM(H, 4, row, 9 + c) = D[3 * r + c];                /* ext theta:    H_proj (L) R_cl2i^T skew(pf_i) */
+            CM(H, 4, row, 12 + c) = -Cc[3 * r + c];             /* ext p                                     */
+            CM(H, 4, row, 15 + c) = eye == 0 ? -B[3 * r + c] : -E[3 * r + c];      /* anchor theta (right rows: Q12) */
+            CM(H, 4, row, 21 + c) = A[3 * r + c];               /* pf                                        */
+        }
+    }
+    return rows;
+}
+
+/* H (rows x 15 col-major, ld = 4): [curr pose 6 | anchor 6 | pf 3]; LandmarkUpdate.cpp:574-626 (mono) and its stereo twin. */
+int orc_landmark_rows_sw(const double R_cm[9], const double p_cm[3], const double pf[3], const double* uv, int stereo,
+                         const double R_lr[9], const double t_lr[3], int curr_is_anchor, double* H, double* res)
+{
+    const int rows = stereo ? 4 : 2;
+    double d[3], pf_cl[3], pf_cr[3], RT[9], Sk[9];
+    for (int i = 0; i < 3; ++i) d[i] = pf[i] - p_cm[i];
+    m3_tmulv(R_cm, d, pf_cl);
+    m3_T(R_cm, RT);
+    orc_skew(pf, Sk);
+    memset(H, 0, sizeof(double) * 4 * 15);
+    for (int eye = 0; eye < (stereo ? 2 : 1); ++eye) {
+        double q[3], Hp[6], L[9];
+        if (eye == 0) { memcpy(q, pf_cl, sizeof q); m3_eye(L); }
+        else {
+            m3_mulv(R_lr, pf_cl, pf_cr);
+            for (int i = 0; i < 3; ++i) pf_cr[i] += t_lr[i];
+            memcpy(q, pf_cr, sizeof q); memcpy(L, R_lr, sizeof L);
+        }
+        proj_jac(q, Hp);
+        res[2 * eye] = uv[2 * eye] - q[0] / q[2];
+        res[2 * eye + 1] = uv[2 * eye + 1] - q[1] / q[2];
+        double HL[6], A[6], B[6];
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c)
+            HL[3 * r + c] = Hp[3 * r] * L[c] + Hp[3 * r + 1] * L[3 + c] + Hp[3 * r + 2] * L[6 + c];
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) {
+            double a = 0;
+            for (int l = 0; l < 3; ++l) a += HL[3 * r + l] * RT[3 * l + c];
+            A[3 * r + c] = a;
+        }
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) {
+            double b = 0;
+            for (int l = 0; l < 3; ++l) b += A[3 * r + l] * Sk[3 * l + c];
+            B[3 * r + c] = b;
+        }
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) {
+            const int row = 2 * eye + r;
+            if (!curr_is_anchor) { CM(H, 4, row, c) = B[3 * r + c]; CM(H, 4, row, 6 + c) = -B[3 * r + c]; }
+            CM(H, 4, row, 3 + c) = -A[3 * r + c];
+            CM(H, 4, row, 12 + c) = A[3 * r + c];
+        }
+    }
+    return rows;
+}

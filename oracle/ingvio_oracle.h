@@ -188,7 +188,32 @@ typedef struct {
  * untouched on its early "translation too small" exit, callers ignore it on failure). */
 int orc_triangulate(const orc_tri_in* in, double pf[3]);
 
+/* ---- SLAM-landmark path ---------------------------------------------
+ * StateManager::addVariableDelayedInvertible (StateManager.cpp:461-543): appends s rows/cols to P (n -> n+s),
+ * H_old s x sum(vsize) (ldh), H_new s x s (ldn). */
+void orc_add_variable_delayed_invertible(double* P, int n, int ld, const int* vidx, const int* vsize, int k,
+                                         const double* H_old, int ldh, const double* H_new, int ldn, int s, double noise);
+/* StateManager::addVariableDelayed (:549-637): Givens QR of H_new (m x s) applied to H_old / res IN PLACE, chi2 of the
+ * lower m-s rows against chi2_mult * chi2_check (chi2_check = quantile(chi_squared(m), 0.95), supplied by the caller),
+ * invertible add with the top s rows, EKF update with the rest (dx [n+s], boxPlus is the caller's).
+ * Returns 1 (added, *n_io += s) or 0 (rejected / m <= s). */
+int orc_add_variable_delayed(double* P, int* n_io, int ld, const int* vidx, const int* vsize, int k,
+                             double* H_old, int ldh, double* H_new, int ldn, int m, int s, double* res,
+                             double noise, double chi2_mult, int do_chi2, double chi2_check, double* dx, double* chi2_out);
+/* StateManager::replaceVarLinear (:639-693): rows/cols of the target variable <- P H^T, diagonal block <- H Pcc H^T. */
+void orc_replace_var_linear(double* P, int n, int ld, int tidx, int tsize, const int* vidx, const int* vsize, int k,
+                            const double* H, int ldh);
+/* LandmarkUpdate::calcResJacobianSingleLandmark{Mono,Stereo} (LandmarkUpdate.cpp:521-572, 619-686):
+ * H rows x 24 column-major (ld 4) = [extended pose 9 | extrinsics 6 | anchor 6 | landmark 3]; returns rows. */
+int orc_landmark_rows_epose(const double R_i2w[9], const double p_i2w[3], const double R_cl2i[9], const double p_c2i[3],
+                            const double pf[3], const double* uv, int stereo, const double R_lr[9], const double t_lr[3],
+                            double* H, double* res);
+/* the sliding-window-pose form (:574-617): H rows x 15 (ld 4) = [current clone 6 | anchor 6 | landmark 3]. */
+int orc_landmark_rows_sw(const double R_cm[9], const double p_cm[3], const double pf[3], const double* uv, int stereo,
+                         const double R_lr[9], const double t_lr[3], int curr_is_anchor, double* H, double* res);
+
 #ifdef __cplusplus
 }
 #endif
+
 #endif

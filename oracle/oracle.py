@@ -203,6 +203,41 @@ class Cov:
                                   _d(f64(res)), _d(Rb), C.c_int(kind), _d(dx))
         return dx, rc
 
+    # ---- SURVEY 8(f) f-2 -------------------------------------------------------------------------
+    def add_variable_delayed_invertible(self, vidx, vsize, H_old, H_new, noise):
+        H_old = np.asfortranarray(np.atleast_2d(H_old), dtype=np.float64)
+        H_new = np.asfortranarray(np.atleast_2d(H_new), dtype=np.float64)
+        s = H_new.shape[0]
+        assert self.n + s <= self.ld
+        lib().orc_add_variable_delayed_invertible(_d(self.buf), C.c_int(self.n), C.c_int(self.ld), _i(i32(vidx)), _i(i32(vsize)),
+                                                  C.c_int(len(vidx)), _d(H_old), C.c_int(s), _d(H_new), C.c_int(s), C.c_int(s),
+                                                  C.c_double(noise))
+        self.n += s
+        return self.n - s
+
+    def add_variable_delayed(self, vidx, vsize, H_old, H_new, res, noise, chi2_mult=1.0, do_chi2=True, chi2_check=None):
+        """Returns (added, dx[n+s], chi2).  chi2_check defaults to quantile(chi2(m), 0.95) (scipy)."""
+        H_old = np.array(np.atleast_2d(H_old), dtype=np.float64, order="F")
+        H_new = np.array(np.atleast_2d(H_new), dtype=np.float64, order="F")
+        res = f64(res).copy()
+        m, s = H_new.shape
+        if chi2_check is None:
+            from scipy.stats import chi2 as _chi2
+            chi2_check = float(_chi2.ppf(0.95, m))
+        dx = np.zeros(self.n + s); n_io = C.c_int(self.n); chi2 = C.c_double(0.0)
+        assert self.n + s <= self.ld
+        added = lib().orc_add_variable_delayed(_d(self.buf), C.byref(n_io), C.c_int(self.ld), _i(i32(vidx)), _i(i32(vsize)),
+                                               C.c_int(len(vidx)), _d(H_old), C.c_int(m), _d(H_new), C.c_int(m), C.c_int(m),
+                                               C.c_int(s), _d(res), C.c_double(noise), C.c_double(chi2_mult),
+                                               C.c_int(1 if do_chi2 else 0), C.c_double(chi2_check), _d(dx), C.byref(chi2))
+        self.n = n_io.value
+        return bool(added), dx, chi2.value
+
+    def replace_var_linear(self, tidx, tsize, vidx, vsize, H):
+        H = np.asfortranarray(np.atleast_2d(H), dtype=np.float64)
+        lib().orc_replace_var_linear(_d(self.buf), C.c_int(self.n), C.c_int(self.ld), C.c_int(tidx), C.c_int(tsize),
+                                     _i(i32(vidx)), _i(i32(vsize)), C.c_int(len(vidx)), _d(H), C.c_int(H.shape[0]))
+
     def msckf_update(self, frame, **kw):
         ms, keep = make_msckf_in(frame, **kw)
         F = ms.n_feat
@@ -346,6 +381,23 @@ def triangulate(clone_R, clone_p, mask, uv, stereo, R_lr=None, t_lr=None, **para
     pf = np.zeros(3)
     ok = lib().orc_triangulate(C.byref(t), _d(pf))
     return bool(ok), pf
+
+
+def landmark_rows_epose(R_i2w, p_i2w, R_cl2i, p_c2i, pf, uv, stereo, R_lr=None, t_lr=None):
+    """LandmarkUpdate::calcResJacobianSingleLandmark{Mono,Stereo}: (H rows x 24, res)."""
+    H = np.zeros((4, 24), order="F"); res = np.zeros(4)
+    R_lr = np.eye(3) if R_lr is None else R_lr; t_lr = np.zeros(3) if t_lr is None else t_lr
+    rows = lib().orc_landmark_rows_epose(_d(f64(R_i2w)), _d(f64(p_i2w)), _d(f64(R_cl2i)), _d(f64(p_c2i)), _d(f64(pf)), _d(f64(uv)),
+                                         C.c_int(1 if stereo else 0), _d(f64(R_lr)), _d(f64(t_lr)), _d(H), _d(res))
+    return H[:rows].copy(), res[:rows].copy()
+
+
+def landmark_rows_sw(R_cm, p_cm, pf, uv, stereo, curr_is_anchor, R_lr=None, t_lr=None):
+    H = np.zeros((4, 15), order="F"); res = np.zeros(4)
+    R_lr = np.eye(3) if R_lr is None else R_lr; t_lr = np.zeros(3) if t_lr is None else t_lr
+    rows = lib().orc_landmark_rows_sw(_d(f64(R_cm)), _d(f64(p_cm)), _d(f64(pf)), _d(f64(uv)), C.c_int(1 if stereo else 0),
+                                      _d(f64(R_lr)), _d(f64(t_lr)), C.c_int(1 if curr_is_anchor else 0), _d(H), _d(res))
+    return H[:rows].copy(), res[:rows].copy()
 
 
 def qr_compress(A, b):
