@@ -112,6 +112,26 @@ int ingvio_chi2_gamma(ingvio_ctx* ctx, int b, const int* vidx, const int* vsize,
                       const double* H, int ldh, int m, const double* res,
                       const double* R, int r_kind, double* gamma);
 
+/* ---- SLAM-landmark covariance operations -----------------------------
+ * addVariableDelayedInvertible (StateManager.cpp:461-543): H_old s x sum(vsize) (ldh), H_new s x s (ldn),
+ * s <= 6; appends s rows/columns, new_idx receives the new variable's idx (== old N). */
+int ingvio_add_variable_delayed_invertible(ingvio_ctx* ctx, int b, const int* vidx, const int* vsize, int k,
+                                           const double* H_old, int ldh, const double* H_new, int ldn, int s,
+                                           double noise, int* new_idx);
+/* addVariableDelayed (StateManager.cpp:549-637): H_old m x sum(vsize), H_new m x s, res [m] (inputs are not
+ * modified; the Givens rotations run on the device copy).  chi2_check = quantile(chi_squared(m), 0.95)
+ * (boost in the reference, :610-612; the caller supplies it).  *added = 0 when m <= s (:571-575) or when the
+ * chi2 test fails (:614-618; state untouched).  On success the variable is appended (new_idx), the EKF update
+ * with the remaining m-s rows is applied to the covariance and dx_out [N+s] = K res; the host applies boxPlus. */
+int ingvio_add_variable_delayed(ingvio_ctx* ctx, int b, const int* vidx, const int* vsize, int k,
+                                const double* H_old, int ldh, const double* H_new, int ldn, int m, int s,
+                                const double* res, double noise, double chi2_mult, int do_chi2, double chi2_check,
+                                double* dx_out, int* added, int* new_idx, double* chi2_out);
+/* replaceVarLinear (StateManager.cpp:639-693): the target variable (tidx, tsize <= 6) becomes H * [dependence
+ * variables]: its rows/columns <- P H^T, its diagonal block <- H Pcc H^T.  H tsize x sum(vsize) (ldh). */
+int ingvio_replace_var_linear(ingvio_ctx* ctx, int b, int tidx, int tsize, const int* vidx, const int* vsize, int k,
+                              const double* H, int ldh);
+
 /* ---- MSCKF visual update: K3-K11 ----------------------------------------------------------
  * One frame of flattened MapServer data for one filter (FeatureInfo/_stereo_obs/_landmark,
  * MapServer.h:69-134, flattened by the host shim).  Clones in ascending timestamp. */

@@ -27,6 +27,7 @@ EXPORTS = [
     "ingvio_frame_stage", "ingvio_frame_run", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_select",
     "ingvio_profile_reset",
     "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_debug_read", "ingvio_triangulate",
+    "ingvio_add_variable_delayed_invertible", "ingvio_add_variable_delayed", "ingvio_replace_var_linear",
 ]
 
 
@@ -265,6 +266,36 @@ class Context:
         self._chk(self.L.ingvio_chi2_gamma(self.h, b, _i(i32(vidx)), _i(i32(vsize)), len(vidx), _d(H), m, m, _d(f64(res)),
                                            _d(Rb), kind, C.byref(g)))
         return g.value
+
+    # ---- SLAM-landmark path (f-2) --------------------------------------------------------------
+    def add_variable_delayed_invertible(self, b, vidx, vsize, H_old, H_new, noise):
+        H_old = np.asfortranarray(np.atleast_2d(H_old), dtype=np.float64)
+        H_new = np.asfortranarray(np.atleast_2d(H_new), dtype=np.float64)
+        s = H_new.shape[0]
+        idx = C.c_int(-1)
+        self._chk(self.L.ingvio_add_variable_delayed_invertible(self.h, b, _i(i32(vidx)), _i(i32(vsize)), len(vidx), _d(H_old), s,
+                                                                _d(H_new), s, s, C.c_double(noise), C.byref(idx)))
+        return idx.value
+
+    def add_variable_delayed(self, b, vidx, vsize, H_old, H_new, res, noise, chi2_mult=1.0, do_chi2=True, chi2_check=None):
+        """Returns (added, dx[n+s] or None, chi2, new_idx)."""
+        H_old = np.asfortranarray(np.atleast_2d(H_old), dtype=np.float64)
+        H_new = np.asfortranarray(np.atleast_2d(H_new), dtype=np.float64)
+        m, s = H_new.shape
+        if chi2_check is None:
+            from scipy.stats import chi2 as _chi2
+            chi2_check = float(_chi2.ppf(0.95, m))
+        dx = np.zeros(self.n(b) + s); added = C.c_int(0); idx = C.c_int(-1); chi2 = C.c_double(0.0)
+        self._chk(self.L.ingvio_add_variable_delayed(self.h, b, _i(i32(vidx)), _i(i32(vsize)), len(vidx), _d(H_old), m, _d(H_new), m,
+                                                     m, s, _d(f64(res)), C.c_double(noise), C.c_double(chi2_mult),
+                                                     1 if do_chi2 else 0, C.c_double(chi2_check), _d(dx), C.byref(added),
+                                                     C.byref(idx), C.byref(chi2)))
+        return bool(added.value), (dx if added.value else None), chi2.value, idx.value
+
+    def replace_var_linear(self, b, tidx, tsize, vidx, vsize, H):
+        H = np.asfortranarray(np.atleast_2d(H), dtype=np.float64)
+        self._chk(self.L.ingvio_replace_var_linear(self.h, b, int(tidx), int(tsize), _i(i32(vidx)), _i(i32(vsize)), len(vidx),
+                                                   _d(H), H.shape[0]))
 
     def msckf_update(self, b0, frames, max_accept=0, compress_rule=1, selected_variant=0):
         """frames: list of frame dicts (one per filter).  Returns (dx[nb,n], accepted[nb,F], gamma[nb,F], rows[nb])."""

@@ -7,6 +7,7 @@
 #include "launch_msckf.h"
 #include "launch_factored.h"
 #include "launch_tri.h"
+#include "launch_lm.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -53,7 +54,7 @@ struct ingvio_ctx {
     double *d_clone_R, *d_clone_p, *d_pf, *d_uv, *d_chi2;
     unsigned long long* d_mask;
     // msckf / ekf workspaces
-    double *d_gamma, *d_Rpart, *d_H, *d_res, *d_noise, *d_noise1, *d_Y, *d_Yc, *d_dx, *d_rec;
+    double *d_gamma, *d_Rpart, *d_H, *d_res, *d_noise, *d_noise1, *d_Y, *d_Yc, *d_dx, *d_rec, *d_hnew;
     int method;                    // 0 dense TSQR path, 1 factored (information-form) path
     int *d_accept, *d_used, *d_chunk_used, *d_colmap, *d_m, *d_nc, *d_status, *d_pcbase;
     double *d_big_sg, *d_big_wk;        // large-window workspaces (c_max > 16)
@@ -336,6 +337,7 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
         rc |= dalloc(c, &c->d_big_sg, (size_t)B * bigwin_sg_doubles(c->G)); rc |= dalloc(c, &c->d_big_wk, (size_t)B * bigwin_wk_doubles());
     }
     rc |= dalloc(c, &c->d_noise, B); rc |= dalloc(c, &c->d_noise1, (size_t)c->mld * c->mld);
+    rc |= dalloc(c, &c->d_hnew, (size_t)c->mld * 6);
     rc |= dalloc(c, &c->d_Y, (size_t)B * c->ystride); rc |= dalloc(c, &c->d_Yc, (size_t)B * c->ystride);
     rc |= dalloc(c, &c->d_dx, (size_t)B * c->ldp);
     rc |= dalloc(c, &c->d_rec, (size_t)B * fm * factored_rec_size(desc->c_max));
@@ -352,7 +354,7 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
     void* ptrs[] = { c->Pbase, c->Psnap, c->d_cur, c->d_n, c->d_n_snap, c->d_Phi, c->d_G, c->d_dt, c->d_R, c->d_blk, c->d_gnss,
                      c->d_idx, c->d_clone_idx, c->d_nclones, c->d_nfeat, c->d_anchor, c->d_dof, c->d_clone_R, c->d_clone_p,
                      c->d_pf, c->d_uv, c->d_chi2, c->d_mask, c->d_gamma, c->d_accept, c->d_used, c->d_Rpart, c->d_chunk_used,
-                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk, c->d_tri_ok };
+                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk, c->d_tri_ok, c->d_hnew };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (c->own_stream) hipStreamDestroy(c->st);
@@ -603,6 +605,101 @@ int ingvio_msckf_update(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame*
         if (status[i] & 2) soft = INGVIO_NEG_DIAG;
     }
     return nb == 1 ? soft : (soft == INGVIO_NEG_DIAG ? soft : INGVIO_OK);
+}
+
+// ---- SLAM-landmark covariance operations -------------------------------------------------------
+static int stage_hnew(ingvio_ctx* c, const double* H_new, int ldn, int m, int s)
+{
+    if (!H_new || s < 1 || s > 6 || ldn < m || m > c->mld) return INGVIO_E_ARG;
+    std::vector<double> Hn((size_t)c->mld * s, 0.0);
+    for (int j = 0; j < s; ++j) memcpy(&Hn[(size_t)j * c->mld], H_new + (size_t)j * ldn, 8 * (size_t)m);
+    if (up(c, c->d_hnew, Hn.data(), 8 * Hn.size())) return INGVIO_E_HIP;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return 0;
+}
+
+int ingvio_add_variable_delayed_invertible(ingvio_ctx* c, int b, const int* vidx, const int* vsize, int k, const double* H_old, int ldh,
+                                           const double* H_new, int ldn, int s, double noise, int* new_idx)
+{
+    if (check_range(c, b, 1)) return INGVIO_E_ARG;
+    if (c->h_n[b] + s > c->d.n_max) return INGVIO_E_CAPACITY;
+    int nc = 0;
+    const double var = noise * noise;
+    std::vector<double> zero((size_t)(s > 0 ? s : 1), 0.0);
+    int rc = stage_generic(c, b, vidx, vsize, k, H_old, ldh, s, zero.data(), &var, 0, &nc);
+    if (rc) return rc;
+    rc = stage_hnew(c, H_new, ldn, s, s);
+    if (rc) return rc;
+    if (launch_delayed_add(view(c), b, c->d_H + (size_t)b * c->hstride, c->d_hnew, c->d_colmap + (size_t)b * c->cstride, s, nc, c->mld,
+                           var, c->d_Y + (size_t)b * c->ystride, c->st)) return INGVIO_E_CAPACITY;
+    if (new_idx) *new_idx = c->h_n[b];
+    c->h_n[b] += s;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return last_launch(c);
+}
+
+int ingvio_add_variable_delayed(ingvio_ctx* c, int b, const int* vidx, const int* vsize, int k, const double* H_old, int ldh,
+                                const double* H_new, int ldn, int m, int s, const double* res, double noise, double chi2_mult,
+                                int do_chi2, double chi2_check, double* dx_out, int* added, int* new_idx, double* chi2_out)
+{
+    if (check_range(c, b, 1) || !added) return INGVIO_E_ARG;
+    *added = 0;
+    if (m <= s) return INGVIO_OK;                                                  // StateManager.cpp:571-575
+    if (c->h_n[b] + s > c->d.n_max) return INGVIO_E_CAPACITY;
+    int nc = 0;
+    const double var = noise * noise;
+    int rc = stage_generic(c, b, vidx, vsize, k, H_old, ldh, m, res, &var, 0, &nc);
+    if (rc) return rc;
+    rc = stage_hnew(c, H_new, ldn, m, s);
+    if (rc) return rc;
+    double* dH = c->d_H + (size_t)b * c->hstride;
+    double* dres = c->d_res + (size_t)b * c->mld;
+    const int* dcm = c->d_colmap + (size_t)b * c->cstride;
+    if (launch_delayed_qr(dH, dres, c->d_hnew, m, s, nc, c->mld, c->st)) return INGVIO_E_CAPACITY;      // :577-589
+    const int mu = m - s;
+    if ((size_t)8 * ((size_t)nc * mu + (size_t)(mu + 1) * (mu + 1)) > 150 * 1024) return INGVIO_E_CAPACITY;
+    launch_gamma(view(c), b, dH + s, dres + s, dcm, mu, nc, c->d_noise1, 0, c->mld, c->d_gamma + (size_t)b * c->d.f_max, c->st);   // :601-608
+    double chi2 = 0.0;
+    if (down_sync(c, &chi2, c->d_gamma + (size_t)b * c->d.f_max, 8)) return INGVIO_E_HIP;
+    if (chi2_out) *chi2_out = chi2;
+    if (chi2 > chi2_mult * chi2_check && do_chi2) return last_launch(c);           // :614-618
+    if (launch_delayed_add(view(c), b, dH, c->d_hnew, dcm, s, nc, c->mld, var, c->d_Y + (size_t)b * c->ystride, c->st))
+        return INGVIO_E_CAPACITY;
+    if (new_idx) *new_idx = c->h_n[b];
+    c->h_n[b] += s;
+    *added = 1;
+    // :623-624 ekfUpdate with the lower rows on the extended state
+    int zero = 0;
+    if (up(c, c->d_status + b, &zero, sizeof(int)) || up(c, c->d_m + b, &mu, sizeof(int))) return INGVIO_E_HIP;
+    EkfLaunch E;
+    memset(&E, 0, sizeof E);
+    E.cv = view(c); E.b0 = b; E.nb = 1; E.H = dH + s; E.res = dres + s; E.colmap = dcm; E.m = c->d_m + b; E.nc = c->d_nc + b;
+    E.noise = c->d_noise1; E.r_kind = 0; E.mld = c->mld; E.hstride = c->hstride; E.cstride = c->cstride;
+    E.nstride = c->mld * c->mld; E.Y = c->d_Y + (size_t)b * c->ystride; E.ystride = c->ystride; E.dx = c->d_dx;
+    E.status = c->d_status; E.m_cap = mu; E.nc_cap = nc;
+    launch_ekf_core(E, c->st);
+    launch_downdate(E, c->h_n[b], c->st);
+    int status = 0;
+    if (dx_out && down_sync(c, dx_out, c->d_dx + (size_t)b * c->ldp, 8 * (size_t)c->h_n[b])) return INGVIO_E_HIP;
+    if (down_sync(c, &status, c->d_status + b, sizeof(int))) return INGVIO_E_HIP;
+    rc = last_launch(c);
+    if (rc) return rc;
+    return (status & 2) ? INGVIO_NEG_DIAG : INGVIO_OK;
+}
+
+int ingvio_replace_var_linear(ingvio_ctx* c, int b, int tidx, int tsize, const int* vidx, const int* vsize, int k, const double* H, int ldh)
+{
+    if (check_range(c, b, 1) || tsize < 1 || tsize > 6) return INGVIO_E_ARG;
+    if (tidx < 0 || tidx + tsize > c->h_n[b]) return INGVIO_E_NOT_IN_STATE;       // "Target var not in state" (:653-657)
+    int nc = 0;
+    const double one = 1.0;
+    std::vector<double> zero((size_t)tsize, 0.0);
+    int rc = stage_generic(c, b, vidx, vsize, k, H, ldh, tsize, zero.data(), &one, 0, &nc);
+    if (rc) return rc;
+    if (launch_replace_var(view(c), b, c->d_H + (size_t)b * c->hstride, c->d_colmap + (size_t)b * c->cstride, tidx, tsize, nc, c->mld,
+                           c->d_Y + (size_t)b * c->ystride, c->st)) return INGVIO_E_CAPACITY;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return last_launch(c);
 }
 
 // Triangulator::triangulate{Mono,Stereo}Obs for every feature of the given (or staged) frames

@@ -180,3 +180,114 @@ def test_landmark_rows_sw_finite_differences():
     assert np.allclose(H, Hfd, atol=2e-5) and np.allclose(res, 0.01, atol=1e-14)
     Ha, _ = orc.landmark_rows_sw(Rm, pm, pf, uv, False, True)                   # current clone IS the anchor (:607-611)
     assert np.all(Ha[:, 0:3] == 0) and np.all(Ha[:, 6:9] == 0) and np.array_equal(Ha[:, 3:6], H[:, 3:6])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GPU: the same operations through the C ABI vs the oracle
+# ------------------------------------------------------------------------------------------------------------------
+def _ctx(n, C, m_max=96):
+    from ingvio_amd import capi
+    return capi.Context(batch=2, n_max=((n + 15) // 16) * 16 + 16, c_max=C, f_max=32, m_max=m_max)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,nobs,s,stereo", [(11, 11, 3, True), (11, 11, 3, False), (6, 5, 3, True), (11, 9, 1, False), (21, 21, 3, True)])
+def test_gpu_add_variable_delayed(C, nobs, s, stereo):
+    rng = np.random.default_rng(100 + C + nobs + s)
+    n = 21 + 6 * C
+    P0 = spd(n, rng, 1e-2)
+    vidx = [21 + 6 * i for i in range(C)]; vsize = [6] * C
+    m = (4 if stereo else 2) * nobs
+    H_old = rng.standard_normal((m, 6 * C)); H_new = rng.standard_normal((m, s)); res = 0.05 * rng.standard_normal(m)
+    ctx = _ctx(n, C, m_max=max(96, m + 8))
+    for b in (0, 1):
+        ctx.cov_set(b, P0)
+    c = orc.Cov(P0)
+    addo, dxo, chi2o = c.add_variable_delayed(vidx, vsize, H_old, H_new, res, 0.1, 1.0, False)
+    addg, dxg, chi2g, idx = ctx.add_variable_delayed(1, vidx, vsize, H_old, H_new, res, 0.1, 1.0, False)
+    assert addo and addg and idx == n and ctx.n(1) == n + s and ctx.n(0) == n
+    Pg = ctx.cov_get(1)
+    assert np.linalg.norm(Pg - c.P) / np.linalg.norm(c.P) < 1e-11
+    assert np.linalg.norm(dxg - dxo) < 1e-9 * max(1.0, np.linalg.norm(dxo)) and abs(chi2g - chi2o) < 1e-9 * max(1.0, chi2o)
+    assert np.array_equal(Pg, Pg.T) and np.array_equal(ctx.cov_get(0), P0)
+    # chi2 rejection leaves the state untouched (:614-618); m <= s is refused (:571-575)
+    addg, dxg, chi2g, _ = ctx.add_variable_delayed(0, vidx, vsize, H_old, H_new, 50.0 * np.ones(m), 0.1, 0.95, True)
+    assert not addg and ctx.n(0) == n and np.array_equal(ctx.cov_get(0), P0)
+    addg, _, _, _ = ctx.add_variable_delayed(0, vidx, vsize, H_old[:s], H_new[:s], res[:s], 0.1, 1.0, False)
+    assert not addg and ctx.n(0) == n
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_add_variable_delayed_invertible_and_replace():
+    rng = np.random.default_rng(300)
+    C = 8; n = 21 + 6 * C
+    P0 = spd(n, rng, 1e-2)
+    ctx = _ctx(n, C)
+    ctx.cov_set(0, P0)
+    c = orc.Cov(P0)
+    # addVarInv shape of the reference test (scalar on the extended pose), then a 3-vector on two clones
+    H1 = rng.uniform(-1, 1, (1, 9))
+    assert ctx.add_variable_delayed_invertible(0, [0], [9], H1, np.array([[1.0]]), 2.0) == c.add_variable_delayed_invertible([0], [9], H1, np.array([[1.0]]), 2.0)
+    Hx = rng.standard_normal((3, 12)); Hf = rng.standard_normal((3, 3)) + 2 * np.eye(3)
+    ig = ctx.add_variable_delayed_invertible(0, [21, 45], [6, 6], Hx, Hf, 0.05)
+    io = c.add_variable_delayed_invertible([21, 45], [6, 6], Hx, Hf, 0.05)
+    assert ig == io == n + 1 and ctx.n(0) == n + 4
+    assert np.linalg.norm(ctx.cov_get(0) - c.P) / np.linalg.norm(c.P) < 1e-12
+    # anchor change of that 3-vector (MapServerManager.cpp:363-375)
+    pf = rng.standard_normal(3)
+    H = np.zeros((3, 15)); H[:, 0:3] = -skew(pf); H[:, 6:9] = skew(pf); H[:, 12:15] = np.eye(3)
+    ctx.replace_var_linear(0, ig, 3, [21, 63, ig], [6, 6, 3], H)
+    c.replace_var_linear(io, 3, [21, 63, io], [6, 6, 3], H)
+    Pg = ctx.cov_get(0)
+    assert np.linalg.norm(Pg - c.P) / np.linalg.norm(c.P) < 1e-12 and np.array_equal(Pg, Pg.T)
+    # errors: target outside the state, capacity
+    from ingvio_amd import capi
+    with pytest.raises(capi.IngvioError):
+        ctx.replace_var_linear(0, ctx.n(0), 3, [21], [6], np.zeros((3, 6)))
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stereo", [True, False])
+def test_gpu_landmark_update_rows_through_generic_update(stereo):
+    """updateLandmark{Mono,Stereo} (LandmarkUpdate.cpp:32-149, 688-8xx) = per-landmark rows, whitenResidual gate, stacked
+    ekfUpdate: the covariance arithmetic is ingvio_chi2_gamma + ingvio_ekf_update on the oracle's rows."""
+    rng = np.random.default_rng(400)
+    C, L = 6, 5
+    n = 21 + 6 * C + 3 * L
+    P0 = spd(n, rng, 1e-3)
+    ctx = _ctx(n, C, m_max=128)
+    ctx.cov_set(0, P0)
+    c = orc.Cov(P0)
+    Ri, Rc, Rlr = rot(rng), rot(rng, 0.1), rot(rng, 0.02)
+    pi, pc, tlr = rng.standard_normal(3), 0.1 * rng.standard_normal(3), np.array([-0.11, 0.001, 0.002])
+    rows = 4 if stereo else 2
+    Hs, rs, order = [], [], [(0, 9), (15, 6)]
+    col = {0: 0, 15: 9}; ncol = 15
+    blocks = []
+    for l in range(L):
+        pf = pi + Ri @ (Rc @ np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(3, 9)]) + pc)
+        uv = _meas_epose(Ri, pi, Rc, pc, pf, True, Rlr, tlr) + 0.003 * rng.standard_normal(4)
+        H, r = orc.landmark_rows_epose(Ri, pi, Rc, pc, pf, uv, stereo, Rlr, tlr)
+        a_idx = 21 + 6 * int(rng.integers(0, C)); l_idx = 21 + 6 * C + 3 * l
+        vo = [0, 15, a_idx, l_idx]; vs = [9, 6, 6, 3]
+        go = c.whiten(vo, vs, H, r, 0.01 ** 2)
+        gg = ctx.chi2_gamma(0, vo, vs, H, r, 0.01 ** 2)
+        assert abs(go - gg) < 1e-9 * max(1.0, go)
+        for v, sz in ((a_idx, 6), (l_idx, 3)):
+            if v not in col:
+                col[v] = ncol; ncol += sz; order.append((v, sz))
+        blocks.append((H, r, a_idx, l_idx))
+    Hl = np.zeros((rows * L, ncol)); rl = np.zeros(rows * L)
+    for l, (H, r, a_idx, l_idx) in enumerate(blocks):
+        sl = slice(rows * l, rows * l + rows)
+        Hl[sl, 0:9] = H[:, 0:9]; Hl[sl, 9:15] = H[:, 9:15]
+        Hl[sl, col[a_idx]:col[a_idx] + 6] = H[:, 15:21]; Hl[sl, col[l_idx]:col[l_idx] + 3] = H[:, 21:24]
+        rl[sl] = r
+    vo = [v for v, _ in order]; vs = [s for _, s in order]
+    dxo, _ = c.ekf_update(vo, vs, Hl, rl, 0.01 ** 2)
+    dxg, _ = ctx.ekf_update(0, vo, vs, Hl, rl, 0.01 ** 2)
+    assert np.linalg.norm(ctx.cov_get(0) - c.P) / np.linalg.norm(c.P) < 1e-11
+    assert np.linalg.norm(dxg - dxo) < 1e-9 * max(1.0, np.linalg.norm(dxo))
+    ctx.close()
