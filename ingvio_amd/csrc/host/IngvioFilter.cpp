@@ -13,6 +13,7 @@ IngvioFilter::IngvioFilter(const IngvioParams& params, std::shared_ptr<Triangula
     _remove_lost_update = std::make_shared<RemoveLostUpdate>(_filter_params);
     _sw_marg_update = std::make_shared<SwMargUpdate>(_filter_params);
     _keyframe_update = std::make_shared<KeyframeUpdate>(_filter_params);
+    _landmark_update = std::make_shared<LandmarkUpdate>(_filter_params);                // :90
 }
 
 void IngvioFilter::callbackIMU(const ImuMsg& m)
@@ -35,6 +36,7 @@ void IngvioFilter::collectStereoMeas(const StereoFrameMsg& f)
             fi->_landmark->resetAnchoredPose(anchor);
             it = _map_server->insert({ o.id, fi }).first;
         }
+        if (it->second->_ftype == FeatureInfo::SLAM) it->second->_stereo_obs.clear();      // MapServerManager.cpp:178-179
         auto sm = std::make_shared<StereoMeas>();
         sm->_u0 = o.u0; sm->_v0 = o.v0; sm->_u1 = o.u1; sm->_v1 = o.v1;
         it->second->_stereo_obs[f.stamp] = sm;
@@ -52,6 +54,7 @@ void IngvioFilter::collectMonoMeas(const MonoFrameMsg& f)
             fi->_landmark->resetAnchoredPose(anchor);
             it = _map_server->insert({ o.id, fi }).first;
         }
+        if (it->second->_ftype == FeatureInfo::SLAM) it->second->_mono_obs.clear();        // MapServerManager.cpp:136-137
         auto mm = std::make_shared<MonoMeas>();
         mm->_u0 = o.u0; mm->_v0 = o.v0;
         it->second->_mono_obs[f.stamp] = mm;
@@ -70,13 +73,27 @@ void IngvioFilter::callbackStereoFrame(const StereoFrameMsg& frame)
     _remove_lost_update->updateStateStereo(_state, _map_server, _tri);
     if (_filter_params._is_key_frame) {
         _keyframe_update->updateStateStereo(_state, _map_server, _tri);
+        if (_filter_params._max_lm_feats > 0) {                                         // :283-289
+            _landmark_update->updateLandmarkStereo(_state, _map_server);
+            _landmark_update->initNewLandmarkStereo(_state, _map_server, _tri, _filter_params._max_sw_clones);
+        }
         _keyframe_update->cleanStereoObsAtMargTime(_state, _map_server);
         _keyframe_update->changeMSCKFAnchor(_state, _map_server);
+        if (_filter_params._max_lm_feats > 0) {                                         // :295-301
+            std::vector<double> marg_kfs;
+            _keyframe_update->getMargKfs(_state, marg_kfs);
+            _landmark_update->changeLandmarkAnchor(_state, _map_server, marg_kfs);
+        }
         _keyframe_update->margSwPose(_state);
     } else {
         _sw_marg_update->updateStateStereo(_state, _map_server, _tri);
+        if (_filter_params._max_lm_feats > 0) {                                         // :309-315
+            _landmark_update->updateLandmarkStereo(_state, _map_server);
+            _landmark_update->initNewLandmarkStereo(_state, _map_server, _tri, _filter_params._max_sw_clones);
+        }
         _sw_marg_update->cleanStereoObsAtMargTime(_state, _map_server);
         _sw_marg_update->changeMSCKFAnchor(_state, _map_server);
+        if (_filter_params._max_lm_feats > 0) _landmark_update->changeLandmarkAnchor(_state, _map_server);      // :321-322
         _sw_marg_update->margSwPose(_state);
     }
     eraseInvalidFeatures(_map_server, _state);
@@ -95,13 +112,27 @@ void IngvioFilter::callbackMonoFrame(const MonoFrameMsg& frame)
     _remove_lost_update->updateStateMono(_state, _map_server, _tri);
     if (_filter_params._is_key_frame) {
         _keyframe_update->updateStateMono(_state, _map_server, _tri);
+        if (_filter_params._max_lm_feats > 0) {                                         // :155-161
+            _landmark_update->updateLandmarkMono(_state, _map_server);
+            _landmark_update->initNewLandmarkMono(_state, _map_server, _tri, _filter_params._max_sw_clones);
+        }
         _keyframe_update->cleanMonoObsAtMargTime(_state, _map_server);
         _keyframe_update->changeMSCKFAnchor(_state, _map_server);
+        if (_filter_params._max_lm_feats > 0) {                                         // :167-173
+            std::vector<double> marg_kfs;
+            _keyframe_update->getMargKfs(_state, marg_kfs);
+            _landmark_update->changeLandmarkAnchor(_state, _map_server, marg_kfs);
+        }
         _keyframe_update->margSwPose(_state);
     } else {
         _sw_marg_update->updateStateMono(_state, _map_server, _tri);
+        if (_filter_params._max_lm_feats > 0) {                                         // :181-187
+            _landmark_update->updateLandmarkMono(_state, _map_server);
+            _landmark_update->initNewLandmarkMono(_state, _map_server, _tri, _filter_params._max_sw_clones);
+        }
         _sw_marg_update->cleanMonoObsAtMargTime(_state, _map_server);
         _sw_marg_update->changeMSCKFAnchor(_state, _map_server);
+        if (_filter_params._max_lm_feats > 0) _landmark_update->changeLandmarkAnchor(_state, _map_server);      // :193-194
         _sw_marg_update->margSwPose(_state);
     }
     eraseInvalidFeatures(_map_server, _state);

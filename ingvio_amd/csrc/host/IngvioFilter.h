@@ -12,6 +12,7 @@
 #include "ImuPropagator.h"
 #include "IngvioParams.h"
 #include "MapServer.h"
+#include "LandmarkUpdate.h"
 #include "MsckfUpdates.h"
 #include "State.h"
 
@@ -33,6 +34,7 @@ public:
     std::shared_ptr<State> state() { return _state; }
     std::shared_ptr<MapServer> mapServer() { return _map_server; }
     std::shared_ptr<ImuPropagator> imuPropagator() { return _imu_propa; }
+    std::shared_ptr<LandmarkUpdate> landmarkUpdate() { return _landmark_update; }
     int framesProcessed() const { return _frames; }
 
 protected:
@@ -46,6 +48,7 @@ protected:
     std::shared_ptr<RemoveLostUpdate> _remove_lost_update;
     std::shared_ptr<SwMargUpdate> _sw_marg_update;
     std::shared_ptr<KeyframeUpdate> _keyframe_update;
+    std::shared_ptr<LandmarkUpdate> _landmark_update;
     bool _hasImageCome = false, _hasInitState = false;
     int _frames = 0;
 };

@@ -180,10 +180,18 @@ void RemoveLostUpdate::updateStateStereo(std::shared_ptr<State> s, std::shared_p
 void RemoveLostUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri, bool stereo)
 {
     _last_rows = 0; _last_accepted = 0;
-    // MapServerManager::mark{Mono,Stereo}Features (MapServerManager.cpp:219-273), MSCKF part
+    // MapServerManager::markMarg{Mono,Stereo}Features (MapServerManager.cpp:219-273): lost SLAM landmarks leave the state
+    std::vector<int> lost_slam_ids;
     for (auto& item : *map_server) {
         const bool has = stereo ? item.second->_stereo_obs.count(state->_timestamp) > 0 : item.second->_mono_obs.count(state->_timestamp) > 0;
-        if (!has) item.second->_isToMarg = true;
+        if (!has) {
+            item.second->_isToMarg = true;
+            if (item.second->_ftype == FeatureInfo::SLAM) lost_slam_ids.push_back(item.first);
+        }
+    }
+    for (const int id : lost_slam_ids) {
+        StateManager::margAnchoredLandmarkInState(state, id);
+        map_server->erase(id);
     }
     std::vector<int> update_ids, direct_marg_ids;
     for (auto& item : *map_server)
@@ -399,7 +407,7 @@ void KeyframeUpdate::margSwPose(std::shared_ptr<State> state)
     for (const double& marg_time : marg_kfs) StateManager::margSlidingWindowPose(state, marg_time);
 }
 
-void eraseInvalidFeatures(std::shared_ptr<MapServer> map_server, std::shared_ptr<State>)
+void eraseInvalidFeatures(std::shared_ptr<MapServer> map_server, std::shared_ptr<State> state)
 {
     std::vector<int> ids_to_remove;
     for (const auto& item : *map_server) {
@@ -410,7 +418,10 @@ void eraseInvalidFeatures(std::shared_ptr<MapServer> map_server, std::shared_ptr
         const Vec3d body = anchor_ptr->valueLinearAsMat().transpose() * (fi->_landmark->valuePosXyz() - anchor_ptr->valueTrans());
         if (body.z() <= 0.2) ids_to_remove.push_back(item.first);
     }
-    for (const int& id : ids_to_remove) map_server->erase(id);
+    for (const int& id : ids_to_remove) {
+        if (map_server->at(id)->_ftype == FeatureInfo::SLAM) StateManager::margAnchoredLandmarkInState(state, id);      // :485-486
+        map_server->erase(id);
+    }
 }
 
 }  // namespace ingvio

@@ -66,7 +66,14 @@ State::State(const IngvioParams& filter_params) : _state_params(filter_params)
     ingvio_ctx_desc d;
     d.batch = 1; d.n_max = filter_params._hip_n_max;
     d.c_max = filter_params._max_sw_clones + 1;                     // <= 36: the ABI refuses larger windows (INGVIO_E_CAPACITY)
-    d.f_max = filter_params._hip_f_max; d.m_max = 64; d.device = filter_params._hip_device; d.stream = nullptr;
+    d.f_max = filter_params._hip_f_max; d.device = filter_params._hip_device; d.stream = nullptr;
+    d.m_max = 64;
+    if (filter_params._max_lm_feats > 0) {
+        // SLAM landmarks (f-2): the stacked landmark update has up to 4 L rows and 15 + 6 C + 3 L columns, the delayed
+        // initialisation 4 C rows over 6 C columns
+        const int L = filter_params._max_lm_feats, C = d.c_max;
+        for (int need : { 4 * L, 15 + 6 * C + 3 * L, 4 * C }) if (need > d.m_max) d.m_max = need;
+    }
     if (ingvio_ctx_create(&d, &_ctx) != INGVIO_OK) {
         std::cout << "[State]: libingvio_hip: no MI355X context (" << (_ctx ? ingvio_last_error(_ctx) : "no device") << ")" << std::endl;
         std::exit(EXIT_FAILURE);

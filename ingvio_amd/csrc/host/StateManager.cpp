@@ -1,4 +1,5 @@
 #include "StateManager.h"
+#include "Update.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -212,6 +213,90 @@ void StateManager::ekfUpdate(std::shared_ptr<State> state, const std::vector<std
     if (rc == INGVIO_NEG_DIAG)
         std::cout << "[StateManager]: EKF Update and found negative diag cov elements! " << std::endl;      // :418
     boxPlus(state, dx);                                                                      // :425
+}
+
+void StateManager::addVariableDelayedInvertible(std::shared_ptr<State> state, std::shared_ptr<Type> var_new,
+                                                const std::vector<std::shared_ptr<Type>>& var_old_order, const MatXd& H_old,
+                                                const MatXd& H_new, const VecXd& res, double noise_iso_meas)
+{
+    if (std::find(state->_err_variables.begin(), state->_err_variables.end(), var_new) != state->_err_variables.end()) {
+        std::cout << "[StateManager]: New var already in state! Cannot perform add var delayed inv!" << std::endl;
+        return;
+    }
+    if (!checkSubOrder(state, var_old_order)) std::exit(EXIT_FAILURE);                       // assert, :473
+    if ((int)res.size() != H_old.rows() || H_new.rows() != H_new.cols() || H_new.cols() != var_new->size() ||
+        H_old.cols() != calcSubVarSize(var_old_order) || H_new.rows() != H_old.rows()) {      // asserts :477-481
+        std::cout << "[StateManager]: add var delayed inv: inconsistent sizes!" << std::endl;
+        std::exit(EXIT_FAILURE);
+    }
+    std::vector<int> vidx, vsize;
+    orderOf(var_old_order, vidx, vsize);
+    int new_idx = -1;
+    const int rc = ingvio_add_variable_delayed_invertible(state->_ctx, state->_b, vidx.data(), vsize.data(), (int)vidx.size(),
+                                                          H_old.data(), H_old.rows(), H_new.data(), H_new.rows(), H_new.rows(),
+                                                          noise_iso_meas, &new_idx);
+    if (rc != INGVIO_OK) fatal(state, "addVariableDelayedInvertible", rc);
+    var_new->set_cov_idx(new_idx);                                                           // :536
+    state->_err_variables.push_back(var_new);
+}
+
+bool StateManager::addVariableDelayed(std::shared_ptr<State> state, std::shared_ptr<Type> var_new,
+                                      const std::vector<std::shared_ptr<Type>>& var_old_order, const MatXd& H_old, const MatXd& H_new,
+                                      const VecXd& res, double noise_iso_meas, double chi2_mult_factor, bool do_chi2)
+{
+    if (std::find(state->_err_variables.begin(), state->_err_variables.end(), var_new) != state->_err_variables.end()) {
+        std::cout << "[StateManager]: New var already in state! Cannot perform add var delayed inv!" << std::endl;
+        return false;
+    }
+    if (!checkSubOrder(state, var_old_order)) std::exit(EXIT_FAILURE);                       // assert, :564
+    if ((int)res.size() != H_old.rows() || (int)res.size() != H_new.rows() || H_new.cols() != var_new->size() ||
+        H_old.cols() != calcSubVarSize(var_old_order)) {                                     // asserts :566-570
+        std::cout << "[StateManager]: add var delayed: inconsistent sizes!" << std::endl;
+        std::exit(EXIT_FAILURE);
+    }
+    if (H_new.rows() <= H_new.cols()) {
+        std::cout << "[StateManager]: H_new rows should be larger than H_new cols!" << std::endl;      // :571-575
+        return false;
+    }
+    std::vector<int> vidx, vsize;
+    orderOf(var_old_order, vidx, vsize);
+    const double chi2_check = chi2Quantile((int)res.size(), 0.95);                           // boost quantile, :610-612
+    VecXd dx(state->curr_cov_size() + var_new->size(), 0.0);
+    int added = 0, new_idx = -1;
+    const int rc = ingvio_add_variable_delayed(state->_ctx, state->_b, vidx.data(), vsize.data(), (int)vidx.size(), H_old.data(),
+                                               H_old.rows(), H_new.data(), H_new.rows(), H_new.rows(), H_new.cols(), res.data(),
+                                               noise_iso_meas, chi2_mult_factor, do_chi2 ? 1 : 0, chi2_check, dx.data(), &added,
+                                               &new_idx, nullptr);
+    if (rc < 0) fatal(state, "addVariableDelayed", rc);
+    if (!added) {
+        std::cout << "[StateManager]: Cannot add variable due to chi2 test failure!" << std::endl;     // :616
+        return false;
+    }
+    var_new->set_cov_idx(new_idx);
+    state->_err_variables.push_back(var_new);
+    if (rc == INGVIO_NEG_DIAG)
+        std::cout << "[StateManager]: EKF Update and found negative diag cov elements! " << std::endl;
+    boxPlus(state, dx);                                                                      // the ekfUpdate of :623-624 ends with boxPlus
+    return true;
+}
+
+void StateManager::replaceVarLinear(std::shared_ptr<State> state, const std::shared_ptr<Type> target_var,
+                                    const std::vector<std::shared_ptr<Type>>& dependence_order, const MatXd& H)
+{
+    if (std::find(state->_err_variables.begin(), state->_err_variables.end(), target_var) == state->_err_variables.end()) {
+        std::cout << "[StateManager]: Target var not in state, cannot linearly replace!" << std::endl;  // :653-657
+        return;
+    }
+    if (!checkSubOrder(state, dependence_order)) std::exit(EXIT_FAILURE);
+    if (target_var->size() != H.rows() || calcSubVarSize(dependence_order) != H.cols()) {
+        std::cout << "[StateManager]: replace var linear: inconsistent sizes!" << std::endl;
+        std::exit(EXIT_FAILURE);
+    }
+    std::vector<int> vidx, vsize;
+    orderOf(dependence_order, vidx, vsize);
+    const int rc = ingvio_replace_var_linear(state->_ctx, state->_b, target_var->idx(), target_var->size(), vidx.data(), vsize.data(),
+                                             (int)vidx.size(), H.data(), H.rows());
+    if (rc != INGVIO_OK) fatal(state, "replaceVarLinear", rc);
 }
 
 bool StateManager::checkSubOrder(std::shared_ptr<State> state, const std::vector<std::shared_ptr<Type>>& sub_order)

@@ -38,6 +38,16 @@ public:
     // R: m x m (the reference's signature).  Diagonal / scalar*I matrices are detected and sent as such.
     static void ekfUpdate(std::shared_ptr<State> state, const std::vector<std::shared_ptr<Type>>& var_order,
                           const MatXd& H, const VecXd& res, const MatXd& R);                 // :359-426
+    // SLAM-landmark path.  H_old / H_new / res are left untouched: the Givens rotations of
+    // :577-589 run on the device copy (the reference rotates its arguments in place and never reads them again).
+    static void addVariableDelayedInvertible(std::shared_ptr<State> state, std::shared_ptr<Type> var_new,
+                                             const std::vector<std::shared_ptr<Type>>& var_old_order, const MatXd& H_old,
+                                             const MatXd& H_new, const VecXd& res, double noise_iso_meas);       // :461-543
+    static bool addVariableDelayed(std::shared_ptr<State> state, std::shared_ptr<Type> var_new,
+                                   const std::vector<std::shared_ptr<Type>>& var_old_order, const MatXd& H_old, const MatXd& H_new,
+                                   const VecXd& res, double noise_iso_meas, double chi2_mult_factor, bool do_chi2 = true);   // :549-637
+    static void replaceVarLinear(std::shared_ptr<State> state, const std::shared_ptr<Type> target_var,
+                                 const std::vector<std::shared_ptr<Type>>& dependence_order, const MatXd& H);       // :639-693
     static bool checkSubOrder(std::shared_ptr<State> state, const std::vector<std::shared_ptr<Type>>& sub_order);   // :428-445
     static int calcSubVarSize(const std::vector<std::shared_ptr<Type>>& sub_var);            // :447-456
 

@@ -258,6 +258,136 @@ static void testStateCovUpdate()      // TestStateManager.cpp:478-557
     (void)lm_before;
 }
 
+// AddDelayedTest (TestStateManager.cpp:559-592 fixture): 21-dim state, one propagation step
+struct DelayedFixture {
+    IngvioParams fp;
+    std::shared_ptr<State> state;
+    DelayedFixture()
+    {
+        fp = params();
+        state = std::make_shared<State>(fp);
+        state->_extended_pose->setValueLinearByMat(rrand()); state->_extended_pose->setValueTrans1(vrand()); state->_extended_pose->setValueTrans2(vrand());
+        state->_bg->setValue(vrand()); state->_ba->setValue(vrand());
+        state->_camleft_imu_extrinsics->setValue(rrand(), vrand());
+        Quatd qi{ 1, 0, 0, 0 };
+        state->initStateAndCov(1.0, qi);
+        double Phi[225], G[180];
+        randPhiG(Phi, G);
+        state->_timestamp = 1.0;
+        StateManager::propagateStateCov(state, Phi, G, 1.5);
+        state->_timestamp = 2.5;
+    }
+};
+
+static void testAddVarInv()      // TestStateManager.cpp:594-642
+{
+    DelayedFixture f;
+    auto& state = f.state;
+    VecXd res(1); res[0] = urand();
+    std::vector<std::shared_ptr<Type>> sub_var_old = { state->_extended_pose };
+    MatXd H_old(1, 9);
+    for (int j = 0; j < 9; ++j) H_old(0, j) = urand();
+    MatXd H_new(1, 1); H_new(0, 0) = 1.0;
+    std::shared_ptr<Scalar> tgps = std::make_shared<Scalar>();
+    tgps->setValue(urand());
+    state->_gnss[State::GPS] = tgps;
+    const MatXd cov_orig = StateManager::getFullCov(state);
+    const double noise_meas_iso = 2.0;
+    StateManager::addVariableDelayedInvertible(state, tgps, sub_var_old, H_old, H_new, res, noise_meas_iso);
+    ASSERT_TRUE(StateManager::checkStateContinuity(state));
+    ASSERT_EQ(state->curr_cov_size(), cov_orig.cols() + 1);
+    ASSERT_EQ(state->_gnss[State::GPS]->idx(), cov_orig.rows());
+    const MatXd cov_new = StateManager::getFullCov(state);
+    MatXd H_old_large(1, 21);
+    for (int j = 0; j < 9; ++j) H_old_large(0, j) = H_old(0, j);
+    const MatXd x1 = mul(mul(H_old_large, cov_orig), H_old_large, true);
+    ASSERT_NEAR(cov_new(21, 21), (x1(0, 0) + std::pow(noise_meas_iso, 2.0)) / std::pow(H_new(0, 0), 2.0), 1e-8);
+    const MatXd cross = mul(cov_orig, H_old_large, true);
+    double d = 0;
+    for (int i = 0; i < 21; ++i) d += std::pow(cov_new(i, 21) + cross(i, 0) / H_new(0, 0), 2);
+    ASSERT_TRUE(std::sqrt(d) < 1e-8);
+}
+
+static void testAddVar()      // TestStateManager.cpp:644-7xx
+{
+    DelayedFixture f;
+    auto& state = f.state;
+    VecXd res(2); res[0] = urand(); res[1] = urand();
+    std::vector<std::shared_ptr<Type>> sub_var_old = { state->_extended_pose };
+    MatXd H_old(2, 9);
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 9; ++j) H_old(i, j) = urand();
+    MatXd H_new(2, 1); H_new(0, 0) = 1.0; H_new(1, 0) = 1.0;
+    std::shared_ptr<Scalar> tgps = std::make_shared<Scalar>();
+    tgps->setValue(urand());
+    state->_gnss[State::GPS] = tgps;
+    const MatXd cov_orig = StateManager::getFullCov(state);
+    const double noise_meas_iso = 2.0;
+    ASSERT_TRUE(StateManager::addVariableDelayed(state, tgps, sub_var_old, H_old, H_new, res, noise_meas_iso, 1.0, false));
+    ASSERT_TRUE(StateManager::checkStateContinuity(state));
+    ASSERT_EQ(state->curr_cov_size(), cov_orig.cols() + 1);
+    ASSERT_EQ(state->_gnss[State::GPS]->idx(), cov_orig.rows());
+    const MatXd cov_new = StateManager::getFullCov(state);
+    // the Givens rotation of H_new = [1; 1]
+    const double q = std::sqrt(2.0) / 2.0;
+    MatXd Ho(2, 9); double Hn0 = q * H_new(0, 0) + q * H_new(1, 0);
+    for (int j = 0; j < 9; ++j) { Ho(0, j) = q * H_old(0, j) + q * H_old(1, j); Ho(1, j) = -q * H_old(0, j) + q * H_old(1, j); }
+    MatXd Hl0(1, 21), Hl1(1, 22);
+    for (int j = 0; j < 9; ++j) { Hl0(0, j) = Ho(0, j); Hl1(0, j) = Ho(1, j); }
+    const MatXd x1 = mul(mul(Hl0, cov_orig), Hl0, true);
+    MatXd cov_before(22, 22);
+    for (int j = 0; j < 21; ++j) for (int i = 0; i < 21; ++i) cov_before(i, j) = cov_orig(i, j);
+    cov_before(21, 21) = (x1(0, 0) + std::pow(noise_meas_iso, 2.0)) / std::pow(Hn0, 2.0);
+    const MatXd cr = mul(cov_orig, Hl0, true);
+    for (int i = 0; i < 21; ++i) { cov_before(i, 21) = -cr(i, 0) / Hn0; cov_before(21, i) = cov_before(i, 21); }
+    MatXd S = mul(mul(Hl1, cov_before), Hl1, true);
+    S(0, 0) += std::pow(noise_meas_iso, 2.0);
+    const MatXd K = mul(mul(cov_before, Hl1, true), inverse(S));
+    MatXd IKH = MatXd::Identity(22);
+    const MatXd KH = mul(K, Hl1);
+    for (int j = 0; j < 22; ++j) for (int i = 0; i < 22; ++i) IKH(i, j) -= KH(i, j);
+    ASSERT_NEAR(normDiff(mul(IKH, cov_before), cov_new), 0.0, 1e-08);
+    // shape guard (:571-575) and "already in state"
+    auto t2 = std::make_shared<Scalar>();
+    MatXd Hsq(1, 1); Hsq(0, 0) = 1.0; MatXd Ho1(1, 9); VecXd r1(1, 0.0);
+    ASSERT_TRUE(!StateManager::addVariableDelayed(state, t2, sub_var_old, Ho1, Hsq, r1, 1.0, 1.0, false));
+    ASSERT_TRUE(!StateManager::addVariableDelayed(state, tgps, sub_var_old, H_old, H_new, res, 1.0, 1.0, false));
+}
+
+// replaceVarLinear through FeatureInfoManager::changeAnchoredPose (MapServerManager.cpp:343-379): P' = J P J^T
+static void testChangeAnchoredPose()
+{
+    Fixture f;
+    auto& state = f.state;
+    state->_timestamp = 1.0;
+    StateManager::propagateStateCov(state, f.Phi_imu, f.G_imu, 0.5);
+    for (double t : { 1.5, 2.0, 2.5 }) { state->_timestamp = t; StateManager::augmentSlidingWindowPose(state); }
+    auto fi = std::make_shared<FeatureInfo>();
+    fi->_id = 7; fi->_ftype = FeatureInfo::SLAM;
+    fi->_landmark->resetAnchoredPose(state->_sw_camleft_poses.at(1.5));
+    fi->_landmark->setValuePosXyz(vrand());
+    MatXd c0(3, 3);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) c0(i, j) = (i == j ? 0.3 : 0.02);
+    StateManager::addAnchoredLandmarkInState(state, fi->_landmark, 7, c0);
+    // correlate the landmark with the rest through one update
+    {
+        std::vector<std::shared_ptr<Type>> vo = { state->_sw_camleft_poses.at(1.5), fi->_landmark };
+        MatXd H(2, 9); VecXd r(2);
+        for (int i = 0; i < 2; ++i) { r[i] = 0.1 * urand(); for (int j = 0; j < 9; ++j) H(i, j) = urand(); }
+        MatXd R = MatXd::Identity(2);
+        StateManager::ekfUpdate(state, vo, H, r, R);
+    }
+    const MatXd P0 = StateManager::getFullCov(state);
+    const int n = P0.rows(), li = fi->_landmark->idx(), a0 = state->_sw_camleft_poses.at(1.5)->idx(), a1 = state->_sw_camleft_poses.at(2.5)->idx();
+    const Vec3d pf = fi->_landmark->valuePosXyz();
+    FeatureInfoManager::changeAnchoredPose(fi, state, 2.5);
+    ASSERT_TRUE(fi->_landmark->getAnchoredPose() == state->_sw_camleft_poses.at(2.5));
+    MatXd J = MatXd::Identity(n);
+    const double S[3][3] = { { 0, -pf[2], pf[1] }, { pf[2], 0, -pf[0] }, { -pf[1], pf[0], 0 } };
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { J(li + r, a0 + c) = -S[r][c]; J(li + r, a1 + c) = S[r][c]; }
+    ASSERT_NEAR(normDiff(mul(mul(J, P0), J, true), StateManager::getFullCov(state)), 0.0, 1e-10);
+    ASSERT_TRUE(StateManager::checkStateContinuity(state));
+}
+
 static void testPropagator()      // TestPropagator.cpp:191-259
 {
     IngvioParams fp = params();
@@ -369,12 +499,15 @@ static void testFilterEndToEnd()
 {
     // {key-frame mode, window}: the two update policies at the 11-clone window of BASELINE config 2, then the window of
     // the reference's shipped stereo config (config/fw_zed2i_f9p/ingvio_stereo.yaml: 21 poses -> large-window kernels)
-    const int runs[3][3] = { { 1, 11, 7 }, { 0, 11, 7 }, { 0, 21, 16 } };
-    for (int run = 0; run < 3; ++run) {
-        const int keyframe = runs[run][0], window = runs[run][1], life = runs[run][2];
+    // the last two runs keep up to 8 SLAM landmarks in the state (f-2): delayed initialisation from full-window tracks,
+    // landmark update every frame, anchor change before the anchor clone is marginalised
+    const int runs[5][4] = { { 1, 11, 7, 0 }, { 0, 11, 7, 0 }, { 0, 21, 16, 0 }, { 0, 6, 16, 8 }, { 1, 6, 16, 8 } };
+    for (int run = 0; run < 5; ++run) {
+        const int keyframe = runs[run][0], window = runs[run][1], life = runs[run][2], lms = runs[run][3];
         IngvioParams fp = params();
         fp._enable_gnss = 0; fp._max_sw_clones = window; fp._is_key_frame = keyframe; fp._frame_select_interval = 4;
-        fp._init_imu_buffer_sp = -1; fp._visual_noise = 0.08; fp._hip_f_max = 64; fp._hip_n_max = 21 + 6 * (window + 2) + 16;
+        fp._init_imu_buffer_sp = -1; fp._visual_noise = 0.08; fp._hip_f_max = 64; fp._hip_n_max = 21 + 6 * (window + 2) + 16 + 3 * lms;
+        fp._max_lm_feats = lms;
         fp._init_cov_rot = 0.01; fp._init_cov_pos = 0.01;
         auto tri = std::make_shared<Triangulator>(fp);              // the LM triangulation runs on the device (f-1)
         IngvioFilter filter(fp, tri);
@@ -384,7 +517,7 @@ static void testFilterEndToEnd()
         // IngvioFilter::callbackIMU would initialise from gravity alignment; the test starts from the truth
         struct Live { int id; Vec3d pw; int born; };
         std::vector<Live> live;
-        int next_id = 0, frames = 0, rl_rows = 0;
+        int next_id = 0, frames = 0, rl_rows = 0, lm_rows = 0, lm_init = 0, lm_max = 0;
         const Iso3 Tlr = state->_state_params._T_cl2cr;
         std::normal_distribution<double> gn(0.0, 1.0);
         double t = t0;
@@ -423,6 +556,13 @@ static void testFilterEndToEnd()
             }
             filter.callbackStereoFrame(fr);
             ++frames;
+            lm_rows += filter.landmarkUpdate()->lastRows(); lm_init += filter.landmarkUpdate()->lastInitialised();
+            lm_max = std::max(lm_max, (int)state->_anchored_landmarks.size());
+            for (const auto& lm : state->_anchored_landmarks) {                // every in-state landmark is anchored inside the window
+                bool in_window = false;
+                for (const auto& c : state->_sw_camleft_poses) in_window = in_window || c.second == lm.second->getAnchoredPose();
+                ASSERT_TRUE(in_window);
+            }
             ASSERT_TRUE(StateManager::checkStateContinuity(state));
             ASSERT_TRUE((int)state->_sw_camleft_poses.size() <= fp._max_sw_clones + (keyframe ? 0 : 1));
         }
@@ -436,6 +576,13 @@ static void testFilterEndToEnd()
         const double rerr = (state->_extended_pose->valueLinearAsMat() - Truth::R(t)).norm();
         std::printf("  %s mode, window %d: N=%d clones=%zu |dp|=%.4f m |dR|=%.4f features=%zu\n", keyframe ? "keyframe" : "sw-marg", window,
                     state->curr_cov_size(), state->_sw_camleft_poses.size(), perr, rerr, filter.mapServer()->size());
+        if (lms > 0) {
+            std::printf("    SLAM landmarks: %d initialised, %d update rows, at most %d in the state, %zu at the end\n", lm_init, lm_rows, lm_max,
+                        state->_anchored_landmarks.size());
+            ASSERT_TRUE(lm_init > 0);
+            ASSERT_TRUE(lm_rows > 0);
+            ASSERT_TRUE(lm_max <= lms);
+        }
         ASSERT_TRUE(perr < 0.2);          // 2 s of 200 Hz consumer-grade IMU would drift further without the updates
         ASSERT_TRUE(rerr < 0.05);
         (void)rl_rows;
@@ -496,7 +643,8 @@ int main()
     struct { const char* name; void (*fn)(); } tests[] = {
         { "testState.BasicFuncs", testBasicFuncs }, { "testState.StateAddMargProp", testStateAddMargProp },
         { "StateUpdateTest.augmentPose", testAugmentPose }, { "StateUpdateTest.stateBoxPlus", testStateBoxPlus },
-        { "StateUpdateTest.stateCovUpdate", testStateCovUpdate }, { "TestPropagator.propaUntil+propagateAugment", testPropagator },
+        { "StateUpdateTest.stateCovUpdate", testStateCovUpdate }, { "AddDelayedTest.addVarInv", testAddVarInv }, { "AddDelayedTest.addVar", testAddVar }, { "FeatureInfoManager.changeAnchoredPose", testChangeAnchoredPose },
+        { "TestPropagator.propaUntil+propagateAugment", testPropagator },
         { "GnssUpdate.updateTrackedSys", testGnssUpdate }, { "TestTriangulator.mono+stereo", testTriangulator }, { "IngvioFilter.callbacks end-to-end", testFilterEndToEnd },
     };
     for (auto& t : tests) {
