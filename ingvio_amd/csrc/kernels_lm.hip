@@ -42,21 +42,25 @@ __global__ __launch_bounds__(LM_NT) void k_delayed_qr(double* __restrict__ H_old
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* sCS = reinterpret_cast<double*>(smem_raw);                  // [s][m][2]: (c, s) of the rotation on rows (r-1, r) of column col
+    double* sHn = sCS + 2 * (size_t)s * m;                              // [s][m]: H_new staged in LDS for the serial part
     const int tid = threadIdx.x;
+    for (int e = tid; e < s * m; e += LM_NT) sHn[e] = H_new[(e % m) + (size_t)(e / m) * mld];
+    __syncthreads();
     if (tid == 0) {
         for (int col = 0; col < s; ++col)
             for (int r = m - 1; r > col; --r) {
                 double c, sn;
-                make_givens(H_new[(r - 1) + (size_t)col * mld], H_new[r + (size_t)col * mld], c, sn);
+                make_givens(sHn[(r - 1) + col * m], sHn[r + col * m], c, sn);
                 sCS[2 * (col * m + r)] = c; sCS[2 * (col * m + r) + 1] = sn;
                 for (int j = col; j < s; ++j) {                          // applyOnTheLeft(G.adjoint()): x' = c x - s y, y' = s x + c y
-                    const double x = H_new[(r - 1) + (size_t)j * mld], y = H_new[r + (size_t)j * mld];
-                    H_new[(r - 1) + (size_t)j * mld] = c * x - sn * y;
-                    H_new[r + (size_t)j * mld] = sn * x + c * y;
+                    const double x = sHn[(r - 1) + j * m], y = sHn[r + j * m];
+                    sHn[(r - 1) + j * m] = c * x - sn * y;
+                    sHn[r + j * m] = sn * x + c * y;
                 }
             }
     }
     __syncthreads();
+    for (int e = tid; e < s * m; e += LM_NT) H_new[(e % m) + (size_t)(e / m) * mld] = sHn[e];
     for (int j = tid; j <= nc; j += LM_NT) {
         double* A = j < nc ? H_old + (size_t)j * mld : res;
         for (int col = 0; col < s; ++col) {
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(LM_NT) void k_replace_var(CovView cv, int b, const 
 
 int launch_delayed_qr(double* H_old, double* res, double* H_new, int m, int s, int nc, int mld, hipStream_t st)
 {
-    const size_t sm = sizeof(double) * 2 * (size_t)s * m;
+    const size_t sm = sizeof(double) * 3 * (size_t)s * m;
     if (s < 1 || s > LM_SMAX || sm > 60 * 1024) return -1;
     hipLaunchKernelGGL(k_delayed_qr, dim3(1), dim3(LM_NT), sm, st, H_old, res, H_new, m, s, nc, mld);
     return 0;
