@@ -351,6 +351,34 @@ def main():
             t_aw = time.perf_counter() - t_aw
             aw = dict(gpu_updates_per_s=B * 5 / t_aw, cpu_ms_per_update_1thread=cpu.pop("as_written_cap20_ms_per_update_1thread"),
                       note="accepted-feature cap 20, all rows kept (RemoveLostUpdate.cpp:359,390): auxiliary figure, not `value`")
+        # Host hand-over (auxiliary, never `value`): the ABI takes host buffers; one frame of the batch is packed into pinned
+        # memory, sent over PCIe and the results fetched back.  serial = stage; run; fetch.  pipelined = run(i);
+        # stage_async(i+1) on the copy stream into the second input set; fetch(i).
+        handover = None
+        if cpu is not None:
+            kw = dict(max_accept=0, compress_rule=1)
+            sg = (filters[0].sigma(), filters[0].enable_gnss, pr["sigma_cb"], pr["sigma_rw"])
+            st_sync = ctx.frame_stage_prepare(0, steps, frames, *sg, **kw)
+            st_async = ctx.frame_stage_prepare(0, steps, frames, *sg, use_async=True, **kw)
+            for _ in range(4):                                # allocates the pinned ring and the second input set
+                st_sync(); ctx.frame_run(restore_prior=True); ctx.frame_fetch()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                st_sync(); ctx.frame_run(restore_prior=True); ctx.frame_fetch()
+            t_serial = (time.perf_counter() - t0) / 5
+            st_async()
+            for _ in range(3):
+                ctx.frame_run(restore_prior=True); st_async(); ctx.frame_fetch()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                ctx.frame_run(restore_prior=True); st_async(); ctx.frame_fetch()
+            t_pipe = (time.perf_counter() - t0) / 10
+            ctx.sync()
+            in_bytes = sum(np.asarray(v).nbytes for v in frames[0].values() if hasattr(v, "nbytes")) + \
+                sum(np.asarray(v).nbytes for v in steps[0].values() if hasattr(v, "nbytes"))
+            handover = dict(serial_updates_per_s=B / t_serial, pipelined_updates_per_s=B / t_pipe, input_bytes_per_update=in_bytes,
+                            note="host buffers -> pinned slab (8 host threads) -> PCIe -> run -> dx/accept back; pipelined = copy "
+                                 "stream + second device input set (ingvio_frame_stage_async); auxiliary, `value` is device-resident")
         updates = B * world * args.steps
         out = dict(
             metric="ekf_updates_per_sec", value=updates / elapsed, unit="updates/s", n_gpus=world, steps=args.steps,
@@ -363,7 +391,7 @@ def main():
             ms_per_update=elapsed / args.steps * 1e3 / B, accepted_per_filter=F_used, results_finite=ok,
             algorithmic_flops_per_update=total_flops,
             whole_step_fp64_frac=total_flops * B / (elapsed / args.steps) / 1e12 / FP64_PEAK_TFLOPS,
-            method=args.method, roofline=roofline, cpu_baseline=cpu, parity_vs_oracle=parity, as_written_cap20=aw, kernels=kernels,
+            method=args.method, roofline=roofline, cpu_baseline=cpu, parity_vs_oracle=parity, as_written_cap20=aw, host_handover=handover, kernels=kernels,
             kernels_note="per-kernel avg_ms: separate untimed pass of 3 steps with an event pair around every launch; the "
                          "roofline kernel's avg_ms is from the timed region", setup_s=t_build)
         print(json.dumps(out))

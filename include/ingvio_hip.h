@@ -227,6 +227,13 @@ typedef struct {
 int ingvio_frame_stage(ingvio_ctx* ctx, int b0, int nb, const ingvio_frame_step* steps,
                        const ingvio_msckf_frame* frames, const ingvio_msckf_opts* opts,
                        const double sigma[4], int enable_gnss, double sigma_cb, double sigma_rw);
+/* Same as ingvio_frame_stage for the WHOLE batch (b0 = 0, nb = batch), but the inputs travel on a separate copy
+ * stream into a second set of device input buffers, so the call may be issued while the previous ingvio_frame_run is
+ * still executing: PCIe and host packing of frame i+1 overlap the kernels of frame i.  Pattern per frame:
+ * run(i); stage_async(i+1); fetch(i).  The next ingvio_frame_run / ingvio_triangulate(staged) waits for the copy. */
+int ingvio_frame_stage_async(ingvio_ctx* ctx, int b0, int nb, const ingvio_frame_step* steps,
+                             const ingvio_msckf_frame* frames, const ingvio_msckf_opts* opts,
+                             const double sigma[4], int enable_gnss, double sigma_cb, double sigma_rw);
 int ingvio_frame_run(ingvio_ctx* ctx, int restore_prior);
 int ingvio_frame_fetch(ingvio_ctx* ctx, int b0, int nb, double* dx_out, int* accepted, int* rows_out);
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "ingvio_cov_set", "ingvio_cov_get", "ingvio_get_n", "ingvio_cov_get_marginal", "ingvio_cov_snapshot",
     "ingvio_cov_restore", "ingvio_propagate", "ingvio_propagate_fused", "ingvio_augment_clone", "ingvio_marginalize",
     "ingvio_append_independent", "ingvio_ekf_update", "ingvio_chi2_gamma", "ingvio_msckf_update", "ingvio_qr_compress",
-    "ingvio_frame_stage", "ingvio_frame_run", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_select",
+    "ingvio_frame_stage", "ingvio_frame_stage_async", "ingvio_frame_run", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_select",
     "ingvio_profile_reset",
     "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_debug_read", "ingvio_triangulate",
     "ingvio_add_variable_delayed_invertible", "ingvio_add_variable_delayed", "ingvio_replace_var_linear",
@@ -333,6 +333,25 @@ class Context:
         o, chi2 = make_opts(frames[0], max_accept, compress_rule, selected_variant)
         self._chk(self.L.ingvio_frame_stage(self.h, b0, nb, sa, fa, C.byref(o), _d(f64(sigma)), int(enable_gnss),
                                             C.c_double(sigma_cb), C.c_double(sigma_rw)))
+
+    def frame_stage_prepare(self, b0, steps, frames, sigma, enable_gnss=0, sigma_cb=0.0, sigma_rw=0.0, max_accept=0,
+                            compress_rule=1, selected_variant=0, use_async=False):
+        """Builds the C argument arrays once and returns a callable that re-issues ingvio_frame_stage on them (for timing
+        the host hand-over without the Python marshalling)."""
+        nb = len(steps)
+        sa = (FrameStep * nb)(); fa = (MsckfFrame * nb)()
+        keeps = []
+        for i in range(nb):
+            s, k1 = make_step(steps[i]); f, k2 = make_frame(frames[i])
+            sa[i] = s; fa[i] = f; keeps.append((k1, k2))
+        o, chi2 = make_opts(frames[0], max_accept, compress_rule, selected_variant)
+        sg = f64(sigma)
+
+        fn = self.L.ingvio_frame_stage_async if use_async else self.L.ingvio_frame_stage
+
+        def call(_keep=(keeps, chi2, sa, fa, o, sg)):
+            self._chk(fn(self.h, b0, nb, sa, fa, C.byref(o), _d(sg), int(enable_gnss), C.c_double(sigma_cb), C.c_double(sigma_rw)))
+        return call
 
     def frame_run(self, restore_prior=False):
         self._chk(self.L.ingvio_frame_run(self.h, 1 if restore_prior else 0))

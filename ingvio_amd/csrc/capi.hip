@@ -13,6 +13,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #define KMAX 64            // IMU steps per fused propagation call
@@ -65,6 +67,24 @@ struct ingvio_ctx {
     MsckfOpts st_op;
     std::vector<int> st_marg;      // per filter marg idx
     bool staged;
+    // second set of device input buffers + copy stream (ingvio_frame_stage_async): the inputs of frame i+1 travel over
+    // PCIe while frame i computes; the sets swap roles at every asynchronous stage
+    struct InputSet {
+        double *Phi = nullptr, *G = nullptr, *dt = nullptr, *R = nullptr, *clone_R = nullptr, *clone_p = nullptr, *pf = nullptr, *uv = nullptr,
+               *chi2 = nullptr, *noise = nullptr;
+        int *gnss = nullptr, *idx = nullptr, *clone_idx = nullptr, *nclones = nullptr, *nfeat = nullptr, *anchor = nullptr, *dof = nullptr;
+        unsigned long long* mask = nullptr;
+    } alt;
+    bool alt_ready = false;
+    hipStream_t st_copy = nullptr;
+    hipEvent_t ev_copy = nullptr, ev_free[2] = { nullptr, nullptr };      // inputs landed / set no longer read by the compute stream
+    bool copy_pending = false, free_valid[2] = { false, false };
+    int set_id = 0;                                                        // which physical set the d_* pointers name
+    // pinned host staging ring: inputs are packed straight into page-locked memory and copied asynchronously; a slab is
+    // reused only after the copies issued from it have completed (its event), so no call has to synchronise the stream
+    struct PinSlab { char* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; };
+    PinSlab pin[4];
+    int pin_next = 0;
     // profiling
     bool prof;
     std::vector<ProfRec> recs;
@@ -146,51 +166,180 @@ int last_launch(ingvio_ctx* c)
     return 0;
 }
 
-// uploads frames [b0, b0+nb) into the SoA staging; returns max F in *fmax_used
-int stage_frames(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* fr, int* fmax_used)
+// ---- pinned staging ------------------------------------------------------------------------------------------------
+struct Uploader {
+    ingvio_ctx* c;
+    hipStream_t stream = nullptr;      // nullptr: the context's compute stream
+    ingvio_ctx::PinSlab* slab = nullptr;
+    size_t off = 0;
+    int rc = 0;
+    int begin(size_t bytes)
+    {
+        slab = &c->pin[c->pin_next];
+        c->pin_next = (c->pin_next + 1) & 3;
+        if (slab->busy) { HIPCHK(c, hipEventSynchronize(slab->ev)); slab->busy = false; }
+        if (slab->cap < bytes) {
+            if (slab->p) hipHostFree(slab->p);
+            slab->p = nullptr; slab->cap = 0;
+            const size_t cap = (bytes + (1u << 20)) & ~((size_t)(1u << 20) - 1);
+            HIPCHK(c, hipHostMalloc((void**)&slab->p, cap, hipHostMallocDefault));
+            memset(slab->p, 0, cap);
+            slab->cap = cap;
+        }
+        if (!slab->ev) HIPCHK(c, hipEventCreateWithFlags(&slab->ev, hipEventDisableTiming));
+        off = 0;
+        return 0;
+    }
+    template <class T>
+    T* take(size_t count)
+    {
+        off = (off + 63) & ~(size_t)63;
+        T* p = reinterpret_cast<T*>(slab->p + off);
+        off += sizeof(T) * count;
+        return p;
+    }
+    template <class T>
+    void copy(T* dst, const T* src, size_t count)
+    {
+        if (count && hipMemcpyAsync(dst, src, sizeof(T) * count, hipMemcpyHostToDevice, stream ? stream : c->st) != hipSuccess) rc = INGVIO_E_HIP;
+    }
+    int end()
+    {
+        if (rc) { c->err = "hipMemcpyAsync from the pinned staging slab failed"; return rc; }
+        HIPCHK(c, hipEventRecord(slab->ev, stream ? stream : c->st));
+        slab->busy = true;
+        return 0;
+    }
+};
+static size_t pad64(size_t b) { return (b + 63) & ~(size_t)63; }
+
+// fn(i) for i in [0, n): a few host threads when the batch is large enough to pay for them
+template <class F>
+void parallel_for(int n, F fn)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    int T = (int)(hw ? hw : 1);
+    if (T > 8) T = 8;
+    if (T > n / 16) T = n / 16;
+    if (T <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back([=]() { for (int i = t; i < n; i += T) fn(i); });
+    for (int i = 0; i < n; i += T) fn(i);
+    for (auto& x : th) x.join();
+}
+
+// the compute stream must not read staged inputs before the copy stream has delivered them
+int wait_inputs(ingvio_ctx* c)
+{
+    if (c->copy_pending) {
+        HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_copy, 0));
+        c->copy_pending = false;
+    }
+    return 0;
+}
+
+int prepare_async_set(ingvio_ctx* c)
+{
+    if (!c->alt_ready) {
+        const int B = c->d.batch, cm = c->d.c_max, fm = c->d.f_max;
+        auto& a = c->alt;
+        int rc = 0;
+        rc |= dalloc(c, &a.Phi, (size_t)B * KMAX * 225); rc |= dalloc(c, &a.G, (size_t)B * KMAX * 180); rc |= dalloc(c, &a.dt, (size_t)B * KMAX);
+        rc |= dalloc(c, &a.R, (size_t)B * 9); rc |= dalloc(c, &a.gnss, (size_t)B * 5); rc |= dalloc(c, &a.idx, B);
+        rc |= dalloc(c, &a.clone_idx, (size_t)B * cm); rc |= dalloc(c, &a.nclones, B); rc |= dalloc(c, &a.nfeat, B);
+        rc |= dalloc(c, &a.anchor, (size_t)B * fm); rc |= dalloc(c, &a.dof, (size_t)B * fm);
+        rc |= dalloc(c, &a.clone_R, (size_t)B * cm * 9); rc |= dalloc(c, &a.clone_p, (size_t)B * cm * 3);
+        rc |= dalloc(c, &a.pf, (size_t)B * fm * 3); rc |= dalloc(c, &a.uv, (size_t)B * fm * cm * 4);
+        rc |= dalloc(c, &a.chi2, CHI2_CAP); rc |= dalloc(c, &a.mask, (size_t)B * fm); rc |= dalloc(c, &a.noise, B);
+        if (rc) return INGVIO_E_HIP;
+        HIPCHK(c, hipStreamSynchronize(c->st));                        // the zero fills of dalloc
+        HIPCHK(c, hipStreamCreateWithFlags(&c->st_copy, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+        for (auto& e : c->ev_free) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->alt_ready = true;
+    }
+    return 0;
+}
+
+void swap_input_sets(ingvio_ctx* c)
+{
+    auto& a = c->alt;
+    std::swap(c->d_Phi, a.Phi); std::swap(c->d_G, a.G); std::swap(c->d_dt, a.dt); std::swap(c->d_R, a.R);
+    std::swap(c->d_gnss, a.gnss); std::swap(c->d_idx, a.idx); std::swap(c->d_clone_idx, a.clone_idx);
+    std::swap(c->d_nclones, a.nclones); std::swap(c->d_nfeat, a.nfeat); std::swap(c->d_anchor, a.anchor); std::swap(c->d_dof, a.dof);
+    std::swap(c->d_clone_R, a.clone_R); std::swap(c->d_clone_p, a.clone_p); std::swap(c->d_pf, a.pf); std::swap(c->d_uv, a.uv);
+    std::swap(c->d_chi2, a.chi2); std::swap(c->d_mask, a.mask); std::swap(c->d_noise, a.noise);
+    c->set_id ^= 1;
+}
+
+size_t frames_bytes(const ingvio_ctx* c, int nb)
+{
+    const size_t cm = c->d.c_max, fm = c->d.f_max, n = nb;
+    return pad64(4 * n * cm) + 2 * pad64(4 * n) + 2 * pad64(4 * n * fm) + pad64(8 * n * cm * 9) + pad64(8 * n * cm * 3) + pad64(8 * n * fm * 3) +
+           pad64(8 * n * fm * cm * 4) + pad64(8 * n * fm) + 1024;
+}
+
+// packs frames [b0, b0+nb) into the slab of `up` and enqueues the copies into the SoA device staging; max F in *fmax_used
+int pack_frames(ingvio_ctx* c, Uploader& up, int b0, int nb, const ingvio_msckf_frame* fr, int* fmax_used)
 {
     const int cm = c->d.c_max, fm = c->d.f_max;
-    std::vector<int> cidx((size_t)nb * cm, 0), ncl(nb), nft(nb), anc((size_t)nb * fm, 0), dof((size_t)nb * fm, 0);
-    std::vector<double> cR((size_t)nb * cm * 9, 0.0), cp((size_t)nb * cm * 3, 0.0), pf((size_t)nb * fm * 3, 0.0),
-        uv((size_t)nb * fm * cm * 4, 0.0);
-    std::vector<unsigned long long> mk((size_t)nb * fm, 0ULL);
     int fmx = 0;
     for (int i = 0; i < nb; ++i) {
         const ingvio_msckf_frame& f = fr[i];
         if (f.n_clones < 0 || f.n_clones > cm || f.n_feat < 0 || f.n_feat > fm) return INGVIO_E_CAPACITY;
-        ncl[i] = f.n_clones; nft[i] = f.n_feat;
         if (f.n_feat > fmx) fmx = f.n_feat;
-        for (int s = 0; s < f.n_clones; ++s) {
-            cidx[(size_t)i * cm + s] = f.clone_idx[s];
+        for (int s = 0; s < f.n_clones; ++s)
             if (f.clone_idx[s] < 0 || f.clone_idx[s] + 6 > c->d.n_max) return INGVIO_E_ARG;
-            memcpy(&cR[((size_t)i * cm + s) * 9], f.clone_R + 9 * s, 72);
-            memcpy(&cp[((size_t)i * cm + s) * 3], f.clone_p + 3 * s, 24);
-        }
-        for (int j = 0; j < f.n_feat; ++j) {
-            if (f.pf) memcpy(&pf[((size_t)i * fm + j) * 3], f.pf + 3 * j, 24);
-            anc[(size_t)i * fm + j] = f.anchor ? f.anchor[j] : 0;
-            if (f.anchor && (f.anchor[j] < 0 || f.anchor[j] >= f.n_clones)) return INGVIO_E_ARG;
-            mk[(size_t)i * fm + j] = f.obs_mask[j] & (f.n_clones >= 64 ? ~0ULL : ((1ULL << f.n_clones) - 1ULL));
-            dof[(size_t)i * fm + j] = f.dof ? f.dof[j] : 0;
-            for (int s = 0; s < f.n_clones; ++s)
-                memcpy(&uv[(((size_t)i * fm + j) * cm + s) * 4], f.uv + ((size_t)j * f.n_clones + s) * 4, 32);
-        }
+        if (f.anchor)
+            for (int j = 0; j < f.n_feat; ++j) if (f.anchor[j] < 0 || f.anchor[j] >= f.n_clones) return INGVIO_E_ARG;
     }
-    int rc = 0;
-    rc |= up(c, c->d_clone_idx + (size_t)b0 * cm, cidx.data(), sizeof(int) * cidx.size());
-    rc |= up(c, c->d_nclones + b0, ncl.data(), sizeof(int) * nb);
-    rc |= up(c, c->d_nfeat + b0, nft.data(), sizeof(int) * nb);
-    rc |= up(c, c->d_anchor + (size_t)b0 * fm, anc.data(), sizeof(int) * anc.size());
-    rc |= up(c, c->d_dof + (size_t)b0 * fm, dof.data(), sizeof(int) * dof.size());
-    rc |= up(c, c->d_clone_R + (size_t)b0 * cm * 9, cR.data(), 8 * cR.size());
-    rc |= up(c, c->d_clone_p + (size_t)b0 * cm * 3, cp.data(), 8 * cp.size());
-    rc |= up(c, c->d_pf + (size_t)b0 * fm * 3, pf.data(), 8 * pf.size());
-    rc |= up(c, c->d_uv + (size_t)b0 * fm * cm * 4, uv.data(), 8 * uv.size());
-    rc |= up(c, c->d_mask + (size_t)b0 * fm, mk.data(), 8 * mk.size());
-    if (rc) return INGVIO_E_HIP;
-    HIPCHK(c, hipStreamSynchronize(c->st));      // host vectors die at scope exit
+    int* cidx = up.take<int>((size_t)nb * cm); int* ncl = up.take<int>(nb); int* nft = up.take<int>(nb);
+    int* anc = up.take<int>((size_t)nb * fm); int* dof = up.take<int>((size_t)nb * fm);
+    double* cR = up.take<double>((size_t)nb * cm * 9); double* cp = up.take<double>((size_t)nb * cm * 3);
+    double* pf = up.take<double>((size_t)nb * fm * 3); double* uv = up.take<double>((size_t)nb * fm * cm * 4);
+    unsigned long long* mk = up.take<unsigned long long>((size_t)nb * fm);
+    parallel_for(nb, [=](int i) {
+        const ingvio_msckf_frame& f = fr[i];
+        const int C = f.n_clones, F = f.n_feat;
+        ncl[i] = C; nft[i] = F;
+        memcpy(cidx + (size_t)i * cm, f.clone_idx, sizeof(int) * (size_t)C);
+        memcpy(cR + (size_t)i * cm * 9, f.clone_R, 72 * (size_t)C);
+        memcpy(cp + (size_t)i * cm * 3, f.clone_p, 24 * (size_t)C);
+        if (f.pf) memcpy(pf + (size_t)i * fm * 3, f.pf, 24 * (size_t)F); else memset(pf + (size_t)i * fm * 3, 0, 24 * (size_t)F);
+        if (f.anchor) memcpy(anc + (size_t)i * fm, f.anchor, sizeof(int) * (size_t)F); else memset(anc + (size_t)i * fm, 0, sizeof(int) * (size_t)F);
+        if (f.dof) memcpy(dof + (size_t)i * fm, f.dof, sizeof(int) * (size_t)F); else memset(dof + (size_t)i * fm, 0, sizeof(int) * (size_t)F);
+        const unsigned long long cmask = C >= 64 ? ~0ULL : ((1ULL << C) - 1ULL);
+        unsigned long long* mki = mk + (size_t)i * fm;
+        for (int j = 0; j < F; ++j) mki[j] = f.obs_mask[j] & cmask;
+        for (int j = F; j < fm; ++j) mki[j] = 0ULL;
+        double* uvi = uv + (size_t)i * fm * cm * 4;
+        if (C == cm) memcpy(uvi, f.uv, 32 * (size_t)F * C);                           // same layout: one block
+        else for (int j = 0; j < F; ++j) memcpy(uvi + (size_t)j * cm * 4, f.uv + (size_t)j * C * 4, 32 * (size_t)C);
+    });
+    up.copy(c->d_clone_idx + (size_t)b0 * cm, cidx, (size_t)nb * cm);
+    up.copy(c->d_nclones + b0, ncl, nb);
+    up.copy(c->d_nfeat + b0, nft, nb);
+    up.copy(c->d_anchor + (size_t)b0 * fm, anc, (size_t)nb * fm);
+    up.copy(c->d_dof + (size_t)b0 * fm, dof, (size_t)nb * fm);
+    up.copy(c->d_clone_R + (size_t)b0 * cm * 9, cR, (size_t)nb * cm * 9);
+    up.copy(c->d_clone_p + (size_t)b0 * cm * 3, cp, (size_t)nb * cm * 3);
+    up.copy(c->d_pf + (size_t)b0 * fm * 3, pf, (size_t)nb * fm * 3);
+    up.copy(c->d_uv + (size_t)b0 * fm * cm * 4, uv, (size_t)nb * fm * cm * 4);
+    up.copy(c->d_mask + (size_t)b0 * fm, mk, (size_t)nb * fm);
     *fmax_used = fmx;
     return 0;
+}
+
+// uploads frames [b0, b0+nb) into the SoA staging; returns max F in *fmax_used
+int stage_frames(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* fr, int* fmax_used)
+{
+    if (wait_inputs(c)) return INGVIO_E_HIP;
+    Uploader up{ c };
+    int rc = up.begin(frames_bytes(c, nb));
+    if (rc) return rc;
+    rc = pack_frames(c, up, b0, nb, fr, fmax_used);
+    if (rc) return rc;
+    return up.end();
 }
 
 int make_opts(ingvio_ctx* c, const ingvio_msckf_opts* o, MsckfOpts* op)
@@ -356,6 +505,16 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
                      c->d_pf, c->d_uv, c->d_chi2, c->d_mask, c->d_gamma, c->d_accept, c->d_used, c->d_Rpart, c->d_chunk_used,
                      c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk, c->d_tri_ok, c->d_hnew };
     for (void* p : ptrs) if (p) hipFree(p);
+    for (auto& sl : c->pin) { if (sl.p) hipHostFree(sl.p); if (sl.ev) hipEventDestroy(sl.ev); }
+    {
+        auto& a = c->alt;
+        void* ap[] = { a.Phi, a.G, a.dt, a.R, a.gnss, a.idx, a.clone_idx, a.nclones, a.nfeat, a.anchor, a.dof, a.clone_R, a.clone_p, a.pf, a.uv,
+                       a.chi2, a.mask, a.noise };
+        for (void* p : ap) if (p) hipFree(p);
+        if (c->st_copy) hipStreamDestroy(c->st_copy);
+        if (c->ev_copy) hipEventDestroy(c->ev_copy);
+        for (auto e : c->ev_free) if (e) hipEventDestroy(e);
+    }
     for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (c->own_stream) hipStreamDestroy(c->st);
     delete c;
@@ -714,6 +873,7 @@ int ingvio_triangulate(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* 
         if (rc) return rc;
         c->strip_ok = false;
     } else if (!c->staged) return INGVIO_E_ARG;
+    else if (wait_inputs(c)) return INGVIO_E_HIP;
     TriLaunch L;
     memset(&L, 0, sizeof L);
     L.fv = fview(c); L.b0 = b0;
@@ -768,40 +928,73 @@ int ingvio_qr_compress(ingvio_ctx* c, const double* H, int ldh, int m, int n, co
     return last_launch(c);
 }
 
-int ingvio_frame_stage(ingvio_ctx* c, int b0, int nb, const ingvio_frame_step* steps, const ingvio_msckf_frame* frames,
-                       const ingvio_msckf_opts* opts, const double sigma[4], int enable_gnss, double scb, double srw)
+static int frame_stage_impl(ingvio_ctx* c, int b0, int nb, const ingvio_frame_step* steps, const ingvio_msckf_frame* frames,
+                            const ingvio_msckf_opts* opts, const double sigma[4], int enable_gnss, double scb, double srw, bool async)
 {
     if (check_range(c, b0, nb) || !steps || !frames || !opts || !sigma) return INGVIO_E_ARG;
+    if (async && (b0 != 0 || nb != c->d.batch)) return INGVIO_E_ARG;      // a whole input set is replaced
     const int k = steps[0].k;
     if (k < 1 || k > KMAX) return INGVIO_E_ARG;
     c->strip_ok = false;                          // new clock-state indices: the next restore is a full one
-    std::vector<double> Phi((size_t)nb * k * 225), G((size_t)nb * k * 180), dt((size_t)nb * k), R((size_t)nb * 9);
-    std::vector<int> gi((size_t)nb * 5), mi(nb);
+    if (!opts->chi2_table || opts->chi2_len < 2 || opts->chi2_len > CHI2_CAP) return INGVIO_E_ARG;
     for (int i = 0; i < nb; ++i) {
         if (steps[i].k != k) return INGVIO_E_ARG;
-        memcpy(&Phi[(size_t)i * k * 225], steps[i].Phi, 8 * (size_t)k * 225);
-        memcpy(&G[(size_t)i * k * 180], steps[i].G, 8 * (size_t)k * 180);
-        memcpy(&dt[(size_t)i * k], steps[i].dt, 8 * (size_t)k);
-        memcpy(&R[(size_t)i * 9], steps[i].R_i2w, 72);
-        for (int g = 0; g < 5; ++g) gi[(size_t)i * 5 + g] = steps[i].gnss_idx[g];
-        mi[i] = steps[i].marg_idx;
         c->st_marg[b0 + i] = steps[i].marg_idx;
     }
-    int rc = up(c, c->d_Phi + (size_t)b0 * k * 225, Phi.data(), 8 * Phi.size());
-    rc |= up(c, c->d_G + (size_t)b0 * k * 180, G.data(), 8 * G.size());
-    rc |= up(c, c->d_dt + (size_t)b0 * k, dt.data(), 8 * dt.size());
-    rc |= up(c, c->d_R + (size_t)b0 * 9, R.data(), 8 * R.size());
-    rc |= up(c, c->d_gnss + (size_t)b0 * 5, gi.data(), sizeof(int) * gi.size());
-    rc |= up(c, c->d_idx + b0, mi.data(), sizeof(int) * (size_t)nb);
-    if (rc) return INGVIO_E_HIP;
-    HIPCHK(c, hipStreamSynchronize(c->st));
-    rc = make_opts(c, opts, &c->st_op);
+    // everything goes through ONE pinned slab: packed by a few host threads, copied asynchronously, no stream sync
+    Uploader upl{ c };
+    const size_t n = nb;
+    int rc = 0;
+    if (async) {
+        rc = prepare_async_set(c);
+        if (rc) return rc;
+        // the set about to be overwritten was last read two frames ago; its "free" event is on the compute stream
+        if (c->free_valid[c->set_id ^ 1]) HIPCHK(c, hipStreamWaitEvent(c->st_copy, c->ev_free[c->set_id ^ 1], 0));
+        swap_input_sets(c);
+        upl.stream = c->st_copy;
+    } else {
+        rc = wait_inputs(c);              // an earlier asynchronous stage into this set must land before it is overwritten in-stream
+        if (rc) return rc;
+    }
+    rc = upl.begin(pad64(8 * n * k * 225) + pad64(8 * n * k * 180) + pad64(8 * n * k) + pad64(8 * n * 9) + pad64(4 * n * 5) + pad64(4 * n) +
+                       pad64(8 * CHI2_CAP) + pad64(8 * n) + frames_bytes(c, nb) + 1024);
     if (rc) return rc;
+    double* Phi = upl.take<double>(n * k * 225); double* G = upl.take<double>(n * k * 180); double* dt = upl.take<double>(n * k);
+    double* R = upl.take<double>(n * 9); int* gi = upl.take<int>(n * 5); int* mi = upl.take<int>(n);
+    double* chi2 = upl.take<double>(CHI2_CAP); double* nz = upl.take<double>(n);
+    const double var = opts->noise * opts->noise;
+    parallel_for(nb, [=](int i) {
+        memcpy(Phi + (size_t)i * k * 225, steps[i].Phi, 8 * (size_t)k * 225);
+        memcpy(G + (size_t)i * k * 180, steps[i].G, 8 * (size_t)k * 180);
+        memcpy(dt + (size_t)i * k, steps[i].dt, 8 * (size_t)k);
+        memcpy(R + (size_t)i * 9, steps[i].R_i2w, 72);
+        for (int g = 0; g < 5; ++g) gi[(size_t)i * 5 + g] = steps[i].gnss_idx[g];
+        mi[i] = steps[i].marg_idx;
+        nz[i] = var;
+    });
+    memcpy(chi2, opts->chi2_table, 8 * (size_t)opts->chi2_len);
+    upl.copy(c->d_Phi + (size_t)b0 * k * 225, Phi, n * k * 225);
+    upl.copy(c->d_G + (size_t)b0 * k * 180, G, n * k * 180);
+    upl.copy(c->d_dt + (size_t)b0 * k, dt, n * k);
+    upl.copy(c->d_R + (size_t)b0 * 9, R, n * 9);
+    upl.copy(c->d_gnss + (size_t)b0 * 5, gi, n * 5);
+    upl.copy(c->d_idx + b0, mi, n);
+    upl.copy(c->d_chi2, chi2, (size_t)opts->chi2_len);
+    upl.copy(c->d_noise + b0, nz, n);
+    MsckfOpts& op = c->st_op;
+    memcpy(op.R_lr, opts->R_cl2cr, 72);
+    memcpy(op.t_lr, opts->t_cl2cr, 24);
+    op.var = var; op.max_accept = opts->max_accept; op.selected_variant = opts->selected_variant;
+    op.chi2 = c->d_chi2; op.chi2_len = opts->chi2_len;
     int fmx = 0;
-    rc = stage_frames(c, b0, nb, frames, &fmx);
+    rc = pack_frames(c, upl, b0, nb, frames, &fmx);
     if (rc) return rc;
-    rc = fill_noise_scalar(c, b0, nb, c->st_op.var);
+    rc = upl.end();
     if (rc) return rc;
+    if (async) {
+        HIPCHK(c, hipEventRecord(c->ev_copy, c->st_copy));
+        c->copy_pending = true;
+    }
     c->st_k = k; c->st_stereo = opts->stereo; c->st_enable_gnss = enable_gnss; c->st_scb = scb; c->st_srw = srw;
     memcpy(c->st_sigma, sigma, 32);
     if (!c->staged || fmx > c->st_fmax_used) c->st_fmax_used = fmx;
@@ -809,10 +1002,23 @@ int ingvio_frame_stage(ingvio_ctx* c, int b0, int nb, const ingvio_frame_step* s
     return INGVIO_OK;
 }
 
+int ingvio_frame_stage(ingvio_ctx* c, int b0, int nb, const ingvio_frame_step* steps, const ingvio_msckf_frame* frames,
+                       const ingvio_msckf_opts* opts, const double sigma[4], int enable_gnss, double scb, double srw)
+{
+    return frame_stage_impl(c, b0, nb, steps, frames, opts, sigma, enable_gnss, scb, srw, false);
+}
+
+int ingvio_frame_stage_async(ingvio_ctx* c, int b0, int nb, const ingvio_frame_step* steps, const ingvio_msckf_frame* frames,
+                             const ingvio_msckf_opts* opts, const double sigma[4], int enable_gnss, double scb, double srw)
+{
+    return frame_stage_impl(c, b0, nb, steps, frames, opts, sigma, enable_gnss, scb, srw, true);
+}
+
 int ingvio_frame_run(ingvio_ctx* c, int restore_prior)
 {
     if (!c || !c->staged) return INGVIO_E_ARG;
     const int B = c->d.batch;
+    if (wait_inputs(c)) return INGVIO_E_HIP;
     if (restore_prior) {
         if (!c->has_snap) return INGVIO_E_ARG;
         ProfScope p(c, PF_RESTORE);
@@ -845,6 +1051,10 @@ int ingvio_frame_run(ingvio_ctx* c, int restore_prior)
     for (int b = 0; b < B; ++b) { if (c->st_marg[b] >= 0) { c->h_n[b] -= 6; c->h_cur[b] ^= 1; } else all_marg = false; }
     c->strip_ok = fuse && all_marg && restore_prior;
     c->strip_seq = c->mut_seq;
+    if (c->alt_ready) {                            // this input set may be refilled once the kernels above are done with it
+        HIPCHK(c, hipEventRecord(c->ev_free[c->set_id], c->st));
+        c->free_valid[c->set_id] = true;
+    }
     return INGVIO_OK;
 }
 

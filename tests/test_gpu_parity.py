@@ -350,6 +350,54 @@ def test_consecutive_frames_without_restore(orc):
     ctx2.close()
 
 
+def test_async_staging_pipeline(orc):
+    """ingvio_frame_stage_async: the inputs of the next frame go to the second input set over the copy stream while the
+    previous frame's kernels run.  Two different frames (and IMU steps) alternate through the pipeline
+    run(i); stage_async(i+1); fetch(i); every fetched result equals the oracle's for the frame that was run, and a
+    synchronous stage / staged triangulation afterwards still sees consistent inputs."""
+    from ingvio_amd import capi, host, synth
+    nb, F, C = 3, 80, 11
+    ctx2 = capi.Context(batch=nb, n_max=256, c_max=C, f_max=F, m_max=64)
+    sets = []
+    for s0 in (300, 400):
+        cases = []
+        for b in range(nb):
+            flt, step, frame, info = synth.build_case(lambda P, b=b: capi.DeviceCov(ctx2, b, P), host.imu_transition,
+                                                      seed=s0 + b, F=F, C=C)
+            cases.append((step, frame))
+        sets.append(cases)
+    # both frame sets act on the SAME prior (the one build_case of the last set left on the device)
+    priors = [ctx2.cov_get(b) for b in range(nb)]
+    ctx2.snapshot()
+    want = []
+    for cases in sets:
+        res = []
+        for b in range(nb):
+            oc = orc.Cov(priors[b], ld=256)
+            dxo, acco, gamo, m = orc.frame_update(oc, cases[b][0], cases[b][1], max_accept=0, compress_rule=1)
+            res.append((oc.P, dxo, acco))
+        want.append(res)
+    stage = [ctx2.frame_stage_prepare(0, [c[0] for c in cases], [c[1] for c in cases], cases[0][0]["sigma"], 1, 0.2, 0.2, use_async=True)
+             for cases in sets]
+    stage[0]()
+    for it in range(5):
+        cur = it % 2
+        ctx2.frame_run(restore_prior=True)
+        stage[1 - cur]()                                  # next frame's inputs while this one computes
+        dx, acc, rows = ctx2.frame_fetch()
+        for b in range(nb):
+            Pw, dxw, accw = want[cur][b]
+            assert np.array_equal(acc[b, :F], accw), (it, b)
+            assert rel_err(ctx2.cov_get(b), Pw) < TIGHT and rel_err(dx[b, :249], dxw) < 1e-8, (it, b)
+    # a synchronous stage after an asynchronous one (in flight) lands in the right order
+    ctx2.frame_stage(0, [c[0] for c in sets[0]], [c[1] for c in sets[0]], sets[0][0][0]["sigma"], 1, 0.2, 0.2)
+    ctx2.frame_run(restore_prior=True)
+    dx, acc, rows = ctx2.frame_fetch()
+    for b in range(nb):
+        assert np.array_equal(acc[b, :F], want[0][b][2]) and rel_err(ctx2.cov_get(b), want[0][b][0]) < TIGHT
+    ctx2.close()
+
+
 def test_frame_without_marginalisation_in_batch(orc):
     """One filter of the batch keeps its oldest clone (marg_idx = -1): it takes the in-place update path while its
     neighbours take the fused out-of-place one."""
