@@ -112,6 +112,19 @@ int ingvio_chi2_gamma(ingvio_ctx* ctx, int b, const int* vidx, const int* vsize,
                       const double* H, int ldh, int m, const double* res,
                       const double* R, int r_kind, double* gamma);
 
+/* Many independent whitenResidual gates against the same prior in one launch and one synchronisation (all SLAM landmarks of
+ * a frame, LandmarkUpdate.cpp:98-99; the per-row GNSS gates, GnssUpdate.cpp:190,259).  R = noise_var * I. */
+typedef struct {
+    const int* vidx;          /* var_order of this block as (idx, size)[k]                           */
+    const int* vsize;
+    int k;
+    const double* H;          /* m x sum(vsize), column-major, leading dimension ldh                   */
+    int ldh, m;
+    const double* res;        /* [m]                                                                */
+} ingvio_gate_block;
+int ingvio_chi2_gamma_multi(ingvio_ctx* ctx, int b, int nblk, const ingvio_gate_block* blocks, double noise_var,
+                            double* gamma_out);
+
 /* ---- SLAM-landmark covariance operations -----------------------------
  * addVariableDelayedInvertible (StateManager.cpp:461-543): H_old s x sum(vsize) (ldh), H_new s x s (ldn),
  * s <= 6; appends s rows/columns, new_idx receives the new variable's idx (== old N). */

@@ -27,8 +27,13 @@ EXPORTS = [
     "ingvio_frame_stage", "ingvio_frame_stage_async", "ingvio_frame_run", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_select",
     "ingvio_profile_reset",
     "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_debug_read", "ingvio_triangulate",
-    "ingvio_add_variable_delayed_invertible", "ingvio_add_variable_delayed", "ingvio_replace_var_linear",
+    "ingvio_chi2_gamma_multi", "ingvio_add_variable_delayed_invertible", "ingvio_add_variable_delayed", "ingvio_replace_var_linear",
 ]
+
+
+class GateBlock(C.Structure):
+    _fields_ = [("vidx", C.POINTER(C.c_int)), ("vsize", C.POINTER(C.c_int)), ("k", C.c_int), ("H", C.POINTER(C.c_double)),
+                ("ldh", C.c_int), ("m", C.c_int), ("res", C.POINTER(C.c_double))]
 
 
 class CtxDesc(C.Structure):
@@ -266,6 +271,20 @@ class Context:
         self._chk(self.L.ingvio_chi2_gamma(self.h, b, _i(i32(vidx)), _i(i32(vsize)), len(vidx), _d(H), m, m, _d(f64(res)),
                                            _d(Rb), kind, C.byref(g)))
         return g.value
+
+    def chi2_gamma_multi(self, b, blocks, noise_var):
+        """blocks: list of (vidx, vsize, H, res); returns gamma[len(blocks)] (one launch, one sync)."""
+        nb = len(blocks)
+        arr = (GateBlock * nb)(); keep = []
+        for g, (vidx, vsize, H, res) in enumerate(blocks):
+            H = np.asfortranarray(np.atleast_2d(H), dtype=np.float64)
+            vi, vs, r = i32(vidx), i32(vsize), f64(res)
+            keep.append((H, vi, vs, r))
+            arr[g].vidx = _i(vi); arr[g].vsize = _i(vs); arr[g].k = len(vi); arr[g].H = _d(H); arr[g].ldh = H.shape[0]
+            arr[g].m = H.shape[0]; arr[g].res = _d(r)
+        out = np.zeros(max(nb, 1))
+        self._chk(self.L.ingvio_chi2_gamma_multi(self.h, b, nb, arr, C.c_double(noise_var), _d(out)))
+        return out[:nb]
 
     # ---- SLAM-landmark path (f-2) --------------------------------------------------------------
     def add_variable_delayed_invertible(self, b, vidx, vsize, H_old, H_new, noise):

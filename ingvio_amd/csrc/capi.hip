@@ -61,6 +61,8 @@ struct ingvio_ctx {
     int *d_accept, *d_used, *d_chunk_used, *d_colmap, *d_m, *d_nc, *d_status, *d_pcbase;
     double *d_big_sg, *d_big_wk;        // large-window workspaces (c_max > 16)
     int* d_tri_ok;                      // [B][f_max] triangulation flags
+    char* d_multi = nullptr;            // ingvio_chi2_gamma_multi: packed blocks (grown on demand)
+    size_t multi_cap = 0;
     // staged frame state
     int st_k, st_stereo, st_enable_gnss, st_fmax_used;
     double st_sigma[4], st_scb, st_srw;
@@ -503,7 +505,7 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
     void* ptrs[] = { c->Pbase, c->Psnap, c->d_cur, c->d_n, c->d_n_snap, c->d_Phi, c->d_G, c->d_dt, c->d_R, c->d_blk, c->d_gnss,
                      c->d_idx, c->d_clone_idx, c->d_nclones, c->d_nfeat, c->d_anchor, c->d_dof, c->d_clone_R, c->d_clone_p,
                      c->d_pf, c->d_uv, c->d_chi2, c->d_mask, c->d_gamma, c->d_accept, c->d_used, c->d_Rpart, c->d_chunk_used,
-                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk, c->d_tri_ok, c->d_hnew };
+                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk, c->d_tri_ok, c->d_hnew, c->d_multi };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& sl : c->pin) { if (sl.p) hipHostFree(sl.p); if (sl.ev) hipEventDestroy(sl.ev); }
     {
@@ -729,6 +731,67 @@ int ingvio_chi2_gamma(ingvio_ctx* c, int b, const int* vidx, const int* vsize, i
     launch_gamma(view(c), b, c->d_H + (size_t)b * c->hstride, c->d_res + (size_t)b * c->mld, c->d_colmap + (size_t)b * c->cstride,
                  m, nc, c->d_noise1, r_kind, c->mld, c->d_gamma + (size_t)b * c->d.f_max, c->st);
     if (down_sync(c, gamma, c->d_gamma + (size_t)b * c->d.f_max, 8)) return INGVIO_E_HIP;
+    return last_launch(c);
+}
+
+// Many whitenResidual gates against the same prior in ONE launch and one synchronisation (all SLAM landmarks of a frame,
+// LandmarkUpdate.cpp:98-99; the per-row GNSS gates, GnssUpdate.cpp:190,259): gamma_out[g] for block g, R = noise_var * I.
+int ingvio_chi2_gamma_multi(ingvio_ctx* c, int b, int nblk, const ingvio_gate_block* blk, double noise_var, double* gamma_out)
+{
+    if (check_range(c, b, 1) || nblk < 0 || (nblk && (!blk || !gamma_out))) return INGVIO_E_ARG;
+    if (nblk == 0) return INGVIO_OK;
+    size_t nd = 1, ni = 0, lds = 0;                         // doubles (slot 0 = noise), ints
+    for (int g = 0; g < nblk; ++g) {
+        const ingvio_gate_block& q = blk[g];
+        if (!q.vidx || !q.vsize || !q.H || !q.res || q.k < 1 || q.m < 1 || q.ldh < q.m) return INGVIO_E_ARG;
+        int nc = 0;
+        for (int i = 0; i < q.k; ++i) {
+            if (q.vidx[i] < 0 || q.vidx[i] + q.vsize[i] > c->h_n[b]) return INGVIO_E_NOT_IN_STATE;
+            nc += q.vsize[i];
+        }
+        nd += (size_t)q.m * nc + q.m; ni += nc;
+        const size_t l = 8 * ((size_t)nc * q.m + (size_t)(q.m + 1) * (q.m + 1));
+        if (l > lds) lds = l;
+    }
+    if (lds > 150 * 1024) return INGVIO_E_CAPACITY;
+    const size_t bytes_d = pad64(8 * nd), bytes_i = pad64(4 * ni), bytes_desc = pad64(4 * 5 * (size_t)nblk), bytes_g = pad64(8 * (size_t)nblk);
+    const size_t total = bytes_d + bytes_i + bytes_desc + bytes_g;
+    if (c->multi_cap < total) {
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        if (c->d_multi) hipFree(c->d_multi);
+        c->d_multi = nullptr; c->multi_cap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_multi, total * 2));
+        c->multi_cap = total * 2;
+    }
+    Uploader upl{ c };
+    int rc = upl.begin(total + 1024);
+    if (rc) return rc;
+    double* hd = upl.take<double>(bytes_d / 8); int* hi = upl.take<int>(bytes_i / 4); int* hdesc = upl.take<int>(bytes_desc / 4);
+    hd[0] = noise_var;
+    size_t od = 1, oi = 0;
+    for (int g = 0; g < nblk; ++g) {
+        const ingvio_gate_block& q = blk[g];
+        int nc = 0;
+        int* cm = hi + oi;
+        for (int i = 0; i < q.k; ++i) for (int j = 0; j < q.vsize[i]; ++j) cm[nc++] = q.vidx[i] + j;
+        hdesc[5 * g] = (int)od;
+        for (int cc = 0; cc < nc; ++cc) memcpy(hd + od + (size_t)cc * q.m, q.H + (size_t)cc * q.ldh, 8 * (size_t)q.m);
+        od += (size_t)q.m * nc;
+        hdesc[5 * g + 1] = (int)od;
+        memcpy(hd + od, q.res, 8 * (size_t)q.m);
+        od += q.m;
+        hdesc[5 * g + 2] = (int)oi; hdesc[5 * g + 3] = q.m; hdesc[5 * g + 4] = nc;
+        oi += nc;
+    }
+    double* dd = reinterpret_cast<double*>(c->d_multi);
+    int* di = reinterpret_cast<int*>(c->d_multi + bytes_d);
+    int* ddesc = reinterpret_cast<int*>(c->d_multi + bytes_d + bytes_i);
+    double* dg = reinterpret_cast<double*>(c->d_multi + bytes_d + bytes_i + bytes_desc);
+    upl.copy(dd, hd, nd); upl.copy(di, hi, ni); upl.copy(ddesc, hdesc, 5 * (size_t)nblk);
+    rc = upl.end();
+    if (rc) return rc;
+    launch_gamma_multi(view(c), b, nblk, dd, di, ddesc, dd, dg, lds, c->st);
+    if (down_sync(c, gamma_out, dg, 8 * (size_t)nblk)) return INGVIO_E_HIP;
     return last_launch(c);
 }
 

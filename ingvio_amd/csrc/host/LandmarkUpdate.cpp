@@ -226,16 +226,25 @@ void LandmarkUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapSer
     col_of[state->_camleft_imu_extrinsics] = 9;
     int col_cnt = 15;
     struct Block { VecXd res; MatXd H; std::shared_ptr<Type> anchor, lm; };
-    std::vector<Block> accepted;
+    std::vector<Block> all, accepted;
     for (const auto& item : state->_anchored_landmarks) {
         checkTracked(map_server, state, item.first, stereo);
         Block blk;
         blk.anchor = item.second->getAnchoredPose();
         blk.lm = item.second;
         landmarkRows(map_server->at(item.first), state, stereo, blk.res, blk.H);
-        // gate on the prior of [pose, extrinsics, anchor, landmark], dof = rows (Update.cpp:81-102)
-        const std::vector<std::shared_ptr<Type>> order4 = { state->_extended_pose, state->_camleft_imu_extrinsics, blk.anchor, blk.lm };
-        if (!testChiSquared(state, blk.res, blk.H, order4, _noise)) continue;
+        all.push_back(std::move(blk));
+    }
+    // testChiSquared(state, res, H, [pose, extrinsics, anchor, landmark], noise) for every landmark (:98-99): all gates are
+    // against the same prior, so they go to the device in one call; dof = rows (Update.cpp:81-102)
+    std::vector<StateManager::GateBlock> gates;
+    for (const Block& blk : all)
+        gates.push_back({ { state->_extended_pose, state->_camleft_imu_extrinsics, blk.anchor, blk.lm }, &blk.H, &blk.res });
+    const std::vector<double> gamma = StateManager::whitenResidualMulti(state, gates, _noise);
+    const std::vector<double> table = chi2TableDense(per + 1);
+    for (size_t g = 0; g < all.size(); ++g) {
+        if (!(gamma[g] < table[per])) continue;
+        Block& blk = all[g];
         for (const auto& v : { blk.anchor, blk.lm })
             if (col_of.find(v) == col_of.end()) { col_of[v] = col_cnt; col_cnt += v->size(); var_order.push_back(v); }
         accepted.push_back(std::move(blk));

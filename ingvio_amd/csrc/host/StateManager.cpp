@@ -343,6 +343,23 @@ double StateManager::whitenResidual(std::shared_ptr<State> state, const VecXd& r
     return gamma;
 }
 
+std::vector<double> StateManager::whitenResidualMulti(std::shared_ptr<State> state, const std::vector<GateBlock>& blocks, double noise)
+{
+    const int nb = (int)blocks.size();
+    std::vector<double> gamma(nb, 0.0);
+    if (nb == 0) return gamma;
+    std::vector<std::vector<int>> vidx(nb), vsize(nb);
+    std::vector<ingvio_gate_block> gb(nb);
+    for (int g = 0; g < nb; ++g) {
+        orderOf(blocks[g].var_order, vidx[g], vsize[g]);
+        gb[g].vidx = vidx[g].data(); gb[g].vsize = vsize[g].data(); gb[g].k = (int)vidx[g].size();
+        gb[g].H = blocks[g].H->data(); gb[g].ldh = blocks[g].H->rows(); gb[g].m = blocks[g].H->rows(); gb[g].res = blocks[g].res->data();
+    }
+    const int rc = ingvio_chi2_gamma_multi(state->_ctx, state->_b, nb, gb.data(), noise * noise, gamma.data());
+    if (rc != INGVIO_OK) fatal(state, "whitenResidualMulti", rc);
+    return gamma;
+}
+
 bool StateManager::triangulateOne(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_tri_opts& opts, Vec3d& pf)
 {
     const int fm = std::max(ingvio_f_max(state->_ctx), 1);

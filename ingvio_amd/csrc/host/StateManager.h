@@ -57,6 +57,10 @@ public:
     static double whitenResidual(std::shared_ptr<State> state, const VecXd& res, const MatXd& H,
                                  const std::vector<std::shared_ptr<Type>>& var_order, double noise);
 
+    // several gates against the same prior in one device call (ingvio_chi2_gamma_multi); R = noise^2 I for all of them
+    struct GateBlock { std::vector<std::shared_ptr<Type>> var_order; const MatXd* H; const VecXd* res; };
+    static std::vector<double> whitenResidualMulti(std::shared_ptr<State> state, const std::vector<GateBlock>& blocks, double noise);
+
     // MSCKF update on flattened MapServer data + boxPlus; returns rows handed to the Kalman update.
     // f-1: Triangulator::triangulate{Mono,Stereo}Obs of ONE feature on the device (ingvio_triangulate)
     static bool triangulateOne(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_tri_opts& opts, Vec3d& pf);

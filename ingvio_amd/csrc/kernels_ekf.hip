@@ -162,14 +162,12 @@ __global__ __launch_bounds__(256) void k_downdate(CovView cv, int b0, const doub
     }
 }
 
-// whitenResidual for small blocks (GNSS per-row / block gating): one workgroup, m <= 32.
-__global__ __launch_bounds__(256) void k_gamma(CovView cv, int b, const double* __restrict__ H, const double* __restrict__ res,
-                                               const int* __restrict__ colmap, int m, int nc, const double* __restrict__ noise,
-                                               int r_kind, int mld, double* __restrict__ gamma_out)
+// whitenResidual for small blocks (GNSS per-row / landmark / block gating): one workgroup per block.
+__device__ __forceinline__ void gamma_body(const CovView& cv, int b, const double* __restrict__ H, const double* __restrict__ res,
+                                           const int* __restrict__ colmap, int m, int nc, const double* __restrict__ noise, int r_kind,
+                                           int mld, double* __restrict__ gamma_out, double* sT)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* sT = reinterpret_cast<double*>(smem_raw);          // nc x m : Pcc H^T
-    double* sS = sT + (size_t)nc * m;                           // (m+1) x (m+1)
+    double* sS = sT + (size_t)nc * m;                           // sT: nc x m = Pcc H^T ; sS: (m+1) x (m+1)
     const int tid = threadIdx.x, ld = cv.ldp, LS = m + 1;
     const double* P = cov_ptr(cv, b);
     for (int e = tid; e < nc * m; e += 256) {
@@ -204,6 +202,26 @@ __global__ __launch_bounds__(256) void k_gamma(CovView cv, int b, const double* 
     if (tid == 0) *gamma_out = -sS[m * LS + m];
 }
 
+__global__ __launch_bounds__(256) void k_gamma(CovView cv, int b, const double* __restrict__ H, const double* __restrict__ res,
+                                               const int* __restrict__ colmap, int m, int nc, const double* __restrict__ noise,
+                                               int r_kind, int mld, double* __restrict__ gamma_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    gamma_body(cv, b, H, res, colmap, m, nc, noise, r_kind, mld, gamma_out, reinterpret_cast<double*>(smem_raw));
+}
+
+// Many independent gates against the same prior in one launch (all landmarks of a frame, all GNSS rows): block g reads
+// its descriptor {offset of H, of res, of colmap (in ints), m, nc} from desc[5 g ..]; H is m x nc, tight (ld = m).
+__global__ __launch_bounds__(256) void k_gamma_multi(CovView cv, int b, const double* __restrict__ dbuf, const int* __restrict__ ibuf,
+                                                     const int* __restrict__ desc, const double* __restrict__ noise,
+                                                     double* __restrict__ gamma_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int* d = desc + 5 * blockIdx.x;
+    gamma_body(cv, b, dbuf + d[0], dbuf + d[1], ibuf + d[2], d[3], d[4], noise, 0, d[3], gamma_out + blockIdx.x,
+               reinterpret_cast<double*>(smem_raw));
+}
+
 void launch_ekf_core(const EkfLaunch& L, hipStream_t st)
 {
     const size_t sm = sizeof(double) * (size_t)(L.m_cap + 1) * (L.m_cap + 1) + sizeof(int) * (size_t)L.nc_cap + 16;
@@ -217,6 +235,13 @@ void launch_downdate(const EkfLaunch& L, int n_cap, hipStream_t st, const double
     const int nt = (n_cap + 15) / 16;
     const int tiles = nt * (nt + 1) / 2;
     hipLaunchKernelGGL(k_downdate, dim3((tiles + 3) / 4, L.nb), dim3(256), 0, st, L.cv, L.b0, L.Y, Yb ? Yb : L.Y, L.m, L.ystride, L.status);
+}
+
+void launch_gamma_multi(CovView cv, int b, int nblk, const double* dbuf, const int* ibuf, const int* desc, const double* noise,
+                        double* gamma_out, size_t lds_bytes, hipStream_t st)
+{
+    hipFuncSetAttribute((const void*)k_gamma_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(k_gamma_multi, dim3(nblk), dim3(256), lds_bytes, st, cv, b, dbuf, ibuf, desc, noise, gamma_out);
 }
 
 void launch_gamma(CovView cv, int b, const double* H, const double* res, const int* colmap, int m, int nc,

@@ -21,6 +21,8 @@ struct EkfLaunch {
 
 void launch_ekf_core(const EkfLaunch& L, hipStream_t st);
 void launch_downdate(const EkfLaunch& L, int n_cap, hipStream_t st, const double* Yb = nullptr);
+void launch_gamma_multi(CovView cv, int b, int nblk, const double* dbuf, const int* ibuf, const int* desc, const double* noise,
+                        double* gamma_out, size_t lds_bytes, hipStream_t st);
 void launch_gamma(CovView cv, int b, const double* H, const double* res, const int* colmap, int m, int nc,
                   const double* noise, int r_kind, int mld, double* gamma_out, hipStream_t st);
 

@@ -291,3 +291,29 @@ def test_gpu_landmark_update_rows_through_generic_update(stereo):
     assert np.linalg.norm(ctx.cov_get(0) - c.P) / np.linalg.norm(c.P) < 1e-11
     assert np.linalg.norm(dxg - dxo) < 1e-9 * max(1.0, np.linalg.norm(dxo))
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_chi2_gamma_multi():
+    """all gates of a frame in one launch == the gates one by one == the oracle's whitenResidual"""
+    rng = np.random.default_rng(500)
+    C, L = 6, 9
+    n = 21 + 6 * C + 3 * L
+    P0 = spd(n, rng, 1e-3)
+    ctx = _ctx(n, C, m_max=128)
+    ctx.cov_set(1, P0)
+    c = orc.Cov(P0)
+    blocks = []
+    for l in range(L):
+        rows = 4 if l % 2 == 0 else 2                         # mixed block shapes in one call
+        vo = [0, 15, 21 + 6 * int(rng.integers(0, C)), 21 + 6 * C + 3 * l]; vs = [9, 6, 6, 3]
+        if l == 4:
+            vo, vs = [21, 27], [6, 6]                         # a different var_order altogether
+        H = rng.standard_normal((rows, sum(vs))); r = 0.02 * rng.standard_normal(rows)
+        blocks.append((vo, vs, H, r))
+    g = ctx.chi2_gamma_multi(1, blocks, 0.01 ** 2)
+    for l, (vo, vs, H, r) in enumerate(blocks):
+        go = c.whiten(vo, vs, H, r, 0.01 ** 2)
+        assert abs(g[l] - go) < 1e-9 * max(1.0, go) and abs(ctx.chi2_gamma(1, vo, vs, H, r, 0.01 ** 2) - g[l]) < 1e-9 * max(1.0, go)
+    assert len(ctx.chi2_gamma_multi(1, [], 1.0)) == 0
+    ctx.close()
