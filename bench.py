@@ -316,6 +316,13 @@ def main():
                                      "HIP-event time inside the timed region; the kernel executes far fewer operations "
                                      "(Woodbury-reduced system), hence frac can exceed 1; traffic = HBM bytes per launch "
                                      "(rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_rocprofv3_pmc_hbm_traffic.csv)")
+                if dom == "k_feat_gate3" and C == 11:
+                    # what the kernel actually executes (SQ counters of the committed PMC pass, profiles/r01_rocprofv3_pmc_sq.csv:
+                    # ~1.0 k FP64 VALU wave-instructions x 64 lanes x 2 + 32 MFMA x 2048 per feature = 0.19 MFLOP)
+                    ex = 0.19e6 * F * B / (dom_ms * 1e-3) / 1e12
+                    roofline["executed"] = dict(tflops=ex, frac=ex / FP64_PEAK_TFLOPS,
+                                                note="executed (not algorithmic) FP64 operations per launch from the SQ counters; the "
+                                                     "fraction of the FP64 peak the kernel's own instruction stream reaches")
             elif dom in bytes_k:
                 a = kernels[dom]["gbs"]
                 roofline = dict(kernel=dom, bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
