@@ -49,7 +49,7 @@ typedef struct {
     int batch;      /* independent filters held by this context (>= 1)                          */
     int n_max;      /* max state dimension N (21 + gnss + 6C + 3L)                               */
     int c_max;      /* max clones in the sliding window: <= 36; windows above 16 take the large-window kernels (factored path
-                     * only: no dense method, no ingvio_qr_compress), see DESIGN.md                */
+                     * only: no dense MSCKF method), see DESIGN.md                */
     int f_max;      /* max features per MSCKF update                                             */
     int m_max;      /* max rows of a generic ekf_update (<= 128 in this build)                   */
     int device;     /* HIP device ordinal                                                        */
@@ -198,7 +198,8 @@ int ingvio_set_msckf_method(ingvio_ctx* ctx, int method);
 /* Stacked-QR compression on its own (the SPQR call sites RemoveLostUpdate.cpp:376-397,
  * SwMargUpdate.cpp:336-357, KeyframeUpdate.cpp:707-728): H m x n (ldh) column-major, res [m] ->
  * H_thin n x n upper triangular (ldt) and r_thin [n] with H_thin^T H_thin = H^T H,
- * H_thin^T r_thin = H^T res.  n <= 6*c_max. */
+ * H_thin^T r_thin = H^T res.  Any m <= 6144, n <= 4096 (n <= 96 in multiples of 6: the TSQR of the dense MSCKF path;
+ * otherwise the blocked Householder QR of kernels_qr.hip). */
 int ingvio_qr_compress(ingvio_ctx* ctx, const double* H, int ldh, int m, int n, const double* res,
                        double* H_thin, int ldt, double* r_thin);
 

@@ -8,6 +8,7 @@
 #include "launch_factored.h"
 #include "launch_tri.h"
 #include "launch_lm.h"
+#include "launch_qr.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -956,7 +957,30 @@ int ingvio_triangulate(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* 
 int ingvio_qr_compress(ingvio_ctx* c, const double* H, int ldh, int m, int n, const double* res, double* Ht, int ldt, double* rt)
 {
     if (!c || !H || !res || !Ht || !rt || m < 1 || n < 1 || ldh < m || ldt < n) return INGVIO_E_ARG;
-    if (n > 6 * c->d.c_max) return INGVIO_E_CAPACITY;
+    if (n > 96 || n % 6 != 0 || n > 6 * c->d.c_max || c->d.c_max > 16) {
+        // general shapes (wide windows, the 6000 x 800 stress shape): blocked Householder QR, kernels_qr.hip
+        if (n > 4096) return INGVIO_E_CAPACITY;
+        double *dA = nullptr, *db = nullptr, *ws = nullptr, *dT = nullptr;
+        HIPCHK(c, hipMalloc((void**)&dA, 8 * (size_t)ldh * n));
+        HIPCHK(c, hipMalloc((void**)&db, 8 * (size_t)m));
+        HIPCHK(c, hipMalloc((void**)&ws, 8 * qr_dense_workspace_doubles(m, n)));
+        HIPCHK(c, hipMalloc((void**)&dT, 8 * ((size_t)n * n + n)));
+        int rc2 = up(c, dA, H, 8 * (size_t)ldh * n) | up(c, db, res, 8 * (size_t)m);
+        if (!rc2) {
+            ProfScope p(c, PF_FOLD);
+            if (launch_qr_dense(dA, ldh, db, m, n, ws, dT, n, dT + (size_t)n * n, c->st)) rc2 = INGVIO_E_CAPACITY;
+        }
+        if (!rc2) {
+            if (ldt == n) rc2 = hipMemcpyAsync(Ht, dT, 8 * (size_t)n * n, hipMemcpyDeviceToHost, c->st) != hipSuccess;
+            else rc2 = hipMemcpy2DAsync(Ht, 8 * (size_t)ldt, dT, 8 * (size_t)n, 8 * (size_t)n, n, hipMemcpyDeviceToHost, c->st) != hipSuccess;
+            rc2 |= hipMemcpyAsync(rt, dT + (size_t)n * n, 8 * (size_t)n, hipMemcpyDeviceToHost, c->st) != hipSuccess;
+            if (rc2) rc2 = INGVIO_E_HIP;
+        }
+        hipStreamSynchronize(c->st);
+        hipFree(dA); hipFree(db); hipFree(ws); hipFree(dT);
+        if (rc2) return rc2 < 0 ? rc2 : INGVIO_E_HIP;
+        return last_launch(c);
+    }
     double *dH = nullptr, *dres = nullptr;
     HIPCHK(c, hipMalloc((void**)&dH, 8 * (size_t)ldh * n));
     HIPCHK(c, hipMalloc((void**)&dres, 8 * (size_t)m));

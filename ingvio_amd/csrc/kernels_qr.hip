@@ -1,0 +1,289 @@
+// kernels_qr.hip — general stacked-QR compression (K7) for shapes beyond the 96-column TSQR of kernels_msckf.hip:
+// H (m x n) | res  ->  H_thin (n x n upper triangular) | r_thin with H_thin^T H_thin = H^T H, H_thin^T r_thin = H^T res
+// (the SPQR call sites RemoveLostUpdate.cpp:376-397, SwMargUpdate.cpp:336-357, KeyframeUpdate.cpp:707-728, and the
+// BASELINE "stress" shape 6000 x 800).  Blocked Householder QR with panels of QR_NB = 8 columns, no Q is ever formed.
+// The working copy D is PANEL-major: column panel p is a contiguous [row][8] array, so
+//   * the panel kernel's row-owner threads read 64 contiguous bytes each and a wave 4 KB in one piece,
+//   * the trailing kernels map a wave to 8 columns x 8 rows = 512 contiguous bytes per load.
+//   k_qr_panel  one workgroup keeps the whole panel (m x 8) in REGISTERS and runs the 8 reflectors with one block reduction
+//               each: the dots of column k with the columns right of it give the norm AND every v^T a_c at once.  Same
+//               reflector convention as the oracle (alpha = -sign(x0) |x|, v0 = 1).
+//   k_qr_w      W = V^T [V | C] for the trailing columns C (one workgroup per column panel and 512-row chunk); its first 8
+//               columns are V^T V.
+//   k_qr_z      sums the row-chunk partials and solves (striu(V^T V) + diag(1/tau))^T Z = W: the compact-WY factor through
+//               its inverse (T^-1 = striu(V^T V) + diag(1/tau)), so no T is ever built.
+//   k_qr_apply  C -= V Z, one read-modify-write of the trailing matrix per panel.
+// FP64 VALU throughout (FMA rate = MFMA rate on gfx950; the products here are 8-wide, below an MFMA tile).
+// gfx950 only.
+#include "dev_common.h"
+#include "launch_qr.h"
+
+#define QR_NB 8
+#define QR_NT 512                // 8 waves = 2 per SIMD: 256 VGPRs per lane, the 12 x 8 panel slice of a thread stays in registers
+#define QR_RPT 12                // rows per thread in the panel kernel: m - j0 <= 6144
+#define QR_CG 256                // columns per workgroup in k_qr_z
+#define QR_RC 512                // rows per workgroup in k_qr_w / k_qr_apply
+
+namespace {
+
+// element (r, c) of the panel-major working copy; mp8 = 8 * (rows rounded up to 8)
+__device__ __forceinline__ size_t didx(int r, int c, size_t mp8) { return (size_t)(c >> 3) * mp8 + (size_t)r * 8 + (c & 7); }
+
+// column-major H (ldh) | res  ->  panel-major D, column n = res; padding columns of the last panel are zero
+__global__ __launch_bounds__(256) void k_qr_load(const double* __restrict__ H, int ldh, const double* __restrict__ res, int m, int n,
+                                                  double* __restrict__ D, size_t mp8)
+{
+    __shared__ double t[32][33];
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int cc = ty; cc < 32; cc += 8) {
+        const int r = r0 + tx, c = c0 + cc;
+        t[cc][tx] = (r < m && c <= n) ? (c < n ? H[r + (size_t)c * ldh] : res[r]) : 0.0;
+    }
+    __syncthreads();
+    const int ncp = (n + 1 + 7) & ~7;
+    for (int rr = ty; rr < 32; rr += 8) {
+        const int r = r0 + rr, c = c0 + tx;
+        if (r < m && c < ncp) D[didx(r, c, mp8)] = t[tx][rr];
+    }
+}
+
+__global__ __launch_bounds__(QR_NT) void k_qr_panel(double* __restrict__ D, size_t mp8, int m, int j0, int nbp, double* __restrict__ tau_out)
+{
+    __shared__ double red[QR_NT / WAVE][QR_NB];
+    __shared__ double sg[QR_NB], bc[QR_NB];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double* const Pn = D + (size_t)(j0 >> 3) * mp8;                    // this panel: [row][8]
+    double x[QR_RPT][QR_NB];
+#pragma unroll
+    for (int i = 0; i < QR_RPT; ++i) {
+        const int r = j0 + tid + QR_NT * i;
+        const double2* src = reinterpret_cast<const double2*>(Pn + (size_t)(r < m ? r : 0) * 8);
+#pragma unroll
+        for (int c2 = 0; c2 < QR_NB / 2; ++c2) {
+            const double2 v = src[c2];
+            x[i][2 * c2] = (r < m && 2 * c2 < nbp) ? v.x : 0.0;
+            x[i][2 * c2 + 1] = (r < m && 2 * c2 + 1 < nbp) ? v.y : 0.0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < QR_NB; ++k) {
+        if (k < nbp) {                                                   // uniform
+            double p[QR_NB];
+#pragma unroll
+            for (int c = 0; c < QR_NB; ++c) p[c] = 0.0;
+#pragma unroll
+            for (int i = 0; i < QR_RPT; ++i) {
+                const bool act = tid + QR_NT * i >= k;                   // rows j0+k and below
+                const double xk = act ? x[i][k] : 0.0;
+#pragma unroll
+                for (int c = k; c < QR_NB; ++c) p[c] += xk * x[i][c];
+            }
+#pragma unroll
+            for (int c = k; c < QR_NB; ++c) {
+                double v = p[c];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+                if (lane == 0) red[wave][c] = v;
+            }
+            if (tid == k) {
+#pragma unroll
+                for (int c = 0; c < QR_NB; ++c) bc[c] = x[0][c];       // row j0+k of the panel
+            }
+            __syncthreads();
+            if (wave == 0) {                                             // second stage: 8 waves x QR_NB values
+                const int c = lane & (QR_NB - 1), wg = lane / QR_NB;     // wg: 0..7 = the wave whose partial this lane takes
+                double v = red[wg][c];
+#pragma unroll
+                for (int off = QR_NB; off < WAVE; off <<= 1) v += __shfl_xor(v, off, WAVE);
+                if (lane < QR_NB) sg[lane] = v;
+            }
+            __syncthreads();
+            const double x0 = bc[k], nrm = sqrt(sg[k]);
+            double tau = 0.0;
+            if (nrm != 0.0) {                                            // oracle: a zero column is skipped
+                const double alpha = x0 >= 0.0 ? -nrm : nrm, v0 = x0 - alpha, iv0 = 1.0 / v0;
+                tau = -v0 / alpha;
+                double w[QR_NB];
+#pragma unroll
+                for (int c = k + 1; c < QR_NB; ++c) w[c] = tau * ((sg[c] - x0 * bc[c]) * iv0 + bc[c]);
+#pragma unroll
+                for (int i = 0; i < QR_RPT; ++i) {
+                    const int rr = tid + QR_NT * i;
+                    if (rr > k) {
+                        const double v = x[i][k] * iv0;
+                        x[i][k] = v;
+#pragma unroll
+                        for (int c = k + 1; c < QR_NB; ++c) x[i][c] -= w[c] * v;
+                    } else if (rr == k) {
+                        x[i][k] = alpha;
+#pragma unroll
+                        for (int c = k + 1; c < QR_NB; ++c) x[i][c] -= w[c];
+                    }
+                }
+            }
+            if (tid == 0) tau_out[k] = tau;
+            __syncthreads();                                             // red / bc / sg are reused by the next reflector
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < QR_RPT; ++i) {
+        const int r = j0 + tid + QR_NT * i;
+        if (r < m) {
+            double2* dst = reinterpret_cast<double2*>(Pn + (size_t)r * 8);
+#pragma unroll
+            for (int c2 = 0; c2 < QR_NB / 2; ++c2) {                     // columns >= nbp of a short last panel keep their (loaded) value
+                if (2 * c2 + 1 < nbp) dst[c2] = make_double2(x[i][2 * c2], x[i][2 * c2 + 1]);
+                else if (2 * c2 < nbp) Pn[(size_t)r * 8 + 2 * c2] = x[i][2 * c2];
+            }
+        }
+    }
+}
+
+// V as the trailing kernels see it: unit lower-trapezoidal (the panel stores R on and above the diagonal)
+__device__ __forceinline__ double vmask(double d, int rrel, int k) { return rrel > k ? d : (rrel == k ? 1.0 : 0.0); }
+
+// stages V rows [r0, r0+nr) of panel j0 into LDS, masked
+__device__ __forceinline__ void stage_v(const double* __restrict__ D, size_t mp8, int j0, int nbp, int r0, int nr, double (*sV)[QR_NB])
+{
+    const double* Pn = D + (size_t)(j0 >> 3) * mp8;
+    for (int e = threadIdx.x; e < QR_RC * QR_NB; e += 256) {
+        const int rr = e >> 3, k = e & 7;
+        sV[rr][k] = (rr < nr && k < nbp) ? vmask(Pn[(size_t)(r0 + rr) * 8 + k], r0 + rr - j0, k) : 0.0;
+    }
+}
+
+// Wp[chunk][k][cx] = sum over the chunk's rows of V[r][k] * X[r][cx],  X = D[:, j0 ...): V itself (cx < 8), then the trailing
+// columns.  Workgroup = one 8-column panel x 512 rows; lane = (column cl, row lane rl): a wave reads 8 rows x 64 B in one piece.
+__global__ __launch_bounds__(256) void k_qr_w(const double* __restrict__ D, size_t mp8, int m, int ncx, int j0, int nbp, double* __restrict__ Wp)
+{
+    __shared__ double sV[QR_RC][QR_NB];
+    __shared__ double sAcc[4][QR_NB][8];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3, wave = threadIdx.x >> 6, pb = blockIdx.x, chunk = blockIdx.y;
+    const int r0 = j0 + chunk * QR_RC, nr = min(QR_RC, m - r0);
+    stage_v(D, mp8, j0, nbp, r0, nr, sV);
+    __syncthreads();
+    const double* Px = D + (size_t)((j0 >> 3) + pb) * mp8;
+    double acc[QR_NB];
+#pragma unroll
+    for (int k = 0; k < QR_NB; ++k) acc[k] = 0.0;
+#pragma unroll 4
+    for (int rr = rl; rr < nr; rr += 32) {
+        double xv = Px[(size_t)(r0 + rr) * 8 + cl];
+        if (pb == 0) xv = cl < nbp ? vmask(xv, r0 + rr - j0, cl) : xv;   // the V columns of X
+#pragma unroll
+        for (int k = 0; k < QR_NB; ++k) acc[k] += sV[rr][k] * xv;
+    }
+#pragma unroll
+    for (int k = 0; k < QR_NB; ++k) {
+        double v = acc[k];
+        v += __shfl_xor(v, 8, WAVE); v += __shfl_xor(v, 16, WAVE); v += __shfl_xor(v, 32, WAVE);      // the wave's 8 row lanes
+        if ((threadIdx.x & 63) < 8) sAcc[wave][k][cl] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int k = threadIdx.x >> 3, c8 = threadIdx.x & 7, cx = 8 * pb + c8;
+        if (cx < ncx) Wp[((size_t)chunk * QR_NB + k) * ncx + cx] = (sAcc[0][k][c8] + sAcc[1][k][c8]) + (sAcc[2][k][c8] + sAcc[3][k][c8]);
+    }
+}
+
+__global__ __launch_bounds__(QR_CG) void k_qr_z(const double* __restrict__ Wp, int nchunks, int ncx, int nbp, const double* __restrict__ tau,
+                                                 double* __restrict__ Z)
+{
+    __shared__ double sG[QR_NB][QR_NB];                                  // V^T V: rows k, columns = the first QR_NB columns of X
+    const int c = blockIdx.x * QR_CG + threadIdx.x;
+    if (threadIdx.x < QR_NB * QR_NB) {
+        const int k = threadIdx.x / QR_NB, cc = threadIdx.x % QR_NB;
+        double s = 0.0;
+        if (cc < ncx) for (int ch = 0; ch < nchunks; ++ch) s += Wp[((size_t)ch * QR_NB + k) * ncx + cc];
+        sG[k][cc] = s;
+    }
+    __syncthreads();
+    if (c >= ncx || c < nbp) return;                                     // the panel's own columns are final
+    double w[QR_NB], z[QR_NB];
+#pragma unroll
+    for (int k = 0; k < QR_NB; ++k) w[k] = 0.0;
+    for (int ch = 0; ch < nchunks; ++ch) {
+#pragma unroll
+        for (int k = 0; k < QR_NB; ++k) w[k] += Wp[((size_t)ch * QR_NB + k) * ncx + c];
+    }
+    // (striu(G) + diag(1/tau))^T z = w, forward substitution; tau_k = 0 (skipped reflector) gives z_k = 0
+#pragma unroll
+    for (int k = 0; k < QR_NB; ++k) {
+        double s = w[k];
+#pragma unroll
+        for (int l = 0; l < k; ++l) s -= sG[l][k] * z[l];
+        z[k] = k < nbp ? tau[k] * s : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < QR_NB; ++k) Z[(size_t)k * ncx + c] = z[k];
+}
+
+__global__ __launch_bounds__(256) void k_qr_apply(double* __restrict__ D, size_t mp8, int m, int ncx, int j0, int nbp, const double* __restrict__ Z)
+{
+    __shared__ double sV[QR_RC][QR_NB];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3, pb = blockIdx.x, cx = 8 * pb + cl;
+    const int r0 = j0 + blockIdx.y * QR_RC, nr = min(QR_RC, m - r0);
+    stage_v(D, mp8, j0, nbp, r0, nr, sV);
+    __syncthreads();
+    if (cx >= ncx || cx < nbp) return;                                   // (a short last panel shares its 8-group with trailing columns)
+    double z[QR_NB];
+#pragma unroll
+    for (int k = 0; k < QR_NB; ++k) z[k] = Z[(size_t)k * ncx + cx];
+    double* Px = D + (size_t)((j0 >> 3) + pb) * mp8;
+#pragma unroll 4
+    for (int rr = rl; rr < nr; rr += 32) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < QR_NB; ++k) s += sV[rr][k] * z[k];
+        Px[(size_t)(r0 + rr) * 8 + cl] -= s;
+    }
+}
+
+// R (n x n upper, column-major ldt) and Q^T res (first n entries) out of the working copy
+__global__ __launch_bounds__(256) void k_qr_extract(const double* __restrict__ D, size_t mp8, int m, int n, double* __restrict__ Ht, int ldt,
+                                                     double* __restrict__ rt)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n * n) {
+        const int i = e / n, j = e - i * n;                              // row i, column j
+        Ht[i + (size_t)j * ldt] = (i <= j && i < m) ? D[didx(i, j, mp8)] : 0.0;
+    }
+    if (e < n) rt[e] = e < m ? D[didx(e, n, mp8)] : 0.0;
+}
+
+}  // namespace
+
+static size_t qr_mp8(int m) { return (size_t)8 * (((size_t)m + 7) & ~(size_t)7); }
+
+size_t qr_dense_workspace_doubles(int m, int n)
+{
+    const size_t npan = ((size_t)n + 1 + 7) / 8, nch = ((size_t)m + QR_RC - 1) / QR_RC, ncp = npan * 8;
+    return npan * qr_mp8(m) + nch * QR_NB * ncp + (size_t)QR_NB * ncp + 64;
+}
+
+int launch_qr_dense(const double* dH, int ldh, const double* dres, int m, int n, double* ws, double* dHt, int ldt, double* drt, hipStream_t st)
+{
+    if (m > QR_NT * QR_RPT) return -1;
+    const int n1 = n + 1, npan = (n1 + 7) / 8, ncp = npan * 8;
+    const size_t mp8 = qr_mp8(m);
+    double* D = ws;
+    double* Wp = D + (size_t)npan * mp8;
+    const int nch_max = (m + QR_RC - 1) / QR_RC;
+    double* Z = Wp + (size_t)nch_max * QR_NB * ncp;
+    double* tau = Z + (size_t)QR_NB * ncp;
+    hipLaunchKernelGGL(k_qr_load, dim3((m + 31) / 32, (ncp + 31) / 32), dim3(256), 0, st, dH, ldh, dres, m, n, D, mp8);
+    const int nref = m - 1 < n ? m - 1 : n;                              // reflectors: min(m-1, n), as the oracle
+    for (int j0 = 0; j0 < nref; j0 += QR_NB) {
+        const int nbp = nref - j0 < QR_NB ? nref - j0 : QR_NB;
+        hipLaunchKernelGGL(k_qr_panel, dim3(1), dim3(QR_NT), 0, st, D, mp8, m, j0, nbp, tau);
+        const int ncx = n1 - j0;                                         // X = columns j0 .. n (incl. res)
+        if (ncx > nbp) {
+            const int nch = (m - j0 + QR_RC - 1) / QR_RC, npx = (ncx + 7) / 8;
+            hipLaunchKernelGGL(k_qr_w, dim3(npx, nch), dim3(256), 0, st, D, mp8, m, ncx, j0, nbp, Wp);
+            hipLaunchKernelGGL(k_qr_z, dim3((ncx + QR_CG - 1) / QR_CG), dim3(QR_CG), 0, st, Wp, nch, ncx, nbp, tau, Z);
+            hipLaunchKernelGGL(k_qr_apply, dim3(npx, nch), dim3(256), 0, st, D, mp8, m, ncx, j0, nbp, Z);
+        }
+    }
+    hipLaunchKernelGGL(k_qr_extract, dim3((n * n + 255) / 256), dim3(256), 0, st, D, mp8, m, n, dHt, ldt, drt);
+    return 0;
+}

@@ -1,0 +1,9 @@
+// launch_qr.h — general blocked-Householder QR compression (kernels_qr.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+// device workspace (doubles) for an m x n problem
+size_t qr_dense_workspace_doubles(int m, int n);
+// dH m x n column-major (ldh), dres [m] -> dHt n x n upper triangular column-major (ldt), drt [n]; -1: m too large
+int launch_qr_dense(const double* dH, int ldh, const double* dres, int m, int n, double* ws, double* dHt, int ldt, double* drt, hipStream_t st);

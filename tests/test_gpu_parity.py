@@ -567,6 +567,47 @@ def test_qr_compress(ctx):
     assert rel_err(Ht.T @ Ht, A1.T @ A1) < 1e-12
 
 
+@pytest.mark.parametrize("m,n", [(500, 65), (300, 130), (1200, 216), (40, 100), (97, 97), (2100, 8)])
+def test_qr_compress_general_vs_oracle(orc, m, n):
+    """Shapes beyond the 96-column TSQR (any n, windows above 16 clones, m < n): blocked Householder QR (kernels_qr.hip)
+    with the oracle's reflector convention, so R and Q^T res agree entry by entry, not only up to row signs."""
+    from ingvio_amd import capi
+    ctx3 = capi.Context(batch=1, n_max=64, c_max=11, f_max=8, m_max=64)
+    rng = np.random.default_rng(m * 1000 + n)
+    A = rng.standard_normal((m, n)); b = rng.standard_normal(m)
+    if n == 130:
+        A[:, 100:106] = A[:, :6] @ rng.standard_normal((6, 6))             # rank-deficient (Q9)
+    Ht, rt = ctx3.qr_compress(A, b)
+    Ro, ro = orc.qr_compress(A, b)
+    k = min(m, n)
+    scale = np.linalg.norm(Ro)
+    if n != 130:      # rank-deficient: the reflector of a numerically zero column is decided by rounding noise, R is not unique
+        assert np.linalg.norm(Ht[:k] - Ro[:k]) < 1e-11 * scale and np.linalg.norm(rt[:k] - ro[:k]) < 1e-11 * max(1.0, np.linalg.norm(ro))
+    assert not np.tril(Ht, -1).any() and not Ht[k:].any() and np.isfinite(Ht).all()
+    assert rel_err(Ht.T @ Ht, A.T @ A) < 1e-12 and rel_err(Ht.T @ rt, A.T @ b) < 1e-12
+    ctx3.close()
+
+
+def test_qr_compress_stress_shape():
+    """BASELINE config 5's pure-kernel shape: dense 6000 x 800, cond ~ 1e3.  Size-independent properties + LAPACK's R up
+    to row signs."""
+    from ingvio_amd import capi
+    ctx3 = capi.Context(batch=1, n_max=64, c_max=11, f_max=8, m_max=64)
+    rng = np.random.default_rng(5)
+    m, n = 6000, 800
+    U, _ = np.linalg.qr(rng.standard_normal((m, n)))
+    V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    A = (U * np.logspace(0, -3, n)) @ V.T                                   # singular values 1 .. 1e-3
+    b = rng.standard_normal(m)
+    Ht, rt = ctx3.qr_compress(A, b)
+    assert not np.tril(Ht, -1).any()
+    assert rel_err(Ht.T @ Ht, A.T @ A) < 1e-12 and rel_err(Ht.T @ rt, A.T @ b) < 1e-11
+    Rl = np.linalg.qr(A, mode="r")
+    sg = np.sign(np.diag(Rl)) * np.sign(np.diag(Ht))
+    assert np.linalg.norm(Ht - sg[:, None] * Rl) < 1e-9 * np.linalg.norm(Rl)   # cond 1e3: R is determined to ~1e-13 * cond
+    ctx3.close()
+
+
 def test_round_trip_properties_full_size():
     """Size-independent properties at the bench's full size (512 x N=249 would be the bench; here 32):
     the posterior is symmetric, never larger than the prior on the diagonal of the updated clones,
