@@ -567,7 +567,7 @@ def test_qr_compress(ctx):
     assert rel_err(Ht.T @ Ht, A1.T @ A1) < 1e-12
 
 
-@pytest.mark.parametrize("m,n", [(500, 65), (300, 130), (1200, 216), (40, 100), (97, 97), (2100, 8), (1600, 45), (6144, 24)])
+@pytest.mark.parametrize("m,n", [(500, 65), (300, 130), (1200, 216), (40, 100), (97, 97), (2100, 8), (1600, 45), (6144, 25)])
 def test_qr_compress_general_vs_oracle(orc, m, n):
     """Shapes beyond the 96-column TSQR (any n, windows above 16 clones, m < n): blocked Householder QR (kernels_qr.hip)
     with the oracle's reflector convention, so R and Q^T res agree entry by entry, not only up to row signs."""
