@@ -10,9 +10,9 @@
 //               reflector convention as the oracle (alpha = -sign(x0) |x|, v0 = 1).
 //   k_qr_w      W = V^T [V | C] for the trailing columns C (one workgroup per column panel and 512-row chunk); its first 8
 //               columns are V^T V.
-//   k_qr_z      sums the row-chunk partials and solves (striu(V^T V) + diag(1/tau))^T Z = W: the compact-WY factor through
-//               its inverse (T^-1 = striu(V^T V) + diag(1/tau)), so no T is ever built.
-//   k_qr_apply  C -= V Z, one read-modify-write of the trailing matrix per panel.
+//   k_qr_apply  sums the row-chunk partials of its 8 columns, solves (striu(V^T V) + diag(1/tau))^T Z = W - the compact-WY
+//               factor through its inverse (T^-1 = striu(V^T V) + diag(1/tau)), so no T is ever built - and does
+//               C -= V Z, one read-modify-write of the trailing matrix per panel.
 // FP64 VALU throughout (FMA rate = MFMA rate on gfx950; the products here are 8-wide, below an MFMA tile).
 // gfx950 only.
 #include "dev_common.h"
@@ -21,7 +21,6 @@
 #define QR_NB 8
 #define QR_NT 512                // 8 waves = 2 per SIMD: 256 VGPRs per lane, the 12 x 8 panel slice of a thread stays in registers
 #define QR_RPT 12                // rows per thread in the panel kernel: m - j0 <= 6144
-#define QR_CG 256                // columns per workgroup in k_qr_z
 #define QR_RC 512                // rows per workgroup in k_qr_w / k_qr_apply
 
 namespace {
@@ -186,49 +185,40 @@ __global__ __launch_bounds__(256) void k_qr_w(const double* __restrict__ D, size
     }
 }
 
-__global__ __launch_bounds__(QR_CG) void k_qr_z(const double* __restrict__ Wp, int nchunks, int ncx, int nbp, const double* __restrict__ tau,
-                                                 double* __restrict__ Z)
-{
-    __shared__ double sG[QR_NB][QR_NB];                                  // V^T V: rows k, columns = the first QR_NB columns of X
-    const int c = blockIdx.x * QR_CG + threadIdx.x;
-    if (threadIdx.x < QR_NB * QR_NB) {
-        const int k = threadIdx.x / QR_NB, cc = threadIdx.x % QR_NB;
-        double s = 0.0;
-        if (cc < ncx) for (int ch = 0; ch < nchunks; ++ch) s += Wp[((size_t)ch * QR_NB + k) * ncx + cc];
-        sG[k][cc] = s;
-    }
-    __syncthreads();
-    if (c >= ncx || c < nbp) return;                                     // the panel's own columns are final
-    double w[QR_NB], z[QR_NB];
-#pragma unroll
-    for (int k = 0; k < QR_NB; ++k) w[k] = 0.0;
-    for (int ch = 0; ch < nchunks; ++ch) {
-#pragma unroll
-        for (int k = 0; k < QR_NB; ++k) w[k] += Wp[((size_t)ch * QR_NB + k) * ncx + c];
-    }
-    // (striu(G) + diag(1/tau))^T z = w, forward substitution; tau_k = 0 (skipped reflector) gives z_k = 0
-#pragma unroll
-    for (int k = 0; k < QR_NB; ++k) {
-        double s = w[k];
-#pragma unroll
-        for (int l = 0; l < k; ++l) s -= sG[l][k] * z[l];
-        z[k] = k < nbp ? tau[k] * s : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < QR_NB; ++k) Z[(size_t)k * ncx + c] = z[k];
-}
-
-__global__ __launch_bounds__(256) void k_qr_apply(double* __restrict__ D, size_t mp8, int m, int ncx, int j0, int nbp, const double* __restrict__ Z)
+// C -= V Z for one 8-column panel x 512 rows.  Z for these 8 columns is solved here (every row-chunk workgroup repeats the
+// 8 x 8 forward substitution: cheaper than a kernel of its own): W = sum of the row-chunk partials,
+// (striu(V^T V) + diag(1/tau))^T Z = W, V^T V = the first 8 columns of W.  tau_k = 0 (skipped reflector) gives z_k = 0.
+__global__ __launch_bounds__(256) void k_qr_apply(double* __restrict__ D, size_t mp8, int m, int ncx, int j0, int nbp, const double* __restrict__ Wp,
+                                                  int nchunks, const double* __restrict__ tau)
 {
     __shared__ double sV[QR_RC][QR_NB];
+    __shared__ double sW[QR_NB][8], sG[QR_NB][8], sZ[QR_NB][8];
     const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3, pb = blockIdx.x, cx = 8 * pb + cl;
     const int r0 = j0 + blockIdx.y * QR_RC, nr = min(QR_RC, m - r0);
     stage_v(D, mp8, j0, nbp, r0, nr, sV);
+    if (threadIdx.x < 128) {
+        const int t = threadIdx.x & 63, k = t >> 3, c8 = t & 7, col = threadIdx.x < 64 ? 8 * pb + c8 : c8;
+        double s = 0.0;
+        if (col < ncx) for (int ch = 0; ch < nchunks; ++ch) s += Wp[((size_t)ch * QR_NB + k) * ncx + col];
+        if (threadIdx.x < 64) sW[k][c8] = s; else sG[k][c8] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        double z[QR_NB];
+#pragma unroll
+        for (int k = 0; k < QR_NB; ++k) {
+            double s = sW[k][cl];
+#pragma unroll
+            for (int l = 0; l < k; ++l) s -= sG[l][k] * z[l];
+            z[k] = k < nbp ? tau[k] * s : 0.0;
+            sZ[k][cl] = z[k];
+        }
+    }
     __syncthreads();
     if (cx >= ncx || cx < nbp) return;                                   // (a short last panel shares its 8-group with trailing columns)
     double z[QR_NB];
 #pragma unroll
-    for (int k = 0; k < QR_NB; ++k) z[k] = Z[(size_t)k * ncx + cx];
+    for (int k = 0; k < QR_NB; ++k) z[k] = sZ[k][cl];
     double* Px = D + (size_t)((j0 >> 3) + pb) * mp8;
 #pragma unroll 4
     for (int rr = rl; rr < nr; rr += 32) {
@@ -269,8 +259,7 @@ int launch_qr_dense(const double* dH, int ldh, const double* dres, int m, int n,
     double* D = ws;
     double* Wp = D + (size_t)npan * mp8;
     const int nch_max = (m + QR_RC - 1) / QR_RC;
-    double* Z = Wp + (size_t)nch_max * QR_NB * ncp;
-    double* tau = Z + (size_t)QR_NB * ncp;
+    double* tau = Wp + (size_t)nch_max * QR_NB * ncp;
     hipLaunchKernelGGL(k_qr_load, dim3((m + 31) / 32, (ncp + 31) / 32), dim3(256), 0, st, dH, ldh, dres, m, n, D, mp8);
     const int nref = m - 1 < n ? m - 1 : n;                              // reflectors: min(m-1, n), as the oracle
     for (int j0 = 0; j0 < nref; j0 += QR_NB) {
@@ -280,8 +269,7 @@ int launch_qr_dense(const double* dH, int ldh, const double* dres, int m, int n,
         if (ncx > nbp) {
             const int nch = (m - j0 + QR_RC - 1) / QR_RC, npx = (ncx + 7) / 8;
             hipLaunchKernelGGL(k_qr_w, dim3(npx, nch), dim3(256), 0, st, D, mp8, m, ncx, j0, nbp, Wp);
-            hipLaunchKernelGGL(k_qr_z, dim3((ncx + QR_CG - 1) / QR_CG), dim3(QR_CG), 0, st, Wp, nch, ncx, nbp, tau, Z);
-            hipLaunchKernelGGL(k_qr_apply, dim3(npx, nch), dim3(256), 0, st, D, mp8, m, ncx, j0, nbp, Z);
+            hipLaunchKernelGGL(k_qr_apply, dim3(npx, nch), dim3(256), 0, st, D, mp8, m, ncx, j0, nbp, Wp, nch, tau);
         }
     }
     hipLaunchKernelGGL(k_qr_extract, dim3((n * n + 255) / 256), dim3(256), 0, st, D, mp8, m, n, dHt, ldt, drt);
