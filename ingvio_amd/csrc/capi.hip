@@ -226,8 +226,13 @@ void parallel_for(int n, F fn)
     if (T > n / 16) T = n / 16;
     if (T <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
     std::vector<std::thread> th;
-    for (int t = 1; t < T; ++t) th.emplace_back([=]() { for (int i = t; i < n; i += T) fn(i); });
+    int started = 1;                                                     // stripe 0 is this thread's
+    try {
+        for (int t = 1; t < T; ++t) { th.emplace_back([=]() { for (int i = t; i < n; i += T) fn(i); }); ++started; }
+    } catch (...) {                                                      // thread limit reached: the stripes not started run here
+    }
     for (int i = 0; i < n; i += T) fn(i);
+    for (int t = started; t < T; ++t) for (int i = t; i < n; i += T) fn(i);
     for (auto& x : th) x.join();
 }
 
