@@ -62,6 +62,8 @@ struct ingvio_ctx {
     int *d_accept, *d_used, *d_chunk_used, *d_colmap, *d_m, *d_nc, *d_status, *d_pcbase;
     double *d_big_sg, *d_big_wk;        // large-window workspaces (c_max > 16)
     int* d_tri_ok;                      // [B][f_max] triangulation flags
+    // ingvio_qr_compress, general path: device buffers and the captured launch sequence (~300 kernels) of the last shape
+    struct QrCache { int m = 0, n = 0, ldh = 0; double *dA = nullptr, *db = nullptr, *ws = nullptr, *dT = nullptr; hipGraphExec_t exec = nullptr; } qr;
     char* d_multi = nullptr;            // ingvio_chi2_gamma_multi: packed blocks (grown on demand)
     size_t multi_cap = 0;
     // staged frame state
@@ -514,6 +516,8 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
                      c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk, c->d_tri_ok, c->d_hnew, c->d_multi };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& sl : c->pin) { if (sl.p) hipHostFree(sl.p); if (sl.ev) hipEventDestroy(sl.ev); }
+    if (c->qr.exec) hipGraphExecDestroy(c->qr.exec);
+    for (double* p : { c->qr.dA, c->qr.db, c->qr.ws, c->qr.dT }) if (p) hipFree(p);
     {
         auto& a = c->alt;
         void* ap[] = { a.Phi, a.G, a.dt, a.R, a.gnss, a.idx, a.clone_idx, a.nclones, a.nfeat, a.anchor, a.dof, a.clone_R, a.clone_p, a.pf, a.uv,
@@ -965,24 +969,41 @@ int ingvio_qr_compress(ingvio_ctx* c, const double* H, int ldh, int m, int n, co
     if (n > 96 || n % 6 != 0 || n > 6 * c->d.c_max || c->d.c_max > 16) {
         // general shapes (wide windows, the 6000 x 800 stress shape): blocked Householder QR, kernels_qr.hip
         if (n > 4096) return INGVIO_E_CAPACITY;
-        double *dA = nullptr, *db = nullptr, *ws = nullptr, *dT = nullptr;
-        HIPCHK(c, hipMalloc((void**)&dA, 8 * (size_t)ldh * n));
-        HIPCHK(c, hipMalloc((void**)&db, 8 * (size_t)m));
-        HIPCHK(c, hipMalloc((void**)&ws, 8 * qr_dense_workspace_doubles(m, n)));
-        HIPCHK(c, hipMalloc((void**)&dT, 8 * ((size_t)n * n + n)));
-        int rc2 = up(c, dA, H, 8 * (size_t)ldh * n) | up(c, db, res, 8 * (size_t)m);
+        auto& q = c->qr;
+        if (q.m != m || q.n != n || q.ldh != ldh) {                      // new shape: buffers and the launch graph are rebuilt
+            HIPCHK(c, hipStreamSynchronize(c->st));
+            if (q.exec) { hipGraphExecDestroy(q.exec); q.exec = nullptr; }
+            for (double** p : { &q.dA, &q.db, &q.ws, &q.dT }) { if (*p) hipFree(*p); *p = nullptr; }
+            q.m = q.n = q.ldh = 0;
+            HIPCHK(c, hipMalloc((void**)&q.dA, 8 * (size_t)ldh * n));
+            HIPCHK(c, hipMalloc((void**)&q.db, 8 * (size_t)m));
+            HIPCHK(c, hipMalloc((void**)&q.ws, 8 * qr_dense_workspace_doubles(m, n)));
+            HIPCHK(c, hipMalloc((void**)&q.dT, 8 * ((size_t)n * n + n)));
+            // the factorisation is a fixed sequence of 3 launches per 8-column panel: captured once, replayed as one graph
+            hipGraph_t g = nullptr;
+            HIPCHK(c, hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal));
+            const int lrc = launch_qr_dense(q.dA, ldh, q.db, m, n, q.ws, q.dT, n, q.dT + (size_t)n * n, c->st);
+            const hipError_t ce = hipStreamEndCapture(c->st, &g);
+            if (lrc) { if (g) hipGraphDestroy(g); return INGVIO_E_CAPACITY; }
+            if (ce != hipSuccess || !g) { c->err = "hipStreamEndCapture failed"; return INGVIO_E_HIP; }
+            const hipError_t ie = hipGraphInstantiate(&q.exec, g, nullptr, nullptr, 0);
+            hipGraphDestroy(g);
+            if (ie != hipSuccess) { q.exec = nullptr; c->err = "hipGraphInstantiate failed"; return INGVIO_E_HIP; }
+            q.m = m; q.n = n; q.ldh = ldh;
+        }
+        int rc2 = up(c, q.dA, H, 8 * (size_t)ldh * n) | up(c, q.db, res, 8 * (size_t)m);
         if (!rc2) {
             ProfScope p(c, PF_FOLD);
-            if (launch_qr_dense(dA, ldh, db, m, n, ws, dT, n, dT + (size_t)n * n, c->st)) rc2 = INGVIO_E_CAPACITY;
+            if (hipGraphLaunch(q.exec, c->st) != hipSuccess) rc2 = INGVIO_E_HIP;
         }
         if (!rc2) {
+            double* dT = q.dT;
             if (ldt == n) rc2 = hipMemcpyAsync(Ht, dT, 8 * (size_t)n * n, hipMemcpyDeviceToHost, c->st) != hipSuccess;
             else rc2 = hipMemcpy2DAsync(Ht, 8 * (size_t)ldt, dT, 8 * (size_t)n, 8 * (size_t)n, n, hipMemcpyDeviceToHost, c->st) != hipSuccess;
             rc2 |= hipMemcpyAsync(rt, dT + (size_t)n * n, 8 * (size_t)n, hipMemcpyDeviceToHost, c->st) != hipSuccess;
             if (rc2) rc2 = INGVIO_E_HIP;
         }
         hipStreamSynchronize(c->st);
-        hipFree(dA); hipFree(db); hipFree(ws); hipFree(dT);
         if (rc2) return rc2 < 0 ? rc2 : INGVIO_E_HIP;
         return last_launch(c);
     }
