@@ -74,6 +74,7 @@ template <int CMAX, bool STEREO>
 struct Gate3Shared {
     static constexpr int D = STEREO ? 3 : 2;
     static constexpr int NPAIR = CMAX * (CMAX + 1) / 2;
+    static constexpr int KPK = (D * CMAX) * (D * CMAX + 1) / 2;
     FeatShared<CMAX, STEREO, true> f;
     int cna[CMAX];
     int pfl[CMAX];
@@ -84,7 +85,7 @@ struct Gate3Shared {
     static constexpr int NTL = (D * CMAX + 12 + 15) / 16;      // 16x16 tile rows of the bordered matrix (MFMA back end)
     static constexpr int KP = 16 * NTL - 12;                   // K padded with unit pivots to KP, border rows KP..KP+3
     union alignas(16) {
-        double blk[NPAIR][D * D];     // pair blocks
+        double kp[KPK + 16];          // K, packed lower triangle by rows: element (i, j <= i) at i (i + 1) / 2 + j; +16: unclamped reads of padding columns
         double nh[CMAX * 12 + 24];    // before they are built: N_o | h_o per observation and the record's 21 sums
         double pan[16 * NTL][4];      // after the tiles are built: panel exchange of the MFMA elimination
         double bz[16];                // finally: the 4x4 border block
@@ -138,8 +139,15 @@ __device__ __forceinline__ void gate3_body(
 #pragma unroll
                 for (int i = 0; i < 9; ++i) Su[i] += op.var * sh.Ninv[o][i];
             }
+            // rows 3 o + a of the packed triangle, columns 3 o2 + b (the diagonal blocks only keep b <= a)
+            int tri = (3 * o) * (3 * o + 1) / 2 + 3 * o2;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) sh.blk[q][i] = Su[i];
+            for (int a = 0; a < 3; ++a) {
+#pragma unroll
+                for (int b2 = 0; b2 < 3; ++b2)
+                    if (o != o2 || b2 <= a) sh.kp[tri + b2] = Su[3 * a + b2];
+                tri += 3 * o + a + 1;
+            }
         } else {
             double GSm[2][3];
 #pragma unroll
@@ -153,7 +161,8 @@ __device__ __forceinline__ void gate3_body(
                 for (int r2 = 0; r2 < 2; ++r2) {
                     double v = GSm[r][0] * sh.f.G[o2][r2][0] + GSm[r][1] * sh.f.G[o2][r2][1] + GSm[r][2] * sh.f.G[o2][r2][2];
                     if (o == o2 && r == r2) v += op.var;
-                    sh.blk[q][(D * r + r2) % (D * D)] = v;
+                    const int ii = 2 * o + r, jj = 2 * o2 + r2;
+                    if (jj <= ii) sh.kp[ii * (ii + 1) / 2 + jj] = v;
                 }
         }
     };
@@ -419,20 +428,24 @@ __device__ __forceinline__ void gate3_body(
                     }
                 } else {
                     const bool ireal = i < np;
-                    const int ii = ireal ? i : 0, io = ii / D, ic = ii - D * io;
+                    const int ii = ireal ? i : 0, tri_i = ii * (ii + 1) / 2;
 #pragma unroll
                     for (int tj = 0; tj <= ti; ++tj) {
-                        const int o2 = jo[tj], c2 = jc[tj];
-                        const bool low = io >= o2;
-                        const int q = low ? io * (io + 1) / 2 + o2 : o2 * (o2 + 1) / 2 + io;
-                        const double bv = sh.blk[q][low ? D * ic + c2 : D * c2 + ic];
+                        // strictly-below-diagonal tiles: j < i, one read at (row base + lane) + an immediate; diagonal tiles pick
+                        // the stored half.  Padding rows/columns read something valid and are overridden by the selects.
+                        double bv;
+                        if (tj < ti) bv = sh.kp[tri_i + 16 * tj + l15];
+                        else {
+                            const int jj = jreal[tj] ? 16 * tj + l15 : 0;
+                            bv = sh.kp[ii >= jj ? tri_i + jj : jj * (jj + 1) / 2 + ii];
+                        }
                         const double idv = (i == 16 * tj + l15) ? 1.0 : 0.0;      // unit pivots on the padding rows
                         T[ti * (ti + 1) / 2 + tj][r] = (ireal && jreal[tj]) ? bv : ((!ireal && !jreal[tj]) ? idv : 0.0);
                     }
                 }
             }
         }
-        wave_sync();                              // blk is dead from here on: its LDS becomes the panel buffer
+        wave_sync();                              // kp is dead from here on: its LDS becomes the panel buffer
 #pragma unroll
         for (int k = 0; k < KP / 4; ++k) {
             if (k < npan) {
