@@ -317,3 +317,37 @@ def test_gpu_chi2_gamma_multi():
         assert abs(g[l] - go) < 1e-9 * max(1.0, go) and abs(ctx.chi2_gamma(1, vo, vs, H, r, 0.01 ** 2) - g[l]) < 1e-9 * max(1.0, go)
     assert len(ctx.chi2_gamma_multi(1, [], 1.0)) == 0
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_error_paths_of_the_widened_abi():
+    """the reference's fatal conditions come back as negative status codes (the shim turns them into its messages + exit)"""
+    from ingvio_amd import capi, host, synth
+    rng = np.random.default_rng(600)
+    C = 4; n = 21 + 6 * C
+    ctx = capi.Context(batch=2, n_max=48, c_max=C, f_max=16, m_max=64)           # n_max leaves room for ONE more 3-vector
+    ctx.cov_set(0, spd(n, rng, 1e-2))
+    vidx, vsize = [21 + 6 * i for i in range(C)], [6] * C
+    H_old = rng.standard_normal((8, 6 * C)); H_new = rng.standard_normal((8, 3)); res = 0.01 * rng.standard_normal(8)
+    added, _, _, idx = ctx.add_variable_delayed(0, vidx, vsize, H_old, H_new, res, 0.1, 1.0, False)
+    assert added and idx == n and ctx.n(0) == n + 3
+    with pytest.raises(capi.IngvioError) as e:                                      # no room for a second one: capacity, state untouched
+        ctx.add_variable_delayed(0, vidx, vsize, H_old, H_new, res, 0.1, 1.0, False)
+    assert e.value.code == capi.E_CAPACITY and ctx.n(0) == n + 3
+    with pytest.raises(capi.IngvioError) as e:                                      # checkSubOrder: variable beyond the state
+        ctx.chi2_gamma_multi(0, [([0, n + 3], [9, 3], rng.standard_normal((2, 12)), np.zeros(2))], 1.0)
+    assert e.value.code == capi.E_NOT_IN_STATE
+    with pytest.raises(capi.IngvioError) as e:
+        ctx.replace_var_linear(0, n, 3, [21, n + 3], [6, 3], np.zeros((3, 9)))
+    assert e.value.code == capi.E_NOT_IN_STATE
+    with pytest.raises(capi.IngvioError) as e:                                      # m > 6144 rows: the panel kernel's limit
+        ctx.qr_compress(np.zeros((6200, 7)), np.zeros(6200))
+    assert e.value.code == capi.E_CAPACITY
+    # asynchronous staging replaces a whole input set: partial batches are refused
+    flt, step, frame, info = synth.build_case(lambda P: capi.DeviceCov(ctx, 1, P), host.imu_transition, seed=7, F=16, C=C, n_gnss=0,
+                                              n_landmarks=0, stereo=True)
+    st = ctx.frame_stage_prepare(1, [step], [frame], step["sigma"], 0, 0.0, 0.0, use_async=True)
+    with pytest.raises(capi.IngvioError) as e:
+        st()
+    assert e.value.code == capi.E_ARG
+    ctx.close()
