@@ -107,6 +107,20 @@ int ingvio_append_independent(ingvio_ctx* ctx, int b0, int nb, int size, const d
 int ingvio_ekf_update(ingvio_ctx* ctx, int b, const int* vidx, const int* vsize, int k,
                       const double* H, int ldh, int m, const double* res,
                       const double* R, int r_kind, double* dx_out);
+/* ekfUpdate for filters [b0, b0+nb) in ONE launch and one synchronisation (e.g. the GNSS update of a whole batch): block i
+ * belongs to filter b0+i.  R per block: one double (INGVIO_R_SCALAR) or m doubles (INGVIO_R_DIAG).  dx_out [nb][ldp]
+ * (ingvio_ldp), status_out [nb] = INGVIO_OK / INGVIO_NEG_DIAG per filter (may be NULL). */
+typedef struct {
+    const int* vidx;          /* var_order as (idx, size)[k]                                        */
+    const int* vsize;
+    int k;
+    const double* H;          /* m x sum(vsize), column-major, leading dimension ldh                   */
+    int ldh, m;
+    const double* res;        /* [m]                                                                */
+    const double* R;          /* noise, see r_kind                                                  */
+} ingvio_update_block;
+int ingvio_ekf_update_batch(ingvio_ctx* ctx, int b0, int nb, const ingvio_update_block* blocks, int r_kind,
+                            double* dx_out, int* status_out);
 /* whitenResidual (Update.cpp:36-79): gamma = res^T (H Pcc H^T + R)^-1 res. */
 int ingvio_chi2_gamma(ingvio_ctx* ctx, int b, const int* vidx, const int* vsize, int k,
                       const double* H, int ldh, int m, const double* res,

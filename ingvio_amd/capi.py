@@ -27,13 +27,18 @@ EXPORTS = [
     "ingvio_frame_stage", "ingvio_frame_stage_async", "ingvio_frame_run", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_select",
     "ingvio_profile_reset",
     "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_debug_read", "ingvio_triangulate",
-    "ingvio_chi2_gamma_multi", "ingvio_add_variable_delayed_invertible", "ingvio_add_variable_delayed", "ingvio_replace_var_linear",
+    "ingvio_chi2_gamma_multi", "ingvio_ekf_update_batch", "ingvio_add_variable_delayed_invertible", "ingvio_add_variable_delayed", "ingvio_replace_var_linear",
 ]
 
 
 class GateBlock(C.Structure):
     _fields_ = [("vidx", C.POINTER(C.c_int)), ("vsize", C.POINTER(C.c_int)), ("k", C.c_int), ("H", C.POINTER(C.c_double)),
                 ("ldh", C.c_int), ("m", C.c_int), ("res", C.POINTER(C.c_double))]
+
+
+class UpdateBlock(C.Structure):
+    _fields_ = [("vidx", C.POINTER(C.c_int)), ("vsize", C.POINTER(C.c_int)), ("k", C.c_int), ("H", C.POINTER(C.c_double)),
+                ("ldh", C.c_int), ("m", C.c_int), ("res", C.POINTER(C.c_double)), ("R", C.POINTER(C.c_double))]
 
 
 class CtxDesc(C.Structure):
@@ -271,6 +276,21 @@ class Context:
         self._chk(self.L.ingvio_chi2_gamma(self.h, b, _i(i32(vidx)), _i(i32(vsize)), len(vidx), _d(H), m, m, _d(f64(res)),
                                            _d(Rb), kind, C.byref(g)))
         return g.value
+
+    def ekf_update_batch(self, b0, blocks, diag=True):
+        """blocks: list of (vidx, vsize, H, res, R) for filters b0, b0+1, ...; R scalar or 1-D per block (all of one kind).
+        Returns (dx[nb, ldp], status[nb])."""
+        nb = len(blocks)
+        arr = (UpdateBlock * nb)(); keep = []
+        for g, (vidx, vsize, H, res, R) in enumerate(blocks):
+            H = np.asfortranarray(np.atleast_2d(H), dtype=np.float64)
+            vi, vs, r, Rv = i32(vidx), i32(vsize), f64(res), f64(np.atleast_1d(R))
+            keep.append((H, vi, vs, r, Rv))
+            arr[g].vidx = _i(vi); arr[g].vsize = _i(vs); arr[g].k = len(vi); arr[g].H = _d(H); arr[g].ldh = H.shape[0]
+            arr[g].m = H.shape[0]; arr[g].res = _d(r); arr[g].R = _d(Rv)
+        dx = np.zeros((nb, self.ldp)); st = np.zeros(nb, dtype=np.int32)
+        self._chk(self.L.ingvio_ekf_update_batch(self.h, b0, nb, arr, 1 if diag else 0, _d(dx), _i(st)))
+        return dx, st
 
     def chi2_gamma_multi(self, b, blocks, noise_var):
         """blocks: list of (vidx, vsize, H, res); returns gamma[len(blocks)] (one launch, one sync)."""

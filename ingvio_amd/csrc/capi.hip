@@ -64,6 +64,7 @@ struct ingvio_ctx {
     int* d_tri_ok;                      // [B][f_max] triangulation flags
     // ingvio_qr_compress, general path: device buffers and the captured launch sequence (~300 kernels) of the last shape
     struct QrCache { int m = 0, n = 0, ldh = 0; double *dA = nullptr, *db = nullptr, *ws = nullptr, *dT = nullptr; hipGraphExec_t exec = nullptr; } qr;
+    double* d_noiseB = nullptr;         // ingvio_ekf_update_batch: [B][mld] scalar / diagonal noise per filter
     char* d_multi = nullptr;            // ingvio_chi2_gamma_multi: packed blocks (grown on demand)
     size_t multi_cap = 0;
     // staged frame state
@@ -513,7 +514,7 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
     void* ptrs[] = { c->Pbase, c->Psnap, c->d_cur, c->d_n, c->d_n_snap, c->d_Phi, c->d_G, c->d_dt, c->d_R, c->d_blk, c->d_gnss,
                      c->d_idx, c->d_clone_idx, c->d_nclones, c->d_nfeat, c->d_anchor, c->d_dof, c->d_clone_R, c->d_clone_p,
                      c->d_pf, c->d_uv, c->d_chi2, c->d_mask, c->d_gamma, c->d_accept, c->d_used, c->d_Rpart, c->d_chunk_used,
-                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk, c->d_tri_ok, c->d_hnew, c->d_multi };
+                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk, c->d_tri_ok, c->d_hnew, c->d_multi, c->d_noiseB };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& sl : c->pin) { if (sl.p) hipHostFree(sl.p); if (sl.ev) hipEventDestroy(sl.ev); }
     if (c->qr.exec) hipGraphExecDestroy(c->qr.exec);
@@ -728,6 +729,85 @@ int ingvio_ekf_update(ingvio_ctx* c, int b, const int* vidx, const int* vsize, i
     rc = last_launch(c);
     if (rc) return rc;
     return (status & 2) ? INGVIO_NEG_DIAG : INGVIO_OK;
+}
+
+// ekfUpdate for filters [b0, b0+nb) in one launch and one synchronisation (the GNSS update of a whole batch, config 3 x 4):
+// block i = filter b0+i with its own var_order / H / res / noise (R scalar or diagonal).  dx_out [nb][ldp], status_out [nb]
+// (INGVIO_OK / INGVIO_NEG_DIAG per filter, may be NULL).
+int ingvio_ekf_update_batch(ingvio_ctx* c, int b0, int nb, const ingvio_update_block* blk, int r_kind, double* dx_out, int* status_out)
+{
+    if (check_range(c, b0, nb) || !blk) return INGVIO_E_ARG;
+    if (r_kind != INGVIO_R_SCALAR && r_kind != INGVIO_R_DIAG) return INGVIO_E_UNSUPPORTED;
+    int m_cap = 0, nc_cap = 0, n_cap = 0;
+    std::vector<int> ncs(nb);
+    for (int i = 0; i < nb; ++i) {
+        const ingvio_update_block& q = blk[i];
+        const int b = b0 + i;
+        if (!q.vidx || !q.vsize || !q.H || !q.res || !q.R || q.k < 1 || q.m < 1 || q.ldh < q.m) return INGVIO_E_ARG;
+        if (q.m > c->mld) return INGVIO_E_CAPACITY;
+        int nc = 0;
+        for (int j = 0; j < q.k; ++j) {
+            if (q.vidx[j] < 0 || q.vidx[j] + q.vsize[j] > c->h_n[b]) return INGVIO_E_NOT_IN_STATE;      // checkSubOrder
+            nc += q.vsize[j];
+        }
+        if (nc > c->nc_cap) return INGVIO_E_CAPACITY;
+        ncs[i] = nc;
+        if (q.m > m_cap) m_cap = q.m;
+        if (nc > nc_cap) nc_cap = nc;
+        if (c->h_n[b] > n_cap) n_cap = c->h_n[b];
+    }
+    if (!c->d_noiseB) {
+        if (dalloc(c, &c->d_noiseB, (size_t)c->d.batch * c->mld)) return INGVIO_E_HIP;
+    }
+    const size_t mld = c->mld, hs = c->hstride, cs = c->cstride;
+    Uploader upl{ c };
+    int rc = upl.begin(pad64(8 * (size_t)nb * hs) + pad64(8 * (size_t)nb * mld) * 2 + pad64(4 * (size_t)nb * cs) + pad64(4 * (size_t)nb) * 3 + 1024);
+    if (rc) return rc;
+    double* hH = upl.take<double>((size_t)nb * hs); double* hr = upl.take<double>((size_t)nb * mld); double* hn = upl.take<double>((size_t)nb * mld);
+    int* hc = upl.take<int>((size_t)nb * cs); int* hm = upl.take<int>(nb); int* hnc = upl.take<int>(nb); int* hz = upl.take<int>(nb);
+    parallel_for(nb, [=, &ncs](int i) {
+        const ingvio_update_block& q = blk[i];
+        const int nc = ncs[i];
+        double* Hd = hH + (size_t)i * hs;
+        for (int cc = 0; cc < nc; ++cc) {
+            memcpy(Hd + (size_t)cc * mld, q.H + (size_t)cc * q.ldh, 8 * (size_t)q.m);
+            memset(Hd + (size_t)cc * mld + q.m, 0, 8 * (mld - q.m));                              // k_ekf_core reads whole 16-row groups
+        }
+        memcpy(hr + (size_t)i * mld, q.res, 8 * (size_t)q.m);
+        memcpy(hn + (size_t)i * mld, q.R, 8 * (size_t)(r_kind == INGVIO_R_SCALAR ? 1 : q.m));
+        int* cm = hc + (size_t)i * cs;
+        int w = 0;
+        for (int j = 0; j < q.k; ++j) for (int t = 0; t < q.vsize[j]; ++t) cm[w++] = q.vidx[j] + t;
+        hm[i] = q.m; hnc[i] = nc; hz[i] = 0;
+    });
+    upl.copy(c->d_H + (size_t)b0 * hs, hH, (size_t)nb * hs);
+    upl.copy(c->d_res + (size_t)b0 * mld, hr, (size_t)nb * mld);
+    upl.copy(c->d_noiseB + (size_t)b0 * mld, hn, (size_t)nb * mld);
+    upl.copy(c->d_colmap + (size_t)b0 * cs, hc, (size_t)nb * cs);
+    upl.copy(c->d_m + b0, hm, nb); upl.copy(c->d_nc + b0, hnc, nb); upl.copy(c->d_status + b0, hz, nb);
+    rc = upl.end();
+    if (rc) return rc;
+    EkfLaunch E;
+    memset(&E, 0, sizeof E);
+    E.cv = view(c); E.b0 = b0; E.nb = nb; E.H = c->d_H + (size_t)b0 * hs; E.res = c->d_res + (size_t)b0 * mld;
+    E.colmap = c->d_colmap + (size_t)b0 * cs; E.m = c->d_m + b0; E.nc = c->d_nc + b0;
+    E.noise = c->d_noiseB + (size_t)b0 * mld; E.r_kind = r_kind; E.mld = c->mld; E.hstride = c->hstride; E.cstride = c->cstride;
+    E.nstride = c->mld; E.Y = c->d_Y + (size_t)b0 * c->ystride; E.ystride = c->ystride; E.dx = c->d_dx;
+    E.status = c->d_status; E.m_cap = m_cap; E.nc_cap = nc_cap;
+    { ProfScope p(c, PF_EKF_CORE); launch_ekf_core(E, c->st); }
+    { ProfScope p(c, PF_DOWNDATE); launch_downdate(E, n_cap, c->st); }
+    std::vector<int> status(nb, 0);
+    if (dx_out) HIPCHK(c, hipMemcpyAsync(dx_out, c->d_dx + (size_t)b0 * c->ldp, 8 * (size_t)nb * c->ldp, hipMemcpyDeviceToHost, c->st));
+    if (down_sync(c, status.data(), c->d_status + b0, sizeof(int) * (size_t)nb)) return INGVIO_E_HIP;
+    rc = last_launch(c);
+    if (rc) return rc;
+    int soft = INGVIO_OK;
+    for (int i = 0; i < nb; ++i) {
+        const int st = (status[i] & 2) ? INGVIO_NEG_DIAG : INGVIO_OK;
+        if (status_out) status_out[i] = st;
+        if (st != INGVIO_OK) soft = st;
+    }
+    return soft;
 }
 
 int ingvio_chi2_gamma(ingvio_ctx* c, int b, const int* vidx, const int* vsize, int k, const double* H, int ldh, int m,

@@ -567,6 +567,40 @@ def test_qr_compress(ctx):
     assert rel_err(Ht.T @ Ht, A1.T @ A1) < 1e-12
 
 
+def test_ekf_update_batch_vs_oracle(orc):
+    """ingvio_ekf_update_batch: one launch for the generic update of several filters (the GNSS update of a batch) with
+    different var_orders, row counts and diagonal noise per filter == the oracle's ekfUpdate filter by filter."""
+    from ingvio_amd import capi
+    nb = 5
+    ctx3 = capi.Context(batch=nb + 1, n_max=128, c_max=11, f_max=8, m_max=64)
+    rng = np.random.default_rng(77)
+    blocks, want = [], []
+    for b in range(nb):
+        n = 21 + 6 + 6 * (b + 1)
+        A = rng.standard_normal((n, n)); P0 = 1e-2 * (A @ A.T / n + 0.1 * np.eye(n))
+        ctx3.cov_set(b + 1, P0)
+        m = 4 + 3 * b
+        vo = [0, 21 + b % 3, 27 + 6 * (b % 2)]; vs = [9, 1, 6]
+        H = rng.standard_normal((m, 16)); r = 0.1 * rng.standard_normal(m); R = rng.uniform(0.5, 2.0, m)
+        blocks.append((vo, vs, H, r, R))
+        oc = orc.Cov(P0); dxo, _ = oc.ekf_update(vo, vs, H, r, R)
+        want.append((oc.P, dxo, n))
+    dx, st = ctx3.ekf_update_batch(1, blocks, diag=True)
+    assert not st.any()
+    for b in range(nb):
+        Pw, dxw, n = want[b]
+        assert rel_err(ctx3.cov_get(b + 1), Pw) < TIGHT and rel_err(dx[b, :n], dxw) < 1e-9
+    # scalar noise, and a variable outside one filter's state
+    blocks_s = [(vo, vs, H, r, 0.7) for (vo, vs, H, r, R) in blocks]
+    dx, st = ctx3.ekf_update_batch(1, blocks_s, diag=False)
+    assert np.isfinite(dx).all()
+    bad = list(blocks); bad[0] = ([0, 500], [9, 1], np.zeros((2, 10)), np.zeros(2), np.ones(2))
+    with pytest.raises(capi.IngvioError) as e:
+        ctx3.ekf_update_batch(1, bad, diag=True)
+    assert e.value.code == capi.E_NOT_IN_STATE
+    ctx3.close()
+
+
 @pytest.mark.parametrize("m,n", [(500, 65), (300, 130), (1200, 216), (40, 100), (97, 97), (2100, 8), (1600, 45), (6144, 25)])
 def test_qr_compress_general_vs_oracle(orc, m, n):
     """Shapes beyond the 96-column TSQR (any n, windows above 16 clones, m < n): blocked Householder QR (kernels_qr.hip)
