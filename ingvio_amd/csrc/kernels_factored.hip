@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
                     d += __shfl_xor(d, 32, WAVE);
                     if (kq == 0 && ti * 16 + l15 < n) dx_all[(size_t)b * ld + ra] = d;
                 }
-#pragma unroll 1
+#pragma unroll
                 for (int jt = 0; jt < JT; ++jt) {
                     double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
                     const int jc = min(jt * 16 + l15, MP - 1);
