@@ -2,20 +2,29 @@
 """bench.py — EKF updates/s on synthetic stereo MSCKF frames (BASELINE.json metric).
 
 One *step* = one pass of the hot path over one batch: every filter of the batch does
-k=10-step covariance propagation (K1) + clone augmentation (K2) + 150-feature MSCKF update
-(Jacobians K3, nullspace K4, chi^2 gate K5, TSQR compression K6/K7, Kalman update K8-K11) +
+k=10-step covariance propagation (K1) + clone augmentation (K2) + F-feature MSCKF update
+(Jacobians K3, nullspace K4, chi^2 gate K5, stacked compression K6/K7, Kalman update K8-K11) +
 marginalisation of the oldest clone (K12) — SURVEY.md §8(d) "one update".  Inputs (IMU transitions,
 clone poses, feature tracks, the prior covariances) are resident in HBM before the timed region;
 each step restores the same prior device-to-device so the work per step is stationary.
 
-N = 1 workload: BASELINE.json configs[1] (150 feats x 11 clones, N = 249), `--batch` independent
-filters per GPU (default 512 = configs[3]'s 4096 frames / 8 GPUs).  N > 1: weak scaling, each rank
-owns its own `--batch` filters, no data-path collective; RCCL only for the timing
-barrier / max and one end-of-run gather of per-rank summaries.
+Workloads (`--config`, BASELINE.json `configs`):
+  2  (default, the one `metric` is quoted on)  150 feats x 11 clones, `--state nominal` N = 249 (6 GNSS scalars + 52 landmark
+     blocks), `literal` N = 87, `gnss` N = 93; `--batch` independent filters per GPU (default 512 = configs[3]'s 4096 / 8 GPUs)
+  3  config 2 + GnssUpdate::updateTrackedSys with 8 satellites (16 candidate rows), per-row chi^2 gates on, after the frame
+  5  stress: 300 feats x 30 clones, N = 207 (`literal`/`gnss`) or 807 (`nominal`: + 200 landmark blocks), default batch 32
+N > 1: weak scaling, each rank owns its own `--batch` filters, no data-path collective; RCCL only for the
+timing barrier / max and one end-of-run gather of per-rank summaries.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+Roofline: `roofline.achieved` of the dominant kernel = EXECUTED FP64 operations per launch (rocprofv3 SQ counters committed
+under profiles/, read from profiles/counters.json — bench.py cannot collect PMC itself) / the kernel's HIP-event time
+measured live inside the timed region; <= peak by construction.  The ALGORITHMIC rate (SURVEY §8(d)'s dense formulation of
+the reference / the same time) is reported next to it as `algorithmic`: the factored kernels execute about a quarter of
+those operations, so that figure can exceed the peak and is not a fraction of anything.
 """
 import argparse
 import json
@@ -28,8 +37,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector == FP64 MFMA peak (datasheet)
+FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector == FP64 MFMA peak (datasheet; issue rates: tests/micro/issue_rates.hip)
 HBM_PEAK_GBS = 8000.0
+COUNTERS_JSON = os.path.join(ROOT, "profiles", "counters.json")
 
 
 class LazyCov:
@@ -61,7 +71,7 @@ class LazyCov:
 
 
 def build_batch(ctx, B, seed0, F, C, n_gnss, n_landmarks):
-    """Creates B config-2 cases; priors are produced by the HIP path itself (batched propagate+clone)."""
+    """Creates B config-2 style cases; priors are produced by the HIP path itself (batched propagate+clone)."""
     from ingvio_amd import host, synth
     pr = synth.PARAMS
     filters, rngs = [], []
@@ -107,12 +117,12 @@ def build_batch(ctx, B, seed0, F, C, n_gnss, n_landmarks):
             dof=np.full(F, C - 1, dtype=np.int32), stereo=1, R_cl2cr=Rlr, t_cl2cr=tlr, noise=pr["visual_noise"],
             chi2_table=table))
         steps.append(step)
-        infos.append(dict(outlier=outlier, n_prior=flt.cov.n))
+        infos.append(dict(outlier=outlier, n_prior=flt.cov.n, rng=rng))
     return filters, steps, frames, infos
 
 
 def algorithmic_flops(F_used, F, C, N, k):
-    """SURVEY.md §8(d) formula block, per update, split by the kernel that carries the term."""
+    """SURVEY.md §8(d) formula block (the reference's dense formulation), per update, split by the kernel that carries the term."""
     n = 6 * C; rho = 4 * C - 3; m = F_used * rho
     k4 = 12.0 * (4 * C) * (n + 1)
     k5 = 2.0 * rho * n * n + 2.0 * rho * rho * n + rho ** 3 / 3.0 + 2.0 * rho * rho
@@ -122,10 +132,9 @@ def algorithmic_flops(F_used, F, C, N, k):
     k1 = k * (2.0 * 15 * 15 * (N - 15) + 4.0 * 15 ** 3)
     k2 = 2.0 * 6 * 21 * N
     per_kernel = {
-        "k_propagate": k1, "k_augment": k2, "k_msckf_gate": F * (k4 + k5), "k_msckf_fold": F_used * k4 + k7,
-        "k_msckf_merge": 0.0, "k_ekf_core": k8_9_11, "k_downdate": k10, "k_marginalize": 0.0, "restore": 0.0,
-        # factored path: same algorithmic work, different kernels
-        # factored path: same algorithmic work, different kernels (K8/K9 -> k_info_update; K10/K11 and the
+        "k_propagate": k1 + k2, "k_msckf_gate": F * (k4 + k5), "k_msckf_fold": F_used * k4 + k7,
+        "k_ekf_core": k8_9_11, "k_downdate": k10,
+        # factored path: same algorithmic work, carried by other kernels (K8/K9 -> k_info_update; K10/K11 and the
         # P H^T / K products -> k_info_apply)
         "k_feat_gate3": F * (k4 + k5), "k_feat_gram2": F_used * k4 + k7, "k_info_update": 2.0 * n ** 3 + n ** 3 / 3.0,
         "k_info_apply": k10 + 4.0 * N * n * n + 2.0 * N * n}
@@ -133,79 +142,126 @@ def algorithmic_flops(F_used, F, C, N, k):
     return per_kernel, total
 
 
-# HBM bytes per launch of the 512-filter config-2 workload, from the committed rocprofv3 PMC passes
-# (profiles/r01_rocprofv3_pmc_hbm_traffic.csv: FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE calibrated x1 on the
-# pure copy k_restore); a static annotation, bench.py cannot collect PMC counters itself
-TRAFFIC_MIB = {"k_feat_gate3": (46.2 + 113.4) * 2 ** 20, "k_feat_gram2": (113.5 + 23.1) * 2 ** 20,
-               "k_info_update": (38.5 + 18.4) * 2 ** 20, "k_info_apply": (244.6 + 239.6) * 2 ** 20,
-               "k_propagate": (47.5 + 58.3) * 2 ** 20}
+def algorithmic_bytes(N, k_imu, F, C):
+    """bytes a kernel must move at least once per update (FP64).  Only kernels whose traffic has such a
+    closed form are listed: the strip kernels and the update's read+write of P."""
+    return {"k_propagate": 2.0 * 2 * (15 + 6) * N * 8 + 8.0 * k_imu * 405,      # 15-column strip + the 6 new clone rows, both ways
+            "k_info_apply": 2.0 * N * N * 8,                                   # read + write P once
+            "k_marginalize": 2.0 * N * N * 8, "restore_full": 2.0 * N * N * 8}
 
 
-def algorithmic_bytes(N):
-    """HBM-bound strip kernels: bytes each must move once (FP64)."""
-    return {"k_propagate": 2 * 2 * 20 * N * 8.0, "k_augment": (12 + 2 * 6) * N * 8.0, "k_marginalize": 2.0 * N * N * 8,
-            "restore": 2.0 * N * N * 8}
+# ---- counters committed under profiles/ --------------------------------------------------------------------------------
+def load_counters(path, key):
+    """profiles/counters.json: {workloads: {key: {source, kernels: {name: {counter: per-launch average}}}}} written by
+    tests/pmc_summary.py from rocprofv3 --pmc passes.  Returns (kernels dict or None, source note)."""
+    try:
+        with open(path) as f:
+            J = json.load(f)
+    except (OSError, ValueError):
+        return None, "no %s" % os.path.relpath(path, ROOT)
+    w = J.get("workloads", {}).get(key)
+    if w is None:
+        return None, "%s holds no workload %r (has: %s)" % (os.path.relpath(path, ROOT), key, ", ".join(sorted(J.get("workloads", {}))))
+    return w.get("kernels", {}), "%s[%s] <- %s" % (os.path.relpath(path, ROOT), key, w.get("source", "?"))
 
 
-def cpu_baseline(ctx, steps, frames, n_prior, target_s=10.0):
-    """Times the oracle (C port of the reference algorithm, OpenMP one-filter-per-thread) on a
-    bounded sample of the same workload, and cross-checks the GPU posterior on that sample.
-    Only the C call is inside the timed loop (structs are prepared once)."""
+def executed_fp64_flops(c):
+    """FP64 operations one launch EXECUTES, from the SQ counters (wave-level instruction counts x 64 lanes; an FMA is two
+    operations; SQ_INSTS_VALU_MFMA_MOPS_F64 counts MFMA operations in units of 512 — rocprofiler-sdk counter_defs.yaml,
+    TOTAL_64_OPS).  Lanes masked off by EXEC are included: this is what the FP64 pipe is occupied with, an upper bound of
+    the useful arithmetic."""
+    need = ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MFMA_MOPS_F64")
+    if c is None or any(k not in c for k in need):
+        return None
+    valu = 64.0 * (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
+                   + 2.0 * c["SQ_INSTS_VALU_FMA_F64"])
+    mfma = 512.0 * c["SQ_INSTS_VALU_MFMA_MOPS_F64"]
+    return dict(total=valu + mfma, valu=valu, mfma=mfma)
+
+
+def hbm_traffic_bytes(c):
+    """HBM bytes per launch from the PMC passes, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE (KiB) reports half of
+    the bytes of wide coalesced reads on gfx950 -> x2; WRITE_SIZE (KiB) as is (both calibrated on the pure-copy restore kernel,
+    profiles/README.md)."""
+    if c is None or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        return None
+    return dict(read=2.0 * 1024.0 * c["FETCH_SIZE"], written=1024.0 * c["WRITE_SIZE"],
+                total=2.0 * 1024.0 * c["FETCH_SIZE"] + 1024.0 * c["WRITE_SIZE"])
+
+
+BIG_NAMES = {"k_feat_gate3": "k_feat_gate3_big", "k_feat_gram2": "k_feat_gram_big", "k_info_update": "k_info_update_big",
+             "k_info_apply": "k_info_apply_big"}
+
+
+def cpu_baseline(ctx, steps, frames, n_prior, ld, quick=False):
+    """Times the oracle (C port of the reference algorithm) on a bounded sample of the same workload and cross-checks the GPU
+    posterior on that sample.  Protocol: the reference is single-threaded (IngvioNode.cpp:36), so the primary
+    figure is ONE thread: 10 warm-up updates, >= 100 timed updates (each on its own frame of the bench batch, cycled), median
+    and p95 per update.  Beside it the all-cores figure (one filter per thread, OpenMP) for the batched configuration.
+    Only the C call is inside a timed interval (structs are prepared once)."""
     from oracle import oracle as orc
     cores = os.cpu_count() or 1
     S = min(len(steps), cores)
-    ld = 256
     ctx.restore(); ctx.sync()
     P0 = np.zeros((S, ld, ld))
     for b in range(S):
         P0[b, :n_prior, :n_prior] = ctx.cov_get(b)
     n0 = np.full(S, n_prior, dtype=np.int32)
+    # ---- one thread: warm-up 10, timed >= 100, median + p95 ---------------------------------------------------------
+    n_warm, n_timed = (2, 10) if quick else (10, 100)
+    nsingle = min(S, 16)
+    singles = [orc.PreparedBatch(steps[i:i + 1], frames[i:i + 1], max_accept=0, compress_rule=1) for i in range(nsingle)]
+    samples = []
+    for it in range(n_warm + n_timed):
+        i = it % nsingle
+        Pw, nw = P0[i:i + 1].copy(), n0[i:i + 1].copy()
+        t0 = time.perf_counter()
+        singles[i].run(Pw, nw, ld, threads=1)
+        dt = time.perf_counter() - t0
+        if it >= n_warm:
+            samples.append(dt)
+        if len(samples) >= 10 and sum(samples) > (12.0 if not quick else 2.0):
+            break                                                 # config 5 (0.5 s per update): bounded sample, reported as such
+    samples = np.array(samples)
+    one = dict(ms_median=float(np.median(samples) * 1e3), ms_p95=float(np.percentile(samples, 95) * 1e3),
+               ms_mean=float(samples.mean() * 1e3), timed=int(len(samples)), warmup=n_warm,
+               updates_per_s=float(1.0 / np.median(samples)))
+    # ---- all cores, one filter per thread.  The container may be CPU-throttled (cgroup quota) well below os.cpu_count():
+    #      more threads than the quota makes the baseline SLOWER, so probe a few counts and keep the best (reported as `cores`)
     prep = orc.PreparedBatch(steps[:S], frames[:S], max_accept=0, compress_rule=1)
-    # The container may be CPU-throttled (cgroup quota) well below os.cpu_count(): more threads than the quota makes the
-    # baseline SLOWER, so probe a few thread counts and keep the best one (the thread count used is reported as `cores`).
-    def rate(th, min_s):
+
+    def rate(th, min_s, max_rounds=500):
         prep.run(P0.copy(), n0.copy(), ld, threads=th)
-        r, e = 0, 0.0
-        last = None
-        while e < min_s and r < 500:
+        times, last, Pw, nw = [], None, None, None
+        while (sum(times) < min_s and len(times) < max_rounds) or len(times) < 2:
             Pw, nw = P0.copy(), n0.copy()
             t0 = time.perf_counter()
             last = prep.run(Pw, nw, ld, threads=th)
-            e += time.perf_counter() - t0
-            r += 1
-        return r * S / e, r, (Pw, nw) + tuple(last)
+            times.append(time.perf_counter() - t0)
+        return S / float(np.median(times)), times, (Pw, nw) + tuple(last)
     probes = {}
     for th in sorted({cores, min(cores, 64), min(cores, 32), min(cores, 16), min(cores, 8)}, reverse=True):
-        probes[th] = rate(th, 1.5)[0]
+        probes[th] = rate(th, 0.8 if not quick else 0.2, 20)[0]
     best = max(probes, key=probes.get)
-    val, rounds, (P1, n1, dx1, acc1) = rate(best, target_s)
-    el = rounds * S / val
-    host_cpus = cores
-    cores = best
-    # 1-thread figure on a few frames (the reference itself is single-threaded, IngvioNode.cpp:36)
-    s1 = min(S, 4)
-    prep1 = orc.PreparedBatch(steps[:s1], frames[:s1], max_accept=0, compress_rule=1)
-    Pa, na = P0[:s1].copy(), n0[:s1].copy()
-    prep1.run(Pa.copy(), na.copy(), ld, threads=1)
-    t1 = time.perf_counter()
-    prep1.run(Pa, na, ld, threads=1)
-    one = (time.perf_counter() - t1) / s1
+    val, times, (P1, n1, dx1, acc1) = rate(best, 6.0 if not quick else 0.5)
     # the reference AS WRITTEN (quirks Q2/Q3: accepted-feature cap 20, RemoveLost keeps all rows after SPQR, so S is
-    # 820 x 820): one thread, two frames
+    # 820 x 820): one thread
     s2 = min(S, 2)
     prep2 = orc.PreparedBatch(steps[:s2], frames[:s2], max_accept=20, compress_rule=0)
-    Pb, nb_ = P0[:s2].copy(), n0[:s2].copy()
-    t2 = time.perf_counter()
-    prep2.run(Pb, nb_, ld, threads=1)
-    one_aw = (time.perf_counter() - t2) / s2
-    return dict(value=rounds * S / el, unit="updates/s", cores=cores, kind="port",
-                as_written_cap20_ms_per_update_1thread=one_aw * 1e3,
-                sample="%d rounds x %d of the bench's own frames (150 feats x 11 clones, N=249, top_n compression), "
-                       "oracle/ingvio_oracle.c, OpenMP one filter per thread on %d threads (best of the probed thread counts "
-                       "%s on a host reporting %d CPUs); single thread (the reference is single-threaded): "
-                       "%.1f ms/update = %.1f updates/s"
-                       % (rounds, S, cores, {k: round(v) for k, v in sorted(probes.items())}, host_cpus, one * 1e3, 1.0 / one),
-                ms_per_update_1thread=one * 1e3, updates_per_s_1thread=1.0 / one), (P1, n1, dx1, acc1, S)
+    aw = []
+    for it in range(1 + (3 if not quick else 1)):
+        Pb, nb_ = P0[:s2].copy(), n0[:s2].copy()
+        t2 = time.perf_counter()
+        prep2.run(Pb, nb_, ld, threads=1)
+        if it:
+            aw.append((time.perf_counter() - t2) / s2)
+    return dict(value=val, unit="updates/s", cores=best, kind="port",
+                sample="oracle/ingvio_oracle.c on the bench's own frames (top_n compression, no accepted-feature cap): `value` = one "
+                       "filter per thread on %d OpenMP threads, median of %d rounds x %d frames (best of the probed thread counts %s "
+                       "on a host reporting %d CPUs); `one_thread` = the reference's execution model: %d warm-up + %d timed "
+                       "single-filter updates" % (best, len(times), S, {k: round(v) for k, v in sorted(probes.items())}, cores,
+                                                  n_warm, len(samples)),
+                one_thread=one, as_written_cap20_ms_per_update_1thread=float(np.median(aw) * 1e3)), (P1, n1, dx1, acc1, S)
 
 
 def main():
@@ -213,52 +269,72 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="independent filters per GPU")
-    ap.add_argument("--feats", type=int, default=150)
-    ap.add_argument("--clones", type=int, default=11)
-    ap.add_argument("--literal", action="store_true", help="N=87 (no GNSS / landmark padding) instead of N=249")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5], help="workload, numbered as in the docstring (= BASELINE.json configs[] position, 1-based)")
+    ap.add_argument("--batch", type=int, default=None, help="independent filters per GPU (default 512; config 5: 32)")
+    ap.add_argument("--feats", type=int, default=None)
+    ap.add_argument("--clones", type=int, default=None)
+    ap.add_argument("--state", default="nominal", choices=["nominal", "literal", "gnss"],
+                    help="nominal: + 6 GNSS scalars + landmark padding (N = 249 / 807); literal: clones only (N = 87 / 201); gnss: + 6 GNSS scalars")
+    ap.add_argument("--literal", action="store_true", help="same as --state literal")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--quick-cpu", action="store_true", help="short CPU baseline (smoke runs)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--method", default="factored", choices=["factored", "dense"])
+    ap.add_argument("--counters", default=COUNTERS_JSON)
     args = ap.parse_args()
+    if args.literal:
+        args.state = "literal"
 
-    from ingvio_amd import capi
+    from ingvio_amd import capi, host, synth
     from ingvio_amd.parallel import Group
     grp = Group()                                  # RCCL ("nccl") when WORLD_SIZE > 1
     rank, world, local_rank = grp.rank, grp.world, grp.local_rank
-    B, F, C = args.batch, args.feats, args.clones
-    n_gnss, n_lm = (0, 0) if args.literal else (6, 52)
+    big = args.config == 5
+    B = args.batch if args.batch else (32 if big else 512)
+    F = args.feats if args.feats else (300 if big else 150)
+    C = args.clones if args.clones else (30 if big else 11)
+    if args.config == 3 and args.state == "literal":
+        args.state = "gnss"                                    # the GNSS update needs the clock / YOF scalars in the state
+    n_gnss = 0 if args.state == "literal" else 6
+    n_lm = 0 if args.state != "nominal" else (200 if big else 52)
     N = 21 + n_gnss + 3 * n_lm + 6 * C
     ctx = capi.Context(batch=B, n_max=((N + 15) // 16) * 16, c_max=C, f_max=F, m_max=64, device=local_rank)
     ctx.set_method(args.method)
+    ld = ctx.ldp
     t_build = time.perf_counter()
     filters, steps, frames, infos = build_batch(ctx, B, rank * B, F, C, n_gnss, n_lm)
     ctx.snapshot()
-    from ingvio_amd import synth
     pr = synth.PARAMS
     ctx.frame_stage(0, steps, frames, filters[0].sigma(), filters[0].enable_gnss, pr["sigma_cb"], pr["sigma_rw"],
                     max_accept=0, compress_rule=1)
+    gnss = None
+    if args.config == 3:
+        gnss = [synth.make_gnss(infos[b]["rng"], filters[b]) for b in range(B)]
+        ctx.gnss_stage(0, [host.gnss_rows(g) for g in gnss], frames[0]["chi2_table"], gate_rows=True, strong_reject=False)
     ctx.sync()
     t_build = time.perf_counter() - t_build
+
+    def one_step():
+        ctx.frame_run(restore_prior=True)
+        if gnss is not None:
+            ctx.gnss_run()
 
     def barrier():
         ctx.sync()
         grp.barrier()
 
     for _ in range(args.warmup):
-        ctx.frame_run(restore_prior=True)
+        one_step()
     # Per-kernel table: a separate UNTIMED pass of 3 steps with a HIP-event pair around every launch (an event pair
     # per launch costs ~6 % of the step, so the timed region below only brackets the dominant kernel).
     prof, dom_name = {}, None
     if not args.no_profile:
         ctx.profile_select(None); ctx.profile_reset(); ctx.profile_enable(True)
         for _ in range(3):
-            ctx.frame_run(restore_prior=True)
+            one_step()
         ctx.sync(); ctx.profile_enable(False)
         prof = ctx.profile_get()
-        pk0, _ = algorithmic_flops(float(F), F, C, N, synth.IMU_PER_FRAME)
-        bk0 = algorithmic_bytes(N)
-        cand = [(ms / calls, name) for name, (ms, calls) in prof.items() if calls and (pk0.get(name, 0.0) > 0 or name in bk0)]
+        cand = [(ms / calls, name) for name, (ms, calls) in prof.items() if calls and name != "restore"]
         dom_name = max(cand)[1] if cand else None
         ctx.profile_select(dom_name)
 
@@ -267,17 +343,22 @@ def main():
     ctx.profile_enable(dom_name is not None)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ctx.frame_run(restore_prior=True)
+        one_step()
     ctx.sync()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
     ctx.profile_enable(False)
     if dom_name is not None:
         prof[dom_name] = ctx.profile_get()[dom_name]      # the dominant kernel: measured live inside the timed region
-    elapsed = grp.max_over_ranks(elapsed)
+    elapsed = grp.max_over_ranks(elapsed_local)
+    per_rank_ms = [t / args.steps * 1e3 for t in grp.gather_scalars(elapsed_local)]
 
     dx, acc, rows = ctx.frame_fetch()
     n_acc = acc[:, :F].sum(axis=1)
     ok = bool(np.isfinite(dx).all() and (rows == 6 * C).all())
+    gn_used = None
+    if gnss is not None:
+        dxg, gn_used, keep, gam, st = ctx.gnss_fetch()
+        ok = ok and bool(np.isfinite(dxg).all() and (st == 0).all())
     # one end-of-run gather of per-rank summaries
     summ = grp.gather_summaries([float(n_acc.sum()), float(np.abs(dx).sum()), float(ok)])
     ok = bool(summ[:, 2].all())
@@ -285,51 +366,63 @@ def main():
     if rank == 0:
         F_used = float(n_acc.mean())
         per_kernel, total_flops = algorithmic_flops(F_used, F, C, N, synth.IMU_PER_FRAME)
-        bytes_k = algorithmic_bytes(N)
+        bytes_k = algorithmic_bytes(N, synth.IMU_PER_FRAME, F, C)
+        wkey = "c%d_B%d_F%d_C%d_N%d" % (args.config, B, F, C, N)
+        counters, csrc = load_counters(args.counters, wkey)
         kernels = {}
-        dom, dom_ms = None, -1.0
         for name, (ms, calls) in prof.items():
             if calls == 0:
                 continue
             avg = ms / calls
             e = dict(avg_ms=avg, calls=calls)
+            cn = BIG_NAMES.get(name, name) if C > 16 else name
+            c = (counters or {}).get(cn)
+            ex = executed_fp64_flops(c)
+            if ex is not None:
+                e["executed_fp64_flop_per_launch"] = ex["total"]
+                e["executed_fp64_mfma_share"] = ex["mfma"] / ex["total"] if ex["total"] else 0.0
+                e["executed_tflops"] = ex["total"] / (avg * 1e-3) / 1e12
+                e["frac_fp64_peak"] = e["executed_tflops"] / FP64_PEAK_TFLOPS
+            tr = hbm_traffic_bytes(c)
+            if tr is not None:
+                e["hbm_bytes_per_launch"] = tr
+                e["hbm_gbs"] = tr["total"] / (avg * 1e-3) / 1e9
+                e["frac_hbm_peak"] = e["hbm_gbs"] / HBM_PEAK_GBS
             if per_kernel.get(name, 0.0) > 0:
-                e["algorithmic_flops_per_launch"] = per_kernel[name] * B
-                e["tflops"] = per_kernel[name] * B / (avg * 1e-3) / 1e12
-                e["frac_fp64_peak"] = e["tflops"] / FP64_PEAK_TFLOPS
+                e["algorithmic_flop_per_launch"] = per_kernel[name] * B
+                e["algorithmic_tflops"] = per_kernel[name] * B / (avg * 1e-3) / 1e12
             if name in bytes_k:
                 e["algorithmic_bytes_per_launch"] = bytes_k[name] * B
-                e["gbs"] = bytes_k[name] * B / (avg * 1e-3) / 1e9
-                e["frac_hbm_peak"] = e["gbs"] / HBM_PEAK_GBS
             kernels[name] = e
-            if avg > dom_ms and (per_kernel.get(name, 0.0) > 0 or name in bytes_k):
-                dom, dom_ms = name, avg
         roofline = None
-        if dom is not None:
-            if per_kernel.get(dom, 0.0) > 0:
-                a = kernels[dom]["tflops"]
-                roofline = dict(kernel=dom, bound="mfma", achieved=a, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
-                                frac=a / FP64_PEAK_TFLOPS, traffic=TRAFFIC_MIB.get(dom), avg_launch_ms=dom_ms,
-                                launches_timed=kernels[dom]["calls"],
-                                note="FP64: vector and MFMA peaks coincide on MI355X (78.6 TFLOP/s); achieved = SURVEY.md "
-                                     "8(d) ALGORITHMIC FLOPs (the reference's dense formulation) x filters per launch / "
-                                     "HIP-event time inside the timed region; the kernel executes far fewer operations "
-                                     "(Woodbury-reduced system), hence frac can exceed 1; traffic = HBM bytes per launch "
-                                     "(rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_rocprofv3_pmc_hbm_traffic.csv)")
-                if dom == "k_feat_gate3" and C == 11:
-                    # what the kernel actually executes (SQ counters of the committed PMC pass, profiles/r01_rocprofv3_pmc_sq.csv:
-                    # ~1.0 k FP64 VALU wave-instructions x 64 lanes x 2 + 32 MFMA x 2048 per feature = 0.19 MFLOP)
-                    ex = 0.19e6 * F * B / (dom_ms * 1e-3) / 1e12
-                    roofline["executed"] = dict(tflops=ex, frac=ex / FP64_PEAK_TFLOPS,
-                                                note="executed (not algorithmic) FP64 operations per launch from the SQ counters; the "
-                                                     "fraction of the FP64 peak the kernel's own instruction stream reaches")
-            elif dom in bytes_k:
-                a = kernels[dom]["gbs"]
-                roofline = dict(kernel=dom, bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
-                                frac=a / HBM_PEAK_GBS, traffic=TRAFFIC_MIB.get(dom), avg_launch_ms=dom_ms)
+        if dom_name is not None and dom_name in kernels:
+            k = kernels[dom_name]
+            if "executed_tflops" in k:
+                mf = k["executed_fp64_mfma_share"]
+                roofline = dict(kernel=dom_name, bound="mfma" if mf > 0.5 else "valu", achieved=k["executed_tflops"], peak=FP64_PEAK_TFLOPS,
+                                unit="TFLOP/s", frac=k["frac_fp64_peak"],
+                                traffic=k.get("hbm_bytes_per_launch", {}).get("total"), avg_launch_ms=k["avg_ms"],
+                                launches_timed=k["calls"], executed_fp64_flop_per_launch=k["executed_fp64_flop_per_launch"],
+                                mfma_share_of_executed=mf,
+                                algorithmic=dict(tflops=k.get("algorithmic_tflops"), flop_per_launch=k.get("algorithmic_flop_per_launch"),
+                                                 note="SURVEY 8(d) dense formulation of the reference / the same time; not a "
+                                                      "fraction of the peak (the kernel executes fewer operations)"),
+                                counters=csrc,
+                                note="achieved = EXECUTED FP64 operations per launch (rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 "
+                                     "lanes, FMA = 2, + SQ_INSTS_VALU_MFMA_MOPS_F64 x 512) / HIP-event time of the launches inside "
+                                     "the timed region; peak: FP64 vector and FP64 MFMA peaks coincide on MI355X (78.6 TFLOP/s), "
+                                     "`bound` names the pipe that carries most of the executed operations; traffic = HBM bytes per "
+                                     "launch (FETCH_SIZE x 2 + WRITE_SIZE)")
+            else:
+                roofline = dict(kernel=dom_name, bound="valu", achieved=None, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=None,
+                                traffic=None, avg_launch_ms=k["avg_ms"], launches_timed=k["calls"],
+                                algorithmic=dict(tflops=k.get("algorithmic_tflops"), flop_per_launch=k.get("algorithmic_flop_per_launch")),
+                                counters=csrc,
+                                note="no committed SQ counters for this workload: the executed-operation count, and with it the "
+                                     "achieved fraction, is unknown (collect with tests/gpu_counters.sh)")
         cpu, parity = None, None
         if world == 1 and not args.no_cpu:
-            cpu, (P1, n1, dx1, acc1, S) = cpu_baseline(ctx, steps, frames, infos[0]["n_prior"])
+            cpu, (P1, n1, dx1, acc1, S) = cpu_baseline(ctx, steps, frames, infos[0]["n_prior"], ld, quick=args.quick_cpu)
             ctx.frame_run(restore_prior=True)
             dxg, accg, rowsg = ctx.frame_fetch(0, S)
             errs = []
@@ -344,7 +437,7 @@ def main():
                           max_rel_dx_err=float(max(np.linalg.norm(dxg[b, :N] - dx1[b, :N]) / max(np.linalg.norm(dx1[b, :N]), 1e-300)
                                                    for b in range(S))))
         aw = None
-        if cpu is not None:
+        if cpu is not None and not big:
             # the reference as written (Q2/Q3): only the first 20 accepted features are used
             ctx.frame_stage(0, steps, frames, filters[0].sigma(), filters[0].enable_gnss, pr["sigma_cb"], pr["sigma_rw"],
                             max_accept=20, compress_rule=0)
@@ -362,7 +455,7 @@ def main():
         # memory, sent over PCIe and the results fetched back.  serial = stage; run; fetch.  pipelined = run(i);
         # stage_async(i+1) on the copy stream into the second input set; fetch(i).
         handover = None
-        if cpu is not None:
+        if cpu is not None and not big and args.config == 2:
             kw = dict(max_accept=0, compress_rule=1)
             sg = (filters[0].sigma(), filters[0].enable_gnss, pr["sigma_cb"], pr["sigma_rw"])
             st_sync = ctx.frame_stage_prepare(0, steps, frames, *sg, **kw)
@@ -387,20 +480,34 @@ def main():
                             note="host buffers -> pinned slab (8 host threads) -> PCIe -> run -> dx/accept back; pipelined = copy "
                                  "stream + second device input set (ingvio_frame_stage_async); auxiliary, `value` is device-resident")
         updates = B * world * args.steps
+        step_desc = "propagate(k=10)+clone+MSCKF update+marginalise" + ("+GNSS update (8 sats, per-row chi2 gates)" if gnss is not None else "")
+        # executed FP64 rate of the whole step, where counters exist for every kernel that ran
+        step_exec = None
+        if counters is not None:
+            tot, missing = 0.0, []
+            for name, e in kernels.items():
+                if "executed_fp64_flop_per_launch" in e:
+                    tot += e["executed_fp64_flop_per_launch"]
+                elif name not in ("restore", "k_marginalize"):
+                    missing.append(name)
+            step_exec = dict(executed_fp64_flop_per_step=tot, tflops=tot / (elapsed / args.steps) / 1e12,
+                             frac_fp64_peak=tot / (elapsed / args.steps) / 1e12 / FP64_PEAK_TFLOPS, kernels_without_counters=missing)
         out = dict(
             metric="ekf_updates_per_sec", value=updates / elapsed, unit="updates/s", n_gpus=world, steps=args.steps,
             warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak",
             vs_baseline=None, dtype="f64", data="synthetic",
-            config=dict(workload="synthetic stereo MSCKF, %d feats x %d clones, state dim N=%d (update at N), "
-                                 "%d independent filters per GPU; step = propagate(k=10)+clone+MSCKF update+marginalise"
-                                 % (F, C, N, B), filters_per_gpu=B, feats=F, clones=C, state_dim=N, imu_steps=synth.IMU_PER_FRAME,
+            config=dict(workload="BASELINE configs[%d]: synthetic stereo MSCKF, %d feats x %d clones, state dim N=%d (update at N), "
+                                 "%d independent filters per GPU; step = %s" % (args.config - 1, F, C, N, B, step_desc),
+                        baseline_config=args.config, filters_per_gpu=B, feats=F, clones=C, state_dim=N, imu_steps=synth.IMU_PER_FRAME,
+                        gnss_rows_used_per_filter=None if gn_used is None else float(np.mean(gn_used)),
                         parallelism="independent filters, %d rank(s), no data-path collective" % world),
-            ms_per_update=elapsed / args.steps * 1e3 / B, accepted_per_filter=F_used, results_finite=ok,
-            algorithmic_flops_per_update=total_flops,
-            whole_step_fp64_frac=total_flops * B / (elapsed / args.steps) / 1e12 / FP64_PEAK_TFLOPS,
-            method=args.method, roofline=roofline, cpu_baseline=cpu, parity_vs_oracle=parity, as_written_cap20=aw, host_handover=handover, kernels=kernels,
+            ms_per_update=elapsed / args.steps * 1e3 / B, per_rank_ms_per_step=per_rank_ms, accepted_per_filter=F_used, results_finite=ok,
+            algorithmic_flops_per_update=total_flops, whole_step_executed=step_exec,
+            method=args.method, roofline=roofline, cpu_baseline=cpu, parity_vs_oracle=parity, as_written_cap20=aw, host_handover=handover,
+            kernels=kernels,
             kernels_note="per-kernel avg_ms: separate untimed pass of 3 steps with an event pair around every launch; the "
-                         "roofline kernel's avg_ms is from the timed region", setup_s=t_build)
+                         "roofline kernel's avg_ms is from the timed region; executed_* and hbm_* come from the committed PMC passes "
+                         "(%s)" % csrc, setup_s=t_build)
         print(json.dumps(out))
     grp.close()
     ctx.close()

@@ -37,6 +37,7 @@ extern "C" {
 #define INGVIO_OK 0
 #define INGVIO_NO_ROWS 1             /* soft: no measurement rows survived gating              */
 #define INGVIO_NEG_DIAG 2            /* soft: negative diagonal after update (StateManager.cpp:413-421, assert only) */
+#define INGVIO_REJECTED 3            /* soft (per-filter status): the block chi^2 gate refused the update, state untouched (GnssUpdate.cpp:286) */
 #define INGVIO_E_ARG (-1)            /* bad argument / out of range                            */
 #define INGVIO_E_CAPACITY (-2)       /* n_max / c_max / f_max / m_max exceeded                 */
 #define INGVIO_E_HIP (-3)            /* HIP runtime error, see ingvio_last_error               */
@@ -121,6 +122,34 @@ typedef struct {
 } ingvio_update_block;
 int ingvio_ekf_update_batch(ingvio_ctx* ctx, int b0, int nb, const ingvio_update_block* blocks, int r_kind,
                             double* dx_out, int* status_out);
+/* ---- GnssUpdate::updateTrackedSys, covariance part, for filters [b0, b0+nb) (GnssUpdate.cpp:148-290) --------------------
+ * Block i carries ALL candidate rows of filter b0+i as the host assembled them (pseudo-range rows, then Doppler rows; R = the m
+ * row variances) over var_order = [SE23, YOF, clock biases..., FS] (<= 32 columns, <= 256 rows; m = 0: no measurement).  On the
+ * device, in one launch sequence and without host round trips:
+ *   gate_rows     (_is_gnss_chi2_test, :190,:259)  every row is tested alone on the PRIOR: r^2 / (h Pvv h^T + R_i) < chi2_table[1];
+ *                 a row only touches the columns of its own sub_order, so the stacked row gives the reference's 11-column product;
+ *                 rejected rows are removed, the rest move up (order kept).  A clock column whose rows were all rejected stays
+ *                 in var_order as a zero column: the same posterior as the reference's shorter var_order.
+ *   strong_reject (_is_gnss_strong_reject, :286)   if <= 14 rows survive, the block is gated as a whole against chi2_table[rows];
+ *                 on failure the state is untouched and the filter's status is INGVIO_REJECTED.
+ *   ekfUpdate     (:290) with the diagonal R; dx_out [nb][ldp] = K res (zero when nothing was applied).
+ * rows_out [nb]: rows handed to ekfUpdate; keep_out [nb][ingvio_mld()]: 1/0 per candidate row; status_out [nb].
+ * stage / run / fetch are the same operation split for device-resident throughput runs (run only enqueues kernels and may be
+ * repeated: the staged rows are read-only, each run compacts them into working buffers). */
+typedef struct {
+    int gate_rows;
+    int strong_reject;
+    const double* chi2_table;      /* UpdateBase::_chi_squared_table, chi2_table[dof] */
+    int chi2_len;
+} ingvio_gnss_opts;
+int ingvio_gnss_update_batch(ingvio_ctx* ctx, int b0, int nb, const ingvio_update_block* blocks, const ingvio_gnss_opts* opts,
+                             double* dx_out, int* rows_out, int* keep_out, int* status_out);
+int ingvio_gnss_stage(ingvio_ctx* ctx, int b0, int nb, const ingvio_update_block* blocks, const ingvio_gnss_opts* opts);
+int ingvio_gnss_run(ingvio_ctx* ctx, int b0, int nb);
+int ingvio_gnss_fetch(ingvio_ctx* ctx, int b0, int nb, double* dx_out, int* rows_out, int* keep_out, double* gamma_out,
+                      int* status_out);
+int ingvio_mld(ingvio_ctx* ctx);                      /* row stride of keep_out / gamma_out */
+
 /* whitenResidual (Update.cpp:36-79): gamma = res^T (H Pcc H^T + R)^-1 res. */
 int ingvio_chi2_gamma(ingvio_ctx* ctx, int b, const int* vidx, const int* vsize, int k,
                       const double* H, int ldh, int m, const double* res,
@@ -264,6 +293,11 @@ int ingvio_frame_stage_async(ingvio_ctx* ctx, int b0, int nb, const ingvio_frame
                              const double sigma[4], int enable_gnss, double sigma_cb, double sigma_rw);
 int ingvio_frame_run(ingvio_ctx* ctx, int restore_prior);
 int ingvio_frame_fetch(ingvio_ctx* ctx, int b0, int nb, double* dx_out, int* accepted, int* rows_out);
+
+/* parity hook (tests): the stacked measurement information of filter b's LAST MSCKF update, A_out [ncol][ncol+1] row-major =
+ * [sum_j H_j^T H_j | sum_j H_j^T r_j] over the used features in window-slot column order, ncol = 6 * n_clones (caller provides
+ * (6 c_max) * (6 c_max + 1) doubles).  Factored method: the gram kernel's partial sums; dense method: R^T R from the TSQR factor. */
+int ingvio_debug_msckf_info(ingvio_ctx* ctx, int b, double* A_out, int* ncol_out);
 
 /* debug: shader-clock stamps written by block (0,0) of the instrumented kernels (see dev_common.h) */
 int ingvio_debug_read(ingvio_ctx* ctx, long long* out, int n);

@@ -15,7 +15,7 @@ c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int)
 c_up = C.POINTER(C.c_ulonglong)
 
-OK, NO_ROWS, NEG_DIAG = 0, 1, 2
+OK, NO_ROWS, NEG_DIAG, REJECTED = 0, 1, 2, 3
 E_ARG, E_CAPACITY, E_HIP, E_NOT_IN_STATE, E_UNSUPPORTED = -1, -2, -3, -4, -5
 R_SCALAR, R_DIAG, R_FULL = 0, 1, 2
 
@@ -27,6 +27,7 @@ EXPORTS = [
     "ingvio_frame_stage", "ingvio_frame_stage_async", "ingvio_frame_run", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_select",
     "ingvio_profile_reset",
     "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_debug_read", "ingvio_triangulate",
+    "ingvio_gnss_update_batch", "ingvio_gnss_stage", "ingvio_gnss_run", "ingvio_gnss_fetch", "ingvio_mld", "ingvio_debug_msckf_info",
     "ingvio_chi2_gamma_multi", "ingvio_ekf_update_batch", "ingvio_add_variable_delayed_invertible", "ingvio_add_variable_delayed", "ingvio_replace_var_linear",
 ]
 
@@ -39,6 +40,10 @@ class GateBlock(C.Structure):
 class UpdateBlock(C.Structure):
     _fields_ = [("vidx", C.POINTER(C.c_int)), ("vsize", C.POINTER(C.c_int)), ("k", C.c_int), ("H", C.POINTER(C.c_double)),
                 ("ldh", C.c_int), ("m", C.c_int), ("res", C.POINTER(C.c_double)), ("R", C.POINTER(C.c_double))]
+
+
+class GnssOpts(C.Structure):
+    _fields_ = [("gate_rows", C.c_int), ("strong_reject", C.c_int), ("chi2_table", C.POINTER(C.c_double)), ("chi2_len", C.c_int)]
 
 
 class CtxDesc(C.Structure):
@@ -291,6 +296,58 @@ class Context:
         dx = np.zeros((nb, self.ldp)); st = np.zeros(nb, dtype=np.int32)
         self._chk(self.L.ingvio_ekf_update_batch(self.h, b0, nb, arr, 1 if diag else 0, _d(dx), _i(st)))
         return dx, st
+
+    # ---- GnssUpdate::updateTrackedSys for a batch: per-row gates + compaction + block gate + ekfUpdate on the device ----
+    @staticmethod
+    def _update_blocks(blocks):
+        nb = len(blocks)
+        arr = (UpdateBlock * nb)(); keep = []
+        for g, blk in enumerate(blocks):
+            if blk is None:                               # no measurement for this filter
+                arr[g].m = 0; arr[g].k = 0
+                continue
+            vidx, vsize, H, res, R = blk
+            H = np.asfortranarray(np.atleast_2d(H), dtype=np.float64)
+            vi, vs, r, Rv = i32(vidx), i32(vsize), f64(res), f64(np.atleast_1d(R))
+            keep.append((H, vi, vs, r, Rv))
+            arr[g].vidx = _i(vi); arr[g].vsize = _i(vs); arr[g].k = len(vi); arr[g].H = _d(H); arr[g].ldh = H.shape[0]
+            arr[g].m = H.shape[0]; arr[g].res = _d(r); arr[g].R = _d(Rv)
+        return arr, keep
+
+    def gnss_stage(self, b0, blocks, chi2_table, gate_rows=True, strong_reject=False):
+        """blocks: per filter (vidx, vsize, H [m, nc] candidate rows, res [m], Rdiag [m]) or None."""
+        arr, keep = self._update_blocks(blocks)
+        tab = f64(chi2_table)
+        o = GnssOpts(); o.gate_rows = int(gate_rows); o.strong_reject = int(strong_reject); o.chi2_table = _d(tab); o.chi2_len = len(tab)
+        self._chk(self.L.ingvio_gnss_stage(self.h, b0, len(blocks), arr, C.byref(o)))
+        self._gnss_range = (b0, len(blocks))
+
+    def gnss_run(self, b0=None, nb=None):
+        b0, nb = (self._gnss_range if b0 is None else (b0, nb))
+        self._chk(self.L.ingvio_gnss_run(self.h, b0, nb))
+
+    def gnss_fetch(self, b0=None, nb=None):
+        """-> (dx [nb, ldp], rows [nb], keep [nb, mld], gamma [nb, mld], status [nb])"""
+        b0, nb = (self._gnss_range if b0 is None else (b0, nb))
+        mld = self.L.ingvio_mld(self.h)
+        dx = np.zeros((nb, self.ldp)); rows = np.zeros(nb, dtype=np.int32); keep = np.zeros((nb, mld), dtype=np.int32)
+        gam = np.zeros((nb, mld)); st = np.zeros(nb, dtype=np.int32)
+        self._chk(self.L.ingvio_gnss_fetch(self.h, b0, nb, _d(dx), _i(rows), _i(keep), _d(gam), _i(st)))
+        return dx, rows, keep, gam, st
+
+    def gnss_update_batch(self, b0, blocks, chi2_table, gate_rows=True, strong_reject=False):
+        self.gnss_stage(b0, blocks, chi2_table, gate_rows, strong_reject)
+        self.gnss_run()
+        return self.gnss_fetch()
+
+    def debug_msckf_info(self, b):
+        """[A | b] of filter b's last MSCKF update: (A [ncol, ncol], b [ncol])."""
+        cap = 6 * self.c_max
+        out = np.zeros(cap * (cap + 1)); nc = C.c_int(0)
+        self._chk(self.L.ingvio_debug_msckf_info(self.h, b, _d(out), C.byref(nc)))
+        n = nc.value
+        M = out[:n * (n + 1)].reshape(n, n + 1)
+        return M[:, :n].copy(), M[:, n].copy()
 
     def chi2_gamma_multi(self, b, blocks, noise_var):
         """blocks: list of (vidx, vsize, H, res); returns gamma[len(blocks)] (one launch, one sync)."""

@@ -24,10 +24,10 @@
 namespace {
 
 enum ProfId { PF_RESTORE, PF_PROPAGATE, PF_AUGMENT, PF_GATE, PF_FOLD, PF_MERGE, PF_EKF_CORE, PF_DOWNDATE, PF_MARG,
-              PF_GATE2, PF_GRAM, PF_INFO, PF_APPLY, PF_COUNT };
+              PF_GATE2, PF_GRAM, PF_INFO, PF_APPLY, PF_ROWGATE, PF_COUNT };
 const char* kProfNames[PF_COUNT] = { "restore", "k_propagate", "k_augment", "k_msckf_gate", "k_msckf_fold",
                                      "k_msckf_merge", "k_ekf_core", "k_downdate", "k_marginalize",
-                                     "k_feat_gate3", "k_feat_gram2", "k_info_update", "k_info_apply" };
+                                     "k_feat_gate3", "k_feat_gram2", "k_info_update", "k_info_apply", "k_rows_gate" };
 struct ProfRec { int id; hipEvent_t a, b; };
 
 }  // namespace
@@ -65,6 +65,16 @@ struct ingvio_ctx {
     // ingvio_qr_compress, general path: device buffers and the captured launch sequence (~300 kernels) of the last shape
     struct QrCache { int m = 0, n = 0, ldh = 0; double *dA = nullptr, *db = nullptr, *ws = nullptr, *dT = nullptr; hipGraphExec_t exec = nullptr; } qr;
     double* d_noiseB = nullptr;         // ingvio_ekf_update_batch: [B][mld] scalar / diagonal noise per filter
+    // ingvio_gnss_stage / _run / _fetch: the staged candidate rows of the batch (pristine: every run gates and compacts them
+    // into the generic update's working buffers d_H / d_res / d_noiseB)
+    struct GnssStage {
+        double *H = nullptr, *res = nullptr, *noise = nullptr, *gamma = nullptr, *chi2 = nullptr;
+        int *m = nullptr, *nc = nullptr, *colmap = nullptr, *keep = nullptr;
+        int ncw = 0, m_cap = 0, n_vars_hi = 0, chi2_len = 0, gate_rows = 0, strong = 0;
+        double thr1 = 0.0;
+        std::vector<int> hi;            // per filter: highest state index named by the staged var_order (+1)
+        bool staged = false;
+    } gn;
     char* d_multi = nullptr;            // ingvio_chi2_gamma_multi: packed blocks (grown on demand)
     size_t multi_cap = 0;
     // staged frame state
@@ -72,6 +82,7 @@ struct ingvio_ctx {
     double st_sigma[4], st_scb, st_srw;
     MsckfOpts st_op;
     std::vector<int> st_marg;      // per filter marg idx
+    std::vector<int> st_cidx_hi;   // per filter: highest staged clone idx (checked against the live state by frame_run)
     bool staged;
     // second set of device input buffers + copy stream (ingvio_frame_stage_async): the inputs of frame i+1 travel over
     // PCIe while frame i computes; the sets swap roles at every asynchronous stage
@@ -291,19 +302,39 @@ size_t frames_bytes(const ingvio_ctx* c, int nb)
 }
 
 // packs frames [b0, b0+nb) into the slab of `up` and enqueues the copies into the SoA device staging; max F in *fmax_used
-int pack_frames(ingvio_ctx* c, Uploader& up, int b0, int nb, const ingvio_msckf_frame* fr, int* fmax_used)
+// Everything that can be wrong with the caller's frames, checked BEFORE any context state is touched.  `grow` = rows/columns
+// the state gains between now and the update (6: the clone ingvio_frame_run appends; 0: ingvio_msckf_update).
+int validate_frames(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* fr, int grow, int* fmax_used)
 {
     const int cm = c->d.c_max, fm = c->d.f_max;
     int fmx = 0;
     for (int i = 0; i < nb; ++i) {
         const ingvio_msckf_frame& f = fr[i];
         if (f.n_clones < 0 || f.n_clones > cm || f.n_feat < 0 || f.n_feat > fm) return INGVIO_E_CAPACITY;
+        if (f.n_clones > 0 && (!f.clone_idx || !f.clone_R || !f.clone_p)) return INGVIO_E_ARG;
+        if (f.n_feat > 0 && (!f.obs_mask || !f.uv)) return INGVIO_E_ARG;
         if (f.n_feat > fmx) fmx = f.n_feat;
-        for (int s = 0; s < f.n_clones; ++s)
-            if (f.clone_idx[s] < 0 || f.clone_idx[s] + 6 > c->d.n_max) return INGVIO_E_ARG;
+        // a clone must lie inside the filter's LIVE state at update time (not merely inside the buffer): the gate and gram
+        // kernels would otherwise read stale covariance (checkSubOrder, StateManager.cpp:340-357)
+        const int n_live = grow >= 0 ? c->h_n[b0 + i] + grow : c->d.n_max;
+        const int n_lim = n_live < c->d.n_max ? n_live : c->d.n_max;
+        for (int s = 0; s < f.n_clones; ++s) {
+            if (f.clone_idx[s] < 0) return INGVIO_E_ARG;
+            if (f.clone_idx[s] + 6 > n_lim) return f.clone_idx[s] + 6 > c->d.n_max ? INGVIO_E_ARG : INGVIO_E_NOT_IN_STATE;
+        }
         if (f.anchor)
             for (int j = 0; j < f.n_feat; ++j) if (f.anchor[j] < 0 || f.anchor[j] >= f.n_clones) return INGVIO_E_ARG;
     }
+    if (fmax_used) *fmax_used = fmx;
+    return 0;
+}
+
+// packs already VALIDATED frames: cannot fail
+int pack_frames(ingvio_ctx* c, Uploader& up, int b0, int nb, const ingvio_msckf_frame* fr, int* fmax_used)
+{
+    const int cm = c->d.c_max, fm = c->d.f_max;
+    int fmx = 0;
+    for (int i = 0; i < nb; ++i) if (fr[i].n_feat > fmx) fmx = fr[i].n_feat;
     int* cidx = up.take<int>((size_t)nb * cm); int* ncl = up.take<int>(nb); int* nft = up.take<int>(nb);
     int* anc = up.take<int>((size_t)nb * fm); int* dof = up.take<int>((size_t)nb * fm);
     double* cR = up.take<double>((size_t)nb * cm * 9); double* cp = up.take<double>((size_t)nb * cm * 3);
@@ -342,14 +373,15 @@ int pack_frames(ingvio_ctx* c, Uploader& up, int b0, int nb, const ingvio_msckf_
 }
 
 // uploads frames [b0, b0+nb) into the SoA staging; returns max F in *fmax_used
-int stage_frames(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* fr, int* fmax_used)
+int stage_frames(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* fr, int* fmax_used, int grow = 0)
 {
+    int rc = validate_frames(c, b0, nb, fr, grow, nullptr);
+    if (rc) return rc;
     if (wait_inputs(c)) return INGVIO_E_HIP;
     Uploader up{ c };
-    int rc = up.begin(frames_bytes(c, nb));
+    rc = up.begin(frames_bytes(c, nb));
     if (rc) return rc;
-    rc = pack_frames(c, up, b0, nb, fr, fmax_used);
-    if (rc) return rc;
+    pack_frames(c, up, b0, nb, fr, fmax_used);
     return up.end();
 }
 
@@ -414,7 +446,7 @@ int run_msckf(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int stereo, in
     E.cv = view(c); E.b0 = b0; E.nb = nb; E.H = L.Hout; E.res = L.res_out; E.colmap = L.colmap; E.m = L.m_out; E.nc = L.nc_out;
     E.noise = c->d_noise + b0; E.r_kind = 0; E.mld = c->mld; E.hstride = c->hstride; E.cstride = c->cstride; E.nstride = 1;
     E.Y = c->d_Y + (size_t)b0 * c->ystride; E.ystride = c->ystride; E.dx = c->d_dx; E.status = c->d_status;
-    E.m_cap = 6 * c->d.c_max; E.nc_cap = c->nc_cap;
+    E.m_cap = 6 * c->d.c_max; E.nc_cap = 6 * c->d.c_max;
     { ProfScope p(c, PF_EKF_CORE); launch_ekf_core(E, c->st); }
     { ProfScope p(c, PF_DOWNDATE); launch_downdate(E, c->d.n_max, c->st); }
     return last_launch(c);
@@ -457,7 +489,9 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     const int cpad = cls0 > desc->c_max ? cls0 : desc->c_max;
     const int mcap = c->d.m_max > 6 * cpad ? c->d.m_max : 6 * cpad;
     c->mld = (mcap + 15) & ~15;
-    c->nc_cap = mcap;
+    // column capacity of a generic update (var_order may name any part of the state: 15 + 6 C + 3 L columns for the
+    // landmark stack, LandmarkUpdate.cpp:32-149) is bounded by the state dimension, NOT by the row capacity m_max
+    c->nc_cap = c->ldp > mcap ? c->ldp : mcap;
     c->G = 512 / B; if (c->G > 16) c->G = 16; if (c->G < 1) c->G = 1;      // ~2 resident gram workgroups per CU
     if (const char* e = getenv("INGVIO_GRAM_CHUNKS")) { const int g = atoi(e); if (g >= 1 && g <= 16) c->G = g; }
     c->cls = msckf_cmax_class(desc->c_max);
@@ -472,7 +506,7 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
         c->method = (e && (!strcmp(e, "dense") || !strcmp(e, "0"))) ? 0 : 1;
     }
     memset(c->prof_ms, 0, sizeof c->prof_ms); memset(c->prof_calls, 0, sizeof c->prof_calls);
-    c->h_n.assign(B, 0); c->h_cur.assign(B, 0); c->h_n_snap.assign(B, 0); c->st_marg.assign(B, -1);
+    c->h_n.assign(B, 0); c->h_cur.assign(B, 0); c->h_n_snap.assign(B, 0); c->st_marg.assign(B, -1); c->st_cidx_hi.assign(B, -1);
     const size_t pp = (size_t)c->ldp * c->ldp;
     const int cm = desc->c_max, fm = desc->f_max;
     int rc = 0;
@@ -514,7 +548,8 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
     void* ptrs[] = { c->Pbase, c->Psnap, c->d_cur, c->d_n, c->d_n_snap, c->d_Phi, c->d_G, c->d_dt, c->d_R, c->d_blk, c->d_gnss,
                      c->d_idx, c->d_clone_idx, c->d_nclones, c->d_nfeat, c->d_anchor, c->d_dof, c->d_clone_R, c->d_clone_p,
                      c->d_pf, c->d_uv, c->d_chi2, c->d_mask, c->d_gamma, c->d_accept, c->d_used, c->d_Rpart, c->d_chunk_used,
-                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk, c->d_tri_ok, c->d_hnew, c->d_multi, c->d_noiseB };
+                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk, c->d_tri_ok, c->d_hnew, c->d_multi, c->d_noiseB,
+                     c->gn.H, c->gn.res, c->gn.noise, c->gn.gamma, c->gn.chi2, c->gn.m, c->gn.nc, c->gn.colmap, c->gn.keep };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& sl : c->pin) { if (sl.p) hipHostFree(sl.p); if (sl.ev) hipEventDestroy(sl.ev); }
     if (c->qr.exec) hipGraphExecDestroy(c->qr.exec);
@@ -678,12 +713,18 @@ int ingvio_append_independent(ingvio_ctx* c, int b0, int nb, int size, const dou
     return last_launch(c);
 }
 
+// k_ekf_core keeps S (+ one border row/column) and the column map in LDS (launch_ekf_core): 160 KB per workgroup on gfx950
+static bool ekf_core_fits(int m, int nc)
+{
+    return sizeof(double) * (size_t)(m + 1) * (m + 1) + sizeof(int) * (size_t)nc + 16 <= 160 * 1024;
+}
+
 static int stage_generic(ingvio_ctx* c, int b, const int* vidx, const int* vsize, int k, const double* H, int ldh, int m,
                          const double* res, const double* R, int r_kind, int* nc_out)
 {
     if (check_range(c, b, 1) || !vidx || !vsize || !H || !res || !R || k < 1 || m < 1 || ldh < m) return INGVIO_E_ARG;
     if (r_kind < 0 || r_kind > 2) return INGVIO_E_ARG;
-    if (m > c->d.m_max && m > 6 * c->d.c_max) return INGVIO_E_CAPACITY;
+    if ((m > c->d.m_max && m > 6 * c->d.c_max) || m > c->mld) return INGVIO_E_CAPACITY;
     int nc = 0;
     std::vector<int> cm;
     for (int i = 0; i < k; ++i) {
@@ -712,6 +753,7 @@ int ingvio_ekf_update(ingvio_ctx* c, int b, const int* vidx, const int* vsize, i
     int nc = 0;
     int rc = stage_generic(c, b, vidx, vsize, k, H, ldh, m, res, R, r_kind, &nc);
     if (rc) return rc;
+    if (!ekf_core_fits(m, nc)) return INGVIO_E_CAPACITY;          // before anything touches the covariance
     int zero = 0;
     if (up(c, c->d_status + b, &zero, sizeof(int))) return INGVIO_E_HIP;
     EkfLaunch E;
@@ -750,7 +792,7 @@ int ingvio_ekf_update_batch(ingvio_ctx* c, int b0, int nb, const ingvio_update_b
             if (q.vidx[j] < 0 || q.vidx[j] + q.vsize[j] > c->h_n[b]) return INGVIO_E_NOT_IN_STATE;      // checkSubOrder
             nc += q.vsize[j];
         }
-        if (nc > c->nc_cap) return INGVIO_E_CAPACITY;
+        if (nc > c->nc_cap || !ekf_core_fits(q.m, nc)) return INGVIO_E_CAPACITY;
         ncs[i] = nc;
         if (q.m > m_cap) m_cap = q.m;
         if (nc > nc_cap) nc_cap = nc;
@@ -759,7 +801,9 @@ int ingvio_ekf_update_batch(ingvio_ctx* c, int b0, int nb, const ingvio_update_b
     if (!c->d_noiseB) {
         if (dalloc(c, &c->d_noiseB, (size_t)c->d.batch * c->mld)) return INGVIO_E_HIP;
     }
-    const size_t mld = c->mld, hs = c->hstride, cs = c->cstride;
+    // compact strides for this call: only the widest var_order of the batch travels over PCIe (the d_H / d_colmap slots are
+    // sized for nc_cap = ldp columns per filter, so the compact layout always fits)
+    const size_t mld = c->mld, hs = (size_t)c->mld * nc_cap, cs = nc_cap;
     Uploader upl{ c };
     int rc = upl.begin(pad64(8 * (size_t)nb * hs) + pad64(8 * (size_t)nb * mld) * 2 + pad64(4 * (size_t)nb * cs) + pad64(4 * (size_t)nb) * 3 + 1024);
     if (rc) return rc;
@@ -791,7 +835,7 @@ int ingvio_ekf_update_batch(ingvio_ctx* c, int b0, int nb, const ingvio_update_b
     memset(&E, 0, sizeof E);
     E.cv = view(c); E.b0 = b0; E.nb = nb; E.H = c->d_H + (size_t)b0 * hs; E.res = c->d_res + (size_t)b0 * mld;
     E.colmap = c->d_colmap + (size_t)b0 * cs; E.m = c->d_m + b0; E.nc = c->d_nc + b0;
-    E.noise = c->d_noiseB + (size_t)b0 * mld; E.r_kind = r_kind; E.mld = c->mld; E.hstride = c->hstride; E.cstride = c->cstride;
+    E.noise = c->d_noiseB + (size_t)b0 * mld; E.r_kind = r_kind; E.mld = c->mld; E.hstride = (int)hs; E.cstride = (int)cs;
     E.nstride = c->mld; E.Y = c->d_Y + (size_t)b0 * c->ystride; E.ystride = c->ystride; E.dx = c->d_dx;
     E.status = c->d_status; E.m_cap = m_cap; E.nc_cap = nc_cap;
     { ProfScope p(c, PF_EKF_CORE); launch_ekf_core(E, c->st); }
@@ -809,6 +853,148 @@ int ingvio_ekf_update_batch(ingvio_ctx* c, int b0, int nb, const ingvio_update_b
     }
     return soft;
 }
+
+// ---- GnssUpdate::updateTrackedSys for a batch (GnssUpdate.cpp:148-290): per-row gates, compaction, block gate, ekfUpdate ----
+#define GNSS_NCW 32        // widest var_order of a staged GNSS update (the reference's is 9 + 1 + 4 + 1 = 15 columns)
+
+int ingvio_gnss_stage(ingvio_ctx* c, int b0, int nb, const ingvio_update_block* blk, const ingvio_gnss_opts* o)
+{
+    if (check_range(c, b0, nb) || !blk || !o) return INGVIO_E_ARG;
+    if ((o->gate_rows || o->strong_reject) && (!o->chi2_table || o->chi2_len < 2 || o->chi2_len > CHI2_CAP)) return INGVIO_E_ARG;
+    auto& g = c->gn;
+    int m_cap = 0;
+    std::vector<int> ncs(nb), his(nb);
+    for (int i = 0; i < nb; ++i) {
+        const ingvio_update_block& q = blk[i];
+        if (q.m < 0 || q.k < 0) return INGVIO_E_ARG;
+        if (q.m == 0) { ncs[i] = 0; his[i] = 0; continue; }                     // no measurement for this filter
+        if (!q.vidx || !q.vsize || !q.H || !q.res || !q.R || q.k < 1 || q.ldh < q.m) return INGVIO_E_ARG;
+        if (q.m > c->mld || q.m > 256) return INGVIO_E_CAPACITY;
+        int nc = 0, hi = 0;
+        for (int j = 0; j < q.k; ++j) {
+            if (q.vidx[j] < 0 || q.vsize[j] < 1 || q.vidx[j] + q.vsize[j] > c->d.n_max) return INGVIO_E_NOT_IN_STATE;
+            if (q.vidx[j] + q.vsize[j] > hi) hi = q.vidx[j] + q.vsize[j];
+            nc += q.vsize[j];
+        }
+        if (nc > GNSS_NCW || !ekf_core_fits(q.m, nc)) return INGVIO_E_CAPACITY;
+        ncs[i] = nc; his[i] = hi;
+        if (q.m > m_cap) m_cap = q.m;
+    }
+    const size_t B = c->d.batch, mld = c->mld, hs = mld * GNSS_NCW;
+    if (!g.H) {
+        int rc = 0;
+        rc |= dalloc(c, &g.H, B * hs); rc |= dalloc(c, &g.res, B * mld); rc |= dalloc(c, &g.noise, B * mld); rc |= dalloc(c, &g.gamma, B * mld);
+        rc |= dalloc(c, &g.chi2, CHI2_CAP); rc |= dalloc(c, &g.m, B); rc |= dalloc(c, &g.nc, B); rc |= dalloc(c, &g.colmap, B * GNSS_NCW);
+        rc |= dalloc(c, &g.keep, B * mld);
+        if (!c->d_noiseB) rc |= dalloc(c, &c->d_noiseB, B * mld);
+        if (rc) return INGVIO_E_HIP;
+        g.hi.assign(B, 0);
+    }
+    Uploader upl{ c };
+    int rc = upl.begin(pad64(8 * (size_t)nb * hs) + 2 * pad64(8 * (size_t)nb * mld) + pad64(4 * (size_t)nb * GNSS_NCW) + 2 * pad64(4 * (size_t)nb) +
+                       pad64(8 * CHI2_CAP) + 1024);
+    if (rc) return rc;
+    double* hH = upl.take<double>((size_t)nb * hs); double* hr = upl.take<double>((size_t)nb * mld); double* hn = upl.take<double>((size_t)nb * mld);
+    int* hc = upl.take<int>((size_t)nb * GNSS_NCW); int* hm = upl.take<int>(nb); int* hnc = upl.take<int>(nb);
+    double* hchi = upl.take<double>(CHI2_CAP);
+    parallel_for(nb, [=, &ncs](int i) {
+        const ingvio_update_block& q = blk[i];
+        const int nc = ncs[i];
+        double* Hd = hH + (size_t)i * hs;
+        for (int cc = 0; cc < nc; ++cc) {
+            memcpy(Hd + (size_t)cc * mld, q.H + (size_t)cc * q.ldh, 8 * (size_t)q.m);
+            memset(Hd + (size_t)cc * mld + q.m, 0, 8 * (mld - q.m));
+        }
+        if (q.m) { memcpy(hr + (size_t)i * mld, q.res, 8 * (size_t)q.m); memcpy(hn + (size_t)i * mld, q.R, 8 * (size_t)q.m); }
+        int* cm = hc + (size_t)i * GNSS_NCW;
+        int w = 0;
+        if (q.m) for (int j = 0; j < q.k; ++j) for (int t = 0; t < q.vsize[j]; ++t) cm[w++] = q.vidx[j] + t;
+        hm[i] = q.m; hnc[i] = nc;
+    });
+    for (int i = 0; i < nb; ++i) g.hi[b0 + i] = his[i];
+    upl.copy(g.H + (size_t)b0 * hs, hH, (size_t)nb * hs);
+    upl.copy(g.res + (size_t)b0 * mld, hr, (size_t)nb * mld);
+    upl.copy(g.noise + (size_t)b0 * mld, hn, (size_t)nb * mld);
+    upl.copy(g.colmap + (size_t)b0 * GNSS_NCW, hc, (size_t)nb * GNSS_NCW);
+    upl.copy(g.m + b0, hm, nb); upl.copy(g.nc + b0, hnc, nb);
+    g.chi2_len = 0;
+    if (o->chi2_table) {
+        memcpy(hchi, o->chi2_table, 8 * (size_t)o->chi2_len);
+        upl.copy(g.chi2, hchi, (size_t)o->chi2_len);
+        g.chi2_len = o->chi2_len;
+    }
+    rc = upl.end();
+    if (rc) return rc;
+    g.gate_rows = o->gate_rows ? 1 : 0; g.strong = o->strong_reject ? 1 : 0;
+    g.thr1 = o->gate_rows ? o->chi2_table[1] : __builtin_inf();
+    if (!g.staged || m_cap > g.m_cap) g.m_cap = m_cap;
+    g.staged = true;
+    return INGVIO_OK;
+}
+
+int ingvio_gnss_run(ingvio_ctx* c, int b0, int nb)
+{
+    if (check_range(c, b0, nb) || !c->gn.staged) return INGVIO_E_ARG;
+    auto& g = c->gn;
+    int n_cap = 0;
+    for (int i = 0; i < nb; ++i) {
+        if (g.hi[b0 + i] > c->h_n[b0 + i]) return INGVIO_E_NOT_IN_STATE;          // checkSubOrder against the LIVE state
+        if (c->h_n[b0 + i] > n_cap) n_cap = c->h_n[b0 + i];
+    }
+    if (g.m_cap == 0) return INGVIO_OK;
+    const size_t mld = c->mld, hs = mld * GNSS_NCW;
+    HIPCHK(c, hipMemsetAsync(c->d_status + b0, 0, sizeof(int) * (size_t)nb, c->st));
+    EkfLaunch E;
+    memset(&E, 0, sizeof E);
+    E.cv = view(c); E.b0 = b0; E.nb = nb; E.H = c->d_H + (size_t)b0 * hs; E.res = c->d_res + (size_t)b0 * mld;
+    E.colmap = c->d_colmap + (size_t)b0 * GNSS_NCW; E.m = c->d_m + b0; E.nc = c->d_nc + b0;
+    E.noise = c->d_noiseB + (size_t)b0 * mld; E.r_kind = INGVIO_R_DIAG; E.mld = c->mld; E.hstride = (int)hs; E.cstride = GNSS_NCW;
+    E.nstride = c->mld; E.Y = c->d_Y + (size_t)b0 * c->ystride; E.ystride = c->ystride; E.dx = c->d_dx;
+    E.status = c->d_status; E.m_cap = g.m_cap; E.nc_cap = GNSS_NCW;
+    if (g.strong) { E.chi2 = g.chi2; E.chi2_len = g.chi2_len; E.gate_max_rows = 14; }      // GnssUpdate.cpp:286
+    RowsGateIn in{ g.H + (size_t)b0 * hs, g.res + (size_t)b0 * mld, g.noise + (size_t)b0 * mld, g.m + b0, g.colmap + (size_t)b0 * GNSS_NCW,
+                   g.nc + b0, (int)hs, GNSS_NCW };
+    {
+        ProfScope p(c, PF_ROWGATE);
+        if (launch_rows_gate(E, in, g.thr1, g.gamma + (size_t)b0 * mld, g.keep + (size_t)b0 * mld, c->st)) return INGVIO_E_CAPACITY;
+    }
+    { ProfScope p(c, PF_EKF_CORE); launch_ekf_core(E, c->st); }
+    { ProfScope p(c, PF_DOWNDATE); launch_downdate(E, n_cap, c->st); }
+    return last_launch(c);
+}
+
+int ingvio_gnss_fetch(ingvio_ctx* c, int b0, int nb, double* dx_out, int* rows_out, int* keep_out, double* gamma_out, int* status_out)
+{
+    if (check_range(c, b0, nb) || !c->gn.staged) return INGVIO_E_ARG;
+    const size_t mld = c->mld;
+    std::vector<int> status(nb, 0);
+    if (dx_out) HIPCHK(c, hipMemcpyAsync(dx_out, c->d_dx + (size_t)b0 * c->ldp, 8 * (size_t)nb * c->ldp, hipMemcpyDeviceToHost, c->st));
+    if (rows_out) HIPCHK(c, hipMemcpyAsync(rows_out, c->d_m + b0, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, c->st));
+    if (keep_out) HIPCHK(c, hipMemcpyAsync(keep_out, c->gn.keep + (size_t)b0 * mld, sizeof(int) * (size_t)nb * mld, hipMemcpyDeviceToHost, c->st));
+    if (gamma_out) HIPCHK(c, hipMemcpyAsync(gamma_out, c->gn.gamma + (size_t)b0 * mld, 8 * (size_t)nb * mld, hipMemcpyDeviceToHost, c->st));
+    if (down_sync(c, status.data(), c->d_status + b0, sizeof(int) * (size_t)nb)) return INGVIO_E_HIP;
+    int rc = last_launch(c);
+    if (rc) return rc;
+    int soft = INGVIO_OK;
+    for (int i = 0; i < nb; ++i) {
+        const int st = (status[i] & 8) ? INGVIO_REJECTED : ((status[i] & 2) ? INGVIO_NEG_DIAG : INGVIO_OK);
+        if (status_out) status_out[i] = st;
+        if (st == INGVIO_NEG_DIAG) soft = st;
+    }
+    return soft;
+}
+
+int ingvio_gnss_update_batch(ingvio_ctx* c, int b0, int nb, const ingvio_update_block* blk, const ingvio_gnss_opts* o, double* dx_out,
+                             int* rows_out, int* keep_out, int* status_out)
+{
+    int rc = ingvio_gnss_stage(c, b0, nb, blk, o);
+    if (rc) return rc;
+    rc = ingvio_gnss_run(c, b0, nb);
+    if (rc) return rc;
+    return ingvio_gnss_fetch(c, b0, nb, dx_out, rows_out, keep_out, nullptr, status_out);
+}
+
+int ingvio_mld(ingvio_ctx* c) { return c ? c->mld : 0; }
 
 int ingvio_chi2_gamma(ingvio_ctx* c, int b, const int* vidx, const int* vsize, int k, const double* H, int ldh, int m,
                       const double* res, const double* R, int r_kind, double* gamma)
@@ -964,6 +1150,7 @@ int ingvio_add_variable_delayed(ingvio_ctx* c, int b, const int* vidx, const int
     if (rc) return rc;
     rc = stage_hnew(c, H_new, ldn, m, s);
     if (rc) return rc;
+    if (!ekf_core_fits(m - s, nc)) return INGVIO_E_CAPACITY;     // the trailing EKF update must fit before the state is touched
     double* dH = c->d_H + (size_t)b * c->hstride;
     double* dres = c->d_res + (size_t)b * c->mld;
     const int* dcm = c->d_colmap + (size_t)b * c->cstride;
@@ -1022,7 +1209,7 @@ int ingvio_triangulate(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* 
     if (o->outer_loop_max_iter < 0 || o->inner_loop_max_iter < 0) return INGVIO_E_ARG;
     int fmx = c->d.f_max;
     if (frames) {
-        const int rc = stage_frames(c, b0, nb, frames, &fmx);
+        const int rc = stage_frames(c, b0, nb, frames, &fmx, -1);      // poses and observations only: no state indices needed
         if (rc) return rc;
         c->strip_ok = false;
     } else if (!c->staged) return INGVIO_E_ARG;
@@ -1124,34 +1311,52 @@ int ingvio_qr_compress(ingvio_ctx* c, const double* H, int ldh, int m, int n, co
 static int frame_stage_impl(ingvio_ctx* c, int b0, int nb, const ingvio_frame_step* steps, const ingvio_msckf_frame* frames,
                             const ingvio_msckf_opts* opts, const double sigma[4], int enable_gnss, double scb, double srw, bool async)
 {
+    // ---- validation: nothing of the context is modified until every input has been accepted ---------------------------
     if (check_range(c, b0, nb) || !steps || !frames || !opts || !sigma) return INGVIO_E_ARG;
     if (async && (b0 != 0 || nb != c->d.batch)) return INGVIO_E_ARG;      // a whole input set is replaced
     const int k = steps[0].k;
     if (k < 1 || k > KMAX) return INGVIO_E_ARG;
-    c->strip_ok = false;                          // new clock-state indices: the next restore is a full one
     if (!opts->chi2_table || opts->chi2_len < 2 || opts->chi2_len > CHI2_CAP) return INGVIO_E_ARG;
-    for (int i = 0; i < nb; ++i) {
-        if (steps[i].k != k) return INGVIO_E_ARG;
-        c->st_marg[b0 + i] = steps[i].marg_idx;
-    }
-    // everything goes through ONE pinned slab: packed by a few host threads, copied asynchronously, no stream sync
+    for (int i = 0; i < nb; ++i)
+        if (steps[i].k != k || !steps[i].Phi || !steps[i].G || !steps[i].dt) return INGVIO_E_ARG;
+    int fmx = 0;
+    // clone indices are checked against the buffer only (grow < 0): the live size at run time depends on whether the run
+    // restores the snapshot; ingvio_frame_run checks them against the live state before its first launch
+    int rc = validate_frames(c, b0, nb, frames, -1, &fmx);
+    if (rc) return rc;
+    // ---- resources that may fail, still without side effects on the staged state --------------------------------------
     Uploader upl{ c };
     const size_t n = nb;
-    int rc = 0;
     if (async) {
         rc = prepare_async_set(c);
         if (rc) return rc;
+    }
+    rc = upl.begin(pad64(8 * n * k * 225) + pad64(8 * n * k * 180) + pad64(8 * n * k) + pad64(8 * n * 9) + pad64(4 * n * 5) + pad64(4 * n) +
+                   pad64(8 * CHI2_CAP) + pad64(8 * n) + frames_bytes(c, nb) + 1024);
+    if (rc) return rc;
+    // ---- from here on only HIP runtime errors can occur; they invalidate the staged frame -----------------------------
+    c->strip_ok = false;                          // new clock-state indices: the next restore is a full one
+    auto fail = [&](int code) {
+        hipStreamSynchronize(c->st);
+        if (c->st_copy) hipStreamSynchronize(c->st_copy);
+        c->staged = false; c->copy_pending = false;
+        return code;
+    };
+    if (async) {
         // the set about to be overwritten was last read two frames ago; its "free" event is on the compute stream
-        if (c->free_valid[c->set_id ^ 1]) HIPCHK(c, hipStreamWaitEvent(c->st_copy, c->ev_free[c->set_id ^ 1], 0));
+        if (c->free_valid[c->set_id ^ 1] && hipStreamWaitEvent(c->st_copy, c->ev_free[c->set_id ^ 1], 0) != hipSuccess) return fail(INGVIO_E_HIP);
         swap_input_sets(c);
         upl.stream = c->st_copy;
     } else {
-        rc = wait_inputs(c);              // an earlier asynchronous stage into this set must land before it is overwritten in-stream
-        if (rc) return rc;
+        if (wait_inputs(c)) return fail(INGVIO_E_HIP);   // an earlier asynchronous stage into this set must land before it is overwritten in-stream
     }
-    rc = upl.begin(pad64(8 * n * k * 225) + pad64(8 * n * k * 180) + pad64(8 * n * k) + pad64(8 * n * 9) + pad64(4 * n * 5) + pad64(4 * n) +
-                       pad64(8 * CHI2_CAP) + pad64(8 * n) + frames_bytes(c, nb) + 1024);
-    if (rc) return rc;
+    for (int i = 0; i < nb; ++i) {
+        c->st_marg[b0 + i] = steps[i].marg_idx;
+        int hi = -1;
+        for (int q = 0; q < frames[i].n_clones; ++q) if (frames[i].clone_idx[q] > hi) hi = frames[i].clone_idx[q];
+        c->st_cidx_hi[b0 + i] = hi;
+    }
+    // everything goes through ONE pinned slab: packed by a few host threads, copied asynchronously, no stream sync
     double* Phi = upl.take<double>(n * k * 225); double* G = upl.take<double>(n * k * 180); double* dt = upl.take<double>(n * k);
     double* R = upl.take<double>(n * 9); int* gi = upl.take<int>(n * 5); int* mi = upl.take<int>(n);
     double* chi2 = upl.take<double>(CHI2_CAP); double* nz = upl.take<double>(n);
@@ -1179,13 +1384,11 @@ static int frame_stage_impl(ingvio_ctx* c, int b0, int nb, const ingvio_frame_st
     memcpy(op.t_lr, opts->t_cl2cr, 24);
     op.var = var; op.max_accept = opts->max_accept; op.selected_variant = opts->selected_variant;
     op.chi2 = c->d_chi2; op.chi2_len = opts->chi2_len;
-    int fmx = 0;
-    rc = pack_frames(c, upl, b0, nb, frames, &fmx);
-    if (rc) return rc;
+    pack_frames(c, upl, b0, nb, frames, &fmx);
     rc = upl.end();
-    if (rc) return rc;
+    if (rc) return fail(rc);
     if (async) {
-        HIPCHK(c, hipEventRecord(c->ev_copy, c->st_copy));
+        if (hipEventRecord(c->ev_copy, c->st_copy) != hipSuccess) return fail(INGVIO_E_HIP);
         c->copy_pending = true;
     }
     c->st_k = k; c->st_stereo = opts->stereo; c->st_enable_gnss = enable_gnss; c->st_scb = scb; c->st_srw = srw;
@@ -1211,9 +1414,20 @@ int ingvio_frame_run(ingvio_ctx* c, int restore_prior)
 {
     if (!c || !c->staged) return INGVIO_E_ARG;
     const int B = c->d.batch;
+    // ---- every check that can refuse the step comes before the first launch and before any host-side state changes ----
+    if (restore_prior && !c->has_snap) return INGVIO_E_ARG;
+    if (c->method == 0 && c->d.c_max > 16) return INGVIO_E_UNSUPPORTED;       // the dense MSCKF method stops at 16 clones
+    {
+        const std::vector<int>& n0 = restore_prior ? c->h_n_snap : c->h_n;
+        for (int b = 0; b < B; ++b) {
+            if (n0[b] < 21) return INGVIO_E_ARG;
+            if (n0[b] + 6 > c->d.n_max) return INGVIO_E_CAPACITY;
+            if (c->st_cidx_hi[b] + 6 > n0[b] + 6) return INGVIO_E_NOT_IN_STATE;      // a staged clone lies beyond the live state
+            if (c->st_marg[b] >= 0 && c->st_marg[b] + 6 > n0[b] + 6) return INGVIO_E_NOT_IN_STATE;
+        }
+    }
     if (wait_inputs(c)) return INGVIO_E_HIP;
     if (restore_prior) {
-        if (!c->has_snap) return INGVIO_E_ARG;
         ProfScope p(c, PF_RESTORE);
         const bool strips = c->strip_ok && c->mut_seq == c->strip_seq;
         if (strips) launch_restore_strips(view(c), c->d.n_max, c->Psnap, c->d_n_snap, c->st_enable_gnss ? c->d_gnss : nullptr, c->st);
@@ -1221,7 +1435,6 @@ int ingvio_frame_run(ingvio_ctx* c, int restore_prior)
         c->h_n = c->h_n_snap;
         std::fill(c->h_cur.begin(), c->h_cur.end(), 0);
     }
-    for (int b = 0; b < B; ++b) if (c->h_n[b] + 6 > c->d.n_max) return INGVIO_E_CAPACITY;
     {
         // one launch: status reset + K1 (k composed IMU steps) + K2 (clone) when a workgroup owns a whole filter
         ProfScope p(c, PF_PROPAGATE);
@@ -1266,6 +1479,47 @@ int ingvio_set_msckf_method(ingvio_ctx* c, int method)
 {
     if (!c || method < 0 || method > 1) return INGVIO_E_ARG;
     c->method = method;
+    return INGVIO_OK;
+}
+
+// parity hook: [A | b] = [sum_j H_j^T H_j | sum_j H_j^T r_j] of the last MSCKF update of filter b, ncol x (ncol + 1) row-major
+int ingvio_debug_msckf_info(ingvio_ctx* c, int b, double* A_out, int* ncol_out)
+{
+    if (check_range(c, b, 1) || !A_out || !ncol_out) return INGVIO_E_ARG;
+    int C = 0;
+    if (down_sync(c, &C, c->d_nclones + b, sizeof(int))) return INGVIO_E_HIP;
+    const int ncol = 6 * C;
+    *ncol_out = ncol;
+    const size_t w = (size_t)ncol + 1;
+    for (size_t e = 0; e < (size_t)ncol * w; ++e) A_out[e] = 0.0;
+    if (c->method == 1) {
+        std::vector<int> used(c->G);
+        if (down_sync(c, used.data(), c->d_chunk_used + (size_t)b * c->G, sizeof(int) * (size_t)c->G)) return INGVIO_E_HIP;
+        std::vector<double> part((size_t)ncol * w);
+        for (int g = 0; g < c->G; ++g) {
+            if (!used[g]) continue;
+            if (down_sync(c, part.data(), c->d_Rpart + ((size_t)b * c->G + g) * c->rstride, 8 * part.size())) return INGVIO_E_HIP;
+            for (size_t e = 0; e < part.size(); ++e) A_out[e] += part[e];
+        }
+        return INGVIO_OK;
+    }
+    // dense method: the merged factor R (upper triangular, column-major ld = mld) and Q^T r in d_H / d_res
+    int m = 0;
+    if (down_sync(c, &m, c->d_m + b, sizeof(int))) return INGVIO_E_HIP;
+    if (m == 0) return INGVIO_OK;
+    std::vector<double> R((size_t)c->mld * ncol), z(c->mld);
+    if (down_sync(c, R.data(), c->d_H + (size_t)b * c->hstride, 8 * R.size()) || down_sync(c, z.data(), c->d_res + (size_t)b * c->mld, 8 * (size_t)ncol))
+        return INGVIO_E_HIP;
+    for (int i = 0; i < ncol; ++i) {
+        for (int j = 0; j < ncol; ++j) {
+            double a = 0.0;
+            for (int k = 0; k <= (i < j ? i : j); ++k) a += R[k + (size_t)i * c->mld] * R[k + (size_t)j * c->mld];
+            A_out[i * w + j] = a;
+        }
+        double bb = 0.0;
+        for (int k = 0; k <= i; ++k) bb += R[k + (size_t)i * c->mld] * z[k];
+        A_out[i * w + ncol] = bb;
+    }
     return INGVIO_OK;
 }
 

@@ -26,6 +26,12 @@ struct GnssResiduals {
     Mat3d R_w2ecef;                       // getRenu2ecef() * calcRw2enu(state)
 };
 
+// candidate rows of updateTrackedSys (all pseudo-range rows, then all Doppler rows; H column-major, ldh >= 2 nsat, 15 columns;
+// vidx / vsize hold up to 7 variables); returns the row count
+int gnssCandidateRows(const GnssResiduals& g, const Vec3d& p_w, const Vec3d& v_w, int idx_se23, int idx_yof, const int idx_cb[4],
+                      int idx_fs, double psr_amp, double dopp_amp, double* H, int ldh, double* res, double* Rd, int* vidx, int* vsize,
+                      int* nvar);
+
 class GnssUpdate : public UpdateBase {
 public:
     GnssUpdate(const IngvioParams& filter_params);
@@ -35,6 +41,7 @@ public:
 protected:
     double _psr_noise_amp, _dopp_noise_amp;
     bool _is_gnss_chi2_test, _is_gnss_strong_reject, _is_adjust_yof;
+    bool _warned_yof = false;
 };
 
 }  // namespace ingvio

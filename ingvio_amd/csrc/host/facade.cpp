@@ -1,5 +1,6 @@
 // facade.cpp — small extern "C" surface of libingvio_host.so for the Python harness (bench.py,
 // tests): lets Python drive the C++ host shim without a C++ test runner.  Not part of the HIP ABI.
+#include "GnssUpdate.h"
 #include "ImuTransition.h"
 #include "Update.h"
 
@@ -23,6 +24,24 @@ void ingvio_host_gamma(const double* vec, int m, double* out)
 {
     const ingvio::Mat3d g = ingvio::GammaFunc(ingvio::Vec3d(vec), m);
     for (int i = 0; i < 9; ++i) out[i] = g.m[i];
+}
+
+// GnssUpdate::updateTrackedSys, row assembly (GnssUpdate.cpp:148-272) without the gates: los [nsat][3] (= -J_pos_ecef rows),
+// sys [nsat] (gnss_comm::sys2idx), idx_cb [4] (-1: constellation not in the state).  H column-major [ldh][15].
+int ingvio_host_gnss_rows(int nsat, const double* los, const int* sys, const double* res_pos, const double* res_vel, const double* sin_el,
+                          const double* ura, const double* psr_std, const double* dopp_std_mps, const double* R_w2ecef,
+                          const double* p_w, const double* v_w, int idx_se23, int idx_yof, const int* idx_cb, int idx_fs,
+                          double psr_amp, double dopp_amp, double* H, int ldh, double* res, double* Rd, int* vidx, int* vsize, int* nvar)
+{
+    ingvio::GnssResiduals g;
+    for (int i = 0; i < nsat; ++i) {
+        g.unit_rv2sv.push_back(ingvio::Vec3d(los + 3 * i)); g.sys.push_back(sys[i]); g.res_pos.push_back(res_pos[i]);
+        g.res_vel.push_back(res_vel[i]); g.sin_el.push_back(sin_el[i]); g.ura.push_back(ura[i]); g.psr_std.push_back(psr_std[i]);
+        g.dopp_std_mps.push_back(dopp_std_mps[i]);
+    }
+    g.R_w2ecef = ingvio::Mat3d(R_w2ecef);
+    return ingvio::gnssCandidateRows(g, ingvio::Vec3d(p_w), ingvio::Vec3d(v_w), idx_se23, idx_yof, idx_cb, idx_fs, psr_amp, dopp_amp,
+                                     H, ldh, res, Rd, vidx, vsize, nvar);
 }
 
 double ingvio_host_chi2_quantile(int dof, double p) { return ingvio::chi2Quantile(dof, p); }

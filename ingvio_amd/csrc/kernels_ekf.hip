@@ -18,9 +18,10 @@
 
 __global__ __launch_bounds__(EKF_THREADS) void k_ekf_core(
     CovView cv, int b0, const double* __restrict__ Hall, const double* __restrict__ res_all,
-    const int* __restrict__ colmap_all, const int* __restrict__ m_all, const int* __restrict__ nc_all,
+    const int* __restrict__ colmap_all, int* __restrict__ m_all, const int* __restrict__ nc_all,
     const double* __restrict__ noise_all, int r_kind, int mld, int hstride, int cstride, int nstride,
-    double* __restrict__ Yall, int ystride, double* __restrict__ dx_all, int* __restrict__ status)
+    double* __restrict__ Yall, int ystride, double* __restrict__ dx_all, int* __restrict__ status,
+    const double* __restrict__ chi2, int chi2_len, int gate_max_rows)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* sS = reinterpret_cast<double*>(smem_raw);
@@ -97,6 +98,18 @@ __global__ __launch_bounds__(EKF_THREADS) void k_ekf_core(
     for (int j = tid; j < m; j += EKF_THREADS) sS[j * LS + j] = sqrt(sS[j * LS + j]);
     __syncthreads();
     if (bad) atomicOr(&status[b], 4);
+    // ---- optional block gate on the prior (GnssUpdate.cpp:286: `rows <= 14 && strong_reject && !testChiSquared(.., R, rows)`):
+    //      gamma = res^T S^-1 res = |z|^2 is already in the border of the factorisation
+    if (gate_max_rows > 0 && m <= gate_max_rows) {
+        double g = 0.0;
+        for (int j = 0; j < m; ++j) g += sS[m * LS + j] * sS[m * LS + j];          // uniform: every thread sums the same LDS row
+        const bool pass = m < chi2_len && g < chi2[m];                              // Update.cpp:160
+        if (!pass) {
+            for (int r = tid; r < n; r += EKF_THREADS) dx[r] = 0.0;
+            if (tid == 0) { m_all[bl] = 0; atomicOr(&status[b], 8); }               // k_downdate sees m = 0: state untouched
+            return;
+        }
+    }
     // ---- Y = PHT L^-T (row-wise forward substitution), dx = Y z -----------------------------
     for (int r = tid; r < n; r += EKF_THREADS) {
         double d = 0.0;
@@ -110,6 +123,73 @@ __global__ __launch_bounds__(EKF_THREADS) void k_ekf_core(
         dx[r] = d;
         for (int j = m; j < ((m + 3) & ~3); ++j) Y[r + (size_t)j * ld] = 0.0;      // pad K dim for MFMA
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-row whitenResidual gates of a stacked update against the prior, then in-place compaction of the accepted rows
+// (GnssUpdate.cpp:190,259: every pseudo-range / Doppler row is tested on its own, dof 1, before it joins the stack).
+// Row i only has non-zero entries in the columns of its own sub_order, so h_i Pvv h_i^T over the stacked var_order
+// equals the reference's 11-column sub-block product.  One workgroup per filter; m <= 256 candidate rows.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rows_gate(
+    CovView cv, int b0, const double* __restrict__ Hin_all, const double* __restrict__ res_in_all, const double* __restrict__ noise_in_all,
+    const int* __restrict__ m_in_all, const int* __restrict__ colmap_all, const int* __restrict__ nc_all, int in_hstride, int in_cstride,
+    double* __restrict__ Hall, double* __restrict__ res_all, double* __restrict__ noise_all, int* __restrict__ m_all,
+    int* __restrict__ colmap_out, int* __restrict__ nc_out, int mld, int hstride, int cstride,
+    double thr, double* __restrict__ gamma_all, int* __restrict__ keep_all)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int bl = blockIdx.x, b = b0 + bl, tid = threadIdx.x;
+    const int m = m_in_all[bl], nc = nc_all[bl], ld = cv.ldp;
+    double* sP = reinterpret_cast<double*>(smem_raw);             // nc x nc marginal
+    double* sH = sP + (size_t)nc * nc;                            // m x nc candidate rows (row-major)
+    __shared__ int sPos[257];
+    const double* P = cov_ptr(cv, b);
+    const double* Hin = Hin_all + (size_t)bl * in_hstride;
+    const double* res_in = res_in_all + (size_t)bl * mld;
+    const double* noise_in = noise_in_all + (size_t)bl * mld;
+    const int* cm = colmap_all + (size_t)bl * in_cstride;
+    double* H = Hall + (size_t)bl * hstride;
+    double* res = res_all + (size_t)bl * mld;
+    double* noise = noise_all + (size_t)bl * mld;
+    for (int e = tid; e < nc * nc; e += 256) { const int c = e % nc, c2 = e / nc; sP[e] = P[cm[c] + (size_t)cm[c2] * ld]; }
+    for (int e = tid; e < m * nc; e += 256) { const int i = e % m, c = e / m; sH[i * nc + c] = Hin[i + (size_t)c * mld]; }
+    for (int c = tid; c < nc; c += 256) colmap_out[(size_t)bl * cstride + c] = cm[c];
+    sPos[tid] = 0;
+    if (tid == 0) { sPos[256] = 0; nc_out[bl] = nc; }
+    __syncthreads();
+    bool keep = false;
+    double r_i = 0.0, n_i = 0.0;
+    if (tid < m) {
+        const double* h = sH + tid * nc;
+        double s = 0.0;
+        for (int c = 0; c < nc; ++c) {
+            double t = 0.0;
+            for (int c2 = 0; c2 < nc; ++c2) t += sP[c + c2 * nc] * h[c2];
+            s += h[c] * t;
+        }
+        r_i = res_in[tid]; n_i = noise_in[tid];
+        const double g = r_i * r_i / (s + n_i);                   // Update.cpp:36-56 with a 1 x 1 S
+        keep = g < thr;                                           // :93-97, dof = res.rows() = 1 (thr = +inf: gate off)
+        gamma_all[(size_t)bl * mld + tid] = g;
+        keep_all[(size_t)bl * mld + tid] = keep ? 1 : 0;
+        sPos[tid + 1] = keep ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid == 0) for (int i = 0; i < m; ++i) sPos[i + 1] += sPos[i];      // m <= 256: a serial scan is cheaper than its barriers
+    __syncthreads();
+    const int mk = sPos[m];
+    if (tid < m && keep) {
+        const int d = sPos[tid];
+        res[d] = r_i; noise[d] = n_i;
+    }
+    const int mpad = (m + 15) & ~15;                                       // k_ekf_core reads whole 16-row groups: rows >= mk are zero
+    for (int e = tid; e < mpad * nc; e += 256) {
+        const int i = e % mpad, c = e / mpad;
+        if (i < m && sPos[i + 1] != sPos[i]) H[sPos[i] + (size_t)c * mld] = sH[i * nc + c];
+        if (i >= mk && i < mld) H[i + (size_t)c * mld] = 0.0;
+    }
+    if (tid == 0) m_all[bl] = mk;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -227,9 +307,21 @@ void launch_ekf_core(const EkfLaunch& L, hipStream_t st)
     const size_t sm = sizeof(double) * (size_t)(L.m_cap + 1) * (L.m_cap + 1) + sizeof(int) * (size_t)L.nc_cap + 16;
     hipFuncSetAttribute((const void*)k_ekf_core, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     hipLaunchKernelGGL(k_ekf_core, dim3(L.nb), dim3(EKF_THREADS), sm, st, L.cv, L.b0, L.H, L.res, L.colmap, L.m, L.nc,
-                       L.noise, L.r_kind, L.mld, L.hstride, L.cstride, L.nstride, L.Y, L.ystride, L.dx, L.status);
+                       L.noise, L.r_kind, L.mld, L.hstride, L.cstride, L.nstride, L.Y, L.ystride, L.dx, L.status,
+                       L.chi2, L.chi2_len, L.gate_max_rows);
 }
 
+// per-row gates + compaction from the staged (pristine) rows into the working rows; returns non-zero when they do not fit in LDS
+int launch_rows_gate(const EkfLaunch& L, const RowsGateIn& in, double thr, double* gamma, int* keep, hipStream_t st)
+{
+    const size_t sm = sizeof(double) * ((size_t)L.nc_cap * L.nc_cap + (size_t)L.m_cap * L.nc_cap);
+    if (L.m_cap > 256 || sm > 150 * 1024) return -1;
+    hipFuncSetAttribute((const void*)k_rows_gate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(k_rows_gate, dim3(L.nb), dim3(256), sm, st, L.cv, L.b0, in.H, in.res, in.noise, in.m, in.colmap, in.nc,
+                       in.hstride, in.cstride, const_cast<double*>(L.H), const_cast<double*>(L.res), const_cast<double*>(L.noise), L.m,
+                       const_cast<int*>(L.colmap), const_cast<int*>(L.nc), L.mld, L.hstride, L.cstride, thr, gamma, keep);
+    return 0;
+}
 void launch_downdate(const EkfLaunch& L, int n_cap, hipStream_t st, const double* Yb)
 {
     const int nt = (n_cap + 15) / 16;

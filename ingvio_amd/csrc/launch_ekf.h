@@ -8,7 +8,7 @@ struct EkfLaunch {
     const double* H;        // [nb][hstride], column-major ld = mld
     const double* res;      // [nb][mld]
     const int* colmap;      // [nb][cstride]
-    const int* m;           // [nb]
+    int* m;                 // [nb] (the gates may shrink it)
     const int* nc;          // [nb]
     const double* noise;    // [nb][nstride]
     int r_kind, mld, hstride, cstride, nstride;
@@ -17,10 +17,18 @@ struct EkfLaunch {
     double* dx;             // [B][ldp]
     int* status;            // [B]
     int m_cap, nc_cap;      // LDS sizing
+    const double* chi2;     // optional block gate of k_ekf_core (GnssUpdate.cpp:286): device table, chi2[dof]
+    int chi2_len, gate_max_rows;   // gate_max_rows > 0: updates with m <= gate_max_rows rows are gated as one block
 };
 
 void launch_ekf_core(const EkfLaunch& L, hipStream_t st);
 void launch_downdate(const EkfLaunch& L, int n_cap, hipStream_t st, const double* Yb = nullptr);
+struct RowsGateIn {         // the staged candidate rows of a batch (read-only; the gate writes its compacted copy into EkfLaunch's H/res/noise/m)
+    const double *H, *res, *noise;
+    const int *m, *colmap, *nc;
+    int hstride, cstride;
+};
+int launch_rows_gate(const EkfLaunch& L, const RowsGateIn& in, double thr, double* gamma, int* keep, hipStream_t st);
 void launch_gamma_multi(CovView cv, int b, int nblk, const double* dbuf, const int* ibuf, const int* desc, const double* noise,
                         double* gamma_out, size_t lds_bytes, hipStream_t st);
 void launch_gamma(CovView cv, int b, const double* H, const double* res, const int* colmap, int m, int nc,

@@ -47,3 +47,25 @@ def imu_transition(R, p, v, bg, ba, gyro, acc, gravity, dt):
 def chi2_quantile(dof, p=0.95):
     """UpdateBase's table entry: boost::math::quantile(chi_squared(dof), p) without Boost."""
     return lib().ingvio_host_chi2_quantile(C.c_int(dof), C.c_double(p))
+
+
+def gnss_rows(g):
+    """Candidate rows of GnssUpdate::updateTrackedSys (GnssUpdate.cpp:148-272; gates NOT applied — they run on the device,
+    ingvio_gnss_update_batch).  g: dict with los[ns,3], sys[ns], res_pos, res_vel, sin_el, ura, psr_std, dopp_std_mps,
+    R_w2ecef[3,3], p_w, v_w, idx_se23, idx_yof, idx_cb[4], idx_fs (psr_amp, dopp_amp optional).
+    Returns (vidx, vsize, H[rows, ncols], res[rows], Rdiag[rows])."""
+    ns = len(g["sys"])
+    c_ip = C.POINTER(C.c_int)
+    sysv = np.ascontiguousarray(g["sys"], dtype=np.int32); icb = np.ascontiguousarray(g["idx_cb"], dtype=np.int32)
+    ldh = max(2 * ns, 1)
+    H = np.zeros((ldh, 15), order="F"); res = np.zeros(ldh); Rd = np.zeros(ldh)
+    vidx = np.zeros(8, dtype=np.int32); vsize = np.zeros(8, dtype=np.int32); nv = C.c_int(0)
+    rows = lib().ingvio_host_gnss_rows(
+        C.c_int(ns), _d(_f(g["los"])), sysv.ctypes.data_as(c_ip), _d(_f(g["res_pos"])), _d(_f(g["res_vel"])), _d(_f(g["sin_el"])),
+        _d(_f(g["ura"])), _d(_f(g["psr_std"])), _d(_f(g["dopp_std_mps"])), _d(_f(np.asarray(g["R_w2ecef"]).reshape(9))),
+        _d(_f(g["p_w"])), _d(_f(g["v_w"])), C.c_int(int(g["idx_se23"])), C.c_int(int(g["idx_yof"])), icb.ctypes.data_as(c_ip),
+        C.c_int(int(g["idx_fs"])), C.c_double(float(g.get("psr_amp", 1.0))), C.c_double(float(g.get("dopp_amp", 1.0))),
+        _d(H), C.c_int(ldh), _d(res), _d(Rd), vidx.ctypes.data_as(c_ip), vsize.ctypes.data_as(c_ip), C.byref(nv))
+    k = nv.value
+    nc = int(vsize[:k].sum())
+    return vidx[:k].copy(), vsize[:k].copy(), H[:rows, :nc].copy(), res[:rows].copy(), Rd[:rows].copy()

@@ -14,13 +14,15 @@ def shard(total, world, rank):
 class Group:
     """Thin wrapper: works for world == 1 without importing torch."""
 
-    def __init__(self, backend=None):
+    def __init__(self, backend=None, force_init=False):
+        """force_init: create the process group even at world size 1 (exercises the collective backend itself)."""
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.dist = None
         self.device = None
-        if self.world > 1:
+        self.backend = None
+        if self.world > 1 or force_init:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL)
             import torch
             import torch.distributed as dist
@@ -35,6 +37,16 @@ class Group:
                 dist.init_process_group(backend)
             self.dist = dist
             self.torch = torch
+            self.backend = backend
+
+    def shard(self, total):
+        """[lo, hi) of the frame ids this rank owns (static block partition)."""
+        start, count = shard(total, self.world, self.rank)
+        return start, start + count
+
+    def gather_scalars(self, x):
+        """One float per rank -> list over ranks (per-rank ms_per_step: hidden host serialisation would show here)."""
+        return [float(r[0]) for r in self.gather_summaries([float(x)])]
 
     def barrier(self):
         if self.dist is not None:

@@ -366,3 +366,32 @@ def build_case(cov_factory, transition, seed=0, F=150, C=11, n_gnss=6, n_landmar
     info = dict(outlier=outlier, N_prior=flt.cov.n, N_update=flt.cov.n + 6, new_idx=new_idx,
                 marg_idx=step["marg_idx"])
     return flt, step, frame, info
+
+
+def make_gnss(rng, flt, n_sat=8, outliers=(5,)):
+    """BASELINE config 3 / SURVEY 8(d): 8 satellites on the upper hemisphere (el in [20, 80] deg, az uniform), constellations
+    {GPS x4, BDS x2, GAL x2} (gnss_comm::sys2idx GPS 0 / GLO 1 / GAL 2 / BDS 3), ura 2.0, psr_std 1.0, dopp_std 0.5 (cycles/s -> m/s at
+    L1), residuals N(0, sigma_row^2); `outliers`: satellites whose pseudo-range residual is gross (the per-row gate must refuse them).
+    The values are the OUTPUTS of gnss_comm's psr_res / dopp_res / sat_states: gnss_comm itself is not needed.
+    Returns the dict ingvio_amd.host.gnss_rows / the oracle's gnss_rows take (state indices from `flt`)."""
+    el = np.deg2rad(rng.uniform(20.0, 80.0, n_sat)); az = rng.uniform(0.0, 2.0 * np.pi, n_sat)
+    los = np.stack([np.cos(el) * np.sin(az), np.cos(el) * np.cos(az), np.sin(el)], axis=1)
+    sysv = np.array(([0, 0, 0, 0, 3, 3, 2, 2] * ((n_sat + 7) // 8))[:n_sat], dtype=np.int32)
+    yaw = rng.uniform(0.0, 2.0 * np.pi)
+    # ENU -> ECEF at a mid-latitude point composed with the world yaw offset: any proper rotation serves the covariance path
+    lat, lon = np.deg2rad(31.0), np.deg2rad(121.4)
+    R_enu2ecef = np.array([[-np.sin(lon), -np.sin(lat) * np.cos(lon), np.cos(lat) * np.cos(lon)],
+                           [np.cos(lon), -np.sin(lat) * np.sin(lon), np.cos(lat) * np.sin(lon)],
+                           [0.0, np.cos(lat), np.sin(lat)]])
+    R_w2enu = np.array([[np.cos(yaw), -np.sin(yaw), 0.0], [np.sin(yaw), np.cos(yaw), 0.0], [0.0, 0.0, 1.0]])
+    ura = np.full(n_sat, 2.0); psr_std = np.full(n_sat, 1.0)
+    dopp_std_mps = np.full(n_sat, 0.5 * 299792458.0 / 1575.42e6)
+    sig_p = np.sqrt(ura * psr_std) / np.sin(el); sig_d = np.sqrt(ura * dopp_std_mps) / np.sin(el)
+    res_pos = rng.normal(0.0, 1.0, n_sat) * sig_p; res_vel = rng.normal(0.0, 1.0, n_sat) * sig_d
+    for i in outliers:
+        if i < n_sat:
+            res_pos[i] = 80.0
+    return dict(los=los, sys=sysv, res_pos=res_pos, res_vel=res_vel, sin_el=np.sin(el), ura=ura, psr_std=psr_std,
+                dopp_std_mps=dopp_std_mps, R_w2ecef=R_enu2ecef @ R_w2enu, p_w=flt.p.copy(), v_w=flt.v.copy(), idx_se23=0,
+                idx_yof=flt.idx_yof, idx_cb=np.array(flt.gnss_idx[:4], dtype=np.int32), idx_fs=flt.gnss_idx[4],
+                psr_amp=1.0, dopp_amp=1.0)

@@ -1,21 +1,69 @@
-"""Averages rocprofv3 --pmc counter_collection CSVs per kernel and launch.
-usage: python tests/pmc_summary.py out.csv dir1 [dir2 ...]   (each dir: one `rocprofv3 --pmc ... -d dir --output-format csv` pass;
-counters are collected in their own passes, never together with trace domains)."""
-import collections, csv, glob, re, sys
+"""Folds rocprofv3 --pmc counter_collection CSVs into profiles/counters.json (per kernel, per launch), the file bench.py reads
+its executed-operation counts and HBM traffic from.
 
-out, dirs = sys.argv[1], sys.argv[2:]
-acc = collections.defaultdict(lambda: collections.defaultdict(float))
-cnt = collections.defaultdict(lambda: collections.defaultdict(int))
-for d in dirs:
+usage: python tests/pmc_summary.py --key c2_B512_F150_C11_N249 --last 3 --source "..." --out profiles/counters.json dir1 [dir2 ...]
+       (each dir: one `rocprofv3 --pmc ... -d dir --output-format csv` pass; counters are collected in their own passes, never
+       together with trace domains).  --last N keeps only the last N dispatches of every kernel (the frame steps; earlier
+       dispatches of the same kernel belong to the set-up of the priors).  --csv also writes the table as CSV.
+A counter that appears in several passes is averaged over them."""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import re
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--key", required=True)
+ap.add_argument("--last", type=int, default=0)
+ap.add_argument("--source", default="")
+ap.add_argument("--out", required=True)
+ap.add_argument("--csv", default=None)
+ap.add_argument("dirs", nargs="+")
+a = ap.parse_args()
+
+
+def norm(k):
+    k = re.sub(r"^void ", "", k)
+    k = re.sub(r"\(anonymous namespace\)::", "", k)
+    return re.split(r"[<(]", k)[0].strip()
+
+
+table = collections.defaultdict(lambda: collections.defaultdict(list))       # kernel -> counter -> per-pass averages
+launches = {}
+for d in a.dirs:
+    rows = []
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            k = re.sub(r"^void ", "", r["Kernel_Name"])
-            k = re.sub(r"\(anonymous namespace\)::", "", k)
-            k = re.split(r"[<(]", k)[0].strip()
-            acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
-names = sorted({c for k in acc for c in acc[k]})
-with open(out, "w") as fo:
-    fo.write("kernel," + ",".join(names) + "\n")
-    for k in acc:
-        fo.write(k + "," + ",".join(("%.4g" % (acc[k][c] / cnt[k][c])) if cnt[k][c] else "" for c in names) + "\n")
-print("wrote", out, "kernels:", len(acc))
+        rows += list(csv.DictReader(open(f)))
+    # (kernel, counter) -> {dispatch id: value summed over the dimension rows of that dispatch}
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in rows:
+        per[(norm(r["Kernel_Name"]), r["Counter_Name"])][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+    for (k, c), byd in per.items():
+        ids = sorted(byd)
+        if a.last > 0:
+            ids = ids[-a.last:]
+        table[k][c].append(sum(byd[i] for i in ids) / len(ids))
+        launches[k] = len(ids)
+kernels = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in table.items()}
+for k in kernels:
+    kernels[k]["_launches_averaged"] = launches[k]
+J = {"workloads": {}}
+if os.path.exists(a.out):
+    try:
+        J = json.load(open(a.out))
+    except ValueError:
+        pass
+J.setdefault("workloads", {})[a.key] = {"source": a.source, "kernels": kernels}
+J["note"] = ("per-launch averages of rocprofv3 --pmc counters (tests/pmc_summary.py); FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 "
+             "reports them (bench.py applies the gfx950 x2 on FETCH_SIZE); SQ_INSTS_* are wave-level instruction counts")
+with open(a.out, "w") as f:
+    json.dump(J, f, indent=1, sort_keys=True)
+if a.csv:
+    names = sorted({c for k in kernels for c in kernels[k]})
+    with open(a.csv, "w") as fo:
+        fo.write("kernel," + ",".join(names) + "\n")
+        for k in sorted(kernels):
+            fo.write(k + "," + ",".join(("%.6g" % kernels[k][c]) if c in kernels[k] else "" for c in names) + "\n")
+print("wrote", a.out, "workload", a.key, "kernels:", len(kernels))

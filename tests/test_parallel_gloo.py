@@ -42,6 +42,9 @@ def _worker(rank, world, port, q):
     tmax = g.max_over_ranks(1.0 + rank)
     tot = g.sum_over_ranks(c)
     allv = g.gather_summaries(summ)
+    per_rank = g.gather_scalars(0.5 + rank)          # bench.py's per-rank ms_per_step
+    lo, hi = g.shard(len(names))
+    assert (lo, hi) == (s, s + c) and per_rank == [0.5, 1.5]
     q.put((rank, tmax, tot, allv))
     g.close()
 
