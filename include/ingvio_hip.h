@@ -299,6 +299,10 @@ int ingvio_frame_fetch(ingvio_ctx* ctx, int b0, int nb, double* dx_out, int* acc
  * (6 c_max) * (6 c_max + 1) doubles).  Factored method: the gram kernel's partial sums; dense method: R^T R from the TSQR factor. */
 int ingvio_debug_msckf_info(ingvio_ctx* ctx, int b, double* A_out, int* ncol_out);
 
+/* parity hook (tests): [M | t] of filter b's last factored update as the solve kernel left it (MP x MP row-major + MP, MP = 6 * window class
+ * rounded up to 4); count doubles are copied. */
+int ingvio_debug_info_solution(ingvio_ctx* ctx, int b, double* out, int count);
+
 /* debug: shader-clock stamps written by block (0,0) of the instrumented kernels (see dev_common.h) */
 int ingvio_debug_read(ingvio_ctx* ctx, long long* out, int n);
 

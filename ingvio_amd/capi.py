@@ -27,7 +27,7 @@ EXPORTS = [
     "ingvio_frame_stage", "ingvio_frame_stage_async", "ingvio_frame_run", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_select",
     "ingvio_profile_reset",
     "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_debug_read", "ingvio_triangulate",
-    "ingvio_gnss_update_batch", "ingvio_gnss_stage", "ingvio_gnss_run", "ingvio_gnss_fetch", "ingvio_mld", "ingvio_debug_msckf_info",
+    "ingvio_gnss_update_batch", "ingvio_gnss_stage", "ingvio_gnss_run", "ingvio_gnss_fetch", "ingvio_mld", "ingvio_debug_msckf_info", "ingvio_debug_info_solution",
     "ingvio_chi2_gamma_multi", "ingvio_ekf_update_batch", "ingvio_add_variable_delayed_invertible", "ingvio_add_variable_delayed", "ingvio_replace_var_linear",
 ]
 
@@ -348,6 +348,14 @@ class Context:
         n = nc.value
         M = out[:n * (n + 1)].reshape(n, n + 1)
         return M[:, :n].copy(), M[:, n].copy()
+
+    def debug_info_solution(self, b):
+        """(M [nc, nc], t [nc]) of filter b's last factored update, nc = 6 * (window class of c_max)."""
+        cls = 6 if self.c_max <= 6 else (11 if self.c_max <= 11 else 16)
+        nc = 6 * cls; mp = (nc + 3) & ~3
+        out = np.zeros(mp * mp + mp)
+        self._chk(self.L.ingvio_debug_info_solution(self.h, b, _d(out), out.size))
+        return out[:mp * mp].reshape(mp, mp)[:nc, :nc].copy(), out[mp * mp:mp * mp + nc].copy()
 
     def chi2_gamma_multi(self, b, blocks, noise_var):
         """blocks: list of (vidx, vsize, H, res); returns gamma[len(blocks)] (one launch, one sync)."""

@@ -1523,6 +1523,14 @@ int ingvio_debug_msckf_info(ingvio_ctx* c, int b, double* A_out, int* ncol_out)
     return INGVIO_OK;
 }
 
+// parity hook: [M | t] handed from the information solve to the apply kernel (MP x MP row-major, then MP entries), filter b
+int ingvio_debug_info_solution(ingvio_ctx* c, int b, double* out, int count)
+{
+    if (check_range(c, b, 1) || !out || count < 1 || count > c->ystride) return INGVIO_E_ARG;
+    if (down_sync(c, out, c->d_Y + (size_t)b * c->ystride, 8 * (size_t)count)) return INGVIO_E_HIP;
+    return INGVIO_OK;
+}
+
 int ingvio_debug_read(ingvio_ctx* c, long long* out, int n)
 {
     if (!c || !out || n < 1 || n > 64) return INGVIO_E_ARG;

@@ -14,6 +14,8 @@
 //        rank n-6):  P <- P - (Pc M) Pc^T,  dx = Pc (A Pcc + s^2 I)^-1 b,  Pc = P[:, clone cols].
 // gfx950 only.
 #include <algorithm>
+#include <stdlib.h>
+#include <string.h>
 #include "launch_factored.h"
 
 #include "gate_kernel.h"
@@ -759,6 +761,10 @@ int launch_factored(const FactoredLaunch& L, hipStream_t st)
         return 0;
     }
     if (L.stage == 2) {
+        // default: the symmetric LDL^T solve on the matrix cores (kernels_solve.hip); INGVIO_INFO_SOLVE=gj selects the older
+        // Gauss-Jordan on A Pcc + s^2 I below (kept for comparison and for the 12..16-clone class)
+        static const bool use_gj = [] { const char* e = getenv("INGVIO_INFO_SOLVE"); return !(e && !strcmp(e, "ldl")); }();   // TEMP default gj until the LDL^T kernel is tuned
+        if (!use_gj && launch_info_solve(L, st) == 0) return 0;
 #define INFO_DISPATCH(NC)                                                                                                   \
         {                                                                                                                   \
             const size_t sm = sizeof(double) * (size_t)NC * (2 * NC + 1) + sizeof(int) * (size_t)NC + 16;                     \
