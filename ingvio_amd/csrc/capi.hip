@@ -1535,9 +1535,10 @@ int ingvio_debug_read(ingvio_ctx* c, long long* out, int n)
 {
     if (!c || !out || n < 1 || n > 64) return INGVIO_E_ARG;
     HIPCHK(c, hipStreamSynchronize(c->st));
-    long long a[64], bq[64], cq[64];
-    if (dbg_read_factored(a, 64) || dbg_read_cov(bq, 64) || dbg_read_bigwin(cq, 64)) return INGVIO_E_HIP;
-    for (int i = 0; i < n; ++i) out[i] = i >= 48 ? cq[i] : ((i < 16 || i >= 24) ? a[i] : bq[i]);      // 16..23 cov, 48.. large-window TU
+    long long a[64], bq[64], cq[64], sq[64];
+    if (dbg_read_factored(a, 64) || dbg_read_cov(bq, 64) || dbg_read_bigwin(cq, 64) || dbg_read_solve(sq, 64)) return INGVIO_E_HIP;
+    for (int i = 0; i < n; ++i)      // 16..23 cov, 24..31 the symmetric solve (its slots 0..7), 48.. large-window TU
+        out[i] = i >= 48 ? cq[i] : ((i >= 24 && i < 32) ? sq[i - 24] : ((i < 16 || i >= 32) ? a[i] : bq[i]));
     return INGVIO_OK;
 }
 

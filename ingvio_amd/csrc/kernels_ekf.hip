@@ -30,7 +30,7 @@ __global__ __launch_bounds__(EKF_THREADS) void k_ekf_core(
     const int n = cv.n[b], ld = cv.ldp;
     double* dx = dx_all + (size_t)b * ld;
     if (m == 0) {
-        for (int r = tid; r < n; r += EKF_THREADS) dx[r] = 0.0;
+        for (int r = tid; r < ld; r += EKF_THREADS) dx[r] = 0.0;      // the whole row: callers fetch ldp entries per filter
         return;
     }
     const double* P = cov_ptr(cv, b);
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(EKF_THREADS) void k_ekf_core(
         for (int j = 0; j < m; ++j) g += sS[m * LS + j] * sS[m * LS + j];          // uniform: every thread sums the same LDS row
         const bool pass = m < chi2_len && g < chi2[m];                              // Update.cpp:160
         if (!pass) {
-            for (int r = tid; r < n; r += EKF_THREADS) dx[r] = 0.0;
+            for (int r = tid; r < ld; r += EKF_THREADS) dx[r] = 0.0;
             if (tid == 0) { m_all[bl] = 0; atomicOr(&status[b], 8); }               // k_downdate sees m = 0: state untouched
             return;
         }

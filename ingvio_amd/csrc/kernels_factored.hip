@@ -763,7 +763,7 @@ int launch_factored(const FactoredLaunch& L, hipStream_t st)
     if (L.stage == 2) {
         // default: the symmetric LDL^T solve on the matrix cores (kernels_solve.hip); INGVIO_INFO_SOLVE=gj selects the older
         // Gauss-Jordan on A Pcc + s^2 I below (kept for comparison and for the 12..16-clone class)
-        static const bool use_gj = [] { const char* e = getenv("INGVIO_INFO_SOLVE"); return !(e && !strcmp(e, "ldl")); }();   // TEMP default gj until the LDL^T kernel is tuned
+        static const bool use_gj = [] { const char* e = getenv("INGVIO_INFO_SOLVE"); return e && !strcmp(e, "gj"); }();
         if (!use_gj && launch_info_solve(L, st) == 0) return 0;
 #define INFO_DISPATCH(NC)                                                                                                   \
         {                                                                                                                   \

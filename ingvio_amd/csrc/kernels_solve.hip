@@ -4,7 +4,8 @@
 // push-through identity, see kernels_factored.hip).  A Pcc + s^2 I is a product of two symmetric matrices plus a shift: its
 // eigenvalues are those of the SPD innovation matrix, but it is far from normal (A has rank n - 6), and Gauss-Jordan on it loses
 // cond(A^1/2) more digits than the reference's SPD solve (measured: dx off by 3e-5 at a 100x inflated prior, tests/test_gpu_pinning.py).
-// With  Pcc = L D L^T  (unit lower L):
+// With  Pcc = L D L^T  (L unit BLOCK lower, D block diagonal with SPD 4x4 blocks: block pivots keep the dependent chain per
+// panel at two reciprocals):
 //        A Pcc + s^2 I = L^-T (L^T A L + s^2 D^-1) D L^T,      W := L^T A L + s^2 D^-1   SPD, eigenvalues >= s^2 / max(D)
 //        M = (L^-T D^-1) W^-1 (L^T A),   t = (L^-T D^-1) W^-1 (L^T b)
 // and with  W = L2 D2 L2^T:   M = R2' D2^-1 R1'^T,   R2' = (L^-T D^-1) L2^-T,   R1' = (A L) L2^-T.
@@ -25,88 +26,147 @@ template <int NC>
 struct SolveCfg {
     static constexpr int NT = (NC + 15) / 16, NP = 16 * NT;          // tile rows / padded size of the n x n matrices
     static constexpr int NR1 = (NC + 1 + 15) / 16, R1ROWS = 16 * NR1; // rows of [A L ; b^T L]: the b row sits at row NC
-    static constexpr int NLT = NT * (NT + 1) / 2;
-    static constexpr int NW = 4;
-    static constexpr int P1 = 2 * NLT, P2 = NLT + NR1 * NT + NLT;    // tiles of the two factorisations (matrix + carried)
-    static constexpr int S1 = (P1 + NW - 1) / NW, S2 = (P2 + NW - 1) / NW;
+    static constexpr int NW = 8, RW = 2;                              // waves per filter, tile rows a wave may own
     static constexpr int MROWS = R1ROWS > NP ? R1ROWS : NP, LDM = NP + 1;
     static constexpr int PANROWS = NP + R1ROWS + NP;
     static constexpr int MP = (NC + 3) & ~3;
-    static constexpr size_t lds_bytes() { return sizeof(double) * (2 * (size_t)MROWS * LDM + 2 * (size_t)PANROWS * 4 + 2 * NP) + sizeof(int) * NP; }
+    static constexpr size_t lds_bytes() { return sizeof(double) * (2 * (size_t)MROWS * LDM + 2 * (size_t)PANROWS * 4 + 4 * NP) + sizeof(int) * NP; }
 };
 
-__device__ __forceinline__ void tri_decode(int q, int& hi, int& lo)      // q -> (hi >= lo), row-major over the lower triangle
+// A tile ROW owned by a wave: its 16 rows live at pan rows [arow, arow + 16), its tiles are the column tiles c0..c1.
+// kind 0: row of the matrix being factorised (tile row rt, tiles 0..rt); 1: carried row with a full set of tiles (rt = its index);
+// 2: carried row of an upper-triangular block (tiles rt..NT-1; nothing happens to it before the panel reaches its diagonal tile).
+struct TileRow { int kind, rt, arow, c0, c1; bool valid; };
+
+// The tile rows of the two factorisations, in descending tile count.
+template <int NC, int PHASE>
+constexpr TileRow row_desc(int i)
 {
-    hi = 0;
-    while ((hi + 1) * (hi + 2) / 2 <= q) ++hi;
-    lo = q - hi * (hi + 1) / 2;
+    using C = SolveCfg<NC>;
+    TileRow r{ 0, 0, 0, 1, 0, true };
+    if (PHASE == 2 && i < C::NR1) { r.kind = 1; r.rt = i; r.arow = C::NP + 16 * i; r.c0 = 0; r.c1 = C::NT - 1; return r; }
+    const int q = PHASE == 2 ? i - C::NR1 : i, m = C::NT - (q >> 1);
+    if (q & 1) { r.kind = 2; r.rt = C::NT - m; r.arow = C::NP + (PHASE == 2 ? C::R1ROWS : 0) + 16 * r.rt; r.c0 = r.rt; r.c1 = C::NT - 1; }
+    else { r.kind = 0; r.rt = m - 1; r.arow = 16 * (m - 1); r.c0 = 0; r.c1 = m - 1; }
+    return r;
 }
 
-struct Slot { int arow, tcol, rt; bool valid; };      // pan row base of the tile's rows, its column tile, carried-upper row tile or -1
+// Deals the tile rows to the NW waves at compile time: every row goes to the wave that owns the fewest tiles so far.
+template <int NC, int PHASE>
+struct Deal {
+    using C = SolveCfg<NC>;
+    static constexpr int NROWS = (PHASE == 2 ? C::NR1 : 0) + 2 * C::NT;
+    TileRow rows[C::NW][C::RW];
+    int count[C::NW];
+    constexpr Deal() : rows{}, count{}
+    {
+        int load[C::NW] = {};
+        for (int w = 0; w < C::NW; ++w) { count[w] = 0; for (int q = 0; q < C::RW; ++q) rows[w][q] = TileRow{ 0, 0, 0, 1, 0, false }; }
+        for (int i = 0; i < NROWS; ++i) {
+            const TileRow r = row_desc<NC, PHASE>(i);
+            int best = 0;
+            for (int w = 1; w < C::NW; ++w) if (load[w] < load[best]) best = w;
+            load[best] += r.c1 - r.c0 + 1;
+            rows[best][count[best] < C::RW ? count[best] : C::RW - 1] = r;
+            ++count[best];
+        }
+    }
+    constexpr bool fits() const { for (int w = 0; w < C::NW; ++w) if (count[w] > C::RW) return false; return true; }
+};
 
-// One blocked LDL^T sweep over the tiles of T (S slots per wave).  emit(row, col, x, x * dinv) is called once for every (pan row,
-// pivot column) with the row's L^-T-transformed entry; dsave(k, q, 1/d) once per pivot.
-template <int S, int PANROWS, int NW, class Emit, class DSave>
-__device__ __forceinline__ void ldl_sweep(double4_f (&T)[S], const Slot (&sl)[S], int npan, int np_rows, int nrowtiles, double (*pan)[PANROWS][4],
-                                          int wave, int lane, Emit emit, DSave dsave, int* bad)
+// One blocked LDL^T sweep (panels of 4 pivots) as seen by wave W: every structural decision (which tiles exist, which are still
+// live at a given panel) is a compile-time constant, the only run-time loop is over the four panels of a tile column.
+// emit(own row w, pan row, pivot column, x, x / d): the entry of the row transformed by L_d^-T and its factor entry.
+template <int NC, int PHASE, int W, class Emit, class DSave>
+__device__ __forceinline__ void ldl_sweep(double4_f (&T)[SolveCfg<NC>::RW][SolveCfg<NC>::NT], double (*pan)[SolveCfg<NC>::PANROWS][4],
+                                          int lane, Emit emit, DSave dsave, int* bad)
 {
+    using C = SolveCfg<NC>;
+    constexpr int NT = C::NT, RW = C::RW;
+    constexpr Deal<NC, PHASE> D{};
     const int kq = lane >> 4, l15 = lane & 15;
-    for (int k = 0; k < npan; ++k) {
-        const int buf = k & 1, tj0 = k >> 2, cb = 4 * (k & 3);
-        if (l15 >= cb && l15 < cb + 4) {
 #pragma unroll
-            for (int u = 0; u < S; ++u)
-                if (sl[u].valid && sl[u].tcol == tj0) {
+    for (int tj0 = 0; tj0 < NT; ++tj0) {
+#pragma unroll 1
+        for (int kk = 0; kk < 4; ++kk) {
+            const int k = 4 * tj0 + kk, buf = k & 1, cb = 4 * kk;
+            if (l15 >= cb && l15 < cb + 4) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pan[buf][sl[u].arow + kq + 4 * r][l15 - cb] = T[u][r];
+                for (int w = 0; w < RW; ++w) {
+                    if (D.rows[W][w].valid && tj0 >= D.rows[W][w].c0 && tj0 <= D.rows[W][w].c1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pan[buf][D.rows[W][w].arow + kq + 4 * r][l15 - cb] = T[w][tj0][r];
+                    }
                 }
-        }
-        __syncthreads();
-        double a[4][4];
+            }
+            __syncthreads();
+            double a[4][4];
 #pragma unroll
-        for (int ra = 0; ra < 4; ++ra) {
-            const double2* pr = reinterpret_cast<const double2*>(pan[buf][4 * k + ra]);
-            const double2 u0 = pr[0], u1 = pr[1];
-            a[ra][0] = u0.x; a[ra][1] = u0.y; a[ra][2] = u1.x; a[ra][3] = u1.y;
-        }
-        // 4x4 LDL^T of the diagonal block (every lane, uniform data)
-        const double p0 = a[0][0], r0 = fast_rcp(p0);
-        const double l10 = a[1][0] * r0, l20 = a[2][0] * r0, l30 = a[3][0] * r0;
-        const double p1 = a[1][1] - l10 * a[1][0], r1 = fast_rcp(p1);
-        const double t21 = a[2][1] - l20 * a[1][0], t31 = a[3][1] - l30 * a[1][0];
-        const double l21 = t21 * r1, l31 = t31 * r1;
-        const double p2 = a[2][2] - l20 * a[2][0] - l21 * t21, r2 = fast_rcp(p2);
-        const double t32 = a[3][2] - l30 * a[2][0] - l31 * t21;
-        const double l32 = t32 * r2;
-        const double p3 = a[3][3] - l30 * a[3][0] - l31 * t31 - l32 * t32, r3 = fast_rcp(p3);
-        const double dsel = kq == 0 ? r0 : (kq == 1 ? r1 : (kq == 2 ? r2 : r3));
-        if (!(p0 > 0.0) || !(p1 > 0.0) || !(p2 > 0.0) || !(p3 > 0.0)) *bad = 1;
-        if (wave == 0 && lane < 4) dsave(k, lane, lane == 0 ? r0 : (lane == 1 ? r1 : (lane == 2 ? r2 : r3)));
-        auto xrow = [&](int row) {              // entry kq of (pan row) L_d^-T
-            const double2* pr = reinterpret_cast<const double2*>(pan[buf][row]);
-            const double2 u0 = pr[0], u1 = pr[1];
-            const double x0 = u0.x;
-            const double x1 = u0.y - l10 * x0;
-            const double x2 = u1.x - l20 * x0 - l21 * x1;
-            const double x3 = u1.y - l30 * x0 - l31 * x1 - l32 * x2;
-            return kq == 0 ? x0 : (kq == 1 ? x1 : (kq == 2 ? x2 : x3));
-        };
-        // the factor entries of this panel: row tiles are dealt to the waves
-        for (int t = wave; t < nrowtiles; t += NW) {
-            const int row = 16 * t + l15;
-            if (row < np_rows && row < 4 * k) continue;      // finished matrix rows: L is zero above the diagonal
-            const double x = xrow(row);
-            emit(t, row, 4 * k + kq, tj0, x, x * dsel);
-        }
-        // trailing update: T(ti, tj) -= X_i D^-1 X_j^T
+            for (int ra = 0; ra < 4; ++ra) {
+                const double2* pr = reinterpret_cast<const double2*>(pan[buf][4 * k + ra]);
+                const double2 u0 = pr[0], u1 = pr[1];
+                a[ra][0] = u0.x; a[ra][1] = u0.y; a[ra][2] = u1.x; a[ra][3] = u1.y;
+            }
+            // inverse of the SPD 4x4 pivot block [[E, F], [F^T, G]] by 2x2 blocks (every lane, uniform data): two dependent reciprocals
+            const double e00 = a[0][0], e10 = a[1][0], e11 = a[1][1];
+            const double f00 = a[2][0], f01 = a[3][0], f10 = a[2][1], f11 = a[3][1];          // F[i][j] = block(i, 2 + j) = a[2 + j][i]
+            const double g00 = a[2][2], g10 = a[3][2], g11 = a[3][3];
+            const double detE = e00 * e11 - e10 * e10, rE = fast_rcp(detE);
+            const double ei00 = e11 * rE, ei10 = -e10 * rE, ei11 = e00 * rE;                   // E^-1
+            const double h00 = ei00 * f00 + ei10 * f10, h01 = ei00 * f01 + ei10 * f11;         // H = E^-1 F
+            const double h10 = ei10 * f00 + ei11 * f10, h11 = ei10 * f01 + ei11 * f11;
+            const double s00 = g00 - (f00 * h00 + f10 * h10), s10 = g10 - (f01 * h00 + f11 * h10), s11 = g11 - (f01 * h01 + f11 * h11);   // S = G - F^T H
+            const double detS = s00 * s11 - s10 * s10, rS = fast_rcp(detS);
+            const double si00 = s11 * rS, si10 = -s10 * rS, si11 = s00 * rS;                   // S^-1
+            if (!(e00 > 0.0) || !(detE > 0.0) || !(s00 > 0.0) || !(detS > 0.0)) *bad = 1;
+            const double q00 = h00 * si00 + h01 * si10, q01 = h00 * si10 + h01 * si11;         // Q = H S^-1
+            const double q10 = h10 * si00 + h11 * si10, q11 = h10 * si10 + h11 * si11;
+            // block^-1 = [[E^-1 + Q H^T, -Q], [-Q^T, S^-1]]
+            const double v00 = ei00 + q00 * h00 + q01 * h01, v10 = ei10 + q10 * h00 + q11 * h01, v11 = ei11 + q10 * h10 + q11 * h11;
+            // column kq of the inverse: this lane's coefficients for (row) block^-1
+            const double c0 = kq == 0 ? v00 : (kq == 1 ? v10 : (kq == 2 ? -q00 : -q01));
+            const double c1 = kq == 0 ? v10 : (kq == 1 ? v11 : (kq == 2 ? -q10 : -q11));
+            const double c2 = kq == 0 ? -q00 : (kq == 1 ? -q10 : (kq == 2 ? si00 : si10));
+            const double c3 = kq == 0 ? -q01 : (kq == 1 ? -q11 : (kq == 2 ? si10 : si11));
+            if (W == 0 && lane < 16) {                      // the inverse block, row-major 4x4, for the s^2 D^-1 term
+                const int bi = lane >> 2, bj = lane & 3;
+                const double col0 = bj == 0 ? v00 : (bj == 1 ? v10 : (bj == 2 ? -q00 : -q01));
+                const double col1 = bj == 0 ? v10 : (bj == 1 ? v11 : (bj == 2 ? -q10 : -q11));
+                const double col2 = bj == 0 ? -q00 : (bj == 1 ? -q10 : (bj == 2 ? si00 : si10));
+                const double col3 = bj == 0 ? -q01 : (bj == 1 ? -q11 : (bj == 2 ? si10 : si11));
+                dsave(16 * k + lane, bi == 0 ? col0 : (bi == 1 ? col1 : (bi == 2 ? col2 : col3)));
+            }
+            auto xinv = [&](int row) {                      // entry kq of (pan row) block^-1
+                const double2* pr = reinterpret_cast<const double2*>(pan[buf][row]);
+                const double2 u0 = pr[0], u1 = pr[1];
+                return fma(u1.y, c3, fma(u1.x, c2, fma(u0.y, c1, u0.x * c0)));
+            };
+            double xb[NT], xa[RW];
 #pragma unroll
-        for (int u = 0; u < S; ++u) {
-            if (sl[u].valid && sl[u].tcol >= tj0 && (sl[u].rt < 0 || sl[u].rt <= tj0)) {
-                const int ra = sl[u].arow + l15, rb = 16 * sl[u].tcol + l15;
-                double xa = xrow(ra), xb = -xrow(rb) * dsel;
-                if (ra < np_rows && ra <= 4 * k + 3) xa = 0.0;      // pivot rows and everything above: finished
-                if (rb <= 4 * k + 3) xb = 0.0;
-                T[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, xb, T[u], 0, 0, 0);
+            for (int c = tj0; c < NT; ++c) {               // B operands: -(matrix rows of the live column tiles) block^-1
+                const int rb = 16 * c + l15;
+                const double x = xinv(rb);
+                xb[c] = (c == tj0 && rb <= 4 * k + 3) ? 0.0 : -x;
+            }
+#pragma unroll
+            for (int w = 0; w < RW; ++w) {
+                const bool live = D.rows[W][w].valid && D.rows[W][w].c1 >= tj0 && (D.rows[W][w].kind != 2 || D.rows[W][w].rt <= tj0);
+                xa[w] = 0.0;
+                if (live) {
+                    const int ra = D.rows[W][w].arow + l15;
+                    const double x = pan[buf][ra][kq];      // A operand: the row's panel entries as they are
+                    if (D.rows[W][w].kind != 0 || ra >= 4 * k) emit(w, ra, 4 * k + kq, k, x, xinv(ra));
+                    xa[w] = (D.rows[W][w].kind == 0 && ra <= 4 * k + 3) ? 0.0 : x;      // pivot rows and everything above: finished
+                }
+            }
+            // trailing update: T(row, c) -= R_row block^-1 R_c^T
+#pragma unroll
+            for (int w = 0; w < RW; ++w) {
+                const bool live = D.rows[W][w].valid && (D.rows[W][w].kind != 2 || D.rows[W][w].rt <= tj0);
+#pragma unroll
+                for (int c = tj0; c < NT; ++c)
+                    if (live && c >= D.rows[W][w].c0 && c <= D.rows[W][w].c1)
+                        T[w][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[w], xb[c], T[w][c], 0, 0, 0);
             }
         }
     }
@@ -114,166 +174,215 @@ __device__ __forceinline__ void ldl_sweep(double4_f (&T)[S], const Slot (&sl)[S]
 }
 
 template <int NC>
-__global__ __launch_bounds__(256) void k_info_solve(
+struct SolveArgs {
+    const double* P; const int* sCol; double *X, *Y; double (*pan)[SolveCfg<NC>::PANROWS][4]; double *sD1inv, *sD2inv;
+    const double* Apart; const int* chunk_used; int G, rstride, bl, ncol, ld, lane; double var;
+};
+
+// Everything wave W does between the set-up and the final product: both factorisations and the two products in between.
+template <int NC, int W>
+__device__ __forceinline__ void solve_wave(const SolveArgs<NC>& a, int* bad)
+{
+    using C = SolveCfg<NC>;
+    constexpr int NT = C::NT, NP = C::NP, R1ROWS = C::R1ROWS, RW = C::RW, LDM = C::LDM, MROWS = C::MROWS, NTH = 64 * C::NW;
+    constexpr Deal<NC, 1> D1{};
+    constexpr Deal<NC, 2> D2{};
+    static_assert(D1.fits() && D2.fits(), "a wave would own more tile rows than RW");
+    const int lane = a.lane, kq = lane >> 4, l15 = lane & 15, ncol = a.ncol, ld = a.ld;
+    double* X = a.X; double* Y = a.Y;
+    double4_f T[RW][NT];
+    // The A fragments of this wave's [A ; b^T] tile rows (product R1 = [A ; b^T] L below): the loads are issued now and
+    // complete under factorisation 1.  A is exactly symmetric (k_feat_gram2 builds both halves from the same sums): element
+    // (row, col) is read at (col, row), which runs along the 16 lanes of a fragment (coalesced); the b row is column ncol.
+    double af[RW][NT][4];
+#pragma unroll
+    for (int w = 0; w < RW; ++w) {
+        if (D2.rows[W][w].valid && D2.rows[W][w].kind == 1) {
+            const int row = 16 * D2.rows[W][w].rt + l15;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int col = 16 * kt + 4 * s + kq;
+                    double v = 0.0;
+                    if (col < ncol && (row < ncol || row == NC)) {      // row NC = b^T
+                        const size_t e = (size_t)col * (ncol + 1) + (row == NC ? ncol : row);
+                        for (int g = 0; g < a.G; ++g) if (a.chunk_used[a.bl * a.G + g]) v += a.Apart[((size_t)a.bl * a.G + g) * a.rstride + e];
+                    }
+                    af[w][kt][s] = v;
+                }
+        }
+    }
+    // ================= factorisation 1: Pcc = L D L^T, identity carried =================
+    {
+        int scol_c[NT], scol_r[RW][4];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) scol_c[c] = a.sCol[16 * c + l15];
+#pragma unroll
+        for (int w = 0; w < RW; ++w)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scol_r[w][r] = a.sCol[(D1.rows[W][w].valid ? 16 * D1.rows[W][w].rt : 0) + kq + 4 * r];
+#pragma unroll
+        for (int w = 0; w < RW; ++w)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                const int col = 16 * c + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * D1.rows[W][w].rt + kq + 4 * r;
+                    double v = row == col ? 1.0 : 0.0;
+                    if (D1.rows[W][w].valid && D1.rows[W][w].kind == 0 && c <= D1.rows[W][w].c1 && row < ncol && col < ncol)
+                        v = a.P[scol_c[c] + (size_t)scol_r[w][r] * ld];          // symmetric: read along the coalesced direction
+                    T[w][c][r] = v;
+                }
+            }
+        auto emit = [&](int w, int row, int col, int k, double x, double xs) {
+            if (D1.rows[W][w].kind == 0) X[row * LDM + col] = row > 4 * k + 3 ? xs : (row == col ? 1.0 : 0.0);   // L: identity pivot blocks
+            else Y[(row - NP) * LDM + col] = xs;                                                             // L^-T D^-1 (upper)
+        };
+        auto dsave = [&](int e, double v) { a.sD1inv[e] = v; };
+        ldl_sweep<NC, 1, W>(T, a.pan, lane, emit, dsave, bad);
+    }
+    dbg_stamp(2);
+    // ================= second matrix W = L^T A L + s^2 D^-1 and its carried rows [A L ; b^T L], L^-T D^-1 =================
+#pragma unroll
+    for (int w = 0; w < RW; ++w)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            T[w][c] = double4_f{ 0.0, 0.0, 0.0, 0.0 };
+            if (D2.rows[W][w].valid && D2.rows[W][w].kind == 2 && c >= D2.rows[W][w].c0) {        // R2 = L^-T D^-1 from factorisation 1
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T[w][c][r] = Y[(16 * D2.rows[W][w].rt + kq + 4 * r) * LDM + 16 * c + l15];
+            }
+        }
+    __syncthreads();                                          // every wave has its R2 tiles: Y may be overwritten
+    // ---- R1 = [A ; b^T ; 0] L  (A symmetric, from the gram partials in global memory; L in X) ----
+#pragma unroll
+    for (int w = 0; w < RW; ++w) {
+        if (D2.rows[W][w].valid && D2.rows[W][w].kind == 1) {
+            constexpr int dummy = 0; (void)dummy;
+            const int i = D2.rows[W][w].rt;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                for (int kt = j; kt < NT; ++kt)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[w][kt][s], X[(16 * kt + 4 * s + kq) * LDM + 16 * j + l15], acc, 0, 0, 0);
+                T[w][j] = acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Y[(16 * i + kq + 4 * r) * LDM + 16 * j + l15] = acc[r];
+            }
+        }
+    }
+    __syncthreads();
+    dbg_stamp(3);
+    // ---- W = L^T (A L) + s^2 D^-1, lower tiles ----
+#pragma unroll
+    for (int w = 0; w < RW; ++w) {
+        if (D2.rows[W][w].valid && D2.rows[W][w].kind == 0) {
+            constexpr int dummy = 0; (void)dummy;
+            const int i = D2.rows[W][w].rt;
+            double4_f acc[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = double4_f{ 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                if (kt >= i) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int kr = 16 * kt + 4 * s + kq;
+                        const double afv = X[kr * LDM + 16 * i + l15];                  // A[i'][k'] = L[k][i]
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            if (j <= i) {
+                                const double bfv = (NC < NP && kr >= NC) ? 0.0 : Y[kr * LDM + 16 * j + l15];   // row NC of Y is b^T L, not a row of A L
+                                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(afv, bfv, acc[j], 0, 0, 0);
+                            }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                if (j <= i) {
+                    if (j == i) {                             // + s^2 D^-1: the 4x4 inverse pivot blocks of factorisation 1
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int rr = kq + 4 * r;        // row within the tile; its pivot block is r (rows 4 r .. 4 r + 3), row kq inside
+                            if ((l15 >> 2) == r) acc[j][r] += a.var * a.sD1inv[16 * (4 * i + r) + 4 * kq + (l15 & 3)];
+                            (void)rr;
+                        }
+                    }
+                    T[w][j] = acc[j];
+                }
+        }
+    }
+    __syncthreads();                                          // X (L) and Y (A L) are dead: they become the outputs of sweep 2
+    dbg_stamp(4);
+    for (int e = W * 64 + lane; e < MROWS * LDM; e += NTH) Y[e] = 0.0;   // R2' is upper triangular by tiles
+    // ================= factorisation 2: W = L2 D2 L2^T with [A L ; b^T L] and L^-T D^-1 carried =================
+    {
+        auto emit = [&](int w, int row, int col, int k, double x, double xs) {
+            if (D2.rows[W][w].kind == 1) X[(row - NP) * LDM + col] = xs;                          // R1' D2^-1
+            else if (D2.rows[W][w].kind == 2) Y[(row - NP - R1ROWS) * LDM + col] = x;             // R2'      (L2 itself is not needed)
+        };
+        auto dsave = [&](int, double) {};
+        ldl_sweep<NC, 2, W>(T, a.pan, lane, emit, dsave, bad);
+    }
+}
+
+template <int NC>
+__global__ __launch_bounds__(512) void k_info_solve(
     CovView cv, FrameView fv, int b0, const double* __restrict__ Apart, const int* __restrict__ chunk_used, int G, int rstride,
     const double* __restrict__ noise_all, double* __restrict__ Mall, int mstride, double* __restrict__ Pcall, int ystride,
     double* __restrict__ dx_all, int* __restrict__ m_out, int* __restrict__ nc_out, int* __restrict__ status,
     const int* __restrict__ marg_idx, int* __restrict__ pc_base_out)
 {
     using Cfg = SolveCfg<NC>;
-    constexpr int NT = Cfg::NT, NP = Cfg::NP, NR1 = Cfg::NR1, R1ROWS = Cfg::R1ROWS, NLT = Cfg::NLT, NW = Cfg::NW;
-    constexpr int S1 = Cfg::S1, S2 = Cfg::S2, LDM = Cfg::LDM, MROWS = Cfg::MROWS, PANROWS = Cfg::PANROWS, MP = Cfg::MP;
+    constexpr int NT = Cfg::NT, NP = Cfg::NP, NR1 = Cfg::NR1, NW = Cfg::NW;
+    constexpr int LDM = Cfg::LDM, MROWS = Cfg::MROWS, PANROWS = Cfg::PANROWS, MP = Cfg::MP, NTH = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* X = reinterpret_cast<double*>(smem_raw);                 // MROWS x LDM: L, later R1' D2^-1
     double* Y = X + (size_t)MROWS * LDM;                             // MROWS x LDM: L^-T D^-1, then A L, later R2'
     double (*pan)[PANROWS][4] = reinterpret_cast<double (*)[PANROWS][4]>(Y + (size_t)MROWS * LDM);
-    double* sD1inv = reinterpret_cast<double*>(pan) + 2 * (size_t)PANROWS * 4;      // NP
-    double* sD2inv = sD1inv + NP;                                                    // NP
-    int* sCol = reinterpret_cast<int*>(sD2inv + NP);                                 // NP
+    double* sD1inv = reinterpret_cast<double*>(pan) + 2 * (size_t)PANROWS * 4;      // NP / 4 inverse pivot blocks, 16 doubles each
+    double* sD2inv = nullptr;
+    int* sCol = reinterpret_cast<int*>(sD1inv + 4 * NP);                             // NP
     __shared__ int sBad;
-    const int bl = blockIdx.x, b = b0 + bl, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int bl = blockIdx.x, b = b0 + bl, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int kq = lane >> 4, l15 = lane & 15;
     const int C = fv.n_clones[b], ncol = 6 * C, n = cv.n[b], ld = cv.ldp;
     double* dx = dx_all + (size_t)b * ld;
     int total = 0;
     for (int g = 0; g < G; ++g) total += chunk_used[bl * G + g];
     if (total == 0) {
-        for (int r = tid; r < n; r += 256) dx[r] = 0.0;
+        for (int r = tid; r < n; r += NTH) dx[r] = 0.0;
         if (tid == 0) { m_out[bl] = 0; nc_out[bl] = ncol; pc_base_out[bl] = -1; }
         return;
     }
     const double* P = cov_ptr(cv, b);
-    const double var = noise_all[bl];
-    for (int c = tid; c < NP; c += 256) { const int cc = c < ncol ? c : 0; sCol[c] = fv.clone_idx[(size_t)b * fv.cmax + cc / 6] + cc % 6; }
-    for (int e = tid; e < 2 * MROWS * LDM; e += 256) X[e] = 0.0;
+    for (int c = tid; c < NP; c += NTH) { const int cc = c < ncol ? c : 0; sCol[c] = fv.clone_idx[(size_t)b * fv.cmax + cc / 6] + cc % 6; }
+    for (int e = tid; e < 2 * MROWS * LDM; e += NTH) X[e] = 0.0;
     if (tid == 0) sBad = 0;
     __syncthreads();
     const bool fused = marg_idx && marg_idx[bl] >= 0;
     const int contig = __syncthreads_and(tid >= ncol || sCol[tid < NP ? tid : 0] == sCol[0] + tid);
     const bool zero_copy = fused && contig && sCol[0] + MP <= ld;
     int bad = 0;
-
-    // ================= factorisation 1: Pcc = L D L^T, identity carried =================
-    {
-        Slot sl[S1];
-        double4_f T[S1];
-#pragma unroll
-        for (int u = 0; u < S1; ++u) {
-            const int p = u * NW + wave;
-            sl[u].valid = p < Cfg::P1;
-            int hi = 0, lo = 0;
-            tri_decode(p < NLT ? p : (p < Cfg::P1 ? p - NLT : 0), hi, lo);
-            const bool carried = p >= NLT;
-            sl[u].arow = carried ? NP + 16 * lo : 16 * hi;      // lower tile (hi, lo) / carried upper tile (row lo, col hi)
-            sl[u].tcol = carried ? hi : lo;
-            sl[u].rt = carried ? lo : -1;
-            const int rt = carried ? lo : hi, ct = sl[u].tcol;
-            const int col = 16 * ct + l15;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * rt + kq + 4 * r;
-                double v = row == col ? 1.0 : 0.0;
-                if (!carried && sl[u].valid && row < ncol && col < ncol) v = P[sCol[col] + (size_t)sCol[row] * ld];   // symmetric: coalesced along l15
-                T[u][r] = v;
-            }
-        }
-        auto emit = [&](int t, int row, int col, int tj0, double x, double xs) {
-            if (row < NP) X[row * LDM + col] = row == col ? 1.0 : (row < col ? 0.0 : xs);   // L (unit lower, exactly)
-            else if (t - NT <= tj0) Y[(row - NP) * LDM + col] = xs;                       // L^-T D^-1 (upper)
-        };
-        auto dsave = [&](int k, int q, double r) { sD1inv[4 * k + q] = r; };
-        ldl_sweep<S1, PANROWS, NW>(T, sl, NP / 4, NP, 2 * NT, pan, wave, lane, emit, dsave, &bad);
+    dbg_stamp(0);
+    SolveArgs<NC> sa{ P, sCol, X, Y, pan, sD1inv, sD2inv, Apart, chunk_used, G, rstride, bl, ncol, ld, lane, noise_all[bl] };
+    switch (wave) {                                           // wave-uniform: every wave runs the code specialised for its tile rows
+    case 0: solve_wave<NC, 0>(sa, &bad); break;
+    case 1: solve_wave<NC, 1>(sa, &bad); break;
+    case 2: solve_wave<NC, 2>(sa, &bad); break;
+    case 3: solve_wave<NC, 3>(sa, &bad); break;
+    case 4: solve_wave<NC, 4>(sa, &bad); break;
+    case 5: solve_wave<NC, 5>(sa, &bad); break;
+    case 6: solve_wave<NC, 6>(sa, &bad); break;
+    default: solve_wave<NC, 7>(sa, &bad); break;
     }
-    // ================= second matrix and its carried rows =================
-    Slot sl[S2];
-    double4_f T[S2];
-#pragma unroll
-    for (int u = 0; u < S2; ++u) {
-        const int p = u * NW + wave;
-        sl[u].valid = p < Cfg::P2;
-        int kind = p < NLT ? 0 : (p < NLT + NR1 * NT ? 1 : 2);
-        int hi = 0, lo = 0;
-        if (kind == 0) tri_decode(p, hi, lo);
-        else if (kind == 2) tri_decode(p < Cfg::P2 ? p - NLT - NR1 * NT : 0, hi, lo);
-        else { hi = (p - NLT) / NT; lo = (p - NLT) % NT; }
-        sl[u].arow = kind == 0 ? 16 * hi : (kind == 1 ? NP + 16 * hi : NP + R1ROWS + 16 * lo);
-        sl[u].tcol = kind == 2 ? hi : lo;
-        sl[u].rt = kind == 2 ? lo : -1;
-        T[u] = double4_f{ 0.0, 0.0, 0.0, 0.0 };
-        if (kind == 2 && sl[u].valid) {                       // R2 = L^-T D^-1 from factorisation 1
-#pragma unroll
-            for (int r = 0; r < 4; ++r) T[u][r] = Y[(16 * lo + kq + 4 * r) * LDM + 16 * hi + l15];
-        }
-    }
-    __syncthreads();                                          // every wave has its R2 tiles: Y may be overwritten
-    // ---- R1 = [A ; b^T ; 0] L  (A symmetric, from the gram partials in global memory; L in X) ----
-    auto Aext = [&](int row, int col) {                       // row NC = b^T
-        double s = 0.0;
-        if (col < ncol && (row < ncol || row == NC)) {
-            const size_t e = row == NC ? (size_t)col * (ncol + 1) + ncol : (size_t)row * (ncol + 1) + col;
-            for (int g = 0; g < G; ++g) if (chunk_used[bl * G + g]) s += Apart[((size_t)bl * G + g) * rstride + e];
-        }
-        return s;
-    };
-#pragma unroll
-    for (int u = 0; u < S2; ++u) {
-        const int p = u * NW + wave;
-        if (sl[u].valid && p >= NLT && p < NLT + NR1 * NT) {
-            const int i = (p - NLT) / NT, j = (p - NLT) % NT;
-            double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
-            for (int kt = j; kt < NT; ++kt) {
-                double af[4], bf[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    af[s] = Aext(16 * i + l15, 16 * kt + 4 * s + kq);
-                    bf[s] = X[(16 * kt + 4 * s + kq) * LDM + 16 * j + l15];
-                }
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bf[s], acc, 0, 0, 0);
-            }
-            T[u] = acc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Y[(16 * i + kq + 4 * r) * LDM + 16 * j + l15] = acc[r];
-        }
-    }
-    __syncthreads();
-    // ---- W = L^T (A L) + s^2 D^-1, lower tiles ----
-#pragma unroll
-    for (int u = 0; u < S2; ++u) {
-        const int p = u * NW + wave;
-        if (sl[u].valid && p < NLT) {
-            const int i = sl[u].arow >> 4, j = sl[u].tcol;
-            double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
-            for (int kt = i; kt < NT; ++kt) {
-                double af[4], bf[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int kr = 16 * kt + 4 * s + kq;
-                    af[s] = X[kr * LDM + 16 * i + l15];                          // A[i'][k'] = L[k][i]
-                    bf[s] = (NC < NP && kr >= NC) ? 0.0 : Y[kr * LDM + 16 * j + l15];      // row NC of Y is b^T L, not a row of A L
-                }
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bf[s], acc, 0, 0, 0);
-            }
-            if (i == j) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (kq + 4 * r == l15) acc[r] += var * sD1inv[16 * i + l15];
-            }
-            T[u] = acc;
-        }
-    }
-    __syncthreads();                                          // X (L) and Y (A L) are dead: they become the outputs of sweep 2
-    for (int e = tid; e < MROWS * LDM; e += 256) Y[e] = 0.0;   // R2' is upper triangular by tiles
-    // ================= factorisation 2: W = L2 D2 L2^T with [A L ; b^T L] and L^-T D^-1 carried =================
-    {
-        auto emit = [&](int t, int row, int col, int tj0, double x, double xs) {
-            if (row < NP) return;                                                          // L2 itself is not needed
-            if (row < NP + R1ROWS) X[(row - NP) * LDM + col] = xs;                        // R1' D2^-1
-            else if (t - NT - NR1 <= tj0) Y[(row - NP - R1ROWS) * LDM + col] = x;         // R2'
-        };
-        auto dsave = [&](int k, int q, double r) { sD2inv[4 * k + q] = r; };
-        ldl_sweep<S2, PANROWS, NW>(T, sl, NP / 4, NP, NT + NR1 + NT, pan, wave, lane, emit, dsave, &bad);
-    }
+    dbg_stamp(5);
     if (bad) sBad = 1;
     // ---- [M | t] = R2' (R1' D2^-1)^T : tile (i, j), j over the NR1 row tiles of R1' (column NC carries t) ----
     double* Mg = Mall + (size_t)bl * mstride;
@@ -299,20 +408,21 @@ __global__ __launch_bounds__(256) void k_info_solve(
             if (col == NC && row < MP) Mg[(size_t)MP * MP + row] = v;
         }
     }
-    if (NC == MP) { /* column NC of M does not exist: nothing to clear */ }
     __syncthreads();
+    dbg_stamp(6);
     if (sBad && tid == 0) atomicOr(&status[b], 4);
     // Pc = P[:, clone cols] for the in-place update (the apply kernel must read the PRE-update columns)
     double* Pc = Pcall + (size_t)bl * ystride;
     if (!zero_copy) {
         const int tx = tid & 63, ty = tid >> 6;
-        for (int k = ty; k < MP; k += 4) {
+        for (int k = ty; k < MP; k += NW) {
             const int gk = k < NP ? sCol[k] : 0;
             const bool real = k < ncol;
             for (int r = tx; r < n; r += 64) Pc[r + (size_t)k * ld] = real ? P[r + (size_t)gk * ld] : 0.0;
         }
     }
     if (tid == 0) { m_out[bl] = ncol; nc_out[bl] = ncol; pc_base_out[bl] = zero_copy ? sCol[0] : -1; }
+    dbg_stamp(7);
 }
 
 }  // namespace
@@ -326,7 +436,7 @@ int launch_info_solve(const FactoredLaunch& L, hipStream_t st)
         const size_t sm = SolveCfg<NC>::lds_bytes();                                                                          \
         static bool attr_set = false;                                                                                         \
         if (!attr_set) { hipFuncSetAttribute((const void*)k_info_solve<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; } \
-        hipLaunchKernelGGL(k_info_solve<NC>, dim3(L.nb), dim3(256), sm, st, L.cv, L.fv, L.b0, L.Apart, L.chunk_used, L.G, L.rstride, \
+        hipLaunchKernelGGL(k_info_solve<NC>, dim3(L.nb), dim3(64 * SolveCfg<NC>::NW), sm, st, L.cv, L.fv, L.b0, L.Apart, L.chunk_used, L.G, L.rstride, \
                            L.noise, L.T, L.mstride, L.Pc, L.ystride, L.dx, L.m_out, L.nc_out, L.status, L.marg_idx, L.pc_base);       \
         return 0;                                                                                                             \
     }
@@ -335,3 +445,5 @@ int launch_info_solve(const FactoredLaunch& L, hipStream_t st)
 #undef SOLVE_DISPATCH
     return 1;
 }
+
+int dbg_read_solve(long long* out, int n) { return dbg_read_local(out, n); }

@@ -35,6 +35,7 @@ struct FactoredLaunch {
 int launch_factored(const FactoredLaunch& L, hipStream_t st);
 // kernels_solve.hip: stage 2 in symmetric (LDL^T) form on the matrix cores; non-zero when the window class is not covered
 int launch_info_solve(const FactoredLaunch& L, hipStream_t st);
+int dbg_read_solve(long long* out, int n);
 int factored_rec_size(int cmax);
 int dbg_read_factored(long long* out, int n);
 
