@@ -70,7 +70,7 @@ __host__ __device__ constexpr int rec_size(int cmax) { return REC_HDR + REC_OBS 
 // The 3x3 (2x2) blocks of K are built one observation pair per lane from nine 3x3 blocks of P
 // and exchanged once through LDS.  Also writes the feature's compact record for k_feat_gram.
 // ---------------------------------------------------------------------------------------------
-template <int CMAX, bool STEREO>
+template <int CMAX, bool STEREO, bool WREC = true>
 struct Gate3Shared {
     static constexpr int D = STEREO ? 3 : 2;
     static constexpr int NPAIR = CMAX * (CMAX + 1) / 2;
@@ -78,7 +78,7 @@ struct Gate3Shared {
     FeatShared<CMAX, STEREO, true> f;
     int cna[CMAX];
     int pfl[CMAX];
-    double recbuf[REC_HDR + REC_OBS * CMAX];      // the feature record, staged: stored once, coalesced, at the very end
+    double recbuf[WREC ? REC_HDR + REC_OBS * CMAX : 8];      // the feature record, staged: stored once, coalesced, at the very end (WREC)
     double Ninv[CMAX][9];
     double u[CMAX][3];
     double rperp[CMAX];
@@ -105,13 +105,16 @@ __device__ __forceinline__ void wave_sync()      // LDS hand-over between the la
 // the per-observation terms) only has one lane of work per window slot / observation; with FPW = 4 wave 0 runs it for
 // four features at once, 16 lanes each (window classes up to 16 clones), instead of four waves issuing the same
 // instructions for 11 lanes each.  The BACK (pair blocks, tile fill, blocked LDL^T) is one wave per feature.
-template <int CMAX, bool STEREO, int FPW>
+// WREC: also write the per-feature record for a gram kernel that reads it (large-window path); the 6 / 11 / 16-clone gram kernel
+// recomputes the few per-observation quantities it needs from the frame inputs instead (k_feat_gram2), so the small-window
+// gate neither builds nor stores a record.
+template <int CMAX, bool STEREO, int FPW, bool WREC = true>
 __device__ __forceinline__ void gate3_body(
     CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out,
     int* __restrict__ accept_out, double* __restrict__ rec_out)
 {
     using Cfg = FeatCfg<CMAX, STEREO>;
-    using SH = Gate3Shared<CMAX, STEREO>;
+    using SH = Gate3Shared<CMAX, STEREO, WREC>;
     constexpr int RPO = Cfg::RPO, D = SH::D, GS = WAVE / FPW;
     static_assert(FPW == 1 || CMAX <= GS, "a lane group must cover the window");
     __shared__ SH sh4[FPW];
@@ -207,7 +210,7 @@ __device__ __forceinline__ void gate3_body(
         double* const rec = sh.recbuf;            // global stores wait in vmcnt with the loads (gfx9): the record is staged
         if (sl == 0) {
             sh.f.nobs = fok ? nobs : 0;
-            if (jok && !fok) { gamma_out[oidx] = __builtin_nan(""); accept_out[oidx] = 0; rec_out[oidx * rec_size(CMAX)] = 0.0; }
+            if (jok && !fok) { gamma_out[oidx] = __builtin_nan(""); accept_out[oidx] = 0; if (WREC) rec_out[oidx * rec_size(CMAX)] = 0.0; }
         }
         wave_sync();
         double* const Nh = sh.nh;
@@ -218,7 +221,7 @@ __device__ __forceinline__ void gate3_body(
             sh.cna[sl] = cn;
             sh.pfl[sl] = pl;
             double* ro = rec + REC_HDR + REC_OBS * sl;
-            ro[0] = so; ro[1] = cn ? 1.0 : 0.0; ro[2] = pl ? 1.0 : 0.0;
+            if (WREC) { ro[0] = so; ro[1] = cn ? 1.0 : 0.0; ro[2] = pl ? 1.0 : 0.0; }
             double N[9], h[3];
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
@@ -228,17 +231,18 @@ __device__ __forceinline__ void gate3_body(
 #pragma unroll
                     for (int q = 0; q < RPO; ++q) sN += sh.f.G[sl][q][m] * sh.f.G[sl][q][m2];
                     N[3 * m + m2] = sN;
-                    ro[3 + 3 * m + m2] = sN;
+                    if (WREC) ro[3 + 3 * m + m2] = sN;
                 }
                 double hh = 0.0;
 #pragma unroll
                 for (int q = 0; q < RPO; ++q) hh += sh.f.G[sl][q][m] * sh.f.res[sl][q];
                 h[m] = hh;
-                ro[12 + m] = hh;
-                Nh[sl * 12 + 9 + m] = hh;
+                if (WREC) { ro[12 + m] = hh; Nh[sl * 12 + 9 + m] = hh; }
             }
+            if (WREC) {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) Nh[sl * 12 + i] = N[i];
+                for (int i = 0; i < 9; ++i) Nh[sl * 12 + i] = N[i];
+            }
             if (STEREO) {
                 double Ni[9];
                 inv3sym(N, Ni);
@@ -257,13 +261,16 @@ __device__ __forceinline__ void gate3_body(
             }
         }
         if (fok && sl == 0) {
-            unsigned long long sm = 0ULL;
-            for (int o = 0; o < nobs; ++o) sm |= 1ULL << sh.f.slot[o];
-            rec[0] = nobs; rec[1] = a; rec[2] = px; rec[3] = py; rec[4] = pz; rec[5] = (double)sm;
+            rec[2] = px; rec[3] = py; rec[4] = pz;                       // the back end reads p_f from here
+            if (WREC) {
+                unsigned long long sm = 0ULL;
+                for (int o = 0; o < nobs; ++o) sm |= 1ULL << sh.f.slot[o];
+                rec[0] = nobs; rec[1] = a; rec[5] = (double)sm;
+            }
         }
         wave_sync();
-        // sums for k_feat_gram2 (this kernel is VALU-bound, the gram kernel latency-bound: the reduction is cheaper here)
-        if (fok) {
+        // sums for the large-window gram kernel
+        if (WREC && fok) {
             for (int cmp = sl; cmp < 21; cmp += GS) {
                 const int anch = cmp >= 12, comp = anch ? cmp - 12 : cmp;
                 double tt[CMAX];
@@ -275,15 +282,15 @@ __device__ __forceinline__ void gate3_body(
                 sums[cmp] = sacc;
             }
         }
-        wave_sync();
-        if (fok) {
+        if (WREC) wave_sync();
+        if (WREC && fok) {
             for (int cmp = sl; cmp < 21; cmp += GS) {
                 double v = sums[cmp];
                 if (cmp < 9) { double Nsi[9]; inv3sym(sums, Nsi); v = Nsi[cmp]; }
                 rec[6 + cmp] = v;
             }
         }
-        wave_sync();
+        if (WREC) wave_sync();
         // ---- Su = D Pcc D^T in 3x3 blocks.  With U_o = P(th_o, th_a), V_o = P(p_o, th_a):
         //        Su[o][o'] = T_oo' - cn' R_o - cn R_o'^T + cn cn' Q
         //        T_oo' = cn cn' X P(th_o,th_o') X^T + cn pl' X^T P(th_o,p_o') + pl cn' P(p_o,th_o') X + pl pl' P(p_o,p_o')
@@ -526,7 +533,7 @@ __device__ __forceinline__ void gate3_body(
             gamma_out[oidx] = g;
             accept_out[oidx] = ok ? 1 : 0;
         }
-        for (int e = tid; e < REC_HDR + REC_OBS * nobs; e += WAVE) rec_g[e] = rec[e];
+        if (WREC) { for (int e = tid; e < REC_HDR + REC_OBS * nobs; e += WAVE) rec_g[e] = rec[e]; }
         return;
     }
 }

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(GATE_FPW * WAVE) __attribute__((amdgpu_waves_per_eu
     CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out,
     int* __restrict__ accept_out, double* __restrict__ rec_out)
 {
-    gate3_body<CMAX, STEREO, GATE_FPW>(cv, fv, op, b0, nb, fmax_used, gamma_out, accept_out, rec_out);
+    gate3_body<CMAX, STEREO, GATE_FPW, false>(cv, fv, op, b0, nb, fmax_used, gamma_out, accept_out, rec_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -60,15 +60,12 @@ struct Gram2Cfg {
     static constexpr int NTILE = TI * TJ;
     static constexpr int NUP = TI * TJ - TI * (TI - 1) / 2;   // tiles (ti <= tj): the rank-3 Gram is symmetric
     static constexpr int TPW = (NUP + 3) / 4;              // accumulator tiles per wave
-    static constexpr int PRE = (GRAM_NB * (REC_HDR + REC_OBS * CMAX) + GRAM_NT - 1) / GRAM_NT;
-    static constexpr int REC = REC_HDR + REC_OBS * CMAX;
     static constexpr int KR = 3 * GRAM_NB;                 // stacked rows per batch
     static constexpr int SPW = 34;                         // per (feature, slot) sparse scratch: S1 NXs S3 (9 each) s4 s5 (3 each) key
 };
 template <int CMAX>
 struct Gram2Batch {
     using Cfg = Gram2Cfg<CMAX>;
-    double rec[GRAM_NB][Cfg::REC];
     double Bm[Cfg::KR][Cfg::LDW];
     double Ym[Cfg::KR][Cfg::LDW];
     double sp[GRAM_NB][CMAX][Cfg::SPW];
@@ -80,14 +77,14 @@ struct Gram2Out {
     double S[CMAX][CMAX][34];                // per (slot, anchor) sparse sums: S1 NXs S3 s4 s5
 };
 
-template <int CMAX>
+template <int CMAX, bool STEREO>
 __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
     FrameView fv, MsckfOpts op, int b0, const int* __restrict__ accept_in, int* __restrict__ used_out,
-    const double* __restrict__ rec_in, double* __restrict__ Apart, int* __restrict__ chunk_used, int G, int rstride)
+    double* __restrict__ Apart, int* __restrict__ chunk_used, int G, int rstride)
 {
     using Cfg = Gram2Cfg<CMAX>;
-    constexpr int NC = Cfg::NC, TJ = Cfg::TJ, LDW = Cfg::LDW, NTILE = Cfg::NTILE, TPW = Cfg::TPW, REC = Cfg::REC, KR = Cfg::KR;
-    constexpr int NUP = Cfg::NUP, TI = Cfg::TI, PRE = Cfg::PRE;
+    constexpr int NC = Cfg::NC, TJ = Cfg::TJ, LDW = Cfg::LDW, NTILE = Cfg::NTILE, TPW = Cfg::TPW, KR = Cfg::KR;
+    constexpr int NUP = Cfg::NUP, TI = Cfg::TI, RPO = STEREO ? 4 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Gram2Batch<CMAX>& sb = *reinterpret_cast<Gram2Batch<CMAX>*>(smem_raw);
     Gram2Out<CMAX>& so = *reinterpret_cast<Gram2Out<CMAX>*>(smem_raw);             // epilogue view of the same LDS
@@ -95,8 +92,13 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
     int* sUse = reinterpret_cast<int*>(smem_raw + ((UNI + 15) / 16) * 16);
     int* sList = sUse + fv.fmax;
     __shared__ int sNu;
+    __shared__ double sPose[16][12];                              // the window's clone poses: R (9, row-major), p (3)
     const int bl = blockIdx.y, b = b0 + bl, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int F = fv.n_feat[b], C = fv.n_clones[b], ncol = 6 * C;
+    for (int e = tid; e < 12 * C; e += GRAM_NT) {
+        const int c = e / 12, q = e - 12 * c;
+        sPose[c][q] = q < 9 ? fv.clone_R[((size_t)b * fv.cmax + c) * 9 + q] : fv.clone_p[((size_t)b * fv.cmax + c) * 3 + q - 9];
+    }
 
     dbg_stamp(32);
     for (int j = tid; j < F; j += GRAM_NT) {                    // RemoveLostUpdate.cpp:357-359
@@ -149,46 +151,95 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
     for (int i = 0; i < 3; ++i) { s4[i] = 0.0; s5[i] = 0.0; }
     const int kq = lane >> 4, l15 = lane & 15;
 
-    double pre[PRE];
-    auto fetch = [&](int qb) {                                  // this thread's share of a batch's records
-        const int nbf = min(GRAM_NB, q1 - qb);
+    // The per-observation quantities (N_o = G_o^T G_o, h_o = G_o^T r_o) are recomputed here from the frame inputs (one projection
+    // per (feature, slot) lane) instead of travelling through a 1.5 KB per-feature record written by the gate kernel: the record
+    // cost 113 MiB of HBM writes + 113 MiB of reads per launch of the 512-filter batch, the recomputation ~25 VALU per feature.
+    // Lane (f, c) = (tid >> 4, tid & 15) of the first 16 GRAM_NB threads; its raw inputs for the NEXT batch are fetched into
+    // registers while the matrix cores run the current one.
+    double in_uv[4], in_pf[3];
+    unsigned long long in_mask = 0ULL;
+    int in_anchor = 0;
+    auto fetch = [&](int qb) {
+        const int f = tid >> 4, c = tid & 15;
+        in_mask = 0ULL; in_anchor = 0;
 #pragma unroll
-        for (int u = 0; u < PRE; ++u) {
-            const int e = tid + u * GRAM_NT, f = e / REC, w = e - f * REC;
-            pre[u] = (qb < q1 && e < nbf * REC) ? rec_in[((size_t)b * fv.fmax + sList[qb + f]) * REC + w] : 0.0;
+        for (int i = 0; i < 4; ++i) in_uv[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) in_pf[i] = 0.0;
+        if (tid < GRAM_NB * 16 && qb + f < q1) {
+            const size_t oidx = (size_t)b * fv.fmax + sList[qb + f];
+            in_mask = fv.obs_mask[oidx]; in_anchor = fv.anchor[oidx];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) in_pf[i] = fv.pf[oidx * 3 + i];
+            if (c < C && ((in_mask >> c) & 1ULL)) {
+                const double* z = fv.uv + (oidx * fv.cmax + c) * 4;
+                in_uv[0] = z[0]; in_uv[1] = z[1];
+                if (STEREO) { in_uv[2] = z[2]; in_uv[3] = z[3]; }
+            }
         }
+    };
+    auto sum16 = [](double v) {                                  // over the 16 lanes of a feature
+        v += __shfl_xor(v, 8, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 1, 16);
+        return v;
     };
     fetch(q0);
     for (int qb = q0; qb < q1; qb += GRAM_NB) {
         const int nbf = min(GRAM_NB, q1 - qb);
         dbg_stamp(34);
-        // ---- P0: records (prefetched into registers during the previous batch's MFMA phase) ---------------
-#pragma unroll
-        for (int u = 0; u < PRE; ++u) { const int e = tid + u * GRAM_NT; if (e < nbf * REC) (&sb.rec[0][0])[e] = pre[u]; }
         if (nbf < GRAM_NB) {                                   // short last batch: clear the unused stacked rows
             for (int e = tid; e < (KR - 3 * nbf) * LDW; e += GRAM_NT) { (&sb.Bm[3 * nbf][0])[e] = 0.0; (&sb.Ym[3 * nbf][0])[e] = 0.0; }
         }
-        __syncthreads();
         dbg_stamp(35);
         // ---- P2: operand rows B, Y = Ns^-1 B and the sparse scratch, lane = (feature, window slot) -----
         if (tid < nbf * 16) {
             const int f = tid >> 4, c = tid & 15;
-            if (c < C) {
-                const double* rc = sb.rec[f];
-                const int a = (int)rc[1];
-                const double px = rc[2], py = rc[3], pz = rc[4];
-                const unsigned mask = (unsigned)rc[5];
-                const bool obs = (mask >> c) & 1u;
-                const int o = __popc(mask & ((1u << c) - 1u));
-                const double* ro = rc + REC_HDR + REC_OBS * (obs ? o : 0);
-                const double* Nsi = rc + 6;                          // Ns^-1, hs, Nsa from the gate kernel
-                const double* hs = rc + 15;
-                const double* Nsa = rc + 18;
-                double Bt[9], Bp[9], NX[9];
-                const double cn = (obs && ro[1] != 0.0) ? 1.0 : 0.0, pl = (obs && ro[2] != 0.0) ? 1.0 : 0.0;
-                mulX(ro + 3, px, py, pz, NX);                       // N_o X
+            const int a = in_anchor;
+            const double px = in_pf[0], py = in_pf[1], pz = in_pf[2];
+            bool obs = c < C && ((in_mask >> c) & 1ULL);
+            double N[9], h[3];
 #pragma unroll
-                for (int i = 0; i < 9; ++i) { Bt[i] = cn * NX[i]; Bp[i] = -pl * ro[3 + i]; }
+            for (int i = 0; i < 9; ++i) N[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) h[i] = 0.0;
+            if (obs) {                                          // RemoveLostUpdate.cpp:435-506 for this (feature, clone)
+                double Gm[RPO][3], rs[RPO];
+                obs = feat_obs<STEREO>(sPose[c], sPose[c] + 9, in_uv, px, py, pz, op, Gm, rs);      // false: skipped by the NaN guard (:486)
+                if (obs) {
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+#pragma unroll
+                        for (int m2 = 0; m2 < 3; ++m2) {
+                            double sN = 0.0;
+#pragma unroll
+                            for (int q = 0; q < RPO; ++q) sN += Gm[q][m] * Gm[q][m2];
+                            N[3 * m + m2] = sN;
+                        }
+                        double hh = 0.0;
+#pragma unroll
+                        for (int q = 0; q < RPO; ++q) hh += Gm[q][m] * rs[q];
+                        h[m] = hh;
+                    }
+                }
+            }
+            const double cn = (obs && c != a) ? 1.0 : 0.0, pl = (obs && !(op.selected_variant && c == a)) ? 1.0 : 0.0;
+            // Ns = sum_o N_o (= Hf^T Hf), hs = sum_o h_o, Nsa = sum over the observations whose clone is not the anchor
+            double Ns[9], hs[3], Nsa[9];
+            {
+                const double n0 = sum16(N[0]), n1 = sum16(N[1]), n2 = sum16(N[2]), n4 = sum16(N[4]), n5 = sum16(N[5]), n8 = sum16(N[8]);
+                Ns[0] = n0; Ns[1] = n1; Ns[2] = n2; Ns[3] = n1; Ns[4] = n4; Ns[5] = n5; Ns[6] = n2; Ns[7] = n5; Ns[8] = n8;
+                const double a0 = sum16(cn * N[0]), a1 = sum16(cn * N[1]), a2 = sum16(cn * N[2]), a4 = sum16(cn * N[4]), a5 = sum16(cn * N[5]),
+                             a8 = sum16(cn * N[8]);
+                Nsa[0] = a0; Nsa[1] = a1; Nsa[2] = a2; Nsa[3] = a1; Nsa[4] = a4; Nsa[5] = a5; Nsa[6] = a2; Nsa[7] = a5; Nsa[8] = a8;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) hs[i] = sum16(h[i]);
+            }
+            if (c < C) {
+                double Nsi[9];
+                inv3sym(Ns, Nsi);
+                double Bt[9], Bp[9], NX[9];
+                mulX(N, px, py, pz, NX);                            // N_o X
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { Bt[i] = cn * NX[i]; Bp[i] = -pl * N[i]; }
                 if (c == a) {                                       // theta_anchor block: -Nsa X   (the anchor's own cn is 0)
                     double T[9];
                     mulX(Nsa, px, py, pz, T);
@@ -217,13 +268,13 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
                 mulXt(NX, px, py, pz, S1);                          // X^T N X
 #pragma unroll
                 for (int i = 0; i < 9; ++i) { sp[i] = cn * S1[i]; sp[9 + i] = cn * pl * NX[i]; }
-                sp[18] = cn * (pz * ro[13] - py * ro[14]);          // X^T h_o = h_o x p_f
-                sp[19] = cn * (px * ro[14] - pz * ro[12]);
-                sp[20] = cn * (py * ro[12] - px * ro[13]);
+                sp[18] = cn * (pz * h[1] - py * h[2]);              // X^T h_o = h_o x p_f
+                sp[19] = cn * (px * h[2] - pz * h[0]);
+                sp[20] = cn * (py * h[0] - px * h[1]);
 #pragma unroll
-                for (int i = 0; i < 9; ++i) sp[21 + i] = pl * ro[3 + i];                 // pl N_o
+                for (int i = 0; i < 9; ++i) sp[21 + i] = pl * N[i];                      // pl N_o
 #pragma unroll
-                for (int i = 0; i < 3; ++i) sp[30 + i] = pl * ro[12 + i];                // pl h_o
+                for (int i = 0; i < 3; ++i) sp[30 + i] = pl * h[i];                      // pl h_o
                 sp[33] = obs ? (double)a : -1.0;                       // key: the anchor slot this contribution belongs to
             }
         }
@@ -732,11 +783,11 @@ static void launch_ft(const FactoredLaunch& L, hipStream_t st)
         const size_t sm = ((uni + 15) / 16) * 16 + 2 * sizeof(int) * (size_t)L.fv.fmax;
         static size_t attr_sm = 0;
         if (sm > attr_sm) {
-            hipFuncSetAttribute((const void*)k_feat_gram2<CMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            hipFuncSetAttribute((const void*)k_feat_gram2<CMAX, STEREO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
             attr_sm = sm;
         }
-        hipLaunchKernelGGL((k_feat_gram2<CMAX>), dim3(L.G, L.nb), dim3(GRAM_NT), sm, st,
-                           L.fv, L.op, L.b0, L.accept, L.used, L.rec, L.Apart, L.chunk_used, L.G, L.rstride);
+        hipLaunchKernelGGL((k_feat_gram2<CMAX, STEREO>), dim3(L.G, L.nb), dim3(GRAM_NT), sm, st,
+                           L.fv, L.op, L.b0, L.accept, L.used, L.Apart, L.chunk_used, L.G, L.rstride);
     }
 }
 
