@@ -107,4 +107,126 @@ int GnssUpdate::updateTrackedSys(std::shared_ptr<State> state, const GnssResidua
     return used;
 }
 
+// ---- the GNSS epoch path ------------------------------------------------------------------------------------------------
+static Mat3d rotZ(double yaw)           // GnssManager::calcRw2enu (GnssManager.cpp:57-60): AngleAxisd(yaw, UnitZ)
+{
+    Mat3d R = Mat3d::Identity();
+    R(0, 0) = std::cos(yaw); R(0, 1) = -std::sin(yaw); R(1, 0) = std::sin(yaw); R(1, 1) = std::cos(yaw);
+    return R;
+}
+
+void GnssUpdate::checkYofStatus(std::shared_ptr<State> state, const GvioAlignment& aligner)
+{
+    if (!state->_state_params._enable_gnss || !aligner.isAlign()) return;
+    if (state->_gnss.find(State::YOF) == state->_gnss.end())
+        StateManager::addGNSSVariable(state, State::YOF, aligner.yaw_offset, state->_state_params._init_cov_yof);      // :40-43
+}
+
+GnssResiduals GnssUpdate::residualsAt(std::shared_ptr<State> state, const GnssMeas& gm, const GvioAlignment& al, const double* cb_override,
+                                      const double* fs_override)
+{
+    const double yo = state->_gnss.count(State::YOF) ? state->_gnss.at(State::YOF)->value() : 0.0;
+    const Mat3d Rw2enu = rotZ(yo);
+    const Vec3d rcv = al.R_enu2ecef * (Rw2enu * state->_extended_pose->valueTrans1()) + al.anchor_ecef;              // :102 getTenu2ecef * calcTw2enu * p
+    double xyzt[7] = { rcv[0], rcv[1], rcv[2], 0, 0, 0, 0 };
+    for (int s = 0; s < 4; ++s) {                                                                                     // getClockbiasVec
+        auto it = state->_gnss.find(s);
+        if (it != state->_gnss.end()) xyzt[3 + s] = it->second->value();
+        if (cb_override && cb_override[s] == cb_override[s]) xyzt[3 + s] = cb_override[s];
+    }
+    const Vec3d vel = al.R_enu2ecef * (Rw2enu * state->_extended_pose->valueTrans2());                               // :108
+    double dopp[4] = { vel[0], vel[1], vel[2], state->_gnss.count(State::FS) ? state->_gnss.at(State::FS)->value() : 0.0 };
+    if (fs_override) dopp[3] = *fs_override;
+    GnssResiduals g;
+    std::vector<double> az, el;
+    gnss::psr_res(xyzt, gm.sats, g.res_pos, g.unit_rv2sv, az, el);
+    gnss::dopp_res(dopp, rcv, gm.sats, g.res_vel);
+    for (size_t i = 0; i < gm.sats.size(); ++i) {
+        g.sys.push_back(gm.sats[i].sys);
+        g.sin_el.push_back(std::sin(el[i]));
+        g.ura.push_back(gm.sats[i].ura); g.psr_std.push_back(gm.sats[i].psr_std);
+        g.dopp_std_mps.push_back(gm.sats[i].dopp_std * gnss::LIGHT_SPEED / gm.sats[i].freq);                      // :253
+    }
+    g.R_w2ecef = al.R_enu2ecef * Rw2enu;                                                                              // :141
+    return g;
+}
+
+int GnssUpdate::updateTrackedSys(std::shared_ptr<State> state, const GnssMeas& gm, const GvioAlignment& al)
+{
+    if (!state->_state_params._enable_gnss || !al.isAlign()) return 0;                                              // :89-90
+    if (gm.sats.empty()) return 0;
+    if (state->_gnss.find(State::YOF) == state->_gnss.end() || state->_gnss.find(State::FS) == state->_gnss.end()) return 0;   // checkGnssStates
+    bool any = false;
+    for (int s = 0; s < 4; ++s) any = any || state->_gnss.count(s);
+    if (!any) return 0;
+    return updateTrackedSys(state, residualsAt(state, gm, al));
+}
+
+void GnssUpdate::removeUntrackedSys(std::shared_ptr<State> state, const GnssMeas& gm)
+{
+    if (!state->_state_params._enable_gnss) return;
+    std::unordered_set<int> sys;                                                                                     // getSysInGnssMeas :47-63
+    sys.insert(State::YOF);
+    for (const auto& o : gm.sats) sys.insert(o.sys);
+    if (sys.size() > 1) sys.insert(State::FS);
+    std::vector<int> to_marg;
+    for (const auto& kv : state->_gnss) if (!sys.count(kv.first)) to_marg.push_back(kv.first);
+    for (int g : to_marg) StateManager::margGNSSVariable(state, (State::GNSSType)g);
+}
+
+// addNewTrackedSys (:319-469): every clock state the SPP fix knows about and the filter does not yet carry is initialised from
+// the rows of its constellation by StateManager::addVariableDelayed (Givens QR, chi^2 on the rows below, EKF update).
+int GnssUpdate::addNewTrackedSys(std::shared_ptr<State> state, const GnssMeas& gm, const SppMeas& spp, const GvioAlignment& al)
+{
+    if (!state->_state_params._enable_gnss || !al.isAlign()) return 0;
+    if (gm.sats.empty()) return 0;
+    if (state->_gnss.find(State::YOF) == state->_gnss.end()) return 0;
+    std::vector<int> to_add;                                                                                         // getSysInSppMeas / calcSysToAdd
+    if (std::fabs(spp.velSpp[3]) > 1e-03 && !state->_gnss.count(State::FS)) to_add.push_back(State::FS);
+    for (int i = 0; i < 4; ++i) if (std::fabs(spp.posSpp[3 + i]) > 1e-03 && !state->_gnss.count(i)) to_add.push_back(i);
+    if (to_add.empty()) return 0;
+    const double nan = std::nan("");
+    double cb_over[4] = { nan, nan, nan, nan };
+    bool add_fs = false;
+    for (int g : to_add) { if (g == State::FS) add_fs = true; else cb_over[g] = spp.posSpp[3 + g]; }                // :351-356
+    const double fs_val = spp.velSpp[3];
+    if (!add_fs && !state->_gnss.count(State::FS)) std::cout << "[GnssUpdate]: Fs is either added or in the state!" << std::endl;
+    const GnssResiduals g = residualsAt(state, gm, al, cb_over, add_fs ? &fs_val : nullptr);
+    const Vec3d p = state->_extended_pose->valueTrans1(), v = state->_extended_pose->valueTrans2();
+    const Mat3d RSp = g.R_w2ecef * skew(p), RSv = g.R_w2ecef * skew(v);
+    std::vector<std::shared_ptr<Type>> x_order = { state->_extended_pose, state->_gnss.at(State::YOF) };
+    int added = 0;
+    for (int gtype : to_add) {
+        const bool fs = gtype == State::FS;
+        std::vector<int> rows;
+        for (size_t i = 0; i < gm.sats.size(); ++i) if (fs ? (gm.sats[i].sys >= 0 && gm.sats[i].sys <= 3) : gm.sats[i].sys == gtype) rows.push_back((int)i);
+        if (rows.empty()) continue;
+        const int m = (int)rows.size();
+        MatXd Hx(m, 10), Hf(m, 1);
+        VecXd res(m, 0.0);
+        double avg = 0.0;
+        for (int r = 0; r < m; ++r) {
+            const int i = rows[r];
+            const Vec3d& u = g.unit_rv2sv[i];
+            const Mat3d& RS = fs ? RSv : RSp;
+            for (int c = 0; c < 3; ++c) {
+                Hx(r, c) = u[0] * RS(0, c) + u[1] * RS(1, c) + u[2] * RS(2, c);                                     // :389 / :440
+                Hx(r, (fs ? 6 : 3) + c) = -(u[0] * g.R_w2ecef(0, c) + u[1] * g.R_w2ecef(1, c) + u[2] * g.R_w2ecef(2, c));
+            }
+            Hf(r, 0) = 1.0;
+            res[r] = -(fs ? g.res_vel[i] : g.res_pos[i]);
+            double se = g.sin_el[i];
+            if (std::fabs(se) < 1e-6) se = 1e-6;
+            avg += g.ura[i] * (fs ? g.dopp_std_mps[i] : g.psr_std[i]) / (se * se);                                   // :411-418 / :507-514
+        }
+        const double noise = (fs ? _dopp_noise_amp : _psr_noise_amp) * std::sqrt(avg / m);
+        auto var = std::make_shared<Scalar>();
+        var->setValue(fs ? spp.velSpp[3] : spp.posSpp[3 + gtype]);
+        if (!StateManager::addVariableDelayed(state, var, x_order, Hx, Hf, res, noise, 0.95, true)) continue;      // :421 / :463
+        state->_gnss[gtype] = var;
+        ++added;
+    }
+    return added;
+}
+
 }  // namespace ingvio

@@ -7,6 +7,10 @@
 #include <memory>
 #include <vector>
 
+#include <queue>
+#include <unordered_set>
+
+#include "GnssComm.h"
 #include "Mat3.h"
 #include "Update.h"
 
@@ -32,11 +36,66 @@ int gnssCandidateRows(const GnssResiduals& g, const Vec3d& p_w, const Vec3d& v_w
                       int idx_fs, double psr_amp, double dopp_amp, double* H, int ldh, double* res, double* Rd, int* vidx, int* vsize,
                       int* nvar);
 
+// One GNSS epoch as GnssProcessor::callbackGnssMeas hands it on (GnssProcessor.cpp:119-220: valid L1 observations with their
+// ephemerides; here with the satellite states already evaluated) and one SPP fix (GnssSync.h SppMeas).
+struct GnssMeas { double stamp = 0; std::vector<gnss::SatObs> sats; };
+struct SppMeas { double stamp = 0; double posSpp[7] = { 0 }; double velSpp[4] = { 0 }; };      // (ecef xyz, clock biases) / (ecef vel, drift)
+
+// What GnssUpdate reads from GvioAligner (GvioAligner.h: isAlign, getYawOffset, getRenu2ecef, getTenu2ecef); the batch
+// alignment itself (GvioAligner.cpp:199-383) is out of scope: the result is set by the caller.
+struct GvioAlignment {
+    bool aligned = false;
+    double yaw_offset = 0.0;
+    Mat3d R_enu2ecef = Mat3d::Identity();
+    Vec3d anchor_ecef;
+    bool isAlign() const { return aligned; }
+};
+
+// GnssSync (GnssSync.cpp:25-236): bounded FIFO buffers and the pick-by-frame-time rule of getGnssMeasAt / getSppAt.  The
+// ROS-time <-> GNSS-time offset estimation (storeTimePair) is plumbing: stamps are local times here, setSync() marks the
+// buffers usable.
+class GnssSync {
+public:
+    explicit GnssSync(double unsync_thres = 0.05) : _unsync_thres(unsync_thres) {}
+    bool isSync() const { return _isSync; }
+    void setSync(bool s = true) { _isSync = s; }
+    void bufferGnssMeas(const GnssMeas& m) { if (!_isSync) return; while (_gnss.size() > 100) _gnss.pop(); _gnss.push(m); }      // :27-46
+    void bufferSppMeas(const SppMeas& m) { if (!_isSync) return; while (_spp.size() > 100) _spp.pop(); _spp.push(m); }           // :48-68
+    bool getGnssMeasAt(double target_time, GnssMeas& out) { return pick(_gnss, target_time, out); }                                // :136-164
+    bool getSppAt(double target_time, SppMeas& out) { return pick(_spp, target_time, out); }                                        // :166-194
+private:
+    template <class T> bool pick(std::queue<T>& q, double target_time, T& out)
+    {
+        if (!_isSync) return false;
+        while (!q.empty()) {
+            const double g_time = q.front().stamp;
+            if (g_time < target_time - _unsync_thres) { q.pop(); continue; }
+            if (g_time >= target_time + _unsync_thres) break;
+            out = q.front(); q.pop();
+            return true;
+        }
+        return false;
+    }
+    double _unsync_thres;
+    bool _isSync = false;
+    std::queue<GnssMeas> _gnss;
+    std::queue<SppMeas> _spp;
+};
+
 class GnssUpdate : public UpdateBase {
 public:
     GnssUpdate(const IngvioParams& filter_params);
     // returns rows handed to ekfUpdate (0: nothing done)
     int updateTrackedSys(std::shared_ptr<State> state, const GnssResiduals& g);
+    // GnssUpdate.cpp:33-44, :84-293, :319-469 on a GNSS epoch: residuals by the restated psr_res / dopp_res (GnssComm.h), then the
+    // row assembly, gates and update on the device
+    void checkYofStatus(std::shared_ptr<State> state, const GvioAlignment& aligner);
+    int updateTrackedSys(std::shared_ptr<State> state, const GnssMeas& gnss_meas, const GvioAlignment& aligner);
+    int addNewTrackedSys(std::shared_ptr<State> state, const GnssMeas& gnss_meas, const SppMeas& spp_meas, const GvioAlignment& aligner);
+    void removeUntrackedSys(std::shared_ptr<State> state, const GnssMeas& gnss_meas);                    // :65-82
+    // psr_res + dopp_res at the current state (:98-122; `xyzt` / `dopp` may carry SPP values for systems about to be added)
+    GnssResiduals residualsAt(std::shared_ptr<State> state, const GnssMeas& gnss_meas, const GvioAlignment& aligner,
+                              const double* cb_override = nullptr, const double* fs_override = nullptr);
 
 protected:
     double _psr_noise_amp, _dopp_noise_amp;

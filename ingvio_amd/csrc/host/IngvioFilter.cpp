@@ -14,6 +14,26 @@ IngvioFilter::IngvioFilter(const IngvioParams& params, std::shared_ptr<Triangula
     _sw_marg_update = std::make_shared<SwMargUpdate>(_filter_params);
     _keyframe_update = std::make_shared<KeyframeUpdate>(_filter_params);
     _landmark_update = std::make_shared<LandmarkUpdate>(_filter_params);                // :90
+    _gnss_update = std::make_shared<GnssUpdate>(_filter_params);                        // :92-96
+    _gnss_sync = std::make_shared<GnssSync>();
+}
+
+// The GNSS block at the end of both camera callbacks (IngvioFilter.cpp:329-362, :200-233).
+void IngvioFilter::gnssBlock(double stamp)
+{
+    _last_gnss_rows = 0;
+    if (!_filter_params._enable_gnss) return;
+    GnssMeas gnss_meas;
+    SppMeas spp_meas;
+    const bool flag = _gnss_sync->getSppAt(stamp, spp_meas);                            // :336-340
+    if (_gnss_sync->getGnssMeasAt(stamp, gnss_meas)) {
+        // :344-345 batchAlign is out of scope: the alignment is provided by setGnssAlignment()
+        if (_gvio_aligner.isAlign()) {
+            _gnss_update->checkYofStatus(_state, _gvio_aligner);                        // :349
+            _last_gnss_rows = _gnss_update->updateTrackedSys(_state, gnss_meas, _gvio_aligner);      // :353-354
+            if (flag) _gnss_vars_added += _gnss_update->addNewTrackedSys(_state, gnss_meas, spp_meas, _gvio_aligner);   // :356-359
+        }
+    }
 }
 
 void IngvioFilter::callbackIMU(const ImuMsg& m)
@@ -63,6 +83,7 @@ void IngvioFilter::collectMonoMeas(const MonoFrameMsg& f)
 
 void IngvioFilter::callbackStereoFrame(const StereoFrameMsg& frame)
 {
+    if (_filter_params._enable_gnss && !_gnss_sync->isSync()) return;                   // :254-255
     if (!_hasImageCome) { _hasImageCome = true; return; }                               // :257-261
     if (!_hasInitState) return;
     const double target_time = frame.stamp;
@@ -97,11 +118,13 @@ void IngvioFilter::callbackStereoFrame(const StereoFrameMsg& frame)
         _sw_marg_update->margSwPose(_state);
     }
     eraseInvalidFeatures(_map_server, _state);
+    gnssBlock(frame.stamp);
     ++_frames;
 }
 
 void IngvioFilter::callbackMonoFrame(const MonoFrameMsg& frame)
 {
+    if (_filter_params._enable_gnss && !_gnss_sync->isSync()) return;                   // :126-127
     if (!_hasImageCome) { _hasImageCome = true; return; }
     if (!_hasInitState) return;
     const double target_time = frame.stamp;
@@ -136,6 +159,7 @@ void IngvioFilter::callbackMonoFrame(const MonoFrameMsg& frame)
         _sw_marg_update->margSwPose(_state);
     }
     eraseInvalidFeatures(_map_server, _state);
+    gnssBlock(frame.stamp);
     ++_frames;
 }
 

@@ -2,8 +2,10 @@
 // (IngvioFilter.cpp:252-407): callbackIMU / callbackStereoFrame / callbackMonoFrame with POD
 // messages shaped like sensor_msgs/Imu and feature_tracker/{Mono,Stereo}Frame, same early-return logic
 // and the same per-frame orchestration (propagate+clone -> collect -> RemoveLost -> Keyframe|SwMarg ->
-// clean / re-anchor / marginalise -> erase invalid).  ROS, tf, publishers and the GNSS
-// sync/aligner plumbing (IngvioFilter.cpp:50-122, 329-498) are out of scope.
+// clean / re-anchor / marginalise -> erase invalid -> GNSS block (:329-362: pick the epoch of this frame, checkYofStatus,
+// updateTrackedSys, addNewTrackedSys)).  callbackGnssMeas / callbackSppMeas buffer the epochs as GnssProcessor does
+// (GnssProcessor.cpp:119-220).  ROS, tf, publishers, the RINEX / ephemeris handling and GvioAligner::batchAlign are out of
+// scope: the alignment result is set with setGnssAlignment().
 #pragma once
 #include <memory>
 #include <vector>
@@ -30,6 +32,13 @@ public:
     void callbackIMU(const ImuMsg& imu_msg);                                            // IngvioFilter.cpp:381-407
     void callbackStereoFrame(const StereoFrameMsg& stereo_frame);                       // :252-379
     void callbackMonoFrame(const MonoFrameMsg& mono_frame);                             // :124-250
+    void callbackGnssMeas(const GnssMeas& gnss_meas) { _gnss_sync->bufferGnssMeas(gnss_meas); }       // GnssProcessor.cpp:119-220 -> GnssSync
+    void callbackSppMeas(const SppMeas& spp_meas) { _gnss_sync->bufferSppMeas(spp_meas); }
+    void setGnssAlignment(const GvioAlignment& a) { _gvio_aligner = a; }
+    std::shared_ptr<GnssSync> gnssSync() { return _gnss_sync; }
+    std::shared_ptr<GnssUpdate> gnssUpdate() { return _gnss_update; }
+    int lastGnssRows() const { return _last_gnss_rows; }
+    int gnssVarsAdded() const { return _gnss_vars_added; }
 
     std::shared_ptr<State> state() { return _state; }
     std::shared_ptr<MapServer> mapServer() { return _map_server; }
@@ -40,6 +49,7 @@ public:
 protected:
     void collectStereoMeas(const StereoFrameMsg& f);                                    // MapServerManager.cpp:147-217
     void collectMonoMeas(const MonoFrameMsg& f);
+    void gnssBlock(double stamp);                                                       // IngvioFilter.cpp:329-362 / :200-233
     IngvioParams _filter_params;
     std::shared_ptr<State> _state;
     std::shared_ptr<ImuPropagator> _imu_propa;
@@ -49,6 +59,10 @@ protected:
     std::shared_ptr<SwMargUpdate> _sw_marg_update;
     std::shared_ptr<KeyframeUpdate> _keyframe_update;
     std::shared_ptr<LandmarkUpdate> _landmark_update;
+    std::shared_ptr<GnssUpdate> _gnss_update;
+    std::shared_ptr<GnssSync> _gnss_sync;
+    GvioAlignment _gvio_aligner;
+    int _last_gnss_rows = 0, _gnss_vars_added = 0;
     bool _hasImageCome = false, _hasInitState = false;
     int _frames = 0;
 };

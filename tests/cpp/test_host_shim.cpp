@@ -589,6 +589,138 @@ static void testFilterEndToEnd()
     }
 }
 
+
+// BASELINE config 3 through the callback surface: IMU + stereo frames + one GNSS epoch per frame (8 satellites: GPS x4, BDS x2,
+// GAL x2; pseudo-range and Doppler), gnss_chi2_test on.  IngvioFilter.cpp:329-362: the epoch of the frame is picked from the
+// GnssSync buffer, checkYofStatus adds the yaw offset, addNewTrackedSys initialises FS and the clock biases from the SPP fix by
+// delayed initialisation, updateTrackedSys runs the 16 candidate rows (per-row gates + update on the device).  One satellite
+// carries a gross pseudo-range error in every epoch: the per-row gate must refuse exactly that row.
+static void testFilterGnssEndToEnd()
+{
+    for (int strong = 0; strong <= 1; ++strong) {
+        IngvioParams fp = params();
+        fp._enable_gnss = 1; fp._max_sw_clones = 11; fp._is_key_frame = 0; fp._init_imu_buffer_sp = -1; fp._visual_noise = 0.08;
+        fp._hip_f_max = 64; fp._hip_n_max = 21 + 6 + 6 * 13 + 16; fp._max_lm_feats = 0;
+        fp._init_cov_rot = 0.01; fp._init_cov_pos = 0.01;
+        fp._is_gnss_chi2_test = 1; fp._is_gnss_strong_reject = strong;
+        auto tri = std::make_shared<Triangulator>(fp);
+        IngvioFilter filter(fp, tri);
+        auto state = filter.state();
+        double t = 0.0;
+        state->initStateAndCov(t, quatFromRot(Truth::R(t)), Truth::p(t), Truth::v(t), Vec3d(), Vec3d());
+        struct Peek : public IngvioFilter { using IngvioFilter::_hasInitState; };
+        static_cast<Peek*>(static_cast<IngvioFilter*>(&filter))->_hasInitState = true;
+        // geometry of the GNSS side: local ENU at (31 N, 121.4 E), world = ENU rotated by the yaw offset
+        const double yo_true = 0.3;
+        const Vec3d lla(31.0, 121.4, 30.0);
+        GvioAlignment al; al.aligned = true; al.yaw_offset = yo_true + 0.01; al.R_enu2ecef = gnss::geo2rotation(lla); al.anchor_ecef = gnss::geo2ecef(lla);
+        Mat3d Rz = Mat3d::Identity(); Rz(0, 0) = std::cos(yo_true); Rz(0, 1) = -std::sin(yo_true); Rz(1, 0) = std::sin(yo_true); Rz(1, 1) = std::cos(yo_true);
+        const Mat3d Rw2ecef = al.R_enu2ecef * Rz;
+        filter.gnssSync()->setSync();
+        filter.setGnssAlignment(al);
+        const int ns = 8; const int sysv[8] = { 0, 0, 0, 0, 3, 3, 2, 2 };
+        const double cb0[4] = { 150.0, 0.0, 165.0, 180.0 }, fs_true = 5.0;
+        std::vector<Vec3d> sv_pos(ns), sv_vel(ns);
+        for (int i = 0; i < ns; ++i) {
+            const double el = (25 + 50.0 * i / ns) * M_PI / 180, az = 2 * M_PI * (i * 0.37 + 0.1);
+            const Vec3d dir(std::cos(el) * std::sin(az), std::cos(el) * std::cos(az), std::sin(el));
+            sv_pos[i] = al.anchor_ecef + al.R_enu2ecef * (dir * 2.2e7);
+            sv_vel[i] = al.R_enu2ecef * Vec3d(2500.0 * std::cos(az), -2500.0 * std::sin(az), 300.0 * (i % 3 - 1));
+        }
+        std::normal_distribution<double> gn(0.0, 1.0);
+        struct Live { int id; Vec3d pw; int born; };
+        std::vector<Live> live;
+        int next_id = 0, epochs_used = 0, rows_min = 100, rows_max = 0;
+        const Iso3 Tlr = state->_state_params._T_cl2cr;
+        for (int f = 0; f <= 40; ++f) {
+            for (int k = 0; k < 10; ++k) {
+                t += 0.005;
+                const Mat3d R = Truth::R(t);
+                const Vec3d aw(-0.16 * 5 * std::cos(0.4 * t), -0.16 * 5 * std::sin(0.4 * t), 9.8);
+                const Vec3d gy = R.transpose() * Vec3d(0, 0, 0.4) + Vec3d(gn(rng), gn(rng), gn(rng)) * 0.004;
+                const Vec3d ac = R.transpose() * aw + Vec3d(gn(rng), gn(rng), gn(rng)) * 0.08;
+                ImuMsg m; m.stamp = t; for (int i = 0; i < 3; ++i) { m.gyro[i] = gy[i]; m.accel[i] = ac[i]; }
+                filter.callbackIMU(m);
+            }
+            // the GNSS epoch of this frame time, generated from the TRUE receiver state with the formulas psr_res / dopp_res invert
+            const Vec3d rcv = Rw2ecef * Truth::p(t) + al.anchor_ecef, vel = Rw2ecef * Truth::v(t);
+            GnssMeas gm; gm.stamp = t;
+            for (int i = 0; i < ns; ++i) {
+                gnss::SatObs o;
+                o.sys = sysv[i]; o.freq = sysv[i] == 3 ? gnss::FREQ1_BDS : gnss::FREQ1; o.psr_std = 1.0; o.dopp_std = 0.5; o.ura = 2.0;
+                o.sv_pos = sv_pos[i] + sv_vel[i] * t; o.sv_vel = sv_vel[i];
+                o.sv_dt = 1e-5 * (i + 1); o.sv_ddt = 1e-11 * i; o.tgd = 2e-9 * i; o.ion_delay = 2.0 + 0.3 * i; o.tro_delay = 2.5 + 0.2 * i;
+                const Vec3d d = o.sv_pos - rcv; const double range = d.norm(); const Vec3d u = d * (1.0 / range);
+                const double cb = cb0[o.sys] + fs_true * t;
+                const double sag = gnss::EARTH_OMG_GPS * (o.sv_pos[0] * rcv[1] - o.sv_pos[1] * rcv[0]) / gnss::LIGHT_SPEED;
+                o.psr = range + sag + cb - o.sv_dt * gnss::LIGHT_SPEED + o.tro_delay + o.ion_delay + o.tgd * gnss::LIGHT_SPEED + 0.8 * gn(rng);
+                if (i == 5 && f >= 8) o.psr += 80.0;                                // a gross outlier once the clock states exist (a delayed
+                                                                                    // initialisation with an outlier among its rows fails its own chi^2, as written)
+                const double sagd = gnss::EARTH_OMG_GPS / gnss::LIGHT_SPEED * (o.sv_vel[0] * rcv[1] + o.sv_pos[0] * vel[1] - o.sv_vel[1] * rcv[0] - o.sv_pos[1] * vel[0]);
+                const Vec3d dv = o.sv_vel - vel;
+                const double est = dv[0] * u[0] + dv[1] * u[1] + dv[2] * u[2] + fs_true + sagd - o.sv_ddt * gnss::LIGHT_SPEED;
+                o.dopp = -(est + 0.05 * gn(rng)) * o.freq / gnss::LIGHT_SPEED;
+                gm.sats.push_back(o);
+            }
+            SppMeas spp; spp.stamp = t;
+            for (int c = 0; c < 3; ++c) spp.posSpp[c] = rcv[c] + 2.0 * gn(rng);
+            for (int s4 = 0; s4 < 4; ++s4) spp.posSpp[3 + s4] = cb0[s4] == 0.0 ? 0.0 : cb0[s4] + fs_true * t + 3.0 * gn(rng);
+            for (int c = 0; c < 3; ++c) spp.velSpp[c] = vel[c];
+            spp.velSpp[3] = fs_true + 0.2 * gn(rng);
+            filter.callbackGnssMeas(gm);
+            filter.callbackSppMeas(spp);
+            // the stereo frame
+            const Mat3d Rc = Truth::R(t) * fp._T_cl2i.R;
+            const Vec3d pc = Truth::p(t) + Truth::R(t) * fp._T_cl2i.t;
+            std::vector<Live> keep;
+            for (auto& l : live) if (f - l.born < 7) keep.push_back(l);
+            live = keep;
+            while ((int)live.size() < 40) {
+                const double d = 3.0 + 10.0 * std::fabs(urand());
+                Live l; l.id = next_id++; l.born = f; l.pw = Rc * Vec3d(0.4 * urand() * d, 0.3 * urand() * d, d) + pc;
+                live.push_back(l);
+            }
+            StereoFrameMsg fr; fr.stamp = t;
+            for (auto& l : live) {
+                const Vec3d q = Rc.transpose() * (l.pw - pc), qr = Tlr * q;
+                if (q.z() < 0.5 || qr.z() < 0.5) continue;
+                StereoObsMsg o; o.id = l.id;
+                o.u0 = q.x() / q.z() + 1e-3 * gn(rng); o.v0 = q.y() / q.z() + 1e-3 * gn(rng);
+                o.u1 = qr.x() / qr.z() + 1e-3 * gn(rng); o.v1 = qr.y() / qr.z() + 1e-3 * gn(rng);
+                fr.stereo_meas.push_back(o);
+            }
+            filter.callbackStereoFrame(fr);
+            ASSERT_TRUE(StateManager::checkStateContinuity(state));
+            if (filter.lastGnssRows() > 0 && f >= 8) { ++epochs_used; rows_min = std::min(rows_min, filter.lastGnssRows()); rows_max = std::max(rows_max, filter.lastGnssRows()); }
+        }
+        // YOF by checkYofStatus, FS + GPS + GAL + BDS by delayed initialisation (GLO never observed)
+        ASSERT_TRUE(state->_gnss.count(State::YOF) && state->_gnss.count(State::FS) && state->_gnss.count(State::GPS));
+        ASSERT_TRUE(state->_gnss.count(State::GAL) && state->_gnss.count(State::BDS) && !state->_gnss.count(State::GLO));
+        ASSERT_EQ(filter.gnssVarsAdded(), 4);
+        ASSERT_TRUE(epochs_used >= 30);
+        ASSERT_EQ(rows_max, 15);                  // 16 candidate rows, the outlier's pseudo-range row refused by its gate in every epoch
+        ASSERT_TRUE(rows_min >= 13);              // an occasional 2-sigma row may go as well
+        const double cb_err = std::fabs(state->_gnss.at(State::GPS)->value() - (cb0[0] + fs_true * t));
+        const double fs_err = std::fabs(state->_gnss.at(State::FS)->value() - fs_true);
+        const MatXd P = StateManager::getFullCov(state);
+        double asym = 0, dmin = 1e300;
+        for (int j = 0; j < P.cols(); ++j) { dmin = std::min(dmin, P(j, j)); for (int i = 0; i < P.rows(); ++i) asym = std::max(asym, std::fabs(P(i, j) - P(j, i))); }
+        const double perr = (state->_extended_pose->valueTrans1() - Truth::p(t)).norm();
+        const double rerr = (state->_extended_pose->valueLinearAsMat() - Truth::R(t)).norm();
+        const int igps = state->_gnss.at(State::GPS)->idx();
+        std::printf("  strong_reject=%d: N=%d epochs used %d rows [%d, %d] |dp|=%.4f m |dR|=%.4f |d cb_gps|=%.2f m (sigma %.2f) |d fs|=%.3f m/s yof=%.4f (true %.4f)\n",
+                    strong, state->curr_cov_size(), epochs_used, rows_min, rows_max, perr, rerr, cb_err, std::sqrt(P(igps, igps)), fs_err,
+                    state->_gnss.at(State::YOF)->value(), yo_true);
+        ASSERT_TRUE(asym == 0.0);
+        ASSERT_TRUE(dmin > 0.0);
+        ASSERT_TRUE(perr < 0.3);
+        ASSERT_TRUE(rerr < 0.05);
+        ASSERT_TRUE(cb_err < 3.0);
+        ASSERT_TRUE(fs_err < 0.5);
+        ASSERT_TRUE(std::sqrt(P(igps, igps)) < 2.0);          // the clock bias is observed: far below its 2 m / sqrt(s) random walk alone
+    }
+}
+
 static void testGnssUpdate()      // GnssUpdate.cpp:148-290 through the shim vs the dense identity
 {
     Fixture f;
@@ -636,6 +768,54 @@ static void testGnssUpdate()      // GnssUpdate.cpp:148-290 through the shim vs 
     const MatXd KH = mul(K, HL);
     for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) IKH(i, j) -= KH(i, j);
     ASSERT_NEAR(normDiff(mul(IKH, P0), StateManager::getFullCov(state)), 0.0, 1e-08);
+    // the same epoch with _is_gnss_chi2_test = 1 and one gross residual: the device gate drops exactly that row, the posterior
+    // equals the dense identity over the remaining rows
+    {
+        Fixture f2;
+        auto& st2 = f2.state;
+        st2->_timestamp = 1.0;
+        StateManager::propagateStateCov(st2, f2.Phi_imu, f2.G_imu, 0.2);
+        GnssResiduals g2 = g;
+        g2.res_pos[1] = 500.0;
+        fp._is_gnss_chi2_test = 1;
+        GnssUpdate gu2(fp);
+        const MatXd Q0 = StateManager::getFullCov(st2);
+        const Vec3d p2 = st2->_extended_pose->valueTrans1(), v2 = st2->_extended_pose->valueTrans2();      // before boxPlus moves them
+        const int rows2 = gu2.updateTrackedSys(st2, g2);
+        ASSERT_EQ(rows2, rows - 1);
+        // the candidate rows at THIS fixture's pose (the Jacobian holds [p]x and [v]x)
+        MatXd HF(rows, n);
+        int rr = 0;
+        auto add2 = [&](int i, bool dop) {
+            const Vec3d& u = g.unit_rv2sv[i];
+            const Mat3d M = g.R_w2ecef * skew(dop ? v2 : p2);
+            for (int c = 0; c < 3; ++c) {
+                HF(rr, c) = u[0] * M(0, c) + u[1] * M(1, c) + u[2] * M(2, c);
+                HF(rr, (dop ? 6 : 3) + c) = -(u[0] * g.R_w2ecef(0, c) + u[1] * g.R_w2ecef(1, c) + u[2] * g.R_w2ecef(2, c));
+            }
+            HF(rr, dop ? fs : (g.sys[i] == 0 ? gps : bds)) = 1.0;
+            ++rr;
+        };
+        for (int i = 0; i < ns; ++i) if (g.sys[i] != 2) add2(i, false);
+        for (int i = 0; i < ns; ++i) if (g.sys[i] != 2) add2(i, true);
+        // which single row did the device drop?  (the posterior identifies it)
+        int best_i = -1; double best = 1e300;
+        for (int drop = 0; drop < rows; ++drop) {
+            MatXd H2(rows - 1, n); VecXd R2(rows - 1);
+            int w = 0;
+            for (int i = 0; i < rows; ++i) { if (i == drop) continue; for (int c = 0; c < n; ++c) H2(w, c) = HF(i, c); R2[w] = Rd[i]; ++w; }
+            MatXd S2 = mul(mul(H2, Q0), H2, true);
+            for (int i = 0; i < rows - 1; ++i) S2(i, i) += R2[i];
+            const MatXd K2 = mul(mul(Q0, H2, true), inverse(S2));
+            MatXd I2 = MatXd::Identity(n);
+            const MatXd KH2 = mul(K2, H2);
+            for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) I2(i, j) -= KH2(i, j);
+            const double d = normDiff(mul(I2, Q0), StateManager::getFullCov(st2));
+            if (d < best) { best = d; best_i = drop; }
+        }
+        ASSERT_EQ(best_i, 1);
+        ASSERT_NEAR(best, 0.0, 1e-08);
+    }
 }
 
 int main()
@@ -646,6 +826,7 @@ int main()
         { "StateUpdateTest.stateCovUpdate", testStateCovUpdate }, { "AddDelayedTest.addVarInv", testAddVarInv }, { "AddDelayedTest.addVar", testAddVar }, { "FeatureInfoManager.changeAnchoredPose", testChangeAnchoredPose },
         { "TestPropagator.propaUntil+propagateAugment", testPropagator },
         { "GnssUpdate.updateTrackedSys", testGnssUpdate }, { "TestTriangulator.mono+stereo", testTriangulator }, { "IngvioFilter.callbacks end-to-end", testFilterEndToEnd },
+        { "IngvioFilter.callbacks with GNSS epochs (config 3)", testFilterGnssEndToEnd },
     };
     for (auto& t : tests) {
         const int before = g_fail;
