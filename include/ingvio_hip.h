@@ -150,6 +150,39 @@ int ingvio_gnss_fetch(ingvio_ctx* ctx, int b0, int nb, double* dx_out, int* rows
                       int* status_out);
 int ingvio_mld(ingvio_ctx* ctx);                      /* row stride of keep_out / gamma_out */
 
+/* ---- the gnss_comm front of the GNSS update on the device ----------------------------------------
+ * What GnssUpdate::updateTrackedSys obtains from gnss_comm before it builds its rows (GnssUpdate.cpp:98-122): satellite states
+ * from the broadcast ephemerides at transmit time (gnss_comm/src/gnss_spp.cpp:50-98, gnss_utility.cpp:390-640), elevation,
+ * Saastamoinen/Niell and Klobuchar delays (:762-899), pseudo-range and Doppler residuals (gnss_spp.cpp:100-146, :256-282).
+ * ingvio_gnss_front_stage evaluates all of it for every filter of the range (one lane per satellite) and writes the candidate
+ * rows where ingvio_gnss_stage would have put them: follow with ingvio_gnss_run / ingvio_gnss_fetch.  GLONASS satellites are
+ * skipped (their Runge-Kutta orbit is not built).  Times are seconds of the GPS week.
+ * Flat records of doubles:
+ *   ephemeris [INGVIO_EPH_N]: sys (gnss_comm::sys2idx: GPS 0, GLO 1, GAL 2, BDS 3), prn, toe, toe in the constellation's own
+ *     week (BDS: BDT of toe - 14 s, gnss_utility.cpp:489; else = toe), toc, A, e, i0, omg, OMG0, M0, delta_n, OMG_dot, i_dot,
+ *     cuc, cus, crc, crs, cic, cis, af0, af1, af2, tgd[0], ura
+ *   observation [INGVIO_OBS_N]: receive time, L1 pseudo-range (m), L1 Doppler (Hz), psr_std, dopp_std, L1 frequency (Hz, < 0: no L1) */
+#define INGVIO_EPH_N 25
+#define INGVIO_OBS_N 6
+#define INGVIO_GNSS_MAX_SAT 64
+typedef struct {
+    int n_sat;                                /* <= INGVIO_GNSS_MAX_SAT                                                */
+    const double* eph;                        /* [n_sat][INGVIO_EPH_N]                                                 */
+    const double* obs;                        /* [n_sat][INGVIO_OBS_N]                                                 */
+    const double* ion;                        /* [8] Klobuchar parameters (latest_gnss_iono_params) or NULL            */
+    double doy;                               /* gnss_comm::time2doy of the epoch                                      */
+    double p_w[3], v_w[3];                    /* State::_extended_pose valueTrans1() / valueTrans2()                   */
+    double cb[4], fs;                         /* GnssManager::getClockbiasVec (m), FS value (m/s)                      */
+    double yaw_offset;                        /* YOF value                                                             */
+    double R_enu2ecef[9], anchor_ecef[3];     /* GvioAligner::getRenu2ecef (row-major), translation of getTenu2ecef    */
+    int idx_se23, idx_yof, idx_fs, idx_cb[4]; /* Type::idx() of the variables (idx_cb[s] = -1: clock s not in the state) */
+    double psr_noise_amp, dopp_noise_amp;     /* GnssUpdate::_psr_noise_amp / _dopp_noise_amp                          */
+} ingvio_gnss_epoch;
+int ingvio_gnss_front_stage(ingvio_ctx* ctx, int b0, int nb, const ingvio_gnss_epoch* epochs, const ingvio_gnss_opts* opts);
+/* per-satellite results of the last front_stage: out [nb][INGVIO_GNSS_MAX_SAT][10] = res_pos, res_vel, unit receiver->satellite
+ * (3), azimuth, elevation, ionosphere delay, troposphere delay, usable (1/0) */
+int ingvio_gnss_front_fetch(ingvio_ctx* ctx, int b0, int nb, double* out);
+
 /* whitenResidual (Update.cpp:36-79): gamma = res^T (H Pcc H^T + R)^-1 res. */
 int ingvio_chi2_gamma(ingvio_ctx* ctx, int b, const int* vidx, const int* vsize, int k,
                       const double* H, int ldh, int m, const double* res,

@@ -27,7 +27,7 @@ EXPORTS = [
     "ingvio_frame_stage", "ingvio_frame_stage_async", "ingvio_frame_run", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_select",
     "ingvio_profile_reset",
     "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_debug_read", "ingvio_triangulate",
-    "ingvio_gnss_update_batch", "ingvio_gnss_stage", "ingvio_gnss_run", "ingvio_gnss_fetch", "ingvio_mld", "ingvio_debug_msckf_info", "ingvio_debug_info_solution",
+    "ingvio_gnss_front_stage", "ingvio_gnss_front_fetch", "ingvio_gnss_update_batch", "ingvio_gnss_stage", "ingvio_gnss_run", "ingvio_gnss_fetch", "ingvio_mld", "ingvio_debug_msckf_info", "ingvio_debug_info_solution",
     "ingvio_chi2_gamma_multi", "ingvio_ekf_update_batch", "ingvio_add_variable_delayed_invertible", "ingvio_add_variable_delayed", "ingvio_replace_var_linear",
 ]
 
@@ -44,6 +44,14 @@ class UpdateBlock(C.Structure):
 
 class GnssOpts(C.Structure):
     _fields_ = [("gate_rows", C.c_int), ("strong_reject", C.c_int), ("chi2_table", C.POINTER(C.c_double)), ("chi2_len", C.c_int)]
+
+
+class GnssEpoch(C.Structure):
+    _fields_ = [("n_sat", C.c_int), ("eph", C.POINTER(C.c_double)), ("obs", C.POINTER(C.c_double)), ("ion", C.POINTER(C.c_double)),
+                ("doy", C.c_double), ("p_w", C.c_double * 3), ("v_w", C.c_double * 3), ("cb", C.c_double * 4), ("fs", C.c_double),
+                ("yaw_offset", C.c_double), ("R_enu2ecef", C.c_double * 9), ("anchor_ecef", C.c_double * 3), ("idx_se23", C.c_int),
+                ("idx_yof", C.c_int), ("idx_fs", C.c_int), ("idx_cb", C.c_int * 4), ("psr_noise_amp", C.c_double),
+                ("dopp_noise_amp", C.c_double)]
 
 
 class CtxDesc(C.Structure):
@@ -321,6 +329,36 @@ class Context:
         o = GnssOpts(); o.gate_rows = int(gate_rows); o.strong_reject = int(strong_reject); o.chi2_table = _d(tab); o.chi2_len = len(tab)
         self._chk(self.L.ingvio_gnss_stage(self.h, b0, len(blocks), arr, C.byref(o)))
         self._gnss_range = (b0, len(blocks))
+
+    def gnss_front_stage(self, b0, epochs, chi2_table, gate_rows=True, strong_reject=False):
+        """epochs: per filter a dict(eph [ns,25], obs [ns,6], ion [8] or None, doy, p_w, v_w, cb [4], fs, yaw_offset, R_enu2ecef [3,3],
+        anchor_ecef, idx_se23, idx_yof, idx_fs, idx_cb [4], psr_amp, dopp_amp): raw GNSS epochs -> candidate rows on the device."""
+        nb = len(epochs)
+        arr = (GnssEpoch * nb)(); keep = []
+        for i, e in enumerate(epochs):
+            eph, obs = f64(e["eph"]), f64(e["obs"])
+            ion = f64(e["ion"]) if e.get("ion") is not None else None
+            keep.append((eph, obs, ion))
+            a = arr[i]
+            a.n_sat = eph.shape[0]; a.eph = _d(eph); a.obs = _d(obs); a.ion = _d(ion) if ion is not None else None
+            a.doy = float(e["doy"]); a.p_w = (C.c_double * 3)(*e["p_w"]); a.v_w = (C.c_double * 3)(*e["v_w"])
+            a.cb = (C.c_double * 4)(*e["cb"]); a.fs = float(e["fs"]); a.yaw_offset = float(e["yaw_offset"])
+            a.R_enu2ecef = (C.c_double * 9)(*np.asarray(e["R_enu2ecef"], dtype=np.float64).reshape(9))
+            a.anchor_ecef = (C.c_double * 3)(*e["anchor_ecef"])
+            a.idx_se23 = int(e["idx_se23"]); a.idx_yof = int(e["idx_yof"]); a.idx_fs = int(e["idx_fs"])
+            a.idx_cb = (C.c_int * 4)(*[int(x) for x in e["idx_cb"]])
+            a.psr_noise_amp = float(e.get("psr_amp", 1.0)); a.dopp_noise_amp = float(e.get("dopp_amp", 1.0))
+        tab = f64(chi2_table)
+        o = GnssOpts(); o.gate_rows = int(gate_rows); o.strong_reject = int(strong_reject); o.chi2_table = _d(tab); o.chi2_len = len(tab)
+        self._chk(self.L.ingvio_gnss_front_stage(self.h, b0, nb, arr, C.byref(o)))
+        self._gnss_range = (b0, nb)
+
+    def gnss_front_fetch(self, b0=None, nb=None):
+        """-> [nb, 64, 10]: res_pos, res_vel, los (3), az, el, ion, tro, usable per satellite"""
+        b0, nb = (self._gnss_range if b0 is None else (b0, nb))
+        out = np.zeros((nb, 64, 10))
+        self._chk(self.L.ingvio_gnss_front_fetch(self.h, b0, nb, _d(out)))
+        return out
 
     def gnss_run(self, b0=None, nb=None):
         b0, nb = (self._gnss_range if b0 is None else (b0, nb))

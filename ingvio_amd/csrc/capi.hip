@@ -9,6 +9,7 @@
 #include "launch_tri.h"
 #include "launch_lm.h"
 #include "launch_qr.h"
+#include "launch_gnss.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -70,6 +71,7 @@ struct ingvio_ctx {
     struct GnssStage {
         double *H = nullptr, *res = nullptr, *noise = nullptr, *gamma = nullptr, *chi2 = nullptr;
         int *m = nullptr, *nc = nullptr, *colmap = nullptr, *keep = nullptr;
+        double *feph = nullptr, *fobs = nullptr, *frcv = nullptr, *front = nullptr;      // ingvio_gnss_front_stage inputs / per-satellite results
         int ncw = 0, m_cap = 0, n_vars_hi = 0, chi2_len = 0, gate_rows = 0, strong = 0;
         double thr1 = 0.0;
         std::vector<int> hi;            // per filter: highest state index named by the staged var_order (+1)
@@ -549,7 +551,8 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
                      c->d_idx, c->d_clone_idx, c->d_nclones, c->d_nfeat, c->d_anchor, c->d_dof, c->d_clone_R, c->d_clone_p,
                      c->d_pf, c->d_uv, c->d_chi2, c->d_mask, c->d_gamma, c->d_accept, c->d_used, c->d_Rpart, c->d_chunk_used,
                      c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk, c->d_tri_ok, c->d_hnew, c->d_multi, c->d_noiseB,
-                     c->gn.H, c->gn.res, c->gn.noise, c->gn.gamma, c->gn.chi2, c->gn.m, c->gn.nc, c->gn.colmap, c->gn.keep };
+                     c->gn.H, c->gn.res, c->gn.noise, c->gn.gamma, c->gn.chi2, c->gn.m, c->gn.nc, c->gn.colmap, c->gn.keep,
+                     c->gn.feph, c->gn.fobs, c->gn.frcv, c->gn.front };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& sl : c->pin) { if (sl.p) hipHostFree(sl.p); if (sl.ev) hipEventDestroy(sl.ev); }
     if (c->qr.exec) hipGraphExecDestroy(c->qr.exec);
@@ -857,6 +860,21 @@ int ingvio_ekf_update_batch(ingvio_ctx* c, int b0, int nb, const ingvio_update_b
 // ---- GnssUpdate::updateTrackedSys for a batch (GnssUpdate.cpp:148-290): per-row gates, compaction, block gate, ekfUpdate ----
 #define GNSS_NCW 32        // widest var_order of a staged GNSS update (the reference's is 9 + 1 + 4 + 1 = 15 columns)
 
+static int gnss_alloc(ingvio_ctx* c)
+{
+    auto& g = c->gn;
+    if (g.H) return 0;
+    const size_t B = c->d.batch, mld = c->mld, hs = mld * GNSS_NCW;
+    int rc = 0;
+    rc |= dalloc(c, &g.H, B * hs); rc |= dalloc(c, &g.res, B * mld); rc |= dalloc(c, &g.noise, B * mld); rc |= dalloc(c, &g.gamma, B * mld);
+    rc |= dalloc(c, &g.chi2, CHI2_CAP); rc |= dalloc(c, &g.m, B); rc |= dalloc(c, &g.nc, B); rc |= dalloc(c, &g.colmap, B * GNSS_NCW);
+    rc |= dalloc(c, &g.keep, B * mld);
+    if (!c->d_noiseB) rc |= dalloc(c, &c->d_noiseB, B * mld);
+    if (rc) return INGVIO_E_HIP;
+    g.hi.assign(B, 0);
+    return 0;
+}
+
 int ingvio_gnss_stage(ingvio_ctx* c, int b0, int nb, const ingvio_update_block* blk, const ingvio_gnss_opts* o)
 {
     if (check_range(c, b0, nb) || !blk || !o) return INGVIO_E_ARG;
@@ -880,16 +898,8 @@ int ingvio_gnss_stage(ingvio_ctx* c, int b0, int nb, const ingvio_update_block* 
         ncs[i] = nc; his[i] = hi;
         if (q.m > m_cap) m_cap = q.m;
     }
-    const size_t B = c->d.batch, mld = c->mld, hs = mld * GNSS_NCW;
-    if (!g.H) {
-        int rc = 0;
-        rc |= dalloc(c, &g.H, B * hs); rc |= dalloc(c, &g.res, B * mld); rc |= dalloc(c, &g.noise, B * mld); rc |= dalloc(c, &g.gamma, B * mld);
-        rc |= dalloc(c, &g.chi2, CHI2_CAP); rc |= dalloc(c, &g.m, B); rc |= dalloc(c, &g.nc, B); rc |= dalloc(c, &g.colmap, B * GNSS_NCW);
-        rc |= dalloc(c, &g.keep, B * mld);
-        if (!c->d_noiseB) rc |= dalloc(c, &c->d_noiseB, B * mld);
-        if (rc) return INGVIO_E_HIP;
-        g.hi.assign(B, 0);
-    }
+    const size_t mld = c->mld, hs = mld * GNSS_NCW;
+    if (gnss_alloc(c)) return INGVIO_E_HIP;
     Uploader upl{ c };
     int rc = upl.begin(pad64(8 * (size_t)nb * hs) + 2 * pad64(8 * (size_t)nb * mld) + pad64(4 * (size_t)nb * GNSS_NCW) + 2 * pad64(4 * (size_t)nb) +
                        pad64(8 * CHI2_CAP) + 1024);
@@ -930,6 +940,89 @@ int ingvio_gnss_stage(ingvio_ctx* c, int b0, int nb, const ingvio_update_block* 
     if (!g.staged || m_cap > g.m_cap) g.m_cap = m_cap;
     g.staged = true;
     return INGVIO_OK;
+}
+
+// raw GNSS epochs -> candidate rows, on the device (kernels_gnss.hip)
+int ingvio_gnss_front_stage(ingvio_ctx* c, int b0, int nb, const ingvio_gnss_epoch* ep, const ingvio_gnss_opts* o)
+{
+    static_assert(GNSS_FRONT_NCW == GNSS_NCW, "column stride of the staged rows");
+    if (check_range(c, b0, nb) || !ep || !o) return INGVIO_E_ARG;
+    if ((o->gate_rows || o->strong_reject) && (!o->chi2_table || o->chi2_len < 2 || o->chi2_len > CHI2_CAP)) return INGVIO_E_ARG;
+    int smax = 1;
+    std::vector<int> his(nb, 0);
+    for (int i = 0; i < nb; ++i) {
+        const ingvio_gnss_epoch& e = ep[i];
+        if (e.n_sat < 0 || e.n_sat > INGVIO_GNSS_MAX_SAT || (e.n_sat && (!e.eph || !e.obs))) return INGVIO_E_ARG;
+        if (2 * e.n_sat > c->mld || 2 * e.n_sat > 256) return INGVIO_E_CAPACITY;
+        if (e.n_sat > smax) smax = e.n_sat;
+        int hi = 0;
+        const int idx[7] = { e.idx_se23 + 9, e.idx_yof + 1, e.idx_fs + 1, e.idx_cb[0] + 1, e.idx_cb[1] + 1, e.idx_cb[2] + 1, e.idx_cb[3] + 1 };
+        if (e.n_sat) { if (e.idx_se23 < 0 || e.idx_yof < 0 || e.idx_fs < 0) return INGVIO_E_NOT_IN_STATE; for (int v : idx) { if (v > c->d.n_max) return INGVIO_E_NOT_IN_STATE; if (v > hi) hi = v; } }
+        his[i] = hi;
+        if (!ekf_core_fits(2 * e.n_sat ? 2 * e.n_sat : 1, 15)) return INGVIO_E_CAPACITY;
+    }
+    int rc = gnss_alloc(c);
+    if (rc) return rc;
+    auto& g = c->gn;
+    const size_t B = c->d.batch;
+    if (!g.front) {
+        rc |= dalloc(c, &g.feph, B * INGVIO_GNSS_MAX_SAT * GE_N); rc |= dalloc(c, &g.fobs, B * INGVIO_GNSS_MAX_SAT * GO_N);
+        rc |= dalloc(c, &g.frcv, B * GR_N); rc |= dalloc(c, &g.front, B * 64 * GF_N);
+        if (rc) return INGVIO_E_HIP;
+    }
+    const size_t S = INGVIO_GNSS_MAX_SAT;
+    Uploader upl{ c };
+    rc = upl.begin(pad64(8 * (size_t)nb * S * GE_N) + pad64(8 * (size_t)nb * S * GO_N) + pad64(8 * (size_t)nb * GR_N) + pad64(8 * CHI2_CAP) + 1024);
+    if (rc) return rc;
+    double* he = upl.take<double>((size_t)nb * S * GE_N); double* ho = upl.take<double>((size_t)nb * S * GO_N);
+    double* hr = upl.take<double>((size_t)nb * GR_N); double* hchi = upl.take<double>(CHI2_CAP);
+    parallel_for(nb, [=](int i) {
+        const ingvio_gnss_epoch& e = ep[i];
+        memcpy(he + (size_t)i * S * GE_N, e.eph, 8 * (size_t)e.n_sat * GE_N);
+        memcpy(ho + (size_t)i * S * GO_N, e.obs, 8 * (size_t)e.n_sat * GO_N);
+        double* r = hr + (size_t)i * GR_N;
+        memset(r, 0, 8 * GR_N);
+        r[GR_NSAT] = e.n_sat; r[GR_DOY] = e.doy; r[GR_HAVE_ION] = e.ion ? 1.0 : 0.0;
+        if (e.ion) memcpy(r + GR_ION, e.ion, 64);
+        memcpy(r + GR_PW, e.p_w, 24); memcpy(r + GR_VW, e.v_w, 24); memcpy(r + GR_CB, e.cb, 32);
+        r[GR_FS] = e.fs; r[GR_YAW] = e.yaw_offset;
+        memcpy(r + GR_RENU, e.R_enu2ecef, 72); memcpy(r + GR_ANCHOR, e.anchor_ecef, 24);
+        r[GR_IDX_SE23] = e.idx_se23; r[GR_IDX_YOF] = e.idx_yof; r[GR_IDX_FS] = e.idx_fs;
+        for (int s = 0; s < 4; ++s) r[GR_IDX_CB + s] = e.idx_cb[s];
+        r[GR_PSR_AMP] = e.psr_noise_amp; r[GR_DOPP_AMP] = e.dopp_noise_amp;
+    });
+    upl.copy(g.feph + (size_t)b0 * S * GE_N, he, (size_t)nb * S * GE_N);
+    upl.copy(g.fobs + (size_t)b0 * S * GO_N, ho, (size_t)nb * S * GO_N);
+    upl.copy(g.frcv + (size_t)b0 * GR_N, hr, (size_t)nb * GR_N);
+    g.chi2_len = 0;
+    if (o->chi2_table) {
+        memcpy(hchi, o->chi2_table, 8 * (size_t)o->chi2_len);
+        upl.copy(g.chi2, hchi, (size_t)o->chi2_len);
+        g.chi2_len = o->chi2_len;
+    }
+    rc = upl.end();
+    if (rc) return rc;
+    const size_t mld = c->mld, hs = mld * GNSS_NCW;
+    GnssFrontLaunch L;
+    L.eph = g.feph + (size_t)b0 * S * GE_N; L.obs = g.fobs + (size_t)b0 * S * GO_N; L.rcv = g.frcv + (size_t)b0 * GR_N; L.smax = (int)S;
+    L.front = g.front + (size_t)b0 * 64 * GF_N;
+    L.H = g.H + (size_t)b0 * hs; L.res = g.res + (size_t)b0 * mld; L.noise = g.noise + (size_t)b0 * mld;
+    L.m = g.m + b0; L.nc = g.nc + b0; L.colmap = g.colmap + (size_t)b0 * GNSS_NCW; L.mld = c->mld; L.hstride = (int)hs;
+    launch_gnss_front(L, nb, c->st);
+    for (int i = 0; i < nb; ++i) g.hi[b0 + i] = his[i];
+    g.gate_rows = o->gate_rows ? 1 : 0; g.strong = o->strong_reject ? 1 : 0;
+    g.thr1 = o->gate_rows ? o->chi2_table[1] : __builtin_inf();
+    const int m_cap = 2 * smax;
+    if (!g.staged || m_cap > g.m_cap) g.m_cap = m_cap;
+    g.staged = true;
+    return last_launch(c);
+}
+
+int ingvio_gnss_front_fetch(ingvio_ctx* c, int b0, int nb, double* out)
+{
+    if (check_range(c, b0, nb) || !out || !c->gn.front) return INGVIO_E_ARG;
+    if (down_sync(c, out, c->gn.front + (size_t)b0 * 64 * GF_N, 8 * (size_t)nb * 64 * GF_N)) return INGVIO_E_HIP;
+    return last_launch(c);
 }
 
 int ingvio_gnss_run(ingvio_ctx* c, int b0, int nb)

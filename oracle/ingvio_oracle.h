@@ -212,6 +212,22 @@ int orc_landmark_rows_epose(const double R_i2w[9], const double p_i2w[3], const 
 int orc_landmark_rows_sw(const double R_cm[9], const double p_cm[3], const double pf[3], const double* uv, int stereo,
                          const double R_lr[9], const double t_lr[3], int curr_is_anchor, double* H, double* res);
 
+/* ---- the gnss_comm front of the GNSS update (oracle/gnss_front_oracle.c) ----------------------
+ * Flat records (doubles): a broadcast Kepler ephemeris, one L1 observation, a satellite state. */
+enum { ORC_EPH_SYS = 0, ORC_EPH_PRN, ORC_EPH_TOE, ORC_EPH_TOE_SYS, ORC_EPH_TOC, ORC_EPH_A, ORC_EPH_E, ORC_EPH_I0, ORC_EPH_OMG,
+       ORC_EPH_OMG0, ORC_EPH_M0, ORC_EPH_DELTA_N, ORC_EPH_OMG_DOT, ORC_EPH_I_DOT, ORC_EPH_CUC, ORC_EPH_CUS, ORC_EPH_CRC,
+       ORC_EPH_CRS, ORC_EPH_CIC, ORC_EPH_CIS, ORC_EPH_AF0, ORC_EPH_AF1, ORC_EPH_AF2, ORC_EPH_TGD, ORC_EPH_URA, ORC_EPH_N };
+enum { ORC_OBS_TOW = 0, ORC_OBS_PSR, ORC_OBS_DOPP, ORC_OBS_PSR_STD, ORC_OBS_DOPP_STD, ORC_OBS_FREQ, ORC_OBS_N };
+enum { ORC_SAT_N = 10 };      /* pos 3, vel 3, dt, ddt, tgd, ttx */
+int orc_gnss_sat_state(const double* eph, const double* obs, double* sat);
+void orc_gnss_ecef2geo(const double xyz[3], double lla[3]);
+void orc_gnss_azel(const double rcv[3], const double sat[3], double azel[2]);
+double orc_gnss_trop(double doy, const double lla[3], const double azel[2]);
+double orc_gnss_iono(double tow, const double ion[8], const double lla[3], const double azel[2]);
+void orc_gnss_residuals(int ns, const double* eph, const double* obs, const double ion[8], int have_ion, double doy,
+                        const double rcv_xyzt[7], const double rcv_vel[4], double* res_pos, double* res_vel, double* los,
+                        double* azel_out, double* atmos, double* sat_out, int* usable);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,10 +19,8 @@ c_up = C.POINTER(C.c_ulonglong)
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "ingvio_oracle.c")
-    hdr = os.path.join(_HERE, "ingvio_oracle.h")
-    if (not force and os.path.exists(_LIB)
-            and os.path.getmtime(_LIB) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+    srcs = [os.path.join(_HERE, f) for f in ("ingvio_oracle.c", "gnss_front_oracle.c", "ingvio_oracle.h")]
+    if not force and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= max(os.path.getmtime(f) for f in srcs):
         return _LIB
     subprocess.check_call(["make", "-C", _HERE, "-s"], stdout=subprocess.DEVNULL)
     return _LIB
@@ -431,3 +429,20 @@ def gnss_rows(cov, g):
     k = nv.value
     ncols = int(vsize[:k].sum())
     return H[:rows, :ncols].copy(), res[:rows].copy(), Rd[:rows].copy(), vidx[:k].copy(), vsize[:k].copy()
+
+
+# ---- the gnss_comm front (oracle/gnss_front_oracle.c) --------------------------------------------
+EPH_N, OBS_N, SAT_N = 25, 6, 10
+
+
+def gnss_residuals(eph, obs, ion, doy, rcv_xyzt, rcv_vel):
+    """eph [ns, 25], obs [ns, 6] (flat records, see ingvio_oracle.h), ion [8] or None.
+    Returns dict(res_pos, res_vel, los [ns,3], azel [ns,2], atmos [ns,2], sat [ns,10], usable [ns])."""
+    eph = f64(eph); obs = f64(obs); ns = eph.shape[0]
+    ionv = f64(ion if ion is not None else np.zeros(8))
+    out = dict(res_pos=np.zeros(ns), res_vel=np.zeros(ns), los=np.zeros((ns, 3)), azel=np.zeros((ns, 2)),
+               atmos=np.zeros((ns, 2)), sat=np.zeros((ns, SAT_N)), usable=np.zeros(ns, dtype=np.int32))
+    lib().orc_gnss_residuals(C.c_int(ns), _d(eph), _d(obs), _d(ionv), C.c_int(0 if ion is None else 1), C.c_double(doy),
+                             _d(f64(rcv_xyzt)), _d(f64(rcv_vel)), _d(out["res_pos"]), _d(out["res_vel"]), _d(out["los"]),
+                             _d(out["azel"]), _d(out["atmos"]), _d(out["sat"]), _i(out["usable"]))
+    return out
