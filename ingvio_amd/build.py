@@ -58,7 +58,7 @@ def build_host(force=False, verbose=False):
     srcs = sorted(os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".cpp"))
     if not srcs:
         return None
-    deps = _all_deps([host_dir, os.path.join(os.path.dirname(HERE), "include")])
+    deps = _all_deps([host_dir, os.path.join(os.path.dirname(HERE), "include")]) + [HIP_LIB]      # an ABI change relinks the shim
     if force or _newer(HOST_LIB, deps):
         cmd = ["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-I", os.path.join(os.path.dirname(HERE), "include"),
                "-o", HOST_LIB] + srcs + ["-L", LIB, "-lingvio_hip", "-Wl,-rpath,$ORIGIN"]
@@ -75,9 +75,26 @@ def build_cpp_tests(force=False, verbose=False):
     exe = os.path.join(LIB, "test_host_shim")
     if not os.path.exists(src) or not os.path.exists(HOST_LIB):
         return None
-    deps = _all_deps([os.path.join(CSRC, "host"), os.path.join(root, "include")]) + [src, HOST_LIB]
+    deps = _all_deps([os.path.join(CSRC, "host"), os.path.join(root, "include")]) + [src, HOST_LIB, HIP_LIB]
     if force or _newer(exe, deps):
         cmd = ["g++", "-O1", "-std=c++14", "-I", os.path.join(root, "include"), src, "-o", exe, "-L", LIB,
+               "-lingvio_host", "-lingvio_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return exe
+
+
+def build_tools(force=False, verbose=False):
+    """tools/ingvio_replay.cpp -> ingvio_amd/lib/ingvio_replay (the rosbag-free replay driver)."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tools", "ingvio_replay.cpp")
+    exe = os.path.join(LIB, "ingvio_replay")
+    if not os.path.exists(src) or not os.path.exists(HOST_LIB):
+        return None
+    deps = _all_deps([os.path.join(CSRC, "host"), os.path.join(root, "include")]) + [src, HOST_LIB, HIP_LIB]
+    if force or _newer(exe, deps):
+        cmd = ["g++", "-O2", "-std=c++14", "-I", os.path.join(root, "include"), src, "-o", exe, "-L", LIB,
                "-lingvio_host", "-lingvio_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
@@ -89,6 +106,7 @@ def build_all(force=False, verbose=False):
     a = build_hip(force, verbose)
     b = build_host(force, verbose)
     build_cpp_tests(force, verbose)
+    build_tools(force, verbose)
     return a, b
 
 

@@ -54,8 +54,10 @@ void ImuPropagator::storeImu(const ImuCtrl& imu_ctrl)
 void ImuPropagator::stateAndCovTransition(std::shared_ptr<State> state, const ImuCtrl& imu_ctrl, double dt,
                                           double Phi[225], double G[180], bool isAnalytic)
 {
-    if (!isAnalytic)
+    if (!isAnalytic && !_warned_rk4) {           // said once, not 200-400 times per second
         std::cout << "[ImuPropagator]: RK4 branch (ImuPropagator.cpp:163-229) is not carried by the shim; using the analytic one." << std::endl;
+        _warned_rk4 = true;
+    }
     Mat3d R = state->_extended_pose->valueLinearAsMat();
     Vec3d p = state->_extended_pose->valueTrans1(), v = state->_extended_pose->valueTrans2();
     state->_timestamp += dt;                                                                  // :124

@@ -42,6 +42,7 @@ public:
     void propagateToExpectedPoseAndAugment(std::shared_ptr<State> state, double t_end, const Mat3d& R_i2w, const Vec3d& p_i2w);   // :316-334
 
     bool isInit() const { return _has_gravity_set; }
+    bool _warned_rk4 = false;
     const Vec3d& getGravity() const { return _gravity; }
     const Quatd& getInitQuat() const { return _quat_init; }
     size_t bufferSize() const { return _imu_ctrl_buffer.size(); }

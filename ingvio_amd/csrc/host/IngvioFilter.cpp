@@ -163,4 +163,43 @@ void IngvioFilter::callbackMonoFrame(const MonoFrameMsg& frame)
     ++_frames;
 }
 
+// ---- the ROS-shaped surface (Messages.h) ------------------------------------------------------------------------------
+void IngvioFilter::callbackIMU(const msg::Imu& m)
+{
+    ImuMsg i; i.stamp = m.header.stamp.toSec();
+    i.gyro[0] = m.angular_velocity.x; i.gyro[1] = m.angular_velocity.y; i.gyro[2] = m.angular_velocity.z;
+    i.accel[0] = m.linear_acceleration.x; i.accel[1] = m.linear_acceleration.y; i.accel[2] = m.linear_acceleration.z;
+    callbackIMU(i);
+}
+
+void IngvioFilter::callbackStereoFrame(const msg::StereoFrame& f)
+{
+    StereoFrameMsg s; s.stamp = f.header.stamp.toSec();
+    s.stereo_meas.reserve(f.stereo_features.size());
+    for (const auto& o : f.stereo_features) { StereoObsMsg q; q.id = (int)o.id; q.u0 = o.u0; q.v0 = o.v0; q.u1 = o.u1; q.v1 = o.v1; s.stereo_meas.push_back(q); }
+    callbackStereoFrame(s);
+}
+
+void IngvioFilter::callbackMonoFrame(const msg::MonoFrame& f)
+{
+    MonoFrameMsg s; s.stamp = f.header.stamp.toSec();
+    s.mono_meas.reserve(f.mono_features.size());
+    for (const auto& o : f.mono_features) { MonoObsMsg q; q.id = (int)o.id; q.u0 = o.u0; q.v0 = o.v0; s.mono_meas.push_back(q); }
+    callbackMonoFrame(s);
+}
+
+bool IngvioFilter::odometry(const msg::Header& header, msg::Odometry& od) const
+{
+    const Mat3d R = _state->_extended_pose->valueLinearAsMat();
+    const Vec3d p = _state->_extended_pose->valueTrans1(), v = _state->_extended_pose->valueTrans2();
+    for (int i = 0; i < 9; ++i) if (R.m[i] != R.m[i]) return false;                      // hasNaN, :418-419
+    for (int i = 0; i < 3; ++i) if (p[i] != p[i] || v[i] != v[i]) return false;
+    od.header.stamp = header.stamp; od.header.seq = header.seq; od.header.frame_id = "world"; od.child_frame_id = "uav";      // :425-427
+    od.position.x = p[0]; od.position.y = p[1]; od.position.z = p[2];
+    const Quatd q = _state->_extended_pose->valueLinearAsQuat();
+    od.orientation.x = q.x; od.orientation.y = q.y; od.orientation.z = q.z; od.orientation.w = q.w;
+    od.linear_velocity.x = v[0]; od.linear_velocity.y = v[1]; od.linear_velocity.z = v[2];
+    return true;
+}
+
 }  // namespace ingvio

@@ -14,6 +14,7 @@
 #include "ImuPropagator.h"
 #include "IngvioParams.h"
 #include "MapServer.h"
+#include "Messages.h"
 #include "LandmarkUpdate.h"
 #include "MsckfUpdates.h"
 #include "State.h"
@@ -32,6 +33,12 @@ public:
     void callbackIMU(const ImuMsg& imu_msg);                                            // IngvioFilter.cpp:381-407
     void callbackStereoFrame(const StereoFrameMsg& stereo_frame);                       // :252-379
     void callbackMonoFrame(const MonoFrameMsg& mono_frame);                             // :124-250
+    // the same callbacks on structs shaped like the ROS messages (Messages.h): what a ROS1 wrapper node or the replay driver feeds
+    void callbackIMU(const msg::Imu& imu_msg);
+    void callbackStereoFrame(const msg::StereoFrame& stereo_frame);
+    void callbackMonoFrame(const msg::MonoFrame& mono_frame);
+    // IngvioFilter::visualize (:409-447): the nav_msgs/Odometry it publishes; false when the state holds NaN (:418-419)
+    bool odometry(const msg::Header& header, msg::Odometry& out) const;
     void callbackGnssMeas(const GnssMeas& gnss_meas) { _gnss_sync->bufferGnssMeas(gnss_meas); }       // GnssProcessor.cpp:119-220 -> GnssSync
     void callbackSppMeas(const SppMeas& spp_meas) { _gnss_sync->bufferSppMeas(spp_meas); }
     void setGnssAlignment(const GvioAlignment& a) { _gvio_aligner = a; }
