@@ -1326,79 +1326,49 @@ int ingvio_triangulate(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* 
 int ingvio_qr_compress(ingvio_ctx* c, const double* H, int ldh, int m, int n, const double* res, double* Ht, int ldt, double* rt)
 {
     if (!c || !H || !res || !Ht || !rt || m < 1 || n < 1 || ldh < m || ldt < n) return INGVIO_E_ARG;
-    if (n > 96 || n % 6 != 0 || n > 6 * c->d.c_max || c->d.c_max > 16) {
-        // general shapes (wide windows, the 6000 x 800 stress shape): blocked Householder QR, kernels_qr.hip
-        if (n > 4096) return INGVIO_E_CAPACITY;
-        auto& q = c->qr;
-        if (q.m != m || q.n != n || q.ldh != ldh) {                      // new shape: buffers and the launch graph are rebuilt
-            HIPCHK(c, hipStreamSynchronize(c->st));
-            if (q.exec) { hipGraphExecDestroy(q.exec); q.exec = nullptr; }
-            for (double** p : { &q.dA, &q.db, &q.ws, &q.dT }) { if (*p) hipFree(*p); *p = nullptr; }
-            q.m = q.n = q.ldh = 0;
-            HIPCHK(c, hipMalloc((void**)&q.dA, 8 * (size_t)ldh * n));
-            HIPCHK(c, hipMalloc((void**)&q.db, 8 * (size_t)m));
-            HIPCHK(c, hipMalloc((void**)&q.ws, 8 * qr_dense_workspace_doubles(m, n)));
-            HIPCHK(c, hipMalloc((void**)&q.dT, 8 * ((size_t)n * n + n)));
-            // the factorisation is a fixed sequence of 3 launches per 8-column panel: captured once, replayed as one graph
-            hipGraph_t g = nullptr;
-            HIPCHK(c, hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal));
-            const int lrc = launch_qr_dense(q.dA, ldh, q.db, m, n, q.ws, q.dT, n, q.dT + (size_t)n * n, c->st);
-            const hipError_t ce = hipStreamEndCapture(c->st, &g);
-            if (lrc) { if (g) hipGraphDestroy(g); return INGVIO_E_CAPACITY; }
-            if (ce != hipSuccess || !g) { c->err = "hipStreamEndCapture failed"; return INGVIO_E_HIP; }
-            const hipError_t ie = hipGraphInstantiate(&q.exec, g, nullptr, nullptr, 0);
-            hipGraphDestroy(g);
-            if (ie != hipSuccess) { q.exec = nullptr; c->err = "hipGraphInstantiate failed"; return INGVIO_E_HIP; }
-            q.m = m; q.n = n; q.ldh = ldh;
-        }
-        int rc2 = up(c, q.dA, H, 8 * (size_t)ldh * n) | up(c, q.db, res, 8 * (size_t)m);
-        if (!rc2) {
-            ProfScope p(c, PF_FOLD);
-            if (hipGraphLaunch(q.exec, c->st) != hipSuccess) rc2 = INGVIO_E_HIP;
-        }
-        if (!rc2) {
-            double* dT = q.dT;
-            if (ldt == n) rc2 = hipMemcpyAsync(Ht, dT, 8 * (size_t)n * n, hipMemcpyDeviceToHost, c->st) != hipSuccess;
-            else rc2 = hipMemcpy2DAsync(Ht, 8 * (size_t)ldt, dT, 8 * (size_t)n, 8 * (size_t)n, n, hipMemcpyDeviceToHost, c->st) != hipSuccess;
-            rc2 |= hipMemcpyAsync(rt, dT + (size_t)n * n, 8 * (size_t)n, hipMemcpyDeviceToHost, c->st) != hipSuccess;
-            if (rc2) rc2 = INGVIO_E_HIP;
-        }
-        hipStreamSynchronize(c->st);
-        if (rc2) return rc2 < 0 ? rc2 : INGVIO_E_HIP;
-        return last_launch(c);
+    // Every shape takes the blocked Householder QR of kernels_qr.hip (device buffers and the launch graph cached per shape): no
+    // per-call allocation and no use of any filter's staging buffers - a drop-in for six SPQR call sites must not touch batch state.
+    // Matrices taller than 6144 rows are factorised in row chunks (launch_qr_dense).
+    {
+    if (n > 4096) return INGVIO_E_CAPACITY;
+    auto& q = c->qr;
+    if (q.m != m || q.n != n || q.ldh != ldh) {                      // new shape: buffers and the launch graph are rebuilt
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        if (q.exec) { hipGraphExecDestroy(q.exec); q.exec = nullptr; }
+        for (double** p : { &q.dA, &q.db, &q.ws, &q.dT }) { if (*p) hipFree(*p); *p = nullptr; }
+        q.m = q.n = q.ldh = 0;
+        HIPCHK(c, hipMalloc((void**)&q.dA, 8 * (size_t)ldh * n));
+        HIPCHK(c, hipMalloc((void**)&q.db, 8 * (size_t)m));
+        HIPCHK(c, hipMalloc((void**)&q.ws, 8 * qr_dense_workspace_doubles(m, n)));
+        HIPCHK(c, hipMalloc((void**)&q.dT, 8 * ((size_t)n * n + n)));
+        // the factorisation is a fixed sequence of 3 launches per 8-column panel: captured once, replayed as one graph
+        hipGraph_t g = nullptr;
+        HIPCHK(c, hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal));
+        const int lrc = launch_qr_dense(q.dA, ldh, q.db, m, n, q.ws, q.dT, n, q.dT + (size_t)n * n, c->st);
+        const hipError_t ce = hipStreamEndCapture(c->st, &g);
+        if (lrc) { if (g) hipGraphDestroy(g); return INGVIO_E_CAPACITY; }
+        if (ce != hipSuccess || !g) { c->err = "hipStreamEndCapture failed"; return INGVIO_E_HIP; }
+        const hipError_t ie = hipGraphInstantiate(&q.exec, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (ie != hipSuccess) { q.exec = nullptr; c->err = "hipGraphInstantiate failed"; return INGVIO_E_HIP; }
+        q.m = m; q.n = n; q.ldh = ldh;
     }
-    double *dH = nullptr, *dres = nullptr;
-    HIPCHK(c, hipMalloc((void**)&dH, 8 * (size_t)ldh * n));
-    HIPCHK(c, hipMalloc((void**)&dres, 8 * (size_t)m));
-    int rc = up(c, dH, H, 8 * (size_t)ldh * n) | up(c, dres, res, 8 * (size_t)m);
-    if (rc) { hipFree(dH); hipFree(dres); return INGVIO_E_HIP; }
-    // leaf: G chunks of row blocks -> partial factors in filter 0's Rpart slots
-    MsckfLaunch L;
-    memset(&L, 0, sizeof L);
-    L.stage = 3; L.stereo = 1; L.fv = fview(c); L.G = c->G; L.rstride = c->rstride; L.Rpart = c->d_Rpart;
-    L.chunk_used = c->d_chunk_used; L.dH = dH; L.dres = dres; L.ldh = ldh; L.m = m; L.ncol = n;
-    { ProfScope p(c, PF_FOLD); launch_msckf(L, c->st); }
-    // merge needs n_clones-independent ncol: reuse k_msckf_merge through a 1-filter FrameView whose n_clones = n/6
-    if (n % 6 != 0) { hipStreamSynchronize(c->st); hipFree(dH); hipFree(dres); return INGVIO_E_UNSUPPORTED; }
-    int ncl = n / 6, zero = 0;
-    std::vector<int> keep(2);
-    HIPCHK(c, hipMemcpyAsync(&keep[0], c->d_nclones, sizeof(int), hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipStreamSynchronize(c->st));
-    rc = up(c, c->d_nclones, &ncl, sizeof(int));
-    (void)zero;
-    L.stage = 2; L.b0 = 0; L.nb = 1; L.Hout = c->d_H; L.res_out = c->d_res; L.colmap = c->d_colmap; L.m_out = c->d_m;
-    L.nc_out = c->d_nc; L.mld = c->mld; L.hstride = c->hstride; L.cstride = c->cstride;
-    { ProfScope p(c, PF_MERGE); launch_msckf(L, c->st); }
-    std::vector<double> Hh((size_t)c->mld * n), rh(c->mld);
-    HIPCHK(c, hipMemcpyAsync(Hh.data(), c->d_H, 8 * Hh.size(), hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipMemcpyAsync(rh.data(), c->d_res, 8 * (size_t)n, hipMemcpyDeviceToHost, c->st));
-    rc |= up(c, c->d_nclones, &keep[0], sizeof(int));
-    HIPCHK(c, hipStreamSynchronize(c->st));
-    hipFree(dH); hipFree(dres);
-    if (rc) return INGVIO_E_HIP;
-    for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) Ht[(size_t)j * ldt + i] = (i <= j) ? Hh[(size_t)j * c->mld + i] : 0.0;
-    for (int i = 0; i < n; ++i) rt[i] = rh[i];
+    int rc2 = up(c, q.dA, H, 8 * (size_t)ldh * n) | up(c, q.db, res, 8 * (size_t)m);
+    if (!rc2) {
+        ProfScope p(c, PF_FOLD);
+        if (hipGraphLaunch(q.exec, c->st) != hipSuccess) rc2 = INGVIO_E_HIP;
+    }
+    if (!rc2) {
+        double* dT = q.dT;
+        if (ldt == n) rc2 = hipMemcpyAsync(Ht, dT, 8 * (size_t)n * n, hipMemcpyDeviceToHost, c->st) != hipSuccess;
+        else rc2 = hipMemcpy2DAsync(Ht, 8 * (size_t)ldt, dT, 8 * (size_t)n, 8 * (size_t)n, n, hipMemcpyDeviceToHost, c->st) != hipSuccess;
+        rc2 |= hipMemcpyAsync(rt, dT + (size_t)n * n, 8 * (size_t)n, hipMemcpyDeviceToHost, c->st) != hipSuccess;
+        if (rc2) rc2 = INGVIO_E_HIP;
+    }
+    hipStreamSynchronize(c->st);
+    if (rc2) return rc2 < 0 ? rc2 : INGVIO_E_HIP;
     return last_launch(c);
+    }
 }
 
 static int frame_stage_impl(ingvio_ctx* c, int b0, int nb, const ingvio_frame_step* steps, const ingvio_msckf_frame* frames,

@@ -54,7 +54,7 @@ __device__ __forceinline__ void mulXt(const double M[9], double x, double y, dou
 __host__ __device__ constexpr int rec_size(int cmax) { return REC_HDR + REC_OBS * cmax; }
 
 // ---------------------------------------------------------------------------------------------
-// K3 + K5, one WAVE per (feature, filter): "column-owner" LDL^T in the reduced observation space.
+// K3 + K5, one WAVE per (feature, filter): blocked LDL^T in the reduced observation space.
 //
 // Stereo (G_o is 4x3, full column rank): by Woodbury on S = s^2 I + Gblk Su Gblk^T,
 //     S^-1 = s^-2 (I - Gblk N^-1 Gblk^T) + Gblk N^-1 K^-1 N^-1 Gblk^T,   K = Su + s^2 N^-1,  N = blockdiag(G_o^T G_o)
@@ -63,12 +63,11 @@ __host__ __device__ constexpr int rec_size(int cmax) { return REC_HDR + REC_OBS 
 // a (3 nobs)-dimensional SPD system instead of the (4 nobs)-dimensional S, and no G_o products on Su.
 // Mono (G_o is 2x3): K = s^2 I + Gblk Su Gblk^T itself (2 nobs), W = [r | Hf].
 //
-// Lane j holds column j of the bordered matrix [[0, W^T], [W, K]] (border FIRST: indices 0..3) in
-// registers; pivot p broadcasts column p with v_readlane (lane index and register index are compile-time
-// constants after unrolling), every lane updates its own column: no LDS traffic, no barriers, the wave
-// runs D*nobs pivots back to back and leaves -W^T K^-1 W in the 4x4 border.
-// The 3x3 (2x2) blocks of K are built one observation pair per lane from nine 3x3 blocks of P
-// and exchanged once through LDS.  Also writes the feature's compact record for k_feat_gram.
+// The bordered matrix [[K, W], [W^T, 0]] (K padded with unit pivots to a multiple of 16 minus 12, then the four rows of W^T) is
+// held as 16x16 lower tiles in the MFMA C/D layout and eliminated in panels of 4 pivots on the matrix cores (see the
+// "blocked LDL^T" block in gate3_body); the 4x4 border block ends up holding -W^T K^-1 W.
+// The 3x3 (2x2) blocks of K are built one observation pair per lane from four 3x3 blocks of P and collected in a packed lower
+// triangle in LDS, from which the tiles are filled.
 // ---------------------------------------------------------------------------------------------
 template <int CMAX, bool STEREO, bool WREC = true>
 struct Gate3Shared {

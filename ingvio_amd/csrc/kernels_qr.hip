@@ -28,22 +28,33 @@ namespace {
 // element (r, c) of the panel-major working copy; mp8 = 8 * (rows rounded up to 8)
 __device__ __forceinline__ size_t didx(int r, int c, size_t mp8) { return (size_t)(c >> 3) * mp8 + (size_t)r * 8 + (c & 7); }
 
-// column-major H (ldh) | res  ->  panel-major D, column n = res; padding columns of the last panel are zero
-__global__ __launch_bounds__(256) void k_qr_load(const double* __restrict__ H, int ldh, const double* __restrict__ res, int m, int n,
-                                                  double* __restrict__ D, size_t mp8)
+// column-major H (ldh) | res  ->  panel-major D, column n = res; padding columns of the last panel are zero.
+// Rows [src0, src0 + cnt) of the input go to rows [dst0, dst0 + cnt) of the working copy.
+__global__ __launch_bounds__(256) void k_qr_load(const double* __restrict__ H, int ldh, const double* __restrict__ res, int n,
+                                                  double* __restrict__ D, size_t mp8, int src0, int dst0, int cnt)
 {
     __shared__ double t[32][33];
     const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int cc = ty; cc < 32; cc += 8) {
         const int r = r0 + tx, c = c0 + cc;
-        t[cc][tx] = (r < m && c <= n) ? (c < n ? H[r + (size_t)c * ldh] : res[r]) : 0.0;
+        t[cc][tx] = (r < cnt && c <= n) ? (c < n ? H[(size_t)(src0 + r) + (size_t)c * ldh] : res[src0 + r]) : 0.0;
     }
     __syncthreads();
     const int ncp = (n + 1 + 7) & ~7;
     for (int rr = ty; rr < 32; rr += 8) {
         const int r = r0 + rr, c = c0 + tx;
-        if (r < m && c < ncp) D[didx(r, c, mp8)] = t[tx][rr];
+        if (r < cnt && c < ncp) D[didx(dst0 + r, c, mp8)] = t[tx][rr];
     }
+}
+
+// between two row chunks of a tall matrix: the top n rows keep R (and Q^T res in column n), the reflectors stored below the
+// diagonal are cleared so that [R ; next rows] is the next matrix to factorise
+__global__ __launch_bounds__(256) void k_qr_clear_lower(double* __restrict__ D, size_t mp8, int n)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * n) return;
+    const int i = e / n, j = e - i * n;
+    if (i > j) D[didx(i, j, mp8)] = 0.0;
 }
 
 __global__ __launch_bounds__(QR_NT) void k_qr_panel(double* __restrict__ D, size_t mp8, int m, int j0, int nbp, double* __restrict__ tau_out)
@@ -245,33 +256,57 @@ __global__ __launch_bounds__(256) void k_qr_extract(const double* __restrict__ D
 
 static size_t qr_mp8(int m) { return (size_t)8 * (((size_t)m + 7) & ~(size_t)7); }
 
-size_t qr_dense_workspace_doubles(int m, int n)
-{
-    const size_t npan = ((size_t)n + 1 + 7) / 8, nch = ((size_t)m + QR_RC - 1) / QR_RC, ncp = npan * 8;
-    return npan * qr_mp8(m) + nch * QR_NB * ncp + (size_t)QR_NB * ncp + 64;
-}
 
-int launch_qr_dense(const double* dH, int ldh, const double* dres, int m, int n, double* ws, double* dHt, int ldt, double* drt, hipStream_t st)
+// one factorisation of the top m_eff rows of the working copy (all columns incl. res)
+static void qr_factor_rows(double* D, size_t mp8, int m_eff, int n, double* Wp, double* tau, hipStream_t st)
 {
-    if (m > QR_NT * QR_RPT) return -1;
-    const int n1 = n + 1, npan = (n1 + 7) / 8, ncp = npan * 8;
-    const size_t mp8 = qr_mp8(m);
-    double* D = ws;
-    double* Wp = D + (size_t)npan * mp8;
-    const int nch_max = (m + QR_RC - 1) / QR_RC;
-    double* tau = Wp + (size_t)nch_max * QR_NB * ncp;
-    hipLaunchKernelGGL(k_qr_load, dim3((m + 31) / 32, (ncp + 31) / 32), dim3(256), 0, st, dH, ldh, dres, m, n, D, mp8);
-    const int nref = m - 1 < n ? m - 1 : n;                              // reflectors: min(m-1, n), as the oracle
+    const int n1 = n + 1;
+    const int nref = m_eff - 1 < n ? m_eff - 1 : n;                      // reflectors: min(m-1, n), as the oracle
     for (int j0 = 0; j0 < nref; j0 += QR_NB) {
         const int nbp = nref - j0 < QR_NB ? nref - j0 : QR_NB;
-        hipLaunchKernelGGL(k_qr_panel, dim3(1), dim3(QR_NT), 0, st, D, mp8, m, j0, nbp, tau);
+        hipLaunchKernelGGL(k_qr_panel, dim3(1), dim3(QR_NT), 0, st, D, mp8, m_eff, j0, nbp, tau);
         const int ncx = n1 - j0;                                         // X = columns j0 .. n (incl. res)
         if (ncx > nbp) {
-            const int nch = (m - j0 + QR_RC - 1) / QR_RC, npx = (ncx + 7) / 8;
-            hipLaunchKernelGGL(k_qr_w, dim3(npx, nch), dim3(256), 0, st, D, mp8, m, ncx, j0, nbp, Wp);
-            hipLaunchKernelGGL(k_qr_apply, dim3(npx, nch), dim3(256), 0, st, D, mp8, m, ncx, j0, nbp, Wp, nch, tau);
+            const int nch = (m_eff - j0 + QR_RC - 1) / QR_RC, npx = (ncx + 7) / 8;
+            hipLaunchKernelGGL(k_qr_w, dim3(npx, nch), dim3(256), 0, st, D, mp8, m_eff, ncx, j0, nbp, Wp);
+            hipLaunchKernelGGL(k_qr_apply, dim3(npx, nch), dim3(256), 0, st, D, mp8, m_eff, ncx, j0, nbp, Wp, nch, tau);
         }
     }
-    hipLaunchKernelGGL(k_qr_extract, dim3((n * n + 255) / 256), dim3(256), 0, st, D, mp8, m, n, dHt, ldt, drt);
+}
+
+#define QR_ROW_CAP (QR_NT * QR_RPT)      // rows the register-resident panel kernel can hold
+
+size_t qr_dense_workspace_doubles(int m, int n)
+{
+    const size_t mw = m < QR_ROW_CAP ? m : QR_ROW_CAP;
+    const size_t npan = ((size_t)n + 1 + 7) / 8, nch = (mw + QR_RC - 1) / QR_RC, ncp = npan * 8;
+    return npan * qr_mp8((int)mw) + nch * QR_NB * ncp + (size_t)QR_NB * ncp + 64;
+}
+
+// Any m: a matrix taller than the panel kernel's 6144 rows is factorised in row chunks (a sequential TSQR): the first 6144 rows
+// give R_0, then [R_s ; next 6144 - n rows] gives R_s+1 ... - e.g. BASELINE config 5's literal stacked shape 35100 x 180
+// (RemoveLostUpdate.cpp:376-397 at F = 300, C = 30) takes 6 factorisations.  Returns -1 when n leaves no room for a chunk.
+int launch_qr_dense(const double* dH, int ldh, const double* dres, int m, int n, double* ws, double* dHt, int ldt, double* drt, hipStream_t st)
+{
+    if (m > QR_ROW_CAP && n + 64 > QR_ROW_CAP) return -1;
+    const int n1 = n + 1, npan = (n1 + 7) / 8, ncp = npan * 8;
+    const int mw = m < QR_ROW_CAP ? m : QR_ROW_CAP;
+    const size_t mp8 = qr_mp8(mw);
+    double* D = ws;
+    double* Wp = D + (size_t)npan * mp8;
+    const int nch_max = (mw + QR_RC - 1) / QR_RC;
+    double* tau = Wp + (size_t)nch_max * QR_NB * ncp;
+    hipLaunchKernelGGL(k_qr_load, dim3((mw + 31) / 32, (ncp + 31) / 32), dim3(256), 0, st, dH, ldh, dres, n, D, mp8, 0, 0, mw);
+    qr_factor_rows(D, mp8, mw, n, Wp, tau, st);
+    int done = mw, m_last = mw;
+    while (done < m) {
+        const int cnt = m - done < QR_ROW_CAP - n ? m - done : QR_ROW_CAP - n;
+        hipLaunchKernelGGL(k_qr_clear_lower, dim3((n * n + 255) / 256), dim3(256), 0, st, D, mp8, n);
+        hipLaunchKernelGGL(k_qr_load, dim3((cnt + 31) / 32, (ncp + 31) / 32), dim3(256), 0, st, dH, ldh, dres, n, D, mp8, done, n, cnt);
+        m_last = n + cnt;
+        qr_factor_rows(D, mp8, m_last, n, Wp, tau, st);
+        done += cnt;
+    }
+    hipLaunchKernelGGL(k_qr_extract, dim3((n * n + 255) / 256), dim3(256), 0, st, D, mp8, m_last, n, dHt, ldt, drt);
     return 0;
 }

@@ -622,6 +622,29 @@ def test_qr_compress_general_vs_oracle(orc, m, n):
     ctx3.close()
 
 
+def test_qr_compress_tall_literal_config5_shape(orc):
+    """The literal stacked shape of BASELINE config 5: 300 features x 30 clones, stereo -> 35100 x 180 (RemoveLostUpdate.cpp:376-397).
+    Taller than the panel kernel's 6144 rows: factorised in row chunks.  R and Q^T r against the oracle's one-shot Householder up
+    to row signs; the call must not touch any filter of the context."""
+    from ingvio_amd import capi
+    ctx3 = capi.Context(batch=2, n_max=64, c_max=11, f_max=8, m_max=64)
+    rng = np.random.default_rng(35100)
+    P = np.eye(30) * 0.5 + 0.01
+    ctx3.cov_set(0, P); ctx3.cov_set(1, 2 * P)
+    m, n = 35100, 180
+    A = rng.standard_normal((m, n)) * np.logspace(0, -2, n); b = rng.standard_normal(m)
+    Ht, rt = ctx3.qr_compress(A, b)
+    assert not np.tril(Ht, -1).any() and np.isfinite(Ht).all()
+    assert rel_err(Ht.T @ Ht, A.T @ A) < 1e-12 and rel_err(Ht.T @ rt, A.T @ b) < 1e-11
+    Ro, ro = orc.qr_compress(A, b)
+    sg = np.sign(np.diag(Ro[:n])) * np.sign(np.diag(Ht))
+    assert np.linalg.norm(Ht - sg[:, None] * Ro[:n]) < 1e-10 * np.linalg.norm(Ro[:n]) and np.linalg.norm(rt - sg * ro[:n]) < 1e-10 * np.linalg.norm(ro[:n])
+    assert np.array_equal(ctx3.cov_get(0), P) and np.array_equal(ctx3.cov_get(1), 2 * P)
+    Ht2, rt2 = ctx3.qr_compress(A, b)                                      # cached graph: bit-identical on replay
+    assert np.array_equal(Ht, Ht2) and np.array_equal(rt, rt2)
+    ctx3.close()
+
+
 def test_qr_compress_stress_shape():
     """BASELINE config 5's pure-kernel shape: dense 6000 x 800, cond ~ 1e3.  Size-independent properties + LAPACK's R up
     to row signs."""
