@@ -191,6 +191,20 @@ def hbm_traffic_bytes(c):
 
 BIG_NAMES = {"k_feat_gate3": "k_feat_gate3_big", "k_feat_gram2": "k_feat_gram_big", "k_info_update": "k_info_update_big",
              "k_info_apply": "k_info_apply_big"}
+# the library's profile slots are named after the stage; the kernel rocprofv3 sees for the K8/K9 stage is k_info_solve (windows up
+# to 11 clones) or k_info_update (12..16)
+ALIASES = {"k_info_update": ("k_info_solve", "k_info_update"), "restore": ("k_restore_strips", "k_restore")}
+
+
+def counters_for(counters, name, big):
+    if counters is None:
+        return None
+    if big and name in BIG_NAMES:
+        return counters.get(BIG_NAMES[name])
+    for cand in ALIASES.get(name, (name,)):
+        if cand in counters:
+            return counters[cand]
+    return None
 
 
 def cpu_baseline(ctx, steps, frames, n_prior, ld, quick=False):
@@ -375,8 +389,7 @@ def main():
                 continue
             avg = ms / calls
             e = dict(avg_ms=avg, calls=calls)
-            cn = BIG_NAMES.get(name, name) if C > 16 else name
-            c = (counters or {}).get(cn)
+            c = counters_for(counters, name, C > 16)
             ex = executed_fp64_flops(c)
             if ex is not None:
                 e["executed_fp64_flop_per_launch"] = ex["total"]
