@@ -420,7 +420,7 @@ int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int s
     L.big_wk = c->d_big_wk ? c->d_big_wk + (size_t)b0 * bigwin_wk_doubles() : nullptr;
     { ProfScope p(c, PF_GATE2); L.stage = 0; if (launch_factored(L, c->st)) return INGVIO_E_UNSUPPORTED; }
     { ProfScope p(c, PF_GRAM); L.stage = 1; launch_factored(L, c->st); }
-    L.mstride = c->ystride; L.n_cap = c->d.n_max;
+    L.mstride = c->ystride; L.n_cap = c->d.n_max; L.ncol_cap = 6 * c->d.c_max;
     L.marg_idx = marg_idx; L.marg_size = marg_size; L.pc_base = c->d_pcbase + b0;
     { ProfScope p(c, PF_INFO); L.stage = 2; launch_factored(L, c->st); }
     { ProfScope p(c, PF_APPLY); L.stage = 3; launch_factored(L, c->st); }

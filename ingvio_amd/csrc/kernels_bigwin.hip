@@ -12,6 +12,8 @@
 // Correct and parallel, not tuned: the batched config-2 benchmark never takes this path.  gfx950 only.
 #include <algorithm>
 #include "launch_factored.h"
+#include "launch_chol.h"
+#include <stdlib.h>
 #include "gate_kernel.h"
 
 #define BIG_CMAX 36
@@ -470,6 +472,150 @@ __global__ __launch_bounds__(IB_NT, 1) void k_info_update_big(
 }
 
 // ---------------------------------------------------------------------------------------------
+// K8/K9/K11 in symmetric form across the whole GPU (round 2): the same mathematics as kernels_solve.hip,
+//     Pcc = L L^T,  W = L^T A L + s^2 I = L2 L2^T,  M = (L^-T L2^-T)(A L L2^-T)^T,  t = (L^-T L2^-T)(b^T L L2^-T)^T,
+// built from the batched blocks of kernels_chol.hip (two Cholesky sweeps with carried rows, three GEMMs) instead of ONE
+// workgroup eliminating 216 pivots.  Workspace per filter, column-major, n32 = 6 c_max rounded up to 32 (padding: identity in
+// Pcc, zero in A, so every window size up to the capacity runs the same launches):
+//     AB [n32+16][n32]   A, then the row b^T           X1, Y1 [2 n32][n32]      [Pcc; I] -> [L; L^-T]
+//     X2, Y2 [3 n32+16][n32]   [W; A L; b^T L; L^-T] -> [L2; R1; r1b; R2]
+// ---------------------------------------------------------------------------------------------
+struct BigWs {
+    int n32, ld1, ld2, ldab;
+    size_t oAB, oX1, oY1, oX2, oY2, oT, total;
+    __host__ __device__ explicit BigWs(int n32_) : n32(n32_), ld1(2 * n32_), ld2(3 * n32_ + 16), ldab(n32_ + 16)
+    {
+        oAB = 0; oX1 = oAB + (size_t)ldab * n32; oY1 = oX1 + (size_t)ld1 * n32; oX2 = oY1 + (size_t)ld1 * n32;
+        oY2 = oX2 + (size_t)ld2 * n32; oT = oY2 + (size_t)ld2 * n32; total = oT + 1024;
+    }
+};
+
+__global__ __launch_bounds__(256) void k_big_prep(
+    CovView cv, FrameView fv, int b0, const double* __restrict__ Apart, const int* __restrict__ chunk_used, int G, int rstride,
+    double* __restrict__ Pcall, int ystride, double* __restrict__ dx_all, int* __restrict__ m_out, int* __restrict__ nc_out,
+    const int* __restrict__ marg_idx, int* __restrict__ pc_base_out, double* __restrict__ ws_all, size_t ws_stride, int n32)
+{
+    constexpr int NC = BIG_NC, MP = NC;
+    __shared__ int sCol[NC];
+    const BigWs w(n32);
+    const int bl = blockIdx.y, b = b0 + bl, tid = threadIdx.x, nwg = gridDim.x, wg = blockIdx.x;
+    const int C = fv.n_clones[b], ncol = 6 * C, n = cv.n[b], ld = cv.ldp;
+    int total = 0;
+    for (int g = 0; g < G; ++g) total += chunk_used[bl * G + g];
+    if (total == 0) {
+        double* dx = dx_all + (size_t)b * ld;
+        for (int r = wg * 256 + tid; r < n; r += nwg * 256) dx[r] = 0.0;
+        if (wg == 0 && tid == 0) { m_out[bl] = 0; nc_out[bl] = ncol; pc_base_out[bl] = -1; }
+        return;
+    }
+    for (int c = tid; c < NC; c += 256) {
+        const int cc = c < ncol ? c : 0;
+        sCol[c] = fv.clone_idx[(size_t)b * fv.cmax + cc / 6] + cc % 6;
+    }
+    __syncthreads();
+    const double* P = cov_ptr(cv, b);
+    double* ws = ws_all + (size_t)bl * ws_stride;
+    double *AB = ws + w.oAB, *X1 = ws + w.oX1;
+    const int gt = wg * 256 + tid, gn = nwg * 256;
+    // [A; b^T] from the chunk partials (A symmetric: element (i, j) read as partial row j, column i - coalesced along i)
+    for (int e = gt; e < w.ldab * n32; e += gn) {
+        const int i = e % w.ldab, j = e / w.ldab;
+        double s = 0.0;
+        if (j < ncol && (i < ncol || i == n32)) {
+            const size_t src = (size_t)j * (ncol + 1) + (i == n32 ? ncol : i);
+            for (int g0 = 0; g0 < G; g0 += 8) {
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int g = g0 + u;
+                    t[u] = (g < G && chunk_used[bl * G + g]) ? Apart[((size_t)bl * G + g) * rstride + src] : 0.0;
+                }
+                s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+            }
+        }
+        AB[e] = s;
+    }
+    // [Pcc; I], identity in the padding
+    for (int e = gt; e < w.ld1 * n32; e += gn) {
+        const int i = e % w.ld1, j = e / w.ld1;
+        double v;
+        if (i < n32) v = (i < ncol && j < ncol) ? P[sCol[i] + (size_t)sCol[j] * ld] : (i == j ? 1.0 : 0.0);
+        else v = (i - n32 == j) ? 1.0 : 0.0;
+        X1[e] = v;
+    }
+    const bool fused = marg_idx && marg_idx[bl] >= 0;
+    bool contig = true;
+    for (int c = 0; c < ncol; ++c) contig = contig && (sCol[c] == sCol[0] + c);
+    const bool zero_copy = fused && contig && sCol[0] + MP <= ld;
+    if (!zero_copy) {
+        double* Pc = Pcall + (size_t)bl * ystride;
+        for (int e = gt; e < MP * n; e += gn) {
+            const int r = e % n, k = e / n;
+            Pc[r + (size_t)k * ld] = k < ncol ? P[r + (size_t)sCol[k] * ld] : 0.0;
+        }
+    }
+    if (wg == 0 && tid == 0) { m_out[bl] = ncol; nc_out[bl] = ncol; pc_base_out[bl] = zero_copy ? sCol[0] : -1; }
+}
+
+// rows [src_row, +nrows) of S (ld lds) -> rows [dst_row, +nrows) of D (ld ldd), ncols columns, per batch element
+__global__ __launch_bounds__(256) void k_copy_rows(const double* __restrict__ S, size_t ss, int lds, int src_row, double* __restrict__ D,
+                                                   size_t sd, int ldd, int dst_row, int nrows, int ncols, const int* __restrict__ active)
+{
+    const int bl = blockIdx.y;
+    if (active && !active[bl]) return;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < nrows * ncols; e += gridDim.x * 256) {
+        const int i = e % nrows, j = e / nrows;
+        D[(size_t)bl * sd + dst_row + i + (size_t)j * ldd] = S[(size_t)bl * ss + src_row + i + (size_t)j * lds];
+    }
+}
+
+static int big_n32(int ncol_cap) { const int n = ncol_cap > 0 ? ncol_cap : BIG_NC; return (n + 31) / 32 * 32; }
+
+static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
+{
+    const int n32 = big_n32(L.ncol_cap), MP = BIG_NC;
+    const BigWs w(n32);
+    const size_t wss = bigwin_wk_doubles();
+    double* ws = L.big_wk;
+    hipLaunchKernelGGL(k_big_prep, dim3(32, L.nb), dim3(256), 0, st, L.cv, L.fv, L.b0, L.Apart, L.chunk_used, L.G, L.rstride, L.Pc,
+                       L.ystride, L.dx, L.m_out, L.nc_out, L.marg_idx, L.pc_base, ws, wss, n32);
+    const int* act = L.m_out;                                            // 0 = nothing accepted: every later launch skips the filter
+    CholArgs c1 = {};
+    c1.X = ws + w.oX1; c1.Y = ws + w.oY1; c1.xs = wss; c1.ld = w.ld1; c1.rows = 2 * n32; c1.ncols = n32;
+    c1.status = L.status + L.b0; c1.fail_bit = 4; c1.active = act; c1.batch = L.nb; c1.Tb = ws + w.oT; c1.ts = wss;
+    launch_chol_sweep(c1, st);
+    GemmArgs g = {};
+    // [A; b^T] L -> X2 rows n32 ..
+    g.A = ws + w.oAB; g.sa = wss; g.lda = w.ldab; g.modeA = 0;
+    g.B = ws + w.oY1; g.sb = wss; g.ldb = w.ld1; g.modeB = 1;
+    g.C = ws + w.oX2 + n32; g.sc = wss; g.rs = 1; g.cs = w.ld2;
+    g.M = n32 + 16; g.N = n32; g.K = n32; g.m_lim = n32 + 16; g.n_lim = n32; g.ksplit = 1; g.active = act; g.batch = L.nb;
+    launch_gemm(g, st);
+    // W = L^T (A L) + s^2 I -> X2 rows 0 .. (lower blocks)
+    g = GemmArgs{};
+    g.A = ws + w.oY1; g.sa = wss; g.lda = w.ld1; g.modeA = 1;
+    g.B = ws + w.oX2 + n32; g.sb = wss; g.ldb = w.ld2; g.modeB = 1;
+    g.C = ws + w.oX2; g.sc = wss; g.rs = 1; g.cs = w.ld2;
+    g.M = n32; g.N = n32; g.K = n32; g.m_lim = n32; g.n_lim = n32; g.ksplit = 1; g.lower = 1; g.diag_add_vec = L.noise;
+    g.active = act; g.batch = L.nb;
+    launch_gemm(g, st);
+    hipLaunchKernelGGL(k_copy_rows, dim3(16, L.nb), dim3(256), 0, st, ws + w.oY1, wss, w.ld1, n32, ws + w.oX2, wss, w.ld2, 2 * n32 + 16,
+                       n32, n32, act);
+    CholArgs c2 = c1;
+    c2.X = ws + w.oX2; c2.Y = ws + w.oY2; c2.ld = w.ld2; c2.rows = 3 * n32 + 16;
+    launch_chol_sweep(c2, st);
+    // M = R2 R1^T (row-major, MP wide), t = R2 r1b^T
+    g = GemmArgs{};
+    g.A = ws + w.oY2 + 2 * n32 + 16; g.sa = wss; g.lda = w.ld2; g.modeA = 0;
+    g.B = ws + w.oY2 + n32; g.sb = wss; g.ldb = w.ld2; g.modeB = 0;
+    g.C = L.T; g.sc = L.mstride; g.rs = MP; g.cs = 1;
+    g.M = n32; g.N = n32; g.K = n32; g.m_lim = MP; g.n_lim = MP; g.ksplit = 1; g.active = act; g.batch = L.nb;
+    launch_gemm(g, st);
+    g.B = ws + w.oY2 + 2 * n32; g.C = L.T + (size_t)MP * MP; g.rs = 1; g.cs = 0; g.N = 1; g.n_lim = 1;
+    launch_gemm(g, st);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K10 (+ fused K12), see k_info_apply: one wave per 16-row tile row, T row in LDS, K streamed.
 // ---------------------------------------------------------------------------------------------
 struct ABShared {
@@ -584,7 +730,7 @@ __global__ __launch_bounds__(256, 1) void k_info_apply_big(
 // ---------------------------------------------------------------------------------------------
 int dbg_read_bigwin(long long* out, int n) { return dbg_read_local(out, n); }
 size_t bigwin_sg_doubles(int G) { return (size_t)G * BIG_CMAX * BIG_CMAX * GB_SW; }
-size_t bigwin_wk_doubles() { return (size_t)BIG_NC * (2 * BIG_NC + 1); }
+size_t bigwin_wk_doubles() { const size_t gj = (size_t)BIG_NC * (2 * BIG_NC + 1), ch = BigWs(big_n32(BIG_NC)).total; return gj > ch ? gj : ch; }
 int bigwin_rec_size() { return rec_size(BIG_CMAX); }
 int bigwin_cmax() { return BIG_CMAX; }
 
@@ -610,6 +756,8 @@ int launch_bigwin(const FactoredLaunch& L, hipStream_t st)
         return 0;
     }
     if (L.stage == 2) {
+        static const bool use_gj = [] { const char* e = getenv("INGVIO_BIG_SOLVE"); return e && e[0] == 'g'; }();
+        if (!use_gj) { launch_big_solve(L, st); return 0; }
         hipLaunchKernelGGL(k_info_update_big, dim3(L.nb), dim3(IB_NT), 0, st, L.cv, L.fv, L.b0, L.Apart, L.chunk_used, L.G,
                            L.rstride, L.noise, L.T, L.mstride, L.Pc, L.ystride, L.dx, L.m_out, L.nc_out, L.status, L.marg_idx,
                            L.pc_base, L.big_wk);

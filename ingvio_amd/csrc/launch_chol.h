@@ -1,0 +1,44 @@
+// launch_chol.h — batched SPD building blocks out of HBM/L2 (kernels_chol.hip): FP64 MFMA GEMM with split-K and a blocked
+// left-looking Cholesky sweep with carried rows.  Used where one workgroup's registers/LDS cannot hold the matrix: the Kalman
+// solve of 17..36-clone windows (StateManager.cpp:359-411 at 6C = 102..216), Cholesky-QR of tall stacks (the thin-QR compression
+// of RemoveLostUpdate.cpp:376-397), generic ekfUpdate with more rows than S fits in LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+// C(i, j) = sum_k opA(i, k) opB(k, j)  [+ diag_add on i == j], i < M, j < N, k < K; operands are read with bounds checks (any M, N, K).
+//   modeA 0: opA(i, k) = A[i + k lda]   ("row-contiguous": 16 lanes read 16 consecutive i)
+//   modeA 1: opA(i, k) = A[k + i lda]   ("k-contiguous")                     -- same for modeB with j in the place of i
+//   Ax / Bx (optional): row index ax of opA (column index bx of opB) is read from the vector Ax[k] (Bx[k]) instead
+//   C written at C[i rs + j cs] for i < m_lim, j < n_lim;  lower != 0: only 32x32 blocks with bi >= bj are computed
+//   ksplit > 1: grid-level split of K, partial p goes to C + p * csplit (the caller reduces); batch stride s*, grid.z = batch
+//   active (optional): per batch element, 0 = skip
+struct GemmArgs {
+    const double* A; size_t sa; int lda, modeA;
+    const double* B; size_t sb; int ldb, modeB;
+    const double* Ax; int ax; const double* Bx; int bx;
+    double* C; size_t sc; long rs, cs;
+    int M, N, K, m_lim, n_lim;
+    int ksplit; size_t csplit;
+    int lower;
+    double diag_add; const double* diag_add_vec;    // diag_add_vec[batch] (e.g. the per-filter measurement variance) overrides diag_add
+    const int* active;
+    int batch;
+};
+void launch_gemm(const GemmArgs& g, hipStream_t st);
+
+// Blocked left-looking Cholesky of the leading ncols x ncols block of X (column-major, ld rows, ncols a multiple of 32, lower
+// triangle read), out of place into Y:  Y[0:ncols] = L (upper part zero),  rows ncols..rows (a multiple of 16) are CARRIED:
+// Y[r] = X[r] L^-T.  Two launches per 32-column panel: the diagonal block (one workgroup per batch element), then one workgroup per 16 rows below it.
+//   clamp != 0: a pivot <= clamp_rel * (original diagonal) zeroes its column (semi-definite input: rank-deficient gram);
+//   clamp == 0: a non-positive pivot also zeroes the column and sets bit `fail_bit` in status[batch] (status may be null).
+struct CholArgs {
+    const double* X; double* Y; size_t xs; int ld;
+    double* Tb; size_t ts;      // scratch for the current panel's L_d^-T: 1024 doubles per batch element, stride ts
+    int rows, ncols;
+    int clamp; double clamp_rel;
+    int* status; int fail_bit;
+    const int* active;
+    int batch;
+};
+void launch_chol_sweep(const CholArgs& a, hipStream_t st);

@@ -29,7 +29,8 @@ struct FactoredLaunch {
     int marg_size;
     int* pc_base;         // [nb] stage 2 -> 3: first clone column when Pc is read straight from P, else -1
     double* big_sg;       // large-window path: [nb][G][36][36][34] sparse sums (kernels_bigwin.hip)
-    double* big_wk;       // large-window path: [nb][216][433] Gauss-Jordan workspace
+    double* big_wk;       // large-window path: per-filter solve workspace (bigwin_wk_doubles)
+    int ncol_cap;         // 6 * (context c_max): size class of the large-window solve
 };
 
 int launch_factored(const FactoredLaunch& L, hipStream_t st);
