@@ -274,9 +274,13 @@ int ingvio_set_msckf_method(ingvio_ctx* ctx, int method);
 /* Stacked-QR compression on its own (the SPQR call sites RemoveLostUpdate.cpp:376-397,
  * SwMargUpdate.cpp:336-357, KeyframeUpdate.cpp:707-728): H m x n (ldh) column-major, res [m] ->
  * H_thin n x n upper triangular (ldt) and r_thin [n] with H_thin^T H_thin = H^T H,
- * H_thin^T r_thin = H^T res.  Any m, n <= 4096 (for m > 6144: n <= 6080): blocked Householder QR (kernels_qr.hip), taller matrices in
- * row chunks - e.g. the 35100 x 180 stack of 300 features x 30 clones.  Touches no filter state; device buffers and the launch
- * graph are cached per shape. */
+ * H_thin^T r_thin = H^T res.  Any m, n <= 4096.  Two methods (ingvio_set_qr_method): blocked Householder QR (kernels_qr.hip; the
+ * oracle's reflector convention, rows above 6144 in chunks) and, by default for tall stacks (n >= 128, m >= 6 n: the 35100 x 180
+ * stack of 300 features x 30 clones, the 6000 x 800 stress shape), Cholesky-QR: H_thin = chol([H|res]^T [H|res]) on the matrix
+ * cores (kernels_chol.hip), diagonal positive, identical H_thin^T H_thin / H_thin^T r_thin - which is all ekfUpdate reads.
+ * Touches no filter state; device buffers and the launch graph are cached per shape. */
+/* method: 0 automatic (default), 1 Householder always, 2 Cholesky-QR always */
+int ingvio_set_qr_method(ingvio_ctx* ctx, int method);
 int ingvio_qr_compress(ingvio_ctx* ctx, const double* H, int ldh, int m, int n, const double* res,
                        double* H_thin, int ldt, double* r_thin);
 

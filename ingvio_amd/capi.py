@@ -26,7 +26,7 @@ EXPORTS = [
     "ingvio_append_independent", "ingvio_ekf_update", "ingvio_chi2_gamma", "ingvio_msckf_update", "ingvio_qr_compress",
     "ingvio_frame_stage", "ingvio_frame_stage_async", "ingvio_frame_run", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_select",
     "ingvio_profile_reset",
-    "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_debug_read", "ingvio_triangulate",
+    "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_set_qr_method", "ingvio_debug_read", "ingvio_triangulate",
     "ingvio_gnss_front_stage", "ingvio_gnss_front_fetch", "ingvio_gnss_update_batch", "ingvio_gnss_stage", "ingvio_gnss_run", "ingvio_gnss_fetch", "ingvio_mld", "ingvio_debug_msckf_info", "ingvio_debug_info_solution",
     "ingvio_chi2_gamma_multi", "ingvio_ekf_update_batch", "ingvio_add_variable_delayed_invertible", "ingvio_add_variable_delayed", "ingvio_replace_var_linear",
 ]
@@ -183,6 +183,10 @@ class Context:
     def set_method(self, method):
         """'dense' (literal TSQR path) or 'factored' (default, structure-exploiting information form)."""
         self._chk(self.L.ingvio_set_msckf_method(self.h, {"dense": 0, "factored": 1}[method]))
+
+    def set_qr_method(self, method):
+        """qr_compress: "auto" (default), "householder", "cholesky" (ingvio_set_qr_method)"""
+        self._chk(self.L.ingvio_set_qr_method(self.h, {"auto": 0, "householder": 1, "cholesky": 2}[method]))
 
     def debug_read(self, n=32):
         out = (C.c_longlong * n)()

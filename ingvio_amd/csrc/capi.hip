@@ -9,6 +9,7 @@
 #include "launch_tri.h"
 #include "launch_lm.h"
 #include "launch_qr.h"
+#include "launch_chol.h"
 #include "launch_gnss.h"
 
 #include <stdio.h>
@@ -64,7 +65,8 @@ struct ingvio_ctx {
     double *d_big_sg, *d_big_wk;        // large-window workspaces (c_max > 16)
     int* d_tri_ok;                      // [B][f_max] triangulation flags
     // ingvio_qr_compress, general path: device buffers and the captured launch sequence (~300 kernels) of the last shape
-    struct QrCache { int m = 0, n = 0, ldh = 0; double *dA = nullptr, *db = nullptr, *ws = nullptr, *dT = nullptr; hipGraphExec_t exec = nullptr; } qr;
+    struct QrCache { int m = 0, n = 0, ldh = 0, chol = 0; double *dA = nullptr, *db = nullptr, *ws = nullptr, *dT = nullptr; hipGraphExec_t exec = nullptr; } qr;
+    int qr_method = 0;                  // ingvio_set_qr_method: 0 auto, 1 Householder, 2 Cholesky-QR
     double* d_noiseB = nullptr;         // ingvio_ekf_update_batch: [B][mld] scalar / diagonal noise per filter
     // ingvio_gnss_stage / _run / _fetch: the staged candidate rows of the batch (pristine: every run gates and compacts them
     // into the generic update's working buffers d_H / d_res / d_noiseB)
@@ -1323,6 +1325,13 @@ int ingvio_triangulate(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* 
     return last_launch(c);
 }
 
+int ingvio_set_qr_method(ingvio_ctx* c, int method)
+{
+    if (!c || method < 0 || method > 2) return INGVIO_E_ARG;
+    c->qr_method = method;
+    return INGVIO_OK;
+}
+
 int ingvio_qr_compress(ingvio_ctx* c, const double* H, int ldh, int m, int n, const double* res, double* Ht, int ldt, double* rt)
 {
     if (!c || !H || !res || !Ht || !rt || m < 1 || n < 1 || ldh < m || ldt < n) return INGVIO_E_ARG;
@@ -1332,26 +1341,31 @@ int ingvio_qr_compress(ingvio_ctx* c, const double* H, int ldh, int m, int n, co
     {
     if (n > 4096) return INGVIO_E_CAPACITY;
     auto& q = c->qr;
-    if (q.m != m || q.n != n || q.ldh != ldh) {                      // new shape: buffers and the launch graph are rebuilt
+    // tall stacks (the stacked MSCKF rows: 35100 x 180, the 6000 x 800 stress shape) take Cholesky-QR, everything else Householder
+    const int chol = c->qr_method == 2 || (c->qr_method == 0 && n >= 128 && (long long)m >= 6LL * n);
+    if (q.m != m || q.n != n || q.ldh != ldh || q.chol != chol) {                      // new shape: buffers and the launch graph are rebuilt
         HIPCHK(c, hipStreamSynchronize(c->st));
         if (q.exec) { hipGraphExecDestroy(q.exec); q.exec = nullptr; }
         for (double** p : { &q.dA, &q.db, &q.ws, &q.dT }) { if (*p) hipFree(*p); *p = nullptr; }
         q.m = q.n = q.ldh = 0;
         HIPCHK(c, hipMalloc((void**)&q.dA, 8 * (size_t)ldh * n));
         HIPCHK(c, hipMalloc((void**)&q.db, 8 * (size_t)m));
-        HIPCHK(c, hipMalloc((void**)&q.ws, 8 * qr_dense_workspace_doubles(m, n)));
+        const size_t wsd = chol ? qr_chol_workspace_doubles(m, n) : qr_dense_workspace_doubles(m, n);
+        HIPCHK(c, hipMalloc((void**)&q.ws, 8 * wsd));
+        HIPCHK(c, hipMemsetAsync(q.ws, 0, 8 * wsd, c->st));
         HIPCHK(c, hipMalloc((void**)&q.dT, 8 * ((size_t)n * n + n)));
         // the factorisation is a fixed sequence of 3 launches per 8-column panel: captured once, replayed as one graph
         hipGraph_t g = nullptr;
         HIPCHK(c, hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal));
-        const int lrc = launch_qr_dense(q.dA, ldh, q.db, m, n, q.ws, q.dT, n, q.dT + (size_t)n * n, c->st);
+        const int lrc = chol ? launch_qr_chol(q.dA, ldh, q.db, m, n, q.ws, q.dT, n, q.dT + (size_t)n * n, c->st)
+                             : launch_qr_dense(q.dA, ldh, q.db, m, n, q.ws, q.dT, n, q.dT + (size_t)n * n, c->st);
         const hipError_t ce = hipStreamEndCapture(c->st, &g);
         if (lrc) { if (g) hipGraphDestroy(g); return INGVIO_E_CAPACITY; }
         if (ce != hipSuccess || !g) { c->err = "hipStreamEndCapture failed"; return INGVIO_E_HIP; }
         const hipError_t ie = hipGraphInstantiate(&q.exec, g, nullptr, nullptr, 0);
         hipGraphDestroy(g);
         if (ie != hipSuccess) { q.exec = nullptr; c->err = "hipGraphInstantiate failed"; return INGVIO_E_HIP; }
-        q.m = m; q.n = n; q.ldh = ldh;
+        q.m = m; q.n = n; q.ldh = ldh; q.chol = chol;
     }
     int rc2 = up(c, q.dA, H, 8 * (size_t)ldh * n) | up(c, q.db, res, 8 * (size_t)m);
     if (!rc2) {
@@ -1600,8 +1614,10 @@ int ingvio_debug_read(ingvio_ctx* c, long long* out, int n)
     HIPCHK(c, hipStreamSynchronize(c->st));
     long long a[64], bq[64], cq[64], sq[64];
     if (dbg_read_factored(a, 64) || dbg_read_cov(bq, 64) || dbg_read_bigwin(cq, 64) || dbg_read_solve(sq, 64)) return INGVIO_E_HIP;
-    for (int i = 0; i < n; ++i)      // 16..23 cov, 24..31 the symmetric solve (its slots 0..7), 48.. large-window TU
-        out[i] = i >= 48 ? cq[i] : ((i >= 24 && i < 32) ? sq[i - 24] : ((i < 16 || i >= 32) ? a[i] : bq[i]));
+    long long hq[64];
+    if (dbg_read_chol(hq, 64)) return INGVIO_E_HIP;
+    for (int i = 0; i < n; ++i)      // 16..23 cov, 24..31 the symmetric solve (its slots 0..7), 48..55 large-window TU, 56..63 kernels_chol (0..7)
+        out[i] = i >= 56 ? hq[i - 56] : (i >= 48 ? cq[i] : ((i >= 24 && i < 32) ? sq[i - 24] : ((i < 16 || i >= 32) ? a[i] : bq[i])));
     return INGVIO_OK;
 }
 

@@ -477,16 +477,17 @@ __global__ __launch_bounds__(IB_NT, 1) void k_info_update_big(
 // built from the batched blocks of kernels_chol.hip (two Cholesky sweeps with carried rows, three GEMMs) instead of ONE
 // workgroup eliminating 216 pivots.  Workspace per filter, column-major, n32 = 6 c_max rounded up to 32 (padding: identity in
 // Pcc, zero in A, so every window size up to the capacity runs the same launches):
-//     AB [n32+16][n32]   A, then the row b^T           X1, Y1 [2 n32][n32]      [Pcc; I] -> [L; L^-T]
-//     X2, Y2 [3 n32+16][n32]   [W; A L; b^T L; L^-T] -> [L2; R1; r1b; R2]
+//     AB [n32+32][n32]   A, then the row b^T           X1, Y1 [2 n32][n32]      [Pcc; I] -> [L; L^-T]
+//     X2, Y2 [3 n32+32][n32]   [W; A L; b^T L; L^-T] -> [L2; R1; r1b; R2]
+// (X1, X2 are working copies: the right-looking sweep updates their trailing parts in place)
 // ---------------------------------------------------------------------------------------------
 struct BigWs {
     int n32, ld1, ld2, ldab;
     size_t oAB, oX1, oY1, oX2, oY2, oT, total;
-    __host__ __device__ explicit BigWs(int n32_) : n32(n32_), ld1(2 * n32_), ld2(3 * n32_ + 16), ldab(n32_ + 16)
+    __host__ __device__ explicit BigWs(int n32_) : n32(n32_), ld1(2 * n32_), ld2(3 * n32_ + 32), ldab(n32_ + 32)
     {
         oAB = 0; oX1 = oAB + (size_t)ldab * n32; oY1 = oX1 + (size_t)ld1 * n32; oX2 = oY1 + (size_t)ld1 * n32;
-        oY2 = oX2 + (size_t)ld2 * n32; oT = oY2 + (size_t)ld2 * n32; total = oT + 1024;
+        oY2 = oX2 + (size_t)ld2 * n32; oT = oY2 + (size_t)ld2 * n32; total = oT + 2048 + n32;
     }
 };
 
@@ -581,7 +582,7 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
                        L.ystride, L.dx, L.m_out, L.nc_out, L.marg_idx, L.pc_base, ws, wss, n32);
     const int* act = L.m_out;                                            // 0 = nothing accepted: every later launch skips the filter
     CholArgs c1 = {};
-    c1.X = ws + w.oX1; c1.Y = ws + w.oY1; c1.xs = wss; c1.ld = w.ld1; c1.rows = 2 * n32; c1.ncols = n32;
+    c1.W = ws + w.oX1; c1.Y = ws + w.oY1; c1.xs = wss; c1.ld = w.ld1; c1.rows = 2 * n32; c1.ncols = n32;
     c1.status = L.status + L.b0; c1.fail_bit = 4; c1.active = act; c1.batch = L.nb; c1.Tb = ws + w.oT; c1.ts = wss;
     launch_chol_sweep(c1, st);
     GemmArgs g = {};
@@ -589,7 +590,7 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
     g.A = ws + w.oAB; g.sa = wss; g.lda = w.ldab; g.modeA = 0;
     g.B = ws + w.oY1; g.sb = wss; g.ldb = w.ld1; g.modeB = 1;
     g.C = ws + w.oX2 + n32; g.sc = wss; g.rs = 1; g.cs = w.ld2;
-    g.M = n32 + 16; g.N = n32; g.K = n32; g.m_lim = n32 + 16; g.n_lim = n32; g.ksplit = 1; g.active = act; g.batch = L.nb;
+    g.M = n32 + 32; g.N = n32; g.K = n32; g.m_lim = n32 + 32; g.n_lim = n32; g.ksplit = 1; g.active = act; g.batch = L.nb;
     launch_gemm(g, st);
     // W = L^T (A L) + s^2 I -> X2 rows 0 .. (lower blocks)
     g = GemmArgs{};
@@ -599,14 +600,14 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
     g.M = n32; g.N = n32; g.K = n32; g.m_lim = n32; g.n_lim = n32; g.ksplit = 1; g.lower = 1; g.diag_add_vec = L.noise;
     g.active = act; g.batch = L.nb;
     launch_gemm(g, st);
-    hipLaunchKernelGGL(k_copy_rows, dim3(16, L.nb), dim3(256), 0, st, ws + w.oY1, wss, w.ld1, n32, ws + w.oX2, wss, w.ld2, 2 * n32 + 16,
+    hipLaunchKernelGGL(k_copy_rows, dim3(16, L.nb), dim3(256), 0, st, ws + w.oY1, wss, w.ld1, n32, ws + w.oX2, wss, w.ld2, 2 * n32 + 32,
                        n32, n32, act);
     CholArgs c2 = c1;
-    c2.X = ws + w.oX2; c2.Y = ws + w.oY2; c2.ld = w.ld2; c2.rows = 3 * n32 + 16;
+    c2.W = ws + w.oX2; c2.Y = ws + w.oY2; c2.ld = w.ld2; c2.rows = 3 * n32 + 32;
     launch_chol_sweep(c2, st);
     // M = R2 R1^T (row-major, MP wide), t = R2 r1b^T
     g = GemmArgs{};
-    g.A = ws + w.oY2 + 2 * n32 + 16; g.sa = wss; g.lda = w.ld2; g.modeA = 0;
+    g.A = ws + w.oY2 + 2 * n32 + 32; g.sa = wss; g.lda = w.ld2; g.modeA = 0;
     g.B = ws + w.oY2 + n32; g.sb = wss; g.ldb = w.ld2; g.modeB = 0;
     g.C = L.T; g.sc = L.mstride; g.rs = MP; g.cs = 1;
     g.M = n32; g.N = n32; g.K = n32; g.m_lim = MP; g.n_lim = MP; g.ksplit = 1; g.active = act; g.batch = L.nb;

@@ -2,12 +2,11 @@
 //
 //   k_gemm        FP64 GEMM on v_mfma_f64_16x16x4: one workgroup per 32x32 block of C, its four waves split K and reduce through
 //                 LDS (no atomics: deterministic), optional grid-level split of K into partial buffers.
-//   k_chol_panel  one 32-column panel of a blocked LEFT-looking Cholesky with carried rows.  Every workgroup owns 16 rows of the
-//                 panel: it subtracts the contribution of the finished panels from its rows AND from the 32x32 diagonal block
-//                 (redundantly - the operands are the same fragments, 3 extra MFMA per step, no inter-workgroup dependency),
-//                 factorises the block with one wave (one lane per row, the identity carried below it so that T = L_d^-T falls
-//                 out), and multiplies its rows by T on the matrix cores.  Out of place (X is never written), so a panel is one
-//                 launch with no ordering between its workgroups.
+//   k_chol_step   one 32-column panel of a blocked RIGHT-looking Cholesky with carried rows: one launch per panel, one
+//                 workgroup per 32 x 32 block of the trailing matrix, every workgroup a single memory round trip deep; the
+//                 workgroup that updates the next diagonal block factorises it on the spot with one wave (one lane per row, the
+//                 identity carried below it so that T = L_d^-T falls out).  A left-looking version (one K-loop per panel)
+//                 measured 23 us per panel against 8 here: its loads come from the other XCDs' writes, ~1 us per dependent trip.
 //
 // What they replace: the single-workgroup 216-pivot Gauss-Jordan of the large-window Kalman solve (kernels_bigwin.hip; reference
 // maths StateManager.cpp:399-405) and, through Cholesky-QR, the single-workgroup Householder panel of kernels_qr.hip for tall
@@ -56,17 +55,21 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g)
     const int w_lo = c_lo + wave * per_wave, w_hi = min(c_hi, w_lo + per_wave);
     const int i0 = bi * 32 + l15, i1 = i0 + 16, j0 = bj * 32 + l15, j1 = j0 + 16;
     double4_f c00 = { 0, 0, 0, 0 }, c01 = c00, c10 = c00, c11 = c00;
-#pragma unroll 1
-    for (int ch = w_lo; ch < w_hi; ++ch) {
+    double a0[4], a1[4], b0[4], b1[4], na0[4], na1[4], nb0[4], nb1[4];
+    auto fetch = [&](int ch, double* x0, double* x1, double* y0, double* y1) {
         const int kb = ch * 16 + 4 * kq;
-        double a0[4], a1[4], b0[4], b1[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            a0[s] = ld_op<MA>(A, g.lda, i0, kb + s, g.M, g.K, g.Ax, g.ax);
-            a1[s] = ld_op<MA>(A, g.lda, i1, kb + s, g.M, g.K, g.Ax, g.ax);
-            b0[s] = ld_op<MB>(B, g.ldb, j0, kb + s, g.N, g.K, g.Bx, g.bx);
-            b1[s] = ld_op<MB>(B, g.ldb, j1, kb + s, g.N, g.K, g.Bx, g.bx);
+            x0[s] = ld_op<MA>(A, g.lda, i0, kb + s, g.M, g.K, g.Ax, g.ax);
+            x1[s] = ld_op<MA>(A, g.lda, i1, kb + s, g.M, g.K, g.Ax, g.ax);
+            y0[s] = ld_op<MB>(B, g.ldb, j0, kb + s, g.N, g.K, g.Bx, g.bx);
+            y1[s] = ld_op<MB>(B, g.ldb, j1, kb + s, g.N, g.K, g.Bx, g.bx);
         }
+    };
+    if (w_lo < w_hi) fetch(w_lo, a0, a1, b0, b1);
+#pragma unroll 1
+    for (int ch = w_lo; ch < w_hi; ++ch) {
+        if (ch + 1 < w_hi) fetch(ch + 1, na0, na1, nb0, nb1);              // the next chunk's operands travel under these MFMAs
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], b0[s], c00, 0, 0, 0);
@@ -74,6 +77,8 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g)
             c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], b0[s], c10, 0, 0, 0);
             c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], b1[s], c11, 0, 0, 0);
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { a0[s] = na0[s]; a1[s] = na1[s]; b0[s] = nb0[s]; b1[s] = nb1[s]; }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -99,6 +104,76 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Gram matrix of a tall matrix, lower 64 x 64 blocks: G = [H | r]^T [H | r], H m x n column-major (ld), r [m] (column n).
+// grid = (blocks bi >= bj, ksplit): partial p of the K split goes to part + p * pstride (column-major n_ld x n_ld).
+// Per 32-row chunk the workgroup stages its two 64-column panels in LDS (each thread 8 consecutive rows of one column: 256
+// contiguous bytes per column and wave), the next chunk's loads in flight under the 32 MFMA per wave of the current one.
+// ---------------------------------------------------------------------------------------------
+#define GR_S 36                                                         // LDS row stride (doubles) of a staged column
+__global__ __launch_bounds__(256) void k_gram_tn(const double* __restrict__ H, int ldh, const double* __restrict__ rv, int m, int n,
+                                                 double* __restrict__ part, size_t pstride, int n_ld, int ksplit)
+{
+    __shared__ __attribute__((aligned(16))) double sA[64][GR_S];
+    __shared__ __attribute__((aligned(16))) double sB[64][GR_S];
+    int t = blockIdx.x, bi = 0;
+    while (t >= bi + 1) { t -= bi + 1; ++bi; }
+    const int bj = t;
+    const bool diag = bi == bj;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int n1 = n + 1;
+    const int chunks = (m + 31) / 32, per = (chunks + ksplit - 1) / ksplit;
+    const int c_lo = blockIdx.y * per, c_hi = min(chunks, c_lo + per);
+    const int col = tid >> 2, kseg = (tid & 3) * 8;                      // staging role: column of the panel, 8 rows of the chunk
+    const int ca = 64 * bi + col, cb = 64 * bj + col;
+    const double* pa = ca < n ? H + (size_t)ca * ldh : (ca == n ? rv : nullptr);
+    const double* pb = cb < n ? H + (size_t)cb * ldh : (cb == n ? rv : nullptr);
+    double ra[8], rb[8];
+    auto fetch = [&](int ch) {
+        const int k0 = 32 * ch + kseg;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool on = k0 + u < m;
+            ra[u] = (pa && on) ? pa[k0 + u] : 0.0;
+            rb[u] = (!diag && pb && on) ? pb[k0 + u] : 0.0;
+        }
+    };
+    const int wi = wave >> 1, wj = wave & 1;                             // this wave's 32 x 32 quadrant
+    double4_f c00 = { 0, 0, 0, 0 }, c01 = c00, c10 = c00, c11 = c00;
+    if (c_lo < c_hi) fetch(c_lo);
+#pragma unroll 1
+    for (int ch = c_lo; ch < c_hi; ++ch) {
+        __syncthreads();                                                 // the previous chunk's fragments have been read
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            *reinterpret_cast<double2*>(&sA[col][kseg + u]) = make_double2(ra[u], ra[u + 1]);
+            if (!diag) *reinterpret_cast<double2*>(&sB[col][kseg + u]) = make_double2(rb[u], rb[u + 1]);
+        }
+        __syncthreads();
+        if (ch + 1 < c_hi) fetch(ch + 1);
+        const double (*sBB)[GR_S] = diag ? sA : sB;
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+            const double a0 = sA[32 * wi + l15][4 * k4 + kq], a1 = sA[32 * wi + 16 + l15][4 * k4 + kq];
+            const double b0 = sBB[32 * wj + l15][4 * k4 + kq], b1 = sBB[32 * wj + 16 + l15][4 * k4 + kq];
+            c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);
+        }
+    }
+    double* C = part + (size_t)blockIdx.y * pstride;
+    const int gi0 = 64 * bi + 32 * wi, gj0 = 64 * bj + 32 * wj;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = gi0 + kq + 4 * r, j = gj0 + l15;
+        if (i < n1 && j < n1) C[(size_t)i + (size_t)j * n_ld] = c00[r];
+        if (i < n1 && j + 16 < n1) C[(size_t)i + (size_t)(j + 16) * n_ld] = c01[r];
+        if (i + 16 < n1 && j < n1) C[(size_t)(i + 16) + (size_t)j * n_ld] = c10[r];
+        if (i + 16 < n1 && j + 16 < n1) C[(size_t)(i + 16) + (size_t)(j + 16) * n_ld] = c11[r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // 1 / sqrt(p) to full precision: v_rsq_f64 + two Newton steps
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double fast_rsqrt(double p)
@@ -119,66 +194,18 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Diagonal block of one panel (columns c0 .. c0+31).  grid = batch, 512 threads: the eight waves split K of
-// D = X_dd - Y_d Y_d^T (three tiles, both operands the same fragments), one wave factorises [D; I] with a lane per row.
-// The column of multipliers travels through LDS (one broadcast read serves two columns); only the NEXT pivot's column takes
-// the short way through v_readlane, so the chain pivot -> rsqrt -> scale -> next pivot never waits on LDS.
-// Writes L_d into Y's diagonal rows and T = L_d^-T (row-major 32 x 32) into Tb[batch].
+// Factorisation of one 32 x 32 diagonal block by ONE wave: lane l < 32 holds row l of the block, lanes 32..63 the rows of an
+// identity carried below it, so that they end up as T = L_d^-T.  sDI = [D; I] (64 x 33), floorv = this lane's pivot floor
+// (lane j: pivot j).  Elimination in LDL^T form, scaled to Cholesky at the end: the column that is broadcast is the UNSCALED
+// one, so it leaves for LDS before the pivot's reciprocal exists, and the chain pivot j -> pivot j+1 is rcp + mul + fma +
+// v_readlane.  Software pipeline: step j runs that chain and, behind it, the bulk update with column j-1 (its broadcast reads
+// are issued at the top of the step).  Returns through d[] the scaled rows; `bad`: a pivot of THIS lane's row was rejected.
 // ---------------------------------------------------------------------------------------------
-#define CD_NW 4
-__global__ __launch_bounds__(64 * CD_NW) void k_chol_diag(CholArgs a, int c0, double* __restrict__ Tb, size_t ts)
+__device__ __forceinline__ void factor32(double (*sDI)[33], double (*sC)[32], int lane, double floorv, double (&d)[32], bool& bad)
 {
-    __shared__ double sPart[CD_NW][3][4][64];
-    __shared__ double sD[64][33];                                       // [D; I]
-    __shared__ double sOrig[32];
-    __shared__ __attribute__((aligned(16))) double sC[2][32];
-    const int batch = blockIdx.x;
-    if (a.active && !a.active[batch]) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4, ld = a.ld;
-    const double* X = a.X + (size_t)batch * a.xs;
-    double* Y = a.Y + (size_t)batch * a.xs;
-    double4_f d00 = { 0, 0, 0, 0 }, d10 = d00, d11 = d00;
-    {
-        const int steps = c0 >> 2, per = (steps + CD_NW - 1) / CD_NW;
-        const int s_lo = wave * per, s_hi = min(steps, s_lo + per);
-        const double* pb = Y + c0 + l15 + (size_t)kq * ld;
-#pragma unroll 2
-        for (int s4 = s_lo; s4 < s_hi; ++s4) {
-            const double bv = pb[(size_t)(4 * s4) * ld], bw = pb[(size_t)(4 * s4) * ld + 16];
-            d00 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, bv, d00, 0, 0, 0);
-            d10 = __builtin_amdgcn_mfma_f64_16x16x4f64(bw, bv, d10, 0, 0, 0);
-            d11 = __builtin_amdgcn_mfma_f64_16x16x4f64(bw, bw, d11, 0, 0, 0);
-        }
-    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { sPart[wave][0][r][lane] = d00[r]; sPart[wave][1][r][lane] = d10[r]; sPart[wave][2][r][lane] = d11[r]; }
-    __syncthreads();
-    for (int e = tid; e < 1024; e += 64 * CD_NW) {
-        const int i = e & 31, j = e >> 5;
-        double v = 0.0;
-        if (j <= i) {
-            const int slot = (i >> 4) + (j >> 4);                         // (0,0) -> 0, (1,0) -> 1, (1,1) -> 2
-            const int rr = i & 15, cc = j & 15, sl = (rr & 3) * 16 + cc, sr = rr >> 2;
-            const double x = X[(size_t)(c0 + i) + (size_t)(c0 + j) * ld];
-            double sum = 0.0;
-#pragma unroll
-            for (int w = 0; w < CD_NW; ++w) sum += sPart[w][slot][sr][sl];
-            v = x - sum;
-            if (i == j) sOrig[i] = x;
-        }
-        sD[i][j] = v;
-        sD[32 + i][j] = i == j ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    double d[32];
-    const int row = lane & 31;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) d[j] = sD[lane][j];
-    int bad = 0;
-    const double crel = a.clamp ? a.clamp_rel : 0.0;
-    // Software pipeline: step j runs the chain (pivot j -> rsqrt -> scale column j -> column j+1 through v_readlane) and, behind
-    // it, the bulk update with column j-1, whose broadcast reads were issued at the top of the step.
+    for (int j = 0; j < 32; ++j) d[j] = sDI[lane][j];
+    double m_prev = 0.0, pv = 1.0;
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
         double lc[32];
@@ -186,99 +213,175 @@ __global__ __launch_bounds__(64 * CD_NW) void k_chol_diag(CholArgs a, int c0, do
 #pragma unroll
             for (int c = j + 1; c < 32; ++c) lc[c] = sC[(j - 1) & 1][c];
         }
+        if (lane < 32) sC[j & 1][lane] = d[j];
         asm volatile("" ::: "memory");
         const double p = readlane_f64(d[j], j);
-        const bool ok = p > crel * sOrig[j];
-        if (!ok && !a.clamp) bad = 1;
-        const double rs = ok ? fast_rsqrt(p) : 0.0;
-        d[j] *= rs;
+        const bool ok = p > readlane_f64(floorv, j);
+        const double rinv = ok ? fast_rcp(p) : 0.0;
+        const double m = d[j] * rinv;
+        if (lane == j) pv = d[j];
         if (j < 31) {
-            const double ln = readlane_f64(d[j], j + 1);
-            d[j + 1] = fma(-d[j], ln, d[j + 1]);
-            if (lane < 32) sC[j & 1][lane] = d[j];
+            const double x = readlane_f64(d[j], j + 1);
+            d[j + 1] = fma(-m, x, d[j + 1]);
         }
         asm volatile("" ::: "memory");
         if (j >= 1) {
 #pragma unroll
             for (int c = j + 1; c < 32; ++c) {
-                d[c] = fma(-d[j - 1], lc[c], d[c]);
+                d[c] = fma(-m_prev, lc[c], d[c]);
                 asm volatile("" : "+v"(d[c]));          // pin the update here: left alone, the scheduler sinks every column's
             }                                            // updates to its pivot step (a 30-deep chain, all broadcasts live)
         }
+        m_prev = m;
     }
-    double* T = Tb + (size_t)batch * ts;
+    // 1 / sqrt(pivot) per column (0 for a rejected pivot), broadcast, and the final column scaling
+    const bool okp = pv > floorv;
+    if (lane < 32) sC[0][lane] = okp ? fast_rsqrt(pv) : 0.0;
+    asm volatile("" ::: "memory");
+    bad = lane < 32 && !okp;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) d[j] *= sC[0][j];
+}
+
+// stores of a factorised diagonal block: L_d into Lout's block (upper part zero), T (row-major 32 x 32) into Tout
+__device__ __forceinline__ void store_factor(const double (&d)[32], int lane, double* __restrict__ Ld, int ld, double* __restrict__ Tout)
+{
+    const int row = lane & 31;
     if (lane < 32) {
 #pragma unroll
-        for (int j = 0; j < 32; ++j) Y[(size_t)(c0 + row) + (size_t)(c0 + j) * ld] = j <= row ? d[j] : 0.0;
+        for (int j = 0; j < 32; ++j) Ld[(size_t)row + (size_t)j * ld] = j <= row ? d[j] : 0.0;
     } else {
 #pragma unroll
-        for (int j = 0; j < 32; ++j) T[row * 32 + j] = d[j];
+        for (int j = 0; j < 32; ++j) Tout[row * 32 + j] = d[j];
     }
-    if (bad && lane == 0 && a.status) atomicOr(&a.status[batch], a.fail_bit);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Rows below the diagonal block of one panel: Y[r, panel] = (X[r, panel] - Y[r, :c0] Y[panel, :c0]^T) T.
-// grid = ((rows - c0 - 32) / 16, batch), 256 threads: the four waves split K, reduce through LDS, two waves apply T.
+// First diagonal block + the original diagonal (the reference of the pivot floor).  grid = batch, 256 threads.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chol_panel(CholArgs a, int c0, const double* __restrict__ Tb, size_t ts)
+__global__ __launch_bounds__(256) void k_chol_first(CholArgs a)
 {
-    __shared__ double sPart[4][2][4][64];
-    __shared__ double sU[16][33];
+    __shared__ double sDI[64][33];
+    __shared__ __attribute__((aligned(16))) double sC[2][32];
+    const int batch = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    if (a.active && !a.active[batch]) return;
+    double* W = a.W + (size_t)batch * a.xs;
+    double* Y = a.Y + (size_t)batch * a.xs;
+    double* od = a.Tb + (size_t)batch * a.ts + 2048;
+    for (int c = tid; c < a.ncols; c += 256) od[c] = W[(size_t)c + (size_t)c * a.ld];
+    for (int e = tid; e < 1024; e += 256) {
+        const int i = e & 31, j = e >> 5;
+        sDI[i][j] = W[(size_t)i + (size_t)j * a.ld];
+        sDI[32 + i][j] = i == j ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    const double floorv = a.clamp ? a.clamp_rel * sDI[lane & 31][lane & 31] : 0.0;
+    double d[32]; bool bad;
+    factor32(sDI, sC, lane, floorv, d, bad);
+    store_factor(d, lane, Y, a.ld, a.Tb + (size_t)batch * a.ts);
+    if (__any(bad && !a.clamp) && lane == 0 && a.status) atomicOr(&a.status[batch], a.fail_bit);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One step of the RIGHT-looking sweep: panel k (32 columns) is scaled with T_k and the whole trailing part is updated, every
+// workgroup one 32 x 32 block and one memory round trip deep:
+//     Y_i = W[i, k] T_k,  Y_j = W[j, k] T_k   (both recomputed by every workgroup that needs them: 2 x 32 MFMA, no ordering)
+//     W[i, j] -= Y_i Y_j^T                     (i >= j > k; block rows beyond the columns are the carried rows)
+// The workgroups of column j = k+1 also store Y_i into the output; the workgroup of the next diagonal block (k+1, k+1)
+// factorises it on the spot (one wave, factor32) and leaves T_k+1 for the next launch.  The last panel has no trailing blocks:
+// its launch only scales the rows below.  grid = (blocks, batch), 256 threads.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_chol_step(CholArgs a, int k)
+{
     __shared__ double sT[32][33];
+    __shared__ double sUi[32][33];
+    __shared__ double sUj[32][33];
+    __shared__ double sDI[64][33];                                       // Y_i (rows 0..31), Y_j (rows 32..63); later [D; I]
+    __shared__ __attribute__((aligned(16))) double sC[2][32];
     const int batch = blockIdx.y;
     if (a.active && !a.active[batch]) return;
+    const int nbr = a.rows >> 5, ncb = a.ncols >> 5, ld = a.ld;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
-    const int r0 = c0 + 32 + 16 * blockIdx.x, ld = a.ld;
-    const double* X = a.X + (size_t)batch * a.xs;
+    // block of this workgroup: column blocks j = k+1 .. ncb-1, rows i = j .. nbr-1; or (last panel) rows only
+    int i, j;
+    const bool tail_only = k + 1 >= ncb;
+    if (tail_only) { i = k + 1 + blockIdx.x; j = -1; }
+    else {
+        int t = blockIdx.x; j = k + 1;
+        while (t >= nbr - j) { t -= nbr - j; ++j; }
+        i = j + t;
+    }
+    double* W = a.W + (size_t)batch * a.xs;
     double* Y = a.Y + (size_t)batch * a.xs;
-    double4_f u0 = { 0, 0, 0, 0 }, u1 = u0;
-    {
-        const int kw = c0 >> 2, k_lo = wave * kw, k_hi = k_lo + kw;       // c0 is a multiple of 32: quarters are multiples of 8
-        const double* pa = Y + r0 + l15 + (size_t)kq * ld;
-        const double* pb = Y + c0 + l15 + (size_t)kq * ld;
-#pragma unroll 1
-        for (int k = k_lo; k < k_hi; k += 8) {
-            const double av0 = pa[(size_t)k * ld], bv0 = pb[(size_t)k * ld], bw0 = pb[(size_t)k * ld + 16];
-            const double av1 = pa[(size_t)(k + 4) * ld], bv1 = pb[(size_t)(k + 4) * ld], bw1 = pb[(size_t)(k + 4) * ld + 16];
-            u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, bv0, u0, 0, 0, 0);
-            u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, bw0, u1, 0, 0, 0);
-            u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, bv1, u0, 0, 0, 0);
-            u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, bw1, u1, 0, 0, 0);
-        }
+    double* Tb = a.Tb + (size_t)batch * a.ts;
+    const double* Tk = Tb + (size_t)(k & 1) * 1024;
+    const double* Wi = W + (size_t)32 * i + (size_t)(32 * k) * ld;
+    const double* Wj = W + (size_t)32 * (j < 0 ? i : j) + (size_t)(32 * k) * ld;
+    const bool diag = i == j;
+    // one round trip: T_k, the two panel blocks, the trailing block (tile layout: wave w = tile (w >> 1, w & 1))
+    for (int e = tid; e < 1024; e += 256) {
+        const int r = e & 31, c = e >> 5;
+        sT[c][r] = Tk[e];                                                // Tk row-major: e = row * 32 + col -> sT[row][col]
+        sUi[r][c] = Wi[(size_t)r + (size_t)c * ld];
+        if (!diag && !tail_only) sUj[r][c] = Wj[(size_t)r + (size_t)c * ld];
     }
+    const int ti = wave >> 1, tj = wave & 1;
+    double4_f cacc = { 0, 0, 0, 0 };
+    double* Cij = tail_only ? nullptr : W + (size_t)(32 * i + 16 * ti) + (size_t)(32 * j + 16 * tj) * ld;
+    if (!tail_only) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { sPart[wave][0][r][lane] = u0[r]; sPart[wave][1][r][lane] = u1[r]; }
-    {
-        const double* T = Tb + (size_t)batch * ts;
-        for (int e = tid; e < 1024; e += 256) sT[e >> 5][e & 31] = T[e];
+        for (int r = 0; r < 4; ++r) cacc[r] = Cij[(size_t)(kq + 4 * r) + (size_t)l15 * ld];
     }
     __syncthreads();
-    for (int e = tid; e < 512; e += 256) {
-        const int i = e & 15, j = e >> 4;
-        const int slot = j >> 4, cc = j & 15, sl = (i & 3) * 16 + cc, sr = i >> 2;
-        const double x = X[(size_t)(r0 + i) + (size_t)(c0 + j) * ld];
-        sU[i][j] = x - (sPart[0][slot][sr][sl] + sPart[1][slot][sr][sl] + sPart[2][slot][sr][sl] + sPart[3][slot][sr][sl]);
-    }
-    __syncthreads();
-    if (wave < 2) {
-        double4_f acc = { 0, 0, 0, 0 };
+    // Y_i (and Y_j) on the matrix cores: tile (ti, tj) of U T
+    {
+        double4_f yi = { 0, 0, 0, 0 }, yj = { 0, 0, 0, 0 };
 #pragma unroll
-        for (int k4 = 0; k4 < 8; ++k4)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sU[l15][4 * k4 + kq], sT[4 * k4 + kq][16 * wave + l15], acc, 0, 0, 0);
-        double* so = &sPart[wave][0][0][0];                                 // through LDS so that the store runs along the rows
+        for (int k4 = 0; k4 < 8; ++k4) {
+            const double tb = sT[4 * k4 + kq][16 * tj + l15];
+            yi = __builtin_amdgcn_mfma_f64_16x16x4f64(sUi[16 * ti + l15][4 * k4 + kq], tb, yi, 0, 0, 0);
+            if (!diag && !tail_only) yj = __builtin_amdgcn_mfma_f64_16x16x4f64(sUj[16 * ti + l15][4 * k4 + kq], tb, yj, 0, 0, 0);
+        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) so[(kq + 4 * r) * 17 + l15] = acc[r];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int col = kq + 4 * q;
-            Y[(size_t)(r0 + l15) + (size_t)(c0 + 16 * wave + col) * ld] = so[l15 * 17 + col];
+        for (int r = 0; r < 4; ++r) {
+            sDI[16 * ti + kq + 4 * r][16 * tj + l15] = yi[r];
+            sDI[32 + 16 * ti + kq + 4 * r][16 * tj + l15] = diag ? yi[r] : yj[r];
         }
     }
+    __syncthreads();
+    if (tail_only || j == k + 1) {                                       // this workgroup owns the output of block row i
+        double* Yo = Y + (size_t)32 * i + (size_t)(32 * k) * ld;
+        for (int e = tid; e < 1024; e += 256) { const int r = e & 31, c = e >> 5; Yo[(size_t)r + (size_t)c * ld] = sDI[r][c]; }
+    }
+    if (tail_only) return;
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4)
+        cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(-sDI[16 * ti + l15][4 * k4 + kq], sDI[32 + 16 * tj + l15][4 * k4 + kq], cacc, 0, 0, 0);
+    const bool next_diag = diag && j == k + 1;
+    if (!next_diag) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cij[(size_t)(kq + 4 * r) + (size_t)l15 * ld] = cacc[r];
+        return;
+    }
+    // the next diagonal block: factorise it now (its updated value is final), T_k+1 for the next launch
+    __syncthreads();                                                     // every wave is done reading Y_i / Y_j from sDI
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sDI[16 * ti + kq + 4 * r][16 * tj + l15] = cacc[r];
+    for (int e = tid; e < 1024; e += 256) { const int r = e & 31, c = e >> 5; sDI[32 + r][c] = r == c ? 1.0 : 0.0; }
+    __syncthreads();
+    if (wave != 0) return;
+    const double* od = Tb + 2048;
+    const double floorv = a.clamp ? a.clamp_rel * od[32 * j + (lane & 31)] : 0.0;
+    double d[32]; bool bad;
+    factor32(sDI, sC, lane, floorv, d, bad);
+    store_factor(d, lane, Y + (size_t)32 * j + (size_t)(32 * j) * ld, ld, Tb + (size_t)((k + 1) & 1) * 1024);
+    if (__any(bad && !a.clamp) && lane == 0 && a.status) atomicOr(&a.status[batch], a.fail_bit);
 }
 
 }  // namespace
+
+int dbg_read_chol(long long* out, int n) { return dbg_read_local(out, n); }
 
 void launch_gemm(const GemmArgs& g, hipStream_t st)
 {
@@ -293,11 +396,30 @@ void launch_gemm(const GemmArgs& g, hipStream_t st)
     else hipLaunchKernelGGL((k_gemm<1, 1>), grid, dim3(256), 0, st, h);
 }
 
+int gram_ksplit(int m, int n)
+{
+    const int nb = (n + 1 + 63) / 64, blocks = nb * (nb + 1) / 2;
+    int ks = (1024 + blocks - 1) / blocks;
+    const int kmax = (m + 127) / 128;                                       // at least 4 chunks of 32 rows per workgroup
+    if (ks > kmax) ks = kmax;
+    if (ks > 64) ks = 64;
+    return ks < 1 ? 1 : ks;
+}
+
+void launch_gram(const double* H, int ldh, const double* rv, int m, int n, double* part, size_t pstride, int n_ld, int ksplit, hipStream_t st)
+{
+    const int nb = (n + 1 + 63) / 64;
+    hipLaunchKernelGGL(k_gram_tn, dim3(nb * (nb + 1) / 2, ksplit), dim3(256), 0, st, H, ldh, rv, m, n, part, pstride, n_ld, ksplit);
+}
+
 void launch_chol_sweep(const CholArgs& a, hipStream_t st)
 {
-    for (int c0 = 0; c0 < a.ncols; c0 += 32) {
-        hipLaunchKernelGGL(k_chol_diag, dim3(a.batch), dim3(64 * CD_NW), 0, st, a, c0, a.Tb, a.ts);
-        if (a.rows > c0 + 32)
-            hipLaunchKernelGGL(k_chol_panel, dim3((a.rows - c0 - 32) / 16, a.batch), dim3(256), 0, st, a, c0, a.Tb, a.ts);
+    const int nbr = a.rows / 32, ncb = a.ncols / 32;
+    hipLaunchKernelGGL(k_chol_first, dim3(a.batch), dim3(256), 0, st, a);
+    for (int k = 0; k < ncb; ++k) {
+        int blocks = 0;
+        if (k + 1 >= ncb) blocks = nbr - (k + 1);
+        else for (int j = k + 1; j < ncb; ++j) blocks += nbr - j;
+        if (blocks > 0) hipLaunchKernelGGL(k_chol_step, dim3(blocks, a.batch), dim3(256), 0, st, a, k);
     }
 }

@@ -17,6 +17,7 @@
 // gfx950 only.
 #include "dev_common.h"
 #include "launch_qr.h"
+#include "launch_chol.h"
 
 #define QR_NB 8
 #define QR_NT 512                // 8 waves = 2 per SIMD: 256 VGPRs per lane, the 12 x 8 panel slice of a thread stays in registers
@@ -252,7 +253,61 @@ __global__ __launch_bounds__(256) void k_qr_extract(const double* __restrict__ D
     if (e < n) rt[e] = e < m ? D[didx(e, n, mp8)] : 0.0;
 }
 
+// ---- Cholesky-QR for tall stacks (launch_qr_chol) ----------------------------------------------------------------------
+// lower triangle of G = sum of the split-K partials of [H | r]^T [H | r]; identity on the padding diagonal
+__global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ part, size_t pstride, int ks, int n1, int n32, double* __restrict__ X)
+{
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < (size_t)n32 * n32; e += (size_t)gridDim.x * 256) {
+        const int i = (int)(e % n32), j = (int)(e / n32);
+        double v = 0.0;
+        if (i >= j) {
+            if (i < n1) { for (int s = 0; s < ks; ++s) v += part[(size_t)s * pstride + e]; }
+            else v = i == j ? 1.0 : 0.0;
+        }
+        X[e] = v;
+    }
+}
+
+// R = L^T (n x n upper triangular, column-major ldt), Q^T r = row n of L
+__global__ __launch_bounds__(256) void k_chol_extract(const double* __restrict__ Y, int n32, int n, double* __restrict__ Ht, int ldt, double* __restrict__ rt)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n * n) {
+        const int j = e % n, i = e / n;                                     // consecutive threads read along a column of L
+        Ht[i + (size_t)j * ldt] = j >= i ? Y[(size_t)j + (size_t)i * n32] : 0.0;
+    }
+    if (e < n) rt[e] = Y[(size_t)n + (size_t)e * n32];
+}
+
 }  // namespace
+
+static int qrc_n32(int n) { return (n + 1 + 31) / 32 * 32; }
+static int qrc_ksplit(int m, int n) { return gram_ksplit(m, n); }
+size_t qr_chol_workspace_doubles(int m, int n)
+{
+    const size_t n32 = qrc_n32(n);
+    return ((size_t)qrc_ksplit(m, n) + 2) * n32 * n32 + 2048 + n32;
+}
+
+// Cholesky-QR: R^T R = H^T H and R^T z = H^T r are all the Kalman update reads from the thin QR (StateManager.cpp:359-411 is
+// invariant under any orthogonal transformation of the stacked rows), so R is taken as the Cholesky factor of the Gram matrix
+// of [H | r] - one FP64 MFMA GEMM over the m rows and a blocked Cholesky of n+1 columns (kernels_chol.hip) instead of n
+// dependent Householder reflectors.  Diagonal of R positive; a rank-deficient H (quirk Q9) gives zero rows where a pivot falls
+// below 1e-13 of its column's squared norm.  Entry-wise accuracy of R is cond(H)^2 eps (Householder: cond(H) eps); R^T R is
+// exact to eps |H|^2 either way.
+int launch_qr_chol(const double* dH, int ldh, const double* dres, int m, int n, double* ws, double* dHt, int ldt, double* drt, hipStream_t st)
+{
+    const int n1 = n + 1, n32 = qrc_n32(n), ks = qrc_ksplit(m, n);
+    const size_t nn = (size_t)n32 * n32;
+    double *part = ws, *X = ws + (size_t)ks * nn, *Y = X + nn, *Tb = Y + nn;
+    launch_gram(dH, ldh, dres, m, n, part, nn, n32, ks, st);
+    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((nn + 1023) / 1024)), dim3(256), 0, st, part, nn, ks, n1, n32, X);
+    CholArgs c = {};
+    c.W = X; c.Y = Y; c.xs = 0; c.ld = n32; c.Tb = Tb; c.ts = 0; c.rows = n32; c.ncols = n32; c.clamp = 1; c.clamp_rel = 1e-13; c.batch = 1;
+    launch_chol_sweep(c, st);
+    hipLaunchKernelGGL(k_chol_extract, dim3((n * n + 255) / 256), dim3(256), 0, st, Y, n32, n, dHt, ldt, drt);
+    return 0;
+}
 
 static size_t qr_mp8(int m) { return (size_t)8 * (((size_t)m + 7) & ~(size_t)7); }
 

@@ -27,14 +27,20 @@ struct GemmArgs {
 };
 void launch_gemm(const GemmArgs& g, hipStream_t st);
 
-// Blocked left-looking Cholesky of the leading ncols x ncols block of X (column-major, ld rows, ncols a multiple of 32, lower
-// triangle read), out of place into Y:  Y[0:ncols] = L (upper part zero),  rows ncols..rows (a multiple of 16) are CARRIED:
-// Y[r] = X[r] L^-T.  Two launches per 32-column panel: the diagonal block (one workgroup per batch element), then one workgroup per 16 rows below it.
+// Lower triangle of [H | r]^T [H | r] (H m x n column-major, r the extra column n) as `ksplit` partial sums of the K split, each
+// column-major with n_ld rows at part + p * pstride; entries above the diagonal of a 64-block row may be written too.
+int gram_ksplit(int m, int n);
+void launch_gram(const double* H, int ldh, const double* rv, int m, int n, double* part, size_t pstride, int n_ld, int ksplit, hipStream_t st);
+
+// Blocked right-looking Cholesky of the leading ncols x ncols block of W (column-major, ld rows, ncols and rows multiples of 32,
+// lower triangle read).  W is a WORKING copy (its trailing part is updated in place); the result goes to Y:
+// Y[0:ncols] = L (upper part zero), rows ncols..rows are CARRIED: Y[r] = W[r] L^-T.  One launch per 32-column panel.
 //   clamp != 0: a pivot <= clamp_rel * (original diagonal) zeroes its column (semi-definite input: rank-deficient gram);
 //   clamp == 0: a non-positive pivot also zeroes the column and sets bit `fail_bit` in status[batch] (status may be null).
+//   Tb: scratch, 2048 + ncols doubles per batch element (stride ts): two T buffers and the original diagonal.
 struct CholArgs {
-    const double* X; double* Y; size_t xs; int ld;
-    double* Tb; size_t ts;      // scratch for the current panel's L_d^-T: 1024 doubles per batch element, stride ts
+    double* W; double* Y; size_t xs; int ld;
+    double* Tb; size_t ts;
     int rows, ncols;
     int clamp; double clamp_rel;
     int* status; int fail_bit;
@@ -42,3 +48,4 @@ struct CholArgs {
     int batch;
 };
 void launch_chol_sweep(const CholArgs& a, hipStream_t st);
+int dbg_read_chol(long long* out, int n);

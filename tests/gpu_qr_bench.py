@@ -3,6 +3,7 @@ python tests/gpu_qr_bench.py  (under rocprofv3 --kernel-trace --stats for the de
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
+sys.path.insert(0, "/root/repo")
 from ingvio_amd import capi
 
 m, n = 6000, 800
