@@ -729,6 +729,161 @@ __global__ __launch_bounds__(256, 1) void k_info_apply_big(
 }
 
 // ---------------------------------------------------------------------------------------------
+// K10 (+ fused K12) in two flat launches (round 2): T = Pc M (k_apply_T, one workgroup per 32 x 32 block of T), then
+// P <- P - T Pc^T over the lower 32 x 32 blocks (k_apply_sym), both with the four waves of a workgroup splitting K = 6C and
+// reducing through LDS.  k_info_apply_big above walks a whole tile row per wave - one filter keeps 13 workgroups busy for
+// 0.48 ms; here the same filter spreads over ~350 workgroups.
+// ---------------------------------------------------------------------------------------------
+struct ApplyPtrs { const double* P; double* dst; const double* Pc; const double* M; int n, ld, midx; bool upd, fused; };
+
+__device__ __forceinline__ bool apply_setup(const CovView& cv, int b0, int bl, const double* Mall, int mstride, const double* Pcall, int ystride,
+                                            const int* m_all, const int* marg_idx, const int* pc_base, ApplyPtrs& q)
+{
+    const int b = b0 + bl;
+    q.upd = m_all[bl] != 0;
+    q.midx = marg_idx ? marg_idx[bl] : -1;
+    q.fused = q.midx >= 0;
+    if (!q.upd && !q.fused) return false;
+    q.n = cv.n[b]; q.ld = cv.ldp;
+    q.P = cov_ptr(cv, b);
+    q.dst = q.fused ? cov_alt_ptr(cv, b) : cov_ptr(cv, b);
+    const int pcb = q.upd ? pc_base[bl] : -1;
+    q.Pc = pcb >= 0 ? q.P + (size_t)pcb * q.ld : Pcall + (size_t)bl * ystride;
+    q.M = Mall + (size_t)bl * mstride;
+    return true;
+}
+
+// four waves split K = MP (padded to 16-chunks), partial tiles summed through LDS: returns this thread's four sums of the
+// 32 x 32 block in (r = tid & 31, c = (tid >> 5) + 8 q) order.  opA(i, k) = A[i + k lda] (i < ilim), opB(k, j) = B[j sb_j + k sb_k].
+template <class FB>
+__device__ __forceinline__ void block_gemm_k216(const double* __restrict__ A, int lda, int i0, int ilim, FB opB, double (&out)[4],
+                                                double (*sPart)[4][4][64])
+{
+    constexpr int MP = BIG_NC;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    double4_f c00 = { 0, 0, 0, 0 }, c01 = c00, c10 = c00, c11 = c00;
+    const int ia = min(i0 + l15, ilim - 1), ib = min(i0 + 16 + l15, ilim - 1);
+    constexpr int CH = (MP + 15) / 16;                                   // 14 chunks of 16
+    const int w_lo = wave * 4 < CH ? wave * 4 : CH, w_hi = min(CH, w_lo + 4);
+    double a0[4][4], a1[4][4], b0[4][4], b1[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int k = (w_lo + u) * 16 + 4 * kq + s4;
+            const bool on = w_lo + u < w_hi && k < MP;
+            const int kk = on ? k : 0;
+            a0[u][s4] = on ? A[(size_t)ia + (size_t)kk * lda] : 0.0;
+            a1[u][s4] = on ? A[(size_t)ib + (size_t)kk * lda] : 0.0;
+            b0[u][s4] = on ? opB(kk, l15) : 0.0;
+            b1[u][s4] = on ? opB(kk, 16 + l15) : 0.0;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u][s4], b0[u][s4], c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u][s4], b1[u][s4], c01, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u][s4], b0[u][s4], c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u][s4], b1[u][s4], c11, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sPart[wave][0][r][lane] = c00[r]; sPart[wave][1][r][lane] = c01[r];
+        sPart[wave][2][r][lane] = c10[r]; sPart[wave][3][r][lane] = c11[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = tid & 31, c = (tid >> 5) + 8 * q;
+        const int tile = (r >> 4) * 2 + (c >> 4), rr = r & 15, cc = c & 15, sl = (rr & 3) * 16 + cc, sr = rr >> 2;
+        out[q] = sPart[0][tile][sr][sl] + sPart[1][tile][sr][sl] + sPart[2][tile][sr][sl] + sPart[3][tile][sr][sl];
+    }
+}
+
+// T[rows, cols] = Pc[rows, :] M[:, cols] (T column-major, ldt), and dx = Pc t by the workgroups of column block 0
+__global__ __launch_bounds__(256) void k_apply_T(CovView cv, int b0, const double* __restrict__ Mall, int mstride, const double* __restrict__ Pcall,
+                                                 int ystride, const int* __restrict__ m_all, const int* __restrict__ marg_idx,
+                                                 const int* __restrict__ pc_base, double* __restrict__ Tall, size_t tstride, int ldt,
+                                                 double* __restrict__ dx_all)
+{
+    constexpr int MP = BIG_NC;
+    __shared__ double sPart[4][4][4][64];
+    const int bl = blockIdx.z, bi = blockIdx.x, bj = blockIdx.y;
+    ApplyPtrs q;
+    if (!apply_setup(cv, b0, bl, Mall, mstride, Pcall, ystride, m_all, marg_idx, pc_base, q) || !q.upd) return;
+    if (32 * bi >= q.n) return;
+    const double* M = q.M;
+    double out[4];
+    block_gemm_k216(q.Pc, q.ld, 32 * bi, q.n, [&](int k, int jj) { const int j = 32 * bj + jj; return j < MP ? M[(size_t)k * MP + j] : 0.0; }, out, sPart);
+    double* T = Tall + (size_t)bl * tstride;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = 32 * bi + (tid & 31), c = 32 * bj + (tid >> 5) + 8 * u;
+        if (r < q.n && c < MP) T[(size_t)r + (size_t)c * ldt] = out[u];
+    }
+    if (bj == 0 && tid < 32) {
+        const int r = 32 * bi + tid;
+        if (r < q.n) {
+            const double* tv = M + (size_t)MP * MP;
+            double d0 = 0.0, d1 = 0.0;
+            for (int k = 0; k < MP; k += 2) { d0 += q.Pc[(size_t)r + (size_t)k * q.ld] * tv[k]; d1 += q.Pc[(size_t)r + (size_t)(k + 1) * q.ld] * tv[k + 1]; }
+            dx_all[(size_t)(b0 + bl) * q.ld + r] = d0 + d1;
+        }
+    }
+}
+
+// lower 32 x 32 block (bi >= bj) of P - T Pc^T, written (with the fused marginalisation's index shift) to both triangles
+__global__ __launch_bounds__(256) void k_apply_sym(CovView cv, int b0, const double* __restrict__ Mall, int mstride, const double* __restrict__ Pcall,
+                                                   int ystride, const int* __restrict__ m_all, const int* __restrict__ marg_idx, int msize,
+                                                   const int* __restrict__ pc_base, const double* __restrict__ Tall, size_t tstride, int ldt,
+                                                   int* __restrict__ status)
+{
+    __shared__ double sPart[4][4][4][64];
+    __shared__ double sV[32][33];
+    const int bl = blockIdx.y;
+    int t = blockIdx.x, bi = 0;
+    while (t >= bi + 1) { t -= bi + 1; ++bi; }
+    const int bj = t;
+    ApplyPtrs q;
+    if (!apply_setup(cv, b0, bl, Mall, mstride, Pcall, ystride, m_all, marg_idx, pc_base, q)) return;
+    if (32 * bi >= q.n) return;
+    const int n = q.n, ld = q.ld, midx = q.midx, tid = threadIdx.x;
+    const bool fused = q.fused;
+    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+    if (q.upd) {
+        const double* Pc = q.Pc;
+        const int j0 = 32 * bj;
+        block_gemm_k216(Tall + (size_t)bl * tstride, ldt, 32 * bi, n,
+                        [&](int k, int jj) { return Pc[(size_t)min(j0 + jj, n - 1) + (size_t)k * ld]; }, acc, sPart);
+    }
+    auto alive = [&](int i) { return !(fused && i >= midx && i < midx + msize); };
+    auto remap = [&](int i) { return (fused && i >= midx) ? i - msize : i; };
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int rr = tid & 31, cc = (tid >> 5) + 8 * u;
+        const int row = 32 * bi + rr, col = 32 * bj + cc;
+        double v = 0.0;
+        if (row < n && col < n && (bi > bj || row >= col)) {
+            v = q.P[(size_t)row + (size_t)col * ld] - acc[u];
+            if (alive(row) && alive(col)) q.dst[(size_t)remap(row) + (size_t)remap(col) * ld] = v;
+            if (q.upd && row == col && v < 0.0) atomicOr(&status[b0 + bl], 2);
+        }
+        sV[rr][cc] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                                        // mirror: consecutive threads along the block's columns
+        const int cc = tid & 31, rr = (tid >> 5) + 8 * u;
+        const int row = 32 * bi + rr, col = 32 * bj + cc;
+        if (row < n && col < n && row > col && alive(row) && alive(col)) q.dst[(size_t)remap(col) + (size_t)remap(row) * ld] = sV[rr][cc];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 int dbg_read_bigwin(long long* out, int n) { return dbg_read_local(out, n); }
 size_t bigwin_sg_doubles(int G) { return (size_t)G * BIG_CMAX * BIG_CMAX * GB_SW; }
 size_t bigwin_wk_doubles() { const size_t gj = (size_t)BIG_NC * (2 * BIG_NC + 1), ch = BigWs(big_n32(BIG_NC)).total; return gj > ch ? gj : ch; }
@@ -763,6 +918,21 @@ int launch_bigwin(const FactoredLaunch& L, hipStream_t st)
                            L.rstride, L.noise, L.T, L.mstride, L.Pc, L.ystride, L.dx, L.m_out, L.nc_out, L.status, L.marg_idx,
                            L.pc_base, L.big_wk);
         return 0;
+    }
+    static const bool old_apply = [] { const char* e = getenv("INGVIO_BIG_APPLY"); return e && e[0] == 'o'; }();
+    if (!old_apply) {
+        // T lives in the solve workspace's X2/Y2 region (free once M has been extracted)
+        const BigWs w(big_n32(L.ncol_cap));
+        const int ldt = (L.n_cap + 31) / 32 * 32, nbr = ldt / 32;
+        if ((size_t)ldt * BIG_NC <= 2 * (size_t)w.ld2 * w.n32) {
+            double* T = L.big_wk + w.oX2;
+            const size_t wss = bigwin_wk_doubles();
+            hipLaunchKernelGGL(k_apply_T, dim3(nbr, (BIG_NC + 31) / 32, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
+                               L.m_out, L.marg_idx, L.pc_base, T, wss, ldt, L.dx);
+            hipLaunchKernelGGL(k_apply_sym, dim3(nbr * (nbr + 1) / 2, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
+                               L.m_out, L.marg_idx, L.marg_size, L.pc_base, T, wss, ldt, L.status);
+            return 0;
+        }
     }
     const int nt = (L.n_cap + 15) / 16, wgpf = (nt + 3) / 4, nb8 = (L.nb + 7) / 8 * 8;
     static bool attr_done = false;
