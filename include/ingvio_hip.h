@@ -183,6 +183,38 @@ int ingvio_gnss_front_stage(ingvio_ctx* ctx, int b0, int nb, const ingvio_gnss_e
  * (3), azimuth, elevation, ionosphere delay, troposphere delay, usable (1/0) */
 int ingvio_gnss_front_fetch(ingvio_ctx* ctx, int b0, int nb, double* out);
 
+/* ---- batched SLAM-landmark update (LandmarkUpdate::updateLandmark{Mono,Stereo}, LandmarkUpdate.cpp:32-149) ----------------
+ * For every in-state landmark observed in the current frame: rows against [extended pose | extrinsics | anchor clone | landmark]
+ * (calcResJacobianSingleLandmark*, :521-572 / :619-686, as written), the per-landmark chi^2 gate on the prior (:98-99), the
+ * accepted rows stacked, one ekfUpdate (:146) - rows, gates, stacking and the update on the device for a range of filters, with
+ * S = H P H^T + s^2 I factorised outside LDS (up to INGVIO_LM_MAX landmarks = 256 stereo rows per filter).
+ * The nominal values are the host's: it hands over the CURRENT pose / extrinsics / landmark positions and applies dx itself. */
+#define INGVIO_LM_MAX 64
+typedef struct {
+    double R_i2w[9], p_i2w[3];    /* extended pose (row-major rotation, position)                          */
+    double R_cl2i[9], p_c2i[3];   /* left camera -> IMU extrinsics                                          */
+    int idx_epose, idx_ext;       /* state indices (9 and 6 columns)                                        */
+    int n_lm;                     /* <= INGVIO_LM_MAX                                                       */
+    const int* lm_idx;            /* [n_lm] state index of each landmark (3 columns)                        */
+    const int* anchor_idx;        /* [n_lm] state index of its anchor clone (6 columns)                     */
+    const double* pf;             /* [n_lm][3] world position (AnchoredLandmark::valuePosXyz)               */
+    const double* uv;             /* [n_lm][4] current observation u0 v0 u1 v1 (mono: first two)            */
+    const unsigned char* tracked; /* [n_lm] 1 = observed in this frame (0: the landmark is skipped)         */
+} ingvio_landmark_frame;
+typedef struct {
+    int stereo;
+    double noise;                 /* visual noise (sigma)                                                   */
+    double chi2_thr;              /* quantile(chi_squared(rows per landmark), 0.95) (Update.cpp:98-100)     */
+    double R_cl2cr[9], t_cl2cr[3];
+    int in_frame;                 /* 1: ingvio_frame_run performs the update between the MSCKF update and the marginalisation
+                                     (IngvioFilter.cpp:296-322 order) for every staged filter               */
+} ingvio_landmark_opts;
+int ingvio_landmark_stage(ingvio_ctx* ctx, int b0, int nb, const ingvio_landmark_frame* frames, const ingvio_landmark_opts* opts);
+int ingvio_landmark_run(ingvio_ctx* ctx, int b0, int nb);
+/* dx [nb][ldp] (may be NULL), rows [nb] accepted rows, accept [nb][INGVIO_LM_MAX] 1/0, gamma [nb][INGVIO_LM_MAX] (-1: not
+ * tracked), status [nb] (INGVIO_NEG_DIAG etc. as ingvio_ekf_update); any pointer may be NULL */
+int ingvio_landmark_fetch(ingvio_ctx* ctx, int b0, int nb, double* dx, int* rows, int* accept, double* gamma, int* status);
+
 /* whitenResidual (Update.cpp:36-79): gamma = res^T (H Pcc H^T + R)^-1 res. */
 int ingvio_chi2_gamma(ingvio_ctx* ctx, int b, const int* vidx, const int* vsize, int k,
                       const double* H, int ldh, int m, const double* res,

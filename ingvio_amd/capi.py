@@ -26,7 +26,8 @@ EXPORTS = [
     "ingvio_append_independent", "ingvio_ekf_update", "ingvio_chi2_gamma", "ingvio_msckf_update", "ingvio_qr_compress",
     "ingvio_frame_stage", "ingvio_frame_stage_async", "ingvio_frame_run", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_select",
     "ingvio_profile_reset",
-    "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_set_qr_method", "ingvio_debug_read", "ingvio_triangulate",
+    "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_set_qr_method", "ingvio_landmark_stage", "ingvio_landmark_run",
+    "ingvio_landmark_fetch", "ingvio_debug_read", "ingvio_triangulate",
     "ingvio_gnss_front_stage", "ingvio_gnss_front_fetch", "ingvio_gnss_update_batch", "ingvio_gnss_stage", "ingvio_gnss_run", "ingvio_gnss_fetch", "ingvio_mld", "ingvio_debug_msckf_info", "ingvio_debug_info_solution",
     "ingvio_chi2_gamma_multi", "ingvio_ekf_update_batch", "ingvio_add_variable_delayed_invertible", "ingvio_add_variable_delayed", "ingvio_replace_var_linear",
 ]
@@ -52,6 +53,21 @@ class GnssEpoch(C.Structure):
                 ("yaw_offset", C.c_double), ("R_enu2ecef", C.c_double * 9), ("anchor_ecef", C.c_double * 3), ("idx_se23", C.c_int),
                 ("idx_yof", C.c_int), ("idx_fs", C.c_int), ("idx_cb", C.c_int * 4), ("psr_noise_amp", C.c_double),
                 ("dopp_noise_amp", C.c_double)]
+
+
+class LandmarkFrame(C.Structure):
+    _fields_ = [("R_i2w", C.c_double * 9), ("p_i2w", C.c_double * 3), ("R_cl2i", C.c_double * 9), ("p_c2i", C.c_double * 3),
+                ("idx_epose", C.c_int), ("idx_ext", C.c_int), ("n_lm", C.c_int), ("lm_idx", C.POINTER(C.c_int)),
+                ("anchor_idx", C.POINTER(C.c_int)), ("pf", C.POINTER(C.c_double)), ("uv", C.POINTER(C.c_double)),
+                ("tracked", C.POINTER(C.c_ubyte))]
+
+
+class LandmarkOpts(C.Structure):
+    _fields_ = [("stereo", C.c_int), ("noise", C.c_double), ("chi2_thr", C.c_double), ("R_cl2cr", C.c_double * 9),
+                ("t_cl2cr", C.c_double * 3), ("in_frame", C.c_int)]
+
+
+LM_MAX = 64
 
 
 class CtxDesc(C.Structure):
@@ -363,6 +379,40 @@ class Context:
         out = np.zeros((nb, 64, 10))
         self._chk(self.L.ingvio_gnss_front_fetch(self.h, b0, nb, _d(out)))
         return out
+
+    def landmark_stage(self, b0, frames, stereo, noise, chi2_thr, R_cl2cr=None, t_cl2cr=None, in_frame=False):
+        """frames: per filter a dict(R_i2w, p_i2w, R_cl2i, p_c2i, idx_epose, idx_ext, lm_idx [L], anchor_idx [L], pf [L,3], uv [L,4],
+        tracked [L]): the in-state landmarks seen in the current frame (ingvio_landmark_stage)."""
+        nb = len(frames)
+        arr = (LandmarkFrame * nb)(); keep = []
+        for i, f in enumerate(frames):
+            li = np.ascontiguousarray(f["lm_idx"], dtype=np.int32); ai = np.ascontiguousarray(f["anchor_idx"], dtype=np.int32)
+            pf = f64(f["pf"]).reshape(-1, 3); uv = f64(f["uv"]).reshape(-1, 4)
+            tr = np.ascontiguousarray(f.get("tracked", np.ones(len(li))), dtype=np.uint8)
+            keep.append((li, ai, pf, uv, tr))
+            a = arr[i]
+            a.R_i2w = (C.c_double * 9)(*f64(f["R_i2w"]).reshape(9)); a.p_i2w = (C.c_double * 3)(*f64(f["p_i2w"]).reshape(3))
+            a.R_cl2i = (C.c_double * 9)(*f64(f["R_cl2i"]).reshape(9)); a.p_c2i = (C.c_double * 3)(*f64(f["p_c2i"]).reshape(3))
+            a.idx_epose = int(f["idx_epose"]); a.idx_ext = int(f["idx_ext"]); a.n_lm = len(li)
+            a.lm_idx = _i(li); a.anchor_idx = _i(ai); a.pf = _d(pf); a.uv = _d(uv); a.tracked = tr.ctypes.data_as(C.POINTER(C.c_ubyte))
+        o = LandmarkOpts(); o.stereo = int(bool(stereo)); o.noise = float(noise); o.chi2_thr = float(chi2_thr)
+        o.R_cl2cr = (C.c_double * 9)(*f64(np.eye(3) if R_cl2cr is None else R_cl2cr).reshape(9))
+        o.t_cl2cr = (C.c_double * 3)(*f64(np.zeros(3) if t_cl2cr is None else t_cl2cr).reshape(3))
+        o.in_frame = int(bool(in_frame))
+        self._chk(self.L.ingvio_landmark_stage(self.h, b0, nb, arr, C.byref(o)))
+        self._lm_range = (b0, nb)
+
+    def landmark_run(self, b0=None, nb=None):
+        b0, nb = (self._lm_range if b0 is None else (b0, nb))
+        self._chk(self.L.ingvio_landmark_run(self.h, b0, nb))
+
+    def landmark_fetch(self, b0=None, nb=None):
+        """-> (dx [nb, ldp], rows [nb], accept [nb, 64], gamma [nb, 64], status [nb])"""
+        b0, nb = (self._lm_range if b0 is None else (b0, nb))
+        dx = np.zeros((nb, self.ldp)); rows = np.zeros(nb, dtype=np.int32); acc = np.zeros((nb, LM_MAX), dtype=np.int32)
+        gam = np.zeros((nb, LM_MAX)); st = np.zeros(nb, dtype=np.int32)
+        self._chk(self.L.ingvio_landmark_fetch(self.h, b0, nb, _d(dx), _i(rows), _i(acc), _d(gam), _i(st)))
+        return dx, rows, acc, gam, st
 
     def gnss_run(self, b0=None, nb=None):
         b0, nb = (self._gnss_range if b0 is None else (b0, nb))

@@ -11,6 +11,7 @@
 #include "launch_qr.h"
 #include "launch_chol.h"
 #include "launch_gnss.h"
+#include "launch_lmbatch.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -26,10 +27,11 @@
 namespace {
 
 enum ProfId { PF_RESTORE, PF_PROPAGATE, PF_AUGMENT, PF_GATE, PF_FOLD, PF_MERGE, PF_EKF_CORE, PF_DOWNDATE, PF_MARG,
-              PF_GATE2, PF_GRAM, PF_INFO, PF_APPLY, PF_ROWGATE, PF_COUNT };
+              PF_GATE2, PF_GRAM, PF_INFO, PF_APPLY, PF_ROWGATE, PF_LM_BUILD, PF_LM_GEMM, PF_LM_CHOL, PF_COUNT };
 const char* kProfNames[PF_COUNT] = { "restore", "k_propagate", "k_augment", "k_msckf_gate", "k_msckf_fold",
                                      "k_msckf_merge", "k_ekf_core", "k_downdate", "k_marginalize",
-                                     "k_feat_gate3", "k_feat_gram2", "k_info_update", "k_info_apply", "k_rows_gate" };
+                                     "k_feat_gate3", "k_feat_gram2", "k_info_update", "k_info_apply", "k_rows_gate",
+                                     "k_lm_build", "k_lm_gemm", "k_lm_chol" };
 struct ProfRec { int id; hipEvent_t a, b; };
 
 }  // namespace
@@ -79,6 +81,21 @@ struct ingvio_ctx {
         std::vector<int> hi;            // per filter: highest state index named by the staged var_order (+1)
         bool staged = false;
     } gn;
+    // dense-H update workspace (kernels_lmbatch.hip + kernels_chol.hip): the batched landmark update and generic updates whose S
+    // does not fit in LDS.  Rows live in Hd [m_cap][n_ld] per filter, the sweep in X / Y [ldx][m_cap].
+    struct DenseWs {
+        double *Hd = nullptr, *X = nullptr, *Y = nullptr, *Tb = nullptr;
+        int *m = nullptr;
+        int m_cap = 0, n_ld = 0, n32 = 0, ldx = 0;
+        size_t hstride = 0, xstride = 0, tstride = 0;
+    } dw;
+    struct LmStage {
+        double *pose = nullptr, *pf = nullptr, *uv = nullptr, *gamma = nullptr, *dx = nullptr;      // dx: its own [B][ldp] (the frame's MSCKF dx stays in d_dx)
+        int *idx = nullptr, *n_lm = nullptr, *lm_idx = nullptr, *anchor_idx = nullptr, *tracked = nullptr, *accept = nullptr;
+        LmOpts op;
+        int l_hi = 0, in_frame = 0;
+        bool alloc = false, staged = false;
+    } lm;
     char* d_multi = nullptr;            // ingvio_chi2_gamma_multi: packed blocks (grown on demand)
     size_t multi_cap = 0;
     // staged frame state
@@ -555,7 +572,9 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
                      c->d_pf, c->d_uv, c->d_chi2, c->d_mask, c->d_gamma, c->d_accept, c->d_used, c->d_Rpart, c->d_chunk_used,
                      c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk, c->d_tri_ok, c->d_hnew, c->d_multi, c->d_noiseB,
                      c->gn.H, c->gn.res, c->gn.noise, c->gn.gamma, c->gn.chi2, c->gn.m, c->gn.nc, c->gn.colmap, c->gn.keep,
-                     c->gn.feph, c->gn.fobs, c->gn.frcv, c->gn.front };
+                     c->gn.feph, c->gn.fobs, c->gn.frcv, c->gn.front,
+                     c->dw.Hd, c->dw.X, c->dw.Y, c->dw.Tb, c->dw.m, c->lm.pose, c->lm.pf, c->lm.uv, c->lm.gamma, c->lm.idx, c->lm.n_lm,
+                     c->lm.lm_idx, c->lm.anchor_idx, c->lm.tracked, c->lm.accept, c->lm.dx };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& sl : c->pin) { if (sl.p) hipHostFree(sl.p); if (sl.ev) hipEventDestroy(sl.ev); }
     if (c->qr.exec) hipGraphExecDestroy(c->qr.exec);
@@ -1326,6 +1345,173 @@ int ingvio_triangulate(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* 
     return last_launch(c);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Dense-H update: rows already in dw.Hd (by state column), residual in the carried row of dw.X, row counts in dw.m.
+//   S = H P H^T (+ noise), Y = P H^T L^-T, z = L^-1 res by one Cholesky sweep with carried rows; dx = Y z; P -= Y Y^T.
+// ---------------------------------------------------------------------------------------------------------------------
+static int dense_ws_alloc(ingvio_ctx* c, int m_need)
+{
+    auto& w = c->dw;
+    const int m_cap = (m_need + 31) / 32 * 32;
+    if (w.Hd && w.m_cap >= m_cap) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    for (double** p : { &w.Hd, &w.X, &w.Y, &w.Tb }) { if (*p) hipFree(*p); *p = nullptr; }
+    if (w.m) { hipFree(w.m); w.m = nullptr; }
+    const int B = c->d.batch;
+    w.m_cap = m_cap; w.n32 = (c->d.n_max + 31) / 32 * 32; w.n_ld = w.n32; w.ldx = m_cap + w.n32 + 32;
+    w.hstride = (size_t)m_cap * w.n_ld; w.xstride = (size_t)w.ldx * m_cap; w.tstride = 2048 + (size_t)m_cap;
+    int rc = dalloc(c, &w.Hd, (size_t)B * w.hstride) | dalloc(c, &w.X, (size_t)B * w.xstride) | dalloc(c, &w.Y, (size_t)B * w.xstride)
+           | dalloc(c, &w.Tb, (size_t)B * w.tstride) | dalloc(c, &w.m, (size_t)B);
+    return rc ? INGVIO_E_HIP : 0;
+}
+
+// noise: r_kind < 0 -> scalar variance `var` on the whole diagonal (the GEMM's epilogue); else d_noise (stride nstride) through k_add_noise
+static int run_dense_update(ingvio_ctx* c, int b0, int nb, double var, int r_kind, const double* d_noise, int nstride, double* d_dx)
+{
+    auto& w = c->dw;
+    const int mc = w.m_cap, n_cap = c->d.n_max, B = c->d.batch;
+    const size_t pp = (size_t)c->ldp * c->ldp;
+    double *Hd = w.Hd + (size_t)b0 * w.hstride, *X = w.X + (size_t)b0 * w.xstride, *Y = w.Y + (size_t)b0 * w.xstride;
+    const int* act = w.m + b0;
+    {
+        ProfScope p(c, PF_LM_GEMM);
+        GemmArgs g = {};
+        // P H^T -> carried rows mc .. of X
+        g.A = c->Pbase + (size_t)b0 * pp; g.sa = pp; g.lda = c->ldp; g.modeA = 0; g.a_sel = c->d_cur + b0; g.a_sel_stride = (size_t)B * pp;
+        g.B = Hd; g.sb = w.hstride; g.ldb = w.n_ld; g.modeB = 1;
+        g.C = X + mc; g.sc = w.xstride; g.rs = 1; g.cs = w.ldx;
+        g.M = n_cap; g.N = mc; g.K = n_cap; g.m_lim = n_cap; g.n_lim = mc; g.ksplit = 1; g.active = act; g.batch = nb;
+        launch_gemm(g, c->st);
+        // S = H (P H^T), lower blocks
+        g = GemmArgs{};
+        g.A = Hd; g.sa = w.hstride; g.lda = w.n_ld; g.modeA = 1;
+        g.B = X + mc; g.sb = w.xstride; g.ldb = w.ldx; g.modeB = 1;
+        g.C = X; g.sc = w.xstride; g.rs = 1; g.cs = w.ldx;
+        g.M = mc; g.N = mc; g.K = n_cap; g.m_lim = mc; g.n_lim = mc; g.ksplit = 1; g.lower = 1; g.diag_add = r_kind < 0 ? var : 0.0;
+        g.active = act; g.batch = nb;
+        launch_gemm(g, c->st);
+        if (r_kind >= 0) launch_add_noise(X, w.xstride, w.ldx, d_noise, nstride, r_kind, act, mc, nb, c->st);
+    }
+    {
+        ProfScope p(c, PF_LM_CHOL);
+        CholArgs a = {};
+        a.W = X; a.Y = Y; a.xs = w.xstride; a.ld = w.ldx; a.Tb = w.Tb + (size_t)b0 * w.tstride; a.ts = w.tstride;
+        a.rows = w.ldx; a.ncols = mc; a.status = c->d_status + b0; a.fail_bit = 4; a.active = act; a.batch = nb;
+        launch_chol_sweep(a, c->st);
+        launch_lm_finish(view(c), b0, nb, Y, w.xstride, w.ldx, mc, mc + w.n32, act, d_dx, c->st);
+    }
+    {
+        ProfScope p(c, PF_DOWNDATE);
+        EkfLaunch E;
+        memset(&E, 0, sizeof E);
+        E.cv = view(c); E.b0 = b0; E.nb = nb; E.Y = Y + mc; E.m = w.m + b0; E.status = c->d_status;
+        launch_downdate(E, n_cap, c->st, nullptr, w.ldx, w.xstride);
+    }
+    c->mut_seq++;
+    return last_launch(c);
+}
+
+static int landmark_update_launch(ingvio_ctx* c, int b0, int nb)
+{
+    auto& w = c->dw;
+    auto& s = c->lm;
+    {
+        ProfScope p(c, PF_LM_BUILD);
+        LmBuild L;
+        memset(&L, 0, sizeof L);
+        L.cv = view(c); L.op = s.op; L.b0 = b0; L.nb = nb;
+        L.lv.pose = s.pose; L.lv.idx = s.idx; L.lv.n_lm = s.n_lm; L.lv.lm_idx = s.lm_idx; L.lv.anchor_idx = s.anchor_idx;
+        L.lv.pf = s.pf; L.lv.uv = s.uv; L.lv.tracked = s.tracked; L.lv.lmax = LM_MAX;
+        L.Hd = w.Hd + (size_t)b0 * w.hstride; L.hstride = w.hstride; L.n_ld = w.n_ld; L.m_cap = w.m_cap;
+        L.X = w.X + (size_t)b0 * w.xstride; L.xstride = w.xstride; L.ldx = w.ldx; L.res_row = w.m_cap + w.n32;
+        L.gamma = s.gamma + (size_t)b0 * LM_MAX; L.accept = s.accept + (size_t)b0 * LM_MAX; L.m_out = w.m + b0; L.dx = s.dx;
+        launch_lm_build(L, c->st);
+    }
+    return run_dense_update(c, b0, nb, s.op.var, -1, nullptr, 0, s.dx);
+}
+
+int ingvio_landmark_stage(ingvio_ctx* c, int b0, int nb, const ingvio_landmark_frame* fr, const ingvio_landmark_opts* o)
+{
+    if (check_range(c, b0, nb) || !fr || !o || !(o->noise > 0.0)) return INGVIO_E_ARG;
+    auto& s = c->lm;
+    int l_hi = 0;
+    for (int i = 0; i < nb; ++i) {
+        const auto& f = fr[i];
+        if (f.n_lm < 0 || f.n_lm > LM_MAX) return INGVIO_E_CAPACITY;
+        if (f.n_lm && (!f.lm_idx || !f.anchor_idx || !f.pf || !f.uv || !f.tracked)) return INGVIO_E_ARG;
+        if (f.idx_epose < 0 || f.idx_epose + 9 > c->d.n_max || f.idx_ext < 0 || f.idx_ext + 6 > c->d.n_max) return INGVIO_E_NOT_IN_STATE;
+        for (int l = 0; l < f.n_lm; ++l)
+            if (f.lm_idx[l] < 0 || f.lm_idx[l] + 3 > c->d.n_max || f.anchor_idx[l] < 0 || f.anchor_idx[l] + 6 > c->d.n_max) return INGVIO_E_NOT_IN_STATE;
+        l_hi = std::max(l_hi, f.n_lm);
+    }
+    const int B = c->d.batch;
+    if (!s.alloc) {
+        int rc = dalloc(c, &s.pose, (size_t)B * 24) | dalloc(c, &s.pf, (size_t)B * LM_MAX * 3) | dalloc(c, &s.uv, (size_t)B * LM_MAX * 4)
+               | dalloc(c, &s.gamma, (size_t)B * LM_MAX) | dalloc(c, &s.idx, (size_t)B * 2) | dalloc(c, &s.n_lm, (size_t)B)
+               | dalloc(c, &s.lm_idx, (size_t)B * LM_MAX) | dalloc(c, &s.anchor_idx, (size_t)B * LM_MAX) | dalloc(c, &s.tracked, (size_t)B * LM_MAX)
+               | dalloc(c, &s.accept, (size_t)B * LM_MAX) | dalloc(c, &s.dx, (size_t)B * c->ldp);
+        if (rc) return INGVIO_E_HIP;
+        s.alloc = true;
+    }
+    s.l_hi = std::max(s.l_hi, l_hi);
+    if (int rc = dense_ws_alloc(c, std::max(32, 4 * s.l_hi))) return rc;
+    Uploader upl{ c };
+    if (int rc = upl.begin(pad64(8 * (size_t)nb * (24 + 7 * LM_MAX)) + pad64(4 * (size_t)nb * (3 + 3 * LM_MAX)) + 1024)) return rc;
+    double* hp = upl.take<double>((size_t)nb * 24);
+    double* hpf = upl.take<double>((size_t)nb * LM_MAX * 3);
+    double* huv = upl.take<double>((size_t)nb * LM_MAX * 4);
+    int* hidx = upl.take<int>((size_t)nb * 2);
+    int* hn = upl.take<int>((size_t)nb);
+    int* hl = upl.take<int>((size_t)nb * LM_MAX);
+    int* ha = upl.take<int>((size_t)nb * LM_MAX);
+    int* ht = upl.take<int>((size_t)nb * LM_MAX);
+    for (int i = 0; i < nb; ++i) {
+        const auto& f = fr[i];
+        memcpy(hp + 24 * i, f.R_i2w, 72); memcpy(hp + 24 * i + 9, f.p_i2w, 24); memcpy(hp + 24 * i + 12, f.R_cl2i, 72); memcpy(hp + 24 * i + 21, f.p_c2i, 24);
+        hidx[2 * i] = f.idx_epose; hidx[2 * i + 1] = f.idx_ext; hn[i] = f.n_lm;
+        for (int l = 0; l < LM_MAX; ++l) {
+            const bool on = l < f.n_lm;
+            hl[i * LM_MAX + l] = on ? f.lm_idx[l] : -1; ha[i * LM_MAX + l] = on ? f.anchor_idx[l] : -1; ht[i * LM_MAX + l] = on ? f.tracked[l] : 0;
+            for (int k = 0; k < 3; ++k) hpf[((size_t)i * LM_MAX + l) * 3 + k] = on ? f.pf[3 * l + k] : 0.0;
+            for (int k = 0; k < 4; ++k) huv[((size_t)i * LM_MAX + l) * 4 + k] = on ? ((o->stereo || k < 2) ? f.uv[4 * l + k] : 0.0) : 0.0;
+        }
+    }
+    upl.copy(s.pose + (size_t)b0 * 24, hp, (size_t)nb * 24);
+    upl.copy(s.pf + (size_t)b0 * LM_MAX * 3, hpf, (size_t)nb * LM_MAX * 3);
+    upl.copy(s.uv + (size_t)b0 * LM_MAX * 4, huv, (size_t)nb * LM_MAX * 4);
+    upl.copy(s.idx + (size_t)b0 * 2, hidx, (size_t)nb * 2);
+    upl.copy(s.n_lm + b0, hn, (size_t)nb);
+    upl.copy(s.lm_idx + (size_t)b0 * LM_MAX, hl, (size_t)nb * LM_MAX);
+    upl.copy(s.anchor_idx + (size_t)b0 * LM_MAX, ha, (size_t)nb * LM_MAX);
+    upl.copy(s.tracked + (size_t)b0 * LM_MAX, ht, (size_t)nb * LM_MAX);
+    if (int rc = upl.end()) return rc;
+    memcpy(s.op.R_lr, o->R_cl2cr, 72); memcpy(s.op.t_lr, o->t_cl2cr, 24);
+    s.op.var = o->noise * o->noise; s.op.chi2_thr = o->chi2_thr; s.op.stereo = o->stereo ? 1 : 0;
+    s.in_frame = o->in_frame ? 1 : 0;
+    s.staged = true;
+    return INGVIO_OK;
+}
+
+int ingvio_landmark_run(ingvio_ctx* c, int b0, int nb)
+{
+    if (check_range(c, b0, nb) || !c->lm.staged) return INGVIO_E_ARG;
+    HIPCHK(c, hipMemsetAsync(c->d_status + b0, 0, sizeof(int) * (size_t)nb, c->st));
+    return landmark_update_launch(c, b0, nb);
+}
+
+int ingvio_landmark_fetch(ingvio_ctx* c, int b0, int nb, double* dx, int* rows, int* accept, double* gamma, int* status)
+{
+    if (check_range(c, b0, nb) || !c->lm.alloc) return INGVIO_E_ARG;
+    if (dx) HIPCHK(c, hipMemcpyAsync(dx, c->lm.dx + (size_t)b0 * c->ldp, 8 * (size_t)nb * c->ldp, hipMemcpyDeviceToHost, c->st));
+    if (rows) HIPCHK(c, hipMemcpyAsync(rows, c->dw.m + b0, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, c->st));
+    if (accept) HIPCHK(c, hipMemcpyAsync(accept, c->lm.accept + (size_t)b0 * LM_MAX, sizeof(int) * (size_t)nb * LM_MAX, hipMemcpyDeviceToHost, c->st));
+    if (gamma) HIPCHK(c, hipMemcpyAsync(gamma, c->lm.gamma + (size_t)b0 * LM_MAX, 8 * (size_t)nb * LM_MAX, hipMemcpyDeviceToHost, c->st));
+    if (status) HIPCHK(c, hipMemcpyAsync(status, c->d_status + b0, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    if (status) for (int i = 0; i < nb; ++i) status[i] = (status[i] & 4) ? INGVIO_E_UNSUPPORTED : ((status[i] & 2) ? INGVIO_NEG_DIAG : INGVIO_OK);   // bit 4: S not positive definite
+    return last_launch(c);
+}
+
 int ingvio_set_qr_method(ingvio_ctx* c, int method)
 {
     if (!c || method < 0 || method > 2) return INGVIO_E_ARG;
@@ -1522,10 +1708,15 @@ int ingvio_frame_run(ingvio_ctx* c, int restore_prior)
     for (int b = 0; b < B; ++b) c->h_n[b] += 6;
     // factored path: the marginalisation of the oldest clone rides on the update's write-back (k_info_apply
     // stores the updated covariance compacted into the other ping-pong half); dense path: separate kernel
-    const bool fuse = c->method == 1;
+    // staged in-frame landmark update (IngvioFilter.cpp:296-322: MSCKF updates, landmark update, then the marginalisation):
+    // the marginalisation cannot ride on the MSCKF write-back then
+    const bool with_lm = c->lm.staged && c->lm.in_frame;
+    const bool fuse = c->method == 1 && !with_lm;
     int rc = fuse ? run_msckf_factored(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used, c->d_idx, 6)
-                  : run_msckf(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used);
+                  : (c->method == 1 ? run_msckf_factored(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used)
+                                    : run_msckf(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used));
     if (rc) return rc;
+    if (with_lm) { rc = landmark_update_launch(c, 0, B); if (rc) return rc; }
     {
         ProfScope p(c, PF_MARG);
         if (fuse) launch_post_marg(view(c), 0, B, c->d_idx, 6, c->st);

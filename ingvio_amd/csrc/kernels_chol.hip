@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g)
         bj = t;
     } else { bi = blockIdx.x / nbj; bj = blockIdx.x - bi * nbj; }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
-    const double* A = g.A + (size_t)batch * g.sa;
+    const double* A = g.A + (size_t)batch * g.sa + (g.a_sel ? (size_t)g.a_sel[batch] * g.a_sel_stride : 0);
     const double* B = g.B + (size_t)batch * g.sb;
     // K range of this workgroup, then of this wave (multiples of 16)
     const int kchunks = (g.K + 15) / 16;

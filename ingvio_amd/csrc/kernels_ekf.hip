@@ -202,7 +202,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void k_downdate(CovView cv, int b0, const double* __restrict__ Yall,
                                                   const double* __restrict__ Yball,
-                                                  const int* __restrict__ m_all, int ystride, int* __restrict__ status)
+                                                  const int* __restrict__ m_all, size_t ystride, int* __restrict__ status, int ldy)
 {
     const int bl = blockIdx.y, b = b0 + bl;
     const int m = m_all[bl];
@@ -224,8 +224,8 @@ __global__ __launch_bounds__(256) void k_downdate(CovView cv, int b0, const doub
     double4_t acc = { 0.0, 0.0, 0.0, 0.0 };
     const int mp = (m + 3) & ~3;
     for (int k0 = 0; k0 < mp; k0 += 4) {
-        const double a = va ? Y[ra + (size_t)(k0 + kq) * ld] : 0.0;
-        const double bb = vb ? Yb[rb + (size_t)(k0 + kq) * ld] : 0.0;
+        const double a = va ? Y[ra + (size_t)(k0 + kq) * ldy] : 0.0;
+        const double bb = vb ? Yb[rb + (size_t)(k0 + kq) * ldy] : 0.0;
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
     }
     const int col = tj * 16 + (lane & 15);
@@ -322,11 +322,11 @@ int launch_rows_gate(const EkfLaunch& L, const RowsGateIn& in, double thr, doubl
                        const_cast<int*>(L.colmap), const_cast<int*>(L.nc), L.mld, L.hstride, L.cstride, thr, gamma, keep);
     return 0;
 }
-void launch_downdate(const EkfLaunch& L, int n_cap, hipStream_t st, const double* Yb)
+void launch_downdate(const EkfLaunch& L, int n_cap, hipStream_t st, const double* Yb, int ldy, size_t ystride)
 {
     const int nt = (n_cap + 15) / 16;
     const int tiles = nt * (nt + 1) / 2;
-    hipLaunchKernelGGL(k_downdate, dim3((tiles + 3) / 4, L.nb), dim3(256), 0, st, L.cv, L.b0, L.Y, Yb ? Yb : L.Y, L.m, L.ystride, L.status);
+    hipLaunchKernelGGL(k_downdate, dim3((tiles + 3) / 4, L.nb), dim3(256), 0, st, L.cv, L.b0, L.Y, Yb ? Yb : L.Y, L.m, ystride ? ystride : (size_t)L.ystride, L.status, ldy ? ldy : L.cv.ldp);
 }
 
 void launch_gamma_multi(CovView cv, int b, int nblk, const double* dbuf, const int* ibuf, const int* desc, const double* noise,

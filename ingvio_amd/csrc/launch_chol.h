@@ -15,6 +15,7 @@
 //   active (optional): per batch element, 0 = skip
 struct GemmArgs {
     const double* A; size_t sa; int lda, modeA;
+    const int* a_sel; size_t a_sel_stride;          // optional: A += a_sel[batch] * a_sel_stride (the live ping-pong half of a covariance)
     const double* B; size_t sb; int ldb, modeB;
     const double* Ax; int ax; const double* Bx; int bx;
     double* C; size_t sc; long rs, cs;

@@ -22,7 +22,8 @@ struct EkfLaunch {
 };
 
 void launch_ekf_core(const EkfLaunch& L, hipStream_t st);
-void launch_downdate(const EkfLaunch& L, int n_cap, hipStream_t st, const double* Yb = nullptr);
+// ldy / ystride (0: the covariance's ld / L.ystride): leading dimension and per-filter stride of Y when it lives in another workspace
+void launch_downdate(const EkfLaunch& L, int n_cap, hipStream_t st, const double* Yb = nullptr, int ldy = 0, size_t ystride = 0);
 struct RowsGateIn {         // the staged candidate rows of a batch (read-only; the gate writes its compacted copy into EkfLaunch's H/res/noise/m)
     const double *H, *res, *noise;
     const int *m, *colmap, *nc;

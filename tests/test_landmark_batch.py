@@ -1,0 +1,119 @@
+"""Batched SLAM-landmark update (ingvio_landmark_stage / _run / _fetch, kernels_lmbatch.hip + kernels_chol.hip) against the oracle:
+rows from orc.landmark_rows_epose (LandmarkUpdate.cpp:521-686 restated, itself pinned by finite differences in test_landmark_path.py),
+per-landmark gates with numpy, the stacked update with orc.Cov.ekf_update.  Also the dense-H route of ingvio_ekf_update for row counts
+whose S does not fit in LDS."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+
+def spd(n, rng, scale=1.0):
+    A = rng.standard_normal((n, n))
+    return scale * (A @ A.T / n + 0.1 * np.eye(n))
+
+
+def rot(rng, mag=1.0):
+    return orc.gamma(mag * rng.standard_normal(3), 0).reshape(3, 3)
+
+CHI2_4, CHI2_2 = 9.487729036781154, 5.991464547107979
+
+
+def make_filter(rng, C, L, stereo, n_gnss=6, outliers=(), untracked=()):
+    """state [epose 9 | biases 6 | ext 6 | gnss | clones 6C | landmarks 3L], everything in view of the camera"""
+    i_ext = 15; i_cl = 21 + n_gnss; i_lm = i_cl + 6 * C
+    n = i_lm + 3 * L
+    R_i2w = rot(rng, 0.3); p_i2w = rng.standard_normal(3)
+    R_cl2i = rot(rng, 0.05); p_c2i = 0.05 * rng.standard_normal(3)
+    Rlr = rot(rng, 0.01); tlr = np.array([-0.11, 0.002, 0.001])
+    R_w2c = R_cl2i.T @ R_i2w.T
+    pf, uv = np.zeros((L, 3)), np.zeros((L, 4))
+    for l in range(L):
+        q = np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1.0, 1.0), rng.uniform(3.0, 9.0)])      # in the left camera
+        pf[l] = R_i2w @ (R_cl2i @ q + p_c2i) + p_i2w
+        qr = Rlr @ q + tlr
+        uv[l] = [q[0] / q[2], q[1] / q[2], qr[0] / qr[2], qr[1] / qr[2]]
+        uv[l] += 0.01 * rng.standard_normal(4) * (30.0 if l in outliers else 1.0)
+    tracked = np.ones(L, dtype=np.uint8)
+    for l in untracked: tracked[l] = 0
+    frame = dict(R_i2w=R_i2w, p_i2w=p_i2w, R_cl2i=R_cl2i, p_c2i=p_c2i, idx_epose=0, idx_ext=i_ext,
+                 lm_idx=[i_lm + 3 * l for l in range(L)], anchor_idx=[i_cl + 6 * int(rng.integers(0, C)) for _ in range(L)],
+                 pf=pf, uv=uv, tracked=tracked)
+    return n, frame, Rlr, tlr
+
+
+def oracle_update(P0, frame, stereo, noise, Rlr, tlr):
+    per = 4 if stereo else 2
+    thr = CHI2_4 if stereo else CHI2_2
+    n = P0.shape[0]
+    rows, res, acc, gam = [], [], [], []
+    for l, (il, ia) in enumerate(zip(frame["lm_idx"], frame["anchor_idx"])):
+        if not frame["tracked"][l]:
+            acc.append(0); gam.append(-1.0); continue
+        H, r = orc.landmark_rows_epose(frame["R_i2w"], frame["p_i2w"], frame["R_cl2i"], frame["p_c2i"], frame["pf"][l], frame["uv"][l],
+                                       stereo, Rlr, tlr)
+        Hd = np.zeros((per, n))
+        Hd[:, 0:9] += H[:per, 0:9]; Hd[:, 15:21] += H[:per, 9:15]; Hd[:, ia:ia + 6] += H[:per, 15:21]; Hd[:, il:il + 3] += H[:per, 21:24]
+        S = Hd @ P0 @ Hd.T + noise ** 2 * np.eye(per)
+        g = float(r[:per] @ np.linalg.solve(S, r[:per]))
+        gam.append(g)
+        if g < thr:
+            acc.append(1); rows.append(Hd); res.append(r[:per])
+        else:
+            acc.append(0)
+    oc = orc.Cov(P0)
+    dx = np.zeros(n)
+    if rows:
+        H = np.vstack(rows); r = np.concatenate(res)
+        dx, _ = oc.ekf_update([0], [n], H, r, noise ** 2)
+    return oc.P, dx, np.array(acc), np.array(gam), per * int(np.sum(acc))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stereo,L", [(True, 52), (False, 20), (True, 3), (True, 64)])
+def test_landmark_batch_vs_oracle(stereo, L):
+    from ingvio_amd import capi
+    rng = np.random.default_rng(1000 + L)
+    B, C, noise = 3, 11, 0.02
+    frames, priors, extras = [], [], []
+    n_max = 0
+    for b in range(B):
+        n, fr, Rlr, tlr = make_filter(rng, C, L, stereo, outliers=(1, 5) if L > 6 else (1,), untracked=(2,) if b == 1 else ())
+        frames.append(fr); priors.append(spd(n, rng, 1e-3)); extras.append((Rlr, tlr)); n_max = max(n_max, n)
+    Rlr, tlr = extras[0]
+    ctx = capi.Context(batch=B, n_max=n_max + 6, c_max=C, f_max=8, m_max=64)
+    for b in range(B): ctx.cov_set(b, priors[b])
+    ctx.landmark_stage(0, frames, stereo, noise, CHI2_4 if stereo else CHI2_2, Rlr, tlr)
+    ctx.landmark_run()
+    dx, rows, acc, gam, st = ctx.landmark_fetch()
+    assert not st.any()
+    for b in range(B):
+        Pw, dxw, accw, gamw, mw = oracle_update(priors[b], frames[b], stereo, noise, Rlr, tlr)
+        n = priors[b].shape[0]
+        assert np.array_equal(acc[b, :L], accw) and rows[b] == mw
+        on = gamw >= 0
+        assert np.allclose(gam[b, :L][on], gamw[on], rtol=1e-9, atol=1e-12) and (gam[b, :L][~on] == -1).all()
+        P = ctx.cov_get(b)
+        assert np.linalg.norm(P - Pw) < 1e-9 * np.linalg.norm(Pw) and np.array_equal(P, P.T)
+        assert np.linalg.norm(dx[b, :n] - dxw) < 1e-8 * max(1e-6, np.linalg.norm(dxw))
+    # replay: staged inputs are read-only
+    for b in range(B): ctx.cov_set(b, priors[b])
+    ctx.landmark_run()
+    dx2, rows2, acc2, _, _ = ctx.landmark_fetch()
+    assert np.array_equal(dx, dx2) and np.array_equal(acc, acc2)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_landmark_batch_nothing_accepted_leaves_state():
+    from ingvio_amd import capi
+    rng = np.random.default_rng(77)
+    n, fr, Rlr, tlr = make_filter(rng, 6, 5, True, untracked=(0, 1, 2, 3, 4))
+    P0 = spd(n, rng, 1e-3)
+    ctx = capi.Context(batch=1, n_max=n + 6, c_max=6, f_max=8, m_max=64)
+    ctx.cov_set(0, P0)
+    ctx.landmark_stage(0, [fr], True, 0.02, CHI2_4, Rlr, tlr)
+    ctx.landmark_run()
+    dx, rows, acc, gam, st = ctx.landmark_fetch()
+    assert rows[0] == 0 and not acc.any() and not dx.any() and np.array_equal(ctx.cov_get(0), P0)
+    ctx.close()
