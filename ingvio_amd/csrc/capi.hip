@@ -84,7 +84,7 @@ struct ingvio_ctx {
     // dense-H update workspace (kernels_lmbatch.hip + kernels_chol.hip): the batched landmark update and generic updates whose S
     // does not fit in LDS.  Rows live in Hd [m_cap][n_ld] per filter, the sweep in X / Y [ldx][m_cap].
     struct DenseWs {
-        double *Hd = nullptr, *X = nullptr, *Y = nullptr, *Tb = nullptr;
+        double *Hd = nullptr, *X = nullptr, *Y = nullptr, *Tb = nullptr, *noise = nullptr;      // noise: one filter's R (ingvio_ekf_update)
         int *m = nullptr;
         int m_cap = 0, n_ld = 0, n32 = 0, ldx = 0;
         size_t hstride = 0, xstride = 0, tstride = 0;
@@ -573,7 +573,7 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
                      c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk, c->d_tri_ok, c->d_hnew, c->d_multi, c->d_noiseB,
                      c->gn.H, c->gn.res, c->gn.noise, c->gn.gamma, c->gn.chi2, c->gn.m, c->gn.nc, c->gn.colmap, c->gn.keep,
                      c->gn.feph, c->gn.fobs, c->gn.frcv, c->gn.front,
-                     c->dw.Hd, c->dw.X, c->dw.Y, c->dw.Tb, c->dw.m, c->lm.pose, c->lm.pf, c->lm.uv, c->lm.gamma, c->lm.idx, c->lm.n_lm,
+                     c->dw.Hd, c->dw.X, c->dw.Y, c->dw.Tb, c->dw.noise, c->dw.m, c->lm.pose, c->lm.pf, c->lm.uv, c->lm.gamma, c->lm.idx, c->lm.n_lm,
                      c->lm.lm_idx, c->lm.anchor_idx, c->lm.tracked, c->lm.accept, c->lm.dx };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& sl : c->pin) { if (sl.p) hipHostFree(sl.p); if (sl.ev) hipEventDestroy(sl.ev); }
@@ -738,6 +738,41 @@ int ingvio_append_independent(ingvio_ctx* c, int b0, int nb, int size, const dou
     return last_launch(c);
 }
 
+static int dense_ws_alloc(ingvio_ctx* c, int m_need);
+static int run_dense_update(ingvio_ctx* c, int b0, int nb, double var, int r_kind, const double* d_noise, int nstride, double* d_dx);
+#define DENSE_M_MAX 1024      // rows of one generic update through the dense-H route (S factorised out of HBM, kernels_chol.hip)
+
+// ingvio_ekf_update for row counts whose S does not fit in LDS (or beyond the context's m_max): the host scatters the columns
+// into the dense row layout of kernels_lmbatch.hip and the update runs as GEMM + Cholesky sweep + downdate.
+static int ekf_update_dense_route(ingvio_ctx* c, int b, const int* vidx, const int* vsize, int k, const double* H, int ldh, int m,
+                                  const double* res, const double* R, int r_kind, double* dx_out)
+{
+    if (check_range(c, b, 1) || !vidx || !vsize || !H || !res || !R || k < 1 || m < 1 || ldh < m || r_kind < 0 || r_kind > 2) return INGVIO_E_ARG;
+    if (m > DENSE_M_MAX) return INGVIO_E_CAPACITY;
+    for (int i = 0; i < k; ++i) if (vidx[i] < 0 || vsize[i] < 0 || vidx[i] + vsize[i] > c->h_n[b]) return INGVIO_E_NOT_IN_STATE;
+    if (int rc = dense_ws_alloc(c, m)) return rc;
+    auto& w = c->dw;
+    std::vector<double> Hd((size_t)w.m_cap * w.n_ld, 0.0), rr((size_t)w.m_cap, 0.0);
+    int col = 0;
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < vsize[i]; ++j, ++col)
+            for (int r = 0; r < m; ++r) Hd[(size_t)r * w.n_ld + vidx[i] + j] += H[(size_t)r + (size_t)col * ldh];
+    memcpy(rr.data(), res, 8 * (size_t)m);
+    int zero = 0, rc = up(c, w.Hd + (size_t)b * w.hstride, Hd.data(), 8 * Hd.size());
+    if (hipMemcpy2DAsync(w.X + (size_t)b * w.xstride + w.m_cap + w.n32, 8 * (size_t)w.ldx, rr.data(), 8, 8, (size_t)w.m_cap, hipMemcpyHostToDevice, c->st) != hipSuccess) rc = INGVIO_E_HIP;
+    rc |= up(c, w.m + b, &m, sizeof(int));
+    rc |= up(c, w.noise, R, 8 * (size_t)(r_kind == 0 ? 1 : (r_kind == 1 ? m : (size_t)m * m)));
+    rc |= up(c, c->d_status + b, &zero, sizeof(int));
+    if (rc) return INGVIO_E_HIP;
+    HIPCHK(c, hipStreamSynchronize(c->st));                                       // the host vectors go out of scope
+    rc = run_dense_update(c, b, 1, 0.0, r_kind, w.noise, 0, c->d_dx);
+    if (rc) return rc;
+    int status = 0;
+    if (dx_out && down_sync(c, dx_out, c->d_dx + (size_t)b * c->ldp, 8 * (size_t)c->h_n[b])) return INGVIO_E_HIP;
+    if (down_sync(c, &status, c->d_status + b, sizeof(int))) return INGVIO_E_HIP;
+    return (status & 2) ? INGVIO_NEG_DIAG : INGVIO_OK;
+}
+
 // k_ekf_core keeps S (+ one border row/column) and the column map in LDS (launch_ekf_core): 160 KB per workgroup on gfx950
 static bool ekf_core_fits(int m, int nc)
 {
@@ -776,6 +811,12 @@ int ingvio_ekf_update(ingvio_ctx* c, int b, const int* vidx, const int* vsize, i
                       const double* res, const double* R, int r_kind, double* dx_out)
 {
     int nc = 0;
+    if (c && vsize && k >= 1) {                                     // S beyond LDS / rows beyond m_max: the dense route
+        int ncq = 0;
+        for (int i = 0; i < k; ++i) ncq += vsize[i];
+        if (m > c->mld || (m > c->d.m_max && m > 6 * c->d.c_max) || ncq > c->nc_cap || !ekf_core_fits(m, ncq))
+            return ekf_update_dense_route(c, b, vidx, vsize, k, H, ldh, m, res, R, r_kind, dx_out);
+    }
     int rc = stage_generic(c, b, vidx, vsize, k, H, ldh, m, res, R, r_kind, &nc);
     if (rc) return rc;
     if (!ekf_core_fits(m, nc)) return INGVIO_E_CAPACITY;          // before anything touches the covariance
@@ -1355,13 +1396,13 @@ static int dense_ws_alloc(ingvio_ctx* c, int m_need)
     const int m_cap = (m_need + 31) / 32 * 32;
     if (w.Hd && w.m_cap >= m_cap) return 0;
     HIPCHK(c, hipStreamSynchronize(c->st));
-    for (double** p : { &w.Hd, &w.X, &w.Y, &w.Tb }) { if (*p) hipFree(*p); *p = nullptr; }
+    for (double** p : { &w.Hd, &w.X, &w.Y, &w.Tb, &w.noise }) { if (*p) hipFree(*p); *p = nullptr; }
     if (w.m) { hipFree(w.m); w.m = nullptr; }
     const int B = c->d.batch;
     w.m_cap = m_cap; w.n32 = (c->d.n_max + 31) / 32 * 32; w.n_ld = w.n32; w.ldx = m_cap + w.n32 + 32;
     w.hstride = (size_t)m_cap * w.n_ld; w.xstride = (size_t)w.ldx * m_cap; w.tstride = 2048 + (size_t)m_cap;
     int rc = dalloc(c, &w.Hd, (size_t)B * w.hstride) | dalloc(c, &w.X, (size_t)B * w.xstride) | dalloc(c, &w.Y, (size_t)B * w.xstride)
-           | dalloc(c, &w.Tb, (size_t)B * w.tstride) | dalloc(c, &w.m, (size_t)B);
+           | dalloc(c, &w.Tb, (size_t)B * w.tstride) | dalloc(c, &w.m, (size_t)B) | dalloc(c, &w.noise, (size_t)m_cap * m_cap);
     return rc ? INGVIO_E_HIP : 0;
 }
 

@@ -11,8 +11,8 @@
 //                 residual into the carried row of the Cholesky workspace.  Dense columns make the two products plain GEMMs
 //                 (P H^T and H (P H^T)) with no gather; with 52 landmarks the involved columns are 237 of 249 anyway.
 //   k_lm_finish   dx = Y z from the carried rows of the sweep (Y = P H^T L^-T, z = L^-1 res).
-//   k_scatter_H   the same dense layout from a compact (H, colmap) block: the route of ingvio_ekf_update(_batch) for row counts
-//                 whose S does not fit in LDS.
+//   k_add_noise   diagonal / dense measurement noise added to S: ingvio_ekf_update hands rows over in the same dense layout when
+//                 their S does not fit in LDS (the host scatters the columns).
 // Between them: launch_gemm / launch_chol_sweep (kernels_chol.hip) and k_downdate (kernels_ekf.hip).
 #include "launch_lmbatch.h"
 
@@ -240,35 +240,6 @@ __global__ __launch_bounds__(256) void k_lm_finish(CovView cv, int b0, const dou
     dx_all[(size_t)b * ld + r] = d0 + d1;
 }
 
-// compact block (H m x nc column-major mld, colmap) -> dense rows by state column (zero fill, then scatter); residual into the
-// carried row
-__global__ __launch_bounds__(256) void k_scatter_zero(const int* __restrict__ m_all, double* __restrict__ Hd_all, size_t hstride, int n_ld, int m_cap)
-{
-    const int bl = blockIdx.y;
-    if (m_all[bl] == 0) return;
-    double* Hd = Hd_all + (size_t)bl * hstride;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < (size_t)m_cap * n_ld; e += (size_t)gridDim.x * 256) Hd[e] = 0.0;
-}
-
-__global__ __launch_bounds__(256) void k_scatter_H2(const double* __restrict__ H_all, int hstride_in, int mld, const double* __restrict__ res_all,
-                                                    const int* __restrict__ colmap_all, int cstride, const int* __restrict__ m_all,
-                                                    const int* __restrict__ nc_all, double* __restrict__ Hd_all, size_t hstride, int n_ld,
-                                                    double* __restrict__ X_all, size_t xstride, int ldx, int res_row, int m_cap)
-{
-    const int bl = blockIdx.y, m = m_all[bl], nc = nc_all[bl];
-    if (m == 0) return;
-    const double* H = H_all + (size_t)bl * hstride_in;
-    const int* cm = colmap_all + (size_t)bl * cstride;
-    double* Hd = Hd_all + (size_t)bl * hstride;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < m * nc; e += gridDim.x * 256) {
-        const int i = e % m, c = e / m;
-        Hd[(size_t)i * n_ld + cm[c]] = H[(size_t)i + (size_t)c * mld];
-    }
-    double* X = X_all + (size_t)bl * xstride;
-    const double* res = res_all + (size_t)bl * mld;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < m_cap; i += gridDim.x * 256) X[(size_t)res_row + (size_t)i * ldx] = i < m ? res[i] : 0.0;
-}
-
 // S (lower, in the sweep's working matrix) += R for the diagonal / dense noise models; r_kind 0 is the GEMM's diag_add
 __global__ __launch_bounds__(256) void k_add_noise(double* __restrict__ X_all, size_t xstride, int ldx, const double* __restrict__ noise_all,
                                                    int nstride, int r_kind, const int* __restrict__ m_all, int m_cap)
@@ -300,14 +271,6 @@ void launch_lm_finish(CovView cv, int b0, int nb, const double* Y, size_t ystrid
                       hipStream_t st)
 {
     hipLaunchKernelGGL(k_lm_finish, dim3((cv.ldp + 255) / 256, nb), dim3(256), 0, st, cv, b0, Y, ystride, ldy, y_row0, z_row, m, dx);
-}
-
-void launch_scatter_H(const double* H, int hstride_in, int mld, const double* res, const int* colmap, int cstride, const int* m, const int* nc,
-                      double* Hd, size_t hstride, int n_ld, int m_cap, double* X, size_t xstride, int ldx, int res_row, int nb, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_scatter_zero, dim3(32, nb), dim3(256), 0, st, m, Hd, hstride, n_ld, m_cap);
-    hipLaunchKernelGGL(k_scatter_H2, dim3(8, nb), dim3(256), 0, st, H, hstride_in, mld, res, colmap, cstride, m, nc, Hd, hstride, n_ld,
-                       X, xstride, ldx, res_row, m_cap);
 }
 
 void launch_add_noise(double* X, size_t xstride, int ldx, const double* noise, int nstride, int r_kind, const int* m, int m_cap, int nb,

@@ -35,7 +35,5 @@ struct LmBuild {
 void launch_lm_build(const LmBuild& L, hipStream_t st);
 void launch_lm_finish(CovView cv, int b0, int nb, const double* Y, size_t ystride, int ldy, int y_row0, int z_row, const int* m, double* dx,
                       hipStream_t st);
-void launch_scatter_H(const double* H, int hstride_in, int mld, const double* res, const int* colmap, int cstride, const int* m, const int* nc,
-                      double* Hd, size_t hstride, int n_ld, int m_cap, double* X, size_t xstride, int ldx, int res_row, int nb, hipStream_t st);
 void launch_add_noise(double* X, size_t xstride, int ldx, const double* noise, int nstride, int r_kind, const int* m, int m_cap, int nb,
                       hipStream_t st);

@@ -117,3 +117,28 @@ def test_landmark_batch_nothing_accepted_leaves_state():
     dx, rows, acc, gam, st = ctx.landmark_fetch()
     assert rows[0] == 0 and not acc.any() and not dx.any() and np.array_equal(ctx.cov_get(0), P0)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,r_kind", [(300, "diag"), (150, "full"), (200, "scalar")])
+def test_ekf_update_rows_beyond_lds(m, r_kind):
+    """ingvio_ekf_update with more rows than S fits in LDS (round 1: INGVIO_E_CAPACITY above 128 / 136 rows): the dense-H route
+    (GEMM + Cholesky sweep with carried rows + downdate) against the oracle's ekfUpdate (StateManager.cpp:359-411)."""
+    from ingvio_amd import capi
+    rng = np.random.default_rng(m)
+    n = 21 + 66 + 30
+    P0 = spd(n, rng, 1e-2)
+    ctx = capi.Context(batch=2, n_max=n + 3, c_max=11, f_max=8, m_max=64)
+    ctx.cov_set(1, P0); ctx.cov_set(0, 2 * P0)
+    vo, vs = [0, 27, 87, 21], [9, 30, 30, 6]
+    H = rng.standard_normal((m, sum(vs))); r = 0.1 * rng.standard_normal(m)
+    if r_kind == "diag": R = rng.uniform(0.5, 2.0, m)
+    elif r_kind == "full": A = rng.standard_normal((m, m)); R = A @ A.T / m + 0.5 * np.eye(m)
+    else: R = 0.7
+    oc = orc.Cov(P0); dxw, _ = oc.ekf_update(vo, vs, H, r, R)
+    dx, _ = ctx.ekf_update(1, vo, vs, H, r, R)
+    P = ctx.cov_get(1)
+    assert np.linalg.norm(P - oc.P) < 1e-10 * np.linalg.norm(oc.P) and np.array_equal(P, P.T)
+    assert np.linalg.norm(dx[:n] - dxw) < 1e-9 * np.linalg.norm(dxw)
+    assert np.array_equal(ctx.cov_get(0), 2 * P0)                       # the neighbour filter is untouched
+    ctx.close()
