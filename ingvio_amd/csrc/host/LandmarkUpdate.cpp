@@ -217,57 +217,46 @@ void LandmarkUpdate::updateLandmarkStereo(std::shared_ptr<State> s, std::shared_
 
 void LandmarkUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, bool stereo)
 {
+    // LandmarkUpdate.cpp:32-149: rows of every in-state landmark, a chi^2 gate per landmark on the prior (:98-99, dof = rows),
+    // the accepted rows stacked, one ekfUpdate - all of it in one device call (kernels_lmbatch.hip); the nominal values stay here
     _last_rows = 0;
-    if (state->_anchored_landmarks.size() == 0) return;
+    const int L = (int)state->_anchored_landmarks.size();
+    if (L == 0) return;
+    if (L > INGVIO_LM_MAX) {
+        std::cout << "[LandmarkUpdate]: more than " << INGVIO_LM_MAX << " in-state landmarks!" << std::endl;
+        std::exit(EXIT_FAILURE);
+    }
     const int per = stereo ? 4 : 2;
-    std::vector<std::shared_ptr<Type>> var_order = { state->_extended_pose, state->_camleft_imu_extrinsics };
-    std::map<std::shared_ptr<Type>, int> col_of;
-    col_of[state->_extended_pose] = 0;
-    col_of[state->_camleft_imu_extrinsics] = 9;
-    int col_cnt = 15;
-    struct Block { VecXd res; MatXd H; std::shared_ptr<Type> anchor, lm; };
-    std::vector<Block> all, accepted;
+    const double t = state->_timestamp;
+    std::vector<int> lm_idx, anchor_idx;
+    std::vector<double> pf, uv;
+    std::vector<unsigned char> tracked;
     for (const auto& item : state->_anchored_landmarks) {
         checkTracked(map_server, state, item.first, stereo);
-        Block blk;
-        blk.anchor = item.second->getAnchoredPose();
-        blk.lm = item.second;
-        landmarkRows(map_server->at(item.first), state, stereo, blk.res, blk.H);
-        all.push_back(std::move(blk));
+        const auto fi = map_server->at(item.first);
+        lm_idx.push_back(item.second->idx());
+        anchor_idx.push_back(item.second->getAnchoredPose()->idx());
+        const Vec3d p = item.second->valuePosXyz();
+        pf.insert(pf.end(), { p.x(), p.y(), p.z() });
+        if (stereo) { const auto& m = fi->_stereo_obs.at(t); uv.insert(uv.end(), { m->_u0, m->_v0, m->_u1, m->_v1 }); }
+        else { const auto& m = fi->_mono_obs.at(t); uv.insert(uv.end(), { m->_u0, m->_v0, 0.0, 0.0 }); }
+        tracked.push_back(1);
     }
-    // testChiSquared(state, res, H, [pose, extrinsics, anchor, landmark], noise) for every landmark (:98-99): all gates are
-    // against the same prior, so they go to the device in one call; dof = rows (Update.cpp:81-102)
-    std::vector<StateManager::GateBlock> gates;
-    for (const Block& blk : all)
-        gates.push_back({ { state->_extended_pose, state->_camleft_imu_extrinsics, blk.anchor, blk.lm }, &blk.H, &blk.res });
-    const std::vector<double> gamma = StateManager::whitenResidualMulti(state, gates, _noise);
-    const std::vector<double> table = chi2TableDense(per + 1);
-    for (size_t g = 0; g < all.size(); ++g) {
-        if (!(gamma[g] < table[per])) continue;
-        Block& blk = all[g];
-        for (const auto& v : { blk.anchor, blk.lm })
-            if (col_of.find(v) == col_of.end()) { col_of[v] = col_cnt; col_cnt += v->size(); var_order.push_back(v); }
-        accepted.push_back(std::move(blk));
-    }
-    if (accepted.empty()) return;
-    const int rows = per * (int)accepted.size();
-    MatXd H_large(rows, col_cnt);
-    VecXd res_large(rows, 0.0);
-    for (size_t a = 0; a < accepted.size(); ++a) {
-        const Block& blk = accepted[a];
-        const int ca = col_of.at(blk.anchor), cl = col_of.at(blk.lm);
-        for (int r = 0; r < per; ++r) {
-            const int R = per * (int)a + r;
-            res_large[R] = blk.res[r];
-            for (int c = 0; c < 15; ++c) H_large(R, c) = blk.H(r, c);
-            for (int c = 0; c < 6; ++c) H_large(R, ca + c) = blk.H(r, 15 + c);
-            for (int c = 0; c < 3; ++c) H_large(R, cl + c) = blk.H(r, 21 + c);
-        }
-    }
-    MatXd Rn = MatXd::Identity(rows);
-    for (int i = 0; i < rows; ++i) Rn(i, i) = std::pow(_noise, 2);
-    StateManager::ekfUpdate(state, var_order, H_large, res_large, Rn);
-    _last_rows = rows;
+    ingvio_landmark_frame fr;
+    std::memset(&fr, 0, sizeof fr);
+    const Mat3d R_i2w = state->_extended_pose->valueLinearAsMat(), R_cl2i = state->_camleft_imu_extrinsics->valueLinearAsMat();
+    const Vec3d p_i2w = state->_extended_pose->valueTrans1(), p_c2i = state->_camleft_imu_extrinsics->valueTrans();
+    std::memcpy(fr.R_i2w, R_i2w.m, sizeof fr.R_i2w); std::memcpy(fr.R_cl2i, R_cl2i.m, sizeof fr.R_cl2i);
+    for (int i = 0; i < 3; ++i) { fr.p_i2w[i] = p_i2w[i]; fr.p_c2i[i] = p_c2i[i]; }
+    fr.idx_epose = state->_extended_pose->idx(); fr.idx_ext = state->_camleft_imu_extrinsics->idx();
+    fr.n_lm = L; fr.lm_idx = lm_idx.data(); fr.anchor_idx = anchor_idx.data(); fr.pf = pf.data(); fr.uv = uv.data(); fr.tracked = tracked.data();
+    ingvio_landmark_opts op;
+    std::memset(&op, 0, sizeof op);
+    op.stereo = stereo ? 1 : 0; op.noise = _noise; op.chi2_thr = chi2TableDense(per + 1)[per];
+    const Iso3& T_lr = state->_state_params._T_cl2cr;
+    std::memcpy(op.R_cl2cr, T_lr.R.m, sizeof op.R_cl2cr);
+    for (int i = 0; i < 3; ++i) op.t_cl2cr[i] = T_lr.t[i];
+    _last_rows = StateManager::landmarkUpdate(state, fr, op);
 }
 
 void LandmarkUpdate::updateLandmarkMonoSw(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server)

@@ -69,16 +69,16 @@ State::State(const IngvioParams& filter_params) : _state_params(filter_params)
     d.f_max = filter_params._hip_f_max; d.device = filter_params._hip_device; d.stream = nullptr;
     d.m_max = 64;
     if (filter_params._max_lm_feats > 0) {
-        // SLAM landmarks (f-2): the stacked landmark update has up to 4 L ROWS (its 15 + 6 C + 3 L columns are bounded by the
-        // state dimension, not by m_max), the delayed initialisation 4 C rows
-        const int L = filter_params._max_lm_feats, C = d.c_max;
-        for (int need : { 4 * L, 4 * C }) if (need > d.m_max) d.m_max = need;
+        // SLAM landmarks (f-2): the delayed initialisation has 4 C rows.  The stacked landmark update (up to 4 L rows) does not
+        // count: it runs through ingvio_landmark_* with S outside LDS (up to 64 landmarks)
+        const int C = d.c_max;
+        if (4 * C > d.m_max) d.m_max = 4 * C;
     }
     const int rc = ingvio_ctx_create(&d, &_ctx);
     if (rc != INGVIO_OK) {
         if (rc == INGVIO_E_CAPACITY)
             std::cout << "[State]: libingvio_hip: configuration exceeds this build's limits (window " << d.c_max << " clones <= 36, update rows "
-                      << d.m_max << " <= 128: max_landmark_features <= 32 stereo)" << std::endl;
+                      << d.m_max << " <= 128)" << std::endl;
         else
             std::cout << "[State]: libingvio_hip: no MI355X context, error " << rc << " (" << (_ctx ? ingvio_last_error(_ctx) : "no device")
                       << ")" << std::endl;

@@ -215,6 +215,30 @@ void StateManager::ekfUpdate(std::shared_ptr<State> state, const std::vector<std
     boxPlus(state, dx);                                                                      // :425
 }
 
+int StateManager::landmarkUpdate(std::shared_ptr<State> state, const ingvio_landmark_frame& frame, const ingvio_landmark_opts& opts,
+                                 std::vector<int>* accept)
+{
+    int rc = ingvio_landmark_stage(state->_ctx, state->_b, 1, &frame, &opts);
+    if (rc < 0) fatal(state, "landmarkUpdate (stage)", rc);
+    rc = ingvio_landmark_run(state->_ctx, state->_b, 1);
+    if (rc < 0) fatal(state, "landmarkUpdate (run)", rc);
+    const int ldp = ingvio_ldp(state->_ctx);
+    std::vector<double> dxl((size_t)ldp, 0.0);
+    std::vector<int> acc(INGVIO_LM_MAX, 0);
+    int rows = 0, status = 0;
+    rc = ingvio_landmark_fetch(state->_ctx, state->_b, 1, dxl.data(), &rows, acc.data(), nullptr, &status);
+    if (rc < 0) fatal(state, "landmarkUpdate (fetch)", rc);
+    if (status < 0) fatal(state, "landmarkUpdate", status);
+    if (accept) accept->assign(acc.begin(), acc.begin() + frame.n_lm);
+    if (rows == 0) return 0;
+    if (status == INGVIO_NEG_DIAG)
+        std::cout << "[StateManager]: EKF Update and found negative diag cov elements! " << std::endl;      // StateManager.cpp:418
+    VecXd dx(state->curr_cov_size(), 0.0);
+    for (int i = 0; i < state->curr_cov_size(); ++i) dx[i] = dxl[i];
+    boxPlus(state, dx);
+    return rows;
+}
+
 void StateManager::addVariableDelayedInvertible(std::shared_ptr<State> state, std::shared_ptr<Type> var_new,
                                                 const std::vector<std::shared_ptr<Type>>& var_old_order, const MatXd& H_old,
                                                 const MatXd& H_new, const VecXd& res, double noise_iso_meas)

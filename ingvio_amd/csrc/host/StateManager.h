@@ -61,6 +61,10 @@ public:
     struct GateBlock { std::vector<std::shared_ptr<Type>> var_order; const MatXd* H; const VecXd* res; };
     static std::vector<double> whitenResidualMulti(std::shared_ptr<State> state, const std::vector<GateBlock>& blocks, double noise);
 
+    // all in-state landmarks of the current frame in one device call (ingvio_landmark_stage / _run / _fetch): rows, per-landmark
+    // gates, stacking, ekfUpdate + boxPlus; returns the rows of the update, accept [n_lm] optional
+    static int landmarkUpdate(std::shared_ptr<State> state, const ingvio_landmark_frame& frame, const ingvio_landmark_opts& opts,
+                              std::vector<int>* accept = nullptr);
     // MSCKF update on flattened MapServer data + boxPlus; returns rows handed to the Kalman update.
     // f-1: Triangulator::triangulate{Mono,Stereo}Obs of ONE feature on the device (ingvio_triangulate)
     static bool triangulateOne(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_tri_opts& opts, Vec3d& pf);
