@@ -70,14 +70,15 @@ class LazyCov:
         return self.n - 6
 
 
-def build_batch(ctx, B, seed0, F, C, n_gnss, n_landmarks):
+def build_batch(ctx, B, seed0, F, C, n_gnss, n_landmarks, lm_sigma=1.0):
     """Creates B config-2 style cases; priors are produced by the HIP path itself (batched propagate+clone)."""
     from ingvio_amd import host, synth
     pr = synth.PARAMS
     filters, rngs = [], []
     for b in range(B):
         rng = np.random.default_rng(0x1A6F10 + seed0 + b)
-        flt = synth.Filter(LazyCov, host.imu_transition, t0=0.1 * ((seed0 + b) % 997), n_gnss=n_gnss, n_landmarks=n_landmarks)
+        flt = synth.Filter(LazyCov, host.imu_transition, t0=0.1 * ((seed0 + b) % 997), n_gnss=n_gnss, n_landmarks=n_landmarks,
+                           lm_sigma=lm_sigma)
         flt.cov.host_init = False
         ctx.cov_set(b, flt.cov.M)
         filters.append(flt); rngs.append(rng)
@@ -295,6 +296,10 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--method", default="factored", choices=["factored", "dense"])
     ap.add_argument("--counters", default=COUNTERS_JSON)
+    ap.add_argument("--landmarks", default="padded", choices=["padded", "real"],
+                    help="nominal state: the 3-column landmark blocks are padding (default) or REAL in-state SLAM landmarks that "
+                         "receive rows every frame (LandmarkUpdate.cpp:32-149, batched on the device between the MSCKF update and "
+                         "the marginalisation)")
     args = ap.parse_args()
     if args.literal:
         args.state = "literal"
@@ -316,11 +321,17 @@ def main():
     ctx.set_method(args.method)
     ld = ctx.ldp
     t_build = time.perf_counter()
-    filters, steps, frames, infos = build_batch(ctx, B, rank * B, F, C, n_gnss, n_lm)
+    real_lm = args.landmarks == "real" and n_lm > 0
+    n_lm_real = min(n_lm, capi.LM_MAX) if real_lm else 0
+    filters, steps, frames, infos = build_batch(ctx, B, rank * B, F, C, n_gnss, n_lm, lm_sigma=0.05 if real_lm else 1.0)
     ctx.snapshot()
     pr = synth.PARAMS
     ctx.frame_stage(0, steps, frames, filters[0].sigma(), filters[0].enable_gnss, pr["sigma_cb"], pr["sigma_rw"],
                     max_accept=0, compress_rule=1)
+    if real_lm:
+        lms = [synth.make_landmarks(infos[b]["rng"], filters[b], frames[b], n_lm_real) for b in range(B)]
+        Rlr, tlr = synth.t_cl2cr()
+        ctx.landmark_stage(0, lms, True, pr["visual_noise"], 9.487729036781154, Rlr, tlr, in_frame=True)
     gnss = None
     if args.config == 3:
         gnss = [synth.make_gnss(infos[b]["rng"], filters[b]) for b in range(B)]
@@ -373,6 +384,10 @@ def main():
     if gnss is not None:
         dxg, gn_used, keep, gam, st = ctx.gnss_fetch()
         ok = ok and bool(np.isfinite(dxg).all() and (st == 0).all())
+    lm_rows = None
+    if real_lm:
+        dxl, lm_rows, lacc, lgam, lst = ctx.landmark_fetch()
+        ok = ok and bool(np.isfinite(dxl).all() and (lst == 0).all() and (lm_rows > 0).all())
     # one end-of-run gather of per-rank summaries
     summ = grp.gather_summaries([float(n_acc.sum()), float(np.abs(dx).sum()), float(ok)])
     ok = bool(summ[:, 2].all())
@@ -434,7 +449,7 @@ def main():
                                 note="no committed SQ counters for this workload: the executed-operation count, and with it the "
                                      "achieved fraction, is unknown (collect with tests/gpu_counters.sh)")
         cpu, parity = None, None
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and not real_lm:      # the C oracle's frame has no landmark update: parity of that path is tests/test_landmark_batch.py
             cpu, (P1, n1, dx1, acc1, S) = cpu_baseline(ctx, steps, frames, infos[0]["n_prior"], ld, quick=args.quick_cpu)
             ctx.frame_run(restore_prior=True)
             dxg, accg, rowsg = ctx.frame_fetch(0, S)
@@ -493,7 +508,8 @@ def main():
                             note="host buffers -> pinned slab (8 host threads) -> PCIe -> run -> dx/accept back; pipelined = copy "
                                  "stream + second device input set (ingvio_frame_stage_async); auxiliary, `value` is device-resident")
         updates = B * world * args.steps
-        step_desc = "propagate(k=10)+clone+MSCKF update+marginalise" + ("+GNSS update (8 sats, per-row chi2 gates)" if gnss is not None else "")
+        step_desc = ("propagate(k=10)+clone+MSCKF update" + ("+landmark update (%d in-state landmarks, per-landmark chi2 gates)" % n_lm_real if real_lm else "")
+                     + "+marginalise" + ("+GNSS update (8 sats, per-row chi2 gates)" if gnss is not None else ""))
         # executed FP64 rate of the whole step, where counters exist for every kernel that ran
         step_exec = None
         if counters is not None:
@@ -513,6 +529,8 @@ def main():
                                  "%d independent filters per GPU; step = %s" % (args.config - 1, F, C, N, B, step_desc),
                         baseline_config=args.config, filters_per_gpu=B, feats=F, clones=C, state_dim=N, imu_steps=synth.IMU_PER_FRAME,
                         gnss_rows_used_per_filter=None if gn_used is None else float(np.mean(gn_used)),
+                        landmarks=args.landmarks if n_lm else None, landmarks_in_state=n_lm_real if real_lm else 0,
+                        landmark_rows_per_filter=None if lm_rows is None else float(np.mean(lm_rows)),
                         parallelism="independent filters, %d rank(s), no data-path collective" % world),
             ms_per_update=elapsed / args.steps * 1e3 / B, per_rank_ms_per_step=per_rank_ms, accepted_per_filter=F_used, results_finite=ok,
             algorithmic_flops_per_update=total_flops, whole_step_executed=step_exec,

@@ -605,7 +605,7 @@ class Context:
         self._chk(self.L.ingvio_profile_reset(self.h))
 
     def profile_get(self):
-        cap = 16
+        cap = 32
         names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); calls = (C.c_int * cap)()
         k = self.L.ingvio_profile_get(self.h, names, ms, calls, cap)
         return {names[i].decode(): (ms[i], calls[i]) for i in range(k)}

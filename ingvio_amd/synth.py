@@ -164,7 +164,7 @@ class Filter:
     Type::idx()/size() table (State.cpp:62-88, StateManager.cpp:155-231,253-296) and the window of
     clones.  Covariance arithmetic goes to ``cov`` (engine), nominal propagation to ``transition``."""
 
-    def __init__(self, cov_factory, transition, t0=0.0, n_gnss=0, n_landmarks=0, rng=None):
+    def __init__(self, cov_factory, transition, t0=0.0, n_gnss=0, n_landmarks=0, rng=None, lm_sigma=1.0):
         pr = PARAMS
         self.transition = transition
         self.t = t0
@@ -195,7 +195,7 @@ class Filter:
                 self.gnss_idx[g] = self._append("gnss%d" % g, np.array([[var]]))
             self.idx_yof = self._append("yof", np.array([[pr["init_cov_yof"] ** 2]]))
         for i in range(n_landmarks):      # addAnchoredLandmarkInState (StateManager.cpp:298-314), padding
-            self._append("lm%d" % i, np.eye(3))
+            self._append("lm%d" % i, lm_sigma ** 2 * np.eye(3))
         self.clones = []                  # dicts: name, t, R_c2w, p_c (estimated)
 
     # -- index bookkeeping ---------------------------------------------------------------
@@ -335,13 +335,13 @@ def frame_from_filter(flt, pf, uv, obs_mask=None, anchor=None, dof=None, stereo=
 
 
 def build_case(cov_factory, transition, seed=0, F=150, C=11, n_gnss=6, n_landmarks=52, stereo=True,
-               outlier_every=20, table=None):
+               outlier_every=20, table=None, lm_sigma=1.0):
     """Config-2 style case.  Runs C-1 propagate+clone cycles to create a realistic prior, then
     prepares the measured frame: k IMU steps, clone #C, F features seen by all C clones, marginalise
     the oldest clone afterwards.  Returns (flt, step, frame, info) with the covariance engine inside
     ``flt.cov`` holding the PRIOR (N = 21 + n_gnss + 3*n_landmarks + 6*(C-1))."""
     rng = np.random.default_rng(0x1A6F10 + seed)
-    flt = Filter(cov_factory, transition, t0=0.1 * seed, n_gnss=n_gnss, n_landmarks=n_landmarks)
+    flt = Filter(cov_factory, transition, t0=0.1 * seed, n_gnss=n_gnss, n_landmarks=n_landmarks, lm_sigma=lm_sigma)
     for _ in range(C - 1):
         flt.propagate_cov(flt.imu_steps(rng))
         flt.clone()
@@ -366,6 +366,32 @@ def build_case(cov_factory, transition, seed=0, F=150, C=11, n_gnss=6, n_landmar
     info = dict(outlier=outlier, N_prior=flt.cov.n, N_update=flt.cov.n + 6, new_idx=new_idx,
                 marg_idx=step["marg_idx"])
     return flt, step, frame, info
+
+
+def make_landmarks(rng, flt, frame, n_lm, outlier_every=13, noise=None, untracked=()):
+    """In-state SLAM landmarks seen in the CURRENT frame (LandmarkUpdate::updateLandmarkStereo, LandmarkUpdate.cpp:32-149): the
+    filter's `lm<i>` blocks become landmarks anchored at clones of the window (never the oldest one, which the frame
+    marginalises), placed in view of the current camera, observed with `noise` (every `outlier_every`-th grossly off).
+    `frame`: the MSCKF frame dict of the same step (its clone_idx are the anchors' state indices).  Returns the dict
+    Context.landmark_stage takes."""
+    noise = PARAMS["visual_noise"] if noise is None else noise
+    Rlr, tlr = t_cl2cr()
+    R_c2w, p_c = flt.R @ R_CL2I, flt.p + flt.R @ T_CL2I
+    C = len(frame["clone_idx"])
+    pf, uv = np.zeros((n_lm, 3)), np.zeros((n_lm, 4))
+    for l in range(n_lm):
+        q = np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1.0, 1.0), rng.uniform(3.0, 9.0)])
+        pf[l] = R_c2w @ q + p_c
+        qr = Rlr @ q + tlr
+        uv[l] = [q[0] / q[2], q[1] / q[2], qr[0] / qr[2], qr[1] / qr[2]]
+        uv[l] += noise * rng.standard_normal(4) * (30.0 if outlier_every and l % outlier_every == outlier_every - 1 else 1.0)
+    tracked = np.ones(n_lm, dtype=np.uint8)
+    for l in untracked:
+        tracked[l] = 0
+    return dict(R_i2w=flt.R.copy(), p_i2w=flt.p.copy(), R_cl2i=R_CL2I.copy(), p_c2i=T_CL2I.copy(), idx_epose=0, idx_ext=15,
+                lm_idx=np.array([flt.idx_of("lm%d" % l) for l in range(n_lm)], dtype=np.int32),
+                anchor_idx=np.array([int(frame["clone_idx"][1 + l % (C - 1)]) for l in range(n_lm)], dtype=np.int32),
+                pf=pf, uv=uv, tracked=tracked)
 
 
 def make_gnss(rng, flt, n_sat=8, outliers=(5,)):

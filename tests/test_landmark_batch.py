@@ -142,3 +142,47 @@ def test_ekf_update_rows_beyond_lds(m, r_kind):
     assert np.linalg.norm(dx[:n] - dxw) < 1e-9 * np.linalg.norm(dxw)
     assert np.array_equal(ctx.cov_get(0), 2 * P0)                       # the neighbour filter is untouched
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_frame_with_in_state_landmarks_vs_oracle():
+    """The frame path carrying REAL in-state landmarks: N = 249 with 52 landmarks that receive rows.  Device:
+    ingvio_frame_run = propagate + clone + MSCKF update, then the batched landmark update, then the marginalisation
+    (IngvioFilter.cpp:296-322 order; nominal values fixed over the step).  Oracle: the same sequence on orc.Cov."""
+    from ingvio_amd import capi, host, synth
+    nb, L, noise = 4, 52, synth.PARAMS["visual_noise"]
+    ctx = capi.Context(batch=nb, n_max=256, c_max=11, f_max=150, m_max=64)
+    cases = []
+    for b in range(nb):
+        flt, step, frame, info = synth.build_case(lambda P, b=b: capi.DeviceCov(ctx, b, P), host.imu_transition, seed=500 + b, lm_sigma=0.05)
+        lm = synth.make_landmarks(np.random.default_rng(40 + b), flt, frame, L, untracked=(3,) if b == 2 else ())
+        cases.append((flt, step, frame, info, lm))
+    priors = [ctx.cov_get(b) for b in range(nb)]
+    Rlr, tlr = synth.t_cl2cr()
+    ctx.snapshot()
+    ctx.frame_stage(0, [c[1] for c in cases], [c[2] for c in cases], cases[0][1]["sigma"], 1, 0.2, 0.2)
+    ctx.landmark_stage(0, [c[4] for c in cases], True, noise, CHI2_4, Rlr, tlr, in_frame=True)
+    ctx.frame_run(restore_prior=True)
+    dxv, acc, rows = ctx.frame_fetch()
+    dxl, lrows, lacc, lgam, st = ctx.landmark_fetch()
+    assert not st.any()
+    for b in range(nb):
+        flt, step, frame, info, lm = cases[b]
+        oc = orc.Cov(priors[b], ld=256)
+        for Phi, G, dt in zip(step["Phi"], step["G"], step["dt"]):
+            oc.propagate(Phi, G, dt, step["sigma"], step["enable_gnss"], step["gnss_idx"], 0.2, 0.2)
+        oc.augment(step["R_i2w"])
+        dxo, acco, _ = oc.msckf_update(frame, max_accept=0, compress_rule=1)[:3]
+        assert np.array_equal(acc[b, :150], acco)
+        Pw, dxw, accw, gamw, mw = oracle_update(oc.P, lm, True, noise, Rlr, tlr)
+        assert np.array_equal(lacc[b, :L], accw) and lrows[b] == mw and mw >= 2 * L
+        oc2 = orc.Cov(Pw, ld=256)
+        oc2.marginalize(step["marg_idx"], 6)
+        P = ctx.cov_get(b)
+        assert ctx.n(b) == 243 and np.linalg.norm(P - oc2.P) < 1e-9 * np.linalg.norm(oc2.P) and np.array_equal(P, P.T)
+        assert np.linalg.norm(dxl[b, :249] - dxw) < 1e-8 * np.linalg.norm(dxw)
+    P1 = [ctx.cov_get(b) for b in range(nb)]
+    ctx.frame_run(restore_prior=True)                                     # repeatable from the restored prior
+    for b in range(nb):
+        assert np.array_equal(ctx.cov_get(b), P1[b])
+    ctx.close()
