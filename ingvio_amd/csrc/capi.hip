@@ -430,6 +430,7 @@ int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int s
     memset(&L, 0, sizeof L);
     L.stereo = stereo; L.cv = view(c); L.fv = fview(c); L.op = op; L.b0 = b0; L.nb = nb;
     L.fmax_used = fmax_used > 0 ? fmax_used : 1;
+    L.ncol_cap = 6 * c->d.c_max;
     L.gamma = c->d_gamma; L.accept = c->d_accept; L.used = c->d_used; L.rec = c->d_rec;
     L.Apart = c->d_Rpart + (size_t)b0 * c->G * c->rstride; L.chunk_used = c->d_chunk_used + (size_t)b0 * c->G;
     L.G = c->G; L.rstride = c->rstride; L.noise = c->d_noise + b0;
@@ -439,7 +440,7 @@ int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int s
     L.big_wk = c->d_big_wk ? c->d_big_wk + (size_t)b0 * bigwin_wk_doubles() : nullptr;
     { ProfScope p(c, PF_GATE2); L.stage = 0; if (launch_factored(L, c->st)) return INGVIO_E_UNSUPPORTED; }
     { ProfScope p(c, PF_GRAM); L.stage = 1; launch_factored(L, c->st); }
-    L.mstride = c->ystride; L.n_cap = c->d.n_max; L.ncol_cap = 6 * c->d.c_max;
+    L.mstride = c->ystride; L.n_cap = c->d.n_max;
     L.marg_idx = marg_idx; L.marg_size = marg_size; L.pc_base = c->d_pcbase + b0;
     { ProfScope p(c, PF_INFO); L.stage = 2; launch_factored(L, c->st); }
     { ProfScope p(c, PF_APPLY); L.stage = 3; launch_factored(L, c->st); }

@@ -107,7 +107,7 @@ __device__ __forceinline__ void wave_sync()      // LDS hand-over between the la
 // WREC: also write the per-feature record for a gram kernel that reads it (large-window path); the 6 / 11 / 16-clone gram kernel
 // recomputes the few per-observation quantities it needs from the frame inputs instead (k_feat_gram2), so the small-window
 // gate neither builds nor stores a record.
-template <int CMAX, bool STEREO, int FPW, bool WREC = true>
+template <int CMAX, bool STEREO, int FPW, bool WREC = true, int RSTRIDE = REC_HDR + REC_OBS * CMAX>      // RSTRIDE: doubles between the records of two features
 __device__ __forceinline__ void gate3_body(
     CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out,
     int* __restrict__ accept_out, double* __restrict__ rec_out)
@@ -209,7 +209,7 @@ __device__ __forceinline__ void gate3_body(
         double* const rec = sh.recbuf;            // global stores wait in vmcnt with the loads (gfx9): the record is staged
         if (sl == 0) {
             sh.f.nobs = fok ? nobs : 0;
-            if (jok && !fok) { gamma_out[oidx] = __builtin_nan(""); accept_out[oidx] = 0; if (WREC) rec_out[oidx * rec_size(CMAX)] = 0.0; }
+            if (jok && !fok) { gamma_out[oidx] = __builtin_nan(""); accept_out[oidx] = 0; if (WREC) rec_out[oidx * RSTRIDE] = 0.0; }
         }
         wave_sync();
         double* const Nh = sh.nh;
@@ -353,7 +353,7 @@ __device__ __forceinline__ void gate3_body(
     if (nobs == 0) return;                            // nothing to gate (reported by the front)
     const size_t oidx = (size_t)b * fv.fmax + j;
     double* const rec = sh.recbuf;
-    double* const rec_g = rec_out + oidx * rec_size(CMAX);
+    double* const rec_g = rec_out + oidx * RSTRIDE;
     const double px = rec[2], py = rec[3], pz = rec[4];
     const int oa = sh.oa;
     {

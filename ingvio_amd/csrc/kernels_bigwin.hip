@@ -19,12 +19,23 @@
 #define BIG_CMAX 36
 #define BIG_NC (6 * BIG_CMAX)
 
-template <bool STEREO>
+// Window classes of the gate: its LDS (the packed triangle of K: 3C (3C + 1) / 2 doubles) and its tile count are set by the class,
+// so a 30-clone window runs the 32 class (48 KB per wave, 3 waves per CU, 28 lower tiles) instead of the 36 class (60 KB, 2
+// waves, 36 tiles).  The record keeps the 36-clone stride that k_feat_gram_big reads.
+template <bool STEREO, int CM>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_feat_gate3_big(
     CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out,
     int* __restrict__ accept_out, double* __restrict__ rec_out)
 {
-    gate3_body<BIG_CMAX, STEREO, 1>(cv, fv, op, b0, nb, fmax_used, gamma_out, accept_out, rec_out);
+    gate3_body<CM, STEREO, 1, true, REC_HDR + REC_OBS * BIG_CMAX>(cv, fv, op, b0, nb, fmax_used, gamma_out, accept_out, rec_out);
+}
+
+template <bool STEREO, int CM>
+static void launch_gate_big(const FactoredLaunch& L, hipStream_t st)
+{
+    const int nb8 = (L.nb + 7) / 8 * 8;
+    hipLaunchKernelGGL((k_feat_gate3_big<STEREO, CM>), dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st,
+                       L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -894,13 +905,10 @@ int launch_bigwin(const FactoredLaunch& L, hipStream_t st)
 {
     if (L.fv.cmax > BIG_CMAX) return -1;
     if (L.stage == 0) {
-        const int nb8 = (L.nb + 7) / 8 * 8;
-        if (L.stereo)
-            hipLaunchKernelGGL(k_feat_gate3_big<true>, dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st,
-                               L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
-        else
-            hipLaunchKernelGGL(k_feat_gate3_big<false>, dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st,
-                               L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
+        const int cm = L.ncol_cap > 0 ? L.ncol_cap / 6 : BIG_CMAX;                 // the context's c_max picks the class
+        if (cm <= 24) { if (L.stereo) launch_gate_big<true, 24>(L, st); else launch_gate_big<false, 24>(L, st); }
+        else if (cm <= 32) { if (L.stereo) launch_gate_big<true, 32>(L, st); else launch_gate_big<false, 32>(L, st); }
+        else { if (L.stereo) launch_gate_big<true, BIG_CMAX>(L, st); else launch_gate_big<false, BIG_CMAX>(L, st); }
         return 0;
     }
     if (L.stage == 1) {
