@@ -190,21 +190,34 @@ def hbm_traffic_bytes(c):
                 total=2.0 * 1024.0 * c["FETCH_SIZE"] + 1024.0 * c["WRITE_SIZE"])
 
 
-BIG_NAMES = {"k_feat_gate3": "k_feat_gate3_big", "k_feat_gram2": "k_feat_gram_big", "k_info_update": "k_info_update_big",
-             "k_info_apply": "k_info_apply_big"}
-# the library's profile slots are named after the stage; the kernel rocprofv3 sees for the K8/K9 stage is k_info_solve (windows up
-# to 11 clones) or k_info_update (12..16)
-ALIASES = {"k_info_update": ("k_info_solve", "k_info_update"), "restore": ("k_restore_strips", "k_restore")}
+# The library's profile slots are named after the STAGE; rocprofv3 sees kernels.  Stage -> candidates, each candidate a tuple of
+# kernels whose counters are added up (x their launches per step): the first candidate with counters for all its kernels wins.
+STAGE_KERNELS = {
+    "k_info_update": (("k_info_solve",), ("k_info_update",)),            # windows up to 11 clones / 12..16
+    "restore": (("k_restore_strips",), ("k_restore",)),
+    "k_lm_gemm": (("k_gemm",),),
+    "k_lm_chol": (("k_chol_first", "k_chol_step", "k_lm_finish"),),
+}
+STAGE_KERNELS_BIG = {                                                      # windows of 17..36 clones (kernels_bigwin.hip)
+    "k_feat_gate3": (("k_feat_gate3_big",),), "k_feat_gram2": (("k_feat_gram_big",),),
+    "k_info_update": (("k_big_prep", "k_chol_first", "k_chol_step", "k_gemm", "k_copy_rows"), ("k_info_update_big",)),
+    "k_info_apply": (("k_apply_T", "k_apply_sym"), ("k_info_apply_big",)),
+}
 
 
 def counters_for(counters, name, big):
     if counters is None:
         return None
-    if big and name in BIG_NAMES:
-        return counters.get(BIG_NAMES[name])
-    for cand in ALIASES.get(name, (name,)):
-        if cand in counters:
-            return counters[cand]
+    table = STAGE_KERNELS_BIG if big and name in STAGE_KERNELS_BIG else STAGE_KERNELS
+    for cand in table.get(name, ((name,),)):
+        if all(k in counters for k in cand):
+            out = {}
+            for k in cand:
+                mult = counters[k].get("_launches_per_step", 1)
+                for c, v in counters[k].items():
+                    if not c.startswith("_"):
+                        out[c] = out.get(c, 0.0) + v * mult
+            return out
     return None
 
 
@@ -377,7 +390,11 @@ def main():
     elapsed = grp.max_over_ranks(elapsed_local)
     per_rank_ms = [t / args.steps * 1e3 for t in grp.gather_scalars(elapsed_local)]
 
+    if gnss is not None:                           # the GNSS update reuses the row-count slot: fetch the frame's results in between
+        ctx.frame_run(restore_prior=True)
     dx, acc, rows = ctx.frame_fetch()
+    if gnss is not None:
+        ctx.gnss_run()
     n_acc = acc[:, :F].sum(axis=1)
     ok = bool(np.isfinite(dx).all() and (rows == 6 * C).all())
     gn_used = None
@@ -396,7 +413,7 @@ def main():
         F_used = float(n_acc.mean())
         per_kernel, total_flops = algorithmic_flops(F_used, F, C, N, synth.IMU_PER_FRAME)
         bytes_k = algorithmic_bytes(N, synth.IMU_PER_FRAME, F, C)
-        wkey = "c%d_B%d_F%d_C%d_N%d" % (args.config, B, F, C, N)
+        wkey = "c%d_B%d_F%d_C%d_N%d" % (args.config, B, F, C, N) + ("_lmreal" if real_lm else "")
         counters, csrc = load_counters(args.counters, wkey)
         kernels = {}
         for name, (ms, calls) in prof.items():

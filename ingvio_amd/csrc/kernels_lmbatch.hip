@@ -102,14 +102,14 @@ __device__ __forceinline__ void lm_rows(const double* pose, const double* pf, co
     }
 }
 
-#define LMB_NT 256
+#define LMB_NT 1024
 __global__ __launch_bounds__(LMB_NT) void k_lm_build(CovView cv, LmView lv, LmOpts op, int b0, double* __restrict__ Hd_all, size_t hstride,
                                                       int n_ld, int m_cap, double* __restrict__ X_all, size_t xstride, int ldx, int res_row,
                                                       double* __restrict__ gamma_out, int* __restrict__ accept_out, int* __restrict__ m_out,
                                                       double* __restrict__ dx_all)
 {
     __shared__ double sH[LM_MAX][100];                                   // rows of every landmark: H_j 96 + res 4
-    __shared__ int sCol[4][24];
+    __shared__ int sCol[LMB_NT / 64][24];
     __shared__ int sAcc[LM_MAX], sOff[LM_MAX + 1];
     const int bl = blockIdx.x, b = b0 + bl, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int L = min(lv.n_lm[b], LM_MAX), n = cv.n[b], ld = cv.ldp;

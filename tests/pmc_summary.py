@@ -20,8 +20,11 @@ ap.add_argument("--last", type=int, default=0)
 ap.add_argument("--source", default="")
 ap.add_argument("--out", required=True)
 ap.add_argument("--csv", default=None)
+ap.add_argument("--per-step", default="", help="kernel=launches per bench step, comma separated: for these the average runs over the "
+                "last (--last x launches) dispatches and the count is stored as _launches_per_step (stages made of several launches)")
 ap.add_argument("dirs", nargs="+")
 a = ap.parse_args()
+per_step = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.per_step.split(",") if "=" in kv}
 
 
 def norm(k):
@@ -43,12 +46,13 @@ for d in a.dirs:
     for (k, c), byd in per.items():
         ids = sorted(byd)
         if a.last > 0:
-            ids = ids[-a.last:]
+            ids = ids[-a.last * per_step.get(k, 1):]
         table[k][c].append(sum(byd[i] for i in ids) / len(ids))
         launches[k] = len(ids)
 kernels = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in table.items()}
 for k in kernels:
     kernels[k]["_launches_averaged"] = launches[k]
+    kernels[k]["_launches_per_step"] = per_step.get(k, 1)
 J = {"workloads": {}}
 if os.path.exists(a.out):
     try:
