@@ -515,8 +515,9 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     // landmark stack, LandmarkUpdate.cpp:32-149) is bounded by the state dimension, NOT by the row capacity m_max
     c->nc_cap = c->ldp > mcap ? c->ldp : mcap;
     c->G = (desc->c_max > 16 ? 256 : 512) / B;                              // ~2 resident gram workgroups per CU (large windows: 1,
-    if (c->G > 16) c->G = 16; if (c->G < 1) c->G = 1;                       // and every chunk costs a 0.35 MB partial + sparse sums)
-    if (const char* e = getenv("INGVIO_GRAM_CHUNKS")) { const int g = atoi(e); if (g >= 1 && g <= 16) c->G = g; }
+    { const int gmax = desc->c_max > 16 ? 32 : 16; if (c->G > gmax) c->G = gmax; }   // and every chunk costs a 0.35 MB partial + sparse sums)
+    if (c->G < 1) c->G = 1;
+    if (const char* e = getenv("INGVIO_GRAM_CHUNKS")) { const int g = atoi(e); if (g >= 1 && g <= 64) c->G = g; }
     c->cls = msckf_cmax_class(desc->c_max);
     const int ncm = 6 * desc->c_max;
     c->rstride = ncm * (ncm + 1);
