@@ -85,7 +85,7 @@ struct ingvio_ctx {
     // does not fit in LDS.  Rows live in Hd [m_cap][n_ld] per filter, the sweep in X / Y [ldx][m_cap].
     struct DenseWs {
         double *Hd = nullptr, *X = nullptr, *Y = nullptr, *Tb = nullptr, *noise = nullptr;      // noise: one filter's R (ingvio_ekf_update)
-        int *m = nullptr;
+        int *m = nullptr, *cidx = nullptr;
         int m_cap = 0, n_ld = 0, n32 = 0, ldx = 0;
         size_t hstride = 0, xstride = 0, tstride = 0;
     } dw;
@@ -575,7 +575,7 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
                      c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk, c->d_tri_ok, c->d_hnew, c->d_multi, c->d_noiseB,
                      c->gn.H, c->gn.res, c->gn.noise, c->gn.gamma, c->gn.chi2, c->gn.m, c->gn.nc, c->gn.colmap, c->gn.keep,
                      c->gn.feph, c->gn.fobs, c->gn.frcv, c->gn.front,
-                     c->dw.Hd, c->dw.X, c->dw.Y, c->dw.Tb, c->dw.noise, c->dw.m, c->lm.pose, c->lm.pf, c->lm.uv, c->lm.gamma, c->lm.idx, c->lm.n_lm,
+                     c->dw.Hd, c->dw.X, c->dw.Y, c->dw.Tb, c->dw.noise, c->dw.m, c->dw.cidx, c->lm.pose, c->lm.pf, c->lm.uv, c->lm.gamma, c->lm.idx, c->lm.n_lm,
                      c->lm.lm_idx, c->lm.anchor_idx, c->lm.tracked, c->lm.accept, c->lm.dx };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& sl : c->pin) { if (sl.p) hipHostFree(sl.p); if (sl.ev) hipEventDestroy(sl.ev); }
@@ -741,7 +741,7 @@ int ingvio_append_independent(ingvio_ctx* c, int b0, int nb, int size, const dou
 }
 
 static int dense_ws_alloc(ingvio_ctx* c, int m_need);
-static int run_dense_update(ingvio_ctx* c, int b0, int nb, double var, int r_kind, const double* d_noise, int nstride, double* d_dx);
+static int run_dense_update(ingvio_ctx* c, int b0, int nb, double var, int r_kind, const double* d_noise, int nstride, double* d_dx, bool products_done = false);
 #define DENSE_M_MAX 1024      // rows of one generic update through the dense-H route (S factorised out of HBM, kernels_chol.hip)
 
 // ingvio_ekf_update for row counts whose S does not fit in LDS (or beyond the context's m_max): the host scatters the columns
@@ -1400,23 +1400,25 @@ static int dense_ws_alloc(ingvio_ctx* c, int m_need)
     HIPCHK(c, hipStreamSynchronize(c->st));
     for (double** p : { &w.Hd, &w.X, &w.Y, &w.Tb, &w.noise }) { if (*p) hipFree(*p); *p = nullptr; }
     if (w.m) { hipFree(w.m); w.m = nullptr; }
+    if (w.cidx) { hipFree(w.cidx); w.cidx = nullptr; }
     const int B = c->d.batch;
     w.m_cap = m_cap; w.n32 = (c->d.n_max + 31) / 32 * 32; w.n_ld = w.n32; w.ldx = m_cap + w.n32 + 32;
-    w.hstride = (size_t)m_cap * w.n_ld; w.xstride = (size_t)w.ldx * m_cap; w.tstride = 2048 + (size_t)m_cap;
+    w.hstride = std::max((size_t)m_cap * w.n_ld, (size_t)LM_MAX * 100);      // also holds the landmark path's compact blocks
+    w.xstride = (size_t)w.ldx * m_cap; w.tstride = 2048 + (size_t)m_cap;
     int rc = dalloc(c, &w.Hd, (size_t)B * w.hstride) | dalloc(c, &w.X, (size_t)B * w.xstride) | dalloc(c, &w.Y, (size_t)B * w.xstride)
-           | dalloc(c, &w.Tb, (size_t)B * w.tstride) | dalloc(c, &w.m, (size_t)B) | dalloc(c, &w.noise, (size_t)m_cap * m_cap);
+           | dalloc(c, &w.Tb, (size_t)B * w.tstride) | dalloc(c, &w.m, (size_t)B) | dalloc(c, &w.noise, (size_t)m_cap * m_cap) | dalloc(c, &w.cidx, (size_t)B * LM_MAX * 4);
     return rc ? INGVIO_E_HIP : 0;
 }
 
 // noise: r_kind < 0 -> scalar variance `var` on the whole diagonal (the GEMM's epilogue); else d_noise (stride nstride) through k_add_noise
-static int run_dense_update(ingvio_ctx* c, int b0, int nb, double var, int r_kind, const double* d_noise, int nstride, double* d_dx)
+static int run_dense_update(ingvio_ctx* c, int b0, int nb, double var, int r_kind, const double* d_noise, int nstride, double* d_dx, bool products_done)
 {
     auto& w = c->dw;
     const int mc = w.m_cap, n_cap = c->d.n_max, B = c->d.batch;
     const size_t pp = (size_t)c->ldp * c->ldp;
     double *Hd = w.Hd + (size_t)b0 * w.hstride, *X = w.X + (size_t)b0 * w.xstride, *Y = w.Y + (size_t)b0 * w.xstride;
     const int* act = w.m + b0;
-    {
+    if (!products_done) {
         ProfScope p(c, PF_LM_GEMM);
         GemmArgs g = {};
         // P H^T -> carried rows mc .. of X
@@ -1468,9 +1470,10 @@ static int landmark_update_launch(ingvio_ctx* c, int b0, int nb)
         L.Hd = w.Hd + (size_t)b0 * w.hstride; L.hstride = w.hstride; L.n_ld = w.n_ld; L.m_cap = w.m_cap;
         L.X = w.X + (size_t)b0 * w.xstride; L.xstride = w.xstride; L.ldx = w.ldx; L.res_row = w.m_cap + w.n32;
         L.gamma = s.gamma + (size_t)b0 * LM_MAX; L.accept = s.accept + (size_t)b0 * LM_MAX; L.m_out = w.m + b0; L.dx = s.dx;
+        L.cidx = w.cidx + (size_t)b0 * LM_MAX * 4; L.n_rows = w.n32;
         launch_lm_build(L, c->st);
     }
-    return run_dense_update(c, b0, nb, s.op.var, -1, nullptr, 0, s.dx);
+    return run_dense_update(c, b0, nb, s.op.var, -1, nullptr, 0, s.dx, true);
 }
 
 int ingvio_landmark_stage(ingvio_ctx* c, int b0, int nb, const ingvio_landmark_frame* fr, const ingvio_landmark_opts* o)

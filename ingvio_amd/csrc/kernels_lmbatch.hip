@@ -6,10 +6,11 @@
 // a chi^2 gate per landmark on the prior (dof = rows, Update.cpp:81-102), the accepted rows stacked, one ekfUpdate.
 //
 //   k_lm_build    one workgroup per filter, one wave per landmark at a time: rows, S_j = H_j P H_j^T + s^2 I (4x4, the 24
-//                 involved columns gathered from the resident covariance), gamma_j, the gate; then the accepted rows are
-//                 written COMPACTED into a dense row-major H [m_cap][n_ld] addressed by STATE column (zero elsewhere) and the
-//                 residual into the carried row of the Cholesky workspace.  Dense columns make the two products plain GEMMs
-//                 (P H^T and H (P H^T)) with no gather; with 52 landmarks the involved columns are 237 of 249 anyway.
+//                 involved columns gathered from the resident covariance), gamma_j, the gate; then the accepted landmarks'
+//                 blocks are written COMPACTED (24 columns + 4 column bases each) and the residual into the carried row of the
+//                 Cholesky workspace.
+//   k_lm_products P H^T and H P H^T + s^2 I from the compact blocks (24-sparse rows: a dense GEMM would spend 90 % of its
+//                 arithmetic on zeros), written straight into the sweep's working matrix.
 //   k_lm_finish   dx = Y z from the carried rows of the sweep (Y = P H^T L^-T, z = L^-1 res).
 //   k_add_noise   diagonal / dense measurement noise added to S: ingvio_ekf_update hands rows over in the same dense layout when
 //                 their S does not fit in LDS (the host scatters the columns).
@@ -106,7 +107,7 @@ __device__ __forceinline__ void lm_rows(const double* pose, const double* pf, co
 __global__ __launch_bounds__(LMB_NT) void k_lm_build(CovView cv, LmView lv, LmOpts op, int b0, double* __restrict__ Hd_all, size_t hstride,
                                                       int n_ld, int m_cap, double* __restrict__ X_all, size_t xstride, int ldx, int res_row,
                                                       double* __restrict__ gamma_out, int* __restrict__ accept_out, int* __restrict__ m_out,
-                                                      double* __restrict__ dx_all)
+                                                      double* __restrict__ dx_all, int* __restrict__ cidx_all)
 {
     __shared__ double sH[LM_MAX][100];                                   // rows of every landmark: H_j 96 + res 4
     __shared__ int sCol[LMB_NT / 64][24];
@@ -195,27 +196,94 @@ __global__ __launch_bounds__(LMB_NT) void k_lm_build(CovView cv, LmView lv, LmOp
         for (int r = tid; r < ld; r += LMB_NT) dx[r] = 0.0;
         return;
     }
-    // dense rows by state column; one wave per row
-    for (int R = wave; R < m_cap; R += LMB_NT / 64) {
-        int l = -1, r = 0;
-        if (R < m) {
-            for (int q = 0; q < L; ++q) if (sAcc[q] && R >= sOff[q] && R < sOff[q] + per) { l = q; r = R - sOff[q]; }
-        }
-        double* row = Hd + (size_t)R * n_ld;
-        int il = 0, ia = 0;
-        if (l >= 0) { const size_t o = (size_t)b * lv.lmax + l; il = lv.lm_idx[o]; ia = lv.anchor_idx[o]; }
-        for (int k = lane; k < n_ld; k += 64) {
-            double v = 0.0;
-            if (l >= 0) {
-                const double* h = &sH[l][24 * r];
-                if (k >= ie && k < ie + 9) v += h[k - ie];
-                if (k >= ix && k < ix + 6) v += h[9 + k - ix];
-                if (k >= ia && k < ia + 6) v += h[15 + k - ia];
-                if (k >= il && k < il + 3) v += h[21 + k - il];
+    // the accepted landmarks' blocks, compacted: [96 row entries | 4 residuals] and the four column bases; residuals into the
+    // carried row of the sweep's working matrix
+    int* cidx = cidx_all + (size_t)bl * LM_MAX * 4;
+    for (int l = wave; l < L; l += LMB_NT / 64) {
+        if (!sAcc[l]) continue;
+        const int a = sOff[l] / per;
+        const size_t o = (size_t)b * lv.lmax + l;
+        for (int e = lane; e < 100; e += 64) Hd[(size_t)a * 100 + e] = sH[l][e];
+        if (lane < 4) cidx[4 * a + lane] = lane == 0 ? ie : (lane == 1 ? ix : (lane == 2 ? lv.anchor_idx[o] : lv.lm_idx[o]));
+        if (lane < per) X[(size_t)res_row + (size_t)(sOff[l] + lane) * ldx] = sH[l][96 + lane];
+    }
+    for (int R = m + tid; R < m_cap; R += LMB_NT) X[(size_t)res_row + (size_t)R * ldx] = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// P H^T and S = H P H^T + s^2 I from the compact blocks.  A landmark's 4 rows share its 24 columns, so one pass over those 24
+// columns of P serves four columns of P H^T (a row-by-row gather would read 4x as much; the dense GEMM this replaces did 10x
+// the arithmetic on zeros).  grid = (groups of 4 landmarks covering m_cap columns, nb), 256 threads:
+//   phase A, thread = state row r:   y_R[r] = sum_c P[r, col_c] h_R[c]  for the group's (up to) 16 rows R  -> carried rows of X
+//   phase B, thread = stacked row R2: S[R2, R] = sum_c h_R2[c] y_R[col_R2,c]  (+ s^2 on the diagonal)       -> S block of X
+// Columns beyond the accepted rows are written as padding (s^2 on the diagonal: the sweep runs on whole 32-column panels).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lm_products(CovView cv, int b0, const double* __restrict__ Hc_all, size_t hstride,
+                                                     const int* __restrict__ cidx_all, const int* __restrict__ m_all, int per, double var,
+                                                     double* __restrict__ X_all, size_t xstride, int ldx, int m_cap, int n_rows)
+{
+    const int bl = blockIdx.y, b = b0 + bl, m = m_all[bl];
+    if (m == 0) return;
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int R0 = per * 4 * g, R1 = min(m_cap, R0 + per * 4);          // this workgroup's columns of X
+    if (R0 >= m_cap) return;
+    const int n = cv.n[b], ld = cv.ldp;
+    const double* P = cov_ptr(cv, b);
+    const double* Hc = Hc_all + (size_t)bl * hstride;
+    const int* cidx = cidx_all + (size_t)bl * LM_MAX * 4;
+    double* X = X_all + (size_t)bl * xstride;
+    double* Yc = X + m_cap;                                              // carried rows: P H^T
+    // ---- phase A
+    for (int r = tid; r < n_rows; r += 256) {
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int Ra = R0 + per * q4;                                // first row of landmark 4 g + q4
+            if (Ra >= R1) break;
+            if (Ra < m && r < n) {
+                const int a = 4 * g + q4;
+                const double* h = Hc + (size_t)a * 100;
+                const int c0 = cidx[4 * a], c1 = cidx[4 * a + 1], c2 = cidx[4 * a + 2], c3 = cidx[4 * a + 3];
+                double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
+#pragma unroll
+                for (int c = 0; c < 24; ++c) {
+                    const int col = c < 9 ? c0 + c : (c < 15 ? c1 + c - 9 : (c < 21 ? c2 + c - 15 : c3 + c - 21));
+                    const double p = P[(size_t)r + (size_t)col * ld];
+                    y0 += p * h[c]; y1 += p * h[24 + c]; y2 += p * h[48 + c]; y3 += p * h[72 + c];
+                }
+                Yc[(size_t)r + (size_t)Ra * ldx] = y0;
+                Yc[(size_t)r + (size_t)(Ra + 1) * ldx] = y1;
+                if (per == 4) { Yc[(size_t)r + (size_t)(Ra + 2) * ldx] = y2; Yc[(size_t)r + (size_t)(Ra + 3) * ldx] = y3; }
+            } else {
+                for (int q = 0; q < per; ++q) Yc[(size_t)r + (size_t)(Ra + q) * ldx] = 0.0;      // padding column / rows beyond the state
             }
-            row[k] = v;
         }
-        if (lane == 0) X[(size_t)res_row + (size_t)R * ldx] = l >= 0 ? sH[l][96 + r] : 0.0;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- phase B
+    for (int R2 = tid; R2 < m_cap; R2 += 256) {
+        double h2[24];
+        int k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+        const bool live = R2 < m;
+        if (live) {
+            const int a2 = R2 / per, q2 = R2 - per * a2;
+            const double* h = Hc + (size_t)a2 * 100 + 24 * q2;
+#pragma unroll
+            for (int c = 0; c < 24; ++c) h2[c] = h[c];
+            k0 = cidx[4 * a2]; k1 = cidx[4 * a2 + 1]; k2 = cidx[4 * a2 + 2]; k3 = cidx[4 * a2 + 3];
+        }
+        for (int R = R0; R < R1; ++R) {
+            double s = 0.0;
+            if (live && R < m) {
+                const double* y = Yc + (size_t)R * ldx;
+#pragma unroll
+                for (int c = 0; c < 24; ++c) {
+                    const int col = c < 9 ? k0 + c : (c < 15 ? k1 + c - 9 : (c < 21 ? k2 + c - 15 : k3 + c - 21));
+                    s += h2[c] * y[col];
+                }
+            }
+            if (R2 == R) s += var;
+            X[(size_t)R2 + (size_t)R * ldx] = s;
+        }
     }
 }
 
@@ -264,7 +332,10 @@ __global__ __launch_bounds__(256) void k_add_noise(double* __restrict__ X_all, s
 void launch_lm_build(const LmBuild& L, hipStream_t st)
 {
     hipLaunchKernelGGL(k_lm_build, dim3(L.nb), dim3(LMB_NT), 0, st, L.cv, L.lv, L.op, L.b0, L.Hd, L.hstride, L.n_ld, L.m_cap, L.X, L.xstride,
-                       L.ldx, L.res_row, L.gamma, L.accept, L.m_out, L.dx);
+                       L.ldx, L.res_row, L.gamma, L.accept, L.m_out, L.dx, L.cidx);
+    const int per4 = (L.op.stereo ? 4 : 2) * 4;
+    hipLaunchKernelGGL(k_lm_products, dim3((L.m_cap + per4 - 1) / per4, L.nb), dim3(256), 0, st, L.cv, L.b0, L.Hd, L.hstride, L.cidx, L.m_out, L.op.stereo ? 4 : 2, L.op.var,
+                       L.X, L.xstride, L.ldx, L.m_cap, L.n_rows);
 }
 
 void launch_lm_finish(CovView cv, int b0, int nb, const double* Y, size_t ystride, int ldy, int y_row0, int z_row, const int* m, double* dx,

@@ -27,7 +27,8 @@ struct LmOpts {
 struct LmBuild {
     CovView cv; LmView lv; LmOpts op;
     int b0, nb;
-    double* Hd; size_t hstride; int n_ld, m_cap;        // dense rows [m_cap][n_ld] per filter
+    double* Hd; size_t hstride; int n_ld, m_cap;        // compact blocks [LM_MAX][100] per filter (in the dense-row buffer of the generic route)
+    int* cidx; int n_rows;                              // [nb][LM_MAX][4] column bases; rows of P H^T to write (n32)
     double* X; size_t xstride; int ldx, res_row;        // the Cholesky working matrix: residual into row res_row
     double* gamma; int* accept; int* m_out;             // [nb][LM_MAX], [nb][LM_MAX], [nb]
     double* dx;
