@@ -1404,7 +1404,7 @@ static int dense_ws_alloc(ingvio_ctx* c, int m_need)
     const int B = c->d.batch;
     w.m_cap = m_cap; w.n32 = (c->d.n_max + 31) / 32 * 32; w.n_ld = w.n32; w.ldx = m_cap + w.n32 + 32;
     w.hstride = std::max((size_t)m_cap * w.n_ld, (size_t)LM_MAX * 100);      // also holds the landmark path's compact blocks
-    w.xstride = (size_t)w.ldx * m_cap; w.tstride = 2048 + (size_t)m_cap;
+    w.xstride = (size_t)w.ldx * m_cap; w.tstride = (size_t)(m_cap / 32) * 1024 + (size_t)m_cap;
     int rc = dalloc(c, &w.Hd, (size_t)B * w.hstride) | dalloc(c, &w.X, (size_t)B * w.xstride) | dalloc(c, &w.Y, (size_t)B * w.xstride)
            | dalloc(c, &w.Tb, (size_t)B * w.tstride) | dalloc(c, &w.m, (size_t)B) | dalloc(c, &w.noise, (size_t)m_cap * m_cap) | dalloc(c, &w.cidx, (size_t)B * LM_MAX * 4);
     return rc ? INGVIO_E_HIP : 0;
@@ -1440,7 +1440,7 @@ static int run_dense_update(ingvio_ctx* c, int b0, int nb, double var, int r_kin
     {
         ProfScope p(c, PF_LM_CHOL);
         CholArgs a = {};
-        a.W = X; a.Y = Y; a.xs = w.xstride; a.ld = w.ldx; a.Tb = w.Tb + (size_t)b0 * w.tstride; a.ts = w.tstride;
+        a.W = X; a.Y = Y; a.xs = w.xstride; a.ld = w.ldx; a.Tb = w.Tb + (size_t)b0 * w.tstride; a.ts = w.tstride; a.t_slots = mc / 32;
         a.rows = w.ldx; a.ncols = mc; a.status = c->d_status + b0; a.fail_bit = 4; a.active = act; a.batch = nb;
         launch_chol_sweep(a, c->st);
         launch_lm_finish(view(c), b0, nb, Y, w.xstride, w.ldx, mc, mc + w.n32, act, d_dx, c->st);

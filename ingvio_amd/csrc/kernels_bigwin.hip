@@ -498,7 +498,7 @@ struct BigWs {
     __host__ __device__ explicit BigWs(int n32_) : n32(n32_), ld1(2 * n32_), ld2(3 * n32_ + 32), ldab(n32_ + 32)
     {
         oAB = 0; oX1 = oAB + (size_t)ldab * n32; oY1 = oX1 + (size_t)ld1 * n32; oX2 = oY1 + (size_t)ld1 * n32;
-        oY2 = oX2 + (size_t)ld2 * n32; oT = oY2 + (size_t)ld2 * n32; total = oT + 2048 + n32;
+        oY2 = oX2 + (size_t)ld2 * n32; oT = oY2 + (size_t)ld2 * n32; total = oT + (size_t)(n32 / 32) * 1024 + n32;
     }
 };
 
@@ -594,7 +594,7 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
     const int* act = L.m_out;                                            // 0 = nothing accepted: every later launch skips the filter
     CholArgs c1 = {};
     c1.W = ws + w.oX1; c1.Y = ws + w.oY1; c1.xs = wss; c1.ld = w.ld1; c1.rows = 2 * n32; c1.ncols = n32;
-    c1.status = L.status + L.b0; c1.fail_bit = 4; c1.active = act; c1.batch = L.nb; c1.Tb = ws + w.oT; c1.ts = wss;
+    c1.status = L.status + L.b0; c1.fail_bit = 4; c1.active = act; c1.batch = L.nb; c1.Tb = ws + w.oT; c1.ts = wss; c1.t_slots = n32 / 32;
     launch_chol_sweep(c1, st);
     GemmArgs g = {};
     // [A; b^T] L -> X2 rows n32 ..

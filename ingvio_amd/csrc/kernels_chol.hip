@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_chol_first(CholArgs a)
     if (a.active && !a.active[batch]) return;
     double* W = a.W + (size_t)batch * a.xs;
     double* Y = a.Y + (size_t)batch * a.xs;
-    double* od = a.Tb + (size_t)batch * a.ts + 2048;
+    double* od = a.Tb + (size_t)batch * a.ts + (size_t)a.t_slots * 1024;
     for (int c = tid; c < a.ncols; c += 256) od[c] = W[(size_t)c + (size_t)c * a.ld];
     for (int e = tid; e < 1024; e += 256) {
         const int i = e & 31, j = e >> 5;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void k_chol_step(CholArgs a, int k)
     double* W = a.W + (size_t)batch * a.xs;
     double* Y = a.Y + (size_t)batch * a.xs;
     double* Tb = a.Tb + (size_t)batch * a.ts;
-    const double* Tk = Tb + (size_t)(k & 1) * 1024;
+    const double* Tk = Tb + (size_t)(k % a.t_slots) * 1024;
     const double* Wi = W + (size_t)32 * i + (size_t)(32 * k) * ld;
     const double* Wj = W + (size_t)32 * (j < 0 ? i : j) + (size_t)(32 * k) * ld;
     const bool diag = i == j;
@@ -371,12 +371,87 @@ __global__ __launch_bounds__(256) void k_chol_step(CholArgs a, int k)
     for (int e = tid; e < 1024; e += 256) { const int r = e & 31, c = e >> 5; sDI[32 + r][c] = r == c ? 1.0 : 0.0; }
     __syncthreads();
     if (wave != 0) return;
-    const double* od = Tb + 2048;
+    const double* od = Tb + (size_t)a.t_slots * 1024;
     const double floorv = a.clamp ? a.clamp_rel * od[32 * j + (lane & 31)] : 0.0;
     double d[32]; bool bad;
     factor32(sDI, sC, lane, floorv, d, bad);
-    store_factor(d, lane, Y + (size_t)32 * j + (size_t)(32 * j) * ld, ld, Tb + (size_t)((k + 1) & 1) * 1024);
+    store_factor(d, lane, Y + (size_t)32 * j + (size_t)(32 * j) * ld, ld, Tb + (size_t)((k + 1) % a.t_slots) * 1024);
     if (__any(bad && !a.clamp) && lane == 0 && a.status) atomicOr(&a.status[batch], a.fail_bit);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Carried rows after the factorisation (split sweep): one workgroup per 32-row block i >= ncols / 32 walks the panels itself,
+//     Y_i[:, k] = (W_i[:, k] - sum_{p<k} Y_i[:, p] L[k, p]^T) T_k,
+// its row block resident in LDS, L and the T_k of all panels read from L2.  The right-looking step kernel would re-read and
+// re-write the block's trailing part once per panel (10 MB per filter for a 224-column S with 288 carried rows; here 1.3 MB).
+// grid = (carried block rows, batch), 256 threads; needs a.t_slots >= ncols / 32 (every T_k kept).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_chol_carried(CholArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sRow[];          // [32][ncols + 4]: W_i, overwritten panel by panel with Y_i (stride = 4 mod 32: the A-operand reads spread over the banks)
+    __shared__ double sU[32][36];
+    __shared__ double sT[32][36];
+    const int batch = blockIdx.y;
+    if (a.active && !a.active[batch]) return;
+    const int ncb = a.ncols >> 5, ld = a.ld, lds = a.ncols + 4;
+    const int i = ncb + blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int ti = wave >> 1, tj = wave & 1;
+    const double* W = a.W + (size_t)batch * a.xs;
+    double* Y = a.Y + (size_t)batch * a.xs;
+    const double* Tb = a.Tb + (size_t)batch * a.ts;
+    for (int e = tid; e < 32 * a.ncols; e += 256) {
+        const int r = e & 31, c = e >> 5;
+        sRow[r * lds + c] = W[(size_t)(32 * i + r) + (size_t)c * ld];
+    }
+    __syncthreads();
+    double tn[4];                                                          // T of the next panel, in flight during this one
+#pragma unroll
+    for (int u = 0; u < 4; ++u) tn[u] = Tb[tid + 256 * u];
+    for (int k = 0; k < ncb; ++k) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int e = tid + 256 * u; sT[e >> 5][e & 31] = tn[u]; }
+        if (k + 1 < ncb) {
+            const double* Tn = Tb + (size_t)((k + 1) % a.t_slots) * 1024;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) tn[u] = Tn[tid + 256 * u];
+        }
+        // tile (ti, tj) of U: W_i[:, k] minus the contribution of the finished panels
+        double4_f acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = sRow[(16 * ti + kq + 4 * r) * lds + 32 * k + 16 * tj + l15];
+        const double* Lrow = Y + (size_t)(32 * k + 16 * tj + l15) + (size_t)kq * ld;      // L[32 k + 16 tj + l15][kq + ...]
+#pragma unroll 1
+        for (int p0 = 0; p0 < k; p0 += 4) {                              // four panels' operands (32 loads) in flight at once
+            double bf[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k4 = 0; k4 < 8; ++k4) bf[u][k4] = p0 + u < k ? Lrow[(size_t)(32 * (p0 + u) + 4 * k4) * ld] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (p0 + u < k) {
+#pragma unroll
+                    for (int k4 = 0; k4 < 8; ++k4)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-sRow[(16 * ti + l15) * lds + 32 * (p0 + u) + 4 * k4 + kq], bf[u][k4], acc, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sU[16 * ti + kq + 4 * r][16 * tj + l15] = acc[r];
+        __syncthreads();
+        double4_f y = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4)
+            y = __builtin_amdgcn_mfma_f64_16x16x4f64(sU[16 * ti + l15][4 * k4 + kq], sT[4 * k4 + kq][16 * tj + l15], y, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sRow[(16 * ti + kq + 4 * r) * lds + 32 * k + 16 * tj + l15] = y[r];
+        __syncthreads();
+    }
+    for (int e = tid; e < 32 * a.ncols; e += 256) {
+        const int r = e & 31, c = e >> 5;
+        Y[(size_t)(32 * i + r) + (size_t)c * ld] = sRow[r * lds + c];
+    }
 }
 
 }  // namespace
@@ -412,14 +487,28 @@ void launch_gram(const double* H, int ldh, const double* rv, int m, int n, doubl
     hipLaunchKernelGGL(k_gram_tn, dim3(nb * (nb + 1) / 2, ksplit), dim3(256), 0, st, H, ldh, rv, m, n, part, pstride, n_ld, ksplit);
 }
 
-void launch_chol_sweep(const CholArgs& a, hipStream_t st)
+void launch_chol_sweep(const CholArgs& a0, hipStream_t st)
 {
-    const int nbr = a.rows / 32, ncb = a.ncols / 32;
+    CholArgs a = a0;
+    const int ncb = a.ncols / 32;
+    if (a.t_slots < 2) a.t_slots = 2;
+    // split sweep: factorise the square part with the step kernel, then every carried 32-row block in ONE launch
+    const size_t lds_row = sizeof(double) * 32 * (size_t)(a.ncols + 4);
+    const bool split = a.t_slots >= ncb && a.rows > a.ncols && lds_row <= 96 * 1024;
+    const int rows_all = a.rows;
+    if (split) a.rows = a.ncols;
+    const int nbr = a.rows / 32;
     hipLaunchKernelGGL(k_chol_first, dim3(a.batch), dim3(256), 0, st, a);
     for (int k = 0; k < ncb; ++k) {
         int blocks = 0;
         if (k + 1 >= ncb) blocks = nbr - (k + 1);
         else for (int j = k + 1; j < ncb; ++j) blocks += nbr - j;
         if (blocks > 0) hipLaunchKernelGGL(k_chol_step, dim3(blocks, a.batch), dim3(256), 0, st, a, k);
+    }
+    if (split) {
+        static size_t attr = 0;
+        if (lds_row > attr) { hipFuncSetAttribute((const void*)k_chol_carried, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row); attr = lds_row; }
+        a.rows = rows_all;
+        hipLaunchKernelGGL(k_chol_carried, dim3((rows_all - a.ncols) / 32, a.batch), dim3(256), lds_row, st, a);
     }
 }

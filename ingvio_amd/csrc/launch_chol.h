@@ -38,10 +38,12 @@ void launch_gram(const double* H, int ldh, const double* rv, int m, int n, doubl
 // Y[0:ncols] = L (upper part zero), rows ncols..rows are CARRIED: Y[r] = W[r] L^-T.  One launch per 32-column panel.
 //   clamp != 0: a pivot <= clamp_rel * (original diagonal) zeroes its column (semi-definite input: rank-deficient gram);
 //   clamp == 0: a non-positive pivot also zeroes the column and sets bit `fail_bit` in status[batch] (status may be null).
-//   Tb: scratch, 2048 + ncols doubles per batch element (stride ts): two T buffers and the original diagonal.
+//   Tb: scratch, t_slots * 1024 + ncols doubles per batch element (stride ts): the T = L_d^-T of the panels and the original
+//   diagonal.  t_slots = 2 (default): ping-pong, carried rows ride through the panel launches.  t_slots >= ncols / 32: every T is
+//   kept and the carried rows are done by ONE launch after the factorisation (one workgroup per 32 rows, resident in LDS).
 struct CholArgs {
     double* W; double* Y; size_t xs; int ld;
-    double* Tb; size_t ts;
+    double* Tb; size_t ts; int t_slots;
     int rows, ncols;
     int clamp; double clamp_rel;
     int* status; int fail_bit;
