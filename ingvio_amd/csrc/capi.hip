@@ -1449,7 +1449,7 @@ static int run_dense_update(ingvio_ctx* c, int b0, int nb, double var, int r_kin
         ProfScope p(c, PF_DOWNDATE);
         EkfLaunch E;
         memset(&E, 0, sizeof E);
-        E.cv = view(c); E.b0 = b0; E.nb = nb; E.Y = Y + mc; E.m = w.m + b0; E.status = c->d_status;
+        E.cv = view(c); E.b0 = b0; E.nb = nb; E.Y = Y + mc; E.m = w.m + b0; E.status = c->d_status; E.m_cap = mc;
         launch_downdate(E, n_cap, c->st, nullptr, w.ldx, w.xstride);
     }
     c->mut_seq++;
