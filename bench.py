@@ -195,12 +195,14 @@ def hbm_traffic_bytes(c):
 STAGE_KERNELS = {
     "k_info_update": (("k_info_solve",), ("k_info_update",)),            # windows up to 11 clones / 12..16
     "restore": (("k_restore_strips",), ("k_restore",)),
+    "k_lm_build": (("k_lm_build", "k_lm_products"),),
     "k_lm_gemm": (("k_gemm",),),
-    "k_lm_chol": (("k_chol_first", "k_chol_step", "k_lm_finish"),),
+    "k_lm_chol": (("k_chol_first", "k_chol_step", "k_chol_carried", "k_lm_finish"),),
+    "k_downdate": (("k_downdate64",), ("k_downdate",)),
 }
 STAGE_KERNELS_BIG = {                                                      # windows of 17..36 clones (kernels_bigwin.hip)
     "k_feat_gate3": (("k_feat_gate3_big",),), "k_feat_gram2": (("k_feat_gram_big",),),
-    "k_info_update": (("k_big_prep", "k_chol_first", "k_chol_step", "k_gemm", "k_copy_rows"), ("k_info_update_big",)),
+    "k_info_update": (("k_big_prep", "k_chol_first", "k_chol_step", "k_chol_carried", "k_gemm", "k_copy_rows"), ("k_info_update_big",)),
     "k_info_apply": (("k_apply_T", "k_apply_sym"), ("k_info_apply_big",)),
 }
 
