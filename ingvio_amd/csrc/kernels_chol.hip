@@ -494,7 +494,9 @@ void launch_chol_sweep(const CholArgs& a0, hipStream_t st)
     if (a.t_slots < 2) a.t_slots = 2;
     // split sweep: factorise the square part with the step kernel, then every carried 32-row block in ONE launch
     const size_t lds_row = sizeof(double) * 32 * (size_t)(a.ncols + 4);
-    const bool split = a.t_slots >= ncb && a.rows > a.ncols && lds_row <= 96 * 1024;
+    // (for a handful of matrices the carried rows ride through the panel launches instead: the resident kernel's walk over the
+    // panels is a latency chain that only pays off when there are enough workgroups to hide it)
+    const bool split = a.t_slots >= ncb && a.rows > a.ncols && lds_row <= 96 * 1024 && a.batch * ((a.rows - a.ncols) / 32) >= 256;
     const int rows_all = a.rows;
     if (split) a.rows = a.ncols;
     const int nbr = a.rows / 32;
