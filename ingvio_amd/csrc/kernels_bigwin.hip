@@ -13,6 +13,7 @@
 #include <algorithm>
 #include "launch_factored.h"
 #include "launch_chol.h"
+#include "block64.h"
 #include <stdlib.h>
 #include "gate_kernel.h"
 
@@ -894,6 +895,101 @@ __global__ __launch_bounds__(256) void k_apply_sym(CovView cv, int b0, const dou
     }
 }
 
+// ---- the same two launches on 64 x 64 blocks with the operand panels staged through LDS (block64.h): an element of Pc / M / T is
+//      read from L2 once per workgroup instead of once per 32 x 32 block and wave
+__global__ __launch_bounds__(256) void k_apply_T64(CovView cv, int b0, const double* __restrict__ Mall, int mstride, const double* __restrict__ Pcall,
+                                                   int ystride, const int* __restrict__ m_all, const int* __restrict__ marg_idx,
+                                                   const int* __restrict__ pc_base, double* __restrict__ Tall, size_t tstride, int ldt,
+                                                   double* __restrict__ dx_all)
+{
+    constexpr int MP = BIG_NC;
+    __shared__ Block64Lds sAB;
+    const int bl = blockIdx.z, bi = blockIdx.x, bj = blockIdx.y;
+    ApplyPtrs q;
+    if (!apply_setup(cv, b0, bl, Mall, mstride, Pcall, ystride, m_all, marg_idx, pc_base, q) || !q.upd) return;
+    if (64 * bi >= q.n) return;
+    const double* M = q.M;
+    const double* Pc = q.Pc;
+    const int n = q.n, ld = q.ld;
+    b64_d4 c[4];
+    block64_mma(sAB, (MP + 15) & ~15,
+                [&](int r, int k) { return k < MP ? Pc[(size_t)min(64 * bi + r, n - 1) + (size_t)k * ld] : 0.0; },
+                [&](int r, int k) { const int j = 64 * bj + r; return (k < MP && j < MP) ? M[(size_t)k * MP + j] : 0.0; }, true, c);
+    double* T = Tall + (size_t)bl * tstride;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4, wi = wave >> 1, wj = wave & 1;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {                                        // tile h of the quadrant: rows 16 (h >> 1), columns 16 (h & 1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 64 * bi + 32 * wi + 16 * (h >> 1) + kq + 4 * r, col = 64 * bj + 32 * wj + 16 * (h & 1) + l15;
+            if (row < n && col < MP) T[(size_t)row + (size_t)col * ldt] = c[h][r];
+        }
+    }
+    if (bj == 0 && tid < 64) {
+        const int r = 64 * bi + tid;
+        if (r < n) {
+            const double* tv = M + (size_t)MP * MP;
+            double d0 = 0.0, d1 = 0.0;
+            for (int k = 0; k < MP; k += 2) { d0 += Pc[(size_t)r + (size_t)k * ld] * tv[k]; d1 += Pc[(size_t)r + (size_t)(k + 1) * ld] * tv[k + 1]; }
+            dx_all[(size_t)(b0 + bl) * ld + r] = d0 + d1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_apply_sym64(CovView cv, int b0, const double* __restrict__ Mall, int mstride, const double* __restrict__ Pcall,
+                                                     int ystride, const int* __restrict__ m_all, const int* __restrict__ marg_idx, int msize,
+                                                     const int* __restrict__ pc_base, const double* __restrict__ Tall, size_t tstride, int ldt,
+                                                     int* __restrict__ status)
+{
+    constexpr int MP = BIG_NC;
+    __shared__ Block64Lds sAB;
+    __shared__ double sV[4][32][33];
+    const int bl = blockIdx.y;
+    int t = blockIdx.x, bi = 0;
+    while (t >= bi + 1) { t -= bi + 1; ++bi; }
+    const int bj = t;
+    ApplyPtrs q;
+    if (!apply_setup(cv, b0, bl, Mall, mstride, Pcall, ystride, m_all, marg_idx, pc_base, q)) return;
+    if (64 * bi >= q.n) return;
+    const int n = q.n, ld = q.ld, midx = q.midx, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, wi = wave >> 1, wj = wave & 1;
+    const bool fused = q.fused;
+    const bool quad_on = !(bi == bj && wj > wi);
+    b64_d4 c[4];
+    if (q.upd) {
+        const double* T = Tall + (size_t)bl * tstride;
+        const double* Pc = q.Pc;
+        block64_mma(sAB, (MP + 15) & ~15,
+                    [&](int r, int k) { return k < MP ? T[(size_t)min(64 * bi + r, n - 1) + (size_t)k * ldt] : 0.0; },
+                    [&](int r, int k) { return k < MP ? Pc[(size_t)min(64 * bj + r, n - 1) + (size_t)k * ld] : 0.0; }, quad_on, c);
+    } else {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) c[h] = b64_d4{ 0.0, 0.0, 0.0, 0.0 };
+    }
+    if (!quad_on) return;
+    block64_to_lds(c, sV[wave]);
+    auto alive = [&](int i) { return !(fused && i >= midx && i < midx + msize); };
+    auto remap = [&](int i) { return (fused && i >= midx) ? i - msize : i; };
+    const int r0 = 64 * bi + 32 * wi, c0 = 64 * bj + 32 * wj;
+    for (int e = lane; e < 1024; e += 64) {
+        const int rr = e & 31, cc = e >> 5;
+        const int row = r0 + rr, col = c0 + cc;
+        double v = 0.0;
+        if (row < n && col < n && row >= col) {
+            v = q.P[(size_t)row + (size_t)col * ld] - sV[wave][rr][cc];
+            if (alive(row) && alive(col)) q.dst[(size_t)remap(row) + (size_t)remap(col) * ld] = v;
+            if (q.upd && row == col && v < 0.0) atomicOr(&status[b0 + bl], 2);
+        }
+        sV[wave][rr][cc] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < 1024; e += 64) {
+        const int cc = e & 31, rr = e >> 5;
+        const int row = r0 + rr, col = c0 + cc;
+        if (row < n && col < n && row > col && alive(row) && alive(col)) q.dst[(size_t)remap(col) + (size_t)remap(row) * ld] = sV[wave][rr][cc];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 int dbg_read_bigwin(long long* out, int n) { return dbg_read_local(out, n); }
 size_t bigwin_sg_doubles(int G) { return (size_t)G * BIG_CMAX * BIG_CMAX * GB_SW; }
@@ -935,9 +1031,18 @@ int launch_bigwin(const FactoredLaunch& L, hipStream_t st)
         if ((size_t)ldt * BIG_NC <= 2 * (size_t)w.ld2 * w.n32) {
             double* T = L.big_wk + w.oX2;
             const size_t wss = bigwin_wk_doubles();
-            hipLaunchKernelGGL(k_apply_T, dim3(nbr, (BIG_NC + 31) / 32, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
+            static const bool blk32 = [] { const char* e = getenv("INGVIO_BIG_APPLY"); return e && e[0] == '3'; }();
+            if (blk32 || L.nb < 4) {                                          // a few filters: more, smaller workgroups
+                hipLaunchKernelGGL(k_apply_T, dim3(nbr, (BIG_NC + 31) / 32, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
+                                   L.m_out, L.marg_idx, L.pc_base, T, wss, ldt, L.dx);
+                hipLaunchKernelGGL(k_apply_sym, dim3(nbr * (nbr + 1) / 2, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
+                                   L.m_out, L.marg_idx, L.marg_size, L.pc_base, T, wss, ldt, L.status);
+                return 0;
+            }
+            const int nb64 = (ldt + 63) / 64;
+            hipLaunchKernelGGL(k_apply_T64, dim3(nb64, (BIG_NC + 63) / 64, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
                                L.m_out, L.marg_idx, L.pc_base, T, wss, ldt, L.dx);
-            hipLaunchKernelGGL(k_apply_sym, dim3(nbr * (nbr + 1) / 2, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
+            hipLaunchKernelGGL(k_apply_sym64, dim3(nb64 * (nb64 + 1) / 2, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
                                L.m_out, L.marg_idx, L.marg_size, L.pc_base, T, wss, ldt, L.status);
             return 0;
         }

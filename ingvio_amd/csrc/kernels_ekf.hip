@@ -12,6 +12,7 @@
 // reference's general LU `S.inverse()`.  gfx950 only.
 #include "dev_common.h"
 #include "launch_ekf.h"
+#include "block64.h"
 
 #define EKF_THREADS 512
 #define IB 16
@@ -330,8 +331,7 @@ int launch_rows_gate(const EkfLaunch& L, const RowsGateIn& in, double thr, doubl
 __global__ __launch_bounds__(256) void k_downdate64(CovView cv, int b0, const double* __restrict__ Yall, const int* __restrict__ m_all,
                                                     size_t ystride, int* __restrict__ status, int ldy)
 {
-    __shared__ double sA[16][68];
-    __shared__ double sB[16][68];
+    __shared__ Block64Lds sAB;
     __shared__ double sV[4][32][33];
     const int bl = blockIdx.y, b = b0 + bl, m = m_all[bl];
     if (m == 0) return;
@@ -340,49 +340,18 @@ __global__ __launch_bounds__(256) void k_downdate64(CovView cv, int b0, const do
     while (t >= bi + 1) { t -= bi + 1; ++bi; }
     const int bj = t;
     if (64 * bi >= n) return;
-    const bool diag = bi == bj;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wi = wave >> 1, wj = wave & 1;
-    const bool quad_on = !(diag && wj > wi);                             // the upper quadrant of a diagonal block comes from the mirror
+    const bool quad_on = !(bi == bj && wj > wi);                         // the upper quadrant of a diagonal block comes from the mirror
     double* P = cov_ptr(cv, b);
     const double* Y = Yall + (size_t)bl * ystride;
-    typedef double d4 __attribute__((ext_vector_type(4)));
-    d4 c00 = { 0, 0, 0, 0 }, c01 = c00, c10 = c00, c11 = c00;
-    const int mp = (m + 15) & ~15;
-    const int sr = tid & 63, sk = tid >> 6;                              // staging: row of the panel, first of its 4 columns
-    const int ra = min(64 * bi + sr, n - 1), rb = min(64 * bj + sr, n - 1);
-    for (int k0 = 0; k0 < mp; k0 += 16) {
-        double va[4], vb[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = k0 + sk + 4 * u;
-            va[u] = k < m ? Y[(size_t)ra + (size_t)k * ldy] : 0.0;
-            vb[u] = k < m ? Y[(size_t)rb + (size_t)k * ldy] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { sA[sk + 4 * u][sr] = va[u]; sB[sk + 4 * u][sr] = vb[u]; }
-        __syncthreads();
-        if (quad_on)
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const double a0 = sA[4 * s4 + kq][32 * wi + l15], a1 = sA[4 * s4 + kq][32 * wi + 16 + l15];
-            const double q0 = sB[4 * s4 + kq][32 * wj + l15], q1 = sB[4 * s4 + kq][32 * wj + 16 + l15];
-            c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, q0, c00, 0, 0, 0);
-            c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, q1, c01, 0, 0, 0);
-            c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, q0, c10, 0, 0, 0);
-            c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, q1, c11, 0, 0, 0);
-        }
-    }
+    b64_d4 c[4];
+    block64_mma(sAB, (m + 15) & ~15,
+                [&](int r, int k) { return k < m ? Y[(size_t)min(64 * bi + r, n - 1) + (size_t)k * ldy] : 0.0; },
+                [&](int r, int k) { return k < m ? Y[(size_t)min(64 * bj + r, n - 1) + (size_t)k * ldy] : 0.0; }, quad_on, c);
     if (!quad_on) return;                                                // no barrier below
     // this wave's 32 x 32 quadrant through LDS, then row-fast read-modify-write of P and its mirror
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        sV[wave][kq + 4 * r][l15] = c00[r]; sV[wave][kq + 4 * r][16 + l15] = c01[r];
-        sV[wave][16 + kq + 4 * r][l15] = c10[r]; sV[wave][16 + kq + 4 * r][16 + l15] = c11[r];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    block64_to_lds(c, sV[wave]);
     const int r0 = 64 * bi + 32 * wi, q0c = 64 * bj + 32 * wj;
     for (int e = lane; e < 1024; e += 64) {
         const int rr = e & 31, cc = e >> 5;
