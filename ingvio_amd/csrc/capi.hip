@@ -65,6 +65,7 @@ struct ingvio_ctx {
     int method;                    // 0 dense TSQR path, 1 factored (information-form) path
     int *d_accept, *d_used, *d_chunk_used, *d_colmap, *d_m, *d_nc, *d_status, *d_pcbase;
     double *d_big_sg, *d_big_wk;        // large-window workspaces (c_max > 16)
+
     int* d_tri_ok;                      // [B][f_max] triangulation flags
     // ingvio_qr_compress, general path: device buffers and the captured launch sequence (~300 kernels) of the last shape
     struct QrCache { int m = 0, n = 0, ldh = 0, chol = 0; double *dA = nullptr, *db = nullptr, *ws = nullptr, *dT = nullptr; hipGraphExec_t exec = nullptr; } qr;

@@ -900,9 +900,8 @@ __global__ __launch_bounds__(256) void k_apply_sym(CovView cv, int b0, const dou
 __global__ __launch_bounds__(256) void k_apply_T64(CovView cv, int b0, const double* __restrict__ Mall, int mstride, const double* __restrict__ Pcall,
                                                    int ystride, const int* __restrict__ m_all, const int* __restrict__ marg_idx,
                                                    const int* __restrict__ pc_base, double* __restrict__ Tall, size_t tstride, int ldt,
-                                                   double* __restrict__ dx_all)
+                                                   double* __restrict__ dx_all, int MP)
 {
-    constexpr int MP = BIG_NC;
     __shared__ Block64Lds sAB;
     const int bl = blockIdx.z, bi = blockIdx.x, bj = blockIdx.y;
     ApplyPtrs q;
@@ -939,9 +938,8 @@ __global__ __launch_bounds__(256) void k_apply_T64(CovView cv, int b0, const dou
 __global__ __launch_bounds__(256) void k_apply_sym64(CovView cv, int b0, const double* __restrict__ Mall, int mstride, const double* __restrict__ Pcall,
                                                      int ystride, const int* __restrict__ m_all, const int* __restrict__ marg_idx, int msize,
                                                      const int* __restrict__ pc_base, const double* __restrict__ Tall, size_t tstride, int ldt,
-                                                     int* __restrict__ status)
+                                                     int* __restrict__ status, int MP)
 {
-    constexpr int MP = BIG_NC;
     __shared__ Block64Lds sAB;
     __shared__ double sV[4][32][33];
     const int bl = blockIdx.y;
@@ -997,6 +995,16 @@ size_t bigwin_wk_doubles() { const size_t gj = (size_t)BIG_NC * (2 * BIG_NC + 1)
 int bigwin_rec_size() { return rec_size(BIG_CMAX); }
 int bigwin_cmax() { return BIG_CMAX; }
 
+// T = Pc M and P - T Pc^T on 64 x 64 blocks; mp = row length of M (row-major mp x mp, then t), T [n][mp] column-major (ldt)
+void launch_apply64(const FactoredLaunch& L, hipStream_t st, int mp, double* T, size_t tstride, int ldt)
+{
+    const int nb64 = (ldt + 63) / 64;
+    hipLaunchKernelGGL(k_apply_T64, dim3(nb64, (mp + 63) / 64, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
+                       L.m_out, L.marg_idx, L.pc_base, T, tstride, ldt, L.dx, mp);
+    hipLaunchKernelGGL(k_apply_sym64, dim3(nb64 * (nb64 + 1) / 2, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
+                       L.m_out, L.marg_idx, L.marg_size, L.pc_base, T, tstride, ldt, L.status, mp);
+}
+
 int launch_bigwin(const FactoredLaunch& L, hipStream_t st)
 {
     if (L.fv.cmax > BIG_CMAX) return -1;
@@ -1039,11 +1047,7 @@ int launch_bigwin(const FactoredLaunch& L, hipStream_t st)
                                    L.m_out, L.marg_idx, L.marg_size, L.pc_base, T, wss, ldt, L.status);
                 return 0;
             }
-            const int nb64 = (ldt + 63) / 64;
-            hipLaunchKernelGGL(k_apply_T64, dim3(nb64, (BIG_NC + 63) / 64, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
-                               L.m_out, L.marg_idx, L.pc_base, T, wss, ldt, L.dx);
-            hipLaunchKernelGGL(k_apply_sym64, dim3(nb64 * (nb64 + 1) / 2, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
-                               L.m_out, L.marg_idx, L.marg_size, L.pc_base, T, wss, ldt, L.status);
+            launch_apply64(L, st, BIG_NC, T, wss, ldt);
             return 0;
         }
     }

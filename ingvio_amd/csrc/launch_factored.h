@@ -42,6 +42,7 @@ int dbg_read_factored(long long* out, int n);
 
 // kernels_bigwin.hip: windows of 17..36 clones
 int launch_bigwin(const FactoredLaunch& L, hipStream_t st);
+void launch_apply64(const FactoredLaunch& L, hipStream_t st, int mp, double* T, size_t tstride, int ldt);
 size_t bigwin_sg_doubles(int G);
 size_t bigwin_wk_doubles();
 int bigwin_rec_size();
