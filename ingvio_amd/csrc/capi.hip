@@ -85,7 +85,7 @@ struct ingvio_ctx {
     // dense-H update workspace (kernels_lmbatch.hip + kernels_chol.hip): the batched landmark update and generic updates whose S
     // does not fit in LDS.  Rows live in Hd [m_cap][n_ld] per filter, the sweep in X / Y [ldx][m_cap].
     struct DenseWs {
-        double *Hd = nullptr, *X = nullptr, *Y = nullptr, *Tb = nullptr, *noise = nullptr;      // noise: one filter's R (ingvio_ekf_update)
+        double *Hd = nullptr, *X = nullptr, *Y = nullptr, *Tb = nullptr, *noise = nullptr, *noiseB = nullptr;      // noise: one filter's R (ingvio_ekf_update); noiseB [B][m_cap]: scalar / diagonal R per filter (batch)
         int *m = nullptr, *cidx = nullptr;
         int m_cap = 0, n_ld = 0, n32 = 0, ldx = 0;
         size_t hstride = 0, xstride = 0, tstride = 0;
@@ -576,7 +576,7 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
                      c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk, c->d_tri_ok, c->d_hnew, c->d_multi, c->d_noiseB,
                      c->gn.H, c->gn.res, c->gn.noise, c->gn.gamma, c->gn.chi2, c->gn.m, c->gn.nc, c->gn.colmap, c->gn.keep,
                      c->gn.feph, c->gn.fobs, c->gn.frcv, c->gn.front,
-                     c->dw.Hd, c->dw.X, c->dw.Y, c->dw.Tb, c->dw.noise, c->dw.m, c->dw.cidx, c->lm.pose, c->lm.pf, c->lm.uv, c->lm.gamma, c->lm.idx, c->lm.n_lm,
+                     c->dw.Hd, c->dw.X, c->dw.Y, c->dw.Tb, c->dw.noise, c->dw.noiseB, c->dw.m, c->dw.cidx, c->lm.pose, c->lm.pf, c->lm.uv, c->lm.gamma, c->lm.idx, c->lm.n_lm,
                      c->lm.lm_idx, c->lm.anchor_idx, c->lm.tracked, c->lm.accept, c->lm.dx };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& sl : c->pin) { if (sl.p) hipHostFree(sl.p); if (sl.ev) hipEventDestroy(sl.ev); }
@@ -850,22 +850,64 @@ int ingvio_ekf_update_batch(ingvio_ctx* c, int b0, int nb, const ingvio_update_b
     if (check_range(c, b0, nb) || !blk) return INGVIO_E_ARG;
     if (r_kind != INGVIO_R_SCALAR && r_kind != INGVIO_R_DIAG) return INGVIO_E_UNSUPPORTED;
     int m_cap = 0, nc_cap = 0, n_cap = 0;
+    bool dense = false;
     std::vector<int> ncs(nb);
     for (int i = 0; i < nb; ++i) {
         const ingvio_update_block& q = blk[i];
         const int b = b0 + i;
         if (!q.vidx || !q.vsize || !q.H || !q.res || !q.R || q.k < 1 || q.m < 1 || q.ldh < q.m) return INGVIO_E_ARG;
-        if (q.m > c->mld) return INGVIO_E_CAPACITY;
+        if (q.m > DENSE_M_MAX) return INGVIO_E_CAPACITY;
         int nc = 0;
         for (int j = 0; j < q.k; ++j) {
-            if (q.vidx[j] < 0 || q.vidx[j] + q.vsize[j] > c->h_n[b]) return INGVIO_E_NOT_IN_STATE;      // checkSubOrder
+            if (q.vidx[j] < 0 || q.vsize[j] < 0 || q.vidx[j] + q.vsize[j] > c->h_n[b]) return INGVIO_E_NOT_IN_STATE;      // checkSubOrder
             nc += q.vsize[j];
         }
-        if (nc > c->nc_cap || !ekf_core_fits(q.m, nc)) return INGVIO_E_CAPACITY;
+        if (q.m > c->mld || nc > c->nc_cap || !ekf_core_fits(q.m, nc)) dense = true;      // S beyond LDS: the whole call takes the dense-H route
         ncs[i] = nc;
         if (q.m > m_cap) m_cap = q.m;
         if (nc > nc_cap) nc_cap = nc;
         if (c->h_n[b] > n_cap) n_cap = c->h_n[b];
+    }
+    if (dense) {
+        // GEMM + Cholesky sweep with carried rows + downdate on dense rows addressed by state column (kernels_lmbatch.hip /
+        // kernels_chol.hip); the host scatters the columns, filter by filter
+        if (int rc = dense_ws_alloc(c, m_cap)) return rc;
+        auto& w = c->dw;
+        std::vector<double> Hd((size_t)w.m_cap * w.n_ld), rr((size_t)w.m_cap), nz((size_t)w.m_cap);
+        std::vector<int> zeros(nb, 0), ms(nb);
+        int rc = 0;
+        for (int i = 0; i < nb && !rc; ++i) {
+            const ingvio_update_block& q = blk[i];
+            std::fill(Hd.begin(), Hd.end(), 0.0); std::fill(rr.begin(), rr.end(), 0.0); std::fill(nz.begin(), nz.end(), 0.0);
+            int col = 0;
+            for (int j = 0; j < q.k; ++j)
+                for (int t = 0; t < q.vsize[j]; ++t, ++col)
+                    for (int r = 0; r < q.m; ++r) Hd[(size_t)r * w.n_ld + q.vidx[j] + t] += q.H[(size_t)r + (size_t)col * q.ldh];
+            memcpy(rr.data(), q.res, 8 * (size_t)q.m);
+            memcpy(nz.data(), q.R, 8 * (size_t)(r_kind == INGVIO_R_SCALAR ? 1 : q.m));
+            ms[i] = q.m;
+            rc |= up(c, w.Hd + (size_t)(b0 + i) * w.hstride, Hd.data(), 8 * Hd.size());
+            if (hipMemcpy2DAsync(w.X + (size_t)(b0 + i) * w.xstride + w.m_cap + w.n32, 8 * (size_t)w.ldx, rr.data(), 8, 8, (size_t)w.m_cap,
+                                 hipMemcpyHostToDevice, c->st) != hipSuccess) rc = INGVIO_E_HIP;
+            rc |= up(c, w.noiseB + (size_t)(b0 + i) * w.m_cap, nz.data(), 8 * nz.size());
+            if (!rc && hipStreamSynchronize(c->st) != hipSuccess) rc = INGVIO_E_HIP;      // the staging vectors are reused
+        }
+        rc |= up(c, w.m + b0, ms.data(), sizeof(int) * (size_t)nb);
+        rc |= up(c, c->d_status + b0, zeros.data(), sizeof(int) * (size_t)nb);
+        if (rc) return INGVIO_E_HIP;
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        rc = run_dense_update(c, b0, nb, 0.0, r_kind, w.noiseB + (size_t)b0 * w.m_cap, w.m_cap, c->d_dx);
+        if (rc) return rc;
+        std::vector<int> status(nb, 0);
+        if (dx_out) HIPCHK(c, hipMemcpyAsync(dx_out, c->d_dx + (size_t)b0 * c->ldp, 8 * (size_t)nb * c->ldp, hipMemcpyDeviceToHost, c->st));
+        if (down_sync(c, status.data(), c->d_status + b0, sizeof(int) * (size_t)nb)) return INGVIO_E_HIP;
+        int soft = INGVIO_OK;
+        for (int i = 0; i < nb; ++i) {
+            const int st = (status[i] & 2) ? INGVIO_NEG_DIAG : INGVIO_OK;
+            if (status_out) status_out[i] = st;
+            if (st != INGVIO_OK) soft = st;
+        }
+        return soft;
     }
     if (!c->d_noiseB) {
         if (dalloc(c, &c->d_noiseB, (size_t)c->d.batch * c->mld)) return INGVIO_E_HIP;
@@ -1399,7 +1441,7 @@ static int dense_ws_alloc(ingvio_ctx* c, int m_need)
     const int m_cap = (m_need + 31) / 32 * 32;
     if (w.Hd && w.m_cap >= m_cap) return 0;
     HIPCHK(c, hipStreamSynchronize(c->st));
-    for (double** p : { &w.Hd, &w.X, &w.Y, &w.Tb, &w.noise }) { if (*p) hipFree(*p); *p = nullptr; }
+    for (double** p : { &w.Hd, &w.X, &w.Y, &w.Tb, &w.noise, &w.noiseB }) { if (*p) hipFree(*p); *p = nullptr; }
     if (w.m) { hipFree(w.m); w.m = nullptr; }
     if (w.cidx) { hipFree(w.cidx); w.cidx = nullptr; }
     const int B = c->d.batch;
@@ -1407,7 +1449,7 @@ static int dense_ws_alloc(ingvio_ctx* c, int m_need)
     w.hstride = std::max((size_t)m_cap * w.n_ld, (size_t)LM_MAX * 100);      // also holds the landmark path's compact blocks
     w.xstride = (size_t)w.ldx * m_cap; w.tstride = (size_t)(m_cap / 32) * 1024 + (size_t)m_cap;
     int rc = dalloc(c, &w.Hd, (size_t)B * w.hstride) | dalloc(c, &w.X, (size_t)B * w.xstride) | dalloc(c, &w.Y, (size_t)B * w.xstride)
-           | dalloc(c, &w.Tb, (size_t)B * w.tstride) | dalloc(c, &w.m, (size_t)B) | dalloc(c, &w.noise, (size_t)m_cap * m_cap) | dalloc(c, &w.cidx, (size_t)B * LM_MAX * 4);
+           | dalloc(c, &w.Tb, (size_t)B * w.tstride) | dalloc(c, &w.m, (size_t)B) | dalloc(c, &w.noise, (size_t)m_cap * m_cap) | dalloc(c, &w.cidx, (size_t)B * LM_MAX * 4) | dalloc(c, &w.noiseB, (size_t)B * m_cap);
     return rc ? INGVIO_E_HIP : 0;
 }
 

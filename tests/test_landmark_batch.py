@@ -186,3 +186,29 @@ def test_frame_with_in_state_landmarks_vs_oracle():
     for b in range(nb):
         assert np.array_equal(ctx.cov_get(b), P1[b])
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_ekf_update_batch_rows_beyond_lds():
+    """ingvio_ekf_update_batch with row counts whose S does not fit LDS: the whole call takes the dense-H route."""
+    from ingvio_amd import capi
+    rng = np.random.default_rng(4242)
+    nb, n = 3, 21 + 66 + 30
+    ctx = capi.Context(batch=nb + 1, n_max=n + 3, c_max=11, f_max=8, m_max=64)
+    blocks, want = [], []
+    for b in range(nb):
+        P0 = spd(n, rng, 1e-2)
+        ctx.cov_set(b + 1, P0)
+        m = (200, 150, 40)[b]
+        vo, vs = [0, 27 + 6 * b, 87], [9, 30, 30]
+        H = rng.standard_normal((m, sum(vs))); r = 0.1 * rng.standard_normal(m); R = rng.uniform(0.5, 2.0, m)
+        blocks.append((vo, vs, H, r, R))
+        oc = orc.Cov(P0); dxo, _ = oc.ekf_update(vo, vs, H, r, R)
+        want.append((oc.P, dxo))
+    dx, st = ctx.ekf_update_batch(1, blocks, diag=True)
+    assert not st.any()
+    for b in range(nb):
+        P = ctx.cov_get(b + 1)
+        assert np.linalg.norm(P - want[b][0]) < 1e-10 * np.linalg.norm(want[b][0]) and np.array_equal(P, P.T)
+        assert np.linalg.norm(dx[b, :n] - want[b][1]) < 1e-9 * np.linalg.norm(want[b][1])
+    ctx.close()
