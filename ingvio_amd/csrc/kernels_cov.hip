@@ -76,67 +76,28 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
     __shared__ int sA[NA_MAX];
     __shared__ int sNA;
     __shared__ double sDt[64];
+    __shared__ double sQg[26];                                  // GNSS clock block of the composed step (+ total time), from the compose loop's idle thread
 
     dbg_stamp(16);
     if (tid < 225) { sPhi[tid] = (tid % 15 == tid / 15) ? 1.0 : 0.0; sQ[tid] = 0.0; }
     const double* PhiB = Phi + (size_t)bl * k * 225;
     const double* GB = G + (size_t)bl * k * 180;
     const double* dtB = dts + (size_t)bl * k;
+    for (int s = tid; s < k; s += PROP_THREADS) sDt[s] = dtB[s];
+    // the 5x5 clock block's recursion (sequential in the steps, a few FLOP each) rides on thread 255, which has no element of the
+    // 15 x 15 products: it used to run after the loop on thread 0 with everybody waiting (13 k cycles)
+    int gi[5];
+    double qg[5][5], Tg = 0.0;
+    if (tid == PROP_THREADS - 1) {
+        for (int g = 0; g < 5; ++g) gi[g] = (enable_gnss && gnss_idx) ? gnss_idx[bl * 5 + g] : -1;
+        for (int a = 0; a < 5; ++a) for (int c = 0; c < 5; ++c) qg[a][c] = 0.0;
+    }
     __syncthreads();
     for (int s = 0; s < k; ++s) {
-        if (s % PROP_KCH == 0) {
-            const int cnt = min(PROP_KCH, k - s);
-            for (int e = tid; e < cnt * 405; e += PROP_THREADS) {
-                const int q = e / 405, w = e - q * 405;
-                sAll[e] = w < 225 ? PhiB[(s + q) * 225 + w] : GB[(s + q) * 180 + (w - 225)] * (w < 225 + 45 ? sg0 : w < 225 + 90 ? sg1 : w < 225 + 135 ? sg2 : sg3);   // G_tmp, :92-96
-            }
-            __syncthreads();
-        }
-        const double* sStep = sAll + (s % PROP_KCH) * 405;
-        const double* sG = sStep + 225;
-        const double dt = dtB[s];
-        const int i = tid % 15, j = tid / 15;
-        if (tid < 180) {
-            double a = 0.0;
-            for (int l = 0; l < 15; ++l) a += sStep[i + 15 * l] * sG[l + 15 * j];
-            sPG[tid] = a;                                                   // Phi * G_tmp
-        }
-        if (tid < 225) {
-            double a = 0.0, c = 0.0;
-            for (int l = 0; l < 15; ++l) { a += sStep[i + 15 * l] * sQ[l + 15 * j]; c += sStep[i + 15 * l] * sPhi[l + 15 * j]; }
-            sT1[tid] = a; sT2[tid] = c;
-        }
-        __syncthreads();
-        if (tid < 225) {
-            double a = 0.0, q = 0.0;
-            for (int l = 0; l < 15; ++l) a += sT1[i + 15 * l] * sStep[j + 15 * l];
-            for (int l = 0; l < 12; ++l) q += sPG[i + 15 * l] * sPG[j + 15 * l];
-            sQ[tid] = a + dt * q;                                           // :51 + :97 composed
-            sPhi[tid] = sT2[tid];
-        }
-        __syncthreads();
-    }
-    dbg_stamp(17);
-    for (int a = tid; a < NA_MAX * NA_MAX; a += PROP_THREADS) { sPhiA[a] = 0.0; sQA[a] = 0.0; }
-    for (int s = tid; s < k; s += PROP_THREADS) sDt[s] = dtB[s];
-    __syncthreads();
-    // active set + GNSS clock block (thread 0, <= 5x5 work)
-    if (tid == 0) {
-        int gi[5], na = 15;
-        for (int g = 0; g < 5; ++g) gi[g] = (enable_gnss && gnss_idx) ? gnss_idx[bl * 5 + g] : -1;
-        for (int a = 0; a < 15; ++a) sA[a] = a;
-        int loc[5];
-        for (int g = 0; g < 5; ++g) { loc[g] = -1; if (gi[g] >= 0) { loc[g] = na; sA[na++] = gi[g]; } }
-        sNA = na;
-        for (int a = na; a < NA_MAX; ++a) sA[a] = 0;      // padding: loads stay unconditional, Phi_A rows/cols there are zero
-        double qg[5][5];
-        for (int a = 0; a < 5; ++a) for (int c = 0; c < 5; ++c) qg[a][c] = 0.0;
-        double T = 0.0;
-        const bool has_fs = gi[4] >= 0;
-        for (int s = 0; s < k; ++s) {
+        if (tid == PROP_THREADS - 1) {
             const double dt = sDt[s];
-            if (has_fs) {
-                T += dt;
+            if (gi[4] >= 0) {
+                Tg += dt;
                 for (int g = 0; g < 4; ++g) if (gi[g] >= 0) for (int c = 0; c < 5; ++c) qg[g][c] += dt * qg[4][c];
                 for (int g = 0; g < 4; ++g) if (gi[g] >= 0) for (int r = 0; r < 5; ++r) qg[r][g] += dt * qg[r][4];
             }
@@ -150,6 +111,73 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
                 }
             }
         }
+        if (s % PROP_KCH == 0) {
+            const int cnt = min(PROP_KCH, k - s);
+            // all of the chunk's loads are issued before the first LDS store (a rolled loop pays one memory latency per pass)
+            constexpr int PER = (PROP_KCH * 405 + PROP_THREADS - 1) / PROP_THREADS;
+            double v[PER];
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int e = tid + u * PROP_THREADS, q = e / 405, w = e - q * 405;
+                v[u] = e < cnt * 405 ? (w < 225 ? PhiB[(s + q) * 225 + w] : GB[(s + q) * 180 + (w - 225)]) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int e = tid + u * PROP_THREADS, w = e % 405;
+                if (e < cnt * 405) sAll[e] = w < 225 ? v[u] : v[u] * (w < 225 + 45 ? sg0 : w < 225 + 90 ? sg1 : w < 225 + 135 ? sg2 : sg3);   // G_tmp, :92-96
+            }
+            __syncthreads();
+            if (s == 0) dbg_stamp(21);
+        }
+        const double* sStep = sAll + (s % PROP_KCH) * 405;
+        const double* sG = sStep + 225;
+        const double dt = sDt[s];
+        const int i = tid % 15, j = tid / 15;
+        // the dot products are unrolled so that all operand reads are in flight before the first FMA (rolled, every FMA waited
+        // for its own two LDS reads: 6.4 k cycles per step)
+        if (tid < 180) {
+            double a = 0.0;
+#pragma unroll
+            for (int l = 0; l < 15; ++l) a += sStep[i + 15 * l] * sG[l + 15 * j];
+            sPG[tid] = a;                                                   // Phi * G_tmp
+        }
+        if (tid < 225) {
+            double a = 0.0, c = 0.0;
+#pragma unroll
+            for (int l = 0; l < 15; ++l) { a += sStep[i + 15 * l] * sQ[l + 15 * j]; c += sStep[i + 15 * l] * sPhi[l + 15 * j]; }
+            sT1[tid] = a; sT2[tid] = c;
+        }
+        __syncthreads();
+        if (tid < 225) {
+            double a = 0.0, q = 0.0;
+#pragma unroll
+            for (int l = 0; l < 15; ++l) a += sT1[i + 15 * l] * sStep[j + 15 * l];
+#pragma unroll
+            for (int l = 0; l < 12; ++l) q += sPG[i + 15 * l] * sPG[j + 15 * l];
+            sQ[tid] = a + dt * q;                                           // :51 + :97 composed
+            sPhi[tid] = sT2[tid];
+        }
+        __syncthreads();
+    }
+    dbg_stamp(17);
+    for (int a = tid; a < NA_MAX * NA_MAX; a += PROP_THREADS) { sPhiA[a] = 0.0; sQA[a] = 0.0; }
+    if (tid == PROP_THREADS - 1) {
+        for (int a = 0; a < 5; ++a) for (int c = 0; c < 5; ++c) sQg[5 * a + c] = qg[a][c];
+        sQg[25] = Tg;
+    }
+    __syncthreads();
+    // active set + GNSS clock block (thread 0, bookkeeping only)
+    if (tid == 0) {
+        int gi[5], na = 15;
+        for (int g = 0; g < 5; ++g) gi[g] = (enable_gnss && gnss_idx) ? gnss_idx[bl * 5 + g] : -1;
+        for (int a = 0; a < 15; ++a) sA[a] = a;
+        int loc[5];
+        for (int g = 0; g < 5; ++g) { loc[g] = -1; if (gi[g] >= 0) { loc[g] = na; sA[na++] = gi[g]; } }
+        sNA = na;
+        for (int a = na; a < NA_MAX; ++a) sA[a] = 0;      // padding: loads stay unconditional, Phi_A rows/cols there are zero
+        const bool has_fs = gi[4] >= 0;
+        const double T = sQg[25];
+        const double (*qg)[5] = reinterpret_cast<const double (*)[5]>(sQg);
         for (int a = 0; a < 5; ++a) {
             if (loc[a] < 0) continue;
             sPhiA[loc[a] * NA_MAX + loc[a]] = 1.0;
