@@ -7,7 +7,7 @@ run c2_n87 --state literal --no-cpu
 run c2_n93 --state gnss --no-cpu
 run c3 --config 3 --no-cpu
 run c5_n807 --config 5
-run c5_n207 --config 5 --state literal --no-cpu
+run c5_n201 --config 5 --state literal --no-cpu
 run c5_n807_b128 --config 5 --batch 128 --no-cpu
 run c5_n807_b1 --config 5 --batch 1 --no-cpu --steps 50
 run c2_lmreal --landmarks real --no-cpu
