@@ -183,6 +183,18 @@ int ingvio_gnss_front_stage(ingvio_ctx* ctx, int b0, int nb, const ingvio_gnss_e
  * (3), azimuth, elevation, ionosphere delay, troposphere delay, usable (1/0) */
 int ingvio_gnss_front_fetch(ingvio_ctx* ctx, int b0, int nb, double* out);
 
+/* ---- feature-sharded single filter (optional mode): the per-feature work (K3-K5 gate, K6/K7 in information form)
+ * is independent given the prior, so G replicas of ONE filter can each take F/G of the frame's features:
+ *   ingvio_frame_run_phase(ctx, restore, 1)   propagate + clone + gate + Gram of the staged (local) features
+ *   ingvio_debug_msckf_info(ctx, b, A, &ncol) the local [A | b] = [sum H_j^T H_j | sum H_j^T r_j]  (35 KB at 11 clones, 260 KB at 30)
+ *   -- the ONE exchange step: sum over the replicas (all-reduce; ingvio_amd/parallel.py::sharded_frame_update) --
+ *   ingvio_info_set(ctx, b, A_sum, ncol, n_accepted_total)
+ *   ingvio_frame_run_phase(ctx, 0, 2)         solve + apply + marginalise: identical posterior on every replica
+ * phase 0 = ingvio_frame_run.  Factored method only; the accepted-feature cap (max_accept) is a global order and is not
+ * supported across shards. */
+int ingvio_frame_run_phase(ingvio_ctx* ctx, int restore_prior, int phase);
+int ingvio_info_set(ingvio_ctx* ctx, int b, const double* A, int ncol, int n_accepted);
+
 /* ---- batched SLAM-landmark update (LandmarkUpdate::updateLandmark{Mono,Stereo}, LandmarkUpdate.cpp:32-149) ----------------
  * For every in-state landmark observed in the current frame: rows against [extended pose | extrinsics | anchor clone | landmark]
  * (calcResJacobianSingleLandmark*, :521-572 / :619-686, as written), the per-landmark chi^2 gate on the prior (:98-99), the

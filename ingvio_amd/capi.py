@@ -27,7 +27,7 @@ EXPORTS = [
     "ingvio_frame_stage", "ingvio_frame_stage_async", "ingvio_frame_run", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_select",
     "ingvio_profile_reset",
     "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_set_qr_method", "ingvio_landmark_stage", "ingvio_landmark_run",
-    "ingvio_landmark_fetch", "ingvio_debug_read", "ingvio_triangulate",
+    "ingvio_landmark_fetch", "ingvio_frame_run_phase", "ingvio_info_set", "ingvio_debug_read", "ingvio_triangulate",
     "ingvio_gnss_front_stage", "ingvio_gnss_front_fetch", "ingvio_gnss_update_batch", "ingvio_gnss_stage", "ingvio_gnss_run", "ingvio_gnss_fetch", "ingvio_mld", "ingvio_debug_msckf_info", "ingvio_debug_info_solution",
     "ingvio_chi2_gamma_multi", "ingvio_ekf_update_batch", "ingvio_add_variable_delayed_invertible", "ingvio_add_variable_delayed", "ingvio_replace_var_linear",
 ]
@@ -379,6 +379,14 @@ class Context:
         out = np.zeros((nb, 64, 10))
         self._chk(self.L.ingvio_gnss_front_fetch(self.h, b0, nb, _d(out)))
         return out
+
+    def frame_run_phase(self, phase, restore_prior=False):
+        """1: propagate + clone + gate + Gram of the staged features; 2: solve + apply + marginalise (ingvio_frame_run_phase)"""
+        self._chk(self.L.ingvio_frame_run_phase(self.h, int(restore_prior), int(phase)))
+
+    def info_set(self, b, A, n_accepted):
+        A = f64(A)
+        self._chk(self.L.ingvio_info_set(self.h, b, _d(A), A.shape[0], int(n_accepted)))
 
     def landmark_stage(self, b0, frames, stereo, noise, chi2_thr, R_cl2cr=None, t_cl2cr=None, in_frame=False):
         """frames: per filter a dict(R_i2w, p_i2w, R_cl2i, p_c2i, idx_epose, idx_ext, lm_idx [L], anchor_idx [L], pf [L,3], uv [L,4],

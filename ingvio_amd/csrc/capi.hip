@@ -424,8 +424,9 @@ int make_opts(ingvio_ctx* c, const ingvio_msckf_opts* o, MsckfOpts* op)
 }
 
 // K3..K11 for filters [b0, b0+nb) using the staged frames; asynchronous.
+// phase 0: the whole update; 1: gate + gram only (the chunk partials [A | b] stay in d_Rpart); 2: solve + apply from the partials
 int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int stereo, int fmax_used,
-                       const int* marg_idx = nullptr, int marg_size = 0)
+                       const int* marg_idx = nullptr, int marg_size = 0, int phase = 0)
 {
     FactoredLaunch L;
     memset(&L, 0, sizeof L);
@@ -439,8 +440,11 @@ int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int s
     L.dx = c->d_dx; L.m_out = c->d_m + b0; L.nc_out = c->d_nc + b0; L.status = c->d_status;
     L.big_sg = c->d_big_sg ? c->d_big_sg + (size_t)b0 * bigwin_sg_doubles(c->G) : nullptr;
     L.big_wk = c->d_big_wk ? c->d_big_wk + (size_t)b0 * bigwin_wk_doubles() : nullptr;
-    { ProfScope p(c, PF_GATE2); L.stage = 0; if (launch_factored(L, c->st)) return INGVIO_E_UNSUPPORTED; }
-    { ProfScope p(c, PF_GRAM); L.stage = 1; launch_factored(L, c->st); }
+    if (phase != 2) {
+        { ProfScope p(c, PF_GATE2); L.stage = 0; if (launch_factored(L, c->st)) return INGVIO_E_UNSUPPORTED; }
+        { ProfScope p(c, PF_GRAM); L.stage = 1; launch_factored(L, c->st); }
+    }
+    if (phase == 1) return last_launch(c);
     L.mstride = c->ystride; L.n_cap = c->d.n_max;
     L.marg_idx = marg_idx; L.marg_size = marg_size; L.pc_base = c->d_pcbase + b0;
     { ProfScope p(c, PF_INFO); L.stage = 2; launch_factored(L, c->st); }
@@ -1763,9 +1767,27 @@ int ingvio_frame_stage_async(ingvio_ctx* c, int b0, int nb, const ingvio_frame_s
     return frame_stage_impl(c, b0, nb, steps, frames, opts, sigma, enable_gnss, scb, srw, true);
 }
 
-int ingvio_frame_run(ingvio_ctx* c, int restore_prior)
+static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
 {
     if (!c || !c->staged) return INGVIO_E_ARG;
+    if (phase && c->method != 1) return INGVIO_E_UNSUPPORTED;             // the split needs the information form's [A | b]
+    if (phase == 2) {                                                       // back half: solve + apply + marginalise from the partials
+        const int B2 = c->d.batch;
+        const bool with_lm2 = c->lm.staged && c->lm.in_frame;
+        int rc2 = run_msckf_factored(c, 0, B2, c->st_op, c->st_stereo, c->st_fmax_used, with_lm2 ? nullptr : c->d_idx, with_lm2 ? 0 : 6, 2);
+        if (rc2) return rc2;
+        if (with_lm2) { rc2 = landmark_update_launch(c, 0, B2); if (rc2) return rc2; }
+        {
+            ProfScope p(c, PF_MARG);
+            if (!with_lm2) launch_post_marg(view(c), 0, B2, c->d_idx, 6, c->st);
+            else launch_marginalize(view(c), 0, B2, c->d.n_max, c->d_idx, 6, c->st);
+        }
+        for (int b = 0; b < B2; ++b) if (c->st_marg[b] >= 0) { c->h_n[b] -= 6; c->h_cur[b] ^= 1; }
+        c->strip_ok = false;
+        c->mut_seq++;
+        if (c->alt_ready) { HIPCHK(c, hipEventRecord(c->ev_free[c->set_id], c->st)); c->free_valid[c->set_id] = true; }
+        return INGVIO_OK;
+    }
     const int B = c->d.batch;
     // ---- every check that can refuse the step comes before the first launch and before any host-side state changes ----
     if (restore_prior && !c->has_snap) return INGVIO_E_ARG;
@@ -1801,6 +1823,11 @@ int ingvio_frame_run(ingvio_ctx* c, int restore_prior)
     // the marginalisation cannot ride on the MSCKF write-back then
     const bool with_lm = c->lm.staged && c->lm.in_frame;
     const bool fuse = c->method == 1 && !with_lm;
+    if (phase == 1) {                                                       // front half only: [A | b] partials stay on the device
+        c->strip_ok = false;
+        c->mut_seq++;
+        return run_msckf_factored(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used, nullptr, 0, 1);
+    }
     int rc = fuse ? run_msckf_factored(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used, c->d_idx, 6)
                   : (c->method == 1 ? run_msckf_factored(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used)
                                     : run_msckf(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used));
@@ -1819,6 +1846,27 @@ int ingvio_frame_run(ingvio_ctx* c, int restore_prior)
         HIPCHK(c, hipEventRecord(c->ev_free[c->set_id], c->st));
         c->free_valid[c->set_id] = true;
     }
+    return INGVIO_OK;
+}
+
+int ingvio_frame_run(ingvio_ctx* c, int restore_prior) { return frame_run_impl(c, restore_prior, 0); }
+int ingvio_frame_run_phase(ingvio_ctx* c, int restore_prior, int phase)
+{
+    if (phase < 0 || phase > 2) return INGVIO_E_ARG;
+    return frame_run_impl(c, restore_prior, phase);
+}
+
+// the stacked information [A | b] = [sum_j H_j^T H_j | sum_j H_j^T r_j] of filter b replaces the chunk partials (feature-sharded
+// single filter: every rank sums the ranks' partials and continues with ingvio_frame_run_phase(.., 2))
+int ingvio_info_set(ingvio_ctx* c, int b, const double* A, int ncol, int n_accepted)
+{
+    if (check_range(c, b, 1) || !A || ncol < 6 || (size_t)ncol * (ncol + 1) > (size_t)c->rstride || n_accepted < 0) return INGVIO_E_ARG;
+    std::vector<int> used(c->G, 0);
+    used[0] = n_accepted;
+    int rc = up(c, c->d_Rpart + (size_t)b * c->G * c->rstride, A, 8 * (size_t)ncol * (ncol + 1));
+    rc |= up(c, c->d_chunk_used + (size_t)b * c->G, used.data(), sizeof(int) * (size_t)c->G);
+    if (rc) return INGVIO_E_HIP;
+    HIPCHK(c, hipStreamSynchronize(c->st));
     return INGVIO_OK;
 }
 

@@ -1,6 +1,8 @@
 """Multi-GPU plumbing: the hot path shards over independent filters/frames, so the
 only collectives are the timing barrier / max and one end-of-run gather of per-rank summaries.
-One process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm, "gloo" on CPU)."""
+One process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm, "gloo" on CPU).
+Optional second mode (stress only): ONE filter whose features are dealt to the ranks, with exactly one exchange
+step per frame - the sum of the ranks' [A | b] (sharded_frame_update)."""
 import os
 
 
@@ -83,3 +85,44 @@ class Group:
         if self.dist is not None:
             self.dist.barrier()
             self.dist.destroy_process_group()
+
+
+    def sum_array(self, a):
+        """All-reduce(sum) of a float64 array (the one exchange step of the feature-sharded filter)."""
+        import numpy as np
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if self.dist is None:
+            return a
+        t = self.torch.from_numpy(a.copy()).to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+
+def shard_features(frame, world, rank):
+    """The frame dict restricted to the features j = rank (mod world): every rank sees the same window and poses."""
+    import numpy as np
+    keep = np.arange(rank, len(frame["pf"]), world)
+    out = dict(frame)
+    for k in ("pf", "anchor", "obs_mask", "uv", "dof"):
+        out[k] = np.asarray(frame[k])[keep]
+    return out, keep
+
+
+def sharded_frame_update(ctx, grp, b, step, frame, sigma, enable_gnss, sigma_cb, sigma_rw, restore_prior=False):
+    """One frame of ONE filter (replicated prior on every rank, filter b of each rank's context) with its features dealt to the
+    ranks: local propagate + clone + gate + Gram, ONE all-reduce of [A | b] (n x (n+1) doubles), then the identical solve + apply +
+    marginalisation everywhere.  Returns (dx, accepted feature ids of this rank, rows).  `ctx` must hold only this filter (batch 1)
+    or the call applies the staged frames of the whole batch."""
+    import numpy as np
+    local, keep = shard_features(frame, grp.world, grp.rank)
+    ctx.frame_stage(b, [step], [local], sigma, enable_gnss, sigma_cb, sigma_rw, max_accept=0, compress_rule=1)
+    ctx.frame_run_phase(1, restore_prior=restore_prior)
+    _, acc, _ = ctx.frame_fetch(b, 1)
+    A, bvec = ctx.debug_msckf_info(b)
+    packed = np.concatenate([np.column_stack([A, bvec]).reshape(-1), [float(acc[0, :len(keep)].sum())]])
+    tot = grp.sum_array(packed)
+    n = A.shape[0]
+    ctx.info_set(b, tot[:-1].reshape(n, n + 1), int(round(tot[-1])))
+    ctx.frame_run_phase(2)
+    dx, _, rows = ctx.frame_fetch(b, 1)
+    return dx[0], keep[acc[0, :len(keep)] != 0], int(rows[0])
