@@ -169,6 +169,7 @@ __device__ __forceinline__ void gate3_body(
         }
     };
 
+    dbg_stamp(5);
     // ================= FRONT: wave 0, lane group f = lane / GS handles feature jbase + f =================
     if (wave == 0) {
         const int f = lane / GS, sl = lane - GS * f;               // feature of this lane group, lane within the group
@@ -342,7 +343,9 @@ __device__ __forceinline__ void gate3_body(
             }
         }
     }
+    dbg_stamp(6);
     __syncthreads();
+    dbg_stamp(7);
 
     // ================= BACK: wave w finishes feature jbase + w =================
     SH& sh = sh4[wave];
@@ -387,6 +390,7 @@ __device__ __forceinline__ void gate3_body(
         }
     }
     wave_sync();
+    dbg_stamp(8);
     {
         // ---- blocked LDL^T on the matrix cores --------------------------------------------------------
         // The bordered matrix (K padded with unit pivots to KP rows, then the 4 rows of W^T) is held as 16x16
@@ -508,6 +512,7 @@ __device__ __forceinline__ void gate3_body(
                 wave_sync();
             }
         }
+        dbg_stamp(9);
         // border block: tile (NTL-1, NTL-1), rows KP..KP+3 = local 4..7 -> r = 1, kq = 0..3; cols local 4..7
         if (l15 >= 4 && l15 < 8) sh.bz[kq * 4 + (l15 - 4)] = T[NLT - 1][1];
         wave_sync();
@@ -533,6 +538,7 @@ __device__ __forceinline__ void gate3_body(
             accept_out[oidx] = ok ? 1 : 0;
         }
         if (WREC) { for (int e = tid; e < REC_HDR + REC_OBS * nobs; e += WAVE) rec_g[e] = rec[e]; }
+        dbg_stamp(10);
         return;
     }
 }
