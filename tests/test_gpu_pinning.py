@@ -324,3 +324,33 @@ def test_rccl_world_size_1():
                HSA_ENABLE_IPC_MODE_LEGACY="0", INGVIO_ROOT=ROOT)
     r = subprocess.run([sys.executable, "-c", RCCL_SNIPPET], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("scale", [1e-4, 1.0, 1e4])
+def test_large_window_sigma_scale_sweep(orc, scale):
+    """The same conditioning sweep on a 20-clone window: there stage 2 is the batched Cholesky form of kernels_chol.hip
+    (P_cc = L L^T, W = L^T A L + s^2 I = L2 L2^T, no pivoting anywhere).  Accept masks equal to the oracle's, covariance within
+    the BASELINE tolerance for every sigma x prior scale."""
+    from ingvio_amd import capi, host, synth
+    sigmas = [0.18, 0.08, 1e-2, 1e-3]
+    C, F, n_lm = 20, 60, 20
+    n_max = ((21 + 6 + 3 * n_lm + 6 * C + 15) // 16) * 16
+    ctx = capi.Context(batch=len(sigmas), n_max=n_max, c_max=C, f_max=F, m_max=64)
+    flt, step, frame, info = synth.build_case(lambda P: capi.DeviceCov(ctx, 0, P), host.imu_transition, seed=33, F=F, C=C, n_landmarks=n_lm)
+    P0 = _prior_at_update(ctx, 0, flt, step)
+    n = P0.shape[0]
+    frames = []
+    for b, s in enumerate(sigmas):
+        ctx.cov_set(b, P0 * scale)
+        f = dict(frame); f["noise"] = s
+        frames.append(f)
+    res = [ctx.msckf_update(b, frames[b]) for b in range(len(sigmas))]
+    for b, s in enumerate(sigmas):
+        oc = orc.Cov(P0 * scale, ld=n_max)
+        dxo, acco, gamo, m = oc.msckf_update(frames[b], max_accept=0, compress_rule=1)
+        Pg = ctx.cov_get(b)
+        assert np.array_equal(res[b][1][0, :F], acco), (s, scale)
+        e = rel_err(Pg, oc.P)
+        print("large-window sweep scale %.0e sigma %-6g accepted %3d  cov vs oracle %.1e" % (scale, s, int(acco.sum()), e))
+        assert e < 1e-6, (s, scale, e)
+    ctx.close()
