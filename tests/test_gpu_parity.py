@@ -426,15 +426,16 @@ def test_frame_without_marginalisation_in_batch(orc):
     ctx2.close()
 
 
-@pytest.mark.parametrize("C,stereo", [(20, True), (30, True), (35, False), (17, False), (36, True)])
-def test_large_window_vs_oracle(orc, C, stereo):
+@pytest.mark.parametrize("C,stereo,c_max", [(20, True, 20), (30, True, 30), (35, False, 35), (17, False, 17), (36, True, 36), (22, True, 30), (19, False, 36)])
+def test_large_window_vs_oracle(orc, C, stereo, c_max):
     """Windows of 17..36 clones (the reference's shipped configs: 21..35) take the large-window kernels
-    (kernels_bigwin.hip): whole frames, ragged observations, random anchors, vs the oracle."""
+    (kernels_bigwin.hip): whole frames, ragged observations, random anchors, vs the oracle.  c_max > C: a window that is not
+    yet full runs in the context's class (gate class, padded solve size)."""
     from ingvio_amd import capi, host, synth
     nb, F = 2, 48
     n_gnss, n_lm = 6, 4
     N = 21 + n_gnss + 3 * n_lm + 6 * C
-    ctx2 = capi.Context(batch=nb, n_max=((N + 15) // 16) * 16, c_max=C, f_max=F, m_max=64)
+    ctx2 = capi.Context(batch=nb, n_max=((N + 15) // 16) * 16, c_max=c_max, f_max=F, m_max=64)
     cases = []
     for b in range(nb):
         flt, step, frame, info = synth.build_case(lambda P, b=b: capi.DeviceCov(ctx2, b, P), host.imu_transition,
