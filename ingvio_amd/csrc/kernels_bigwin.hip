@@ -78,6 +78,7 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
     const int F = fv.n_feat[b], C = fv.n_clones[b], ncol = 6 * C;
     double* Sg = Sg_all + ((size_t)bl * G + g) * (size_t)CMAX * CMAX * GB_SW;
 
+    dbg_stamp(48);
     for (int j = tid; j < F; j += GB_NT) {                      // RemoveLostUpdate.cpp:357-359
         int use = accept_in[(size_t)b * fv.fmax + j];
         if (use && op.max_accept > 0) {
@@ -89,7 +90,10 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
         if (g == 0) used_out[(size_t)b * fv.fmax + j] = use;
     }
     for (int e = tid; e < KR * LDW; e += GB_NT) { (&sb.Bm[0][0])[e] = 0.0; (&sb.Ym[0][0])[e] = 0.0; }
-    for (int e = tid; e < CMAX * CMAX * GB_SW; e += GB_NT) Sg[e] = 0.0;
+    for (int e = tid; e < C * C * GB_SW; e += GB_NT) {          // only the (slot, anchor) pairs of this window
+        const int q = e / GB_SW, v = e - q * GB_SW, c = q / C, a2 = q - c * C;
+        Sg[((size_t)c * CMAX + a2) * GB_SW + v] = 0.0;
+    }
     __syncthreads();
     if (wave == 0) {                                            // ordered list of the used features
         int cnt = 0;
@@ -128,6 +132,7 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
         }
     };
     fetch(q0);
+    dbg_stamp(49);
     for (int qb = q0; qb < q1; qb += GB_NB) {
         const int nbf = min(GB_NB, q1 - qb);
 #pragma unroll
@@ -208,15 +213,47 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
             }
         }
         // sparse sums: slot c is always handled by the same 8 threads (part = which of the 33 values), features in order
+        // The batch's contributions are first merged by anchor (later features into the earlier one with the same key, in feature
+        // order), then ALL read-modify-writes of the batch are issued together: one memory trip per batch instead of a dependent
+        // load -> add -> store chain per feature (which was 25 k of the 28 k cycles of a batch).
         if (tid < CMAX * 8) {
             const int c = tid >> 3, part = tid & 7;
             if (c < C) {
-                for (int f = 0; f < nbf; ++f) {
+                int key[GB_NB];
+                double val[GB_NB][5];
+#pragma unroll
+                for (int f = 0; f < GB_NB; ++f) {
                     const double* sp = sb.sp[f][c];
-                    const double key = sp[33];
-                    if (key >= 0.0) {
-                        double* S = Sg + ((size_t)c * CMAX + (int)key) * GB_SW;
-                        for (int v = part; v < 33; v += 8) S[v] += sp[v];
+                    key[f] = f < nbf ? (int)sp[33] : -1;
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) { const int v = part + 8 * j; val[f][j] = (key[f] >= 0 && v < 33) ? sp[v] : 0.0; }
+                }
+#pragma unroll
+                for (int f = 1; f < GB_NB; ++f) {
+                    bool merged = false;
+#pragma unroll
+                    for (int f2 = 0; f2 < f; ++f2) {
+                        if (!merged && key[f] >= 0 && key[f2] == key[f]) {
+#pragma unroll
+                            for (int j = 0; j < 5; ++j) val[f2][j] += val[f][j];
+                            merged = true;
+                        }
+                    }
+                    if (merged) key[f] = -1;
+                }
+                double old[GB_NB][5];
+#pragma unroll
+                for (int f = 0; f < GB_NB; ++f) {
+                    const double* S = Sg + ((size_t)c * CMAX + (key[f] >= 0 ? key[f] : 0)) * GB_SW;
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) { const int v = part + 8 * j; old[f][j] = (key[f] >= 0 && v < 33) ? S[v] : 0.0; }
+                }
+#pragma unroll
+                for (int f = 0; f < GB_NB; ++f) {
+                    if (key[f] >= 0) {
+                        double* S = Sg + ((size_t)c * CMAX + key[f]) * GB_SW;
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) { const int v = part + 8 * j; if (v < 33) S[v] = old[f][j] + val[f][j]; }
                     }
                 }
             }
@@ -224,6 +261,7 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
         __syncthreads();
     }
 
+    dbg_stamp(50);
     // ---- epilogue: [A | b] of the chunk = sparse part - rank-3 part, assembled in global memory ---------------------
     double* out = Apart + ((size_t)bl * G + g) * rstride;      // [ncol][ncol+1] row-major, b in the last column
 #pragma unroll
@@ -246,48 +284,73 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
         }
     }
     __syncthreads();
+    dbg_stamp(51);
+    // diagonal blocks (c, c): the sum over ALL anchors a.  One thread per (slot, output element): its 2 C loads are independent
+    // (one or two memory trips), consecutive threads read consecutive elements of a pair's sums.  One thread per slot walking the
+    // anchors was a 60-load dependent chain and 60 % of this kernel's time for a single filter.
+    for (int q = tid; q < C * 42; q += GB_NT) {
+        const int c = q / 42, v = q - 42 * c;
+        int is, ia = -1, row, col;
+        double ss, sa = 0.0;
+        if (v < 36) {
+            const int m6 = v / 6, k6 = v - 6 * m6;
+            row = m6; col = 6 * c + k6;
+            if (m6 < 3 && k6 < 3) { is = 3 * m6 + k6; ss = 1.0; ia = is; sa = 1.0; }
+            else if (m6 < 3) { is = 9 + 3 * (k6 - 3) + m6; ss = -1.0; }                    // (theta, p) = -NXs^T
+            else if (k6 < 3) { is = 9 + 3 * (m6 - 3) + k6; ss = -1.0; }                    // (p, theta) = -NXs
+            else { is = 21 + 3 * (m6 - 3) + (k6 - 3); ss = 1.0; }
+        } else {
+            const int i = v - 36;
+            row = i; col = ncol;
+            if (i < 3) { is = 18 + i; ss = 1.0; ia = 18 + i; sa = -1.0; }
+            else { is = 30 + (i - 3); ss = -1.0; }
+        }
+        double sum = 0.0;
+        const int iaq = ia >= 0 ? ia : 0;
+        for (int a0 = 0; a0 < C; a0 += 12) {                                               // 24 independent loads per pass, added in order
+            double x[12], y[12];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                const int a = min(a0 + u, C - 1);
+                x[u] = Sg[((size_t)c * CMAX + a) * GB_SW + is];                            // obs at slot c, anchor a
+                y[u] = Sg[((size_t)a * CMAX + c) * GB_SW + iaq];                           // obs at slot a, anchor c
+            }
+#pragma unroll
+            for (int u = 0; u < 12; ++u) if (a0 + u < C) sum += ss * x[u] + sa * y[u];
+        }
+        out[(size_t)(6 * c + row) * (ncol + 1) + col] += sum;
+    }
+    // off-diagonal blocks (c, c2): one (slot, anchor) pair each way
     for (int q = tid; q < C * C; q += GB_NT) {
         const int c = q / C, c2 = q - c * C;
-        double blk[36];
+        if (c == c2) continue;
+        double blk[36];                                                     // the rank-3 part already in `out`: all loads in flight together
 #pragma unroll
-        for (int i = 0; i < 36; ++i) blk[i] = 0.0;
-        double bb[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
-        if (c == c2) {
-            for (int a = 0; a < C; ++a) {
-                const double* S = Sg + ((size_t)c * CMAX + a) * GB_SW;          // obs at slot c, anchor a
-                const double* Sa = Sg + ((size_t)a * CMAX + c) * GB_SW;         // obs at slot a, anchor c
+        for (int m = 0; m < 6; ++m)
 #pragma unroll
-                for (int m = 0; m < 3; ++m)
+            for (int k = 0; k < 6; ++k) blk[6 * m + k] = (m >= 3 && k >= 3) ? 0.0 : out[(size_t)(6 * c + m) * (ncol + 1) + 6 * c2 + k];
+        const double* S = Sg + ((size_t)c * CMAX + c2) * GB_SW;             // obs at slot c, anchor c2
+        const double* St = Sg + ((size_t)c2 * CMAX + c) * GB_SW;            // obs at slot c2, anchor c
+        double s1[9], st1[9], s2[9], st2[9];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        blk[6 * m + k] += S[3 * m + k] + Sa[3 * m + k];
-                        blk[6 * m + 3 + k] -= S[9 + 3 * k + m];            // (theta,p) = -NXs^T
-                        blk[6 * (3 + m) + k] -= S[9 + 3 * m + k];          // (p,theta) = -NXs
-                        blk[6 * (3 + m) + 3 + k] += S[21 + 3 * m + k];
-                    }
+        for (int i = 0; i < 9; ++i) { s1[i] = S[i]; st1[i] = St[i]; s2[i] = S[9 + i]; st2[i] = St[9 + i]; }
 #pragma unroll
-                for (int m = 0; m < 3; ++m) { bb[m] += S[18 + m] - Sa[18 + m]; bb[3 + m] -= S[30 + m]; }
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                blk[6 * m + k] += -s1[3 * m + k] - st1[3 * m + k];
+                blk[6 * (3 + m) + k] += s2[3 * m + k];
+                blk[6 * m + 3 + k] += st2[3 * k + m];
             }
-        } else {
-            const double* S = Sg + ((size_t)c * CMAX + c2) * GB_SW;             // obs at slot c, anchor c2
-            const double* St = Sg + ((size_t)c2 * CMAX + c) * GB_SW;            // obs at slot c2, anchor c
-#pragma unroll
-            for (int m = 0; m < 3; ++m)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    blk[6 * m + k] = -S[3 * m + k] - St[3 * m + k];
-                    blk[6 * (3 + m) + k] = S[9 + 3 * m + k];
-                    blk[6 * m + 3 + k] = St[9 + 3 * k + m];
-                }
-        }
 #pragma unroll
         for (int m = 0; m < 6; ++m) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) out[(size_t)(6 * c + m) * (ncol + 1) + 6 * c2 + k] += blk[6 * m + k];
-            if (c == c2) out[(size_t)(6 * c + m) * (ncol + 1) + ncol] += bb[m];
+            for (int k = 0; k < 6; ++k)
+                if (m < 3 || k < 3) out[(size_t)(6 * c + m) * (ncol + 1) + 6 * c2 + k] = blk[6 * m + k];      // the (p, p) quarter gets nothing here
         }
     }
     if (tid == 0) chunk_used[bl * G + g] = max(0, q1 - q0);
+    dbg_stamp(52);
 }
 
 // ---------------------------------------------------------------------------------------------
