@@ -1945,6 +1945,11 @@ int ingvio_debug_read(ingvio_ctx* c, long long* out, int n)
     if (dbg_read_factored(a, 64) || dbg_read_cov(bq, 64) || dbg_read_bigwin(cq, 64) || dbg_read_solve(sq, 64)) return INGVIO_E_HIP;
     long long hq[64];
     if (dbg_read_chol(hq, 64)) return INGVIO_E_HIP;
+    if (const char* e = getenv("INGVIO_DBG_TU")) {                     // debugging: all slots of one translation unit
+        const long long* src = e[0] == 'b' ? cq : (e[0] == 'c' ? hq : (e[0] == 's' ? sq : a));
+        for (int i = 0; i < n; ++i) out[i] = src[i];
+        return INGVIO_OK;
+    }
     for (int i = 0; i < n; ++i)      // 16..23 cov, 24..31 the symmetric solve (its slots 0..7), 48..55 large-window TU, 56..63 kernels_chol (0..7)
         out[i] = i >= 56 ? hq[i - 56] : (i >= 48 ? cq[i] : ((i >= 24 && i < 32) ? sq[i - 24] : ((i < 16 || i >= 32) ? a[i] : bq[i])));
     return INGVIO_OK;
