@@ -400,9 +400,18 @@ __global__ __launch_bounds__(256) void k_chol_carried(CholArgs a)
     const double* W = a.W + (size_t)batch * a.xs;
     double* Y = a.Y + (size_t)batch * a.xs;
     const double* Tb = a.Tb + (size_t)batch * a.ts;
-    for (int e = tid; e < 32 * a.ncols; e += 256) {
-        const int r = e & 31, c = e >> 5;
-        sRow[r * lds + c] = W[(size_t)(32 * i + r) + (size_t)c * ld];
+    for (int e0 = tid; e0 < 32 * a.ncols; e0 += 256 * 8) {                 // eight loads in flight per thread (ncols a multiple of 32)
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 256 * u, r = e & 31, c = min(e >> 5, a.ncols - 1);
+            v[u] = W[(size_t)(32 * i + r) + (size_t)c * ld];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 256 * u, r = e & 31, c = e >> 5;
+            if (c < a.ncols) sRow[r * lds + c] = v[u];
+        }
     }
     __syncthreads();
     double tn[4];                                                          // T of the next panel, in flight during this one
