@@ -220,8 +220,9 @@ __global__ __launch_bounds__(LMB_NT) void k_lm_build(CovView cv, LmView lv, LmOp
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lm_products(CovView cv, int b0, const double* __restrict__ Hc_all, size_t hstride,
                                                      const int* __restrict__ cidx_all, const int* __restrict__ m_all, int per, double var,
-                                                     double* __restrict__ X_all, size_t xstride, int ldx, int m_cap, int n_rows)
+                                                     double* __restrict__ X_all, size_t xstride, int ldx, int m_cap, int n_rows, int use_lds)
 {
+    extern __shared__ __attribute__((aligned(16))) double sY[];          // [16][n_rows] when it fits: the group's columns of P H^T for phase B
     const int bl = blockIdx.y, b = b0 + bl, m = m_all[bl];
     if (m == 0) return;
     const int g = blockIdx.x, tid = threadIdx.x;
@@ -252,6 +253,11 @@ __global__ __launch_bounds__(256) void k_lm_products(CovView cv, int b0, const d
                 Yc[(size_t)r + (size_t)Ra * ldx] = y0;
                 Yc[(size_t)r + (size_t)(Ra + 1) * ldx] = y1;
                 if (per == 4) { Yc[(size_t)r + (size_t)(Ra + 2) * ldx] = y2; Yc[(size_t)r + (size_t)(Ra + 3) * ldx] = y3; }
+                if (use_lds) {
+                    double* sy = sY + (size_t)(per * q4) * n_rows + r;
+                    sy[0] = y0; sy[n_rows] = y1;
+                    if (per == 4) { sy[2 * (size_t)n_rows] = y2; sy[3 * (size_t)n_rows] = y3; }
+                }
             } else {
                 for (int q = 0; q < per; ++q) Yc[(size_t)r + (size_t)(Ra + q) * ldx] = 0.0;      // padding column / rows beyond the state
             }
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(256) void k_lm_products(CovView cv, int b0, const d
         for (int R = R0; R < R1; ++R) {
             double s = 0.0;
             if (live && R < m) {
-                const double* y = Yc + (size_t)R * ldx;
+                const double* y = use_lds ? sY + (size_t)(R - R0) * n_rows : Yc + (size_t)R * ldx;
 #pragma unroll
                 for (int c = 0; c < 24; ++c) {
                     const int col = c < 9 ? k0 + c : (c < 15 ? k1 + c - 9 : (c < 21 ? k2 + c - 15 : k3 + c - 21));
@@ -334,8 +340,12 @@ void launch_lm_build(const LmBuild& L, hipStream_t st)
     hipLaunchKernelGGL(k_lm_build, dim3(L.nb), dim3(LMB_NT), 0, st, L.cv, L.lv, L.op, L.b0, L.Hd, L.hstride, L.n_ld, L.m_cap, L.X, L.xstride,
                        L.ldx, L.res_row, L.gamma, L.accept, L.m_out, L.dx, L.cidx);
     const int per4 = (L.op.stereo ? 4 : 2) * 4;
-    hipLaunchKernelGGL(k_lm_products, dim3((L.m_cap + per4 - 1) / per4, L.nb), dim3(256), 0, st, L.cv, L.b0, L.Hd, L.hstride, L.cidx, L.m_out, L.op.stereo ? 4 : 2, L.op.var,
-                       L.X, L.xstride, L.ldx, L.m_cap, L.n_rows);
+    const size_t lds = sizeof(double) * 16 * (size_t)L.n_rows;
+    const int use_lds = lds <= 64 * 1024;
+    static size_t attr = 0;
+    if (use_lds && lds > attr) { hipFuncSetAttribute((const void*)k_lm_products, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; }
+    hipLaunchKernelGGL(k_lm_products, dim3((L.m_cap + per4 - 1) / per4, L.nb), dim3(256), use_lds ? lds : 0, st, L.cv, L.b0, L.Hd, L.hstride, L.cidx, L.m_out, L.op.stereo ? 4 : 2, L.op.var,
+                       L.X, L.xstride, L.ldx, L.m_cap, L.n_rows, use_lds);
 }
 
 void launch_lm_finish(CovView cv, int b0, int nb, const double* Y, size_t ystride, int ldy, int y_row0, int z_row, const int* m, double* dx,
