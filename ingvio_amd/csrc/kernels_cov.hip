@@ -264,6 +264,7 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
         double (*sJP)[21] = reinterpret_cast<double (*)[21]>(sAll);
         augment_filter<PROP_THREADS>(cv, b, augR + bl * 9, sJP);
     }
+    dbg_stamp(22);
 }
 
 // ---------------------------------------------------------------------------------------------
