@@ -56,6 +56,15 @@ __device__ __forceinline__ double wave_sum(double x)
     return x;
 }
 
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() is a workgroup-scope release/acquire fence around
+// s_barrier: it also waits for the thread's outstanding GLOBAL loads and stores (s_waitcnt vmcnt(0)) - after a phase that stores
+// results to HBM that is microseconds of store latency per barrier for nothing (k_propagate's fused clone: 42 k -> 8 k cycles).
+// Use only where no thread reads GLOBAL memory another thread of the workgroup wrote before the barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // 1/x to full FP64 precision: v_rcp_f64 + two Newton steps (the IEEE division expands to ~3x the latency)
 __device__ __forceinline__ double fast_rcp(double x)
 {

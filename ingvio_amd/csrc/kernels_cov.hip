@@ -78,6 +78,13 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
     __shared__ double sDt[64];
     __shared__ double sQg[26];                                  // GNSS clock block of the composed step (+ total time), from the compose loop's idle thread
 
+    // fused clone: P[c, 15..20] (extrinsics columns: never in the active set) of this thread's row, untouched by the propagation
+    // when the row is outside the active set - requested now, used at the very end
+    double qpre[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+    if (augR && tid < n) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) qpre[j] = P[tid + (size_t)(15 + j) * ld];
+    }
     dbg_stamp(16);
     if (tid < 225) { sPhi[tid] = (tid % 15 == tid / 15) ? 1.0 : 0.0; sQ[tid] = 0.0; }
     const double* PhiB = Phi + (size_t)bl * k * 225;
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
             sStrip[a * (PROP_THREADS + 1) + tid] = o;
         }
     }
-    __syncthreads();
+    lds_barrier();
     // upper strip = transpose (:89): lanes run along the active index a so that each store instruction
     // covers 16-element row segments instead of 64 different columns
     {
@@ -236,21 +243,21 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
             const int a = e / na, c = e % na;
             sX[a * NA_MAX + c] = P[sA[a] + (size_t)sA[c] * ld];
         }
-        __syncthreads();
+        lds_barrier();
         for (int e = tid; e < na * na; e += PROP_THREADS) {
             const int a = e / na, c = e % na;
             double acc = 0.0;
             for (int l = 0; l < na; ++l) acc += sPhiA[a * NA_MAX + l] * sX[l * NA_MAX + c];
             sY[a * NA_MAX + c] = acc;
         }
-        __syncthreads();
+        lds_barrier();
         for (int e = tid; e < na * na; e += PROP_THREADS) {
             const int a = e / na, c = e % na;
             double acc = 0.0;
             for (int l = 0; l < na; ++l) acc += sY[a * NA_MAX + l] * sPhiA[c * NA_MAX + l];
             sX[a * NA_MAX + c] = acc + sQA[a * NA_MAX + c];
         }
-        __syncthreads();
+        lds_barrier();
         for (int e = tid; e < na * na; e += PROP_THREADS) {
             const int a = e / na, c = e % na;
             P[sA[a] + (size_t)sA[c] * ld] = 0.5 * (sX[a * NA_MAX + c] + sX[c * NA_MAX + a]);   // :118
@@ -260,9 +267,52 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
     // fused K2 (single-tile launches only: this workgroup owns the whole filter): the clone's rows/columns are built
     // from the just-propagated P[0:21, :]
     if (augR) {
-        __syncthreads();
-        double (*sJP)[21] = reinterpret_cast<double (*)[21]>(sAll);
-        augment_filter<PROP_THREADS>(cv, b, augR + bl * 9, sJP);
+        // StateManager::augmentSlidingWindowPose (StateManager.cpp:279-293) from what this workgroup still holds: the new strip
+        // (sStrip: P[r, A] of the rows outside A), the new A x A block (sX, before symmetrisation) and the prefetched extrinsics
+        // columns - re-reading the rows it has just stored cost a store -> load round trip (43 k of the kernel's 145 k cycles)
+        lds_barrier();
+        double (*sJP)[21] = reinterpret_cast<double (*)[21]>(sT1);          // 6 x 21 <= 225
+        double R[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = augR[bl * 9 + i];
+        const int c = tid;
+        if (c < n) {
+            int ac = c < 15 ? c : -1;
+            for (int q = 15; q < na; ++q) if (sA[q] == c) ac = q;
+            double e[6], qv[6], jp[6];
+            if (ac < 0) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { e[j] = sStrip[j * (PROP_THREADS + 1) + tid]; qv[j] = qpre[j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    e[j] = 0.5 * (sX[ac * NA_MAX + j] + sX[j * NA_MAX + ac]);              // the symmetrised A x A block (:118)
+                    qv[j] = sStrip[ac * (PROP_THREADS + 1) + 15 + j];                      // P[15 + j, A] of row 15 + j (outside A)
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                jp[i] = e[i] + R[3 * i] * qv[0] + R[3 * i + 1] * qv[1] + R[3 * i + 2] * qv[2];
+                jp[3 + i] = e[3 + i] + R[3 * i] * qv[3] + R[3 * i + 1] * qv[4] + R[3 * i + 2] * qv[5];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                P[c + (size_t)(n + i) * ld] = jp[i];
+                P[(n + i) + (size_t)c * ld] = jp[i];
+                if (c < 21) sJP[i][c] = jp[i];
+            }
+        }
+        lds_barrier();
+        if (tid < 36) {
+            const int i = tid / 6, i2 = tid % 6;
+            auto X = [&](int a, int cc) {            // (J P J^T)[a][cc] = JP[a][:21] . J[cc][:]
+                const int off = cc < 3 ? 15 : 18, rr = cc % 3;
+                return sJP[a][cc] + R[3 * rr] * sJP[a][off] + R[3 * rr + 1] * sJP[a][off + 1] + R[3 * rr + 2] * sJP[a][off + 2];
+            };
+            P[(n + i) + (size_t)(n + i2) * ld] = 0.5 * (X(i, i2) + X(i2, i));      // :293
+        }
+        lds_barrier();
+        if (tid == 0) cv.n[b] = n + 6;
     }
     dbg_stamp(22);
 }

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
                 sp[33] = obs ? (double)a : -1.0;                       // key: the anchor slot this contribution belongs to
             }
         }
-        __syncthreads();
+        lds_barrier();                                          // LDS hand-over only: the next batch's input loads stay in flight
         dbg_stamp(37);
         // ---- P3a: rank-3 part on the matrix cores (next batch's records are fetched meanwhile) -------------
         fetch(qb + GRAM_NB);
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
             }
         }
         dbg_stamp(41);
-        __syncthreads();
+        lds_barrier();                                          // LDS hand-over only: the next batch's input loads stay in flight
     }
 
     dbg_stamp(39);
@@ -730,9 +730,9 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
         }
     };
     stage_load(0);
-    __syncthreads();                                           // every wave is done with sT
+    lds_barrier();                                           // every wave is done with sT
     stage_store(0);
-    __syncthreads();
+    lds_barrier();
     double pv0[4], pv1[4], pn0[4], pn1[4];
     if (nrows > 0) load_p(tiR[0], 0, pv0);
     if (nrows > 1) load_p(tiR[1], 0, pv1);
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
         if (tj < tjmax) stage_store(buf ^ 1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { pv0[r] = pn0[r]; pv1[r] = pn1[r]; }
-        __syncthreads();
+        lds_barrier();
     }
 }
 

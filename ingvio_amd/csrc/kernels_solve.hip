@@ -99,7 +99,7 @@ __device__ __forceinline__ void ldl_sweep(double4_f (&T)[SolveCfg<NC>::RW][Solve
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
             double a[4][4];
 #pragma unroll
             for (int ra = 0; ra < 4; ++ra) {
@@ -170,7 +170,7 @@ __device__ __forceinline__ void ldl_sweep(double4_f (&T)[SolveCfg<NC>::RW][Solve
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 template <int NC>
