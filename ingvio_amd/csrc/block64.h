@@ -2,7 +2,7 @@
 // the two 64-row operand panels are staged through LDS 16 columns of K at a time, so an operand element is read from L2 once per
 // workgroup instead of once per 16 x 16 tile.  loadA(r, k) / loadB(r, k): element k of operand row r (0..63) of this block, zero
 // outside the problem.  Quadrant (wi, wj) = (wave >> 1, wave & 1); the accumulators are the four 16 x 16 tiles of the quadrant in
-// the MFMA C/D layout (lane (kq, l15), reg r <-> row kq + 4 r, column l15).  Every thread must call it (two barriers per K chunk).
+// the MFMA C/D layout (lane (kq, l15), reg r <-> row kq + 4 r, column l15).  Every thread must call it (two LDS barriers per K chunk: the next chunk's global loads stay in flight across them).
 #pragma once
 #include "dev_common.h"
 
@@ -22,10 +22,10 @@ __device__ __forceinline__ void block64_mma(Block64Lds& s, int K, FA loadA, FB l
 #pragma unroll
     for (int u = 0; u < 4; ++u) { va[u] = loadA(sr, sk + 4 * u); vb[u] = loadB(sr, sk + 4 * u); }
     for (int k0 = 0; k0 < K; k0 += 16) {
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int u = 0; u < 4; ++u) { s.a[sk + 4 * u][sr] = va[u]; s.b[sk + 4 * u][sr] = vb[u]; }
-        __syncthreads();
+        lds_barrier();
         if (k0 + 16 < K) {                                               // the next chunk travels under this chunk's MFMAs
 #pragma unroll
             for (int u = 0; u < 4; ++u) { va[u] = loadA(sr, k0 + 16 + sk + 4 * u); vb[u] = loadB(sr, k0 + 16 + sk + 4 * u); }

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
         if (nbf < GB_NB) {
             for (int e = tid; e < (KR - 3 * nbf) * LDW; e += GB_NT) { (&sb.Bm[3 * nbf][0])[e] = 0.0; (&sb.Ym[3 * nbf][0])[e] = 0.0; }
         }
-        __syncthreads();
+        lds_barrier();
         // operand rows B, Y = Ns^-1 B and the sparse scratch, lane = (feature, window slot)
         if (tid < nbf * WAVE) {
             const int f = tid >> 6, c = tid & 63;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
                 sp[33] = obs ? (double)a : -1.0;
             }
         }
-        __syncthreads();
+        lds_barrier();
         fetch(qb + GB_NB);
         const int nst = (3 * nbf + 3) >> 2;
 #pragma unroll
@@ -258,9 +258,10 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 
+    __syncthreads();                                           // the other threads' global sums (Sg) are read below
     dbg_stamp(50);
     // ---- epilogue: [A | b] of the chunk = sparse part - rank-3 part, assembled in global memory ---------------------
     double* out = Apart + ((size_t)bl * G + g) * rstride;      // [ncol][ncol+1] row-major, b in the last column

@@ -142,13 +142,13 @@ __global__ __launch_bounds__(256) void k_gram_tn(const double* __restrict__ H, i
     if (c_lo < c_hi) fetch(c_lo);
 #pragma unroll 1
     for (int ch = c_lo; ch < c_hi; ++ch) {
-        __syncthreads();                                                 // the previous chunk's fragments have been read
+        lds_barrier();                                                 // the previous chunk's fragments have been read
 #pragma unroll
         for (int u = 0; u < 8; u += 2) {
             *reinterpret_cast<double2*>(&sA[col][kseg + u]) = make_double2(ra[u], ra[u + 1]);
             if (!diag) *reinterpret_cast<double2*>(&sB[col][kseg + u]) = make_double2(rb[u], rb[u + 1]);
         }
-        __syncthreads();
+        lds_barrier();
         if (ch + 1 < c_hi) fetch(ch + 1);
         const double (*sBB)[GR_S] = diag ? sA : sB;
 #pragma unroll
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_chol_step(CholArgs a, int k)
 #pragma unroll
         for (int r = 0; r < 4; ++r) cacc[r] = Cij[(size_t)(kq + 4 * r) + (size_t)l15 * ld];
     }
-    __syncthreads();
+    lds_barrier();
     // Y_i (and Y_j) on the matrix cores: tile (ti, tj) of U T
     {
         double4_f yi = { 0, 0, 0, 0 }, yj = { 0, 0, 0, 0 };
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_chol_step(CholArgs a, int k)
             sDI[32 + 16 * ti + kq + 4 * r][16 * tj + l15] = diag ? yi[r] : yj[r];
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (tail_only || j == k + 1) {                                       // this workgroup owns the output of block row i
         double* Yo = Y + (size_t)32 * i + (size_t)(32 * k) * ld;
         for (int e = tid; e < 1024; e += 256) { const int r = e & 31, c = e >> 5; Yo[(size_t)r + (size_t)c * ld] = sDI[r][c]; }
@@ -365,11 +365,11 @@ __global__ __launch_bounds__(256) void k_chol_step(CholArgs a, int k)
         return;
     }
     // the next diagonal block: factorise it now (its updated value is final), T_k+1 for the next launch
-    __syncthreads();                                                     // every wave is done reading Y_i / Y_j from sDI
+    lds_barrier();                                                     // every wave is done reading Y_i / Y_j from sDI
 #pragma unroll
     for (int r = 0; r < 4; ++r) sDI[16 * ti + kq + 4 * r][16 * tj + l15] = cacc[r];
     for (int e = tid; e < 1024; e += 256) { const int r = e & 31, c = e >> 5; sDI[32 + r][c] = r == c ? 1.0 : 0.0; }
-    __syncthreads();
+    lds_barrier();
     if (wave != 0) return;
     const double* od = Tb + (size_t)a.t_slots * 1024;
     const double floorv = a.clamp ? a.clamp_rel * od[32 * j + (lane & 31)] : 0.0;
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void k_chol_carried(CholArgs a)
             if (c < a.ncols) sRow[r * lds + c] = v[u];
         }
     }
-    __syncthreads();
+    lds_barrier();
     double tn[4];                                                          // T of the next panel, in flight during this one
 #pragma unroll
     for (int u = 0; u < 4; ++u) tn[u] = Tb[tid + 256 * u];
@@ -448,14 +448,14 @@ __global__ __launch_bounds__(256) void k_chol_carried(CholArgs a)
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) sU[16 * ti + kq + 4 * r][16 * tj + l15] = acc[r];
-        __syncthreads();
+        lds_barrier();
         double4_f y = { 0, 0, 0, 0 };
 #pragma unroll
         for (int k4 = 0; k4 < 8; ++k4)
             y = __builtin_amdgcn_mfma_f64_16x16x4f64(sU[16 * ti + l15][4 * k4 + kq], sT[4 * k4 + kq][16 * tj + l15], y, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) sRow[(16 * ti + kq + 4 * r) * lds + 32 * k + 16 * tj + l15] = y[r];
-        __syncthreads();
+        lds_barrier();
     }
     for (int e = tid; e < 32 * a.ncols; e += 256) {
         const int r = e & 31, c = e >> 5;
