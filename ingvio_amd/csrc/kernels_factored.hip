@@ -642,6 +642,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     auto alive = [&](int i) { return !(fused && i >= midx && i < midx + msize); };
     auto remap = [&](int i) { return (fused && i >= midx) ? i - msize : i; };
 
+    dbg_stamp(11);
     // ---- T rows of this wave's (up to) two tile rows, kept as A-operand fragments ------------------------------
     double tfrag[2][K4];
     if (upd) {
@@ -683,6 +684,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
         }
     }
 
+    dbg_stamp(12);
     // ---- tiles (ti, tj): all waves walk tj together; the B tile is staged in LDS once for the four waves ----------
     constexpr int STG = (MP * 16 + 255) / 256;
     double stg[STG];
@@ -768,6 +770,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
         for (int r = 0; r < 4; ++r) { pv0[r] = pn0[r]; pv1[r] = pn1[r]; }
         lds_barrier();
     }
+    dbg_stamp(13);
 }
 
 // ---------------------------------------------------------------------------------------------

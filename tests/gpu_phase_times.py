@@ -19,3 +19,5 @@ seg("gate3 [front, barrier, pair blocks + tile fill, LDL, border + gate]", [5, 6
 seg("gram2 prologue", [32, 33]); seg("gram2 last batch [P0(store+barrier),P2,P3a,P3b]", [34, 35, 37, 38, 41]); seg("gram2 epilogue", [39, 40]); seg("gram2 total", [32, 40])
 seg("propagate [fetch, compose,gnss,strip,AA,fused clone]", [16, 21, 17, 18, 19, 20, 22])
 seg("info_solve [deal+load, sweep1, R2+G1, G2, sweep2, G3, Pc copy]", [24, 25, 26, 27, 28, 29, 30, 31])
+seg("info_apply [setup, T = Pc M, tile loop]", [11, 12, 13]) if False else None
+print("info_apply [T = Pc M, tile loop]", [d[12] - d[11], d[13] - d[12]])
