@@ -68,7 +68,7 @@ struct Gram2Batch {
     using Cfg = Gram2Cfg<CMAX>;
     double Bm[Cfg::KR][Cfg::LDW];
     double Ym[Cfg::KR][Cfg::LDW];
-    double sp[GRAM_NB][CMAX][Cfg::SPW];
+    double sp[CMAX * CMAX <= 128 ? 2 : 1][GRAM_NB][CMAX][Cfg::SPW];      // double-buffered when P3b runs beside the next batch's P2
 };
 template <int CMAX>
 struct Gram2Out {
@@ -142,8 +142,10 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
 #pragma unroll
     for (int u = 0; u < TPW; ++u) acc[u] = double4_f{ 0.0, 0.0, 0.0, 0.0 };
     // sparse accumulators of lane (c, a)
-    const int pc = tid / CMAX, pa = tid - pc * CMAX;
-    const bool pairlane = tid < CMAX * CMAX;
+    constexpr bool OVL = CMAX * CMAX <= 128;                 // pair lanes fit waves 2-3: P3b overlaps the next batch's P2
+    const int ptid = OVL ? tid - 128 : tid;
+    const int pc = ptid >= 0 ? ptid / CMAX : 0, pa = ptid >= 0 ? ptid - pc * CMAX : 0;
+    const bool pairlane = ptid >= 0 && ptid < CMAX * CMAX;
     double sS1[9], sNX[9], sS3[9], s4[3], s5[3];
 #pragma unroll
     for (int i = 0; i < 9; ++i) { sS1[i] = 0.0; sNX[i] = 0.0; sS3[i] = 0.0; }
@@ -183,11 +185,14 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
         return v;
     };
     fetch(q0);
-    for (int qb = q0; qb < q1; qb += GRAM_NB) {
+    // P2 (operand rows + sparse scratch of one batch, lanes (feature, slot) of waves 0-1), P3a (rank-3 part, all waves), P3b (sparse
+    // sums, pair lanes).  Window classes with at most 128 (slot, anchor) pairs put the pair lanes on waves 2-3 and double-buffer the
+    // sparse scratch, so that P3b of batch i runs BESIDE P2 of batch i+1 instead of after it (P2 6.3 k, P3b 3.5 k of a batch's 14.8 k cycles).
+    auto do_p2 = [&](int qb, int buf, int nthr) {              // nthr: threads that make the call (256, or the 128 of waves 0-1)
         const int nbf = min(GRAM_NB, q1 - qb);
         dbg_stamp(34);
         if (nbf < GRAM_NB) {                                   // short last batch: clear the unused stacked rows
-            for (int e = tid; e < (KR - 3 * nbf) * LDW; e += GRAM_NT) { (&sb.Bm[3 * nbf][0])[e] = 0.0; (&sb.Ym[3 * nbf][0])[e] = 0.0; }
+            for (int e = tid; e < (KR - 3 * nbf) * LDW; e += nthr) { (&sb.Bm[3 * nbf][0])[e] = 0.0; (&sb.Ym[3 * nbf][0])[e] = 0.0; }
         }
         dbg_stamp(35);
         // ---- P2: operand rows B, Y = Ns^-1 B and the sparse scratch, lane = (feature, window slot) -----
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
                     for (int k = 0; k < 3; ++k) sb.Bm[3 * f + k][NC] = hs[k];      // extra column: hs
                 }
                 // sparse scratch
-                double* sp = sb.sp[f][c < CMAX ? c : 0];
+                double* sp = sb.sp[buf][f][c < CMAX ? c : 0];
                 double S1[9];
                 mulXt(NX, px, py, pz, S1);                          // X^T N X
 #pragma unroll
@@ -278,10 +283,10 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
                 sp[33] = obs ? (double)a : -1.0;                       // key: the anchor slot this contribution belongs to
             }
         }
-        lds_barrier();                                          // LDS hand-over only: the next batch's input loads stay in flight
-        dbg_stamp(37);
+    };
+    auto do_p3a = [&](int qb) {
+        const int nbf = min(GRAM_NB, q1 - qb);
         // ---- P3a: rank-3 part on the matrix cores (next batch's records are fetched meanwhile) -------------
-        fetch(qb + GRAM_NB);
         const int nst = (3 * nbf + 3) >> 2;
 #pragma unroll
         for (int st = 0; st < KR / 4; ++st) {                // fully unrolled: the fragment reads of the later steps are
@@ -297,13 +302,15 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
                 }
             }
         }
-        dbg_stamp(38);
+    };
+    auto do_p3b = [&](int qb, int buf) {
+        const int nbf = min(GRAM_NB, q1 - qb);
         // ---- P3b: sparse part, lane (c, a): branch-free, one level of LDS reads (the key says whose anchor it is) ----
         if (pairlane) {
 #pragma unroll
             for (int f = 0; f < GRAM_NB; ++f) {
                 if (f < nbf) {
-                    const double* sp = sb.sp[f][pc];
+                    const double* sp = sb.sp[buf][f][pc];
                     const double m = sp[33] == (double)pa ? 1.0 : 0.0;
 #pragma unroll
                     for (int i = 0; i < 9; ++i) { sS1[i] = fma(m, sp[i], sS1[i]); sNX[i] = fma(m, sp[9 + i], sNX[i]); sS3[i] = fma(m, sp[21 + i], sS3[i]); }
@@ -312,8 +319,27 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
                 }
             }
         }
-        dbg_stamp(41);
-        lds_barrier();                                          // LDS hand-over only: the next batch's input loads stay in flight
+    };
+    if (OVL) {
+        if (q0 < q1) { do_p2(q0, 0, GRAM_NT); fetch(q0 + GRAM_NB); }
+        lds_barrier();
+        int it = 0;
+        for (int qb = q0; qb < q1; qb += GRAM_NB, ++it) {
+            do_p3a(qb);
+            lds_barrier();                                      // every wave is done with this batch's operand rows
+            if (wave < 2) { if (qb + GRAM_NB < q1) { do_p2(qb + GRAM_NB, (it + 1) & 1, 128); fetch(qb + 2 * GRAM_NB); } }
+            else do_p3b(qb, it & 1);
+            lds_barrier();
+        }
+    } else {
+        for (int qb = q0; qb < q1; qb += GRAM_NB) {
+            do_p2(qb, 0, GRAM_NT);
+            lds_barrier();                                      // LDS hand-over only: the next batch's input loads stay in flight
+            fetch(qb + GRAM_NB);
+            do_p3a(qb);
+            do_p3b(qb, 0);
+            lds_barrier();
+        }
     }
 
     dbg_stamp(39);
