@@ -54,15 +54,11 @@ void ImuPropagator::storeImu(const ImuCtrl& imu_ctrl)
 void ImuPropagator::stateAndCovTransition(std::shared_ptr<State> state, const ImuCtrl& imu_ctrl, double dt,
                                           double Phi[225], double G[180], bool isAnalytic)
 {
-    if (!isAnalytic && !_warned_rk4) {           // said once, not 200-400 times per second
-        std::cout << "[ImuPropagator]: RK4 branch (ImuPropagator.cpp:163-229) is not carried by the shim; using the analytic one." << std::endl;
-        _warned_rk4 = true;
-    }
     Mat3d R = state->_extended_pose->valueLinearAsMat();
     Vec3d p = state->_extended_pose->valueTrans1(), v = state->_extended_pose->valueTrans2();
     state->_timestamp += dt;                                                                  // :124
-    imuTransitionAnalytic(R, p, v, state->_bg->value(), state->_ba->value(), imu_ctrl._gyro_raw, imu_ctrl._accel_raw,
-                          _gravity, dt, Phi, G);
+    (isAnalytic ? imuTransitionAnalytic : imuTransitionRK4)(R, p, v, state->_bg->value(), state->_ba->value(), imu_ctrl._gyro_raw,
+                                                            imu_ctrl._accel_raw, _gravity, dt, Phi, G);   // :119-162 | :163-229
     state->_extended_pose->setValueLinearByMat(R);
     state->_extended_pose->setValueTrans1(p);
     state->_extended_pose->setValueTrans2(v);

@@ -36,13 +36,12 @@ public:
 
     void storeImu(const ImuCtrl& imu_ctrl);                                                   // ImuPropagator.cpp:29-70
     void stateAndCovTransition(std::shared_ptr<State> state, const ImuCtrl& imu_ctrl, double dt,
-                               double Phi[225], double G[180], bool isAnalytic = true);        // :98-230 (analytic)
+                               double Phi[225], double G[180], bool isAnalytic = true);        // :98-230 (both branches)
     void propagateUntil(std::shared_ptr<State> state, double t_end, bool isAnalytic = true);  // :232-292
     void propagateAugmentAtEnd(std::shared_ptr<State> state, double t_end, bool isAnalytic = true);   // :294-314
     void propagateToExpectedPoseAndAugment(std::shared_ptr<State> state, double t_end, const Mat3d& R_i2w, const Vec3d& p_i2w);   // :316-334
 
     bool isInit() const { return _has_gravity_set; }
-    bool _warned_rk4 = false;
     const Vec3d& getGravity() const { return _gravity; }
     const Quatd& getInitQuat() const { return _quat_init; }
     size_t bufferSize() const { return _imu_ctrl_buffer.size(); }

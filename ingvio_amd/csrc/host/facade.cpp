@@ -20,6 +20,19 @@ void ingvio_host_imu_transition(double* R, double* p, double* v, const double* b
     for (int i = 0; i < 3; ++i) { p[i] = pv[i]; v[i] = vv[i]; }
 }
 
+// The same for the isAnalytic == false branch (ImuPropagator.cpp:163-229).
+void ingvio_host_imu_transition_rk4(double* R, double* p, double* v, const double* bg, const double* ba,
+                                    const double* gyro, const double* acc, const double* gravity, double dt,
+                                    double* Phi, double* G)
+{
+    ingvio::Mat3d Rm(R);
+    ingvio::Vec3d pv(p), vv(v);
+    ingvio::imuTransitionRK4(Rm, pv, vv, ingvio::Vec3d(bg), ingvio::Vec3d(ba), ingvio::Vec3d(gyro),
+                             ingvio::Vec3d(acc), ingvio::Vec3d(gravity), dt, Phi, G);
+    for (int i = 0; i < 9; ++i) R[i] = Rm.m[i];
+    for (int i = 0; i < 3; ++i) { p[i] = pv[i]; v[i] = vv[i]; }
+}
+
 void ingvio_host_gamma(const double* vec, int m, double* out)
 {
     const ingvio::Mat3d g = ingvio::GammaFunc(ingvio::Vec3d(vec), m);

@@ -35,12 +35,14 @@ def gamma(v, m=0):
     return out.reshape(3, 3)
 
 
-def imu_transition(R, p, v, bg, ba, gyro, acc, gravity, dt):
-    """ImuPropagator::stateAndCovTransition (analytic).  Returns (R', p', v', Phi[15,15], G[15,12])."""
+def imu_transition(R, p, v, bg, ba, gyro, acc, gravity, dt, analytic=True):
+    """ImuPropagator::stateAndCovTransition (analytic branch, or the RK4 one with analytic=False).
+    Returns (R', p', v', Phi[15,15], G[15,12])."""
     R = _f(R).copy(); p = _f(p).copy(); v = _f(v).copy()
     Phi = np.zeros(225); G = np.zeros(180)
-    lib().ingvio_host_imu_transition(_d(R), _d(p), _d(v), _d(_f(bg)), _d(_f(ba)), _d(_f(gyro)), _d(_f(acc)),
-                                     _d(_f(gravity)), C.c_double(dt), _d(Phi), _d(G))
+    fn = lib().ingvio_host_imu_transition if analytic else lib().ingvio_host_imu_transition_rk4
+    fn(_d(R), _d(p), _d(v), _d(_f(bg)), _d(_f(ba)), _d(_f(gyro)), _d(_f(acc)),
+       _d(_f(gravity)), C.c_double(dt), _d(Phi), _d(G))
     return R, p, v, Phi.reshape(15, 15, order="F"), G.reshape(15, 12, order="F")
 
 

@@ -15,7 +15,7 @@ and, for propagation / cloning / the Kalman update, evaluates the *identities* t
 gtests assert (dense-Phi propagation incl. GNSS clocks TestStateManager.cpp:95-137; [I;J]P[I;J]^T
 :195-255; (I-KH)P :478-557) rather than the algorithm under test.
 
-Usage: python oracle/gen_golden.py   (writes tests/golden/)
+Usage: python oracle/gen_golden.py   (writes tests/golden/; --only-rk4 writes rk4_transition.npz alone)
 """
 import os
 import sys
@@ -108,6 +108,47 @@ def imu_transition_np(R, p, v, bg, ba, gyro, acc, g, dt):
     Phi[6:9, 9:12] = -skew(vn) @ R @ G1 * dt + R @ psi_np(w, a, dt, 1)
     Phi[3:6, 9:12] = -skew(pn) @ R @ G1 * dt + R @ psi_np(w, a, dt, 2)
     return Rn, pn, vn, Phi, G
+
+
+def imu_transition_rk4_np(R, p, v, bg, ba, gyro, acc, g, dt):
+    """ImuPropagator.cpp:163-229 (isAnalytic == false): quaternion mid-point rotations, RK4 on p and v,
+    Phi as the dense third-order Taylor polynomial of F (F built from the state BEFORE the step)."""
+    from scipy.spatial.transform import Rotation
+    w = gyro - bg; a = acc - ba
+    q = Rotation.from_matrix(R)
+    R_half = (q * Rotation.from_rotvec(0.5 * dt * w)).as_matrix()
+    R_full = (q * Rotation.from_rotvec(dt * w)).as_matrix()
+    k1v = R @ a + g; k1p = v
+    k2v = R_half @ a + g; k2p = v + k1v * dt / 2
+    k3v = R_half @ a + g; k3p = v + k2v * dt / 2
+    k4v = R_full @ a + g; k4p = v + k3v * dt
+    vn = v + dt / 6 * (k1v + 2 * k2v + 2 * k3v + k4v)
+    pn = p + dt / 6 * (k1p + 2 * k2p + 2 * k3p + k4p)
+    F = np.zeros((15, 15))
+    F[3:6, 6:9] = np.eye(3); F[6:9, 0:3] = skew(g)
+    F[0:3, 9:12] = -R; F[3:6, 9:12] = -skew(p) @ R; F[6:9, 9:12] = -skew(v) @ R; F[6:9, 12:15] = -R
+    F2 = F @ F / 2.0; F3 = F2 @ F / 3.0
+    Phi = np.eye(15) + F * dt + F2 * dt * dt + F3 * dt ** 3
+    G = np.zeros((15, 12))
+    G[0:3, 0:3] = R; G[3:6, 0:3] = skew(p) @ R; G[6:9, 0:3] = skew(v) @ R; G[6:9, 3:6] = R
+    G[9:12, 6:9] = np.eye(3); G[12:15, 9:12] = np.eye(3)
+    return R_full, pn, vn, Phi, G
+
+
+def main_rk4():
+    """Own seed and own file, so that the other golden files do not move."""
+    rng = np.random.default_rng(20260927)
+    tr = []
+    for i in range(6):
+        R = rand_rot(rng); p = rng.uniform(-5, 5, 3); v = rng.uniform(-2, 2, 3)
+        bg = rng.normal(0, 0.01, 3); ba = rng.normal(0, 0.05, 3)
+        gy = rng.uniform(-1, 1, 3); ac = rng.uniform(-10, 10, 3); dt = [0.005, 0.01, 0.1, 1e-4, 0.05, 0.005][i]
+        if i == 5:
+            gy = bg.copy()          # zero unbiased rate: AngleAxis(0, 0-vector) = identity
+        g = np.array([0, 0, -9.8])
+        Rn, pn, vn, Phi, G = imu_transition_rk4_np(R, p, v, bg, ba, gy, ac, g, dt)
+        tr.append(dict(R=R, p=p, v=v, bg=bg, ba=ba, gyro=gy, acc=ac, g=g, dt=dt, Rn=Rn, pn=pn, vn=vn, Phi=Phi, G=G))
+    save("rk4_transition", **{k: np.stack([t[k] for t in tr]) for k in tr[0]})
 
 
 def rand_spd(rng, n, scale=1.0):
@@ -502,4 +543,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--only-rk4" in sys.argv:
+        main_rk4()
+    else:
+        main()
+        main_rk4()

@@ -388,6 +388,53 @@ static void testChangeAnchoredPose()
     ASSERT_TRUE(StateManager::checkStateContinuity(state));
 }
 
+// TestPropagator.cpp:116-186 (oneStepProp): the analytic and the RK4 branch of stateAndCovTransition from the same state (with a GPS
+// clock and a frequency shift in it); shrinking dt by 10x five times must shrink both the state distance and |Phi1 - Phi2|.
+static void testOneStepProp()
+{
+    IngvioParams fp = params();
+    fp._init_imu_buffer_sp = -1;
+    ImuPropagator ip(fp);
+    const ImuCtrl imu_ctrl(0.0, vrand(), vrand());
+    const Mat3d R0 = rrand(); const Vec3d p0 = vrand(), v0 = vrand(), bg0 = vrand(), ba0 = vrand();
+    auto fresh = [&]() {
+        std::shared_ptr<State> st = std::make_shared<State>(fp);
+        st->_timestamp = 1.0;
+        st->_extended_pose->setValueLinearByMat(R0); st->_extended_pose->setValueTrans1(p0); st->_extended_pose->setValueTrans2(v0);
+        st->_bg->setValue(bg0); st->_ba->setValue(ba0);
+        StateManager::addGNSSVariable(st, State::GPS, 5000, 9.0);
+        StateManager::addGNSSVariable(st, State::FS, 20, 2.0);
+        return st;
+    };
+    auto distance = [](const std::shared_ptr<State>& a, const std::shared_ptr<State>& b) {
+        double s = 0;
+        const Mat3d Ra = a->_extended_pose->valueLinearAsMat(), Rb = b->_extended_pose->valueLinearAsMat();
+        for (int i = 0; i < 9; ++i) s += (Ra.m[i] - Rb.m[i]) * (Ra.m[i] - Rb.m[i]);
+        const Vec3d dp = a->_extended_pose->valueTrans1() - b->_extended_pose->valueTrans1(), dv = a->_extended_pose->valueTrans2() - b->_extended_pose->valueTrans2();
+        for (int i = 0; i < 3; ++i) s += dp[i] * dp[i] + dv[i] * dv[i];
+        const double dc = a->_gnss.at(State::GPS)->value() - b->_gnss.at(State::GPS)->value();
+        return std::sqrt(s + dc * dc + (a->_timestamp - b->_timestamp) * (a->_timestamp - b->_timestamp));
+    };
+    ASSERT_NEAR(distance(fresh(), fresh()), 0.0, 1e-12);
+    double err1 = INFINITY, err2 = INFINITY;
+    for (int i = 0; i < 5; ++i) {
+        std::shared_ptr<State> s1 = fresh(), s2 = fresh();
+        const double dt = std::pow(10.0, -i);
+        double Phi1[225], Phi2[225], G1[180], G2[180];
+        ip.stateAndCovTransition(s1, imu_ctrl, dt, Phi1, G1, true);
+        ip.stateAndCovTransition(s2, imu_ctrl, dt, Phi2, G2, false);
+        ASSERT_NEAR(s1->_gnss.at(State::GPS)->value(), 5000 + 20 * dt, 1e-9);
+        double ePhi = 0, eG = 0;
+        for (int k = 0; k < 225; ++k) ePhi += (Phi1[k] - Phi2[k]) * (Phi1[k] - Phi2[k]);
+        for (int k = 0; k < 180; ++k) eG += (G1[k] - G2[k]) * (G1[k] - G2[k]);
+        const double eS = distance(s1, s2);
+        ASSERT_TRUE(eS < err1);
+        ASSERT_TRUE(std::sqrt(ePhi) < err2);
+        ASSERT_NEAR(eG, 0.0, 1e-24);                  // G is built before the branch (:112-117)
+        err1 = eS; err2 = std::sqrt(ePhi);
+    }
+}
+
 static void testPropagator()      // TestPropagator.cpp:191-259
 {
     IngvioParams fp = params();
@@ -824,7 +871,7 @@ int main()
         { "testState.BasicFuncs", testBasicFuncs }, { "testState.StateAddMargProp", testStateAddMargProp },
         { "StateUpdateTest.augmentPose", testAugmentPose }, { "StateUpdateTest.stateBoxPlus", testStateBoxPlus },
         { "StateUpdateTest.stateCovUpdate", testStateCovUpdate }, { "AddDelayedTest.addVarInv", testAddVarInv }, { "AddDelayedTest.addVar", testAddVar }, { "FeatureInfoManager.changeAnchoredPose", testChangeAnchoredPose },
-        { "TestPropagator.propaUntil+propagateAugment", testPropagator },
+        { "TestPropagator.oneStepProp", testOneStepProp }, { "TestPropagator.propaUntil+propagateAugment", testPropagator },
         { "GnssUpdate.updateTrackedSys", testGnssUpdate }, { "TestTriangulator.mono+stereo", testTriangulator }, { "IngvioFilter.callbacks end-to-end", testFilterEndToEnd },
         { "IngvioFilter.callbacks with GNSS epochs (config 3)", testFilterGnssEndToEnd },
     };

@@ -24,6 +24,33 @@ def test_host_gamma_and_imu_transition_match_golden():
         assert np.abs(Phi - z["tr_Phi"][i]).max() < 1e-11 and np.abs(G - z["tr_G"][i]).max() < 1e-13
 
 
+def test_host_imu_transition_rk4_branch_matches_golden():
+    """stateAndCovTransition(isAnalytic=false) (ImuPropagator.cpp:163-229): the shim's closed-form Phi and matrix mid-point
+    rotations vs the quaternion / dense-Taylor restatement of oracle/gen_golden.py (rk4_transition.npz)."""
+    from ingvio_amd import host
+    z = load_golden("rk4_transition")
+    for i in range(len(z["dt"])):
+        R, p, v, Phi, G = host.imu_transition(z["R"][i], z["p"][i], z["v"][i], z["bg"][i], z["ba"][i], z["gyro"][i],
+                                              z["acc"][i], z["g"][i], float(z["dt"][i]), analytic=False)
+        assert np.abs(R - z["Rn"][i]).max() < 1e-13 and np.abs(p - z["pn"][i]).max() < 1e-12
+        assert np.abs(v - z["vn"][i]).max() < 1e-12
+        assert np.abs(Phi - z["Phi"][i]).max() < 1e-12 and np.abs(G - z["G"][i]).max() < 1e-13
+        # and it is a different integrator than the analytic one (second-order agreement only)
+        Ra, pa, va, Phia, _ = host.imu_transition(z["R"][i], z["p"][i], z["v"][i], z["bg"][i], z["ba"][i], z["gyro"][i],
+                                                  z["acc"][i], z["g"][i], float(z["dt"][i]))
+        assert np.abs(R - Ra).max() < 1e-13 and np.abs(p - pa).max() < 50 * z["dt"][i] ** 3 + 1e-14
+    # TestPropagator.cpp:159-182 (oneStepProp): dt = 1, 0.1, ... 1e-4 — both distances shrink with every step
+    e_state, e_phi = np.inf, np.inf
+    for k in range(5):
+        a = [z[n][0] for n in ("R", "p", "v", "bg", "ba", "gyro", "acc", "g")]
+        Ra, pa, va, Phia, _ = host.imu_transition(*a, 10.0 ** -k)
+        Rr, pr, vr, Phir, _ = host.imu_transition(*a, 10.0 ** -k, analytic=False)
+        es = np.sqrt(((Ra - Rr) ** 2).sum() + ((pa - pr) ** 2).sum() + ((va - vr) ** 2).sum())
+        ep = np.linalg.norm(Phia - Phir)
+        assert es < e_state and ep < e_phi
+        e_state, e_phi = es, ep
+
+
 def test_host_chi2_quantile_matches_boost_values():
     """UpdateBase::setChiSquaredTable (Update.cpp:27-34) without Boost: equals scipy/Boost quantiles."""
     from ingvio_amd import host
