@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libingvio_hip.so")
+LIB_PATH = os.environ.get("INGVIO_HIP_LIB") or os.path.join(_HERE, "lib", "libingvio_hip.so")     # override: build experiments only
 
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int)

@@ -428,7 +428,7 @@ static void testOneStepProp()
         for (int k = 0; k < 225; ++k) ePhi += (Phi1[k] - Phi2[k]) * (Phi1[k] - Phi2[k]);
         for (int k = 0; k < 180; ++k) eG += (G1[k] - G2[k]) * (G1[k] - G2[k]);
         const double eS = distance(s1, s2);
-        ASSERT_TRUE(eS < err1);
+        ASSERT_TRUE(eS < err1 || eS < 1e-14);         // RK4 differs from the exact step by O(dt^4): below FP64 rounding of |p| ~ 1 at dt = 1e-4
         ASSERT_TRUE(std::sqrt(ePhi) < err2);
         ASSERT_NEAR(eG, 0.0, 1e-24);                  // G is built before the branch (:112-117)
         err1 = eS; err2 = std::sqrt(ePhi);
