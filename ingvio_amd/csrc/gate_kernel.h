@@ -87,7 +87,7 @@ struct Gate3Shared {
         double kp[KPK + 16];          // K, packed lower triangle by rows: element (i, j <= i) at i (i + 1) / 2 + j; +16: unclamped reads of padding columns
         double nh[CMAX * 12 + 24];    // before they are built: N_o | h_o per observation and the record's 21 sums
         double pan[16 * NTL][4];      // after the tiles are built: panel exchange of the MFMA elimination
-        double bz[16];                // finally: the 4x4 border block
+        double bz[64];                // finally: the last diagonal tile's leading 8x8 (left-over pivots 0..2 | pad | the 4x4 border block)
     };
     double Rb[CMAX][9];               // per-observation part of Su: R_o = cn X P(th_o,th_a) X^T + pl P(p_o,th_a) X
     double Qb[9];                     // X P(th_a,th_a) X^T
@@ -400,7 +400,12 @@ __device__ __forceinline__ void gate3_body(
         // rows, forms X = R L^-T for them and feeds X (A operand) and -X D^-1 (B operand) to one
         // v_mfma_f64_16x16x4 per trailing tile: no per-element broadcasts at all.
         constexpr int NTL = SH::NTL, KP = SH::KP, NLT = NTL * (NTL + 1) / 2;
-        const int np = D * nobs, npan = (np + 3) >> 2;
+        // np mod 4 left-over pivots that share the LAST tile row with the border (np = 33 for 11 stereo observations) do not get a
+        // panel of their own (one LDS round trip, a diagonal 4x4 factorisation and an MFMA for one real pivot): lane 0 eliminates
+        // them in the scalar tail below, together with the border block.
+        const int np = D * nobs;
+        const bool tail = (np & 3) != 0 && 4 * (np >> 2) >= 16 * (SH::NTL - 1);
+        const int npan = tail ? np >> 2 : (np + 3) >> 2, rem = tail ? np & 3 : 0;
         const int kq = tid >> 4, l15 = tid & 15;
         // Tile fill, branch-free: one (clamped) LDS read + selects per element.  Row classes are compile-time:
         // i = 16 ti + kq + 4 r is a border row exactly for (ti, r) = (NTL-1, 1) (then i - KP = kq), rows past the
@@ -513,12 +518,46 @@ __device__ __forceinline__ void gate3_body(
             }
         }
         dbg_stamp(9);
-        // border block: tile (NTL-1, NTL-1), rows KP..KP+3 = local 4..7 -> r = 1, kq = 0..3; cols local 4..7
-        if (l15 >= 4 && l15 < 8) sh.bz[kq * 4 + (l15 - 4)] = T[NLT - 1][1];
+        // last diagonal tile (NTL-1, NTL-1): local rows 0..2 = left-over pivots (r = 0, kq = 0..2; pads are unit rows), local rows 4..7 =
+        // the border rows KP..KP+3 (r = 1, kq = 0..3); columns alike
+        if (l15 < 8) { sh.bz[kq * 8 + l15] = T[NLT - 1][0]; sh.bz[(4 + kq) * 8 + l15] = T[NLT - 1][1]; }
         wave_sync();
         if (tid == 0) {
+            double Bd[4][4];
+            for (int p = 0; p < 4; ++p) for (int q = 0; q <= p; ++q) Bd[p][q] = sh.bz[(4 + p) * 8 + 4 + q];
+            if (rem > 0) {
+                double Lk[3][3], Cx[4][3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int q = 0; q <= i; ++q) Lk[i][q] = sh.bz[i * 8 + q];
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) Cx[p][q] = sh.bz[(4 + p) * 8 + q];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    if (p < rem) {
+                        const double rp = fast_rcp(Lk[p][p]);
+#pragma unroll
+                        for (int i = p + 1; i < 3; ++i) {
+                            const double l = Lk[i][p] * rp;
+#pragma unroll
+                            for (int q = p + 1; q <= i; ++q) Lk[i][q] -= l * Lk[q][p];
+                        }
+#pragma unroll
+                        for (int bq = 0; bq < 4; ++bq) {
+                            const double l = Cx[bq][p] * rp;
+#pragma unroll
+                            for (int q = p + 1; q < 3; ++q) Cx[bq][q] -= l * Lk[q][p];
+#pragma unroll
+                            for (int q = 0; q <= bq; ++q) Bd[bq][q] -= l * Cx[q][p];
+                        }
+                    }
+                }
+            }
             double W[4][4];
-            for (int p = 0; p < 4; ++p) for (int q = 0; q <= p; ++q) W[p][q] = -sh.bz[p * 4 + q];
+            for (int p = 0; p < 4; ++p) for (int q = 0; q <= p; ++q) W[p][q] = -Bd[p][q];
             const double r1 = fast_rcp(W[1][1]);
             const double l21 = W[2][1] * r1, l31 = W[3][1] * r1;
             const double r2 = fast_rcp(W[2][2] - l21 * W[2][1]);

@@ -431,15 +431,15 @@ __global__ __launch_bounds__(256) void k_restore_strips(CovView cv, const double
     for (int a = 0; a < 15; ++a) A[a] = a;
 #pragma unroll
     for (int g = 0; g < 5; ++g) { const int gi = gnss_idx ? gnss_idx[b * 5 + g] : -1; A[15 + g] = gi >= 0 ? gi : 0; if (gi >= 0) na = 16 + g; }
-    double v[NA_MAX];
+    double v[NA_MAX], w[NA_MAX];                          // both strips in flight before the first store (the kernel is pure latency)
 #pragma unroll
     for (int a = 0; a < NA_MAX; ++a) v[a] = src[r + (size_t)A[a] * ld];
 #pragma unroll
+    for (int a = 0; a < NA_MAX; ++a) w[a] = src[A[a] + (size_t)r * ld];
+#pragma unroll
     for (int a = 0; a < NA_MAX; ++a) if (a < na) dst[r + (size_t)A[a] * ld] = v[a];
 #pragma unroll
-    for (int a = 0; a < NA_MAX; ++a) v[a] = src[A[a] + (size_t)r * ld];
-#pragma unroll
-    for (int a = 0; a < NA_MAX; ++a) if (a < na) dst[A[a] + (size_t)r * ld] = v[a];
+    for (int a = 0; a < NA_MAX; ++a) if (a < na) dst[A[a] + (size_t)r * ld] = w[a];
 }
 __global__ void k_post_restore(CovView cv, const int* __restrict__ n_snap)
 {
