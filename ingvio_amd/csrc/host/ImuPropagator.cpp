@@ -51,6 +51,20 @@ void ImuPropagator::storeImu(const ImuCtrl& imu_ctrl)
     }
 }
 
+// attitude from the mean specific force of the newest num_ctrls samples: the rotation that takes -f to straight down
+bool ImuPropagator::getAvgQuat(Quatd& quat_avg, int num_ctrls)
+{
+    const int n = (int)_imu_ctrl_buffer.size();
+    if (n == 0 || num_ctrls <= 0) { quat_avg = Quatd{ 1, 0, 0, 0 }; return false; }
+    const int first = n - num_ctrls > 0 ? n - num_ctrls : 0;
+    Vec3d sum_sf;
+    for (int i = n - 1; i >= first; --i) sum_sf += _imu_ctrl_buffer[i]._accel_raw;
+    sum_sf = sum_sf * (1.0 / (n - first));
+    sum_sf = sum_sf * (1.0 / sum_sf.norm());
+    quat_avg = fromTwoVectors(-sum_sf, Vec3d(0, 0, -1));
+    return true;
+}
+
 void ImuPropagator::stateAndCovTransition(std::shared_ptr<State> state, const ImuCtrl& imu_ctrl, double dt,
                                           double Phi[225], double G[180], bool isAnalytic)
 {

@@ -44,6 +44,12 @@ public:
     bool isInit() const { return _has_gravity_set; }
     const Vec3d& getGravity() const { return _gravity; }
     const Quatd& getInitQuat() const { return _quat_init; }
+    bool getInitQuat(Quatd& quat_init) const                                                  // ImuPropagator.h:133-145
+    {
+        quat_init = _has_gravity_set ? _quat_init : Quatd{ 1, 0, 0, 0 };
+        return _has_gravity_set;
+    }
+    bool getAvgQuat(Quatd& quat_avg, int num_ctrls = 1);                                      // ImuPropagator.cpp:72-96
     size_t bufferSize() const { return _imu_ctrl_buffer.size(); }
     void setGravityInitialised(const Vec3d& g) { _gravity = g; _has_gravity_set = true; }
     // true (default): the k covariance steps of one propagateUntil call are sent as ONE fused launch;

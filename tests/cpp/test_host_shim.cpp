@@ -388,6 +388,49 @@ static void testChangeAnchoredPose()
     ASSERT_TRUE(StateManager::checkStateContinuity(state));
 }
 
+// TestPropagator.cpp:54-112 (initGravity): 300 constant specific-force samples; with the init buffer on, gravity = (0,0,-|f|) and the
+// initial attitude takes -f onto it; with it off, gravity is the configured one and the attitude is identity; getAvgQuat agrees.
+static void testInitGravity()
+{
+    IngvioParams fp = params();
+    Vec3d sf = vrand();
+    sf = sf * (9.75 / sf.norm());
+    fp._init_imu_buffer_sp = 300;
+    ImuPropagator ip1(fp);
+    fp._init_imu_buffer_sp = -1;
+    ImuPropagator ip2(fp);
+    for (int i = 0; i < 300; ++i) { const ImuCtrl c(0.01 * i, sf, Vec3d(0, 0, 0)); ip1.storeImu(c); ip2.storeImu(c); }
+    auto rotNear = [](const Quatd& a, const Quatd& b) {
+        const Mat3d Ra = rotFromQuat(a), Rb = rotFromQuat(b);
+        double s = 0;
+        for (int i = 0; i < 9; ++i) s += (Ra.m[i] - Rb.m[i]) * (Ra.m[i] - Rb.m[i]);
+        return std::sqrt(s) < 1e-8;
+    };
+    ASSERT_TRUE(ip1.isInit() && ip2.isInit());
+    ASSERT_NEAR((ip1.getGravity() - Vec3d(0, 0, -sf.norm())).norm(), 0.0, 1e-8);
+    ASSERT_NEAR((ip2.getGravity() - Vec3d(0, 0, -fp._init_gravity)).norm(), 0.0, 1e-8);
+    Quatd q1, q2;
+    ASSERT_TRUE(ip1.getInitQuat(q1));
+    ASSERT_TRUE(ip2.getInitQuat(q2));
+    ASSERT_TRUE(rotNear(q2, Quatd{ 1, 0, 0, 0 }));
+    // the reference rotation: takes -sf to (0, 0, -|sf|)
+    const Mat3d R1 = rotFromQuat(q1);
+    ASSERT_NEAR((R1 * (-1.0 * sf) - Vec3d(0, 0, -sf.norm())).norm(), 0.0, 1e-8);
+    for (int i = 1; i < 400; i += 20) {
+        Quatd t1, t2;
+        ASSERT_TRUE(ip1.getAvgQuat(t1, i));
+        ASSERT_TRUE(ip2.getAvgQuat(t2, i));
+        ASSERT_TRUE(rotNear(q1, t1));
+        ASSERT_TRUE(rotNear(q1, t2));
+    }
+    // not steady: the mean specific force is off by more than 2 % -> buffer cleared, not initialised (ImuPropagator.cpp:52-58)
+    fp._init_imu_buffer_sp = 50;
+    ImuPropagator ip3(fp);
+    for (int i = 0; i < 50; ++i) ip3.storeImu(ImuCtrl(0.01 * i, sf * 1.05, Vec3d(0, 0, 0)));
+    Quatd q3;
+    ASSERT_TRUE(!ip3.isInit() && ip3.bufferSize() == 0 && !ip3.getInitQuat(q3) && !ip3.getAvgQuat(q3, 3));
+}
+
 // TestPropagator.cpp:116-186 (oneStepProp): the analytic and the RK4 branch of stateAndCovTransition from the same state (with a GPS
 // clock and a frequency shift in it); shrinking dt by 10x five times must shrink both the state distance and |Phi1 - Phi2|.
 static void testOneStepProp()
@@ -871,7 +914,7 @@ int main()
         { "testState.BasicFuncs", testBasicFuncs }, { "testState.StateAddMargProp", testStateAddMargProp },
         { "StateUpdateTest.augmentPose", testAugmentPose }, { "StateUpdateTest.stateBoxPlus", testStateBoxPlus },
         { "StateUpdateTest.stateCovUpdate", testStateCovUpdate }, { "AddDelayedTest.addVarInv", testAddVarInv }, { "AddDelayedTest.addVar", testAddVar }, { "FeatureInfoManager.changeAnchoredPose", testChangeAnchoredPose },
-        { "TestPropagator.oneStepProp", testOneStepProp }, { "TestPropagator.propaUntil+propagateAugment", testPropagator },
+        { "TestPropagator.initGravity", testInitGravity }, { "TestPropagator.oneStepProp", testOneStepProp }, { "TestPropagator.propaUntil+propagateAugment", testPropagator },
         { "GnssUpdate.updateTrackedSys", testGnssUpdate }, { "TestTriangulator.mono+stereo", testTriangulator }, { "IngvioFilter.callbacks end-to-end", testFilterEndToEnd },
         { "IngvioFilter.callbacks with GNSS epochs (config 3)", testFilterGnssEndToEnd },
     };
