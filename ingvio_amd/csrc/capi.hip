@@ -1532,9 +1532,12 @@ int ingvio_landmark_stage(ingvio_ctx* c, int b0, int nb, const ingvio_landmark_f
         const auto& f = fr[i];
         if (f.n_lm < 0 || f.n_lm > LM_MAX) return INGVIO_E_CAPACITY;
         if (f.n_lm && (!f.lm_idx || !f.anchor_idx || !f.pf || !f.uv || !f.tracked)) return INGVIO_E_ARG;
-        if (f.idx_epose < 0 || f.idx_epose + 9 > c->d.n_max || f.idx_ext < 0 || f.idx_ext + 6 > c->d.n_max) return INGVIO_E_NOT_IN_STATE;
+        // every variable must lie inside the filter's LIVE state at update time (in_frame: the frame step appends the 6-column clone
+        // first), not merely inside the buffer - rows beyond it would read stale covariance
+        const int n_lim = std::min(c->d.n_max, c->h_n[b0 + i] + (o->in_frame ? 6 : 0));
+        if (f.idx_epose < 0 || f.idx_epose + 9 > n_lim || f.idx_ext < 0 || f.idx_ext + 6 > n_lim) return INGVIO_E_NOT_IN_STATE;
         for (int l = 0; l < f.n_lm; ++l)
-            if (f.lm_idx[l] < 0 || f.lm_idx[l] + 3 > c->d.n_max || f.anchor_idx[l] < 0 || f.anchor_idx[l] + 6 > c->d.n_max) return INGVIO_E_NOT_IN_STATE;
+            if (f.lm_idx[l] < 0 || f.lm_idx[l] + 3 > n_lim || f.anchor_idx[l] < 0 || f.anchor_idx[l] + 6 > n_lim) return INGVIO_E_NOT_IN_STATE;
         l_hi = std::max(l_hi, f.n_lm);
     }
     const int B = c->d.batch;
