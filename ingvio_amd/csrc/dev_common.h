@@ -65,7 +65,8 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// 1/x to full FP64 precision: v_rcp_f64 + two Newton steps (the IEEE division expands to ~3x the latency)
+// 1/x to full FP64 precision: v_rcp_f64 + two Newton steps (the IEEE division expands to ~3x the latency).  Measured on MI355X
+// (tests/micro/rcp_f64.hip, 4 M doubles over 2^+-300): v_rcp_f64 alone 4.6e-8 relative, one step 2.2e-15, two steps 1.1e-16.
 __device__ __forceinline__ double fast_rcp(double x)
 {
     double r = __builtin_amdgcn_rcp(x);
