@@ -43,6 +43,8 @@ extern "C" {
 #define INGVIO_E_HIP (-3)            /* HIP runtime error, see ingvio_last_error               */
 #define INGVIO_E_NOT_IN_STATE (-4)   /* StateManager.cpp:157-161 "Marg is not in the current state" */
 #define INGVIO_E_UNSUPPORTED (-5)
+#define INGVIO_E_NOT_PD (-6)         /* the innovation covariance S = H P H^T + R of a generic / landmark update is not positive definite:
+                                        the filter's state is left untouched and its dx is zero */
 
 typedef struct ingvio_ctx ingvio_ctx;
 
@@ -191,9 +193,21 @@ int ingvio_gnss_front_fetch(ingvio_ctx* ctx, int b0, int nb, double* out);
  *   ingvio_info_set(ctx, b, A_sum, ncol, n_accepted_total)
  *   ingvio_frame_run_phase(ctx, 0, 2)         solve + apply + marginalise: identical posterior on every replica
  * phase 0 = ingvio_frame_run.  Factored method only; the accepted-feature cap (max_accept) is a global order and is not
- * supported across shards. */
+ * supported across shards (INGVIO_E_ARG when the staged options carry max_accept > 0 and phase != 0).
+ * Protocol: phase 1 leaves the filters half-stepped (cloned, n + 6, not yet updated); until phase 2 has run, every entry point
+ * that changes or snapshots the covariance — ingvio_frame_run, a second phase 1, ingvio_frame_stage, ingvio_ekf_update, ... —
+ * returns INGVIO_E_ARG; reading (ingvio_cov_get, ingvio_debug_msckf_info, ingvio_frame_fetch) and ingvio_info_set are allowed.
+ * Phase 2 without a pending phase 1 (or twice) is INGVIO_E_ARG.  ingvio_cov_restore abandons a pending split step. */
 int ingvio_frame_run_phase(ingvio_ctx* ctx, int restore_prior, int phase);
 int ingvio_info_set(ingvio_ctx* ctx, int b, const double* A, int ncol, int n_accepted);
+/* The same exchange WITHOUT a host hop: ingvio_info_reduce sums filter b's chunk partials on the device into one contiguous buffer
+ * [A | b | n_accepted] (row-major ncol x (ncol + 1), then the local accepted count as a double; *count = ncol (ncol + 1) + 1) and
+ * returns its DEVICE pointer (valid until the context is destroyed; complete when the call returns).  The caller all-reduces (sum)
+ * the buffer in place over the replicas - ncclAllReduce on the pointer, or torch.distributed on a zero-copy view
+ * (__cuda_array_interface__, ingvio_amd/parallel.py::sharded_frame_update) - and must have that collective finished (stream
+ * synchronised) before ingvio_info_commit, which installs the buffer as the filter's information for phase 2. */
+int ingvio_info_reduce(ingvio_ctx* ctx, int b, double** dev_ptr, int* count, int* ncol_out);
+int ingvio_info_commit(ingvio_ctx* ctx, int b);
 
 /* ---- batched SLAM-landmark update (LandmarkUpdate::updateLandmark{Mono,Stereo}, LandmarkUpdate.cpp:32-149) ----------------
  * For every in-state landmark observed in the current frame: rows against [extended pose | extrinsics | anchor clone | landmark]

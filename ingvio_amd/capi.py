@@ -16,7 +16,7 @@ c_ip = C.POINTER(C.c_int)
 c_up = C.POINTER(C.c_ulonglong)
 
 OK, NO_ROWS, NEG_DIAG, REJECTED = 0, 1, 2, 3
-E_ARG, E_CAPACITY, E_HIP, E_NOT_IN_STATE, E_UNSUPPORTED = -1, -2, -3, -4, -5
+E_ARG, E_CAPACITY, E_HIP, E_NOT_IN_STATE, E_UNSUPPORTED, E_NOT_PD = -1, -2, -3, -4, -5, -6
 R_SCALAR, R_DIAG, R_FULL = 0, 1, 2
 
 EXPORTS = [
@@ -29,6 +29,7 @@ EXPORTS = [
     "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_set_qr_method", "ingvio_landmark_stage", "ingvio_landmark_run",
     "ingvio_landmark_fetch", "ingvio_frame_run_phase", "ingvio_info_set", "ingvio_debug_read", "ingvio_triangulate",
     "ingvio_gnss_front_stage", "ingvio_gnss_front_fetch", "ingvio_gnss_update_batch", "ingvio_gnss_stage", "ingvio_gnss_run", "ingvio_gnss_fetch", "ingvio_mld", "ingvio_debug_msckf_info", "ingvio_debug_info_solution",
+    "ingvio_info_reduce", "ingvio_info_commit",
     "ingvio_chi2_gamma_multi", "ingvio_ekf_update_batch", "ingvio_add_variable_delayed_invertible", "ingvio_add_variable_delayed", "ingvio_replace_var_linear",
 ]
 
@@ -174,7 +175,7 @@ class Context:
         if rc != 0:
             msg = self.L.ingvio_last_error(self.h).decode() if self.h else "no HIP device / library"
             raise IngvioError(rc, msg)
-        self.batch, self.n_max, self.c_max, self.f_max = batch, n_max, c_max, f_max
+        self.batch, self.n_max, self.c_max, self.f_max, self.device = batch, n_max, c_max, f_max, device
         self.ldp = self.L.ingvio_ldp(self.h)
 
     def close(self):
@@ -383,6 +384,16 @@ class Context:
     def frame_run_phase(self, phase, restore_prior=False):
         """1: propagate + clone + gate + Gram of the staged features; 2: solve + apply + marginalise (ingvio_frame_run_phase)"""
         self._chk(self.L.ingvio_frame_run_phase(self.h, int(restore_prior), int(phase)))
+
+    def info_reduce(self, b):
+        """[A | b | n_accepted] of filter b summed over its chunk partials ON THE DEVICE: returns (device pointer, count of
+        doubles, ncol) - the buffer the feature-sharded filter all-reduces in place (ingvio_info_reduce)."""
+        ptr = C.POINTER(C.c_double)(); cnt = C.c_int(0); nc = C.c_int(0)
+        self._chk(self.L.ingvio_info_reduce(self.h, b, C.byref(ptr), C.byref(cnt), C.byref(nc)))
+        return C.cast(ptr, C.c_void_p).value, cnt.value, nc.value
+
+    def info_commit(self, b):
+        self._chk(self.L.ingvio_info_commit(self.h, b))
 
     def info_set(self, b, A, n_accepted):
         A = f64(A)

@@ -96,6 +96,7 @@ struct ingvio_ctx {
         LmOpts op;
         int l_hi = 0, in_frame = 0;
         bool alloc = false, staged = false;
+        std::vector<int> hi;            // per filter: one past the highest state index the staged rows name (re-checked against the live n at run time)
     } lm;
     char* d_multi = nullptr;            // ingvio_chi2_gamma_multi: packed blocks (grown on demand)
     size_t multi_cap = 0;
@@ -106,6 +107,8 @@ struct ingvio_ctx {
     std::vector<int> st_marg;      // per filter marg idx
     std::vector<int> st_cidx_hi;   // per filter: highest staged clone idx (checked against the live state by frame_run)
     bool staged;
+    double* d_xchg = nullptr;      // [B][rstride + 8]: [A | b | n_accepted] of the split step's exchange (ingvio_info_reduce / _commit)
+    bool phase_pending = false;    // ingvio_frame_run_phase(.., 1) ran and (.., 2) has not yet: the filters are half-stepped (n + 6, no update)
     // second set of device input buffers + copy stream (ingvio_frame_stage_async): the inputs of frame i+1 travel over
     // PCIe while frame i computes; the sets swap roles at every asynchronous stage
     struct InputSet {
@@ -182,6 +185,17 @@ struct ProfScope {
 int check_range(ingvio_ctx* c, int b0, int nb)
 {
     if (!c || b0 < 0 || nb < 1 || b0 + nb > c->d.batch) return INGVIO_E_ARG;
+    return 0;
+}
+
+// Entry points that change (or snapshot) the covariance refuse to run between the two halves of a split frame step
+// (ingvio_frame_run_phase 1 -> 2): the filters are half-stepped there (cloned, not yet updated / marginalised).
+static int phase_busy(ingvio_ctx* c)
+{
+    if (c && c->phase_pending) {
+        c->err = "a split frame step is pending: finish it with ingvio_frame_run_phase(ctx, 0, 2) first";
+        return 1;
+    }
     return 0;
 }
 
@@ -581,7 +595,7 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
                      c->gn.H, c->gn.res, c->gn.noise, c->gn.gamma, c->gn.chi2, c->gn.m, c->gn.nc, c->gn.colmap, c->gn.keep,
                      c->gn.feph, c->gn.fobs, c->gn.frcv, c->gn.front,
                      c->dw.Hd, c->dw.X, c->dw.Y, c->dw.Tb, c->dw.noise, c->dw.noiseB, c->dw.m, c->dw.cidx, c->lm.pose, c->lm.pf, c->lm.uv, c->lm.gamma, c->lm.idx, c->lm.n_lm,
-                     c->lm.lm_idx, c->lm.anchor_idx, c->lm.tracked, c->lm.accept, c->lm.dx };
+                     c->lm.lm_idx, c->lm.anchor_idx, c->lm.tracked, c->lm.accept, c->lm.dx, c->d_xchg };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& sl : c->pin) { if (sl.p) hipHostFree(sl.p); if (sl.ev) hipEventDestroy(sl.ev); }
     if (c->qr.exec) hipGraphExecDestroy(c->qr.exec);
@@ -615,6 +629,7 @@ int ingvio_f_max(ingvio_ctx* c) { return c ? c->d.f_max : 0; }
 
 int ingvio_cov_set(ingvio_ctx* c, int b, const double* P, int ld, int n)
 {
+    if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b, 1) || !P || n < 0 || n > c->d.n_max || ld < n) return INGVIO_E_ARG;
     double* dst = c->Pbase + ((size_t)c->h_cur[b] * c->d.batch + b) * (size_t)c->ldp * c->ldp;
     if (n) HIPCHK(c, hipMemcpy2DAsync(dst, 8 * (size_t)c->ldp, P, 8 * (size_t)ld, 8 * (size_t)n, n, hipMemcpyHostToDevice, c->st));
@@ -667,6 +682,7 @@ int ingvio_cov_get_marginal(ingvio_ctx* c, int b, const int* vidx, const int* vs
 
 int ingvio_cov_snapshot(ingvio_ctx* c)
 {
+    if (phase_busy(c)) return INGVIO_E_ARG;
     if (!c) return INGVIO_E_ARG;
     launch_snapshot(view(c), c->d.n_max, c->Psnap, c->d_n_snap, c->st);
     c->h_n_snap = c->h_n;
@@ -677,6 +693,7 @@ int ingvio_cov_snapshot(ingvio_ctx* c)
 int ingvio_cov_restore(ingvio_ctx* c)
 {
     if (!c || !c->has_snap) return INGVIO_E_ARG;
+    c->phase_pending = false;                      // the way out of an abandoned split step: every filter returns to the snapshot
     launch_restore(view(c), c->d.n_max, c->Psnap, c->d_n_snap, c->st);
     c->h_n = c->h_n_snap;
     std::fill(c->h_cur.begin(), c->h_cur.end(), 0);
@@ -686,6 +703,7 @@ int ingvio_cov_restore(ingvio_ctx* c)
 int ingvio_propagate_fused(ingvio_ctx* c, int b0, int nb, int k, const double* Phi, const double* G, const double* dt,
                            const double sigma[4], int enable_gnss, const int* gnss_idx, double scb, double srw)
 {
+    if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || k < 1 || k > KMAX || !Phi || !G || !dt || !sigma) return INGVIO_E_ARG;
     for (int i = 0; i < nb; ++i) if (c->h_n[b0 + i] < 15) return INGVIO_E_ARG;
     int rc = up(c, c->d_Phi, Phi, 8 * (size_t)nb * k * 225);
@@ -710,6 +728,7 @@ int ingvio_propagate(ingvio_ctx* c, int b0, int nb, const double* Phi, const dou
 
 int ingvio_augment_clone(ingvio_ctx* c, int b0, int nb, const double* R, int* new_idx)
 {
+    if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || !R) return INGVIO_E_ARG;
     for (int i = 0; i < nb; ++i) {
         if (c->h_n[b0 + i] < 21) return INGVIO_E_ARG;
@@ -724,6 +743,7 @@ int ingvio_augment_clone(ingvio_ctx* c, int b0, int nb, const double* R, int* ne
 
 int ingvio_marginalize(ingvio_ctx* c, int b0, int nb, const int* idx, int size)
 {
+    if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || !idx || size < 1) return INGVIO_E_ARG;
     for (int i = 0; i < nb; ++i)
         if (idx[i] >= 0 && idx[i] + size > c->h_n[b0 + i]) return INGVIO_E_NOT_IN_STATE;
@@ -736,6 +756,7 @@ int ingvio_marginalize(ingvio_ctx* c, int b0, int nb, const int* idx, int size)
 
 int ingvio_append_independent(ingvio_ctx* c, int b0, int nb, int size, const double* blk, int* new_idx)
 {
+    if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || !blk || size < 1 || size > 6) return INGVIO_E_ARG;
     for (int i = 0; i < nb; ++i) if (c->h_n[b0 + i] + size > c->d.n_max) return INGVIO_E_CAPACITY;
     if (up(c, c->d_blk, blk, 8 * (size_t)nb * size * size)) return INGVIO_E_HIP;
@@ -777,7 +798,7 @@ static int ekf_update_dense_route(ingvio_ctx* c, int b, const int* vidx, const i
     int status = 0;
     if (dx_out && down_sync(c, dx_out, c->d_dx + (size_t)b * c->ldp, 8 * (size_t)c->h_n[b])) return INGVIO_E_HIP;
     if (down_sync(c, &status, c->d_status + b, sizeof(int))) return INGVIO_E_HIP;
-    return (status & 2) ? INGVIO_NEG_DIAG : INGVIO_OK;
+    return (status & 4) ? INGVIO_E_NOT_PD : ((status & 2) ? INGVIO_NEG_DIAG : INGVIO_OK);
 }
 
 // k_ekf_core keeps S (+ one border row/column) and the column map in LDS (launch_ekf_core): 160 KB per workgroup on gfx950
@@ -817,6 +838,7 @@ static int stage_generic(ingvio_ctx* c, int b, const int* vidx, const int* vsize
 int ingvio_ekf_update(ingvio_ctx* c, int b, const int* vidx, const int* vsize, int k, const double* H, int ldh, int m,
                       const double* res, const double* R, int r_kind, double* dx_out)
 {
+    if (phase_busy(c)) return INGVIO_E_ARG;
     int nc = 0;
     if (c && vsize && k >= 1) {                                     // S beyond LDS / rows beyond m_max: the dense route
         int ncq = 0;
@@ -843,7 +865,7 @@ int ingvio_ekf_update(ingvio_ctx* c, int b, const int* vidx, const int* vsize, i
     if (down_sync(c, &status, c->d_status + b, sizeof(int))) return INGVIO_E_HIP;
     rc = last_launch(c);
     if (rc) return rc;
-    return (status & 2) ? INGVIO_NEG_DIAG : INGVIO_OK;
+    return (status & 4) ? INGVIO_E_NOT_PD : ((status & 2) ? INGVIO_NEG_DIAG : INGVIO_OK);
 }
 
 // ekfUpdate for filters [b0, b0+nb) in one launch and one synchronisation (the GNSS update of a whole batch, config 3 x 4):
@@ -851,6 +873,7 @@ int ingvio_ekf_update(ingvio_ctx* c, int b, const int* vidx, const int* vsize, i
 // (INGVIO_OK / INGVIO_NEG_DIAG per filter, may be NULL).
 int ingvio_ekf_update_batch(ingvio_ctx* c, int b0, int nb, const ingvio_update_block* blk, int r_kind, double* dx_out, int* status_out)
 {
+    if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || !blk) return INGVIO_E_ARG;
     if (r_kind != INGVIO_R_SCALAR && r_kind != INGVIO_R_DIAG) return INGVIO_E_UNSUPPORTED;
     int m_cap = 0, nc_cap = 0, n_cap = 0;
@@ -907,7 +930,7 @@ int ingvio_ekf_update_batch(ingvio_ctx* c, int b0, int nb, const ingvio_update_b
         if (down_sync(c, status.data(), c->d_status + b0, sizeof(int) * (size_t)nb)) return INGVIO_E_HIP;
         int soft = INGVIO_OK;
         for (int i = 0; i < nb; ++i) {
-            const int st = (status[i] & 2) ? INGVIO_NEG_DIAG : INGVIO_OK;
+            const int st = (status[i] & 4) ? INGVIO_E_NOT_PD : ((status[i] & 2) ? INGVIO_NEG_DIAG : INGVIO_OK);
             if (status_out) status_out[i] = st;
             if (st != INGVIO_OK) soft = st;
         }
@@ -962,7 +985,7 @@ int ingvio_ekf_update_batch(ingvio_ctx* c, int b0, int nb, const ingvio_update_b
     if (rc) return rc;
     int soft = INGVIO_OK;
     for (int i = 0; i < nb; ++i) {
-        const int st = (status[i] & 2) ? INGVIO_NEG_DIAG : INGVIO_OK;
+        const int st = (status[i] & 4) ? INGVIO_E_NOT_PD : ((status[i] & 2) ? INGVIO_NEG_DIAG : INGVIO_OK);
         if (status_out) status_out[i] = st;
         if (st != INGVIO_OK) soft = st;
     }
@@ -1139,6 +1162,7 @@ int ingvio_gnss_front_fetch(ingvio_ctx* c, int b0, int nb, double* out)
 
 int ingvio_gnss_run(ingvio_ctx* c, int b0, int nb)
 {
+    if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || !c->gn.staged) return INGVIO_E_ARG;
     auto& g = c->gn;
     int n_cap = 0;
@@ -1182,7 +1206,7 @@ int ingvio_gnss_fetch(ingvio_ctx* c, int b0, int nb, double* dx_out, int* rows_o
     if (rc) return rc;
     int soft = INGVIO_OK;
     for (int i = 0; i < nb; ++i) {
-        const int st = (status[i] & 8) ? INGVIO_REJECTED : ((status[i] & 2) ? INGVIO_NEG_DIAG : INGVIO_OK);
+        const int st = (status[i] & 8) ? INGVIO_REJECTED : ((status[i] & 4) ? INGVIO_E_NOT_PD : ((status[i] & 2) ? INGVIO_NEG_DIAG : INGVIO_OK));
         if (status_out) status_out[i] = st;
         if (st == INGVIO_NEG_DIAG) soft = st;
     }
@@ -1192,6 +1216,7 @@ int ingvio_gnss_fetch(ingvio_ctx* c, int b0, int nb, double* dx_out, int* rows_o
 int ingvio_gnss_update_batch(ingvio_ctx* c, int b0, int nb, const ingvio_update_block* blk, const ingvio_gnss_opts* o, double* dx_out,
                              int* rows_out, int* keep_out, int* status_out)
 {
+    if (phase_busy(c)) return INGVIO_E_ARG;
     int rc = ingvio_gnss_stage(c, b0, nb, blk, o);
     if (rc) return rc;
     rc = ingvio_gnss_run(c, b0, nb);
@@ -1279,6 +1304,7 @@ int ingvio_chi2_gamma_multi(ingvio_ctx* c, int b, int nblk, const ingvio_gate_bl
 int ingvio_msckf_update(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* frames, const ingvio_msckf_opts* opts,
                         double* dx_out, int* accepted, double* gamma, int* rows_out)
 {
+    if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || !frames || !opts) return INGVIO_E_ARG;
     MsckfOpts op;
     int rc = make_opts(c, opts, &op);
@@ -1324,6 +1350,7 @@ static int stage_hnew(ingvio_ctx* c, const double* H_new, int ldn, int m, int s)
 int ingvio_add_variable_delayed_invertible(ingvio_ctx* c, int b, const int* vidx, const int* vsize, int k, const double* H_old, int ldh,
                                            const double* H_new, int ldn, int s, double noise, int* new_idx)
 {
+    if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b, 1)) return INGVIO_E_ARG;
     if (c->h_n[b] + s > c->d.n_max) return INGVIO_E_CAPACITY;
     int nc = 0;
@@ -1345,6 +1372,7 @@ int ingvio_add_variable_delayed(ingvio_ctx* c, int b, const int* vidx, const int
                                 const double* H_new, int ldn, int m, int s, const double* res, double noise, double chi2_mult,
                                 int do_chi2, double chi2_check, double* dx_out, int* added, int* new_idx, double* chi2_out)
 {
+    if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b, 1) || !added) return INGVIO_E_ARG;
     *added = 0;
     if (m <= s) return INGVIO_OK;                                                  // StateManager.cpp:571-575
@@ -1388,11 +1416,12 @@ int ingvio_add_variable_delayed(ingvio_ctx* c, int b, const int* vidx, const int
     if (down_sync(c, &status, c->d_status + b, sizeof(int))) return INGVIO_E_HIP;
     rc = last_launch(c);
     if (rc) return rc;
-    return (status & 2) ? INGVIO_NEG_DIAG : INGVIO_OK;
+    return (status & 4) ? INGVIO_E_NOT_PD : ((status & 2) ? INGVIO_NEG_DIAG : INGVIO_OK);
 }
 
 int ingvio_replace_var_linear(ingvio_ctx* c, int b, int tidx, int tsize, const int* vidx, const int* vsize, int k, const double* H, int ldh)
 {
+    if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b, 1) || tsize < 1 || tsize > 6) return INGVIO_E_ARG;
     if (tidx < 0 || tidx + tsize > c->h_n[b]) return INGVIO_E_NOT_IN_STATE;       // "Target var not in state" (:653-657)
     int nc = 0;
@@ -1490,7 +1519,7 @@ static int run_dense_update(ingvio_ctx* c, int b0, int nb, double var, int r_kin
         a.W = X; a.Y = Y; a.xs = w.xstride; a.ld = w.ldx; a.Tb = w.Tb + (size_t)b0 * w.tstride; a.ts = w.tstride; a.t_slots = mc / 32;
         a.rows = w.ldx; a.ncols = mc; a.status = c->d_status + b0; a.fail_bit = 4; a.active = act; a.batch = nb;
         launch_chol_sweep(a, c->st);
-        launch_lm_finish(view(c), b0, nb, Y, w.xstride, w.ldx, mc, mc + w.n32, act, d_dx, c->st);
+        launch_lm_finish(view(c), b0, nb, Y, w.xstride, w.ldx, mc, mc + w.n32, act, d_dx, c->d_status, c->st);
     }
     {
         ProfScope p(c, PF_DOWNDATE);
@@ -1528,6 +1557,7 @@ int ingvio_landmark_stage(ingvio_ctx* c, int b0, int nb, const ingvio_landmark_f
     if (check_range(c, b0, nb) || !fr || !o || !(o->noise > 0.0)) return INGVIO_E_ARG;
     auto& s = c->lm;
     int l_hi = 0;
+    std::vector<int> hi_new(nb, 0);
     for (int i = 0; i < nb; ++i) {
         const auto& f = fr[i];
         if (f.n_lm < 0 || f.n_lm > LM_MAX) return INGVIO_E_CAPACITY;
@@ -1538,6 +1568,9 @@ int ingvio_landmark_stage(ingvio_ctx* c, int b0, int nb, const ingvio_landmark_f
         if (f.idx_epose < 0 || f.idx_epose + 9 > n_lim || f.idx_ext < 0 || f.idx_ext + 6 > n_lim) return INGVIO_E_NOT_IN_STATE;
         for (int l = 0; l < f.n_lm; ++l)
             if (f.lm_idx[l] < 0 || f.lm_idx[l] + 3 > n_lim || f.anchor_idx[l] < 0 || f.anchor_idx[l] + 6 > n_lim) return INGVIO_E_NOT_IN_STATE;
+        int hi = f.n_lm ? std::max(f.idx_epose + 9, f.idx_ext + 6) : 0;
+        for (int l = 0; l < f.n_lm; ++l) hi = std::max(hi, std::max(f.lm_idx[l] + 3, f.anchor_idx[l] + 6));
+        hi_new[i] = hi;
         l_hi = std::max(l_hi, f.n_lm);
     }
     const int B = c->d.batch;
@@ -1584,13 +1617,27 @@ int ingvio_landmark_stage(ingvio_ctx* c, int b0, int nb, const ingvio_landmark_f
     memcpy(s.op.R_lr, o->R_cl2cr, 72); memcpy(s.op.t_lr, o->t_cl2cr, 24);
     s.op.var = o->noise * o->noise; s.op.chi2_thr = o->chi2_thr; s.op.stereo = o->stereo ? 1 : 0;
     s.in_frame = o->in_frame ? 1 : 0;
+    if ((int)s.hi.size() != B) s.hi.assign(B, 0);
+    for (int i = 0; i < nb; ++i) s.hi[b0 + i] = hi_new[i];
     s.staged = true;
+    return INGVIO_OK;
+}
+
+// The staged landmark rows name state columns: a marginalisation between stage and run may have shrunk or shifted the state,
+// so every run re-validates them against the live dimension (as ingvio_gnss_run does with its staged var_order).
+static int landmark_in_state(ingvio_ctx* c, int b0, int nb, const std::vector<int>& n_live, int extra)
+{
+    if ((int)c->lm.hi.size() != c->d.batch) return INGVIO_OK;
+    for (int b = b0; b < b0 + nb; ++b)
+        if (c->lm.hi[b] > n_live[b] + extra) { c->err = "a staged landmark row names a column beyond the live state"; return INGVIO_E_NOT_IN_STATE; }
     return INGVIO_OK;
 }
 
 int ingvio_landmark_run(ingvio_ctx* c, int b0, int nb)
 {
+    if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || !c->lm.staged) return INGVIO_E_ARG;
+    if (int rc = landmark_in_state(c, b0, nb, c->h_n, 0)) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_status + b0, 0, sizeof(int) * (size_t)nb, c->st));
     return landmark_update_launch(c, b0, nb);
 }
@@ -1604,7 +1651,7 @@ int ingvio_landmark_fetch(ingvio_ctx* c, int b0, int nb, double* dx, int* rows, 
     if (gamma) HIPCHK(c, hipMemcpyAsync(gamma, c->lm.gamma + (size_t)b0 * LM_MAX, 8 * (size_t)nb * LM_MAX, hipMemcpyDeviceToHost, c->st));
     if (status) HIPCHK(c, hipMemcpyAsync(status, c->d_status + b0, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
-    if (status) for (int i = 0; i < nb; ++i) status[i] = (status[i] & 4) ? INGVIO_E_UNSUPPORTED : ((status[i] & 2) ? INGVIO_NEG_DIAG : INGVIO_OK);   // bit 4: S not positive definite
+    if (status) for (int i = 0; i < nb; ++i) status[i] = (status[i] & 4) ? INGVIO_E_NOT_PD : ((status[i] & 2) ? INGVIO_NEG_DIAG : INGVIO_OK);   // bit 4: S not positive definite
     return last_launch(c);
 }
 
@@ -1671,6 +1718,7 @@ int ingvio_qr_compress(ingvio_ctx* c, const double* H, int ldh, int m, int n, co
 static int frame_stage_impl(ingvio_ctx* c, int b0, int nb, const ingvio_frame_step* steps, const ingvio_msckf_frame* frames,
                             const ingvio_msckf_opts* opts, const double sigma[4], int enable_gnss, double scb, double srw, bool async)
 {
+    if (phase_busy(c)) return INGVIO_E_ARG;
     // ---- validation: nothing of the context is modified until every input has been accepted ---------------------------
     if (check_range(c, b0, nb) || !steps || !frames || !opts || !sigma) return INGVIO_E_ARG;
     if (async && (b0 != 0 || nb != c->d.batch)) return INGVIO_E_ARG;      // a whole input set is replaced
@@ -1774,7 +1822,13 @@ static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
 {
     if (!c || !c->staged) return INGVIO_E_ARG;
     if (phase && c->method != 1) return INGVIO_E_UNSUPPORTED;             // the split needs the information form's [A | b]
+    // protocol of the split step: 1 -> (ingvio_debug_msckf_info / ingvio_info_set) -> 2, exactly once each; the accepted-feature
+    // cap is a global order over the features and is not defined across shards
+    if (phase != 2 && phase_busy(c)) return INGVIO_E_ARG;
+    if (phase == 2 && !c->phase_pending) { c->err = "ingvio_frame_run_phase(.., 2) without a preceding phase 1"; return INGVIO_E_ARG; }
+    if (phase != 0 && c->st_op.max_accept > 0) { c->err = "max_accept is not supported by the split (feature-sharded) frame step"; return INGVIO_E_ARG; }
     if (phase == 2) {                                                       // back half: solve + apply + marginalise from the partials
+        c->phase_pending = false;
         const int B2 = c->d.batch;
         const bool with_lm2 = c->lm.staged && c->lm.in_frame;
         int rc2 = run_msckf_factored(c, 0, B2, c->st_op, c->st_stereo, c->st_fmax_used, with_lm2 ? nullptr : c->d_idx, with_lm2 ? 0 : 6, 2);
@@ -1803,6 +1857,7 @@ static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
             if (c->st_cidx_hi[b] + 6 > n0[b] + 6) return INGVIO_E_NOT_IN_STATE;      // a staged clone lies beyond the live state
             if (c->st_marg[b] >= 0 && c->st_marg[b] + 6 > n0[b] + 6) return INGVIO_E_NOT_IN_STATE;
         }
+        if (c->lm.staged && c->lm.in_frame) { if (int rc = landmark_in_state(c, 0, B, n0, 6)) return rc; }
     }
     if (wait_inputs(c)) return INGVIO_E_HIP;
     if (restore_prior) {
@@ -1829,7 +1884,9 @@ static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
     if (phase == 1) {                                                       // front half only: [A | b] partials stay on the device
         c->strip_ok = false;
         c->mut_seq++;
-        return run_msckf_factored(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used, nullptr, 0, 1);
+        const int rc1 = run_msckf_factored(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used, nullptr, 0, 1);
+        c->phase_pending = true;                                            // h_n is already + 6: only phase 2 may follow
+        return rc1;
     }
     int rc = fuse ? run_msckf_factored(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used, c->d_idx, 6)
                   : (c->method == 1 ? run_msckf_factored(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used)
@@ -1841,6 +1898,9 @@ static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
         if (fuse) launch_post_marg(view(c), 0, B, c->d_idx, 6, c->st);
         else launch_marginalize(view(c), 0, B, c->d.n_max, c->d_idx, 6, c->st);
     }
+    // a landmark stage belongs to ONE frame: unless the caller replays the same prior (restore_prior, the bench and the parity tests)
+    // the staged rows are consumed here, so that a later frame cannot re-apply them to a state that has moved on
+    if (with_lm && !restore_prior) c->lm.staged = false;
     bool all_marg = true;
     for (int b = 0; b < B; ++b) { if (c->st_marg[b] >= 0) { c->h_n[b] -= 6; c->h_cur[b] ^= 1; } else all_marg = false; }
     c->strip_ok = fuse && all_marg && restore_prior;
@@ -1871,6 +1931,60 @@ int ingvio_info_set(ingvio_ctx* c, int b, const double* A, int ncol, int n_accep
     if (rc) return INGVIO_E_HIP;
     HIPCHK(c, hipStreamSynchronize(c->st));
     return INGVIO_OK;
+}
+
+// ---- device-resident exchange of the feature-sharded filter (the ONE exchange step per frame) ---------------------
+// ingvio_info_reduce sums filter b's chunk partials into one contiguous device buffer [A | b | n_accepted] (ncol (ncol + 1) + 1
+// doubles; the accepted count rides along as a double so that ONE all-reduce carries everything) and hands out the DEVICE
+// pointer: the caller all-reduces it in place (RCCL on the pointer itself, or torch.distributed on a zero-copy view,
+// ingvio_amd/parallel.py) - nothing crosses PCIe.  ingvio_info_commit makes the reduced buffer the filter's information
+// (chunk 0 = the sum, its count = the summed n_accepted) for ingvio_frame_run_phase(.., 2).
+namespace {
+__global__ __launch_bounds__(256) void k_info_reduce(const double* __restrict__ Apart, const int* __restrict__ chunk_used, int G, int rstride,
+                                                     int cnt, double* __restrict__ out)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e > cnt) return;
+    double s = 0.0;
+    if (e < cnt) { for (int g = 0; g < G; ++g) if (chunk_used[g]) s += Apart[(size_t)g * rstride + e]; }
+    else { for (int g = 0; g < G; ++g) s += (double)chunk_used[g]; }
+    out[e] = s;
+}
+__global__ __launch_bounds__(256) void k_info_commit(const double* __restrict__ in, int cnt, double* __restrict__ Apart0, int* __restrict__ chunk_used, int G)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < cnt) Apart0[e] = in[e];
+    if (e < G) chunk_used[e] = e == 0 ? (int)llrint(in[cnt]) : 0;
+}
+}  // namespace
+
+int ingvio_info_reduce(ingvio_ctx* c, int b, double** dev_ptr, int* count, int* ncol_out)
+{
+    if (check_range(c, b, 1) || !dev_ptr || !count || c->method != 1) return INGVIO_E_ARG;
+    int C = 0;
+    if (down_sync(c, &C, c->d_nclones + b, sizeof(int))) return INGVIO_E_HIP;
+    const int ncol = 6 * C, cnt = ncol * (ncol + 1);
+    if (cnt <= 0 || cnt > c->rstride) return INGVIO_E_ARG;
+    if (!c->d_xchg && dalloc(c, &c->d_xchg, (size_t)c->d.batch * (c->rstride + 8))) return INGVIO_E_HIP;
+    double* out = c->d_xchg + (size_t)b * (c->rstride + 8);
+    hipLaunchKernelGGL(k_info_reduce, dim3((cnt + 256) / 256), dim3(256), 0, c->st, c->d_Rpart + (size_t)b * c->G * c->rstride,
+                       c->d_chunk_used + (size_t)b * c->G, c->G, c->rstride, cnt, out);
+    HIPCHK(c, hipStreamSynchronize(c->st));              // the caller's collective runs on ITS stream: the buffer must be complete
+    *dev_ptr = out; *count = cnt + 1;
+    if (ncol_out) *ncol_out = ncol;
+    return last_launch(c);
+}
+
+int ingvio_info_commit(ingvio_ctx* c, int b)
+{
+    if (check_range(c, b, 1) || !c->d_xchg || c->method != 1) return INGVIO_E_ARG;
+    int C = 0;
+    if (down_sync(c, &C, c->d_nclones + b, sizeof(int))) return INGVIO_E_HIP;
+    const int ncol = 6 * C, cnt = ncol * (ncol + 1);
+    if (cnt <= 0 || cnt > c->rstride) return INGVIO_E_ARG;
+    hipLaunchKernelGGL(k_info_commit, dim3((std::max(cnt, c->G) + 255) / 256), dim3(256), 0, c->st, c->d_xchg + (size_t)b * (c->rstride + 8), cnt,
+                       c->d_Rpart + (size_t)b * c->G * c->rstride, c->d_chunk_used + (size_t)b * c->G, c->G);
+    return last_launch(c);
 }
 
 int ingvio_frame_fetch(ingvio_ctx* c, int b0, int nb, double* dx_out, int* accepted, int* rows_out)

@@ -17,7 +17,7 @@ GnssUpdate::GnssUpdate(const IngvioParams& fp)
 // (:190,:259), the compaction and the block gate (:286) run on the device (ingvio_gnss_update_batch).
 int gnssCandidateRows(const GnssResiduals& g, const Vec3d& p_w, const Vec3d& v_w, int idx_se23, int idx_yof, const int idx_cb[4],
                       int idx_fs, double psr_amp, double dopp_amp, double* H, int ldh, double* res, double* Rd, int* vidx, int* vsize,
-                      int* nvar)
+                      int* nvar, bool adjust_yof)
 {
     const int nsat = (int)g.sys.size();
     int nv = 0, rows = 0, col_cnt = 10;
@@ -26,6 +26,8 @@ int gnssCandidateRows(const GnssResiduals& g, const Vec3d& p_w, const Vec3d& v_w
     vidx[nv] = idx_yof; vsize[nv++] = 1;
     for (int c = 0; c < 15; ++c) for (int i = 0; i < 2 * nsat; ++i) H[i + (size_t)c * ldh] = 0.0;
     const Mat3d RSp = g.R_w2ecef * skew(p_w), RSv = g.R_w2ecef * skew(v_w);
+    const bool yof = adjust_yof && g.has_yof_jac;
+    const Vec3d dp = yof ? g.dRw2ecef_dyof * p_w : Vec3d(), dv = yof ? g.dRw2ecef_dyof * v_w : Vec3d();      // Renu2ecef dotRw2enu p | v
     auto usable = [&](int i) { return g.sys[i] >= 0 && g.sys[i] <= 3 && idx_cb[g.sys[i]] >= 0; };     // :153
     for (int i = 0; i < nsat; ++i) {                                                                  // :148-211
         if (!usable(i)) continue;
@@ -37,6 +39,7 @@ int gnssCandidateRows(const GnssResiduals& g, const Vec3d& p_w, const Vec3d& v_w
         double sin_el = g.sin_el[i];
         if (std::fabs(sin_el) < 1e-6) sin_el = 1e-6;
         const double psr_noise = psr_amp * std::pow(g.ura[i] * g.psr_std[i] / (sin_el * sin_el), 0.5);   // :187
+        if (yof) H[rows + (size_t)9 * ldh] = -(u[0] * dp[0] + u[1] * dp[1] + u[2] * dp[2]);                          // :164-167
         res[rows] = -g.res_pos[i]; Rd[rows] = psr_noise * psr_noise;
         const int s = g.sys[i];
         if (cb_col[s] < 0) { cb_col[s] = col_cnt++; vidx[nv] = idx_cb[s]; vsize[nv++] = 1; }          // :200-206
@@ -55,6 +58,7 @@ int gnssCandidateRows(const GnssResiduals& g, const Vec3d& p_w, const Vec3d& v_w
         double sin_el = g.sin_el[i];
         if (std::fabs(sin_el) < 1e-6) sin_el = 1e-6;
         const double dopp_noise = dopp_amp * std::pow(g.ura[i] * g.dopp_std_mps[i] / (sin_el * sin_el), 0.5);   // :256
+        if (yof) H[rows + (size_t)9 * ldh] = -(u[0] * dv[0] + u[1] * dv[1] + u[2] * dv[2]);                          // :239-242
         res[rows] = -g.res_vel[i]; Rd[rows] = dopp_noise * dopp_noise;
         H[rows + (size_t)fs_col * ldh] = 1.0;
         ++rows;
@@ -69,10 +73,6 @@ int GnssUpdate::updateTrackedSys(std::shared_ptr<State> state, const GnssResidua
     const int nsat = (int)g.sys.size();
     if (nsat <= 0) return 0;
     if (state->_gnss.find(State::YOF) == state->_gnss.end() || state->_gnss.find(State::FS) == state->_gnss.end()) return 0;   // checkGnssStates
-    if (_is_adjust_yof && !_warned_yof) {
-        std::cout << "[GnssUpdate]: is_adjust_yof needs GvioAligner's dotRw2enu, not carried by the shim; YOF column stays 0." << std::endl;
-        _warned_yof = true;
-    }
     int idx_cb[4] = { -1, -1, -1, -1 };
     for (int s = 0; s < 4; ++s) { auto it = state->_gnss.find(s); if (it != state->_gnss.end()) idx_cb[s] = it->second->idx(); }
     const int ldh = 2 * nsat;
@@ -81,7 +81,7 @@ int GnssUpdate::updateTrackedSys(std::shared_ptr<State> state, const GnssResidua
     const int rows = gnssCandidateRows(g, state->_extended_pose->valueTrans1(), state->_extended_pose->valueTrans2(),
                                        state->_extended_pose->idx(), state->_gnss.at(State::YOF)->idx(), idx_cb,
                                        state->_gnss.at(State::FS)->idx(), _psr_noise_amp, _dopp_noise_amp, H.data(), ldh, res.data(),
-                                       Rd.data(), vidx, vsize, &nvar);
+                                       Rd.data(), vidx, vsize, &nvar, _is_adjust_yof);
     if (rows == 0) return 0;
     // the gates need table[1] (rows, :190/:259) and table[rows] (block, :286): UpdateBase::testChiSquared extends its table on demand
     const std::vector<double> table = chi2TableDense(rows + 1);
@@ -108,6 +108,15 @@ int GnssUpdate::updateTrackedSys(std::shared_ptr<State> state, const GnssResidua
 }
 
 // ---- the GNSS epoch path ------------------------------------------------------------------------------------------------
+Mat3d dotRw2enu(double yo)               // GnssManager.cpp:101-113
+{
+    Mat3d D;
+    D(0, 0) = -std::sin(yo); D(0, 1) = -std::cos(yo); D(0, 2) = 0.0;
+    D(1, 0) = std::cos(yo);  D(1, 1) = -std::sin(yo); D(1, 2) = 0.0;
+    D(2, 0) = 0.0;           D(2, 1) = 0.0;           D(2, 2) = 0.0;
+    return D;
+}
+
 static Mat3d rotZ(double yaw)           // GnssManager::calcRw2enu (GnssManager.cpp:57-60): AngleAxisd(yaw, UnitZ)
 {
     Mat3d R = Mat3d::Identity();
@@ -148,6 +157,10 @@ GnssResiduals GnssUpdate::residualsAt(std::shared_ptr<State> state, const GnssMe
         g.dopp_std_mps.push_back(gm.sats[i].dopp_std * gnss::LIGHT_SPEED / gm.sats[i].freq);                      // :253
     }
     g.R_w2ecef = al.R_enu2ecef * Rw2enu;                                                                              // :141
+    g.R_enu2ecef = al.R_enu2ecef;
+    g.dRw2ecef_dyof = al.R_enu2ecef * dotRw2enu(yo);                          // zero when YOF is not in the state (GnssManager.cpp:103-104)
+    if (!state->_gnss.count(State::YOF)) g.dRw2ecef_dyof = Mat3d::Zero();
+    g.has_yof_jac = true;
     return g;
 }
 
@@ -192,12 +205,16 @@ int GnssUpdate::addNewTrackedSys(std::shared_ptr<State> state, const GnssMeas& g
     const double fs_val = spp.velSpp[3];
     if (!add_fs && !state->_gnss.count(State::FS)) std::cout << "[GnssUpdate]: Fs is either added or in the state!" << std::endl;
     const GnssResiduals g = residualsAt(state, gm, al, cb_over, add_fs ? &fs_val : nullptr);
-    const Vec3d p = state->_extended_pose->valueTrans1(), v = state->_extended_pose->valueTrans2();
-    const Mat3d RSp = g.R_w2ecef * skew(p), RSv = g.R_w2ecef * skew(v);
     std::vector<std::shared_ptr<Type>> x_order = { state->_extended_pose, state->_gnss.at(State::YOF) };
     int added = 0;
+    // Order of the additions: FS first, then the clock biases GPS, GLO, GAL, BDS (the reference iterates an unordered_set, :360/:433,
+    // i.e. an implementation-defined order).  As in the reference the residuals and R_w2ecef are evaluated once, before the loop
+    // (:357-358), while [p]x and [v]x are read from the state INSIDE it (valueTrans1/2 at :397 / :458): every successful
+    // addVariableDelayed ends with an EKF update that moves p and v, so the second and later systems see the moved values.
     for (int gtype : to_add) {
         const bool fs = gtype == State::FS;
+        const Vec3d p = state->_extended_pose->valueTrans1(), v = state->_extended_pose->valueTrans2();
+        const Mat3d RSp = g.R_w2ecef * skew(p), RSv = g.R_w2ecef * skew(v);
         std::vector<int> rows;
         for (size_t i = 0; i < gm.sats.size(); ++i) if (fs ? (gm.sats[i].sys >= 0 && gm.sats[i].sys <= 3) : gm.sats[i].sys == gtype) rows.push_back((int)i);
         if (rows.empty()) continue;
@@ -212,6 +229,14 @@ int GnssUpdate::addNewTrackedSys(std::shared_ptr<State> state, const GnssMeas& g
             for (int c = 0; c < 3; ++c) {
                 Hx(r, c) = u[0] * RS(0, c) + u[1] * RS(1, c) + u[2] * RS(2, c);                                     // :389 / :440
                 Hx(r, (fs ? 6 : 3) + c) = -(u[0] * g.R_w2ecef(0, c) + u[1] * g.R_w2ecef(1, c) + u[2] * g.R_w2ecef(2, c));
+            }
+            // is_adjust_yof, AS WRITTEN (:401-404 / :462-465): -u^T getRecef2enu() dotRw2enu(state) x with x = v in the FS branch and
+            // p in the clock-bias branches - note Recef2enu here, where updateTrackedSys (:166, :241) has Renu2ecef (quirk Q14)
+            Hx(r, 9) = 0.0;
+            if (_is_adjust_yof) {
+                const double yo = state->_gnss.at(State::YOF)->value();
+                const Vec3d w = g.R_enu2ecef.transpose() * (dotRw2enu(yo) * (fs ? v : p));
+                Hx(r, 9) = -(u[0] * w[0] + u[1] * w[1] + u[2] * w[2]);
             }
             Hf(r, 0) = 1.0;
             res[r] = -(fs ? g.res_vel[i] : g.res_pos[i]);

@@ -28,13 +28,21 @@ struct GnssResiduals {
     std::vector<double> ura, psr_std;     // ephem ura, obs psr_std[l1]
     std::vector<double> dopp_std_mps;     // dopp_std[l1] * LIGHT_SPEED / L1 frequency
     Mat3d R_w2ecef;                       // getRenu2ecef() * calcRw2enu(state)
+    // is_adjust_yof (GnssUpdate.cpp:164-167, 239-242): the yaw-offset column of a row is -u^T Renu2ecef dotRw2enu(state) p (v for
+    // Doppler rows).  dRw2ecef_dyof = getRenu2ecef() * GnssManager::dotRw2enu(state); used only when has_yof_jac is set.
+    Mat3d R_enu2ecef = Mat3d::Identity();
+    Mat3d dRw2ecef_dyof;
+    bool has_yof_jac = false;
 };
+
+// GnssManager::dotRw2enu (GnssManager.cpp:101-113): d/d(yaw offset) of calcRw2enu = AngleAxis(yo, UnitZ); nine entries from yo.
+Mat3d dotRw2enu(double yaw_offset);
 
 // candidate rows of updateTrackedSys (all pseudo-range rows, then all Doppler rows; H column-major, ldh >= 2 nsat, 15 columns;
 // vidx / vsize hold up to 7 variables); returns the row count
 int gnssCandidateRows(const GnssResiduals& g, const Vec3d& p_w, const Vec3d& v_w, int idx_se23, int idx_yof, const int idx_cb[4],
                       int idx_fs, double psr_amp, double dopp_amp, double* H, int ldh, double* res, double* Rd, int* vidx, int* vsize,
-                      int* nvar);
+                      int* nvar, bool adjust_yof = false);
 
 // One GNSS epoch as GnssProcessor::callbackGnssMeas hands it on (GnssProcessor.cpp:119-220: valid L1 observations with their
 // ephemerides; here with the satellite states already evaluated) and one SPP fix (GnssSync.h SppMeas).
@@ -100,7 +108,6 @@ public:
 protected:
     double _psr_noise_amp, _dopp_noise_amp;
     bool _is_gnss_chi2_test, _is_gnss_strong_reject, _is_adjust_yof;
-    bool _warned_yof = false;
 };
 
 }  // namespace ingvio

@@ -222,9 +222,10 @@ void LandmarkUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapSer
     _last_rows = 0;
     const int L = (int)state->_anchored_landmarks.size();
     if (L == 0) return;
-    if (L > INGVIO_LM_MAX) {
-        std::cout << "[LandmarkUpdate]: more than " << INGVIO_LM_MAX << " in-state landmarks!" << std::endl;
-        std::exit(EXIT_FAILURE);
+    if (L > INGVIO_LM_MAX) {          // unreachable: State::construct refuses max_landmark_features > INGVIO_LM_MAX at start-up
+        std::cout << "[LandmarkUpdate]: " << L << " in-state landmarks exceed the device limit of " << INGVIO_LM_MAX
+                  << ", landmark update skipped for this frame" << std::endl;
+        return;
     }
     const int per = stereo ? 4 : 2;
     const double t = state->_timestamp;

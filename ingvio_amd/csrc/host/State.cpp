@@ -35,6 +35,13 @@ StateParams::StateParams(const IngvioParams& filter_params)      // State.cpp:25
 
 void State::construct(const IngvioParams& filter_params)      // State.cpp:60-91
 {
+    // configuration-time check: the batched landmark update (ingvio_landmark_*) carries INGVIO_LM_MAX landmarks per filter; a
+    // larger max_landmark_features is refused here, at start-up, not in the middle of a run when landmark #65 is initialised
+    if (filter_params._max_lm_feats > INGVIO_LM_MAX) {
+        std::cout << "[State]: max_landmark_features = " << filter_params._max_lm_feats << " exceeds this build's limit of "
+                  << INGVIO_LM_MAX << " in-state landmarks" << std::endl;
+        std::exit(EXIT_FAILURE);
+    }
     int idx = 0;
     _extended_pose = std::make_shared<SE23>();
     _extended_pose->set_cov_idx(idx);

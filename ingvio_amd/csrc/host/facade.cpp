@@ -57,6 +57,28 @@ int ingvio_host_gnss_rows(int nsat, const double* los, const int* sys, const dou
                                      H, ldh, res, Rd, vidx, vsize, nvar);
 }
 
+// The same with is_adjust_yof = 1 (GnssUpdate.cpp:164-167, 239-242): the yaw-offset column -u^T Renu2ecef dotRw2enu(yo) p | v,
+// GnssManager::dotRw2enu (GnssManager.cpp:101-113) evaluated at `yaw_offset`; R_w2ecef must be Renu2ecef * calcRw2enu(yaw_offset).
+int ingvio_host_gnss_rows_yof(int nsat, const double* los, const int* sys, const double* res_pos, const double* res_vel, const double* sin_el,
+                              const double* ura, const double* psr_std, const double* dopp_std_mps, const double* R_w2ecef,
+                              const double* R_enu2ecef, double yaw_offset, const double* p_w, const double* v_w, int idx_se23, int idx_yof,
+                              const int* idx_cb, int idx_fs, double psr_amp, double dopp_amp, double* H, int ldh, double* res, double* Rd,
+                              int* vidx, int* vsize, int* nvar)
+{
+    ingvio::GnssResiduals g;
+    for (int i = 0; i < nsat; ++i) {
+        g.unit_rv2sv.push_back(ingvio::Vec3d(los + 3 * i)); g.sys.push_back(sys[i]); g.res_pos.push_back(res_pos[i]);
+        g.res_vel.push_back(res_vel[i]); g.sin_el.push_back(sin_el[i]); g.ura.push_back(ura[i]); g.psr_std.push_back(psr_std[i]);
+        g.dopp_std_mps.push_back(dopp_std_mps[i]);
+    }
+    g.R_w2ecef = ingvio::Mat3d(R_w2ecef);
+    g.R_enu2ecef = ingvio::Mat3d(R_enu2ecef);
+    g.dRw2ecef_dyof = g.R_enu2ecef * ingvio::dotRw2enu(yaw_offset);
+    g.has_yof_jac = true;
+    return ingvio::gnssCandidateRows(g, ingvio::Vec3d(p_w), ingvio::Vec3d(v_w), idx_se23, idx_yof, idx_cb, idx_fs, psr_amp, dopp_amp,
+                                     H, ldh, res, Rd, vidx, vsize, nvar, true);
+}
+
 double ingvio_host_chi2_quantile(int dof, double p) { return ingvio::chi2Quantile(dof, p); }
 
 }  // extern "C"

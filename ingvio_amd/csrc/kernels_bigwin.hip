@@ -15,6 +15,7 @@
 #include "launch_chol.h"
 #include "block64.h"
 #include <stdlib.h>
+#include <string.h>
 #include "gate_kernel.h"
 
 #define BIG_CMAX 36
@@ -559,21 +560,23 @@ __global__ __launch_bounds__(IB_NT, 1) void k_info_update_big(
 // ---------------------------------------------------------------------------------------------
 struct BigWs {
     int n32, ld1, ld2, ldab;
-    size_t oAB, oX1, oY1, oX2, oY2, oT, total;
+    size_t oAB, oX1, oY1, oX2, oY2, oT, oRef, total;      // oRef: the gauge reference slot of the filter (as a double)
     __host__ __device__ explicit BigWs(int n32_) : n32(n32_), ld1(2 * n32_), ld2(3 * n32_ + 32), ldab(n32_ + 32)
     {
         oAB = 0; oX1 = oAB + (size_t)ldab * n32; oY1 = oX1 + (size_t)ld1 * n32; oX2 = oY1 + (size_t)ld1 * n32;
-        oY2 = oX2 + (size_t)ld2 * n32; oT = oY2 + (size_t)ld2 * n32; total = oT + (size_t)(n32 / 32) * 1024 + n32;
+        oY2 = oX2 + (size_t)ld2 * n32; oT = oY2 + (size_t)ld2 * n32; oRef = oT + (size_t)(n32 / 32) * 1024 + n32; total = oRef + 1;
     }
 };
 
 __global__ __launch_bounds__(256) void k_big_prep(
     CovView cv, FrameView fv, int b0, const double* __restrict__ Apart, const int* __restrict__ chunk_used, int G, int rstride,
     double* __restrict__ Pcall, int ystride, double* __restrict__ dx_all, int* __restrict__ m_out, int* __restrict__ nc_out,
-    const int* __restrict__ marg_idx, int* __restrict__ pc_base_out, double* __restrict__ ws_all, size_t ws_stride, int n32)
+    const int* __restrict__ marg_idx, int* __restrict__ pc_base_out, double* __restrict__ ws_all, size_t ws_stride, int n32, int gauge)
 {
     constexpr int NC = BIG_NC, MP = NC;
     __shared__ int sCol[NC];
+    __shared__ double sTr[BIG_CMAX];
+    __shared__ int sRefSlot;
     const BigWs w(n32);
     const int bl = blockIdx.y, b = b0 + bl, tid = threadIdx.x, nwg = gridDim.x, wg = blockIdx.x;
     const int C = fv.n_clones[b], ncol = 6 * C, n = cv.n[b], ld = cv.ldp;
@@ -589,16 +592,36 @@ __global__ __launch_bounds__(256) void k_big_prep(
         const int cc = c < ncol ? c : 0;
         sCol[c] = fv.clone_idx[(size_t)b * fv.cmax + cc / 6] + cc % 6;
     }
+    // Gauge-reduced form (kernels_solve.hip, k_info_solve): the reference clone = the one with the largest translation
+    // information; its block is treated like an absent clone (identity in the covariance, zero in A), the other clones enter
+    // through the covariance of their DIFFERENCES to it; k_big_gauge_fix borders M with the reference block afterwards.
+    if (gauge && tid < C) {
+        double tr = 0.0;
+        for (int q = 3; q < 6; ++q) {
+            const size_t e = (size_t)(6 * tid + q) * (ncol + 1) + 6 * tid + q;
+            for (int g = 0; g < G; ++g) if (chunk_used[bl * G + g]) tr += Apart[((size_t)bl * G + g) * rstride + e];
+        }
+        sTr[tid] = tr;
+    }
     __syncthreads();
+    if (tid == 0) {
+        int best = -1;
+        if (gauge) { best = 0; for (int c = 1; c < C; ++c) if (sTr[c] > sTr[best]) best = c; }
+        sRefSlot = best;
+    }
+    __syncthreads();
+    const int ref6 = sRefSlot >= 0 ? 6 * sRefSlot : (1 << 20);
+    auto inref = [&](int i) { return i >= ref6 && i < ref6 + 6; };
     const double* P = cov_ptr(cv, b);
     double* ws = ws_all + (size_t)bl * ws_stride;
     double *AB = ws + w.oAB, *X1 = ws + w.oX1;
     const int gt = wg * 256 + tid, gn = nwg * 256;
+    if (gt == 0) ws[w.oRef] = (double)sRefSlot;
     // [A; b^T] from the chunk partials (A symmetric: element (i, j) read as partial row j, column i - coalesced along i)
     for (int e = gt; e < w.ldab * n32; e += gn) {
         const int i = e % w.ldab, j = e / w.ldab;
         double s = 0.0;
-        if (j < ncol && (i < ncol || i == n32)) {
+        if (j < ncol && (i < ncol || i == n32) && !inref(i) && !inref(j)) {
             const size_t src = (size_t)j * (ncol + 1) + (i == n32 ? ncol : i);
             for (int g0 = 0; g0 < G; g0 += 8) {
                 double t[8];
@@ -616,8 +639,15 @@ __global__ __launch_bounds__(256) void k_big_prep(
     for (int e = gt; e < w.ld1 * n32; e += gn) {
         const int i = e % w.ld1, j = e / w.ld1;
         double v;
-        if (i < n32) v = (i < ncol && j < ncol) ? P[sCol[i] + (size_t)sCol[j] * ld] : (i == j ? 1.0 : 0.0);
-        else v = (i - n32 == j) ? 1.0 : 0.0;
+        if (i < n32) {
+            if (i < ncol && j < ncol && !inref(i) && !inref(j)) {
+                v = P[sCol[i] + (size_t)sCol[j] * ld];
+                if (sRefSlot >= 0) {
+                    const int ri = sCol[ref6 + i % 6], rj = sCol[ref6 + j % 6];
+                    v = (v - P[ri + (size_t)sCol[j] * ld]) - (P[sCol[i] + (size_t)rj * ld] - P[ri + (size_t)rj * ld]);
+                }
+            } else v = i == j ? 1.0 : 0.0;
+        } else v = (i - n32 == j) ? 1.0 : 0.0;
         X1[e] = v;
     }
     const bool fused = marg_idx && marg_idx[bl] >= 0;
@@ -646,6 +676,42 @@ __global__ __launch_bounds__(256) void k_copy_rows(const double* __restrict__ S,
     }
 }
 
+// The reference clone's block row / column of [M | t]: minus the sums over the other clones' blocks (every block row and column
+// of the n x n solution sums to zero: M = T^-T diag(0, Mr) T^-1, see k_info_solve).  One workgroup per filter.
+__global__ __launch_bounds__(256) void k_big_gauge_fix(FrameView fv, int b0, double* __restrict__ Mall, int mstride, const double* __restrict__ ws_all,
+                                                       size_t ws_stride, size_t oref, const int* __restrict__ active)
+{
+    constexpr int MP = BIG_NC;
+    const int bl = blockIdx.x, tid = threadIdx.x;
+    if (active && !active[bl]) return;
+    const int ref = (int)ws_all[(size_t)bl * ws_stride + oref];
+    if (ref < 0) return;
+    const int C = fv.n_clones[b0 + bl], ref6 = 6 * ref;
+    double* Mg = Mall + (size_t)bl * mstride;
+    for (int e = tid; e < 2 * 6 * (MP + 1); e += 256) {
+        const int side = e / (6 * (MP + 1)), q = e - side * 6 * (MP + 1), k = q / (MP + 1), J = q - k * (MP + 1);
+        if (J == MP) {
+            if (side == 0) {
+                double s = 0.0;
+                for (int c = 0; c < C; ++c) if (c != ref) s += Mg[(size_t)MP * MP + 6 * c + k];
+                Mg[(size_t)MP * MP + ref6 + k] = -s;
+            }
+        } else if (J < ref6 || J >= ref6 + 6) {
+            double s = 0.0;
+            for (int c = 0; c < C; ++c)
+                if (c != ref) s += side == 0 ? Mg[(size_t)(6 * c + k) * MP + J] : Mg[(size_t)J * MP + 6 * c + k];
+            if (side == 0) Mg[(size_t)(ref6 + k) * MP + J] = -s; else Mg[(size_t)J * MP + ref6 + k] = -s;
+        }
+    }
+    __syncthreads();
+    if (tid < 36) {
+        const int k = tid / 6, l = tid - 6 * k;
+        double s = 0.0;
+        for (int c = 0; c < C; ++c) if (c != ref) s += Mg[(size_t)(ref6 + k) * MP + 6 * c + l];
+        Mg[(size_t)(ref6 + k) * MP + ref6 + l] = -s;
+    }
+}
+
 static int big_n32(int ncol_cap) { const int n = ncol_cap > 0 ? ncol_cap : BIG_NC; return (n + 31) / 32 * 32; }
 
 static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
@@ -654,8 +720,11 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
     const BigWs w(n32);
     const size_t wss = bigwin_wk_doubles();
     double* ws = L.big_wk;
+    // gauge-reduced solve for the RemoveLost form of the Jacobians (see kernels_solve.hip); INGVIO_INFO_GAUGE=off for comparison
+    static const bool no_gauge = [] { const char* e = getenv("INGVIO_INFO_GAUGE"); return e && !strcmp(e, "off"); }();
+    const int gauge = (!L.op.selected_variant && !no_gauge) ? 1 : 0;
     hipLaunchKernelGGL(k_big_prep, dim3(32, L.nb), dim3(256), 0, st, L.cv, L.fv, L.b0, L.Apart, L.chunk_used, L.G, L.rstride, L.Pc,
-                       L.ystride, L.dx, L.m_out, L.nc_out, L.marg_idx, L.pc_base, ws, wss, n32);
+                       L.ystride, L.dx, L.m_out, L.nc_out, L.marg_idx, L.pc_base, ws, wss, n32, gauge);
     const int* act = L.m_out;                                            // 0 = nothing accepted: every later launch skips the filter
     CholArgs c1 = {};
     c1.W = ws + w.oX1; c1.Y = ws + w.oY1; c1.xs = wss; c1.ld = w.ld1; c1.rows = 2 * n32; c1.ncols = n32;
@@ -690,6 +759,7 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
     launch_gemm(g, st);
     g.B = ws + w.oY2 + 2 * n32; g.C = L.T + (size_t)MP * MP; g.rs = 1; g.cs = 0; g.N = 1; g.n_lim = 1;
     launch_gemm(g, st);
+    if (gauge) hipLaunchKernelGGL(k_big_gauge_fix, dim3(L.nb), dim3(256), 0, st, L.fv, L.b0, L.T, L.mstride, ws, wss, w.oRef, act);
 }
 
 // ---------------------------------------------------------------------------------------------

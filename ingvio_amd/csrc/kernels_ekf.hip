@@ -98,7 +98,11 @@ __global__ __launch_bounds__(EKF_THREADS) void k_ekf_core(
     __syncthreads();
     for (int j = tid; j < m; j += EKF_THREADS) sS[j * LS + j] = sqrt(sS[j * LS + j]);
     __syncthreads();
-    if (bad) atomicOr(&status[b], 4);
+    if (__syncthreads_or(bad)) {                                                    // S = H P H^T + R is not positive definite:
+        for (int r = tid; r < ld; r += EKF_THREADS) dx[r] = 0.0;                   // no update (INGVIO_E_NOT_PD), k_downdate skips the filter
+        if (tid == 0) atomicOr(&status[b], 4);
+        return;
+    }
     // ---- optional block gate on the prior (GnssUpdate.cpp:286: `rows <= 14 && strong_reject && !testChiSquared(.., R, rows)`):
     //      gamma = res^T S^-1 res = |z|^2 is already in the border of the factorisation
     if (gate_max_rows > 0 && m <= gate_max_rows) {
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(256) void k_downdate(CovView cv, int b0, const doub
 {
     const int bl = blockIdx.y, b = b0 + bl;
     const int m = m_all[bl];
-    if (m == 0) return;
+    if (m == 0 || (status[b] & 4)) return;                               // bit 4: S not positive definite, the state stays untouched
     const int n = cv.n[b], ld = cv.ldp;
     const int nt = (n + 15) >> 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(256) void k_downdate64(CovView cv, int b0, const do
     __shared__ Block64Lds sAB;
     __shared__ double sV[4][32][33];
     const int bl = blockIdx.y, b = b0 + bl, m = m_all[bl];
-    if (m == 0) return;
+    if (m == 0 || (status[b] & 4)) return;                               // bit 4: S not positive definite, the state stays untouched
     const int n = cv.n[b], ld = cv.ldp;
     int t = blockIdx.x, bi = 0;
     while (t >= bi + 1) { t -= bi + 1; ++bi; }

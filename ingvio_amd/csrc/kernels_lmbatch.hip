@@ -295,12 +295,14 @@ __global__ __launch_bounds__(256) void k_lm_products(CovView cv, int b0, const d
 
 // dx = Y z (rows < n), Y = carried rows [y_row0, y_row0 + n) of the sweep's output, z = row z_row
 __global__ __launch_bounds__(256) void k_lm_finish(CovView cv, int b0, const double* __restrict__ Y_all, size_t ystride, int ldy, int y_row0,
-                                                   int z_row, const int* __restrict__ m_all, double* __restrict__ dx_all)
+                                                   int z_row, const int* __restrict__ m_all, double* __restrict__ dx_all,
+                                                   const int* __restrict__ status)
 {
     const int bl = blockIdx.y, b = b0 + bl, m = m_all[bl];
     if (m == 0) return;
     const int n = cv.n[b], ld = cv.ldp, r = blockIdx.x * 256 + threadIdx.x;
     if (r >= ld) return;
+    if (status[b] & 4) { dx_all[(size_t)b * ld + r] = 0.0; return; }      // S not positive definite (the sweep's fail bit): no update
     const double* Y = Y_all + (size_t)bl * ystride;
     double d0 = 0.0, d1 = 0.0;
     if (r < n) {
@@ -349,9 +351,9 @@ void launch_lm_build(const LmBuild& L, hipStream_t st)
 }
 
 void launch_lm_finish(CovView cv, int b0, int nb, const double* Y, size_t ystride, int ldy, int y_row0, int z_row, const int* m, double* dx,
-                      hipStream_t st)
+                      const int* status, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_lm_finish, dim3((cv.ldp + 255) / 256, nb), dim3(256), 0, st, cv, b0, Y, ystride, ldy, y_row0, z_row, m, dx);
+    hipLaunchKernelGGL(k_lm_finish, dim3((cv.ldp + 255) / 256, nb), dim3(256), 0, st, cv, b0, Y, ystride, ldy, y_row0, z_row, m, dx, status);
 }
 
 void launch_add_noise(double* X, size_t xstride, int ldx, const double* noise, int nstride, int r_kind, const int* m, int m_cap, int nb,

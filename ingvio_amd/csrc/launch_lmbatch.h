@@ -35,6 +35,6 @@ struct LmBuild {
 };
 void launch_lm_build(const LmBuild& L, hipStream_t st);
 void launch_lm_finish(CovView cv, int b0, int nb, const double* Y, size_t ystride, int ldy, int y_row0, int z_row, const int* m, double* dx,
-                      hipStream_t st);
+                      const int* status /* [B] absolute: bit 4 = the sweep's fail bit, filter skipped */, hipStream_t st);
 void launch_add_noise(double* X, size_t xstride, int ldx, const double* noise, int nstride, int r_kind, const int* m, int m_cap, int nb,
                       hipStream_t st);

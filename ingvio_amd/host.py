@@ -54,7 +54,8 @@ def chi2_quantile(dof, p=0.95):
 def gnss_rows(g):
     """Candidate rows of GnssUpdate::updateTrackedSys (GnssUpdate.cpp:148-272; gates NOT applied — they run on the device,
     ingvio_gnss_update_batch).  g: dict with los[ns,3], sys[ns], res_pos, res_vel, sin_el, ura, psr_std, dopp_std_mps,
-    R_w2ecef[3,3], p_w, v_w, idx_se23, idx_yof, idx_cb[4], idx_fs (psr_amp, dopp_amp optional).
+    R_w2ecef[3,3], p_w, v_w, idx_se23, idx_yof, idx_cb[4], idx_fs (psr_amp, dopp_amp optional).  With g["adjust_yof"] set (the
+    reference's is_adjust_yof = 1) the yaw-offset column is filled from g["R_enu2ecef"] and g["yaw_offset"] (:164-167, :239-242).
     Returns (vidx, vsize, H[rows, ncols], res[rows], Rdiag[rows])."""
     ns = len(g["sys"])
     c_ip = C.POINTER(C.c_int)
@@ -62,9 +63,12 @@ def gnss_rows(g):
     ldh = max(2 * ns, 1)
     H = np.zeros((ldh, 15), order="F"); res = np.zeros(ldh); Rd = np.zeros(ldh)
     vidx = np.zeros(8, dtype=np.int32); vsize = np.zeros(8, dtype=np.int32); nv = C.c_int(0)
-    rows = lib().ingvio_host_gnss_rows(
+    yof = bool(g.get("adjust_yof", False))
+    fn = lib().ingvio_host_gnss_rows_yof if yof else lib().ingvio_host_gnss_rows
+    extra = (_d(_f(np.asarray(g["R_enu2ecef"]).reshape(9))), C.c_double(float(g["yaw_offset"]))) if yof else ()
+    rows = fn(
         C.c_int(ns), _d(_f(g["los"])), sysv.ctypes.data_as(c_ip), _d(_f(g["res_pos"])), _d(_f(g["res_vel"])), _d(_f(g["sin_el"])),
-        _d(_f(g["ura"])), _d(_f(g["psr_std"])), _d(_f(g["dopp_std_mps"])), _d(_f(np.asarray(g["R_w2ecef"]).reshape(9))),
+        _d(_f(g["ura"])), _d(_f(g["psr_std"])), _d(_f(g["dopp_std_mps"])), _d(_f(np.asarray(g["R_w2ecef"]).reshape(9))), *extra,
         _d(_f(g["p_w"])), _d(_f(g["v_w"])), C.c_int(int(g["idx_se23"])), C.c_int(int(g["idx_yof"])), icb.ctypes.data_as(c_ip),
         C.c_int(int(g["idx_fs"])), C.c_double(float(g.get("psr_amp", 1.0))), C.c_double(float(g.get("dopp_amp", 1.0))),
         _d(H), C.c_int(ldh), _d(res), _d(Rd), vidx.ctypes.data_as(c_ip), vsize.ctypes.data_as(c_ip), C.byref(nv))

@@ -86,16 +86,29 @@ class Group:
             self.dist.barrier()
             self.dist.destroy_process_group()
 
-
-    def sum_array(self, a):
-        """All-reduce(sum) of a float64 array (the one exchange step of the feature-sharded filter)."""
-        import numpy as np
-        a = np.ascontiguousarray(a, dtype=np.float64)
+    def sum_device(self, ptr, count, device_index=None):
+        """In-place all-reduce(sum) of `count` doubles at DEVICE pointer `ptr` (a buffer of libingvio_hip.so): torch sees the
+        memory through __cuda_array_interface__ and, with backend "nccl", RCCL reduces it in place over xGMI - no host staging.
+        With the gloo backend (the two-ranks-on-one-GPU test) the view is copied to the host, reduced and copied back.  The
+        caller must have synchronised the stream that produced the buffer; on return the collective has completed."""
         if self.dist is None:
-            return a
-        t = self.torch.from_numpy(a.copy()).to(self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return t.cpu().numpy()
+            return
+        idx = self.local_rank if device_index is None else int(device_index)
+        t = self.torch.as_tensor(_DeviceBuffer(ptr, count), device=self.torch.device("cuda", idx))
+        if self.backend == "nccl":
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        else:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM)
+            t.copy_(h)
+        self.torch.cuda.synchronize(idx)
+
+
+class _DeviceBuffer:
+    """Zero-copy view of a device buffer of `count` doubles for torch (``torch.as_tensor(_DeviceBuffer(...), device=...)``)."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = dict(shape=(int(count),), typestr="<f8", data=(int(ptr), False), version=2, strides=None)
 
 
 def shard_features(frame, world, rank):
@@ -108,7 +121,7 @@ def shard_features(frame, world, rank):
     return out, keep
 
 
-def sharded_frame_update(ctx, grp, b, step, frame, sigma, enable_gnss, sigma_cb, sigma_rw, restore_prior=False):
+def sharded_frame_update(ctx, grp, b, step, frame, sigma, enable_gnss, sigma_cb, sigma_rw, restore_prior=False, device_exchange=True):
     """One frame of ONE filter (replicated prior on every rank, filter b of each rank's context) with its features dealt to the
     ranks: local propagate + clone + gate + Gram, ONE all-reduce of [A | b] (n x (n+1) doubles), then the identical solve + apply +
     marginalisation everywhere.  Returns (dx, accepted feature ids of this rank, rows).  `ctx` must hold only this filter (batch 1)
@@ -118,11 +131,18 @@ def sharded_frame_update(ctx, grp, b, step, frame, sigma, enable_gnss, sigma_cb,
     ctx.frame_stage(b, [step], [local], sigma, enable_gnss, sigma_cb, sigma_rw, max_accept=0, compress_rule=1)
     ctx.frame_run_phase(1, restore_prior=restore_prior)
     _, acc, _ = ctx.frame_fetch(b, 1)
-    A, bvec = ctx.debug_msckf_info(b)
-    packed = np.concatenate([np.column_stack([A, bvec]).reshape(-1), [float(acc[0, :len(keep)].sum())]])
-    tot = grp.sum_array(packed)
-    n = A.shape[0]
-    ctx.info_set(b, tot[:-1].reshape(n, n + 1), int(round(tot[-1])))
+    if device_exchange:
+        # the ONE exchange step, on the device: [A | b | n_accepted] is summed over the chunk partials into one buffer of the
+        # library, all-reduced in place through a zero-copy torch view (RCCL / xGMI with backend "nccl") and committed
+        ptr, count, n = ctx.info_reduce(b)
+        grp.sum_device(ptr, count, getattr(ctx, "device", None))
+        ctx.info_commit(b)
+    else:                                                       # host-staged variant (round 2), kept as the cross-check
+        A, bvec = ctx.debug_msckf_info(b)
+        packed = np.concatenate([np.column_stack([A, bvec]).reshape(-1), [float(acc[0, :len(keep)].sum())]])
+        tot = grp.sum_array(packed)
+        n = A.shape[0]
+        ctx.info_set(b, tot[:-1].reshape(n, n + 1), int(round(tot[-1])))
     ctx.frame_run_phase(2)
     dx, _, rows = ctx.frame_fetch(b, 1)
     return dx[0], keep[acc[0, :len(keep)] != 0], int(rows[0])

@@ -59,6 +59,44 @@ def test_host_chi2_quantile_matches_boost_values():
     assert np.abs(got - z["chi2_095"]).max() < 1e-9
 
 
+def test_gnss_rows_yaw_offset_column_is_the_derivative_of_the_prediction():
+    """is_adjust_yof = 1 (GnssUpdate.cpp:164-167, 239-242; GnssManager::dotRw2enu, GnssManager.cpp:101-113): column 9 of a
+    pseudo-range row is d(range)/d(yaw offset) with the receiver at Renu2ecef Rz(yo) p + anchor, of a Doppler row the same with
+    v — checked by central differences of the geometric prediction, no closed form of the derivative in the test.  Without the
+    flag the column stays zero (every shipped config)."""
+    from ingvio_amd import host
+    rng = np.random.default_rng(12)
+    ns = 6
+    yo = 0.7
+    Q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    R_e2e = Q * np.sign(np.linalg.det(Q))
+    Rz = lambda a: np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]])
+    anchor = np.array([-2.2e6, 5.0e6, 3.2e6])
+    p_w = np.array([12.0, -7.0, 1.5]); v_w = np.array([1.2, 0.4, -0.1])
+    sats = anchor + 2.0e7 * rng.standard_normal((ns, 3))
+    sat_v = 3.0e3 * rng.standard_normal((ns, 3))
+    rcv = lambda a: R_e2e @ Rz(a) @ p_w + anchor
+    los = np.array([(s - rcv(yo)) / np.linalg.norm(s - rcv(yo)) for s in sats])
+    g = dict(los=los, sys=np.array([0, 0, 2, 3, 3, 0]), res_pos=rng.standard_normal(ns), res_vel=rng.standard_normal(ns),
+             sin_el=np.full(ns, 0.7), ura=np.full(ns, 2.0), psr_std=np.ones(ns), dopp_std_mps=np.full(ns, 0.1),
+             R_w2ecef=R_e2e @ Rz(yo), p_w=p_w, v_w=v_w, idx_se23=0, idx_yof=21, idx_cb=[22, -1, 23, 24], idx_fs=25)
+    vidx, vsize, H0, res0, Rd0 = host.gnss_rows(g)
+    assert not H0[:, 9].any()
+    g.update(adjust_yof=True, R_enu2ecef=R_e2e, yaw_offset=yo)
+    vidx1, vsize1, H, res, Rd = host.gnss_rows(g)
+    assert np.array_equal(vidx, vidx1) and np.array_equal(res, res0) and np.array_equal(Rd, Rd0)
+    mask = np.ones(H.shape[1], dtype=bool); mask[9] = False
+    assert np.array_equal(H[:, mask], H0[:, mask])                          # only the yaw-offset column changes
+    h = 1e-4
+    LD = np.longdouble                                                      # a 2e7 m range differenced over 1e-4 rad needs more than 53 bits
+    rng_of = lambda a, i: np.sqrt((((sats[i] - anchor).astype(LD) - (R_e2e @ Rz(a) @ p_w).astype(LD)) ** 2).sum())
+    # range rate with the line of sight held at the linearisation point (dopp_res differentiates the velocity term only)
+    rr_of = lambda a, i: los[i] @ (sat_v[i] - R_e2e @ Rz(a) @ v_w)
+    for i in range(ns):
+        assert abs(H[i, 9] - float(rng_of(yo + h, i) - rng_of(yo - h, i)) / (2 * h)) < 1e-6 * np.linalg.norm(p_w)
+        assert abs(H[ns + i, 9] - (rr_of(yo + h, i) - rr_of(yo - h, i)) / (2 * h)) < 1e-8 * np.linalg.norm(v_w)
+
+
 def test_c_abi_exports_every_declared_symbol():
     """The library loads without a GPU and exports every function include/ingvio_hip.h declares."""
     import re
