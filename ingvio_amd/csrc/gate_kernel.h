@@ -582,3 +582,310 @@ __device__ __forceinline__ void gate3_body(
     }
 }
 
+
+// =============================================================================================
+// K3 + K5, stereo, second generation (round 3): the chi^2 gate in DIFFERENCE coordinates of the observations.
+//
+// With W = [u | E], E = 1 (x) I_3 (Hf = Gblk E) the gate value is  gamma = u^T [K^-1 - K^-1 E (E^T K^-1 E)^-1 E^T K^-1] u + |r_perp|^2 / s^2
+// (see gate3_body), and for any basis Z of null(E^T) the bracket equals Z (Z^T K Z)^-1 Z^T.  null(E^T) = {x : sum_o x_o = 0}; with
+// Z^T x = (x_o - x_b)_{o != b} for a reference observation b (the first one)
+//     gamma = w^T Kr^-1 w + |r_perp|^2 / s^2,      w_o = u_o - u_b,      Kr = Z^T K Z   (3 (nobs - 1) square, SPD).
+// K = Su + s^2 N^-1 with Su[x][y] = D_x Pcc D_y^T and D_x u = X (th_x - th_a) - pl_x p_x for EVERY observation x (for the anchor's
+// own observation the two rotation terms cancel, RemoveLostUpdate.cpp:476-482), so the anchor drops out of the differences:
+//     (D_o - D_b) u = X (th_o - th_b) - (pl_o p_o - pl_b p_b)      =: F_o u_o - F_b u_b,      F_c = [X | -pl_c I]  on clone c's 6 columns
+//     Kr[o][o'] = T_oo' - R_o - R_o'^T + Q + delta_oo' s^2 N_o^-1,
+//     T_oo' = F_o P_oo' F_o'^T   (4 blocks of P per pair),   R_o = F_o P_ob F_b^T   (per observation),   Q = F_b P_bb F_b^T + s^2 N_b^-1.
+// The bordered matrix [[Kr, w], [w^T, 0]] has 3 (nobs - 1) + 1 rows: 31 for an 11-clone window = TWO 16-row tile rows with nothing
+// wasted (first generation: K (33) + 4 border rows -> three tile rows, 21 of its 37 MFMAs in a last tile row holding 5 real rows),
+// 15 MFMAs instead of 37, 8 panels with 2 tile rows instead of 8 with 3 + a scalar tail, no anchor pairs, no G / residuals in LDS.
+// The border row is the LAST row of the last tile (BR); K is padded with unit pivots up to it; after the last panel element (BR, BR)
+// holds -w^T Kr^-1 w.  Same tile / panel machinery as gate3_body.  pl_c = 0 only for the anchor's own observation in the
+// Selected-timestamp variants (quirk Q10), which this form covers as well.
+// =============================================================================================
+template <int CMAX>
+struct Gate4Shared {
+    static constexpr int NR = CMAX - 1;                       // observations after the reference one
+    static constexpr int NPMAX = 3 * NR;
+    static constexpr int NTL = (NPMAX + 1 + 15) / 16;         // tile rows of the bordered matrix
+    static constexpr int BR = 16 * NTL - 1;                   // the border row
+    static constexpr int KPK = NPMAX * (NPMAX + 1) / 2;
+    int gidx[CMAX];                  // state index of the first column of observation o's clone
+    int pl[CMAX];
+    int nobs;
+    double rpsum;                    // sum_o |r_perp,o|^2
+    double pf[3];
+    double vNinv[CMAX][9];           // s^2 N_o^-1
+    double w[3 * CMAX];              // w_o = u_o - u_b at 3 (o - 1)
+    double Rb[CMAX][9];              // R_o; Rb[0] = Q
+    union alignas(16) {
+        double kp[KPK + 16];         // Kr, packed lower triangle by rows (+16: unclamped reads of padding columns)
+        double pan[16 * NTL][4];     // panel exchange of the elimination
+    };
+};
+
+// F_c P(c, c2) F_c2^T for the clones whose first state columns are g and g2 (X = [p_f]x, X^T = -X)
+__device__ __forceinline__ void gate4_pairblock(const double* __restrict__ P, int ld, int g, int g2, double pl, double pl2, double px, double py,
+                                                double pz, double out[9])
+{
+    double Att[9], Atp[9], Apt[9], App[9], T1[9], T2[9];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            Att[3 * m + q] = P[(g + m) + (size_t)(g2 + q) * ld];
+            Atp[3 * m + q] = P[(g + m) + (size_t)(g2 + 3 + q) * ld];
+            Apt[3 * m + q] = P[(g + 3 + m) + (size_t)(g2 + q) * ld];
+            App[3 * m + q] = P[(g + 3 + m) + (size_t)(g2 + 3 + q) * ld];
+        }
+    mulXt(Att, px, py, pz, T1);
+    mulX(T1, px, py, pz, T2);                 // X Ptt' X^T
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[k] = T2[k] + (pl * pl2) * App[k];
+    mulXt(Atp, px, py, pz, T1);               // X^T Ptp' = -X Ptp'
+    mulX(Apt, px, py, pz, T2);                // Ppt' X  = -Ppt' X^T
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[k] += pl2 * T1[k] + pl * T2[k];
+}
+
+template <int CMAX>
+__device__ __forceinline__ void gate4_body(CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out,
+                                           int* __restrict__ accept_out)
+{
+    using SH = Gate4Shared<CMAX>;
+    constexpr int NTL = SH::NTL, NLT = NTL * (NTL + 1) / 2, BR = SH::BR, NPMAX = SH::NPMAX;
+    static_assert(CMAX <= 64 && NPMAX < 16 * NTL, "window class");
+    __shared__ SH sh;
+    // XCD-aware mapping: consecutive workgroups go round-robin to the 8 XCDs, so give every XCD whole filters
+    const int wg = blockIdx.x, xcd = wg & 7, t = wg >> 3;
+    const int bl = xcd + 8 * (t / fmax_used), j = t % fmax_used;
+    if (bl >= nb) return;
+    const int b = b0 + bl, lane = threadIdx.x & (WAVE - 1);
+    const int F = fv.n_feat[b];
+    if (j >= F) return;
+    const int C = fv.n_clones[b], ld = cv.ldp;
+    const double* P = cov_ptr(cv, b);
+    const size_t oidx = (size_t)b * fv.fmax + j;
+    dbg_stamp(5);
+    // ================= per window slot (lane = slot): projection, N_o, u_o, the block against the reference observation =================
+    const int a = fv.anchor[oidx];
+    const double* pf = fv.pf + oidx * 3;
+    const double px = pf[0], py = pf[1], pz = pf[2];
+    const unsigned long long mask = fv.obs_mask[oidx];
+    const int sl = lane;
+    const int cidx = sl < C ? fv.clone_idx[(size_t)b * fv.cmax + sl] : 0;
+    bool valid = false;
+    double Gm[4][3], rs[4];
+    if (sl < C && ((mask >> sl) & 1ULL)) {
+        const double* R = fv.clone_R + ((size_t)b * fv.cmax + sl) * 9;
+        const double* pp = fv.clone_p + ((size_t)b * fv.cmax + sl) * 3;
+        const double* z = fv.uv + (oidx * fv.cmax + sl) * 4;
+        const double zz[4] = { z[0], z[1], z[2], z[3] };
+        valid = feat_obs<true>(R, pp, zz, px, py, pz, op, Gm, rs);          // RemoveLostUpdate.cpp:435-506; false: NaN guard (:486)
+    }
+    const unsigned long long vm = __ballot(valid);
+    const int nobs = __popcll(vm);
+    const bool fok = 4 * nobs - 3 > 0;
+    if (!fok) {
+        if (lane == 0) { gamma_out[oidx] = __builtin_nan(""); accept_out[oidx] = 0; }
+        return;
+    }
+    const int bslot = __ffsll((long long)vm) - 1;                      // the reference observation: the first one (wave-uniform)
+    const int od = __popcll(vm & ((1ULL << sl) - 1ULL));
+    const double plo = (valid && !(op.selected_variant && sl == a)) ? 1.0 : 0.0;
+    const double plb = !(op.selected_variant && bslot == a) ? 1.0 : 0.0;
+    const int gb = __builtin_amdgcn_readlane(cidx, bslot);
+    double u[3] = { 0.0, 0.0, 0.0 }, Ni[9], rr = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Ni[i] = 0.0;
+    if (valid) {
+        double N[9], h[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+#pragma unroll
+            for (int m2 = m; m2 < 3; ++m2) {
+                double sN = 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sN += Gm[q][m] * Gm[q][m2];
+                N[3 * m + m2] = sN; N[3 * m2 + m] = sN;
+            }
+            double hh = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hh += Gm[q][m] * rs[q];
+            h[m] = hh;
+        }
+        inv3sym(N, Ni);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rr += rs[q] * rs[q];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            u[m] = Ni[3 * m] * h[0] + Ni[3 * m + 1] * h[1] + Ni[3 * m + 2] * h[2];
+            rr -= h[m] * u[m];
+        }
+    }
+    const double rsum = wave_sum(rr);
+    double ub[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(u[m]), bslot), hi = __builtin_amdgcn_readlane(__double2hiint(u[m]), bslot);
+        ub[m] = __hiloint2double(hi, lo);
+    }
+    if (lane == 0) { sh.nobs = nobs; sh.rpsum = rsum; sh.pf[0] = px; sh.pf[1] = py; sh.pf[2] = pz; }
+    if (valid) {
+        sh.gidx[od] = cidx;
+        sh.pl[od] = plo != 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sh.vNinv[od][i] = op.var * Ni[i];
+        if (od > 0) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) sh.w[3 * (od - 1) + m] = u[m] - ub[m];
+        }
+        double Rb[9];
+        gate4_pairblock(P, ld, cidx, gb, plo, plb, px, py, pz, Rb);          // R_o = F_o P_ob F_b^T  (o = b: F_b P_bb F_b^T)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sh.Rb[od][i] = od == 0 ? Rb[i] + op.var * Ni[i] : Rb[i];      // Rb[0] = Q
+    }
+    wave_sync();
+    dbg_stamp(7);
+    // ================= Kr blocks, one observation pair per lane =================
+    const int tid = lane;
+    const int nred = nobs - 1, np = 3 * nred;
+    {
+        const int npair = nred * (nred + 1) / 2;
+        double Q[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Q[i] = sh.Rb[0][i];
+        for (int q = tid; q < npair; q += WAVE) {
+            int i = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
+            while ((i + 1) * (i + 2) / 2 <= q) ++i;
+            while (i * (i + 1) / 2 > q) --i;
+            const int i2 = q - i * (i + 1) / 2;
+            const int o = i + 1, o2 = i2 + 1;
+            double Su[9];
+            gate4_pairblock(P, ld, sh.gidx[o], sh.gidx[o2], sh.pl[o] ? 1.0 : 0.0, sh.pl[o2] ? 1.0 : 0.0, px, py, pz, Su);
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) Su[3 * m + k] += Q[3 * m + k] - sh.Rb[o][3 * m + k] - sh.Rb[o2][3 * k + m];
+            if (i == i2) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Su[k] += sh.vNinv[o][k];
+            }
+            // rows 3 i + a of the packed triangle, columns 3 i2 + c (the diagonal blocks only keep c <= a)
+            int tri = (3 * i) * (3 * i + 1) / 2 + 3 * i2;
+#pragma unroll
+            for (int a2 = 0; a2 < 3; ++a2) {
+#pragma unroll
+                for (int c2 = 0; c2 < 3; ++c2)
+                    if (i != i2 || c2 <= a2) sh.kp[tri + c2] = Su[3 * a2 + c2];
+                tri += 3 * i + a2 + 1;
+            }
+        }
+    }
+    wave_sync();
+    dbg_stamp(8);
+    // ================= blocked LDL^T on the matrix cores (see gate3_body) =================
+    const int kq = tid >> 4, l15 = tid & 15;
+    const int npan = (np + 3) >> 2;
+    double4_f T[NLT];
+    bool jreal[NTL];
+#pragma unroll
+    for (int tj = 0; tj < NTL; ++tj) jreal[tj] = 16 * tj + l15 < np;
+#pragma unroll
+    for (int ti = 0; ti < NTL; ++ti) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * ti + kq + 4 * r;
+            const bool ireal = i < np;
+            const int ii = ireal ? i : 0, tri_i = ii * (ii + 1) / 2;
+#pragma unroll
+            for (int tj = 0; tj <= ti; ++tj) {
+                const int jcol = 16 * tj + l15;
+                // strictly-below-diagonal tiles: j < i, one read at (row base + lane); diagonal tiles pick the stored half.  Padding rows /
+                // columns read something valid and are overridden by the selects.
+                double bv;
+                if (tj < ti) bv = sh.kp[tri_i + jcol];
+                else {
+                    const int jj = jreal[tj] ? jcol : 0;
+                    bv = sh.kp[ii >= jj ? tri_i + jj : jj * (jj + 1) / 2 + ii];
+                }
+                const double idv = (i == jcol) ? 1.0 : 0.0;                       // unit pivots on the padding rows
+                double v = (ireal && jreal[tj]) ? bv : ((!ireal && !jreal[tj]) ? idv : 0.0);
+                if (ti == NTL - 1 && r == 3) {                                    // i == BR for kq == 3: the border row w^T, corner 0
+                    const double wv = sh.w[jreal[tj] ? jcol : 0];
+                    v = kq == 3 ? (jreal[tj] ? wv : 0.0) : v;
+                }
+                T[ti * (ti + 1) / 2 + tj][r] = v;
+            }
+        }
+    }
+    wave_sync();                              // kp is dead from here on: its LDS becomes the panel buffer
+    constexpr int KPAN = (NPMAX + 3) / 4;
+#pragma unroll
+    for (int k = 0; k < KPAN; ++k) {
+        if (k < npan) {
+            const int tj0 = k >> 2, cb = 4 * (k & 3);
+            if (l15 >= cb && l15 < cb + 4) {
+#pragma unroll
+                for (int ti = tj0; ti < NTL; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sh.pan[16 * ti + kq + 4 * r][l15 - cb] = T[ti * (ti + 1) / 2 + tj0][r];
+            }
+            wave_sync();
+            double a4[4][4];
+#pragma unroll
+            for (int ra = 0; ra < 4; ++ra) {
+                const double2* pr = reinterpret_cast<const double2*>(sh.pan[4 * k + ra]);
+                const double2 u0 = pr[0], u1 = pr[1];
+                a4[ra][0] = u0.x; a4[ra][1] = u0.y; a4[ra][2] = u1.x; a4[ra][3] = u1.y;
+            }
+            double m[NTL][4];
+#pragma unroll
+            for (int tt = tj0; tt < NTL; ++tt) {
+                const double2* pr = reinterpret_cast<const double2*>(sh.pan[16 * tt + l15]);
+                const double2 u0 = pr[0], u1 = pr[1];
+                m[tt][0] = u0.x; m[tt][1] = u0.y; m[tt][2] = u1.x; m[tt][3] = u1.y;
+            }
+            // 4x4 LDL^T of the diagonal block (every lane, uniform data)
+            const double r0 = fast_rcp(a4[0][0]);
+            const double l10 = a4[1][0] * r0, l20 = a4[2][0] * r0, l30 = a4[3][0] * r0;
+            const double r1 = fast_rcp(a4[1][1] - l10 * a4[1][0]);
+            const double t21 = a4[2][1] - l20 * a4[1][0], t31 = a4[3][1] - l30 * a4[1][0];
+            const double l21 = t21 * r1, l31 = t31 * r1;
+            const double r2 = fast_rcp(a4[2][2] - l20 * a4[2][0] - l21 * t21);
+            const double t32 = a4[3][2] - l30 * a4[2][0] - l31 * t21;
+            const double l32 = t32 * r2;
+            const double r3 = fast_rcp(a4[3][3] - l30 * a4[3][0] - l31 * t31 - l32 * t32);
+            // The last panel of the tile grid (k = 4 NTL - 1) ends ON the border row: BR is its fourth row but not a pivot - it stays
+            // active (finished-row threshold one lower) and its column takes no part in the update (zero pivot reciprocal).
+            const bool bord = (k == 4 * NTL - 1);
+            const double dsel = kq == 0 ? r0 : (kq == 1 ? r1 : (kq == 2 ? r2 : (bord ? 0.0 : r3)));
+            double A[NTL], B[NTL];
+#pragma unroll
+            for (int tt = tj0; tt < NTL; ++tt) {
+                const double x0 = m[tt][0];
+                const double x1 = m[tt][1] - l10 * x0;
+                const double x2 = m[tt][2] - l20 * x0 - l21 * x1;
+                const double x3 = m[tt][3] - l30 * x0 - l31 * x1 - l32 * x2;
+                double xs = kq == 0 ? x0 : (kq == 1 ? x1 : (kq == 2 ? x2 : x3));
+                if (16 * tt + l15 <= 4 * k + (bord ? 2 : 3)) xs = 0.0;   // pivot rows and everything above: finished
+                A[tt] = xs;
+                B[tt] = -xs * dsel;
+            }
+#pragma unroll
+            for (int ti = tj0; ti < NTL; ++ti)
+#pragma unroll
+                for (int tj = tj0; tj <= ti; ++tj)
+                    T[ti * (ti + 1) / 2 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ti], B[tj], T[ti * (ti + 1) / 2 + tj], 0, 0, 0);
+            wave_sync();
+        }
+    }
+    dbg_stamp(9);
+    if (tid == WAVE - 1) {                        // lane (kq = 3, l15 = 15) holds element (BR, BR) = -w^T Kr^-1 w
+        const double g = -T[NLT - 1][3] + sh.rpsum / op.var;
+        const int dof = fv.dof[oidx];
+        const bool ok = dof >= 1 && dof < op.chi2_len && g < op.chi2[dof];      // Update.cpp:120
+        gamma_out[oidx] = g;
+        accept_out[oidx] = ok ? 1 : 0;
+    }
+    dbg_stamp(10);
+}

@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256) void k_big_prep(
 {
     constexpr int NC = BIG_NC, MP = NC;
     __shared__ int sCol[NC];
-    __shared__ double sTr[BIG_CMAX];
+    __shared__ double sTr[BIG_CMAX * 4];
     __shared__ int sRefSlot;
     const BigWs w(n32);
     const int bl = blockIdx.y, b = b0 + bl, tid = threadIdx.x, nwg = gridDim.x, wg = blockIdx.x;
@@ -595,18 +595,31 @@ __global__ __launch_bounds__(256) void k_big_prep(
     // Gauge-reduced form (kernels_solve.hip, k_info_solve): the reference clone = the one with the largest translation
     // information; its block is treated like an absent clone (identity in the covariance, zero in A), the other clones enter
     // through the covariance of their DIFFERENCES to it; k_big_gauge_fix borders M with the reference block afterwards.
-    if (gauge && tid < C) {
-        double tr = 0.0;
-        for (int q = 3; q < 6; ++q) {
-            const size_t e = (size_t)(6 * tid + q) * (ncol + 1) + 6 * tid + q;
-            for (int g = 0; g < G; ++g) if (chunk_used[bl * G + g]) tr += Apart[((size_t)bl * G + g) * rstride + e];
+    if (gauge) {                                              // lane (clone, chunk group of 4): fixed summation order below
+        for (int e0 = tid; e0 < BIG_CMAX * 4; e0 += 256) {
+            const int c = e0 >> 2, g0 = e0 & 3;
+            double tr = 0.0;
+            if (c < C) {
+                for (int g = g0; g < G; g += 4) {
+                    const double* Ap = Apart + ((size_t)bl * G + g) * rstride;
+                    const double u = chunk_used[bl * G + g] ? 1.0 : 0.0;
+                    const size_t e = (size_t)(6 * c + 3) * (ncol + 1) + 6 * c + 3;
+                    tr += u * ((Ap[e] + Ap[e + ncol + 2]) + Ap[e + 2 * (ncol + 2)]);
+                }
+            }
+            sTr[e0] = tr;
         }
-        sTr[tid] = tr;
     }
     __syncthreads();
     if (tid == 0) {
         int best = -1;
-        if (gauge) { best = 0; for (int c = 1; c < C; ++c) if (sTr[c] > sTr[best]) best = c; }
+        if (gauge) {
+            double tb = -1.0;
+            for (int c = 0; c < C; ++c) {
+                const double t = (sTr[4 * c] + sTr[4 * c + 1]) + (sTr[4 * c + 2] + sTr[4 * c + 3]);
+                if (t > tb) { tb = t; best = c; }
+            }
+        }
         sRefSlot = best;
     }
     __syncthreads();
@@ -678,8 +691,8 @@ __global__ __launch_bounds__(256) void k_copy_rows(const double* __restrict__ S,
 
 // The reference clone's block row / column of [M | t]: minus the sums over the other clones' blocks (every block row and column
 // of the n x n solution sums to zero: M = T^-T diag(0, Mr) T^-1, see k_info_solve).  One workgroup per filter.
-__global__ __launch_bounds__(256) void k_big_gauge_fix(FrameView fv, int b0, double* __restrict__ Mall, int mstride, const double* __restrict__ ws_all,
-                                                       size_t ws_stride, size_t oref, const int* __restrict__ active)
+__global__ __launch_bounds__(1024) void k_big_gauge_fix(FrameView fv, int b0, double* __restrict__ Mall, int mstride, const double* __restrict__ ws_all,
+                                                        size_t ws_stride, size_t oref, const int* __restrict__ active)
 {
     constexpr int MP = BIG_NC;
     const int bl = blockIdx.x, tid = threadIdx.x;
@@ -688,18 +701,20 @@ __global__ __launch_bounds__(256) void k_big_gauge_fix(FrameView fv, int b0, dou
     if (ref < 0) return;
     const int C = fv.n_clones[b0 + bl], ref6 = 6 * ref;
     double* Mg = Mall + (size_t)bl * mstride;
-    for (int e = tid; e < 2 * 6 * (MP + 1); e += 256) {
+    for (int e = tid; e < 2 * 6 * (MP + 1); e += 1024) {
         const int side = e / (6 * (MP + 1)), q = e - side * 6 * (MP + 1), k = q / (MP + 1), J = q - k * (MP + 1);
         if (J == MP) {
             if (side == 0) {
                 double s = 0.0;
-                for (int c = 0; c < C; ++c) if (c != ref) s += Mg[(size_t)MP * MP + 6 * c + k];
+#pragma unroll 6
+                for (int c = 0; c < C; ++c) s += (c != ref ? 1.0 : 0.0) * Mg[(size_t)MP * MP + 6 * c + k];
                 Mg[(size_t)MP * MP + ref6 + k] = -s;
             }
         } else if (J < ref6 || J >= ref6 + 6) {
             double s = 0.0;
-            for (int c = 0; c < C; ++c)
-                if (c != ref) s += side == 0 ? Mg[(size_t)(6 * c + k) * MP + J] : Mg[(size_t)J * MP + 6 * c + k];
+            const size_t base = side == 0 ? (size_t)k * MP + J : (size_t)J * MP + k, step = side == 0 ? (size_t)6 * MP : 6;
+#pragma unroll 6
+            for (int c = 0; c < C; ++c) s += (c != ref ? 1.0 : 0.0) * Mg[base + c * step];      // loads independent of the mask: all in flight
             if (side == 0) Mg[(size_t)(ref6 + k) * MP + J] = -s; else Mg[(size_t)J * MP + ref6 + k] = -s;
         }
     }
@@ -759,7 +774,7 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
     launch_gemm(g, st);
     g.B = ws + w.oY2 + 2 * n32; g.C = L.T + (size_t)MP * MP; g.rs = 1; g.cs = 0; g.N = 1; g.n_lim = 1;
     launch_gemm(g, st);
-    if (gauge) hipLaunchKernelGGL(k_big_gauge_fix, dim3(L.nb), dim3(256), 0, st, L.fv, L.b0, L.T, L.mstride, ws, wss, w.oRef, act);
+    if (gauge) hipLaunchKernelGGL(k_big_gauge_fix, dim3(L.nb), dim3(1024), 0, st, L.fv, L.b0, L.T, L.mstride, ws, wss, w.oRef, act);
 }
 
 // ---------------------------------------------------------------------------------------------

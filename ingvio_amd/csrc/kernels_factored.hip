@@ -33,6 +33,15 @@ __global__ __launch_bounds__(GATE_FPW * WAVE) __attribute__((amdgpu_waves_per_eu
     gate3_body<CMAX, STEREO, GATE_FPW, false>(cv, fv, op, b0, nb, fmax_used, gamma_out, accept_out, rec_out);
 }
 
+// Stereo windows up to 16 clones: the gate in difference coordinates of the observations (gate_kernel.h, gate4_body): a
+// 3 (nobs - 1) + 1 bordered system, two 16-row tile rows for an 11-clone window instead of three.  One wave per (feature, filter).
+template <int CMAX>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 6))) void k_feat_gate4(
+    CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out, int* __restrict__ accept_out)
+{
+    gate4_body<CMAX>(cv, fv, op, b0, nb, fmax_used, gamma_out, accept_out);
+}
+
 // ---------------------------------------------------------------------------------------------
 // K4 + K6/K7 in Gram form, second generation: block-sparse part + rank-3 MFMA part.
 //
@@ -805,6 +814,16 @@ static void launch_ft(const FactoredLaunch& L, hipStream_t st)
 {
     if (L.stage == 0) {
         const int nb8 = (L.nb + 7) / 8 * 8;
+        // INGVIO_GATE=3 selects the first-generation gate (K + 4 border rows) for comparison; mono always takes it (its K lives in
+        // the 2-rows-per-observation measurement space, where Hf is not a stack of identities)
+        static const bool gate3 = [] { const char* e = getenv("INGVIO_GATE"); return e && e[0] == '3'; }();
+        if constexpr (STEREO) {
+            if (!gate3) {
+                hipLaunchKernelGGL((k_feat_gate4<CMAX>), dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st, L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used,
+                                   L.gamma, L.accept);
+                return;
+            }
+        }
         hipLaunchKernelGGL((k_feat_gate3<CMAX, STEREO>), dim3(nb8 * ((L.fmax_used + GATE_FPW - 1) / GATE_FPW)), dim3(GATE_FPW * WAVE), 0, st,
                            L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
     } else {

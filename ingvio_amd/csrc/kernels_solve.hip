@@ -382,8 +382,8 @@ __global__ __launch_bounds__(512) void k_info_solve(
     // need the kernel's LDS under 80 KB)
     int* sColF = reinterpret_cast<int*>(&pan[1][0][0]);              // NPF: state column of every window column
     int* sRef = sColF + NPF;                                         // NP: same component in the reference clone's block
-    double* sTr = reinterpret_cast<double*>(sRef + NPF + (NPF & 1)); // 16
-    static_assert(sizeof(int) * (2 * NPF + 2) + sizeof(double) * 16 <= sizeof(double) * PANROWS * 4, "set-up tables exceed a panel buffer");
+    double* sTr = reinterpret_cast<double*>(sRef + NPF + (NPF & 1)); // 16 clones x 16 chunk lanes
+    static_assert(sizeof(int) * (2 * NPF + 2) + sizeof(double) * 256 <= sizeof(double) * PANROWS * 4, "set-up tables exceed a panel buffer");
     const int bl = blockIdx.x, b = b0 + bl, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int kq = lane >> 4, l15 = lane & 15;
     const int C = fv.n_clones[b], ncolF = 6 * C, n = cv.n[b], ld = cv.ldp;
@@ -397,13 +397,17 @@ __global__ __launch_bounds__(512) void k_info_solve(
     }
     const double* P = cov_ptr(cv, b);
     for (int c = tid; c < NPF; c += NTH) { const int cc = c < ncolF ? c : 0; sColF[c] = fv.clone_idx[(size_t)b * fv.cmax + cc / 6] + cc % 6; }
-    if (RED && tid < 16) {                                   // translation information of clone tid: trace of its (p, p) block
-        double tr = -1.0;
-        if (tid < C) {
-            tr = 0.0;
-            for (int q = 3; q < 6; ++q) {
-                const size_t e = (size_t)(6 * tid + q) * (ncolF + 1) + 6 * tid + q;
-                for (int g = 0; g < G; ++g) if (chunk_used[bl * G + g]) tr += Apart[((size_t)bl * G + g) * rstride + e];
+    if (RED && tid < 256) {                                  // translation information of every clone: trace of its (p, p) block
+        // lane (clone c, chunk g): three loads; the per-clone sums over the chunks are taken in chunk order below, so the choice
+        // of the reference clone - and with it every bit of the result - does not depend on the order the lanes ran in
+        const int c = tid >> 4, g0 = tid & 15;
+        double tr = 0.0;
+        if (c < C) {
+            for (int g = g0; g < G; g += 16) {
+                const double* Ap = Apart + ((size_t)bl * G + g) * rstride;
+                const double u = chunk_used[bl * G + g] ? 1.0 : 0.0;
+                const size_t e = (size_t)(6 * c + 3) * (ncolF + 1) + 6 * c + 3;
+                tr += u * ((Ap[e] + Ap[e + ncolF + 2]) + Ap[e + 2 * (ncolF + 2)]);
             }
         }
         sTr[tid] = tr;
@@ -412,8 +416,12 @@ __global__ __launch_bounds__(512) void k_info_solve(
     if (tid == 0) sBad = 0;
     __syncthreads();
     if (RED && tid == 0) {
-        int best = 0;
-        for (int c = 1; c < C; ++c) if (sTr[c] > sTr[best]) best = c;
+        int best = 0; double tb = -1.0;
+        for (int c = 0; c < C; ++c) {
+            double t = 0.0;
+            for (int g = 0; g < 16; ++g) t += sTr[16 * c + g];
+            if (t > tb) { tb = t; best = c; }
+        }
         sRefSlot = best;
     }
     const bool fused = marg_idx && marg_idx[bl] >= 0;

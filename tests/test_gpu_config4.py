@@ -83,7 +83,7 @@ def test_cholesky_qr_on_rank_deficient_msckf_stack(orc, C):
     sv = np.linalg.svd(H, compute_uv=False)
     assert (sv[-6:] < 1e-9 * sv[0]).all() and sv[-7] > 1e-6 * sv[0]          # rank n - 6
     N = 21 + n
-    ctx = capi.Context(batch=3, n_max=((N + 15) // 16) * 16, c_max=C, f_max=8, m_max=max(64, n))
+    ctx = capi.Context(batch=3, n_max=((N + 15) // 16) * 16, c_max=C, f_max=8, m_max=64)      # 6 C update rows: the dense-H route
     rng = np.random.default_rng(C)
     G = rng.standard_normal((N, N)); P0 = 1e-3 * (G @ G.T / N + 0.2 * np.eye(N))
     vidx = [21 + 6 * c for c in range(C)]; vsize = [6] * C
