@@ -177,7 +177,16 @@ def executed_fp64_flops(c):
     valu = 64.0 * (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
                    + 2.0 * c["SQ_INSTS_VALU_FMA_F64"])
     mfma = 512.0 * c["SQ_INSTS_VALU_MFMA_MOPS_F64"]
-    return dict(total=valu + mfma, valu=valu, mfma=mfma)
+    out = dict(total=valu + mfma, valu=valu, mfma=mfma)
+    # lane utilisation of the VALU stream (rocprofiler's derived metric VALUUtilization = SQ_THREAD_CYCLES_VALU /
+    # (SQ_ACTIVE_INST_VALU x wave size)): the share of the 64 lanes that are enabled, averaged over the VALU instructions' cycles.
+    # `useful` discounts the VALU part of the executed operations by it (the counter covers every VALU instruction, not the FP64
+    # ones alone - an approximation, stated as such); matrix-core operations are not lane-masked.
+    if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
+        lu = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+        out["lane_utilisation"] = lu
+        out["useful"] = valu * min(lu, 1.0) + mfma
+    return out
 
 
 def hbm_traffic_bytes(c):
@@ -193,6 +202,7 @@ def hbm_traffic_bytes(c):
 # The library's profile slots are named after the STAGE; rocprofv3 sees kernels.  Stage -> candidates, each candidate a tuple of
 # kernels whose counters are added up (x their launches per step): the first candidate with counters for all its kernels wins.
 STAGE_KERNELS = {
+    "k_feat_gate3": (("k_feat_gate4",), ("k_feat_gate3",)),              # stereo: gate in difference coordinates (round 3) / first generation, mono
     "k_info_update": (("k_info_solve",), ("k_info_update",)),            # windows up to 11 clones / 12..16
     "restore": (("k_restore_strips",), ("k_restore",)),
     "k_lm_build": (("k_lm_build", "k_lm_products"),),
@@ -470,6 +480,9 @@ def run_workload(args, grp, aux=False):
                 e["executed_fp64_mfma_share"] = ex["mfma"] / ex["total"] if ex["total"] else 0.0
                 e["executed_tflops"] = ex["total"] / (avg * 1e-3) / 1e12
                 e["frac_fp64_peak"] = e["executed_tflops"] / FP64_PEAK_TFLOPS
+                if "lane_utilisation" in ex:
+                    e["valu_lane_utilisation"] = ex["lane_utilisation"]
+                    e["useful_frac_fp64_peak"] = ex["useful"] / (avg * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
             tr = hbm_traffic_bytes(c)
             if tr is not None:
                 e["hbm_bytes_per_launch"] = tr
@@ -490,7 +503,8 @@ def run_workload(args, grp, aux=False):
                                 unit="TFLOP/s", frac=k["frac_fp64_peak"],
                                 traffic=k.get("hbm_bytes_per_launch", {}).get("total"), avg_launch_ms=k["avg_ms"],
                                 launches_timed=k["calls"], executed_fp64_flop_per_launch=k["executed_fp64_flop_per_launch"],
-                                mfma_share_of_executed=mf,
+                                mfma_share_of_executed=mf, lane_utilisation=k.get("valu_lane_utilisation"),
+                                useful_frac=k.get("useful_frac_fp64_peak"),
                                 algorithmic=dict(tflops=k.get("algorithmic_tflops"), flop_per_launch=k.get("algorithmic_flop_per_launch"),
                                                  note="SURVEY 8(d) dense formulation of the reference / the same time; not a "
                                                       "fraction of the peak (the kernel executes fewer operations)"),
@@ -499,7 +513,9 @@ def run_workload(args, grp, aux=False):
                                      "lanes, FMA = 2, + SQ_INSTS_VALU_MFMA_MOPS_F64 x 512) / HIP-event time of the launches inside "
                                      "the timed region; peak: FP64 vector and FP64 MFMA peaks coincide on MI355X (78.6 TFLOP/s), "
                                      "`bound` names the pipe that carries most of the executed operations; traffic = HBM bytes per "
-                                     "launch (FETCH_SIZE x 2 + WRITE_SIZE)")
+                                     "launch (FETCH_SIZE x 2 + WRITE_SIZE); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 "
+                                     "SQ_ACTIVE_INST_VALU), useful_frac = (VALU operations x lane_utilisation + matrix-core "
+                                     "operations) / time / peak: the executed figure counts masked-off lanes, this one does not")
             else:
                 roofline = dict(kernel=dom_name, bound="valu", achieved=None, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=None,
                                 traffic=None, avg_launch_ms=k["avg_ms"], launches_timed=k["calls"],

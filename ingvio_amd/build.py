@@ -37,7 +37,7 @@ EXTRA_FLAGS = {"kernels_bigwin.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"
 def build_hip(force=False, verbose=False):
     os.makedirs(LIB, exist_ok=True)
     deps = _all_deps([CSRC, os.path.join(os.path.dirname(HERE), "include")])
-    objs = []
+    objs, cmds = [], []
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     for src in HIP_SOURCES:
         obj = os.path.join(LIB, src.replace(".hip", ".o"))
@@ -49,7 +49,11 @@ def build_hip(force=False, verbose=False):
                 cmd.insert(1, "-DINGVIO_DBG_STAMPS")
             if verbose:
                 print(" ".join(cmd))
-            subprocess.check_call(cmd)
+            cmds.append(cmd)
+    if cmds:                                    # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(cmds), os.cpu_count() or 4)) as ex:
+            list(ex.map(subprocess.check_call, cmds))
     if force or _newer(HIP_LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs
         subprocess.check_call(cmd)

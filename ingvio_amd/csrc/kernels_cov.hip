@@ -67,7 +67,7 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
     const int n = cv.n[b], ld = cv.ldp;
     double* P = cov_ptr(cv, b);
 
-    __shared__ double sPhi[225], sQ[225], sPG[180], sT1[225], sT2[225];
+    __shared__ double sT1[225];                                  // the fused clone's 6 x 21 scratch
     // a chunk of steps' (Phi, G~) fetched at once (one memory latency per chunk); after the composition the
     // same LDS holds the new strip, transposed for the row-wise store
     __shared__ __attribute__((aligned(16))) double sAll[NA_MAX * (PROP_THREADS + 1) > PROP_KCH * 405 ? NA_MAX * (PROP_THREADS + 1) : PROP_KCH * 405];
@@ -86,92 +86,149 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
         for (int j = 0; j < 6; ++j) qpre[j] = P[tid + (size_t)(15 + j) * ld];
     }
     dbg_stamp(16);
-    if (tid < 225) { sPhi[tid] = (tid % 15 == tid / 15) ? 1.0 : 0.0; sQ[tid] = 0.0; }
     const double* PhiB = Phi + (size_t)bl * k * 225;
     const double* GB = G + (size_t)bl * k * 180;
     const double* dtB = dts + (size_t)bl * k;
     for (int s = tid; s < k; s += PROP_THREADS) sDt[s] = dtB[s];
-    // the 5x5 clock block's recursion (sequential in the steps, a few FLOP each) rides on thread 255, which has no element of the
-    // 15 x 15 products: it used to run after the loop on thread 0 with everybody waiting (13 k cycles)
-    int gi[5];
-    double qg[5][5], Tg = 0.0;
-    if (tid == PROP_THREADS - 1) {
-        for (int g = 0; g < 5; ++g) gi[g] = (enable_gnss && gnss_idx) ? gnss_idx[bl * 5 + g] : -1;
-        for (int a = 0; a < 5; ++a) for (int c = 0; c < 5; ++c) qg[a][c] = 0.0;
-    }
-    __syncthreads();
-    for (int s = 0; s < k; ++s) {
-        if (tid == PROP_THREADS - 1) {
-            const double dt = sDt[s];
-            if (gi[4] >= 0) {
-                Tg += dt;
-                for (int g = 0; g < 4; ++g) if (gi[g] >= 0) for (int c = 0; c < 5; ++c) qg[g][c] += dt * qg[4][c];
-                for (int g = 0; g < 4; ++g) if (gi[g] >= 0) for (int r = 0; r < 5; ++r) qg[r][g] += dt * qg[r][4];
+    // Loads that depend on nothing go out first and in this order: the clock-state indices (tiny, the strip's columns depend on
+    // them), the LAST chunk of (Phi, G) (the composition starts with it), then the strip rows P[r, A] of this wave as MFMA
+    // B-operand fragments: lane (kq, l15) holds, for each of its four 16-row tiles rt, P[row(rt, l15), A[4 t + kq]], t = 0..4.
+    int giq[5];
+#pragma unroll
+    for (int g = 0; g < 5; ++g) giq[g] = (enable_gnss && gnss_idx) ? gnss_idx[bl * 5 + g] : -1;
+    constexpr int PER = (PROP_KCH * 405 + PROP_THREADS - 1) / PROP_THREADS;
+    const int nchunk = (k + PROP_KCH - 1) / PROP_KCH;
+    double vch[PER];
+    auto chunk_load = [&](int ci) {                              // all of a chunk's loads are issued before the first LDS store
+        const int s0 = ci * PROP_KCH, cnt = min(PROP_KCH, k - s0);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = tid + u * PROP_THREADS, q = e / 405, w = e - q * 405;
+            vch[u] = e < cnt * 405 ? (w < 225 ? PhiB[(s0 + q) * 225 + w] : GB[(s0 + q) * 180 + (w - 225)]) : 0.0;
+        }
+    };
+    auto chunk_store = [&](int ci) {
+        const int s0 = ci * PROP_KCH, cnt = min(PROP_KCH, k - s0);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = tid + u * PROP_THREADS, w = e % 405;
+            if (e < cnt * 405) sAll[e] = w < 225 ? vch[u] : vch[u] * (w < 225 + 45 ? sg0 : w < 225 + 90 ? sg1 : w < 225 + 135 ? sg2 : sg3);   // G_tmp, :92-96
+        }
+    };
+    chunk_load(nchunk - 1);
+    const int lane = tid & 63, kq = lane >> 4, l15 = lane & 15, wv = tid >> 6;
+    double pvf[4][5];                                            // the strip fragments
+    int naq = 15;
+    double aap[2] = { 0.0, 0.0 };                                // this thread's (up to) two elements of the A x A block, tile 0 only
+    int cg[5] = { 0, 0, 0, 0, 0 };                               // active-set columns 15..19: the clock states that are present, in order
+    auto in_active = [&](int row) { return row < 15 || row == giq[0] || row == giq[1] || row == giq[2] || row == giq[3] || row == giq[4]; };
+    {
+#pragma unroll
+        for (int g = 0; g < 5; ++g) {
+            if (giq[g] >= 0) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) cg[q] = (naq - 15 == q) ? giq[g] : cg[q];
+                ++naq;
             }
-            for (int a = 0; a < 5; ++a) {
-                if (gi[a] < 0) continue;
-                for (int c = 0; c < 5; ++c) {
-                    if (gi[c] < 0) continue;
-                    if (a != 4 && c != 4) qg[a][c] += dt * scb * scb + dt * dt * dt * srw * srw;   // :110
-                    else if (a == 4 && c == 4) qg[a][c] += dt * srw * srw;                         // :112
-                    else qg[a][c] += dt * dt * srw * srw;                                          // :114
+        }
+#pragma unroll
+        for (int t4 = 0; t4 < 5; ++t4) {
+            // column 4 t + kq of the active set (padding: column 0, its Phi_A entries are zero)
+            int cc = 4 * t4 + kq;
+            if (t4 == 3) cc = kq == 3 ? cg[0] : cc;
+            if (t4 == 4) cc = kq == 0 ? cg[1] : (kq == 1 ? cg[2] : (kq == 2 ? cg[3] : cg[4]));
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const int row = blockIdx.x * PROP_THREADS + 64 * wv + 16 * rt + l15;
+                pvf[rt][t4] = row < n ? P[row + (size_t)cc * ld] : 0.0;
+            }
+        }
+        if (blockIdx.x == 0) {
+            auto acol = [&](int i) { return i < 15 ? i : (i == 15 ? cg[0] : i == 16 ? cg[1] : i == 17 ? cg[2] : i == 18 ? cg[3] : cg[4]); };
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = tid + u * PROP_THREADS;
+                if (e < naq * naq) { const int a = e / naq, c = e - a * naq; aap[u] = P[acol(a) + (size_t)acol(c) * ld]; }
+            }
+        }
+    }
+    // the 5x5 clock block's recursion (sequential in the steps, a few FLOP each) rides on thread 255, beside the matrix-core
+    // composition of wave 0
+    // ---- composition of the k IMU steps on the matrix cores, ONE wave, no barrier inside a chunk (round 3) -----------------------
+    // With Psi_s = Phi_k ... Phi_s:   Phi_tot = Psi_1,   Q_tot = sum_s dt_s (Psi_s G~_s)(Psi_s G~_s)^T   (:51 + :97 composed).
+    // Going backwards in s the transposes chain through the MFMA layouts without any data movement: a 16 x 16 result in the C/D
+    // layout (lane (kq, l15), register r = element (kq + 4 r, l15)) IS the B operand of the next product (k-step r), and for
+    // X^T X it is the A operand as well:
+    //     Psi_s^T = Phi_s^T Psi_{s+1}^T          A = Phi_s^T fragments from LDS, B = the registers of Psi_{s+1}^T        (4 MFMA)
+    //     X_s     = G~_s^T Psi_s^T   (12 x 15)   A = G~_s^T fragments from LDS, B = the registers of Psi_s^T             (4 MFMA)
+    //     Q      += dt_s X_s^T X_s               A = B = the registers of X_s                                            (3 MFMA)
+    // (the first version ran two barrier-separated phases of 15-term LDS dot products per step: 3.7 k cycles per step, 37 k of the
+    // kernel's 145 k; the steps of a chunk now take 11 MFMAs each).
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    d4 PsiT = { 0.0, 0.0, 0.0, 0.0 }, Qacc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+    for (int r = 0; r < 4; ++r) PsiT[r] = (kq + 4 * r == l15) ? 1.0 : 0.0;
+    for (int ci = nchunk - 1; ci >= 0; --ci) {
+        const int s0 = ci * PROP_KCH, cnt = min(PROP_KCH, k - s0);
+        if (ci != nchunk - 1) chunk_load(ci);
+        chunk_store(ci);
+        __syncthreads();
+        if (ci == nchunk - 1) dbg_stamp(21);
+        if (tid < 64) {
+            for (int s = s0 + cnt - 1; s >= s0; --s) {
+                const double* sStep = sAll + (s - s0) * 405;
+                const double dt = sDt[s];
+                const bool rowok = l15 < 15;
+                double af[4], gf[4];
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int kk = 4 * t4 + kq;
+                    const bool ok = rowok && kk < 15;
+                    af[t4] = ok ? sStep[kk + 15 * l15] : 0.0;                               // Phi_s^T [i = l15][k = kk]
+                    gf[t4] = (ok && l15 < 12) ? sStep[225 + kk + 15 * l15] : 0.0;           // G~_s^T  [i = l15][k = kk]
+                }
+                d4 nw = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) nw = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t4], PsiT[t4], nw, 0, 0, 0);
+                PsiT = nw;
+                d4 X = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) X = __builtin_amdgcn_mfma_f64_16x16x4f64(gf[t4], PsiT[t4], X, 0, 0, 0);
+#pragma unroll
+                for (int t4 = 0; t4 < 3; ++t4) Qacc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[t4], dt * X[t4], Qacc, 0, 0, 0);
+            }
+        }
+        else if (wv == 3 && ci == nchunk - 1) {
+            // beside wave 0's first chunk: the 5 x 5 clock block's recursion over ALL steps (sequential in the steps, :56-86 and
+            // :99-116 composed), one element per lane of wave 3: lane e = 5 a + c holds qg[a][c]; a step is two lane exchanges
+            // (row 4 into the present rows, then the updated column 4 into the present columns) and the noise terms.
+            const int ea = lane / 5, ec = lane - 5 * ea;
+            auto present = [&](int q) { return (q == 0 ? giq[0] : q == 1 ? giq[1] : q == 2 ? giq[2] : q == 3 ? giq[3] : giq[4]) >= 0; };
+            const bool el = lane < 25, pa = el && present(ea), pc = el && present(ec), has_fs = giq[4] >= 0;
+            double v = 0.0, Tg = 0.0;
+#pragma unroll 1
+            for (int s = 0; s < k; ++s) {
+                const double dt = sDt[s];
+                if (has_fs) {
+                    Tg += dt;
+                    const double x = __shfl(v, 20 + (el ? ec : 0), WAVE);          // qg[4][c]
+                    if (pa && ea < 4) v += dt * x;
+                    const double y = __shfl(v, el ? 5 * ea + 4 : 0, WAVE);          // qg[r][4], after the row pass
+                    if (pc && ec < 4) v += dt * y;
+                }
+                if (pa && pc) {
+                    if (ea != 4 && ec != 4) v += dt * scb * scb + dt * dt * dt * srw * srw;      // :110
+                    else if (ea == 4 && ec == 4) v += dt * srw * srw;                            // :112
+                    else v += dt * dt * srw * srw;                                               // :114
                 }
             }
+            if (el) sQg[lane] = v;
+            if (lane == 0) sQg[25] = Tg;
         }
-        if (s % PROP_KCH == 0) {
-            const int cnt = min(PROP_KCH, k - s);
-            // all of the chunk's loads are issued before the first LDS store (a rolled loop pays one memory latency per pass)
-            constexpr int PER = (PROP_KCH * 405 + PROP_THREADS - 1) / PROP_THREADS;
-            double v[PER];
-#pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                const int e = tid + u * PROP_THREADS, q = e / 405, w = e - q * 405;
-                v[u] = e < cnt * 405 ? (w < 225 ? PhiB[(s + q) * 225 + w] : GB[(s + q) * 180 + (w - 225)]) : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                const int e = tid + u * PROP_THREADS, w = e % 405;
-                if (e < cnt * 405) sAll[e] = w < 225 ? v[u] : v[u] * (w < 225 + 45 ? sg0 : w < 225 + 90 ? sg1 : w < 225 + 135 ? sg2 : sg3);   // G_tmp, :92-96
-            }
-            __syncthreads();
-            if (s == 0) dbg_stamp(21);
-        }
-        const double* sStep = sAll + (s % PROP_KCH) * 405;
-        const double* sG = sStep + 225;
-        const double dt = sDt[s];
-        const int i = tid % 15, j = tid / 15;
-        // the dot products are unrolled so that all operand reads are in flight before the first FMA (rolled, every FMA waited
-        // for its own two LDS reads: 6.4 k cycles per step)
-        if (tid < 180) {
-            double a = 0.0;
-#pragma unroll
-            for (int l = 0; l < 15; ++l) a += sStep[i + 15 * l] * sG[l + 15 * j];
-            sPG[tid] = a;                                                   // Phi * G_tmp
-        }
-        if (tid < 225) {
-            double a = 0.0, c = 0.0;
-#pragma unroll
-            for (int l = 0; l < 15; ++l) { a += sStep[i + 15 * l] * sQ[l + 15 * j]; c += sStep[i + 15 * l] * sPhi[l + 15 * j]; }
-            sT1[tid] = a; sT2[tid] = c;
-        }
-        __syncthreads();
-        if (tid < 225) {
-            double a = 0.0, q = 0.0;
-#pragma unroll
-            for (int l = 0; l < 15; ++l) a += sT1[i + 15 * l] * sStep[j + 15 * l];
-#pragma unroll
-            for (int l = 0; l < 12; ++l) q += sPG[i + 15 * l] * sPG[j + 15 * l];
-            sQ[tid] = a + dt * q;                                           // :51 + :97 composed
-            sPhi[tid] = sT2[tid];
-        }
-        __syncthreads();
+        __syncthreads();                                        // the chunk's LDS may be overwritten
     }
     dbg_stamp(17);
     for (int a = tid; a < NA_MAX * NA_MAX; a += PROP_THREADS) { sPhiA[a] = 0.0; sQA[a] = 0.0; }
-    if (tid == PROP_THREADS - 1) {
-        for (int a = 0; a < 5; ++a) for (int c = 0; c < 5; ++c) sQg[5 * a + c] = qg[a][c];
-        sQg[25] = Tg;
-    }
     __syncthreads();
     // active set + GNSS clock block (thread 0, bookkeeping only)
     if (tid == 0) {
@@ -192,33 +249,54 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
             for (int c = 0; c < 5; ++c) if (loc[c] >= 0) sQA[loc[a] * NA_MAX + loc[c]] = qg[a][c];
         }
     }
-    if (tid < 225) {
-        const int a = tid % 15, c = tid / 15;
-        sPhiA[a * NA_MAX + c] = sPhi[a + 15 * c];
-        sQA[a * NA_MAX + c] = sQ[a + 15 * c];
+    __syncthreads();                                            // the zero fill and thread 0's clock entries before wave 0's block
+    if (tid < 64) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = kq + 4 * r;
+            if (l15 < 15 && c < 15) {
+                sPhiA[l15 * NA_MAX + c] = PsiT[r];              // Psi^T[c][l15] = Phi_tot(l15, c)
+                sQA[c * NA_MAX + l15] = Qacc[r];                // Q(c, l15)
+            }
+        }
     }
     __syncthreads();
     dbg_stamp(18);
     const int na = sNA;
-    // strip rows outside A
-    const int r = blockIdx.x * PROP_THREADS + tid;
-    bool inA = r < 15;
-    for (int a = 15; a < na; ++a) inA |= (sA[a] == r);
-    if (r < n && !inA) {
-        double s[NA_MAX];
+    // ---- strip rows outside A on the matrix cores:  (P[r, A] Phi_A^T)^T = Phi_A P[r, A]^T, 16 rows r per tile -------------------
+    // A operand = Phi_A fragments (ten per lane, read from LDS once), B operand = the prefetched strip fragments; the result tile
+    // (i = active index, j = row) lands with the rows along the 16 lanes: the lower-strip store P[r, A[i]] is coalesced, the upper
+    // strip goes through LDS as before.  (First version: every thread one row, 20 outputs x 20 FMAs with Phi_A broadcast from LDS -
+    // 8 waves x 10 ds_read_b128 per output column made the phase LDS-issue bound: 23 k of the kernel's 91 k cycles.)
+    {
+        double phf[2][5];
 #pragma unroll
-        for (int a = 0; a < NA_MAX; ++a) s[a] = P[r + (size_t)sA[a] * ld];      // 20 independent loads in flight
-        // one output column at a time: keeps the live set at s[] + one row of Phi_A (the fully unrolled
-        // 20x20 form hoists all 400 LDS reads and spills)
-#pragma unroll 1
-        for (int a = 0; a < na; ++a) {
-            const double2* ph = reinterpret_cast<const double2*>(sPhiA + a * NA_MAX);
-            double acc0 = 0.0, acc1 = 0.0;
+        for (int it = 0; it < 2; ++it)
 #pragma unroll
-            for (int c = 0; c < NA_MAX / 2; ++c) { const double2 w = ph[c]; acc0 += s[2 * c] * w.x; acc1 += s[2 * c + 1] * w.y; }
-            const double o = acc0 + acc1;
-            P[r + (size_t)sA[a] * ld] = o;
-            sStrip[a * (PROP_THREADS + 1) + tid] = o;
+            for (int t4 = 0; t4 < 5; ++t4) {
+                const int i = 16 * it + l15;
+                phf[it][t4] = i < NA_MAX ? sPhiA[i * NA_MAX + 4 * t4 + kq] : 0.0;          // Phi_A[i][k = 4 t + kq]
+            }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            const int rloc = 64 * wv + 16 * rt + l15, row = blockIdx.x * PROP_THREADS + rloc;
+            const bool ina = in_active(row);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                d4 acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                for (int t4 = 0; t4 < 5; ++t4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(phf[it][t4], pvf[rt][t4], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * it + kq + 4 * r;
+                    // state column of active index i, from registers (i < 15: itself; 15..19: the clock states)
+                    const int ci = it == 0 ? (i < 15 ? i : cg[0]) : (kq == 0 ? cg[1] : kq == 1 ? cg[2] : kq == 2 ? cg[3] : cg[4]);
+                    if (i < na) {
+                        sStrip[i * (PROP_THREADS + 1) + rloc] = acc[r];
+                        if (row < n && !ina) P[row + (size_t)ci * ld] = acc[r];
+                    }
+                }
+            }
         }
     }
     lds_barrier();
@@ -228,9 +306,7 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
         const int a = tid & 15, rr0 = tid >> 4;
         for (int rr = rr0; rr < PROP_THREADS; rr += PROP_THREADS / 16) {
             const int r2 = blockIdx.x * PROP_THREADS + rr;
-            bool in2 = r2 < 15;
-            for (int q = 15; q < na; ++q) in2 |= (sA[q] == r2);
-            if (r2 < n && !in2) {
+            if (r2 < n && !in_active(r2)) {
                 if (a < na) P[sA[a] + (size_t)r2 * ld] = sStrip[a * (PROP_THREADS + 1) + rr];
                 if (a + 16 < na) P[sA[a + 16] + (size_t)r2 * ld] = sStrip[(a + 16) * (PROP_THREADS + 1) + rr];
             }
@@ -239,9 +315,10 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
     dbg_stamp(19);
     // A x A block, tile 0 only
     if (blockIdx.x == 0) {
-        for (int e = tid; e < na * na; e += PROP_THREADS) {
-            const int a = e / na, c = e % na;
-            sX[a * NA_MAX + c] = P[sA[a] + (size_t)sA[c] * ld];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                          // requested at the top of the kernel (behind the strip's stores a load
+            const int e = tid + u * PROP_THREADS;              // issued here would wait for their acknowledgements: one vmcnt queue)
+            if (e < na * na) { const int a = e / na, c = e - a * na; sX[a * NA_MAX + c] = aap[u]; }
         }
         lds_barrier();
         for (int e = tid; e < na * na; e += PROP_THREADS) {

@@ -104,6 +104,17 @@ class Group:
         self.torch.cuda.synchronize(idx)
 
 
+    def sum_array(self, a):
+        """All-reduce(sum) of a float64 host array (the host-staged variant of the feature-sharded filter's exchange step)."""
+        import numpy as np
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if self.dist is None:
+            return a
+        t = self.torch.from_numpy(a.copy()).to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+
 class _DeviceBuffer:
     """Zero-copy view of a device buffer of `count` doubles for torch (``torch.as_tensor(_DeviceBuffer(...), device=...)``)."""
 
