@@ -157,12 +157,15 @@ int ingvio_mld(ingvio_ctx* ctx);                      /* row stride of keep_out 
  * from the broadcast ephemerides at transmit time (gnss_comm/src/gnss_spp.cpp:50-98, gnss_utility.cpp:390-640), elevation,
  * Saastamoinen/Niell and Klobuchar delays (:762-899), pseudo-range and Doppler residuals (gnss_spp.cpp:100-146, :256-282).
  * ingvio_gnss_front_stage evaluates all of it for every filter of the range (one lane per satellite) and writes the candidate
- * rows where ingvio_gnss_stage would have put them: follow with ingvio_gnss_run / ingvio_gnss_fetch.  GLONASS satellites are
- * skipped (their Runge-Kutta orbit is not built).  Times are seconds of the GPS week.
+ * rows where ingvio_gnss_stage would have put them: follow with ingvio_gnss_run / ingvio_gnss_fetch.  GLONASS satellites take
+ * geph2svdt / geph2pos / geph2vel (gnss_utility.cpp:642-731: Runge-Kutta integration of the broadcast PZ-90 state vector).
+ * Times are seconds of the GPS week.
  * Flat records of doubles:
  *   ephemeris [INGVIO_EPH_N]: sys (gnss_comm::sys2idx: GPS 0, GLO 1, GAL 2, BDS 3), prn, toe, toe in the constellation's own
  *     week (BDS: BDT of toe - 14 s, gnss_utility.cpp:489; else = toe), toc, A, e, i0, omg, OMG0, M0, delta_n, OMG_dot, i_dot,
  *     cuc, cus, crc, crs, cic, cis, af0, af1, af2, tgd[0], ura
+ *     GLONASS (sys == 1, GloEphem): sys, prn, toe (GPS week seconds), 0, 0, pos[3], vel[3], acc[3] (m, m/s, m/s^2, PZ-90 ECEF),
+ *     tau_n, gamma, zeros up to ura at [24]; the observation's frequency is the satellite's FDMA channel
  *   observation [INGVIO_OBS_N]: receive time, L1 pseudo-range (m), L1 Doppler (Hz), psr_std, dopp_std, L1 frequency (Hz, < 0: no L1) */
 #define INGVIO_EPH_N 25
 #define INGVIO_OBS_N 6
@@ -181,9 +184,17 @@ typedef struct {
     double psr_noise_amp, dopp_noise_amp;     /* GnssUpdate::_psr_noise_amp / _dopp_noise_amp                          */
 } ingvio_gnss_epoch;
 int ingvio_gnss_front_stage(ingvio_ctx* ctx, int b0, int nb, const ingvio_gnss_epoch* epochs, const ingvio_gnss_opts* opts);
-/* per-satellite results of the last front_stage: out [nb][INGVIO_GNSS_MAX_SAT][10] = res_pos, res_vel, unit receiver->satellite
- * (3), azimuth, elevation, ionosphere delay, troposphere delay, usable (1/0) */
+/* per-satellite results of the last front_stage: out [nb][INGVIO_GNSS_MAX_SAT][INGVIO_GNSS_SAT_REC] = res_pos, res_vel, unit
+ * receiver->satellite (3), azimuth, elevation, ionosphere delay, troposphere delay, usable (1/0), then the gnss_comm::SatState
+ * (gnss_constant.hpp:506-516): pos (3), vel (3), dt, ddt, tgd, transmit time */
+#define INGVIO_GNSS_SAT_REC 20
 int ingvio_gnss_front_fetch(ingvio_ctx* ctx, int b0, int nb, double* out);
+/* The same evaluation for any list of epochs, detached from the filters and from the staged rows (the idx_* / noise fields of
+ * the epochs are ignored): the residual evaluator of gnss_comm::psr_pos (gnss_spp.cpp:148-254) and GvioAligner::batchAlign
+ * (GvioAligner.cpp:88-383), whose iterations live in the host shim (host/GvioAligner.cpp).  To evaluate at a receiver given in
+ * ECEF set R_enu2ecef = I, yaw_offset = 0, p_w = 0, anchor_ecef = position, v_w = ECEF velocity.
+ * out [n_epochs][INGVIO_GNSS_MAX_SAT][INGVIO_GNSS_SAT_REC]. */
+int ingvio_gnss_sat_eval(ingvio_ctx* ctx, int n_epochs, const ingvio_gnss_epoch* epochs, double* out);
 
 /* ---- feature-sharded single filter (optional mode): the per-feature work (K3-K5 gate, K6/K7 in information form)
  * is independent given the prior, so G replicas of ONE filter can each take F/G of the frame's features:

@@ -29,7 +29,7 @@ EXPORTS = [
     "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_set_qr_method", "ingvio_landmark_stage", "ingvio_landmark_run",
     "ingvio_landmark_fetch", "ingvio_frame_run_phase", "ingvio_info_set", "ingvio_debug_read", "ingvio_triangulate",
     "ingvio_gnss_front_stage", "ingvio_gnss_front_fetch", "ingvio_gnss_update_batch", "ingvio_gnss_stage", "ingvio_gnss_run", "ingvio_gnss_fetch", "ingvio_mld", "ingvio_debug_msckf_info", "ingvio_debug_info_solution",
-    "ingvio_info_reduce", "ingvio_info_commit",
+    "ingvio_info_reduce", "ingvio_info_commit", "ingvio_gnss_sat_eval",
     "ingvio_chi2_gamma_multi", "ingvio_ekf_update_batch", "ingvio_add_variable_delayed_invertible", "ingvio_add_variable_delayed", "ingvio_replace_var_linear",
 ]
 
@@ -351,9 +351,8 @@ class Context:
         self._chk(self.L.ingvio_gnss_stage(self.h, b0, len(blocks), arr, C.byref(o)))
         self._gnss_range = (b0, len(blocks))
 
-    def gnss_front_stage(self, b0, epochs, chi2_table, gate_rows=True, strong_reject=False):
-        """epochs: per filter a dict(eph [ns,25], obs [ns,6], ion [8] or None, doy, p_w, v_w, cb [4], fs, yaw_offset, R_enu2ecef [3,3],
-        anchor_ecef, idx_se23, idx_yof, idx_fs, idx_cb [4], psr_amp, dopp_amp): raw GNSS epochs -> candidate rows on the device."""
+    @staticmethod
+    def _gnss_epochs(epochs):
         nb = len(epochs)
         arr = (GnssEpoch * nb)(); keep = []
         for i, e in enumerate(epochs):
@@ -369,15 +368,31 @@ class Context:
             a.idx_se23 = int(e["idx_se23"]); a.idx_yof = int(e["idx_yof"]); a.idx_fs = int(e["idx_fs"])
             a.idx_cb = (C.c_int * 4)(*[int(x) for x in e["idx_cb"]])
             a.psr_noise_amp = float(e.get("psr_amp", 1.0)); a.dopp_noise_amp = float(e.get("dopp_amp", 1.0))
+        return arr, keep
+
+    def gnss_sat_eval(self, epochs):
+        """ingvio_gnss_sat_eval: the front's per-satellite records [n_epochs, 64, 20] for free-standing epochs (dicts as for
+        gnss_front_stage; the idx_* entries may be omitted)."""
+        eps = [dict(dict(idx_se23=0, idx_yof=0, idx_fs=0, idx_cb=[-1] * 4), **e) for e in epochs]
+        arr, keep = self._gnss_epochs(eps)
+        out = np.zeros((len(eps), 64, 20))
+        self._chk(self.L.ingvio_gnss_sat_eval(self.h, len(eps), arr, _d(out)))
+        return out
+
+    def gnss_front_stage(self, b0, epochs, chi2_table, gate_rows=True, strong_reject=False):
+        """epochs: per filter a dict(eph [ns,25], obs [ns,6], ion [8] or None, doy, p_w, v_w, cb [4], fs, yaw_offset, R_enu2ecef [3,3],
+        anchor_ecef, idx_se23, idx_yof, idx_fs, idx_cb [4], psr_amp, dopp_amp): raw GNSS epochs -> candidate rows on the device."""
+        nb = len(epochs)
+        arr, keep = self._gnss_epochs(epochs)
         tab = f64(chi2_table)
         o = GnssOpts(); o.gate_rows = int(gate_rows); o.strong_reject = int(strong_reject); o.chi2_table = _d(tab); o.chi2_len = len(tab)
         self._chk(self.L.ingvio_gnss_front_stage(self.h, b0, nb, arr, C.byref(o)))
         self._gnss_range = (b0, nb)
 
     def gnss_front_fetch(self, b0=None, nb=None):
-        """-> [nb, 64, 10]: res_pos, res_vel, los (3), az, el, ion, tro, usable per satellite"""
+        """-> [nb, 64, 20]: res_pos, res_vel, los (3), az, el, ion, tro, usable, then the SatState: pos (3), vel (3), dt, ddt, tgd, ttx"""
         b0, nb = (self._gnss_range if b0 is None else (b0, nb))
-        out = np.zeros((nb, 64, 10))
+        out = np.zeros((nb, 64, 20))
         self._chk(self.L.ingvio_gnss_front_fetch(self.h, b0, nb, _d(out)))
         return out
 

@@ -1153,6 +1153,54 @@ int ingvio_gnss_front_stage(ingvio_ctx* c, int b0, int nb, const ingvio_gnss_epo
     return last_launch(c);
 }
 
+// gnss_comm::sat_states + psr_res + dopp_res for an arbitrary list of epochs, detached from the filters of the context and from
+// the staged update rows: what GvioAligner::batchAlign (GvioAligner.cpp:88-383) and gnss_comm::psr_pos (gnss_spp.cpp:148-254)
+// iterate on.  One launch for all epochs, temporary device buffers, nothing of the context's state is touched.
+int ingvio_gnss_sat_eval(ingvio_ctx* c, int n_epochs, const ingvio_gnss_epoch* ep, double* out)
+{
+    if (!c || n_epochs < 1 || !ep || !out) return INGVIO_E_ARG;
+    const size_t S = INGVIO_GNSS_MAX_SAT;
+    for (int i = 0; i < n_epochs; ++i) {
+        const ingvio_gnss_epoch& e = ep[i];
+        if (e.n_sat < 0 || e.n_sat > INGVIO_GNSS_MAX_SAT) return INGVIO_E_CAPACITY;
+        if (e.n_sat && (!e.eph || !e.obs)) return INGVIO_E_ARG;
+    }
+    std::vector<double> he((size_t)n_epochs * S * GE_N, 0.0), ho((size_t)n_epochs * S * GO_N, 0.0), hr((size_t)n_epochs * GR_N, 0.0);
+    for (int i = 0; i < n_epochs; ++i) {
+        const ingvio_gnss_epoch& e = ep[i];
+        if (e.n_sat) {
+            memcpy(he.data() + (size_t)i * S * GE_N, e.eph, 8 * (size_t)e.n_sat * GE_N);
+            memcpy(ho.data() + (size_t)i * S * GO_N, e.obs, 8 * (size_t)e.n_sat * GO_N);
+        }
+        double* r = hr.data() + (size_t)i * GR_N;
+        r[GR_NSAT] = e.n_sat; r[GR_DOY] = e.doy; r[GR_HAVE_ION] = e.ion ? 1.0 : 0.0;
+        if (e.ion) memcpy(r + GR_ION, e.ion, 64);
+        memcpy(r + GR_PW, e.p_w, 24); memcpy(r + GR_VW, e.v_w, 24); memcpy(r + GR_CB, e.cb, 32);
+        r[GR_FS] = e.fs; r[GR_YAW] = e.yaw_offset;
+        memcpy(r + GR_RENU, e.R_enu2ecef, 72); memcpy(r + GR_ANCHOR, e.anchor_ecef, 24);
+        for (int s4 = 0; s4 < 4; ++s4) r[GR_IDX_CB + s4] = -1.0;
+        r[GR_PSR_AMP] = e.psr_noise_amp; r[GR_DOPP_AMP] = e.dopp_noise_amp;
+    }
+    double *de = nullptr, *dob = nullptr, *dr = nullptr, *df = nullptr;
+    auto freeall = [&]() { for (double* q : { de, dob, dr, df }) if (q) hipFree(q); };
+    if (hipMalloc((void**)&de, 8 * he.size()) != hipSuccess || hipMalloc((void**)&dob, 8 * ho.size()) != hipSuccess ||
+        hipMalloc((void**)&dr, 8 * hr.size()) != hipSuccess || hipMalloc((void**)&df, 8 * (size_t)n_epochs * 64 * GF_N) != hipSuccess) {
+        freeall();
+        return INGVIO_E_HIP;
+    }
+    int rc = up(c, de, he.data(), 8 * he.size()) | up(c, dob, ho.data(), 8 * ho.size()) | up(c, dr, hr.data(), 8 * hr.size());
+    if (!rc) {
+        GnssFrontLaunch L;
+        memset(&L, 0, sizeof L);
+        L.eph = de; L.obs = dob; L.rcv = dr; L.smax = (int)S; L.front = df;      // L.H == nullptr: no candidate rows
+        launch_gnss_front(L, n_epochs, c->st);
+        rc = down_sync(c, out, df, 8 * (size_t)n_epochs * 64 * GF_N);
+    }
+    hipStreamSynchronize(c->st);
+    freeall();
+    return rc ? INGVIO_E_HIP : last_launch(c);
+}
+
 int ingvio_gnss_front_fetch(ingvio_ctx* c, int b0, int nb, double* out)
 {
     if (check_range(c, b0, nb) || !out || !c->gn.front) return INGVIO_E_ARG;

@@ -1,6 +1,7 @@
 // facade.cpp — small extern "C" surface of libingvio_host.so for the Python harness (bench.py,
 // tests): lets Python drive the C++ host shim without a C++ test runner.  Not part of the HIP ABI.
 #include "GnssUpdate.h"
+#include "GvioAligner.h"
 #include "ImuTransition.h"
 #include "Update.h"
 
@@ -77,6 +78,33 @@ int ingvio_host_gnss_rows_yof(int nsat, const double* los, const int* sys, const
     g.has_yof_jac = true;
     return ingvio::gnssCandidateRows(g, ingvio::Vec3d(p_w), ingvio::Vec3d(v_w), idx_se23, idx_yof, idx_cb, idx_fs, psr_amp, dopp_amp,
                                      H, ldh, res, Rd, vidx, vsize, nvar, true);
+}
+
+// GvioAligner::batchAlign (GvioAligner.cpp:88-197) driven from Python: n_epochs raw epochs (flat records as ingvio_gnss_epoch wants
+// them, at most smax satellites each) with the VIO position / velocity of each; the call that finds the buffer full
+// (n_epochs = batch_size + 1) runs the alignment.  out[22] = aligned, yaw offset, refined anchor (3), R_enu2ecef row-major (9),
+// receiver clock drift of the yaw stage, rough anchor xyzt (7).
+int ingvio_host_aligner_run(void* ctx, int n_epochs, int smax, const double* eph, const double* obs, const int* nsat, const double* doy,
+                            const double* p_w, const double* v_w, const double* iono, int batch_size, int max_iter, double conv_epsilon,
+                            double vel_thres, double* out)
+{
+    ingvio::GvioAligner al((ingvio_ctx*)ctx, batch_size, max_iter, conv_epsilon, vel_thres);
+    std::vector<double> ion;
+    if (iono) ion.assign(iono, iono + 8);
+    for (int i = 0; i < n_epochs; ++i) {
+        ingvio::RawGnssEpoch m;
+        m.eph.assign(eph + (size_t)i * smax * INGVIO_EPH_N, eph + ((size_t)i * smax + nsat[i]) * INGVIO_EPH_N);
+        m.obs.assign(obs + (size_t)i * smax * INGVIO_OBS_N, obs + ((size_t)i * smax + nsat[i]) * INGVIO_OBS_N);
+        m.doy = doy[i];
+        al.batchAlign(m, ingvio::Vec3d(p_w + 3 * i), ingvio::Vec3d(v_w + 3 * i), ion);
+    }
+    const ingvio::GvioAlignment a = al.alignment();
+    out[0] = a.aligned ? 1.0 : 0.0; out[1] = a.yaw_offset;
+    for (int c = 0; c < 3; ++c) out[2 + c] = a.anchor_ecef[c];
+    for (int c = 0; c < 9; ++c) out[5 + c] = a.R_enu2ecef.m[c];
+    out[14] = al.lastRcvDdt();
+    for (int c = 0; c < 7; ++c) out[15 + c] = al.lastRoughAnchor()[c];
+    return a.aligned ? 1 : 0;
 }
 
 double ingvio_host_chi2_quantile(int dof, double p) { return ingvio::chi2Quantile(dof, p); }

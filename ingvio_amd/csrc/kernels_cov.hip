@@ -289,11 +289,9 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = 16 * it + kq + 4 * r;
-                    // state column of active index i, from registers (i < 15: itself; 15..19: the clock states)
-                    const int ci = it == 0 ? (i < 15 ? i : cg[0]) : (kq == 0 ? cg[1] : kq == 1 ? cg[2] : kq == 2 ? cg[3] : cg[4]);
                     if (i < na) {
                         sStrip[i * (PROP_THREADS + 1) + rloc] = acc[r];
-                        if (row < n && !ina) P[row + (size_t)ci * ld] = acc[r];
+                        if (row < n && !ina) P[row + (size_t)sA[i] * ld] = acc[r];
                     }
                 }
             }

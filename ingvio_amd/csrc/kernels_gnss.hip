@@ -6,8 +6,9 @@
 // (ingvio_estimator/src/GnssUpdate.cpp:148-272) written straight into the staged-row buffers ingvio_gnss_run gates and
 // applies: a GNSS epoch goes from raw observations to the posterior without leaving the device.
 // Scalar geodesy with transcendental functions: bound by the latency of a few hundred dependent FP64 operations per lane, the
-// point is that it runs for every filter of the batch at once and needs no host assembly.  GLONASS (Runge-Kutta orbit
-// integration, gnss_utility.cpp:642-731) is not built: its satellites are skipped.  gfx950 only.
+// point is that it runs for every filter of the batch at once and needs no host assembly.  GLONASS satellites (round 3) carry a
+// PZ-90 state vector instead of Kepler elements: geph2svdt / deq / glo_orbit / geph2pos / geph2vel (gnss_utility.cpp:642-731),
+// classical Runge-Kutta in 60 s steps from toe to the transmit time, on the satellite's lane.  gfx950 only.
 #include "launch_gnss.h"
 
 #include <math.h>
@@ -80,6 +81,52 @@ __device__ void eph2posvel(double t, const double* __restrict__ ep, double pos[3
     const double dt = wrap_week(t - ep[GE_TOC]);
     svdt = ep[GE_AF0] + ep[GE_AF1] * dt + ep[GE_AF2] * dt * dt - 2.0 * sqrt(mu * A) * e * sE / kC / kC;
     svddt = ep[GE_AF1] + 2.0 * ep[GE_AF2] * dt - 2.0 * sqrt(mu * A) * e * cE * Ed / kC / kC;
+}
+
+// ---- GLONASS (record layout: launch_gnss.h GE_GLO_*) ---------------------------------------------------------------------------
+constexpr double kOmgGlo = 7.2921150000e-5, kReGlo = 6378136.0, kJ2Glo = 1.0826257E-3, kTstep = 60.0;
+
+__device__ double geph2svdt(double t, const double* __restrict__ ep)      // :679-690
+{
+    double dt = wrap_week(t - ep[GE_TOE]);
+    for (int i = 0; i < 2; ++i) dt -= -ep[GE_GLO_TAUN] + ep[GE_GLO_GAMMA] * dt;
+    return -ep[GE_GLO_TAUN] + ep[GE_GLO_GAMMA] * dt;
+}
+
+__device__ __forceinline__ void glo_deq(const double x[6], const double acc[3], double xd[6])      // :642-660
+{
+    const double r2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2], r3 = r2 * sqrt(r2), omg2 = kOmgGlo * kOmgGlo;
+    if (r2 <= 0.0) { for (int i = 0; i < 6; ++i) xd[i] = 0.0; return; }
+    const double a = 1.5 * kJ2Glo * kMu * kReGlo * kReGlo / r2 / r3;       // 3/2 J2 mu Ae^2 / r^5
+    const double b = 5.0 * x[2] * x[2] / r2;
+    const double c = -kMu / r3 - a * (1.0 - b);
+    xd[0] = x[3]; xd[1] = x[4]; xd[2] = x[5];
+    xd[3] = (c + omg2) * x[0] + 2.0 * kOmgGlo * x[4] + acc[0];
+    xd[4] = (c + omg2) * x[1] - 2.0 * kOmgGlo * x[3] + acc[1];
+    xd[5] = (c - 2.0 * a) * x[2] + acc[2];
+}
+
+// geph2pos (:692-708) + geph2vel (:710-726): one integration serves both
+__device__ void geph2posvel(double t, const double* __restrict__ ep, double pos[3], double vel[3], double& svdt, double& svddt)
+{
+    double x[6], acc[3];
+    for (int i = 0; i < 3; ++i) { x[i] = ep[GE_GLO_POS + i]; x[3 + i] = ep[GE_GLO_VEL + i]; acc[i] = ep[GE_GLO_ACC + i]; }
+    double dt = wrap_week(t - ep[GE_TOE]);
+    svdt = -ep[GE_GLO_TAUN] + ep[GE_GLO_GAMMA] * dt;
+    svddt = ep[GE_GLO_GAMMA];
+    for (double tt = dt < 0.0 ? -kTstep : kTstep; fabs(dt) > 1e-9; dt -= tt) {
+        if (fabs(dt) < kTstep) tt = dt;
+        double k1[6], k2[6], k3[6], k4[6], w[6];                          // glo_orbit :662-677
+        glo_deq(x, acc, k1);
+        for (int i = 0; i < 6; ++i) w[i] = x[i] + 0.5 * k1[i] * tt;
+        glo_deq(w, acc, k2);
+        for (int i = 0; i < 6; ++i) w[i] = x[i] + 0.5 * k2[i] * tt;
+        glo_deq(w, acc, k3);
+        for (int i = 0; i < 6; ++i) w[i] = x[i] + k3[i] * tt;
+        glo_deq(w, acc, k4);
+        for (int i = 0; i < 6; ++i) x[i] += (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]) * tt / 6.0;
+    }
+    for (int i = 0; i < 3; ++i) { pos[i] = x[i]; vel[i] = x[3 + i]; }
 }
 
 __device__ void ecef2geo(const double x[3], double lla[3])               // :347-388
@@ -163,8 +210,8 @@ __global__ __launch_bounds__(64) void k_gnss_front(GnssFrontLaunch L)
     const int ns = (int)rc[GR_NSAT];
     __shared__ int sCbCol[4];
     __shared__ int sIdx[4];
-    double* H = L.H + (size_t)bl * L.hstride;
-    for (int e = i; e < L.mld * GNSS_FRONT_NCW; e += 64) H[e] = 0.0;
+    double* H = L.H ? L.H + (size_t)bl * L.hstride : nullptr;
+    if (H) { for (int e = i; e < L.mld * GNSS_FRONT_NCW; e += 64) H[e] = 0.0; }
     // receiver in ECEF: rcv = R_enu2ecef Rz(yaw) p_w + anchor (GnssUpdate.cpp:102), same rotation for the velocity (:108)
     const double cy = cos(rc[GR_YAW]), sy = sin(rc[GR_YAW]);
     double Rw[9];                                                     // R_w2ecef = R_enu2ecef Rz(yaw), row-major (:141)
@@ -184,16 +231,26 @@ __global__ __launch_bounds__(64) void k_gnss_front(GnssFrontLaunch L)
     bool usable = false;
     int sys = -1;
     double res_pos = 0, res_vel = 0, u[3] = { 0, 0, 0 }, az = 0, el = M_PI / 2, ion_d = 0, tro_d = 0, npsr = 0, ndop = 0;
+    double st[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };                  // SatState (gnss_constant.hpp:506-516): pos, vel, dt, ddt, tgd, ttx
     if (i < ns) {
         const double* ep = L.eph + ((size_t)bl * L.smax + i) * GE_N;
         const double* ob = L.obs + ((size_t)bl * L.smax + i) * GO_N;
         sys = (int)ep[GE_SYS];
-        if (sys != 1 && sys >= 0 && sys <= 3 && ob[GO_FREQ] >= 0) {
+        if (sys >= 0 && sys <= 3 && ob[GO_FREQ] >= 0) {
             // sat_states (gnss_spp.cpp:50-98)
             double ttx = ob[GO_TOW] - ob[GO_PSR] / kC;
-            ttx -= eph2svdt(ttx, ep);
-            double sp[3], sv[3], dts, ddts;
-            eph2posvel(ttx, ep, sp, sv, dts, ddts);
+            double sp[3], sv[3], dts, ddts, tgd;
+            if (sys == 1) {                                           // GLONASS (:72-79): SatState::tgd keeps its default 0
+                ttx -= geph2svdt(ttx, ep);
+                geph2posvel(ttx, ep, sp, sv, dts, ddts);
+                tgd = 0.0;
+            } else {
+                ttx -= eph2svdt(ttx, ep);
+                eph2posvel(ttx, ep, sp, sv, dts, ddts);
+                tgd = ep[GE_TGD];
+            }
+            for (int c = 0; c < 3; ++c) { st[c] = sp[c]; st[3 + c] = sv[c]; }
+            st[6] = dts; st[7] = ddts; st[8] = tgd; st[9] = ttx;
             const double d[3] = { sp[0] - xyz[0], sp[1] - xyz[1], sp[2] - xyz[2] };
             const double range = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
             for (int c = 0; c < 3; ++c) u[c] = d[c] / range;
@@ -207,7 +264,7 @@ __global__ __launch_bounds__(64) void k_gnss_front(GnssFrontLaunch L)
                 ion_d = rc[GR_HAVE_ION] != 0.0 ? iono_delay(ttx, rc + GR_ION, lla, az, el) : 0.0;
             }
             const double sag = kOmgGps * (sp[0] * xyz[1] - sp[1] * xyz[0]) / kC;
-            res_pos = range + sag + rc[GR_CB + sys] - dts * kC + tro_d + ion_d + ep[GE_TGD] * kC - ob[GO_PSR];      // :132-139
+            res_pos = range + sag + rc[GR_CB + sys] - dts * kC + tro_d + ion_d + tgd * kC - ob[GO_PSR];      // :132-139
             const double sagd = kOmgGps / kC * (sv[0] * xyz[1] + sp[0] * vel[1] - sv[1] * xyz[0] - sp[1] * vel[0]);
             res_vel = (sv[0] - vel[0]) * u[0] + (sv[1] - vel[1]) * u[1] + (sv[2] - vel[2]) * u[2] + rc[GR_FS] + sagd - ddts * kC
                       + ob[GO_DOPP] * (kC / ob[GO_FREQ]);                                                                  // :267-277
@@ -221,6 +278,8 @@ __global__ __launch_bounds__(64) void k_gnss_front(GnssFrontLaunch L)
     double* fr = L.front + ((size_t)bl * 64 + i) * GF_N;
     fr[0] = res_pos; fr[1] = res_vel; fr[2] = u[0]; fr[3] = u[1]; fr[4] = u[2]; fr[5] = az; fr[6] = el; fr[7] = ion_d; fr[8] = tro_d;
     fr[9] = usable ? 1.0 : 0.0;
+    for (int c = 0; c < 10; ++c) fr[10 + c] = st[c];
+    if (!H) return;                                                   // satellite evaluation only (ingvio_gnss_sat_eval)
     // ---- candidate rows of updateTrackedSys (GnssUpdate.cpp:148-272): only constellations whose clock is in the state ----
     if (i < 4) sIdx[i] = (int)rc[GR_IDX_CB + i];
     __syncthreads();

@@ -75,3 +75,22 @@ def gnss_rows(g):
     k = nv.value
     nc = int(vsize[:k].sum())
     return vidx[:k].copy(), vsize[:k].copy(), H[:rows, :nc].copy(), res[:rows].copy(), Rd[:rows].copy()
+
+
+def aligner_run(ctx, epochs, p_w, v_w, iono=None, batch_size=25, max_iter=10, conv_epsilon=1e-5, vel_thres=0.4):
+    """The shim's GvioAligner::batchAlign (host/GvioAligner.cpp; satellite geodesy on the device through ingvio_gnss_sat_eval) on
+    a list of raw epochs: dicts with eph [ns, 25], obs [ns, 6], doy.  `ctx` is a capi.Context.  Returns dict(aligned, yaw_offset,
+    anchor_ecef, R_enu2ecef, rcv_ddt, rough_anchor)."""
+    n = len(epochs)
+    smax = max(len(e["obs"]) for e in epochs)
+    eph = np.zeros((n, smax, 25)); obs = np.zeros((n, smax, 6)); ns = np.zeros(n, dtype=np.int32); doy = np.zeros(n)
+    for i, e in enumerate(epochs):
+        k = len(e["obs"]); eph[i, :k] = e["eph"]; obs[i, :k] = e["obs"]; ns[i] = k; doy[i] = e["doy"]
+    out = np.zeros(22)
+    L = lib()
+    ion = _f(iono) if iono is not None else None
+    L.ingvio_host_aligner_run(ctx.h, C.c_int(n), C.c_int(smax), _d(eph), _d(obs), ns.ctypes.data_as(C.POINTER(C.c_int)), _d(doy),
+                              _d(_f(p_w)), _d(_f(v_w)), _d(ion) if ion is not None else None, C.c_int(batch_size), C.c_int(max_iter),
+                              C.c_double(conv_epsilon), C.c_double(vel_thres), _d(out))
+    return dict(aligned=bool(out[0]), yaw_offset=out[1], anchor_ecef=out[2:5].copy(), R_enu2ecef=out[5:14].reshape(3, 3).copy(),
+                rcv_ddt=out[14], rough_anchor=out[15:22].copy())

@@ -1,6 +1,7 @@
 """Fixtures for SURVEY.md 8(f) row f-3 (the gnss_comm front of the GNSS update): an independent numpy transcription of
 gnss_comm/src/gnss_spp.cpp:50-146,256-282 and gnss_utility.cpp:347-388,390-640,733-772,774-899, evaluated on a synthetic but
-physically sensible constellation (GPS / Galileo / BeiDou MEO + one BeiDou GEO + one GLONASS entry that must be skipped).
+physically sensible constellation (GPS / Galileo / BeiDou MEO + one BeiDou GEO + two GLONASS satellites, whose ephemeris is a PZ-90
+state vector integrated by Runge-Kutta, gnss_utility.cpp:642-731 + one entry without an L1 observation that must be skipped).
 Runs in the build container only; writes tests/golden/gnss_front.npz.  The C oracle (oracle/gnss_front_oracle.c) and the HIP
 kernel are checked against these numbers; nothing of the reference travels.
 
@@ -20,6 +21,9 @@ D2R = math.pi / 180.0
 (SYS, PRN, TOE, TOE_SYS, TOC, A, E, I0, OMG, OMG0, M0, DELTA_N, OMG_DOT, I_DOT, CUC, CUS, CRC, CRS, CIC, CIS, AF0, AF1, AF2, TGD,
  URA) = range(25)
 TOW, PSR, DOPP, PSR_STD, DOPP_STD, FREQ = range(6)
+# GLONASS record (sys == 1), same 25 doubles: sys, prn, toe (GPS week seconds), -, -, pos[3], vel[3], acc[3], tau_n, gamma; ura at 24
+GLO_POS, GLO_VEL, GLO_ACC, GLO_TAUN, GLO_GAMMA = 5, 8, 11, 14, 15
+OMG_GLO, RE_GLO, J2_GLO, TSTEP = 7.2921150000e-5, 6378136.0, 1.0826257E-3, 60.0
 
 
 def wrap(t):
@@ -121,6 +125,51 @@ def eph2vel(t, ep):
     return vel, ddts
 
 
+def geph2svdt(t, ep):                                          # gnss_utility.cpp:679-690
+    dt = wrap(t - ep[TOE])
+    for _ in range(2):
+        dt -= -ep[GLO_TAUN] + ep[GLO_GAMMA] * dt
+    return -ep[GLO_TAUN] + ep[GLO_GAMMA] * dt
+
+
+def glo_deq(x, acc):                                           # :642-660 (PZ-90 force model: central term, J2, frame rotation)
+    pos, vel = x[:3], x[3:]
+    r2 = float(pos @ pos)
+    if r2 <= 0.0:
+        return np.zeros(6)
+    r3 = r2 * math.sqrt(r2)
+    omg2 = OMG_GLO * OMG_GLO
+    a = 1.5 * J2_GLO * MU * RE_GLO * RE_GLO / r2 / r3
+    b = 5.0 * pos[2] * pos[2] / r2
+    c = -MU / r3 - a * (1.0 - b)
+    return np.array([vel[0], vel[1], vel[2],
+                     (c + omg2) * pos[0] + 2.0 * OMG_GLO * vel[1] + acc[0],
+                     (c + omg2) * pos[1] - 2.0 * OMG_GLO * vel[0] + acc[1],
+                     (c - 2.0 * a) * pos[2] + acc[2]])
+
+
+def glo_orbit(dt, x, acc):                                     # :662-677, classical RK4
+    k1 = glo_deq(x, acc)
+    k2 = glo_deq(x + 0.5 * dt * k1, acc)
+    k3 = glo_deq(x + 0.5 * dt * k2, acc)
+    k4 = glo_deq(x + dt * k3, acc)
+    return x + (k1 + 2.0 * k2 + 2.0 * k3 + k4) * dt / 6.0
+
+
+def geph2posvel(t, ep):                                        # geph2pos :692-708, geph2vel :710-726 (the same integration twice)
+    x = np.r_[ep[GLO_POS:GLO_POS + 3], ep[GLO_VEL:GLO_VEL + 3]].astype(float)
+    acc = ep[GLO_ACC:GLO_ACC + 3]
+    dt = wrap(t - ep[TOE])                                     # time_diff of absolute times: the wrap of week seconds
+    dts = -ep[GLO_TAUN] + ep[GLO_GAMMA] * dt
+    tt = -TSTEP if dt < 0.0 else TSTEP
+    while abs(dt) > 1e-9:
+        if abs(dt) < TSTEP:
+            tt = dt
+        x = glo_orbit(tt, x, acc)
+        dt -= tt
+    return x[:3], x[3:], dts, ep[GLO_GAMMA]
+
+
 def ecef2geo(x):
     e2, a = 6.69437999014e-3, 6378137.0
     a2 = a * a; b2 = a2 * (1 - e2); b = math.sqrt(b2); ep2 = (a2 - b2) / b2
@@ -215,9 +264,13 @@ def iono(tow, ion, lla, azel):
 
 
 def sat_state(ep, ob):
-    if int(ep[SYS]) == 1 or ob[FREQ] < 0:
+    if ob[FREQ] < 0:
         return None
     ttx = ob[TOW] - ob[PSR] / C_LIGHT
+    if int(ep[SYS]) == 1:                                      # gnss_spp.cpp:72-79
+        ttx -= geph2svdt(ttx, ep)
+        pos, vel, dt, ddt = geph2posvel(ttx, ep)
+        return pos, vel, dt, ddt, 0.0, ttx
     ttx -= eph2svdt(ttx, ep)
     pos, dt = eph2pos(ttx, ep)
     vel, ddt = eph2vel(ttx, ep)
@@ -277,25 +330,55 @@ def make_constellation(rng, rcv, t_rx, want=(("gps", 0, 4), ("bds", 3, 2), ("gal
     return np.array(ephs)
 
 
+def make_glonass(rng, rcv, t_rx, cnt=2):
+    """GLONASS broadcast records: a circular orbit (r = 25510 km, i = 64.8 deg) sampled at toe, expressed in the rotating PZ-90
+    frame (v_ecef = v_inertial - omega x r), lunisolar acceleration of the broadcast order of magnitude; keeps satellites above
+    20 degrees.  toe within the +-15 min validity of a GLONASS ephemeris."""
+    out, prn = [], 0
+    while len(out) < cnt:
+        prn += 1
+        r, inc = 25510e3, 64.8 * D2R
+        raan, u = rng.uniform(-math.pi, math.pi), rng.uniform(-math.pi, math.pi)
+        vcirc = math.sqrt(MU / r)
+        Rz = np.array([[math.cos(raan), -math.sin(raan), 0], [math.sin(raan), math.cos(raan), 0], [0, 0, 1.0]])
+        Rx = np.array([[1, 0, 0], [0, math.cos(inc), -math.sin(inc)], [0, math.sin(inc), math.cos(inc)]])
+        pos = Rz @ Rx @ np.array([r * math.cos(u), r * math.sin(u), 0.0])
+        vin = Rz @ Rx @ np.array([-vcirc * math.sin(u), vcirc * math.cos(u), 0.0])
+        vel = vin - np.cross([0, 0, OMG_GLO], pos)
+        ep = np.zeros(25)
+        ep[SYS], ep[PRN] = 1, prn
+        ep[TOE] = t_rx - rng.uniform(120.0, 800.0) * (1 if len(out) == 0 else -1)      # one integrates forwards, one backwards
+        ep[GLO_POS:GLO_POS + 3], ep[GLO_VEL:GLO_VEL + 3] = pos, vel
+        ep[GLO_ACC:GLO_ACC + 3] = rng.uniform(-2e-6, 2e-6, 3)
+        ep[GLO_TAUN], ep[GLO_GAMMA] = rng.uniform(-2e-4, 2e-4), rng.uniform(-2e-12, 2e-12)
+        ep[URA] = 2.0
+        p_now = geph2posvel(t_rx - 0.075, ep)[0]
+        if sat_azel(rcv, p_now)[1] > 20 * D2R:
+            out.append(ep)
+    return np.array(out)
+
+
 def make_obs(rng, eph, rcv, vel, cb, fs, ion, doy, t_rx, noise=True):
     """L1 observations consistent with receiver (rcv, vel), clock biases cb[4] (m) and drift fs (m/s)."""
     obs = np.zeros((len(eph), 6))
     lla = ecef2geo(rcv)
     for i, ep in enumerate(eph):
         obs[i, TOW] = t_rx
-        obs[i, FREQ] = 1.561098e9 if int(ep[SYS]) == 3 else 1.57542e9
+        glo = int(ep[SYS]) == 1
+        obs[i, FREQ] = 1.561098e9 if int(ep[SYS]) == 3 else (1.602e9 + (int(ep[PRN]) - 3) * 0.5625e6 if glo else 1.57542e9)      # GLONASS FDMA channel
         obs[i, PSR_STD], obs[i, DOPP_STD] = 1.0, 0.5
-        if int(ep[SYS]) == 1:
-            obs[i, PSR] = 2.1e7; continue
         ttx = t_rx - 0.075
         for _ in range(6):                                      # light-time iteration
-            pos, dts = eph2pos(ttx, ep)
+            pos, dts = (geph2posvel(ttx, ep)[0], geph2posvel(ttx, ep)[2]) if glo else eph2pos(ttx, ep)
             rng_ = np.linalg.norm(pos - rcv)
             ttx = t_rx - rng_ / C_LIGHT
-        velv, ddts = eph2vel(ttx, ep)
+        if glo:
+            _, velv, _, ddts = geph2posvel(ttx, ep)
+        else:
+            velv, ddts = eph2vel(ttx, ep)
         azel = sat_azel(rcv, pos)
         sag = OMG_GPS * (pos[0] * rcv[1] - pos[1] * rcv[0]) / C_LIGHT
-        obs[i, PSR] = rng_ + sag + cb[int(ep[SYS])] - dts * C_LIGHT + trop(doy, lla, azel) + iono(ttx, ion, lla, azel) + ep[TGD] * C_LIGHT \
+        obs[i, PSR] = rng_ + sag + cb[int(ep[SYS])] - dts * C_LIGHT + trop(doy, lla, azel) + iono(ttx, ion, lla, azel) + (0.0 if glo else ep[TGD]) * C_LIGHT \
             + (rng.normal(0, 0.8) if noise else 0.0)
         u = (pos - rcv) / rng_
         sagd = OMG_GPS / C_LIGHT * (velv[0] * rcv[1] + pos[0] * vel[1] - velv[1] * rcv[0] - pos[1] * vel[0])
@@ -309,7 +392,7 @@ def main():
     t_rx, doy = 360300.0, 270.4
     rcv = geo2ecef(np.array([31.0, 121.4, 30.0]))
     vel = np.array([1.2, -0.7, 0.3])
-    cb = np.array([150.0, 0.0, 165.0, 180.0]); fs = 5.0
+    cb = np.array([150.0, 140.0, 165.0, 180.0]); fs = 5.0
     ion = np.array([0.1118e-07, 0.2235e-07, -0.1192e-06, -0.1192e-06, 0.1167e+06, 0.1802e+06, -0.1311e+06, -0.4588e+06])
     eph = make_constellation(rng, rcv, t_rx)
     geo = eph[4].copy()                                         # a BeiDou GEO entry (prn <= 5 takes the rotated-frame branch)
@@ -318,11 +401,13 @@ def main():
         geo[OMG0], geo[M0] = rng.uniform(-math.pi, math.pi), rng.uniform(-math.pi, math.pi)
         if sat_azel(rcv, eph2pos(t_rx - 0.12, geo)[0])[1] > 20 * D2R:
             break
-    glo = eph[0].copy(); glo[SYS] = 1                           # GLONASS: no Kepler state, must come back unusable
-    eph = np.vstack([eph, geo, glo])
+    glo = make_glonass(rng, rcv, t_rx)                          # two GLONASS satellites (Runge-Kutta orbit)
+    nol1 = eph[1].copy()                                        # an entry whose observation has no L1 signal: must come back unusable
+    eph = np.vstack([eph, geo, glo, nol1])
     obs = make_obs(rng, eph, rcv, vel, cb, fs, ion, doy, t_rx)
+    obs[-1, FREQ] = -1.0
     # evaluate at a perturbed receiver state (what the filter would hold)
-    xyzt = np.r_[rcv + np.array([3.0, -2.0, 1.5]), cb + np.array([2.0, 0.0, -1.0, 1.5])]
+    xyzt = np.r_[rcv + np.array([3.0, -2.0, 1.5]), cb + np.array([2.0, -1.5, -1.0, 1.5])]
     velt = np.r_[vel + np.array([0.05, -0.02, 0.01]), fs + 0.1]
     out = residuals(eph, obs, ion, doy, xyzt, velt)
     out_noion = residuals(eph, obs, None, doy, xyzt, velt)

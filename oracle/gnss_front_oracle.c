@@ -5,8 +5,9 @@
  * gnss_comm is vendored in the reference (gnss_comm/src/gnss_spp.cpp, gnss_utility.cpp) but needs Eigen + glog: not buildable
  * here, and the reference holds NO test for it — parity unpinned by reference tests; pinned by an independent numpy
  * transcription (oracle/gen_gnss_golden.py) and by physical identities (tests/test_gnss_front.py).
- * Times are seconds of the GPS week (the reference's gtime_t differences are the same numbers); GLONASS (Runge-Kutta orbit,
- * gnss_utility.cpp:642-731) is not restated: its satellites are reported unusable. */
+ * Times are seconds of the GPS week (the reference's gtime_t differences are the same numbers, up to the wrap at the week
+ * boundary).  GLONASS (round 3): geph2svdt / deq / glo_orbit / geph2pos / geph2vel, gnss_utility.cpp:642-731 - the broadcast PZ-90
+ * state vector integrated by classical Runge-Kutta in 60 s steps with the J2 + frame-rotation force model; record layout below. */
 #define _USE_MATH_DEFINES
 #define _GNU_SOURCE
 #include <math.h>
@@ -25,6 +26,17 @@
 #define SIN_N5 (-0.0871557427476582)
 #define COS_N5 0.9961946980917456
 #define D2R (M_PI / 180.0)
+
+/* GLONASS ephemeris record (sys == 1), same ORC_EPH_N doubles: sys, prn, toe, -, -, pos[3], vel[3], acc[3], tau_n, gamma; ura */
+#define GLO_POS 5
+#define GLO_VEL 8
+#define GLO_ACC 11
+#define GLO_TAUN 14
+#define GLO_GAMMA 15
+#define OMG_GLO 7.2921150000e-5
+#define RE_GLO 6378136.0
+#define J2_GLO 1.0826257E-3
+#define TSTEP 60.0
 
 static double wrap_week(double t)                        /* gnss_utility.cpp:451-456 */
 {
@@ -111,14 +123,69 @@ static void eph2posvel(double t, const double* eph, double pos[3], double vel[3]
     *svddt = eph[ORC_EPH_AF1] + 2.0 * eph[ORC_EPH_AF2] * dt - 2.0 * sqrt(mu * A) * e * cos_Ek * Ek_dot / LIGHT_SPEED / LIGHT_SPEED;
 }
 
-/* sat_states (gnss_spp.cpp:50-98), Kepler systems.  sat = {pos 3, vel 3, dt, ddt, tgd, ttx}; returns 0 for GLONASS / no L1. */
+static double geph2svdt(double t, const double* eph)     /* :679-690 */
+{
+    double dt = wrap_week(t - eph[ORC_EPH_TOE]);
+    for (int i = 0; i < 2; ++i) dt -= -eph[GLO_TAUN] + eph[GLO_GAMMA] * dt;
+    return -eph[GLO_TAUN] + eph[GLO_GAMMA] * dt;
+}
+
+static void glo_deq(const double x[6], const double acc[3], double xdot[6])      /* :642-660 */
+{
+    const double r2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2], r3 = r2 * sqrt(r2), omg2 = OMG_GLO * OMG_GLO;
+    if (r2 <= 0.0) { for (int i = 0; i < 6; ++i) xdot[i] = 0.0; return; }
+    const double a = 1.5 * J2_GLO * MU_GAL * RE_GLO * RE_GLO / r2 / r3;           /* 3/2 J2 mu Ae^2 / r^5 (MU: GAL, BDS, GLO share it) */
+    const double b = 5.0 * x[2] * x[2] / r2;
+    const double c = -MU_GAL / r3 - a * (1.0 - b);
+    xdot[0] = x[3]; xdot[1] = x[4]; xdot[2] = x[5];
+    xdot[3] = (c + omg2) * x[0] + 2.0 * OMG_GLO * x[4] + acc[0];
+    xdot[4] = (c + omg2) * x[1] - 2.0 * OMG_GLO * x[3] + acc[1];
+    xdot[5] = (c - 2.0 * a) * x[2] + acc[2];
+}
+
+static void glo_orbit(double dt, double x[6], const double acc[3])                /* :662-677 */
+{
+    double k1[6], k2[6], k3[6], k4[6], w[6];
+    glo_deq(x, acc, k1);
+    for (int i = 0; i < 6; ++i) w[i] = x[i] + 0.5 * k1[i] * dt;
+    glo_deq(w, acc, k2);
+    for (int i = 0; i < 6; ++i) w[i] = x[i] + 0.5 * k2[i] * dt;
+    glo_deq(w, acc, k3);
+    for (int i = 0; i < 6; ++i) w[i] = x[i] + k3[i] * dt;
+    glo_deq(w, acc, k4);
+    for (int i = 0; i < 6; ++i) x[i] += (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]) * dt / 6.0;
+}
+
+/* geph2pos (:692-708) and geph2vel (:710-726) run the same integration; dts = -tau_n + gamma dt, ddts = gamma */
+static void geph2posvel(double t, const double* eph, double pos[3], double vel[3], double* svdt, double* svddt)
+{
+    double x[6];
+    for (int i = 0; i < 3; ++i) { x[i] = eph[GLO_POS + i]; x[3 + i] = eph[GLO_VEL + i]; }
+    double dt = wrap_week(t - eph[ORC_EPH_TOE]);
+    *svdt = -eph[GLO_TAUN] + eph[GLO_GAMMA] * dt;
+    *svddt = eph[GLO_GAMMA];
+    for (double tt = dt < 0.0 ? -TSTEP : TSTEP; fabs(dt) > 1e-9; dt -= tt) {
+        if (fabs(dt) < TSTEP) tt = dt;
+        glo_orbit(tt, x, eph + GLO_ACC);
+    }
+    for (int i = 0; i < 3; ++i) { pos[i] = x[i]; vel[i] = x[3 + i]; }
+}
+
+/* sat_states (gnss_spp.cpp:50-98).  sat = {pos 3, vel 3, dt, ddt, tgd, ttx}; returns 0 without an L1 observation. */
 int orc_gnss_sat_state(const double* eph, const double* obs, double* sat)
 {
     memset(sat, 0, sizeof(double) * ORC_SAT_N);
     const int sys = (int)eph[ORC_EPH_SYS];
-    if (sys == 1 || sys < 0 || sys > 3 || obs[ORC_OBS_FREQ] < 0) return 0;
+    if (sys < 0 || sys > 3 || obs[ORC_OBS_FREQ] < 0) return 0;
     const double tof = obs[ORC_OBS_PSR] / LIGHT_SPEED;
     double ttx = obs[ORC_OBS_TOW] - tof;
+    if (sys == 1) {                                                                /* :72-79 */
+        double svdt = geph2svdt(ttx, eph), svddt = 0.0;
+        ttx -= svdt;
+        geph2posvel(ttx, eph, sat, sat + 3, &svdt, &svddt);
+        sat[6] = svdt; sat[7] = svddt; sat[8] = 0.0; sat[9] = ttx;                /* SatState::tgd keeps its default 0 */
+        return 1;
+    }
     double svdt = eph2svdt(ttx, eph), svddt = 0.0;
     ttx -= svdt;
     eph2posvel(ttx, eph, sat, sat + 3, &svdt, &svddt);
@@ -229,7 +296,7 @@ double orc_gnss_iono(double tow, const double ion[8], const double lla[3], const
 /* sat_states + psr_res (gnss_spp.cpp:100-146) + dopp_res (:256-282) for one epoch of ns satellites.
  * rcv_xyzt = (ecef xyz, clock bias of GPS / GLO / GAL / BDS, m); rcv_vel = (ecef velocity, clock drift m/s).
  * Outputs per satellite: res_pos, res_vel, los [3] (unit receiver -> satellite), azel [2], atmos [2] (ion, tro), sat [ORC_SAT_N];
- * usable[i] = 0 for satellites without a state (GLONASS): their outputs are zero. */
+ * usable[i] = 0 for satellites without a state (no L1 observation): their outputs are zero. */
 void orc_gnss_residuals(int ns, const double* eph, const double* obs, const double ion[8], int have_ion, double doy,
                         const double rcv_xyzt[7], const double rcv_vel[4], double* res_pos, double* res_vel, double* los,
                         double* azel_out, double* atmos, double* sat_out, int* usable)

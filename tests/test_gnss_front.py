@@ -20,7 +20,8 @@ def _z():
 def test_oracle_matches_numpy_transcription(orc):
     z = _z()
     o = orc.gnss_residuals(z["eph"], z["obs"], z["ion"], float(z["doy"]), z["xyzt"], z["velt"])
-    assert np.array_equal(o["usable"], z["usable"]) and o["usable"].sum() == 9 and o["usable"][-1] == 0      # the GLONASS entry is skipped
+    assert np.array_equal(o["usable"], z["usable"]) and o["usable"].sum() == 11 and o["usable"][-1] == 0      # the entry without L1 is skipped
+    assert (z["eph"][:, 0] == 1).sum() == 2                                                                     # two GLONASS satellites
     assert np.abs(o["sat"][:, :3] - z["sat"][:, :3]).max() < 1e-6          # satellite position, m (range 2.6e7: 4e-14 relative)
     assert np.abs(o["sat"][:, 3:6] - z["sat"][:, 3:6]).max() < 1e-9 and np.abs(o["sat"][:, 6:9] - z["sat"][:, 6:9]).max() < 1e-15
     assert np.abs(o["res_pos"] - z["res_pos"]).max() < 1e-6 and np.abs(o["res_vel"] - z["res_vel"]).max() < 1e-9
@@ -43,7 +44,12 @@ def test_satellite_velocity_is_the_time_derivative_of_position(orc):
         fd = (sat[1][:3] - sat[-1][:3]) / (sat[1][9] - sat[-1][9])
         v = sat[0][3:6]
         geo = int(eph[i][0]) == 3 and int(eph[i][1]) <= 5             # the geostationary entry barely moves in ECEF
+        glo = int(eph[i][0]) == 1
         assert (np.linalg.norm(v) < 200.0 if geo else 2300.0 < np.linalg.norm(v) < 4200.0) and 2.0e7 < np.linalg.norm(sat[0][:3]) < 4.3e7
+        if glo:      # geph2vel integrates the very ODE whose position part is d pos / dt = vel: exact up to the step error of RK4
+            assert np.abs(fd - v).max() < 2e-5, (i, fd, v)          # central differences over +-0.5 s: truncation h^2 |jerk| / 6 ~ 5e-6
+            assert abs(abs(sat[0][7]) - abs(eph[i][15])) < 1e-18          # clock drift = gamma
+            continue
         # (for the GEO entry the as-written z term below leaks into x / y through the 5-degree frame rotation: 6e-4 m/s)
         assert np.abs(fd[:2] - v[:2]).max() < (1e-3 if geo else 2e-4), (i, fd, v)
         # z component: the reference's last term reads y'_k i_dot cos(i) where the derivative has y_k i_dot cos(i)
@@ -163,6 +169,12 @@ def test_gnss_front_kernel_vs_oracle_and_through_the_update(orc):
     ctx.restore()
     dx2, used2, keep2, gam2, st2 = ctx.gnss_update_batch(0, blocks, table, gate_rows=True)
     assert np.array_equal(used1, used2) and np.array_equal(keep1, keep2) and (used1 > 10).all() and (st1 == 0).all()
+    # the two GLONASS satellites (Runge-Kutta orbit on the device) are part of the epoch: their pseudo-range and Doppler rows pass the
+    # per-row gates like everybody else's (candidate rows: the usable satellites in order, pseudo-ranges first)
+    sysu = z["eph"][z["usable"] == 1, 0].astype(int)
+    glo_rows = np.flatnonzero(sysu == 1)
+    assert len(glo_rows) == 2
+    assert keep1[:, glo_rows].sum() >= nb and keep1[:, len(sysu) + glo_rows].sum() >= nb      # (a gate may refuse a row; most pass)
     for b in range(nb):
         assert rel_err(P1[b], ctx.cov_get(b)) < 1e-11 and rel_err(dx1[b], dx2[b]) < 1e-7
     ctx.close()
