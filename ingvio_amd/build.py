@@ -94,6 +94,24 @@ def build_cpp_tests(force=False, verbose=False):
     return exe
 
 
+def build_ros_adapter_test(force=False, verbose=False):
+    """tests/cpp/test_ros_adapter.cpp -> ingvio_amd/lib/test_ros_adapter: the ROS1 node's conversion core (ros1/include/RosAdapter.h)
+    on mock message structs; ROS itself is not needed (run by pytest -m "not gpu")."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tests", "cpp", "test_ros_adapter.cpp")
+    exe = os.path.join(LIB, "test_ros_adapter")
+    if not os.path.exists(src) or not os.path.exists(HOST_LIB):
+        return None
+    deps = _all_deps([os.path.join(CSRC, "host"), os.path.join(root, "include"), os.path.join(root, "ros1", "include")]) + [src, HOST_LIB, HIP_LIB]
+    if force or _newer(exe, deps):
+        cmd = ["g++", "-O1", "-std=c++14", "-I", os.path.join(root, "include"), "-I", os.path.join(CSRC, "host"), "-I", os.path.join(root, "ros1", "include"),
+               src, "-o", exe, "-L", LIB, "-lingvio_host", "-lingvio_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return exe
+
+
 def build_tools(force=False, verbose=False):
     """tools/ingvio_replay.cpp -> ingvio_amd/lib/ingvio_replay (the rosbag-free replay driver)."""
     root = os.path.dirname(HERE)
@@ -115,6 +133,7 @@ def build_all(force=False, verbose=False):
     a = build_hip(force, verbose)
     b = build_host(force, verbose)
     build_cpp_tests(force, verbose)
+    build_ros_adapter_test(force, verbose)
     build_tools(force, verbose)
     return a, b
 

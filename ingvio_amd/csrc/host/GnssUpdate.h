@@ -46,7 +46,15 @@ int gnssCandidateRows(const GnssResiduals& g, const Vec3d& p_w, const Vec3d& v_w
 
 // One GNSS epoch as GnssProcessor::callbackGnssMeas hands it on (GnssProcessor.cpp:119-220: valid L1 observations with their
 // ephemerides; here with the satellite states already evaluated) and one SPP fix (GnssSync.h SppMeas).
-struct GnssMeas { double stamp = 0; std::vector<gnss::SatObs> sats; };
+struct GnssMeas {
+    double stamp = 0;
+    std::vector<gnss::SatObs> sats;
+    // the raw content of the epoch (GnssData.h GnssMeas = (obs, ephems) + latest_gnss_iono_params), flat records in the layout of
+    // ingvio_gnss_epoch: only GvioAligner::batchAlign reads it (the alignment needs the ephemerides, not satellite states at
+    // one receiver position); empty = the alignment must be provided with IngvioFilter::setGnssAlignment
+    std::vector<double> raw_eph, raw_obs, iono;
+    double doy = 0.0;
+};
 struct SppMeas { double stamp = 0; double posSpp[7] = { 0 }; double velSpp[4] = { 0 }; };      // (ecef xyz, clock biases) / (ecef vel, drift)
 
 // What GnssUpdate reads from GvioAligner (GvioAligner.h: isAlign, getYawOffset, getRenu2ecef, getTenu2ecef); the batch

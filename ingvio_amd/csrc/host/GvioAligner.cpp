@@ -137,6 +137,49 @@ bool GvioAligner::psrPos(const std::vector<const RawGnssEpoch*>& epochs, double 
     return true;
 }
 
+// gnss_comm::dopp_vel (gnss_spp.cpp:284-380): weighted Gauss-Newton on (ecef velocity, clock drift), elevation from the reference
+// position, weight sin^2(el) / (dopp_std / 0.256) / (ura - 1 | ura - 2 | 2).  (The residual is linear in the unknowns: the second
+// iteration only confirms convergence.)
+bool GvioAligner::doppVel(const RawGnssEpoch& m, const double ref_ecef[3], double out[4])
+{
+    for (int i = 0; i < 4; ++i) out[i] = 0.0;
+    int n_valid = 0;
+    for (int i = 0; i < m.n_sat(); ++i) if (m.obs[(size_t)i * INGVIO_OBS_N + 5] >= 0) ++n_valid;
+    if (n_valid < 4) return false;
+    double x[4] = { 0, 0, 0, 0 }, dx_norm = 1.0;
+    int num_iter = 0;
+    std::vector<ingvio_gnss_epoch> eps(1);
+    std::vector<double> rec;
+    while (num_iter < MAX_ITER_PVT && dx_norm > EPSILON_PVT) {
+        fillEpoch(eps[0], m, nullptr);
+        std::memcpy(eps[0].anchor_ecef, ref_ecef, 24);
+        std::memcpy(eps[0].v_w, x, 24);
+        eps[0].fs = x[3];
+        if (!evalEpochs(eps, rec)) return false;
+        std::vector<double> N(16, 0.0), g(4, 0.0);
+        for (int i = 0; i < m.n_sat(); ++i) {
+            const double* r = rec.data() + (size_t)i * REC;
+            if (r[9] == 0.0 || !(r[6] > CUT_OFF_DEGREE / 180.0 * M_PI)) continue;
+            const int sys = (int)m.eph[(size_t)i * INGVIO_EPH_N];
+            const double ura = m.eph[(size_t)i * INGVIO_EPH_N + 24], dstd = m.obs[(size_t)i * INGVIO_OBS_N + 4];
+            const double sin_el = std::sin(r[6]);
+            double w = sin_el * sin_el;
+            if (dstd > 0) w /= (dstd / 0.256);
+            if (sys == 0 || sys == 3) w /= ura - 1; else if (sys == 2) w /= ura - 2; else if (sys == 1) w /= 2;
+            const double G[4] = { -r[2], -r[3], -r[4], 1.0 };
+            for (int a = 0; a < 4; ++a) { g[a] += G[a] * w * r[1]; for (int c = 0; c < 4; ++c) N[a * 4 + c] += G[a] * w * G[c]; }
+        }
+        double dx[4];
+        if (!solveNormal(4, N, g, dx)) return false;
+        dx_norm = 0.0;
+        for (int a = 0; a < 4; ++a) { x[a] += dx[a]; dx_norm += dx[a] * dx[a]; }
+        dx_norm = std::sqrt(dx_norm);
+        ++num_iter;
+    }
+    for (int i = 0; i < 4; ++i) out[i] = x[i];
+    return true;
+}
+
 void GvioAligner::batchAlign(const RawGnssEpoch& gnss_meas, const std::shared_ptr<SE23> epose, const std::vector<double>& iono)
 {
     batchAlign(gnss_meas, epose->valueTrans1(), epose->valueTrans2(), iono);

@@ -48,6 +48,9 @@ public:
     void batchAlign(const RawGnssEpoch& gnss_meas, const std::shared_ptr<SE23> epose, const std::vector<double>& iono);
     // gnss_comm::psr_pos (gnss_spp.cpp:148-254) on one set of epochs sharing ONE receiver state; false = no solution
     bool psrPos(const std::vector<const RawGnssEpoch*>& epochs, double xyzt[7]);
+    // gnss_comm::dopp_vel (gnss_spp.cpp:284-380): (ecef velocity, clock drift) of one epoch at the reference position ref_ecef
+    bool doppVel(const RawGnssEpoch& epoch, const double ref_ecef[3], double vel_ddt[4]);
+    void setIono(const std::vector<double>& iono) { _iono_params = iono; }
     int bufferSize() const { return (int)_align_buffer.size(); }
     // diagnostics of the last completed alignment
     double lastRcvDdt() const { return _last_rcv_ddt; }

@@ -16,6 +16,8 @@ IngvioFilter::IngvioFilter(const IngvioParams& params, std::shared_ptr<Triangula
     _landmark_update = std::make_shared<LandmarkUpdate>(_filter_params);                // :90
     _gnss_update = std::make_shared<GnssUpdate>(_filter_params);                        // :92-96
     _gnss_sync = std::make_shared<GnssSync>();
+    _aligner = std::make_shared<GvioAligner>(StateManager::ctx(_state), _filter_params._gv_align_batch_size, _filter_params._gv_align_max_iter,
+                                             _filter_params._gv_align_conv_epsilon, _filter_params._gv_align_vel_thres);      // :95
 }
 
 // The GNSS block at the end of both camera callbacks (IngvioFilter.cpp:329-362, :200-233).
@@ -27,7 +29,12 @@ void IngvioFilter::gnssBlock(double stamp)
     SppMeas spp_meas;
     const bool flag = _gnss_sync->getSppAt(stamp, spp_meas);                            // :336-340
     if (_gnss_sync->getGnssMeasAt(stamp, gnss_meas)) {
-        // :344-345 batchAlign is out of scope: the alignment is provided by setGnssAlignment()
+        if (flag && !_gvio_aligner.isAlign() && !gnss_meas.raw_obs.empty()) {          // :344-345
+            RawGnssEpoch raw;
+            raw.eph = gnss_meas.raw_eph; raw.obs = gnss_meas.raw_obs; raw.doy = gnss_meas.doy;
+            _aligner->batchAlign(raw, _state->_extended_pose, gnss_meas.iono);
+            if (_aligner->isAlign()) _gvio_aligner = _aligner->alignment();
+        }
         if (_gvio_aligner.isAlign()) {
             _gnss_update->checkYofStatus(_state, _gvio_aligner);                        // :349
             _last_gnss_rows = _gnss_update->updateTrackedSys(_state, gnss_meas, _gvio_aligner);      // :353-354

@@ -4,13 +4,14 @@
 // and the same per-frame orchestration (propagate+clone -> collect -> RemoveLost -> Keyframe|SwMarg ->
 // clean / re-anchor / marginalise -> erase invalid -> GNSS block (:329-362: pick the epoch of this frame, checkYofStatus,
 // updateTrackedSys, addNewTrackedSys)).  callbackGnssMeas / callbackSppMeas buffer the epochs as GnssProcessor does
-// (GnssProcessor.cpp:119-220).  ROS, tf, publishers, the RINEX / ephemeris handling and GvioAligner::batchAlign are out of
-// scope: the alignment result is set with setGnssAlignment().
+// (GnssProcessor.cpp:119-220).  ROS, tf, publishers and the RINEX / ephemeris handling are out of scope.  GvioAligner::batchAlign
+// runs when the buffered epochs carry their raw content (GnssMeas::raw_*); otherwise the alignment is set with setGnssAlignment().
 #pragma once
 #include <memory>
 #include <vector>
 
 #include "GnssUpdate.h"
+#include "GvioAligner.h"
 #include "ImuPropagator.h"
 #include "IngvioParams.h"
 #include "MapServer.h"
@@ -42,6 +43,7 @@ public:
     void callbackGnssMeas(const GnssMeas& gnss_meas) { _gnss_sync->bufferGnssMeas(gnss_meas); }       // GnssProcessor.cpp:119-220 -> GnssSync
     void callbackSppMeas(const SppMeas& spp_meas) { _gnss_sync->bufferSppMeas(spp_meas); }
     void setGnssAlignment(const GvioAlignment& a) { _gvio_aligner = a; }
+    std::shared_ptr<GvioAligner> gvioAligner() { return _aligner; }                     // batchAlign on the raw epochs (IngvioFilter.cpp:344-345)
     std::shared_ptr<GnssSync> gnssSync() { return _gnss_sync; }
     std::shared_ptr<GnssUpdate> gnssUpdate() { return _gnss_update; }
     int lastGnssRows() const { return _last_gnss_rows; }
@@ -69,6 +71,7 @@ protected:
     std::shared_ptr<GnssUpdate> _gnss_update;
     std::shared_ptr<GnssSync> _gnss_sync;
     GvioAlignment _gvio_aligner;
+    std::shared_ptr<GvioAligner> _aligner;
     int _last_gnss_rows = 0, _gnss_vars_added = 0;
     bool _hasImageCome = false, _hasInitState = false;
     int _frames = 0;

@@ -38,6 +38,9 @@ public:
     int _frame_select_interval = 18;
     int _is_gnss_chi2_test = 0, _is_gnss_strong_reject = 1, _is_adjust_yof = 0;
     double _psr_noise_amp = 1.0, _dopp_noise_amp = 1.0;
+    // GvioAligner (IngvioParams.cpp:121-124, config/fw_zed2i_f9p/ingvio_stereo.yaml:70-73)
+    int _gv_align_batch_size = 25, _gv_align_max_iter = 10;
+    double _gv_align_conv_epsilon = 1e-05, _gv_align_vel_thres = 0.4;
     Iso3 _T_cl2i, _T_cr2i;
 
     // device-side capacity of the covariance engine behind this filter (new: not in the reference)

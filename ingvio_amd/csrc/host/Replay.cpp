@@ -186,6 +186,10 @@ bool applyParamsText(const std::string& text, IngvioParams& p)
         else if (key == "max_sliding_window_poses") inum(p._max_sw_clones);
         else if (key == "is_key_frame") inum(p._is_key_frame);
         else if (key == "max_landmark_features") inum(p._max_lm_feats);
+        else if (key == "gv_align_batch_size") inum(p._gv_align_batch_size);
+        else if (key == "gv_align_max_iter") inum(p._gv_align_max_iter);
+        else if (key == "gv_align_conv_epsilon") num(p._gv_align_conv_epsilon);
+        else if (key == "gv_align_vel_thres") num(p._gv_align_vel_thres);
         else if (key == "enable_gnss") inum(p._enable_gnss);
         else if (key == "noise_gyro") num(p._noise_g);
         else if (key == "noise_accel") num(p._noise_a);

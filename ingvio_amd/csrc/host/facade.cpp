@@ -107,6 +107,19 @@ int ingvio_host_aligner_run(void* ctx, int n_epochs, int smax, const double* eph
     return a.aligned ? 1 : 0;
 }
 
+// gnss_comm::psr_pos + dopp_vel of ONE epoch through the shim (what GnssProcessor::callbackGnssMeas buffers as the SPP fix,
+// GnssProcessor.cpp:196-217): out[11] = xyzt (7), velocity + drift (4); returns 1 when both solved.
+int ingvio_host_spp(void* ctx, int nsat, const double* eph, const double* obs, double doy, const double* iono, double* out)
+{
+    ingvio::GvioAligner al((ingvio_ctx*)ctx);
+    if (iono) al.setIono(std::vector<double>(iono, iono + 8));
+    ingvio::RawGnssEpoch m;
+    m.eph.assign(eph, eph + (size_t)nsat * INGVIO_EPH_N); m.obs.assign(obs, obs + (size_t)nsat * INGVIO_OBS_N); m.doy = doy;
+    std::vector<const ingvio::RawGnssEpoch*> one{ &m };
+    if (!al.psrPos(one, out)) return 0;
+    return al.doppVel(m, out, out + 7) ? 1 : 0;
+}
+
 double ingvio_host_chi2_quantile(int dof, double p) { return ingvio::chi2Quantile(dof, p); }
 
 }  // extern "C"

@@ -94,3 +94,12 @@ def aligner_run(ctx, epochs, p_w, v_w, iono=None, batch_size=25, max_iter=10, co
                               C.c_double(conv_epsilon), C.c_double(vel_thres), _d(out))
     return dict(aligned=bool(out[0]), yaw_offset=out[1], anchor_ecef=out[2:5].copy(), R_enu2ecef=out[5:14].reshape(3, 3).copy(),
                 rcv_ddt=out[14], rough_anchor=out[15:22].copy())
+
+
+def spp(ctx, epoch, iono=None):
+    """gnss_comm::psr_pos + dopp_vel of one raw epoch (dict eph, obs, doy) through the shim: (xyzt [7], vel_ddt [4]) or None."""
+    eph, obs = _f(epoch["eph"]), _f(epoch["obs"])
+    out = np.zeros(11)
+    ion = _f(iono) if iono is not None else None
+    ok = lib().ingvio_host_spp(ctx.h, C.c_int(len(obs)), _d(eph), _d(obs), C.c_double(float(epoch["doy"])), _d(ion) if ion is not None else None, _d(out))
+    return (out[:7].copy(), out[7:].copy()) if ok else None

@@ -158,6 +158,15 @@ def test_shim_aligner_on_device_matches_checker_and_truth(orc, noise):
     # against the generating values
     assert abs(got["yaw_offset"] - tr["yaw"]) < (2e-2 if noise else 1e-3)
     assert np.linalg.norm(got["anchor_ecef"] - tr["anchor"]) < (3.0 if noise else 0.05)
+    # the per-epoch SPP fix GnssProcessor buffers (psr_pos + dopp_vel, GnssProcessor.cpp:196-217) on the last epoch
+    R = geo2rotation(ecef2geo(tr["anchor"]))
+    k = len(tr["epochs"]) - 1
+    fix = host.spp(ctx, tr["epochs"][k], iono=tr["ion"])
+    assert fix is not None
+    rcv_true = tr["anchor"] + R @ rotz(tr["yaw"]) @ tr["p_w"][k]
+    vel_true = R @ rotz(tr["yaw"]) @ tr["v_w"][k]
+    assert np.linalg.norm(fix[0][:3] - rcv_true) < (8.0 if noise else 1e-3)
+    assert np.linalg.norm(fix[1][:3] - vel_true) < (0.3 if noise else 1e-4) and abs(fix[1][3] - tr["fs"]) < (0.3 if noise else 1e-4)
     # not enough horizontal excitation: the buffer is dropped, nothing is aligned (:101-124)
     slow = host.aligner_run(ctx, tr["epochs"], tr["p_w"], 0.05 * tr["v_w"], iono=tr["ion"])
     assert not slow["aligned"]

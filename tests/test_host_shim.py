@@ -132,3 +132,13 @@ def test_reference_gtests_against_shim_and_hip_backend():
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert "0 failures" in r.stdout
+
+
+def test_ros1_adapter_conversions_on_mock_messages():
+    """ros1/include/RosAdapter.h (the field-by-field core of ros1/src/ingvio_node.cpp) instantiated with mock structs shaped like the
+    ROS messages: frames / IMU / odometry, gnss_comm's satellite numbering and L1 selection, ephemeris records, best-ephemeris choice,
+    tracking counters, evaluated records -> GnssMeas.  Built without ROS by ingvio_amd/build.py."""
+    exe = os.path.join(ROOT, "ingvio_amd", "lib", "test_ros_adapter")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
