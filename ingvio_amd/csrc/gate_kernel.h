@@ -889,3 +889,358 @@ __device__ __forceinline__ void gate4_body(CovView cv, FrameView fv, MsckfOpts o
     }
     dbg_stamp(10);
 }
+
+// =============================================================================================
+// The same gate (gate4_body: difference coordinates of the observations) for LARGE windows (17..36 clones), TWO waves per feature.
+// The first generation ran one wave per feature with 28 (32-clone class) lower tiles in VGPRs + AGPRs and 48 KB of LDS: three
+// waves per CU, every LDS round trip and every MFMA chain fully exposed (config 5: 0.60 ms per 32 filters, 0.19 of the FP64 peak).
+// Here the 3 (nobs - 1) + 1 bordered system has one tile row less (6 instead of 7 for 30 clones: 21 tiles), the tile rows are dealt
+// to the two waves at compile time (each holds ~half of the tiles, in VGPRs only), the pair blocks are built by 128 lanes, and the
+// panel exchange is double-buffered: ONE workgroup barrier per panel.  Both waves transform the panel rows of every live tile row
+// (the B operands of the other wave's tiles) - a few VALU instructions - and issue MFMAs for their own tiles only.  Wave 0 runs
+// the per-observation front and stages the record k_feat_gram_big reads (same layout as gate3_body's, rec_size(BIG_CMAX) stride).
+// =============================================================================================
+template <int CMAX>
+struct Gate4BigShared {
+    static constexpr int NR = CMAX - 1, NPMAX = 3 * NR, NTL = (NPMAX + 1 + 15) / 16, BR = 16 * NTL - 1, KPK = NPMAX * (NPMAX + 1) / 2;
+    int gidx[CMAX];
+    int pl[CMAX], cna[CMAX], slot[CMAX];
+    int nobs;
+    double rpsum;
+    double pf[3];
+    double vNinv[CMAX][9];
+    double w[3 * CMAX];
+    double Rb[CMAX][9];
+    double recbuf[REC_HDR + REC_OBS * CMAX];
+    union alignas(16) {
+        double kp[KPK + 16];
+        double nh[CMAX * 12 + 24];          // front: N_o | h_o per observation and the record's 21 sums
+        double pan[2][16 * NTL][4];         // double-buffered panel exchange
+    };
+};
+
+// tile row ti of the bordered matrix -> owning wave (0 / 1): rows taken from the largest down, each to the lighter wave
+template <int NTL>
+__host__ __device__ constexpr int gate4_row_owner(int ti)
+{
+    int load0 = 0, load1 = 0, own = 0;
+    for (int r = NTL - 1; r >= 0; --r) {
+        const int o = load0 <= load1 ? 0 : 1;
+        if (o == 0) load0 += r + 1; else load1 += r + 1;
+        if (r == ti) own = o;
+    }
+    return own;
+}
+
+template <int CMAX, int W>
+__device__ __forceinline__ void gate4_big_back(Gate4BigShared<CMAX>& sh, const MsckfOpts& op, const FrameView& fv, size_t oidx, int lane,
+                                               double* __restrict__ gamma_out, int* __restrict__ accept_out)
+{
+    using SH = Gate4BigShared<CMAX>;
+    constexpr int NTL = SH::NTL, NLT = NTL * (NTL + 1) / 2, NPMAX = SH::NPMAX;
+    const int kq = lane >> 4, l15 = lane & 15;
+    const int np = 3 * (sh.nobs - 1), npan = (np + 3) >> 2;
+    double4_f T[NLT];                         // only the tiles of this wave's rows are ever touched (the others fold away)
+    bool jreal[NTL];
+#pragma unroll
+    for (int tj = 0; tj < NTL; ++tj) jreal[tj] = 16 * tj + l15 < np;
+#pragma unroll
+    for (int ti = 0; ti < NTL; ++ti) {
+        if (gate4_row_owner<NTL>(ti) != W) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * ti + kq + 4 * r;
+            const bool ireal = i < np;
+            const int ii = ireal ? i : 0, tri_i = ii * (ii + 1) / 2;
+#pragma unroll
+            for (int tj = 0; tj <= ti; ++tj) {
+                const int jcol = 16 * tj + l15;
+                double bv;
+                if (tj < ti) bv = sh.kp[tri_i + jcol];
+                else {
+                    const int jj = jreal[tj] ? jcol : 0;
+                    bv = sh.kp[ii >= jj ? tri_i + jj : jj * (jj + 1) / 2 + ii];
+                }
+                const double idv = (i == jcol) ? 1.0 : 0.0;
+                double v = (ireal && jreal[tj]) ? bv : ((!ireal && !jreal[tj]) ? idv : 0.0);
+                if (ti == NTL - 1 && r == 3) {
+                    const double wv = sh.w[jreal[tj] ? jcol : 0];
+                    v = kq == 3 ? (jreal[tj] ? wv : 0.0) : v;
+                }
+                T[ti * (ti + 1) / 2 + tj][r] = v;
+            }
+        }
+    }
+    __syncthreads();                          // kp is dead: its LDS becomes the panel buffers
+    dbg_stamp(9);
+    constexpr int KPAN = (NPMAX + 3) / 4;
+#pragma unroll
+    for (int k = 0; k < KPAN; ++k) {
+        if (k < npan) {
+            const int tj0 = k >> 2, cb = 4 * (k & 3), buf = k & 1;
+            if (l15 >= cb && l15 < cb + 4) {
+#pragma unroll
+                for (int ti = tj0; ti < NTL; ++ti) {
+                    if (gate4_row_owner<NTL>(ti) != W) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sh.pan[buf][16 * ti + kq + 4 * r][l15 - cb] = T[ti * (ti + 1) / 2 + tj0][r];
+                }
+            }
+            __syncthreads();
+            double a4[4][4];
+#pragma unroll
+            for (int ra = 0; ra < 4; ++ra) {
+                const double2* pr = reinterpret_cast<const double2*>(sh.pan[buf][4 * k + ra]);
+                const double2 u0 = pr[0], u1 = pr[1];
+                a4[ra][0] = u0.x; a4[ra][1] = u0.y; a4[ra][2] = u1.x; a4[ra][3] = u1.y;
+            }
+            const double r0 = fast_rcp(a4[0][0]);
+            const double l10 = a4[1][0] * r0, l20 = a4[2][0] * r0, l30 = a4[3][0] * r0;
+            const double r1 = fast_rcp(a4[1][1] - l10 * a4[1][0]);
+            const double t21 = a4[2][1] - l20 * a4[1][0], t31 = a4[3][1] - l30 * a4[1][0];
+            const double l21 = t21 * r1, l31 = t31 * r1;
+            const double r2 = fast_rcp(a4[2][2] - l20 * a4[2][0] - l21 * t21);
+            const double t32 = a4[3][2] - l30 * a4[2][0] - l31 * t21;
+            const double l32 = t32 * r2;
+            const double r3 = fast_rcp(a4[3][3] - l30 * a4[3][0] - l31 * t31 - l32 * t32);
+            const bool bord = (k == 4 * NTL - 1);            // the last panel of the grid ends ON the border row (see gate4_body)
+            const double dsel = kq == 0 ? r0 : (kq == 1 ? r1 : (kq == 2 ? r2 : (bord ? 0.0 : r3)));
+            double A[NTL], B[NTL];
+#pragma unroll
+            for (int tt = tj0; tt < NTL; ++tt) {
+                const double2* pr = reinterpret_cast<const double2*>(sh.pan[buf][16 * tt + l15]);
+                const double2 u0 = pr[0], u1 = pr[1];
+                const double x0 = u0.x;
+                const double x1 = u0.y - l10 * x0;
+                const double x2 = u1.x - l20 * x0 - l21 * x1;
+                const double x3 = u1.y - l30 * x0 - l31 * x1 - l32 * x2;
+                double xs = kq == 0 ? x0 : (kq == 1 ? x1 : (kq == 2 ? x2 : x3));
+                if (16 * tt + l15 <= 4 * k + (bord ? 2 : 3)) xs = 0.0;
+                A[tt] = xs;
+                B[tt] = -xs * dsel;
+            }
+#pragma unroll
+            for (int ti = tj0; ti < NTL; ++ti) {
+                if (gate4_row_owner<NTL>(ti) != W) continue;
+#pragma unroll
+                for (int tj = tj0; tj <= ti; ++tj)
+                    T[ti * (ti + 1) / 2 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ti], B[tj], T[ti * (ti + 1) / 2 + tj], 0, 0, 0);
+            }
+        }
+    }
+    if (gate4_row_owner<NTL>(NTL - 1) == W && lane == WAVE - 1) {      // element (BR, BR) = -w^T Kr^-1 w
+        const double g = -T[NLT - 1][3] + sh.rpsum / op.var;
+        const int dof = fv.dof[oidx];
+        const bool ok = dof >= 1 && dof < op.chi2_len && g < op.chi2[dof];      // Update.cpp:120
+        gamma_out[oidx] = g;
+        accept_out[oidx] = ok ? 1 : 0;
+    }
+}
+
+template <int CMAX, int RSTRIDE>
+__device__ __forceinline__ void gate4_big_body(CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out,
+                                               int* __restrict__ accept_out, double* __restrict__ rec_out)
+{
+    using SH = Gate4BigShared<CMAX>;
+    static_assert(CMAX <= 64, "one lane per window slot");
+    extern __shared__ __attribute__((aligned(16))) char gate4_smem[];
+    SH& sh = *reinterpret_cast<SH*>(gate4_smem);
+    const int wg = blockIdx.x, xcd = wg & 7, t = wg >> 3;
+    const int bl = xcd + 8 * (t / fmax_used), j = t % fmax_used;
+    if (bl >= nb) return;
+    const int b = b0 + bl, tid = threadIdx.x, wave = tid >> 6, lane = tid & (WAVE - 1);
+    const int F = fv.n_feat[b];
+    if (j >= F) return;
+    const int C = fv.n_clones[b], ld = cv.ldp;
+    const double* P = cov_ptr(cv, b);
+    const size_t oidx = (size_t)b * fv.fmax + j;
+    const int a = fv.anchor[oidx];
+    const double* pf = fv.pf + oidx * 3;
+    const double px = pf[0], py = pf[1], pz = pf[2];
+    double* const rec = sh.recbuf;
+    dbg_stamp(5);
+    // ================= front, lane = window slot, BOTH waves: each evaluates the projections (validity and ordering of the observations
+    // must be known to both); wave 0 goes on with N_o, u_o, the gate's per-observation terms and the record, wave 1 with the blocks
+    // R_o = F_o P_ob F_b^T against the reference observation (36 loads and two cross-product passes per lane) =================
+    {
+        const unsigned long long mask = fv.obs_mask[oidx];
+        const int sl = lane;
+        const int cidx = sl < C ? fv.clone_idx[(size_t)b * fv.cmax + sl] : 0;
+        bool valid = false;
+        double Gm[4][3], rs[4];
+        if (sl < C && ((mask >> sl) & 1ULL)) {
+            const double* R = fv.clone_R + ((size_t)b * fv.cmax + sl) * 9;
+            const double* pp = fv.clone_p + ((size_t)b * fv.cmax + sl) * 3;
+            const double* z = fv.uv + (oidx * fv.cmax + sl) * 4;
+            const double zz[4] = { z[0], z[1], z[2], z[3] };
+            valid = feat_obs<true>(R, pp, zz, px, py, pz, op, Gm, rs);
+        }
+        const unsigned long long vm = __ballot(valid);
+        const int nobs = __popcll(vm);
+        const bool fok = 4 * nobs - 3 > 0;
+        if (wave == 0 && lane == 0) {
+            sh.nobs = fok ? nobs : 0;
+            if (!fok) { gamma_out[oidx] = __builtin_nan(""); accept_out[oidx] = 0; rec_out[oidx * RSTRIDE] = 0.0; }
+        }
+        if (fok) {
+            const int bslot = __ffsll((long long)vm) - 1;
+            const int od = __popcll(vm & ((1ULL << sl) - 1ULL));
+            const bool cn = sl != a, plf = !(op.selected_variant && sl == a);
+            if (wave == 1) {
+                const double plo = (valid && plf) ? 1.0 : 0.0;
+                const double plb = !(op.selected_variant && bslot == a) ? 1.0 : 0.0;
+                const int gb = __builtin_amdgcn_readlane(cidx, bslot);
+                if (valid) {
+                    double Rb[9];
+                    gate4_pairblock(P, ld, cidx, gb, plo, plb, px, py, pz, Rb);
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) sh.Rb[od][i] = Rb[i];              // Rb[0] = F_b P_bb F_b^T: Q = Rb[0] + s^2 N_b^-1 is formed by the pair lanes
+                }
+            } else {
+                double u[3] = { 0.0, 0.0, 0.0 }, Ni[9], N[9], h[3] = { 0.0, 0.0, 0.0 }, rr = 0.0;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { Ni[i] = 0.0; N[i] = 0.0; }
+                if (valid) {
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+#pragma unroll
+                        for (int m2 = m; m2 < 3; ++m2) {
+                            double sN = 0.0;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) sN += Gm[q][m] * Gm[q][m2];
+                            N[3 * m + m2] = sN; N[3 * m2 + m] = sN;
+                        }
+                        double hh = 0.0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) hh += Gm[q][m] * rs[q];
+                        h[m] = hh;
+                    }
+                    inv3sym(N, Ni);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rr += rs[q] * rs[q];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        u[m] = Ni[3 * m] * h[0] + Ni[3 * m + 1] * h[1] + Ni[3 * m + 2] * h[2];
+                        rr -= h[m] * u[m];
+                    }
+                }
+                const double rsum = wave_sum(rr);
+                double ub[3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const int lo = __builtin_amdgcn_readlane(__double2loint(u[m]), bslot), hi = __builtin_amdgcn_readlane(__double2hiint(u[m]), bslot);
+                    ub[m] = __hiloint2double(hi, lo);
+                }
+                if (lane == 0) {
+                    sh.rpsum = rsum; sh.pf[0] = px; sh.pf[1] = py; sh.pf[2] = pz;
+                    rec[0] = nobs; rec[1] = a; rec[2] = px; rec[3] = py; rec[4] = pz; rec[5] = (double)vm;      // the valid observations' slot mask
+                }
+                double* const Nh = sh.nh;
+                if (valid) {
+                    sh.gidx[od] = cidx; sh.pl[od] = plf; sh.cna[od] = cn; sh.slot[od] = sl;
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) sh.vNinv[od][i] = op.var * Ni[i];
+                    if (od > 0) {
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) sh.w[3 * (od - 1) + m] = u[m] - ub[m];
+                    }
+                    // the record of k_feat_gram_big: per observation {slot, cna, pfl, N_o (9), h_o (3)}
+                    double* ro = rec + REC_HDR + REC_OBS * od;
+                    ro[0] = sl; ro[1] = cn ? 1.0 : 0.0; ro[2] = plf ? 1.0 : 0.0;
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) { ro[3 + i] = N[i]; Nh[od * 12 + i] = N[i]; }
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { ro[12 + i] = h[i]; Nh[od * 12 + 9 + i] = h[i]; }
+                }
+                wave_sync();
+                // the record's sums: Ns = sum N_o (-> Ns^-1), hs = sum h_o, Nsa = sum over the observations whose clone is not the anchor
+                double* const sums = Nh + CMAX * 12;
+                if (lane < 21) {
+                    const int anch = lane >= 12, comp = anch ? lane - 12 : lane;
+                    double sacc = 0.0;
+                    for (int o = 0; o < nobs; ++o) sacc += (!anch || sh.cna[o]) ? Nh[o * 12 + comp] : 0.0;
+                    sums[lane] = sacc;
+                }
+                wave_sync();
+                if (lane < 21) {
+                    double v = sums[lane];
+                    if (lane < 9) { double Nsi[9]; inv3sym(sums, Nsi); v = Nsi[lane]; }
+                    rec[6 + lane] = v;
+                }
+            }
+        }
+    }
+    dbg_stamp(6);
+    __syncthreads();
+    dbg_stamp(7);
+    const int nobs = sh.nobs;
+    if (nobs == 0) return;
+    // ================= Kr blocks, one observation pair per lane (128 lanes).  The 36 covariance loads of a lane's NEXT pair are issued
+    // before the arithmetic of the current one (three to four rounds per feature at 30 clones: the rounds used to pay one L2
+    // round trip each) =================
+    {
+        const int nred = nobs - 1, npair = nred * (nred + 1) / 2;
+        double Q[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Q[i] = sh.Rb[0][i] + sh.vNinv[0][i];
+        auto pair_of = [&](int q, int& i, int& i2) {
+            i = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
+            while ((i + 1) * (i + 2) / 2 <= q) ++i;
+            while (i * (i + 1) / 2 > q) --i;
+            i2 = q - i * (i + 1) / 2;
+        };
+        double Att[9], Atp[9], Apt[9], App[9];
+        auto load4 = [&](int g, int g2) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    Att[3 * m + c] = P[(g + m) + (size_t)(g2 + c) * ld];
+                    Atp[3 * m + c] = P[(g + m) + (size_t)(g2 + 3 + c) * ld];
+                    Apt[3 * m + c] = P[(g + 3 + m) + (size_t)(g2 + c) * ld];
+                    App[3 * m + c] = P[(g + 3 + m) + (size_t)(g2 + 3 + c) * ld];
+                }
+        };
+        int i = 0, i2 = 0;
+        if (tid < npair) { pair_of(tid, i, i2); load4(sh.gidx[i + 1], sh.gidx[i2 + 1]); }
+        for (int q = tid; q < npair; q += 2 * WAVE) {
+            const int o = i + 1, o2 = i2 + 1, ci = i, ci2 = i2;
+            const double pl = sh.pl[o] ? 1.0 : 0.0, pl2 = sh.pl[o2] ? 1.0 : 0.0;
+            double T1[9], T2[9], Su[9], Bt[9], Bp[9];
+            mulXt(Att, px, py, pz, T1);
+            mulX(T1, px, py, pz, T2);                 // X Ptt' X^T
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { Su[k] = T2[k] + (pl * pl2) * App[k]; Bt[k] = Atp[k]; Bp[k] = Apt[k]; }
+            if (q + 2 * WAVE < npair) { pair_of(q + 2 * WAVE, i, i2); load4(sh.gidx[i + 1], sh.gidx[i2 + 1]); }      // next pair's loads in flight
+            mulXt(Bt, px, py, pz, T1);
+            mulX(Bp, px, py, pz, T2);
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    Su[3 * m + k] += pl2 * T1[3 * m + k] + pl * T2[3 * m + k] + Q[3 * m + k] - sh.Rb[o][3 * m + k] - sh.Rb[o2][3 * k + m];
+            if (ci == ci2) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Su[k] += sh.vNinv[o][k];
+            }
+            int tri = (3 * ci) * (3 * ci + 1) / 2 + 3 * ci2;
+#pragma unroll
+            for (int a2 = 0; a2 < 3; ++a2) {
+#pragma unroll
+                for (int c2 = 0; c2 < 3; ++c2)
+                    if (ci != ci2 || c2 <= a2) sh.kp[tri + c2] = Su[3 * a2 + c2];
+                tri += 3 * ci + a2 + 1;
+            }
+        }
+    }
+    __syncthreads();
+    dbg_stamp(8);
+    // the record leaves now (its stores complete under the elimination)
+    {
+        double* const rec_g = rec_out + oidx * RSTRIDE;
+        for (int e = tid; e < REC_HDR + REC_OBS * nobs; e += 2 * WAVE) rec_g[e] = rec[e];
+    }
+    if (wave == 0) gate4_big_back<CMAX, 0>(sh, op, fv, oidx, lane, gamma_out, accept_out);
+    else gate4_big_back<CMAX, 1>(sh, op, fv, oidx, lane, gamma_out, accept_out);
+    dbg_stamp(10);
+}

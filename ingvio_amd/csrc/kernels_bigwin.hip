@@ -32,10 +32,29 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1))) vo
     gate3_body<CM, STEREO, 1, true, REC_HDR + REC_OBS * BIG_CMAX>(cv, fv, op, b0, nb, fmax_used, gamma_out, accept_out, rec_out);
 }
 
+// Stereo, round 3: the gate in difference coordinates of the observations with TWO waves per feature (gate_kernel.h, gate4_big_body).
+template <int CM>
+__global__ __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_feat_gate4_big(CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used,
+                                                             double* __restrict__ gamma_out, int* __restrict__ accept_out, double* __restrict__ rec_out)
+{
+    gate4_big_body<CM, REC_HDR + REC_OBS * BIG_CMAX>(cv, fv, op, b0, nb, fmax_used, gamma_out, accept_out, rec_out);
+}
+
 template <bool STEREO, int CM>
 static void launch_gate_big(const FactoredLaunch& L, hipStream_t st)
 {
     const int nb8 = (L.nb + 7) / 8 * 8;
+    static const bool gate3 = [] { const char* e = getenv("INGVIO_GATE"); return e && e[0] == '3'; }();      // first generation, for comparison
+    if constexpr (STEREO) {
+        if (!gate3) {
+            const size_t sm = sizeof(Gate4BigShared<CM>);
+            static bool attr_set = false;
+            if (!attr_set) { hipFuncSetAttribute((const void*)k_feat_gate4_big<CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
+            hipLaunchKernelGGL((k_feat_gate4_big<CM>), dim3(nb8 * L.fmax_used), dim3(2 * WAVE), sm, st, L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used,
+                               L.gamma, L.accept, L.rec);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_feat_gate3_big<STEREO, CM>), dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st,
                        L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
 }
@@ -691,17 +710,27 @@ __global__ __launch_bounds__(256) void k_copy_rows(const double* __restrict__ S,
 
 // The reference clone's block row / column of [M | t]: minus the sums over the other clones' blocks (every block row and column
 // of the n x n solution sums to zero: M = T^-T diag(0, Mr) T^-1, see k_info_solve).  One workgroup per filter.
-__global__ __launch_bounds__(1024) void k_big_gauge_fix(FrameView fv, int b0, double* __restrict__ Mall, int mstride, const double* __restrict__ ws_all,
-                                                        size_t ws_stride, size_t oref, const int* __restrict__ active)
+__global__ __launch_bounds__(256) void k_big_gauge_fix(FrameView fv, int b0, double* __restrict__ Mall, int mstride, const double* __restrict__ ws_all,
+                                                       size_t ws_stride, size_t oref, const int* __restrict__ active, int corner)
 {
     constexpr int MP = BIG_NC;
-    const int bl = blockIdx.x, tid = threadIdx.x;
+    const int bl = blockIdx.y, tid = threadIdx.x;
     if (active && !active[bl]) return;
     const int ref = (int)ws_all[(size_t)bl * ws_stride + oref];
     if (ref < 0) return;
     const int C = fv.n_clones[b0 + bl], ref6 = 6 * ref;
     double* Mg = Mall + (size_t)bl * mstride;
-    for (int e = tid; e < 2 * 6 * (MP + 1); e += 1024) {
+    if (corner) {                                             // second launch: the 6 x 6 corner from the reference rows just written
+        if (blockIdx.x == 0 && tid < 36) {
+            const int k = tid / 6, l = tid - 6 * k;
+            double s = 0.0;
+#pragma unroll 6
+            for (int c = 0; c < C; ++c) s += (c != ref ? 1.0 : 0.0) * Mg[(size_t)(ref6 + k) * MP + 6 * c + l];
+            Mg[(size_t)(ref6 + k) * MP + ref6 + l] = -s;
+        }
+        return;
+    }
+    for (int e = blockIdx.x * 256 + tid; e < 2 * 6 * (MP + 1); e += gridDim.x * 256) {
         const int side = e / (6 * (MP + 1)), q = e - side * 6 * (MP + 1), k = q / (MP + 1), J = q - k * (MP + 1);
         if (J == MP) {
             if (side == 0) {
@@ -717,13 +746,6 @@ __global__ __launch_bounds__(1024) void k_big_gauge_fix(FrameView fv, int b0, do
             for (int c = 0; c < C; ++c) s += (c != ref ? 1.0 : 0.0) * Mg[base + c * step];      // loads independent of the mask: all in flight
             if (side == 0) Mg[(size_t)(ref6 + k) * MP + J] = -s; else Mg[(size_t)J * MP + ref6 + k] = -s;
         }
-    }
-    __syncthreads();
-    if (tid < 36) {
-        const int k = tid / 6, l = tid - 6 * k;
-        double s = 0.0;
-        for (int c = 0; c < C; ++c) if (c != ref) s += Mg[(size_t)(ref6 + k) * MP + 6 * c + l];
-        Mg[(size_t)(ref6 + k) * MP + ref6 + l] = -s;
     }
 }
 
@@ -774,7 +796,10 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
     launch_gemm(g, st);
     g.B = ws + w.oY2 + 2 * n32; g.C = L.T + (size_t)MP * MP; g.rs = 1; g.cs = 0; g.N = 1; g.n_lim = 1;
     launch_gemm(g, st);
-    if (gauge) hipLaunchKernelGGL(k_big_gauge_fix, dim3(L.nb), dim3(1024), 0, st, L.fv, L.b0, L.T, L.mstride, ws, wss, w.oRef, act);
+    if (gauge) {
+        hipLaunchKernelGGL(k_big_gauge_fix, dim3(11, L.nb), dim3(256), 0, st, L.fv, L.b0, L.T, L.mstride, ws, wss, w.oRef, act, 0);
+        hipLaunchKernelGGL(k_big_gauge_fix, dim3(1, L.nb), dim3(256), 0, st, L.fv, L.b0, L.T, L.mstride, ws, wss, w.oRef, act, 1);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

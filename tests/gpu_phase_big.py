@@ -15,4 +15,4 @@ d = ctx.debug_read(56)
 print("gram_big [prologue, batch loop, rank-3 epilogue, sparse epilogue]", [d[i + 1] - d[i] for i in range(48, 52)], "total", d[52] - d[48])
 import os
 if os.environ.get("INGVIO_DBG_TU") == "b":
-    print("gate3_big [front, barrier, pair blocks + tile fill, LDL, border + gate]", [d[i + 1] - d[i] for i in range(5, 10)], "total", d[10] - d[5])
+    print("gate4_big [front, barrier, pair blocks, tile fill, LDL + gate]", [d[i + 1] - d[i] for i in range(5, 10)], "total", d[10] - d[5])

@@ -617,7 +617,15 @@ def test_qr_compress_general_vs_oracle(orc, m, n):
     k = min(m, n)
     scale = np.linalg.norm(Ro)
     if n != 130:      # rank-deficient: the reflector of a numerically zero column is decided by rounding noise, R is not unique
+        if m >= 6 * n:   # tall: Cholesky-QR (positive diagonal) - R is unique up to the sign of each row
+            sg = np.sign(np.diag(Ro[:k])) * np.sign(np.diag(Ht[:k]))
+            Ro = Ro.copy(); ro = ro.copy(); Ro[:k] *= sg[:, None]; ro[:k] *= sg
         assert np.linalg.norm(Ht[:k] - Ro[:k]) < 1e-11 * scale and np.linalg.norm(rt[:k] - ro[:k]) < 1e-11 * max(1.0, np.linalg.norm(ro))
+        if m >= 6 * n:
+            ctx3.set_qr_method("householder")             # the same shape through the Householder route: the oracle's convention, entry by entry
+            Hh, rh = ctx3.qr_compress(A, b)
+            Ro2, ro2 = orc.qr_compress(A, b)
+            assert np.linalg.norm(Hh[:k] - Ro2[:k]) < 1e-11 * scale and np.linalg.norm(rh[:k] - ro2[:k]) < 1e-11 * max(1.0, np.linalg.norm(ro2))
     assert not np.tril(Ht, -1).any() and not Ht[k:].any() and np.isfinite(Ht).all()
     assert rel_err(Ht.T @ Ht, A.T @ A) < 1e-12 and rel_err(Ht.T @ rt, A.T @ b) < 1e-12
     ctx3.close()
