@@ -85,10 +85,10 @@ struct ingvio_ctx {
     // dense-H update workspace (kernels_lmbatch.hip + kernels_chol.hip): the batched landmark update and generic updates whose S
     // does not fit in LDS.  Rows live in Hd [m_cap][n_ld] per filter, the sweep in X / Y [ldx][m_cap].
     struct DenseWs {
-        double *Hd = nullptr, *X = nullptr, *Y = nullptr, *Tb = nullptr, *noise = nullptr, *noiseB = nullptr;      // noise: one filter's R (ingvio_ekf_update); noiseB [B][m_cap]: scalar / diagonal R per filter (batch)
+        double *Hd = nullptr, *X = nullptr, *Y = nullptr, *Tb = nullptr, *U = nullptr, *noise = nullptr, *noiseB = nullptr;      // U: factor tiles of the register-resident solve (m_cap <= 256); noise: one filter's R (ingvio_ekf_update); noiseB [B][m_cap]: scalar / diagonal R per filter (batch)
         int *m = nullptr, *cidx = nullptr;
         int m_cap = 0, n_ld = 0, n32 = 0, ldx = 0;
-        size_t hstride = 0, xstride = 0, tstride = 0;
+        size_t hstride = 0, xstride = 0, tstride = 0, ustride = 0;
     } dw;
     struct LmStage {
         double *pose = nullptr, *pf = nullptr, *uv = nullptr, *gamma = nullptr, *dx = nullptr;      // dx: its own [B][ldp] (the frame's MSCKF dx stays in d_dx)
@@ -1522,15 +1522,16 @@ static int dense_ws_alloc(ingvio_ctx* c, int m_need)
     const int m_cap = (m_need + 31) / 32 * 32;
     if (w.Hd && w.m_cap >= m_cap) return 0;
     HIPCHK(c, hipStreamSynchronize(c->st));
-    for (double** p : { &w.Hd, &w.X, &w.Y, &w.Tb, &w.noise, &w.noiseB }) { if (*p) hipFree(*p); *p = nullptr; }
+    for (double** p : { &w.Hd, &w.X, &w.Y, &w.Tb, &w.U, &w.noise, &w.noiseB }) { if (*p) hipFree(*p); *p = nullptr; }
     if (w.m) { hipFree(w.m); w.m = nullptr; }
     if (w.cidx) { hipFree(w.cidx); w.cidx = nullptr; }
     const int B = c->d.batch;
     w.m_cap = m_cap; w.n32 = (c->d.n_max + 31) / 32 * 32; w.n_ld = w.n32; w.ldx = m_cap + w.n32 + 32;
     w.hstride = std::max((size_t)m_cap * w.n_ld, (size_t)LM_MAX * 100);      // also holds the landmark path's compact blocks
     w.xstride = (size_t)w.ldx * m_cap; w.tstride = (size_t)(m_cap / 32) * 1024 + (size_t)m_cap;
+    w.ustride = m_cap <= 256 ? lm_chol_ws_doubles(m_cap) : 0;
     int rc = dalloc(c, &w.Hd, (size_t)B * w.hstride) | dalloc(c, &w.X, (size_t)B * w.xstride) | dalloc(c, &w.Y, (size_t)B * w.xstride)
-           | dalloc(c, &w.Tb, (size_t)B * w.tstride) | dalloc(c, &w.m, (size_t)B) | dalloc(c, &w.noise, (size_t)m_cap * m_cap) | dalloc(c, &w.cidx, (size_t)B * LM_MAX * 4) | dalloc(c, &w.noiseB, (size_t)B * m_cap);
+           | dalloc(c, &w.Tb, (size_t)B * w.tstride) | (w.ustride ? dalloc(c, &w.U, (size_t)B * w.ustride) : 0) | dalloc(c, &w.m, (size_t)B) | dalloc(c, &w.noise, (size_t)m_cap * m_cap) | dalloc(c, &w.cidx, (size_t)B * LM_MAX * 4) | dalloc(c, &w.noiseB, (size_t)B * m_cap);
     return rc ? INGVIO_E_HIP : 0;
 }
 
@@ -1561,7 +1562,15 @@ static int run_dense_update(ingvio_ctx* c, int b0, int nb, double var, int r_kin
         launch_gemm(g, c->st);
         if (r_kind >= 0) launch_add_noise(X, w.xstride, w.ldx, d_noise, nstride, r_kind, act, mc, nb, c->st);
     }
-    {
+    // S of up to 256 rows: one workgroup per filter, S in registers (kernels_lmchol.hip); larger: the sweep out of L2 (kernels_chol.hip)
+    static const bool sweep_only = getenv("INGVIO_LM_SOLVE") && !strcmp(getenv("INGVIO_LM_SOLVE"), "sweep");
+    if (w.U && !sweep_only) {
+        ProfScope p(c, PF_LM_CHOL);
+        LmCholArgs a = {};
+        a.cv = view(c); a.b0 = b0; a.nb = nb; a.X = X; a.Y = Y; a.xs = w.xstride; a.ldx = w.ldx; a.mc = mc; a.res_row = mc + w.n32;
+        a.U = w.U + (size_t)b0 * w.ustride; a.us = w.ustride; a.m = act; a.status = c->d_status + b0; a.fail_bit = 4; a.dx = d_dx;
+        launch_lm_chol(a, c->st);
+    } else {
         ProfScope p(c, PF_LM_CHOL);
         CholArgs a = {};
         a.W = X; a.Y = Y; a.xs = w.xstride; a.ld = w.ldx; a.Tb = w.Tb + (size_t)b0 * w.tstride; a.ts = w.tstride; a.t_slots = mc / 32;

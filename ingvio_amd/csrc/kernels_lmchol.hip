@@ -1,0 +1,301 @@
+// kernels_lmchol.hip — the SPD solve of a stacked update with up to 256 rows, ONE workgroup per filter, matrix resident in
+// registers (gfx950 only).  Used by the batched SLAM-landmark update (LandmarkUpdate.cpp:32-149: S = H P H^T + s^2 I with 4 rows
+// per stereo landmark, 208 rows at 52 landmarks) and by generic ekfUpdate calls of that size (StateManager.cpp:359-411).
+//
+// kernels_chol.hip factorises out of HBM / L2 with one launch per 32-column panel and one workgroup per 32 x 32 block: made for
+// a handful of large matrices (config 5).  With hundreds of filters every one of its workgroups is a memory round trip deep and
+// does 40 MFMA: 512 filters x 208 rows took 0.34 ms (factor) + 0.35 ms (carried rows) + 0.07 ms (dx).  Here:
+//
+//   k_lm_factor   S = U^T U by 16-column panels, the upper triangle of S dealt round-robin as 16 x 16 tiles to the 8 waves of the
+//                 workgroup and kept in registers in the MFMA C/D layout (lane (kq, l15), register r = element (kq + 4 r, l15)).
+//                 That layout IS the B operand of v_mfma_f64_16x16x4 when k-step r covers rows kq + 4 r, and also the A operand
+//                 of a product with the tile transposed - so, per panel k:
+//                     (A) the wave that owns S_kk factorises it (one lane per row, identity carried: T = L_kk^-T falls out)
+//                     (B) U_kb = L_kk^-1 S_kb      : A = L_kk^-1 from LDS, B = the tile's registers           (b > k)
+//                     (C) S_ab -= U_ka^T U_kb       : A and B both straight from the panel buffer in LDS       (k < a <= b)
+//                 two workgroup barriers per panel, no transposes.  The residual rides along on the vector ALU: z = L^-1 res.
+//                 Output: U and the L_kk^-1 as tiles in that register layout (lane-linear: 512-byte rows), z.
+//   k_lm_carry    V = L^-1 (P H^T)^T by forward substitution, one wave per 16 state rows: V_k = L_kk^-1 (C_k - sum_p<k U_pk^T V_p)
+//                 with the V_p of the block resident in registers (again C/D layout = B operand) and the U tiles streamed as A
+//                 operands; writes Y = V^T in the layout k_downdate64 reads, and dx = V^T z.
+// Parity: tests/test_landmark_batch.py, tests/test_landmark_path.py, tests/test_gpu_parity.py (dense-H route) - all through the C ABI.
+#include "launch_chol.h"
+#include "dev_common.h"
+
+typedef double double4_f __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ double rsqrt_full(double p)                  // v_rsq_f64 + two Newton steps
+{
+    double y = __builtin_amdgcn_rsq(p);
+    double e = fma(-p * y, y, 1.0);
+    y = fma(y * e, fma(e, 0.375, 0.5), y);
+    e = fma(-p * y, y, 1.0);
+    y = fma(y * e, 0.5, y);
+    return y;
+}
+
+__device__ __forceinline__ double lane_f64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int tri_tiles(int ntm) { return ntm * (ntm + 1) / 2; }
+// row-major index of tile (a, b), a <= b, in the upper triangle of an ntm x ntm tile grid
+__host__ __device__ constexpr int tri_index(int ntm, int a, int b) { return a * ntm - a * (a - 1) / 2 + (b - a); }
+
+// ---------------------------------------------------------------------------------------------
+// Factorisation of one 16 x 16 diagonal tile by ONE wave.  sDI = [D; I] (32 x 17): lane l < 16 holds row l of D, lane 16 + i
+// row i of the identity carried below it (lanes 32..63 shadow lanes 0..31).  Elimination in LDL^T form, scaled to Cholesky at
+// the end, the column update of pivot j - 1 software-pipelined behind the pivot chain of j (the scheme of factor32 in
+// kernels_chol.hip).  Returns the scaled rows: lanes 0..15 rows of L, lanes 16..31 rows of T = L^-T.  bad: a pivot of this
+// lane's row was not positive (its column is zeroed).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void factor16(double (*sDI)[17], double (*sC)[16], int lane, double (&d)[16], bool& bad)
+{
+    const int row = lane & 31;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) d[j] = sDI[row][j];
+    double m_prev = 0.0, pv = 1.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        double lc[16];
+        if (j >= 1) {
+#pragma unroll
+            for (int c = j + 1; c < 16; ++c) lc[c] = sC[(j - 1) & 1][c];
+        }
+        if (lane < 16) sC[j & 1][lane] = d[j];
+        asm volatile("" ::: "memory");
+        const double p = lane_f64(d[j], j);
+        const bool ok = p > 0.0;
+        const double rinv = ok ? fast_rcp(p) : 0.0;
+        const double m = d[j] * rinv;
+        if (row == j) pv = d[j];
+        if (j < 15) {
+            const double x = lane_f64(d[j], j + 1);
+            d[j + 1] = fma(-m, x, d[j + 1]);
+        }
+        asm volatile("" ::: "memory");
+        if (j >= 1) {
+#pragma unroll
+            for (int c = j + 1; c < 16; ++c) {
+                d[c] = fma(-m_prev, lc[c], d[c]);
+                asm volatile("" : "+v"(d[c]));
+            }
+        }
+        m_prev = m;
+    }
+    const bool okp = pv > 0.0;
+    if (lane < 16) sC[0][lane] = okp ? rsqrt_full(pv) : 0.0;
+    asm volatile("" ::: "memory");
+    bad = lane < 16 && !okp;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) d[j] *= sC[0][j];
+}
+
+// ---------------------------------------------------------------------------------------------
+// grid = filters, 512 threads.
+// ---------------------------------------------------------------------------------------------
+template <int NTM>
+__global__ __launch_bounds__(512) void k_lm_factor(LmCholArgs a)
+{
+    constexpr int NTILES = tri_tiles(NTM), NW = 8, NS = (NTILES + NW - 1) / NW;
+    __shared__ __attribute__((aligned(16))) double pan[NTM][4][64];      // row panel k of U: tile (k, b) at pan[b], register layout
+    __shared__ double sDI[32][17];
+    __shared__ double sT[16][17];                                        // T = L_kk^-T: sT[i][j] = L_kk^-1 [j][i]
+    __shared__ __attribute__((aligned(16))) double sC[2][16];
+    __shared__ double sR[16 * NTM], sZ[16];
+    __shared__ int sBad;
+    const int bl = blockIdx.x, m = a.m[bl];
+    if (m == 0) return;
+    const int nt = min(NTM, (m + 15) >> 4);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const double* X = a.X + (size_t)bl * a.xs;
+    double* Ug = a.U + (size_t)bl * a.us;
+    double* zg = Ug + (size_t)(NTILES + NTM) * 256;
+    const int ldx = a.ldx;
+    // this wave's tiles: t = wave + 8 s
+    int sa[NS], sb[NS];
+    double4_f T[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        int t = wave + NW * s, ta = 0;
+        if (t >= NTILES) { sa[s] = NTM; sb[s] = NTM; }
+        else {
+            while (t >= NTM - ta) { t -= NTM - ta; ++ta; }
+            sa[s] = ta; sb[s] = ta + t;
+        }
+        // S is symmetric, its LOWER triangle is what every producer fills (the GEMM's lower blocks, k_add_noise): element
+        // (16 a + i, 16 b + j) is read at row 16 b + j of column 16 a + i (16 lanes contiguous), mirrored inside diagonal tiles
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int R1 = 16 * sa[s] + kq + 4 * r, R2 = 16 * sb[s] + l15;
+            T[s][r] = sb[s] < nt ? X[(size_t)max(R1, R2) + (size_t)min(R1, R2) * ldx] : 0.0;
+        }
+    }
+    for (int e = tid; e < 16 * NTM; e += 512) sR[e] = e < 16 * nt ? X[(size_t)a.res_row + (size_t)e * ldx] : 0.0;
+    if (tid == 0) sBad = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < nt; ++k) {
+        // ---- (A) the diagonal tile
+        bool mine = false;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (sa[s] == k && sb[s] == k) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sDI[kq + 4 * r][l15] = T[s][r];
+                mine = true;
+            }
+        }
+        if (mine) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int e = lane + 64 * u; sDI[16 + (e >> 4)][e & 15] = (e >> 4) == (e & 15) ? 1.0 : 0.0; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            double d[16]; bool bad;
+            factor16(sDI, sC, lane, d, bad);
+            if (lane >= 16 && lane < 32) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) sT[lane - 16][j] = d[j];
+            }
+            if (__any(bad) && lane == 0) sBad = 1;
+        }
+        lds_barrier();
+        // ---- (B) row panel k
+        double A[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A[r] = sT[kq + 4 * r][l15];          // A[m = l15][k = kq + 4 r] = L_kk^-1 [l15][kq + 4 r]
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ug[(size_t)(NTILES + k) * 256 + 64 * r + lane] = A[r];
+        }
+        if (wave == NW - 1 && lane < 16) {
+            double z = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) z = fma(sT[j][lane], sR[16 * k + j], z);
+            sZ[lane] = z;
+            zg[16 * k + lane] = z;
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (sa[s] == k && sb[s] > k && sb[s] < nt) {
+                double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[r], T[s][r], acc, 0, 0, 0);
+                T[s] = acc;
+                double* ug = Ug + (size_t)tri_index(NTM, k, sb[s]) * 256 + lane;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pan[sb[s]][r][lane] = acc[r]; ug[64 * r] = acc[r]; }
+            }
+        }
+        lds_barrier();
+        // ---- (C) trailing update
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (sa[s] > k && sb[s] < nt) {
+                double4_f acc = T[s];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pan[sa[s]][r][lane], pan[sb[s]][r][lane], acc, 0, 0, 0);
+                T[s] = acc;
+            }
+        }
+        if (tid < 16 * (nt - k - 1)) {                                   // res_b -= U_kb^T z_k
+            const int b = k + 1 + (tid >> 4), j = tid & 15;
+            double v = sR[16 * b + j];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v = fma(-pan[b][i >> 2][(i & 3) * 16 + j], sZ[i], v);
+            sR[16 * b + j] = v;
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && sBad) atomicOr(&a.status[bl], a.fail_bit);
+}
+
+// ---------------------------------------------------------------------------------------------
+// grid = (16-row blocks of the state / 4, filters), 256 threads: wave w = block 4 blockIdx.x + w.
+// ---------------------------------------------------------------------------------------------
+template <int NTM>
+__global__ __launch_bounds__(256) void k_lm_carry(LmCholArgs a)
+{
+    constexpr int NTILES = tri_tiles(NTM);
+    const int bl = blockIdx.y, m = a.m[bl];
+    if (m == 0) return;
+    const int b = a.b0 + bl, n = a.cv.n[b], ld = a.cv.ldp;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int cb = 4 * blockIdx.x + wave, j = 16 * cb + l15;
+    if (16 * cb >= ld) return;
+    double* dx = a.dx + (size_t)b * ld;
+    if ((a.status[bl] & a.fail_bit) || 16 * cb >= n) {                   // S not positive definite: no update
+        if (kq == 0 && j < ld) dx[j] = 0.0;
+        return;
+    }
+    const int nt = min(NTM, (m + 15) >> 4), ldx = a.ldx;
+    const double* C0 = a.X + (size_t)bl * a.xs + a.mc + j;              // (P H^T)[j][R] at C0[R ldx]
+    double* Y0 = a.Y + (size_t)bl * a.xs + a.mc + j;
+    const double* Ug = a.U + (size_t)bl * a.us + lane;
+    const double* zg = a.U + (size_t)bl * a.us + (size_t)(NTILES + NTM) * 256;
+    double4_f V[NTM];
+    double dxa = 0.0;
+#pragma unroll
+    for (int k = 0; k < NTM; ++k) {
+        if (k < nt) {
+            double4_f acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = C0[(size_t)(16 * k + kq + 4 * r) * ldx];
+#pragma unroll
+            for (int p = 0; p < k; ++p) {
+                const double* ut = Ug + (size_t)tri_index(NTM, p, k) * 256;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-ut[64 * r], V[p][r], acc, 0, 0, 0);
+            }
+            const double* tt = Ug + (size_t)(NTILES + k) * 256;
+            double4_f y = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f64_16x16x4f64(tt[64 * r], acc[r], y, 0, 0, 0);
+            V[k] = y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Y0[(size_t)(16 * k + kq + 4 * r) * ldx] = y[r];
+                dxa = fma(y[r], zg[16 * k + kq + 4 * r], dxa);
+            }
+        }
+    }
+    dxa += __shfl_xor(dxa, 16, WAVE);
+    dxa += __shfl_xor(dxa, 32, WAVE);
+    if (kq == 0 && j < ld) dx[j] = j < n ? dxa : 0.0;
+}
+
+template <int NTM>
+void launch_t(const LmCholArgs& a, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_lm_factor<NTM>), dim3(a.nb), dim3(512), 0, st, a);
+    hipLaunchKernelGGL((k_lm_carry<NTM>), dim3((a.cv.ldp + 63) / 64, a.nb), dim3(256), 0, st, a);
+}
+
+int pick_ntm(int mc)
+{
+    const int t = (mc + 15) / 16;
+    return t <= 4 ? 4 : (t <= 8 ? 8 : (t <= 12 ? 12 : (t <= 14 ? 14 : 16)));
+}
+
+}  // namespace
+
+size_t lm_chol_ws_doubles(int mc)
+{
+    const int ntm = pick_ntm(mc);
+    return (size_t)(tri_tiles(ntm) + ntm) * 256 + (size_t)16 * ntm;
+}
+
+void launch_lm_chol(const LmCholArgs& a, hipStream_t st)
+{
+    switch (pick_ntm(a.mc)) {
+    case 4: launch_t<4>(a, st); break;
+    case 8: launch_t<8>(a, st); break;
+    case 12: launch_t<12>(a, st); break;
+    case 14: launch_t<14>(a, st); break;
+    default: launch_t<16>(a, st); break;
+    }
+}

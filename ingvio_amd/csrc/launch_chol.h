@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include "dev_common.h"
 
 // C(i, j) = sum_k opA(i, k) opB(k, j)  [+ diag_add on i == j], i < M, j < N, k < K; operands are read with bounds checks (any M, N, K).
 //   modeA 0: opA(i, k) = A[i + k lda]   ("row-contiguous": 16 lanes read 16 consecutive i)
@@ -51,4 +52,18 @@ struct CholArgs {
     int batch;
 };
 void launch_chol_sweep(const CholArgs& a, hipStream_t st);
+
+// The same solve for S of up to 256 rows with ONE workgroup per filter and S resident in registers (kernels_lmchol.hip): what
+// hundreds of filters want (the sweep above is one memory round trip per 32 x 32 block and launch).  Reads S (whole, symmetric)
+// and the carried rows P H^T / the residual row from X as the sweep does, writes Y (carried rows only: what k_downdate64 reads)
+// and dx = Y z; a non-positive pivot sets fail_bit in status[filter] and leaves dx = 0.
+struct LmCholArgs {
+    CovView cv; int b0, nb;                      // dx and cv are indexed by the absolute filter b0 + i, everything else by i
+    const double* X; double* Y; size_t xs; int ldx, mc, res_row;
+    double* U; size_t us;                        // scratch: lm_chol_ws_doubles(mc) per filter (factor tiles, z)
+    const int* m; int* status; int fail_bit;
+    double* dx;
+};
+size_t lm_chol_ws_doubles(int mc);
+void launch_lm_chol(const LmCholArgs& a, hipStream_t st);
 int dbg_read_chol(long long* out, int n);
