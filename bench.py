@@ -205,9 +205,9 @@ STAGE_KERNELS = {
     "k_feat_gate3": (("k_feat_gate4",), ("k_feat_gate3",)),              # stereo: gate in difference coordinates (round 3) / first generation, mono
     "k_info_update": (("k_info_solve",), ("k_info_update",)),            # windows up to 11 clones / 12..16
     "restore": (("k_restore_strips",), ("k_restore",)),
-    "k_lm_build": (("k_lm_build", "k_lm_products"),),
+    "k_lm_build": (("k_lm_rows", "k_lm_front"), ("k_lm_build", "k_lm_products")),        # fused front (round 3) / compacting build + products
     "k_lm_gemm": (("k_gemm",),),
-    "k_lm_chol": (("k_chol_first", "k_chol_step", "k_chol_carried", "k_lm_finish"),),
+    "k_lm_chol": (("k_lm_factor", "k_lm_carry"), ("k_chol_first", "k_chol_step", "k_chol_carried", "k_lm_finish")),      # register-resident solve (round 3) / sweep out of L2
     "k_downdate": (("k_downdate64",), ("k_downdate",)),
 }
 STAGE_KERNELS_BIG = {                                                      # windows of 17..36 clones (kernels_bigwin.hip)

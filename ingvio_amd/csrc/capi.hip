@@ -86,7 +86,7 @@ struct ingvio_ctx {
     // does not fit in LDS.  Rows live in Hd [m_cap][n_ld] per filter, the sweep in X / Y [ldx][m_cap].
     struct DenseWs {
         double *Hd = nullptr, *X = nullptr, *Y = nullptr, *Tb = nullptr, *U = nullptr, *noise = nullptr, *noiseB = nullptr;      // U: factor tiles of the register-resident solve (m_cap <= 256); noise: one filter's R (ingvio_ekf_update); noiseB [B][m_cap]: scalar / diagonal R per filter (batch)
-        int *m = nullptr, *cidx = nullptr;
+        int *m = nullptr, *cidx = nullptr, *rowmap = nullptr;      // rowmap [B][m_cap]: the landmark front's accepted rows (k_lm_front)
         int m_cap = 0, n_ld = 0, n32 = 0, ldx = 0;
         size_t hstride = 0, xstride = 0, tstride = 0, ustride = 0;
     } dw;
@@ -767,7 +767,8 @@ int ingvio_append_independent(ingvio_ctx* c, int b0, int nb, int size, const dou
 }
 
 static int dense_ws_alloc(ingvio_ctx* c, int m_need);
-static int run_dense_update(ingvio_ctx* c, int b0, int nb, double var, int r_kind, const double* d_noise, int nstride, double* d_dx, bool products_done = false);
+static int run_dense_update(ingvio_ctx* c, int b0, int nb, double var, int r_kind, const double* d_noise, int nstride, double* d_dx, bool products_done = false,
+                            const int* rowmap = nullptr, const int* marg_idx = nullptr, int marg_size = 0, bool* marg_fused = nullptr);
 #define DENSE_M_MAX 1024      // rows of one generic update through the dense-H route (S factorised out of HBM, kernels_chol.hip)
 
 // ingvio_ekf_update for row counts whose S does not fit in LDS (or beyond the context's m_max): the host scatters the columns
@@ -1525,18 +1526,21 @@ static int dense_ws_alloc(ingvio_ctx* c, int m_need)
     for (double** p : { &w.Hd, &w.X, &w.Y, &w.Tb, &w.U, &w.noise, &w.noiseB }) { if (*p) hipFree(*p); *p = nullptr; }
     if (w.m) { hipFree(w.m); w.m = nullptr; }
     if (w.cidx) { hipFree(w.cidx); w.cidx = nullptr; }
+    if (w.rowmap) { hipFree(w.rowmap); w.rowmap = nullptr; }
     const int B = c->d.batch;
     w.m_cap = m_cap; w.n32 = (c->d.n_max + 31) / 32 * 32; w.n_ld = w.n32; w.ldx = m_cap + w.n32 + 32;
     w.hstride = std::max((size_t)m_cap * w.n_ld, (size_t)LM_MAX * 100);      // also holds the landmark path's compact blocks
     w.xstride = (size_t)w.ldx * m_cap; w.tstride = (size_t)(m_cap / 32) * 1024 + (size_t)m_cap;
     w.ustride = m_cap <= 256 ? lm_chol_ws_doubles(m_cap) : 0;
     int rc = dalloc(c, &w.Hd, (size_t)B * w.hstride) | dalloc(c, &w.X, (size_t)B * w.xstride) | dalloc(c, &w.Y, (size_t)B * w.xstride)
-           | dalloc(c, &w.Tb, (size_t)B * w.tstride) | (w.ustride ? dalloc(c, &w.U, (size_t)B * w.ustride) : 0) | dalloc(c, &w.m, (size_t)B) | dalloc(c, &w.noise, (size_t)m_cap * m_cap) | dalloc(c, &w.cidx, (size_t)B * LM_MAX * 4) | dalloc(c, &w.noiseB, (size_t)B * m_cap);
+           | dalloc(c, &w.Tb, (size_t)B * w.tstride) | (w.ustride ? dalloc(c, &w.U, (size_t)B * w.ustride) : 0) | dalloc(c, &w.m, (size_t)B) | dalloc(c, &w.noise, (size_t)m_cap * m_cap) | dalloc(c, &w.cidx, (size_t)B * LM_MAX * 4) | dalloc(c, &w.noiseB, (size_t)B * m_cap)
+           | dalloc(c, &w.rowmap, (size_t)B * m_cap);
     return rc ? INGVIO_E_HIP : 0;
 }
 
 // noise: r_kind < 0 -> scalar variance `var` on the whole diagonal (the GEMM's epilogue); else d_noise (stride nstride) through k_add_noise
-static int run_dense_update(ingvio_ctx* c, int b0, int nb, double var, int r_kind, const double* d_noise, int nstride, double* d_dx, bool products_done)
+static int run_dense_update(ingvio_ctx* c, int b0, int nb, double var, int r_kind, const double* d_noise, int nstride, double* d_dx, bool products_done,
+                            const int* rowmap, const int* marg_idx, int marg_size, bool* marg_fused)
 {
     auto& w = c->dw;
     const int mc = w.m_cap, n_cap = c->d.n_max, B = c->d.batch;
@@ -1569,6 +1573,7 @@ static int run_dense_update(ingvio_ctx* c, int b0, int nb, double var, int r_kin
         LmCholArgs a = {};
         a.cv = view(c); a.b0 = b0; a.nb = nb; a.X = X; a.Y = Y; a.xs = w.xstride; a.ldx = w.ldx; a.mc = mc; a.res_row = mc + w.n32;
         a.U = w.U + (size_t)b0 * w.ustride; a.us = w.ustride; a.m = act; a.status = c->d_status + b0; a.fail_bit = 4; a.dx = d_dx;
+        a.rowmap = rowmap; a.rm_stride = mc;
         launch_lm_chol(a, c->st);
     } else {
         ProfScope p(c, PF_LM_CHOL);
@@ -1583,16 +1588,21 @@ static int run_dense_update(ingvio_ctx* c, int b0, int nb, double var, int r_kin
         EkfLaunch E;
         memset(&E, 0, sizeof E);
         E.cv = view(c); E.b0 = b0; E.nb = nb; E.Y = Y + mc; E.m = w.m + b0; E.status = c->d_status; E.m_cap = mc;
-        launch_downdate(E, n_cap, c->st, nullptr, w.ldx, w.xstride);
+        const bool fused = launch_downdate(E, n_cap, c->st, nullptr, w.ldx, w.xstride, marg_idx, marg_size);
+        if (marg_fused) *marg_fused = fused;
     }
     c->mut_seq++;
     return last_launch(c);
 }
 
-static int landmark_update_launch(ingvio_ctx* c, int b0, int nb)
+// marg_idx / marg_size (optional): the marginalisation that follows the update in the frame, fused into the write-back where the
+// downdate kernel supports it (*marg_fused; the caller then only flips the halves: launch_post_marg)
+static int landmark_update_launch(ingvio_ctx* c, int b0, int nb, const int* marg_idx = nullptr, int marg_size = 0, bool* marg_fused = nullptr)
 {
+    if (marg_fused) *marg_fused = false;
     auto& w = c->dw;
     auto& s = c->lm;
+    const int* rowmap = nullptr;
     {
         ProfScope p(c, PF_LM_BUILD);
         LmBuild L;
@@ -1604,9 +1614,15 @@ static int landmark_update_launch(ingvio_ctx* c, int b0, int nb)
         L.X = w.X + (size_t)b0 * w.xstride; L.xstride = w.xstride; L.ldx = w.ldx; L.res_row = w.m_cap + w.n32;
         L.gamma = s.gamma + (size_t)b0 * LM_MAX; L.accept = s.accept + (size_t)b0 * LM_MAX; L.m_out = w.m + b0; L.dx = s.dx;
         L.cidx = w.cidx + (size_t)b0 * LM_MAX * 4; L.n_rows = w.n32;
-        launch_lm_build(L, c->st);
+        // states of up to 256 rows with the register-resident solve: rows, products and gate in one kernel (k_lm_front), the accepted
+        // rows handed on as a row map; otherwise k_lm_build + k_lm_products write the compacted system
+        static const bool split_front = getenv("INGVIO_LM_FRONT") && !strcmp(getenv("INGVIO_LM_FRONT"), "split");
+        static const bool sweep_only = getenv("INGVIO_LM_SOLVE") && !strcmp(getenv("INGVIO_LM_SOLVE"), "sweep");
+        if (w.U && !split_front && !sweep_only && launch_lm_front(L, s.l_hi, w.rowmap + (size_t)b0 * w.m_cap, c->st))
+            rowmap = w.rowmap + (size_t)b0 * w.m_cap;
+        else launch_lm_build(L, c->st);
     }
-    return run_dense_update(c, b0, nb, s.op.var, -1, nullptr, 0, s.dx, true);
+    return run_dense_update(c, b0, nb, s.op.var, -1, nullptr, 0, s.dx, true, rowmap, marg_idx, marg_size, marg_fused);
 }
 
 int ingvio_landmark_stage(ingvio_ctx* c, int b0, int nb, const ingvio_landmark_frame* fr, const ingvio_landmark_opts* o)
@@ -1952,10 +1968,11 @@ static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
                   : (c->method == 1 ? run_msckf_factored(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used)
                                     : run_msckf(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used));
     if (rc) return rc;
-    if (with_lm) { rc = landmark_update_launch(c, 0, B); if (rc) return rc; }
+    bool lm_fused = false;
+    if (with_lm) { rc = landmark_update_launch(c, 0, B, c->d_idx, 6, &lm_fused); if (rc) return rc; }
     {
         ProfScope p(c, PF_MARG);
-        if (fuse) launch_post_marg(view(c), 0, B, c->d_idx, 6, c->st);
+        if (fuse || lm_fused) launch_post_marg(view(c), 0, B, c->d_idx, 6, c->st);
         else launch_marginalize(view(c), 0, B, c->d.n_max, c->d_idx, 6, c->st);
     }
     // a landmark stage belongs to ONE frame: unless the caller replays the same prior (restore_prior, the bench and the parity tests)
@@ -2122,8 +2139,10 @@ int ingvio_debug_read(ingvio_ctx* c, long long* out, int n)
     if (dbg_read_factored(a, 64) || dbg_read_cov(bq, 64) || dbg_read_bigwin(cq, 64) || dbg_read_solve(sq, 64)) return INGVIO_E_HIP;
     long long hq[64];
     if (dbg_read_chol(hq, 64)) return INGVIO_E_HIP;
+    long long lq[64];
+    if (dbg_read_lmbatch(lq, 64)) return INGVIO_E_HIP;
     if (const char* e = getenv("INGVIO_DBG_TU")) {                     // debugging: all slots of one translation unit
-        const long long* src = e[0] == 'b' ? cq : (e[0] == 'c' ? hq : (e[0] == 's' ? sq : a));
+        const long long* src = e[0] == 'b' ? cq : (e[0] == 'c' ? hq : (e[0] == 's' ? sq : (e[0] == 'l' ? lq : a)));
         for (int i = 0; i < n; ++i) out[i] = src[i];
         return INGVIO_OK;
     }

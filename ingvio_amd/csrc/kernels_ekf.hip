@@ -333,12 +333,19 @@ int launch_rows_gate(const EkfLaunch& L, const RowsGateIn& in, double thr, doubl
 // every element of Y is read once per block row/column pair instead of once per 16 x 16 tile (4x less L2 traffic).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_downdate64(CovView cv, int b0, const double* __restrict__ Yall, const int* __restrict__ m_all,
-                                                    size_t ystride, int* __restrict__ status, int ldy)
+                                                    size_t ystride, int* __restrict__ status, int ldy, const int* __restrict__ marg_idx, int marg_size)
 {
     __shared__ Block64Lds sAB;
     __shared__ double sV[4][32][33];
     const int bl = blockIdx.y, b = b0 + bl, m = m_all[bl];
-    if (m == 0 || (status[b] & 4)) return;                               // bit 4: S not positive definite, the state stays untouched
+    // fused marginalisation (marg_idx[bl] >= 0): the updated covariance is written into the OTHER ping-pong half without the
+    // marg_size rows / columns at marg_idx (k_post_marg flips the halves afterwards) - the frame's landmark update is followed
+    // by the marginalisation of the oldest clone (IngvioFilter.cpp:296-322), a full extra read + write of every covariance when
+    // it runs as a kernel of its own.  Then a filter without rows (or with a failed solve) is still copied.
+    const int midx = marg_idx ? marg_idx[bl] : -1;
+    const bool fuse = midx >= 0;
+    const bool upd = m > 0 && !(status[b] & 4);                          // bit 4: S not positive definite, the state stays untouched
+    if (!upd && !fuse) return;
     const int n = cv.n[b], ld = cv.ldp;
     int t = blockIdx.x, bi = 0;
     while (t >= bi + 1) { t -= bi + 1; ++bi; }
@@ -347,24 +354,28 @@ __global__ __launch_bounds__(256) void k_downdate64(CovView cv, int b0, const do
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wi = wave >> 1, wj = wave & 1;
     const bool quad_on = !(bi == bj && wj > wi);                         // the upper quadrant of a diagonal block comes from the mirror
-    double* P = cov_ptr(cv, b);
+    const double* P = cov_ptr(cv, b);
+    double* D = fuse ? cov_alt_ptr(cv, b) : cov_ptr(cv, b);
     const double* Y = Yall + (size_t)bl * ystride;
     b64_d4 c[4];
-    block64_mma(sAB, (m + 15) & ~15,
+    block64_mma(sAB, upd ? (m + 15) & ~15 : 0,
                 [&](int r, int k) { return k < m ? Y[(size_t)min(64 * bi + r, n - 1) + (size_t)k * ldy] : 0.0; },
                 [&](int r, int k) { return k < m ? Y[(size_t)min(64 * bj + r, n - 1) + (size_t)k * ldy] : 0.0; }, quad_on, c);
     if (!quad_on) return;                                                // no barrier below
     // this wave's 32 x 32 quadrant through LDS, then row-fast read-modify-write of P and its mirror
     block64_to_lds(c, sV[wave]);
     const int r0 = 64 * bi + 32 * wi, q0c = 64 * bj + 32 * wj;
+    const int mhi = fuse ? midx + marg_size : 0;
     for (int e = lane; e < 1024; e += 64) {
         const int rr = e & 31, cc = e >> 5;
         const int row = r0 + rr, col = q0c + cc;
         if (row < n && col < n && row >= col) {
             const double v = P[(size_t)row + (size_t)col * ld] - sV[wave][rr][cc];
-            P[(size_t)row + (size_t)col * ld] = v;
             sV[wave][rr][cc] = v;
             if (row == col && v < 0.0) atomicOr(&status[b], 2);
+            if (!fuse) D[(size_t)row + (size_t)col * ld] = v;
+            else if ((row < midx || row >= mhi) && (col < midx || col >= mhi))
+                D[(size_t)(row < midx ? row : row - marg_size) + (size_t)(col < midx ? col : col - marg_size) * ld] = v;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -372,21 +383,26 @@ __global__ __launch_bounds__(256) void k_downdate64(CovView cv, int b0, const do
     for (int e = lane; e < 1024; e += 64) {
         const int cc = e & 31, rr = e >> 5;
         const int row = r0 + rr, col = q0c + cc;
-        if (row < n && col < n && row > col) P[(size_t)col + (size_t)row * ld] = sV[wave][rr][cc];
+        if (row < n && col < n && row > col) {
+            if (!fuse) D[(size_t)col + (size_t)row * ld] = sV[wave][rr][cc];
+            else if ((row < midx || row >= mhi) && (col < midx || col >= mhi))
+                D[(size_t)(col < midx ? col : col - marg_size) + (size_t)(row < midx ? row : row - marg_size) * ld] = sV[wave][rr][cc];
+        }
     }
 }
 
-void launch_downdate(const EkfLaunch& L, int n_cap, hipStream_t st, const double* Yb, int ldy, size_t ystride)
+bool launch_downdate(const EkfLaunch& L, int n_cap, hipStream_t st, const double* Yb, int ldy, size_t ystride, const int* marg_idx, int marg_size)
 {
     const int nt = (n_cap + 15) / 16;
     const int tiles = nt * (nt + 1) / 2;
     if (ldy && L.m_cap >= 64 && !Yb) {                                     // the dense-H route with many rows: the LDS-blocked variant
         const int nb64 = (n_cap + 63) / 64;
         hipLaunchKernelGGL(k_downdate64, dim3(nb64 * (nb64 + 1) / 2, L.nb), dim3(256), 0, st, L.cv, L.b0, L.Y, L.m,
-                           ystride ? ystride : (size_t)L.ystride, L.status, ldy ? ldy : L.cv.ldp);
-        return;
+                           ystride ? ystride : (size_t)L.ystride, L.status, ldy ? ldy : L.cv.ldp, marg_idx, marg_size);
+        return marg_idx != nullptr;
     }
     hipLaunchKernelGGL(k_downdate, dim3((tiles + 3) / 4, L.nb), dim3(256), 0, st, L.cv, L.b0, L.Y, Yb ? Yb : L.Y, L.m, ystride ? ystride : (size_t)L.ystride, L.status, ldy ? ldy : L.cv.ldp);
+    return false;
 }
 
 void launch_gamma_multi(CovView cv, int b, int nblk, const double* dbuf, const int* ibuf, const int* desc, const double* noise,

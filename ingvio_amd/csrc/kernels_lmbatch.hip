@@ -52,8 +52,11 @@ __device__ __forceinline__ void m23_mul(const double* A, const double* B, double
 }
 
 // rows of one landmark: Hj [4][24] row-major = [epose 9 | ext 6 | anchor 6 | pf 3], res [4]; returns rows (2 mono / 4 stereo)
+// COMPACT: Hj [4][21], the extended pose's three velocity columns (structurally zero) left out: [theta 3 | p 3 | ext 6 | anchor 6 | pf 3]
+template <bool COMPACT = false>
 __device__ __forceinline__ void lm_rows(const double* pose, const double* pf, const double* uv, const LmOpts& op, double* Hj, double* res)   // Hj, res: LDS
 {
+    constexpr int RS = COMPACT ? 21 : 24, O_EXT = COMPACT ? 6 : 9, O_ANC = COMPACT ? 12 : 15, O_PF = COMPACT ? 18 : 21;
     const double *R_i2w = pose, *p_i2w = pose + 9, *R_cl2i = pose + 12, *p_c2i = pose + 21;
     double RiT[9], RcT[9], Rw2cl[9], d[3], pf_i[3], d2[3], pf_cl[3], Sw[9], Si[9];
     m3_T(R_i2w, RiT); m3_T(R_cl2i, RcT);
@@ -66,7 +69,7 @@ __device__ __forceinline__ void lm_rows(const double* pose, const double* pf, co
     m3_mul(RcT, RiT, Rw2cl);
     skew3(pf, Sw); skew3(pf_i, Si);
 #pragma unroll 4
-    for (int e = 0; e < 96; ++e) Hj[e] = 0.0;
+    for (int e = 0; e < 4 * RS; ++e) Hj[e] = 0.0;
     res[0] = res[1] = res[2] = res[3] = 0.0;
     const int eyes = op.stereo ? 2 : 1;
 #pragma unroll
@@ -93,11 +96,11 @@ __device__ __forceinline__ void lm_rows(const double* pose, const double* pf, co
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    double* h = Hj + 24 * (2 * eye + r);
+                    double* h = Hj + RS * (2 * eye + r);
                     h[c] = B[3 * r + c]; h[3 + c] = -A[3 * r + c];
-                    h[9 + c] = D[3 * r + c]; h[12 + c] = -Cc[3 * r + c];
-                    h[15 + c] = eye == 0 ? -B[3 * r + c] : -E[3 * r + c];
-                    h[21 + c] = A[3 * r + c];
+                    h[O_EXT + c] = D[3 * r + c]; h[O_EXT + 3 + c] = -Cc[3 * r + c];
+                    h[O_ANC + c] = eye == 0 ? -B[3 * r + c] : -E[3 * r + c];
+                    h[O_PF + c] = A[3 * r + c];
                 }
         }
     }
@@ -293,6 +296,255 @@ __global__ __launch_bounds__(256) void k_lm_products(CovView cv, int b0, const d
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_lm_rows + k_lm_front: k_lm_build + k_lm_products for states of up to 256 rows.
+//   k_lm_rows   one lane per landmark: the rows of every TRACKED landmark as compact 4 x 21 blocks (+ residual) and the list of
+//               candidates (landmark, anchor column, landmark column) in global memory.  A kernel of its own because its register
+//               appetite (the rotation algebra) would cap the occupancy of the product loops - and because rows that the NEXT kernel
+//               only reads can be fetched there with SCALAR loads: a row of H is the same for every lane of a wave.
+//   k_lm_front  one workgroup per filter, 512 threads, in chunks of 4 landmarks (16 columns):
+//                 A  thread = state row r: the chunk's columns of P H^T - the 12 shared columns of P (pose, extrinsics) sit in
+//                    registers for the whole kernel, 9 loads per landmark, the entries of H arrive in SGPRs
+//                 B  thread = stacked row: the chunk's columns of S = H (P H^T) + s^2 I, lower triangle, from the chunk's P H^T in
+//                    LDS and the thread's own row of H
+//               then the chi^2 gate per landmark on the DIAGONAL BLOCKS of that S (S_j = H_j P H_j^T + s^2 I is what
+//               Update.cpp:81-102 tests; the 24 x 24 gather per landmark of k_lm_build is gone) and the row map of the accepted
+//               landmarks: k_lm_factor / k_lm_carry (kernels_lmchol.hip) pick their rows of S and P H^T through it.
+// ---------------------------------------------------------------------------------------------
+#define LMF_NT 512
+#ifndef LMF_WPE
+#define LMF_WPE 4                                                        // two workgroups per CU
+#endif
+#define LMF_HS 90                                                        // 4 x 21 row entries, 4 residuals, pad (even: 16-byte rows)
+#define LMF_YS 18                                                        // LDS row stride of the chunk's columns of P H^T (16-byte aligned rows)
+__global__ __launch_bounds__(64) void k_lm_rows(CovView cv, LmView lv, LmOpts op, int b0, int lcap, double* __restrict__ Hc_all, size_t hstride,
+                                                int* __restrict__ cand_all, double* __restrict__ gamma_out, int* __restrict__ accept_out)
+{
+    const int bl = blockIdx.x, b = b0 + bl, lane = threadIdx.x;
+    const int L = min(min(lv.n_lm[b], LM_MAX), lcap), n = cv.n[b];
+    double* Hc = Hc_all + (size_t)bl * hstride;
+    int* cand = cand_all + (size_t)bl * LM_MAX * 4;                      // [a]: landmark, anchor column, landmark column; cand[3] = candidates
+    const int l = lane;
+    const size_t o = (size_t)b * lv.lmax + l;
+    int il = -1, ia = -1;
+    bool on = false;
+    if (l < L) {
+        il = lv.lm_idx[o]; ia = lv.anchor_idx[o];
+        on = lv.tracked[o] != 0 && il >= 0 && il + 3 <= n && ia >= 0 && ia + 6 <= n;
+        if (!on) { gamma_out[(size_t)bl * LM_MAX + l] = -1.0; accept_out[(size_t)bl * LM_MAX + l] = 0; }
+    }
+    const unsigned long long mask = __ballot(on);
+    const int a = __popcll(mask & ((1ull << lane) - 1ull));
+    if (on) {
+        double hj[88];
+        lm_rows<true>(lv.pose + (size_t)b * 24, lv.pf + 3 * o, lv.uv + 4 * o, op, hj, hj + 84);
+#pragma unroll
+        for (int e = 0; e < 88; ++e) Hc[(size_t)a * LMF_HS + e] = hj[e];
+        cand[4 * a] = l; cand[4 * a + 1] = ia; cand[4 * a + 2] = il;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (lane == 0) cand[3] = __popcll(mask);                             // (slot 3 of candidate 0 is unused)
+}
+
+typedef double double4_l __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(LMF_NT) __attribute__((amdgpu_waves_per_eu(LMF_WPE, LMF_WPE)))
+void k_lm_front(CovView cv, LmView lv, LmOpts op, int b0, int lcap, int m_cap, int n_rows, const double* __restrict__ Hc_all, size_t hstride,
+                const int* __restrict__ cand_all, double* __restrict__ X_all, size_t xstride, int ldx, int res_row, double* __restrict__ gamma_out,
+                int* __restrict__ accept_out, int* __restrict__ m_out, double* __restrict__ dx_all, int* __restrict__ rowmap_all)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];        // sY [256][LMF_YS] | sH [lcap][LMF_HS]
+    __shared__ int sAcc[LM_MAX], sIa[LM_MAX], sIl[LM_MAX], sM;
+    double* sY = smem;
+    double* sH = smem + 256 * LMF_YS;                                    // candidate a: entry c of row q at [a][4 c + q], residuals at [a][84 + q]
+    const int bl = blockIdx.x, b = b0 + bl, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int kq = lane >> 4, l15 = lane & 15;
+    const int n = cv.n[b], ld = cv.ldp;
+    const int per = op.stereo ? 4 : 2;
+    const double* P = cov_ptr(cv, b);
+    const int ie = lv.idx[2 * b], ix = lv.idx[2 * b + 1];
+    double* X = X_all + (size_t)bl * xstride;
+    const double* __restrict__ Hc = Hc_all + (size_t)bl * hstride;
+    const int* __restrict__ cand = cand_all + (size_t)bl * LM_MAX * 4;
+    const int La = cand[3], M0 = per * La;
+    dbg_stamp(0);
+    if (La == 0) {
+        if (tid == 0) m_out[bl] = 0;
+        double* dx = dx_all + (size_t)b * ld;
+        for (int q = tid; q < ld; q += LMF_NT) dx[q] = 0.0;
+        for (int R = tid; R < m_cap; R += LMF_NT) rowmap_all[(size_t)bl * m_cap + R] = -1;
+        return;
+    }
+    for (int e = tid; e < La * LMF_HS; e += LMF_NT) {                    // k_lm_rows wrote [q][21]: transposed on the way in
+        const int a = e / LMF_HS, i = e - a * LMF_HS;
+        sH[a * LMF_HS + (i < 84 ? 4 * (i % 21) + i / 21 : i)] = Hc[e];
+    }
+    if (tid < La) { sIa[tid] = cand[4 * tid + 1]; sIl[tid] = cand[4 * tid + 2]; }
+    // ---- phase A on the matrix cores: (P H^T)^T chunk [16 columns] x [16 state rows] = Hblk [16 x 48] Pg^T [48 x 16], the 48
+    // gathered columns of P being 12 shared ones (pose theta / p, extrinsics; k-steps 0..2) and 9 per landmark of the chunk
+    // (anchor 6, position 3; k-step 3 + c takes entry c of ALL FOUR landmarks, lane group kq = landmark slot) - Hblk is
+    // block-sparse there.  Wave w owns the row blocks 2 w, 2 w + 1.  B operand: lane (kq, l15) supplies
+    // P[16 blk + l15][gcol(4 s + kq)] for k-step s; the three steps of the shared columns stay in registers for the whole kernel.
+    int rowA[2], rrA[2];
+    double bsh[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        rowA[i] = 16 * (2 * wave + i) + l15;
+        rrA[i] = rowA[i] < n ? rowA[i] : 0;                              // rows beyond the state: loads from row 0, results zeroed
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+            const int k = 4 * st + kq;
+            bsh[i][st] = P[(size_t)rrA[i] + (size_t)(k < 6 ? ie + k : ix + k - 6) * ld];
+        }
+    }
+    const int slot_m = l15 >> 2, q_m = l15 & 3;                          // the lane's column of the chunk as A operand: landmark slot, row
+    // phase B: thread (slot = wave < 4, a2 = lane): the 4 x 4 block S[rows of candidate a2][columns of candidate 4 g + slot]
+    const int a2 = lane;
+    const bool rowB = wave < 4 && a2 < La;
+    __syncthreads();
+    const int c2a = rowB ? sIa[a2] : 0, c2l = rowB ? sIl[a2] : 0;
+    dbg_stamp(1);
+    double* Yc = X + m_cap;                                              // carried rows: P H^T
+    const int nch = (La + 3) >> 2;
+    double bv[2][9];
+    auto fetch_b = [&](int g) {
+        const int ak = min(4 * g + kq, La - 1), cia = sIa[ak], cil = sIl[ak];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int c = 0; c < 9; ++c) bv[i][c] = P[(size_t)rrA[i] + (size_t)(c < 6 ? cia + c : cil + c - 6) * ld];
+    };
+#pragma unroll 1
+    for (int g = 0; g < nch; ++g) {
+        // ---- A  (fetching chunk g + 1 under phase B was tried: the conditional stores that follow the loads in program order
+        //          make the wait for them a full drain, s_waitcnt vmcnt(0) - 0.19 ms against 0.16)
+        {
+            fetch_b(g);
+            const int a_m = 4 * g + slot_m;
+            const bool col_on = a_m < La && q_m < per;
+            const double* hm = sH + (size_t)(col_on ? a_m : 0) * LMF_HS + q_m;
+            double af[12];
+#pragma unroll
+            for (int st = 0; st < 3; ++st) af[st] = col_on ? hm[4 * (4 * st + kq)] : 0.0;
+            const bool own = col_on && slot_m == kq;
+#pragma unroll
+            for (int st = 3; st < 12; ++st) af[st] = own ? hm[4 * (9 + st)] : 0.0;
+            double4_l accs[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                double4_l acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                for (int st = 0; st < 3; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[st], bsh[i][st], acc, 0, 0, 0);
+#pragma unroll
+                for (int st = 3; st < 12; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[st], bv[i][st - 3], acc, 0, 0, 0);
+                accs[i] = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const double4_l acc = accs[i];
+                // acc[r] = (P H^T)[row rowA][column 4 r + kq of the chunk]: landmark slot r, row kq
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double y = rowA[i] < n ? acc[r] : 0.0;
+                    const int a = 4 * g + r;
+                    if (a < La && kq < per && rowA[i] < n_rows) Yc[(size_t)rowA[i] + (size_t)(per * a + kq) * ldx] = y;      // the carried part has n_rows (n32) rows
+                    sY[(size_t)rowA[i] * LMF_YS + 4 * r + kq] = y;
+                }
+            }
+        }
+        lds_barrier();
+        if (g == 0) dbg_stamp(2);
+        // ---- B (lower triangle: the row's landmark is not before the column's)
+        {
+            const int ac = 4 * g + wave;
+            if (rowB && ac < La && a2 >= ac) {
+                double s[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s[i][j] = 0.0;
+                const double* hrow = sH + (size_t)a2 * LMF_HS;
+#pragma unroll
+                for (int c = 0; c < 21; ++c) {
+                    const int row = c < 6 ? ie + c : (c < 12 ? ix + c - 6 : (c < 18 ? c2a + c - 12 : c2l + c - 18));
+                    const double2 v0 = *reinterpret_cast<const double2*>(&sY[(size_t)row * LMF_YS + 4 * wave]);
+                    const double2 v1 = *reinterpret_cast<const double2*>(&sY[(size_t)row * LMF_YS + 4 * wave + 2]);
+                    const double2 h0 = *reinterpret_cast<const double2*>(&hrow[4 * c]);
+                    const double2 h1 = *reinterpret_cast<const double2*>(&hrow[4 * c + 2]);
+                    const double hv[4] = { h0.x, h0.y, h1.x, h1.y }, vv[4] = { v0.x, v0.y, v1.x, v1.y };
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            s[i][j] = fma(hv[i], vv[j], s[i][j]);
+                            asm volatile("" : "+v"(s[i][j]));            // pinned: left alone, the scheduler runs one accumulator's 21 steps at a
+                        }                                                // time, every operand of the block live (spills)
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (i < per && j < per) X[(size_t)(per * a2 + i) + (size_t)(per * ac + j) * ldx] = s[i][j] + ((a2 == ac && i == j) ? op.var : 0.0);
+            }
+        }
+        lds_barrier();
+        if (g == 0) dbg_stamp(3);
+    }
+    dbg_stamp(4);
+    __syncthreads();                                                     // the diagonal blocks of S are visible to the gate
+    // ---- the gate: gamma = res^T S_j^-1 res through the Cholesky factor of the per x per diagonal block
+    if (tid < La) {
+        const int a = tid, l = cand[4 * a];
+        const double* h = sH + (size_t)a * LMF_HS;
+        double Lc[10], z[4], g = 0.0;
+        bool ok = true;
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j, ++t) {
+                if (i < per) {
+                    double v = X[(size_t)(per * a + i) + (size_t)(per * a + j) * ldx];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) v -= Lc[i * (i + 1) / 2 + k] * Lc[j * (j + 1) / 2 + k];
+                    if (i == j) { ok = ok && v > 0.0; Lc[t] = sqrt(v); } else Lc[t] = v / Lc[j * (j + 1) / 2 + j];
+                } else Lc[t] = i == j ? 1.0 : 0.0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double v = i < per ? h[84 + i] : 0.0;
+#pragma unroll
+            for (int k = 0; k < i; ++k) v -= Lc[i * (i + 1) / 2 + k] * z[k];
+            z[i] = v / Lc[i * (i + 1) / 2 + i];
+            g += z[i] * z[i];
+        }
+        const bool acc = ok && g < op.chi2_thr;                          // Update.cpp:98-100 with dof = rows
+        sAcc[a] = acc ? 1 : 0;
+        gamma_out[(size_t)bl * LM_MAX + l] = g;
+        accept_out[(size_t)bl * LM_MAX + l] = acc ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (q < per) X[(size_t)res_row + (size_t)(per * a + q) * ldx] = h[84 + q];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const bool acc = lane < La && sAcc[lane] != 0;
+        const unsigned long long mask = __ballot(acc);
+        const int pos = __popcll(mask & ((1ull << lane) - 1ull)), m = per * __popcll(mask);
+        int* rowmap = rowmap_all + (size_t)bl * m_cap;
+        if (acc) for (int q = 0; q < per; ++q) rowmap[per * pos + q] = per * lane + q;
+        for (int R = m + lane; R < m_cap; R += 64) rowmap[R] = -1;
+        if (lane == 0) { m_out[bl] = m; sM = m; }
+    }
+    __syncthreads();
+    if (sM == 0) {
+        double* dx = dx_all + (size_t)b * ld;
+        for (int q = tid; q < ld; q += LMF_NT) dx[q] = 0.0;
+    }
+    dbg_stamp(5);
+    (void)M0;
+}
+
 // dx = Y z (rows < n), Y = carried rows [y_row0, y_row0 + n) of the sweep's output, z = row z_row
 __global__ __launch_bounds__(256) void k_lm_finish(CovView cv, int b0, const double* __restrict__ Y_all, size_t ystride, int ldy, int y_row0,
                                                    int z_row, const int* __restrict__ m_all, double* __restrict__ dx_all,
@@ -337,6 +589,8 @@ __global__ __launch_bounds__(256) void k_add_noise(double* __restrict__ X_all, s
 
 }  // namespace
 
+int dbg_read_lmbatch(long long* out, int n) { return dbg_read_local(out, n); }
+
 void launch_lm_build(const LmBuild& L, hipStream_t st)
 {
     hipLaunchKernelGGL(k_lm_build, dim3(L.nb), dim3(LMB_NT), 0, st, L.cv, L.lv, L.op, L.b0, L.Hd, L.hstride, L.n_ld, L.m_cap, L.X, L.xstride,
@@ -348,6 +602,19 @@ void launch_lm_build(const LmBuild& L, hipStream_t st)
     if (use_lds && lds > attr) { hipFuncSetAttribute((const void*)k_lm_products, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; }
     hipLaunchKernelGGL(k_lm_products, dim3((L.m_cap + per4 - 1) / per4, L.nb), dim3(256), use_lds ? lds : 0, st, L.cv, L.b0, L.Hd, L.hstride, L.cidx, L.m_out, L.op.stereo ? 4 : 2, L.op.var,
                        L.X, L.xstride, L.ldx, L.m_cap, L.n_rows, use_lds);
+}
+
+// the fused front (states of up to 256 rows); returns false when the shape does not fit (the caller falls back to launch_lm_build)
+bool launch_lm_front(const LmBuild& L, int lcap, int* rowmap, hipStream_t st)
+{
+    if (L.n_rows > 256 || lcap > LM_MAX || (L.op.stereo ? 4 : 2) * lcap > L.m_cap || L.hstride < (size_t)LM_MAX * LMF_HS) return false;
+    hipLaunchKernelGGL(k_lm_rows, dim3(L.nb), dim3(64), 0, st, L.cv, L.lv, L.op, L.b0, lcap, L.Hd, L.hstride, L.cidx, L.gamma, L.accept);
+    const size_t lds = sizeof(double) * ((size_t)256 * LMF_YS + (size_t)lcap * LMF_HS);
+    static size_t attr = 0;
+    if (lds > attr) { hipFuncSetAttribute((const void*)k_lm_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; }
+    hipLaunchKernelGGL(k_lm_front, dim3(L.nb), dim3(LMF_NT), lds, st, L.cv, L.lv, L.op, L.b0, lcap, L.m_cap, L.n_rows, L.Hd, L.hstride, L.cidx, L.X, L.xstride,
+                       L.ldx, L.res_row, L.gamma, L.accept, L.m_out, L.dx, rowmap);
+    return true;
 }
 
 void launch_lm_finish(CovView cv, int b0, int nb, const double* Y, size_t ystride, int ldy, int y_row0, int z_row, const int* m, double* dx,

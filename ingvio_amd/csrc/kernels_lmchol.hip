@@ -117,6 +117,12 @@ __global__ __launch_bounds__(512) void k_lm_factor(LmCholArgs a)
     double* Ug = a.U + (size_t)bl * a.us;
     double* zg = Ug + (size_t)(NTILES + NTM) * 256;
     const int ldx = a.ldx;
+    // compact row R of the stacked system = row sMap[R] of X (the landmark front gates AFTER it built S for every candidate, so
+    // the accepted rows are picked here; no map: identity); a negative entry is a padding row (unit diagonal)
+    __shared__ int sMap[16 * NTM];
+    for (int e = tid; e < 16 * NTM; e += 512) sMap[e] = e < 16 * nt ? (a.rowmap ? a.rowmap[(size_t)bl * a.rm_stride + e] : e) : -1;
+    if (tid == 0) sBad = 0;
+    __syncthreads();
     // this wave's tiles: t = wave + 8 s
     int sa[NS], sb[NS];
     double4_f T[NS];
@@ -128,16 +134,20 @@ __global__ __launch_bounds__(512) void k_lm_factor(LmCholArgs a)
             while (t >= NTM - ta) { t -= NTM - ta; ++ta; }
             sa[s] = ta; sb[s] = ta + t;
         }
-        // S is symmetric, its LOWER triangle is what every producer fills (the GEMM's lower blocks, k_add_noise): element
-        // (16 a + i, 16 b + j) is read at row 16 b + j of column 16 a + i (16 lanes contiguous), mirrored inside diagonal tiles
+        // S is symmetric, its LOWER triangle is what every producer fills (the GEMM's lower blocks, k_add_noise, k_lm_front): element
+        // (R1, R2) is read at row max, column min (for a < b: 16 lanes contiguous), mirrored inside diagonal tiles
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int R1 = 16 * sa[s] + kq + 4 * r, R2 = 16 * sb[s] + l15;
-            T[s][r] = sb[s] < nt ? X[(size_t)max(R1, R2) + (size_t)min(R1, R2) * ldx] : 0.0;
+            double v = R1 == R2 ? 1.0 : 0.0;
+            if (sb[s] < nt) {
+                const int o1 = sMap[R1], o2 = sMap[R2];
+                if (o1 >= 0 && o2 >= 0) v = X[(size_t)max(o1, o2) + (size_t)min(o1, o2) * ldx];
+            }
+            T[s][r] = v;
         }
     }
-    for (int e = tid; e < 16 * NTM; e += 512) sR[e] = e < 16 * nt ? X[(size_t)a.res_row + (size_t)e * ldx] : 0.0;
-    if (tid == 0) sBad = 0;
+    for (int e = tid; e < 16 * NTM; e += 512) sR[e] = sMap[e] >= 0 ? X[(size_t)a.res_row + (size_t)sMap[e] * ldx] : 0.0;
     __syncthreads();
 #pragma unroll 1
     for (int k = 0; k < nt; ++k) {
@@ -215,57 +225,87 @@ __global__ __launch_bounds__(512) void k_lm_factor(LmCholArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// grid = (16-row blocks of the state / 4, filters), 256 threads: wave w = block 4 blockIdx.x + w.
+// grid = (16-row blocks of the state / 4, filters), 256 threads: wave w = block 4 blockIdx.x + w.  The four waves need the same
+// A operands (the U tiles of column k and L_kk^-1, k + 1 tiles per step): the workgroup stages them through LDS, double-buffered,
+// the next step's tiles in flight (one double per thread and tile) under this step's MFMAs; one barrier per step.
 // ---------------------------------------------------------------------------------------------
 template <int NTM>
 __global__ __launch_bounds__(256) void k_lm_carry(LmCholArgs a)
 {
     constexpr int NTILES = tri_tiles(NTM);
+    __shared__ __attribute__((aligned(16))) double sA[2][NTM + 1][256];
     const int bl = blockIdx.y, m = a.m[bl];
     if (m == 0) return;
     const int b = a.b0 + bl, n = a.cv.n[b], ld = a.cv.ldp;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const int cb = 4 * blockIdx.x + wave, j = 16 * cb + l15;
-    if (16 * cb >= ld) return;
     double* dx = a.dx + (size_t)b * ld;
-    if ((a.status[bl] & a.fail_bit) || 16 * cb >= n) {                   // S not positive definite: no update
+    if (a.status[bl] & a.fail_bit) {                                     // S not positive definite: no update
         if (kq == 0 && j < ld) dx[j] = 0.0;
         return;
     }
+    const bool on = 16 * cb < n;                                         // (a wave beyond the state still helps staging the tiles)
     const int nt = min(NTM, (m + 15) >> 4), ldx = a.ldx;
-    const double* C0 = a.X + (size_t)bl * a.xs + a.mc + j;              // (P H^T)[j][R] at C0[R ldx]
+    const double* C0 = a.X + (size_t)bl * a.xs + a.mc + (on ? j : 0);   // (P H^T)[j][R] at C0[R ldx]
     double* Y0 = a.Y + (size_t)bl * a.xs + a.mc + j;
-    const double* Ug = a.U + (size_t)bl * a.us + lane;
+    const double* Ug = a.U + (size_t)bl * a.us + tid;
     const double* zg = a.U + (size_t)bl * a.us + (size_t)(NTILES + NTM) * 256;
+    __shared__ int sMap[16 * NTM];                                       // compact row -> row of X (see k_lm_factor)
+    for (int e = tid; e < 16 * NTM; e += 256) sMap[e] = e < 16 * ((m + 15) >> 4) ? (a.rowmap ? a.rowmap[(size_t)bl * a.rm_stride + e] : e) : -1;
+    __syncthreads();
     double4_f V[NTM];
     double dxa = 0.0;
+    double pre[NTM + 1], cn[4];
+    auto fetch = [&](int k) {                                            // tiles (p, k), p < k, then L_kk^-1; the block's rows of P H^T
+#pragma unroll
+        for (int p = 0; p < NTM; ++p) if (p < k) pre[p] = Ug[(size_t)tri_index(NTM, p, k) * 256];
+        pre[NTM] = Ug[(size_t)(NTILES + k) * 256];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = sMap[16 * k + kq + 4 * r];
+            cn[r] = o >= 0 ? C0[(size_t)o * ldx] : 0.0;
+        }
+    };
+    auto stash = [&](int k) {
+#pragma unroll
+        for (int p = 0; p < NTM; ++p) if (p < k) sA[k & 1][p][tid] = pre[p];
+        sA[k & 1][NTM][tid] = pre[NTM];
+    };
+    fetch(0);
+    stash(0);
+    lds_barrier();
 #pragma unroll
     for (int k = 0; k < NTM; ++k) {
         if (k < nt) {
-            double4_f acc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = C0[(size_t)(16 * k + kq + 4 * r) * ldx];
+            double4_f acc = { cn[0], cn[1], cn[2], cn[3] }, acc2 = { 0.0, 0.0, 0.0, 0.0 };
+            if (k + 1 < nt) fetch(k + 1);
+            const double (*buf)[256] = sA[k & 1];
 #pragma unroll
             for (int p = 0; p < k; ++p) {
-                const double* ut = Ug + (size_t)tri_index(NTM, p, k) * 256;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-ut[64 * r], V[p][r], acc, 0, 0, 0);
+                for (int r = 0; r < 4; ++r) {
+                    if (p & 1) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-buf[p][64 * r + lane], V[p][r], acc2, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-buf[p][64 * r + lane], V[p][r], acc, 0, 0, 0);
+                }
             }
-            const double* tt = Ug + (size_t)(NTILES + k) * 256;
+            if (k > 1) acc += acc2;
             double4_f y = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f64_16x16x4f64(tt[64 * r], acc[r], y, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[NTM][64 * r + lane], acc[r], y, 0, 0, 0);
             V[k] = y;
+            if (on) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                Y0[(size_t)(16 * k + kq + 4 * r) * ldx] = y[r];
-                dxa = fma(y[r], zg[16 * k + kq + 4 * r], dxa);
+                for (int r = 0; r < 4; ++r) {
+                    Y0[(size_t)(16 * k + kq + 4 * r) * ldx] = y[r];
+                    dxa = fma(y[r], zg[16 * k + kq + 4 * r], dxa);
+                }
             }
+            if (k + 1 < nt) { stash(k + 1); lds_barrier(); }
         }
     }
     dxa += __shfl_xor(dxa, 16, WAVE);
     dxa += __shfl_xor(dxa, 32, WAVE);
-    if (kq == 0 && j < ld) dx[j] = j < n ? dxa : 0.0;
+    if (kq == 0 && j < ld) dx[j] = (on && j < n) ? dxa : 0.0;
 }
 
 template <int NTM>

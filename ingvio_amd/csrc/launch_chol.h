@@ -63,6 +63,7 @@ struct LmCholArgs {
     double* U; size_t us;                        // scratch: lm_chol_ws_doubles(mc) per filter (factor tiles, z)
     const int* m; int* status; int fail_bit;
     double* dx;
+    const int* rowmap; int rm_stride;            // optional [nb][rm_stride]: compact row R of the system = row rowmap[R] of X (< 0: padding)
 };
 size_t lm_chol_ws_doubles(int mc);
 void launch_lm_chol(const LmCholArgs& a, hipStream_t st);

@@ -23,7 +23,10 @@ struct EkfLaunch {
 
 void launch_ekf_core(const EkfLaunch& L, hipStream_t st);
 // ldy / ystride (0: the covariance's ld / L.ystride): leading dimension and per-filter stride of Y when it lives in another workspace
-void launch_downdate(const EkfLaunch& L, int n_cap, hipStream_t st, const double* Yb = nullptr, int ldy = 0, size_t ystride = 0);
+// marg_idx [nb] (optional, with marg_size): fused marginalisation - where the LDS-blocked variant runs (returns true) the updated
+// covariance goes compacted into the other ping-pong half (launch_post_marg must follow); false: not fused, nothing changed
+bool launch_downdate(const EkfLaunch& L, int n_cap, hipStream_t st, const double* Yb = nullptr, int ldy = 0, size_t ystride = 0,
+                     const int* marg_idx = nullptr, int marg_size = 0);
 struct RowsGateIn {         // the staged candidate rows of a batch (read-only; the gate writes its compacted copy into EkfLaunch's H/res/noise/m)
     const double *H, *res, *noise;
     const int *m, *colmap, *nc;

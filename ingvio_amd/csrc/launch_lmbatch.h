@@ -34,7 +34,11 @@ struct LmBuild {
     double* dx;
 };
 void launch_lm_build(const LmBuild& L, hipStream_t st);
+// fused rows + products + gate for states of up to 256 rows (k_lm_front): S and P H^T for every tracked landmark, the accepted rows
+// named by rowmap [nb][m_cap] (what launch_lm_chol reads through).  false: shape not covered, use launch_lm_build.
+bool launch_lm_front(const LmBuild& L, int lcap, int* rowmap, hipStream_t st);
 void launch_lm_finish(CovView cv, int b0, int nb, const double* Y, size_t ystride, int ldy, int y_row0, int z_row, const int* m, double* dx,
                       const int* status /* [B] absolute: bit 4 = the sweep's fail bit, filter skipped */, hipStream_t st);
 void launch_add_noise(double* X, size_t xstride, int ldx, const double* noise, int nstride, int r_kind, const int* m, int m_cap, int nb,
                       hipStream_t st);
+int dbg_read_lmbatch(long long* out, int n);
