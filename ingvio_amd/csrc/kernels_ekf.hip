@@ -333,11 +333,15 @@ int launch_rows_gate(const EkfLaunch& L, const RowsGateIn& in, double thr, doubl
 // every element of Y is read once per block row/column pair instead of once per 16 x 16 tile (4x less L2 traffic).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_downdate64(CovView cv, int b0, const double* __restrict__ Yall, const int* __restrict__ m_all,
-                                                    size_t ystride, int* __restrict__ status, int ldy, const int* __restrict__ marg_idx, int marg_size)
+                                                    size_t ystride, int* __restrict__ status, int ldy, const int* __restrict__ marg_idx, int marg_size, int nb, int nblk)
 {
     __shared__ Block64Lds sAB;
     __shared__ double sV[4][32][33];
-    const int bl = blockIdx.y, b = b0 + bl, m = m_all[bl];
+    // workgroup -> (filter, block) so that the blocks of one filter run on ONE XCD (workgroups are dealt round-robin to the 8 XCDs):
+    // its rows of Y are then fetched from HBM once and served to the other blocks by that XCD's L2
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bl = (slot / nblk) * 8 + xcd, blk = slot % nblk;
+    if (bl >= nb) return;
+    const int b = b0 + bl, m = m_all[bl];
     // fused marginalisation (marg_idx[bl] >= 0): the updated covariance is written into the OTHER ping-pong half without the
     // marg_size rows / columns at marg_idx (k_post_marg flips the halves afterwards) - the frame's landmark update is followed
     // by the marginalisation of the oldest clone (IngvioFilter.cpp:296-322), a full extra read + write of every covariance when
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(256) void k_downdate64(CovView cv, int b0, const do
     const bool upd = m > 0 && !(status[b] & 4);                          // bit 4: S not positive definite, the state stays untouched
     if (!upd && !fuse) return;
     const int n = cv.n[b], ld = cv.ldp;
-    int t = blockIdx.x, bi = 0;
+    int t = blk, bi = 0;
     while (t >= bi + 1) { t -= bi + 1; ++bi; }
     const int bj = t;
     if (64 * bi >= n) return;
@@ -357,6 +361,17 @@ __global__ __launch_bounds__(256) void k_downdate64(CovView cv, int b0, const do
     const double* P = cov_ptr(cv, b);
     double* D = fuse ? cov_alt_ptr(cv, b) : cov_ptr(cv, b);
     const double* Y = Yall + (size_t)bl * ystride;
+    // this lane's elements of the prior block, requested now: they arrive under the MFMA loop (a read-modify-write that starts its
+    // loads after the loop leaves the matrix cores idle for a memory round trip per workgroup)
+    const int r0 = 64 * bi + 32 * wi, q0c = 64 * bj + 32 * wj;
+    double pold[16];
+    if (quad_on) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = lane + 64 * u, row = r0 + (e & 31), col = q0c + (e >> 5);
+            pold[u] = (row < n && col < n && row >= col) ? P[(size_t)row + (size_t)col * ld] : 0.0;
+        }
+    }
     b64_d4 c[4];
     block64_mma(sAB, upd ? (m + 15) & ~15 : 0,
                 [&](int r, int k) { return k < m ? Y[(size_t)min(64 * bi + r, n - 1) + (size_t)k * ldy] : 0.0; },
@@ -364,13 +379,13 @@ __global__ __launch_bounds__(256) void k_downdate64(CovView cv, int b0, const do
     if (!quad_on) return;                                                // no barrier below
     // this wave's 32 x 32 quadrant through LDS, then row-fast read-modify-write of P and its mirror
     block64_to_lds(c, sV[wave]);
-    const int r0 = 64 * bi + 32 * wi, q0c = 64 * bj + 32 * wj;
     const int mhi = fuse ? midx + marg_size : 0;
-    for (int e = lane; e < 1024; e += 64) {
-        const int rr = e & 31, cc = e >> 5;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int e = lane + 64 * u, rr = e & 31, cc = e >> 5;
         const int row = r0 + rr, col = q0c + cc;
         if (row < n && col < n && row >= col) {
-            const double v = P[(size_t)row + (size_t)col * ld] - sV[wave][rr][cc];
+            const double v = pold[u] - sV[wave][rr][cc];
             sV[wave][rr][cc] = v;
             if (row == col && v < 0.0) atomicOr(&status[b], 2);
             if (!fuse) D[(size_t)row + (size_t)col * ld] = v;
@@ -397,8 +412,9 @@ bool launch_downdate(const EkfLaunch& L, int n_cap, hipStream_t st, const double
     const int tiles = nt * (nt + 1) / 2;
     if (ldy && L.m_cap >= 64 && !Yb) {                                     // the dense-H route with many rows: the LDS-blocked variant
         const int nb64 = (n_cap + 63) / 64;
-        hipLaunchKernelGGL(k_downdate64, dim3(nb64 * (nb64 + 1) / 2, L.nb), dim3(256), 0, st, L.cv, L.b0, L.Y, L.m,
-                           ystride ? ystride : (size_t)L.ystride, L.status, ldy ? ldy : L.cv.ldp, marg_idx, marg_size);
+        const int nblk = nb64 * (nb64 + 1) / 2;
+        hipLaunchKernelGGL(k_downdate64, dim3((L.nb + 7) / 8 * 8 * nblk), dim3(256), 0, st, L.cv, L.b0, L.Y, L.m,
+                           ystride ? ystride : (size_t)L.ystride, L.status, ldy ? ldy : L.cv.ldp, marg_idx, marg_size, L.nb, nblk);
         return marg_idx != nullptr;
     }
     hipLaunchKernelGGL(k_downdate, dim3((tiles + 3) / 4, L.nb), dim3(256), 0, st, L.cv, L.b0, L.Y, Yb ? Yb : L.Y, L.m, ystride ? ystride : (size_t)L.ystride, L.status, ldy ? ldy : L.cv.ldp);

@@ -336,10 +336,7 @@ __global__ __launch_bounds__(64) void k_lm_rows(CovView cv, LmView lv, LmOpts op
     const unsigned long long mask = __ballot(on);
     const int a = __popcll(mask & ((1ull << lane) - 1ull));
     if (on) {
-        double hj[88];
-        lm_rows<true>(lv.pose + (size_t)b * 24, lv.pf + 3 * o, lv.uv + 4 * o, op, hj, hj + 84);
-#pragma unroll
-        for (int e = 0; e < 88; ++e) Hc[(size_t)a * LMF_HS + e] = hj[e];
+        lm_rows<true>(lv.pose + (size_t)b * 24, lv.pf + 3 * o, lv.uv + 4 * o, op, Hc + (size_t)a * LMF_HS, Hc + (size_t)a * LMF_HS + 84);   // straight to global (a private array: scratch)
         cand[4 * a] = l; cand[4 * a + 1] = ia; cand[4 * a + 2] = il;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

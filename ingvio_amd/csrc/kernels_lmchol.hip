@@ -225,7 +225,7 @@ __global__ __launch_bounds__(512) void k_lm_factor(LmCholArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// grid = (16-row blocks of the state / 4, filters), 256 threads: wave w = block 4 blockIdx.x + w.  The four waves need the same
+// grid = filters x blocks of 64 state rows, 256 threads: wave w = 16-row block 4 blk + w.  The four waves need the same
 // A operands (the U tiles of column k and L_kk^-1, k + 1 tiles per step): the workgroup stages them through LDS, double-buffered,
 // the next step's tiles in flight (one double per thread and tile) under this step's MFMAs; one barrier per step.
 // ---------------------------------------------------------------------------------------------
@@ -234,11 +234,15 @@ __global__ __launch_bounds__(256) void k_lm_carry(LmCholArgs a)
 {
     constexpr int NTILES = tri_tiles(NTM);
     __shared__ __attribute__((aligned(16))) double sA[2][NTM + 1][256];
-    const int bl = blockIdx.y, m = a.m[bl];
+    // workgroup -> (filter, block of 64 state rows) with the blocks of one filter on ONE XCD: its factor tiles come from HBM once
+    const int nblk = (a.cv.ldp + 63) / 64;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bl = (slot / nblk) * 8 + xcd, blk = slot % nblk;
+    if (bl >= a.nb) return;
+    const int m = a.m[bl];
     if (m == 0) return;
     const int b = a.b0 + bl, n = a.cv.n[b], ld = a.cv.ldp;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
-    const int cb = 4 * blockIdx.x + wave, j = 16 * cb + l15;
+    const int cb = 4 * blk + wave, j = 16 * cb + l15;
     double* dx = a.dx + (size_t)b * ld;
     if (a.status[bl] & a.fail_bit) {                                     // S not positive definite: no update
         if (kq == 0 && j < ld) dx[j] = 0.0;
@@ -312,7 +316,7 @@ template <int NTM>
 void launch_t(const LmCholArgs& a, hipStream_t st)
 {
     hipLaunchKernelGGL((k_lm_factor<NTM>), dim3(a.nb), dim3(512), 0, st, a);
-    hipLaunchKernelGGL((k_lm_carry<NTM>), dim3((a.cv.ldp + 63) / 64, a.nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_lm_carry<NTM>), dim3((a.nb + 7) / 8 * 8 * ((a.cv.ldp + 63) / 64)), dim3(256), 0, st, a);
 }
 
 int pick_ntm(int mc)
