@@ -687,8 +687,12 @@ static void testFilterEndToEnd()
 // carries a gross pseudo-range error in every epoch: the per-row gate must refuse exactly that row.
 static void testFilterGnssEndToEnd()
 {
-    for (int strong = 0; strong <= 1; ++strong) {
+    for (int variant = 0; variant <= 2; ++variant) {
+        // variant 2: is_adjust_yof = 1 (GnssUpdate.cpp:164-167, 239-242: every row carries the yaw-offset column
+        // -u^T R_enu2ecef dotRw2enu(yo) p | v, GnssManager.cpp:101-113) - the yaw offset is then estimated, not just carried
+        const int strong = variant == 1 ? 1 : 0, adjust_yof = variant == 2 ? 1 : 0;
         IngvioParams fp = params();
+        fp._is_adjust_yof = adjust_yof;
         fp._enable_gnss = 1; fp._max_sw_clones = 11; fp._is_key_frame = 0; fp._init_imu_buffer_sp = -1; fp._visual_noise = 0.08;
         fp._hip_f_max = 64; fp._hip_n_max = 21 + 6 + 6 * 13 + 16; fp._max_lm_feats = 0;
         fp._init_cov_rot = 0.01; fp._init_cov_pos = 0.01;
@@ -798,9 +802,15 @@ static void testFilterGnssEndToEnd()
         const double perr = (state->_extended_pose->valueTrans1() - Truth::p(t)).norm();
         const double rerr = (state->_extended_pose->valueLinearAsMat() - Truth::R(t)).norm();
         const int igps = state->_gnss.at(State::GPS)->idx();
-        std::printf("  strong_reject=%d: N=%d epochs used %d rows [%d, %d] |dp|=%.4f m |dR|=%.4f |d cb_gps|=%.2f m (sigma %.2f) |d fs|=%.3f m/s yof=%.4f (true %.4f)\n",
-                    strong, state->curr_cov_size(), epochs_used, rows_min, rows_max, perr, rerr, cb_err, std::sqrt(P(igps, igps)), fs_err,
-                    state->_gnss.at(State::YOF)->value(), yo_true);
+        const int iyof = state->_gnss.at(State::YOF)->idx();
+        const double yof_var0 = state->_state_params._init_cov_yof;
+        std::printf("  strong_reject=%d adjust_yof=%d: N=%d epochs used %d rows [%d, %d] |dp|=%.4f m |dR|=%.4f |d cb_gps|=%.2f m (sigma %.2f) |d fs|=%.3f m/s yof=%.4f (true %.4f, sigma %.4f)\n",
+                    strong, adjust_yof, state->curr_cov_size(), epochs_used, rows_min, rows_max, perr, rerr, cb_err, std::sqrt(P(igps, igps)), fs_err,
+                    state->_gnss.at(State::YOF)->value(), yo_true, std::sqrt(P(iyof, iyof)));
+        if (adjust_yof) {      // the column makes the offset observable: its variance must have come down from the prior, the value stays near the truth
+            ASSERT_TRUE(std::fabs(state->_gnss.at(State::YOF)->value() - yo_true) < 0.1);
+            ASSERT_TRUE(P(iyof, iyof) < yof_var0);
+        }
         ASSERT_TRUE(asym == 0.0);
         ASSERT_TRUE(dmin > 0.0);
         ASSERT_TRUE(perr < 0.3);
