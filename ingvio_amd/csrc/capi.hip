@@ -2139,10 +2139,10 @@ int ingvio_debug_read(ingvio_ctx* c, long long* out, int n)
     if (dbg_read_factored(a, 64) || dbg_read_cov(bq, 64) || dbg_read_bigwin(cq, 64) || dbg_read_solve(sq, 64)) return INGVIO_E_HIP;
     long long hq[64];
     if (dbg_read_chol(hq, 64)) return INGVIO_E_HIP;
-    long long lq[64];
-    if (dbg_read_lmbatch(lq, 64)) return INGVIO_E_HIP;
+    long long lq[64], mq[64];
+    if (dbg_read_lmbatch(lq, 64) || dbg_read_lmchol(mq, 64)) return INGVIO_E_HIP;
     if (const char* e = getenv("INGVIO_DBG_TU")) {                     // debugging: all slots of one translation unit
-        const long long* src = e[0] == 'b' ? cq : (e[0] == 'c' ? hq : (e[0] == 's' ? sq : (e[0] == 'l' ? lq : a)));
+        const long long* src = e[0] == 'b' ? cq : (e[0] == 'c' ? hq : (e[0] == 's' ? sq : (e[0] == 'l' ? lq : (e[0] == 'm' ? mq : a))));
         for (int i = 0; i < n; ++i) out[i] = src[i];
         return INGVIO_OK;
     }

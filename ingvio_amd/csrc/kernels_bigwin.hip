@@ -579,11 +579,13 @@ __global__ __launch_bounds__(IB_NT, 1) void k_info_update_big(
 // ---------------------------------------------------------------------------------------------
 struct BigWs {
     int n32, ld1, ld2, ldab;
-    size_t oAB, oX1, oY1, oX2, oY2, oT, oRef, total;      // oRef: the gauge reference slot of the filter (as a double)
+    size_t oAB, oX1, oY1, oX2, oY2, oT, oRef, oU, total;  // oRef: the gauge reference slot of the filter (as a double); oU: factor tiles of launch_lm_chol
     __host__ __device__ explicit BigWs(int n32_) : n32(n32_), ld1(2 * n32_), ld2(3 * n32_ + 32), ldab(n32_ + 32)
     {
         oAB = 0; oX1 = oAB + (size_t)ldab * n32; oY1 = oX1 + (size_t)ld1 * n32; oX2 = oY1 + (size_t)ld1 * n32;
-        oY2 = oX2 + (size_t)ld2 * n32; oT = oY2 + (size_t)ld2 * n32; oRef = oT + (size_t)(n32 / 32) * 1024 + n32; total = oRef + 1;
+        oY2 = oX2 + (size_t)ld2 * n32; oT = oY2 + (size_t)ld2 * n32; oRef = oT + (size_t)(n32 / 32) * 1024 + n32; oU = oRef + 2;
+        const int ntm = (n32 + 15) / 16 <= 12 ? 12 : ((n32 + 15) / 16 <= 14 ? 14 : 16);      // as pick_ntm (kernels_lmchol.hip)
+        total = oU + (size_t)(ntm * (ntm + 1) / 2 + ntm) * 256 + (size_t)16 * ntm;
     }
 };
 
@@ -766,7 +768,17 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
     CholArgs c1 = {};
     c1.W = ws + w.oX1; c1.Y = ws + w.oY1; c1.xs = wss; c1.ld = w.ld1; c1.rows = 2 * n32; c1.ncols = n32;
     c1.status = L.status + L.b0; c1.fail_bit = 4; c1.active = act; c1.batch = L.nb; c1.Tb = ws + w.oT; c1.ts = wss; c1.t_slots = n32 / 32;
-    launch_chol_sweep(c1, st);
+    // both factorisations with ONE workgroup per filter and the matrix in registers (kernels_lmchol.hip: two launches each instead of
+    // one per 32-column panel: the sweep is 15 of the solve's 23 dependent launches)
+    // measured: SLOWER here - 0.75 vs 0.39 ms per 32 filters, 0.61 vs 0.23 for one: a single workgroup's panel takes ~5 us
+    // (13 x 16 serial pivots + two barriers), which 512 filters hide and 32 do not; the sweep's panel launches spread a
+    // panel over many CUs.  Kept selectable: INGVIO_BIG_SOLVE=regs
+    static const bool use_sweep = [] { const char* e = getenv("INGVIO_BIG_SOLVE"); return !(e && !strcmp(e, "regs")); }();
+    LmCholArgs q = {};
+    q.cv = L.cv; q.b0 = L.b0; q.nb = L.nb; q.xs = wss; q.mc = n32; q.res_row = -1; q.U = ws + w.oU; q.us = wss; q.m = act;
+    q.status = L.status + L.b0; q.fail_bit = 4; q.m_fixed = n32;
+    if (use_sweep) launch_chol_sweep(c1, st);
+    else { q.X = ws + w.oX1; q.Y = ws + w.oY1; q.ldx = w.ld1; q.carried_rows = n32; q.write_L = 1; launch_lm_chol(q, st); }
     GemmArgs g = {};
     // [A; b^T] L -> X2 rows n32 ..
     g.A = ws + w.oAB; g.sa = wss; g.lda = w.ldab; g.modeA = 0;
@@ -786,7 +798,8 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
                        n32, n32, act);
     CholArgs c2 = c1;
     c2.W = ws + w.oX2; c2.Y = ws + w.oY2; c2.ld = w.ld2; c2.rows = 3 * n32 + 32;
-    launch_chol_sweep(c2, st);
+    if (use_sweep) launch_chol_sweep(c2, st);
+    else { q.X = ws + w.oX2; q.Y = ws + w.oY2; q.ldx = w.ld2; q.carried_rows = 2 * n32 + 32; q.write_L = 0; launch_lm_chol(q, st); }
     // M = R2 R1^T (row-major, MP wide), t = R2 r1b^T
     g = GemmArgs{};
     g.A = ws + w.oY2 + 2 * n32 + 32; g.sa = wss; g.lda = w.ld2; g.modeA = 0;

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
         const int s0 = ci * PROP_KCH, cnt = min(PROP_KCH, k - s0);
         if (ci != nchunk - 1) chunk_load(ci);
         chunk_store(ci);
-        __syncthreads();
+        lds_barrier();                                          // LDS only: the strip fragments requested above stay in flight under the composition (__syncthreads would drain them: 22 k cycles of "fetch" at 512 filters)
         if (ci == nchunk - 1) dbg_stamp(21);
         if (tid < 64) {
             for (int s = s0 + cnt - 1; s >= s0; --s) {
@@ -225,11 +225,11 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
             if (el) sQg[lane] = v;
             if (lane == 0) sQg[25] = Tg;
         }
-        __syncthreads();                                        // the chunk's LDS may be overwritten
+        lds_barrier();                                        // the chunk's LDS may be overwritten
     }
     dbg_stamp(17);
     for (int a = tid; a < NA_MAX * NA_MAX; a += PROP_THREADS) { sPhiA[a] = 0.0; sQA[a] = 0.0; }
-    __syncthreads();
+    lds_barrier();
     // active set + GNSS clock block (thread 0, bookkeeping only)
     if (tid == 0) {
         int gi[5], na = 15;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
             for (int c = 0; c < 5; ++c) if (loc[c] >= 0) sQA[loc[a] * NA_MAX + loc[c]] = qg[a][c];
         }
     }
-    __syncthreads();                                            // the zero fill and thread 0's clock entries before wave 0's block
+    lds_barrier();                                            // the zero fill and thread 0's clock entries before wave 0's block
     if (tid < 64) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     dbg_stamp(18);
     const int na = sNA;
     // ---- strip rows outside A on the matrix cores:  (P[r, A] Phi_A^T)^T = Phi_A P[r, A]^T, 16 rows r per tile -------------------

@@ -109,8 +109,9 @@ __global__ __launch_bounds__(512) void k_lm_factor(LmCholArgs a)
     __shared__ __attribute__((aligned(16))) double sC[2][16];
     __shared__ double sR[16 * NTM], sZ[16];
     __shared__ int sBad;
-    const int bl = blockIdx.x, m = a.m[bl];
-    if (m == 0) return;
+    const int bl = blockIdx.x;
+    if (a.m[bl] == 0) return;
+    const int m = a.m_fixed > 0 ? a.m_fixed : a.m[bl];
     const int nt = min(NTM, (m + 15) >> 4);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const double* X = a.X + (size_t)bl * a.xs;
@@ -147,10 +148,13 @@ __global__ __launch_bounds__(512) void k_lm_factor(LmCholArgs a)
             T[s][r] = v;
         }
     }
-    for (int e = tid; e < 16 * NTM; e += 512) sR[e] = sMap[e] >= 0 ? X[(size_t)a.res_row + (size_t)sMap[e] * ldx] : 0.0;
+    for (int e = tid; e < 16 * NTM; e += 512) sR[e] = (a.res_row >= 0 && sMap[e] >= 0) ? X[(size_t)a.res_row + (size_t)sMap[e] * ldx] : 0.0;
+    double* Lg = a.write_L ? a.Y + (size_t)bl * a.xs : nullptr;          // L in matrix form (rows [0, 16 nt) of Y), for callers that multiply with it
     __syncthreads();
+    dbg_stamp(0);
 #pragma unroll 1
     for (int k = 0; k < nt; ++k) {
+        if (k == 1) dbg_stamp(1);
         // ---- (A) the diagonal tile
         bool mine = false;
 #pragma unroll
@@ -171,9 +175,15 @@ __global__ __launch_bounds__(512) void k_lm_factor(LmCholArgs a)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) sT[lane - 16][j] = d[j];
             }
+            if (Lg && lane < 16) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) Lg[(size_t)(16 * k + lane) + (size_t)(16 * k + j) * ldx] = j <= lane ? d[j] : 0.0;
+            }
             if (__any(bad) && lane == 0) sBad = 1;
         }
+        if (k == 1) dbg_stamp(2);
         lds_barrier();
+        if (k == 1) dbg_stamp(3);
         // ---- (B) row panel k
         double A[4];
 #pragma unroll
@@ -199,9 +209,17 @@ __global__ __launch_bounds__(512) void k_lm_factor(LmCholArgs a)
                 double* ug = Ug + (size_t)tri_index(NTM, k, sb[s]) * 256 + lane;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { pan[sb[s]][r][lane] = acc[r]; ug[64 * r] = acc[r]; }
+                if (Lg) {                                                // L[16 b + j][16 k + i] = U_kb[i][j]; the mirrored block is zero
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        Lg[(size_t)(16 * sb[s] + l15) + (size_t)(16 * k + kq + 4 * r) * ldx] = acc[r];
+                        Lg[(size_t)(16 * k + l15) + (size_t)(16 * sb[s] + kq + 4 * r) * ldx] = 0.0;
+                    }
+                }
             }
         }
         lds_barrier();
+        if (k == 1) dbg_stamp(4);
         // ---- (C) trailing update
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -219,7 +237,9 @@ __global__ __launch_bounds__(512) void k_lm_factor(LmCholArgs a)
             for (int i = 0; i < 16; ++i) v = fma(-pan[b][i >> 2][(i & 3) * 16 + j], sZ[i], v);
             sR[16 * b + j] = v;
         }
+        if (k == 1) dbg_stamp(5);
     }
+    dbg_stamp(6);
     __syncthreads();
     if (tid == 0 && sBad) atomicOr(&a.status[bl], a.fail_bit);
 }
@@ -235,17 +255,18 @@ __global__ __launch_bounds__(256) void k_lm_carry(LmCholArgs a)
     constexpr int NTILES = tri_tiles(NTM);
     __shared__ __attribute__((aligned(16))) double sA[2][NTM + 1][256];
     // workgroup -> (filter, block of 64 state rows) with the blocks of one filter on ONE XCD: its factor tiles come from HBM once
-    const int nblk = (a.cv.ldp + 63) / 64;
+    const bool gen = a.carried_rows > 0;
+    const int nblk = ((gen ? a.carried_rows : a.cv.ldp) + 63) / 64;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bl = (slot / nblk) * 8 + xcd, blk = slot % nblk;
     if (bl >= a.nb) return;
-    const int m = a.m[bl];
-    if (m == 0) return;
-    const int b = a.b0 + bl, n = a.cv.n[b], ld = a.cv.ldp;
+    if (a.m[bl] == 0) return;
+    const int m = a.m_fixed > 0 ? a.m_fixed : a.m[bl];
+    const int b = a.b0 + bl, n = gen ? a.carried_rows : a.cv.n[b], ld = gen ? a.carried_rows : a.cv.ldp;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const int cb = 4 * blk + wave, j = 16 * cb + l15;
-    double* dx = a.dx + (size_t)b * ld;
+    double* dx = a.dx ? a.dx + (size_t)b * ld : nullptr;
     if (a.status[bl] & a.fail_bit) {                                     // S not positive definite: no update
-        if (kq == 0 && j < ld) dx[j] = 0.0;
+        if (dx && kq == 0 && j < ld) dx[j] = 0.0;
         return;
     }
     const bool on = 16 * cb < n;                                         // (a wave beyond the state still helps staging the tiles)
@@ -301,7 +322,7 @@ __global__ __launch_bounds__(256) void k_lm_carry(LmCholArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     Y0[(size_t)(16 * k + kq + 4 * r) * ldx] = y[r];
-                    dxa = fma(y[r], zg[16 * k + kq + 4 * r], dxa);
+                    if (dx) dxa = fma(y[r], zg[16 * k + kq + 4 * r], dxa);
                 }
             }
             if (k + 1 < nt) { stash(k + 1); lds_barrier(); }
@@ -309,14 +330,15 @@ __global__ __launch_bounds__(256) void k_lm_carry(LmCholArgs a)
     }
     dxa += __shfl_xor(dxa, 16, WAVE);
     dxa += __shfl_xor(dxa, 32, WAVE);
-    if (kq == 0 && j < ld) dx[j] = (on && j < n) ? dxa : 0.0;
+    if (dx && kq == 0 && j < ld) dx[j] = (on && j < n) ? dxa : 0.0;
 }
 
 template <int NTM>
 void launch_t(const LmCholArgs& a, hipStream_t st)
 {
     hipLaunchKernelGGL((k_lm_factor<NTM>), dim3(a.nb), dim3(512), 0, st, a);
-    hipLaunchKernelGGL((k_lm_carry<NTM>), dim3((a.nb + 7) / 8 * 8 * ((a.cv.ldp + 63) / 64)), dim3(256), 0, st, a);
+    const int crows = a.carried_rows > 0 ? a.carried_rows : a.cv.ldp;
+    hipLaunchKernelGGL((k_lm_carry<NTM>), dim3((a.nb + 7) / 8 * 8 * ((crows + 63) / 64)), dim3(256), 0, st, a);
 }
 
 int pick_ntm(int mc)
@@ -326,6 +348,8 @@ int pick_ntm(int mc)
 }
 
 }  // namespace
+
+int dbg_read_lmchol(long long* out, int n) { return dbg_read_local(out, n); }
 
 size_t lm_chol_ws_doubles(int mc)
 {

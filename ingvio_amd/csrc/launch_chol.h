@@ -64,7 +64,12 @@ struct LmCholArgs {
     const int* m; int* status; int fail_bit;
     double* dx;
     const int* rowmap; int rm_stride;            // optional [nb][rm_stride]: compact row R of the system = row rowmap[R] of X (< 0: padding)
-};
+    // generic use (the large-window solve, kernels_bigwin.hip): the drop-in for launch_chol_sweep when ncols <= 256
+    int carried_rows;                            // > 0: that many carried rows (rows mc .. of X) instead of the state's; dx / cv are not used then
+    int m_fixed;                                 // > 0: factorise that many rows for every active filter (m[i] only says active / not)
+    int write_L;                                 // != 0: also write L into rows [0, m) of Y (upper part zero), as the sweep does
+};                                               // res_row < 0: no residual row (no z, no dx)
 size_t lm_chol_ws_doubles(int mc);
 void launch_lm_chol(const LmCholArgs& a, hipStream_t st);
+int dbg_read_lmchol(long long* out, int n);
 int dbg_read_chol(long long* out, int n);

@@ -16,3 +16,6 @@ for _ in range(3):
     ctx.frame_run(restore_prior=True)
 d = ctx.debug_read(8)
 print("B=%d k_lm_front [rows to LDS, A(0), B(0), chunks 1.., gate + map]" % B, [d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[4]], "total", d[5] - d[0])
+import os
+if os.environ.get("INGVIO_DBG_TU") == "m":
+    print("B=%d k_lm_factor panel 1 [(A) diag tile, wait, (B) row panel, (C) trailing]" % B, [d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[4]], "all panels", d[6] - d[0])

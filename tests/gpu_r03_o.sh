@@ -2,6 +2,5 @@
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 for B in 1 512; do
-INGVIO_DBG_TU=l INGVIO_HIP_LIB=$PWD/build_var/lm_dbg/libingvio_hip.so timeout 300 python tests/gpu_phase_lm.py $B 2>&1 | tail -1
+INGVIO_DBG_TU=m INGVIO_HIP_LIB=$PWD/build_var/dbg/libingvio_hip.so timeout 300 python tests/gpu_phase_lm.py $B 2>&1 | tail -1
 done
-bash tests/gpu_r03_m.sh
