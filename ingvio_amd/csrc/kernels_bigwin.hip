@@ -1160,8 +1160,8 @@ __global__ __launch_bounds__(256) void k_apply_sym64(CovView cv, int b0, const d
         const int row = r0 + rr, col = c0 + cc;
         double v = 0.0;
         if (row < n && col < n && row >= col) {
-            v = q.P[(size_t)row + (size_t)col * ld] - sV[wave][rr][cc];
-            if (alive(row) && alive(col)) q.dst[(size_t)remap(row) + (size_t)remap(col) * ld] = v;
+            v = NT_LOAD(&q.P[(size_t)row + (size_t)col * ld]) - sV[wave][rr][cc];
+            if (alive(row) && alive(col)) NT_STORE(&q.dst[(size_t)remap(row) + (size_t)remap(col) * ld], v);
             if (q.upd && row == col && v < 0.0) atomicOr(&status[b0 + bl], 2);
         }
         sV[wave][rr][cc] = v;
@@ -1171,7 +1171,7 @@ __global__ __launch_bounds__(256) void k_apply_sym64(CovView cv, int b0, const d
     for (int e = lane; e < 1024; e += 64) {
         const int cc = e & 31, rr = e >> 5;
         const int row = r0 + rr, col = c0 + cc;
-        if (row < n && col < n && row > col && alive(row) && alive(col)) q.dst[(size_t)remap(col) + (size_t)remap(row) * ld] = sV[wave][rr][cc];
+        if (row < n && col < n && row > col && alive(row) && alive(col)) NT_STORE(&q.dst[(size_t)remap(col) + (size_t)remap(row) * ld], sV[wave][rr][cc]);
     }
 }
 

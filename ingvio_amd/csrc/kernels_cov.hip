@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void k_marginalize(CovView cv, int b0, const i
         const int sj = j < idx ? j : j + size;
         for (int i = tid; i < nn; i += 256) {
             const int si = i < idx ? i : i + size;
-            dst[i + (size_t)j * ld] = src[si + (size_t)sj * ld];
+            NT_STORE(&dst[i + (size_t)j * ld], NT_LOAD(&src[si + (size_t)sj * ld]));
         }
     }
 }
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void k_restore(CovView cv, const double* __res
     for (int jj = 0; jj < MARG_COLS; ++jj) {
         const int j = blockIdx.x * MARG_COLS + jj;
         if (j >= n) break;
-        for (int i = tid; i < n; i += 256) dst[i + (size_t)j * ld] = src[i + (size_t)j * ld];
+        for (int i = tid; i < n; i += 256) NT_STORE(&dst[i + (size_t)j * ld], NT_LOAD(&src[i + (size_t)j * ld]));      // a plain copy: streaming both ways
     }
 }
 // Partial restore after a fused frame step (propagate + clone + out-of-place update/marginalise): half 0 still holds

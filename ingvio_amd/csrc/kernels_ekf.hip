@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void k_downdate64(CovView cv, int b0, const do
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int e = lane + 64 * u, row = r0 + (e & 31), col = q0c + (e >> 5);
-            pold[u] = (row < n && col < n && row >= col) ? P[(size_t)row + (size_t)col * ld] : 0.0;
+            pold[u] = (row < n && col < n && row >= col) ? NT_LOAD(&P[(size_t)row + (size_t)col * ld]) : 0.0;      // read once: streaming
         }
     }
     b64_d4 c[4];
@@ -388,9 +388,9 @@ __global__ __launch_bounds__(256) void k_downdate64(CovView cv, int b0, const do
             const double v = pold[u] - sV[wave][rr][cc];
             sV[wave][rr][cc] = v;
             if (row == col && v < 0.0) atomicOr(&status[b], 2);
-            if (!fuse) D[(size_t)row + (size_t)col * ld] = v;
+            if (!fuse) NT_STORE(&D[(size_t)row + (size_t)col * ld], v);                     // the posterior: streaming stores (see k_info_apply)
             else if ((row < midx || row >= mhi) && (col < midx || col >= mhi))
-                D[(size_t)(row < midx ? row : row - marg_size) + (size_t)(col < midx ? col : col - marg_size) * ld] = v;
+                NT_STORE(&D[(size_t)(row < midx ? row : row - marg_size) + (size_t)(col < midx ? col : col - marg_size) * ld], v);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -399,9 +399,9 @@ __global__ __launch_bounds__(256) void k_downdate64(CovView cv, int b0, const do
         const int cc = e & 31, rr = e >> 5;
         const int row = r0 + rr, col = q0c + cc;
         if (row < n && col < n && row > col) {
-            if (!fuse) D[(size_t)col + (size_t)row * ld] = sV[wave][rr][cc];
+            if (!fuse) NT_STORE(&D[(size_t)col + (size_t)row * ld], sV[wave][rr][cc]);
             else if ((row < midx || row >= mhi) && (col < midx || col >= mhi))
-                D[(size_t)(col < midx ? col : col - marg_size) + (size_t)(row < midx ? row : row - marg_size) * ld] = sV[wave][rr][cc];
+                NT_STORE(&D[(size_t)(col < midx ? col : col - marg_size) + (size_t)(row < midx ? row : row - marg_size) * ld], sV[wave][rr][cc]);
         }
     }
 }

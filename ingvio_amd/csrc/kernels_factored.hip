@@ -634,7 +634,20 @@ __global__ __launch_bounds__(INFO_NT, 2) void k_info_update(
 // grid = (ceil(nt / 4), nb), 4 waves per workgroup.
 // ---------------------------------------------------------------------------------------------
 
-template <int NC>
+// The posterior is written with STREAMING stores: nothing in this kernel re-reads it, and 240 MB of write-allocated lines evict what
+// the next kernels want from L2 / MALL (the snapshot strips, the next frame's inputs).  Measured: apply 0.153 -> 0.144 ms and the
+// rest of the step faster too (propagate 0.051 -> 0.046, gate 0.286 -> 0.276): 0.730 -> 0.698 ms per step.
+#ifdef INGVIO_APPLY_NO_NT
+#define APPLY_STORE(p, v) (*(p) = (v))
+#else
+#define APPLY_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#endif
+#ifdef INGVIO_APPLY_NO_NT          // the prior's tiles (each read once) as streaming loads as well: 0.706 -> 0.693 ms per step
+#define APPLY_LOADP(p) (*(p))
+#else
+#define APPLY_LOADP(p) __builtin_nontemporal_load(p)
+#endif
+template <int NC, int TW>
 __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int nb, int wgpf, const double* __restrict__ Mall, int mstride,
                                                        const double* __restrict__ Pcall, int ystride, const int* __restrict__ m_all,
                                                        double* __restrict__ dx_all, int* __restrict__ status,
@@ -643,10 +656,12 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     constexpr int MP = (NC + 3) & ~3, K4 = MP / 4, JT = (MP + 15) / 16;
     // sT (layout change of T, first phase) and sB (B-operand tile Pc[16 tj .. +16][0..MP), staged once per workgroup
     // per step, second phase) share their LDS
-    constexpr int ST_DOUBLES = 4 * 16 * (MP + 2), SB_DOUBLES = 2 * MP * 16;
+    // TW tile columns per step (round 3: 2 - half as many steps, each a dependent chain global load -> LDS -> barrier -> MFMA -> store)
+    constexpr int BW = 16 * TW;
+    constexpr int ST_DOUBLES = 4 * 16 * (MP + 2), SB_DOUBLES = 2 * MP * BW;
     __shared__ __attribute__((aligned(16))) double sTB[ST_DOUBLES > SB_DOUBLES ? ST_DOUBLES : SB_DOUBLES];
     double (*sT)[16][MP + 2] = reinterpret_cast<double (*)[16][MP + 2]>(sTB);
-    double (*sB)[MP][16] = reinterpret_cast<double (*)[MP][16]>(sTB);
+    double (*sB)[MP][BW] = reinterpret_cast<double (*)[MP][BW]>(sTB);
     __shared__ double sV[4][16][17];
     // XCD-aware order: the workgroups of one filter share an L2 (they all stream the same Pc and M)
     const int wg = blockIdx.x, xcd = wg & 7, tq = wg >> 3;
@@ -721,18 +736,18 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
 
     dbg_stamp(12);
     // ---- tiles (ti, tj): all waves walk tj together; the B tile is staged in LDS once for the four waves ----------
-    constexpr int STG = (MP * 16 + 255) / 256;
+    constexpr int STG = (MP * BW + 255) / 256;
     double stg[STG];
-    auto stage_load = [&](int tj) {                            // element e = k * 16 + r  ->  Pc[16 tj + r][k]
+    auto stage_load = [&](int tjj) {                           // element e = k * BW + r  ->  Pc[16 tjj + r][k]
 #pragma unroll
         for (int u = 0; u < STG; ++u) {
-            const int e = tid + 256 * u, k = e >> 4, r = e & 15;
-            stg[u] = (upd && e < MP * 16) ? Pc[min(16 * tj + r, n - 1) + (size_t)k * ld] : 0.0;
+            const int e = tid + 256 * u, k = e / BW, r = e - k * BW;
+            stg[u] = (upd && e < MP * BW) ? Pc[min(16 * tjj + r, n - 1) + (size_t)k * ld] : 0.0;
         }
     };
     auto stage_store = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < STG; ++u) { const int e = tid + 256 * u; if (e < MP * 16) (&sB[buf][0][0])[e] = stg[u]; }
+        for (int u = 0; u < STG; ++u) { const int e = tid + 256 * u; if (e < MP * BW) (&sB[buf][0][0])[e] = stg[u]; }
     };
     auto store_tile = [&](int ti, int tj, const double4_f& acc, const double (&pv)[4]) {
         // element (row, col), row >= col: stored through the mirrored address (col fastest, coalesced); its transpose
@@ -743,7 +758,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
             const int row = ti * 16 + kq + 4 * r;
             const double v = pv[r] - acc[r];
             if (row < n && col < n && row >= col) {
-                if (alive(row) && alive(col)) dst[remap(col) + (size_t)remap(row) * ld] = v;
+                if (alive(row) && alive(col)) APPLY_STORE(&dst[remap(col) + (size_t)remap(row) * ld], v);
                 if (upd && row == col && v < 0.0) atomicOr(&status[b], 2);      // StateManager.cpp:413-421
             }
             sV[wave][kq + 4 * r][l15] = v;
@@ -754,7 +769,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
         for (int r = 0; r < 4; ++r) {
             const int col2 = tj * 16 + kq + 4 * r;
             if (row2 < n && col2 < n && row2 > col2 && alive(row2) && alive(col2))
-                dst[remap(row2) + (size_t)remap(col2) * ld] = sV[wave][l15][kq + 4 * r];
+                APPLY_STORE(&dst[remap(row2) + (size_t)remap(col2) * ld], sV[wave][l15][kq + 4 * r]);
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -763,46 +778,59 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = ti * 16 + kq + 4 * r;
-            pv[r] = (row < n && col < n && row >= col) ? P[col + (size_t)row * ld] : 0.0;      // mirrored (coalesced) address
+            pv[r] = (row < n && col < n && row >= col) ? APPLY_LOADP(&P[col + (size_t)row * ld]) : 0.0;      // mirrored (coalesced) address
         }
     };
     stage_load(0);
     lds_barrier();                                           // every wave is done with sT
     stage_store(0);
     lds_barrier();
-    double pv0[4], pv1[4], pn0[4], pn1[4];
-    if (nrows > 0) load_p(tiR[0], 0, pv0);
-    if (nrows > 1) load_p(tiR[1], 0, pv1);
-    for (int tj = 0; tj <= tjmax; ++tj) {
-        const int buf = tj & 1;
-        if (tj < tjmax) stage_load(tj + 1);                    // next B tile and next P values in flight during this step's MFMAs
-        const bool do0 = nrows > 0 && tj <= tiR[0], do1 = nrows > 1 && tj <= tiR[1];
-        if (nrows > 0 && tj + 1 <= tiR[0]) load_p(tiR[0], tj + 1, pn0);
-        if (nrows > 1 && tj + 1 <= tiR[1]) load_p(tiR[1], tj + 1, pn1);
-        double bfrag[K4];
-        if (upd && (do0 || do1)) {
+    double pv[2][TW][4], pn[2][TW][4];
 #pragma unroll
-            for (int k4 = 0; k4 < K4; ++k4) bfrag[k4] = sB[buf][4 * k4 + kq][l15];      // B[k][j] = Pc[16 tj + j][k]
-        }
-        if (do0) {
-            double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
-            if (upd) {
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tfrag[0][k4], bfrag[k4], acc, 0, 0, 0);
+        for (int q = 0; q < TW; ++q) if (h < nrows && q <= tiR[h]) load_p(tiR[h], q, pv[h][q]);
+    int buf = 0;
+    for (int tjj = 0; tjj <= tjmax; tjj += TW, buf ^= 1) {
+        const bool more = tjj + TW <= tjmax;
+        if (more) stage_load(tjj + TW);                        // next B tile(s) and next P values in flight during this step's MFMAs
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < TW; ++q) if (h < nrows && tjj + TW + q <= tiR[h]) load_p(tiR[h], tjj + TW + q, pn[h][q]);
+#pragma unroll
+        for (int q = 0; q < TW; ++q) {
+            const int tj = tjj + q;
+            const bool do0 = nrows > 0 && tj <= tiR[0], do1 = nrows > 1 && tj <= tiR[1];
+            double bfrag[K4];
+            if (upd && (do0 || do1)) {
+#pragma unroll
+                for (int k4 = 0; k4 < K4; ++k4) bfrag[k4] = sB[buf][4 * k4 + kq][16 * q + l15];      // B[k][j] = Pc[16 tj + j][k]
             }
-            store_tile(tiR[0], tj, acc, pv0);
-        }
-        if (do1) {
-            double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
-            if (upd) {
+            if (do0) {
+                double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
+                if (upd) {
 #pragma unroll
-                for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tfrag[1][k4], bfrag[k4], acc, 0, 0, 0);
+                    for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tfrag[0][k4], bfrag[k4], acc, 0, 0, 0);
+                }
+                store_tile(tiR[0], tj, acc, pv[0][q]);
             }
-            store_tile(tiR[1], tj, acc, pv1);
-        }
-        if (tj < tjmax) stage_store(buf ^ 1);
+            if (do1) {
+                double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
+                if (upd) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { pv0[r] = pn0[r]; pv1[r] = pn1[r]; }
+                    for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tfrag[1][k4], bfrag[k4], acc, 0, 0, 0);
+                }
+                store_tile(tiR[1], tj, acc, pv[1][q]);
+            }
+        }
+        if (more) stage_store(buf ^ 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < TW; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv[h][q][r] = pn[h][q][r];
         lds_barrier();
     }
     dbg_stamp(13);
@@ -852,8 +880,12 @@ int launch_factored(const FactoredLaunch& L, hipStream_t st)
     const int ncm = 6 * L.fv.cmax;
     if (L.stage == 3) {
         const int nt = (L.n_cap + 15) / 16, wgpf = ((nt + 1) / 2 + 3) / 4, nb8 = (L.nb + 7) / 8 * 8;
+        // two tile columns per step (half the steps): measured 0.194 against 0.151 ms (256 VGPRs + 76 B scratch) - selectable only
+        static const bool tw1 = [] { const char* e = getenv("INGVIO_APPLY_TW"); return !(e && e[0] == '2'); }();
 #define APPLY_DISPATCH(NC)                                                                                            \
-        hipLaunchKernelGGL(k_info_apply<NC>, dim3(nb8 * wgpf), dim3(256), 0, st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride, L.Pc, \
+        if (tw1) hipLaunchKernelGGL((k_info_apply<NC, 1>), dim3(nb8 * wgpf), dim3(256), 0, st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride, L.Pc, \
+                           L.ystride, L.m_out, L.dx, L.status, L.marg_idx, L.marg_size, L.pc_base);                    \
+        else hipLaunchKernelGGL((k_info_apply<NC, 2>), dim3(nb8 * wgpf), dim3(256), 0, st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride, L.Pc, \
                            L.ystride, L.m_out, L.dx, L.status, L.marg_idx, L.marg_size, L.pc_base);
         if (ncm <= 36) { APPLY_DISPATCH(36) } else if (ncm <= 66) { APPLY_DISPATCH(66) } else { APPLY_DISPATCH(96) }
 #undef APPLY_DISPATCH

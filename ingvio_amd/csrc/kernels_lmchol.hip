@@ -99,7 +99,7 @@ __device__ __forceinline__ void factor16(double (*sDI)[17], double (*sC)[16], in
 // ---------------------------------------------------------------------------------------------
 // grid = filters, 512 threads.
 // ---------------------------------------------------------------------------------------------
-template <int NTM>
+template <int NTM, bool WL>                                              // WL: also write L in matrix form (a template flag: as a run-time one it cost the landmark instantiation 512 B of spills)
 __global__ __launch_bounds__(512) void k_lm_factor(LmCholArgs a)
 {
     constexpr int NTILES = tri_tiles(NTM), NW = 8, NS = (NTILES + NW - 1) / NW;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(512) void k_lm_factor(LmCholArgs a)
         }
     }
     for (int e = tid; e < 16 * NTM; e += 512) sR[e] = (a.res_row >= 0 && sMap[e] >= 0) ? X[(size_t)a.res_row + (size_t)sMap[e] * ldx] : 0.0;
-    double* Lg = a.write_L ? a.Y + (size_t)bl * a.xs : nullptr;          // L in matrix form (rows [0, 16 nt) of Y), for callers that multiply with it
+    double* Lg = WL ? a.Y + (size_t)bl * a.xs : nullptr;                 // L in matrix form (rows [0, 16 nt) of Y), for callers that multiply with it
     __syncthreads();
     dbg_stamp(0);
 #pragma unroll 1
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512) void k_lm_factor(LmCholArgs a)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) sT[lane - 16][j] = d[j];
             }
-            if (Lg && lane < 16) {
+            if (WL && lane < 16) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) Lg[(size_t)(16 * k + lane) + (size_t)(16 * k + j) * ldx] = j <= lane ? d[j] : 0.0;
             }
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(512) void k_lm_factor(LmCholArgs a)
                 double* ug = Ug + (size_t)tri_index(NTM, k, sb[s]) * 256 + lane;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { pan[sb[s]][r][lane] = acc[r]; ug[64 * r] = acc[r]; }
-                if (Lg) {                                                // L[16 b + j][16 k + i] = U_kb[i][j]; the mirrored block is zero
+                if (WL) {                                                // L[16 b + j][16 k + i] = U_kb[i][j]; the mirrored block is zero
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         Lg[(size_t)(16 * sb[s] + l15) + (size_t)(16 * k + kq + 4 * r) * ldx] = acc[r];
@@ -336,7 +336,8 @@ __global__ __launch_bounds__(256) void k_lm_carry(LmCholArgs a)
 template <int NTM>
 void launch_t(const LmCholArgs& a, hipStream_t st)
 {
-    hipLaunchKernelGGL((k_lm_factor<NTM>), dim3(a.nb), dim3(512), 0, st, a);
+    if (a.write_L) hipLaunchKernelGGL((k_lm_factor<NTM, true>), dim3(a.nb), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_lm_factor<NTM, false>), dim3(a.nb), dim3(512), 0, st, a);
     const int crows = a.carried_rows > 0 ? a.carried_rows : a.cv.ldp;
     hipLaunchKernelGGL((k_lm_carry<NTM>), dim3((a.nb + 7) / 8 * 8 * ((crows + 63) / 64)), dim3(256), 0, st, a);
 }
