@@ -281,30 +281,58 @@ __global__ __launch_bounds__(256) void k_lm_carry(LmCholArgs a)
     double4_f V[NTM];
     double dxa = 0.0;
     double pre[NTM + 1], cn[4];
-    auto fetch = [&](int k) {                                            // tiles (p, k), p < k, then L_kk^-1; the block's rows of P H^T
-#pragma unroll
-        for (int p = 0; p < NTM; ++p) if (p < k) pre[p] = Ug[(size_t)tri_index(NTM, p, k) * 256];
-        pre[NTM] = Ug[(size_t)(NTILES + k) * 256];
+    auto fetch_c = [&](int k, double (&c)[4]) {                          // the block's rows of P H^T for step k
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int o = sMap[16 * k + kq + 4 * r];
-            cn[r] = o >= 0 ? C0[(size_t)o * ldx] : 0.0;
+            c[r] = o >= 0 ? C0[(size_t)o * ldx] : 0.0;
         }
     };
-    auto stash = [&](int k) {
+    auto fetch = [&](int k) {                                            // tiles (p, k), p < k, then L_kk^-1
 #pragma unroll
-        for (int p = 0; p < NTM; ++p) if (p < k) sA[k & 1][p][tid] = pre[p];
-        sA[k & 1][NTM][tid] = pre[NTM];
+        for (int p = 0; p < NTM; ++p) if (p < k) pre[p] = Ug[(size_t)tri_index(NTM, p, k) * 256];
+        pre[NTM] = Ug[(size_t)(NTILES + k) * 256];
+        fetch_c(k, cn);
     };
-    fetch(0);
-    stash(0);
+    // The first PRO steps are too short to hide a memory round trip each (step k is 4 (k + 1) MFMAs): their k + 1 tiles and their
+    // rows of P H^T are all requested up front and staged in buffer 0 (slot k (k + 1) / 2 + p); from step PRO on the tiles of
+    // step k sit in buffer (k - PRO + 1) & 1, requested one step ahead.
+    constexpr int PRO = NTM >= 12 ? 4 : (NTM >= 8 ? 3 : 2);
+    static_assert(NTM >= PRO && PRO * (PRO + 1) / 2 <= NTM + 1, "prologue slots");
+    auto bufidx = [](int k) { return (k - PRO + 1) & 1; };             // step PRO -> buffer 1 (buffer 0 still serves the prologue steps)
+    double cpro[PRO][4];
+    {
+        double ppre[PRO * (PRO + 1) / 2];
+#pragma unroll
+        for (int k = 0; k < PRO; ++k) {
+#pragma unroll
+            for (int p = 0; p <= k; ++p)
+                ppre[k * (k + 1) / 2 + p] = p < k ? Ug[(size_t)tri_index(NTM, p, k) * 256] : Ug[(size_t)(NTILES + k) * 256];
+            fetch_c(k, cpro[k]);
+        }
+#pragma unroll
+        for (int e = 0; e < PRO * (PRO + 1) / 2; ++e) sA[0][e][tid] = ppre[e];
+    }
+    if (PRO < nt) fetch(PRO);
     lds_barrier();
+    // A step's results are stored at the top of the NEXT step, before that step's loads are requested: stores that follow loads in
+    // program order turn the wait for the loads into a full drain of the store queue (one counter for both on gfx9).
+    auto store_y = [&](int k) {
+        if (on) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Y0[(size_t)(16 * k + kq + 4 * r) * ldx] = V[k][r];
+        }
+    };
 #pragma unroll
     for (int k = 0; k < NTM; ++k) {
         if (k < nt) {
-            double4_f acc = { cn[0], cn[1], cn[2], cn[3] }, acc2 = { 0.0, 0.0, 0.0, 0.0 };
-            if (k + 1 < nt) fetch(k + 1);
-            const double (*buf)[256] = sA[k & 1];
+            double4_f acc, acc2 = { 0.0, 0.0, 0.0, 0.0 };
+            if (k < PRO) acc = double4_f{ cpro[k][0], cpro[k][1], cpro[k][2], cpro[k][3] };
+            else acc = double4_f{ cn[0], cn[1], cn[2], cn[3] };
+            if (k > 0) store_y(k - 1);
+            if (k >= PRO && k + 1 < nt) fetch(k + 1);
+            const double (*buf)[256] = k < PRO ? sA[0] + k * (k + 1) / 2 : sA[bufidx(k)];
+            const int tslot = k < PRO ? k : NTM;
 #pragma unroll
             for (int p = 0; p < k; ++p) {
 #pragma unroll
@@ -316,16 +344,19 @@ __global__ __launch_bounds__(256) void k_lm_carry(LmCholArgs a)
             if (k > 1) acc += acc2;
             double4_f y = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[NTM][64 * r + lane], acc[r], y, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[tslot][64 * r + lane], acc[r], y, 0, 0, 0);
             V[k] = y;
-            if (on) {
+            if (dx && on) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    Y0[(size_t)(16 * k + kq + 4 * r) * ldx] = y[r];
-                    if (dx) dxa = fma(y[r], zg[16 * k + kq + 4 * r], dxa);
-                }
+                for (int r = 0; r < 4; ++r) dxa = fma(y[r], zg[16 * k + kq + 4 * r], dxa);
             }
-            if (k + 1 < nt) { stash(k + 1); lds_barrier(); }
+            if (k >= PRO - 1 && k + 1 < nt) {                            // the tiles of step k + 1 into its buffer
+#pragma unroll
+                for (int p = 0; p < NTM; ++p) if (p < k + 1) sA[bufidx(k + 1)][p][tid] = pre[p];
+                sA[bufidx(k + 1)][NTM][tid] = pre[NTM];
+                lds_barrier();
+            }
+            if (k + 1 >= nt) store_y(k);                                 // the last step's own results
         }
     }
     dxa += __shfl_xor(dxa, 16, WAVE);
