@@ -637,16 +637,8 @@ __global__ __launch_bounds__(INFO_NT, 2) void k_info_update(
 // The posterior is written with STREAMING stores: nothing in this kernel re-reads it, and 240 MB of write-allocated lines evict what
 // the next kernels want from L2 / MALL (the snapshot strips, the next frame's inputs).  Measured: apply 0.153 -> 0.144 ms and the
 // rest of the step faster too (propagate 0.051 -> 0.046, gate 0.286 -> 0.276): 0.730 -> 0.698 ms per step.
-#ifdef INGVIO_APPLY_NO_NT
-#define APPLY_STORE(p, v) (*(p) = (v))
-#else
-#define APPLY_STORE(p, v) __builtin_nontemporal_store((v), (p))
-#endif
-#ifdef INGVIO_APPLY_NO_NT          // the prior's tiles (each read once) as streaming loads as well: 0.706 -> 0.693 ms per step
-#define APPLY_LOADP(p) (*(p))
-#else
-#define APPLY_LOADP(p) __builtin_nontemporal_load(p)
-#endif
+#define APPLY_STORE(p, v) NT_STORE(p, v)      // dev_common.h; -DINGVIO_NO_NT builds the ordinary-store variant for A/B runs
+#define APPLY_LOADP(p) NT_LOAD(p)             // the prior's tiles (each read once) as streaming loads as well: 0.706 -> 0.693 ms per step
 template <int NC, int TW>
 __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int nb, int wgpf, const double* __restrict__ Mall, int mstride,
                                                        const double* __restrict__ Pcall, int ystride, const int* __restrict__ m_all,
