@@ -35,8 +35,15 @@ __global__ __launch_bounds__(GATE_FPW * WAVE) __attribute__((amdgpu_waves_per_eu
 
 // Stereo windows up to 16 clones: the gate in difference coordinates of the observations (gate_kernel.h, gate4_body): a
 // 3 (nobs - 1) + 1 bordered system, two 16-row tile rows for an 11-clone window instead of three.  One wave per (feature, filter).
+#ifndef GATE4_WPE             // occupancy window of the gate, waves per SIMD.  Measured (512 filters): max 6 (the default: 100 VGPRs ->
+#define GATE4_WPE 2           // 4 waves) 0.282 ms; forced to 5 (96 VGPRs, 12 B scratch) 0.291; forced to 6 (80 VGPRs, 36 B) 0.323;
+                              // capped at 3 (114 VGPRs) 0.306, at 2: 0.390 - four waves per SIMD is the optimum
+#endif
+#ifndef GATE4_WPE_MAX
+#define GATE4_WPE_MAX 6
+#endif
 template <int CMAX>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 6))) void k_feat_gate4(
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(GATE4_WPE, GATE4_WPE_MAX))) void k_feat_gate4(
     CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out, int* __restrict__ accept_out)
 {
     gate4_body<CMAX>(cv, fv, op, b0, nb, fmax_used, gamma_out, accept_out);
