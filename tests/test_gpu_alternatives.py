@@ -1,0 +1,41 @@
+"""The selectable alternative code paths of libingvio_hip.so (kept for A/B measurements) must stay CORRECT: each is
+switched on through its environment variable in a child process (the switches are read once per process) that runs the parity
+tests covering it.  One toggle per case:
+
+  INGVIO_GATE=3            first-generation gate (k_feat_gate3 / k_feat_gate3_big) instead of the difference-coordinate one
+  INGVIO_INFO_GAUGE=off    full-size symmetric solve (no reduction to difference coordinates of a reference clone)
+  INGVIO_INFO_SOLVE=gj     Gauss-Jordan on A Pcc + s^2 I
+  INGVIO_BIG_SOLVE=regs    large-window solve on the register-resident factorisation (kernels_lmchol.hip) instead of the sweep
+  INGVIO_APPLY_TW=2        k_info_apply with two tile columns per step
+  INGVIO_LM_FRONT=split    landmark update with k_lm_build + k_lm_products (compacting) instead of the fused front
+  INGVIO_LM_SOLVE=sweep    landmark / dense-H update on the Cholesky sweep out of L2 instead of the register-resident solve
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("INGVIO_GATE", "3", ["tests/test_gpu_parity.py", "-k", "test_full_n249_batch_vs_oracle or test_large_window_vs_oracle or test_msckf_small"]),
+    ("INGVIO_INFO_GAUGE", "off", ["tests/test_gpu_parity.py", "-k", "test_full_n249_batch_vs_oracle or test_large_window_vs_oracle or test_window_size_classes"]),
+    ("INGVIO_INFO_SOLVE", "gj", ["tests/test_gpu_parity.py", "-k", "test_full_n249_batch_vs_oracle or test_window_size_classes"]),
+    ("INGVIO_BIG_SOLVE", "regs", ["tests/test_gpu_parity.py", "-k", "test_large_window or test_config5_stress"]),
+    ("INGVIO_APPLY_TW", "2", ["tests/test_gpu_parity.py", "-k", "test_full_n249_batch_vs_oracle or test_window_size_classes or test_consecutive_frames"]),
+    ("INGVIO_LM_FRONT", "split", ["tests/test_landmark_batch.py"]),
+    ("INGVIO_LM_SOLVE", "sweep", ["tests/test_landmark_batch.py"]),
+]
+
+
+@pytest.mark.parametrize("var,value,args", CASES, ids=["%s=%s" % (c[0], c[1]) for c in CASES])
+def test_alternative_path_stays_correct(var, value, args):
+    env = dict(os.environ)
+    env[var] = value
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + args, cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    tail = "\n".join(r.stdout.strip().splitlines()[-15:])
+    assert r.returncode == 0, "%s=%s:\n%s\n%s" % (var, value, tail, r.stderr[-2000:])
+    assert " passed" in tail and " failed" not in tail, tail
