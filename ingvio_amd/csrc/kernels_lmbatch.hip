@@ -334,7 +334,16 @@ __global__ __launch_bounds__(64) void k_lm_rows(CovView cv, LmView lv, LmOpts op
         if (!on) { gamma_out[(size_t)bl * LM_MAX + l] = -1.0; accept_out[(size_t)bl * LM_MAX + l] = 0; }
     }
     const unsigned long long mask = __ballot(on);
-    const int a = __popcll(mask & ((1ull << lane) - 1ull));
+    // candidate order: by anchor clone, then by landmark.  The order of the stacked rows is free (the update is invariant to it); with
+    // the landmarks of a chunk sharing their anchor, k_lm_front's gathers of the anchor's six columns of P coincide for the four lane
+    // groups and repeat from chunk to chunk while the lines are still in L2 (in tracked order the kernel re-read them from HBM:
+    // 814 MiB per launch of 512 filters against 566 for P, P H^T and S once).
+    int a = 0;
+    {
+        const int key = on ? ia * 64 + lane : 0x7fffffff;
+#pragma unroll 8
+        for (int j = 0; j < 64; ++j) a += (__shfl(key, j, WAVE) < key) ? 1 : 0;
+    }
     if (on) {
         lm_rows<true>(lv.pose + (size_t)b * 24, lv.pf + 3 * o, lv.uv + 4 * o, op, Hc + (size_t)a * LMF_HS, Hc + (size_t)a * LMF_HS + 84);   // straight to global (a private array: scratch)
         cand[4 * a] = l; cand[4 * a + 1] = ia; cand[4 * a + 2] = il;
