@@ -2,7 +2,7 @@
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_landmark_batch.py tests/test_landmark_path.py -m gpu -q -x > gpurun_out/gputest_t.log 2>&1
+timeout 1500 python -m pytest tests/test_landmark_batch.py tests/test_landmark_path.py tests/test_host_shim.py tests/test_replay.py -m gpu -q -x > gpurun_out/gputest_t.log 2>&1
 echo "pytest rc=$?"; tail -3 gpurun_out/gputest_t.log | cut -c1-300
 run() { tag=$1; shift; timeout 600 python bench.py "$@" --steps 20 --warmup 5 --no-cpu --no-aux 2>/dev/null | python -c "
 import json,sys
