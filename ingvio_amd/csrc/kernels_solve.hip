@@ -451,55 +451,77 @@ __global__ __launch_bounds__(512) void k_info_solve(
     if (bad) sBad = 1;
     // ---- [M | t] = R2' (R1' D2^-1)^T : tile (i, j), j over the NR1 row tiles of R1' (column NC carries t) ----
     double* Mg = Mall + (size_t)bl * mstride;
-    for (int q = wave; q < NT * NR1; q += NW) {
-        const int i = q / NR1, j = q % NR1;
+    constexpr int NQ = (NT * NR1 + NW - 1) / NW;                     // tiles per wave
+    double4_f accs[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        const int q = wave + NW * u;
         double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
-        for (int kt = i; kt < NT; ++kt) {
-            double af[4], bf[4];
+        if (q < NT * NR1) {
+            const int i = q / NR1, j = q % NR1;
+            for (int kt = i; kt < NT; ++kt) {
+                double af[4], bf[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                af[s] = Y[(16 * i + l15) * LDM + 16 * kt + 4 * s + kq];
-                bf[s] = X[(16 * j + l15) * LDM + 16 * kt + 4 * s + kq];          // B[k'][j'] = (R1' D2^-1)[j][k]
+                for (int s = 0; s < 4; ++s) {
+                    af[s] = Y[(16 * i + l15) * LDM + 16 * kt + 4 * s + kq];
+                    bf[s] = X[(16 * j + l15) * LDM + 16 * kt + 4 * s + kq];          // B[k'][j'] = (R1' D2^-1)[j][k]
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bf[s], acc, 0, 0, 0);
             }
+            const int col = 16 * j + l15;
+            if (RED) {                                            // scattered into the full layout; the reference block follows below
+                const int colF = col + (col >= ref6 ? 6 : 0);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bf[s], acc, 0, 0, 0);
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * i + kq + 4 * r, rowF = row + (row >= ref6 ? 6 : 0);
+                    if (row < NC && col < NC) Mg[(size_t)rowF * MPF + colF] = acc[r];
+                    if (row < NC && col == NC) Mg[(size_t)MPF * MPF + rowF] = acc[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * i + kq + 4 * r;
+                    const double v = (row < NC) ? acc[r] : 0.0;
+                    if (row < MPF && col < MPF) Mg[(size_t)row * MPF + col] = col < NC ? v : 0.0;
+                    if (col == NC && row < MPF) Mg[(size_t)MPF * MPF + row] = v;
+                }
+            }
         }
-        const int col = 16 * j + l15;
-        if (RED) {                                            // scattered into the full layout; the reference block follows below
-            const int colF = col + (col >= ref6 ? 6 : 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * i + kq + 4 * r, rowF = row + (row >= ref6 ? 6 : 0);
-                if (row < NC && col < NC) Mg[(size_t)rowF * MPF + colF] = acc[r];
-                if (row < NC && col == NC) Mg[(size_t)MPF * MPF + rowF] = acc[r];
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * i + kq + 4 * r;
-                const double v = (row < NC) ? acc[r] : 0.0;
-                if (row < MPF && col < MPF) Mg[(size_t)row * MPF + col] = col < NC ? v : 0.0;
-                if (col == NC && row < MPF) Mg[(size_t)MPF * MPF + row] = v;
-            }
-        }
+        accs[u] = acc;
     }
-    __syncthreads();
     if (RED) {
-        // the reference clone's block row and column: minus the sums over the other clones' blocks, component by component
+        // The reference clone's block row and column: minus the sums over the other clones' blocks, component by component -
+        // taken from a copy of [Mr | tr] in LDS (X is free once every wave has its tiles; reading the sums back from the global
+        // M just written cost two store -> load round trips behind workgroup barriers: 38 k of the kernel's 150 k cycles).
+        lds_barrier();
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int q = wave + NW * u;
+            if (q < NT * NR1) {
+                const int i = q / NR1, j = q % NR1, col = 16 * j + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * i + kq + 4 * r;
+                    if (col < LDM) X[row * LDM + col] = accs[u][r];
+                }
+            }
+        }
+        lds_barrier();
         for (int e = tid; e < 2 * 6 * (MPF + 1); e += NTH) {
             const int side = e / (6 * (MPF + 1)), q = e - side * 6 * (MPF + 1), k = q / (MPF + 1), J = q - k * (MPF + 1);
             const bool inref = J >= ref6 && J < ref6 + 6;
             if (J == MPF) {                                   // t (row task only)
                 if (side == 0) {
                     double s = 0.0;
-                    for (int c = 0; c < CF; ++c) if (6 * c != ref6) s += Mg[(size_t)MPF * MPF + 6 * c + k];
+                    for (int cr = 0; cr < CF - 1; ++cr) s += X[(6 * cr + k) * LDM + NC];
                     Mg[(size_t)MPF * MPF + ref6 + k] = -s;
                 }
             } else if (!inref) {
                 double s = 0.0;
                 if (J < NCF) {
-                    for (int c = 0; c < CF; ++c)
-                        if (6 * c != ref6) s += side == 0 ? Mg[(size_t)(6 * c + k) * MPF + J] : Mg[(size_t)J * MPF + 6 * c + k];
+                    const int Jr = J < ref6 ? J : J - 6;
+                    for (int cr = 0; cr < CF - 1; ++cr) s += side == 0 ? X[(6 * cr + k) * LDM + Jr] : X[Jr * LDM + 6 * cr + k];
                 }
                 if (side == 0) Mg[(size_t)(ref6 + k) * MPF + J] = -s; else Mg[(size_t)J * MPF + ref6 + k] = -s;
             }
@@ -513,12 +535,12 @@ __global__ __launch_bounds__(512) void k_info_solve(
                 Mg[(size_t)(NCF + e / (MPF - NCF)) * MPF + NCF + e % (MPF - NCF)] = 0.0;
             if (tid < MPF - NCF) Mg[(size_t)MPF * MPF + NCF + tid] = 0.0;
         }
-        __syncthreads();
-        if (tid < 36) {                                       // corner: from the reference rows just written
+        if (tid < 36) {                                       // corner: + the sum over all the other clones' blocks
             const int k = tid / 6, l = tid - 6 * k;
             double s = 0.0;
-            for (int c = 0; c < CF; ++c) if (6 * c != ref6) s += Mg[(size_t)(ref6 + k) * MPF + 6 * c + l];
-            Mg[(size_t)(ref6 + k) * MPF + ref6 + l] = -s;
+            for (int cr = 0; cr < CF - 1; ++cr)
+                for (int c2 = 0; c2 < CF - 1; ++c2) s += X[(6 * cr + k) * LDM + 6 * c2 + l];
+            Mg[(size_t)(ref6 + k) * MPF + ref6 + l] = s;
         }
     }
     dbg_stamp(6);

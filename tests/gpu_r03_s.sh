@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-for V in default g3 g2; do
+for V in default pnt default pnt; do
 L=""; if [ $V != default ]; then L=$PWD/build_var/$V/libingvio_hip.so; fi
 INGVIO_HIP_LIB=$L timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu --no-aux 2>/dev/null | python -c "
 import json,sys
