@@ -45,6 +45,7 @@ struct ingvio_ctx {
     std::string err;
     // covariances
     double *Pbase, *Psnap;
+    size_t pp = 0;                 // doubles between consecutive filters' covariances (ldp * ldp + pad)
     int *d_cur, *d_n, *d_n_snap;
     std::vector<int> h_n, h_cur, h_n_snap;
     bool has_snap;
@@ -157,7 +158,7 @@ int dalloc(ingvio_ctx* c, T** p, size_t count)
 CovView view(ingvio_ctx* c)
 {
     CovView v;
-    v.Pbase = c->Pbase; v.cur = c->d_cur; v.n = c->d_n; v.ldp = c->ldp; v.B = c->d.batch;
+    v.Pbase = c->Pbase; v.cur = c->d_cur; v.n = c->d_n; v.ldp = c->ldp; v.B = c->d.batch; v.pstride = c->pp;
     ++c->mut_seq;
     return v;
 }
@@ -551,7 +552,14 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     }
     memset(c->prof_ms, 0, sizeof c->prof_ms); memset(c->prof_calls, 0, sizeof c->prof_calls);
     c->h_n.assign(B, 0); c->h_cur.assign(B, 0); c->h_n_snap.assign(B, 0); c->st_marg.assign(B, -1); c->st_cidx_hi.assign(B, -1);
-    const size_t pp = (size_t)c->ldp * c->ldp;
+    // Consecutive filters' covariances must not sit a power of two apart: with ldp = 256 the stride would be 512 KB, and the SAME
+    // element of every filter (the window block P_cc every gate wave of a filter reads, 64 filters per XCD) would fall into the same
+    // L2 sets.  67 cache lines of pad walk the filters through the sets.  (Precaution: one default bench run showed the gate at
+    // 1.30 ms instead of 0.28 in its config-3 pass; tests/gpu_alloc_sensitivity.py could not reproduce that with either layout -
+    // six contexts per process, perturbed allocations, 0.289 - 0.294 ms for both -, so the pad is not the proven cure.)
+    static const bool no_pad = [] { const char* e = getenv("INGVIO_P_PAD"); return e && e[0] == '0'; }();
+    c->pp = (size_t)c->ldp * c->ldp + (no_pad ? 0 : 67 * 16);
+    const size_t pp = c->pp;
     const int cm = desc->c_max, fm = desc->f_max;
     int rc = 0;
     rc |= dalloc(c, &c->Pbase, 2 * (size_t)B * pp);
@@ -634,7 +642,7 @@ int ingvio_cov_set(ingvio_ctx* c, int b, const double* P, int ld, int n)
 {
     if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b, 1) || !P || n < 0 || n > c->d.n_max || ld < n) return INGVIO_E_ARG;
-    double* dst = c->Pbase + ((size_t)c->h_cur[b] * c->d.batch + b) * (size_t)c->ldp * c->ldp;
+    double* dst = c->Pbase + ((size_t)c->h_cur[b] * c->d.batch + b) * c->pp;
     if (n) HIPCHK(c, hipMemcpy2DAsync(dst, 8 * (size_t)c->ldp, P, 8 * (size_t)ld, 8 * (size_t)n, n, hipMemcpyHostToDevice, c->st));
     c->h_n[b] = n;
     HIPCHK(c, hipMemcpyAsync(c->d_n + b, &c->h_n[b], sizeof(int), hipMemcpyHostToDevice, c->st));
@@ -647,7 +655,7 @@ int ingvio_cov_get(ingvio_ctx* c, int b, double* P, int ld)
     if (check_range(c, b, 1) || !P) return INGVIO_E_ARG;
     const int n = c->h_n[b];
     if (ld < n) return INGVIO_E_ARG;
-    const double* src = c->Pbase + ((size_t)c->h_cur[b] * c->d.batch + b) * (size_t)c->ldp * c->ldp;
+    const double* src = c->Pbase + ((size_t)c->h_cur[b] * c->d.batch + b) * c->pp;
     if (n) HIPCHK(c, hipMemcpy2DAsync(P, 8 * (size_t)ld, src, 8 * (size_t)c->ldp, 8 * (size_t)n, n, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
     HIPCHK(c, hipGetLastError());
@@ -1547,7 +1555,7 @@ static int run_dense_update(ingvio_ctx* c, int b0, int nb, double var, int r_kin
 {
     auto& w = c->dw;
     const int mc = w.m_cap, n_cap = c->d.n_max, B = c->d.batch;
-    const size_t pp = (size_t)c->ldp * c->ldp;
+    const size_t pp = c->pp;
     double *Hd = w.Hd + (size_t)b0 * w.hstride, *X = w.X + (size_t)b0 * w.xstride, *Y = w.Y + (size_t)b0 * w.xstride;
     const int* act = w.m + b0;
     if (!products_done) {

@@ -6,22 +6,23 @@
 #define WAVE 64
 
 // Device view of a context: B filters, two ping-pong covariance buffers per filter.
-// Filter b's current covariance = Pbase + (cur[b] * B + b) * ldp * ldp, column-major, ld = ldp.
+// Filter b's current covariance = Pbase + (cur[b] * B + b) * pstride, column-major, ld = ldp.
 struct CovView {
     double* Pbase;
     int* cur;     // [B] 0/1: which ping-pong half is live
     int* n;       // [B] current state dimension
     int ldp;
     int B;
+    size_t pstride;   // doubles between consecutive filters' covariances: ldp * ldp + a pad that is NOT a power of two (see ingvio_ctx_create)
 };
 
 __device__ __forceinline__ double* cov_ptr(const CovView& v, int b)
 {
-    return v.Pbase + ((size_t)v.cur[b] * v.B + b) * (size_t)v.ldp * v.ldp;
+    return v.Pbase + ((size_t)v.cur[b] * v.B + b) * v.pstride;
 }
 __device__ __forceinline__ double* cov_alt_ptr(const CovView& v, int b)
 {
-    return v.Pbase + ((size_t)(1 - v.cur[b]) * v.B + b) * (size_t)v.ldp * v.ldp;
+    return v.Pbase + ((size_t)(1 - v.cur[b]) * v.B + b) * v.pstride;
 }
 
 // MSCKF frame inputs, SoA over the batch (strides are the context maxima).

@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void k_snapshot(CovView cv, double* __restrict
 {
     const int b = blockIdx.y, tid = threadIdx.x, n = cv.n[b], ld = cv.ldp;
     const double* src = cov_ptr(cv, b);
-    double* dst = snap + (size_t)b * ld * ld;
+    double* dst = snap + (size_t)b * cv.pstride;
     for (int jj = 0; jj < MARG_COLS; ++jj) {
         const int j = blockIdx.x * MARG_COLS + jj;
         if (j >= n) break;
@@ -481,8 +481,8 @@ __global__ __launch_bounds__(256) void k_snapshot(CovView cv, double* __restrict
 __global__ __launch_bounds__(256) void k_restore(CovView cv, const double* __restrict__ snap, const int* __restrict__ n_snap)
 {
     const int b = blockIdx.y, tid = threadIdx.x, n = n_snap[b], ld = cv.ldp;
-    const double* src = snap + (size_t)b * ld * ld;
-    double* dst = cv.Pbase + (size_t)b * ld * ld;          // half 0
+    const double* src = snap + (size_t)b * cv.pstride;
+    double* dst = cv.Pbase + (size_t)b * cv.pstride;          // half 0
     for (int jj = 0; jj < MARG_COLS; ++jj) {
         const int j = blockIdx.x * MARG_COLS + jj;
         if (j >= n) break;
@@ -499,8 +499,8 @@ __global__ __launch_bounds__(256) void k_restore_strips(CovView cv, const double
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r == 0) { cv.cur[b] = 0; cv.n[b] = n; }           // nothing in this kernel reads cur / n
     if (r >= n) return;
-    const double* src = snap + (size_t)b * ld * ld;
-    double* dst = cv.Pbase + (size_t)b * ld * ld;          // half 0
+    const double* src = snap + (size_t)b * cv.pstride;
+    double* dst = cv.Pbase + (size_t)b * cv.pstride;          // half 0
     int A[NA_MAX], na = 15;
 #pragma unroll
     for (int a = 0; a < 15; ++a) A[a] = a;
