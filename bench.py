@@ -37,9 +37,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector == FP64 MFMA peak (datasheet; issue rates: tests/micro/issue_rates.hip)
+FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector == FP64 MFMA peak (datasheet; issue rates: tools/micro/issue_rates.hip)
 HBM_PEAK_GBS = 8000.0
 COUNTERS_JSON = os.path.join(ROOT, "profiles", "counters.json")
+DETAIL_JSON = os.path.join(ROOT, "bench_detail.json")
 
 
 class LazyCov:
@@ -154,16 +155,29 @@ def algorithmic_bytes(N, k_imu, F, C):
 # ---- counters committed under profiles/ --------------------------------------------------------------------------------
 def load_counters(path, key):
     """profiles/counters.json: {workloads: {key: {source, kernels: {name: {counter: per-launch average}}}}} written by
-    tests/pmc_summary.py from rocprofv3 --pmc passes.  Returns (kernels dict or None, source note)."""
+    tools/pmc_summary.py from rocprofv3 --pmc passes.  Returns (kernels dict or None, source note)."""
     try:
         with open(path) as f:
             J = json.load(f)
     except (OSError, ValueError):
-        return None, "no %s" % os.path.relpath(path, ROOT)
+        return None, "no %s" % os.path.relpath(path, ROOT), None
     w = J.get("workloads", {}).get(key)
     if w is None:
-        return None, "%s holds no workload %r (has: %s)" % (os.path.relpath(path, ROOT), key, ", ".join(sorted(J.get("workloads", {}))))
-    return w.get("kernels", {}), "%s[%s] <- %s" % (os.path.relpath(path, ROOT), key, w.get("source", "?"))
+        return None, "%s holds no workload %r" % (os.path.relpath(path, ROOT), key), None
+    return w.get("kernels", {}), "%s[%s]" % (os.path.relpath(path, ROOT), key), w.get("build")
+
+
+def stale_kernels(kernel_names, recorded_tu, live_build):
+    """Kernels of `kernel_names` whose committed counters do NOT belong to the running library: the workload's counters were
+    folded (tools/pmc_summary.py) with the per-translation-unit hashes of the library that produced them; a kernel is current
+    when the hash of ITS translation unit (text + included headers + flags, ingvio_build_id()) is the one recorded.  Counters
+    without a record (collected before round 4) are stale by definition."""
+    out = []
+    for k in kernel_names:
+        tu = (live_build or {}).get("kernels", {}).get(k)
+        if recorded_tu is None or tu is None or recorded_tu.get(tu) != live_build["tu"].get(tu):
+            out.append(k)
+    return out
 
 
 def executed_fp64_flops(c):
@@ -219,10 +233,12 @@ STAGE_KERNELS_BIG = {                                                      # win
 
 
 def counters_for(counters, name, big):
-    if counters is None:
-        return None
+    """-> (summed counters of the stage's kernels or None, the kernels they belong to)."""
     table = STAGE_KERNELS_BIG if big and name in STAGE_KERNELS_BIG else STAGE_KERNELS
-    for cand in table.get(name, ((name,),)):
+    cands = table.get(name, ((name,),))
+    if counters is None:
+        return None, cands[0]
+    for cand in cands:
         if all(k in counters for k in cand):
             out = {}
             for k in cand:
@@ -230,8 +246,19 @@ def counters_for(counters, name, big):
                 for c, v in counters[k].items():
                     if not c.startswith("_"):
                         out[c] = out.get(c, 0.0) + v * mult
-            return out
-    return None
+            return out, cand
+    return None, cands[0]
+
+
+def kernel_that_ran(stage, cand, C, stereo=True):
+    """The kernel rocprofv3 sees for a profile slot (slots are named after the stage)."""
+    name = "+".join(cand)
+    if stage == "k_feat_gate3":
+        if not stereo:
+            return "k_feat_gate3%s<%d>" % ("_big" if C > 16 else "", C)
+        cls = 6 if C <= 6 else 11 if C <= 11 else 16 if C <= 16 else 24 if C <= 24 else 32 if C <= 32 else 36      # launch_factored / launch_bigwin classes
+        return "%s<%d>" % (cand[0], cls)
+    return name
 
 
 def cpu_baseline(ctx, steps, frames, n_prior, ld, quick=False):
@@ -357,6 +384,8 @@ def parse_args():
                          "receive rows every frame (LandmarkUpdate.cpp:32-149, batched on the device between the MSCKF update and "
                          "the marginalisation)")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary config-3 / config-5 passes of the default run")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-filter latency figures (C++ shim stream) of the default run")
+    ap.add_argument("--detail", default=DETAIL_JSON, help="where the full result (per-kernel tables, notes) is written")
     args = ap.parse_args()
     if args.literal:
         args.state = "literal"
@@ -377,7 +406,7 @@ def run_workload(args, grp, aux=False):
     n_gnss = 0 if args.state == "literal" else 6
     n_lm = 0 if args.state != "nominal" else (200 if big else 52)
     N = 21 + n_gnss + 3 * n_lm + 6 * C
-    ctx = capi.Context(batch=B, n_max=((N + 15) // 16) * 16, c_max=C, f_max=F, m_max=64, device=local_rank)
+    ctx = capi.Context(batch=B, n_max=((N + 15) // 16) * 16, c_max=C, f_max=F, m_max=64, device=grp.device_index)
     ctx.set_method(args.method)
     ld = ctx.ldp
     t_build = time.perf_counter()
@@ -457,8 +486,14 @@ def run_workload(args, grp, aux=False):
     if real_lm:
         dxl, lm_rows, lacc, lgam, lst = ctx.landmark_fetch()
         ok = ok and bool(np.isfinite(dxl).all() and (lst == 0).all() and (lm_rows > 0).all())
+    # N > 1: every rank cross-checks its FIRST filter against the oracle (covariance, accept mask) - a rank whose device or
+    # library misbehaves shows up in the line, not only rank 0's
+    rank_par = [0.0, 1.0]
+    if world > 1 and not real_lm:
+        rp = oracle_parity_sample(ctx, one_step, steps, frames, gnss, infos[0]["n_prior"], ld, N, F, 1)
+        rank_par = [rp["max_rel_cov_err"], float(rp["accept_mask_equal"])]
     # one end-of-run gather of per-rank summaries
-    summ = grp.gather_summaries([float(n_acc.sum()), float(np.abs(dx).sum()), float(ok)])
+    summ = grp.gather_summaries([float(n_acc.sum()), float(np.abs(dx).sum()), float(ok)] + rank_par)
     ok = bool(summ[:, 2].all())
 
     out = None
@@ -467,14 +502,20 @@ def run_workload(args, grp, aux=False):
         per_kernel, total_flops = algorithmic_flops(F_used, F, C, N, synth.IMU_PER_FRAME)
         bytes_k = algorithmic_bytes(N, synth.IMU_PER_FRAME, F, C)
         wkey = "c%d_B%d_F%d_C%d_N%d" % (args.config, B, F, C, N) + ("_lmreal" if real_lm else "")
-        counters, csrc = load_counters(args.counters, wkey)
+        counters, csrc, rec_build = load_counters(args.counters, wkey)
+        live_build = capi.build_id()
         kernels = {}
         for name, (ms, calls) in prof.items():
             if calls == 0:
                 continue
             avg = ms / calls
-            e = dict(avg_ms=avg, calls=calls)
-            c = counters_for(counters, name, C > 16)
+            c, cand = counters_for(counters, name, C > 16)
+            e = dict(avg_ms=avg, calls=calls, kernel=kernel_that_ran(name, cand, C))
+            if c is not None:
+                st = stale_kernels(cand, rec_build, live_build)
+                if st:                                  # counters of another build of this kernel: no price, say so
+                    e["counters_stale"] = st
+                    c = None
             ex = executed_fp64_flops(c)
             if ex is not None:
                 e["executed_fp64_flop_per_launch"] = ex["total"]
@@ -500,7 +541,7 @@ def run_workload(args, grp, aux=False):
             k = kernels[dom_name]
             if "executed_tflops" in k:
                 mf = k["executed_fp64_mfma_share"]
-                roofline = dict(kernel=dom_name, bound="mfma" if mf > 0.5 else "valu", achieved=k["executed_tflops"], peak=FP64_PEAK_TFLOPS,
+                roofline = dict(kernel=k["kernel"], stage=dom_name, bound="mfma" if mf > 0.5 else "valu", achieved=k["executed_tflops"], peak=FP64_PEAK_TFLOPS,
                                 unit="TFLOP/s", frac=k["frac_fp64_peak"],
                                 traffic=k.get("hbm_bytes_per_launch", {}).get("total"), avg_launch_ms=k["avg_ms"],
                                 launches_timed=k["calls"], executed_fp64_flop_per_launch=k["executed_fp64_flop_per_launch"],
@@ -518,16 +559,26 @@ def run_workload(args, grp, aux=False):
                                      "SQ_ACTIVE_INST_VALU), useful_frac = (VALU operations x lane_utilisation + matrix-core "
                                      "operations) / time / peak: the executed figure counts masked-off lanes, this one does not")
             else:
-                roofline = dict(kernel=dom_name, bound="valu", achieved=None, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=None,
+                roofline = dict(kernel=k["kernel"], stage=dom_name, bound="valu", achieved=None, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=None,
                                 traffic=None, avg_launch_ms=k["avg_ms"], launches_timed=k["calls"],
+                                counters_stale=bool(k.get("counters_stale")),
                                 algorithmic=dict(tflops=k.get("algorithmic_tflops"), flop_per_launch=k.get("algorithmic_flop_per_launch")),
                                 counters=csrc,
-                                note="no committed SQ counters for this workload: the executed-operation count, and with it the "
-                                     "achieved fraction, is unknown (collect with tests/gpu_counters.sh)")
+                                note=("the committed SQ counters of this kernel were collected on ANOTHER build of its translation "
+                                      "unit (%s): not used" % ", ".join(k["counters_stale"])) if k.get("counters_stale") else
+                                     "no committed SQ counters for this workload: the executed-operation count, and with it the "
+                                     "achieved fraction, is unknown (collect with tools/gpu_counters.sh)")
         cpu, parity = None, None
+        if world > 1 and not real_lm:
+            parity = dict(sample=world, filters="filter 0 of every rank", max_rel_cov_err=float(summ[:, 3].max()),
+                          per_rank_rel_cov_err=[float(x) for x in summ[:, 3]], accept_mask_equal=bool(summ[:, 4].all()))
+        oracle_1t = None
         if aux and not real_lm:
             # auxiliary workload: no CPU timing, but the same in-run cross-check against the oracle on a strided sample
+            t_or = time.perf_counter()
             parity = oracle_parity_sample(ctx, one_step, steps, frames, gnss, infos[0]["n_prior"], ld, N, F, 2 if big else 8)
+            # (python-side structure packing included: an upper bound of the oracle's single-thread update time, for the latency line)
+            oracle_1t = (time.perf_counter() - t_or) / parity["sample"] * 1e3
         if world == 1 and not args.no_cpu and not real_lm and not aux:      # the C oracle's frame has no landmark update: parity of that path is tests/test_landmark_batch.py
             cpu, (P1, n1, dx1, acc1, S) = cpu_baseline(ctx, steps, frames, infos[0]["n_prior"], ld, quick=args.quick_cpu)
             ctx.frame_run(restore_prior=True)
@@ -598,8 +649,10 @@ def run_workload(args, grp, aux=False):
                     tot += e["executed_fp64_flop_per_launch"]
                 elif name not in ("restore", "k_marginalize"):
                     missing.append(name)
+            complete = not missing                       # a kernel without current counters makes the sum a lower bound only
             step_exec = dict(executed_fp64_flop_per_step=tot, tflops=tot / (elapsed / args.steps) / 1e12,
-                             frac_fp64_peak=tot / (elapsed / args.steps) / 1e12 / FP64_PEAK_TFLOPS, kernels_without_counters=missing)
+                             frac_fp64_peak=tot / (elapsed / args.steps) / 1e12 / FP64_PEAK_TFLOPS if complete else None,
+                             kernels_without_current_counters=missing)
         out = dict(
             metric="ekf_updates_per_sec", value=updates / elapsed, unit="updates/s", n_gpus=world, steps=args.steps,
             warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak",
@@ -614,7 +667,7 @@ def run_workload(args, grp, aux=False):
             ms_per_update=elapsed / args.steps * 1e3 / B, per_rank_ms_per_step=per_rank_ms, per_rank_spread=rank_spread, rank_balance_ok=bool(rank_spread <= 0.05), accepted_per_filter=F_used, results_finite=ok,
             algorithmic_flops_per_update=total_flops, whole_step_executed=step_exec,
             method=args.method, roofline=roofline, cpu_baseline=cpu, parity_vs_oracle=parity, as_written_cap20=aw, host_handover=handover,
-            kernels=kernels,
+            kernels=kernels, oracle_update_ms_upper_bound=oracle_1t,
             kernels_note="per-kernel avg_ms: separate untimed pass of 3 steps with an event pair around every launch; the "
                          "roofline kernel's avg_ms is from the timed region; executed_* and hbm_* come from the committed PMC passes "
                          "(%s)" % csrc, setup_s=t_build)
@@ -622,14 +675,124 @@ def run_workload(args, grp, aux=False):
     return out
 
 
+REPLAY_TOOL = os.path.join(ROOT, "ingvio_amd", "lib", "ingvio_replay")
+LATENCY_STREAMS = {      # SynthStream.h specs: every `life` frames a whole cohort of tracks is lost -> one RemoveLost update over all of them
+    "config2": "feats=150,clones=11,life=10,cohort=1,frames=75,key=1",
+    "config5": "feats=300,clones=30,life=29,cohort=1,frames=125,key=1",
+}
+
+
+def latency_b1(args):
+    """Single-filter latency: ONE filter driven through the C++ shim's callback surface
+    (IngvioFilter::callbackIMU / callbackStereoFrame, IngvioFilter.cpp:252-379: propagate + clone, RemoveLost update, key-frame
+    update, re-anchoring, marginalisation - as the reference sequences them) on a synthetic stream, wall time per camera
+    callback measured inside tools/ingvio_replay.cpp.  `heavy` = the frames on which a whole cohort of tracks is lost (150 / 300
+    features with up to window - 1 observations each in one RemoveLost update); `lifted` runs RemoveLost without the reference's
+    accepted-feature cap of 20 and with top-n compression (quirks Q3 / Q2 off), `as_written` with both as in the reference."""
+    import subprocess
+    if not os.path.exists(REPLAY_TOOL):
+        return dict(error="ingvio_replay not built")
+    out = {}
+    for name, spec in LATENCY_STREAMS.items():
+        e = {}
+        for label, sets in (("lifted", ["--set", "hip_max_valid_ids: 0", "--set", "hip_compress_rule: 1"]), ("as_written", [])):
+            try:
+                r = subprocess.run([REPLAY_TOOL, "--synth", spec, "--time"] + sets, capture_output=True, text=True, timeout=300)
+            except subprocess.TimeoutExpired:
+                e[label] = dict(error="timeout"); continue
+            line = [l for l in r.stdout.splitlines() if l.startswith("LATENCY")]
+            if r.returncode != 0 or not line:
+                e[label] = dict(error=(r.stderr or r.stdout)[-200:]); continue
+            kv = dict(x.split("=") for x in line[0].split()[1:])
+            e[label] = dict(heavy_ms=float(kv["heavy_median_ms"]), heavy_min_ms=float(kv["heavy_min_ms"]), heavy_frames=int(kv["heavy_frames"]),
+                            heavy_accepted=int(kv["heavy_accepted"]), heavy_rows=int(kv["heavy_rows"]), other_ms=float(kv["other_median_ms"]),
+                            all_ms=float(kv["median_ms"]), frames=int(kv["timed"]), final_pos_err_m=float(kv["final_pos_err_m"]))
+        e["stream"] = spec
+        out[name] = e
+    return out
+
+
 AUX_KEYS = ("value", "unit", "ms_per_step", "ms_per_update", "steps", "warmup", "config", "accepted_per_filter", "results_finite",
-            "roofline", "whole_step_executed", "parity_vs_oracle", "kernels", "setup_s")
+            "roofline", "whole_step_executed", "parity_vs_oracle", "kernels", "setup_s", "oracle_update_ms_upper_bound")
+LINE_LIMIT = 6000                        # the driver keeps the last ~8 KB of stdout: the final line must fit with room to spare
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def _rnd(x, sig=6):
+    """Floats to `sig` significant digits (the line is for a parser and a reader, not for bit-exact replay)."""
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x)) if np.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _rnd(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_rnd(v, sig) for v in x]
+    return x
+
+
+def compact_line(full):
+    """The ONE JSON line the driver parses, from the full result dict: the contract's keys, `roofline` and `cpu_baseline` reduced
+    to their figures, a compact `aux_configs`; per-kernel tables, notes, the host hand-over and the as-written figures stay in
+    bench_detail.json.  VERDICT r03 #1: the round-3 line (22 KB) no longer fitted the driver's stdout tail."""
+    out = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data", "ms_per_update", "per_rank_ms_per_step", "rank_balance_ok",
+                       "accepted_per_filter", "results_finite"))
+    out["config"] = _pick(full.get("config"), ("workload", "baseline_config", "filters_per_gpu", "feats", "clones", "state_dim",
+                                               "imu_steps", "parallelism"))
+    rl = full.get("roofline")
+    if rl is not None:
+        r = _pick(rl, ("kernel", "bound", "achieved", "peak", "unit", "frac", "useful_frac", "traffic", "avg_launch_ms",
+                       "launches_timed", "counters_stale", "counters"))
+        r["executed_flop_per_launch"] = rl.get("executed_fp64_flop_per_launch")
+        r["algorithmic_flop_per_launch"] = (rl.get("algorithmic") or {}).get("flop_per_launch")
+        out["roofline"] = r
+    ws = full.get("whole_step_executed")
+    if ws is not None:
+        out["whole_step_frac_fp64_peak"] = ws.get("frac_fp64_peak")
+    cb = full.get("cpu_baseline")
+    if cb is not None:
+        c = _pick(cb, ("value", "unit", "cores", "kind"))
+        c["sample"] = "oracle/ingvio_oracle.c on the bench's own frames; value: one filter per thread, one_thread: 1 filter, 1 thread"
+        c["one_thread"] = _pick(cb.get("one_thread"), ("ms_median", "ms_p95", "timed"))
+        out["cpu_baseline"] = c
+    else:
+        out["cpu_baseline"] = None
+    out["parity_vs_oracle"] = _pick(full.get("parity_vs_oracle"), ("sample", "max_rel_cov_err", "accept_mask_equal", "max_rel_dx_err",
+                                                                   "per_rank_rel_cov_err"))
+    lat = full.get("latency_b1_ms")
+    if lat is not None:
+        # one filter, C++ shim callbacks, ms per camera callback: heavy = a RemoveLost update over a whole lost cohort (cap lifted /
+        # as written: cap 20, all rows kept), other = the frames in between; the oracle's single-thread update time beside it
+        cl = {}
+        for k, e in lat.items():
+            if not isinstance(e, dict):
+                continue
+            c = {}
+            for label in ("lifted", "as_written"):
+                v = e.get(label) or {}
+                c[label] = _pick(v, ("heavy_ms", "heavy_accepted", "other_ms", "error"))
+            c["oracle_1thread_update_ms"] = e.get("oracle_1thread_update_ms")
+            cl[k] = c
+        out["latency_b1_ms"] = cl
+    if full.get("aux_configs"):
+        out["aux_configs"] = {
+            k: dict(value=v.get("value"), ms_per_step=v.get("ms_per_step"), workload=(v.get("config") or {}).get("workload"),
+                    roofline_kernel=(v.get("roofline") or {}).get("kernel"), roofline_frac=(v.get("roofline") or {}).get("frac"),
+                    max_rel_cov_err=(v.get("parity_vs_oracle") or {}).get("max_rel_cov_err"),
+                    accept_mask_equal=(v.get("parity_vs_oracle") or {}).get("accept_mask_equal"))
+            for k, v in full["aux_configs"].items()}
+    out["detail"] = "bench_detail.json (per-kernel table, notes, host hand-over, as-written cap-20 figures)"
+    line = json.dumps(_rnd(out))
+    assert len(line) < LINE_LIMIT, "bench line %d chars >= %d: move keys to bench_detail.json" % (len(line), LINE_LIMIT)
+    return line
 
 
 def main():
     args = parse_args()
     from ingvio_amd.parallel import Group
-    grp = Group()                                  # RCCL ("nccl") when WORLD_SIZE > 1
+    grp = Group()                                  # RCCL ("nccl") when WORLD_SIZE > 1 (INGVIO_DIST_BACKEND=gloo: shared-device test)
     out = run_workload(args, grp, aux=False)
     # BASELINE configs 3 and 5 on the same clock: after the headline measurement the default single-GPU run
     # makes a short pass over each and reports it under `aux_configs` (same steps / warm-up, no CPU timing, an in-run oracle
@@ -642,8 +805,20 @@ def main():
             r = run_workload(a, grp, aux=True)
             aux["config%d" % cfg] = {k: r[k] for k in AUX_KEYS if k in r}
         out["aux_configs"] = aux
+        if not args.no_latency:
+            lat = latency_b1(args)
+            if isinstance(lat.get("config2"), dict) and out.get("cpu_baseline"):
+                lat["config2"]["oracle_1thread_update_ms"] = out["cpu_baseline"]["one_thread"]["ms_median"]
+            if isinstance(lat.get("config5"), dict):
+                lat["config5"]["oracle_1thread_update_ms"] = aux["config5"].get("oracle_update_ms_upper_bound")
+            out["latency_b1_ms"] = lat
     if grp.rank == 0:
-        print(json.dumps(out))
+        try:
+            with open(args.detail, "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError as e:                       # read-only checkout: the line still goes out
+            print("bench.py: could not write %s: %s" % (args.detail, e), file=sys.stderr)
+        print(compact_line(out))
     grp.close()
 
 

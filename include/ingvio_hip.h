@@ -67,6 +67,10 @@ void* ingvio_ctx_stream(ingvio_ctx* ctx);             /* the hipStream_t all ker
 const char* ingvio_last_error(ingvio_ctx* ctx);
 int ingvio_ldp(ingvio_ctx* ctx);                      /* leading dimension of the device P buffers  */
 int ingvio_f_max(ingvio_ctx* ctx);                    /* feature capacity: length of the accepted[] arrays */
+/* Identity of the device code this library was built from (no reference counterpart): a JSON string
+ * {"tu": {translation unit: hash of its text + headers + flags}, "kernels": {kernel: translation unit}} written by
+ * ingvio_amd/build.py.  Profile counters are stored with it; bench.py prices a kernel only with counters of the same build. */
+const char* ingvio_build_id(void);
 
 /* initStateAndCov / getFullCov (State.cpp:126-167, StateManager.cpp:121-126). cov_get synchronises. */
 int ingvio_cov_set(ingvio_ctx* ctx, int b, const double* P, int ld, int n);

@@ -34,11 +34,66 @@ def _all_deps(dirs):
 EXTRA_FLAGS = {"kernels_bigwin.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
+def source_build_id():
+    """Identity of the DEVICE code a libingvio_hip.so is built from: {"tu": {file: sha1 of the translation unit's own text + the
+    headers it includes (transitively, csrc/ and include/ingvio_hip.h) + its extra flags}, "kernels": {__global__ name: file}}.  build_hip() embeds it in the
+    library (ingvio_build_id()); tools/pmc_summary.py stores it beside the counters it folds, and bench.py refuses to price a
+    kernel with counters that were collected on another build of that kernel's translation unit."""
+    import hashlib
+    import re
+    inc_dir = os.path.join(os.path.dirname(HERE), "include")
+    texts = {f: open(os.path.join(CSRC, f), "rb").read() for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))}
+    texts["ingvio_hip.h"] = open(os.path.join(inc_dir, "ingvio_hip.h"), "rb").read()
+    inc_pat = re.compile(rb'#include\s+"([^"]+)"')
+
+    def closure(f, seen):
+        for m in inc_pat.finditer(texts[f]):
+            h = os.path.basename(m.group(1).decode())
+            if h in texts and h not in seen:
+                seen.add(h); closure(h, seen)
+        return seen
+    tu, kernels = {}, {}
+    for src in HIP_SOURCES:
+        h = hashlib.sha1(texts[src])
+        for hd in sorted(closure(src, set())):
+            h.update(hd.encode()); h.update(texts[hd])
+        h.update(" ".join(EXTRA_FLAGS.get(src, [])).encode())
+        tu[src] = h.hexdigest()[:16]
+    # kernels defined in a header belong to every translation unit that instantiates them: attributed to the first .hip that
+    # includes the header (good enough: a header change flips every hash anyway)
+    pat = re.compile(rb"__global__[^;{]{0,300}?\bvoid\s+(k_[A-Za-z0-9_]+)\s*\(", re.S)
+    for f, t in texts.items():
+        for m in pat.finditer(t):
+            name = m.group(1).decode()
+            if f.endswith(".hip"):
+                kernels[name] = f
+            else:
+                owner = next((s for s in HIP_SOURCES if ('#include "%s"' % f).encode() in texts[s]), None)
+                kernels.setdefault(name, owner or HIP_SOURCES[0])
+    return {"tu": tu, "kernels": kernels}
+
+
+def _write_build_id():
+    """lib/build_id.cpp: the JSON of source_build_id() as a string the loaded library returns (ingvio_build_id)."""
+    import json
+    txt = json.dumps(source_build_id(), sort_keys=True)
+    src = os.path.join(LIB, "build_id.cpp")
+    body = 'extern "C" const char* ingvio_build_id(void) { return R"BID(%s)BID"; }\n' % txt
+    if not os.path.exists(src) or open(src).read() != body:
+        with open(src, "w") as f:
+            f.write(body)
+    return src
+
+
 def build_hip(force=False, verbose=False):
     os.makedirs(LIB, exist_ok=True)
     deps = _all_deps([CSRC, os.path.join(os.path.dirname(HERE), "include")])
     objs, cmds = [], []
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    bid_src = _write_build_id()
+    bid_obj = os.path.join(LIB, "build_id.o")
+    if force or _newer(bid_obj, [bid_src]):
+        subprocess.check_call(["g++", "-O1", "-fPIC", "-c", bid_src, "-o", bid_obj])
     for src in HIP_SOURCES:
         obj = os.path.join(LIB, src.replace(".hip", ".o"))
         objs.append(obj)
@@ -54,8 +109,8 @@ def build_hip(force=False, verbose=False):
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(cmds), os.cpu_count() or 4)) as ex:
             list(ex.map(subprocess.check_call, cmds))
-    if force or _newer(HIP_LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs
+    if force or _newer(HIP_LIB, objs + [bid_obj]):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs + [bid_obj]
         subprocess.check_call(cmd)
     return HIP_LIB
 

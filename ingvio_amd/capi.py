@@ -21,6 +21,7 @@ R_SCALAR, R_DIAG, R_FULL = 0, 1, 2
 
 EXPORTS = [
     "ingvio_ctx_create", "ingvio_ctx_destroy", "ingvio_sync", "ingvio_ctx_stream", "ingvio_f_max", "ingvio_last_error", "ingvio_ldp",
+    "ingvio_build_id",
     "ingvio_cov_set", "ingvio_cov_get", "ingvio_get_n", "ingvio_cov_get_marginal", "ingvio_cov_snapshot",
     "ingvio_cov_restore", "ingvio_propagate", "ingvio_propagate_fused", "ingvio_augment_clone", "ingvio_marginalize",
     "ingvio_append_independent", "ingvio_ekf_update", "ingvio_chi2_gamma", "ingvio_msckf_update", "ingvio_qr_compress",
@@ -104,7 +105,14 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.ingvio_last_error.restype = C.c_char_p
         _lib.ingvio_ctx_stream.restype = C.c_void_p
+        _lib.ingvio_build_id.restype = C.c_char_p
     return _lib
+
+
+def build_id():
+    """{"tu": {...}, "kernels": {...}} of the LOADED library (ingvio_build_id, written by build.py at build time)."""
+    import json
+    return json.loads(lib().ingvio_build_id().decode())
 
 
 def _d(a):

@@ -555,7 +555,7 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     // Consecutive filters' covariances must not sit a power of two apart: with ldp = 256 the stride would be 512 KB, and the SAME
     // element of every filter (the window block P_cc every gate wave of a filter reads, 64 filters per XCD) would fall into the same
     // L2 sets.  67 cache lines of pad walk the filters through the sets.  (Precaution: one default bench run showed the gate at
-    // 1.30 ms instead of 0.28 in its config-3 pass; tests/gpu_alloc_sensitivity.py could not reproduce that with either layout -
+    // 1.30 ms instead of 0.28 in its config-3 pass; tools/gpu_alloc_sensitivity.py could not reproduce that with either layout -
     // six contexts per process, perturbed allocations, 0.289 - 0.294 ms for both -, so the pad is not the proven cure.)
     static const bool no_pad = [] { const char* e = getenv("INGVIO_P_PAD"); return e && e[0] == '0'; }();
     c->pp = (size_t)c->ldp * c->ldp + (no_pad ? 0 : 67 * 16);

@@ -67,7 +67,7 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 // 1/x to full FP64 precision: v_rcp_f64 + two Newton steps (the IEEE division expands to ~3x the latency).  Measured on MI355X
-// (tests/micro/rcp_f64.hip, 4 M doubles over 2^+-300): v_rcp_f64 alone 4.6e-8 relative, one step 2.2e-15, two steps 1.1e-16.
+// (tools/micro/rcp_f64.hip, 4 M doubles over 2^+-300): v_rcp_f64 alone 4.6e-8 relative, one step 2.2e-15, two steps 1.1e-16.
 __device__ __forceinline__ double fast_rcp(double x)
 {
     double r = __builtin_amdgcn_rcp(x);
@@ -91,7 +91,7 @@ __device__ __forceinline__ double fast_rcp(double x)
 static __device__ long long g_dbg[64];      // one copy per translation unit (no -fgpu-rdc)
 __device__ __forceinline__ void dbg_stamp(int slot)
 {
-#ifdef INGVIO_DBG_STAMPS      // build with INGVIO_DBG_STAMPS=1 python ingvio_amd/build.py --force (tests/gpu_phase_times.py)
+#ifdef INGVIO_DBG_STAMPS      // build with INGVIO_DBG_STAMPS=1 python ingvio_amd/build.py --force (tools/gpu_phase_times.py)
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_dbg[slot] = clock64();
 #else
     (void)slot;

@@ -54,6 +54,9 @@ public:
     std::shared_ptr<ImuPropagator> imuPropagator() { return _imu_propa; }
     std::shared_ptr<LandmarkUpdate> landmarkUpdate() { return _landmark_update; }
     int framesProcessed() const { return _frames; }
+    std::shared_ptr<RemoveLostUpdate> removeLostUpdate() { return _remove_lost_update; }
+    std::shared_ptr<KeyframeUpdate> keyframeUpdate() { return _keyframe_update; }
+    std::shared_ptr<SwMargUpdate> swMargUpdate() { return _sw_marg_update; }
 
 protected:
     void collectStereoMeas(const StereoFrameMsg& f);                                    // MapServerManager.cpp:147-217

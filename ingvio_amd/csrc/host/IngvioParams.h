@@ -45,6 +45,10 @@ public:
 
     // device-side capacity of the covariance engine behind this filter (new: not in the reference)
     int _hip_n_max = 256, _hip_f_max = 160, _hip_device = 0;
+    // quirks Q3 / Q2 as parameters (defaults = the reference as written): RemoveLost's accepted-feature cap
+    // (RemoveLostUpdate.h:38: 20; 0 = no cap) and its compression rule (0 = keep all rows after the rotation, RemoveLostUpdate.cpp:390;
+    // 1 = keep the top n rows like the other two update classes)
+    int _hip_max_valid_ids = 20, _hip_compress_rule = 0;
 };
 
 }  // namespace ingvio

@@ -69,11 +69,8 @@ bool Triangulator::triangulateStereoObs(const std::shared_ptr<State> state,
 }
 
 // FeatureInfoManager::triangulateFeatureInfoMono / Stereo (MapServerManager.cpp:274-341)
-bool Triangulator::triangulate(std::shared_ptr<FeatureInfo> fi, const std::shared_ptr<State> state, bool stereo)
+bool Triangulator::accept(std::shared_ptr<FeatureInfo> fi, bool flag, const Vec3d& pf) const
 {
-    Vec3d pf;
-    const bool flag = stereo ? triangulateStereoObs(state, fi->_stereo_obs, state->_sw_camleft_poses, state->_state_params._T_cl2cr, pf)
-                             : triangulateMonoObs(state, fi->_mono_obs, state->_sw_camleft_poses, pf);
     if (!flag || pf[0] != pf[0] || pf[1] != pf[1] || pf[2] != pf[2]) return false;
     ++fi->_numOfTri;
     const auto anchor = fi->_landmark->getAnchoredPose();
@@ -88,6 +85,73 @@ bool Triangulator::triangulate(std::shared_ptr<FeatureInfo> fi, const std::share
     }
     fi->_landmark->setValuePosXyz(pf);
     return true;
+}
+
+bool Triangulator::triangulate(std::shared_ptr<FeatureInfo> fi, const std::shared_ptr<State> state, bool stereo)
+{
+    Vec3d pf;
+    const bool flag = stereo ? triangulateStereoObs(state, fi->_stereo_obs, state->_sw_camleft_poses, state->_state_params._T_cl2cr, pf)
+                             : triangulateMonoObs(state, fi->_mono_obs, state->_sw_camleft_poses, pf);
+    return accept(fi, flag, pf);
+}
+
+void Triangulator::triangulateMany(const std::vector<std::shared_ptr<FeatureInfo>>& feats, const std::shared_ptr<State> state, bool stereo,
+                                   std::vector<char>& ok)
+{
+    ok.assign(feats.size(), 0);
+    const int fcap = ingvio_f_max(StateManager::ctx(state));
+    const auto& sw = state->_sw_camleft_poses;
+    const int C = (int)sw.size();
+    if (feats.empty() || C == 0 || C > 64) {                        // no window (or one the mask cannot name): feature by feature
+        for (size_t i = 0; i < feats.size(); ++i) ok[i] = triangulate(feats[i], state, stereo) ? 1 : 0;
+        return;
+    }
+    std::vector<double> times, cR, cp;
+    std::vector<int> cidx((size_t)C, 0);
+    for (const auto& item : sw) {                                   // ascending timestamp = the order filterCommonTimestamp yields
+        times.push_back(item.first);
+        const Mat3d& R = item.second->valueLinearAsMat();
+        const Vec3d& p = item.second->valueTrans();
+        cR.insert(cR.end(), R.m, R.m + 9);
+        cp.insert(cp.end(), p.v, p.v + 3);
+    }
+    ingvio_tri_opts o;
+    std::memset(&o, 0, sizeof o);
+    o.stereo = stereo ? 1 : 0;
+    std::memcpy(o.R_cl2cr, state->_state_params._T_cl2cr.R.m, sizeof o.R_cl2cr);
+    std::memcpy(o.t_cl2cr, state->_state_params._T_cl2cr.t.v, sizeof o.t_cl2cr);
+    o.trans_thres = _trans_thres; o.huber_epsilon = _huber_epsilon; o.conv_precision = _conv_precision;
+    o.init_damping = _init_damping; o.outer_loop_max_iter = _outer_loop_max_iter; o.inner_loop_max_iter = _inner_loop_max_iter;
+    o.max_depth = _max_depth; o.min_depth = _min_depth;
+    for (size_t f0 = 0; f0 < feats.size(); f0 += (size_t)fcap) {    // the device frame holds f_max features
+        const int nf = (int)std::min((size_t)fcap, feats.size() - f0);
+        std::vector<unsigned long long> mask((size_t)nf, 0ULL);
+        std::vector<double> uv((size_t)nf * C * 4, 0.0);
+        for (int j = 0; j < nf; ++j) {
+            const auto& fi = feats[f0 + j];
+            for (int s = 0; s < C; ++s) {
+                double* q = &uv[((size_t)j * C + s) * 4];
+                if (stereo) {
+                    const auto it = fi->_stereo_obs.find(times[s]);
+                    if (it == fi->_stereo_obs.end()) continue;
+                    q[0] = it->second->_u0; q[1] = it->second->_v0; q[2] = it->second->_u1; q[3] = it->second->_v1;
+                } else {
+                    const auto it = fi->_mono_obs.find(times[s]);
+                    if (it == fi->_mono_obs.end()) continue;
+                    q[0] = it->second->_u0; q[1] = it->second->_v0;
+                }
+                mask[j] |= 1ULL << s;
+            }
+        }
+        ingvio_msckf_frame fr;
+        std::memset(&fr, 0, sizeof fr);
+        fr.n_clones = C; fr.clone_idx = cidx.data(); fr.clone_R = cR.data(); fr.clone_p = cp.data();
+        fr.n_feat = nf; fr.obs_mask = mask.data(); fr.uv = uv.data();
+        std::vector<Vec3d> pf;
+        std::vector<char> flag;
+        StateManager::triangulateFrame(state, fr, o, pf, flag);
+        for (int j = 0; j < nf; ++j) ok[f0 + j] = accept(feats[f0 + j], mask[j] != 0ULL && flag[j], pf[j]) ? 1 : 0;
+    }
 }
 
 namespace {
@@ -172,7 +236,7 @@ ingvio_msckf_opts makeOpts(const std::shared_ptr<State>& state, bool stereo, dou
 
 // ---------------------------------------------------------------------------------------------
 RemoveLostUpdate::RemoveLostUpdate(const IngvioParams& fp)
-    : UpdateBase(fp._chi2_max_dof, fp._chi2_thres), _max_valid_ids(20), _noise(fp._visual_noise) {}
+    : UpdateBase(fp._chi2_max_dof, fp._chi2_thres), _max_valid_ids(fp._hip_max_valid_ids), _compress_rule(fp._hip_compress_rule), _noise(fp._visual_noise) {}
 
 void RemoveLostUpdate::updateStateMono(std::shared_ptr<State> s, std::shared_ptr<MapServer> m, std::shared_ptr<Triangulator> t) { update(s, m, t, false); }
 void RemoveLostUpdate::updateStateStereo(std::shared_ptr<State> s, std::shared_ptr<MapServer> m, std::shared_ptr<Triangulator> t) { update(s, m, t, true); }
@@ -193,13 +257,17 @@ void RemoveLostUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapS
         StateManager::margAnchoredLandmarkInState(state, id);
         map_server->erase(id);
     }
-    std::vector<int> update_ids, direct_marg_ids;
+    std::vector<int> update_ids, direct_marg_ids, cand_ids;
+    std::vector<std::shared_ptr<FeatureInfo>> cand;
     for (auto& item : *map_server)
-        if (item.second->_ftype == FeatureInfo::MSCKF && item.second->_isToMarg) {
-            const bool enough = stereo ? item.second->numOfStereoFrames() >= 3 : item.second->numOfMonoFrames() >= 4;   // :287 / :51
-            if (tri->triangulate(item.second, state, stereo) && enough) update_ids.push_back(item.first);
-            else direct_marg_ids.push_back(item.first);
-        }
+        if (item.second->_ftype == FeatureInfo::MSCKF && item.second->_isToMarg) { cand_ids.push_back(item.first); cand.push_back(item.second); }
+    std::vector<char> tri_ok;
+    tri->triangulateMany(cand, state, stereo, tri_ok);                 // one device call for the frame's lost features
+    for (size_t i = 0; i < cand.size(); ++i) {
+        const bool enough = stereo ? cand[i]->numOfStereoFrames() >= 3 : cand[i]->numOfMonoFrames() >= 4;               // :287 / :51
+        if (tri_ok[i] && enough) update_ids.push_back(cand_ids[i]);
+        else direct_marg_ids.push_back(cand_ids[i]);
+    }
     for (const auto& id : direct_marg_ids) map_server->erase(id);
     if (update_ids.size() == 0) return;
     FlatFrame ff(state);
@@ -213,7 +281,7 @@ void RemoveLostUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapS
     if (ff.F > 0) {
         const std::vector<double> table = chi2TableDense(max_dof + 1);
         const ingvio_msckf_frame fr = ff.view();
-        const ingvio_msckf_opts op = makeOpts(state, stereo, _noise, table, _max_valid_ids, 0 /* as written, Q2 */, 0);
+        const ingvio_msckf_opts op = makeOpts(state, stereo, _noise, table, _max_valid_ids, _compress_rule /* 0 = as written, Q2 */, 0);
         std::vector<int> acc;
         _last_rows = StateManager::msckfUpdate(state, fr, op, &acc);
         for (int a : acc) _last_accepted += a;
@@ -247,15 +315,19 @@ static int selectedUpdate(UpdateBase& base, std::shared_ptr<State> state, std::s
 {
     // features observed at every selected stamp (SwMargUpdate.cpp:236-257 / KeyframeUpdate.cpp:607-628)
     FlatFrame ff(state);
+    std::vector<std::shared_ptr<FeatureInfo>> cand;
     for (const auto& item : *map_server) {
         const auto& fi = item.second;
         if (fi->_ftype != FeatureInfo::MSCKF) continue;
         bool miss = false;
         for (double ts : sel)
             if (stereo ? fi->_stereo_obs.find(ts) == fi->_stereo_obs.end() : fi->_mono_obs.find(ts) == fi->_mono_obs.end()) { miss = true; break; }
-        if (miss) continue;
-        if (tri->triangulate(fi, state, stereo)) ff.add(fi, stereo, &sel, dof);
+        if (!miss) cand.push_back(fi);
     }
+    std::vector<char> tri_ok;
+    tri->triangulateMany(cand, state, stereo, tri_ok);
+    for (size_t i = 0; i < cand.size(); ++i)
+        if (tri_ok[i]) ff.add(cand[i], stereo, &sel, dof);
     if (ff.F == 0) return 0;
     const std::vector<double> table = base.chi2TableDense(dof + 1);
     const ingvio_msckf_frame fr = ff.view();

@@ -37,8 +37,15 @@ public:
     bool triangulateStereoObs(const std::shared_ptr<State> state, const std::map<double, std::shared_ptr<StereoMeas>>& stereo_obs,
                               const std::map<double, std::shared_ptr<SE3>>& sw_poses, const Iso3& T_cl2cr, Vec3d& pf) const;
     virtual bool triangulate(std::shared_ptr<FeatureInfo> feature_info, const std::shared_ptr<State> state, bool stereo);
+    // The same for a list of features in ONE device call (the reference triangulates inside its per-feature loops,
+    // RemoveLostUpdate.cpp:283-299 / SwMargUpdate.cpp:236-257: each feature's triangulation reads the window poses only, so
+    // the loop order is immaterial): ok[i] = what triangulate(features[i]) returns.  The window is sent once, each feature
+    // names its observations by a mask over the window slots.
+    virtual void triangulateMany(const std::vector<std::shared_ptr<FeatureInfo>>& features, const std::shared_ptr<State> state, bool stereo,
+                                 std::vector<char>& ok);
 
 protected:
+    bool accept(std::shared_ptr<FeatureInfo> fi, bool flag, const Vec3d& pf) const;      // MapServerManager.cpp:283-305 / :318-340
     bool run(const std::shared_ptr<State> state, const std::map<double, std::shared_ptr<SE3>>& sw_poses,
              const std::vector<double>& stamps, const std::vector<double>& uv4, bool stereo, const Iso3& T_cl2cr, Vec3d& pf) const;
     double _trans_thres = 0.1, _huber_epsilon = 0.01, _conv_precision = 5e-7, _init_damping = 1e-3;      // Triangulator.h:67-75
@@ -58,6 +65,7 @@ public:
 protected:
     void update(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri, bool stereo);
     int _max_valid_ids;
+    int _compress_rule = 0;
     double _noise;
     int _last_rows = 0, _last_accepted = 0;
 };

@@ -1,5 +1,7 @@
 #include "Replay.h"
 
+#include <chrono>
+#include <cmath>
 #include <cstring>
 #include <sstream>
 
@@ -232,6 +234,8 @@ bool applyParamsText(const std::string& text, IngvioParams& p)
         else if (key == "hip_n_max") inum(p._hip_n_max);
         else if (key == "hip_f_max") inum(p._hip_f_max);
         else if (key == "hip_device") inum(p._hip_device);
+        else if (key == "hip_max_valid_ids") inum(p._hip_max_valid_ids);
+        else if (key == "hip_compress_rule") inum(p._hip_compress_rule);
         else continue;                             // topics, tracker and aligner keys: not read by this path
         if (vs.fail()) ok = false;
     }
@@ -294,6 +298,81 @@ bool replayFile(const std::string& path, const std::string& overrides, bool dump
         }
     }
     if (!rd.error().empty()) { err = rd.error(); return false; }
+    return true;
+}
+
+namespace {
+
+struct FileSink : SynthSink {
+    ReplayWriter w;
+    void params(const std::string& t) override { w.params(t); }
+    void imu(const msg::Imu& m) override { w.imu(m); }
+    void stereo(const msg::StereoFrame& m) override { w.stereo(m); }
+    void mono(const msg::MonoFrame& m) override { w.mono(m); }
+    void truth(double stamp, const double p[3], const double q[4]) override { w.truth(stamp, p, q); }
+};
+
+struct FilterSink : SynthSink {
+    std::string overrides;
+    std::unique_ptr<IngvioFilter> filter;
+    IngvioParams fp;
+    std::vector<FrameTiming>* out = nullptr;
+    double last_truth[3] = { 0, 0, 0 };
+    bool ok = true;
+    std::string err;
+    void params(const std::string& t) override
+    {
+        if (!applyParamsText(t, fp) || !applyParamsText(overrides, fp)) { ok = false; err = "unreadable value in the parameters"; return; }
+        filter.reset(new IngvioFilter(fp, std::make_shared<Triangulator>(fp)));
+        if (fp._enable_gnss) filter->gnssSync()->setSync();
+    }
+    void imu(const msg::Imu& m) override { if (filter) filter->callbackIMU(m); }
+    template <class F> void frame(const F& m, uint32_t k, bool is_mono)
+    {
+        if (!filter) return;
+        const int before = filter->framesProcessed();
+        const auto t0 = std::chrono::steady_clock::now();
+        callFrame(m);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (filter->framesProcessed() > before && out) {
+            FrameTiming ft;
+            ft.k = (int)k; ft.ms = ms;
+            ft.lost_rows = filter->removeLostUpdate()->lastRows(); ft.lost_accepted = filter->removeLostUpdate()->lastAccepted();
+            ft.select_rows = fp._is_key_frame ? filter->keyframeUpdate()->lastRows() : filter->swMargUpdate()->lastRows();
+            ft.n = filter->state()->curr_cov_size(); ft.clones = (int)filter->state()->_sw_camleft_poses.size();
+            out->push_back(ft);
+        }
+        (void)is_mono;
+    }
+    void callFrame(const msg::StereoFrame& m) { filter->callbackStereoFrame(m); }
+    void callFrame(const msg::MonoFrame& m) { filter->callbackMonoFrame(m); }
+    void stereo(const msg::StereoFrame& m) override { frame(m, m.header.seq, false); }
+    void mono(const msg::MonoFrame& m) override { frame(m, m.header.seq, true); }
+    void truth(double, const double p[3], const double*) override { for (int i = 0; i < 3; ++i) last_truth[i] = p[i]; }
+};
+
+}  // namespace
+
+bool writeSynthRecording(const SynthConfig& cfg, const std::string& path)
+{
+    FileSink s;
+    if (!s.w.open(path)) return false;
+    synthStream(cfg, s);
+    s.w.close();
+    return true;
+}
+
+bool playSynth(const SynthConfig& cfg, const std::string& overrides, std::vector<FrameTiming>& timings, double* truth_err, std::string& err)
+{
+    FilterSink s;
+    s.overrides = overrides; s.out = &timings;
+    synthStream(cfg, s);
+    if (!s.ok || !s.filter) { err = s.err.empty() ? "no filter was built" : s.err; return false; }
+    if (truth_err) {
+        const Vec3d p = s.filter->state()->_extended_pose->valueTrans1();
+        *truth_err = std::sqrt((p[0] - s.last_truth[0]) * (p[0] - s.last_truth[0]) + (p[1] - s.last_truth[1]) * (p[1] - s.last_truth[1]) +
+                               (p[2] - s.last_truth[2]) * (p[2] - s.last_truth[2]));
+    }
     return true;
 }
 

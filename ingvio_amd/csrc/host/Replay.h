@@ -21,6 +21,7 @@
 
 #include "IngvioFilter.h"
 #include "Messages.h"
+#include "SynthStream.h"
 
 namespace ingvio {
 
@@ -74,5 +75,17 @@ struct ReplayStats { uint64_t counts[RP_COUNT] = { 0 }; uint64_t features = 0; d
 // filter processed, with the odometry visualize() would publish.  dump_only: parse and count, no filter (needs no GPU).
 bool replayFile(const std::string& path, const std::string& overrides, bool dump_only,
                 const std::function<void(const msg::Odometry&, const IngvioFilter&)>& on_odom, ReplayStats& stats, std::string& err);
+
+// ---- synthetic streams (SynthStream.h) ------------------------------------------------------------------------------------
+// Writes the stream of `cfg` as an INGVIOR1 file.
+bool writeSynthRecording(const SynthConfig& cfg, const std::string& path);
+
+// One processed camera frame of a timed play: wall time of the callback (it ends with the frame's results on the host: the
+// update calls synchronise), what the RemoveLost / key-frame (or SwMarg) updates did, and the state afterwards.
+struct FrameTiming { int k = 0; double ms = 0; int lost_rows = 0, lost_accepted = 0, select_rows = 0, n = 0, clones = 0; };
+
+// Plays the stream of `cfg` straight into a filter (no file), timing every camera callback.  `truth_err` (may be NULL) receives
+// the position error against the ground truth at the last frame.  Needs a GPU.
+bool playSynth(const SynthConfig& cfg, const std::string& overrides, std::vector<FrameTiming>& timings, double* truth_err, std::string& err);
 
 }  // namespace ingvio

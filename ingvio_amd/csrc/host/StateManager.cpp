@@ -395,6 +395,18 @@ bool StateManager::triangulateOne(std::shared_ptr<State> state, const ingvio_msc
     return ok[0] != 0;
 }
 
+void StateManager::triangulateFrame(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_tri_opts& opts,
+                                    std::vector<Vec3d>& pf, std::vector<char>& ok)
+{
+    const int fm = std::max(ingvio_f_max(state->_ctx), 1);
+    std::vector<double> pfo(3 * (size_t)fm, 0.0);
+    std::vector<int> oko((size_t)fm, 0);
+    const int rc = ingvio_triangulate(state->_ctx, state->_b, 1, &frame, &opts, pfo.data(), oko.data());
+    if (rc < 0) fatal(state, "triangulate", rc);
+    pf.resize((size_t)frame.n_feat); ok.resize((size_t)frame.n_feat);
+    for (int j = 0; j < frame.n_feat; ++j) { pf[j] = Vec3d(pfo[3 * j], pfo[3 * j + 1], pfo[3 * j + 2]); ok[j] = oko[j] != 0; }
+}
+
 int StateManager::msckfUpdate(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_msckf_opts& opts,
                               std::vector<int>* accepted)
 {

@@ -68,6 +68,9 @@ public:
     // MSCKF update on flattened MapServer data + boxPlus; returns rows handed to the Kalman update.
     // f-1: Triangulator::triangulate{Mono,Stereo}Obs of ONE feature on the device (ingvio_triangulate)
     static bool triangulateOne(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_tri_opts& opts, Vec3d& pf);
+    // ... and of every feature of `frame` in one call: pf[j], ok[j] for j < frame.n_feat (n_feat <= ingvio_f_max)
+    static void triangulateFrame(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_tri_opts& opts,
+                                 std::vector<Vec3d>& pf, std::vector<char>& ok);
     static int msckfUpdate(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_msckf_opts& opts,
                            std::vector<int>* accepted = nullptr);
 

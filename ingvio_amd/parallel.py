@@ -17,10 +17,15 @@ class Group:
     """Thin wrapper: works for world == 1 without importing torch."""
 
     def __init__(self, backend=None, force_init=False):
-        """force_init: create the process group even at world size 1 (exercises the collective backend itself)."""
+        """force_init: create the process group even at world size 1 (exercises the collective backend itself).
+        Environment: INGVIO_DIST_BACKEND = nccl | gloo overrides the backend choice; INGVIO_DEVICE = ordinal puts every rank's
+        context on that device instead of LOCAL_RANK (both for exercising the N > 1 code path of bench.py / the sharded filter
+        on a box with ONE GPU: RCCL refuses two ranks on one device, gloo carries the barrier / max / gather instead)."""
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device_index = int(os.environ["INGVIO_DEVICE"]) if os.environ.get("INGVIO_DEVICE") else self.local_rank
+        backend = backend or os.environ.get("INGVIO_DIST_BACKEND") or None
         self.dist = None
         self.device = None
         self.backend = None
@@ -31,8 +36,8 @@ class Group:
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
             if backend == "nccl":
-                torch.cuda.set_device(self.local_rank)
-                self.device = torch.device("cuda", self.local_rank)
+                torch.cuda.set_device(self.device_index)
+                self.device = torch.device("cuda", self.device_index)
                 dist.init_process_group("nccl", device_id=self.device)
             else:
                 self.device = torch.device("cpu")
@@ -93,7 +98,7 @@ class Group:
         caller must have synchronised the stream that produced the buffer; on return the collective has completed."""
         if self.dist is None:
             return
-        idx = self.local_rank if device_index is None else int(device_index)
+        idx = self.device_index if device_index is None else int(device_index)
         t = self.torch.as_tensor(_DeviceBuffer(ptr, count), device=self.torch.device("cuda", idx))
         if self.backend == "nccl":
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)

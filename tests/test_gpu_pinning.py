@@ -189,7 +189,7 @@ def test_sigma_and_prior_scale_sweep(orc, scale):
             report.append((method, scale, s, int(acco.sum()), e_full, g_win, o_win, g_dx, o_dx))
             assert e_full < 1e-6, (method, s, scale, e_full)
             # Round 3: no exempted regime.  What used to lose the window block at a 1e4 x prior and s <= 1e-2 was not the
-            # cancellation in P - (Pc M) Pc^T but the eps |A| violation of A's gauge null space (tests/gpu_gauge_diag.py);
+            # cancellation in P - (Pc M) Pc^T but the eps |A| violation of A's gauge null space (tools/gpu_gauge_diag.py);
             # the information solve now runs in difference coordinates to a reference clone (kernels_solve.hip), where A has
             # full rank, and both methods are held to the same bound everywhere.
             bound = 1e-6
@@ -297,7 +297,7 @@ def test_rccl_world_size_1():
     from conftest import ROOT
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631",
                HSA_ENABLE_IPC_MODE_LEGACY="0", INGVIO_ROOT=ROOT)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_rccl_ws1.py")], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "worker_rccl_ws1.py")], env=env, capture_output=True, text=True, timeout=600)
     print(r.stdout[-1500:]); print(r.stderr[-6000:])
     assert r.returncode == 0 and "RCCL_OK" in r.stdout
 

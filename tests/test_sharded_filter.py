@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_feature_sharded_filter_two_ranks(clones, feats):
     env = dict(os.environ, SHARD_CLONES=str(clones), SHARD_FEATS=str(feats), HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29540 + clones), os.path.join(ROOT, "tests", "gpu_sharded_filter.py")]
+           "--master-port", str(29540 + clones), os.path.join(ROOT, "tests", "worker_sharded_filter.py")]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     assert "SHARDED world=2" in p.stdout and "replicas_equal=True" in p.stdout, p.stdout[-2000:]

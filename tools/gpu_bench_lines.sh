@@ -11,4 +11,4 @@ run c5_n201 --config 5 --state literal --no-cpu --no-aux
 run c5_n807_b128 --config 5 --batch 128 --no-cpu --no-aux
 run c5_n807_b1 --config 5 --batch 1 --no-cpu --steps 50 --no-aux
 run c2_lmreal --landmarks real --no-cpu --no-aux
-python tests/gpu_qr_shapes.py > gpurun_out/qr_shapes.log 2>&1; tail -5 gpurun_out/qr_shapes.log
+python tools/gpu_qr_shapes.py > gpurun_out/qr_shapes.log 2>&1; tail -5 gpurun_out/qr_shapes.log

@@ -2,8 +2,8 @@
 # Collects, on the GPU box, everything profiles/ needs for one bench workload:
 #   1. rocprofv3 --kernel-trace --stats of the bench command        -> gpurun_out/prof_<tag>/stats
 #   2. rocprofv3 --pmc passes (counters only, no trace domains)      -> gpurun_out/prof_<tag>/pmc_*  -> profiles/counters.json
-# usage: [PER_STEP=k_chol_step=12,k_gemm=4] tests/gpu_counters.sh <tag> <counters key> <bench args...>      e.g.  tests/gpu_counters.sh c2 c2_B512_F150_C11_N249 --config 2
-#   PER_STEP: kernels launched several times per bench step (stages made of several launches), see tests/pmc_summary.py
+# usage: [PER_STEP=k_chol_step=12,k_gemm=4] tools/gpu_counters.sh <tag> <counters key> <bench args...>      e.g.  tools/gpu_counters.sh c2 c2_B512_F150_C11_N249 --config 2
+#   PER_STEP: kernels launched several times per bench step (stages made of several launches), see tools/pmc_summary.py
 set -u
 TAG=$1; KEY=$2; shift 2
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -28,7 +28,7 @@ for P in "${PASSES[@]}"; do
   i=$((i+1))
 done
 cd "$ROOT"
-python tests/pmc_summary.py --key "$KEY" --last 3 --per-step "${PER_STEP:-}" --out gpurun_out/counters.json --csv "gpurun_out/counters_$TAG.csv" \
+python tools/pmc_summary.py --key "$KEY" --last 3 --per-step "${PER_STEP:-}" --out gpurun_out/counters.json --csv "gpurun_out/counters_$TAG.csv" \
   --source "rocprofv3 --pmc (5 passes) -- python bench.py --no-cpu --no-profile --steps 3 --warmup 1 $*; last 3 dispatches per kernel" $DIRS
 find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "gpurun_out/kernel_stats_$TAG.csv" \;
 tail -2 "$OUT/stats.log"

@@ -1,5 +1,5 @@
 """Host hand-over cost of one batched frame: ingvio_frame_stage (pack + H2D) / ingvio_frame_run / ingvio_frame_fetch (D2H),
-serialised, next to the device-resident step time.  python tests/gpu_host_handover.py [batch]"""
+serialised, next to the device-resident step time.  python tools/gpu_host_handover.py [batch]"""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")

@@ -1,5 +1,5 @@
 """BASELINE config 5's pure-kernel run: dense 6000 x 800 FP64 QR compression (cond ~ 1e3) through ingvio_qr_compress.
-python tests/gpu_qr_bench.py  (under rocprofv3 --kernel-trace --stats for the device time)"""
+python tools/gpu_qr_bench.py  (under rocprofv3 --kernel-trace --stats for the device time)"""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")

@@ -1,6 +1,6 @@
 """Experiment: the batch cut into S slices, one context + HIP stream per slice, stream priorities staggered so that the
 slices fall out of lock-step and the latency-bound kernels of one slice overlap the gate kernel of another.
-python tests/gpu_slice_pipeline.py [slices] [prio-mode]"""
+python tools/gpu_slice_pipeline.py [slices] [prio-mode]"""
 import sys, time, ctypes
 import numpy as np
 sys.path.insert(0, ".")

@@ -1,5 +1,5 @@
 """Throughput of the batched triangulation on the device next to the oracle on one host thread.
-Run on the GPU box: python tests/gpu_tri_bench.py [batch]   (rocprofv3 --kernel-trace --stats for the kernel time)"""
+Run on the GPU box: python tools/gpu_tri_bench.py [batch]   (rocprofv3 --kernel-trace --stats for the kernel time)"""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")

@@ -2,25 +2,105 @@
 // the odometry IngvioFilter::visualize would publish, one line per processed camera frame:
 //     stamp px py pz qx qy qz qw vx vy vz N clones
 // usage: ingvio_replay <file> [--dump] [--set "key: value" ...]
-//   --dump  parse and count the records only (no device needed)
+//        ingvio_replay --synth "feats=150,clones=11,life=10,cohort=1,frames=60,..." [--write <file> | --frame <k> | --time] [--set ...]
+//   --dump   parse and count the records only (no device needed)
+//   --synth  a synthetic stream (ingvio_amd/csrc/host/SynthStream.h; keys = the fields of SynthConfig) instead of a file:
+//            --write  store it as an INGVIOR1 file (no device needed)
+//            --frame  print the feature message of frame k regenerated from the seed alone: "FEAT id u0 v0 u1 v1" (no device needed)
+//            --time   play it into a filter and print the wall time of every camera callback: "FRAME k ms lost_rows lost_accepted
+//                     select_rows N clones", then "LATENCY ..." (single-filter latency)
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <sstream>
 #include <string>
 
 #include "../ingvio_amd/csrc/host/Replay.h"
 
+static bool parseSynth(const std::string& spec, ingvio::SynthConfig& c)
+{
+    std::istringstream in(spec);
+    std::string kv;
+    while (std::getline(in, kv, ',')) {
+        const size_t eq = kv.find('=');
+        if (eq == std::string::npos) { if (kv.empty()) continue; return false; }
+        const std::string k = kv.substr(0, eq), v = kv.substr(eq + 1);
+        if (k == "feats") c.feats = std::atoi(v.c_str());
+        else if (k == "clones") c.clones = std::atoi(v.c_str());
+        else if (k == "stereo") c.stereo = std::atoi(v.c_str());
+        else if (k == "key") c.is_key_frame = std::atoi(v.c_str());
+        else if (k == "life") c.life = std::atoi(v.c_str());
+        else if (k == "cohort") c.cohort = std::atoi(v.c_str());
+        else if (k == "outlier_every") c.outlier_every = std::atoi(v.c_str());
+        else if (k == "frames") c.frames = std::atoi(v.c_str());
+        else if (k == "pixel_noise") c.pixel_noise = std::atof(v.c_str());
+        else if (k == "visual_noise") c.visual_noise = std::atof(v.c_str());
+        else if (k == "seed") c.seed = std::strtoull(v.c_str(), nullptr, 0);
+        else return false;
+    }
+    return c.feats > 0 && c.clones >= 3 && c.life >= 1 && c.frames >= 1;
+}
+
+static double median(std::vector<double> v)
+{
+    if (v.empty()) return 0.0;
+    std::sort(v.begin(), v.end());
+    return v.size() % 2 ? v[v.size() / 2] : 0.5 * (v[v.size() / 2 - 1] + v[v.size() / 2]);
+}
+
 int main(int argc, char** argv)
 {
-    if (argc < 2) { std::fprintf(stderr, "usage: ingvio_replay <file> [--dump] [--set \"key: value\" ...]\n"); return 2; }
-    bool dump = false;
-    std::string overrides;
-    for (int i = 2; i < argc; ++i) {
+    if (argc < 2) { std::fprintf(stderr, "usage: ingvio_replay <file> [--dump] [--set \"key: value\" ...] | --synth <spec> [--write f | --frame k | --time]\n"); return 2; }
+    bool dump = false, timed = false;
+    std::string overrides, synth, write_path, file;
+    int frame_k = -1;
+    for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--dump")) dump = true;
+        else if (!std::strcmp(argv[i], "--time")) timed = true;
         else if (!std::strcmp(argv[i], "--set") && i + 1 < argc) { overrides += argv[++i]; overrides += "\n"; }
+        else if (!std::strcmp(argv[i], "--synth") && i + 1 < argc) synth = argv[++i];
+        else if (!std::strcmp(argv[i], "--write") && i + 1 < argc) write_path = argv[++i];
+        else if (!std::strcmp(argv[i], "--frame") && i + 1 < argc) frame_k = std::atoi(argv[++i]);
+        else if (argv[i][0] != '-' && file.empty()) file = argv[i];
+        else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
+    }
+    if (!synth.empty() || timed || frame_k >= 0 || !write_path.empty()) {
+        ingvio::SynthConfig cfg;
+        if (!parseSynth(synth, cfg)) { std::fprintf(stderr, "bad --synth spec\n"); return 2; }
+        if (frame_k >= 0) {
+            ingvio::msg::StereoFrame f;
+            ingvio::synthFrame(cfg, frame_k, f);
+            std::printf("STAMP %llu\n", (unsigned long long)f.header.stamp.toNSec());
+            for (const auto& m : f.stereo_features) std::printf("FEAT %llu %.17g %.17g %.17g %.17g\n", (unsigned long long)m.id, m.u0, m.v0, m.u1, m.v1);
+            return 0;
+        }
+        if (!write_path.empty()) {
+            if (!ingvio::writeSynthRecording(cfg, write_path)) { std::fprintf(stderr, "cannot write %s\n", write_path.c_str()); return 1; }
+            return 0;
+        }
+        std::vector<ingvio::FrameTiming> tm;
+        double terr = 0;
+        std::string err;
+        if (!ingvio::playSynth(cfg, overrides, tm, &terr, err)) { std::fprintf(stderr, "synthetic play failed: %s\n", err.c_str()); return 1; }
+        std::vector<double> heavy, light, all;
+        int heavy_acc = 0, heavy_rows = 0;
+        for (const auto& t : tm) {
+            std::printf("FRAME %d %.4f %d %d %d %d %d\n", t.k, t.ms, t.lost_rows, t.lost_accepted, t.select_rows, t.n, t.clones);
+            // warm-up: the first frames allocate workspaces and build the window; heavy = a RemoveLost update over at least half the tracks
+            if (t.k <= 2 * cfg.life + 2) continue;
+            all.push_back(t.ms);
+            if (t.lost_accepted * 2 >= cfg.feats || (t.lost_rows > 0 && cfg.cohort)) { heavy.push_back(t.ms); heavy_acc = std::max(heavy_acc, t.lost_accepted); heavy_rows = std::max(heavy_rows, t.lost_rows); }
+            else light.push_back(t.ms);
+        }
+        std::printf("LATENCY frames=%zu timed=%zu median_ms=%.4f heavy_frames=%zu heavy_median_ms=%.4f heavy_min_ms=%.4f heavy_accepted=%d heavy_rows=%d "
+                    "other_median_ms=%.4f final_pos_err_m=%.4f\n", tm.size(), all.size(), median(all), heavy.size(), median(heavy),
+                    heavy.empty() ? 0.0 : *std::min_element(heavy.begin(), heavy.end()), heavy_acc, heavy_rows, median(light), terr);
+        return 0;
     }
     ingvio::ReplayStats st;
     std::string err;
-    const bool ok = ingvio::replayFile(argv[1], overrides, dump,
+    const bool ok = ingvio::replayFile(file, overrides, dump,
         [](const ingvio::msg::Odometry& od, const ingvio::IngvioFilter& f) {
             auto& flt = const_cast<ingvio::IngvioFilter&>(f);
             std::printf("ODOM %.9f %.9f %.9f %.9f %.9f %.9f %.9f %.9f %.6f %.6f %.6f %d %zu\n", od.header.stamp.toSec(), od.position.x, od.position.y,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static resources of every kernel of libingvio_hip.so (VGPRs, AGPRs, SGPRs, scratch, LDS, occupancy) as the compiler reports them
 (-Rpass-analysis=kernel-resource-usage), compiled with the flags of ingvio_amd/build.py.  Needs no GPU.
-usage: python tests/kernel_resources.py > profiles/rNN_kernel_resources.txt"""
+usage: python tools/kernel_resources.py > profiles/rNN_kernel_resources.txt"""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from ingvio_amd import build as B

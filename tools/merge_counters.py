@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Merges the workloads of gpurun_out/counters.json (written by tests/gpu_counters.sh) into profiles/counters.json."""
+"""Merges the workloads of gpurun_out/counters.json (written by tools/gpu_counters.sh) into profiles/counters.json."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 new = json.load(open(os.path.join(ROOT, "gpurun_out", "counters.json")))

@@ -2,7 +2,7 @@
 // (four independent 4x4x4 FP64 products per instruction) next to v_mfma_f64_16x16x4_f64 on gfx950.
 //   layout: B = 1 in ONE lane, A[lane] = lane + 1  ->  the non-zero result lanes and their values show which A lanes meet that B lane
 //   cost:   shader clocks per instruction in a dependent chain and with 4 independent accumulators, one wave per SIMD
-// build: hipcc --offload-arch=gfx950 -O3 tests/micro/mfma444.hip -o ingvio_amd/lib/micro_mfma444
+// build: hipcc --offload-arch=gfx950 -O3 tools/micro/mfma444.hip -o ingvio_amd/lib/micro_mfma444
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double double4_f __attribute__((ext_vector_type(4)));

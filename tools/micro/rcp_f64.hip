@@ -1,5 +1,5 @@
 // Micro-probe (debugging aid): relative error of v_rcp_f64 and of one / two Newton steps on it (fast_rcp in dev_common.h uses two).
-// build: hipcc --offload-arch=gfx950 -O3 tests/micro/rcp_f64.hip -o ingvio_amd/lib/micro_rcp_f64
+// build: hipcc --offload-arch=gfx950 -O3 tools/micro/rcp_f64.hip -o ingvio_amd/lib/micro_rcp_f64
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>

@@ -1,7 +1,7 @@
 """Folds rocprofv3 --pmc counter_collection CSVs into profiles/counters.json (per kernel, per launch), the file bench.py reads
 its executed-operation counts and HBM traffic from.
 
-usage: python tests/pmc_summary.py --key c2_B512_F150_C11_N249 --last 3 --source "..." --out profiles/counters.json dir1 [dir2 ...]
+usage: python tools/pmc_summary.py --key c2_B512_F150_C11_N249 --last 3 --source "..." --out profiles/counters.json dir1 [dir2 ...]
        (each dir: one `rocprofv3 --pmc ... -d dir --output-format csv` pass; counters are collected in their own passes, never
        together with trace domains).  --last N keeps only the last N dispatches of every kernel (the frame steps; earlier
        dispatches of the same kernel belong to the set-up of the priors).  --csv also writes the table as CSV.
@@ -22,6 +22,8 @@ ap.add_argument("--out", required=True)
 ap.add_argument("--csv", default=None)
 ap.add_argument("--per-step", default="", help="kernel=launches per bench step, comma separated: for these the average runs over the "
                 "last (--last x launches) dispatches and the count is stored as _launches_per_step (stages made of several launches)")
+ap.add_argument("--no-build-id", action="store_true", help="do not record the loaded library's build id (bench.py then treats the "
+                "workload's counters as of unknown provenance = stale)")
 ap.add_argument("dirs", nargs="+")
 a = ap.parse_args()
 per_step = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.per_step.split(",") if "=" in kv}
@@ -59,8 +61,16 @@ if os.path.exists(a.out):
         J = json.load(open(a.out))
     except ValueError:
         pass
-J.setdefault("workloads", {})[a.key] = {"source": a.source, "kernels": kernels}
-J["note"] = ("per-launch averages of rocprofv3 --pmc counters (tests/pmc_summary.py); FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 "
+entry = {"source": a.source, "kernels": kernels}
+if not a.no_build_id:
+    # the counters belong to the library that produced them: record the per-translation-unit hashes of the library that is
+    # loaded HERE (this script runs on the GPU box right after the PMC passes, against the same snapshot)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from ingvio_amd import capi
+    entry["build"] = capi.build_id()["tu"]
+J.setdefault("workloads", {})[a.key] = entry
+J["note"] = ("per-launch averages of rocprofv3 --pmc counters (tools/pmc_summary.py); FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 "
              "reports them (bench.py applies the gfx950 x2 on FETCH_SIZE); SQ_INSTS_* are wave-level instruction counts")
 with open(a.out, "w") as f:
     json.dump(J, f, indent=1, sort_keys=True)
