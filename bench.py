@@ -261,6 +261,77 @@ def kernel_that_ran(stage, cand, C, stereo=True):
     return name
 
 
+def price_kernels(prof, dom_name, counters, csrc, rec_build, live_build, C, B, per_kernel, bytes_k):
+    """Per-kernel table (time from HIP events, executed operations / HBM bytes from the committed counters - only when they belong
+    to the running build of the kernel's translation unit) and the roofline of the dominant kernel.  Pure function of its
+    inputs: tests/test_bench_line.py flips a hash and sees frac = None."""
+    kernels = {}
+    for name, (ms, calls) in prof.items():
+        if calls == 0:
+            continue
+        avg = ms / calls
+        c, cand = counters_for(counters, name, C > 16)
+        e = dict(avg_ms=avg, calls=calls, kernel=kernel_that_ran(name, cand, C))
+        if c is not None:
+            st = stale_kernels(cand, rec_build, live_build)
+            if st:                                  # counters of another build of this kernel: no price, say so
+                e["counters_stale"] = st
+                c = None
+        ex = executed_fp64_flops(c)
+        if ex is not None:
+            e["executed_fp64_flop_per_launch"] = ex["total"]
+            e["executed_fp64_mfma_share"] = ex["mfma"] / ex["total"] if ex["total"] else 0.0
+            e["executed_tflops"] = ex["total"] / (avg * 1e-3) / 1e12
+            e["frac_fp64_peak"] = e["executed_tflops"] / FP64_PEAK_TFLOPS
+            if "lane_utilisation" in ex:
+                e["valu_lane_utilisation"] = ex["lane_utilisation"]
+                e["useful_frac_fp64_peak"] = ex["useful"] / (avg * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
+        tr = hbm_traffic_bytes(c)
+        if tr is not None:
+            e["hbm_bytes_per_launch"] = tr
+            e["hbm_gbs"] = tr["total"] / (avg * 1e-3) / 1e9
+            e["frac_hbm_peak"] = e["hbm_gbs"] / HBM_PEAK_GBS
+        if per_kernel.get(name, 0.0) > 0:
+            e["algorithmic_flop_per_launch"] = per_kernel[name] * B
+            e["algorithmic_tflops"] = per_kernel[name] * B / (avg * 1e-3) / 1e12
+        if name in bytes_k:
+            e["algorithmic_bytes_per_launch"] = bytes_k[name] * B
+        kernels[name] = e
+    roofline = None
+    if dom_name is not None and dom_name in kernels:
+        k = kernels[dom_name]
+        if "executed_tflops" in k:
+            mf = k["executed_fp64_mfma_share"]
+            roofline = dict(kernel=k["kernel"], stage=dom_name, bound="mfma" if mf > 0.5 else "valu", achieved=k["executed_tflops"], peak=FP64_PEAK_TFLOPS,
+                            unit="TFLOP/s", frac=k["frac_fp64_peak"],
+                            traffic=k.get("hbm_bytes_per_launch", {}).get("total"), avg_launch_ms=k["avg_ms"],
+                            launches_timed=k["calls"], executed_fp64_flop_per_launch=k["executed_fp64_flop_per_launch"],
+                            mfma_share_of_executed=mf, lane_utilisation=k.get("valu_lane_utilisation"),
+                            useful_frac=k.get("useful_frac_fp64_peak"),
+                            algorithmic=dict(tflops=k.get("algorithmic_tflops"), flop_per_launch=k.get("algorithmic_flop_per_launch"),
+                                             note="SURVEY 8(d) dense formulation of the reference / the same time; not a "
+                                                  "fraction of the peak (the kernel executes fewer operations)"),
+                            counters=csrc,
+                            note="achieved = EXECUTED FP64 operations per launch (rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 "
+                                 "lanes, FMA = 2, + SQ_INSTS_VALU_MFMA_MOPS_F64 x 512) / HIP-event time of the launches inside "
+                                 "the timed region; peak: FP64 vector and FP64 MFMA peaks coincide on MI355X (78.6 TFLOP/s), "
+                                 "`bound` names the pipe that carries most of the executed operations; traffic = HBM bytes per "
+                                 "launch (FETCH_SIZE x 2 + WRITE_SIZE); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 "
+                                 "SQ_ACTIVE_INST_VALU), useful_frac = (VALU operations x lane_utilisation + matrix-core "
+                                 "operations) / time / peak: the executed figure counts masked-off lanes, this one does not")
+        else:
+            roofline = dict(kernel=k["kernel"], stage=dom_name, bound="valu", achieved=None, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=None,
+                            traffic=None, avg_launch_ms=k["avg_ms"], launches_timed=k["calls"],
+                            counters_stale=bool(k.get("counters_stale")),
+                            algorithmic=dict(tflops=k.get("algorithmic_tflops"), flop_per_launch=k.get("algorithmic_flop_per_launch")),
+                            counters=csrc,
+                            note=("the committed SQ counters of this kernel were collected on ANOTHER build of its translation "
+                                  "unit (%s): not used" % ", ".join(k["counters_stale"])) if k.get("counters_stale") else
+                                 "no committed SQ counters for this workload: the executed-operation count, and with it the "
+                                 "achieved fraction, is unknown (collect with tools/gpu_counters.sh)")
+    return kernels, roofline
+
+
 def cpu_baseline(ctx, steps, frames, n_prior, ld, quick=False):
     """Times the oracle (C port of the reference algorithm) on a bounded sample of the same workload and cross-checks the GPU
     posterior on that sample.  Protocol: the reference is single-threaded (IngvioNode.cpp:36), so the primary
@@ -504,70 +575,7 @@ def run_workload(args, grp, aux=False):
         wkey = "c%d_B%d_F%d_C%d_N%d" % (args.config, B, F, C, N) + ("_lmreal" if real_lm else "")
         counters, csrc, rec_build = load_counters(args.counters, wkey)
         live_build = capi.build_id()
-        kernels = {}
-        for name, (ms, calls) in prof.items():
-            if calls == 0:
-                continue
-            avg = ms / calls
-            c, cand = counters_for(counters, name, C > 16)
-            e = dict(avg_ms=avg, calls=calls, kernel=kernel_that_ran(name, cand, C))
-            if c is not None:
-                st = stale_kernels(cand, rec_build, live_build)
-                if st:                                  # counters of another build of this kernel: no price, say so
-                    e["counters_stale"] = st
-                    c = None
-            ex = executed_fp64_flops(c)
-            if ex is not None:
-                e["executed_fp64_flop_per_launch"] = ex["total"]
-                e["executed_fp64_mfma_share"] = ex["mfma"] / ex["total"] if ex["total"] else 0.0
-                e["executed_tflops"] = ex["total"] / (avg * 1e-3) / 1e12
-                e["frac_fp64_peak"] = e["executed_tflops"] / FP64_PEAK_TFLOPS
-                if "lane_utilisation" in ex:
-                    e["valu_lane_utilisation"] = ex["lane_utilisation"]
-                    e["useful_frac_fp64_peak"] = ex["useful"] / (avg * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
-            tr = hbm_traffic_bytes(c)
-            if tr is not None:
-                e["hbm_bytes_per_launch"] = tr
-                e["hbm_gbs"] = tr["total"] / (avg * 1e-3) / 1e9
-                e["frac_hbm_peak"] = e["hbm_gbs"] / HBM_PEAK_GBS
-            if per_kernel.get(name, 0.0) > 0:
-                e["algorithmic_flop_per_launch"] = per_kernel[name] * B
-                e["algorithmic_tflops"] = per_kernel[name] * B / (avg * 1e-3) / 1e12
-            if name in bytes_k:
-                e["algorithmic_bytes_per_launch"] = bytes_k[name] * B
-            kernels[name] = e
-        roofline = None
-        if dom_name is not None and dom_name in kernels:
-            k = kernels[dom_name]
-            if "executed_tflops" in k:
-                mf = k["executed_fp64_mfma_share"]
-                roofline = dict(kernel=k["kernel"], stage=dom_name, bound="mfma" if mf > 0.5 else "valu", achieved=k["executed_tflops"], peak=FP64_PEAK_TFLOPS,
-                                unit="TFLOP/s", frac=k["frac_fp64_peak"],
-                                traffic=k.get("hbm_bytes_per_launch", {}).get("total"), avg_launch_ms=k["avg_ms"],
-                                launches_timed=k["calls"], executed_fp64_flop_per_launch=k["executed_fp64_flop_per_launch"],
-                                mfma_share_of_executed=mf, lane_utilisation=k.get("valu_lane_utilisation"),
-                                useful_frac=k.get("useful_frac_fp64_peak"),
-                                algorithmic=dict(tflops=k.get("algorithmic_tflops"), flop_per_launch=k.get("algorithmic_flop_per_launch"),
-                                                 note="SURVEY 8(d) dense formulation of the reference / the same time; not a "
-                                                      "fraction of the peak (the kernel executes fewer operations)"),
-                                counters=csrc,
-                                note="achieved = EXECUTED FP64 operations per launch (rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 "
-                                     "lanes, FMA = 2, + SQ_INSTS_VALU_MFMA_MOPS_F64 x 512) / HIP-event time of the launches inside "
-                                     "the timed region; peak: FP64 vector and FP64 MFMA peaks coincide on MI355X (78.6 TFLOP/s), "
-                                     "`bound` names the pipe that carries most of the executed operations; traffic = HBM bytes per "
-                                     "launch (FETCH_SIZE x 2 + WRITE_SIZE); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 "
-                                     "SQ_ACTIVE_INST_VALU), useful_frac = (VALU operations x lane_utilisation + matrix-core "
-                                     "operations) / time / peak: the executed figure counts masked-off lanes, this one does not")
-            else:
-                roofline = dict(kernel=k["kernel"], stage=dom_name, bound="valu", achieved=None, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=None,
-                                traffic=None, avg_launch_ms=k["avg_ms"], launches_timed=k["calls"],
-                                counters_stale=bool(k.get("counters_stale")),
-                                algorithmic=dict(tflops=k.get("algorithmic_tflops"), flop_per_launch=k.get("algorithmic_flop_per_launch")),
-                                counters=csrc,
-                                note=("the committed SQ counters of this kernel were collected on ANOTHER build of its translation "
-                                      "unit (%s): not used" % ", ".join(k["counters_stale"])) if k.get("counters_stale") else
-                                     "no committed SQ counters for this workload: the executed-operation count, and with it the "
-                                     "achieved fraction, is unknown (collect with tools/gpu_counters.sh)")
+        kernels, roofline = price_kernels(prof, dom_name, counters, csrc, rec_build, live_build, C, B, per_kernel, bytes_k)
         cpu, parity = None, None
         if world > 1 and not real_lm:
             parity = dict(sample=world, filters="filter 0 of every rank", max_rel_cov_err=float(summ[:, 3].max()),
@@ -677,8 +685,8 @@ def run_workload(args, grp, aux=False):
 
 REPLAY_TOOL = os.path.join(ROOT, "ingvio_amd", "lib", "ingvio_replay")
 LATENCY_STREAMS = {      # SynthStream.h specs: every `life` frames a whole cohort of tracks is lost -> one RemoveLost update over all of them
-    "config2": "feats=150,clones=11,life=10,cohort=1,frames=75,key=1",
-    "config5": "feats=300,clones=30,life=29,cohort=1,frames=125,key=1",
+    "config2": "feats=150,clones=11,life=10,cohort=1,birth_frame=2,frames=75,key=1",
+    "config5": "feats=300,clones=30,life=28,cohort=1,birth_frame=2,frames=125,key=1",
 }
 
 

@@ -6,6 +6,13 @@
 
 typedef double double4_f __attribute__((ext_vector_type(4)));
 
+// The per-lane selects of the elimination ("this lane's row of the 4 x 4 block": kq == 0 ? r0 : kq == 1 ? r1 : ...) must stay
+// v_cndmask chains.  Left alone, the compiler SINKS each operand into its own exec-masked branch (the last reciprocal is computed
+// under `kq == 3` only): the same instructions issue anyway, plus four s_cbranch_exec* per panel, and the basic-block boundaries stop
+// the scheduler from interleaving independent chains (seen in the ISA of gate4 / gate5, round 4).  Pinning the operands as
+// outputs of an empty volatile asm keeps them in the straight-line block.
+#define PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+
 __device__ __forceinline__ void inv3sym(const double N[9], double out[9])
 {
     const double a = N[0], b = N[1], c = N[2], d = N[4], e = N[5], f = N[8];
@@ -407,6 +414,7 @@ __device__ __forceinline__ void gate3_body(
         const bool tail = (np & 3) != 0 && 4 * (np >> 2) >= 16 * (SH::NTL - 1);
         const int npan = tail ? np >> 2 : (np + 3) >> 2, rem = tail ? np & 3 : 0;
         const int kq = tid >> 4, l15 = tid & 15;
+        const double mk0 = kq == 0 ? 1.0 : 0.0, mk1 = kq == 1 ? 1.0 : 0.0, mk2 = kq == 2 ? 1.0 : 0.0, mk3 = kq == 3 ? 1.0 : 0.0;      // row selectors of the 4 x 4 block (see PIN4)
         // Tile fill, branch-free: one (clamped) LDS read + selects per element.  Row classes are compile-time:
         // i = 16 ti + kq + 4 r is a border row exactly for (ti, r) = (NTL-1, 1) (then i - KP = kq), rows past the
         // border (ti = NTL-1, r >= 2) are zero; whether a K row/column is real (< np) or a unit pad is a lane select.
@@ -504,7 +512,7 @@ __device__ __forceinline__ void gate3_body(
                     const double x1 = m[t][1] - l10 * x0;
                     const double x2 = m[t][2] - l20 * x0 - l21 * x1;
                     const double x3 = m[t][3] - l30 * x0 - l31 * x1 - l32 * x2;
-                    double xs = kq == 0 ? x0 : (kq == 1 ? x1 : (kq == 2 ? x2 : x3));
+                    double xs = fma(mk3, x3, fma(mk2, x2, fma(mk1, x1, mk0 * x0)));
                     if (16 * t + l15 <= 4 * k + 3) xs = 0.0;              // pivot rows and everything above: finished
                     A[t] = xs;
                     B[t] = -xs * dsel;
@@ -746,6 +754,10 @@ __device__ __forceinline__ void gate4_body(CovView cv, FrameView fv, MsckfOpts o
     }
     wave_sync();
     dbg_stamp(7);
+#if defined(GATE4_STOP_AFTER) && GATE4_STOP_AFTER == 1      // ablation probe (tools/gpu_gate_ablation.sh): time of the front alone
+    if (lane == 0) { gamma_out[oidx] = sh.Rb[0][0] + sh.w[0] + sh.vNinv[nobs - 1][8]; accept_out[oidx] = 0; }
+    return;
+#endif
     // ================= Kr blocks, one observation pair per lane =================
     const int tid = lane;
     const int nred = nobs - 1, np = 3 * nred;
@@ -783,8 +795,13 @@ __device__ __forceinline__ void gate4_body(CovView cv, FrameView fv, MsckfOpts o
     }
     wave_sync();
     dbg_stamp(8);
+#if defined(GATE4_STOP_AFTER) && GATE4_STOP_AFTER == 2      // front + pair blocks
+    if (lane == 0) { gamma_out[oidx] = sh.kp[0] + sh.kp[np * (np + 1) / 2 - 1]; accept_out[oidx] = 0; }
+    return;
+#endif
     // ================= blocked LDL^T on the matrix cores (see gate3_body) =================
     const int kq = tid >> 4, l15 = tid & 15;
+    const double mk0 = kq == 0 ? 1.0 : 0.0, mk1 = kq == 1 ? 1.0 : 0.0, mk2 = kq == 2 ? 1.0 : 0.0, mk3 = kq == 3 ? 1.0 : 0.0;      // row selectors of the 4 x 4 block (see PIN4)
     const int npan = (np + 3) >> 2;
     double4_f T[NLT];
     bool jreal[NTL];
@@ -819,6 +836,16 @@ __device__ __forceinline__ void gate4_body(CovView cv, FrameView fv, MsckfOpts o
         }
     }
     wave_sync();                              // kp is dead from here on: its LDS becomes the panel buffer
+#if defined(GATE4_STOP_AFTER) && GATE4_STOP_AFTER == 3      // front + pair blocks + tile fill
+    {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < NLT; ++q) acc += T[q][0] + T[q][1] + T[q][2] + T[q][3];
+        acc = wave_sum(acc);
+        if (lane == 0) { gamma_out[oidx] = acc; accept_out[oidx] = 0; }
+        return;
+    }
+#endif
     constexpr int KPAN = (NPMAX + 3) / 4;
 #pragma unroll
     for (int k = 0; k < KPAN; ++k) {
@@ -846,27 +873,29 @@ __device__ __forceinline__ void gate4_body(CovView cv, FrameView fv, MsckfOpts o
                 m[tt][0] = u0.x; m[tt][1] = u0.y; m[tt][2] = u1.x; m[tt][3] = u1.y;
             }
             // 4x4 LDL^T of the diagonal block (every lane, uniform data)
-            const double r0 = fast_rcp(a4[0][0]);
+            double r0 = fast_rcp(a4[0][0]);
             const double l10 = a4[1][0] * r0, l20 = a4[2][0] * r0, l30 = a4[3][0] * r0;
-            const double r1 = fast_rcp(a4[1][1] - l10 * a4[1][0]);
+            double r1 = fast_rcp(a4[1][1] - l10 * a4[1][0]);
             const double t21 = a4[2][1] - l20 * a4[1][0], t31 = a4[3][1] - l30 * a4[1][0];
             const double l21 = t21 * r1, l31 = t31 * r1;
-            const double r2 = fast_rcp(a4[2][2] - l20 * a4[2][0] - l21 * t21);
+            double r2 = fast_rcp(a4[2][2] - l20 * a4[2][0] - l21 * t21);
             const double t32 = a4[3][2] - l30 * a4[2][0] - l31 * t21;
             const double l32 = t32 * r2;
-            const double r3 = fast_rcp(a4[3][3] - l30 * a4[3][0] - l31 * t31 - l32 * t32);
+            double r3 = fast_rcp(a4[3][3] - l30 * a4[3][0] - l31 * t31 - l32 * t32);
+            PIN4(r0, r1, r2, r3);
             // The last panel of the tile grid (k = 4 NTL - 1) ends ON the border row: BR is its fourth row but not a pivot - it stays
             // active (finished-row threshold one lower) and its column takes no part in the update (zero pivot reciprocal).
             const bool bord = (k == 4 * NTL - 1);
-            const double dsel = kq == 0 ? r0 : (kq == 1 ? r1 : (kq == 2 ? r2 : (bord ? 0.0 : r3)));
+            const double dsel = bord ? fma(mk2, r2, fma(mk1, r1, mk0 * r0)) : fma(mk3, r3, fma(mk2, r2, fma(mk1, r1, mk0 * r0)));      // this lane's pivot reciprocal (MASKSEL)
             double A[NTL], B[NTL];
 #pragma unroll
             for (int tt = tj0; tt < NTL; ++tt) {
-                const double x0 = m[tt][0];
-                const double x1 = m[tt][1] - l10 * x0;
-                const double x2 = m[tt][2] - l20 * x0 - l21 * x1;
-                const double x3 = m[tt][3] - l30 * x0 - l31 * x1 - l32 * x2;
-                double xs = kq == 0 ? x0 : (kq == 1 ? x1 : (kq == 2 ? x2 : x3));
+                double x0 = m[tt][0];
+                double x1 = m[tt][1] - l10 * x0;
+                double x2 = m[tt][2] - l20 * x0 - l21 * x1;
+                double x3 = m[tt][3] - l30 * x0 - l31 * x1 - l32 * x2;
+                PIN4(x0, x1, x2, x3);
+                double xs = fma(mk3, x3, fma(mk2, x2, fma(mk1, x1, mk0 * x0)));
                 if (16 * tt + l15 <= 4 * k + (bord ? 2 : 3)) xs = 0.0;   // pivot rows and everything above: finished
                 A[tt] = xs;
                 B[tt] = -xs * dsel;
@@ -939,6 +968,7 @@ __device__ __forceinline__ void gate4_big_back(Gate4BigShared<CMAX>& sh, const M
     using SH = Gate4BigShared<CMAX>;
     constexpr int NTL = SH::NTL, NLT = NTL * (NTL + 1) / 2, NPMAX = SH::NPMAX;
     const int kq = lane >> 4, l15 = lane & 15;
+    const double mk0 = kq == 0 ? 1.0 : 0.0, mk1 = kq == 1 ? 1.0 : 0.0, mk2 = kq == 2 ? 1.0 : 0.0, mk3 = kq == 3 ? 1.0 : 0.0;      // row selectors of the 4 x 4 block (see PIN4)
     const int np = 3 * (sh.nobs - 1), npan = (np + 3) >> 2;
     double4_f T[NLT];                         // only the tiles of this wave's rows are ever touched (the others fold away)
     bool jreal[NTL];
@@ -994,17 +1024,18 @@ __device__ __forceinline__ void gate4_big_back(Gate4BigShared<CMAX>& sh, const M
                 const double2 u0 = pr[0], u1 = pr[1];
                 a4[ra][0] = u0.x; a4[ra][1] = u0.y; a4[ra][2] = u1.x; a4[ra][3] = u1.y;
             }
-            const double r0 = fast_rcp(a4[0][0]);
+            double r0 = fast_rcp(a4[0][0]);
             const double l10 = a4[1][0] * r0, l20 = a4[2][0] * r0, l30 = a4[3][0] * r0;
-            const double r1 = fast_rcp(a4[1][1] - l10 * a4[1][0]);
+            double r1 = fast_rcp(a4[1][1] - l10 * a4[1][0]);
             const double t21 = a4[2][1] - l20 * a4[1][0], t31 = a4[3][1] - l30 * a4[1][0];
             const double l21 = t21 * r1, l31 = t31 * r1;
-            const double r2 = fast_rcp(a4[2][2] - l20 * a4[2][0] - l21 * t21);
+            double r2 = fast_rcp(a4[2][2] - l20 * a4[2][0] - l21 * t21);
             const double t32 = a4[3][2] - l30 * a4[2][0] - l31 * t21;
             const double l32 = t32 * r2;
-            const double r3 = fast_rcp(a4[3][3] - l30 * a4[3][0] - l31 * t31 - l32 * t32);
+            double r3 = fast_rcp(a4[3][3] - l30 * a4[3][0] - l31 * t31 - l32 * t32);
+            PIN4(r0, r1, r2, r3);
             const bool bord = (k == 4 * NTL - 1);            // the last panel of the grid ends ON the border row (see gate4_body)
-            const double dsel = kq == 0 ? r0 : (kq == 1 ? r1 : (kq == 2 ? r2 : (bord ? 0.0 : r3)));
+            const double dsel = bord ? fma(mk2, r2, fma(mk1, r1, mk0 * r0)) : fma(mk3, r3, fma(mk2, r2, fma(mk1, r1, mk0 * r0)));      // this lane's pivot reciprocal (MASKSEL)
             double A[NTL], B[NTL];
 #pragma unroll
             for (int tt = tj0; tt < NTL; ++tt) {
@@ -1014,7 +1045,7 @@ __device__ __forceinline__ void gate4_big_back(Gate4BigShared<CMAX>& sh, const M
                 const double x1 = u0.y - l10 * x0;
                 const double x2 = u1.x - l20 * x0 - l21 * x1;
                 const double x3 = u1.y - l30 * x0 - l31 * x1 - l32 * x2;
-                double xs = kq == 0 ? x0 : (kq == 1 ? x1 : (kq == 2 ? x2 : x3));
+                double xs = fma(mk3, x3, fma(mk2, x2, fma(mk1, x1, mk0 * x0)));
                 if (16 * tt + l15 <= 4 * k + (bord ? 2 : 3)) xs = 0.0;
                 A[tt] = xs;
                 B[tt] = -xs * dsel;

@@ -317,7 +317,8 @@ struct FilterSink : SynthSink {
     std::unique_ptr<IngvioFilter> filter;
     IngvioParams fp;
     std::vector<FrameTiming>* out = nullptr;
-    double last_truth[3] = { 0, 0, 0 };
+    double last_truth[3] = { 0, 0, 0 }, first_truth[3] = { 0, 0, 0 }, first_p[3] = { 0, 0, 0 };
+    bool have_first = false;
     bool ok = true;
     std::string err;
     void params(const std::string& t) override
@@ -334,6 +335,11 @@ struct FilterSink : SynthSink {
         const auto t0 = std::chrono::steady_clock::now();
         callFrame(m);
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (filter->framesProcessed() > before && !have_first) {        // displacement reference: the first processed frame (its truth record follows)
+            const Vec3d p = filter->state()->_extended_pose->valueTrans1();
+            for (int i = 0; i < 3; ++i) first_p[i] = p[i];
+            have_first = true; want_first_truth = true;
+        }
         if (filter->framesProcessed() > before && out) {
             FrameTiming ft;
             ft.k = (int)k; ft.ms = ms;
@@ -348,7 +354,12 @@ struct FilterSink : SynthSink {
     void callFrame(const msg::MonoFrame& m) { filter->callbackMonoFrame(m); }
     void stereo(const msg::StereoFrame& m) override { frame(m, m.header.seq, false); }
     void mono(const msg::MonoFrame& m) override { frame(m, m.header.seq, true); }
-    void truth(double, const double p[3], const double*) override { for (int i = 0; i < 3; ++i) last_truth[i] = p[i]; }
+    bool want_first_truth = false;
+    void truth(double, const double p[3], const double*) override
+    {
+        for (int i = 0; i < 3; ++i) last_truth[i] = p[i];
+        if (want_first_truth) { for (int i = 0; i < 3; ++i) first_truth[i] = p[i]; want_first_truth = false; }
+    }
 };
 
 }  // namespace
@@ -369,9 +380,11 @@ bool playSynth(const SynthConfig& cfg, const std::string& overrides, std::vector
     synthStream(cfg, s);
     if (!s.ok || !s.filter) { err = s.err.empty() ? "no filter was built" : s.err; return false; }
     if (truth_err) {
+        // the filter's world frame starts at the origin with the gravity-aligned attitude: compare displacements from the first processed frame
         const Vec3d p = s.filter->state()->_extended_pose->valueTrans1();
-        *truth_err = std::sqrt((p[0] - s.last_truth[0]) * (p[0] - s.last_truth[0]) + (p[1] - s.last_truth[1]) * (p[1] - s.last_truth[1]) +
-                               (p[2] - s.last_truth[2]) * (p[2] - s.last_truth[2]));
+        double e2 = 0;
+        for (int i = 0; i < 3; ++i) { const double d = (p[i] - s.first_p[i]) - (s.last_truth[i] - s.first_truth[i]); e2 += d * d; }
+        *truth_err = std::sqrt(e2);
     }
     return true;
 }

@@ -75,7 +75,7 @@ struct Track { long long birth; long long gen; };
 
 Track trackOf(const SynthConfig& cfg, int k, int slot)
 {
-    const int phase = cfg.cohort ? 0 : slot % cfg.life;
+    const int phase = cfg.cohort ? ((cfg.life + 1 - cfg.birth_frame) % cfg.life + cfg.life) % cfg.life : slot % cfg.life;
     const long long gen = (k - 1 + phase) / cfg.life;
     return Track{ 1 - phase + gen * cfg.life, gen };
 }

@@ -40,6 +40,9 @@ struct SynthConfig {
     int is_key_frame = 1;
     int life = 10;                // frames a track lives (observations a lost feature carries); <= clones - 1 in key-frame mode
     int cohort = 1;
+    int birth_frame = 2;          // cohort mode: the cohorts are born at frames birth_frame + m * life.  In key-frame mode the clone of
+                                  // every other frame is marginalised one frame later and takes the never-triangulated tracks anchored
+                                  // at it along (KeyframeUpdate.cpp:280-328): tracks born on those frames never reach an update
     int outlier_every = 20;
     int frames = 60;              // camera frames after the static phase
     double pixel_noise = 1e-3;    // normalised image coordinates

@@ -19,6 +19,7 @@
 #include "launch_factored.h"
 
 #include "gate_kernel.h"
+#include "gate5_kernel.h"
 
 // K3 + K5 for the window classes 6 / 11 / 16, see gate_kernel.h: workgroups of GATE_FPW waves = GATE_FPW features of one
 // filter; with GATE_FPW > 1 wave 0 runs the per-observation front for all of them (64 / GATE_FPW lanes each), then one
@@ -47,6 +48,18 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(GATE4_WPE,
     CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out, int* __restrict__ accept_out)
 {
     gate4_body<CMAX>(cv, fv, op, b0, nb, fmax_used, gamma_out, accept_out);
+}
+
+// Stereo windows up to 11 clones (round 4): the same gate with FOUR features of a filter per wave (gate5_kernel.h) - the front on 16
+// lanes per feature, every pair lane's block of P loaded once for the four features, four interleaved eliminations.
+#ifndef GATE5_WPE
+#define GATE5_WPE 2
+#endif
+template <int CMAX>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(GATE5_WPE, GATE5_WPE))) void k_feat_gate5(
+    CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out, int* __restrict__ accept_out)
+{
+    gate5_body<CMAX>(cv, fv, op, b0, nb, fmax_used, gamma_out, accept_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -844,6 +857,14 @@ static void launch_ft(const FactoredLaunch& L, hipStream_t st)
         // INGVIO_GATE=3 selects the first-generation gate (K + 4 border rows) for comparison; mono always takes it (its K lives in
         // the 2-rows-per-observation measurement space, where Hf is not a stack of identities)
         static const bool gate3 = [] { const char* e = getenv("INGVIO_GATE"); return e && e[0] == '3'; }();
+        static const bool gate4 = [] { const char* e = getenv("INGVIO_GATE"); return e && e[0] == '4'; }();      // one feature per wave (round 3)
+        if constexpr (STEREO && CMAX <= 11) {
+            if (!gate3 && !gate4) {
+                hipLaunchKernelGGL((k_feat_gate5<CMAX>), dim3(nb8 * ((L.fmax_used + 3) / 4)), dim3(WAVE), 0, st, L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used,
+                                   L.gamma, L.accept);
+                return;
+            }
+        }
         if constexpr (STEREO) {
             if (!gate3) {
                 hipLaunchKernelGGL((k_feat_gate4<CMAX>), dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st, L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used,

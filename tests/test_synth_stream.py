@@ -66,7 +66,7 @@ def frame_py(spec, k):
     Rlr, tlr = synth.t_cl2cr()
     ids, uv = [], []
     for slot in range(F):
-        phase = 0 if spec["cohort"] else slot % life
+        phase = (life + 1 - spec.get("birth_frame", 2)) % life if spec["cohort"] else slot % life
         gen = (k - 1 + phase) // life
         birth = 1 - phase + gen * life
         r = sub(seed, birth, 2, slot)
@@ -108,7 +108,7 @@ def test_splitmix64_known_answers():
 
 
 @needs_tool
-@pytest.mark.parametrize("cohort,k", [(0, 1), (0, 7), (0, 23), (1, 10), (1, 11), (1, 31)])
+@pytest.mark.parametrize("cohort,k", [(0, 1), (0, 7), (0, 23), (1, 1), (1, 2), (1, 11), (1, 12), (1, 31)])
 def test_cpp_generator_matches_python_transcription(cohort, k):
     spec = dict(SPEC, cohort=cohort)
     ids_c, uv_c, stamp = frame_cpp(spec, k)

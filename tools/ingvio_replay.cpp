@@ -32,6 +32,7 @@ static bool parseSynth(const std::string& spec, ingvio::SynthConfig& c)
         else if (k == "key") c.is_key_frame = std::atoi(v.c_str());
         else if (k == "life") c.life = std::atoi(v.c_str());
         else if (k == "cohort") c.cohort = std::atoi(v.c_str());
+        else if (k == "birth_frame") c.birth_frame = std::atoi(v.c_str());
         else if (k == "outlier_every") c.outlier_every = std::atoi(v.c_str());
         else if (k == "frames") c.frames = std::atoi(v.c_str());
         else if (k == "pixel_noise") c.pixel_noise = std::atof(v.c_str());
