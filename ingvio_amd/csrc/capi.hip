@@ -53,6 +53,10 @@ struct ingvio_ctx {
     // fused frame step that began with a restore; any other use of the covariance (view()) invalidates it
     int prof_only = -1;          // >= 0: only this kernel id is bracketed by events (ingvio_profile_select)
     bool strip_ok = false;
+    // ingvio_gnss_sat_eval's device buffers, grown on demand and kept (psr_pos / dopp_vel call it once per Gauss-Newton iteration,
+    // the aligner once per buffered epoch: per-call hipMalloc / hipFree were hundreds of implicit device syncs)
+    struct { double *e = nullptr, *o = nullptr, *r = nullptr, *f = nullptr; int cap = 0; } se;
+    bool phase_restore = false;      // the pending split step was started with restore_prior
     unsigned long long mut_seq = 0, strip_seq = 0;
     // propagation / structure staging
     double *d_Phi, *d_G, *d_dt, *d_R, *d_blk;
@@ -610,7 +614,7 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& sl : c->pin) { if (sl.p) hipHostFree(sl.p); if (sl.ev) hipEventDestroy(sl.ev); }
     if (c->qr.exec) hipGraphExecDestroy(c->qr.exec);
-    for (double* p : { c->qr.dA, c->qr.db, c->qr.ws, c->qr.dT }) if (p) hipFree(p);
+    for (double* p : { c->qr.dA, c->qr.db, c->qr.ws, c->qr.dT, c->se.e, c->se.o, c->se.r, c->se.f }) if (p) hipFree(p);
     {
         auto& a = c->alt;
         void* ap[] = { a.Phi, a.G, a.dt, a.R, a.gnss, a.idx, a.clone_idx, a.nclones, a.nfeat, a.anchor, a.dof, a.clone_R, a.clone_p, a.pf, a.uv,
@@ -1193,23 +1197,30 @@ int ingvio_gnss_sat_eval(ingvio_ctx* c, int n_epochs, const ingvio_gnss_epoch* e
         for (int s4 = 0; s4 < 4; ++s4) r[GR_IDX_CB + s4] = -1.0;
         r[GR_PSR_AMP] = e.psr_noise_amp; r[GR_DOPP_AMP] = e.dopp_noise_amp;
     }
-    double *de = nullptr, *dob = nullptr, *dr = nullptr, *df = nullptr;
-    auto freeall = [&]() { for (double* q : { de, dob, dr, df }) if (q) hipFree(q); };
-    if (hipMalloc((void**)&de, 8 * he.size()) != hipSuccess || hipMalloc((void**)&dob, 8 * ho.size()) != hipSuccess ||
-        hipMalloc((void**)&dr, 8 * hr.size()) != hipSuccess || hipMalloc((void**)&df, 8 * (size_t)n_epochs * 64 * GF_N) != hipSuccess) {
-        freeall();
-        return INGVIO_E_HIP;
+    const size_t S64 = 64;
+    if (n_epochs > c->se.cap) {
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        for (double** q : { &c->se.e, &c->se.o, &c->se.r, &c->se.f }) { if (*q) hipFree(*q); *q = nullptr; }
+        c->se.cap = 0;
+        const int cap = std::max(n_epochs, 32);
+        if (hipMalloc((void**)&c->se.e, 8 * (size_t)cap * S * GE_N) != hipSuccess || hipMalloc((void**)&c->se.o, 8 * (size_t)cap * S * GO_N) != hipSuccess ||
+            hipMalloc((void**)&c->se.r, 8 * (size_t)cap * GR_N) != hipSuccess || hipMalloc((void**)&c->se.f, 8 * (size_t)cap * S64 * GF_N) != hipSuccess) {
+            for (double** q : { &c->se.e, &c->se.o, &c->se.r, &c->se.f }) { if (*q) hipFree(*q); *q = nullptr; }
+            c->err = "hipMalloc failed (ingvio_gnss_sat_eval workspace)";
+            return INGVIO_E_HIP;
+        }
+        c->se.cap = cap;
     }
+    double *de = c->se.e, *dob = c->se.o, *dr = c->se.r, *df = c->se.f;
     int rc = up(c, de, he.data(), 8 * he.size()) | up(c, dob, ho.data(), 8 * ho.size()) | up(c, dr, hr.data(), 8 * hr.size());
     if (!rc) {
         GnssFrontLaunch L;
         memset(&L, 0, sizeof L);
         L.eph = de; L.obs = dob; L.rcv = dr; L.smax = (int)S; L.front = df;      // L.H == nullptr: no candidate rows
         launch_gnss_front(L, n_epochs, c->st);
-        rc = down_sync(c, out, df, 8 * (size_t)n_epochs * 64 * GF_N);
+        rc = down_sync(c, out, df, 8 * (size_t)n_epochs * 64 * GF_N);           // synchronises: the host vectors above may go
     }
-    hipStreamSynchronize(c->st);
-    freeall();
+    else hipStreamSynchronize(c->st);
     return rc ? INGVIO_E_HIP : last_launch(c);
 }
 
@@ -1233,9 +1244,14 @@ int ingvio_gnss_run(ingvio_ctx* c, int b0, int nb)
     if (g.m_cap == 0) return INGVIO_OK;
     const size_t mld = c->mld, hs = mld * GNSS_NCW;
     HIPCHK(c, hipMemsetAsync(c->d_status + b0, 0, sizeof(int) * (size_t)nb, c->st));
+    // after a fused frame step every filter's live covariance sits in the SECOND ping-pong half and this update (k_downdate) is in
+    // place there: the first half still holds the prior up to the propagation strips, so a following ingvio_frame_run(restore_prior)
+    // may keep restoring the strips only (0.03 instead of 0.10 ms per 512 filters)
+    const bool keep_strips = c->strip_ok && c->mut_seq == c->strip_seq;
     EkfLaunch E;
     memset(&E, 0, sizeof E);
-    E.cv = view(c); E.b0 = b0; E.nb = nb; E.H = c->d_H + (size_t)b0 * hs; E.res = c->d_res + (size_t)b0 * mld;
+    E.cv = view(c);
+    if (keep_strips) c->strip_seq = c->mut_seq; E.b0 = b0; E.nb = nb; E.H = c->d_H + (size_t)b0 * hs; E.res = c->d_res + (size_t)b0 * mld;
     E.colmap = c->d_colmap + (size_t)b0 * GNSS_NCW; E.m = c->d_m + b0; E.nc = c->d_nc + b0;
     E.noise = c->d_noiseB + (size_t)b0 * mld; E.r_kind = INGVIO_R_DIAG; E.mld = c->mld; E.hstride = (int)hs; E.cstride = GNSS_NCW;
     E.nstride = c->mld; E.Y = c->d_Y + (size_t)b0 * c->ystride; E.ystride = c->ystride; E.dx = c->d_dx;
@@ -1927,6 +1943,8 @@ static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
             else launch_marginalize(view(c), 0, B2, c->d.n_max, c->d_idx, 6, c->st);
         }
         for (int b = 0; b < B2; ++b) if (c->st_marg[b] >= 0) { c->h_n[b] -= 6; c->h_cur[b] ^= 1; }
+        // as in the unsplit step: a landmark stage belongs to ONE frame unless the caller replays the same prior
+        if (with_lm2 && !c->phase_restore) c->lm.staged = false;
         c->strip_ok = false;
         c->mut_seq++;
         if (c->alt_ready) { HIPCHK(c, hipEventRecord(c->ev_free[c->set_id], c->st)); c->free_valid[c->set_id] = true; }
@@ -1972,7 +1990,10 @@ static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
         c->strip_ok = false;
         c->mut_seq++;
         const int rc1 = run_msckf_factored(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used, nullptr, 0, 1);
-        c->phase_pending = true;                                            // h_n is already + 6: only phase 2 may follow
+        // h_n is already + 6 (the clone exists on the device): only phase 2 may follow - and only after a front half that was
+        // launched; after a refused one the step has to be abandoned with ingvio_cov_restore or replayed with
+        // ingvio_frame_run(restore_prior)
+        if (rc1 == 0) { c->phase_pending = true; c->phase_restore = restore_prior != 0; }
         return rc1;
     }
     // with a landmark update to follow, the MSCKF update is still written OUT OF PLACE (a "marginalisation" of zero columns into the

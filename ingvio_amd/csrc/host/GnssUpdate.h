@@ -7,10 +7,15 @@
 #include <memory>
 #include <vector>
 
+#include <cmath>
+#include <iomanip>
+#include <iostream>
+#include <map>
 #include <queue>
 #include <unordered_set>
 
 #include "GnssComm.h"
+#include "IngvioParams.h"
 #include "Mat3.h"
 #include "Update.h"
 
@@ -73,13 +78,50 @@ struct GvioAlignment {
 class GnssSync {
 public:
     explicit GnssSync(double unsync_thres = 0.05) : _unsync_thres(unsync_thres) {}
+    // GnssSync.h:60-74: with use_fix_time_offset the configured offset is taken and the buffers open at once
+    explicit GnssSync(const IngvioParams& fp, double unsync_thres = 0.05) : _unsync_thres(unsync_thres)
+    {
+        if (fp._use_fix_time_offset) { _gnss2local_time_offset = fp._gnss_local_offset; _isSync = true; }
+    }
     bool isSync() const { return _isSync; }
     void setSync(bool s = true) { _isSync = s; }
+    double getUnsyncTime() const { return _gnss2local_time_offset; }                                                              // GnssSync.h:91-92
+    // GnssSync::storeTimePair (GnssSync.cpp:66-134): both overloads record (arrival time on the local clock -> stamp); once three
+    // GNSS epochs and three sensor headers are held, the pair of arrivals closest to each other defines the offset that maps GNSS
+    // time onto the sensor HEADER clock, corrected by the arrival difference; accepted only if the two arrived within
+    // _unsync_thres of each other.  Either way both tables are cleared and the collection starts over.
+    void storeTimePairGnss(double curr_time, double gnss_time_sec)
+    {
+        if (_isSync) return;
+        if (_arrival_gnss.find(curr_time) == _arrival_gnss.end()) _arrival_gnss[curr_time] = gnss_time_sec;
+        tryPair();
+    }
+    void storeTimePairHeader(double curr_time, double header_time)
+    {
+        if (_isSync) return;
+        if (_arrival_header.find(curr_time) == _arrival_header.end()) _arrival_header[curr_time] = header_time;
+        tryPair();
+    }
     void bufferGnssMeas(const GnssMeas& m) { if (!_isSync) return; while (_gnss.size() > 100) _gnss.pop(); _gnss.push(m); }      // :27-46
     void bufferSppMeas(const SppMeas& m) { if (!_isSync) return; while (_spp.size() > 100) _spp.pop(); _spp.push(m); }           // :48-68
     bool getGnssMeasAt(double target_time, GnssMeas& out) { return pick(_gnss, target_time, out); }                                // :136-164
     bool getSppAt(double target_time, SppMeas& out) { return pick(_spp, target_time, out); }                                        // :166-194
 private:
+    void tryPair()
+    {
+        if (_arrival_gnss.size() < 3 || _arrival_header.size() < 3) return;
+        double delta_time = INFINITY, idx_g = 0, idx_h = 0;
+        for (const auto& g : _arrival_gnss)
+            for (const auto& h : _arrival_header)
+                if (std::fabs(g.first - h.first) < delta_time) { idx_g = g.first; idx_h = h.first; delta_time = std::fabs(idx_g - idx_h); }
+        if (delta_time < _unsync_thres) {
+            _gnss2local_time_offset = _arrival_header.at(idx_h) - _arrival_gnss.at(idx_g) - (idx_h - idx_g);
+            _isSync = true;
+            std::cout << "[GnssSync]: gnss time to local time offset = " << std::setprecision(10) << _gnss2local_time_offset << " (s) " << std::endl;
+        }
+        _arrival_gnss.clear();
+        _arrival_header.clear();
+    }
     template <class T> bool pick(std::queue<T>& q, double target_time, T& out)
     {
         if (!_isSync) return false;
@@ -94,6 +136,8 @@ private:
     }
     double _unsync_thres;
     bool _isSync = false;
+    double _gnss2local_time_offset = 0.0;
+    std::map<double, double> _arrival_gnss, _arrival_header;      // arrival (local clock) -> GNSS time (s) / sensor header stamp (s)
     std::queue<GnssMeas> _gnss;
     std::queue<SppMeas> _spp;
 };

@@ -15,7 +15,7 @@ IngvioFilter::IngvioFilter(const IngvioParams& params, std::shared_ptr<Triangula
     _keyframe_update = std::make_shared<KeyframeUpdate>(_filter_params);
     _landmark_update = std::make_shared<LandmarkUpdate>(_filter_params);                // :90
     _gnss_update = std::make_shared<GnssUpdate>(_filter_params);                        // :92-96
-    _gnss_sync = std::make_shared<GnssSync>();
+    _gnss_sync = std::make_shared<GnssSync>(_filter_params);                            // GnssSync.h:60-74
     _aligner = std::make_shared<GvioAligner>(StateManager::ctx(_state), _filter_params._gv_align_batch_size, _filter_params._gv_align_max_iter,
                                              _filter_params._gv_align_conv_epsilon, _filter_params._gv_align_vel_thres);      // :95
 }

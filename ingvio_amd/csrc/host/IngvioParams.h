@@ -37,6 +37,8 @@ public:
     double _visual_noise = 0.18;
     int _frame_select_interval = 18;
     int _is_gnss_chi2_test = 0, _is_gnss_strong_reject = 1, _is_adjust_yof = 0;
+    int _use_fix_time_offset = 0;                      // IngvioParams.cpp:113-116 (shipped configs: 1 with gnss_local_offset -18.0)
+    double _gnss_local_offset = 0.0;
     double _psr_noise_amp = 1.0, _dopp_noise_amp = 1.0;
     // GvioAligner (IngvioParams.cpp:121-124, config/fw_zed2i_f9p/ingvio_stereo.yaml:70-73)
     int _gv_align_batch_size = 25, _gv_align_max_iter = 10;

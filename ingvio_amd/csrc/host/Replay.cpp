@@ -229,6 +229,8 @@ bool applyParamsText(const std::string& text, IngvioParams& p)
         else if (key == "psr_noise_amp") num(p._psr_noise_amp);
         else if (key == "dopp_noise_amp") num(p._dopp_noise_amp);
         else if (key == "is_adjust_yof") inum(p._is_adjust_yof);
+        else if (key == "use_fix_time_offset") inum(p._use_fix_time_offset);
+        else if (key == "gnss_local_offset") num(p._gnss_local_offset);
         else if (key == "T_cl2i") iso(p._T_cl2i);
         else if (key == "T_cr2i") iso(p._T_cr2i);
         else if (key == "hip_n_max") inum(p._hip_n_max);

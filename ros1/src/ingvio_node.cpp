@@ -111,7 +111,15 @@ public:
     }
 
 private:
-    void callbackIMU(const sensor_msgs::ImuConstPtr& m) { _filter->callbackIMU(ros1::imuFromRos(*m)); }            // :381-407
+    void callbackIMU(const sensor_msgs::ImuConstPtr& m)                                                            // :381-407
+    {
+        const double aux_time = ros::Time::now().toSec();
+        if (_params._enable_gnss) {                                                                               // :385-391
+            _filter->gnssSync()->storeTimePairHeader(aux_time, m->header.stamp.toSec());
+            if (!_filter->gnssSync()->isSync()) return;
+        }
+        _filter->callbackIMU(ros1::imuFromRos(*m));
+    }
 
     void callbackMonoFrame(const feature_tracker::MonoFrameConstPtr& m)                                            // :124-250
     {
@@ -152,14 +160,17 @@ private:
         const double now = ros::Time::now().toSec();
         if (!_params._enable_gnss || _gnss.iono.size() != 8 || m->meas.empty()) return;
         const double t_gnss = ros1::gpstAbs(m->meas[0].time.week, m->meas[0].time.tow);
-        // GnssSync::storeTimePair (GnssSync.cpp:100-134): the offset between the local (ROS) clock and GPS time, fixed once
-        if (!_time_sync) { _gnss2local = now - t_gnss; _time_sync = true; _filter->gnssSync()->setSync(); }
+        // GnssSync::storeTimePair (GnssSync.cpp:66-99, called from GnssProcessor.cpp:130): arrival times of GNSS epochs and of sensor
+        // headers are paired by the shim's GnssSync; nothing is buffered before the offset GNSS time -> header clock is known
+        _filter->gnssSync()->storeTimePairGnss(now, t_gnss);
+        if (!_filter->gnssSync()->isSync()) return;
+        const double gnss2local = _filter->gnssSync()->getUnsyncTime();
         // day of year for the troposphere model (gnss_comm::time2doy): GPS epoch 1980-01-06 = day 6
         const double days = t_gnss / 86400.0 + 5.0;
         const double doy = std::fmod(days, 365.25) + 1.0;
         RawGnssEpoch raw;
         if (_gnss.epochFromRos(*m, doy, raw) <= 0) return;
-        const double stamp = t_gnss + _gnss2local;
+        const double stamp = t_gnss + gnss2local;
         // satellite states + atmosphere at the SPP position of this epoch (psr_pos), the SPP fix itself for the buffer
         auto aligner = _filter->gvioAligner();
         aligner->setIono(_gnss.iono);
@@ -170,7 +181,18 @@ private:
         std::memset(&e, 0, sizeof e);
         e.n_sat = raw.n_sat(); e.eph = raw.eph.data(); e.obs = raw.obs.data(); e.ion = _gnss.iono.data(); e.doy = doy;
         e.R_enu2ecef[0] = e.R_enu2ecef[4] = e.R_enu2ecef[8] = 1.0;
+        // Where the epoch is evaluated (elevation, Klobuchar / Saastamoinen delays ride on the buffered record; the reference's psr_res
+        // computes them at the state's ECEF position, GnssUpdate.cpp:98-122): the SPP fix of this epoch; without one (fewer than four
+        // satellites, no convergence) the filter's own ECEF position once aligned, else the last point used.  An epoch with none of
+        // the three is dropped: a receiver "at the geocentre" has no atmosphere and 90 degree elevations.
         if (have_spp) { std::memcpy(e.anchor_ecef, xyzt, 24); std::memcpy(e.cb, xyzt + 3, 32); }
+        else if (aligner->isAlign()) {
+            const Vec3d p_ecef = aligner->getTecef2w().inverse() * _filter->state()->_extended_pose->valueTrans1();
+            for (int i = 0; i < 3; ++i) e.anchor_ecef[i] = p_ecef[i];
+        }
+        else if (_have_anchor) std::memcpy(e.anchor_ecef, _last_anchor, 24);
+        else return;
+        std::memcpy(_last_anchor, e.anchor_ecef, 24); _have_anchor = true;
         std::vector<double> rec((size_t)INGVIO_GNSS_MAX_SAT * INGVIO_GNSS_SAT_REC);
         if (ingvio_gnss_sat_eval(StateManager::ctx(_filter->state()), 1, &e, rec.data()) != INGVIO_OK) return;
         _filter->callbackGnssMeas(ros1::gnssMeasFromEval(stamp, raw, _gnss.iono, rec.data()));
@@ -206,8 +228,8 @@ private:
     IngvioParams _params;
     std::unique_ptr<IngvioFilter> _filter;
     ros1::GnssFrontEnd _gnss;
-    bool _time_sync = false;
-    double _gnss2local = 0.0;
+    double _last_anchor[3] = { 0, 0, 0 };            // ECEF point the last epoch's satellite geometry / atmosphere was evaluated at
+    bool _have_anchor = false;
     ros::Subscriber _sub_frame, _sub_imu, _sub_ephem, _sub_glo_ephem, _sub_gnss_meas, _sub_iono;
     ros::Publisher _odom_w_pub, _path_w_pub, _odom_spp_pub, _path_spp_pub;
     nav_msgs::Path _path_w, _path_spp;

@@ -97,6 +97,46 @@ int main()
     const GnssMeas gm = ros1::gnssMeasFromEval(100.5, raw, fe.iono, rec.data());
     CHECK(gm.stamp == 100.5 && gm.sats.size() == 1 && gm.sats[0].sys == 0 && gm.sats[0].sv_pos[0] == 1.5e7 && gm.sats[0].sv_vel[1] == -2e3);
     CHECK(gm.sats[0].ion_delay == 3.5 && gm.sats[0].tro_delay == 2.5 && gm.sats[0].tgd == 1e-8 && gm.raw_obs.size() == 2 * INGVIO_OBS_N && gm.iono.size() == 8);
+    // ---- GnssSync::storeTimePair (GnssSync.cpp:66-134) as the node feeds it: arrivals on the local clock, header stamps on ANOTHER
+    // clock (a bag played without --clock): the offset must map GNSS time onto the header clock, minus the arrival difference ----
+    {
+        GnssSync sync(0.05);
+        const double hdr_off = -1000.0;                   // header clock = local clock - 1000 s
+        const double gps_off = 3.0e8;                     // GNSS time = local clock + 3e8 s
+        // three IMU headers arrive first: not enough GNSS epochs yet
+        for (int i = 0; i < 3; ++i) sync.storeTimePairHeader(50.00 + 0.005 * i, 50.00 + 0.005 * i + hdr_off);
+        CHECK(!sync.isSync());
+        sync.storeTimePairGnss(50.10, 50.10 + gps_off - 0.02);      // the epoch was measured 20 ms before it arrived
+        sync.storeTimePairGnss(50.20, 50.20 + gps_off - 0.02);
+        CHECK(!sync.isSync());
+        GnssMeas early; early.stamp = 1.0;
+        sync.bufferGnssMeas(early);                       // ignored before the sync (GnssSync.cpp:27-31)
+        GnssMeas out;
+        CHECK(!sync.getGnssMeasAt(1.0, out));
+        sync.storeTimePairHeader(50.298, 50.298 + hdr_off);
+        sync.storeTimePairGnss(50.30, 50.30 + gps_off - 0.02);      // third epoch: closest pair = (50.30, 50.298), 2 ms apart
+        CHECK(sync.isSync());
+        // offset = header - gnss - (arrival_h - arrival_g) = (50.298 - 1000) - (50.30 + 3e8 - 0.02) - (50.298 - 50.30)
+        const double expect = (50.298 + hdr_off) - (50.30 + gps_off - 0.02) - (50.298 - 50.30);
+        CHECK(std::fabs(sync.getUnsyncTime() - expect) < 1e-6);
+        // an epoch measured at GNSS time g is found at header time g + offset
+        GnssMeas m; m.stamp = (60.0 + gps_off) + sync.getUnsyncTime();
+        sync.bufferGnssMeas(m);
+        CHECK(sync.getGnssMeasAt(60.0 + hdr_off + 0.02, out) && out.stamp == m.stamp);
+        // arrivals further apart than the threshold: no sync, tables cleared, collection starts over
+        GnssSync far(0.05);
+        for (int i = 0; i < 3; ++i) far.storeTimePairHeader(10.0 + 0.005 * i, 10.0);
+        for (int i = 0; i < 3; ++i) far.storeTimePairGnss(10.5 + 0.1 * i, 7.0);
+        CHECK(!far.isSync());
+        far.storeTimePairGnss(10.9, 7.4);                 // only one epoch in the fresh table: still waiting
+        CHECK(!far.isSync());
+        // use_fix_time_offset (GnssSync.h:60-74): synchronised from the start with the configured offset
+        IngvioParams fp; fp._use_fix_time_offset = 1; fp._gnss_local_offset = -18.0;
+        GnssSync fixed(fp);
+        CHECK(fixed.isSync() && fixed.getUnsyncTime() == -18.0);
+        IngvioParams fq2;
+        CHECK(!GnssSync(fq2).isSync());
+    }
     std::printf("ros adapter: %d failures\n", fails);
     return fails ? 1 : 0;
 }

@@ -152,6 +152,33 @@ def test_written_recording_counts(tmp_path):
             assert recs[i - 1][0] == replay.IMU and abs(recs[i - 1][1] - r[1]) < 1e-9
 
 
+@needs_tool
+@pytest.mark.gpu
+def test_stream_through_the_callbacks_on_the_device():
+    """The cohort stream of bench.py's latency line played into IngvioFilter's callbacks (one filter, key-frame mode, RemoveLost cap
+    lifted): the frames on which a cohort is lost carry a RemoveLost update over most of its tracks, the filter follows the circle,
+    and the batched triangulation hands the update what the per-feature one would (same accept counts with either)."""
+    spec = "feats=150,clones=11,life=10,cohort=1,birth_frame=2,frames=55,key=1"
+    sets = ["--set", "hip_max_valid_ids: 0", "--set", "hip_compress_rule: 1"]
+    r = subprocess.run([TOOL, "--synth", spec, "--time"] + sets, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    frames = [l.split() for l in r.stdout.splitlines() if l.startswith("FRAME")]
+    lat = dict(x.split("=") for x in [l for l in r.stdout.splitlines() if l.startswith("LATENCY")][0].split()[1:])
+    heavy = [(int(f[1]), int(f[3]), int(f[4])) for f in frames if int(f[4]) >= 50]      # (frame, rows, accepted)
+    print("heavy frames", heavy, "latency", lat)
+    assert len(heavy) >= 3 and all(k % 10 == 2 for k, _, _ in heavy)                    # cohorts born at 2, 12, ... are lost at 12, 22, ...
+    assert all(rows == 6 * 11 for _, rows, _ in heavy)                                  # top-n compression: n = 6 x window clones rows
+    assert int(lat["heavy_frames"]) >= 2 and float(lat["heavy_median_ms"]) > float(lat["other_median_ms"]) > 0.0
+    assert float(lat["final_pos_err_m"]) < 0.25                                         # ~4 m travelled
+    clones = [int(f[7]) for f in frames[12:]]
+    assert set(clones) == {9, 10}                                                       # 11 -> two key frames marginalised -> 9, then 10
+    # as written (cap 20, all rows kept): at most 20 features per RemoveLost update
+    r2 = subprocess.run([TOOL, "--synth", spec, "--time"], capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    acc2 = [int(l.split()[4]) for l in r2.stdout.splitlines() if l.startswith("FRAME")]
+    assert max(acc2) == 20
+
+
 if __name__ == "__main__" and "--regen" in sys.argv:
     ids, uv, stamp = frame_cpp(SPEC, GOLDEN_FRAME)
     np.savez(GOLDEN, ids=ids, uv=uv, stamp=np.int64(stamp), spec=spec_str(SPEC), frame=GOLDEN_FRAME)
