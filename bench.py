@@ -454,6 +454,8 @@ def parse_args():
                     help="nominal state: the 3-column landmark blocks are padding (default) or REAL in-state SLAM landmarks that "
                          "receive rows every frame (LandmarkUpdate.cpp:32-149, batched on the device between the MSCKF update and "
                          "the marginalisation)")
+    ap.add_argument("--gnss-separate", action="store_true", help="config 3: the GNSS update as its own pass over P after the frame (round 3) "
+                    "instead of in-frame on the MSCKF write-back")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary config-3 / config-5 passes of the default run")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-filter latency figures (C++ shim stream) of the default run")
     ap.add_argument("--detail", default=DETAIL_JSON, help="where the full result (per-kernel tables, notes) is written")
@@ -495,13 +497,15 @@ def run_workload(args, grp, aux=False):
     gnss = None
     if args.config == 3:
         gnss = [synth.make_gnss(infos[b]["rng"], filters[b]) for b in range(B)]
-        ctx.gnss_stage(0, [host.gnss_rows(g) for g in gnss], frames[0]["chi2_table"], gate_rows=True, strong_reject=False)
+        # in-frame: ingvio_frame_run applies the GNSS update on the MSCKF write-back (one sweep over P); --gnss-separate: its own pass
+        ctx.gnss_stage(0, [host.gnss_rows(g) for g in gnss], frames[0]["chi2_table"], gate_rows=True, strong_reject=False,
+                       in_frame=not args.gnss_separate)
     ctx.sync()
     t_build = time.perf_counter() - t_build
 
     def one_step():
         ctx.frame_run(restore_prior=True)
-        if gnss is not None:
+        if gnss is not None and args.gnss_separate:
             ctx.gnss_run()
 
     def barrier():
@@ -542,10 +546,10 @@ def run_workload(args, grp, aux=False):
     if rank == 0 and rank_spread > 0.05:
         print("bench.py: per-rank ms/step spread %.1f %% > 5 %%: %s" % (100 * rank_spread, ["%.3f" % t for t in per_rank_ms]), file=sys.stderr)
 
-    if gnss is not None:                           # the GNSS update reuses the row-count slot: fetch the frame's results in between
+    if gnss is not None and args.gnss_separate:    # the separate GNSS pass reuses the row-count slot: fetch the frame's results in between
         ctx.frame_run(restore_prior=True)
     dx, acc, rows = ctx.frame_fetch()
-    if gnss is not None:
+    if gnss is not None and args.gnss_separate:
         ctx.gnss_run()
     n_acc = acc[:, :F].sum(axis=1)
     ok = bool(np.isfinite(dx).all() and (rows == 6 * C).all())
@@ -647,7 +651,8 @@ def run_workload(args, grp, aux=False):
                                  "stream + second device input set (ingvio_frame_stage_async); auxiliary, `value` is device-resident")
         updates = B * world * args.steps
         step_desc = ("propagate(k=10)+clone+MSCKF update" + ("+landmark update (%d in-state landmarks, per-landmark chi2 gates)" % n_lm_real if real_lm else "")
-                     + "+marginalise" + ("+GNSS update (8 sats, per-row chi2 gates)" if gnss is not None else ""))
+                     + "+marginalise" + (("+GNSS update (8 sats, per-row chi2 gates, %s)" % ("separate pass" if args.gnss_separate else "in-frame: one sweep over P"))
+                                         if gnss is not None else ""))
         # executed FP64 rate of the whole step, where counters exist for every kernel that ran
         step_exec = None
         if counters is not None:

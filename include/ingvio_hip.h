@@ -147,6 +147,14 @@ typedef struct {
     int strong_reject;
     const double* chi2_table;      /* UpdateBase::_chi_squared_table, chi2_table[dof] */
     int chi2_len;
+    int in_frame;                  /* ingvio_gnss_stage only: != 0 - the staged update belongs to the frame staged with ingvio_frame_stage
+                                    * and is applied BY ingvio_frame_run right after the frame's MSCKF update (IngvioFilter.cpp:329-362
+                                    * follows :276-327 in the same callback), in the same sweep over P: the update only reads the <= 16
+                                    * columns var_order of the posterior, which are formed first; its rank-<=16 downdate then rides on
+                                    * the MSCKF write-back (one read + one write of P for both).  Windows up to 16 clones, at most 16
+                                    * candidate rows and 16 columns, no in-frame landmark stage - otherwise ingvio_frame_run applies
+                                    * it as a separate pass.  Results: ingvio_gnss_fetch (dx in the state's index space AFTER the
+                                    * frame's marginalisation).  ingvio_gnss_run must not be called for an in-frame stage. */
 } ingvio_gnss_opts;
 int ingvio_gnss_update_batch(ingvio_ctx* ctx, int b0, int nb, const ingvio_update_block* blocks, const ingvio_gnss_opts* opts,
                              double* dx_out, int* rows_out, int* keep_out, int* status_out);

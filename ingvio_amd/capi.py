@@ -46,7 +46,8 @@ class UpdateBlock(C.Structure):
 
 
 class GnssOpts(C.Structure):
-    _fields_ = [("gate_rows", C.c_int), ("strong_reject", C.c_int), ("chi2_table", C.POINTER(C.c_double)), ("chi2_len", C.c_int)]
+    _fields_ = [("gate_rows", C.c_int), ("strong_reject", C.c_int), ("chi2_table", C.POINTER(C.c_double)), ("chi2_len", C.c_int),
+                ("in_frame", C.c_int)]
 
 
 class GnssEpoch(C.Structure):
@@ -351,11 +352,13 @@ class Context:
             arr[g].m = H.shape[0]; arr[g].res = _d(r); arr[g].R = _d(Rv)
         return arr, keep
 
-    def gnss_stage(self, b0, blocks, chi2_table, gate_rows=True, strong_reject=False):
-        """blocks: per filter (vidx, vsize, H [m, nc] candidate rows, res [m], Rdiag [m]) or None."""
+    def gnss_stage(self, b0, blocks, chi2_table, gate_rows=True, strong_reject=False, in_frame=False):
+        """blocks: per filter (vidx, vsize, H [m, nc] candidate rows, res [m], Rdiag [m]) or None.  in_frame: applied by frame_run
+        right after the frame's MSCKF update, in the same sweep over P (no gnss_run)."""
         arr, keep = self._update_blocks(blocks)
         tab = f64(chi2_table)
         o = GnssOpts(); o.gate_rows = int(gate_rows); o.strong_reject = int(strong_reject); o.chi2_table = _d(tab); o.chi2_len = len(tab)
+        o.in_frame = int(in_frame)
         self._chk(self.L.ingvio_gnss_stage(self.h, b0, len(blocks), arr, C.byref(o)))
         self._gnss_range = (b0, len(blocks))
 

@@ -27,11 +27,11 @@
 namespace {
 
 enum ProfId { PF_RESTORE, PF_PROPAGATE, PF_AUGMENT, PF_GATE, PF_FOLD, PF_MERGE, PF_EKF_CORE, PF_DOWNDATE, PF_MARG,
-              PF_GATE2, PF_GRAM, PF_INFO, PF_APPLY, PF_ROWGATE, PF_LM_BUILD, PF_LM_GEMM, PF_LM_CHOL, PF_COUNT };
+              PF_GATE2, PF_GRAM, PF_INFO, PF_APPLY, PF_ROWGATE, PF_LM_BUILD, PF_LM_GEMM, PF_LM_CHOL, PF_POSTCOLS, PF_COUNT };
 const char* kProfNames[PF_COUNT] = { "restore", "k_propagate", "k_augment", "k_msckf_gate", "k_msckf_fold",
                                      "k_msckf_merge", "k_ekf_core", "k_downdate", "k_marginalize",
                                      "k_feat_gate3", "k_feat_gram2", "k_info_update", "k_info_apply", "k_rows_gate",
-                                     "k_lm_build", "k_lm_gemm", "k_lm_chol" };
+                                     "k_lm_build", "k_lm_gemm", "k_lm_chol", "k_post_cols" };
 struct ProfRec { int id; hipEvent_t a, b; };
 
 }  // namespace
@@ -87,6 +87,13 @@ struct ingvio_ctx {
         double thr1 = 0.0;
         std::vector<int> hi;            // per filter: highest state index named by the staged var_order (+1)
         bool staged = false;
+        // in-frame stage (ingvio_gnss_opts::in_frame): applied by ingvio_frame_run.  W [B][ldp * 16]: the var_order columns of the MSCKF
+        // posterior (k_post_cols); Yf [B][ldp * 16]: the update's Cholesky-form gain, folded into k_info_apply; its own working rows
+        // count / column count / dx (the frame's m, nc and dx slots belong to the MSCKF update)
+        bool in_frame = false, fused_last = false;
+        int nc_max = 0;
+        double *W = nullptr, *Yf = nullptr, *dxf = nullptr;
+        int *mf = nullptr, *ncf = nullptr;
     } gn;
     // dense-H update workspace (kernels_lmbatch.hip + kernels_chol.hip): the batched landmark update and generic updates whose S
     // does not fit in LDS.  Rows live in Hd [m_cap][n_ld] per filter, the sweep in X / Y [ldx][m_cap].
@@ -445,8 +452,41 @@ int make_opts(ingvio_ctx* c, const ingvio_msckf_opts* o, MsckfOpts* op)
 
 // K3..K11 for filters [b0, b0+nb) using the staged frames; asynchronous.
 // phase 0: the whole update; 1: gate + gram only (the chunk partials [A | b] stay in d_Rpart); 2: solve + apply from the partials
+#define GNSS_NCW 32        // widest var_order of a staged GNSS update (the reference's is 9 + 1 + 4 + 1 = 15 columns)
+
+// In-frame GNSS update, between the MSCKF solve (stage 2) and its write-back (stage 3): the var_order columns of the posterior
+// (k_post_cols) -> per-row gates + compaction -> S, Cholesky, gain (k_ekf_core reading those columns instead of P) -> the gain
+// rides on the write-back as a rank-16 downdate (L.gY).  Working rows / counts / dx live in the stage's own buffers.
+static int gnss_in_frame_launch(ingvio_ctx* c, int b0, int nb, FactoredLaunch& L)
+{
+    auto& g = c->gn;
+    const size_t mld = c->mld, hs = mld * GNSS_NCW, ws = (size_t)c->ldp * 16;
+    L.gcolmap = g.colmap + (size_t)b0 * GNSS_NCW; L.gnc = g.nc + b0; L.gcstride = GNSS_NCW;
+    L.gW = g.W + (size_t)b0 * ws; L.gWstride = ws;
+    { ProfScope p(c, PF_POSTCOLS); L.stage = 4; launch_factored(L, c->st); }
+    EkfLaunch E;
+    memset(&E, 0, sizeof E);
+    E.cv = L.cv; E.b0 = b0; E.nb = nb; E.H = c->d_H + (size_t)b0 * hs; E.res = c->d_res + (size_t)b0 * mld;
+    E.colmap = c->d_colmap + (size_t)b0 * GNSS_NCW; E.m = g.mf + b0; E.nc = g.ncf + b0;
+    E.noise = c->d_noiseB + (size_t)b0 * mld; E.r_kind = INGVIO_R_DIAG; E.mld = c->mld; E.hstride = (int)hs; E.cstride = GNSS_NCW;
+    E.nstride = c->mld; E.Y = g.Yf + (size_t)b0 * ws; E.ystride = (int)ws; E.dx = g.dxf;
+    E.status = c->d_status; E.m_cap = g.m_cap; E.nc_cap = GNSS_NCW;
+    E.W = L.gW; E.wstride = ws; E.ypad = 16; E.marg_idx = L.marg_idx; E.marg_size = L.marg_size;
+    if (g.strong) { E.chi2 = g.chi2; E.chi2_len = g.chi2_len; E.gate_max_rows = 14; }      // GnssUpdate.cpp:286
+    RowsGateIn in{ g.H + (size_t)b0 * hs, g.res + (size_t)b0 * mld, g.noise + (size_t)b0 * mld, g.m + b0, g.colmap + (size_t)b0 * GNSS_NCW,
+                   g.nc + b0, (int)hs, GNSS_NCW };
+    {
+        ProfScope p(c, PF_ROWGATE);
+        if (launch_rows_gate(E, in, g.thr1, g.gamma + (size_t)b0 * mld, g.keep + (size_t)b0 * mld, c->st)) return INGVIO_E_CAPACITY;
+    }
+    { ProfScope p(c, PF_EKF_CORE); launch_ekf_core(E, c->st); }
+    L.gY = E.Y; L.gYstride = ws; L.gm = g.mf + b0;
+    g.fused_last = true;
+    return 0;
+}
+
 int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int stereo, int fmax_used,
-                       const int* marg_idx = nullptr, int marg_size = 0, int phase = 0)
+                       const int* marg_idx = nullptr, int marg_size = 0, int phase = 0, bool gnss_fuse = false)
 {
     FactoredLaunch L;
     memset(&L, 0, sizeof L);
@@ -468,6 +508,7 @@ int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int s
     L.mstride = c->ystride; L.n_cap = c->d.n_max;
     L.marg_idx = marg_idx; L.marg_size = marg_size; L.pc_base = c->d_pcbase + b0;
     { ProfScope p(c, PF_INFO); L.stage = 2; launch_factored(L, c->st); }
+    if (gnss_fuse) { if (int rc = gnss_in_frame_launch(c, b0, nb, L)) return rc; }
     { ProfScope p(c, PF_APPLY); L.stage = 3; launch_factored(L, c->st); }
     return last_launch(c);
 }
@@ -614,7 +655,8 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& sl : c->pin) { if (sl.p) hipHostFree(sl.p); if (sl.ev) hipEventDestroy(sl.ev); }
     if (c->qr.exec) hipGraphExecDestroy(c->qr.exec);
-    for (double* p : { c->qr.dA, c->qr.db, c->qr.ws, c->qr.dT, c->se.e, c->se.o, c->se.r, c->se.f }) if (p) hipFree(p);
+    for (double* p : { c->qr.dA, c->qr.db, c->qr.ws, c->qr.dT, c->se.e, c->se.o, c->se.r, c->se.f, c->gn.W, c->gn.Yf, c->gn.dxf }) if (p) hipFree(p);
+    for (int* p : { c->gn.mf, c->gn.ncf }) if (p) hipFree(p);
     {
         auto& a = c->alt;
         void* ap[] = { a.Phi, a.G, a.dt, a.R, a.gnss, a.idx, a.clone_idx, a.nclones, a.nfeat, a.anchor, a.dof, a.clone_R, a.clone_p, a.pf, a.uv,
@@ -1009,7 +1051,6 @@ int ingvio_ekf_update_batch(ingvio_ctx* c, int b0, int nb, const ingvio_update_b
 }
 
 // ---- GnssUpdate::updateTrackedSys for a batch (GnssUpdate.cpp:148-290): per-row gates, compaction, block gate, ekfUpdate ----
-#define GNSS_NCW 32        // widest var_order of a staged GNSS update (the reference's is 9 + 1 + 4 + 1 = 15 columns)
 
 static int gnss_alloc(ingvio_ctx* c)
 {
@@ -1089,9 +1130,23 @@ int ingvio_gnss_stage(ingvio_ctx* c, int b0, int nb, const ingvio_update_block* 
     g.gate_rows = o->gate_rows ? 1 : 0; g.strong = o->strong_reject ? 1 : 0;
     g.thr1 = o->gate_rows ? o->chi2_table[1] : __builtin_inf();
     if (!g.staged || m_cap > g.m_cap) g.m_cap = m_cap;
+    int ncm = 0;
+    for (int i = 0; i < nb; ++i) if (ncs[i] > ncm) ncm = ncs[i];
+    if (!g.staged || ncm > g.nc_max) g.nc_max = ncm;
+    g.in_frame = o->in_frame != 0;
+    g.fused_last = false;
+    if (g.in_frame && !g.W) {
+        const size_t B = c->d.batch, ws = (size_t)c->ldp * 16;
+        if (dalloc(c, &g.W, B * ws) | dalloc(c, &g.Yf, B * ws) | dalloc(c, &g.dxf, B * (size_t)c->ldp) | dalloc(c, &g.mf, B) | dalloc(c, &g.ncf, B)) return INGVIO_E_HIP;
+        HIPCHK(c, hipStreamSynchronize(c->st));
+    }
     g.staged = true;
     return INGVIO_OK;
 }
+
+// The staged GNSS update as its own pass over the covariance (ingvio_gnss_run, and ingvio_frame_run for an in-frame stage that
+// cannot ride on the MSCKF write-back)
+static int gnss_run_separate(ingvio_ctx* c, int b0, int nb, bool own_slots = false);
 
 // raw GNSS epochs -> candidate rows, on the device (kernels_gnss.hip)
 int ingvio_gnss_front_stage(ingvio_ctx* c, int b0, int nb, const ingvio_gnss_epoch* ep, const ingvio_gnss_opts* o)
@@ -1235,7 +1290,16 @@ int ingvio_gnss_run(ingvio_ctx* c, int b0, int nb)
 {
     if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || !c->gn.staged) return INGVIO_E_ARG;
+    if (c->gn.in_frame) { c->err = "the staged GNSS update is in-frame: ingvio_frame_run applies it"; return INGVIO_E_ARG; }
+    return gnss_run_separate(c, b0, nb);
+}
+
+// own_slots: called by ingvio_frame_run for an in-frame stage - row count, column count and dx go to the stage's own buffers (the
+// frame's slots keep the MSCKF update's results for ingvio_frame_fetch) and the frame's status bits stay
+static int gnss_run_separate(ingvio_ctx* c, int b0, int nb, bool own_slots)
+{
     auto& g = c->gn;
+    g.fused_last = own_slots;
     int n_cap = 0;
     for (int i = 0; i < nb; ++i) {
         if (g.hi[b0 + i] > c->h_n[b0 + i]) return INGVIO_E_NOT_IN_STATE;          // checkSubOrder against the LIVE state
@@ -1243,7 +1307,7 @@ int ingvio_gnss_run(ingvio_ctx* c, int b0, int nb)
     }
     if (g.m_cap == 0) return INGVIO_OK;
     const size_t mld = c->mld, hs = mld * GNSS_NCW;
-    HIPCHK(c, hipMemsetAsync(c->d_status + b0, 0, sizeof(int) * (size_t)nb, c->st));
+    if (!own_slots) HIPCHK(c, hipMemsetAsync(c->d_status + b0, 0, sizeof(int) * (size_t)nb, c->st));
     // after a fused frame step every filter's live covariance sits in the SECOND ping-pong half and this update (k_downdate) is in
     // place there: the first half still holds the prior up to the propagation strips, so a following ingvio_frame_run(restore_prior)
     // may keep restoring the strips only (0.03 instead of 0.10 ms per 512 filters)
@@ -1252,9 +1316,9 @@ int ingvio_gnss_run(ingvio_ctx* c, int b0, int nb)
     memset(&E, 0, sizeof E);
     E.cv = view(c);
     if (keep_strips) c->strip_seq = c->mut_seq; E.b0 = b0; E.nb = nb; E.H = c->d_H + (size_t)b0 * hs; E.res = c->d_res + (size_t)b0 * mld;
-    E.colmap = c->d_colmap + (size_t)b0 * GNSS_NCW; E.m = c->d_m + b0; E.nc = c->d_nc + b0;
+    E.colmap = c->d_colmap + (size_t)b0 * GNSS_NCW; E.m = (own_slots ? g.mf : c->d_m) + b0; E.nc = (own_slots ? g.ncf : c->d_nc) + b0;
     E.noise = c->d_noiseB + (size_t)b0 * mld; E.r_kind = INGVIO_R_DIAG; E.mld = c->mld; E.hstride = (int)hs; E.cstride = GNSS_NCW;
-    E.nstride = c->mld; E.Y = c->d_Y + (size_t)b0 * c->ystride; E.ystride = c->ystride; E.dx = c->d_dx;
+    E.nstride = c->mld; E.Y = c->d_Y + (size_t)b0 * c->ystride; E.ystride = c->ystride; E.dx = own_slots ? g.dxf : c->d_dx;
     E.status = c->d_status; E.m_cap = g.m_cap; E.nc_cap = GNSS_NCW;
     if (g.strong) { E.chi2 = g.chi2; E.chi2_len = g.chi2_len; E.gate_max_rows = 14; }      // GnssUpdate.cpp:286
     RowsGateIn in{ g.H + (size_t)b0 * hs, g.res + (size_t)b0 * mld, g.noise + (size_t)b0 * mld, g.m + b0, g.colmap + (size_t)b0 * GNSS_NCW,
@@ -1273,8 +1337,9 @@ int ingvio_gnss_fetch(ingvio_ctx* c, int b0, int nb, double* dx_out, int* rows_o
     if (check_range(c, b0, nb) || !c->gn.staged) return INGVIO_E_ARG;
     const size_t mld = c->mld;
     std::vector<int> status(nb, 0);
-    if (dx_out) HIPCHK(c, hipMemcpyAsync(dx_out, c->d_dx + (size_t)b0 * c->ldp, 8 * (size_t)nb * c->ldp, hipMemcpyDeviceToHost, c->st));
-    if (rows_out) HIPCHK(c, hipMemcpyAsync(rows_out, c->d_m + b0, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, c->st));
+    const bool fz = c->gn.fused_last;             // the in-frame update kept its results apart from the frame's
+    if (dx_out) HIPCHK(c, hipMemcpyAsync(dx_out, (fz ? c->gn.dxf : c->d_dx) + (size_t)b0 * c->ldp, 8 * (size_t)nb * c->ldp, hipMemcpyDeviceToHost, c->st));
+    if (rows_out) HIPCHK(c, hipMemcpyAsync(rows_out, (fz ? c->gn.mf : c->d_m) + b0, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, c->st));
     if (keep_out) HIPCHK(c, hipMemcpyAsync(keep_out, c->gn.keep + (size_t)b0 * mld, sizeof(int) * (size_t)nb * mld, hipMemcpyDeviceToHost, c->st));
     if (gamma_out) HIPCHK(c, hipMemcpyAsync(gamma_out, c->gn.gamma + (size_t)b0 * mld, 8 * (size_t)nb * mld, hipMemcpyDeviceToHost, c->st));
     if (down_sync(c, status.data(), c->d_status + b0, sizeof(int) * (size_t)nb)) return INGVIO_E_HIP;
@@ -2001,7 +2066,12 @@ static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
     // copying them first (0.035 ms per 512 filters), and the landmark downdate writes back into the first half with the real
     // marginalisation fused
     const bool lm_oop = with_lm && c->method == 1;
-    int rc = fuse ? run_msckf_factored(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used, c->d_idx, 6)
+    // in-frame GNSS stage (ingvio_gnss_opts::in_frame): on the MSCKF write-back when everything fits one sweep, else as its own pass below
+    const bool gnss_here = c->gn.staged && c->gn.in_frame && c->gn.m_cap > 0;
+    bool gnss_fuse = gnss_here && fuse && c->d.c_max <= 16 && c->gn.m_cap <= 16 && c->gn.nc_max <= 16;
+    // the update's columns must keep their indices through the frame's marginalisation: var_order entirely below the clone that goes
+    for (int b = 0; b < B && gnss_fuse; ++b) if (c->st_marg[b] < 0 || c->gn.hi[b] > c->st_marg[b]) gnss_fuse = false;
+    int rc = fuse ? run_msckf_factored(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used, c->d_idx, 6, 0, gnss_fuse)
                   : (c->method == 1 ? (lm_oop ? run_msckf_factored(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used, c->d_zero_idx, 0)
                                               : run_msckf_factored(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used))
                                     : run_msckf(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used));
@@ -2024,6 +2094,10 @@ static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
     for (int b = 0; b < B; ++b) { if (c->st_marg[b] >= 0) { c->h_n[b] -= 6; c->h_cur[b] ^= 1; } else all_marg = false; }
     c->strip_ok = fuse && all_marg && restore_prior;
     c->strip_seq = c->mut_seq;
+    if (gnss_here && !gnss_fuse) {                 // not foldable (large window, landmarks in the frame, many rows): its own pass, now
+        rc = gnss_run_separate(c, 0, B, true);
+        if (rc) return rc;
+    }
     if (c->alt_ready) {                            // this input set may be refilled once the kernels above are done with it
         HIPCHK(c, hipEventRecord(c->ev_free[c->set_id], c->st));
         c->free_valid[c->set_id] = true;

@@ -28,8 +28,11 @@ struct Gate5Shared {
         double rpsum;                // sum_o |r_perp,o|^2
     } f[NF];
     static constexpr int KPS = (KPK + 16 + 1) & ~1;
+#ifndef GATE5_DB
+#define GATE5_DB 1               // two triangles: feature f + 1's pair blocks are formed while feature f's tiles are filled
+#endif
     union alignas(16) {
-        double kp[2][KPS];           // Kr of one feature, packed lower triangle by rows (+16: unclamped reads of padding columns); two
+        double kp[GATE5_DB ? 2 : 1][KPS];           // Kr of one feature, packed lower triangle by rows (+16: unclamped reads of padding columns); two
                                      // buffers: feature f + 1's blocks are formed while feature f's tiles are filled
         double pan[NF][16 * NTL][4]; // panel exchange of the four eliminations
     };
@@ -224,7 +227,7 @@ __device__ __forceinline__ void gate5_body(CovView cv, FrameView fv, MsckfOpts o
             }
             // rank of the slots among the feature's observations after the reference one
             const int i = __popc(vq & ((1u << pc) - 1u)) - 1, i2 = __popc(vq & ((1u << pc2) - 1u)) - 1;
-            double* kp = sh.kp[fq & 1];
+            double* kp = sh.kp[GATE5_DB ? (fq & 1) : 0];
             int tri = (3 * i) * (3 * i + 1) / 2 + 3 * i2;
 #pragma unroll
             for (int a2 = 0; a2 < 3; ++a2) {
@@ -236,14 +239,14 @@ __device__ __forceinline__ void gate5_body(CovView cv, FrameView fv, MsckfOpts o
         }
     };
     double4_f T[NF][NLT];
-    pair_blocks(0);
-    wave_sync();
+    if (GATE5_DB) { pair_blocks(0); wave_sync(); }
 #pragma unroll
     for (int fq = 0; fq < NF; ++fq) {
-        if (fq + 1 < NF) pair_blocks(fq + 1);      // independent of the fill below: the scheduler interleaves the two
+        if (GATE5_DB) { if (fq + 1 < NF) pair_blocks(fq + 1); }      // independent of the fill below: the scheduler interleaves the two
+        else { pair_blocks(fq); wave_sync(); }
         const int np = np_g[fq];
         // ---- tile fill of feature fq (gate4_body's), every LDS read unconditional, the padding selected afterwards ----
-        const double* kp = sh.kp[fq & 1];
+        const double* kp = sh.kp[GATE5_DB ? (fq & 1) : 0];
         const double* wq = sh.f[fq].w;
         bool jreal[NTL];
 #pragma unroll

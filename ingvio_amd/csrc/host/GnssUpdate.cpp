@@ -1,4 +1,5 @@
 #include "GnssUpdate.h"
+#include <cstring>
 
 #include <cmath>
 #include <iostream>
@@ -88,6 +89,7 @@ int GnssUpdate::updateTrackedSys(std::shared_ptr<State> state, const GnssResidua
     ingvio_update_block blk;
     blk.vidx = vidx; blk.vsize = vsize; blk.k = nvar; blk.H = H.data(); blk.ldh = ldh; blk.m = rows; blk.res = res.data(); blk.R = Rd.data();
     ingvio_gnss_opts o;
+    std::memset(&o, 0, sizeof o);
     o.gate_rows = _is_gnss_chi2_test ? 1 : 0; o.strong_reject = _is_gnss_strong_reject ? 1 : 0;
     o.chi2_table = table.data(); o.chi2_len = (int)table.size();
     ingvio_ctx* ctx = StateManager::ctx(state);

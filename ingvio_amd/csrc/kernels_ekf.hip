@@ -22,7 +22,8 @@ __global__ __launch_bounds__(EKF_THREADS) void k_ekf_core(
     const int* __restrict__ colmap_all, int* __restrict__ m_all, const int* __restrict__ nc_all,
     const double* __restrict__ noise_all, int r_kind, int mld, int hstride, int cstride, int nstride,
     double* __restrict__ Yall, int ystride, double* __restrict__ dx_all, int* __restrict__ status,
-    const double* __restrict__ chi2, int chi2_len, int gate_max_rows)
+    const double* __restrict__ chi2, int chi2_len, int gate_max_rows,
+    const double* __restrict__ Wall, size_t wstride, int ypad, const int* __restrict__ marg_idx, int marg_size)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* sS = reinterpret_cast<double*>(smem_raw);
@@ -35,6 +36,8 @@ __global__ __launch_bounds__(EKF_THREADS) void k_ekf_core(
         return;
     }
     const double* P = cov_ptr(cv, b);
+    const double* W = Wall ? Wall + (size_t)bl * wstride : nullptr;        // in-frame update: the var_order columns of the posterior to be
+    const int midx = marg_idx ? marg_idx[bl] : -1;                         // dx after the frame's marginalisation
     const double* H = Hall + (size_t)bl * hstride;
     const double* res = res_all + (size_t)bl * mld;
     const int* cm = colmap_all + (size_t)bl * cstride;
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(EKF_THREADS) void k_ekf_core(
 #pragma unroll
             for (int ii = 0; ii < IB; ++ii) acc[ii] = 0.0;
             for (int c = 0; c < nc; ++c) {
-                const double p = P[r + (size_t)sCol[c] * ld];
+                const double p = W ? W[r + (size_t)c * ld] : P[r + (size_t)sCol[c] * ld];
                 const double* hc = H + (size_t)c * mld + ib;      // rows ib.. of column c (zero padded to mld)
 #pragma unroll
                 for (int ii = 0; ii < IB; ++ii) acc[ii] += p * hc[ii];
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(EKF_THREADS) void k_ekf_core(
     __syncthreads();
     if (__syncthreads_or(bad)) {                                                    // S = H P H^T + R is not positive definite:
         for (int r = tid; r < ld; r += EKF_THREADS) dx[r] = 0.0;                   // no update (INGVIO_E_NOT_PD), k_downdate skips the filter
-        if (tid == 0) atomicOr(&status[b], 4);
+        if (tid == 0) { atomicOr(&status[b], 4); if (W) m_all[bl] = 0; }            // in-frame: the write-back must not fold a gain in
         return;
     }
     // ---- optional block gate on the prior (GnssUpdate.cpp:286: `rows <= 14 && strong_reject && !testChiSquared(.., R, rows)`):
@@ -125,9 +128,13 @@ __global__ __launch_bounds__(EKF_THREADS) void k_ekf_core(
             Y[r + (size_t)j * ld] = x;
             d += x * sS[m * LS + j];
         }
-        dx[r] = d;
-        for (int j = m; j < ((m + 3) & ~3); ++j) Y[r + (size_t)j * ld] = 0.0;      // pad K dim for MFMA
+        if (midx < 0) dx[r] = d;
+        else if (r < midx) dx[r] = d;
+        else if (r >= midx + marg_size) dx[r - marg_size] = d;
+        const int kp = ypad > m ? ypad : ((m + 3) & ~3);
+        for (int j = m; j < kp; ++j) Y[r + (size_t)j * ld] = 0.0;                   // pad K dim for MFMA
     }
+    if (midx >= 0) for (int r = n - marg_size + tid; r < ld; r += EKF_THREADS) dx[r] = 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -141,11 +148,12 @@ __global__ __launch_bounds__(256) void k_rows_gate(
     const int* __restrict__ m_in_all, const int* __restrict__ colmap_all, const int* __restrict__ nc_all, int in_hstride, int in_cstride,
     double* __restrict__ Hall, double* __restrict__ res_all, double* __restrict__ noise_all, int* __restrict__ m_all,
     int* __restrict__ colmap_out, int* __restrict__ nc_out, int mld, int hstride, int cstride,
-    double thr, double* __restrict__ gamma_all, int* __restrict__ keep_all)
+    double thr, double* __restrict__ gamma_all, int* __restrict__ keep_all, const double* __restrict__ Wall, size_t wstride)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int bl = blockIdx.x, b = b0 + bl, tid = threadIdx.x;
     const int m = m_in_all[bl], nc = nc_all[bl], ld = cv.ldp;
+    const double* W = Wall ? Wall + (size_t)bl * wstride : nullptr;
     double* sP = reinterpret_cast<double*>(smem_raw);             // nc x nc marginal
     double* sH = sP + (size_t)nc * nc;                            // m x nc candidate rows (row-major)
     __shared__ int sPos[257];
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(256) void k_rows_gate(
     double* H = Hall + (size_t)bl * hstride;
     double* res = res_all + (size_t)bl * mld;
     double* noise = noise_all + (size_t)bl * mld;
-    for (int e = tid; e < nc * nc; e += 256) { const int c = e % nc, c2 = e / nc; sP[e] = P[cm[c] + (size_t)cm[c2] * ld]; }
+    for (int e = tid; e < nc * nc; e += 256) { const int c = e % nc, c2 = e / nc; sP[e] = W ? W[cm[c] + (size_t)c2 * ld] : P[cm[c] + (size_t)cm[c2] * ld]; }
     for (int e = tid; e < m * nc; e += 256) { const int i = e % m, c = e / m; sH[i * nc + c] = Hin[i + (size_t)c * mld]; }
     for (int c = tid; c < nc; c += 256) colmap_out[(size_t)bl * cstride + c] = cm[c];
     sPos[tid] = 0;
@@ -313,7 +321,7 @@ void launch_ekf_core(const EkfLaunch& L, hipStream_t st)
     hipFuncSetAttribute((const void*)k_ekf_core, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     hipLaunchKernelGGL(k_ekf_core, dim3(L.nb), dim3(EKF_THREADS), sm, st, L.cv, L.b0, L.H, L.res, L.colmap, L.m, L.nc,
                        L.noise, L.r_kind, L.mld, L.hstride, L.cstride, L.nstride, L.Y, L.ystride, L.dx, L.status,
-                       L.chi2, L.chi2_len, L.gate_max_rows);
+                       L.chi2, L.chi2_len, L.gate_max_rows, L.W, L.wstride, L.ypad, L.marg_idx, L.marg_size);
 }
 
 // per-row gates + compaction from the staged (pristine) rows into the working rows; returns non-zero when they do not fit in LDS
@@ -324,7 +332,7 @@ int launch_rows_gate(const EkfLaunch& L, const RowsGateIn& in, double thr, doubl
     hipFuncSetAttribute((const void*)k_rows_gate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     hipLaunchKernelGGL(k_rows_gate, dim3(L.nb), dim3(256), sm, st, L.cv, L.b0, in.H, in.res, in.noise, in.m, in.colmap, in.nc,
                        in.hstride, in.cstride, const_cast<double*>(L.H), const_cast<double*>(L.res), const_cast<double*>(L.noise), L.m,
-                       const_cast<int*>(L.colmap), const_cast<int*>(L.nc), L.mld, L.hstride, L.cstride, thr, gamma, keep);
+                       const_cast<int*>(L.colmap), const_cast<int*>(L.nc), L.mld, L.hstride, L.cstride, thr, gamma, keep, L.W, L.wstride);
     return 0;
 }
 // ---------------------------------------------------------------------------------------------

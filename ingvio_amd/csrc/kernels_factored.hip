@@ -659,21 +659,25 @@ __global__ __launch_bounds__(INFO_NT, 2) void k_info_update(
 // rest of the step faster too (propagate 0.051 -> 0.046, gate 0.286 -> 0.276): 0.730 -> 0.698 ms per step.
 #define APPLY_STORE(p, v) NT_STORE(p, v)      // dev_common.h; -DINGVIO_NO_NT builds the ordinary-store variant for A/B runs
 #define APPLY_LOADP(p) NT_LOAD(p)             // the prior's tiles (each read once) as streaming loads as well: 0.706 -> 0.693 ms per step
-template <int NC, int TW>
+// YW > 0 (round 4): a second, rank-YW downdate rides on the same sweep - P - T Pc^T - Yg Yg^T with Yg [n][YW] (ld = ldp) the
+// Cholesky-form gain of an in-frame GNSS update (GnssUpdate.cpp:290 right after the MSCKF update of the same frame): its columns
+// join T's as A fragments and Pc's in the staged B tile.  gm_all[bl] == 0: no GNSS update for that filter.
+template <int NC, int TW, int YW = 0>
 __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int nb, int wgpf, const double* __restrict__ Mall, int mstride,
                                                        const double* __restrict__ Pcall, int ystride, const int* __restrict__ m_all,
                                                        double* __restrict__ dx_all, int* __restrict__ status,
-                                                       const int* __restrict__ marg_idx, int msize, const int* __restrict__ pc_base)
+                                                       const int* __restrict__ marg_idx, int msize, const int* __restrict__ pc_base,
+                                                       const double* __restrict__ Ygall = nullptr, size_t ygstride = 0, const int* __restrict__ gm_all = nullptr)
 {
-    constexpr int MP = (NC + 3) & ~3, K4 = MP / 4, JT = (MP + 15) / 16;
+    constexpr int MP = (NC + 3) & ~3, K4 = MP / 4, JT = (MP + 15) / 16, KY = YW / 4, MPY = MP + YW;
     // sT (layout change of T, first phase) and sB (B-operand tile Pc[16 tj .. +16][0..MP), staged once per workgroup
     // per step, second phase) share their LDS
     // TW tile columns per step (round 3: 2 - half as many steps, each a dependent chain global load -> LDS -> barrier -> MFMA -> store)
     constexpr int BW = 16 * TW;
-    constexpr int ST_DOUBLES = 4 * 16 * (MP + 2), SB_DOUBLES = 2 * MP * BW;
+    constexpr int ST_DOUBLES = 4 * 16 * (MP + 2), SB_DOUBLES = 2 * MPY * BW;
     __shared__ __attribute__((aligned(16))) double sTB[ST_DOUBLES > SB_DOUBLES ? ST_DOUBLES : SB_DOUBLES];
     double (*sT)[16][MP + 2] = reinterpret_cast<double (*)[16][MP + 2]>(sTB);
-    double (*sB)[MP][BW] = reinterpret_cast<double (*)[MP][BW]>(sTB);
+    double (*sB)[MPY][BW] = reinterpret_cast<double (*)[MPY][BW]>(sTB);
     __shared__ double sV[4][16][17];
     // XCD-aware order: the workgroups of one filter share an L2 (they all stream the same Pc and M)
     const int wg = blockIdx.x, xcd = wg & 7, tq = wg >> 3;
@@ -681,9 +685,10 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     if (bl >= nb) return;
     const int b = b0 + bl;
     const bool upd = m_all[bl] != 0;
+    const bool updY = YW > 0 && gm_all[bl] != 0;
     const int midx = marg_idx ? marg_idx[bl] : -1;            // fused StateManager::marginalize of [midx, midx+msize)
     const bool fused = midx >= 0;
-    if (!upd && !fused) return;
+    if (!upd && !updY && !fused) return;
     const int n = cv.n[b], ld = cv.ldp, nt = (n + 15) >> 4;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (2 * part * 4 >= nt) return;                           // whole workgroup idle (uniform)
@@ -700,6 +705,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     const double* Pc = pcb >= 0 ? P + (size_t)pcb * ld : Pcall + (size_t)bl * ystride;
     const double* M = Mall + (size_t)bl * mstride;
     const double* tvec = M + (size_t)MP * MP;
+    const double* Yg = YW > 0 ? Ygall + (size_t)bl * ygstride : nullptr;
     const int l15 = lane & 15, kq = lane >> 4;
     auto alive = [&](int i) { return !(fused && i >= midx && i < midx + msize); };
     auto remap = [&](int i) { return (fused && i >= midx) ? i - msize : i; };
@@ -707,6 +713,16 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     dbg_stamp(11);
     // ---- T rows of this wave's (up to) two tile rows, kept as A-operand fragments ------------------------------
     double tfrag[2][K4];
+    double yfrag[2][KY > 0 ? KY : 1];
+    if (YW > 0 && updY) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (h < nrows) {
+                const int ra = min(tiR[h] * 16 + l15, n - 1);
+#pragma unroll
+                for (int k4 = 0; k4 < KY; ++k4) yfrag[h][k4] = Yg[ra + (size_t)(4 * k4 + kq) * ld];      // A[i][k] = Yg[i][k]
+            }
+    }
     if (upd) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -748,18 +764,21 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
 
     dbg_stamp(12);
     // ---- tiles (ti, tj): all waves walk tj together; the B tile is staged in LDS once for the four waves ----------
-    constexpr int STG = (MP * BW + 255) / 256;
+    constexpr int STG = (MPY * BW + 255) / 256;
     double stg[STG];
-    auto stage_load = [&](int tjj) {                           // element e = k * BW + r  ->  Pc[16 tjj + r][k]
+    auto stage_load = [&](int tjj) {                           // element e = k * BW + r  ->  Pc[16 tjj + r][k]  (k >= MP: Yg[16 tjj + r][k - MP])
 #pragma unroll
         for (int u = 0; u < STG; ++u) {
             const int e = tid + 256 * u, k = e / BW, r = e - k * BW;
-            stg[u] = (upd && e < MP * BW) ? Pc[min(16 * tjj + r, n - 1) + (size_t)k * ld] : 0.0;
+            double v = 0.0;
+            if (e < MP * BW) { if (upd) v = Pc[min(16 * tjj + r, n - 1) + (size_t)k * ld]; }
+            else if (YW > 0 && e < MPY * BW) { if (updY) v = Yg[min(16 * tjj + r, n - 1) + (size_t)(k - MP) * ld]; }
+            stg[u] = v;
         }
     };
     auto stage_store = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < STG; ++u) { const int e = tid + 256 * u; if (e < MP * BW) (&sB[buf][0][0])[e] = stg[u]; }
+        for (int u = 0; u < STG; ++u) { const int e = tid + 256 * u; if (e < MPY * BW) (&sB[buf][0][0])[e] = stg[u]; }
     };
     auto store_tile = [&](int ti, int tj, const double4_f& acc, const double (&pv)[4]) {
         // element (row, col), row >= col: stored through the mirrored address (col fastest, coalesced); its transpose
@@ -771,7 +790,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
             const double v = pv[r] - acc[r];
             if (row < n && col < n && row >= col) {
                 if (alive(row) && alive(col)) APPLY_STORE(&dst[remap(col) + (size_t)remap(row) * ld], v);
-                if (upd && row == col && v < 0.0) atomicOr(&status[b], 2);      // StateManager.cpp:413-421
+                if ((upd || updY) && row == col && v < 0.0) atomicOr(&status[b], 2);      // StateManager.cpp:413-421
             }
             sV[wave][kq + 4 * r][l15] = v;
         }
@@ -815,15 +834,24 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
             const int tj = tjj + q;
             const bool do0 = nrows > 0 && tj <= tiR[0], do1 = nrows > 1 && tj <= tiR[1];
             double bfrag[K4];
+            double bfy[KY > 0 ? KY : 1];
             if (upd && (do0 || do1)) {
 #pragma unroll
                 for (int k4 = 0; k4 < K4; ++k4) bfrag[k4] = sB[buf][4 * k4 + kq][16 * q + l15];      // B[k][j] = Pc[16 tj + j][k]
+            }
+            if (YW > 0 && updY && (do0 || do1)) {
+#pragma unroll
+                for (int k4 = 0; k4 < KY; ++k4) bfy[k4] = sB[buf][MP + 4 * k4 + kq][16 * q + l15];  // B[k][j] = Yg[16 tj + j][k]
             }
             if (do0) {
                 double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
                 if (upd) {
 #pragma unroll
                     for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tfrag[0][k4], bfrag[k4], acc, 0, 0, 0);
+                }
+                if (YW > 0 && updY) {
+#pragma unroll
+                    for (int k4 = 0; k4 < KY; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yfrag[0][k4], bfy[k4], acc, 0, 0, 0);
                 }
                 store_tile(tiR[0], tj, acc, pv[0][q]);
             }
@@ -832,6 +860,10 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
                 if (upd) {
 #pragma unroll
                     for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tfrag[1][k4], bfrag[k4], acc, 0, 0, 0);
+                }
+                if (YW > 0 && updY) {
+#pragma unroll
+                    for (int k4 = 0; k4 < KY; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yfrag[1][k4], bfy[k4], acc, 0, 0, 0);
                 }
                 store_tile(tiR[1], tj, acc, pv[1][q]);
             }
@@ -846,6 +878,67 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
         lds_barrier();
     }
     dbg_stamp(13);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Columns of the MSCKF posterior BEFORE it is written (in-frame GNSS update): W[:, c] = (P - (Pc M) Pc^T)[:, colmap[c]],
+// c < nc <= 16 - all the GNSS update reads of the covariance (GnssUpdate.cpp:148-290 runs ekfUpdate on var_order = [SE23, YOF,
+// clock states, FS]: 15 columns).  One wave per 16-row tile: T_ri = Pc[ri, :] M as in k_info_apply, then one more 16-wide product
+// against the gathered rows Pc[colmap[c], :].  Rows of a clone that the frame will marginalise are computed too (nobody reads them).
+// ---------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(256) void k_post_cols(CovView cv, int b0, const double* __restrict__ Mall, int mstride, const double* __restrict__ Pcall,
+                                                   int ystride, const int* __restrict__ m_all, const int* __restrict__ pc_base,
+                                                   const int* __restrict__ colmap_all, const int* __restrict__ nc_all, int cstride,
+                                                   double* __restrict__ Wall, size_t wstride)
+{
+    // (Pc M) Pc[v, :]^T = Pc Z with Z = M Pc[v, :]^T (MP x 16): the workgroup forms Z once (JT tile rows of 16, K4 MFMAs each, dealt
+    // to the four waves) and every wave then needs K4 MFMAs for its 16 rows instead of (JT + 1) K4 through T = Pc M
+    constexpr int MP = (NC + 3) & ~3, K4 = MP / 4, JT = (MP + 15) / 16;
+    __shared__ __attribute__((aligned(16))) double sZ[16 * JT][17];
+    const int bl = blockIdx.y, b = b0 + bl;
+    const int nc = nc_all[bl];
+    if (nc == 0) return;                                         // no GNSS rows staged for this filter (uniform for the workgroup)
+    const int n = cv.n[b], ld = cv.ldp, nt = (n + 15) >> 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int ti = blockIdx.x * 4 + wave;
+    const bool upd = m_all[bl] != 0;
+    const double* P = cov_ptr(cv, b);
+    const int pcb = upd ? pc_base[bl] : -1;
+    const double* Pc = pcb >= 0 ? P + (size_t)pcb * ld : Pcall + (size_t)bl * ystride;
+    const double* M = Mall + (size_t)bl * mstride;
+    const int* cm = colmap_all + (size_t)bl * cstride;
+    double* W = Wall + (size_t)bl * wstride;
+    const int gcol = cm[min(l15, nc - 1)];                       // state column behind W's column l15
+    if (upd) {
+        double bfrag[K4];                                        // B[k][j] = Pc[colmap[j]][k]
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4) bfrag[k4] = Pc[gcol + (size_t)(4 * k4 + kq) * ld];
+        for (int t = wave; t < JT; t += 4) {
+            double4_f z = { 0.0, 0.0, 0.0, 0.0 };
+            const int mr = min(16 * t + l15, MP - 1);
+#pragma unroll
+            for (int k4 = 0; k4 < K4; ++k4) z = __builtin_amdgcn_mfma_f64_16x16x4f64(M[(size_t)mr * MP + 4 * k4 + kq], bfrag[k4], z, 0, 0, 0);      // A[i][k] = M[16 t + i][k]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sZ[16 * t + kq + 4 * r][l15] = z[r];
+        }
+    }
+    lds_barrier();
+    if (ti >= nt) return;
+    double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
+    if (upd) {
+        const int ra = min(ti * 16 + l15, n - 1);
+#pragma unroll
+        for (int k4 = 0; k4 < K4; ++k4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((Pc + (size_t)(4 * k4) * ld)[ra + kq * ld], sZ[4 * k4 + kq][l15], acc, 0, 0, 0);
+    }
+    if (l15 < nc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = ti * 16 + kq + 4 * r;
+            if (row < n) W[row + (size_t)l15 * ld] = P[row + (size_t)gcol * ld] - acc[r];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -898,12 +991,23 @@ int launch_factored(const FactoredLaunch& L, hipStream_t st)
 {
     if (L.fv.cmax > 16) return launch_bigwin(L, st);          // large windows: kernels_bigwin.hip
     const int ncm = 6 * L.fv.cmax;
+    if (L.stage == 4) {                                       // columns of the posterior for an in-frame GNSS update (between stages 2 and 3)
+        const int nt = (L.n_cap + 15) / 16;
+#define POSTCOLS_DISPATCH(NC)                                                                                           \
+        hipLaunchKernelGGL((k_post_cols<NC>), dim3((nt + 3) / 4, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride, L.m_out, \
+                           L.pc_base, L.gcolmap, L.gnc, L.gcstride, L.gW, L.gWstride);
+        if (ncm <= 36) { POSTCOLS_DISPATCH(36) } else if (ncm <= 66) { POSTCOLS_DISPATCH(66) } else { POSTCOLS_DISPATCH(96) }
+#undef POSTCOLS_DISPATCH
+        return 0;
+    }
     if (L.stage == 3) {
         const int nt = (L.n_cap + 15) / 16, wgpf = ((nt + 1) / 2 + 3) / 4, nb8 = (L.nb + 7) / 8 * 8;
         // two tile columns per step (half the steps): measured 0.194 against 0.151 ms (256 VGPRs + 76 B scratch) - selectable only
         static const bool tw1 = [] { const char* e = getenv("INGVIO_APPLY_TW"); return !(e && e[0] == '2'); }();
 #define APPLY_DISPATCH(NC)                                                                                            \
-        if (tw1) hipLaunchKernelGGL((k_info_apply<NC, 1>), dim3(nb8 * wgpf), dim3(256), 0, st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride, L.Pc, \
+        if (L.gY) hipLaunchKernelGGL((k_info_apply<NC, 1, 16>), dim3(nb8 * wgpf), dim3(256), 0, st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride, L.Pc, \
+                           L.ystride, L.m_out, L.dx, L.status, L.marg_idx, L.marg_size, L.pc_base, L.gY, L.gYstride, L.gm); \
+        else if (tw1) hipLaunchKernelGGL((k_info_apply<NC, 1>), dim3(nb8 * wgpf), dim3(256), 0, st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride, L.Pc, \
                            L.ystride, L.m_out, L.dx, L.status, L.marg_idx, L.marg_size, L.pc_base);                    \
         else hipLaunchKernelGGL((k_info_apply<NC, 2>), dim3(nb8 * wgpf), dim3(256), 0, st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride, L.Pc, \
                            L.ystride, L.m_out, L.dx, L.status, L.marg_idx, L.marg_size, L.pc_base);

@@ -19,6 +19,15 @@ struct EkfLaunch {
     int m_cap, nc_cap;      // LDS sizing
     const double* chi2;     // optional block gate of k_ekf_core (GnssUpdate.cpp:286): device table, chi2[dof]
     int chi2_len, gate_max_rows;   // gate_max_rows > 0: updates with m <= gate_max_rows rows are gated as one block
+    // In-frame GNSS update (one pass over P): the columns var_order of the covariance are NOT read from P but from W
+    // [nb][wstride], column c of W = column colmap[c] of the MSCKF posterior that k_info_apply has yet to write (k_post_cols);
+    // Y is padded with zero columns up to ypad; dx is written in the index space AFTER the frame's marginalisation of
+    // [marg_idx[bl], + marg_size) (rows inside it are skipped)
+    const double* W;
+    size_t wstride;
+    int ypad;
+    const int* marg_idx;
+    int marg_size;
 };
 
 void launch_ekf_core(const EkfLaunch& L, hipStream_t st);

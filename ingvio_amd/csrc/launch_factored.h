@@ -31,6 +31,16 @@ struct FactoredLaunch {
     double* big_sg;       // large-window path: [nb][G][36][36][34] sparse sums (kernels_bigwin.hip)
     double* big_wk;       // large-window path: per-filter solve workspace (bigwin_wk_doubles)
     int ncol_cap;         // 6 * (context c_max): size class of the large-window solve
+    // in-frame GNSS update (windows up to 16 clones): stage 4 = k_post_cols writes gW [nb][gWstride] (columns gcolmap of the posterior);
+    // stage 3 with gY != nullptr folds the rank-16 downdate Yg Yg^T (gm[bl] rows, 0 = none) into the same sweep
+    const int* gcolmap;
+    const int* gnc;
+    int gcstride;
+    double* gW;
+    size_t gWstride;
+    const double* gY;
+    size_t gYstride;
+    const int* gm;
 };
 
 int launch_factored(const FactoredLaunch& L, hipStream_t st);

@@ -265,6 +265,65 @@ def test_config3_frame_vs_oracle(orc, strong_reject):
     ctx.close()
 
 
+@pytest.mark.parametrize("strong_reject,window", [(0, "small"), (1, "small"), (0, "large")])
+def test_config3_in_frame_gnss_vs_oracle(orc, strong_reject, window):
+    """The same frame + GNSS update with the GNSS stage marked in-frame (ingvio_gnss_opts::in_frame): ONE ingvio_frame_run applies
+    both - the var_order columns of the MSCKF posterior are formed first (k_post_cols), the gates / S / gain read them, and the
+    rank-16 downdate rides on the MSCKF write-back (k_info_apply<.., 16>): one read and one write of P.  Must give what the
+    sequential calls give: covariance, both dx (the GNSS one indexed AFTER the marginalisation), kept rows, status.  `large`: a
+    20-clone window cannot fold the update - ingvio_frame_run then applies it as its own pass, same results."""
+    from ingvio_amd import capi, host, synth
+    nb = 5
+    C, F, n_lm = (11, 150, 52) if window == "small" else (20, 60, 20)
+    n_max = ((21 + 6 + 3 * n_lm + 6 * C + 15) // 16) * 16
+    ctx = capi.Context(batch=nb, n_max=n_max, c_max=C, f_max=F, m_max=64)
+    cases = []
+    for b in range(nb):
+        flt, step, frame, info = synth.build_case(lambda P, b=b: capi.DeviceCov(ctx, b, P), host.imu_transition, seed=340 + b, F=F, C=C, n_landmarks=n_lm)
+        g = synth.make_gnss(np.random.default_rng(940 + b), flt, outliers=(5,) if b % 2 == 0 else (1, 6))
+        cases.append((flt, step, frame, info, g))
+    priors = [ctx.cov_get(b) for b in range(nb)]
+    table = cases[0][2]["chi2_table"]
+    ctx.snapshot()
+    ctx.frame_stage(0, [c[1] for c in cases], [c[2] for c in cases], cases[0][1]["sigma"], 1, 0.2, 0.2)
+    blocks = [host.gnss_rows(c[4]) for c in cases]
+    if strong_reject:                                    # filter 1: gross residuals on <= 14 rows, no row may pass on its own merit
+        v, s_, H, r, Rd = blocks[1]
+        blocks[1] = (v, s_, H[:12], np.full(12, 500.0), Rd[:12])
+    ctx.gnss_stage(0, blocks, table, gate_rows=not strong_reject, strong_reject=bool(strong_reject), in_frame=True)
+    with pytest.raises(capi.IngvioError):
+        ctx.gnss_run()                                   # an in-frame stage is applied by frame_run only
+    for rep in range(2):                                 # replayed from the same prior: identical
+        ctx.frame_run(restore_prior=True)
+        dxv, acc, rows = ctx.frame_fetch()
+        dxg, used, keep, gam, st = ctx.gnss_fetch()
+        n_post = 21 + 6 + 3 * n_lm + 6 * (C - 1)
+        for b in range(nb):
+            flt, step, frame, info, g = cases[b]
+            oc = orc.Cov(priors[b], ld=n_max)
+            dxo, acco, gamo, m = orc.frame_update(oc, step, frame, max_accept=0, compress_rule=1)
+            assert np.array_equal(acc[b, :F], acco) and rel_err(dxv[b, :n_post + 6], dxo) < 1e-9 and rows[b] == 6 * C
+            vidx, vsize, Hc, rc, Rdc = blocks[b]
+            gate = not strong_reject
+            if gate:
+                go = dict(g); go.update(chi2_test=1, chi2_table=table)
+                Ho, ro, Rdo, vio, vso = orc.gnss_rows(oc, go)
+                kept = np.flatnonzero(keep[b, :len(rc)])
+                assert used[b] == len(ro) == len(kept) and np.array_equal(rc[kept], ro)
+            else:
+                Ho, ro, Rdo, vio, vso = Hc, rc, Rdc, vidx, vsize
+            blk_ok = not (strong_reject and len(ro) <= 14) or oc.whiten(vio, vso, Ho, ro, Rdo) < table[len(ro)]
+            if blk_ok:
+                dxo2, _ = oc.ekf_update(vio, vso, Ho, ro, Rdo)
+                assert st[b] == 0 and rel_err(dxg[b, :n_post], dxo2) < 1e-9, (b, st[b])
+                assert not dxg[b, n_post:].any()
+            else:
+                assert b == 1 and st[b] == capi.REJECTED and not dxg[b].any()
+            P = ctx.cov_get(b)
+            assert ctx.n(b) == n_post and rel_err(P, oc.P) < 1e-11 and np.array_equal(P, P.T), (b, rel_err(P, oc.P))
+    ctx.close()
+
+
 def test_gnss_stage_run_is_repeatable(orc):
     """ingvio_gnss_run reads the staged rows only: running it twice from the same restored covariance gives identical bits."""
     from ingvio_amd import capi, host, synth
