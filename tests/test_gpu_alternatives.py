@@ -3,6 +3,7 @@ switched on through its environment variable in a child process (the switches ar
 tests covering it.  One toggle per case:
 
   INGVIO_GATE=3            first-generation gate (k_feat_gate3 / k_feat_gate3_big) instead of the difference-coordinate one
+  INGVIO_GATE=4            the difference-coordinate gate with ONE feature per wave (k_feat_gate4, round 3) instead of four (k_feat_gate5)
   INGVIO_INFO_GAUGE=off    full-size symmetric solve (no reduction to difference coordinates of a reference clone)
   INGVIO_INFO_SOLVE=gj     Gauss-Jordan on A Pcc + s^2 I
   INGVIO_BIG_SOLVE=regs    large-window solve on the register-resident factorisation (kernels_lmchol.hip) instead of the sweep
@@ -20,6 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 CASES = [
+    ("INGVIO_GATE", "4", ["tests/test_gpu_parity.py", "tests/test_gpu_pinning.py", "-k",
+                          "test_full_n249_batch_vs_oracle or test_msckf_small or test_window_size_classes or test_ragged or test_gate or test_sigma_and_prior_scale_sweep"]),
     ("INGVIO_GATE", "3", ["tests/test_gpu_parity.py", "-k", "test_full_n249_batch_vs_oracle or test_large_window_vs_oracle or test_msckf_small"]),
     ("INGVIO_INFO_GAUGE", "off", ["tests/test_gpu_parity.py", "-k", "test_full_n249_batch_vs_oracle or test_large_window_vs_oracle or test_window_size_classes"]),
     ("INGVIO_INFO_SOLVE", "gj", ["tests/test_gpu_parity.py", "-k", "test_full_n249_batch_vs_oracle or test_window_size_classes"]),

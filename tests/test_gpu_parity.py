@@ -283,6 +283,49 @@ def test_full_size_ragged_random_anchor_vs_oracle(orc, stereo):
     ctx2.close()
 
 
+@pytest.mark.parametrize("selected,F,C", [(0, 150, 11), (1, 149, 11), (0, 7, 11), (1, 13, 6), (0, 2, 3)])
+def test_gate_mixed_groups_of_four_vs_oracle(orc, selected, F, C):
+    """k_feat_gate5 handles FOUR features per wave: groups whose members have different observation sets (a pair lane's block of
+    P is shared, every feature takes only the pairs its own mask holds), features without any observation, with a single one (no
+    difference coordinates: gamma = |r_perp|^2 / s^2), a reference observation that is not window slot 0, feature counts that are
+    not multiples of four, the Q10 (selected-timestamp) variant - gamma and the accept mask of every feature against the oracle's
+    dense evaluation, then the posterior."""
+    from ingvio_amd import capi, host, synth
+    n_lm = 10
+    n_max = ((21 + 6 + 3 * n_lm + 6 * C + 15) // 16) * 16
+    ctx2 = capi.Context(batch=1, n_max=n_max, c_max=C, f_max=max(F, 4), m_max=64)
+    flt, step, frame, info = synth.build_case(lambda P: capi.DeviceCov(ctx2, 0, P), host.imu_transition, seed=70 + F, F=F, C=C, n_landmarks=n_lm)
+    # the update of build_case's frame is applied to the state AFTER propagate + clone: bring the device there
+    for Phi, G, dt in zip(step["Phi"], step["G"], step["dt"]):
+        flt.cov.propagate(Phi, G, dt, step["sigma"], step["enable_gnss"], step["gnss_idx"], step["sigma_cb"], step["sigma_rw"])
+    flt.cov.augment(step["R_i2w"])
+    P0 = ctx2.cov_get(0)
+    rng = np.random.default_rng(5000 + F)
+    mask = np.zeros(F, dtype=np.uint64); dof = np.zeros(F, dtype=np.int32)
+    for j in range(F):
+        kind = j % 8
+        if kind == 0: obs = []                                                     # no observation at all
+        elif kind == 1: obs = [int(rng.integers(0, C))]                            # one: nobs - 1 = 0 pivots
+        elif kind == 2: obs = list(range(1, C))                                    # reference observation = slot 1, not 0
+        elif kind == 3: obs = list(range(C))                                       # the full window
+        else: obs = sorted(rng.choice(C, size=int(rng.integers(2, C + 1)), replace=False).tolist())
+        mask[j] = np.uint64(sum(1 << int(o) for o in obs)); dof[j] = max(len(obs) - 1, 1)
+    frame = dict(frame); frame["obs_mask"] = mask; frame["dof"] = dof
+    frame["anchor"] = rng.integers(0, C, size=F).astype(np.int32)
+    dx, acc, gam, rows = ctx2.msckf_update(0, frame, selected_variant=selected)
+    oc = orc.Cov(P0, ld=n_max)
+    dxo, acco, gamo, m = oc.msckf_update(frame, max_accept=0, compress_rule=1, selected_variant=selected)
+    assert np.array_equal(acc[0, :F], acco), np.flatnonzero(acc[0, :F] != acco)
+    g = gam[0, :F]
+    empty = np.array([int(mk) == 0 for mk in mask])
+    assert np.isnan(g[empty]).all() and not acc[0, :F][empty].any()
+    ok = ~empty & np.isfinite(gamo)
+    assert np.allclose(g[ok], gamo[ok], rtol=1e-8, atol=1e-10), np.abs(g[ok] - gamo[ok]).max()
+    P = ctx2.cov_get(0)
+    assert rel_err(P, oc.P) < TIGHT and rel_err(dx[0, :P0.shape[0]], dxo) < 1e-8
+    ctx2.close()
+
+
 @pytest.mark.parametrize("C,stereo,method", [(16, True, "factored"), (16, False, "factored"), (6, True, "factored"),
                                              (6, False, "factored"), (13, True, "factored"), (4, True, "factored"),
                                              (13, True, "dense"), (16, False, "dense"), (4, False, "dense")])
