@@ -16,6 +16,15 @@
 #pragma once
 #include "gate_kernel.h"
 
+// reciprocal of a pivot in the eliminations: v_rcp_f64 + TWO Newton steps (1.1e-16 relative, dev_common.h) by default;
+// -DGATE5_RCP1: one step (2.2e-15) - a shorter dependent chain per panel (measured: see DESIGN 4.1)
+#ifdef GATE5_RCP1
+__device__ __forceinline__ double g5_rcp1(double x) { double r = __builtin_amdgcn_rcp(x); return fma(fma(-x, r, 1.0), r, r); }
+#define G5RCP(x) g5_rcp1(x)
+#else
+#define G5RCP(x) fast_rcp(x)
+#endif
+
 template <int CMAX>
 struct Gate5Shared {
     static constexpr int NF = 4;
@@ -328,16 +337,16 @@ __device__ __forceinline__ void gate5_body(CovView cv, FrameView fv, MsckfOpts o
                     const double2 u0 = pr[0], u1 = pr[1];
                     a4[ra][0] = u0.x; a4[ra][1] = u0.y; a4[ra][2] = u1.x; a4[ra][3] = u1.y;
                 }
-                const double r0 = fast_rcp(a4[0][0]);
+                const double r0 = G5RCP(a4[0][0]);
                 const double l10 = a4[1][0] * r0, l20 = a4[2][0] * r0, l30 = a4[3][0] * r0;
-                const double r1 = fast_rcp(a4[1][1] - l10 * a4[1][0]);
+                const double r1 = G5RCP(a4[1][1] - l10 * a4[1][0]);
                 const double t21 = a4[2][1] - l20 * a4[1][0], t31 = a4[3][1] - l30 * a4[1][0];
                 const double l21 = t21 * r1, l31 = t31 * r1;
-                const double r2 = fast_rcp(a4[2][2] - l20 * a4[2][0] - l21 * t21);
+                const double r2 = G5RCP(a4[2][2] - l20 * a4[2][0] - l21 * t21);
                 const double t32 = a4[3][2] - l30 * a4[2][0] - l31 * t21;
                 const double l32 = t32 * r2;
                 // the last panel of the tile grid ends ON the border row: BR is its fourth row but not a pivot (see gate4_body)
-                const double r3 = bord ? 0.0 : fast_rcp(a4[3][3] - l30 * a4[3][0] - l31 * t31 - l32 * t32);
+                const double r3 = bord ? 0.0 : G5RCP(a4[3][3] - l30 * a4[3][0] - l31 * t31 - l32 * t32);
                 if (sl == 0) {
                     double2* o = reinterpret_cast<double2*>(sh.lf[g]);
                     o[0] = make_double2(l10, l20); o[1] = make_double2(l30, l21); o[2] = make_double2(l31, l32);
