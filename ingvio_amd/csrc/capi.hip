@@ -53,6 +53,7 @@ struct ingvio_ctx {
     // fused frame step that began with a restore; any other use of the covariance (view()) invalidates it
     int prof_only = -1;          // >= 0: only this kernel id is bracketed by events (ingvio_profile_select)
     bool strip_ok = false;
+    std::vector<int> h_nclones;      // per filter: n_clones of the staged frame (picks the window class of the MSCKF kernels)
     // ingvio_gnss_sat_eval's device buffers, grown on demand and kept (psr_pos / dopp_vel call it once per Gauss-Newton iteration,
     // the aligner once per buffered epoch: per-call hipMalloc / hipFree were hundreds of implicit device syncs)
     struct { double *e = nullptr, *o = nullptr, *r = nullptr, *f = nullptr; int cap = 0; } se;
@@ -407,6 +408,7 @@ int pack_frames(ingvio_ctx* c, Uploader& up, int b0, int nb, const ingvio_msckf_
         if (C == cm) memcpy(uvi, f.uv, 32 * (size_t)F * C);                           // same layout: one block
         else for (int j = 0; j < F; ++j) memcpy(uvi + (size_t)j * cm * 4, f.uv + (size_t)j * C * 4, 32 * (size_t)C);
     });
+    for (int i = 0; i < nb; ++i) c->h_nclones[b0 + i] = fr[i].n_clones;
     up.copy(c->d_clone_idx + (size_t)b0 * cm, cidx, (size_t)nb * cm);
     up.copy(c->d_nclones + b0, ncl, nb);
     up.copy(c->d_nfeat + b0, nft, nb);
@@ -493,6 +495,7 @@ int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int s
     L.stereo = stereo; L.cv = view(c); L.fv = fview(c); L.op = op; L.b0 = b0; L.nb = nb;
     L.fmax_used = fmax_used > 0 ? fmax_used : 1;
     L.ncol_cap = 6 * c->d.c_max;
+    for (int i = 0; i < nb; ++i) if (c->h_nclones[b0 + i] > L.c_used) L.c_used = c->h_nclones[b0 + i];
     L.gamma = c->d_gamma; L.accept = c->d_accept; L.used = c->d_used; L.rec = c->d_rec;
     L.Apart = c->d_Rpart + (size_t)b0 * c->G * c->rstride; L.chunk_used = c->d_chunk_used + (size_t)b0 * c->G;
     L.G = c->G; L.rstride = c->rstride; L.noise = c->d_noise + b0;
@@ -597,6 +600,7 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     }
     memset(c->prof_ms, 0, sizeof c->prof_ms); memset(c->prof_calls, 0, sizeof c->prof_calls);
     c->h_n.assign(B, 0); c->h_cur.assign(B, 0); c->h_n_snap.assign(B, 0); c->st_marg.assign(B, -1); c->st_cidx_hi.assign(B, -1);
+    c->h_nclones.assign(B, desc->c_max);
     // Consecutive filters' covariances must not sit a power of two apart: with ldp = 256 the stride would be 512 KB, and the SAME
     // element of every filter (the window block P_cc every gate wave of a filter reads, 64 filters per XCD) would fall into the same
     // L2 sets.  67 cache lines of pad walk the filters through the sets.  (Precaution: one default bench run showed the gate at

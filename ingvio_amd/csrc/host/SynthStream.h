@@ -42,7 +42,10 @@ struct SynthConfig {
     int cohort = 1;
     int birth_frame = 2;          // cohort mode: the cohorts are born at frames birth_frame + m * life.  In key-frame mode the clone of
                                   // every other frame is marginalised one frame later and takes the never-triangulated tracks anchored
-                                  // at it along (KeyframeUpdate.cpp:280-328): tracks born on those frames never reach an update
+                                  // at it along (KeyframeUpdate.cpp:280-328): tracks born on those frames never reach an update.
+                                  // The window first holds `clones` poses at frame clones + 1 and marginalises from then on every
+                                  // second frame, always the clone of the frame before: births must have the parity of clones + 1
+                                  // (2 for an 11-pose window, 3 for a 30-pose one)
     int outlier_every = 20;
     int frames = 60;              // camera frames after the static phase
     double pixel_noise = 1e-3;    // normalised image coordinates

@@ -990,7 +990,8 @@ int factored_rec_size(int cmax)
 int launch_factored(const FactoredLaunch& L, hipStream_t st)
 {
     if (L.fv.cmax > 16) return launch_bigwin(L, st);          // large windows: kernels_bigwin.hip
-    const int ncm = 6 * L.fv.cmax;
+    const int cm_sel = (L.c_used > 0 && L.c_used <= L.fv.cmax) ? L.c_used : L.fv.cmax;      // window class by the frames (launch_factored.h)
+    const int ncm = 6 * cm_sel;
     if (L.stage == 4) {                                       // columns of the posterior for an in-frame GNSS update (between stages 2 and 3)
         const int nt = (L.n_cap + 15) / 16;
 #define POSTCOLS_DISPATCH(NC)                                                                                           \
@@ -1032,7 +1033,7 @@ int launch_factored(const FactoredLaunch& L, hipStream_t st)
 #undef INFO_DISPATCH
         return 0;
     }
-    const int cm = L.fv.cmax;
+    const int cm = cm_sel;
     const int cls = cm <= 6 ? 6 : (cm <= 11 ? 11 : (cm <= 16 ? 16 : -1));
     if (cls < 0) return -1;
 #define DISPATCH(CM)                                                         \

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(512) void k_info_solve(
 // returns 0 when the window class is handled here (6 C <= 66), non-zero otherwise (caller falls back to k_info_update)
 int launch_info_solve(const FactoredLaunch& L, hipStream_t st)
 {
-    const int ncm = 6 * L.fv.cmax;
+    const int ncm = 6 * ((L.c_used > 0 && L.c_used <= L.fv.cmax) ? L.c_used : L.fv.cmax);      // window class by the frames (launch_factored.h)
 #define SOLVE_DISPATCH(NCF, RED)                                                                                              \
     {                                                                                                                         \
         const size_t sm = SolveCfg<(RED ? NCF - 6 : NCF)>::lds_bytes();                                                       \

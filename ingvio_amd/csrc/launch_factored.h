@@ -31,6 +31,10 @@ struct FactoredLaunch {
     double* big_sg;       // large-window path: [nb][G][36][36][34] sparse sums (kernels_bigwin.hip)
     double* big_wk;       // large-window path: per-filter solve workspace (bigwin_wk_doubles)
     int ncol_cap;         // 6 * (context c_max): size class of the large-window solve
+    int c_used;           // windows up to 16 clones: the largest n_clones among the staged frames [b0, b0 + nb) (0: unknown, use fv.cmax).
+                          // The kernels are instantiated per window CLASS (6 / 11 / 16 clones); the class follows the frames, not the
+                          // context's capacity: a filter configured for 11 + 1 clones (the shim allocates max_sliding_window_poses + 1)
+                          // otherwise ran every update on the 16-clone class - Gauss-Jordan solve, one-feature-per-wave gate
     // in-frame GNSS update (windows up to 16 clones): stage 4 = k_post_cols writes gW [nb][gWstride] (columns gcolmap of the posterior);
     // stage 3 with gY != nullptr folds the rank-16 downdate Yg Yg^T (gm[bl] rows, 0 = none) into the same sweep
     const int* gcolmap;
