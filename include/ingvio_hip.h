@@ -62,7 +62,11 @@ typedef struct {
 /* State ctor (State.cpp:60-91): allocates P (batch x ldp^2 FP64, two ping-pong buffers) + workspaces. */
 int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out);
 int ingvio_ctx_destroy(ingvio_ctx* ctx);
-int ingvio_sync(ingvio_ctx* ctx);
+int ingvio_sync(ingvio_ctx* ctx);                     /* waits for the context's stream.  ingvio_propagate(_fused), ingvio_augment_clone,
+                                                       * ingvio_marginalize and ingvio_append_independent only ENQUEUE (their inputs are
+                                                       * copied into pinned staging before they return; argument / capacity errors are
+                                                       * reported at once, a device fault by the next call that synchronises: this one,
+                                                       * every cov_get / fetch / update call) */
 void* ingvio_ctx_stream(ingvio_ctx* ctx);             /* the hipStream_t all kernels are launched on */
 const char* ingvio_last_error(ingvio_ctx* ctx);
 int ingvio_ldp(ingvio_ctx* ctx);                      /* leading dimension of the device P buffers  */

@@ -64,6 +64,7 @@ struct ingvio_ctx {
     int *d_gnss, *d_idx;
     int* d_zero_idx = nullptr;      // [B] zeros: "marginalise nothing at 0" = an out-of-place write-back without compaction (frame with landmarks)
     // frame staging
+    char* d_frame_slab[2] = { nullptr, nullptr };      // the frame arrays below are views into these (frame_slab_carve); [1]: the async set
     int *d_clone_idx, *d_nclones, *d_nfeat, *d_anchor, *d_dof;
     double *d_clone_R, *d_clone_p, *d_pf, *d_uv, *d_chi2;
     unsigned long long* d_mask;
@@ -280,6 +281,27 @@ struct Uploader {
 };
 static size_t pad64(size_t b) { return (b + 63) & ~(size_t)63; }
 
+// Small host inputs of the covariance operations that return nothing from the device (propagate, clone, marginalise, append):
+// copied into the pinned ring first, so the call neither reads caller memory after it returns nor has to wait for the stream -
+// a stream synchronisation per call was 15-30 us, four of them made up most of a single filter's 0.09 ms frame (round 4).  A
+// failed launch is reported by the call that made it (hipGetLastError), a device fault by the next synchronising call.
+struct UpItem { void* dst; const void* src; size_t bytes; };
+static int stage_small(ingvio_ctx* c, const UpItem* it, int n)
+{
+    size_t tot = 0;
+    for (int i = 0; i < n; ++i) tot += pad64(it[i].bytes);
+    Uploader up{ c };
+    int rc = up.begin(tot + 64);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        if (!it[i].bytes) continue;
+        char* p = up.take<char>(it[i].bytes);
+        memcpy(p, it[i].src, it[i].bytes);
+        up.copy(reinterpret_cast<char*>(it[i].dst), p, it[i].bytes);
+    }
+    return up.end();
+}
+
 // fn(i) for i in [0, n): a few host threads when the batch is large enough to pay for them
 template <class F>
 void parallel_for(int n, F fn)
@@ -300,6 +322,32 @@ void parallel_for(int n, F fn)
     for (auto& x : th) x.join();
 }
 
+// The ten device arrays of a staged frame set live in ONE allocation, laid out exactly as pack_frames lays them out in the pinned
+// slab (same order, every array 64-byte aligned): a stage of the WHOLE batch is then one host-to-device copy instead of ten (each
+// costs ~3.5 us of API time and a ~4.7 us copy kernel on the stream - 80 us of a single filter's 0.3 ms update, round 4).
+struct FrameSlabPtrs { int *clone_idx, *nclones, *nfeat, *anchor, *dof; double *clone_R, *clone_p, *pf, *uv; unsigned long long* mask; };
+size_t frame_slab_carve(const ingvio_ctx* c, char* base, FrameSlabPtrs* out)
+{
+    const size_t B = c->d.batch, cm = c->d.c_max, fm = c->d.f_max;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { off = (off + 63) & ~(size_t)63; char* p = base ? base + off : nullptr; off += bytes; return p; };
+    FrameSlabPtrs q;
+    q.clone_idx = (int*)take(4 * B * cm); q.nclones = (int*)take(4 * B); q.nfeat = (int*)take(4 * B);
+    q.anchor = (int*)take(4 * B * fm); q.dof = (int*)take(4 * B * fm);
+    q.clone_R = (double*)take(8 * B * cm * 9); q.clone_p = (double*)take(8 * B * cm * 3);
+    q.pf = (double*)take(8 * B * fm * 3); q.uv = (double*)take(8 * B * fm * cm * 4);
+    q.mask = (unsigned long long*)take(8 * B * fm);
+    if (out) *out = q;
+    return (off + 63) & ~(size_t)63;
+}
+int frame_slab_alloc(ingvio_ctx* c, char** slab, FrameSlabPtrs* out)
+{
+    const size_t bytes = frame_slab_carve(c, nullptr, nullptr);
+    if (dalloc(c, slab, bytes)) return INGVIO_E_HIP;
+    frame_slab_carve(c, *slab, out);
+    return 0;
+}
+
 // the compute stream must not read staged inputs before the copy stream has delivered them
 int wait_inputs(ingvio_ctx* c)
 {
@@ -318,11 +366,15 @@ int prepare_async_set(ingvio_ctx* c)
         int rc = 0;
         rc |= dalloc(c, &a.Phi, (size_t)B * KMAX * 225); rc |= dalloc(c, &a.G, (size_t)B * KMAX * 180); rc |= dalloc(c, &a.dt, (size_t)B * KMAX);
         rc |= dalloc(c, &a.R, (size_t)B * 9); rc |= dalloc(c, &a.gnss, (size_t)B * 5); rc |= dalloc(c, &a.idx, B);
-        rc |= dalloc(c, &a.clone_idx, (size_t)B * cm); rc |= dalloc(c, &a.nclones, B); rc |= dalloc(c, &a.nfeat, B);
-        rc |= dalloc(c, &a.anchor, (size_t)B * fm); rc |= dalloc(c, &a.dof, (size_t)B * fm);
-        rc |= dalloc(c, &a.clone_R, (size_t)B * cm * 9); rc |= dalloc(c, &a.clone_p, (size_t)B * cm * 3);
-        rc |= dalloc(c, &a.pf, (size_t)B * fm * 3); rc |= dalloc(c, &a.uv, (size_t)B * fm * cm * 4);
-        rc |= dalloc(c, &a.chi2, CHI2_CAP); rc |= dalloc(c, &a.mask, (size_t)B * fm); rc |= dalloc(c, &a.noise, B);
+        {
+            FrameSlabPtrs q;
+            if (frame_slab_alloc(c, &c->d_frame_slab[1], &q)) rc |= 1;
+            else {
+                a.clone_idx = q.clone_idx; a.nclones = q.nclones; a.nfeat = q.nfeat; a.anchor = q.anchor; a.dof = q.dof;
+                a.clone_R = q.clone_R; a.clone_p = q.clone_p; a.pf = q.pf; a.uv = q.uv; a.mask = q.mask;
+            }
+        }
+        rc |= dalloc(c, &a.chi2, CHI2_CAP); rc |= dalloc(c, &a.noise, B);
         if (rc) return INGVIO_E_HIP;
         HIPCHK(c, hipStreamSynchronize(c->st));                        // the zero fills of dalloc
         HIPCHK(c, hipStreamCreateWithFlags(&c->st_copy, hipStreamNonBlocking));
@@ -385,6 +437,9 @@ int pack_frames(ingvio_ctx* c, Uploader& up, int b0, int nb, const ingvio_msckf_
     const int cm = c->d.c_max, fm = c->d.f_max;
     int fmx = 0;
     for (int i = 0; i < nb; ++i) if (fr[i].n_feat > fmx) fmx = fr[i].n_feat;
+    const bool whole = b0 == 0 && nb == c->d.batch;          // the pinned image then IS the device slab's image
+    up.off = (up.off + 63) & ~(size_t)63;
+    const size_t slab0 = up.off;
     int* cidx = up.take<int>((size_t)nb * cm); int* ncl = up.take<int>(nb); int* nft = up.take<int>(nb);
     int* anc = up.take<int>((size_t)nb * fm); int* dof = up.take<int>((size_t)nb * fm);
     double* cR = up.take<double>((size_t)nb * cm * 9); double* cp = up.take<double>((size_t)nb * cm * 3);
@@ -409,6 +464,11 @@ int pack_frames(ingvio_ctx* c, Uploader& up, int b0, int nb, const ingvio_msckf_
         else for (int j = 0; j < F; ++j) memcpy(uvi + (size_t)j * cm * 4, f.uv + (size_t)j * C * 4, 32 * (size_t)C);
     });
     for (int i = 0; i < nb; ++i) c->h_nclones[b0 + i] = fr[i].n_clones;
+    if (whole) {
+        up.copy(reinterpret_cast<char*>(c->d_clone_idx), up.slab->p + slab0, up.off - slab0);
+        *fmax_used = fmx;
+        return 0;
+    }
     up.copy(c->d_clone_idx + (size_t)b0 * cm, cidx, (size_t)nb * cm);
     up.copy(c->d_nclones + b0, ncl, nb);
     up.copy(c->d_nfeat + b0, nft, nb);
@@ -619,11 +679,15 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     rc |= dalloc(c, &c->d_blk, (size_t)B * 36); rc |= dalloc(c, &c->d_gnss, (size_t)B * 5); rc |= dalloc(c, &c->d_idx, B);
     rc |= dalloc(c, &c->d_zero_idx, B);
     if (!rc && hipMemset(c->d_zero_idx, 0, sizeof(int) * (size_t)B) != hipSuccess) rc = 1;
-    rc |= dalloc(c, &c->d_clone_idx, (size_t)B * cm); rc |= dalloc(c, &c->d_nclones, B); rc |= dalloc(c, &c->d_nfeat, B);
-    rc |= dalloc(c, &c->d_anchor, (size_t)B * fm); rc |= dalloc(c, &c->d_dof, (size_t)B * fm);
-    rc |= dalloc(c, &c->d_clone_R, (size_t)B * cm * 9); rc |= dalloc(c, &c->d_clone_p, (size_t)B * cm * 3);
-    rc |= dalloc(c, &c->d_pf, (size_t)B * fm * 3); rc |= dalloc(c, &c->d_uv, (size_t)B * fm * cm * 4);
-    rc |= dalloc(c, &c->d_chi2, CHI2_CAP); rc |= dalloc(c, &c->d_mask, (size_t)B * fm);
+    {
+        FrameSlabPtrs q;
+        if (frame_slab_alloc(c, &c->d_frame_slab[0], &q)) rc |= 1;
+        else {
+            c->d_clone_idx = q.clone_idx; c->d_nclones = q.nclones; c->d_nfeat = q.nfeat; c->d_anchor = q.anchor; c->d_dof = q.dof;
+            c->d_clone_R = q.clone_R; c->d_clone_p = q.clone_p; c->d_pf = q.pf; c->d_uv = q.uv; c->d_mask = q.mask;
+        }
+    }
+    rc |= dalloc(c, &c->d_chi2, CHI2_CAP);
     rc |= dalloc(c, &c->d_gamma, (size_t)B * fm); rc |= dalloc(c, &c->d_accept, (size_t)B * fm); rc |= dalloc(c, &c->d_used, (size_t)B * fm);
     rc |= dalloc(c, &c->d_Rpart, (size_t)B * c->G * c->rstride); rc |= dalloc(c, &c->d_chunk_used, (size_t)B * c->G);
     rc |= dalloc(c, &c->d_H, (size_t)B * c->hstride); rc |= dalloc(c, &c->d_res, (size_t)B * c->mld);
@@ -649,8 +713,8 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
     if (!c) return INGVIO_E_ARG;
     hipStreamSynchronize(c->st);
     void* ptrs[] = { c->Pbase, c->Psnap, c->d_cur, c->d_n, c->d_n_snap, c->d_Phi, c->d_G, c->d_dt, c->d_R, c->d_blk, c->d_gnss,
-                     c->d_idx, c->d_clone_idx, c->d_nclones, c->d_nfeat, c->d_anchor, c->d_dof, c->d_clone_R, c->d_clone_p,
-                     c->d_pf, c->d_uv, c->d_chi2, c->d_mask, c->d_gamma, c->d_accept, c->d_used, c->d_Rpart, c->d_chunk_used,
+                     c->d_idx, c->d_frame_slab[0], c->d_frame_slab[1],
+                     c->d_chi2, c->d_gamma, c->d_accept, c->d_used, c->d_Rpart, c->d_chunk_used,
                      c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk, c->d_tri_ok, c->d_hnew, c->d_multi, c->d_noiseB,
                      c->gn.H, c->gn.res, c->gn.noise, c->gn.gamma, c->gn.chi2, c->gn.m, c->gn.nc, c->gn.colmap, c->gn.keep,
                      c->gn.feph, c->gn.fobs, c->gn.frcv, c->gn.front,
@@ -663,8 +727,7 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
     for (int* p : { c->gn.mf, c->gn.ncf }) if (p) hipFree(p);
     {
         auto& a = c->alt;
-        void* ap[] = { a.Phi, a.G, a.dt, a.R, a.gnss, a.idx, a.clone_idx, a.nclones, a.nfeat, a.anchor, a.dof, a.clone_R, a.clone_p, a.pf, a.uv,
-                       a.chi2, a.mask, a.noise };
+        void* ap[] = { a.Phi, a.G, a.dt, a.R, a.gnss, a.idx, a.chi2, a.noise };      // its frame arrays: d_frame_slab (freed above)
         for (void* p : ap) if (p) hipFree(p);
         if (c->st_copy) hipStreamDestroy(c->st_copy);
         if (c->ev_copy) hipEventDestroy(c->ev_copy);
@@ -767,18 +830,16 @@ int ingvio_propagate_fused(ingvio_ctx* c, int b0, int nb, int k, const double* P
     if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || k < 1 || k > KMAX || !Phi || !G || !dt || !sigma) return INGVIO_E_ARG;
     for (int i = 0; i < nb; ++i) if (c->h_n[b0 + i] < 15) return INGVIO_E_ARG;
-    int rc = up(c, c->d_Phi, Phi, 8 * (size_t)nb * k * 225);
-    rc |= up(c, c->d_G, G, 8 * (size_t)nb * k * 180);
-    rc |= up(c, c->d_dt, dt, 8 * (size_t)nb * k);
-    if (enable_gnss && gnss_idx) rc |= up(c, c->d_gnss, gnss_idx, sizeof(int) * (size_t)nb * 5);
-    if (rc) return INGVIO_E_HIP;
+    if (wait_inputs(c)) return INGVIO_E_HIP;
+    const UpItem items[4] = { { c->d_Phi, Phi, 8 * (size_t)nb * k * 225 }, { c->d_G, G, 8 * (size_t)nb * k * 180 }, { c->d_dt, dt, 8 * (size_t)nb * k },
+                              { c->d_gnss, gnss_idx, (enable_gnss && gnss_idx) ? sizeof(int) * (size_t)nb * 5 : 0 } };
+    if (stage_small(c, items, 4)) return INGVIO_E_HIP;
     {
         ProfScope p(c, PF_PROPAGATE);
         launch_propagate(view(c), b0, nb, c->d.n_max, c->d_Phi, c->d_G, c->d_dt, k, (enable_gnss && gnss_idx) ? c->d_gnss : nullptr,
                          sigma, enable_gnss, scb, srw, c->st);
     }
-    HIPCHK(c, hipStreamSynchronize(c->st));     // staging buffers are shared: keep the API re-entrant
-    return last_launch(c);
+    return last_launch(c);                      // no stream synchronisation: the inputs were staged through the pinned ring (stage_small)
 }
 
 int ingvio_propagate(ingvio_ctx* c, int b0, int nb, const double* Phi, const double* G, const double* dt,
@@ -795,10 +856,11 @@ int ingvio_augment_clone(ingvio_ctx* c, int b0, int nb, const double* R, int* ne
         if (c->h_n[b0 + i] < 21) return INGVIO_E_ARG;
         if (c->h_n[b0 + i] + 6 > c->d.n_max) return INGVIO_E_CAPACITY;
     }
-    if (up(c, c->d_R, R, 8 * (size_t)nb * 9)) return INGVIO_E_HIP;
+    if (wait_inputs(c)) return INGVIO_E_HIP;
+    const UpItem item = { c->d_R, R, 8 * (size_t)nb * 9 };
+    if (stage_small(c, &item, 1)) return INGVIO_E_HIP;
     { ProfScope p(c, PF_AUGMENT); launch_augment(view(c), b0, nb, c->d_R, c->st); }
     for (int i = 0; i < nb; ++i) { if (new_idx) new_idx[i] = c->h_n[b0 + i]; c->h_n[b0 + i] += 6; }
-    HIPCHK(c, hipStreamSynchronize(c->st));
     return last_launch(c);
 }
 
@@ -808,10 +870,11 @@ int ingvio_marginalize(ingvio_ctx* c, int b0, int nb, const int* idx, int size)
     if (check_range(c, b0, nb) || !idx || size < 1) return INGVIO_E_ARG;
     for (int i = 0; i < nb; ++i)
         if (idx[i] >= 0 && idx[i] + size > c->h_n[b0 + i]) return INGVIO_E_NOT_IN_STATE;
-    if (up(c, c->d_idx, idx, sizeof(int) * (size_t)nb)) return INGVIO_E_HIP;
+    if (wait_inputs(c)) return INGVIO_E_HIP;
+    const UpItem item = { c->d_idx, idx, sizeof(int) * (size_t)nb };
+    if (stage_small(c, &item, 1)) return INGVIO_E_HIP;
     { ProfScope p(c, PF_MARG); launch_marginalize(view(c), b0, nb, c->d.n_max, c->d_idx, size, c->st); }
     for (int i = 0; i < nb; ++i) if (idx[i] >= 0) { c->h_n[b0 + i] -= size; c->h_cur[b0 + i] ^= 1; }
-    HIPCHK(c, hipStreamSynchronize(c->st));
     return last_launch(c);
 }
 
@@ -820,10 +883,11 @@ int ingvio_append_independent(ingvio_ctx* c, int b0, int nb, int size, const dou
     if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || !blk || size < 1 || size > 6) return INGVIO_E_ARG;
     for (int i = 0; i < nb; ++i) if (c->h_n[b0 + i] + size > c->d.n_max) return INGVIO_E_CAPACITY;
-    if (up(c, c->d_blk, blk, 8 * (size_t)nb * size * size)) return INGVIO_E_HIP;
+    if (wait_inputs(c)) return INGVIO_E_HIP;
+    const UpItem item = { c->d_blk, blk, 8 * (size_t)nb * size * size };
+    if (stage_small(c, &item, 1)) return INGVIO_E_HIP;
     launch_append(view(c), b0, nb, size, c->d_blk, c->st);
     for (int i = 0; i < nb; ++i) { if (new_idx) new_idx[i] = c->h_n[b0 + i]; c->h_n[b0 + i] += size; }
-    HIPCHK(c, hipStreamSynchronize(c->st));
     return last_launch(c);
 }
 

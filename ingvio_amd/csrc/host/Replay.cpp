@@ -1,4 +1,5 @@
 #include "Replay.h"
+#include "StateManager.h"
 
 #include <chrono>
 #include <cmath>
@@ -336,6 +337,7 @@ struct FilterSink : SynthSink {
         const int before = filter->framesProcessed();
         const auto t0 = std::chrono::steady_clock::now();
         callFrame(m);
+        ingvio_sync(StateManager::ctx(filter->state()));      // the covariance calls without results only enqueue: the frame ends when the device is done
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (filter->framesProcessed() > before && !have_first) {        // displacement reference: the first processed frame (its truth record follows)
             const Vec3d p = filter->state()->_extended_pose->valueTrans1();
