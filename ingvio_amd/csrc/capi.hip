@@ -64,6 +64,9 @@ struct ingvio_ctx {
     int *d_gnss, *d_idx;
     int* d_zero_idx = nullptr;      // [B] zeros: "marginalise nothing at 0" = an out-of-place write-back without compaction (frame with landmarks)
     // frame staging
+    char* d_result_slab = nullptr;                     // d_dx | d_gamma | d_used | d_m | d_status are views into it; h_result: pinned mirror
+    char* h_result = nullptr;
+    size_t result_bytes = 0, ro_gam = 0, ro_used = 0, ro_m = 0, ro_st = 0;
     char* d_frame_slab[2] = { nullptr, nullptr };      // the frame arrays below are views into these (frame_slab_carve); [1]: the async set
     int *d_clone_idx, *d_nclones, *d_nfeat, *d_anchor, *d_dof;
     double *d_clone_R, *d_clone_p, *d_pf, *d_uv, *d_chi2;
@@ -506,10 +509,9 @@ int make_opts(ingvio_ctx* c, const ingvio_msckf_opts* o, MsckfOpts* op)
     op->selected_variant = o->selected_variant;
     op->chi2 = c->d_chi2;
     op->chi2_len = o->chi2_len;
-    int rc = up(c, c->d_chi2, o->chi2_table, 8 * (size_t)o->chi2_len);
-    if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->st));
-    return 0;
+    if (wait_inputs(c)) return INGVIO_E_HIP;
+    const UpItem item = { c->d_chi2, o->chi2_table, 8 * (size_t)o->chi2_len };      // through the pinned ring: no stream synchronisation
+    return stage_small(c, &item, 1) ? INGVIO_E_HIP : 0;
 }
 
 // K3..K11 for filters [b0, b0+nb) using the staged frames; asynchronous.
@@ -606,10 +608,8 @@ int run_msckf(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int stereo, in
 int fill_noise_scalar(ingvio_ctx* c, int b0, int nb, double var)
 {
     std::vector<double> v(nb, var);
-    int rc = up(c, c->d_noise + b0, v.data(), 8 * (size_t)nb);
-    if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->st));
-    return 0;
+    const UpItem item = { c->d_noise + b0, v.data(), 8 * (size_t)nb };
+    return stage_small(c, &item, 1) ? INGVIO_E_HIP : 0;
 }
 
 }  // namespace
@@ -688,10 +688,22 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
         }
     }
     rc |= dalloc(c, &c->d_chi2, CHI2_CAP);
-    rc |= dalloc(c, &c->d_gamma, (size_t)B * fm); rc |= dalloc(c, &c->d_accept, (size_t)B * fm); rc |= dalloc(c, &c->d_used, (size_t)B * fm);
+    {
+        // the results an update call hands back - dx, gamma, used flags, row count, status - sit in ONE device slab (and a pinned
+        // mirror): a whole-batch fetch is one device-to-host copy instead of five (~18 us each for a single filter)
+        const size_t o_dx = 0, o_gam = pad64(8 * (size_t)B * c->ldp), o_used = o_gam + pad64(8 * (size_t)B * fm), o_m = o_used + pad64(4 * (size_t)B * fm),
+                     o_st = o_m + pad64(4 * (size_t)B), tot = o_st + pad64(4 * (size_t)B);
+        if (dalloc(c, &c->d_result_slab, tot) || hipHostMalloc((void**)&c->h_result, tot, hipHostMallocDefault) != hipSuccess) rc |= 1;
+        else {
+            c->result_bytes = tot; c->ro_gam = o_gam; c->ro_used = o_used; c->ro_m = o_m; c->ro_st = o_st;
+            c->d_dx = (double*)(c->d_result_slab + o_dx); c->d_gamma = (double*)(c->d_result_slab + o_gam);
+            c->d_used = (int*)(c->d_result_slab + o_used); c->d_m = (int*)(c->d_result_slab + o_m); c->d_status = (int*)(c->d_result_slab + o_st);
+        }
+    }
+    rc |= dalloc(c, &c->d_accept, (size_t)B * fm);
     rc |= dalloc(c, &c->d_Rpart, (size_t)B * c->G * c->rstride); rc |= dalloc(c, &c->d_chunk_used, (size_t)B * c->G);
     rc |= dalloc(c, &c->d_H, (size_t)B * c->hstride); rc |= dalloc(c, &c->d_res, (size_t)B * c->mld);
-    rc |= dalloc(c, &c->d_colmap, (size_t)B * c->cstride); rc |= dalloc(c, &c->d_m, B); rc |= dalloc(c, &c->d_nc, B); rc |= dalloc(c, &c->d_pcbase, B);
+    rc |= dalloc(c, &c->d_colmap, (size_t)B * c->cstride); rc |= dalloc(c, &c->d_nc, B); rc |= dalloc(c, &c->d_pcbase, B);
     rc |= dalloc(c, &c->d_tri_ok, (size_t)B * fm);
     c->d_big_sg = nullptr; c->d_big_wk = nullptr;
     if (desc->c_max > 16) {
@@ -700,9 +712,7 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     rc |= dalloc(c, &c->d_noise, B); rc |= dalloc(c, &c->d_noise1, (size_t)c->mld * c->mld);
     rc |= dalloc(c, &c->d_hnew, (size_t)c->mld * 6);
     rc |= dalloc(c, &c->d_Y, (size_t)B * c->ystride); rc |= dalloc(c, &c->d_Yc, (size_t)B * c->ystride);
-    rc |= dalloc(c, &c->d_dx, (size_t)B * c->ldp);
     rc |= dalloc(c, &c->d_rec, (size_t)B * fm * factored_rec_size(desc->c_max));
-    rc |= dalloc(c, &c->d_status, B);
     if (rc || hipStreamSynchronize(c->st) != hipSuccess) { *out = c; return INGVIO_E_HIP; }
     *out = c;
     return INGVIO_OK;
@@ -714,14 +724,15 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
     hipStreamSynchronize(c->st);
     void* ptrs[] = { c->Pbase, c->Psnap, c->d_cur, c->d_n, c->d_n_snap, c->d_Phi, c->d_G, c->d_dt, c->d_R, c->d_blk, c->d_gnss,
                      c->d_idx, c->d_frame_slab[0], c->d_frame_slab[1],
-                     c->d_chi2, c->d_gamma, c->d_accept, c->d_used, c->d_Rpart, c->d_chunk_used,
-                     c->d_H, c->d_res, c->d_colmap, c->d_m, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_dx, c->d_rec, c->d_status, c->d_pcbase, c->d_big_sg, c->d_big_wk, c->d_tri_ok, c->d_hnew, c->d_multi, c->d_noiseB,
+                     c->d_chi2, c->d_result_slab, c->d_accept, c->d_Rpart, c->d_chunk_used,
+                     c->d_H, c->d_res, c->d_colmap, c->d_nc, c->d_noise, c->d_noise1, c->d_Y, c->d_Yc, c->d_rec, c->d_pcbase, c->d_big_sg, c->d_big_wk, c->d_tri_ok, c->d_hnew, c->d_multi, c->d_noiseB,
                      c->gn.H, c->gn.res, c->gn.noise, c->gn.gamma, c->gn.chi2, c->gn.m, c->gn.nc, c->gn.colmap, c->gn.keep,
                      c->gn.feph, c->gn.fobs, c->gn.frcv, c->gn.front,
                      c->dw.Hd, c->dw.X, c->dw.Y, c->dw.Tb, c->dw.noise, c->dw.noiseB, c->dw.m, c->dw.cidx, c->lm.pose, c->lm.pf, c->lm.uv, c->lm.gamma, c->lm.idx, c->lm.n_lm,
                      c->lm.lm_idx, c->lm.anchor_idx, c->lm.tracked, c->lm.accept, c->lm.dx, c->d_xchg, c->dw.U, c->dw.rowmap, c->d_zero_idx };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& sl : c->pin) { if (sl.p) hipHostFree(sl.p); if (sl.ev) hipEventDestroy(sl.ev); }
+    if (c->h_result) hipHostFree(c->h_result);
     if (c->qr.exec) hipGraphExecDestroy(c->qr.exec);
     for (double* p : { c->qr.dA, c->qr.db, c->qr.ws, c->qr.dT, c->se.e, c->se.o, c->se.r, c->se.f, c->gn.W, c->gn.Yf, c->gn.dxf }) if (p) hipFree(p);
     for (int* p : { c->gn.mf, c->gn.ncf }) if (p) hipFree(p);
@@ -1527,13 +1538,23 @@ int ingvio_msckf_update(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame*
     rc = run_msckf(c, b0, nb, op, opts->stereo, fmx);
     if (rc) return rc;
     const int fm = c->d.f_max;
-    if (dx_out) HIPCHK(c, hipMemcpyAsync(dx_out, c->d_dx + (size_t)b0 * c->ldp, 8 * (size_t)nb * c->ldp, hipMemcpyDeviceToHost, c->st));
-    if (accepted) HIPCHK(c, hipMemcpyAsync(accepted, c->d_used + (size_t)b0 * fm, sizeof(int) * (size_t)nb * fm, hipMemcpyDeviceToHost, c->st));
-    if (gamma) HIPCHK(c, hipMemcpyAsync(gamma, c->d_gamma + (size_t)b0 * fm, 8 * (size_t)nb * fm, hipMemcpyDeviceToHost, c->st));
     std::vector<int> rows(nb), status(nb);
-    HIPCHK(c, hipMemcpyAsync(rows.data(), c->d_m + b0, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipMemcpyAsync(status.data(), c->d_status + b0, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    if (b0 == 0 && nb == c->d.batch && c->result_bytes <= (1u << 20)) {      // the whole batch, small: one copy of the result slab
+        HIPCHK(c, hipMemcpyAsync(c->h_result, c->d_result_slab, c->result_bytes, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        if (dx_out) memcpy(dx_out, c->h_result, 8 * (size_t)nb * c->ldp);
+        if (gamma) memcpy(gamma, c->h_result + c->ro_gam, 8 * (size_t)nb * fm);
+        if (accepted) memcpy(accepted, c->h_result + c->ro_used, sizeof(int) * (size_t)nb * fm);
+        memcpy(rows.data(), c->h_result + c->ro_m, sizeof(int) * (size_t)nb);
+        memcpy(status.data(), c->h_result + c->ro_st, sizeof(int) * (size_t)nb);
+    } else {
+        if (dx_out) HIPCHK(c, hipMemcpyAsync(dx_out, c->d_dx + (size_t)b0 * c->ldp, 8 * (size_t)nb * c->ldp, hipMemcpyDeviceToHost, c->st));
+        if (accepted) HIPCHK(c, hipMemcpyAsync(accepted, c->d_used + (size_t)b0 * fm, sizeof(int) * (size_t)nb * fm, hipMemcpyDeviceToHost, c->st));
+        if (gamma) HIPCHK(c, hipMemcpyAsync(gamma, c->d_gamma + (size_t)b0 * fm, 8 * (size_t)nb * fm, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipMemcpyAsync(rows.data(), c->d_m + b0, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipMemcpyAsync(status.data(), c->d_status + b0, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+    }
     rc = last_launch(c);
     if (rc) return rc;
     int soft = INGVIO_OK;
