@@ -710,6 +710,66 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     auto alive = [&](int i) { return !(fused && i >= midx && i < midx + msize); };
     auto remap = [&](int i) { return (fused && i >= midx) ? i - msize : i; };
 
+    dbg_stamp(12);
+    // ---- tiles (ti, tj): all waves walk tj together; the B tile is staged in LDS once for the four waves ----------
+    constexpr int STG = (MPY * BW + 255) / 256;
+    double stg[STG];
+    auto stage_load = [&](int tjj) {                           // element e = k * BW + r  ->  Pc[16 tjj + r][k]  (k >= MP: Yg[16 tjj + r][k - MP])
+#pragma unroll
+        for (int u = 0; u < STG; ++u) {
+            const int e = tid + 256 * u, k = e / BW, r = e - k * BW;
+            double v = 0.0;
+            if (e < MP * BW) { if (upd) v = Pc[min(16 * tjj + r, n - 1) + (size_t)k * ld]; }
+            else if (YW > 0 && e < MPY * BW) { if (updY) v = Yg[min(16 * tjj + r, n - 1) + (size_t)(k - MP) * ld]; }
+            stg[u] = v;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < STG; ++u) { const int e = tid + 256 * u; if (e < MPY * BW) (&sB[buf][0][0])[e] = stg[u]; }
+    };
+    auto store_tile = [&](int ti, int tj, const double4_f& acc, const double (&pv)[4]) {
+        // element (row, col), row >= col: stored through the mirrored address (col fastest, coalesced); its transpose
+        // goes through LDS so that the second store runs along rows, coalesced as well
+        const int col = tj * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = ti * 16 + kq + 4 * r;
+            const double v = pv[r] - acc[r];
+            if (row < n && col < n && row >= col) {
+                if (alive(row) && alive(col)) APPLY_STORE(&dst[remap(col) + (size_t)remap(row) * ld], v);
+                if ((upd || updY) && row == col && v < 0.0) atomicOr(&status[b], 2);      // StateManager.cpp:413-421
+            }
+            sV[wave][kq + 4 * r][l15] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int row2 = ti * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col2 = tj * 16 + kq + 4 * r;
+            if (row2 < n && col2 < n && row2 > col2 && alive(row2) && alive(col2))
+                APPLY_STORE(&dst[remap(row2) + (size_t)remap(col2) * ld], sV[wave][l15][kq + 4 * r]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto load_p = [&](int ti, int tj, double (&pv)[4]) {
+        const int col = tj * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = ti * 16 + kq + 4 * r;
+            pv[r] = (row < n && col < n && row >= col) ? APPLY_LOADP(&P[col + (size_t)row * ld]) : 0.0;      // mirrored (coalesced) address
+        }
+    };
+    // The first B tile and the first prior tiles are requested BEFORE the T phase (round 4; -DAPPLY_LATE: after it, as before): its
+    // ~170 MFMAs per wave (4.5 us) otherwise run with nothing of this workgroup in flight on the memory side (0.147 -> 0.143 ms).
+    double pv[2][TW][4], pn[2][TW][4];
+#ifndef APPLY_LATE
+    stage_load(0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < TW; ++q) if (h < nrows && q <= tiR[h]) load_p(tiR[h], q, pv[h][q]);
+#endif
     dbg_stamp(11);
     // ---- T rows of this wave's (up to) two tile rows, kept as A-operand fragments ------------------------------
     double tfrag[2][K4];
@@ -762,65 +822,18 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
         }
     }
 
-    dbg_stamp(12);
-    // ---- tiles (ti, tj): all waves walk tj together; the B tile is staged in LDS once for the four waves ----------
-    constexpr int STG = (MPY * BW + 255) / 256;
-    double stg[STG];
-    auto stage_load = [&](int tjj) {                           // element e = k * BW + r  ->  Pc[16 tjj + r][k]  (k >= MP: Yg[16 tjj + r][k - MP])
-#pragma unroll
-        for (int u = 0; u < STG; ++u) {
-            const int e = tid + 256 * u, k = e / BW, r = e - k * BW;
-            double v = 0.0;
-            if (e < MP * BW) { if (upd) v = Pc[min(16 * tjj + r, n - 1) + (size_t)k * ld]; }
-            else if (YW > 0 && e < MPY * BW) { if (updY) v = Yg[min(16 * tjj + r, n - 1) + (size_t)(k - MP) * ld]; }
-            stg[u] = v;
-        }
-    };
-    auto stage_store = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < STG; ++u) { const int e = tid + 256 * u; if (e < MPY * BW) (&sB[buf][0][0])[e] = stg[u]; }
-    };
-    auto store_tile = [&](int ti, int tj, const double4_f& acc, const double (&pv)[4]) {
-        // element (row, col), row >= col: stored through the mirrored address (col fastest, coalesced); its transpose
-        // goes through LDS so that the second store runs along rows, coalesced as well
-        const int col = tj * 16 + l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = ti * 16 + kq + 4 * r;
-            const double v = pv[r] - acc[r];
-            if (row < n && col < n && row >= col) {
-                if (alive(row) && alive(col)) APPLY_STORE(&dst[remap(col) + (size_t)remap(row) * ld], v);
-                if ((upd || updY) && row == col && v < 0.0) atomicOr(&status[b], 2);      // StateManager.cpp:413-421
-            }
-            sV[wave][kq + 4 * r][l15] = v;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int row2 = ti * 16 + l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int col2 = tj * 16 + kq + 4 * r;
-            if (row2 < n && col2 < n && row2 > col2 && alive(row2) && alive(col2))
-                APPLY_STORE(&dst[remap(row2) + (size_t)remap(col2) * ld], sV[wave][l15][kq + 4 * r]);
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
-    auto load_p = [&](int ti, int tj, double (&pv)[4]) {
-        const int col = tj * 16 + l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = ti * 16 + kq + 4 * r;
-            pv[r] = (row < n && col < n && row >= col) ? APPLY_LOADP(&P[col + (size_t)row * ld]) : 0.0;      // mirrored (coalesced) address
-        }
-    };
+#ifdef APPLY_LATE
     stage_load(0);
+#endif
     lds_barrier();                                           // every wave is done with sT
     stage_store(0);
     lds_barrier();
-    double pv[2][TW][4], pn[2][TW][4];
+#ifdef APPLY_LATE
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int q = 0; q < TW; ++q) if (h < nrows && q <= tiR[h]) load_p(tiR[h], q, pv[h][q]);
+#endif
     int buf = 0;
     for (int tjj = 0; tjj <= tjmax; tjj += TW, buf ^= 1) {
         const bool more = tjj + TW <= tjmax;
