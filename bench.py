@@ -216,7 +216,7 @@ def hbm_traffic_bytes(c):
 # The library's profile slots are named after the STAGE; rocprofv3 sees kernels.  Stage -> candidates, each candidate a tuple of
 # kernels whose counters are added up (x their launches per step): the first candidate with counters for all its kernels wins.
 STAGE_KERNELS = {
-    "k_feat_gate3": (("k_feat_gate4",), ("k_feat_gate3",)),              # stereo: gate in difference coordinates (round 3) / first generation, mono
+    "k_feat_gate3": (("k_feat_gate5",), ("k_feat_gate4",), ("k_feat_gate3",)),      # stereo: four features per wave (round 4, windows <= 11 clones) / one per wave (round 3) / first generation, mono
     "k_info_update": (("k_info_solve",), ("k_info_update",)),            # windows up to 11 clones / 12..16
     "restore": (("k_restore_strips",), ("k_restore",)),
     "k_lm_build": (("k_lm_rows", "k_lm_front"), ("k_lm_build", "k_lm_products")),        # fused front (round 3) / compacting build + products

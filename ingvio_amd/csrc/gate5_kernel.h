@@ -248,13 +248,33 @@ __device__ __forceinline__ void gate5_body(CovView cv, FrameView fv, MsckfOpts o
         }
     };
     double4_f T[NF][NLT];
+    // lane constants of the tile fill: element (i, j) of the bordered matrix sits at tri(max) + min in the packed triangle; indices
+    // of padding elements are clamped into the buffer (what they read is discarded)
+    int fidx[NLT][4], wcol[NTL];
+    bool fdiag[NLT][4];
+#pragma unroll
+    for (int ti = 0; ti < NTL; ++ti)
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ti + kq + 4 * r, jc = 16 * tj + l15;
+                const int hi = i > jc ? i : jc, lo = i > jc ? jc : i;
+                const int e = hi * (hi + 1) / 2 + lo;
+                fidx[ti * (ti + 1) / 2 + tj][r] = e < SH::KPK + 16 ? e : SH::KPK + 15;
+                fdiag[ti * (ti + 1) / 2 + tj][r] = i == jc;
+            }
+#pragma unroll
+    for (int tj = 0; tj < NTL; ++tj) wcol[tj] = 16 * tj + l15 < 3 * CMAX ? 16 * tj + l15 : 0;
     if (GATE5_DB) { pair_blocks(0); wave_sync(); }
 #pragma unroll
     for (int fq = 0; fq < NF; ++fq) {
         if (GATE5_DB) { if (fq + 1 < NF) pair_blocks(fq + 1); }      // independent of the fill below: the scheduler interleaves the two
         else { pair_blocks(fq); wave_sync(); }
         const int np = np_g[fq];
-        // ---- tile fill of feature fq (gate4_body's), every LDS read unconditional, the padding selected afterwards ----
+        // ---- tile fill of feature fq: the packed-triangle index of every element this lane holds is a lane constant (fidx, set up
+        //      once for the four features); the read is unconditional (padding elements read something valid and are overridden),
+        //      only the selects depend on the feature's size ----
         const double* kp = sh.kp[GATE5_DB ? (fq & 1) : 0];
         const double* wq = sh.f[fq].w;
         bool jreal[NTL];
@@ -264,27 +284,20 @@ __device__ __forceinline__ void gate5_body(CovView cv, FrameView fv, MsckfOpts o
         for (int ti = 0; ti < NTL; ++ti) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = 16 * ti + kq + 4 * r;
-                const bool ireal = i < np;
-                const int ii = ireal ? i : 0, tri_i = ii * (ii + 1) / 2;
+                const bool ireal = 16 * ti + kq + 4 * r < np;
 #pragma unroll
                 for (int tj = 0; tj <= ti; ++tj) {
-                    const int jcol = 16 * tj + l15;
-                    double bv;
-                    if (tj < ti) bv = kp[tri_i + jcol];
-                    else {
-                        const int jj = jreal[tj] ? jcol : 0;
-                        bv = kp[ii >= jj ? tri_i + jj : jj * (jj + 1) / 2 + ii];
-                    }
+                    const int t = ti * (ti + 1) / 2 + tj;
+                    double bv = kp[fidx[t][r]];
                     asm volatile("" : "+v"(bv));                                      // keep the read out of the selects' branches
-                    const double idv = (i == jcol) ? 1.0 : 0.0;                       // unit pivots on the padding rows
-                    double v = (ireal && jreal[tj]) ? bv : ((!ireal && !jreal[tj]) ? idv : 0.0);
-                    if (ti == NTL - 1 && r == 3) {                                    // i == BR for kq == 3: the border row w^T, corner 0
-                        double wv = wq[jreal[tj] ? jcol : 0];
+                    const double padv = (fdiag[t][r] && !ireal) ? 1.0 : 0.0;          // unit pivots on the padding rows
+                    double v = (ireal && jreal[tj]) ? bv : padv;
+                    if (ti == NTL - 1 && r == 3) {                                    // row BR for kq == 3: the border row w^T, corner 0
+                        double wv = wq[wcol[tj]];
                         asm volatile("" : "+v"(wv));
                         v = kq == 3 ? (jreal[tj] ? wv : 0.0) : v;
                     }
-                    T[fq][ti * (ti + 1) / 2 + tj][r] = v;
+                    T[fq][t][r] = v;
                 }
             }
         }

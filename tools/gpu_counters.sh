@@ -11,8 +11,8 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $ROOT/bench.py --no-cpu --no-profile --no-aux --steps 3 --warmup 1 $*"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python $ROOT/bench.py --no-cpu --no-profile --no-aux --steps 20 --warmup 5 "$@" > "$OUT/stats.log" 2>&1
+BENCH="python $ROOT/bench.py --no-cpu --no-profile --no-aux --no-latency --steps 3 --warmup 1 $*"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python $ROOT/bench.py --no-cpu --no-profile --no-aux --no-latency --steps 20 --warmup 5 "$@" > "$OUT/stats.log" 2>&1
 PASSES=(
  "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES"
  "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU"
