@@ -511,7 +511,8 @@ int make_opts(ingvio_ctx* c, const ingvio_msckf_opts* o, MsckfOpts* op)
     op->chi2_len = o->chi2_len;
     if (wait_inputs(c)) return INGVIO_E_HIP;
     const UpItem item = { c->d_chi2, o->chi2_table, 8 * (size_t)o->chi2_len };      // through the pinned ring: no stream synchronisation
-    return stage_small(c, &item, 1) ? INGVIO_E_HIP : 0;
+    if (stage_small(c, &item, 1)) return INGVIO_E_HIP;
+    return 0;
 }
 
 // K3..K11 for filters [b0, b0+nb) using the staged frames; asynchronous.
@@ -609,7 +610,8 @@ int fill_noise_scalar(ingvio_ctx* c, int b0, int nb, double var)
 {
     std::vector<double> v(nb, var);
     const UpItem item = { c->d_noise + b0, v.data(), 8 * (size_t)nb };
-    return stage_small(c, &item, 1) ? INGVIO_E_HIP : 0;
+    if (stage_small(c, &item, 1)) return INGVIO_E_HIP;
+    return 0;
 }
 
 }  // namespace
@@ -1711,7 +1713,10 @@ static int dense_ws_alloc(ingvio_ctx* c, int m_need)
     const int B = c->d.batch;
     w.m_cap = m_cap; w.n32 = (c->d.n_max + 31) / 32 * 32; w.n_ld = w.n32; w.ldx = m_cap + w.n32 + 32;
     w.hstride = std::max((size_t)m_cap * w.n_ld, (size_t)LM_MAX * 100);      // also holds the landmark path's compact blocks
-    w.xstride = (size_t)w.ldx * m_cap; w.tstride = (size_t)(m_cap / 32) * 1024 + (size_t)m_cap;
+    w.xstride = (size_t)w.ldx * m_cap;
+    // launch_chol_sweep works with at least TWO T slots (kernels_chol.hip): a 32-row workspace used to be sized for one, and the last
+    // filter's second slot lay past the allocation (found in round 4 when a change of the allocation order put unmapped memory there)
+    w.tstride = (size_t)std::max(m_cap / 32, 2) * 1024 + (size_t)m_cap;
     w.ustride = m_cap <= 256 ? lm_chol_ws_doubles(m_cap) : 0;
     int rc = dalloc(c, &w.Hd, (size_t)B * w.hstride) | dalloc(c, &w.X, (size_t)B * w.xstride) | dalloc(c, &w.Y, (size_t)B * w.xstride)
            | dalloc(c, &w.Tb, (size_t)B * w.tstride) | (w.ustride ? dalloc(c, &w.U, (size_t)B * w.ustride) : 0) | dalloc(c, &w.m, (size_t)B) | dalloc(c, &w.noise, (size_t)m_cap * m_cap) | dalloc(c, &w.cidx, (size_t)B * LM_MAX * 4) | dalloc(c, &w.noiseB, (size_t)B * m_cap)

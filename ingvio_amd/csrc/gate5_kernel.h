@@ -48,21 +48,6 @@ struct Gate5Shared {
     alignas(16) double lf[NF][12];   // per panel and feature: l10 l20 l30 l21 l31 l32 | r0 r1 r2 r3 of the 4 x 4 diagonal block
 };
 
-// F_c P(c, c2) F_c2^T from the block's four 3 x 3 parts held in registers (gate4_pairblock without the loads)
-__device__ __forceinline__ void gate5_fpf(const double Att[9], const double Atp[9], const double Apt[9], const double App[9], double pl, double pl2,
-                                          double px, double py, double pz, double out[9])
-{
-    double T1[9], T2[9];
-    mulXt(Att, px, py, pz, T1);
-    mulX(T1, px, py, pz, T2);                 // X Ptt' X^T
-#pragma unroll
-    for (int k = 0; k < 9; ++k) out[k] = T2[k] + (pl * pl2) * App[k];
-    mulXt(Atp, px, py, pz, T1);               // X^T Ptp' = -X Ptp'
-    mulX(Apt, px, py, pz, T2);                // Ppt' X  = -Ppt' X^T
-#pragma unroll
-    for (int k = 0; k < 9; ++k) out[k] += pl2 * T1[k] + pl * T2[k];
-}
-
 template <int CMAX>
 __device__ __forceinline__ void gate5_body(CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out,
                                            int* __restrict__ accept_out)

@@ -631,11 +631,36 @@ struct Gate4Shared {
     };
 };
 
+// F_c P(c, c2) F_c2^T from the block's four 3 x 3 parts held in registers, F = [X | -pl I]:
+//   U_t = X Ptt - pl Ppt,  U_p = X Ptp - pl Ppp,  out = U_t X^T - pl2 U_p     (81 operations; term by term as gate4_pairblock: 99)
+__device__ __forceinline__ void gate5_fpf(const double Att[9], const double Atp[9], const double Apt[9], const double App[9], double pl, double pl2,
+                                          double px, double py, double pz, double out[9])
+{
+    // (X M)[r][c] with X = skew(p): row 0 = (0, -z, y), row 1 = (z, 0, -x), row 2 = (-y, x, 0)
+    double Ut[9], Up[9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        Ut[0 + c] = fma(py, Att[6 + c], fma(-pz, Att[3 + c], -pl * Apt[0 + c]));
+        Ut[3 + c] = fma(-px, Att[6 + c], fma(pz, Att[0 + c], -pl * Apt[3 + c]));
+        Ut[6 + c] = fma(px, Att[3 + c], fma(-py, Att[0 + c], -pl * Apt[6 + c]));
+        Up[0 + c] = fma(py, Atp[6 + c], fma(-pz, Atp[3 + c], -pl * App[0 + c]));
+        Up[3 + c] = fma(-px, Atp[6 + c], fma(pz, Atp[0 + c], -pl * App[3 + c]));
+        Up[6 + c] = fma(px, Atp[3 + c], fma(-py, Atp[0 + c], -pl * App[6 + c]));
+    }
+    // (U X^T)[r][c] = sum_k U[r][k] X[c][k]:  X^T columns: c = 0: (0, -z, y), c = 1: (z, 0, -x), c = 2: (-y, x, 0)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        out[3 * r + 0] = fma(py, Ut[3 * r + 2], fma(-pz, Ut[3 * r + 1], -pl2 * Up[3 * r + 0]));
+        out[3 * r + 1] = fma(-px, Ut[3 * r + 2], fma(pz, Ut[3 * r + 0], -pl2 * Up[3 * r + 1]));
+        out[3 * r + 2] = fma(px, Ut[3 * r + 1], fma(-py, Ut[3 * r + 0], -pl2 * Up[3 * r + 2]));
+    }
+}
+
 // F_c P(c, c2) F_c2^T for the clones whose first state columns are g and g2 (X = [p_f]x, X^T = -X)
 __device__ __forceinline__ void gate4_pairblock(const double* __restrict__ P, int ld, int g, int g2, double pl, double pl2, double px, double py,
                                                 double pz, double out[9])
 {
-    double Att[9], Atp[9], Apt[9], App[9], T1[9], T2[9];
+    double Att[9], Atp[9], Apt[9], App[9];
 #pragma unroll
     for (int m = 0; m < 3; ++m)
 #pragma unroll
@@ -645,14 +670,7 @@ __device__ __forceinline__ void gate4_pairblock(const double* __restrict__ P, in
             Apt[3 * m + q] = P[(g + 3 + m) + (size_t)(g2 + q) * ld];
             App[3 * m + q] = P[(g + 3 + m) + (size_t)(g2 + 3 + q) * ld];
         }
-    mulXt(Att, px, py, pz, T1);
-    mulX(T1, px, py, pz, T2);                 // X Ptt' X^T
-#pragma unroll
-    for (int k = 0; k < 9; ++k) out[k] = T2[k] + (pl * pl2) * App[k];
-    mulXt(Atp, px, py, pz, T1);               // X^T Ptp' = -X Ptp'
-    mulX(Apt, px, py, pz, T2);                // Ppt' X  = -Ppt' X^T
-#pragma unroll
-    for (int k = 0; k < 9; ++k) out[k] += pl2 * T1[k] + pl * T2[k];
+    gate5_fpf(Att, Atp, Apt, App, pl, pl2, px, py, pz, out);
 }
 
 template <int CMAX>
