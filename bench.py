@@ -232,10 +232,22 @@ STAGE_KERNELS_BIG = {                                                      # win
 }
 
 
-def counters_for(counters, name, big):
+def gate_kernel_of(C):
+    """The stereo gate kernel launch_factored / launch_bigwin pick for a window of C clones (INGVIO_GATE selects the older ones)."""
+    g = os.environ.get("INGVIO_GATE", "")[:1]
+    if C > 16:
+        return "k_feat_gate3_big" if g == "3" else "k_feat_gate4_big"
+    if g == "3":
+        return "k_feat_gate3"
+    return "k_feat_gate4" if (g == "4" or C > 11) else "k_feat_gate5"
+
+
+def counters_for(counters, name, big, C=None):
     """-> (summed counters of the stage's kernels or None, the kernels they belong to)."""
     table = STAGE_KERNELS_BIG if big and name in STAGE_KERNELS_BIG else STAGE_KERNELS
     cands = table.get(name, ((name,),))
+    if name == "k_feat_gate3" and C is not None:            # the gate that ran is known: counters of another generation do not apply
+        cands = ((gate_kernel_of(C),),)
     if counters is None:
         return None, cands[0]
     for cand in cands:
@@ -270,7 +282,7 @@ def price_kernels(prof, dom_name, counters, csrc, rec_build, live_build, C, B, p
         if calls == 0:
             continue
         avg = ms / calls
-        c, cand = counters_for(counters, name, C > 16)
+        c, cand = counters_for(counters, name, C > 16, C)
         e = dict(avg_ms=avg, calls=calls, kernel=kernel_that_ran(name, cand, C))
         if c is not None:
             st = stale_kernels(cand, rec_build, live_build)
