@@ -14,5 +14,5 @@ for f in kernels_cov kernels_msckf kernels_ekf kernels_factored kernels_solve ke
   OBJS="$OBJS $OUT/$f.o"
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libingvio_hip.so" $OBJS
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libingvio_hip.so" $OBJS "$ROOT/ingvio_amd/lib/build_id.o"      # the regular build's id object (ingvio_build_id): run python ingvio_amd/build.py first
 ls -la "$OUT/libingvio_hip.so"
