@@ -45,7 +45,7 @@ struct Gate5Shared {
                                      // buffers: feature f + 1's blocks are formed while feature f's tiles are filled
         double pan[NF][16 * NTL][4]; // panel exchange of the four eliminations
     };
-    alignas(16) double lf[NF][12];   // per panel and feature: l10 l20 l30 l21 l31 l32 | r0 r1 r2 r3 of the 4 x 4 diagonal block
+    alignas(16) double lf[NF][20];   // per panel and feature: W = L^-1 of the 4 x 4 diagonal block (row-major, 16) | r0 r1 r2 r3
 };
 
 template <int CMAX>
@@ -326,7 +326,7 @@ __device__ __forceinline__ void gate5_body(CovView cv, FrameView fv, MsckfOpts o
             wave_sync();
             const bool bord = (k == 4 * NTL - 1);
             // 4x4 LDL^T of the diagonal blocks: the 16 lanes of group g factorise FEATURE g's block (uniform within the group) - one
-            // pass for the four features instead of one redundant pass per feature on all 64 lanes - and hand l, r over through LDS
+            // pass for the four features instead of one redundant pass per feature on all 64 lanes - and hand L^-1, r over through LDS
             {
                 double a4[4][4];
 #pragma unroll
@@ -345,35 +345,33 @@ __device__ __forceinline__ void gate5_body(CovView cv, FrameView fv, MsckfOpts o
                 const double l32 = t32 * r2;
                 // the last panel of the tile grid ends ON the border row: BR is its fourth row but not a pivot (see gate4_body)
                 const double r3 = bord ? 0.0 : G5RCP(a4[3][3] - l30 * a4[3][0] - l31 * t31 - l32 * t32);
-                if (sl == 0) {
-                    double2* o = reinterpret_cast<double2*>(sh.lf[g]);
-                    o[0] = make_double2(l10, l20); o[1] = make_double2(l30, l21); o[2] = make_double2(l31, l32);
-                    o[3] = make_double2(r0, r1); o[4] = make_double2(r2, r3);
+                // every lane only needs ITS row of the transformed panel, x_kq = (L^-1 m)_kq: hand over the rows of W = L^-1 (unit
+                // lower; row kq = 4 coefficients) and the pivot reciprocals instead of L - a lane then forms its entry with 4
+                // multiply-adds on what it reads, instead of the whole forward substitution (6) plus a 4-way selection (4)
+                const double w20 = fma(l21, l10, -l20), w31 = fma(l32, l21, -l31);
+                const double w30 = fma(-l32, w20, fma(l31, l10, -l30));
+                if (sl < 4) {                               // lane sl of the group writes row sl of W (and r_sl)
+                    const double c0 = sl == 0 ? 1.0 : (sl == 1 ? -l10 : (sl == 2 ? w20 : w30));
+                    const double c1 = sl == 0 ? 0.0 : (sl == 1 ? 1.0 : (sl == 2 ? -l21 : w31));
+                    const double c2 = sl <= 1 ? 0.0 : (sl == 2 ? 1.0 : -l32);
+                    const double c3 = sl == 3 ? 1.0 : 0.0;
+                    double2* o = reinterpret_cast<double2*>(sh.lf[g] + 4 * sl);
+                    o[0] = make_double2(c0, c1); o[1] = make_double2(c2, c3);
+                    sh.lf[g][16 + sl] = sl == 0 ? r0 : (sl == 1 ? r1 : (sl == 2 ? r2 : r3));
                 }
             }
             wave_sync();
 #pragma unroll
             for (int fq = 0; fq < NF; ++fq) {
-                const double2* lp = reinterpret_cast<const double2*>(sh.lf[fq]);
-                const double2 f0 = lp[0], f1 = lp[1], f2 = lp[2], f3 = lp[3], f4 = lp[4];
-                const double l10 = f0.x, l20 = f0.y, l30 = f1.x, l21 = f1.y, l31 = f2.x, l32 = f2.y;
-                const double dsel = fma(mk3, f4.y, fma(mk2, f4.x, fma(mk1, f3.y, mk0 * f3.x)));      // this lane's pivot reciprocal
-                double m[NTL][4];
+                const double2* lp = reinterpret_cast<const double2*>(sh.lf[fq] + 4 * kq);      // row kq of W = L^-1
+                const double2 w01 = lp[0], w23 = lp[1];
+                const double dsel = sh.lf[fq][16 + kq];                                         // this lane's pivot reciprocal (0: the border row)
+                double A[NTL], B[NTL];
 #pragma unroll
                 for (int tt = tj0; tt < NTL; ++tt) {
                     const double2* pr = reinterpret_cast<const double2*>(sh.pan[fq][16 * tt + l15]);
                     const double2 u0 = pr[0], u1 = pr[1];
-                    m[tt][0] = u0.x; m[tt][1] = u0.y; m[tt][2] = u1.x; m[tt][3] = u1.y;
-                }
-                double A[NTL], B[NTL];
-#pragma unroll
-                for (int tt = tj0; tt < NTL; ++tt) {
-                    double x0 = m[tt][0];
-                    double x1 = m[tt][1] - l10 * x0;
-                    double x2 = m[tt][2] - l20 * x0 - l21 * x1;
-                    double x3 = m[tt][3] - l30 * x0 - l31 * x1 - l32 * x2;
-                    PIN4(x0, x1, x2, x3);
-                    double xs = fma(mk3, x3, fma(mk2, x2, fma(mk1, x1, mk0 * x0)));
+                    double xs = fma(w23.y, u1.y, fma(w23.x, u1.x, fma(w01.y, u0.y, w01.x * u0.x)));
                     if (16 * tt + l15 <= 4 * k + (bord ? 2 : 3)) xs = 0.0;   // pivot rows and everything above: finished
                     A[tt] = xs;
                     B[tt] = -xs * dsel;
