@@ -658,6 +658,9 @@ __global__ __launch_bounds__(INFO_NT, 2) void k_info_update(
 // the next kernels want from L2 / MALL (the snapshot strips, the next frame's inputs).  Measured: apply 0.153 -> 0.144 ms and the
 // rest of the step faster too (propagate 0.051 -> 0.046, gate 0.286 -> 0.276): 0.730 -> 0.698 ms per step.
 #define APPLY_STORE(p, v) NT_STORE(p, v)      // dev_common.h; -DINGVIO_NO_NT builds the ordinary-store variant for A/B runs
+#ifndef APPLY_PF
+#define APPLY_PF 1
+#endif
 #define APPLY_LOADP(p) NT_LOAD(p)             // the prior's tiles (each read once) as streaming loads as well: 0.706 -> 0.693 ms per step
 // YW > 0 (round 4): a second, rank-YW downdate rides on the same sweep - P - T Pc^T - Yg Yg^T with Yg [n][YW] (ld = ldp) the
 // Cholesky-form gain of an in-frame GNSS update (GnssUpdate.cpp:290 right after the MSCKF update of the same frame): its columns
@@ -689,7 +692,12 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     const int midx = marg_idx ? marg_idx[bl] : -1;            // fused StateManager::marginalize of [midx, midx+msize)
     const bool fused = midx >= 0;
     if (!upd && !updY && !fused) return;
-    const int n = cv.n[b], ld = cv.ldp, nt = (n + 15) >> 4;
+    // The sweep is tiled in the index space of the OUTPUT (after the fused marginalisation): the rows and columns [midx, midx + msize)
+    // are never formed, and - what matters - every 128-byte run of the posterior is written whole.  Tiled on the prior's indices
+    // (rounds 2-3) all columns past the marginalised clone were written at a 48-byte offset, i.e. as partial lines: streaming stores
+    // of rows at that offset run at 2.6 TB/s against 4.9 TB/s aligned (tools/micro/hbm_mix.hip).  The READS are the misaligned side now.
+    const int n = cv.n[b], ld = cv.ldp;
+    const int no = fused ? n - msize : n, nt = (no + 15) >> 4;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (2 * part * 4 >= nt) return;                           // whole workgroup idle (uniform)
     const int pw = part * 4 + wave;                           // this wave owns tile rows pw and nt-1-pw: nt+1 tiles, balanced
@@ -707,20 +715,20 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     const double* tvec = M + (size_t)MP * MP;
     const double* Yg = YW > 0 ? Ygall + (size_t)bl * ygstride : nullptr;
     const int l15 = lane & 15, kq = lane >> 4;
-    auto alive = [&](int i) { return !(fused && i >= midx && i < midx + msize); };
-    auto remap = [&](int i) { return (fused && i >= midx) ? i - msize : i; };
+    auto src_of = [&](int o) { return (fused && o >= midx) ? o + msize : o; };      // output index -> index in the prior
 
     dbg_stamp(12);
     // ---- tiles (ti, tj): all waves walk tj together; the B tile is staged in LDS once for the four waves ----------
     constexpr int STG = (MPY * BW + 255) / 256;
     double stg[STG];
-    auto stage_load = [&](int tjj) {                           // element e = k * BW + r  ->  Pc[16 tjj + r][k]  (k >= MP: Yg[16 tjj + r][k - MP])
+    auto stage_load = [&](int tjj) {                           // element e = k * BW + r  ->  Pc[src(16 tjj + r)][k]  (k >= MP: Yg[..][k - MP])
 #pragma unroll
         for (int u = 0; u < STG; ++u) {
             const int e = tid + 256 * u, k = e / BW, r = e - k * BW;
+            const int sr = src_of(min(16 * tjj + r, no - 1));
             double v = 0.0;
-            if (e < MP * BW) { if (upd) v = Pc[min(16 * tjj + r, n - 1) + (size_t)k * ld]; }
-            else if (YW > 0 && e < MPY * BW) { if (updY) v = Yg[min(16 * tjj + r, n - 1) + (size_t)(k - MP) * ld]; }
+            if (e < MP * BW) { if (upd) v = Pc[sr + (size_t)k * ld]; }
+            else if (YW > 0 && e < MPY * BW) { if (updY) v = Yg[sr + (size_t)(k - MP) * ld]; }
             stg[u] = v;
         }
     };
@@ -736,8 +744,13 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
         for (int r = 0; r < 4; ++r) {
             const int row = ti * 16 + kq + 4 * r;
             const double v = pv[r] - acc[r];
-            if (row < n && col < n && row >= col) {
-                if (alive(row) && alive(col)) APPLY_STORE(&dst[remap(col) + (size_t)remap(row) * ld], v);
+#if defined(APPLY_ABL) && (APPLY_ABL & 1)      // ablation probe: no stores (one that never happens keeps the value alive)
+            if (v == 1.2345e-300) dst[0] = v;
+            if (false) {
+#else
+            if (row < no && col < no && row >= col) {
+#endif
+                APPLY_STORE(&dst[col + (size_t)row * ld], v);
                 if ((upd || updY) && row == col && v < 0.0) atomicOr(&status[b], 2);      // StateManager.cpp:413-421
             }
             sV[wave][kq + 4 * r][l15] = v;
@@ -747,8 +760,12 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int col2 = tj * 16 + kq + 4 * r;
-            if (row2 < n && col2 < n && row2 > col2 && alive(row2) && alive(col2))
-                APPLY_STORE(&dst[remap(row2) + (size_t)remap(col2) * ld], sV[wave][l15][kq + 4 * r]);
+#if defined(APPLY_ABL) && (APPLY_ABL & 1)
+            if (false)
+#else
+            if (row2 < no && col2 < no && row2 > col2)
+#endif
+                APPLY_STORE(&dst[row2 + (size_t)col2 * ld], sV[wave][l15][kq + 4 * r]);
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -757,18 +774,29 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = ti * 16 + kq + 4 * r;
-            pv[r] = (row < n && col < n && row >= col) ? APPLY_LOADP(&P[col + (size_t)row * ld]) : 0.0;      // mirrored (coalesced) address
+#if defined(APPLY_ABL) && (APPLY_ABL & 2)      // ablation probe: the prior is not read
+            pv[r] = 1.0 + row;
+#else
+            pv[r] = (row < no && col < no && row >= col) ? APPLY_LOADP(&P[src_of(col) + (size_t)src_of(row) * ld]) : 0.0;
+#endif      // mirrored (coalesced) address
         }
     };
     // The first B tile and the first prior tiles are requested BEFORE the T phase (round 4; -DAPPLY_LATE: after it, as before): its
     // ~170 MFMAs per wave (4.5 us) otherwise run with nothing of this workgroup in flight on the memory side (0.147 -> 0.143 ms).
-    double pv[2][TW][4], pn[2][TW][4];
+    // The prior's tiles run APPLY_PF steps ahead of the MFMAs that consume them (a step of one wave is 2 x K4 MFMAs, ~1 us: one step
+    // of lookahead is less than the latency of HBM under load).
+    double pq[APPLY_PF + 1][2][TW][4];
+    double (&pv)[2][TW][4] = pq[0];
+    auto load_step = [&](int tj0, double (&dstp)[2][TW][4]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < TW; ++q) if (h < nrows && tj0 + q <= tiR[h]) load_p(tiR[h], tj0 + q, dstp[h][q]);
+    };
 #ifndef APPLY_LATE
     stage_load(0);
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int q = 0; q < TW; ++q) if (h < nrows && q <= tiR[h]) load_p(tiR[h], q, pv[h][q]);
+    for (int d = 0; d < APPLY_PF; ++d) load_step(d * TW, pq[d]);
 #endif
     dbg_stamp(11);
     // ---- T rows of this wave's (up to) two tile rows, kept as A-operand fragments ------------------------------
@@ -778,17 +806,24 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
 #pragma unroll
         for (int h = 0; h < 2; ++h)
             if (h < nrows) {
-                const int ra = min(tiR[h] * 16 + l15, n - 1);
+                const int ra = src_of(min(tiR[h] * 16 + l15, no - 1));
 #pragma unroll
                 for (int k4 = 0; k4 < KY; ++k4) yfrag[h][k4] = Yg[ra + (size_t)(4 * k4 + kq) * ld];      // A[i][k] = Yg[i][k]
             }
+    }
+    if (upd && fused && part == 0 && wave == 0) {      // the correction of the states about to be marginalised: no tile covers them
+        for (int q = lane; q < msize; q += WAVE) {
+            double d = 0.0;
+            for (int k = 0; k < MP; ++k) d += Pc[midx + q + (size_t)k * ld] * tvec[k];
+            dx_all[(size_t)b * ld + midx + q] = d;
+        }
     }
     if (upd) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (h < nrows) {
                 const int ti = tiR[h];
-                const int ra = min(ti * 16 + l15, n - 1);                    // clamped: rows >= n are computed but never stored
+                const int ra = src_of(min(ti * 16 + l15, no - 1));           // clamped: rows past the end are computed but never stored
                 double afrag[K4];
 #pragma unroll
                 for (int k4 = 0; k4 < K4; ++k4) afrag[k4] = (Pc + (size_t)(4 * k4) * ld)[ra + kq * ld];      // uniform base + one lane offset
@@ -798,7 +833,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
                     for (int k4 = 0; k4 < K4; ++k4) d += afrag[k4] * tvec[4 * k4 + kq];
                     d += __shfl_xor(d, 16, WAVE);
                     d += __shfl_xor(d, 32, WAVE);
-                    if (kq == 0 && ti * 16 + l15 < n) dx_all[(size_t)b * ld + ra] = d;
+                    if (kq == 0 && ti * 16 + l15 < no) dx_all[(size_t)b * ld + ra] = d;      // dx stays in the prior's index space
                 }
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) {
@@ -830,18 +865,13 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     lds_barrier();
 #ifdef APPLY_LATE
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int q = 0; q < TW; ++q) if (h < nrows && q <= tiR[h]) load_p(tiR[h], q, pv[h][q]);
+    for (int d = 0; d < APPLY_PF; ++d) load_step(d * TW, pq[d]);
 #endif
     int buf = 0;
     for (int tjj = 0; tjj <= tjmax; tjj += TW, buf ^= 1) {
         const bool more = tjj + TW <= tjmax;
-        if (more) stage_load(tjj + TW);                        // next B tile(s) and next P values in flight during this step's MFMAs
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int q = 0; q < TW; ++q) if (h < nrows && tjj + TW + q <= tiR[h]) load_p(tiR[h], tjj + TW + q, pn[h][q]);
+        if (more) stage_load(tjj + TW);                        // next B tile(s) in flight during this step's MFMAs
+        load_step(tjj + APPLY_PF * TW, pq[APPLY_PF]);
 #pragma unroll
         for (int q = 0; q < TW; ++q) {
             const int tj = tjj + q;
@@ -883,11 +913,13 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
         }
         if (more) stage_store(buf ^ 1);
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int d = 0; d < APPLY_PF; ++d)
 #pragma unroll
-            for (int q = 0; q < TW; ++q)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pv[h][q][r] = pn[h][q][r];
+                for (int q = 0; q < TW; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pq[d][h][q][r] = pq[d + 1][h][q][r];
         lds_barrier();
     }
     dbg_stamp(13);
