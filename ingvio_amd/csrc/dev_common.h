@@ -87,12 +87,15 @@ __device__ __forceinline__ double fast_rcp(double x)
 #define NT_LOAD(p) __builtin_nontemporal_load(p)
 #endif
 
-// phase-timing probes (debug): block (0,0) lane 0 stamps the shader clock; read with ingvio_debug_read
+// phase-timing probes (debug): block (INGVIO_DBG_BLOCK, 0) lane 0 stamps the shader clock; read with ingvio_debug_read
 static __device__ long long g_dbg[64];      // one copy per translation unit (no -fgpu-rdc)
 __device__ __forceinline__ void dbg_stamp(int slot)
 {
 #ifdef INGVIO_DBG_STAMPS      // build with INGVIO_DBG_STAMPS=1 python ingvio_amd/build.py --force (tools/gpu_phase_times.py)
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_dbg[slot] = clock64();
+#ifndef INGVIO_DBG_BLOCK
+#define INGVIO_DBG_BLOCK 0      // a block in the middle of the grid shows contended timings
+#endif
+    if (blockIdx.x == INGVIO_DBG_BLOCK && blockIdx.y == 0 && threadIdx.x == 0) g_dbg[slot] = clock64();
 #else
     (void)slot;
 #endif

@@ -677,11 +677,16 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     // per step, second phase) share their LDS
     // TW tile columns per step (round 3: 2 - half as many steps, each a dependent chain global load -> LDS -> barrier -> MFMA -> store)
     constexpr int BW = 16 * TW;
-    constexpr int ST_DOUBLES = 4 * 16 * (MP + 2), SB_DOUBLES = 2 * MPY * BW;
-    __shared__ __attribute__((aligned(16))) double sTB[ST_DOUBLES > SB_DOUBLES ? ST_DOUBLES : SB_DOUBLES];
+    // First phase: M itself in LDS (windows up to 11 clones: 37 KB, two workgroups per CU still fit) - the T phase reads it 8 times per
+    // workgroup, and from L2 every one of its 2 x JT products was a dependent round trip of 1-3 us under load.
+    constexpr bool MLDS = MP <= 68;
+    constexpr int ST_DOUBLES = 4 * 16 * (MP + 2), SB_DOUBLES = 2 * MPY * BW, SV_DOUBLES = 4 * 16 * 17, SM_DOUBLES = MLDS ? MP * MP : 0;
+    constexpr int SWEEP_DOUBLES = SB_DOUBLES + SV_DOUBLES;
+    __shared__ __attribute__((aligned(16))) double sTB[(ST_DOUBLES > SWEEP_DOUBLES ? ST_DOUBLES : SWEEP_DOUBLES) + SM_DOUBLES];
     double (*sT)[16][MP + 2] = reinterpret_cast<double (*)[16][MP + 2]>(sTB);
     double (*sB)[MPY][BW] = reinterpret_cast<double (*)[MPY][BW]>(sTB);
-    __shared__ double sV[4][16][17];
+    double (*sV)[16][17] = reinterpret_cast<double (*)[16][17]>(sTB + SB_DOUBLES);      // the stores' transposition buffers: second phase only
+    double* sM = sTB + (ST_DOUBLES > SWEEP_DOUBLES ? ST_DOUBLES : SWEEP_DOUBLES);
     // XCD-aware order: the workgroups of one filter share an L2 (they all stream the same Pc and M)
     const int wg = blockIdx.x, xcd = wg & 7, tq = wg >> 3;
     const int bl = xcd + 8 * (tq / wgpf), part = tq % wgpf;
@@ -720,8 +725,8 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     dbg_stamp(12);
     // ---- tiles (ti, tj): all waves walk tj together; the B tile is staged in LDS once for the four waves ----------
     constexpr int STG = (MPY * BW + 255) / 256;
-    double stg[STG];
-    auto stage_load = [&](int tjj) {                           // element e = k * BW + r  ->  Pc[src(16 tjj + r)][k]  (k >= MP: Yg[..][k - MP])
+    double stgA[STG], stgB[STG];                               // two B tiles in flight: one needed at the end of this step, one at the end of the next
+    auto stage_load = [&](int tjj, double (&stg)[STG]) {       // element e = k * BW + r  ->  Pc[src(16 tjj + r)][k]  (k >= MP: Yg[..][k - MP])
 #pragma unroll
         for (int u = 0; u < STG; ++u) {
             const int e = tid + 256 * u, k = e / BW, r = e - k * BW;
@@ -732,54 +737,69 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
             stg[u] = v;
         }
     };
-    auto stage_store = [&](int buf) {
+    auto stage_store = [&](int buf, const double (&stg)[STG]) {
 #pragma unroll
         for (int u = 0; u < STG; ++u) { const int e = tid + 256 * u; if (e < MPY * BW) (&sB[buf][0][0])[e] = stg[u]; }
     };
+    // A tile strictly below the diagonal whose rows all exist needs no per-element predicate (120 of the 136 tiles at N = 249): its
+    // loads and stores are issued back to back.  (As one predicated region per element - what the general form below compiles to -
+    // a tile's eight stores and four LDS reads were eight dependent exec-mask branches, each waiting for its own LDS read: 1200-1600
+    // cycles per tile on a loaded CU, measured with shader-clock stamps, next to 1100 for the tile's 17 MFMAs.)
+    bool neg_diag = false;                                     // StateManager.cpp:413-421, reported once at the end
     auto store_tile = [&](int ti, int tj, const double4_f& acc, const double (&pv)[4]) {
         // element (row, col), row >= col: stored through the mirrored address (col fastest, coalesced); its transpose
         // goes through LDS so that the second store runs along rows, coalesced as well
-        const int col = tj * 16 + l15;
+        const int col = tj * 16 + l15, row0 = ti * 16 + kq, row2 = ti * 16 + l15, col20 = tj * 16 + kq;
+        double v[4], t[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = ti * 16 + kq + 4 * r;
-            const double v = pv[r] - acc[r];
-#if defined(APPLY_ABL) && (APPLY_ABL & 1)      // ablation probe: no stores (one that never happens keeps the value alive)
-            if (v == 1.2345e-300) dst[0] = v;
-            if (false) {
+        for (int r = 0; r < 4; ++r) { v[r] = pv[r] - acc[r]; sV[wave][kq + 4 * r][l15] = v[r]; }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = sV[wave][l15][kq + 4 * r];
+        __builtin_amdgcn_wave_barrier();
+        double* d1 = dst + col + (size_t)row0 * ld;
+        double* d2 = dst + row2 + (size_t)col20 * ld;
+#if defined(APPLY_ABL) && (APPLY_ABL & 1)      // ablation probe: no stores (one that never happens keeps the values alive)
+        if (v[0] + v[1] + v[2] + v[3] + t[0] + t[1] + t[2] + t[3] == 1.2345e-300) dst[0] = v[0];
 #else
-            if (row < no && col < no && row >= col) {
-#endif
-                APPLY_STORE(&dst[col + (size_t)row * ld], v);
-                if ((upd || updY) && row == col && v < 0.0) atomicOr(&status[b], 2);      // StateManager.cpp:413-421
+        if (ti > tj && ti * 16 + 15 < no) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) APPLY_STORE(d1 + (size_t)(4 * r) * ld, v[r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) APPLY_STORE(d2 + (size_t)(4 * r) * ld, t[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 4 * r;
+                if (row < no && col < no && row >= col) APPLY_STORE(d1 + (size_t)(4 * r) * ld, v[r]);
+                neg_diag |= row == col && row < no && v[r] < 0.0;
             }
-            sV[wave][kq + 4 * r][l15] = v;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int row2 = ti * 16 + l15;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int col2 = tj * 16 + kq + 4 * r;
-#if defined(APPLY_ABL) && (APPLY_ABL & 1)
-            if (false)
-#else
-            if (row2 < no && col2 < no && row2 > col2)
-#endif
-                APPLY_STORE(&dst[row2 + (size_t)col2 * ld], sV[wave][l15][kq + 4 * r]);
+            for (int r = 0; r < 4; ++r) {
+                const int col2 = col20 + 4 * r;
+                if (row2 < no && col2 < no && row2 > col2) APPLY_STORE(d2 + (size_t)(4 * r) * ld, t[r]);
+            }
         }
-        __builtin_amdgcn_wave_barrier();
+#endif
     };
     auto load_p = [&](int ti, int tj, double (&pv)[4]) {
-        const int col = tj * 16 + l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = ti * 16 + kq + 4 * r;
 #if defined(APPLY_ABL) && (APPLY_ABL & 2)      // ablation probe: the prior is not read
-            pv[r] = 1.0 + row;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[r] = 1.0 + r;
 #else
-            pv[r] = (row < no && col < no && row >= col) ? APPLY_LOADP(&P[src_of(col) + (size_t)src_of(row) * ld]) : 0.0;
-#endif      // mirrored (coalesced) address
+        const int col = tj * 16 + l15, row0 = ti * 16 + kq;
+        if (ti > tj && ti * 16 + 15 < no) {                   // mirrored (coalesced) address; rows and columns in the prior's index space
+            const double* p0 = P + src_of(col);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pv[r] = APPLY_LOADP(p0 + (size_t)src_of(row0 + 4 * r) * ld);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 4 * r;
+                pv[r] = (row < no && col < no && row >= col) ? APPLY_LOADP(&P[src_of(col) + (size_t)src_of(row) * ld]) : 0.0;
+            }
         }
+#endif
     };
     // The first B tile and the first prior tiles are requested BEFORE the T phase (round 4; -DAPPLY_LATE: after it, as before): its
     // ~170 MFMAs per wave (4.5 us) otherwise run with nothing of this workgroup in flight on the memory side (0.147 -> 0.143 ms).
@@ -793,11 +813,23 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
 #pragma unroll
             for (int q = 0; q < TW; ++q) if (h < nrows && tj0 + q <= tiR[h]) load_p(tiR[h], tj0 + q, dstp[h][q]);
     };
+    constexpr int MST = (SM_DOUBLES + 255) / 256;
+    double mreg[MST > 0 ? MST : 1];
+    if (MLDS && upd) {                                         // requested first: the first thing the T phase needs
+#pragma unroll
+        for (int u = 0; u < MST; ++u) { const int e = tid + 256 * u; mreg[u] = e < MP * MP ? M[e] : 0.0; }
+    }
 #ifndef APPLY_LATE
-    stage_load(0);
+    stage_load(0, stgA);
+    if (TW <= tjmax) stage_load(TW, stgB);
 #pragma unroll
     for (int d = 0; d < APPLY_PF; ++d) load_step(d * TW, pq[d]);
 #endif
+    if (MLDS && upd) {
+#pragma unroll
+        for (int u = 0; u < MST; ++u) { const int e = tid + 256 * u; if (e < MP * MP) sM[e] = mreg[u]; }
+        lds_barrier();
+    }
     dbg_stamp(11);
     // ---- T rows of this wave's (up to) two tile rows, kept as A-operand fragments ------------------------------
     double tfrag[2][K4];
@@ -841,7 +873,8 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
                     const int jc = min(jt * 16 + l15, MP - 1);
                     double bfrag[K4];
 #pragma unroll
-                    for (int k4 = 0; k4 < K4; ++k4) bfrag[k4] = (M + (size_t)(4 * k4) * MP)[kq * MP + jc];      // B[k][j] = M[k][j]
+                    for (int k4 = 0; k4 < K4; ++k4)      // B[k][j] = M[k][j]
+                        bfrag[k4] = MLDS ? sM[(4 * k4 + kq) * MP + jc] : (M + (size_t)(4 * k4) * MP)[kq * MP + jc];
 #pragma unroll
                     for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[k4], bfrag[k4], acc, 0, 0, 0);
                     if (jt * 16 + l15 < MP) {
@@ -858,19 +891,22 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     }
 
 #ifdef APPLY_LATE
-    stage_load(0);
+    stage_load(0, stgA);
+    if (TW <= tjmax) stage_load(TW, stgB);
 #endif
     lds_barrier();                                           // every wave is done with sT
-    stage_store(0);
+    stage_store(0, stgA);
     lds_barrier();
 #ifdef APPLY_LATE
 #pragma unroll
     for (int d = 0; d < APPLY_PF; ++d) load_step(d * TW, pq[d]);
 #endif
-    int buf = 0;
-    for (int tjj = 0; tjj <= tjmax; tjj += TW, buf ^= 1) {
+    // step s reads sB[s & 1]; the registers that leave for sB[(s + 1) & 1] at its end were requested a step earlier (stgB in even
+    // steps, stgA in odd ones), and the other set is requested now for the step after
+    auto sweep_step = [&](int tjj, int buf, double (&stg_req)[STG], const double (&stg_out)[STG]) {
         const bool more = tjj + TW <= tjmax;
-        if (more) stage_load(tjj + TW);                        // next B tile(s) in flight during this step's MFMAs
+        if (tjj == 4 * TW) dbg_stamp(44);
+        if (tjj + 2 * TW <= tjmax) stage_load(tjj + 2 * TW, stg_req);
         load_step(tjj + APPLY_PF * TW, pq[APPLY_PF]);
 #pragma unroll
         for (int q = 0; q < TW; ++q) {
@@ -886,17 +922,22 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
 #pragma unroll
                 for (int k4 = 0; k4 < KY; ++k4) bfy[k4] = sB[buf][MP + 4 * k4 + kq][16 * q + l15];  // B[k][j] = Yg[16 tj + j][k]
             }
+            if (tjj == 4 * TW) dbg_stamp(48);
             if (do0) {
                 double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
                 if (upd) {
 #pragma unroll
                     for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tfrag[0][k4], bfrag[k4], acc, 0, 0, 0);
                 }
+#ifdef INGVIO_DBG_STAMPS
+                if (tjj == 4 * TW) { if (acc[0] == 1.234e-300) dst[0] = 0.0; dbg_stamp(49); }
+#endif
                 if (YW > 0 && updY) {
 #pragma unroll
                     for (int k4 = 0; k4 < KY; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yfrag[0][k4], bfy[k4], acc, 0, 0, 0);
                 }
                 store_tile(tiR[0], tj, acc, pv[0][q]);
+                if (tjj == 4 * TW) dbg_stamp(50);
             }
             if (do1) {
                 double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
@@ -911,7 +952,9 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
                 store_tile(tiR[1], tj, acc, pv[1][q]);
             }
         }
-        if (more) stage_store(buf ^ 1);
+        if (tjj == 4 * TW) dbg_stamp(45);
+        if (more) stage_store(buf ^ 1, stg_out);
+        if (tjj == 4 * TW) dbg_stamp(46);
 #pragma unroll
         for (int d = 0; d < APPLY_PF; ++d)
 #pragma unroll
@@ -921,7 +964,13 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pq[d][h][q][r] = pq[d + 1][h][q][r];
         lds_barrier();
+        if (tjj == 4 * TW) dbg_stamp(47);
+    };
+    for (int tjj = 0; tjj <= tjmax; tjj += 2 * TW) {
+        sweep_step(tjj, 0, stgA, stgB);
+        if (tjj + TW <= tjmax) sweep_step(tjj + TW, 1, stgB, stgA);
     }
+    if ((upd || updY) && __any(neg_diag) && lane == 0) atomicOr(&status[b], 2);
     dbg_stamp(13);
 }
 

@@ -12,7 +12,7 @@ ctx.snapshot(); pr = synth.PARAMS
 ctx.frame_stage(0, steps, frames, filters[0].sigma(), 1, pr["sigma_cb"], pr["sigma_rw"])
 for _ in range(3):
     ctx.frame_run(restore_prior=True)
-d = ctx.debug_read(48)
+d = ctx.debug_read(64)
 def seg(name, idx):
     print(name, [d[b] - d[a] for a, b in zip(idx[:-1], idx[1:])], "total", d[idx[-1]] - d[idx[0]])
 seg("gate3 [front, barrier, pair blocks + tile fill, LDL, border + gate]", [5, 6, 7, 8, 9, 10])
@@ -21,3 +21,6 @@ seg("propagate [fetch, compose,gnss,strip,AA,fused clone]", [16, 21, 17, 18, 19,
 seg("info_solve [deal+load, sweep1, R2+G1, G2, sweep2, G3, Pc copy]", [24, 25, 26, 27, 28, 29, 30, 31])
 seg("info_apply [setup, T = Pc M, tile loop]", [11, 12, 13]) if False else None
 print("info_apply [T = Pc M, tile loop]", [d[12] - d[11], d[13] - d[12]])
+print("info_apply step 4 [MFMAs + stores, stage store, barrier]", [d[45] - d[44], d[46] - d[45], d[47] - d[46]], " start -> T:", d[11] - d[12], " whole:", d[13] - d[12])
+print("info_apply step 4 [issue loads + B fragments, MFMAs tile 0, store tile 0, tile 1]", [d[48] - d[44], d[49] - d[48], d[50] - d[49], d[45] - d[50]])
+print("info_apply store of tile 0 in step 4 [v + 4 stores + 4 LDS writes, LDS read back, 4 stores]", [d[51] - d[49], d[52] - d[51], d[50] - d[52]])

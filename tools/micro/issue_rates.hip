@@ -33,6 +33,8 @@ __global__ void k(double* out, long long* cyc, int iters)
                 }
                 if (MODE == 3) x[i] = fma(lds[(u * 8 + i) & 1023], 1e-12, x[i]);                         // LDS broadcast read + FMA
                 if (MODE == 4) acc[i & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[i], x[(i + 1) & 7], acc[i & 3], 0, 0, 0);
+                if (MODE == 8) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[i], x[(i + 1) & 7], acc[0], 0, 0, 0);          // ONE dependent chain
+                if (MODE == 9) acc[i & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[i], x[(i + 1) & 7], acc[i & 1], 0, 0, 0);  // two chains
                 if (MODE == 7) {                                                                         // 2x 32-bit DPP row_newbcast + FMA
                     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x[(i + 1) & 7]), 0x150 + 5, 0xf, 0xf, false);
                     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x[(i + 1) & 7]), 0x150 + 5, 0xf, 0xf, false);
@@ -81,6 +83,8 @@ int main()
     run<2>("2 ds_bpermute + fma");
     run<3>("ds_read_b64 bcast + fma");
     run<4>("mfma_f64_16x16x4");
+    run<8>("mfma_f64_16x16x4, one chain");
+    run<9>("mfma_f64_16x16x4, two chains");
     run<5>("2 dpp quad bcast + fma");
     run<7>("2 dpp32 row_newbcast + fma");
     return 0;
