@@ -659,7 +659,7 @@ __global__ __launch_bounds__(INFO_NT, 2) void k_info_update(
 // rest of the step faster too (propagate 0.051 -> 0.046, gate 0.286 -> 0.276): 0.730 -> 0.698 ms per step.
 #define APPLY_STORE(p, v) NT_STORE(p, v)      // dev_common.h; -DINGVIO_NO_NT builds the ordinary-store variant for A/B runs
 #ifndef APPLY_PF
-#define APPLY_PF 1
+#define APPLY_PF 2      // steps the prior's tiles run ahead where the registers allow it (see PF in k_info_apply)
 #endif
 #define APPLY_LOADP(p) NT_LOAD(p)             // the prior's tiles (each read once) as streaming loads as well: 0.706 -> 0.693 ms per step
 // YW > 0 (round 4): a second, rank-YW downdate rides on the same sweep - P - T Pc^T - Yg Yg^T with Yg [n][YW] (ld = ldp) the
@@ -681,12 +681,19 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     // workgroup, and from L2 every one of its 2 x JT products was a dependent round trip of 1-3 us under load.
     constexpr bool MLDS = MP <= 68;
     constexpr int ST_DOUBLES = 4 * 16 * (MP + 2), SB_DOUBLES = 2 * MPY * BW, SV_DOUBLES = 4 * 16 * 17, SM_DOUBLES = MLDS ? MP * MP : 0;
+    // TLDS: the T rows of a wave's SHORT tile row (tiR[0], a few steps of the sweep) stay in LDS and are read as A fragments where they
+    // are used; only the long row's live in registers (34 fewer: room for a second set of the prior's tiles in flight).  The sweep's
+    // buffers then take M's place instead of T's.
+    constexpr bool TLDS = MLDS;
     constexpr int SWEEP_DOUBLES = SB_DOUBLES + SV_DOUBLES;
-    __shared__ __attribute__((aligned(16))) double sTB[(ST_DOUBLES > SWEEP_DOUBLES ? ST_DOUBLES : SWEEP_DOUBLES) + SM_DOUBLES];
+    constexpr int REG_A = TLDS ? ST_DOUBLES : (ST_DOUBLES > SWEEP_DOUBLES ? ST_DOUBLES : SWEEP_DOUBLES);
+    constexpr int REG_B = TLDS ? (SM_DOUBLES > SWEEP_DOUBLES ? SM_DOUBLES : SWEEP_DOUBLES) : SM_DOUBLES;
+    __shared__ __attribute__((aligned(16))) double sTB[REG_A + REG_B];
     double (*sT)[16][MP + 2] = reinterpret_cast<double (*)[16][MP + 2]>(sTB);
-    double (*sB)[MPY][BW] = reinterpret_cast<double (*)[MPY][BW]>(sTB);
-    double (*sV)[16][17] = reinterpret_cast<double (*)[16][17]>(sTB + SB_DOUBLES);      // the stores' transposition buffers: second phase only
-    double* sM = sTB + (ST_DOUBLES > SWEEP_DOUBLES ? ST_DOUBLES : SWEEP_DOUBLES);
+    double* sweep_base = TLDS ? sTB + REG_A : sTB;
+    double (*sB)[MPY][BW] = reinterpret_cast<double (*)[MPY][BW]>(sweep_base);
+    double (*sV)[16][17] = reinterpret_cast<double (*)[16][17]>(sweep_base + SB_DOUBLES);      // the stores' transposition buffers: second phase only
+    double* sM = sTB + REG_A;
     // XCD-aware order: the workgroups of one filter share an L2 (they all stream the same Pc and M)
     const int wg = blockIdx.x, xcd = wg & 7, tq = wg >> 3;
     const int bl = xcd + 8 * (tq / wgpf), part = tq % wgpf;
@@ -805,7 +812,8 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     // ~170 MFMAs per wave (4.5 us) otherwise run with nothing of this workgroup in flight on the memory side (0.147 -> 0.143 ms).
     // The prior's tiles run APPLY_PF steps ahead of the MFMAs that consume them (a step of one wave is 2 x K4 MFMAs, ~1 us: one step
     // of lookahead is less than the latency of HBM under load).
-    double pq[APPLY_PF + 1][2][TW][4];
+    constexpr int PF = (TLDS && YW == 0 && TW == 1) ? APPLY_PF : 1;
+    double pq[PF + 1][2][TW][4];
     double (&pv)[2][TW][4] = pq[0];
     auto load_step = [&](int tj0, double (&dstp)[2][TW][4]) {
 #pragma unroll
@@ -823,7 +831,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     stage_load(0, stgA);
     if (TW <= tjmax) stage_load(TW, stgB);
 #pragma unroll
-    for (int d = 0; d < APPLY_PF; ++d) load_step(d * TW, pq[d]);
+    for (int d = 0; d < PF; ++d) load_step(d * TW, pq[d]);
 #endif
     if (MLDS && upd) {
 #pragma unroll
@@ -832,7 +840,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     }
     dbg_stamp(11);
     // ---- T rows of this wave's (up to) two tile rows, kept as A-operand fragments ------------------------------
-    double tfrag[2][K4];
+    double tfrag[TLDS ? 1 : 2][K4];                            // TLDS: row tiR[1] only
     double yfrag[2][KY > 0 ? KY : 1];
     if (YW > 0 && updY) {
 #pragma unroll
@@ -852,7 +860,8 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     }
     if (upd) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int hh = 0; hh < 2; ++hh) {
+            const int h = TLDS ? 1 - hh : hh;                  // TLDS: the long row first, the short row's T is what remains in sT
             if (h < nrows) {
                 const int ti = tiR[h];
                 const int ra = src_of(min(ti * 16 + l15, no - 1));           // clamped: rows past the end are computed but never stored
@@ -883,8 +892,10 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+                if (!TLDS || h == 1) {
 #pragma unroll
-                for (int k4 = 0; k4 < K4; ++k4) tfrag[h][k4] = sT[wave][l15][4 * k4 + kq];      // A[i][k] = T[i][k]
+                    for (int k4 = 0; k4 < K4; ++k4) tfrag[TLDS ? 0 : h][k4] = sT[wave][l15][4 * k4 + kq];      // A[i][k] = T[i][k]
+                }
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -899,7 +910,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     lds_barrier();
 #ifdef APPLY_LATE
 #pragma unroll
-    for (int d = 0; d < APPLY_PF; ++d) load_step(d * TW, pq[d]);
+    for (int d = 0; d < PF; ++d) load_step(d * TW, pq[d]);
 #endif
     // step s reads sB[s & 1]; the registers that leave for sB[(s + 1) & 1] at its end were requested a step earlier (stgB in even
     // steps, stgA in odd ones), and the other set is requested now for the step after
@@ -907,7 +918,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
         const bool more = tjj + TW <= tjmax;
         if (tjj == 4 * TW) dbg_stamp(44);
         if (tjj + 2 * TW <= tjmax) stage_load(tjj + 2 * TW, stg_req);
-        load_step(tjj + APPLY_PF * TW, pq[APPLY_PF]);
+        load_step(tjj + PF * TW, pq[PF]);
 #pragma unroll
         for (int q = 0; q < TW; ++q) {
             const int tj = tjj + q;
@@ -926,8 +937,16 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
             if (do0) {
                 double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
                 if (upd) {
+                    if (TLDS) {
+                        double a0[K4];
 #pragma unroll
-                    for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tfrag[0][k4], bfrag[k4], acc, 0, 0, 0);
+                        for (int k4 = 0; k4 < K4; ++k4) a0[k4] = sT[wave][l15][4 * k4 + kq];
+#pragma unroll
+                        for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[k4], bfrag[k4], acc, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tfrag[0][k4], bfrag[k4], acc, 0, 0, 0);
+                    }
                 }
 #ifdef INGVIO_DBG_STAMPS
                 if (tjj == 4 * TW) { if (acc[0] == 1.234e-300) dst[0] = 0.0; dbg_stamp(49); }
@@ -943,7 +962,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
                 double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
                 if (upd) {
 #pragma unroll
-                    for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tfrag[1][k4], bfrag[k4], acc, 0, 0, 0);
+                    for (int k4 = 0; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tfrag[TLDS ? 0 : 1][k4], bfrag[k4], acc, 0, 0, 0);
                 }
                 if (YW > 0 && updY) {
 #pragma unroll
@@ -956,7 +975,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
         if (more) stage_store(buf ^ 1, stg_out);
         if (tjj == 4 * TW) dbg_stamp(46);
 #pragma unroll
-        for (int d = 0; d < APPLY_PF; ++d)
+        for (int d = 0; d < PF; ++d)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
