@@ -727,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     const double* tvec = M + (size_t)MP * MP;
     const double* Yg = YW > 0 ? Ygall + (size_t)bl * ygstride : nullptr;
     const int l15 = lane & 15, kq = lane >> 4;
-    auto src_of = [&](int o) { return (fused && o >= midx) ? o + msize : o; };      // output index -> index in the prior
+    auto src_of = [&](int o) __attribute__((always_inline)) { return (fused && o >= midx) ? o + msize : o; };      // output index -> index in the prior
 
     dbg_stamp(12);
     // ---- tiles (ti, tj): all waves walk tj together; the B tile is staged in LDS once for the four waves ----------
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
             stg[u] = v;
         }
     };
-    auto stage_store = [&](int buf, const double (&stg)[STG]) {
+    auto stage_store = [&](int buf, const double (&stg)[STG]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < STG; ++u) { const int e = tid + 256 * u; if (e < MPY * BW) (&sB[buf][0][0])[e] = stg[u]; }
     };
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     // a tile's eight stores and four LDS reads were eight dependent exec-mask branches, each waiting for its own LDS read: 1200-1600
     // cycles per tile on a loaded CU, measured with shader-clock stamps, next to 1100 for the tile's 17 MFMAs.)
     bool neg_diag = false;                                     // StateManager.cpp:413-421, reported once at the end
-    auto store_tile = [&](int ti, int tj, const double4_f& acc, const double (&pv)[4]) {
+    auto store_tile = [&](int ti, int tj, const double4_f& acc, const double (&pv)[4]) __attribute__((always_inline)) {
         // element (row, col), row >= col: stored through the mirrored address (col fastest, coalesced); its transpose
         // goes through LDS so that the second store runs along rows, coalesced as well
         const int col = tj * 16 + l15, row0 = ti * 16 + kq, row2 = ti * 16 + l15, col20 = tj * 16 + kq;
@@ -789,7 +789,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
         }
 #endif
     };
-    auto load_p = [&](int ti, int tj, double (&pv)[4]) {
+    auto load_p = [&](int ti, int tj, double (&pv)[4]) __attribute__((always_inline)) {
 #if defined(APPLY_ABL) && (APPLY_ABL & 2)      // ablation probe: the prior is not read
 #pragma unroll
         for (int r = 0; r < 4; ++r) pv[r] = 1.0 + r;
@@ -815,7 +815,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     constexpr int PF = (TLDS && YW == 0 && TW == 1) ? APPLY_PF : 1;
     double pq[PF + 1][2][TW][4];
     double (&pv)[2][TW][4] = pq[0];
-    auto load_step = [&](int tj0, double (&dstp)[2][TW][4]) {
+    auto load_step = [&](int tj0, double (&dstp)[2][TW][4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -914,7 +914,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
 #endif
     // step s reads sB[s & 1]; the registers that leave for sB[(s + 1) & 1] at its end were requested a step earlier (stgB in even
     // steps, stgA in odd ones), and the other set is requested now for the step after
-    auto sweep_step = [&](int tjj, int buf, double (&stg_req)[STG], const double (&stg_out)[STG]) {
+    auto sweep_step = [&](int tjj, int buf, double (&stg_req)[STG], const double (&stg_out)[STG]) __attribute__((always_inline)) {
         const bool more = tjj + TW <= tjmax;
         if (tjj == 4 * TW) dbg_stamp(44);
         if (tjj + 2 * TW <= tjmax) stage_load(tjj + 2 * TW, stg_req);
@@ -982,7 +982,11 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
                 for (int q = 0; q < TW; ++q)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pq[d][h][q][r] = pq[d + 1][h][q][r];
+#if defined(APPLY_ABL) && (APPLY_ABL & 8)      // ablation probe (results invalid): the waves of a workgroup do not wait for each other
+        __builtin_amdgcn_wave_barrier();
+#else
         lds_barrier();
+#endif
         if (tjj == 4 * TW) dbg_stamp(47);
     };
     for (int tjj = 0; tjj <= tjmax; tjj += 2 * TW) {
