@@ -66,6 +66,16 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// value of lane (i - N) mod 16 of the same 16-lane row (DPP row_ror:N on both halves of the double): no LDS traffic, unlike __shfl
+template <int N>
+__device__ __forceinline__ double row_ror_f64(double v)
+{
+    static_assert(N >= 1 && N <= 15, "row_ror");
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + N, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // 1/x to full FP64 precision: v_rcp_f64 + two Newton steps (the IEEE division expands to ~3x the latency).  Measured on MI355X
 // (tools/micro/rcp_f64.hip, 4 M doubles over 2^+-300): v_rcp_f64 alone 4.6e-8 relative, one step 2.2e-15, two steps 1.1e-16.
 __device__ __forceinline__ double fast_rcp(double x)

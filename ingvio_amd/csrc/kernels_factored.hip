@@ -209,8 +209,15 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
             }
         }
     };
-    auto sum16 = [](double v) {                                  // over the 16 lanes of a feature
+    // sum over the 16 lanes of a feature, left in all of them: rotations within the DPP row (row_ror:8/4/2/1 on the two halves of the
+    // double) instead of __shfl_xor, which compiles to two ds_bpermute_b32 per step - 120 LDS-pipe instructions per lane and batch
+    // for the 15 sums of P2, the phase the batch waits for
+    auto sum16 = [](double v) {
+#ifdef GRAM_SHFL_SUM
         v += __shfl_xor(v, 8, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 1, 16);
+#else
+        v += row_ror_f64<8>(v); v += row_ror_f64<4>(v); v += row_ror_f64<2>(v); v += row_ror_f64<1>(v);
+#endif
         return v;
     };
     fetch(q0);
