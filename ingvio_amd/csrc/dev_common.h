@@ -105,7 +105,10 @@ __device__ __forceinline__ void dbg_stamp(int slot)
 #ifndef INGVIO_DBG_BLOCK
 #define INGVIO_DBG_BLOCK 0      // a block in the middle of the grid shows contended timings
 #endif
-    if (blockIdx.x == INGVIO_DBG_BLOCK && blockIdx.y == 0 && threadIdx.x == 0) g_dbg[slot] = clock64();
+#ifndef INGVIO_DBG_BLOCK_Y
+#define INGVIO_DBG_BLOCK_Y 0
+#endif
+    if (blockIdx.x == INGVIO_DBG_BLOCK && blockIdx.y == INGVIO_DBG_BLOCK_Y && threadIdx.x == 0) g_dbg[slot] = clock64();
 #else
     (void)slot;
 #endif

@@ -361,11 +361,16 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
         lds_barrier();
         int it = 0;
         for (int qb = q0; qb < q1; qb += GRAM_NB, ++it) {
+            if (it == 3) dbg_stamp(36);
             do_p3a(qb);
+            if (it == 3) dbg_stamp(37);
             lds_barrier();                                      // every wave is done with this batch's operand rows
+            if (it == 3) dbg_stamp(38);
             if (wave < 2) { if (qb + GRAM_NB < q1) { do_p2(qb + GRAM_NB, (it + 1) & 1, 128); fetch(qb + 2 * GRAM_NB); } }
             else do_p3b(qb, it & 1);
+            if (it == 3) dbg_stamp(41);
             lds_barrier();
+            if (it == 3) dbg_stamp(42);
         }
     } else {
         for (int qb = q0; qb < q1; qb += GRAM_NB) {

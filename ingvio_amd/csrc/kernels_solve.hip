@@ -32,6 +32,7 @@ struct SolveCfg {
     static constexpr int MROWS = R1ROWS > NP ? R1ROWS : NP, LDM = NP + 1;
     static constexpr int PANROWS = NP + R1ROWS + NP;
     static constexpr int MP = (NC + 3) & ~3;
+    static constexpr int LDSS = NC + 6 + 1;                          // row stride of the staged window block of P (up to NC + 6 columns; odd)
     static constexpr size_t lds_bytes() { return sizeof(double) * (2 * (size_t)MROWS * LDM + 2 * (size_t)PANROWS * 4 + 4 * NP) + sizeof(int) * NP; }
 };
 
@@ -79,9 +80,9 @@ struct Deal {
 // One blocked LDL^T sweep (panels of 4 pivots) as seen by wave W: every structural decision (which tiles exist, which are still
 // live at a given panel) is a compile-time constant, the only run-time loop is over the four panels of a tile column.
 // emit(own row w, pan row, pivot column, x, x / d): the entry of the row transformed by L_d^-T and its factor entry.
-template <int NC, int PHASE, int W, class Emit, class DSave>
+template <int NC, int PHASE, int W, class Emit>
 __device__ __forceinline__ void ldl_sweep(double4_f (&T)[SolveCfg<NC>::RW][SolveCfg<NC>::NT], double (*pan)[SolveCfg<NC>::PANROWS][4],
-                                          int lane, Emit emit, DSave dsave, int* bad)
+                                          int lane, Emit emit, double* __restrict__ dinv, int* bad)
 {
     using C = SolveCfg<NC>;
     constexpr int NT = C::NT, RW = C::RW;
@@ -92,6 +93,9 @@ __device__ __forceinline__ void ldl_sweep(double4_f (&T)[SolveCfg<NC>::RW][Solve
 #pragma unroll 1
         for (int kk = 0; kk < 4; ++kk) {
             const int k = 4 * tj0 + kk, buf = k & 1, cb = 4 * kk;
+#ifdef INGVIO_DBG_STAMPS
+            if (PHASE == 1 && W == 0 && k < 8) dbg_stamp(8 + 5 * k);
+#endif
             if (l15 >= cb && l15 < cb + 4) {
 #pragma unroll
                 for (int w = 0; w < RW; ++w) {
@@ -101,43 +105,59 @@ __device__ __forceinline__ void ldl_sweep(double4_f (&T)[SolveCfg<NC>::RW][Solve
                     }
                 }
             }
-            lds_barrier();
-            double a[4][4];
+            // The inverse of the 4 x 4 pivot block is formed by ONE wave - the owner of the tile row it lies in, from the panel rows it
+            // has just written itself (a hand-over inside the wave, no workgroup barrier) - and left in dinv[16 k ..] for the others,
+            // who read their column after the panel's barrier.  Formed by every wave for itself (round 2-3) it was the longest
+            // stretch of a panel: ~100 instructions x 4 waves per SIMD, issue-bound at 1500-1700 cycles of a panel's 3700
+            // (shader-clock stamps of a workgroup in the middle of the grid).
+            bool owner = false;                             // folds to a constant: tj0 is unrolled, the deal is constexpr
 #pragma unroll
-            for (int ra = 0; ra < 4; ++ra) {
-                const double2* pr = reinterpret_cast<const double2*>(pan[buf][4 * k + ra]);
-                const double2 u0 = pr[0], u1 = pr[1];
-                a[ra][0] = u0.x; a[ra][1] = u0.y; a[ra][2] = u1.x; a[ra][3] = u1.y;
+            for (int w = 0; w < RW; ++w) owner |= D.rows[W][w].valid && D.rows[W][w].kind == 0 && D.rows[W][w].rt == tj0;
+            if (owner) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                double a[4][4];
+#pragma unroll
+                for (int ra = 0; ra < 4; ++ra) {
+                    const double2* pr = reinterpret_cast<const double2*>(pan[buf][4 * k + ra]);
+                    const double2 u0 = pr[0], u1 = pr[1];
+                    a[ra][0] = u0.x; a[ra][1] = u0.y; a[ra][2] = u1.x; a[ra][3] = u1.y;
+                }
+                // inverse of the SPD 4x4 pivot block [[E, F], [F^T, G]] by 2x2 blocks (uniform data): two dependent reciprocals
+                const double e00 = a[0][0], e10 = a[1][0], e11 = a[1][1];
+                const double f00 = a[2][0], f01 = a[3][0], f10 = a[2][1], f11 = a[3][1];          // F[i][j] = block(i, 2 + j) = a[2 + j][i]
+                const double g00 = a[2][2], g10 = a[3][2], g11 = a[3][3];
+                const double detE = e00 * e11 - e10 * e10, rE = fast_rcp(detE);
+                const double ei00 = e11 * rE, ei10 = -e10 * rE, ei11 = e00 * rE;                   // E^-1
+                const double h00 = ei00 * f00 + ei10 * f10, h01 = ei00 * f01 + ei10 * f11;         // H = E^-1 F
+                const double h10 = ei10 * f00 + ei11 * f10, h11 = ei10 * f01 + ei11 * f11;
+                const double s00 = g00 - (f00 * h00 + f10 * h10), s10 = g10 - (f01 * h00 + f11 * h10), s11 = g11 - (f01 * h01 + f11 * h11);   // S = G - F^T H
+                const double detS = s00 * s11 - s10 * s10, rS = fast_rcp(detS);
+                const double si00 = s11 * rS, si10 = -s10 * rS, si11 = s00 * rS;                   // S^-1
+                if (!(e00 > 0.0) || !(detE > 0.0) || !(s00 > 0.0) || !(detS > 0.0)) *bad = 1;
+                const double q00 = h00 * si00 + h01 * si10, q01 = h00 * si10 + h01 * si11;         // Q = H S^-1
+                const double q10 = h10 * si00 + h11 * si10, q11 = h10 * si10 + h11 * si11;
+                // block^-1 = [[E^-1 + Q H^T, -Q], [-Q^T, S^-1]]
+                const double v00 = ei00 + q00 * h00 + q01 * h01, v10 = ei10 + q10 * h00 + q11 * h01, v11 = ei11 + q10 * h10 + q11 * h11;
+                if (lane == 0) {                            // row-major 4 x 4 (symmetric)
+                    double2* o = reinterpret_cast<double2*>(dinv + 16 * k);
+                    o[0] = make_double2(v00, v10); o[1] = make_double2(-q00, -q01);
+                    o[2] = make_double2(v10, v11); o[3] = make_double2(-q10, -q11);
+                    o[4] = make_double2(-q00, -q10); o[5] = make_double2(si00, si10);
+                    o[6] = make_double2(-q01, -q11); o[7] = make_double2(si10, si11);
+                }
             }
-            // inverse of the SPD 4x4 pivot block [[E, F], [F^T, G]] by 2x2 blocks (every lane, uniform data): two dependent reciprocals
-            const double e00 = a[0][0], e10 = a[1][0], e11 = a[1][1];
-            const double f00 = a[2][0], f01 = a[3][0], f10 = a[2][1], f11 = a[3][1];          // F[i][j] = block(i, 2 + j) = a[2 + j][i]
-            const double g00 = a[2][2], g10 = a[3][2], g11 = a[3][3];
-            const double detE = e00 * e11 - e10 * e10, rE = fast_rcp(detE);
-            const double ei00 = e11 * rE, ei10 = -e10 * rE, ei11 = e00 * rE;                   // E^-1
-            const double h00 = ei00 * f00 + ei10 * f10, h01 = ei00 * f01 + ei10 * f11;         // H = E^-1 F
-            const double h10 = ei10 * f00 + ei11 * f10, h11 = ei10 * f01 + ei11 * f11;
-            const double s00 = g00 - (f00 * h00 + f10 * h10), s10 = g10 - (f01 * h00 + f11 * h10), s11 = g11 - (f01 * h01 + f11 * h11);   // S = G - F^T H
-            const double detS = s00 * s11 - s10 * s10, rS = fast_rcp(detS);
-            const double si00 = s11 * rS, si10 = -s10 * rS, si11 = s00 * rS;                   // S^-1
-            if (!(e00 > 0.0) || !(detE > 0.0) || !(s00 > 0.0) || !(detS > 0.0)) *bad = 1;
-            const double q00 = h00 * si00 + h01 * si10, q01 = h00 * si10 + h01 * si11;         // Q = H S^-1
-            const double q10 = h10 * si00 + h11 * si10, q11 = h10 * si10 + h11 * si11;
-            // block^-1 = [[E^-1 + Q H^T, -Q], [-Q^T, S^-1]]
-            const double v00 = ei00 + q00 * h00 + q01 * h01, v10 = ei10 + q10 * h00 + q11 * h01, v11 = ei11 + q10 * h10 + q11 * h11;
-            // column kq of the inverse: this lane's coefficients for (row) block^-1
-            const double c0 = kq == 0 ? v00 : (kq == 1 ? v10 : (kq == 2 ? -q00 : -q01));
-            const double c1 = kq == 0 ? v10 : (kq == 1 ? v11 : (kq == 2 ? -q10 : -q11));
-            const double c2 = kq == 0 ? -q00 : (kq == 1 ? -q10 : (kq == 2 ? si00 : si10));
-            const double c3 = kq == 0 ? -q01 : (kq == 1 ? -q11 : (kq == 2 ? si10 : si11));
-            if (W == 0 && lane < 16) {                      // the inverse block, row-major 4x4, for the s^2 D^-1 term
-                const int bi = lane >> 2, bj = lane & 3;
-                const double col0 = bj == 0 ? v00 : (bj == 1 ? v10 : (bj == 2 ? -q00 : -q01));
-                const double col1 = bj == 0 ? v10 : (bj == 1 ? v11 : (bj == 2 ? -q10 : -q11));
-                const double col2 = bj == 0 ? -q00 : (bj == 1 ? -q10 : (bj == 2 ? si00 : si10));
-                const double col3 = bj == 0 ? -q01 : (bj == 1 ? -q11 : (bj == 2 ? si10 : si11));
-                dsave(16 * k + lane, bi == 0 ? col0 : (bi == 1 ? col1 : (bi == 2 ? col2 : col3)));
-            }
+            lds_barrier();
+#ifdef INGVIO_DBG_STAMPS
+            if (PHASE == 1 && W == 0 && k < 8) dbg_stamp(9 + 5 * k);
+#endif
+            // column kq of the inverse (= its row kq): this lane's coefficients for (row) block^-1
+            const double2* ci = reinterpret_cast<const double2*>(dinv + 16 * k + 4 * kq);
+            const double2 ca = ci[0], cbb = ci[1];
+            const double c0 = ca.x, c1 = ca.y, c2 = cbb.x, c3 = cbb.y;
+#ifdef INGVIO_DBG_STAMPS
+            if (PHASE == 1 && W == 0 && k < 8) { if (c0 + c1 + c2 + c3 == 1.2345e-300) *bad = 1; dbg_stamp(10 + 5 * k); }
+#endif
             auto xinv = [&](int row) {                      // entry kq of (pan row) block^-1
                 const double2* pr = reinterpret_cast<const double2*>(pan[buf][row]);
                 const double2 u0 = pr[0], u1 = pr[1];
@@ -161,6 +181,9 @@ __device__ __forceinline__ void ldl_sweep(double4_f (&T)[SolveCfg<NC>::RW][Solve
                     xa[w] = (D.rows[W][w].kind == 0 && ra <= 4 * k + 3) ? 0.0 : x;      // pivot rows and everything above: finished
                 }
             }
+#ifdef INGVIO_DBG_STAMPS
+            if (PHASE == 1 && W == 0 && k < 8) dbg_stamp(11 + 5 * k);
+#endif
             // trailing update: T(row, c) -= R_row block^-1 R_c^T
 #pragma unroll
             for (int w = 0; w < RW; ++w) {
@@ -222,15 +245,22 @@ __device__ __forceinline__ void solve_wave(const SolveArgs<NC>& a, int* bad)
     }
     // ================= factorisation 1: Pcc = L D L^T, identity carried =================
     {
+        // The window block of P was staged in LDS by the whole workgroup (k_info_solve: S, in the X / Y area, row stride LDS): every
+        // entry of Pdd is four of its elements.  Read from global memory - 128 loads of 8 bytes per lane, 2048 load instructions per
+        // CU with two workgroups resident - the set-up took as long as a factorisation (the address path, not the bandwidth).
+        constexpr int LDS = SolveCfg<NC>::LDSS;
+        const double* S = X;
+        auto wcol = [&](int c) { return RED ? c + (c >= a.ref6 ? 6 : 0) : c; };          // reduced index -> window column
+        auto wref = [&](int c) { return a.ref6 + wcol(c) % 6; };                          // same component of the reference clone
         int scol_c[NT], scol_r[RW][4], sref_c[NT], sref_r[RW][4];
 #pragma unroll
-        for (int c = 0; c < NT; ++c) { scol_c[c] = a.sCol[16 * c + l15]; sref_c[c] = RED ? a.sRef[16 * c + l15] : 0; }
+        for (int c = 0; c < NT; ++c) { const int e = min(16 * c + l15, ncol - 1); scol_c[c] = wcol(e); sref_c[c] = RED ? wref(e) : 0; }
 #pragma unroll
         for (int w = 0; w < RW; ++w)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int e = (D1.rows[W][w].valid ? 16 * D1.rows[W][w].rt : 0) + kq + 4 * r;
-                scol_r[w][r] = a.sCol[e]; sref_r[w][r] = RED ? a.sRef[e] : 0;
+                const int e = min((D1.rows[W][w].valid ? 16 * D1.rows[W][w].rt : 0) + kq + 4 * r, ncol - 1);
+                scol_r[w][r] = wcol(e); sref_r[w][r] = RED ? wref(e) : 0;
             }
 #pragma unroll
         for (int w = 0; w < RW; ++w)
@@ -242,19 +272,22 @@ __device__ __forceinline__ void solve_wave(const SolveArgs<NC>& a, int* bad)
                     const int row = 16 * D1.rows[W][w].rt + kq + 4 * r;
                     double v = row == col ? 1.0 : 0.0;
                     if (D1.rows[W][w].valid && D1.rows[W][w].kind == 0 && c <= D1.rows[W][w].c1 && row < ncol && col < ncol) {
-                        v = a.P[scol_c[c] + (size_t)scol_r[w][r] * ld];          // symmetric: read along the coalesced direction
+                        v = S[scol_r[w][r] * LDS + scol_c[c]];
                         if (RED)                                                 // covariance of the DIFFERENCES to the reference clone
-                            v = (v - a.P[sref_c[c] + (size_t)scol_r[w][r] * ld]) - (a.P[scol_c[c] + (size_t)sref_r[w][r] * ld] - a.P[sref_c[c] + (size_t)sref_r[w][r] * ld]);
+                            v = (v - S[scol_r[w][r] * LDS + sref_c[c]]) - (S[sref_r[w][r] * LDS + scol_c[c]] - S[sref_r[w][r] * LDS + sref_c[c]]);
                     }
                     T[w][c][r] = v;
                 }
             }
+        __syncthreads();                                      // every wave holds its tiles of Pdd: the staging area becomes X and Y
+        for (int e = W * 64 + lane; e < 2 * MROWS * LDM; e += NTH) X[e] = 0.0;
+        __syncthreads();
         auto emit = [&](int w, int row, int col, int k, double x, double xs) {
             if (D1.rows[W][w].kind == 0) X[row * LDM + col] = row > 4 * k + 3 ? xs : (row == col ? 1.0 : 0.0);   // L: identity pivot blocks
             else Y[(row - NP) * LDM + col] = xs;                                                             // L^-T D^-1 (upper)
         };
-        auto dsave = [&](int e, double v) { a.sD1inv[e] = v; };
-        ldl_sweep<NC, 1, W>(T, a.pan, lane, emit, dsave, bad);
+        dbg_stamp(1);
+        ldl_sweep<NC, 1, W>(T, a.pan, lane, emit, a.sD1inv, bad);
     }
     dbg_stamp(2);
     // ================= second matrix W = L^T A L + s^2 D^-1 and its carried rows [A L ; b^T L], L^-T D^-1 =================
@@ -340,8 +373,7 @@ __device__ __forceinline__ void solve_wave(const SolveArgs<NC>& a, int* bad)
             if (D2.rows[W][w].kind == 1) X[(row - NP) * LDM + col] = xs;                          // R1' D2^-1
             else if (D2.rows[W][w].kind == 2) Y[(row - NP - R1ROWS) * LDM + col] = x;             // R2'      (L2 itself is not needed)
         };
-        auto dsave = [&](int, double) {};
-        ldl_sweep<NC, 2, W>(T, a.pan, lane, emit, dsave, bad);
+        ldl_sweep<NC, 2, W>(T, a.pan, lane, emit, a.sD1inv, bad);      // the inverse blocks of factorisation 1 are dead by now: same slots
     }
 }
 
@@ -358,7 +390,7 @@ __device__ __forceinline__ void solve_wave(const SolveArgs<NC>& a, int* bad)
 // the reference block that makes every block row / column sum vanish: M = T^-T diag(0, Mr) T^-1.  The reference clone is the one
 // with the largest translation information.  The solve shrinks from 6 C to 6 (C - 1) columns (5 -> 4 tile rows at 11 clones).
 template <int NCF, bool RED>
-__global__ __launch_bounds__(512) void k_info_solve(
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_info_solve(
     CovView cv, FrameView fv, int b0, const double* __restrict__ Apart, const int* __restrict__ chunk_used, int G, int rstride,
     const double* __restrict__ noise_all, double* __restrict__ Mall, int mstride, double* __restrict__ Pcall, int ystride,
     double* __restrict__ dx_all, int* __restrict__ m_out, int* __restrict__ nc_out, int* __restrict__ status,
@@ -412,9 +444,13 @@ __global__ __launch_bounds__(512) void k_info_solve(
         }
         sTr[tid] = tr;
     }
-    for (int e = tid; e < 2 * MROWS * LDM; e += NTH) X[e] = 0.0;
     if (tid == 0) sBad = 0;
     __syncthreads();
+    static_assert((NC + 6) * Cfg::LDSS <= 2 * MROWS * LDM, "the staged window block exceeds the X / Y area");
+    for (int e = tid; e < ncolF * ncolF; e += NTH) {          // S[i][j] = P(window column j, window column i): j runs along the coalesced direction
+        const int i = e / ncolF, j = e - i * ncolF;
+        X[i * Cfg::LDSS + j] = P[sColF[j] + (size_t)sColF[i] * ld];
+    }
     if (RED && tid == 0) {
         int best = 0; double tb = -1.0;
         for (int c = 0; c < C; ++c) {

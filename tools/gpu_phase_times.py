@@ -16,7 +16,7 @@ d = ctx.debug_read(64)
 def seg(name, idx):
     print(name, [d[b] - d[a] for a, b in zip(idx[:-1], idx[1:])], "total", d[idx[-1]] - d[idx[0]])
 seg("gate3 [front, barrier, pair blocks + tile fill, LDL, border + gate]", [5, 6, 7, 8, 9, 10])
-seg("gram2 prologue", [32, 33]); seg("gram2 last batch [P0(store+barrier),P2,P3a,P3b]", [34, 35, 37, 38, 41]); seg("gram2 epilogue", [39, 40]); seg("gram2 total", [32, 40])
+seg("gram2 prologue", [32, 33]); seg("gram2 batch 3 as wave 0 sees it [P3a, barrier, P2 of the next batch, barrier]", [36, 37, 38, 41, 42]); seg("gram2 epilogue", [39, 40]); seg("gram2 total", [32, 40])
 seg("propagate [fetch, compose,gnss,strip,AA,fused clone]", [16, 21, 17, 18, 19, 20, 22])
 seg("info_solve [deal+load, sweep1, R2+G1, G2, sweep2, G3, Pc copy]", [24, 25, 26, 27, 28, 29, 30, 31])
 seg("info_apply [setup, T = Pc M, tile loop]", [11, 12, 13]) if False else None
