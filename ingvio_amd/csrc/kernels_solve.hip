@@ -416,6 +416,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     int* sRef = sColF + NPF;                                         // NP: same component in the reference clone's block
     double* sTr = reinterpret_cast<double*>(sRef + NPF + (NPF & 1)); // 16 clones x 16 chunk lanes
     static_assert(sizeof(int) * (2 * NPF + 2) + sizeof(double) * 256 <= sizeof(double) * PANROWS * 4, "set-up tables exceed a panel buffer");
+    dbg_stamp(60);
     const int bl = blockIdx.x, b = b0 + bl, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int kq = lane >> 4, l15 = lane & 15;
     const int C = fv.n_clones[b], ncolF = 6 * C, n = cv.n[b], ld = cv.ldp;
@@ -446,6 +447,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     if (tid == 0) sBad = 0;
     __syncthreads();
+    dbg_stamp(61);
     static_assert((NC + 6) * Cfg::LDSS <= 2 * MROWS * LDM, "the staged window block exceeds the X / Y area");
     for (int e = tid; e < ncolF * ncolF; e += NTH) {          // S[i][j] = P(window column j, window column i): j runs along the coalesced direction
         const int i = e / ncolF, j = e - i * ncolF;

@@ -14,3 +14,4 @@ print("solve stamps 0..7 diffs", [d[i + 1] - d[i] for i in range(0, 7)])
 for k in range(8):
     b = 8 + 5 * k
     print("panel", k, "[write pan + barrier, block inverse, xinv + emit, MFMA + to next panel]", d[b + 1] - d[b], d[b + 2] - d[b + 1], d[b + 3] - d[b + 2], (d[b + 5] - d[b + 3]) if k < 7 else None)
+print("set-up: [kernel start -> tables + trace loads done, -> reference clone chosen, S staged, indices ready (stamp 0)]", d[61] - d[60], d[0] - d[61])
