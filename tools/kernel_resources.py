@@ -8,7 +8,7 @@ from ingvio_amd import build as B
 
 def demangle(names):
     out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
-    return [re.sub(r"\(.*$", "", o) for o in out]
+    return [re.sub(r"\(.*$", "", o.replace("(anonymous namespace)::", "")) for o in out]
 
 rows = []
 for src in B.HIP_SOURCES:
