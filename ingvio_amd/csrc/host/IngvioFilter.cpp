@@ -1,4 +1,7 @@
 #include "IngvioFilter.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include "StateManager.h"
 
@@ -95,10 +98,28 @@ void IngvioFilter::callbackStereoFrame(const StereoFrameMsg& frame)
     if (!_hasInitState) return;
     const double target_time = frame.stamp;
     if (_state->_timestamp >= target_time) return;                                      // :267
+    // INGVIO_SHIM_TIMING=1: host wall time of the callback's phases on stderr (where the host waits for the device shows up in the
+    // phase that fetches a result); debugging aid of the single-filter latency figure
+    static const bool timing = std::getenv("INGVIO_SHIM_TIMING") != nullptr;
+    using clk = std::chrono::steady_clock;
+    clk::time_point t0, t1, t2, t3, t4;
+    if (timing) t0 = clk::now();
     _imu_propa->propagateAugmentAtEnd(_state, target_time);
     if (_state->_timestamp < target_time) return;                                       // :273
+    if (timing) t1 = clk::now();
     collectStereoMeas(frame);
+    if (timing) t2 = clk::now();
     _remove_lost_update->updateStateStereo(_state, _map_server, _tri);
+    if (timing) t3 = clk::now();
+    struct Report {
+        const bool on; const clk::time_point &a, &b, &c, &d; const int frame;
+        ~Report() {
+            if (!on) return;
+            auto us = [](clk::time_point x, clk::time_point y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
+            std::fprintf(stderr, "SHIM frame %d us: propagate+clone %.1f collect %.1f remove_lost %.1f rest %.1f\n", frame, us(a, b), us(b, c), us(c, d),
+                         us(d, clk::now()));
+        }
+    } report{ timing, t0, t1, t2, t3, _frames };
     if (_filter_params._is_key_frame) {
         _keyframe_update->updateStateStereo(_state, _map_server, _tri);
         if (_filter_params._max_lm_feats > 0) {                                         // :283-289

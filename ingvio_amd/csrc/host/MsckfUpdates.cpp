@@ -1,3 +1,6 @@
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include "MsckfUpdates.h"
 #include <cstring>
 #include <iostream>
@@ -261,8 +264,13 @@ void RemoveLostUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapS
     std::vector<std::shared_ptr<FeatureInfo>> cand;
     for (auto& item : *map_server)
         if (item.second->_ftype == FeatureInfo::MSCKF && item.second->_isToMarg) { cand_ids.push_back(item.first); cand.push_back(item.second); }
+    static const bool timing = std::getenv("INGVIO_SHIM_TIMING") != nullptr;      // host wall time of the update's phases on stderr (debugging aid)
+    using clk = std::chrono::steady_clock;
+    auto us = [](clk::time_point x, clk::time_point y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
+    const clk::time_point q0 = clk::now();
     std::vector<char> tri_ok;
     tri->triangulateMany(cand, state, stereo, tri_ok);                 // one device call for the frame's lost features
+    const clk::time_point q1 = clk::now();
     for (size_t i = 0; i < cand.size(); ++i) {
         const bool enough = stereo ? cand[i]->numOfStereoFrames() >= 3 : cand[i]->numOfMonoFrames() >= 4;               // :287 / :51
         if (tri_ok[i] && enough) update_ids.push_back(cand_ids[i]);
@@ -278,6 +286,7 @@ void RemoveLostUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapS
         ff.add(fi, stereo, nullptr, dof);
         if (dof > max_dof) max_dof = dof;
     }
+    const clk::time_point q2 = clk::now();
     if (ff.F > 0) {
         const std::vector<double> table = chi2TableDense(max_dof + 1);
         const ingvio_msckf_frame fr = ff.view();
@@ -286,7 +295,10 @@ void RemoveLostUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapS
         _last_rows = StateManager::msckfUpdate(state, fr, op, &acc);
         for (int a : acc) _last_accepted += a;
     }
+    const clk::time_point q3 = clk::now();
     for (const auto& id : update_ids) map_server->erase(id);                                          // :402-403
+    if (timing) std::fprintf(stderr, "SHIM remove_lost us: triangulate %zu features %.1f, frame of %d features %.1f, msckfUpdate %.1f, erase %.1f\n",
+                             cand.size(), us(q0, q1), ff.F, us(q1, q2), us(q2, q3), us(q3, clk::now()));
 }
 
 // ---------------------------------------------------------------------------------------------
