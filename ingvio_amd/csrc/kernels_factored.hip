@@ -268,8 +268,16 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
             {
                 const double n0 = sum16(N[0]), n1 = sum16(N[1]), n2 = sum16(N[2]), n4 = sum16(N[4]), n5 = sum16(N[5]), n8 = sum16(N[8]);
                 Ns[0] = n0; Ns[1] = n1; Ns[2] = n2; Ns[3] = n1; Ns[4] = n4; Ns[5] = n5; Ns[6] = n2; Ns[7] = n5; Ns[8] = n8;
+#ifdef GRAM_NSA_SUMS
                 const double a0 = sum16(cn * N[0]), a1 = sum16(cn * N[1]), a2 = sum16(cn * N[2]), a4 = sum16(cn * N[4]), a5 = sum16(cn * N[5]),
                              a8 = sum16(cn * N[8]);
+#else
+                // the only observation with cn = 0 is the one AT the anchor slot: Nsa = Ns - N_anchor, the anchor lane's N fetched with
+                // six 64-bit shuffles instead of six more 16-lane sums (72 VALU instructions of the phase the batch waits for)
+                const int alane = (lane & 48) | (a & 15);
+                const double a0 = n0 - __shfl(N[0], alane, WAVE), a1 = n1 - __shfl(N[1], alane, WAVE), a2 = n2 - __shfl(N[2], alane, WAVE),
+                             a4 = n4 - __shfl(N[4], alane, WAVE), a5 = n5 - __shfl(N[5], alane, WAVE), a8 = n8 - __shfl(N[8], alane, WAVE);
+#endif
                 Nsa[0] = a0; Nsa[1] = a1; Nsa[2] = a2; Nsa[3] = a1; Nsa[4] = a4; Nsa[5] = a5; Nsa[6] = a2; Nsa[7] = a5; Nsa[8] = a8;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) hs[i] = sum16(h[i]);
