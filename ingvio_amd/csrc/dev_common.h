@@ -76,6 +76,19 @@ __device__ __forceinline__ double row_ror_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
+// value of lane `src` (0..15, a run-time constant after unrolling) of the same 16-lane row: DPP row_newbcast on both halves
+__device__ __forceinline__ double row_bcast_f64(double v, int src)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    switch (src & 15) {
+#define INGVIO_BC(N) case N: lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + N, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + N, 0xf, 0xf, false); break;
+        INGVIO_BC(0) INGVIO_BC(1) INGVIO_BC(2) INGVIO_BC(3) INGVIO_BC(4) INGVIO_BC(5) INGVIO_BC(6) INGVIO_BC(7)
+        INGVIO_BC(8) INGVIO_BC(9) INGVIO_BC(10) INGVIO_BC(11) INGVIO_BC(12) INGVIO_BC(13) INGVIO_BC(14) INGVIO_BC(15)
+#undef INGVIO_BC
+    }
+    return __hiloint2double(hi, lo);
+}
+
 // 1/x to full FP64 precision: v_rcp_f64 + two Newton steps (the IEEE division expands to ~3x the latency).  Measured on MI355X
 // (tools/micro/rcp_f64.hip, 4 M doubles over 2^+-300): v_rcp_f64 alone 4.6e-8 relative, one step 2.2e-15, two steps 1.1e-16.
 __device__ __forceinline__ double fast_rcp(double x)

@@ -44,6 +44,7 @@ struct Gate5Shared {
         double kp[GATE5_DB ? 2 : 1][KPS];           // Kr of one feature, packed lower triangle by rows (+16: unclamped reads of padding columns); two
                                      // buffers: feature f + 1's blocks are formed while feature f's tiles are filled
         double pan[NF][16 * NTL][4]; // panel exchange of the four eliminations
+        double fin[NF][16][18];      // the last 16 x 16 blocks, one row per lane of the feature's group (see the finish of the eliminations)
     };
     alignas(16) double lf[NF][20];   // per panel and feature: W = L^-1 of the 4 x 4 diagonal block (row-major, 16) | r0 r1 r2 r3
 };
@@ -311,9 +312,18 @@ __device__ __forceinline__ void gate5_body(CovView cv, FrameView fv, MsckfOpts o
     for (int q = 0; q < NF; ++q) npmax = np_g[q] > npmax ? np_g[q] : npmax;
     const int npan = (npmax + 3) >> 2;
     constexpr int KPAN = (NPMAX + 3) / 4;
+    // Two tile rows (7 ... 11 clones): once the first tile column is eliminated only the 16 x 16 block (1, 1) is left - 14 pivot rows,
+    // a padding row and the border row.  Taken through four more panels it costs four times the panel's fixed price (two LDS round
+    // trips, the 4 x 4 factorisation, an MFMA) for a quarter of the first panels' work.  Instead every lane of group g takes ONE ROW of
+    // feature g's block and the 15 pivots are eliminated in registers: the pivot row is broadcast inside the 16-lane row by DPP
+    // (row_newbcast), no LDS, no barrier, one reciprocal per pivot.
+#ifndef GATE5_FINISH
+#define GATE5_FINISH 1
+#endif
+    constexpr bool FIN = GATE5_FINISH && NTL == 2;
 #pragma unroll
     for (int k = 0; k < KPAN; ++k) {
-        if (k < npan) {
+        if (k < npan && !(FIN && k >= 4)) {
             const int tj0 = k >> 2, cb = 4 * (k & 3);
             if (l15 >= cb && l15 < cb + 4) {
 #pragma unroll
@@ -384,6 +394,31 @@ __device__ __forceinline__ void gate5_body(CovView cv, FrameView fv, MsckfOpts o
             }
             wave_sync();
         }
+    }
+    if (FIN && npan > 4) {
+#pragma unroll
+        for (int fq = 0; fq < NF; ++fq)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sh.fin[fq][kq + 4 * r][l15] = T[fq][NLT - 1][r];      // C/D layout: column l15, rows kq + 4 r
+        wave_sync();
+        double row[16];
+        {
+            const double2* pr = reinterpret_cast<const double2*>(sh.fin[g][sl]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const double2 u = pr[q]; row[2 * q] = u.x; row[2 * q + 1] = u.y; }
+            // the border is only ever filled and updated as a ROW (the panels read the lower triangle): its column comes from the row
+            if (sl < 15) row[15] = sh.fin[g][15][sl];
+        }
+#pragma unroll
+        for (int i = 0; i < 15; ++i) {
+            const double rinv = G5RCP(row_bcast_f64(row[i], i));      // pivot (i, i): lane i's diagonal element
+            const double l = row[i] * rinv;                           // rows above the pivot hold zeros here: nothing happens to them
+#pragma unroll
+            for (int q = i + 1; q < 16; ++q) row[q] = fma(-l, row_bcast_f64(row[q], i), row[q]);      // the pivot row, by symmetry its column
+        }
+        // the corner (BR, BR) sits in lane 15 of every group: back to where the gate below expects it
+#pragma unroll
+        for (int fq = 0; fq < NF; ++fq) T[fq][NLT - 1][3] = __shfl(row[15], 16 * fq + 15, WAVE);
     }
     dbg_stamp(9);
     if (lane == WAVE - 1) {                       // lane (kq = 3, l15 = 15) holds element (BR, BR) = -w^T Kr^-1 w of every feature
