@@ -23,4 +23,3 @@ seg("info_apply [setup, T = Pc M, tile loop]", [11, 12, 13]) if False else None
 print("info_apply [T = Pc M, tile loop]", [d[12] - d[11], d[13] - d[12]])
 print("info_apply step 4 [MFMAs + stores, stage store, barrier]", [d[45] - d[44], d[46] - d[45], d[47] - d[46]], " start -> T:", d[11] - d[12], " whole:", d[13] - d[12])
 print("info_apply step 4 [issue loads + B fragments, MFMAs tile 0, store tile 0, tile 1]", [d[48] - d[44], d[49] - d[48], d[50] - d[49], d[45] - d[50]])
-print("info_apply store of tile 0 in step 4 [v + 4 stores + 4 LDS writes, LDS read back, 4 stores]", [d[51] - d[49], d[52] - d[51], d[50] - d[52]])
