@@ -702,8 +702,8 @@ def run_workload(args, grp, aux=False):
 
 REPLAY_TOOL = os.path.join(ROOT, "ingvio_amd", "lib", "ingvio_replay")
 LATENCY_STREAMS = {      # SynthStream.h specs: every `life` frames a whole cohort of tracks is lost -> one RemoveLost update over all of them
-    "config2": "feats=150,clones=11,life=10,cohort=1,birth_frame=2,frames=75,key=1",
-    "config5": "feats=300,clones=30,life=28,cohort=1,birth_frame=3,frames=125,key=1",      # births on the frames whose clone survives the next key-frame marginalisation (SynthStream.h)
+    "config2": "feats=150,clones=11,life=10,cohort=1,birth_frame=3,frames=75,key=1",
+    "config5": "feats=300,clones=30,life=28,cohort=1,birth_frame=2,frames=125,key=1",      # births on the frames whose clone survives the next key-frame marginalisation (SynthStream.h)
 }
 
 

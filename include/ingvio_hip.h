@@ -71,6 +71,7 @@ void* ingvio_ctx_stream(ingvio_ctx* ctx);             /* the hipStream_t all ker
 const char* ingvio_last_error(ingvio_ctx* ctx);
 int ingvio_ldp(ingvio_ctx* ctx);                      /* leading dimension of the device P buffers  */
 int ingvio_f_max(ingvio_ctx* ctx);                    /* feature capacity: length of the accepted[] arrays */
+int ingvio_c_max(ingvio_ctx* ctx);                    /* window capacity: the most clones a staged frame may name */
 /* Identity of the device code this library was built from (no reference counterpart): a JSON string
  * {"tu": {translation unit: hash of its text + headers + flags}, "kernels": {kernel: translation unit}} written by
  * ingvio_amd/build.py.  Profile counters are stored with it; bench.py prices a kernel only with counters of the same build. */

@@ -20,7 +20,7 @@ E_ARG, E_CAPACITY, E_HIP, E_NOT_IN_STATE, E_UNSUPPORTED, E_NOT_PD = -1, -2, -3, 
 R_SCALAR, R_DIAG, R_FULL = 0, 1, 2
 
 EXPORTS = [
-    "ingvio_ctx_create", "ingvio_ctx_destroy", "ingvio_sync", "ingvio_ctx_stream", "ingvio_f_max", "ingvio_last_error", "ingvio_ldp",
+    "ingvio_ctx_create", "ingvio_ctx_destroy", "ingvio_sync", "ingvio_ctx_stream", "ingvio_f_max", "ingvio_c_max", "ingvio_last_error", "ingvio_ldp",
     "ingvio_build_id",
     "ingvio_cov_set", "ingvio_cov_get", "ingvio_get_n", "ingvio_cov_get_marginal", "ingvio_cov_snapshot",
     "ingvio_cov_restore", "ingvio_propagate", "ingvio_propagate_fused", "ingvio_augment_clone", "ingvio_marginalize",

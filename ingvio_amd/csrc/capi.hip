@@ -96,6 +96,9 @@ struct ingvio_ctx {
         // posterior (k_post_cols); Yf [B][ldp * 16]: the update's Cholesky-form gain, folded into k_info_apply; its own working rows
         // count / column count / dx (the frame's m, nc and dx slots belong to the MSCKF update)
         bool in_frame = false, fused_last = false;
+        bool results = false;           // an update has run on the current stage: ingvio_gnss_fetch has something to return.  A non-restoring
+                                        // ingvio_frame_run CONSUMES an in-frame stage (staged = false, as it does a landmark stage: the rows
+                                        // belong to one frame); its results stay fetchable until the next stage
         int nc_max = 0;
         double *W = nullptr, *Yf = nullptr, *dxf = nullptr;
         int *mf = nullptr, *ncf = nullptr;
@@ -547,6 +550,7 @@ static int gnss_in_frame_launch(ingvio_ctx* c, int b0, int nb, FactoredLaunch& L
     { ProfScope p(c, PF_EKF_CORE); launch_ekf_core(E, c->st); }
     L.gY = E.Y; L.gYstride = ws; L.gm = g.mf + b0;
     g.fused_last = true;
+    g.results = true;
     return 0;
 }
 
@@ -763,6 +767,7 @@ void* ingvio_ctx_stream(ingvio_ctx* c) { return c ? (void*)c->st : nullptr; }
 const char* ingvio_last_error(ingvio_ctx* c) { return c ? c->err.c_str() : "null context"; }
 int ingvio_ldp(ingvio_ctx* c) { return c ? c->ldp : 0; }
 int ingvio_f_max(ingvio_ctx* c) { return c ? c->d.f_max : 0; }
+int ingvio_c_max(ingvio_ctx* c) { return c ? c->d.c_max : 0; }
 
 int ingvio_cov_set(ingvio_ctx* c, int b, const double* P, int ld, int n)
 {
@@ -1216,6 +1221,7 @@ int ingvio_gnss_stage(ingvio_ctx* c, int b0, int nb, const ingvio_update_block* 
     if (!g.staged || ncm > g.nc_max) g.nc_max = ncm;
     g.in_frame = o->in_frame != 0;
     g.fused_last = false;
+    g.results = false;
     if (g.in_frame && !g.W) {
         const size_t B = c->d.batch, ws = (size_t)c->ldp * 16;
         if (dalloc(c, &g.W, B * ws) | dalloc(c, &g.Yf, B * ws) | dalloc(c, &g.dxf, B * (size_t)c->ldp) | dalloc(c, &g.mf, B) | dalloc(c, &g.ncf, B)) return INGVIO_E_HIP;
@@ -1301,6 +1307,10 @@ int ingvio_gnss_front_stage(ingvio_ctx* c, int b0, int nb, const ingvio_gnss_epo
     g.thr1 = o->gate_rows ? o->chi2_table[1] : __builtin_inf();
     const int m_cap = 2 * smax;
     if (!g.staged || m_cap > g.m_cap) g.m_cap = m_cap;
+    // the front builds the reference's var_order [SE23, YOF, <= 4 clocks, FS] = at most 15 columns; a front-staged update is applied
+    // by ingvio_gnss_run (the flags of an earlier in-frame ingvio_gnss_stage must not leak into this stage)
+    if (o->in_frame) { c->err = "ingvio_gnss_front_stage: in_frame is not supported (stage the rows with ingvio_gnss_stage)"; return INGVIO_E_UNSUPPORTED; }
+    g.in_frame = false; g.nc_max = 15; g.fused_last = false; g.results = false;
     g.staged = true;
     return last_launch(c);
 }
@@ -1381,6 +1391,7 @@ static int gnss_run_separate(ingvio_ctx* c, int b0, int nb, bool own_slots)
 {
     auto& g = c->gn;
     g.fused_last = own_slots;
+    g.results = true;
     int n_cap = 0;
     for (int i = 0; i < nb; ++i) {
         if (g.hi[b0 + i] > c->h_n[b0 + i]) return INGVIO_E_NOT_IN_STATE;          // checkSubOrder against the LIVE state
@@ -1392,11 +1403,14 @@ static int gnss_run_separate(ingvio_ctx* c, int b0, int nb, bool own_slots)
     // after a fused frame step every filter's live covariance sits in the SECOND ping-pong half and this update (k_downdate) is in
     // place there: the first half still holds the prior up to the propagation strips, so a following ingvio_frame_run(restore_prior)
     // may keep restoring the strips only (0.03 instead of 0.10 ms per 512 filters)
-    const bool keep_strips = c->strip_ok && c->mut_seq == c->strip_seq;
+    bool keep_strips = c->strip_ok && c->mut_seq == c->strip_seq;
+    for (int i = 0; i < nb && keep_strips; ++i) if (c->h_cur[b0 + i] != 1) keep_strips = false;      // ... which only holds for filters that sit in the second half
     EkfLaunch E;
     memset(&E, 0, sizeof E);
     E.cv = view(c);
-    if (keep_strips) c->strip_seq = c->mut_seq; E.b0 = b0; E.nb = nb; E.H = c->d_H + (size_t)b0 * hs; E.res = c->d_res + (size_t)b0 * mld;
+    // k_downdate below is strictly in place in the live half (launch_downdate never writes the other one): the strips stay valid
+    if (keep_strips) c->strip_seq = c->mut_seq;
+    E.b0 = b0; E.nb = nb; E.H = c->d_H + (size_t)b0 * hs; E.res = c->d_res + (size_t)b0 * mld;
     E.colmap = c->d_colmap + (size_t)b0 * GNSS_NCW; E.m = (own_slots ? g.mf : c->d_m) + b0; E.nc = (own_slots ? g.ncf : c->d_nc) + b0;
     E.noise = c->d_noiseB + (size_t)b0 * mld; E.r_kind = INGVIO_R_DIAG; E.mld = c->mld; E.hstride = (int)hs; E.cstride = GNSS_NCW;
     E.nstride = c->mld; E.Y = c->d_Y + (size_t)b0 * c->ystride; E.ystride = c->ystride; E.dx = own_slots ? g.dxf : c->d_dx;
@@ -1415,7 +1429,8 @@ static int gnss_run_separate(ingvio_ctx* c, int b0, int nb, bool own_slots)
 
 int ingvio_gnss_fetch(ingvio_ctx* c, int b0, int nb, double* dx_out, int* rows_out, int* keep_out, double* gamma_out, int* status_out)
 {
-    if (check_range(c, b0, nb) || !c->gn.staged) return INGVIO_E_ARG;
+    if (check_range(c, b0, nb)) return INGVIO_E_ARG;
+    if (!c->gn.results) { c->err = "ingvio_gnss_fetch: no GNSS update has run on the staged rows (an in-frame stage is applied by ingvio_frame_run)"; return INGVIO_E_ARG; }
     const size_t mld = c->mld;
     std::vector<int> status(nb, 0);
     const bool fz = c->gn.fused_last;             // the in-frame update kept its results apart from the frame's
@@ -2106,6 +2121,13 @@ static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
         if (with_lm2 && !c->phase_restore) c->lm.staged = false;
         c->strip_ok = false;
         c->mut_seq++;
+        // an in-frame GNSS stage: the split step never folds it into the write-back - its own pass, as the unsplit step does for the
+        // shapes it cannot fold (it used to be dropped silently here)
+        if (c->gn.staged && c->gn.in_frame && c->gn.m_cap > 0) {
+            rc2 = gnss_run_separate(c, 0, B2, true);
+            if (rc2) return rc2;
+            if (!c->phase_restore) c->gn.staged = false;
+        }
         if (c->alt_ready) { HIPCHK(c, hipEventRecord(c->ev_free[c->set_id], c->st)); c->free_valid[c->set_id] = true; }
         return INGVIO_OK;
     }
@@ -2192,6 +2214,9 @@ static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
         rc = gnss_run_separate(c, 0, B, true);
         if (rc) return rc;
     }
+    // like a landmark stage, an in-frame GNSS stage belongs to ONE frame: consumed here unless the caller replays the same prior, so
+    // that a later frame cannot apply the old rows again; ingvio_gnss_fetch still returns this frame's results
+    if (c->gn.staged && c->gn.in_frame && !restore_prior) c->gn.staged = false;
     if (c->alt_ready) {                            // this input set may be refilled once the kernels above are done with it
         HIPCHK(c, hipEventRecord(c->ev_free[c->set_id], c->st));
         c->free_valid[c->set_id] = true;

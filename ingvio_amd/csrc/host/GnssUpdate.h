@@ -77,10 +77,13 @@ struct GvioAlignment {
 // buffers usable.
 class GnssSync {
 public:
-    explicit GnssSync(double unsync_thres = 0.05) : _unsync_thres(unsync_thres) {}
-    // GnssSync.h:60-74: with use_fix_time_offset the configured offset is taken and the buffers open at once
-    explicit GnssSync(const IngvioParams& fp, double unsync_thres = 0.05) : _unsync_thres(unsync_thres)
+    // the reference's threshold is 0.13 s (GnssSync.h:61): it gates the arrival pairing AND the window in which getGnssMeasAt /
+    // getSppAt match an epoch to a frame - epochs older than (frame - 0.13 s) are dropped, the first one before (frame + 0.13 s) taken
+    explicit GnssSync(double unsync_thres = 0.13) : _unsync_thres(unsync_thres) {}
+    // GnssSync.h:60-74: nothing without enable_gnss; with use_fix_time_offset the configured offset is taken and the buffers open at once
+    explicit GnssSync(const IngvioParams& fp, double unsync_thres = 0.13) : _unsync_thres(unsync_thres)
     {
+        if (!fp._enable_gnss) return;
         if (fp._use_fix_time_offset) { _gnss2local_time_offset = fp._gnss_local_offset; _isSync = true; }
     }
     bool isSync() const { return _isSync; }

@@ -48,6 +48,8 @@ void IngvioFilter::gnssBlock(double stamp)
 
 void IngvioFilter::callbackIMU(const ImuMsg& m)
 {
+    if (_filter_params._enable_gnss && !_gnss_sync->isSync()) return;                   // :385-391 (storeTimePair itself is the ROS node's)
+    if (!_hasImageCome) return;                                                         // :393: IMU samples before the first image are dropped
     _imu_propa->storeImu(ImuCtrl(m.stamp, Vec3d(m.accel), Vec3d(m.gyro)));
     if (!_hasInitState && _imu_propa->isInit()) {                                       // :396-406
         _state->initStateAndCov(m.stamp, _imu_propa->getInitQuat());
@@ -55,39 +57,71 @@ void IngvioFilter::callbackIMU(const ImuMsg& m)
     }
 }
 
+// MapServerManager::collectStereoMeas over FeatureInfoManager::collectStereoMeas (MapServerManager.cpp:203-217 over :146-185)
 void IngvioFilter::collectStereoMeas(const StereoFrameMsg& f)
 {
-    const auto anchor = _state->_sw_camleft_poses.at(_state->_timestamp);
+    const double timestamp = _state->_timestamp;
+    const auto pose_it = _state->_sw_camleft_poses.find(timestamp);
+    if (pose_it == _state->_sw_camleft_poses.end()) {
+        std::printf("[FeatureInfoManager]: Meas timestamp not in sw!\n");                 // :152-156 (assert(false) there)
+        std::exit(EXIT_FAILURE);
+    }
     for (const auto& o : f.stereo_meas) {
         auto it = _map_server->find(o.id);
-        if (it == _map_server->end()) {                                                 // new id: MSCKF feature anchored at the current clone
-            auto fi = std::make_shared<FeatureInfo>();
-            fi->_id = o.id; fi->_ftype = FeatureInfo::MSCKF;
-            fi->_landmark->resetAnchoredPose(anchor);
-            it = _map_server->insert({ o.id, fi }).first;
-        }
-        if (it->second->_ftype == FeatureInfo::SLAM) it->second->_stereo_obs.clear();      // MapServerManager.cpp:178-179
+        if (it == _map_server->end()) it = _map_server->insert({ o.id, std::make_shared<FeatureInfo>() }).first;      // :210-211
+        const auto& fi = it->second;
         auto sm = std::make_shared<StereoMeas>();
-        sm->_u0 = o.u0; sm->_v0 = o.v0; sm->_u1 = o.u1; sm->_v1 = o.v1;
-        it->second->_stereo_obs[f.stamp] = sm;
+        sm->_id = o.id; sm->_u0 = o.u0; sm->_v0 = o.v0; sm->_u1 = o.u1; sm->_v1 = o.v1;
+        if (fi->_stereo_obs.size() == 0) {                                              // :158-168: first observation
+            fi->_stereo_obs[timestamp] = sm;
+            fi->_id = o.id;
+            fi->_ftype = FeatureInfo::MSCKF;
+            fi->_isToMarg = false;
+            fi->_isTri = false;
+            fi->_landmark->resetAnchoredPose(pose_it->second);
+        } else {
+            if (fi->hasStereoObsAt(timestamp)) {                                        // :171-175
+                std::printf("[FeatureInfoManager]: Meas timestamp already in stereo obs, skip adding! \n");
+                continue;
+            }
+            if (fi->_ftype == FeatureInfo::SLAM) fi->_stereo_obs.clear();               // :177-178
+            fi->_stereo_obs[timestamp] = sm;
+            fi->_isToMarg = false;                                                      // :184
+        }
     }
 }
 
+// MapServerManager::collectMonoMeas over FeatureInfoManager::collectMonoMeas (MapServerManager.cpp:187-201 over :105-144)
 void IngvioFilter::collectMonoMeas(const MonoFrameMsg& f)
 {
-    const auto anchor = _state->_sw_camleft_poses.at(_state->_timestamp);
+    const double timestamp = _state->_timestamp;
+    const auto pose_it = _state->_sw_camleft_poses.find(timestamp);
+    if (pose_it == _state->_sw_camleft_poses.end()) {
+        std::printf("[FeatureInfoManager]: Meas timestamp not in sw!\n");
+        std::exit(EXIT_FAILURE);
+    }
     for (const auto& o : f.mono_meas) {
         auto it = _map_server->find(o.id);
-        if (it == _map_server->end()) {
-            auto fi = std::make_shared<FeatureInfo>();
-            fi->_id = o.id; fi->_ftype = FeatureInfo::MSCKF;
-            fi->_landmark->resetAnchoredPose(anchor);
-            it = _map_server->insert({ o.id, fi }).first;
-        }
-        if (it->second->_ftype == FeatureInfo::SLAM) it->second->_mono_obs.clear();        // MapServerManager.cpp:136-137
+        if (it == _map_server->end()) it = _map_server->insert({ o.id, std::make_shared<FeatureInfo>() }).first;
+        const auto& fi = it->second;
         auto mm = std::make_shared<MonoMeas>();
-        mm->_u0 = o.u0; mm->_v0 = o.v0;
-        it->second->_mono_obs[f.stamp] = mm;
+        mm->_id = o.id; mm->_u0 = o.u0; mm->_v0 = o.v0;
+        if (fi->_mono_obs.size() == 0) {
+            fi->_mono_obs[timestamp] = mm;
+            fi->_id = o.id;
+            fi->_ftype = FeatureInfo::MSCKF;
+            fi->_isToMarg = false;
+            fi->_isTri = false;
+            fi->_landmark->resetAnchoredPose(pose_it->second);
+        } else {
+            if (fi->hasMonoObsAt(timestamp)) {
+                std::printf("[FeatureInfoManager]: Meas timestamp already in mono obs, skip adding! \n");
+                continue;
+            }
+            if (fi->_ftype == FeatureInfo::SLAM) fi->_mono_obs.clear();
+            fi->_mono_obs[timestamp] = mm;
+            fi->_isToMarg = false;
+        }
     }
 }
 
@@ -145,7 +179,7 @@ void IngvioFilter::callbackStereoFrame(const StereoFrameMsg& frame)
         if (_filter_params._max_lm_feats > 0) _landmark_update->changeLandmarkAnchor(_state, _map_server);      // :321-322
         _sw_marg_update->margSwPose(_state);
     }
-    eraseInvalidFeatures(_map_server, _state);
+    eraseInvalidFeatures(_map_server, _state, &_last_invalid_erased);
     gnssBlock(frame.stamp);
     ++_frames;
 }
@@ -186,7 +220,7 @@ void IngvioFilter::callbackMonoFrame(const MonoFrameMsg& frame)
         if (_filter_params._max_lm_feats > 0) _landmark_update->changeLandmarkAnchor(_state, _map_server);      // :193-194
         _sw_marg_update->margSwPose(_state);
     }
-    eraseInvalidFeatures(_map_server, _state);
+    eraseInvalidFeatures(_map_server, _state, &_last_invalid_erased);
     gnssBlock(frame.stamp);
     ++_frames;
 }

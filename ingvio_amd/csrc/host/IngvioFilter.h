@@ -54,6 +54,7 @@ public:
     std::shared_ptr<ImuPropagator> imuPropagator() { return _imu_propa; }
     std::shared_ptr<LandmarkUpdate> landmarkUpdate() { return _landmark_update; }
     int framesProcessed() const { return _frames; }
+    const std::vector<int>& lastInvalidErased() const { return _last_invalid_erased; }      // eraseInvalidFeatures of the last frame (trace)
     std::shared_ptr<RemoveLostUpdate> removeLostUpdate() { return _remove_lost_update; }
     std::shared_ptr<KeyframeUpdate> keyframeUpdate() { return _keyframe_update; }
     std::shared_ptr<SwMargUpdate> swMargUpdate() { return _sw_marg_update; }
@@ -78,6 +79,7 @@ protected:
     int _last_gnss_rows = 0, _gnss_vars_added = 0;
     bool _hasImageCome = false, _hasInitState = false;
     int _frames = 0;
+    std::vector<int> _last_invalid_erased;
 };
 
 }  // namespace ingvio

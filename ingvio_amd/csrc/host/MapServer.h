@@ -9,13 +9,21 @@
 
 namespace ingvio {
 
-struct MonoMeas { double _u0 = 0, _v0 = 0; };
-struct StereoMeas { double _u0 = 0, _v0 = 0, _u1 = 0, _v1 = 0; };
+struct MonoMeas { int _id = -1; double _u0 = 0, _v0 = 0; };
+struct StereoMeas { int _id = -1; double _u0 = 0, _v0 = 0, _u1 = 0, _v1 = 0; };
 
 class FeatureInfo {
 public:
     enum FeatureType { MSCKF = 0, SLAM };
     FeatureInfo() : _id(-1), _ftype(MSCKF), _isToMarg(false), _isTri(false), _numOfTri(0) { _landmark = std::make_shared<AnchoredLandmark>(); }
+    // the read accessors of MapServer.h:84-113 (the reference's tests and update classes use both these and the members)
+    int getId() const { return _id; }
+    FeatureType getFeatureType() const { return _ftype; }
+    bool isToMarg() const { return _isToMarg; }
+    bool isTri() const { return _isTri; }
+    bool hasMonoObsAt(double t) const { return _mono_obs.find(t) != _mono_obs.end(); }
+    bool hasStereoObsAt(double t) const { return _stereo_obs.find(t) != _stereo_obs.end(); }
+    const std::shared_ptr<AnchoredLandmark> landmark() const { return _landmark; }
     int numOfMonoFrames() const { return (int)_mono_obs.size(); }
     int numOfStereoFrames() const { return (int)_stereo_obs.size(); }
     const std::shared_ptr<SE3> anchor() const { return _landmark->getAnchoredPose(); }

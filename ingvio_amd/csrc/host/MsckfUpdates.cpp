@@ -105,7 +105,9 @@ void Triangulator::triangulateMany(const std::vector<std::shared_ptr<FeatureInfo
     const int fcap = ingvio_f_max(StateManager::ctx(state));
     const auto& sw = state->_sw_camleft_poses;
     const int C = (int)sw.size();
-    if (feats.empty() || C == 0 || C > 64) {                        // no window (or one the mask cannot name): feature by feature
+    // no window, or one the batched call cannot hold (more slots than the context's clone capacity or than the 64-bit mask): feature by
+    // feature - that path sends a feature's COMMON stamps only (the batched call used to refuse such windows for every feature)
+    if (feats.empty() || C == 0 || C > 64 || C > ingvio_c_max(StateManager::ctx(state))) {
         for (size_t i = 0; i < feats.size(); ++i) ok[i] = triangulate(feats[i], state, stereo) ? 1 : 0;
         return;
     }
@@ -247,19 +249,8 @@ void RemoveLostUpdate::updateStateStereo(std::shared_ptr<State> s, std::shared_p
 void RemoveLostUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri, bool stereo)
 {
     _last_rows = 0; _last_accepted = 0;
-    // MapServerManager::markMarg{Mono,Stereo}Features (MapServerManager.cpp:219-273): lost SLAM landmarks leave the state
-    std::vector<int> lost_slam_ids;
-    for (auto& item : *map_server) {
-        const bool has = stereo ? item.second->_stereo_obs.count(state->_timestamp) > 0 : item.second->_mono_obs.count(state->_timestamp) > 0;
-        if (!has) {
-            item.second->_isToMarg = true;
-            if (item.second->_ftype == FeatureInfo::SLAM) lost_slam_ids.push_back(item.first);
-        }
-    }
-    for (const int id : lost_slam_ids) {
-        StateManager::margAnchoredLandmarkInState(state, id);
-        map_server->erase(id);
-    }
+    _rec.clear();
+    markMargFeatures(map_server, state, stereo);                                       // RemoveLostUpdate.cpp:43 / :279
     std::vector<int> update_ids, direct_marg_ids, cand_ids;
     std::vector<std::shared_ptr<FeatureInfo>> cand;
     for (auto& item : *map_server)
@@ -267,26 +258,28 @@ void RemoveLostUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapS
     static const bool timing = std::getenv("INGVIO_SHIM_TIMING") != nullptr;      // host wall time of the update's phases on stderr (debugging aid)
     using clk = std::chrono::steady_clock;
     auto us = [](clk::time_point x, clk::time_point y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
-    const clk::time_point q0 = clk::now();
+    clk::time_point q0, q1, q2, q3;
+    if (timing) q0 = clk::now();
     std::vector<char> tri_ok;
     tri->triangulateMany(cand, state, stereo, tri_ok);                 // one device call for the frame's lost features
-    const clk::time_point q1 = clk::now();
+    if (timing) q1 = clk::now();
     for (size_t i = 0; i < cand.size(); ++i) {
         const bool enough = stereo ? cand[i]->numOfStereoFrames() >= 3 : cand[i]->numOfMonoFrames() >= 4;               // :287 / :51
         if (tri_ok[i] && enough) update_ids.push_back(cand_ids[i]);
         else direct_marg_ids.push_back(cand_ids[i]);
     }
     for (const auto& id : direct_marg_ids) map_server->erase(id);
+    _rec.direct = direct_marg_ids;
     if (update_ids.size() == 0) return;
     FlatFrame ff(state);
     int max_dof = 1;
     for (int id : update_ids) {
         const auto& fi = map_server->at(id);
         const int dof = (stereo ? (int)fi->_stereo_obs.size() : (int)fi->_mono_obs.size()) - 1;       // :332-333 (Q4)
-        ff.add(fi, stereo, nullptr, dof);
+        if (ff.add(fi, stereo, nullptr, dof)) _rec.ids.push_back(id);
         if (dof > max_dof) max_dof = dof;
     }
-    const clk::time_point q2 = clk::now();
+    if (timing) q2 = clk::now();
     if (ff.F > 0) {
         const std::vector<double> table = chi2TableDense(max_dof + 1);
         const ingvio_msckf_frame fr = ff.view();
@@ -294,8 +287,9 @@ void RemoveLostUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapS
         std::vector<int> acc;
         _last_rows = StateManager::msckfUpdate(state, fr, op, &acc);
         for (int a : acc) _last_accepted += a;
+        _rec.accepted = acc; _rec.rows = _last_rows;
     }
-    const clk::time_point q3 = clk::now();
+    if (timing) q3 = clk::now();
     for (const auto& id : update_ids) map_server->erase(id);                                          // :402-403
     if (timing) std::fprintf(stderr, "SHIM remove_lost us: triangulate %zu features %.1f, frame of %d features %.1f, msckfUpdate %.1f, erase %.1f\n",
                              cand.size(), us(q0, q1), ff.F, us(q1, q2), us(q2, q3), us(q3, clk::now()));
@@ -323,8 +317,10 @@ void SwMargUpdate::updateStateMono(std::shared_ptr<State> s, std::shared_ptr<Map
 void SwMargUpdate::updateStateStereo(std::shared_ptr<State> s, std::shared_ptr<MapServer> m, std::shared_ptr<Triangulator> t) { update(s, m, t, true); }
 
 static int selectedUpdate(UpdateBase& base, std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server,
-                          std::shared_ptr<Triangulator> tri, bool stereo, const std::vector<double>& sel, int dof, double noise)
+                          std::shared_ptr<Triangulator> tri, bool stereo, const std::vector<double>& sel, int dof, double noise, UpdateRecord& rec)
 {
+    rec.clear();
+    rec.stamps = sel;
     // features observed at every selected stamp (SwMargUpdate.cpp:236-257 / KeyframeUpdate.cpp:607-628)
     FlatFrame ff(state);
     std::vector<std::shared_ptr<FeatureInfo>> cand;
@@ -339,17 +335,19 @@ static int selectedUpdate(UpdateBase& base, std::shared_ptr<State> state, std::s
     std::vector<char> tri_ok;
     tri->triangulateMany(cand, state, stereo, tri_ok);
     for (size_t i = 0; i < cand.size(); ++i)
-        if (tri_ok[i]) ff.add(cand[i], stereo, &sel, dof);
+        if (tri_ok[i] && ff.add(cand[i], stereo, &sel, dof)) rec.ids.push_back(cand[i]->_id);
     if (ff.F == 0) return 0;
     const std::vector<double> table = base.chi2TableDense(dof + 1);
     const ingvio_msckf_frame fr = ff.view();
     const ingvio_msckf_opts op = makeOpts(state, stereo, noise, table, 0, 1 /* top_n, SwMargUpdate.cpp:350-351 */, 1 /* Q10 */);
-    return StateManager::msckfUpdate(state, fr, op, nullptr);
+    rec.rows = StateManager::msckfUpdate(state, fr, op, &rec.accepted);
+    return rec.rows;
 }
 
 void SwMargUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri, bool stereo)
 {
     _last_rows = 0;
+    _rec.clear(); _maint.clear();
     const double marg_time = state->nextMargTime();
     if (marg_time == INFINITY) return;
     std::vector<double> selected_timestamps;
@@ -359,13 +357,14 @@ void SwMargUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapServe
             std::cout << "[SwMargUpdate]: selected timestamp not in sw!" << std::endl;                // :462-466
             std::exit(EXIT_FAILURE);
         }
-    _last_rows = selectedUpdate(*this, state, map_server, tri, stereo, selected_timestamps, (int)selected_timestamps.size() - 1, _noise);
+    _last_rows = selectedUpdate(*this, state, map_server, tri, stereo, selected_timestamps, (int)selected_timestamps.size() - 1, _noise, _rec);
 }
 
 template <bool STEREO>
-static void cleanObsAt(std::shared_ptr<MapServer> map_server, const std::vector<double>& stamps)
+static void cleanObsAt(std::shared_ptr<MapServer> map_server, const std::vector<double>& stamps, MaintenanceRecord& rec)
 {
-    std::vector<int> ids_to_clean;
+    std::vector<int>& ids_to_clean = rec.clean_erased;
+    ids_to_clean.clear();
     for (auto& item : *map_server)
         for (double t : stamps) {
             if (STEREO) { item.second->_stereo_obs.erase(t); if (item.second->_stereo_obs.empty()) ids_to_clean.push_back(item.first); }
@@ -378,20 +377,21 @@ void SwMargUpdate::cleanMonoObsAtMargTime(std::shared_ptr<State> state, std::sha
 {
     const double marg_time = state->nextMargTime();
     if (marg_time == INFINITY) return;
-    cleanObsAt<false>(map_server, { marg_time });
+    cleanObsAt<false>(map_server, { marg_time }, _maint);
 }
 void SwMargUpdate::cleanStereoObsAtMargTime(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server)
 {
     const double marg_time = state->nextMargTime();
     if (marg_time == INFINITY) return;
-    cleanObsAt<true>(map_server, { marg_time });
+    cleanObsAt<true>(map_server, { marg_time }, _maint);
 }
 
 static void changeAnchor(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server,
-                         const std::unordered_set<std::shared_ptr<SE3>>& old_anchor_set, double min_depth)
+                         const std::unordered_set<std::shared_ptr<SE3>>& old_anchor_set, double min_depth, MaintenanceRecord& rec)
 {
     const std::shared_ptr<SE3> new_anchor = state->_sw_camleft_poses.rbegin()->second;
-    std::vector<int> ids_to_marg;
+    std::vector<int>& ids_to_marg = rec.anchor_erased;
+    ids_to_marg.clear(); rec.anchor_moved.clear();
     for (auto& item : *map_server) {
         if (item.second->_ftype != FeatureInfo::MSCKF) continue;
         if (old_anchor_set.find(item.second->_landmark->getAnchoredPose()) != old_anchor_set.end()) {
@@ -400,6 +400,7 @@ static void changeAnchor(std::shared_ptr<State> state, std::shared_ptr<MapServer
                 const Vec3d body = new_anchor->valueLinearAsMat().transpose() * (pf - new_anchor->valueTrans());
                 if (body.z() <= min_depth) { ids_to_marg.push_back(item.first); continue; }
                 item.second->_landmark->resetAnchoredPose(new_anchor, true);
+                rec.anchor_moved.push_back(item.first);
             } else
                 ids_to_marg.push_back(item.first);
         }
@@ -411,7 +412,7 @@ void SwMargUpdate::changeMSCKFAnchor(std::shared_ptr<State> state, std::shared_p
 {
     const double marg_time = state->nextMargTime();
     if (marg_time == INFINITY || state->_sw_camleft_poses.find(marg_time) == state->_sw_camleft_poses.end()) return;
-    changeAnchor(state, map_server, { state->_sw_camleft_poses.at(marg_time) }, 0.0);               // :395 (body.z() <= 0)
+    changeAnchor(state, map_server, { state->_sw_camleft_poses.at(marg_time) }, 0.0, _maint);       // :395 (body.z() <= 0)
 }
 
 void SwMargUpdate::margSwPose(std::shared_ptr<State> state)
@@ -419,6 +420,7 @@ void SwMargUpdate::margSwPose(std::shared_ptr<State> state)
     const double marg_time = state->nextMargTime();
     if (marg_time == INFINITY) return;
     StateManager::margSlidingWindowPose(state, marg_time);
+    _maint.marg_stamps.assign(1, marg_time);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -454,23 +456,24 @@ void KeyframeUpdate::updateStateStereo(std::shared_ptr<State> s, std::shared_ptr
 void KeyframeUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri, bool stereo)
 {
     _last_rows = 0;
+    _rec.clear(); _maint.clear();
     std::vector<double> selected_timestamps;
     this->getMargKfs(state, selected_timestamps);
     if (selected_timestamps.size() == 0) return;
-    _last_rows = selectedUpdate(*this, state, map_server, tri, stereo, selected_timestamps, 2 /* KeyframeUpdate.cpp:675-676 */, _noise);
+    _last_rows = selectedUpdate(*this, state, map_server, tri, stereo, selected_timestamps, 2 /* KeyframeUpdate.cpp:675-676 */, _noise, _rec);
 }
 
 void KeyframeUpdate::cleanMonoObsAtMargTime(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server)
 {
     std::vector<double> marg_kfs;
     this->getMargKfs(state, marg_kfs);
-    cleanObsAt<false>(map_server, marg_kfs);
+    cleanObsAt<false>(map_server, marg_kfs, _maint);
 }
 void KeyframeUpdate::cleanStereoObsAtMargTime(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server)
 {
     std::vector<double> marg_kfs;
     this->getMargKfs(state, marg_kfs);
-    cleanObsAt<true>(map_server, marg_kfs);
+    cleanObsAt<true>(map_server, marg_kfs, _maint);
 }
 
 void KeyframeUpdate::changeMSCKFAnchor(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server)
@@ -480,7 +483,7 @@ void KeyframeUpdate::changeMSCKFAnchor(std::shared_ptr<State> state, std::shared
     if (marg_kfs.size() == 0) return;
     std::unordered_set<std::shared_ptr<SE3>> old_anchor_set;
     for (const double& marg_time : marg_kfs) old_anchor_set.insert(state->_sw_camleft_poses.at(marg_time));
-    changeAnchor(state, map_server, old_anchor_set, 0.3);                                            // :311
+    changeAnchor(state, map_server, old_anchor_set, 0.3, _maint);                                    // :311
 }
 
 void KeyframeUpdate::margSwPose(std::shared_ptr<State> state)
@@ -489,9 +492,27 @@ void KeyframeUpdate::margSwPose(std::shared_ptr<State> state)
     this->getMargKfs(state, marg_kfs);
     if (marg_kfs.size() == 0) return;
     for (const double& marg_time : marg_kfs) StateManager::margSlidingWindowPose(state, marg_time);
+    _maint.marg_stamps = marg_kfs;
 }
 
-void eraseInvalidFeatures(std::shared_ptr<MapServer> map_server, std::shared_ptr<State> state)
+void markMargFeatures(std::shared_ptr<MapServer> map_server, std::shared_ptr<State> state, bool stereo)
+{
+    const double curr_timestamp = state->_timestamp;
+    std::vector<int> marg_ids;
+    for (auto& item : *map_server) {
+        const bool has = stereo ? item.second->hasStereoObsAt(curr_timestamp) : item.second->hasMonoObsAt(curr_timestamp);
+        if (!has) {
+            item.second->_isToMarg = true;
+            if (item.second->_ftype == FeatureInfo::SLAM) marg_ids.push_back(item.second->_id);
+        }
+    }
+    for (const int id : marg_ids) {
+        StateManager::margAnchoredLandmarkInState(state, id);
+        map_server->erase(id);
+    }
+}
+
+void eraseInvalidFeatures(std::shared_ptr<MapServer> map_server, std::shared_ptr<State> state, std::vector<int>* erased)
 {
     std::vector<int> ids_to_remove;
     for (const auto& item : *map_server) {
@@ -502,6 +523,7 @@ void eraseInvalidFeatures(std::shared_ptr<MapServer> map_server, std::shared_ptr
         const Vec3d body = anchor_ptr->valueLinearAsMat().transpose() * (fi->_landmark->valuePosXyz() - anchor_ptr->valueTrans());
         if (body.z() <= 0.2) ids_to_remove.push_back(item.first);
     }
+    if (erased) *erased = ids_to_remove;
     for (const int& id : ids_to_remove) {
         if (map_server->at(id)->_ftype == FeatureInfo::SLAM) StateManager::margAnchoredLandmarkInState(state, id);      // :485-486
         map_server->erase(id);

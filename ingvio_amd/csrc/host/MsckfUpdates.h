@@ -53,6 +53,23 @@ protected:
     double _max_depth = 60.0, _min_depth = 0.2;
 };
 
+// What one update call consumed and decided (read by tools/ingvio_replay --trace for the golden-stream comparison, tests/
+// test_stream_golden.py): feature ids in the order they were handed to the device, their accept flags, the ids dropped without an
+// update, the clone stamps the update was restricted to.
+struct UpdateRecord {
+    std::vector<int> ids, accepted, direct;
+    std::vector<double> stamps;
+    int rows = 0;
+    void clear() { ids.clear(); accepted.clear(); direct.clear(); stamps.clear(); rows = 0; }
+};
+// what the window maintenance after the updates did: ids erased when their observations ran out, ids erased / re-anchored by the
+// anchor change, the marginalised clone stamps
+struct MaintenanceRecord {
+    std::vector<int> clean_erased, anchor_erased, anchor_moved;
+    std::vector<double> marg_stamps;
+    void clear() { clean_erased.clear(); anchor_erased.clear(); anchor_moved.clear(); marg_stamps.clear(); }
+};
+
 class RemoveLostUpdate : public UpdateBase {
 public:
     RemoveLostUpdate(const IngvioParams& filter_params);
@@ -60,6 +77,7 @@ public:
     void updateStateStereo(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri);
     int lastRows() const { return _last_rows; }
     int lastAccepted() const { return _last_accepted; }
+    const UpdateRecord& lastRecord() const { return _rec; }
     void setMaxValidIds(int n) { _max_valid_ids = n; }      // RemoveLostUpdate.h:38 (20)
 
 protected:
@@ -68,6 +86,7 @@ protected:
     int _compress_rule = 0;
     double _noise;
     int _last_rows = 0, _last_accepted = 0;
+    UpdateRecord _rec;
 };
 
 class SwMargUpdate : public UpdateBase {
@@ -82,12 +101,16 @@ public:
     void selectSwTimestamps(const std::map<double, std::shared_ptr<SE3>>& sw_poses, const double& marg_time,
                             std::vector<double>& selected_timestamps);                                     // :475-497
     int lastRows() const { return _last_rows; }
+    const UpdateRecord& lastRecord() const { return _rec; }
+    MaintenanceRecord& maintenance() { return _maint; }
 
 protected:
     void update(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri, bool stereo);
     double _noise;
     int _frame_select_interval;
     int _last_rows = 0;
+    UpdateRecord _rec;
+    MaintenanceRecord _maint;
 };
 
 class KeyframeUpdate : public UpdateBase {
@@ -101,9 +124,13 @@ public:
     void changeMSCKFAnchor(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server);           // :280-328
     void margSwPose(std::shared_ptr<State> state);                                                         // :118-129
     int lastRows() const { return _last_rows; }
+    const UpdateRecord& lastRecord() const { return _rec; }
+    MaintenanceRecord& maintenance() { return _maint; }
 
 protected:
     void update(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri, bool stereo);
+    UpdateRecord _rec;
+    MaintenanceRecord _maint;
     double _noise;
     int _max_sw_poses;
     // the reference keeps this counter as a process-global static (KeyframeUpdate.cpp:41); per filter here
@@ -113,7 +140,10 @@ protected:
     int _last_rows = 0;
 };
 
+// MapServerManager::markMarg{Mono,Stereo}Features (MapServerManager.cpp:219-273): every feature without an observation at the
+// current state time is flagged; flagged SLAM landmarks leave the state and the map at once
+void markMargFeatures(std::shared_ptr<MapServer> map_server, std::shared_ptr<State> state, bool stereo);
 // MapServerManager::eraseInvalidFeatures (MapServerManager.cpp:454-490), MSCKF part
-void eraseInvalidFeatures(std::shared_ptr<MapServer> map_server, std::shared_ptr<State> state);
+void eraseInvalidFeatures(std::shared_ptr<MapServer> map_server, std::shared_ptr<State> state, std::vector<int>* erased = nullptr);
 
 }  // namespace ingvio

@@ -320,6 +320,7 @@ struct FilterSink : SynthSink {
     std::unique_ptr<IngvioFilter> filter;
     IngvioParams fp;
     std::vector<FrameTiming>* out = nullptr;
+    std::function<void(int, IngvioFilter&)> on_frame;
     double last_truth[3] = { 0, 0, 0 }, first_truth[3] = { 0, 0, 0 }, first_p[3] = { 0, 0, 0 };
     bool have_first = false;
     bool ok = true;
@@ -352,6 +353,7 @@ struct FilterSink : SynthSink {
             ft.n = filter->state()->curr_cov_size(); ft.clones = (int)filter->state()->_sw_camleft_poses.size();
             out->push_back(ft);
         }
+        if (filter->framesProcessed() > before && on_frame) on_frame((int)k, *filter);
         (void)is_mono;
     }
     void callFrame(const msg::StereoFrame& m) { filter->callbackStereoFrame(m); }
@@ -377,10 +379,11 @@ bool writeSynthRecording(const SynthConfig& cfg, const std::string& path)
     return true;
 }
 
-bool playSynth(const SynthConfig& cfg, const std::string& overrides, std::vector<FrameTiming>& timings, double* truth_err, std::string& err)
+bool playSynth(const SynthConfig& cfg, const std::string& overrides, std::vector<FrameTiming>& timings, double* truth_err, std::string& err,
+               const std::function<void(int, IngvioFilter&)>& on_frame)
 {
     FilterSink s;
-    s.overrides = overrides; s.out = &timings;
+    s.overrides = overrides; s.out = &timings; s.on_frame = on_frame;
     synthStream(cfg, s);
     if (!s.ok || !s.filter) { err = s.err.empty() ? "no filter was built" : s.err; return false; }
     if (truth_err) {

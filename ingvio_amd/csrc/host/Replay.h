@@ -86,6 +86,8 @@ struct FrameTiming { int k = 0; double ms = 0; int lost_rows = 0, lost_accepted 
 
 // Plays the stream of `cfg` straight into a filter (no file), timing every camera callback.  `truth_err` (may be NULL) receives
 // the position error against the ground truth at the last frame.  Needs a GPU.
-bool playSynth(const SynthConfig& cfg, const std::string& overrides, std::vector<FrameTiming>& timings, double* truth_err, std::string& err);
+// `on_frame` (may be empty) is called after every PROCESSED camera frame with the frame index k and the filter (ingvio_replay --trace).
+bool playSynth(const SynthConfig& cfg, const std::string& overrides, std::vector<FrameTiming>& timings, double* truth_err, std::string& err,
+               const std::function<void(int, IngvioFilter&)>& on_frame = std::function<void(int, IngvioFilter&)>());
 
 }  // namespace ingvio

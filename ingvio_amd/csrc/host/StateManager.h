@@ -76,6 +76,8 @@ public:
 
     static ingvio_ctx* ctx(const std::shared_ptr<State>& state) { return state->_ctx; }
     static int filterIndex(const std::shared_ptr<State>& state) { return state->_b; }
+    // the error-state variables in covariance order: the (idx, size) table (read-only view for traces and tests)
+    static const std::vector<std::shared_ptr<Type>>& errVariables(const std::shared_ptr<State>& state) { return state->_err_variables; }
 
 private:
     static void fatal(const std::shared_ptr<State>& state, const char* what, int rc);

@@ -153,6 +153,13 @@ int synthStream(const SynthConfig& cfg, SynthSink& sink)
     const int n_static = (int)std::llround(T_STATIC / DT_IMU);
     const int n_imu = n_static + cfg.frames * IMU_PER_FRAME;
     int frames = 0;
+    {   // the tracker is up before the filter: IngvioFilter::callbackIMU drops every IMU sample that arrives before the first image
+        // (IngvioFilter.cpp:393), and the first image itself only sets the flag (:257-261) - one header-only frame at t = 0
+        msg::StereoFrame f0;
+        f0.header.seq = 0; f0.header.stamp = msg::Time::fromNSec(0); f0.header.frame_id = "cam0";
+        if (cfg.stereo) sink.stereo(f0);
+        else { msg::MonoFrame m0; m0.header = f0.header; sink.mono(m0); }
+    }
     for (int n = 1; n <= n_imu; ++n) {
         const double t = n * DT_IMU;
         const long long k = (n - 1) / IMU_PER_FRAME - n_static / IMU_PER_FRAME + 1;      // frame interval the sample leads to (<= 0: static phase)

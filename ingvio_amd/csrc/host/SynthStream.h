@@ -3,6 +3,8 @@
 //
 // A stream is what /imu0 and /stereo_tracker/stereo_feature would carry for a camera on a circle (r = 5 m, angular rate ramping
 // to 0.4 rad/s = 2 m/s, IMU 200 Hz, frames 20 Hz, 2 s static first for the gravity initialisation, IngvioFilter.cpp:396-406):
+//   * one header-only camera frame at t = 0 comes first: the filter drops IMU samples until the first image has arrived
+//     (IngvioFilter.cpp:393) and that image only raises the flag (:257-261) - without it the static phase would be lost;
 //   * every random draw of frame interval k (its 10 IMU samples, the features born at frame k, the pixel noise of frame k) comes
 //     from SplitMix64(seed + k) in a fixed order, so any frame can be regenerated on its own, in any language;
 //   * feature tracks: `cohort` = all F tracks are born together and lost together after `life` frames (the frame after a cohort
@@ -40,12 +42,13 @@ struct SynthConfig {
     int is_key_frame = 1;
     int life = 10;                // frames a track lives (observations a lost feature carries); <= clones - 1 in key-frame mode
     int cohort = 1;
-    int birth_frame = 2;          // cohort mode: the cohorts are born at frames birth_frame + m * life.  In key-frame mode the clone of
+    int birth_frame = 3;          // cohort mode: the cohorts are born at frames birth_frame + m * life.  In key-frame mode the clone of
                                   // every other frame is marginalised one frame later and takes the never-triangulated tracks anchored
                                   // at it along (KeyframeUpdate.cpp:280-328): tracks born on those frames never reach an update.
-                                  // The window first holds `clones` poses at frame clones + 1 and marginalises from then on every
-                                  // second frame, always the clone of the frame before: births must have the parity of clones + 1
-                                  // (2 for an 11-pose window, 3 for a 30-pose one)
+                                  // The first processed frame is frame 1 (the image that raises _hasImageCome is the header-only one
+                                  // at t = 0), so the window first holds `clones` poses at frame `clones` and marginalises from then on
+                                  // every second frame, always the clone of the frame before: births must have the parity of `clones`
+                                  // (3 for an 11-pose window, 2 for a 30-pose one)
     int outlier_every = 20;
     int frames = 60;              // camera frames after the static phase
     double pixel_noise = 1e-3;    // normalised image coordinates

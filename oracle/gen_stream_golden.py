@@ -1,0 +1,76 @@
+"""Golden STREAMS for the policy layer of the camera callback: tests/golden/stream_*.npz.
+
+TEST INFRASTRUCTURE.  For every stream below the C++ generator (ingvio_replay --synth ... --write: the SplitMix64 stream of
+ingvio_amd/csrc/host/SynthStream.cpp, no device needed) writes the INGVIOR1 recording, and oracle/stream_filter.py — the
+independent Python transcription of IngvioFilter::callbackStereoFrame and the classes under it, driving the CPU oracle — plays
+it.  Committed per processed frame: the feature ids each update consumed, their accept masks, the selected / marginalised clone
+stamps, what the anchor change / cleaning / eraseInvalidFeatures removed, the (idx, size) table, the window stamps, the map
+server's ids, the nominal state (R, p, v, bg, ba, extrinsics), diag(P) and |P|_F.
+
+    python -m oracle.gen_stream_golden            # regenerates every stream (about a minute of CPU)
+
+tests/test_stream_golden.py replays the same specs through the C++ shim on the device (ingvio_replay --synth ... --trace) and
+compares frame by frame; a CPU test re-plays the first frames through stream_filter and checks the committed file."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+TOOL = os.path.join(ROOT, "ingvio_amd", "lib", "ingvio_replay")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# name -> (synth spec, parameter overrides as "key: value" lines)
+STREAMS = {
+    # key-frame mode, the 11-pose window of BASELINE config 2, cohort tracks (every 10th frame loses 150 tracks at once), as written:
+    # RemoveLost accepts at most 20 features (Q3) and keeps every row after the rotation (Q2)
+    "kf11": ("feats=150,clones=11,life=10,cohort=1,birth_frame=3,frames=60,key=1", ""),
+    # the same with the cap lifted and top-n compression: the heavy frames of bench.py's latency line
+    "kf11_lifted": ("feats=150,clones=11,life=10,cohort=1,birth_frame=3,frames=60,key=1", "hip_max_valid_ids: 0\nhip_compress_rule: 1\n"),
+    # sliding-window mode (is_key_frame = 0): oldest clone marginalised every frame, selectSwTimestamps with interval 5 -> 3 stamps;
+    # staggered track deaths (15 per frame)
+    "sw11": ("feats=150,clones=11,life=13,cohort=0,frames=60,key=0", "frame_select_interval: 5\n"),
+    # key-frame mode at the window of the reference's shipped stereo config (config/fw_zed2i_f9p/ingvio_stereo.yaml: 21 poses)
+    "kf21": ("feats=100,clones=21,life=19,cohort=0,frames=70,key=1,outlier_every=7", ""),
+    # sliding-window mode, 21 poses, interval 6 -> 4 stamps
+    "sw21": ("feats=100,clones=21,life=25,cohort=0,frames=70,key=0,outlier_every=7", "frame_select_interval: 6\n"),
+}
+
+
+def write_recording(spec, path):
+    subprocess.run([TOOL, "--synth", spec, "--write", path], check=True)
+
+
+def generate(name, keep_P_every=0):
+    from oracle import stream_filter as sf
+    spec, overrides = STREAMS[name]
+    with tempfile.TemporaryDirectory() as d:
+        rec = os.path.join(d, name + ".ingvior")
+        write_recording(spec, rec)
+        traces = sf.play_recording(rec, overrides)
+    out = sf.pack_traces(traces)
+    out["spec"] = np.array(spec)
+    out["overrides"] = np.array(overrides)
+    return traces, out
+
+
+def main(argv):
+    names = [a for a in argv if not a.startswith("-")] or list(STREAMS)
+    for name in names:
+        traces, out = generate(name)
+        path = os.path.join(GOLDEN, "stream_%s.npz" % name)
+        np.savez_compressed(path, **out)
+        lost = [len(t["lost_ids"]) for t in traces]
+        acc = [int(np.sum(t["lost_acc"])) for t in traces]
+        sel = [len(t["sel_ids"]) for t in traces]
+        sacc = [int(np.sum(t["sel_acc"])) for t in traces]
+        print("%s: %d frames, N %d..%d, RemoveLost features/frame max %d (accepted max %d), selected-update features max %d (accepted max %d), "
+              "final |p| %.3f, %d bytes" % (name, len(traces), int(min(t["n"] for t in traces)), int(max(t["n"] for t in traces)), max(lost), max(acc),
+                                            max(sel), max(sacc), float(np.linalg.norm(traces[-1]["pose"][9:12])), os.path.getsize(path)))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -1,0 +1,647 @@
+"""The POLICY layer of InGVIO's camera callback, restated in Python on top of the CPU oracle's covariance arithmetic.
+
+TEST INFRASTRUCTURE ONLY (same rule as oracle/ingvio_oracle.h): imported by oracle/gen_stream_golden.py and tests/; never by
+ingvio_amd/.  Written from the reference sources alone (cited as path:line under /root/reference/ingvio_estimator/src/), NOT
+from the C++ shim in ingvio_amd/csrc/host/ — it is the independent second opinion on which tracks go to which update, which
+clones are selected, when anchors change and what is erased:
+
+    IngvioFilter::callbackIMU                      IngvioFilter.cpp:381-407
+    IngvioFilter::callbackStereoFrame              IngvioFilter.cpp:252-379
+    ImuPropagator::storeImu / propagateUntil / propagateAugmentAtEnd   ImuPropagator.cpp:27-68, 232-314
+    State::State / initStateAndCov / nextMargTime  State.cpp:61-160, State.h:82-91
+    StateManager::augmentSlidingWindowPose / marginalize / boxPlus / margSlidingWindowPose   StateManager.cpp:155-192, 245-296, 318-328
+    MapServerManager::collectStereoMeas / markMargStereoFeatures / eraseInvalidFeatures      MapServerManager.cpp:146-217, 245-273, 456-491
+    FeatureInfoManager::triangulateFeatureInfoStereo                                          MapServerManager.cpp:309-341
+    RemoveLostUpdate::updateStateStereo            RemoveLostUpdate.cpp:276-405
+    SwMargUpdate::updateStateStereo / selectSwTimestamps / changeMSCKFAnchor / cleanStereoObsAtMargTime / margSwPose
+                                                   SwMargUpdate.cpp:216-365, 475-497, 367-413, 425-446, 415-423
+    KeyframeUpdate::getMargKfs / updateStateStereo / changeMSCKFAnchor / cleanStereoObsAtMargTime / margSwPose
+                                                   KeyframeUpdate.cpp:43-129, 587-735, 280-328, 737-760, 119-129
+
+The numerical kernels behind it are the oracle's (oracle/ingvio_oracle.c): orc_imu_transition, orc_propagate_cov,
+orc_augment_clone, orc_triangulate, orc_msckf_update (per-feature Jacobian, nullspace, chi^2 gate, stacking, compression, EKF
+update), orc_marginalize, the retractions.  Scope: stereo, MSCKF features only (max_landmark_features = 0, enable_gnss = 0 — the
+shipped configurations of the visual part).  Every processed camera frame yields a trace record (see `Trace`)."""
+import math
+
+import numpy as np
+from scipy.stats import chi2 as _chi2
+
+from . import oracle as orc
+
+INF = float("inf")
+
+
+def to_sec(ns):
+    """ros::Time::toSec() of a stamp given in nanoseconds: sec + 1e-9 * nsec, in this order (bit-exact with the C++ side)."""
+    ns = int(ns)
+    return float(ns // 1000000000) + 1e-9 * float(ns % 1000000000)
+
+
+def parse_params(text):
+    """The "key: value" lines of an INGVIOR1 PARAMS record -> dict of strings."""
+    out = {}
+    for line in text.splitlines():
+        if not line or line[0] in "#%" or ":" not in line:
+            continue
+        k, v = line.split(":", 1)
+        out[k.strip()] = v.strip()
+    return out
+
+
+def _iso(v):
+    a = np.array([float(x) for x in v.split()]).reshape(3, 4)
+    return a[:, :3].copy(), a[:, 3].copy()
+
+
+def quat_from_two_vectors(a, b):
+    """Eigen::Quaterniond::FromTwoVectors(a, b) (w, x, y, z), the generic branch (the vectors of the gravity initialisation are
+    never opposite)."""
+    v0 = a / np.linalg.norm(a)
+    v1 = b / np.linalg.norm(b)
+    c = float(v1 @ v0)
+    assert c > -1.0 + 1e-12
+    axis = np.cross(v0, v1)
+    s = math.sqrt((1.0 + c) * 2.0)
+    invs = 1.0 / s
+    return np.array([s * 0.5, axis[0] * invs, axis[1] * invs, axis[2] * invs])
+
+
+def quat_to_rot(q):
+    """Eigen::Quaterniond::toRotationMatrix() of the normalised quaternion (setValueLinearByQuat, PoseState.cpp:225-229)."""
+    q = q / np.linalg.norm(q)
+    w, x, y, z = q
+    tx, ty, tz = 2 * x, 2 * y, 2 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    return np.array([[1 - (tyy + tzz), txy - twz, txz + twy],
+                     [txy + twz, 1 - (txx + tzz), tyz - twx],
+                     [txz - twy, tyz + twx, 1 - (txx + tyy)]])
+
+
+class Var:
+    """One error-state variable (Type: idx, size) with its nominal value."""
+
+    def __init__(self, kind, size):
+        self.kind = kind            # 'se23' | 'vec3' | 'se3'
+        self.size = size
+        self.idx = -1
+        self.R = np.eye(3)
+        self.p = np.zeros(3)        # SE23: trans1 (position); SE3: translation; Vec3: the value
+        self.v = np.zeros(3)        # SE23: trans2 (velocity)
+
+    def update(self, dx):
+        i = self.idx
+        if self.kind == "se23":                                          # PoseState.cpp:174-186
+            self.R, self.p, self.v = orc.se23_update(self.R, self.p, self.v, dx[i:i + 9])
+        elif self.kind == "se3":                                         # PoseState.cpp:79-88
+            self.R, self.p = orc.se3_update(self.R, self.p, dx[i:i + 6])
+        else:                                                            # VecState.cpp:25-29
+            self.p = self.p + dx[i:i + 3]
+
+
+class Feature:
+    """FeatureInfo (MapServer.h:69-134), MSCKF type only."""
+
+    def __init__(self):
+        self.id = -1
+        self.is_to_marg = False
+        self.is_tri = False
+        self.num_tri = 0
+        self.anchor = None          # the clone Var (AnchoredLandmark::_anchored_pose)
+        self.pf = np.zeros(3)       # AnchoredLandmark::valuePosXyz (world)
+        self.obs = {}               # stamp -> (u0, v0, u1, v1)
+
+
+class Filter:
+    def __init__(self, params_text, overrides=""):
+        p = parse_params(params_text)
+        p.update(parse_params(overrides))
+        g = lambda k, d: float(p.get(k, d))
+        gi = lambda k, d: int(float(p.get(k, d)))
+        assert gi("cam_nums", 2) == 2 and gi("enable_gnss", 1) == 0 and gi("max_landmark_features", 0) == 0, "scope: stereo, visual only"
+        self.max_sw = gi("max_sliding_window_poses", 27)
+        self.is_key_frame = gi("is_key_frame", 1)
+        self.sigma = [g("noise_gyro", 0.004), g("noise_accel", 0.08), g("noise_bias_gyro", 0.0002), g("noise_bias_accel", 0.008)]
+        self.init_cov = dict(rot=g("init_cov_rot", 0.0), pos=g("init_cov_pos", 0.0), vel=g("init_cov_vel", 0.25), bg=g("init_cov_bg", 0.01),
+                             ba=g("init_cov_ba", 0.01), ext_rot=g("init_cov_ext_rot", 1.8e-2), ext_pos=g("init_cov_ext_pos", 2e-3))
+        self.init_gravity = g("gravity_norm", 9.8)
+        self.max_imu_buffer = gi("max_imu_buffer_size", 3000)
+        self.init_imu_sp = gi("init_imu_buffer_sp", 300)
+        self.tri = dict(trans_thres=g("trans_thres", 0.25), huber_epsilon=g("huber_epsilon", 0.01), conv_precision=g("conv_precision", 5e-7),
+                        init_damping=g("init_damping", 1e-3), outer_loop_max_iter=gi("outer_loop_max_iter", 10),
+                        inner_loop_max_iter=gi("inner_loop_max_iter", 10), max_depth=g("max_depth", 40.0), min_depth=g("min_depth", 0.2))
+        self.chi2_max_dof = gi("chi2_max_dof", 150)
+        self.chi2_thres = g("chi2_thres", 0.95)
+        self.noise = g("visual_noise", 0.18)
+        self.frame_select_interval = gi("frame_select_interval", 18)
+        # the two quirks the shim exposes as parameters; defaults = the reference as written
+        self.max_valid_ids = gi("hip_max_valid_ids", 20)                 # RemoveLostUpdate.h:38
+        self.compress_rule = gi("hip_compress_rule", 0)                  # RemoveLostUpdate.cpp:390 keeps row_cnt rows
+        R_cl2i, t_cl2i = _iso(p["T_cl2i"])
+        R_cr2i, t_cr2i = _iso(p["T_cr2i"])
+        # State.cpp:33: _T_cl2cr = T_cr2i^-1 * T_cl2i
+        self.R_cl2cr = R_cr2i.T @ R_cl2i
+        self.t_cl2cr = R_cr2i.T @ (t_cl2i - t_cr2i)
+        # State::State (State.cpp:61-92): SE23 | bg | ba | extrinsics, cov = 1e-6 I
+        self.ext_pose = Var("se23", 9)
+        self.bg = Var("vec3", 3)
+        self.ba = Var("vec3", 3)
+        self.extr = Var("se3", 6)
+        self.extr.R, self.extr.p = R_cl2i.copy(), t_cl2i.copy()
+        self.T_cl2i = (R_cl2i, t_cl2i)
+        self.err_vars = [self.ext_pose, self.bg, self.ba, self.extr]
+        idx = 0
+        for v in self.err_vars:
+            v.idx = idx
+            idx += v.size
+        self.cov = orc.Cov(1e-3 ** 2 * np.eye(idx), ld=((idx + 6 * (self.max_sw + 3) + 15) // 16) * 16)
+        self.timestamp = -1.0
+        self.sw = {}                 # stamp -> clone Var
+        self.map = {}                # id -> Feature
+        # ImuPropagator (ImuPropagator.h:98-110)
+        self.imu_buf = []            # (stamp, accel, gyro)
+        self.has_gravity = self.init_imu_sp < 0
+        self.gravity = np.array([0.0, 0.0, -self.init_gravity])
+        self.quat_init = np.array([1.0, 0.0, 0.0, 0.0])
+        self.has_image_come = False
+        self.has_init_state = False
+        self.select_cnt = 0          # KeyframeUpdate::_select_cnt (static)
+        self.kf_timestamp = -1.0     # KeyframeUpdate::_timestamp
+        self.kfs = []
+        self.chi2_table = {}
+        self.frames = 0
+
+    # ---- helpers --------------------------------------------------------------------------------------------------------
+    def chi2(self, dof):
+        if dof not in self.chi2_table:
+            self.chi2_table[dof] = float(_chi2.ppf(self.chi2_thres, dof))
+        return self.chi2_table[dof]
+
+    def sw_sorted(self):
+        return sorted(self.sw.items())
+
+    def next_marg_time(self):                                            # State.h:82-91
+        if len(self.sw) > self.max_sw:
+            return min(self.sw)
+        return INF
+
+    def box_plus(self, dx):                                              # StateManager.cpp:245-251
+        for v in self.err_vars:
+            v.update(dx)
+
+    def marginalize(self, var):                                          # StateManager.cpp:155-192
+        assert var in self.err_vars
+        self.cov.marginalize(var.idx, var.size)
+        rest = []
+        for v in self.err_vars:
+            if v is not var:
+                if v.idx > var.idx:
+                    v.idx -= var.size
+                rest.append(v)
+        var.idx = -1
+        self.err_vars = rest
+
+    def marg_sw_pose(self, t):                                           # StateManager.cpp:318-328
+        self.marginalize(self.sw[t])
+        del self.sw[t]
+
+    # ---- IMU ------------------------------------------------------------------------------------------------------------
+    def callback_imu(self, stamp, gyro, accel):                          # IngvioFilter.cpp:381-407
+        if not self.has_image_come:
+            return
+        self.store_imu(stamp, np.asarray(gyro, dtype=float), np.asarray(accel, dtype=float))
+        if self.has_gravity and not self.has_init_state:
+            # State::initStateAndCov(stamp, quat) (State.cpp:126-160): zero position / velocity / biases
+            self.timestamp = stamp
+            ic = self.init_cov
+            d = np.concatenate([[ic["rot"] ** 2] * 3, [ic["pos"] ** 2] * 3, [ic["vel"] ** 2] * 3, [ic["bg"] ** 2] * 3, [ic["ba"] ** 2] * 3,
+                                [ic["ext_rot"] ** 2] * 3, [ic["ext_pos"] ** 2] * 3])
+            for i in range(21):
+                self.cov.buf[i, i] = d[i]
+            self.ext_pose.R = quat_to_rot(self.quat_init)
+            self.ext_pose.p = np.zeros(3)
+            self.ext_pose.v = np.zeros(3)
+            self.bg.p = np.zeros(3)
+            self.ba.p = np.zeros(3)
+            self.extr.R, self.extr.p = self.T_cl2i[0].copy(), self.T_cl2i[1].copy()
+            self.has_init_state = True
+
+    def store_imu(self, stamp, gyro, accel):                             # ImuPropagator.cpp:27-68
+        if len(self.imu_buf) > self.max_imu_buffer:
+            return
+        self.imu_buf.append((stamp, accel, gyro))
+        if not self.has_gravity and self.init_imu_sp > 0:
+            if len(self.imu_buf) < self.init_imu_sp:
+                return
+            s = np.zeros(3)
+            for _, a, _ in self.imu_buf:
+                s = s + a
+            s = s / len(self.imu_buf)
+            n = float(np.linalg.norm(s))
+            if abs(n - self.init_gravity) / self.init_gravity > 0.02:
+                self.imu_buf = []
+                self.has_gravity = False
+            else:
+                self.gravity = np.array([0.0, 0.0, -n])
+                self.quat_init = quat_from_two_vectors(-s, self.gravity)
+                self.has_gravity = True
+
+    def transition(self, ctrl, dt):                                      # ImuPropagator.cpp:98-162 + StateManager.cpp:42-119
+        _, accel, gyro = ctrl
+        e = self.ext_pose
+        self.timestamp += dt
+        e.R, e.p, e.v, Phi, G = orc.imu_transition(e.R, e.p, e.v, self.bg.p, self.ba.p, gyro, accel, self.gravity, dt)
+        self.cov.propagate(Phi, G, dt, self.sigma)
+
+    def propagate_until(self, t_end):                                    # ImuPropagator.cpp:232-292
+        if not self.has_gravity or t_end <= self.timestamp:
+            return
+        if not self.imu_buf:
+            return
+        if self.imu_buf[0][0] > t_end:
+            return
+        propa_cnt = 0
+        last = self.imu_buf[-1]
+        for ctrl in self.imu_buf:
+            t = ctrl[0]
+            if t < self.timestamp:
+                propa_cnt += 1
+                continue
+            if t > t_end:
+                break
+            propa_cnt += 1
+            dt = t - self.timestamp
+            if dt < 1e-6:
+                continue
+            last = ctrl
+            self.transition(ctrl, dt)
+        if self.timestamp < t_end:
+            dt_last = t_end - self.timestamp
+            if dt_last > 1e-6:
+                self.transition(last, dt_last)
+            else:
+                self.timestamp = t_end
+        del self.imu_buf[:propa_cnt]
+
+    def augment(self):                                                   # StateManager.cpp:253-296
+        if self.timestamp in self.sw:
+            return
+        c = Var("se3", 6)
+        e = self.ext_pose
+        c.R = e.R @ self.extr.R
+        c.p = e.R @ self.extr.p + e.p
+        c.idx = self.cov.n
+        self.sw[self.timestamp] = c
+        self.err_vars.append(c)
+        self.cov.augment(e.R)
+
+    def propagate_augment_at_end(self, t_end):                           # ImuPropagator.cpp:294-314
+        if not self.has_gravity:
+            return
+        self.propagate_until(t_end)
+        if self.timestamp < t_end or self.timestamp > t_end:
+            return
+        self.augment()
+
+    # ---- map server -----------------------------------------------------------------------------------------------------
+    def collect_stereo(self, feats):                                     # MapServerManager.cpp:146-185, 203-217
+        ts = self.timestamp
+        assert ts in self.sw
+        for fid, u0, v0, u1, v1 in feats:
+            fid = int(fid)
+            fi = self.map.get(fid)
+            if fi is None:
+                fi = Feature()
+                self.map[fid] = fi
+            if not fi.obs:
+                fi.obs[ts] = (u0, v0, u1, v1)
+                fi.id = fid
+                fi.is_to_marg = False
+                fi.is_tri = False
+                fi.anchor = self.sw[ts]
+            else:
+                if ts in fi.obs:
+                    continue
+                fi.obs[ts] = (u0, v0, u1, v1)
+                fi.is_to_marg = False
+
+    def triangulate(self, fi):                                           # MapServerManager.cpp:309-341 over Triangulator.cpp:320-359
+        sw = self.sw_sorted()
+        C = len(sw)
+        cR = np.stack([c.R for _, c in sw])
+        cp = np.stack([c.p for _, c in sw])
+        uv = np.zeros((C, 4))
+        mask = 0
+        for s, (t, _) in enumerate(sw):                                  # filterCommonTimestamp: obs stamps that are window stamps
+            if t in fi.obs:
+                uv[s] = fi.obs[t]
+                mask |= 1 << s
+        if mask == 0:
+            return False
+        ok, pf = orc.triangulate(cR, cp, mask, uv, True, self.R_cl2cr, self.t_cl2cr, **self.tri)
+        if not ok or np.any(np.isnan(pf)):
+            return False
+        fi.num_tri += 1
+        body = fi.anchor.R.T @ (pf - fi.anchor.p)
+        if body[2] <= 0:
+            return False
+        fi.pf = pf.copy()
+        fi.is_tri = True
+        return True
+
+    def flat_frame(self, ids, sel, dof_of):
+        """The window + the listed features as the oracle's flattened frame.  sel: None = every observation (RemoveLost), else the
+        selected stamps; dof_of(fi) = the dof handed to testChiSquared."""
+        sw = self.sw_sorted()
+        C = len(sw)
+        slot_of = {id(c): s for s, (_, c) in enumerate(sw)}
+        F = len(ids)
+        fr = dict(clone_idx=[c.idx for _, c in sw], clone_R=np.stack([c.R for _, c in sw]), clone_p=np.stack([c.p for _, c in sw]),
+                  pf=np.zeros((F, 3)), anchor=np.zeros(F, dtype=np.int32), obs_mask=np.zeros(F, dtype=np.uint64), uv=np.zeros((F, C, 4)),
+                  dof=np.zeros(F, dtype=np.int32), stereo=1, R_cl2cr=self.R_cl2cr, t_cl2cr=self.t_cl2cr, noise=self.noise)
+        max_dof = 1
+        for j, fid in enumerate(ids):
+            fi = self.map[fid]
+            fr["pf"][j] = fi.pf
+            fr["anchor"][j] = slot_of[id(fi.anchor)]
+            m = 0
+            for s, (t, _) in enumerate(sw):
+                if t in fi.obs and (sel is None or t in sel):
+                    fr["uv"][j, s] = fi.obs[t]
+                    m |= 1 << s
+            fr["obs_mask"][j] = m
+            fr["dof"][j] = dof_of(fi)
+            max_dof = max(max_dof, int(fr["dof"][j]))
+        fr["chi2_table"] = np.array([0.0] + [self.chi2(d) for d in range(1, max_dof + 1)])
+        return fr
+
+    # ---- the three updates ----------------------------------------------------------------------------------------------
+    def remove_lost_update(self, tr):                                    # RemoveLostUpdate.cpp:276-405
+        ts = self.timestamp
+        for fi in self.map.values():                                     # markMargStereoFeatures, MapServerManager.cpp:245-273
+            if ts not in fi.obs:
+                fi.is_to_marg = True
+        update_ids, direct = [], []
+        for fid in sorted(self.map):
+            fi = self.map[fid]
+            if fi.is_to_marg:
+                if self.triangulate(fi) and len(fi.obs) >= 3:
+                    update_ids.append(fid)
+                else:
+                    direct.append(fid)
+        for fid in direct:
+            del self.map[fid]
+        tr["lost_ids"] = list(update_ids)
+        tr["lost_direct"] = list(direct)
+        tr["lost_acc"] = []
+        tr["lost_rows"] = 0
+        if not update_ids:
+            return
+        fr = self.flat_frame(update_ids, None, lambda fi: len(fi.obs) - 1)                    # :332-333
+        dx, acc, gam, m = self.cov.msckf_update(fr, max_accept=self.max_valid_ids, compress_rule=self.compress_rule, selected_variant=0)
+        tr["lost_acc"] = [int(a) for a in acc]
+        tr["lost_rows"] = int(m)
+        if m > 0:                                                        # :399-400
+            self.box_plus(dx)
+        for fid in update_ids:                                           # :402-403
+            del self.map[fid]
+
+    def selected_update(self, sel, dof, tr):                             # SwMargUpdate.cpp:216-365 / KeyframeUpdate.cpp:587-735
+        tr["sel_stamps"] = list(sel)
+        tr["sel_ids"] = []
+        tr["sel_acc"] = []
+        tr["sel_rows"] = 0
+        for t in sel:
+            assert t in self.sw, "selected timestamp not in sw"
+        update_ids = []
+        for fid in sorted(self.map):
+            fi = self.map[fid]
+            if any(t not in fi.obs for t in sel):
+                continue
+            if self.triangulate(fi):
+                update_ids.append(fid)
+        tr["sel_ids"] = list(update_ids)
+        if not update_ids:
+            return
+        selset = set(sel)
+        fr = self.flat_frame(update_ids, selset, lambda fi: dof)
+        dx, acc, gam, m = self.cov.msckf_update(fr, max_accept=0, compress_rule=1, selected_variant=1)
+        tr["sel_acc"] = [int(a) for a in acc]
+        tr["sel_rows"] = int(m)
+        if m > 0:
+            self.box_plus(dx)
+
+    def select_sw_timestamps(self, marg_time):                           # SwMargUpdate.cpp:475-497
+        if marg_time == INF or marg_time not in self.sw:
+            return []
+        out = [marg_time]
+        cnt = 1
+        for t, _ in self.sw_sorted():
+            if t <= marg_time:
+                continue
+            if cnt % self.frame_select_interval == 0:
+                out.append(t)
+            cnt += 1
+        return out
+
+    def get_marg_kfs(self):                                              # KeyframeUpdate.cpp:43-117
+        if len(self.sw) < self.max_sw or self.max_sw < 3:
+            return []
+        if self.timestamp == self.kf_timestamp and self.kfs:
+            return list(self.kfs)
+        assert len(self.sw) <= self.max_sw, "Current sw poses larger than max size!"
+        self.kf_timestamp = self.timestamp
+        rem = self.max_sw - 2
+        idx1 = 2 + self.select_cnt
+        self.select_cnt = (self.select_cnt + 1) % rem
+        desc = sorted(self.sw, reverse=True)                             # rbegin() order
+        self.kfs = [desc[idx1], desc[1]]
+        return list(self.kfs)
+
+    def clean_obs(self, stamps, tr):                                     # SwMargUpdate.cpp:425-446 / KeyframeUpdate.cpp:737-760
+        gone = []
+        for fid in sorted(self.map):
+            fi = self.map[fid]
+            for t in stamps:
+                fi.obs.pop(t, None)
+                if not fi.obs and fid not in gone:
+                    gone.append(fid)
+        for fid in gone:
+            del self.map[fid]
+        tr["clean_erased"] = gone
+
+    def change_anchor(self, old_stamps, min_depth, tr):                  # SwMargUpdate.cpp:367-413 / KeyframeUpdate.cpp:280-328
+        old = [self.sw[t] for t in old_stamps]
+        new_anchor = self.sw[max(self.sw)]
+        gone, moved = [], []
+        for fid in sorted(self.map):
+            fi = self.map[fid]
+            if any(fi.anchor is o for o in old):
+                if fi.is_tri:
+                    body = new_anchor.R.T @ (fi.pf - new_anchor.p)
+                    if body[2] <= min_depth:
+                        gone.append(fid)
+                        continue
+                    fi.anchor = new_anchor                               # resetAnchoredPose(new_anchor, true): the world value stays
+                    moved.append(fid)
+                else:
+                    gone.append(fid)
+        for fid in gone:
+            del self.map[fid]
+        tr["anchor_erased"] = gone
+        tr["anchor_moved"] = moved
+
+    def erase_invalid(self, tr):                                         # MapServerManager.cpp:456-491
+        gone = []
+        for fid in sorted(self.map):
+            fi = self.map[fid]
+            if not fi.is_tri:
+                continue
+            if fi.anchor is None:
+                gone.append(fid)
+                continue
+            body = fi.anchor.R.T @ (fi.pf - fi.anchor.p)
+            if body[2] <= 0.2:
+                gone.append(fid)
+        for fid in gone:
+            del self.map[fid]
+        tr["invalid_erased"] = gone
+
+    # ---- the camera callback ----------------------------------------------------------------------------------------------
+    def callback_stereo(self, stamp, feats):                             # IngvioFilter.cpp:252-379
+        """feats: iterable of (id, u0, v0, u1, v1).  Returns the frame's trace dict, or None when the callback returned early."""
+        if not self.has_image_come:
+            self.has_image_come = True
+            return None
+        if not self.has_init_state:
+            return None
+        if self.timestamp >= stamp:
+            return None
+        self.propagate_augment_at_end(stamp)
+        if self.timestamp < stamp:
+            return None
+        tr = dict(stamp=stamp)
+        self.collect_stereo(feats)
+        self.remove_lost_update(tr)
+        tr["marg_stamps"] = []
+        tr["clean_erased"] = []
+        tr["anchor_erased"] = []
+        tr["anchor_moved"] = []
+        if self.is_key_frame:
+            sel = self.get_marg_kfs()
+            if sel:
+                self.selected_update(sel, 2, tr)                         # KeyframeUpdate.cpp:675-676: dof 2
+            else:
+                tr.update(sel_stamps=[], sel_ids=[], sel_acc=[], sel_rows=0)
+            kfs = self.get_marg_kfs()
+            self.clean_obs(kfs, tr)                                      # cleanStereoObsAtMargTime
+            kfs = self.get_marg_kfs()
+            if kfs:
+                self.change_anchor(kfs, 0.3, tr)                         # changeMSCKFAnchor, body.z() <= 0.3
+            kfs = self.get_marg_kfs()
+            for t in kfs:                                                # margSwPose
+                self.marg_sw_pose(t)
+            tr["marg_stamps"] = list(kfs)
+        else:
+            marg_time = self.next_marg_time()
+            if marg_time != INF:
+                sel = self.select_sw_timestamps(marg_time)
+                self.selected_update(sel, len(sel) - 1, tr)              # SwMargUpdate.cpp:306-307
+            else:
+                tr.update(sel_stamps=[], sel_ids=[], sel_acc=[], sel_rows=0)
+            marg_time = self.next_marg_time()
+            if marg_time != INF:
+                self.clean_obs([marg_time], tr)
+            marg_time = self.next_marg_time()
+            if marg_time != INF and marg_time in self.sw:
+                self.change_anchor([marg_time], 0.0, tr)                 # body.z() <= 0
+            marg_time = self.next_marg_time()
+            if marg_time != INF:
+                self.marg_sw_pose(marg_time)
+                tr["marg_stamps"] = [marg_time]
+        self.erase_invalid(tr)
+        self.frames += 1
+        # the state after the frame
+        tr["table"] = [(v.idx, v.size) for v in self.err_vars]
+        tr["sw_stamps"] = sorted(self.sw)
+        tr["map_ids"] = sorted(self.map)
+        e = self.ext_pose
+        tr["pose"] = np.concatenate([e.R.reshape(-1), e.p, e.v, self.bg.p, self.ba.p, self.extr.R.reshape(-1), self.extr.p])
+        P = self.cov.P
+        tr["n"] = int(P.shape[0])
+        tr["diag"] = np.diag(P).copy()
+        tr["norm"] = float(np.linalg.norm(P))
+        tr["P"] = P
+        return tr
+
+
+LIST_KEYS_INT = ["lost_ids", "lost_direct", "lost_acc", "sel_ids", "sel_acc", "clean_erased", "anchor_erased", "anchor_moved",
+                 "invalid_erased", "map_ids"]
+LIST_KEYS_F64 = ["sel_stamps", "marg_stamps", "sw_stamps", "diag"]
+SCALAR_KEYS = ["stamp", "lost_rows", "sel_rows", "n", "norm"]
+
+
+def pack_traces(traces):
+    """list of trace dicts -> dict of flat numpy arrays (ragged lists as values + offsets) for np.savez."""
+    out = {}
+    for k in LIST_KEYS_INT + LIST_KEYS_F64:
+        dt = np.int64 if k in LIST_KEYS_INT else np.float64
+        vals = [np.asarray(t[k], dtype=dt).reshape(-1) for t in traces]
+        out[k] = np.concatenate(vals) if vals else np.zeros(0, dtype=dt)
+        out[k + "_off"] = np.concatenate([[0], np.cumsum([len(v) for v in vals])]).astype(np.int64)
+    tab = [np.asarray(t["table"], dtype=np.int64).reshape(-1) for t in traces]
+    out["table"] = np.concatenate(tab)
+    out["table_off"] = np.concatenate([[0], np.cumsum([len(v) for v in tab])]).astype(np.int64)
+    for k in SCALAR_KEYS:
+        out[k] = np.array([t[k] for t in traces], dtype=np.float64)
+    out["pose"] = np.stack([t["pose"] for t in traces])
+    return out
+
+
+def unpack_traces(z):
+    """inverse of pack_traces (without the full covariance)."""
+    nf = len(z["stamp"])
+    out = []
+    for f in range(nf):
+        t = {}
+        for k in LIST_KEYS_INT + LIST_KEYS_F64:
+            o = z[k + "_off"]
+            t[k] = z[k][o[f]:o[f + 1]]
+        o = z["table_off"]
+        t["table"] = z["table"][o[f]:o[f + 1]].reshape(-1, 2)
+        for k in SCALAR_KEYS:
+            t[k] = float(z[k][f])
+        t["pose"] = z["pose"][f]
+        out.append(t)
+    return out
+
+
+def play_recording(path, overrides="", max_frames=None):
+    """Plays an INGVIOR1 recording (IMU + STEREO_FRAME records) into a Filter; returns the list of trace dicts."""
+    import struct
+    flt = None
+    traces = []
+    with open(path, "rb") as f:
+        assert f.read(8) == b"INGVIOR1"
+        while True:
+            h = f.read(13)
+            if not h:
+                break
+            typ, ns, n = struct.unpack("<BQI", h)
+            payload = f.read(n)
+            if typ == 0:
+                flt = Filter(payload.decode("ascii"), overrides)
+            elif typ == 1:
+                v = struct.unpack("<6d", payload)
+                flt.callback_imu(to_sec(ns), v[0:3], v[3:6])
+            elif typ == 3:
+                cnt = struct.unpack_from("<I", payload)[0]
+                feats = [struct.unpack_from("<Q4d", payload, 4 + 40 * i) for i in range(cnt)]
+                tr = flt.callback_stereo(to_sec(ns), feats)
+                if tr is not None:
+                    traces.append(tr)
+                    if max_frames and len(traces) >= max_frames:
+                        break
+    return traces

@@ -585,6 +585,69 @@ static void testTriangulator()
     ASSERT_TRUE(!tri.triangulateMonoObs(state, mobs, poses, r));
 }
 
+// TestMapServer.cpp:184-308 (collectFeatureAndMarg): two frames with overlapping id sets through collect{Mono,Stereo}Meas, then
+// markMarg*Features: sizes, ids, types, observation counts, who is flagged, and the anchors (the clone of the frame a feature was
+// first seen in).  The reference's MapServerManager statics are IngvioFilter::collect*Meas + markMargFeatures here.
+static void testCollectFeatureAndMarg()
+{
+    struct Peek : public IngvioFilter { using IngvioFilter::collectStereoMeas; using IngvioFilter::collectMonoMeas; };
+    for (int stereo = 0; stereo <= 1; ++stereo) {
+        IngvioParams fp = params();
+        fp._enable_gnss = 0; fp._init_imu_buffer_sp = -1;
+        IngvioFilter filter(fp);
+        auto state = filter.state();
+        auto map_server = filter.mapServer();
+        auto imu_propa = filter.imuPropagator();
+        state->initStateAndCov(0.0, Quatd{ 1, 0, 0, 0 });
+        const Mat3d R = rrand();
+        const Vec3d p = vrand();
+        auto frame = [&](double t, int first_id) {
+            if (stereo) {
+                StereoFrameMsg f; f.stamp = t;
+                for (int i = 0; i < 4; ++i) { StereoObsMsg o; o.id = first_id + i; o.u0 = urand(); o.v0 = urand(); o.u1 = urand(); o.v1 = urand(); f.stereo_meas.push_back(o); }
+                (static_cast<IngvioFilter*>(&filter)->*(&Peek::collectStereoMeas))(f);
+            } else {
+                MonoFrameMsg f; f.stamp = t;
+                for (int i = 0; i < 4; ++i) { MonoObsMsg o; o.id = first_id + i; o.u0 = urand(); o.v0 = urand(); f.mono_meas.push_back(o); }
+                (static_cast<IngvioFilter*>(&filter)->*(&Peek::collectMonoMeas))(f);
+            }
+        };
+        auto frames_of = [&](int id) { return stereo ? map_server->at(id)->numOfStereoFrames() : map_server->at(id)->numOfMonoFrames(); };
+        auto has_at = [&](int id, double t) { return stereo ? map_server->at(id)->hasStereoObsAt(t) : map_server->at(id)->hasMonoObsAt(t); };
+        imu_propa->propagateToExpectedPoseAndAugment(state, 2.0, R, p);
+        frame(2.0, 1);                                                                   // ids 1..4
+        ASSERT_EQ((int)map_server->size(), 4);
+        for (int i = 1; i < 5; ++i) {
+            ASSERT_EQ(map_server->at(i)->getId(), i);
+            ASSERT_EQ(map_server->at(i)->getFeatureType(), FeatureInfo::MSCKF);
+            ASSERT_EQ(frames_of(i), 1);
+            ASSERT_TRUE(has_at(i, 2.0));
+        }
+        imu_propa->propagateToExpectedPoseAndAugment(state, 4.0, R, p);
+        frame(4.0, 2);                                                                   // ids 2..5
+        ASSERT_EQ((int)map_server->size(), 5);
+        for (int i = 1; i < 6; ++i) {
+            ASSERT_EQ(map_server->at(i)->getId(), i);
+            ASSERT_EQ(map_server->at(i)->getFeatureType(), FeatureInfo::MSCKF);
+            ASSERT_EQ(frames_of(i), (i == 1 || i == 5) ? 1 : 2);
+            if (i > 1) ASSERT_TRUE(has_at(i, 4.0));
+            ASSERT_TRUE(!map_server->at(i)->isToMarg());
+        }
+        markMargFeatures(map_server, state, stereo != 0);
+        ASSERT_EQ((int)map_server->size(), 5);
+        for (int i = 1; i < 6; ++i) ASSERT_TRUE(map_server->at(i)->isToMarg() == (i == 1));
+        for (int i = 1; i < 6; ++i) ASSERT_TRUE(map_server->at(i)->anchor() == state->_sw_camleft_poses.at(i < 5 ? 2.0 : 4.0));
+        // a second message at the same stamp is skipped (MapServerManager.cpp:171-175), a re-observed feature is un-flagged (:184)
+        frame(4.0, 2);
+        for (int i = 2; i < 6; ++i) ASSERT_EQ(frames_of(i), i == 5 ? 1 : 2);
+        imu_propa->propagateToExpectedPoseAndAugment(state, 6.0, R, p);
+        frame(6.0, 1);                                                                   // id 1 comes back
+        ASSERT_TRUE(!map_server->at(1)->isToMarg());
+        ASSERT_EQ(frames_of(1), 2);
+        ASSERT_TRUE(map_server->at(1)->anchor() == state->_sw_camleft_poses.at(2.0));  // the anchor stays the first clone
+    }
+}
+
 static void testFilterEndToEnd()
 {
     // {key-frame mode, window}: the two update policies at the 11-clone window of BASELINE config 2, then the window of
@@ -761,8 +824,10 @@ static void testFilterGnssEndToEnd()
             for (int s4 = 0; s4 < 4; ++s4) spp.posSpp[3 + s4] = cb0[s4] == 0.0 ? 0.0 : cb0[s4] + fs_true * t + 3.0 * gn(rng);
             for (int c = 0; c < 3; ++c) spp.velSpp[c] = vel[c];
             spp.velSpp[3] = fs_true + 0.2 * gn(rng);
-            filter.callbackGnssMeas(gm);
-            filter.callbackSppMeas(spp);
+            // frame 0 only raises _hasImageCome (IngvioFilter.cpp:257-261): its epoch is not buffered, so that every processed frame finds
+            // the epoch of its OWN time at the head of the queue - within the reference's 0.13 s matching window (GnssSync.h:61) an older
+            // epoch left in the buffer would be matched first (GnssSync.cpp:143-160) and every frame would fuse a 50 ms old epoch
+            if (f >= 1) { filter.callbackGnssMeas(gm); filter.callbackSppMeas(spp); }
             // the stereo frame
             const Mat3d Rc = Truth::R(t) * fp._T_cl2i.R;
             const Vec3d pc = Truth::p(t) + Truth::R(t) * fp._T_cl2i.t;
@@ -925,7 +990,7 @@ int main()
         { "StateUpdateTest.augmentPose", testAugmentPose }, { "StateUpdateTest.stateBoxPlus", testStateBoxPlus },
         { "StateUpdateTest.stateCovUpdate", testStateCovUpdate }, { "AddDelayedTest.addVarInv", testAddVarInv }, { "AddDelayedTest.addVar", testAddVar }, { "FeatureInfoManager.changeAnchoredPose", testChangeAnchoredPose },
         { "TestPropagator.initGravity", testInitGravity }, { "TestPropagator.oneStepProp", testOneStepProp }, { "TestPropagator.propaUntil+propagateAugment", testPropagator },
-        { "GnssUpdate.updateTrackedSys", testGnssUpdate }, { "TestTriangulator.mono+stereo", testTriangulator }, { "IngvioFilter.callbacks end-to-end", testFilterEndToEnd },
+        { "GnssUpdate.updateTrackedSys", testGnssUpdate }, { "TestTriangulator.mono+stereo", testTriangulator }, { "TestMapServer.collectFeatureAndMarg", testCollectFeatureAndMarg }, { "IngvioFilter.callbacks end-to-end", testFilterEndToEnd },
         { "IngvioFilter.callbacks with GNSS epochs (config 3)", testFilterGnssEndToEnd },
     };
     for (auto& t : tests) {

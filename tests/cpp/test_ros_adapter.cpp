@@ -136,6 +136,21 @@ int main()
         CHECK(fixed.isSync() && fixed.getUnsyncTime() == -18.0);
         IngvioParams fq2;
         CHECK(!GnssSync(fq2).isSync());
+        IngvioParams fq3; fq3._enable_gnss = 0; fq3._use_fix_time_offset = 1;
+        CHECK(!GnssSync(fq3).isSync());                   // GnssSync.h:64-65: returns before the fixed offset is looked at
+        // the matching window of getGnssMeasAt / getSppAt is the reference's 0.13 s (GnssSync.h:61, GnssSync.cpp:148-156), ADVICE r04:
+        // an epoch 100 ms older than the frame (ordinary receiver latency) is matched, one 131 ms older is dropped, one 130 ms
+        // newer is left for a later frame
+        GnssSync win(fp);
+        GnssMeas a, b, c; a.stamp = 9.869; b.stamp = 9.90; c.stamp = 10.13;
+        win.bufferGnssMeas(a); win.bufferGnssMeas(b); win.bufferGnssMeas(c);
+        CHECK(win.getGnssMeasAt(10.0, out) && out.stamp == 9.90);      // 9.869 < 10 - 0.13: dropped; 9.90 taken
+        CHECK(!win.getGnssMeasAt(10.0, out));                            // 10.13 >= 10 + 0.13: stays in the buffer ...
+        CHECK(win.getGnssMeasAt(10.05, out) && out.stamp == 10.13);     // ... for the next frame
+        SppMeas s1; s1.stamp = 9.95;
+        win.bufferSppMeas(s1);
+        SppMeas so;
+        CHECK(win.getSppAt(10.0, so) && so.stamp == 9.95);
     }
     std::printf("ros adapter: %d failures\n", fails);
     return fails ? 1 : 0;

@@ -324,6 +324,53 @@ def test_config3_in_frame_gnss_vs_oracle(orc, strong_reject, window):
     ctx.close()
 
 
+def test_in_frame_gnss_stage_is_consumed_by_one_frame(orc):
+    """an in-frame GNSS stage belongs to ONE frame.  A non-restoring ingvio_frame_run applies it and consumes it: the
+    results stay fetchable, a second frame run (new frame staged, no new GNSS stage) must NOT apply the old rows again, and a fetch
+    without any update having run on a fresh stage is refused instead of returning the MSCKF slots."""
+    from ingvio_amd import capi, host, synth
+    nb = 2
+    ctx = capi.Context(batch=nb, n_max=256, c_max=11, f_max=150, m_max=64)
+    cases = []
+    for b in range(nb):
+        flt, step, frame, info = synth.build_case(lambda P, b=b: capi.DeviceCov(ctx, b, P), host.imu_transition, seed=350 + b)
+        cases.append((flt, step, frame, info, synth.make_gnss(np.random.default_rng(950 + b), flt)))
+    priors = [ctx.cov_get(b) for b in range(nb)]
+    table = cases[0][2]["chi2_table"]
+    blocks = [host.gnss_rows(c[4]) for c in cases]
+    ctx.frame_stage(0, [c[1] for c in cases], [c[2] for c in cases], cases[0][1]["sigma"], 1, 0.2, 0.2)
+    ctx.gnss_stage(0, blocks, table, gate_rows=True, in_frame=True)
+    with pytest.raises(capi.IngvioError):
+        ctx.gnss_fetch()                                 # staged, nothing has run: there is nothing to fetch
+    ctx.frame_run(restore_prior=False)
+    dxg, used, keep, gam, st = ctx.gnss_fetch()          # this frame's GNSS results, although the stage is consumed
+    assert (used > 0).all() and dxg.any()
+    ocs = []
+    for b in range(nb):
+        flt, step, frame, info, g = cases[b]
+        oc = orc.Cov(priors[b], ld=256)
+        orc.frame_update(oc, step, frame, max_accept=0, compress_rule=1)
+        go = dict(g); go.update(chi2_test=1, chi2_table=table)
+        Ho, ro, Rdo, vio, vso = orc.gnss_rows(oc, go)
+        dxo2, _ = oc.ekf_update(vio, vso, Ho, ro, Rdo)
+        assert rel_err(ctx.cov_get(b), oc.P) < 1e-11 and rel_err(dxg[b, :243], dxo2) < 1e-9
+        ocs.append(oc)
+    with pytest.raises(capi.IngvioError):
+        ctx.gnss_run()                                   # consumed: nothing is staged any more
+    # the next frame on the moved-on state, no GNSS stage: the MSCKF step alone (the oracle applies no GNSS rows either)
+    steps2, frames2 = [], []
+    for b in range(nb):
+        flt, step, frame, info, g = cases[b]
+        steps2.append(step); frames2.append(frame)
+    ctx.frame_stage(0, steps2, frames2, cases[0][1]["sigma"], 1, 0.2, 0.2)
+    ctx.frame_run(restore_prior=False)
+    for b in range(nb):
+        flt, step, frame, info, g = cases[b]
+        orc.frame_update(ocs[b], step, frame, max_accept=0, compress_rule=1)
+        assert ctx.n(b) == ocs[b].n and rel_err(ctx.cov_get(b), ocs[b].P) < 1e-10, (b, rel_err(ctx.cov_get(b), ocs[b].P))
+    ctx.close()
+
+
 def test_gnss_stage_run_is_repeatable(orc):
     """ingvio_gnss_run reads the staged rows only: running it twice from the same restored covariance gives identical bits."""
     from ingvio_amd import capi, host, synth

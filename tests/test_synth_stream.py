@@ -66,7 +66,7 @@ def frame_py(spec, k):
     Rlr, tlr = synth.t_cl2cr()
     ids, uv = [], []
     for slot in range(F):
-        phase = (life + 1 - spec.get("birth_frame", 2)) % life if spec["cohort"] else slot % life
+        phase = (life + 1 - spec.get("birth_frame", 3)) % life if spec["cohort"] else slot % life
         gen = (k - 1 + phase) // life
         birth = 1 - phase + gen * life
         r = sub(seed, birth, 2, slot)
@@ -142,13 +142,15 @@ def test_written_recording_counts(tmp_path):
     subprocess.run([TOOL, "--synth", spec_str(spec), "--write", path], check=True)
     recs = replay.read(path)
     kinds = [r[0] for r in recs]
-    assert kinds.count(replay.PARAMS) == 1 and kinds.count(replay.IMU) == 400 + 120 and kinds.count(replay.STEREO_FRAME) == 12
+    # 12 frames + the header-only frame at t = 0 that raises _hasImageCome before the static phase (IngvioFilter.cpp:257-261, :393)
+    assert kinds.count(replay.PARAMS) == 1 and kinds.count(replay.IMU) == 400 + 120 and kinds.count(replay.STEREO_FRAME) == 13
+    assert recs[1][0] == replay.STEREO_FRAME and recs[1][1] == 0.0 and len(recs[1][2]) == 4
     assert kinds.count(replay.GROUND_TRUTH) == 12
     text = recs[0][2].decode()
     assert "max_sliding_window_poses: 11" in text and "cam_nums: 2" in text
     # every camera frame is preceded by the IMU sample of the same stamp (the filter propagates up to the image time)
     for i, r in enumerate(recs):
-        if r[0] == replay.STEREO_FRAME:
+        if r[0] == replay.STEREO_FRAME and i > 1:
             assert recs[i - 1][0] == replay.IMU and abs(recs[i - 1][1] - r[1]) < 1e-9
 
 
@@ -158,7 +160,7 @@ def test_stream_through_the_callbacks_on_the_device():
     """The cohort stream of bench.py's latency line played into IngvioFilter's callbacks (one filter, key-frame mode, RemoveLost cap
     lifted): the frames on which a cohort is lost carry a RemoveLost update over most of its tracks, the filter follows the circle,
     and the batched triangulation hands the update what the per-feature one would (same accept counts with either)."""
-    spec = "feats=150,clones=11,life=10,cohort=1,birth_frame=2,frames=55,key=1"
+    spec = "feats=150,clones=11,life=10,cohort=1,birth_frame=3,frames=55,key=1"
     sets = ["--set", "hip_max_valid_ids: 0", "--set", "hip_compress_rule: 1"]
     r = subprocess.run([TOOL, "--synth", spec, "--time"] + sets, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -166,7 +168,7 @@ def test_stream_through_the_callbacks_on_the_device():
     lat = dict(x.split("=") for x in [l for l in r.stdout.splitlines() if l.startswith("LATENCY")][0].split()[1:])
     heavy = [(int(f[1]), int(f[3]), int(f[4])) for f in frames if int(f[4]) >= 50]      # (frame, rows, accepted)
     print("heavy frames", heavy, "latency", lat)
-    assert len(heavy) >= 3 and all(k % 10 == 2 for k, _, _ in heavy)                    # cohorts born at 2, 12, ... are lost at 12, 22, ...
+    assert len(heavy) >= 3 and all(k % 10 == 3 for k, _, _ in heavy)                    # cohorts born at 3, 13, ... are lost at 13, 23, ...
     assert all(rows == 6 * 11 for _, rows, _ in heavy)                                  # top-n compression: n = 6 x window clones rows
     assert int(lat["heavy_frames"]) >= 2 and float(lat["heavy_median_ms"]) > float(lat["other_median_ms"]) > 0.0
     assert float(lat["final_pos_err_m"]) < 0.25                                         # ~4 m travelled

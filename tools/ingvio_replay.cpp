@@ -7,9 +7,12 @@
 //   --synth  a synthetic stream (ingvio_amd/csrc/host/SynthStream.h; keys = the fields of SynthConfig) instead of a file:
 //            --write  store it as an INGVIOR1 file (no device needed)
 //            --frame  print the feature message of frame k regenerated from the seed alone: "FEAT id u0 v0 u1 v1" (no device needed)
+//            --trace  play it into a filter and print, for every processed camera frame, what the policy layer decided and the state
+//                     afterwards ("TRACE k stamp" ... "END"): the comparison side of tests/golden/stream_*.npz (tests/test_stream_golden.py)
 //            --time   play it into a filter and print the wall time of every camera callback: "FRAME k ms lost_rows lost_accepted
 //                     select_rows N clones", then "LATENCY ..." (single-filter latency)
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -17,6 +20,7 @@
 #include <string>
 
 #include "../ingvio_amd/csrc/host/Replay.h"
+#include "../ingvio_amd/csrc/host/StateManager.h"
 
 static bool parseSynth(const std::string& spec, ingvio::SynthConfig& c)
 {
@@ -43,6 +47,61 @@ static bool parseSynth(const std::string& spec, ingvio::SynthConfig& c)
     return c.feats > 0 && c.clones >= 3 && c.life >= 1 && c.frames >= 1;
 }
 
+static void printInts(const char* tag, const std::vector<int>& v)
+{
+    std::printf("%s", tag);
+    for (int x : v) std::printf(" %d", x);
+    std::printf("\n");
+}
+static void printDoubles(const char* tag, const std::vector<double>& v)
+{
+    std::printf("%s", tag);
+    for (double x : v) std::printf(" %.17g", x);
+    std::printf("\n");
+}
+
+// One processed frame as the golden streams record it (oracle/stream_filter.py: Filter.callback_stereo's trace dict).
+static void printTrace(int k, ingvio::IngvioFilter& f, bool keyframe)
+{
+    using namespace ingvio;
+    auto state = f.state();
+    std::printf("TRACE %d %.17g\n", k, state->_timestamp);
+    const UpdateRecord& rl = f.removeLostUpdate()->lastRecord();
+    printInts("LOST_IDS", rl.ids); printInts("LOST_ACC", rl.accepted); printInts("LOST_DIRECT", rl.direct);
+    std::printf("LOST_ROWS %d\n", rl.rows);
+    const UpdateRecord& se = keyframe ? f.keyframeUpdate()->lastRecord() : f.swMargUpdate()->lastRecord();
+    const MaintenanceRecord& mt = keyframe ? f.keyframeUpdate()->maintenance() : f.swMargUpdate()->maintenance();
+    printDoubles("SEL_STAMPS", se.stamps); printInts("SEL_IDS", se.ids); printInts("SEL_ACC", se.accepted);
+    std::printf("SEL_ROWS %d\n", se.rows);
+    printDoubles("MARG_STAMPS", mt.marg_stamps); printInts("CLEAN_ERASED", mt.clean_erased); printInts("ANCHOR_ERASED", mt.anchor_erased);
+    printInts("ANCHOR_MOVED", mt.anchor_moved); printInts("INVALID_ERASED", f.lastInvalidErased());
+    std::vector<int> table;
+    for (const auto& v : StateManager::errVariables(state)) { table.push_back(v->idx()); table.push_back(v->size()); }
+    printInts("TABLE", table);
+    std::vector<double> sw;
+    for (const auto& c : state->_sw_camleft_poses) sw.push_back(c.first);
+    printDoubles("SW_STAMPS", sw);
+    std::vector<int> ids;
+    for (const auto& m : *f.mapServer()) ids.push_back(m.first);
+    printInts("MAP_IDS", ids);
+    std::vector<double> pose;
+    const Mat3d R = state->_extended_pose->valueLinearAsMat();
+    pose.insert(pose.end(), R.m, R.m + 9);
+    for (const Vec3d& v : { state->_extended_pose->valueTrans1(), state->_extended_pose->valueTrans2(), state->_bg->value(), state->_ba->value() })
+        pose.insert(pose.end(), v.v, v.v + 3);
+    const Mat3d Re = state->_camleft_imu_extrinsics->valueLinearAsMat();
+    pose.insert(pose.end(), Re.m, Re.m + 9);
+    const Vec3d pe = state->_camleft_imu_extrinsics->valueTrans();
+    pose.insert(pose.end(), pe.v, pe.v + 3);
+    printDoubles("POSE", pose);
+    const MatXd P = StateManager::getFullCov(state);
+    std::vector<double> diag;
+    double fro = 0;
+    for (int j = 0; j < P.cols(); ++j) { diag.push_back(P(j, j)); for (int i = 0; i < P.rows(); ++i) fro += P(i, j) * P(i, j); }
+    printDoubles("DIAG", diag);
+    std::printf("NORM %.17g\nEND\n", std::sqrt(fro));
+}
+
 static double median(std::vector<double> v)
 {
     if (v.empty()) return 0.0;
@@ -53,12 +112,13 @@ static double median(std::vector<double> v)
 int main(int argc, char** argv)
 {
     if (argc < 2) { std::fprintf(stderr, "usage: ingvio_replay <file> [--dump] [--set \"key: value\" ...] | --synth <spec> [--write f | --frame k | --time]\n"); return 2; }
-    bool dump = false, timed = false;
+    bool dump = false, timed = false, trace = false;
     std::string overrides, synth, write_path, file;
     int frame_k = -1;
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--dump")) dump = true;
         else if (!std::strcmp(argv[i], "--time")) timed = true;
+        else if (!std::strcmp(argv[i], "--trace")) trace = true;
         else if (!std::strcmp(argv[i], "--set") && i + 1 < argc) { overrides += argv[++i]; overrides += "\n"; }
         else if (!std::strcmp(argv[i], "--synth") && i + 1 < argc) synth = argv[++i];
         else if (!std::strcmp(argv[i], "--write") && i + 1 < argc) write_path = argv[++i];
@@ -83,7 +143,10 @@ int main(int argc, char** argv)
         std::vector<ingvio::FrameTiming> tm;
         double terr = 0;
         std::string err;
-        if (!ingvio::playSynth(cfg, overrides, tm, &terr, err)) { std::fprintf(stderr, "synthetic play failed: %s\n", err.c_str()); return 1; }
+        std::function<void(int, ingvio::IngvioFilter&)> on_frame;
+        const bool keyframe = cfg.is_key_frame != 0;
+        if (trace) on_frame = [keyframe](int k, ingvio::IngvioFilter& f) { printTrace(k, f, keyframe); };
+        if (!ingvio::playSynth(cfg, overrides, tm, &terr, err, on_frame)) { std::fprintf(stderr, "synthetic play failed: %s\n", err.c_str()); return 1; }
         std::vector<double> heavy, light, all;
         int heavy_acc = 0, heavy_rows = 0;
         for (const auto& t : tm) {
