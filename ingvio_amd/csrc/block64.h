@@ -56,3 +56,65 @@ __device__ __forceinline__ void block64_to_lds(const b64_d4 (&c)[4], double (*sv
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+
+// ---- round 5: the same block product with the operands prefetched TWO chunks ahead (two register sets) and a double-buffered
+//      LDS stage, i.e. ONE barrier per 16 columns of K.  block64_mma above issues the next chunk's loads only one chunk (16 MFMAs,
+//      about 0.4 us) before it needs them: with L2 / HBM latencies of 0.5-2 us under load the four waves of a workgroup stood at
+//      `s_waitcnt vmcnt` most of the time (k_apply_T64: 111 us where its MFMAs need 37).
+struct Block64Lds2 { double a[2][16][68]; double b[2][16][68]; };
+
+template <class FA, class FB>
+__device__ __forceinline__ void block64_mma2(Block64Lds2& s, int K, FA loadA, FB loadB, bool quad_on, b64_d4 (&c)[4])
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int sr = tid & 63, sk = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c[q] = b64_d4{ 0.0, 0.0, 0.0, 0.0 };
+    const int nch = (K + 15) >> 4;
+    if (nch == 0) return;
+    double ra0[4], rb0[4], ra1[4], rb1[4];
+    auto fetch0 = [&](int ch) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { ra0[u] = loadA(sr, 16 * ch + sk + 4 * u); rb0[u] = loadB(sr, 16 * ch + sk + 4 * u); }
+    };
+    auto fetch1 = [&](int ch) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { ra1[u] = loadA(sr, 16 * ch + sk + 4 * u); rb1[u] = loadB(sr, 16 * ch + sk + 4 * u); }
+    };
+    auto mma = [&](int buf) {
+        if (!quad_on) return;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const double a0 = s.a[buf][4 * s4 + kq][32 * wi + l15], a1 = s.a[buf][4 * s4 + kq][32 * wi + 16 + l15];
+            const double q0 = s.b[buf][4 * s4 + kq][32 * wj + l15], q1 = s.b[buf][4 * s4 + kq][32 * wj + 16 + l15];
+            c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, q0, c[0], 0, 0, 0);
+            c[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, q1, c[1], 0, 0, 0);
+            c[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, q0, c[2], 0, 0, 0);
+            c[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, q1, c[3], 0, 0, 0);
+        }
+    };
+    // every fetch is UNCONDITIONAL (past the end the last chunk is fetched again and never used): a branch around a group of loads
+    // makes the number of loads in flight unknown at the join, and the compiler then drains the queue (vmcnt(0)) at the next stage
+    const int last = nch - 1;
+    fetch0(0);
+    fetch1(min(1, last));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s.a[0][sk + 4 * u][sr] = ra0[u]; s.b[0][sk + 4 * u][sr] = rb0[u]; }
+    fetch0(min(2, last));
+    lds_barrier();
+    int k = 0;
+    for (; k + 1 < nch; k += 2) {
+        mma(0);                                                         // chunk k from buffer 0
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s.a[1][sk + 4 * u][sr] = ra1[u]; s.b[1][sk + 4 * u][sr] = rb1[u]; }      // chunk k + 1
+        fetch1(min(k + 3, last));
+        lds_barrier();
+        mma(1);                                                         // chunk k + 1 from buffer 1
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s.a[0][sk + 4 * u][sr] = ra0[u]; s.b[0][sk + 4 * u][sr] = rb0[u]; }      // chunk k + 2 (or a repeat of the last)
+        fetch0(min(k + 4, last));
+        lds_barrier();
+    }
+    if (k < nch) { mma(0); lds_barrier(); }
+}

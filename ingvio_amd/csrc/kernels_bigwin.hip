@@ -1175,6 +1175,124 @@ __global__ __launch_bounds__(256) void k_apply_sym64(CovView cv, int b0, const d
     }
 }
 
+// ---- round 5: the two launches again with (a) the K range cut to the context's window class (kc = 6 c_max columns instead of
+//      the 216 of the largest class: 12 instead of 14 chunks and 3 instead of 4 column blocks of T at 30 clones), (b) operands
+//      prefetched two chunks ahead through a double-buffered LDS stage (block64_mma2), (c) dx = Pc t as column kc of the T product
+//      instead of a 216-step serial loop on 64 threads, (d) the prior's block of k_apply_sym64 requested BEFORE the product: its
+//      16 loads per lane used to start after the last MFMA, one dependent load -> subtract -> store chain per element.
+__global__ __launch_bounds__(256, 3) void k_apply_T64b(CovView cv, int b0, const double* __restrict__ Mall, int mstride, const double* __restrict__ Pcall,
+                                                    int ystride, const int* __restrict__ m_all, const int* __restrict__ marg_idx,
+                                                    const int* __restrict__ pc_base, double* __restrict__ Tall, size_t tstride, int ldt,
+                                                    double* __restrict__ dx_all, int MP, int kc, int nb, int nbi, int nbj)
+{
+    __shared__ Block64Lds2 sAB;
+    // XCD-aware order (workgroup w runs on XCD w % 8): XCD x walks through the filters x, x + 8, ... ONE AFTER THE OTHER, all blocks
+    // of a filter on the same XCD - its Pc (1.2 MB at N = 807) and M (0.26 MB) are then served by that XCD's 4 MB L2 instead of
+    // travelling from MALL / HBM once per block (536 MB per 32 filters in k_apply_sym64)
+    const int per = nbi * nbj, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bl = xcd + 8 * (slot / per), blk = slot % per, bj = blk / nbi, bi = blk - bj * nbi;
+    if (bl >= nb) return;
+    ApplyPtrs q;
+    if (!apply_setup(cv, b0, bl, Mall, mstride, Pcall, ystride, m_all, marg_idx, pc_base, q) || !q.upd) return;
+    if (64 * bi >= q.n) return;
+    const double* M = q.M;
+    const double* tv = M + (size_t)MP * MP;
+    const double* Pc = q.Pc;
+    const int n = q.n, ld = q.ld;
+    b64_d4 c[4];
+    const int tid = threadIdx.x;
+    const int arow = min(64 * bi + (tid & 63), n - 1), jcol = 64 * bj + (tid & 63);
+    const double* Arow = Pc + arow;
+    const double* Bcol = jcol < kc ? M + jcol : tv;                      // column kc of the product is dx = Pc t
+    const size_t bstep = jcol < kc ? (size_t)MP : 1;
+    const bool bon = jcol <= kc;
+    // UNCONDITIONAL loads from clamped (valid, finite) addresses, zeroed by a factor: `k < kc ? p[k] : 0` compiles into one exec-masked
+    // basic block per load, and the compiler - unable to count the loads in flight across those branches - drains the whole queue
+    // (s_waitcnt vmcnt(0)) before every LDS stage: the two-chunk prefetch collapsed to none
+    const double bmask = bon ? 1.0 : 0.0;
+    block64_mma2(sAB, (kc + 15) & ~15,
+                 [&](int, int k) { return Arow[(size_t)min(k, kc - 1) * ld]; },
+                 [&](int, int k) { return (k < kc ? bmask : 0.0) * Bcol[(size_t)min(k, kc - 1) * bstep]; }, true, c);
+    double* T = Tall + (size_t)bl * tstride;
+    const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4, wi = wave >> 1, wj = wave & 1;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {                                        // tile h of the quadrant: rows 16 (h >> 1), columns 16 (h & 1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 64 * bi + 32 * wi + 16 * (h >> 1) + kq + 4 * r, col = 64 * bj + 32 * wj + 16 * (h & 1) + l15;
+            if (row < n) {
+                if (col < kc) T[(size_t)row + (size_t)col * ldt] = c[h][r];
+                else if (col == kc) dx_all[(size_t)(b0 + bl) * ld + row] = c[h][r];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void k_apply_sym64b(CovView cv, int b0, const double* __restrict__ Mall, int mstride, const double* __restrict__ Pcall,
+                                                      int ystride, const int* __restrict__ m_all, const int* __restrict__ marg_idx, int msize,
+                                                      const int* __restrict__ pc_base, const double* __restrict__ Tall, size_t tstride, int ldt,
+                                                      int* __restrict__ status, int kc, int nb, int per)
+{
+    __shared__ union { Block64Lds2 ab; double sV[4][32][33]; } sh;      // the transposition scratch reuses the operand stage
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;              // XCD-aware order, see k_apply_T64b: row-major over the lower blocks,
+    const int bl = xcd + 8 * (slot / per);                               // so consecutive workgroups of an XCD share the T panel of a block row
+    if (bl >= nb) return;
+    int t = slot % per, bi = 0;
+    while (t >= bi + 1) { t -= bi + 1; ++bi; }
+    const int bj = t;
+    ApplyPtrs q;
+    if (!apply_setup(cv, b0, bl, Mall, mstride, Pcall, ystride, m_all, marg_idx, pc_base, q)) return;
+    if (64 * bi >= q.n) return;
+    const int n = q.n, ld = q.ld, midx = q.midx, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, wi = wave >> 1, wj = wave & 1;
+    const bool fused = q.fused;
+    const bool quad_on = !(bi == bj && wj > wi);
+    const int r0 = 64 * bi + 32 * wi, c0 = 64 * bj + 32 * wj;
+    // the prior's quadrant: 16 values per lane, in flight during the product
+    double pv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = lane + 64 * i, row = r0 + (e & 31), col = c0 + (e >> 5);
+        pv[i] = (quad_on && row < n && col < n && row >= col) ? NT_LOAD(&q.P[(size_t)row + (size_t)col * ld]) : 0.0;
+    }
+    b64_d4 c[4];
+    if (q.upd) {
+        const double* Arow = Tall + (size_t)bl * tstride + min(64 * bi + (tid & 63), n - 1);
+        const double* Brow = q.Pc + min(64 * bj + (tid & 63), n - 1);
+        block64_mma2(sh.ab, (kc + 15) & ~15,
+                     [&](int, int k) { return Arow[(size_t)min(k, kc - 1) * ldt]; },
+                     [&](int, int k) { return (k < kc ? 1.0 : 0.0) * Brow[(size_t)min(k, kc - 1) * ld]; }, quad_on, c);
+    } else {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) c[h] = b64_d4{ 0.0, 0.0, 0.0, 0.0 };
+    }
+    if (!quad_on) return;
+    block64_to_lds(c, sh.sV[wave]);
+    auto alive = [&](int i) { return !(fused && i >= midx && i < midx + msize); };
+    auto remap = [&](int i) { return (fused && i >= midx) ? i - msize : i; };
+    bool neg = false;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = lane + 64 * i, rr = e & 31, cc = e >> 5;
+        const int row = r0 + rr, col = c0 + cc;
+        double v = 0.0;
+        if (row < n && col < n && row >= col) {
+            v = pv[i] - sh.sV[wave][rr][cc];
+            if (alive(row) && alive(col)) NT_STORE(&q.dst[(size_t)remap(row) + (size_t)remap(col) * ld], v);
+            neg = neg || (q.upd && row == col && v < 0.0);
+        }
+        sh.sV[wave][rr][cc] = v;
+    }
+    if (neg) atomicOr(&status[b0 + bl], 2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = lane + 64 * i, cc = e & 31, rr = e >> 5;
+        const int row = r0 + rr, col = c0 + cc;
+        if (row < n && col < n && row > col && alive(row) && alive(col)) NT_STORE(&q.dst[(size_t)remap(col) + (size_t)remap(row) * ld], sh.sV[wave][rr][cc]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 int dbg_read_bigwin(long long* out, int n) { return dbg_read_local(out, n); }
 size_t bigwin_sg_doubles(int G) { return (size_t)G * BIG_CMAX * BIG_CMAX * GB_SW; }
@@ -1186,6 +1304,16 @@ int bigwin_cmax() { return BIG_CMAX; }
 void launch_apply64(const FactoredLaunch& L, hipStream_t st, int mp, double* T, size_t tstride, int ldt)
 {
     const int nb64 = (ldt + 63) / 64;
+    static const bool old64 = [] { const char* e = getenv("INGVIO_BIG_APPLY"); return e && e[0] == '6'; }();      // round-4 kernels, for comparison
+    if (!old64) {
+        const int kc = (L.ncol_cap > 0 && L.ncol_cap < mp) ? L.ncol_cap : mp;      // the window class of the context: M, t are zero beyond it
+        const int fpx = (L.nb + 7) / 8, nbj = (kc + 1 + 63) / 64, per = nb64 * (nb64 + 1) / 2;      // filters per XCD
+        hipLaunchKernelGGL(k_apply_T64b, dim3(8 * fpx * nb64 * nbj), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
+                           L.m_out, L.marg_idx, L.pc_base, T, tstride, ldt, L.dx, mp, kc, L.nb, nb64, nbj);
+        hipLaunchKernelGGL(k_apply_sym64b, dim3(8 * fpx * per), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
+                           L.m_out, L.marg_idx, L.marg_size, L.pc_base, T, tstride, ldt, L.status, kc, L.nb, per);
+        return;
+    }
     hipLaunchKernelGGL(k_apply_T64, dim3(nb64, (mp + 63) / 64, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
                        L.m_out, L.marg_idx, L.pc_base, T, tstride, ldt, L.dx, mp);
     hipLaunchKernelGGL(k_apply_sym64, dim3(nb64 * (nb64 + 1) / 2, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
