@@ -658,7 +658,14 @@ def run_workload(args, grp, aux=False):
             ctx.sync()
             in_bytes = sum(np.asarray(v).nbytes for v in frames[0].values() if hasattr(v, "nbytes")) + \
                 sum(np.asarray(v).nbytes for v in steps[0].values() if hasattr(v, "nbytes"))
-            handover = dict(serial_updates_per_s=B / t_serial, pipelined_updates_per_s=B / t_pipe, input_bytes_per_update=in_bytes,
+            stg = None
+            if not aux and world == 1:
+                try:                                      # one PROCESS per stager, as ranks are (the threaded variant: tests/test_gpu_stagers.py)
+                    stg = stagers_rate_processes(8, 64, reps=20)
+                    stg["host_threads"] = os.cpu_count()
+                except Exception as e:                    # auxiliary figure: never takes the bench line down
+                    stg = dict(error=str(e)[-200:])
+            handover = dict(serial_updates_per_s=B / t_serial, pipelined_updates_per_s=B / t_pipe, input_bytes_per_update=in_bytes, stagers8=stg,
                             note="host buffers -> pinned slab (8 host threads) -> PCIe -> run -> dx/accept back; pipelined = copy "
                                  "stream + second device input set (ingvio_frame_stage_async); auxiliary, `value` is device-resident")
         updates = B * world * args.steps
@@ -698,6 +705,118 @@ def run_workload(args, grp, aux=False):
                          "(%s)" % csrc, setup_s=t_build)
     ctx.close()
     return out
+
+
+def stagers_rate(n_stagers=8, filters_each=64, F=150, C=11, n_gnss=6, n_lm=52, reps=12, device=0):
+    """Host hand-over under concurrent stagers (SURVEY 8(d) config 4 "report both"): `n_stagers` contexts of
+    `filters_each` filters on ONE GPU, each driven by its own host thread through the pipelined hand-over
+        run(i); stage_async(i + 1); fetch(i)
+    (pinned slab -> copy stream -> second device input set; ctypes releases the GIL inside the library calls, so the threads pack
+    and copy concurrently) - what 8 ranks of one host would do to the PCIe root and the host cores.  Returns the aggregate staged
+    updates/s, the same for one stager alone, and the device-resident rate of one context (run only) for scale.  Auxiliary: never
+    `value`."""
+    import threading
+    from ingvio_amd import capi, synth
+    N = 21 + n_gnss + 3 * n_lm + 6 * C
+    pr = synth.PARAMS
+    ctxs, calls, lock_free = [], [], []
+    for s in range(n_stagers):
+        ctx = capi.Context(batch=filters_each, n_max=((N + 15) // 16) * 16, c_max=C, f_max=F, m_max=64, device=device)
+        filters, steps, frames, infos = build_batch(ctx, filters_each, 4000 + 97 * s, F, C, n_gnss, n_lm)
+        ctx.snapshot()
+        st = ctx.frame_stage_prepare(0, steps, frames, filters[0].sigma(), filters[0].enable_gnss, pr["sigma_cb"], pr["sigma_rw"],
+                                     max_accept=0, compress_rule=1, use_async=True)
+        st(); ctx.frame_run(restore_prior=True); st(); ctx.frame_fetch(); ctx.sync()      # allocates the pinned ring and the second input set
+        ctxs.append(ctx); calls.append(st)
+        lock_free.append((steps, frames))
+
+    def loop(i, n, out):
+        ctx, st = ctxs[i], calls[i]
+        for _ in range(n):
+            ctx.frame_run(restore_prior=True); st(); out[i] = ctx.frame_fetch()
+        ctx.sync()
+
+    def timed(active, n):
+        res = [None] * n_stagers
+        th = [threading.Thread(target=loop, args=(i, n, res)) for i in active]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0, res
+    timed(range(n_stagers), 2)                                            # warm-up
+    t_all, res_all = timed(range(n_stagers), reps)
+    t_one, res_one = timed([0], reps)
+    # one context device-resident (no staging, no fetch) for scale
+    ctxs[0].sync(); t0 = time.perf_counter()
+    for _ in range(reps):
+        ctxs[0].frame_run(restore_prior=True)
+    ctxs[0].sync(); t_dev = time.perf_counter() - t0
+    same = bool(np.array_equal(res_all[0][0], res_one[0][0]) and np.array_equal(res_all[0][1], res_one[0][1]))
+    finite = all(bool(np.isfinite(r[0]).all()) for r in res_all)
+    for c in ctxs:
+        c.close()
+    return dict(stagers=n_stagers, filters_each=filters_each, aggregate_updates_per_s=n_stagers * filters_each * reps / t_all,
+                one_stager_updates_per_s=filters_each * reps / t_one, device_resident_one_context_updates_per_s=filters_each * reps / t_dev,
+                concurrent_equals_alone=same, results_finite=finite, host_threads=os.cpu_count())
+
+
+def _stager_child():
+    """One stager PROCESS of stagers_rate_processes(): builds its own 64-filter context, reports READY, waits for the common start
+    time on stdin, runs the pipelined hand-over loop and prints its own start / end wall-clock times."""
+    from ingvio_amd import capi, synth
+    i, n_f, reps = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    F, C, n_gnss, n_lm = 150, 11, 6, 52
+    N = 21 + n_gnss + 3 * n_lm + 6 * C
+    pr = synth.PARAMS
+    ctx = capi.Context(batch=n_f, n_max=((N + 15) // 16) * 16, c_max=C, f_max=F, m_max=64, device=int(os.environ.get("INGVIO_DEVICE", "0")))
+    filters, steps, frames, infos = build_batch(ctx, n_f, 4000 + 97 * i, F, C, n_gnss, n_lm)
+    ctx.snapshot()
+    st = ctx.frame_stage_prepare(0, steps, frames, filters[0].sigma(), filters[0].enable_gnss, pr["sigma_cb"], pr["sigma_rw"], max_accept=0,
+                                 compress_rule=1, use_async=True)
+    st()
+    for _ in range(3):
+        ctx.frame_run(restore_prior=True); st(); ctx.frame_fetch()
+    ctx.sync()
+    print("READY", flush=True)
+    t_start = float(sys.stdin.readline())
+    while time.time() < t_start:
+        pass
+    t0 = time.time()
+    for _ in range(reps):
+        ctx.frame_run(restore_prior=True); st(); dx, acc, rows = ctx.frame_fetch()
+    ctx.sync()
+    t1 = time.time()
+    print(json.dumps(dict(t0=t0, t1=t1, finite=bool(np.isfinite(dx).all()), accepted=float(acc.sum()) / n_f)), flush=True)
+    ctx.close()
+
+
+def stagers_rate_processes(n_stagers=8, filters_each=64, reps=20):
+    """The same hand-over loop as stagers_rate() with one PROCESS per stager - what `torchrun --nproc-per-node 8` ranks of one host
+    are: own interpreter, own HIP runtime, own copy queues - all on GPU 0 here (a one-GPU box), started together.  Aggregate =
+    all staged updates / (last end - first start)."""
+    import subprocess
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--stager-child", str(i), str(filters_each), str(reps)], stdin=subprocess.PIPE,
+                              stdout=subprocess.PIPE, text=True, cwd=ROOT) for i in range(n_stagers)]
+    try:
+        for p in procs:
+            line = p.stdout.readline()
+            if not line.startswith("READY"):
+                raise RuntimeError("stager child failed: %r" % line)
+        t_start = time.time() + 0.5
+        for p in procs:
+            p.stdin.write("%r\n" % t_start); p.stdin.flush()
+        res = [json.loads(p.stdout.readline()) for p in procs]
+    finally:
+        for p in procs:
+            try:
+                p.wait(timeout=60)
+            except Exception:
+                p.kill()
+    span = max(r["t1"] for r in res) - min(r["t0"] for r in res)
+    return dict(stagers=n_stagers, filters_each=filters_each, reps=reps, aggregate_updates_per_s=n_stagers * filters_each * reps / span,
+                per_stager_updates_per_s=[filters_each * reps / (r["t1"] - r["t0"]) for r in res], results_finite=all(r["finite"] for r in res))
 
 
 REPLAY_TOOL = os.path.join(ROOT, "ingvio_amd", "lib", "ingvio_replay")
@@ -808,6 +927,14 @@ def compact_line(full):
                     max_rel_cov_err=(v.get("parity_vs_oracle") or {}).get("max_rel_cov_err"),
                     accept_mask_equal=(v.get("parity_vs_oracle") or {}).get("accept_mask_equal"))
             for k, v in full["aux_configs"].items()}
+    hh = full.get("host_handover")
+    if hh is not None:
+        # host buffers in, results out (never `value`): one context serial / pipelined, and 8 concurrent stagers x 64 filters on this GPU
+        h = _pick(hh, ("serial_updates_per_s", "pipelined_updates_per_s"))
+        s8 = hh.get("stagers8") or {}
+        h["stagers8_aggregate_updates_per_s"] = s8.get("aggregate_updates_per_s")
+        h["stagers8_host_threads"] = s8.get("host_threads")
+        out["host_handover"] = h
     out["detail"] = "bench_detail.json (per-kernel table, notes, host hand-over, as-written cap-20 figures)"
     line = json.dumps(_rnd(out))
     assert len(line) < LINE_LIMIT, "bench line %d chars >= %d: move keys to bench_detail.json" % (len(line), LINE_LIMIT)
@@ -848,4 +975,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--stager-child":
+        _stager_child()
+    else:
+        main()

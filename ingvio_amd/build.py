@@ -115,6 +115,33 @@ def build_hip(force=False, verbose=False):
     return HIP_LIB
 
 
+def build_alt(force=False, verbose=False):
+    """build_var/alt/libingvio_hip.so: the same sources with -DINGVIO_ALT_KERNELS - the measured-and-rejected kernel generations and
+    the forced code-path switches (INGVIO_GATE=3, INGVIO_INFO_SOLVE=gj, INGVIO_BIG_SOLVE=regs|gj, INGVIO_BIG_APPLY=o|3|6, INGVIO_APPLY_TW=2,
+    INGVIO_INFO_GAUGE=off, INGVIO_LM_FRONT=split, INGVIO_LM_SOLVE=sweep, INGVIO_GRAM_CHUNKS, INGVIO_P_PAD, INGVIO_MSCKF_METHOD) that the product
+    library no longer carries (VERDICT r04 #7).  tests/test_gpu_alternatives.py loads it through INGVIO_HIP_LIB."""
+    out = os.path.join(os.path.dirname(HERE), "build_var", "alt")
+    os.makedirs(out, exist_ok=True)
+    lib = os.path.join(out, "libingvio_hip.so")
+    deps = _all_deps([CSRC, os.path.join(os.path.dirname(HERE), "include")])
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs, cmds = [], []
+    for src in HIP_SOURCES:
+        obj = os.path.join(out, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(obj, deps):
+            cmds.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-DINGVIO_ALT_KERNELS"]
+                        + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj])
+    if cmds:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(cmds), os.cpu_count() or 4)) as ex:
+            list(ex.map(subprocess.check_call, cmds))
+    bid_obj = os.path.join(LIB, "build_id.o")
+    if force or _newer(lib, objs + [bid_obj]):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + [bid_obj])
+    return lib
+
+
 def build_host(force=False, verbose=False):
     host_dir = os.path.join(CSRC, "host")
     if not os.path.isdir(host_dir):
@@ -186,6 +213,7 @@ def build_tools(force=False, verbose=False):
 
 def build_all(force=False, verbose=False):
     a = build_hip(force, verbose)
+    build_alt(force, verbose)
     b = build_host(force, verbose)
     build_cpp_tests(force, verbose)
     build_ros_adapter_test(force, verbose)

@@ -652,7 +652,9 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     c->G = (desc->c_max > 16 ? 256 : 512) / B;                              // ~2 resident gram workgroups per CU (large windows: 1,
     { const int gmax = desc->c_max > 16 ? 32 : 16; if (c->G > gmax) c->G = gmax; }   // and every chunk costs a 0.35 MB partial + sparse sums)
     if (c->G < 1) c->G = 1;
+#ifdef INGVIO_ALT_KERNELS      // tuning knobs and forced code paths exist in variant builds only (tools/build_variant.sh alt -DINGVIO_ALT_KERNELS)
     if (const char* e = getenv("INGVIO_GRAM_CHUNKS")) { const int g = atoi(e); if (g >= 1 && g <= 64) c->G = g; }
+#endif
     c->cls = msckf_cmax_class(desc->c_max);
     const int ncm = 6 * desc->c_max;
     c->rstride = ncm * (ncm + 1);
@@ -660,10 +662,10 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     c->cstride = c->nc_cap;
     c->ystride = std::max(c->ldp * (c->mld + 4), c->mld * (c->mld + 1));      // Pc copy (ldp x MP) or M | t (MP x MP + MP)
     c->has_snap = false; c->staged = false; c->prof = false;
-    {
-        const char* e = getenv("INGVIO_MSCKF_METHOD");
-        c->method = (e && (!strcmp(e, "dense") || !strcmp(e, "0"))) ? 0 : 1;
-    }
+    c->method = 1;                                                          // information form; ingvio_set_msckf_method(0) selects the literal dense path
+#ifdef INGVIO_ALT_KERNELS
+    if (const char* e = getenv("INGVIO_MSCKF_METHOD")) c->method = (!strcmp(e, "dense") || !strcmp(e, "0")) ? 0 : 1;
+#endif
     memset(c->prof_ms, 0, sizeof c->prof_ms); memset(c->prof_calls, 0, sizeof c->prof_calls);
     c->h_n.assign(B, 0); c->h_cur.assign(B, 0); c->h_n_snap.assign(B, 0); c->st_marg.assign(B, -1); c->st_cidx_hi.assign(B, -1);
     c->h_nclones.assign(B, desc->c_max);
@@ -672,7 +674,11 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     // L2 sets.  67 cache lines of pad walk the filters through the sets.  (Precaution: one default bench run showed the gate at
     // 1.30 ms instead of 0.28 in its config-3 pass; tools/gpu_alloc_sensitivity.py could not reproduce that with either layout -
     // six contexts per process, perturbed allocations, 0.289 - 0.294 ms for both -, so the pad is not the proven cure.)
+#ifdef INGVIO_ALT_KERNELS
     static const bool no_pad = [] { const char* e = getenv("INGVIO_P_PAD"); return e && e[0] == '0'; }();
+#else
+    constexpr bool no_pad = false;
+#endif
     c->pp = (size_t)c->ldp * c->ldp + (no_pad ? 0 : 67 * 16);
     const size_t pp = c->pp;
     const int cm = desc->c_max, fm = desc->f_max;
@@ -1768,7 +1774,11 @@ static int run_dense_update(ingvio_ctx* c, int b0, int nb, double var, int r_kin
         if (r_kind >= 0) launch_add_noise(X, w.xstride, w.ldx, d_noise, nstride, r_kind, act, mc, nb, c->st);
     }
     // S of up to 256 rows: one workgroup per filter, S in registers (kernels_lmchol.hip); larger: the sweep out of L2 (kernels_chol.hip)
+#ifdef INGVIO_ALT_KERNELS
     static const bool sweep_only = getenv("INGVIO_LM_SOLVE") && !strcmp(getenv("INGVIO_LM_SOLVE"), "sweep");
+#else
+    constexpr bool sweep_only = false;
+#endif
     if (w.U && !sweep_only) {
         ProfScope p(c, PF_LM_CHOL);
         LmCholArgs a = {};
@@ -1817,8 +1827,12 @@ static int landmark_update_launch(ingvio_ctx* c, int b0, int nb, const int* marg
         L.cidx = w.cidx + (size_t)b0 * LM_MAX * 4; L.n_rows = w.n32;
         // states of up to 256 rows with the register-resident solve: rows, products and gate in one kernel (k_lm_front), the accepted
         // rows handed on as a row map; otherwise k_lm_build + k_lm_products write the compacted system
+#ifdef INGVIO_ALT_KERNELS
         static const bool split_front = getenv("INGVIO_LM_FRONT") && !strcmp(getenv("INGVIO_LM_FRONT"), "split");
         static const bool sweep_only = getenv("INGVIO_LM_SOLVE") && !strcmp(getenv("INGVIO_LM_SOLVE"), "sweep");
+#else
+        constexpr bool split_front = false, sweep_only = false;
+#endif
         if (w.U && !split_front && !sweep_only && launch_lm_front(L, s.l_hi, w.rowmap + (size_t)b0 * w.m_cap, c->st))
             rowmap = w.rowmap + (size_t)b0 * w.m_cap;
         else launch_lm_build(L, c->st);

@@ -1,6 +1,8 @@
 // MapServer.h — mirrors the data model of ingvio_estimator/src/MapServer.h:30-134 (MonoMeas, StereoMeas,
 // FeatureInfo, MapServer).  The pointer-chasing bookkeeping of MapServerManager stays host-side and out
 // of scope; the Update classes flatten this structure into the SoA of the C ABI.
+// Licence note: class, member and accessor names below are those of the reference (InGVIO, (C) 2022 Changwu Liu, GNU GPL v3 or later)
+// because the drop-in contract is source compatibility with code written against them; distributed under the same licence.
 #pragma once
 #include <map>
 #include <memory>

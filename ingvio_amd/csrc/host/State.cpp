@@ -5,32 +5,34 @@
 
 namespace ingvio {
 
-StateParams::StateParams(const IngvioParams& filter_params)      // State.cpp:25-58
+// Licence note: this file mirrors the MEMBER LIST and the registration ORDER of the reference's State.cpp:25-91 (InGVIO, (C) 2022
+// Changwu Liu, GNU GPL v3 or later) because the drop-in contract fixes both (the (idx, size) table every caller indexes into); it is
+// distributed under the same licence.  The copying itself is table-driven here.
+namespace {
+// which IngvioParams member feeds which StateParams member (State.cpp:27-48)
+struct ParamRow { double StateParams::*dst; double IngvioParams::*src; bool gnss_only; };
+const ParamRow kParamRows[] = {
+    { &StateParams::_noise_a, &IngvioParams::_noise_a, false }, { &StateParams::_noise_g, &IngvioParams::_noise_g, false },
+    { &StateParams::_noise_ba, &IngvioParams::_noise_ba, false }, { &StateParams::_noise_bg, &IngvioParams::_noise_bg, false },
+    { &StateParams::_init_cov_rot, &IngvioParams::_init_cov_rot, false }, { &StateParams::_init_cov_pos, &IngvioParams::_init_cov_pos, false },
+    { &StateParams::_init_cov_vel, &IngvioParams::_init_cov_vel, false }, { &StateParams::_init_cov_bg, &IngvioParams::_init_cov_bg, false },
+    { &StateParams::_init_cov_ba, &IngvioParams::_init_cov_ba, false }, { &StateParams::_init_cov_ext_rot, &IngvioParams::_init_cov_ext_rot, false },
+    { &StateParams::_init_cov_ext_pos, &IngvioParams::_init_cov_ext_pos, false },
+    // only with enable_gnss (:49-57).  Quirk Q1 (State.cpp:51-52): BOTH clock noises are written to _noise_clockbias, in this order,
+    // so it ends up holding the random-walk value and _noise_cb_rw keeps its default 0.2
+    { &StateParams::_noise_clockbias, &IngvioParams::_noise_clockbias, true }, { &StateParams::_noise_clockbias, &IngvioParams::_noise_cb_rw, true },
+    { &StateParams::_init_cov_rcv_clockbias, &IngvioParams::_init_cov_rcv_clockbias, true },
+    { &StateParams::_init_cov_rcv_clockbias_randomwalk, &IngvioParams::_init_cov_rcv_clockbias_randomwalk, true },
+    { &StateParams::_init_cov_yof, &IngvioParams::_init_cov_yof, true },
+};
+}  // namespace
+
+StateParams::StateParams(const IngvioParams& fp)
+    : _cam_nums(fp._cam_nums), _max_sw_poses(fp._max_sw_clones), _max_landmarks(fp._max_lm_feats), _enable_gnss(fp._enable_gnss != 0),
+      _T_cl2cr(fp._T_cr2i.inverse() * fp._T_cl2i), _T_cl2i(fp._T_cl2i)
 {
-    _cam_nums = filter_params._cam_nums;
-    _max_sw_poses = filter_params._max_sw_clones;
-    _max_landmarks = filter_params._max_lm_feats;
-    _T_cl2cr = filter_params._T_cr2i.inverse() * filter_params._T_cl2i;
-    _T_cl2i = filter_params._T_cl2i;
-    _enable_gnss = static_cast<bool>(filter_params._enable_gnss);
-    _noise_a = filter_params._noise_a;
-    _noise_g = filter_params._noise_g;
-    _noise_ba = filter_params._noise_ba;
-    _noise_bg = filter_params._noise_bg;
-    _init_cov_rot = filter_params._init_cov_rot;
-    _init_cov_pos = filter_params._init_cov_pos;
-    _init_cov_vel = filter_params._init_cov_vel;
-    _init_cov_bg = filter_params._init_cov_bg;
-    _init_cov_ba = filter_params._init_cov_ba;
-    _init_cov_ext_rot = filter_params._init_cov_ext_rot;
-    _init_cov_ext_pos = filter_params._init_cov_ext_pos;
-    if (_enable_gnss) {
-        _noise_clockbias = filter_params._noise_clockbias;
-        _noise_clockbias = filter_params._noise_cb_rw;      // quirk Q1, reproduced (State.cpp:51-52): _noise_cb_rw keeps 0.2
-        _init_cov_rcv_clockbias = filter_params._init_cov_rcv_clockbias;
-        _init_cov_rcv_clockbias_randomwalk = filter_params._init_cov_rcv_clockbias_randomwalk;
-        _init_cov_yof = filter_params._init_cov_yof;
-    }
+    for (const ParamRow& r : kParamRows)
+        if (!r.gnss_only || _enable_gnss) this->*r.dst = fp.*r.src;
 }
 
 void State::construct(const IngvioParams& filter_params)      // State.cpp:60-91
@@ -42,25 +44,19 @@ void State::construct(const IngvioParams& filter_params)      // State.cpp:60-91
                   << INGVIO_LM_MAX << " in-state landmarks" << std::endl;
         std::exit(EXIT_FAILURE);
     }
-    int idx = 0;
+    // the four fixed variables in covariance order: extended pose (9), gyro bias (3), accelerometer bias (3), camera extrinsics (6)
     _extended_pose = std::make_shared<SE23>();
-    _extended_pose->set_cov_idx(idx);
-    _err_variables.push_back(_extended_pose);
-    idx += _extended_pose->size();
     _bg = std::make_shared<Vec3>();
-    _bg->set_cov_idx(idx);
-    _err_variables.push_back(_bg);
-    idx += _bg->size();
     _ba = std::make_shared<Vec3>();
-    _ba->set_cov_idx(idx);
-    _err_variables.push_back(_ba);
-    idx += _ba->size();
     _camleft_imu_extrinsics = std::make_shared<SE3>();
-    _camleft_imu_extrinsics->set_cov_idx(idx);
-    _err_variables.push_back(_camleft_imu_extrinsics);
-    idx += _camleft_imu_extrinsics->size();
+    int idx = 0;
+    for (const std::shared_ptr<Type>& v : std::initializer_list<std::shared_ptr<Type>>{ _extended_pose, _bg, _ba, _camleft_imu_extrinsics }) {
+        v->set_cov_idx(idx);
+        _err_variables.push_back(v);
+        idx += v->size();
+    }
     std::vector<double> cov((size_t)idx * idx, 0.0);
-    for (int i = 0; i < idx; ++i) cov[(size_t)i * idx + i] = std::pow(1e-03, 2);      // :88
+    for (int i = 0; i < idx; ++i) cov[(size_t)i * idx + i] = 1e-3 * 1e-3;                 // :88: (1e-3)^2 I
     if (ingvio_cov_set(_ctx, _b, cov.data(), idx, idx) != INGVIO_OK) {
         std::cout << "[State]: cannot initialise the device covariance: " << ingvio_last_error(_ctx) << std::endl;
         std::exit(EXIT_FAILURE);

@@ -1,6 +1,8 @@
 // State.h — mirrors ingvio_estimator/src/State.h:36-139.  The public members are the reference's;
 // the private covariance `Eigen::MatrixXd _cov` (State.h:133) becomes filter `_b` of an
 // `ingvio_ctx` in HBM, still reachable only through `friend class StateManager`.
+// Licence note: class, member and accessor names below are those of the reference (InGVIO, (C) 2022 Changwu Liu, GNU GPL v3 or later)
+// because the drop-in contract is source compatibility with code written against them; distributed under the same licence.
 #pragma once
 #include <cmath>
 #include <map>

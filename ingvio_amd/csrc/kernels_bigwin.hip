@@ -44,7 +44,11 @@ template <bool STEREO, int CM>
 static void launch_gate_big(const FactoredLaunch& L, hipStream_t st)
 {
     const int nb8 = (L.nb + 7) / 8 * 8;
+#ifdef INGVIO_ALT_KERNELS
     static const bool gate3 = [] { const char* e = getenv("INGVIO_GATE"); return e && e[0] == '3'; }();      // first generation, for comparison
+#else
+    constexpr bool gate3 = false;                                     // product library: k_feat_gate3_big serves mono only
+#endif
     if constexpr (STEREO) {
         if (!gate3) {
             const size_t sm = sizeof(Gate4BigShared<CM>);
@@ -55,6 +59,9 @@ static void launch_gate_big(const FactoredLaunch& L, hipStream_t st)
             return;
         }
     }
+#ifndef INGVIO_ALT_KERNELS
+    if constexpr (!STEREO)
+#endif
     hipLaunchKernelGGL((k_feat_gate3_big<STEREO, CM>), dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st,
                        L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
 }
@@ -374,6 +381,7 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
     dbg_stamp(52);
 }
 
+#ifdef INGVIO_ALT_KERNELS      // the Gauss-Jordan solve of round 1 (INGVIO_BIG_SOLVE=gj), variant builds only
 // ---------------------------------------------------------------------------------------------
 // K8/K9/K11 (see k_info_update): [K1 | A | b], K1 = A Pcc + s^2 I, in the global workspace Wk (NC x LA row-major).
 // One workgroup of 1024 threads per filter.
@@ -566,6 +574,7 @@ __global__ __launch_bounds__(IB_NT, 1) void k_info_update_big(
     if (tid == 0) { m_out[bl] = ncol; nc_out[bl] = ncol; pc_base_out[bl] = zero_copy ? sCol[0] : -1; }
     dbg_stamp(52);
 }
+#endif  // INGVIO_ALT_KERNELS
 
 // ---------------------------------------------------------------------------------------------
 // K8/K9/K11 in symmetric form across the whole GPU (round 2): the same mathematics as kernels_solve.hip,
@@ -760,7 +769,11 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
     const size_t wss = bigwin_wk_doubles();
     double* ws = L.big_wk;
     // gauge-reduced solve for the RemoveLost form of the Jacobians (see kernels_solve.hip); INGVIO_INFO_GAUGE=off for comparison
+#ifdef INGVIO_ALT_KERNELS
     static const bool no_gauge = [] { const char* e = getenv("INGVIO_INFO_GAUGE"); return e && !strcmp(e, "off"); }();
+#else
+    constexpr bool no_gauge = false;
+#endif
     const int gauge = (!L.op.selected_variant && !no_gauge) ? 1 : 0;
     hipLaunchKernelGGL(k_big_prep, dim3(32, L.nb), dim3(256), 0, st, L.cv, L.fv, L.b0, L.Apart, L.chunk_used, L.G, L.rstride, L.Pc,
                        L.ystride, L.dx, L.m_out, L.nc_out, L.marg_idx, L.pc_base, ws, wss, n32, gauge);
@@ -773,7 +786,11 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
     // measured: SLOWER here - 0.75 vs 0.39 ms per 32 filters, 0.61 vs 0.23 for one: a single workgroup's panel takes ~5 us
     // (13 x 16 serial pivots + two barriers), which 512 filters hide and 32 do not; the sweep's panel launches spread a
     // panel over many CUs.  Kept selectable: INGVIO_BIG_SOLVE=regs
+#ifdef INGVIO_ALT_KERNELS
     static const bool use_sweep = [] { const char* e = getenv("INGVIO_BIG_SOLVE"); return !(e && !strcmp(e, "regs")); }();
+#else
+    constexpr bool use_sweep = true;
+#endif
     LmCholArgs q = {};
     q.cv = L.cv; q.b0 = L.b0; q.nb = L.nb; q.xs = wss; q.mc = n32; q.res_row = -1; q.U = ws + w.oU; q.us = wss; q.m = act;
     q.status = L.status + L.b0; q.fail_bit = 4; q.m_fixed = n32;
@@ -1082,6 +1099,7 @@ __global__ __launch_bounds__(256) void k_apply_sym(CovView cv, int b0, const dou
     }
 }
 
+#ifdef INGVIO_ALT_KERNELS      // round-4 generation of the 64 x 64 apply (INGVIO_BIG_APPLY=6), variant builds only
 // ---- the same two launches on 64 x 64 blocks with the operand panels staged through LDS (block64.h): an element of Pc / M / T is
 //      read from L2 once per workgroup instead of once per 32 x 32 block and wave
 __global__ __launch_bounds__(256) void k_apply_T64(CovView cv, int b0, const double* __restrict__ Mall, int mstride, const double* __restrict__ Pcall,
@@ -1174,6 +1192,8 @@ __global__ __launch_bounds__(256) void k_apply_sym64(CovView cv, int b0, const d
         if (row < n && col < n && row > col && alive(row) && alive(col)) NT_STORE(&q.dst[(size_t)remap(col) + (size_t)remap(row) * ld], sV[wave][rr][cc]);
     }
 }
+
+#endif  // INGVIO_ALT_KERNELS
 
 // ---- round 5: the two launches again with (a) the K range cut to the context's window class (kc = 6 c_max columns instead of
 //      the 216 of the largest class: 12 instead of 14 chunks and 3 instead of 4 column blocks of T at 30 clones), (b) operands
@@ -1304,20 +1324,26 @@ int bigwin_cmax() { return BIG_CMAX; }
 void launch_apply64(const FactoredLaunch& L, hipStream_t st, int mp, double* T, size_t tstride, int ldt)
 {
     const int nb64 = (ldt + 63) / 64;
+#ifdef INGVIO_ALT_KERNELS
     static const bool old64 = [] { const char* e = getenv("INGVIO_BIG_APPLY"); return e && e[0] == '6'; }();      // round-4 kernels, for comparison
-    if (!old64) {
+#endif
+#ifdef INGVIO_ALT_KERNELS
+    if (old64) {
+        hipLaunchKernelGGL(k_apply_T64, dim3(nb64, (mp + 63) / 64, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
+                           L.m_out, L.marg_idx, L.pc_base, T, tstride, ldt, L.dx, mp);
+        hipLaunchKernelGGL(k_apply_sym64, dim3(nb64 * (nb64 + 1) / 2, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
+                           L.m_out, L.marg_idx, L.marg_size, L.pc_base, T, tstride, ldt, L.status, mp);
+        return;
+    }
+#endif
+    {
         const int kc = (L.ncol_cap > 0 && L.ncol_cap < mp) ? L.ncol_cap : mp;      // the window class of the context: M, t are zero beyond it
         const int fpx = (L.nb + 7) / 8, nbj = (kc + 1 + 63) / 64, per = nb64 * (nb64 + 1) / 2;      // filters per XCD
         hipLaunchKernelGGL(k_apply_T64b, dim3(8 * fpx * nb64 * nbj), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
                            L.m_out, L.marg_idx, L.pc_base, T, tstride, ldt, L.dx, mp, kc, L.nb, nb64, nbj);
         hipLaunchKernelGGL(k_apply_sym64b, dim3(8 * fpx * per), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
                            L.m_out, L.marg_idx, L.marg_size, L.pc_base, T, tstride, ldt, L.status, kc, L.nb, per);
-        return;
     }
-    hipLaunchKernelGGL(k_apply_T64, dim3(nb64, (mp + 63) / 64, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
-                       L.m_out, L.marg_idx, L.pc_base, T, tstride, ldt, L.dx, mp);
-    hipLaunchKernelGGL(k_apply_sym64, dim3(nb64 * (nb64 + 1) / 2, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
-                       L.m_out, L.marg_idx, L.marg_size, L.pc_base, T, tstride, ldt, L.status, mp);
 }
 
 int launch_bigwin(const FactoredLaunch& L, hipStream_t st)
@@ -1339,14 +1365,23 @@ int launch_bigwin(const FactoredLaunch& L, hipStream_t st)
         return 0;
     }
     if (L.stage == 2) {
+#ifdef INGVIO_ALT_KERNELS
         static const bool use_gj = [] { const char* e = getenv("INGVIO_BIG_SOLVE"); return e && e[0] == 'g'; }();
-        if (!use_gj) { launch_big_solve(L, st); return 0; }
-        hipLaunchKernelGGL(k_info_update_big, dim3(L.nb), dim3(IB_NT), 0, st, L.cv, L.fv, L.b0, L.Apart, L.chunk_used, L.G,
-                           L.rstride, L.noise, L.T, L.mstride, L.Pc, L.ystride, L.dx, L.m_out, L.nc_out, L.status, L.marg_idx,
-                           L.pc_base, L.big_wk);
+        if (use_gj) {
+            hipLaunchKernelGGL(k_info_update_big, dim3(L.nb), dim3(IB_NT), 0, st, L.cv, L.fv, L.b0, L.Apart, L.chunk_used, L.G,
+                               L.rstride, L.noise, L.T, L.mstride, L.Pc, L.ystride, L.dx, L.m_out, L.nc_out, L.status, L.marg_idx,
+                               L.pc_base, L.big_wk);
+            return 0;
+        }
+#endif
+        launch_big_solve(L, st);
         return 0;
     }
+#ifdef INGVIO_ALT_KERNELS
     static const bool old_apply = [] { const char* e = getenv("INGVIO_BIG_APPLY"); return e && e[0] == 'o'; }();
+#else
+    constexpr bool old_apply = false;
+#endif
     if (!old_apply) {
         // T lives in the solve workspace's X2/Y2 region (free once M has been extracted)
         const BigWs w(big_n32(L.ncol_cap));
@@ -1354,7 +1389,11 @@ int launch_bigwin(const FactoredLaunch& L, hipStream_t st)
         if ((size_t)ldt * BIG_NC <= 2 * (size_t)w.ld2 * w.n32) {
             double* T = L.big_wk + w.oX2;
             const size_t wss = bigwin_wk_doubles();
+#ifdef INGVIO_ALT_KERNELS
             static const bool blk32 = [] { const char* e = getenv("INGVIO_BIG_APPLY"); return e && e[0] == '3'; }();
+#else
+            constexpr bool blk32 = false;
+#endif
             if (blk32 || L.nb < 4) {                                          // a few filters: more, smaller workgroups
                 hipLaunchKernelGGL(k_apply_T, dim3(nbr, (BIG_NC + 31) / 32, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride,
                                    L.m_out, L.marg_idx, L.pc_base, T, wss, ldt, L.dx);

@@ -1086,7 +1086,13 @@ static void launch_ft(const FactoredLaunch& L, hipStream_t st)
         const int nb8 = (L.nb + 7) / 8 * 8;
         // INGVIO_GATE=3 selects the first-generation gate (K + 4 border rows) for comparison; mono always takes it (its K lives in
         // the 2-rows-per-observation measurement space, where Hf is not a stack of identities)
+        // The product library carries ONE stereo fallback, INGVIO_GATE=4; the first-generation stereo gate and the other measured-and-
+        // rejected variants are compiled only with -DINGVIO_ALT_KERNELS (build_var/alt, tests/test_gpu_alternatives.py)
+#ifdef INGVIO_ALT_KERNELS
         static const bool gate3 = [] { const char* e = getenv("INGVIO_GATE"); return e && e[0] == '3'; }();
+#else
+        constexpr bool gate3 = false;
+#endif
         static const bool gate4 = [] { const char* e = getenv("INGVIO_GATE"); return e && e[0] == '4'; }();      // one feature per wave (round 3)
         if constexpr (STEREO && CMAX <= 11) {
             if (!gate3 && !gate4) {
@@ -1102,6 +1108,9 @@ static void launch_ft(const FactoredLaunch& L, hipStream_t st)
                 return;
             }
         }
+#ifndef INGVIO_ALT_KERNELS
+        if constexpr (!STEREO)                                         // k_feat_gate3<CMAX, true> is not instantiated in the product library
+#endif
         hipLaunchKernelGGL((k_feat_gate3<CMAX, STEREO>), dim3(nb8 * ((L.fmax_used + GATE_FPW - 1) / GATE_FPW)), dim3(GATE_FPW * WAVE), 0, st,
                            L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
     } else {
@@ -1141,22 +1150,32 @@ int launch_factored(const FactoredLaunch& L, hipStream_t st)
     if (L.stage == 3) {
         const int nt = (L.n_cap + 15) / 16, wgpf = ((nt + 1) / 2 + 3) / 4, nb8 = (L.nb + 7) / 8 * 8;
         // two tile columns per step (half the steps): measured 0.194 against 0.151 ms (256 VGPRs + 76 B scratch) - selectable only
+#ifdef INGVIO_ALT_KERNELS
         static const bool tw1 = [] { const char* e = getenv("INGVIO_APPLY_TW"); return !(e && e[0] == '2'); }();
+#define APPLY_TW2(NC) else if (!tw1) hipLaunchKernelGGL((k_info_apply<NC, 2>), dim3(nb8 * wgpf), dim3(256), 0, st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride, L.Pc, \
+                           L.ystride, L.m_out, L.dx, L.status, L.marg_idx, L.marg_size, L.pc_base);
+#else
+#define APPLY_TW2(NC)
+#endif
 #define APPLY_DISPATCH(NC)                                                                                            \
         if (L.gY) hipLaunchKernelGGL((k_info_apply<NC, 1, 16>), dim3(nb8 * wgpf), dim3(256), 0, st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride, L.Pc, \
                            L.ystride, L.m_out, L.dx, L.status, L.marg_idx, L.marg_size, L.pc_base, L.gY, L.gYstride, L.gm); \
-        else if (tw1) hipLaunchKernelGGL((k_info_apply<NC, 1>), dim3(nb8 * wgpf), dim3(256), 0, st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride, L.Pc, \
-                           L.ystride, L.m_out, L.dx, L.status, L.marg_idx, L.marg_size, L.pc_base);                    \
-        else hipLaunchKernelGGL((k_info_apply<NC, 2>), dim3(nb8 * wgpf), dim3(256), 0, st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride, L.Pc, \
+        APPLY_TW2(NC)                                                                                                 \
+        else hipLaunchKernelGGL((k_info_apply<NC, 1>), dim3(nb8 * wgpf), dim3(256), 0, st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride, L.Pc, \
                            L.ystride, L.m_out, L.dx, L.status, L.marg_idx, L.marg_size, L.pc_base);
         if (ncm <= 36) { APPLY_DISPATCH(36) } else if (ncm <= 66) { APPLY_DISPATCH(66) } else { APPLY_DISPATCH(96) }
 #undef APPLY_DISPATCH
+#undef APPLY_TW2
         return 0;
     }
     if (L.stage == 2) {
         // default: the symmetric LDL^T solve on the matrix cores (kernels_solve.hip); INGVIO_INFO_SOLVE=gj selects the older
         // Gauss-Jordan on A Pcc + s^2 I below (kept for comparison and for the 12..16-clone class)
+#ifdef INGVIO_ALT_KERNELS
         static const bool use_gj = [] { const char* e = getenv("INGVIO_INFO_SOLVE"); return e && !strcmp(e, "gj"); }();
+#else
+        constexpr bool use_gj = false;
+#endif
         if (!use_gj && launch_info_solve(L, st) == 0) return 0;
 #define INFO_DISPATCH(NC)                                                                                                   \
         {                                                                                                                   \

@@ -615,7 +615,11 @@ int launch_info_solve(const FactoredLaunch& L, hipStream_t st)
     // The gauge-reduced form needs the block-Laplacian structure of A: the RemoveLost form of the Jacobians.  The Selected-timestamp
     // variants overwrite the anchor's translation columns (quirk Q10, SwMargUpdate.cpp:127,302), which breaks it; INGVIO_INFO_GAUGE=off
     // selects the unreduced solve for comparison.
+#ifdef INGVIO_ALT_KERNELS
     static const bool no_gauge = [] { const char* e = getenv("INGVIO_INFO_GAUGE"); return e && !strcmp(e, "off"); }();
+#else
+    constexpr bool no_gauge = false;
+#endif
     const bool red = !L.op.selected_variant && !no_gauge;
     if (ncm <= 36) { if (red) SOLVE_DISPATCH(36, true) else SOLVE_DISPATCH(36, false) }
     if (ncm <= 66) { if (red) SOLVE_DISPATCH(66, true) else SOLVE_DISPATCH(66, false) }

@@ -1,6 +1,8 @@
-"""The selectable alternative code paths of libingvio_hip.so (kept for A/B measurements) must stay CORRECT: each is
-switched on through its environment variable in a child process (the switches are read once per process) that runs the parity
-tests covering it.  One toggle per case:
+"""The alternative code paths (kept for A/B measurements) must stay CORRECT.  Since round 5 they are NOT in the product
+library: libingvio_hip.so carries the shipped kernels and one stereo gate fallback (INGVIO_GATE=4); everything else is compiled
+only with -DINGVIO_ALT_KERNELS into build_var/alt/libingvio_hip.so (ingvio_amd/build.py::build_alt), which these tests load through
+INGVIO_HIP_LIB.  Each path is switched on through its environment variable in a child process (the switches are read once per
+process) that runs the parity tests covering it.  One toggle per case:
 
   INGVIO_GATE=3            first-generation gate (k_feat_gate3 / k_feat_gate3_big) instead of the difference-coordinate one
   INGVIO_GATE=4            the difference-coordinate gate with ONE feature per wave (k_feat_gate4, round 3) instead of four (k_feat_gate5)
@@ -19,6 +21,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
+ALT_LIB = os.path.join(ROOT, "build_var", "alt", "libingvio_hip.so")
+PRODUCT_ONLY = {("INGVIO_GATE", "4")}                    # the one fallback the product library keeps
 
 CASES = [
     ("INGVIO_GATE", "4", ["tests/test_gpu_parity.py", "tests/test_gpu_pinning.py", "-k",
@@ -37,6 +41,10 @@ CASES = [
 def test_alternative_path_stays_correct(var, value, args):
     env = dict(os.environ)
     env[var] = value
+    if (var, value) not in PRODUCT_ONLY:
+        if not os.path.exists(ALT_LIB):
+            pytest.skip("build_var/alt/libingvio_hip.so not built (python -c 'from ingvio_amd import build; build.build_alt()')")
+        env["INGVIO_HIP_LIB"] = ALT_LIB
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + args, cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=900)
     tail = "\n".join(r.stdout.strip().splitlines()[-15:])
