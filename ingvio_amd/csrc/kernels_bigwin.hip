@@ -1352,6 +1352,12 @@ int launch_bigwin(const FactoredLaunch& L, hipStream_t st)
     if (L.stage == 0) {
         const int cm = L.ncol_cap > 0 ? L.ncol_cap / 6 : BIG_CMAX;                 // the context's c_max picks the class
         if (cm <= 24) { if (L.stereo) launch_gate_big<true, 24>(L, st); else launch_gate_big<false, 24>(L, st); }
+        // round 5: stereo classes 28 and 30.  The two-wave gate needs 231 VGPRs (2 waves per SIMD = 4 workgroups per CU at most) and its
+        // LDS is dominated by the packed triangle of K_r, 3 (C - 1) (3 (C - 1) + 1) / 2 doubles: the 32 class takes 45 KB = THREE
+        // workgroups per CU, the 30 class 40.1 KB and the 28 class 36 KB = four.  A 30-clone window (BASELINE config 5) and the
+        // reference's 25 / 27-pose configs (+ the clone of the frame) no longer pay for two clones they do not have.
+        else if (cm <= 28 && L.stereo) launch_gate_big<true, 28>(L, st);
+        else if (cm <= 30 && L.stereo) launch_gate_big<true, 30>(L, st);
         else if (cm <= 32) { if (L.stereo) launch_gate_big<true, 32>(L, st); else launch_gate_big<false, 32>(L, st); }
         else { if (L.stereo) launch_gate_big<true, BIG_CMAX>(L, st); else launch_gate_big<false, BIG_CMAX>(L, st); }
         return 0;

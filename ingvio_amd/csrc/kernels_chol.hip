@@ -18,13 +18,18 @@ typedef double double4_f __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// One operand element, zero outside [0, I) x [0, K).  The load itself is UNCONDITIONAL, from an index clamped into the operand, and
+// zeroed by a factor: as `ok ? P[..] : 0.0` every element became its own exec-masked basic block, the compiler lost count of the
+// loads in flight across the branches and drained the queue (s_waitcnt vmcnt(0)) before every use - the next chunk's prefetch under
+// this chunk's MFMAs did not exist (round 5; the same trap as block64.h).  Operands are finite inside their range, so 0 * x is 0.
 template <int MODE>
 __device__ __forceinline__ double ld_op(const double* __restrict__ P, int ld, int i, int k, int I, int K, const double* __restrict__ Px, int ix)
 {
-    const bool ok = i < I && k < K;
-    if (!ok) return 0.0;
-    if (Px && i == ix) return Px[k];
-    return MODE == 0 ? P[(size_t)i + (size_t)k * ld] : P[(size_t)k + (size_t)i * ld];
+    const double on = (i < I && k < K) ? 1.0 : 0.0;
+    const int ic = min(i, I - 1), kc = min(k, K - 1);
+    const double* p = MODE == 0 ? P + ((size_t)ic + (size_t)kc * ld) : P + ((size_t)kc + (size_t)ic * ld);
+    p = (Px && i == ix) ? Px + kc : p;
+    return on * *p;
 }
 
 // ---------------------------------------------------------------------------------------------
