@@ -139,6 +139,9 @@ struct ingvio_ctx {
         unsigned long long* mask = nullptr;
     } alt;
     bool alt_ready = false;
+    // large windows: the measurement-independent front of the Kalman solve runs here, under the gate and the Gram kernel (run_msckf_factored)
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t st_copy = nullptr;
     hipEvent_t ev_copy = nullptr, ev_free[2] = { nullptr, nullptr };      // inputs landed / set no longer read by the compute stream
     bool copy_pending = false, free_valid[2] = { false, false };
@@ -570,13 +573,31 @@ int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int s
     L.dx = c->d_dx; L.m_out = c->d_m + b0; L.nc_out = c->d_nc + b0; L.status = c->d_status;
     L.big_sg = c->d_big_sg ? c->d_big_sg + (size_t)b0 * bigwin_sg_doubles(c->G) : nullptr;
     L.big_wk = c->d_big_wk ? c->d_big_wk + (size_t)b0 * bigwin_wk_doubles() : nullptr;
+    // Large windows (kernels_bigwin.hip): the part of the solve that needs the prior only - gauge reference, [Pdd; I], its Cholesky
+    // sweep, the Pc copy: 8 of the chain's dependent launches, 0.12 ms alone - runs on a SECOND, higher-priority stream next to the
+    // gate and the Gram kernel (round 5).  Measured per 32 filters at N = 807: in line 1.167 ms per step; forked before the gate
+    // 1.134 (the sweep's launches crawl - 47 instead of 13 us each - and the gate loses 25 us, but the chain ends with the Gram
+    // kernel); forked after the gate, under the Gram kernel only, 1.192.  Both hosts keep the register file full (the gate: 8 waves of
+    // 231 VGPRs per CU, k_feat_gram_big: one workgroup of 8 waves at 256), so a sweep workgroup only gets a slot when a gate
+    // workgroup retires - which the gate's 9600 short workgroups do all the time and the Gram kernel's 256 long ones never do.
+    const bool big = c->d.c_max > 16;
+    L.mstride = c->ystride; L.n_cap = c->d.n_max;
+    L.marg_idx = marg_idx; L.marg_size = marg_size; L.pc_base = c->d_pcbase + b0;
+    bool forked = false;
+    if (big && phase == 0 && c->st2) {
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->st));                  // after everything that wrote P on the main stream
+        HIPCHK(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
+        L.stage = 5; launch_factored(L, c->st2);
+        HIPCHK(c, hipEventRecord(c->ev_join, c->st2));
+        forked = true;
+    }
     if (phase != 2) {
         { ProfScope p(c, PF_GATE2); L.stage = 0; if (launch_factored(L, c->st)) return INGVIO_E_UNSUPPORTED; }
         { ProfScope p(c, PF_GRAM); L.stage = 1; launch_factored(L, c->st); }
     }
     if (phase == 1) return last_launch(c);
-    L.mstride = c->ystride; L.n_cap = c->d.n_max;
-    L.marg_idx = marg_idx; L.marg_size = marg_size; L.pc_base = c->d_pcbase + b0;
+    if (forked) HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_join, 0));
+    else if (big) { ProfScope p(c, PF_INFO); L.stage = 5; launch_factored(L, c->st); }      // split step / no side stream: in line
     { ProfScope p(c, PF_INFO); L.stage = 2; launch_factored(L, c->st); }
     if (gnss_fuse) { if (int rc = gnss_in_frame_launch(c, b0, nb, L)) return rc; }
     { ProfScope p(c, PF_APPLY); L.stage = 3; launch_factored(L, c->st); }
@@ -638,6 +659,14 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     if (c->own_stream) {
         if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) { delete c; return INGVIO_E_HIP; }
     } else c->st = (hipStream_t)desc->stream;
+    if (desc->c_max > 16) {
+        // a higher priority than the compute stream's default: its short dependent launches take the slots the gate's workgroups free
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&c->st2, hipStreamNonBlocking, hi) != hipSuccess) c->st2 = nullptr;
+        if (c->st2 && (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)) { hipStreamDestroy(c->st2); c->st2 = nullptr; }
+    }
     const int B = desc->batch;
     c->ldp = (desc->n_max + 15) & ~15;
     // the factored kernels run at the padded width of their window class (6 / 11 / 16 clones): size the row/column
@@ -757,6 +786,9 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
         for (auto e : c->ev_free) if (e) hipEventDestroy(e);
     }
     for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    if (c->st2) hipStreamDestroy(c->st2);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->own_stream) hipStreamDestroy(c->st);
     delete c;
     return INGVIO_OK;

@@ -598,87 +598,52 @@ struct BigWs {
     }
 };
 
-__global__ __launch_bounds__(256) void k_big_prep(
-    CovView cv, FrameView fv, int b0, const double* __restrict__ Apart, const int* __restrict__ chunk_used, int G, int rstride,
-    double* __restrict__ Pcall, int ystride, double* __restrict__ dx_all, int* __restrict__ m_out, int* __restrict__ nc_out,
-    const int* __restrict__ marg_idx, int* __restrict__ pc_base_out, double* __restrict__ ws_all, size_t ws_stride, int n32, int gauge)
+// Round 5: the set-up of the solve in two kernels, so that everything that does NOT depend on the measurements - the gauge reference,
+// [Pdd; I], its Cholesky sweep (7 of the chain's 22 dependent launches), the Pc copy - can run on a second stream UNDER the gate and
+// the Gram kernel (launch_bigwin stage 5).  The reference clone used to be the one with the largest translation information (from
+// A); it is now the clone with the smallest prior translation variance (from P alone).  Any reference is exact algebra; the
+// conditioning sweep (tests/test_gpu_pinning.py::test_large_window_sigma_scale_sweep) reads 4e-11 against the oracle with either.
+__global__ __launch_bounds__(256) void k_big_prep_P(
+    CovView cv, FrameView fv, int b0, double* __restrict__ Pcall, int ystride, const int* __restrict__ marg_idx, int* __restrict__ pc_base_out,
+    double* __restrict__ ws_all, size_t ws_stride, int n32, int gauge)
 {
     constexpr int NC = BIG_NC, MP = NC;
     __shared__ int sCol[NC];
-    __shared__ double sTr[BIG_CMAX * 4];
+    __shared__ double sTr[BIG_CMAX];
     __shared__ int sRefSlot;
     const BigWs w(n32);
     const int bl = blockIdx.y, b = b0 + bl, tid = threadIdx.x, nwg = gridDim.x, wg = blockIdx.x;
     const int C = fv.n_clones[b], ncol = 6 * C, n = cv.n[b], ld = cv.ldp;
-    int total = 0;
-    for (int g = 0; g < G; ++g) total += chunk_used[bl * G + g];
-    if (total == 0) {
-        double* dx = dx_all + (size_t)b * ld;
-        for (int r = wg * 256 + tid; r < n; r += nwg * 256) dx[r] = 0.0;
-        if (wg == 0 && tid == 0) { m_out[bl] = 0; nc_out[bl] = ncol; pc_base_out[bl] = -1; }
-        return;
-    }
+    const double* P = cov_ptr(cv, b);
     for (int c = tid; c < NC; c += 256) {
         const int cc = c < ncol ? c : 0;
         sCol[c] = fv.clone_idx[(size_t)b * fv.cmax + cc / 6] + cc % 6;
     }
-    // Gauge-reduced form (kernels_solve.hip, k_info_solve): the reference clone = the one with the largest translation
-    // information; its block is treated like an absent clone (identity in the covariance, zero in A), the other clones enter
-    // through the covariance of their DIFFERENCES to it; k_big_gauge_fix borders M with the reference block afterwards.
-    if (gauge) {                                              // lane (clone, chunk group of 4): fixed summation order below
-        for (int e0 = tid; e0 < BIG_CMAX * 4; e0 += 256) {
-            const int c = e0 >> 2, g0 = e0 & 3;
-            double tr = 0.0;
-            if (c < C) {
-                for (int g = g0; g < G; g += 4) {
-                    const double* Ap = Apart + ((size_t)bl * G + g) * rstride;
-                    const double u = chunk_used[bl * G + g] ? 1.0 : 0.0;
-                    const size_t e = (size_t)(6 * c + 3) * (ncol + 1) + 6 * c + 3;
-                    tr += u * ((Ap[e] + Ap[e + ncol + 2]) + Ap[e + 2 * (ncol + 2)]);
-                }
-            }
-            sTr[e0] = tr;
+    if (tid < BIG_CMAX) {
+        double t = 1e300;
+        if (tid < C) {
+            const int i0 = fv.clone_idx[(size_t)b * fv.cmax + tid] + 3;
+            t = (P[i0 + (size_t)i0 * ld] + P[i0 + 1 + (size_t)(i0 + 1) * ld]) + P[i0 + 2 + (size_t)(i0 + 2) * ld];
         }
+        sTr[tid] = t;
     }
     __syncthreads();
     if (tid == 0) {
         int best = -1;
         if (gauge) {
-            double tb = -1.0;
-            for (int c = 0; c < C; ++c) {
-                const double t = (sTr[4 * c] + sTr[4 * c + 1]) + (sTr[4 * c + 2] + sTr[4 * c + 3]);
-                if (t > tb) { tb = t; best = c; }
-            }
+            double tb = 1e300;
+            for (int c = 0; c < C; ++c) if (sTr[c] < tb) { tb = sTr[c]; best = c; }      // first minimum: deterministic
         }
         sRefSlot = best;
     }
     __syncthreads();
     const int ref6 = sRefSlot >= 0 ? 6 * sRefSlot : (1 << 20);
     auto inref = [&](int i) { return i >= ref6 && i < ref6 + 6; };
-    const double* P = cov_ptr(cv, b);
     double* ws = ws_all + (size_t)bl * ws_stride;
-    double *AB = ws + w.oAB, *X1 = ws + w.oX1;
+    double* X1 = ws + w.oX1;
     const int gt = wg * 256 + tid, gn = nwg * 256;
     if (gt == 0) ws[w.oRef] = (double)sRefSlot;
-    // [A; b^T] from the chunk partials (A symmetric: element (i, j) read as partial row j, column i - coalesced along i)
-    for (int e = gt; e < w.ldab * n32; e += gn) {
-        const int i = e % w.ldab, j = e / w.ldab;
-        double s = 0.0;
-        if (j < ncol && (i < ncol || i == n32) && !inref(i) && !inref(j)) {
-            const size_t src = (size_t)j * (ncol + 1) + (i == n32 ? ncol : i);
-            for (int g0 = 0; g0 < G; g0 += 8) {
-                double t[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int g = g0 + u;
-                    t[u] = (g < G && chunk_used[bl * G + g]) ? Apart[((size_t)bl * G + g) * rstride + src] : 0.0;
-                }
-                s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
-            }
-        }
-        AB[e] = s;
-    }
-    // [Pcc; I], identity in the padding
+    // [Pdd; I], identity in the padding
     for (int e = gt; e < w.ld1 * n32; e += gn) {
         const int i = e % w.ld1, j = e / w.ld1;
         double v;
@@ -704,7 +669,50 @@ __global__ __launch_bounds__(256) void k_big_prep(
             Pc[r + (size_t)k * ld] = k < ncol ? P[r + (size_t)sCol[k] * ld] : 0.0;
         }
     }
-    if (wg == 0 && tid == 0) { m_out[bl] = ncol; nc_out[bl] = ncol; pc_base_out[bl] = zero_copy ? sCol[0] : -1; }
+    if (wg == 0 && tid == 0) pc_base_out[bl] = zero_copy ? sCol[0] : -1;
+}
+
+// ... and the part that needs the measurements: [A; b^T] from the chunk partials (reference block zeroed), the activity flag m_out
+__global__ __launch_bounds__(256) void k_big_prep_A(
+    CovView cv, FrameView fv, int b0, const double* __restrict__ Apart, const int* __restrict__ chunk_used, int G, int rstride,
+    double* __restrict__ dx_all, int* __restrict__ m_out, int* __restrict__ nc_out, double* __restrict__ ws_all, size_t ws_stride, int n32)
+{
+    const BigWs w(n32);
+    const int bl = blockIdx.y, b = b0 + bl, tid = threadIdx.x, nwg = gridDim.x, wg = blockIdx.x;
+    const int C = fv.n_clones[b], ncol = 6 * C, n = cv.n[b], ld = cv.ldp;
+    int total = 0;
+    for (int g = 0; g < G; ++g) total += chunk_used[bl * G + g];
+    if (total == 0) {
+        double* dx = dx_all + (size_t)b * ld;
+        for (int r = wg * 256 + tid; r < n; r += nwg * 256) dx[r] = 0.0;
+        if (wg == 0 && tid == 0) { m_out[bl] = 0; nc_out[bl] = ncol; }
+        return;
+    }
+    double* ws = ws_all + (size_t)bl * ws_stride;
+    const int ref = (int)ws[w.oRef];
+    const int ref6 = ref >= 0 ? 6 * ref : (1 << 20);
+    auto inref = [&](int i) { return i >= ref6 && i < ref6 + 6; };
+    double* AB = ws + w.oAB;
+    const int gt = wg * 256 + tid, gn = nwg * 256;
+    // A symmetric: element (i, j) read as partial row j, column i - coalesced along i; all chunks' loads of an element in flight together
+    for (int e = gt; e < w.ldab * n32; e += gn) {
+        const int i = e % w.ldab, j = e / w.ldab;
+        double s = 0.0;
+        if (j < ncol && (i < ncol || i == n32) && !inref(i) && !inref(j)) {
+            const size_t src = (size_t)j * (ncol + 1) + (i == n32 ? ncol : i);
+            for (int g0 = 0; g0 < G; g0 += 8) {
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int g = g0 + u;
+                    t[u] = (g < G && chunk_used[bl * G + g]) ? Apart[((size_t)bl * G + g) * rstride + src] : 0.0;
+                }
+                s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+            }
+        }
+        AB[e] = s;
+    }
+    if (wg == 0 && tid == 0) { m_out[bl] = ncol; nc_out[bl] = ncol; }
 }
 
 // rows [src_row, +nrows) of S (ld lds) -> rows [dst_row, +nrows) of D (ld ldd), ncols columns, per batch element
@@ -720,28 +728,50 @@ __global__ __launch_bounds__(256) void k_copy_rows(const double* __restrict__ S,
 }
 
 // The reference clone's block row / column of [M | t]: minus the sums over the other clones' blocks (every block row and column
-// of the n x n solution sums to zero: M = T^-T diag(0, Mr) T^-1, see k_info_solve).  One workgroup per filter.
+// of the n x n solution sums to zero: M = T^-T diag(0, Mr) T^-1, see k_info_solve).  Workgroups 0 .. gridDim.x - 2 fill the block
+// row and the block column, the last one the 6 x 6 corner = + the sum of ALL other blocks (the double sum, straight from M, so that
+// it does not have to wait for the block row: one launch instead of two).
 __global__ __launch_bounds__(256) void k_big_gauge_fix(FrameView fv, int b0, double* __restrict__ Mall, int mstride, const double* __restrict__ ws_all,
-                                                       size_t ws_stride, size_t oref, const int* __restrict__ active, int corner)
+                                                       size_t ws_stride, size_t oref, const int* __restrict__ active)
 {
     constexpr int MP = BIG_NC;
+    __shared__ double sPart[36][7];
     const int bl = blockIdx.y, tid = threadIdx.x;
     if (active && !active[bl]) return;
     const int ref = (int)ws_all[(size_t)bl * ws_stride + oref];
     if (ref < 0) return;
     const int C = fv.n_clones[b0 + bl], ref6 = 6 * ref;
     double* Mg = Mall + (size_t)bl * mstride;
-    if (corner) {                                             // second launch: the 6 x 6 corner from the reference rows just written
-        if (blockIdx.x == 0 && tid < 36) {
+    if (blockIdx.x == gridDim.x - 1) {                        // corner (k, l): 7 threads each, partial sums over the block rows c' = q, q + 7, ...
+        const int o = tid / 7, q = tid - 7 * o;
+        if (o < 36) {
+            const int k = o / 6, l = o - 6 * k;
+            double s = 0.0;
+            for (int c2 = q; c2 < C; c2 += 7) {
+                if (c2 == ref) continue;
+                const double* row = Mg + (size_t)(6 * c2 + k) * MP + l;
+                double v[BIG_CMAX];
+#pragma unroll
+                for (int c = 0; c < BIG_CMAX; ++c) v[c] = row[6 * min(c, C - 1)];             // one row of blocks: all loads in flight together
+                double r = 0.0;
+#pragma unroll
+                for (int c = 0; c < BIG_CMAX; ++c) r += (c < C && c != ref ? 1.0 : 0.0) * v[c];
+                s += r;
+            }
+            sPart[o][q] = s;
+        }
+        __syncthreads();
+        if (tid < 36) {
             const int k = tid / 6, l = tid - 6 * k;
             double s = 0.0;
-#pragma unroll 6
-            for (int c = 0; c < C; ++c) s += (c != ref ? 1.0 : 0.0) * Mg[(size_t)(ref6 + k) * MP + 6 * c + l];
-            Mg[(size_t)(ref6 + k) * MP + ref6 + l] = -s;
+#pragma unroll
+            for (int q2 = 0; q2 < 7; ++q2) s += sPart[tid][q2];
+            Mg[(size_t)(ref6 + k) * MP + ref6 + l] = s;
         }
         return;
     }
-    for (int e = blockIdx.x * 256 + tid; e < 2 * 6 * (MP + 1); e += gridDim.x * 256) {
+    const int nwg = gridDim.x - 1;
+    for (int e = blockIdx.x * 256 + tid; e < 2 * 6 * (MP + 1); e += nwg * 256) {
         const int side = e / (6 * (MP + 1)), q = e - side * 6 * (MP + 1), k = q / (MP + 1), J = q - k * (MP + 1);
         if (J == MP) {
             if (side == 0) {
@@ -762,40 +792,45 @@ __global__ __launch_bounds__(256) void k_big_gauge_fix(FrameView fv, int b0, dou
 
 static int big_n32(int ncol_cap) { const int n = ncol_cap > 0 ? ncol_cap : BIG_NC; return (n + 31) / 32 * 32; }
 
-static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
+// the measurement-independent front of the solve (stage 5): gauge reference, [Pdd; I] and its Cholesky sweep -> [L; L^-T], the Pc copy.
+// No activity flags yet (m_out is written by k_big_prep_A): every filter of the range runs.
+static void launch_big_solve_front(const FactoredLaunch& L, hipStream_t st)
 {
-    const int n32 = big_n32(L.ncol_cap), MP = BIG_NC;
+    const int n32 = big_n32(L.ncol_cap);
     const BigWs w(n32);
     const size_t wss = bigwin_wk_doubles();
     double* ws = L.big_wk;
-    // gauge-reduced solve for the RemoveLost form of the Jacobians (see kernels_solve.hip); INGVIO_INFO_GAUGE=off for comparison
 #ifdef INGVIO_ALT_KERNELS
     static const bool no_gauge = [] { const char* e = getenv("INGVIO_INFO_GAUGE"); return e && !strcmp(e, "off"); }();
 #else
     constexpr bool no_gauge = false;
 #endif
     const int gauge = (!L.op.selected_variant && !no_gauge) ? 1 : 0;
-    hipLaunchKernelGGL(k_big_prep, dim3(32, L.nb), dim3(256), 0, st, L.cv, L.fv, L.b0, L.Apart, L.chunk_used, L.G, L.rstride, L.Pc,
-                       L.ystride, L.dx, L.m_out, L.nc_out, L.marg_idx, L.pc_base, ws, wss, n32, gauge);
+    hipLaunchKernelGGL(k_big_prep_P, dim3(32, L.nb), dim3(256), 0, st, L.cv, L.fv, L.b0, L.Pc, L.ystride, L.marg_idx, L.pc_base, ws, wss, n32, gauge);
+    CholArgs c1 = {};
+    c1.W = ws + w.oX1; c1.Y = ws + w.oY1; c1.xs = wss; c1.ld = w.ld1; c1.rows = 2 * n32; c1.ncols = n32;
+    c1.status = L.status + L.b0; c1.fail_bit = 4; c1.active = nullptr; c1.batch = L.nb; c1.Tb = ws + w.oT; c1.ts = wss; c1.t_slots = n32 / 32;
+    launch_chol_sweep(c1, st);
+}
+
+static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
+{
+    const int n32 = big_n32(L.ncol_cap), MP = BIG_NC;
+    const BigWs w(n32);
+    const size_t wss = bigwin_wk_doubles();
+    double* ws = L.big_wk;
+#ifdef INGVIO_ALT_KERNELS
+    static const bool no_gauge = [] { const char* e = getenv("INGVIO_INFO_GAUGE"); return e && !strcmp(e, "off"); }();
+#else
+    constexpr bool no_gauge = false;
+#endif
+    const int gauge = (!L.op.selected_variant && !no_gauge) ? 1 : 0;
+    hipLaunchKernelGGL(k_big_prep_A, dim3(32, L.nb), dim3(256), 0, st, L.cv, L.fv, L.b0, L.Apart, L.chunk_used, L.G, L.rstride, L.dx, L.m_out,
+                       L.nc_out, ws, wss, n32);
     const int* act = L.m_out;                                            // 0 = nothing accepted: every later launch skips the filter
     CholArgs c1 = {};
     c1.W = ws + w.oX1; c1.Y = ws + w.oY1; c1.xs = wss; c1.ld = w.ld1; c1.rows = 2 * n32; c1.ncols = n32;
     c1.status = L.status + L.b0; c1.fail_bit = 4; c1.active = act; c1.batch = L.nb; c1.Tb = ws + w.oT; c1.ts = wss; c1.t_slots = n32 / 32;
-    // both factorisations with ONE workgroup per filter and the matrix in registers (kernels_lmchol.hip: two launches each instead of
-    // one per 32-column panel: the sweep is 15 of the solve's 23 dependent launches)
-    // measured: SLOWER here - 0.75 vs 0.39 ms per 32 filters, 0.61 vs 0.23 for one: a single workgroup's panel takes ~5 us
-    // (13 x 16 serial pivots + two barriers), which 512 filters hide and 32 do not; the sweep's panel launches spread a
-    // panel over many CUs.  Kept selectable: INGVIO_BIG_SOLVE=regs
-#ifdef INGVIO_ALT_KERNELS
-    static const bool use_sweep = [] { const char* e = getenv("INGVIO_BIG_SOLVE"); return !(e && !strcmp(e, "regs")); }();
-#else
-    constexpr bool use_sweep = true;
-#endif
-    LmCholArgs q = {};
-    q.cv = L.cv; q.b0 = L.b0; q.nb = L.nb; q.xs = wss; q.mc = n32; q.res_row = -1; q.U = ws + w.oU; q.us = wss; q.m = act;
-    q.status = L.status + L.b0; q.fail_bit = 4; q.m_fixed = n32;
-    if (use_sweep) launch_chol_sweep(c1, st);
-    else { q.X = ws + w.oX1; q.Y = ws + w.oY1; q.ldx = w.ld1; q.carried_rows = n32; q.write_L = 1; launch_lm_chol(q, st); }
     GemmArgs g = {};
     // [A; b^T] L -> X2 rows n32 ..
     g.A = ws + w.oAB; g.sa = wss; g.lda = w.ldab; g.modeA = 0;
@@ -815,21 +850,18 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
                        n32, n32, act);
     CholArgs c2 = c1;
     c2.W = ws + w.oX2; c2.Y = ws + w.oY2; c2.ld = w.ld2; c2.rows = 3 * n32 + 32;
-    if (use_sweep) launch_chol_sweep(c2, st);
-    else { q.X = ws + w.oX2; q.Y = ws + w.oY2; q.ldx = w.ld2; q.carried_rows = 2 * n32 + 32; q.write_L = 0; launch_lm_chol(q, st); }
+    launch_chol_sweep(c2, st);
     // M = R2 R1^T (row-major, MP wide), t = R2 r1b^T
     g = GemmArgs{};
     g.A = ws + w.oY2 + 2 * n32 + 32; g.sa = wss; g.lda = w.ld2; g.modeA = 0;
     g.B = ws + w.oY2 + n32; g.sb = wss; g.ldb = w.ld2; g.modeB = 0;
     g.C = L.T; g.sc = L.mstride; g.rs = MP; g.cs = 1;
-    g.M = n32; g.N = n32; g.K = n32; g.m_lim = MP; g.n_lim = MP; g.ksplit = 1; g.active = act; g.batch = L.nb;
+    // t rides on the same launch: r1b is the row of Y2 right below R1, i.e. column n32 of the product, stored as the vector after M
+    g.M = n32; g.N = n32 + 1; g.K = n32; g.m_lim = MP; g.n_lim = n32 < MP ? n32 : MP; g.ksplit = 1; g.active = act; g.batch = L.nb;
+    g.Cx = L.T + (size_t)MP * MP; g.scx = L.mstride; g.cx_col = n32;
     launch_gemm(g, st);
-    g.B = ws + w.oY2 + 2 * n32; g.C = L.T + (size_t)MP * MP; g.rs = 1; g.cs = 0; g.N = 1; g.n_lim = 1;
-    launch_gemm(g, st);
-    if (gauge) {
-        hipLaunchKernelGGL(k_big_gauge_fix, dim3(11, L.nb), dim3(256), 0, st, L.fv, L.b0, L.T, L.mstride, ws, wss, w.oRef, act, 0);
-        hipLaunchKernelGGL(k_big_gauge_fix, dim3(1, L.nb), dim3(256), 0, st, L.fv, L.b0, L.T, L.mstride, ws, wss, w.oRef, act, 1);
-    }
+    // one launch for the reference clone's block row / column AND its 6 x 6 corner (the corner from M itself: a double sum)
+    if (gauge) hipLaunchKernelGGL(k_big_gauge_fix, dim3(12, L.nb), dim3(256), 0, st, L.fv, L.b0, L.T, L.mstride, ws, wss, w.oRef, act);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1362,6 +1394,7 @@ int launch_bigwin(const FactoredLaunch& L, hipStream_t st)
         else { if (L.stereo) launch_gate_big<true, BIG_CMAX>(L, st); else launch_gate_big<false, BIG_CMAX>(L, st); }
         return 0;
     }
+    if (L.stage == 5) { launch_big_solve_front(L, st); return 0; }      // the measurement-independent front of stage 2 (may run on a side stream)
     if (L.stage == 1) {
         const size_t sm = ((sizeof(GBBatch) + 15) / 16) * 16 + 2 * sizeof(int) * (size_t)L.fv.fmax;
         static size_t attr_sm = 0;

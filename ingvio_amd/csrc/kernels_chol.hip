@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g)
                  + sPart[2][wave][src_reg][src_lane] + sPart[3][wave][src_reg][src_lane];
         const int gi = bi * 32 + ti * 16 + row, gj = bj * 32 + tj * 16 + col;
         if (gi == gj && blockIdx.y == 0) v += dadd;
-        if (gi < g.m_lim && gj < g.n_lim) C[(size_t)gi * g.rs + (size_t)gj * g.cs] = v;
+        if (g.Cx && gj == g.cx_col) { if (gi < g.m_lim) g.Cx[(size_t)batch * g.scx + gi] = v; }
+        else if (gi < g.m_lim && gj < g.n_lim) C[(size_t)gi * g.rs + (size_t)gj * g.cs] = v;
     }
 }
 

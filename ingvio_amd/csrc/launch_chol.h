@@ -26,6 +26,8 @@ struct GemmArgs {
     double diag_add; const double* diag_add_vec;    // diag_add_vec[batch] (e.g. the per-filter measurement variance) overrides diag_add
     const int* active;
     int batch;
+    double* Cx; size_t scx; int cx_col;             // optional: column cx_col of the product goes to the VECTOR Cx[batch scx + i] instead of C (a
+                                                    // matrix-vector product riding on the GEMM as one more column of opB); Cx == nullptr: off
 };
 void launch_gemm(const GemmArgs& g, hipStream_t st);
 

@@ -3,7 +3,8 @@
 #include "dev_common.h"
 
 struct FactoredLaunch {
-    int stage;            // 0 gate, 1 gram, 2 info solve, 3 info apply (+ downdate)
+    int stage;            // 0 gate, 1 gram, 2 info solve, 3 info apply (+ downdate); large windows also 5: the part of the solve that needs
+                          // the prior only (gauge reference, [Pdd; I] -> [L; L^-T], Pc) - must have run before stage 2, may overlap 0 and 1
     int stereo;
     CovView cv;
     FrameView fv;

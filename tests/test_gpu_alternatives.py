@@ -8,7 +8,6 @@ process) that runs the parity tests covering it.  One toggle per case:
   INGVIO_GATE=4            the difference-coordinate gate with ONE feature per wave (k_feat_gate4, round 3) instead of four (k_feat_gate5)
   INGVIO_INFO_GAUGE=off    full-size symmetric solve (no reduction to difference coordinates of a reference clone)
   INGVIO_INFO_SOLVE=gj     Gauss-Jordan on A Pcc + s^2 I
-  INGVIO_BIG_SOLVE=regs    large-window solve on the register-resident factorisation (kernels_lmchol.hip) instead of the sweep
   INGVIO_APPLY_TW=2        k_info_apply with two tile columns per step
   INGVIO_LM_FRONT=split    landmark update with k_lm_build + k_lm_products (compacting) instead of the fused front
   INGVIO_LM_SOLVE=sweep    landmark / dense-H update on the Cholesky sweep out of L2 instead of the register-resident solve
@@ -30,7 +29,6 @@ CASES = [
     ("INGVIO_GATE", "3", ["tests/test_gpu_parity.py", "-k", "test_full_n249_batch_vs_oracle or test_large_window_vs_oracle or test_msckf_small"]),
     ("INGVIO_INFO_GAUGE", "off", ["tests/test_gpu_parity.py", "-k", "test_full_n249_batch_vs_oracle or test_large_window_vs_oracle or test_window_size_classes"]),
     ("INGVIO_INFO_SOLVE", "gj", ["tests/test_gpu_parity.py", "-k", "test_full_n249_batch_vs_oracle or test_window_size_classes"]),
-    ("INGVIO_BIG_SOLVE", "regs", ["tests/test_gpu_parity.py", "-k", "test_large_window or test_config5_stress"]),
     ("INGVIO_APPLY_TW", "2", ["tests/test_gpu_parity.py", "-k", "test_full_n249_batch_vs_oracle or test_window_size_classes or test_consecutive_frames"]),
     ("INGVIO_LM_FRONT", "split", ["tests/test_landmark_batch.py"]),
     ("INGVIO_LM_SOLVE", "sweep", ["tests/test_landmark_batch.py"]),
