@@ -226,9 +226,10 @@ STAGE_KERNELS = {
 }
 STAGE_KERNELS_BIG = {                                                      # windows of 17..36 clones (kernels_bigwin.hip)
     "k_feat_gate3": (("k_feat_gate4_big",), ("k_feat_gate3_big",)), "k_feat_gram2": (("k_feat_gram_big",),),
-    "k_info_update": (("k_big_prep", "k_chol_first", "k_chol_step", "k_chol_carried", "k_gemm", "k_copy_rows", "k_big_gauge_fix"),
-                      ("k_big_prep", "k_chol_first", "k_chol_step", "k_chol_carried", "k_gemm", "k_copy_rows"), ("k_info_update_big",)),
-    "k_info_apply": (("k_apply_T64", "k_apply_sym64"), ("k_apply_T", "k_apply_sym"), ("k_info_apply_big",)),
+    # round 5: the set-up is k_big_prep_P (prior only, on the side stream together with the first sweep) + k_big_prep_A
+    "k_info_update": (("k_big_prep_P", "k_big_prep_A", "k_chol_first", "k_chol_step", "k_chol_carried", "k_gemm", "k_copy_rows", "k_big_gauge_fix"),
+                      ("k_big_prep_P", "k_big_prep_A", "k_chol_first", "k_chol_step", "k_chol_carried", "k_gemm", "k_copy_rows"), ("k_info_update_big",)),
+    "k_info_apply": (("k_apply_T64b", "k_apply_sym64b"), ("k_apply_T", "k_apply_sym"), ("k_info_apply_big",)),
 }
 
 
@@ -268,7 +269,7 @@ def kernel_that_ran(stage, cand, C, stereo=True):
     if stage == "k_feat_gate3":
         if not stereo:
             return "k_feat_gate3%s<%d>" % ("_big" if C > 16 else "", C)
-        cls = 6 if C <= 6 else 11 if C <= 11 else 16 if C <= 16 else 24 if C <= 24 else 32 if C <= 32 else 36      # launch_factored / launch_bigwin classes
+        cls = 6 if C <= 6 else 11 if C <= 11 else 16 if C <= 16 else 24 if C <= 24 else 28 if C <= 28 else 30 if C <= 30 else 32 if C <= 32 else 36      # launch_factored / launch_bigwin classes
         return "%s<%d>" % (cand[0], cls)
     return name
 
