@@ -63,12 +63,16 @@ __device__ __forceinline__ void block64_to_lds(const b64_d4 (&c)[4], double (*sv
 //      `s_waitcnt vmcnt` most of the time (k_apply_T64: 111 us where its MFMAs need 37).
 struct Block64Lds2 { double a[2][16][68]; double b[2][16][68]; };
 
-template <class FA, class FB>
+// KA / KB: staging role of the operand.  false: a thread takes ONE ROW's element at 4 values of k, consecutive threads consecutive
+// ROWS (coalesced when the operand is row-contiguous in memory: element (r, k) at r + k ld); true: a thread takes 4 CONSECUTIVE k of
+// one row, four threads a row's 16 k (coalesced when the operand is k-contiguous: element (r, k) at k + r ld).
+template <bool KA = false, bool KB = false, class FA, class FB>
 __device__ __forceinline__ void block64_mma2(Block64Lds2& s, int K, FA loadA, FB loadB, bool quad_on, b64_d4 (&c)[4])
 {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const int wi = wave >> 1, wj = wave & 1;
-    const int sr = tid & 63, sk = tid >> 6;
+    const int ar = KA ? tid >> 2 : tid & 63, ak0 = KA ? 4 * (tid & 3) : tid >> 6, aks = KA ? 1 : 4;      // row, first k, k step of this thread's 4 elements
+    const int br = KB ? tid >> 2 : tid & 63, bk0 = KB ? 4 * (tid & 3) : tid >> 6, bks = KB ? 1 : 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) c[q] = b64_d4{ 0.0, 0.0, 0.0, 0.0 };
     const int nch = (K + 15) >> 4;
@@ -76,11 +80,19 @@ __device__ __forceinline__ void block64_mma2(Block64Lds2& s, int K, FA loadA, FB
     double ra0[4], rb0[4], ra1[4], rb1[4];
     auto fetch0 = [&](int ch) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { ra0[u] = loadA(sr, 16 * ch + sk + 4 * u); rb0[u] = loadB(sr, 16 * ch + sk + 4 * u); }
+        for (int u = 0; u < 4; ++u) { ra0[u] = loadA(ar, 16 * ch + ak0 + aks * u); rb0[u] = loadB(br, 16 * ch + bk0 + bks * u); }
     };
     auto fetch1 = [&](int ch) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { ra1[u] = loadA(sr, 16 * ch + sk + 4 * u); rb1[u] = loadB(sr, 16 * ch + sk + 4 * u); }
+        for (int u = 0; u < 4; ++u) { ra1[u] = loadA(ar, 16 * ch + ak0 + aks * u); rb1[u] = loadB(br, 16 * ch + bk0 + bks * u); }
+    };
+    auto put0 = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s.a[buf][ak0 + aks * u][ar] = ra0[u]; s.b[buf][bk0 + bks * u][br] = rb0[u]; }
+    };
+    auto put1 = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s.a[buf][ak0 + aks * u][ar] = ra1[u]; s.b[buf][bk0 + bks * u][br] = rb1[u]; }
     };
     auto mma = [&](int buf) {
         if (!quad_on) return;
@@ -99,20 +111,17 @@ __device__ __forceinline__ void block64_mma2(Block64Lds2& s, int K, FA loadA, FB
     const int last = nch - 1;
     fetch0(0);
     fetch1(min(1, last));
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { s.a[0][sk + 4 * u][sr] = ra0[u]; s.b[0][sk + 4 * u][sr] = rb0[u]; }
+    put0(0);
     fetch0(min(2, last));
     lds_barrier();
     int k = 0;
     for (; k + 1 < nch; k += 2) {
         mma(0);                                                         // chunk k from buffer 0
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { s.a[1][sk + 4 * u][sr] = ra1[u]; s.b[1][sk + 4 * u][sr] = rb1[u]; }      // chunk k + 1
+        put1(1);                                                        // chunk k + 1
         fetch1(min(k + 3, last));
         lds_barrier();
         mma(1);                                                         // chunk k + 1 from buffer 1
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { s.a[0][sk + 4 * u][sr] = ra0[u]; s.b[0][sk + 4 * u][sr] = rb0[u]; }      // chunk k + 2 (or a repeat of the last)
+        put0(0);                                                        // chunk k + 2 (or a repeat of the last)
         fetch0(min(k + 4, last));
         lds_barrier();
     }

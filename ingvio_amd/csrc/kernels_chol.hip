@@ -13,6 +13,7 @@
 // stacks (the thin QR of RemoveLostUpdate.cpp:376-397).
 #include "launch_chol.h"
 #include "dev_common.h"
+#include "block64.h"
 
 typedef double double4_f __attribute__((ext_vector_type(4)));
 
@@ -22,6 +23,18 @@ namespace {
 // zeroed by a factor: as `ok ? P[..] : 0.0` every element became its own exec-masked basic block, the compiler lost count of the
 // loads in flight across the branches and drained the queue (s_waitcnt vmcnt(0)) before every use - the next chunk's prefetch under
 // this chunk's MFMAs did not exist (round 5; the same trap as block64.h).  Operands are finite inside their range, so 0 * x is 0.
+// XCD-aware decode of a 1-D grid of 8 * ceil(nbatch / 8) * per workgroups (workgroup w runs on XCD w % 8): XCD x takes the batch
+// elements x, x + 8, ... one after the other, all `per` blocks of an element on the same XCD (its L2 then serves the element's
+// operands to every block).  false: beyond the batch.
+__device__ __forceinline__ bool xcd_decode(int per, int nbatch, int& batch, int& blk)
+{
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    batch = xcd + 8 * (slot / per);
+    blk = slot % per;
+    return batch < nbatch;
+}
+static inline unsigned xcd_grid(int per, int nbatch) { return 8u * (unsigned)((nbatch + 7) / 8) * (unsigned)per; }
+
 template <int MODE>
 __device__ __forceinline__ double ld_op(const double* __restrict__ P, int ld, int i, int k, int I, int K, const double* __restrict__ Px, int ix)
 {
@@ -40,22 +53,28 @@ template <int MA, int MB>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs g)
 {
     __shared__ double sPart[4][4][4][64];                               // [wave][tile][reg][lane]
-    const int batch = blockIdx.z;
+    // XCD-aware order (round 5; workgroup w runs on XCD w % 8): all blocks of ONE batch element on the same XCD, one element after the
+    // other - its operands (0.3-0.9 MB for the large-window solve) then come from that XCD's 4 MB L2 once, instead of once per 32 x 32
+    // block from MALL / HBM: the three GEMMs of the solve moved 389 MB per 32 filters for 13 MB of operands (FETCH_SIZE, r05 PMC)
+    const int nbj = (g.N + 31) / 32, nbi = (g.M + 31) / 32;
+    const int blocks = g.lower ? nbi * (nbi + 1) / 2 : nbi * nbj, per = blocks * g.ksplit;
+    int batch, rem;
+    if (!xcd_decode(per, g.batch, batch, rem)) return;
+    const int ky = rem / blocks, bx = rem - ky * blocks;
     if (g.active && !g.active[batch]) return;
-    const int nbj = (g.N + 31) / 32;
     int bi, bj;
-    if (g.lower) {                                                      // blockIdx.x enumerates bi >= bj
-        int t = blockIdx.x; bi = 0;
+    if (g.lower) {                                                      // bx enumerates bi >= bj
+        int t = bx; bi = 0;
         while (t >= bi + 1) { t -= bi + 1; ++bi; }
         bj = t;
-    } else { bi = blockIdx.x / nbj; bj = blockIdx.x - bi * nbj; }
+    } else { bi = bx / nbj; bj = bx - bi * nbj; }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const double* A = g.A + (size_t)batch * g.sa + (g.a_sel ? (size_t)g.a_sel[batch] * g.a_sel_stride : 0);
     const double* B = g.B + (size_t)batch * g.sb;
     // K range of this workgroup, then of this wave (multiples of 16)
     const int kchunks = (g.K + 15) / 16;
     const int per_wg = (kchunks + g.ksplit - 1) / g.ksplit;
-    const int c_lo = blockIdx.y * per_wg, c_hi = min(kchunks, c_lo + per_wg);
+    const int c_lo = ky * per_wg, c_hi = min(kchunks, c_lo + per_wg);
     const int per_wave = (max(0, c_hi - c_lo) + 3) / 4;
     const int w_lo = c_lo + wave * per_wave, w_hi = min(c_hi, w_lo + per_wave);
     const int i0 = bi * 32 + l15, i1 = i0 + 16, j0 = bj * 32 + l15, j1 = j0 + 16;
@@ -93,7 +112,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g)
     __syncthreads();
     // wave w finishes tile w: (ti, tj) = (w >> 1, w & 1).  Element (row, col) of a tile sits in reg row >> 2 of lane (row & 3) 16 + col.
     const int ti = wave >> 1, tj = wave & 1;
-    double* C = g.C + (size_t)batch * g.sc + (size_t)blockIdx.y * g.csplit;
+    double* C = g.C + (size_t)batch * g.sc + (size_t)ky * g.csplit;
     const bool row_fast = g.rs <= g.cs;                                 // store along the dimension that is contiguous in memory
     const double dadd = g.diag_add_vec ? g.diag_add_vec[batch] : g.diag_add;
 #pragma unroll
@@ -103,7 +122,53 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g)
         double v = sPart[0][wave][src_reg][src_lane] + sPart[1][wave][src_reg][src_lane]
                  + sPart[2][wave][src_reg][src_lane] + sPart[3][wave][src_reg][src_lane];
         const int gi = bi * 32 + ti * 16 + row, gj = bj * 32 + tj * 16 + col;
-        if (gi == gj && blockIdx.y == 0) v += dadd;
+        if (gi == gj && ky == 0) v += dadd;
+        if (g.Cx && gj == g.cx_col) { if (gi < g.m_lim) g.Cx[(size_t)batch * g.scx + gi] = v; }
+        else if (gi < g.m_lim && gj < g.n_lim) C[(size_t)gi * g.rs + (size_t)gj * g.cs] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same product on 64 x 64 blocks with the operand panels staged through LDS two chunks ahead (block64_mma2): for products that
+// are large enough to have a K loop worth pipelining (the three GEMMs of the large-window solve: 192^3 per filter).  k_gemm gives
+// every 32 x 32 block its own pass over two full-K panels, four waves deep in K with a reduction through LDS: 42 workgroups per filter
+// and product, each three dependent memory round trips long; here 12 workgroups per filter walk K once.  ksplit must be 1.
+// MA / MB as in k_gemm; an operand that is k-contiguous in memory (mode 1) is staged by threads that take 4 consecutive k.
+// ---------------------------------------------------------------------------------------------
+template <int MA, int MB>
+__global__ __launch_bounds__(256) void k_gemm64(GemmArgs g)
+{
+    __shared__ union { Block64Lds2 ab; double sV[4][32][33]; } sh;
+    const int nbj = (g.N + 63) / 64, nbi = (g.M + 63) / 64;
+    const int blocks = g.lower ? nbi * (nbi + 1) / 2 : nbi * nbj;
+    int batch, bx;
+    if (!xcd_decode(blocks, g.batch, batch, bx)) return;
+    if (g.active && !g.active[batch]) return;
+    int bi, bj;
+    if (g.lower) {
+        int t = bx; bi = 0;
+        while (t >= bi + 1) { t -= bi + 1; ++bi; }
+        bj = t;
+    } else { bi = bx / nbj; bj = bx - bi * nbj; }
+    const double* A = g.A + (size_t)batch * g.sa + (g.a_sel ? (size_t)g.a_sel[batch] * g.a_sel_stride : 0);
+    const double* B = g.B + (size_t)batch * g.sb;
+    b64_d4 c[4];
+    block64_mma2<MA == 1, MB == 1>(sh.ab, (g.K + 15) & ~15,
+                                   [&](int r, int k) { return ld_op<MA>(A, g.lda, 64 * bi + r, k, g.M, g.K, g.Ax, g.ax); },
+                                   [&](int r, int k) { return ld_op<MB>(B, g.ldb, 64 * bj + r, k, g.N, g.K, g.Bx, g.bx); }, true, c);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, wi = wave >> 1, wj = wave & 1;
+    block64_to_lds(c, sh.sV[wave]);                                     // the wave's 32 x 32 quadrant, then stores along the contiguous dimension
+    double* C = g.C + (size_t)batch * g.sc;
+    const bool row_fast = g.rs <= g.cs;
+    const double dadd = g.diag_add_vec ? g.diag_add_vec[batch] : g.diag_add;
+    const int r0 = 64 * bi + 32 * wi, c0 = 64 * bj + 32 * wj;
+#pragma unroll 4
+    for (int e = lane; e < 1024; e += 64) {
+        const int rr = row_fast ? e & 31 : e >> 5, cc = row_fast ? e >> 5 : e & 31;
+        const int gi = r0 + rr, gj = c0 + cc;
+        double v = sh.sV[wave][rr][cc];
+        if (gi == gj) v += dadd;
+        if (g.lower && (gj >> 5) > (gi >> 5)) continue;                 // what k_gemm's lower mode writes: the 32 x 32 blocks on and below the diagonal
         if (g.Cx && gj == g.cx_col) { if (gi < g.m_lim) g.Cx[(size_t)batch * g.scx + gi] = v; }
         else if (gi < g.m_lim && gj < g.n_lim) C[(size_t)gi * g.rs + (size_t)gj * g.cs] = v;
     }
@@ -298,23 +363,24 @@ __global__ __launch_bounds__(256) void k_chol_first(CholArgs a)
 // factorises it on the spot (one wave, factor32) and leaves T_k+1 for the next launch.  The last panel has no trailing blocks:
 // its launch only scales the rows below.  grid = (blocks, batch), 256 threads.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chol_step(CholArgs a, int k)
+__global__ __launch_bounds__(256) void k_chol_step(CholArgs a, int k, int per)
 {
     __shared__ double sT[32][33];
     __shared__ double sUi[32][33];
     __shared__ double sUj[32][33];
     __shared__ double sDI[64][33];                                       // Y_i (rows 0..31), Y_j (rows 32..63); later [D; I]
     __shared__ __attribute__((aligned(16))) double sC[2][32];
-    const int batch = blockIdx.y;
+    int batch, blk;
+    if (!xcd_decode(per, a.batch, batch, blk)) return;
     if (a.active && !a.active[batch]) return;
     const int nbr = a.rows >> 5, ncb = a.ncols >> 5, ld = a.ld;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     // block of this workgroup: column blocks j = k+1 .. ncb-1, rows i = j .. nbr-1; or (last panel) rows only
     int i, j;
     const bool tail_only = k + 1 >= ncb;
-    if (tail_only) { i = k + 1 + blockIdx.x; j = -1; }
+    if (tail_only) { i = k + 1 + blk; j = -1; }
     else {
-        int t = blockIdx.x; j = k + 1;
+        int t = blk; j = k + 1;
         while (t >= nbr - j) { t -= nbr - j; ++j; }
         i = j + t;
     }
@@ -392,15 +458,16 @@ __global__ __launch_bounds__(256) void k_chol_step(CholArgs a, int k)
 // re-write the block's trailing part once per panel (10 MB per filter for a 224-column S with 288 carried rows; here 1.3 MB).
 // grid = (carried block rows, batch), 256 threads; needs a.t_slots >= ncols / 32 (every T_k kept).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chol_carried(CholArgs a)
+__global__ __launch_bounds__(256) void k_chol_carried(CholArgs a, int per)
 {
     extern __shared__ __attribute__((aligned(16))) double sRow[];          // [32][ncols + 4]: W_i, overwritten panel by panel with Y_i (stride = 4 mod 32: the A-operand reads spread over the banks)
     __shared__ double sU[32][36];
     __shared__ double sT[32][36];
-    const int batch = blockIdx.y;
+    int batch, blk;
+    if (!xcd_decode(per, a.batch, batch, blk)) return;
     if (a.active && !a.active[batch]) return;
     const int ncb = a.ncols >> 5, ld = a.ld, lds = a.ncols + 4;
-    const int i = ncb + blockIdx.x;
+    const int i = ncb + blk;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const int ti = wave >> 1, tj = wave & 1;
     const double* W = a.W + (size_t)batch * a.xs;
@@ -477,9 +544,18 @@ void launch_gemm(const GemmArgs& g, hipStream_t st)
 {
     const int nbi = (g.M + 31) / 32, nbj = (g.N + 31) / 32;
     const int blocks = g.lower ? nbi * (nbi + 1) / 2 : nbi * nbj;
-    const dim3 grid(blocks, g.ksplit < 1 ? 1 : g.ksplit, g.batch);
     GemmArgs h = g;
     if (h.ksplit < 1) h.ksplit = 1;
+    if (h.ksplit == 1 && g.K >= 96 && g.M >= 96 && g.N >= 64) {          // a K loop worth pipelining: 64 x 64 blocks (k_gemm64)
+        const int n64i = (g.M + 63) / 64, n64j = (g.N + 63) / 64;
+        const dim3 grid64(xcd_grid(g.lower ? n64i * (n64i + 1) / 2 : n64i * n64j, g.batch));
+        if (g.modeA == 0 && g.modeB == 0) hipLaunchKernelGGL((k_gemm64<0, 0>), grid64, dim3(256), 0, st, h);
+        else if (g.modeA == 0 && g.modeB == 1) hipLaunchKernelGGL((k_gemm64<0, 1>), grid64, dim3(256), 0, st, h);
+        else if (g.modeA == 1 && g.modeB == 0) hipLaunchKernelGGL((k_gemm64<1, 0>), grid64, dim3(256), 0, st, h);
+        else hipLaunchKernelGGL((k_gemm64<1, 1>), grid64, dim3(256), 0, st, h);
+        return;
+    }
+    const dim3 grid(xcd_grid(blocks * h.ksplit, g.batch));             // XCD-aware 1-D order, decoded in the kernel
     if (g.modeA == 0 && g.modeB == 0) hipLaunchKernelGGL((k_gemm<0, 0>), grid, dim3(256), 0, st, h);
     else if (g.modeA == 0 && g.modeB == 1) hipLaunchKernelGGL((k_gemm<0, 1>), grid, dim3(256), 0, st, h);
     else if (g.modeA == 1 && g.modeB == 0) hipLaunchKernelGGL((k_gemm<1, 0>), grid, dim3(256), 0, st, h);
@@ -520,12 +596,12 @@ void launch_chol_sweep(const CholArgs& a0, hipStream_t st)
         int blocks = 0;
         if (k + 1 >= ncb) blocks = nbr - (k + 1);
         else for (int j = k + 1; j < ncb; ++j) blocks += nbr - j;
-        if (blocks > 0) hipLaunchKernelGGL(k_chol_step, dim3(blocks, a.batch), dim3(256), 0, st, a, k);
+        if (blocks > 0) hipLaunchKernelGGL(k_chol_step, dim3(xcd_grid(blocks, a.batch)), dim3(256), 0, st, a, k, blocks);
     }
     if (split) {
         static size_t attr = 0;
         if (lds_row > attr) { hipFuncSetAttribute((const void*)k_chol_carried, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row); attr = lds_row; }
         a.rows = rows_all;
-        hipLaunchKernelGGL(k_chol_carried, dim3((rows_all - a.ncols) / 32, a.batch), dim3(256), lds_row, st, a);
+        hipLaunchKernelGGL(k_chol_carried, dim3(xcd_grid((rows_all - a.ncols) / 32, a.batch)), dim3(256), lds_row, st, a, (rows_all - a.ncols) / 32);
     }
 }
