@@ -16,7 +16,7 @@ key() { case $1 in
   c2lm) echo c2_B512_F150_C11_N249_lmreal;; esac; }
 for w in $W; do
   PS=""
-  case $w in c5|c5lit) PS="k_chol_step=11,k_chol_first=2,k_gemm=3";; esac
+  case $w in c5|c5lit) PS="k_chol_step=11,k_chol_first=2,k_gemm64=3";; esac
   T0=$(date +%s)
   PER_STEP=$PS bash tools/gpu_counters.sh $w $(key $w) $(args $w)
   EXTRA="--no-aux --no-latency"
