@@ -36,6 +36,10 @@ STREAMS = {
     # key-frame mode at the window of the reference's shipped stereo config (config/fw_zed2i_f9p/ingvio_stereo.yaml: 21 poses)
     "kf21": ("feats=100,clones=21,life=19,cohort=0,frames=70,key=1,outlier_every=7", ""),
     # sliding-window mode, 21 poses, interval 6 -> 4 stamps
+    # BASELINE configs[0] is MONO (sports-field mono, max_pts_frame 150, 11 poses): the mono callback (IngvioFilter.cpp:124-250), min 4
+    # observations per RemoveLost feature (RemoveLostUpdate.cpp:51), 2 rows per observation; longer tracks (a mono point needs parallax)
+    "kf11_mono": ("feats=150,clones=11,life=10,cohort=0,frames=70,key=1,stereo=0,outlier_every=6", ""),
+    "sw11_mono": ("feats=150,clones=11,life=13,cohort=0,frames=70,key=0,stereo=0,outlier_every=6", "frame_select_interval: 5\n"),
     "sw21": ("feats=100,clones=21,life=25,cohort=0,frames=70,key=0,outlier_every=7", "frame_select_interval: 6\n"),
 }
 

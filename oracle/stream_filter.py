@@ -20,7 +20,7 @@ clones are selected, when anchors change and what is erased:
 
 The numerical kernels behind it are the oracle's (oracle/ingvio_oracle.c): orc_imu_transition, orc_propagate_cov,
 orc_augment_clone, orc_triangulate, orc_msckf_update (per-feature Jacobian, nullspace, chi^2 gate, stacking, compression, EKF
-update), orc_marginalize, the retractions.  Scope: stereo, MSCKF features only (max_landmark_features = 0, enable_gnss = 0 — the
+update), orc_marginalize, the retractions.  Scope: mono and stereo, MSCKF features only (max_landmark_features = 0, enable_gnss = 0 — the
 shipped configurations of the visual part).  Every processed camera frame yields a trace record (see `Trace`)."""
 import math
 
@@ -120,7 +120,8 @@ class Filter:
         p.update(parse_params(overrides))
         g = lambda k, d: float(p.get(k, d))
         gi = lambda k, d: int(float(p.get(k, d)))
-        assert gi("cam_nums", 2) == 2 and gi("enable_gnss", 1) == 0 and gi("max_landmark_features", 0) == 0, "scope: stereo, visual only"
+        assert gi("enable_gnss", 1) == 0 and gi("max_landmark_features", 0) == 0, "scope: visual only, MSCKF features"
+        self.stereo = gi("cam_nums", 2) == 2                             # IngvioFilter.cpp:100-112: cam_nums 1 -> the mono callback
         self.max_sw = gi("max_sliding_window_poses", 27)
         self.is_key_frame = gi("is_key_frame", 1)
         self.sigma = [g("noise_gyro", 0.004), g("noise_accel", 0.08), g("noise_bias_gyro", 0.0002), g("noise_bias_accel", 0.008)]
@@ -306,11 +307,12 @@ class Filter:
         self.augment()
 
     # ---- map server -----------------------------------------------------------------------------------------------------
-    def collect_stereo(self, feats):                                     # MapServerManager.cpp:146-185, 203-217
+    def collect_meas(self, feats):                                       # MapServerManager.cpp:105-217 (mono and stereo twins)
         ts = self.timestamp
         assert ts in self.sw
-        for fid, u0, v0, u1, v1 in feats:
-            fid = int(fid)
+        for rec in feats:
+            fid, u0, v0 = int(rec[0]), rec[1], rec[2]
+            u1, v1 = (rec[3], rec[4]) if self.stereo else (0.0, 0.0)
             fi = self.map.get(fid)
             if fi is None:
                 fi = Feature()
@@ -340,7 +342,7 @@ class Filter:
                 mask |= 1 << s
         if mask == 0:
             return False
-        ok, pf = orc.triangulate(cR, cp, mask, uv, True, self.R_cl2cr, self.t_cl2cr, **self.tri)
+        ok, pf = orc.triangulate(cR, cp, mask, uv, self.stereo, self.R_cl2cr, self.t_cl2cr, **self.tri)      # :274-307 mono / :309-341 stereo
         if not ok or np.any(np.isnan(pf)):
             return False
         fi.num_tri += 1
@@ -360,7 +362,7 @@ class Filter:
         F = len(ids)
         fr = dict(clone_idx=[c.idx for _, c in sw], clone_R=np.stack([c.R for _, c in sw]), clone_p=np.stack([c.p for _, c in sw]),
                   pf=np.zeros((F, 3)), anchor=np.zeros(F, dtype=np.int32), obs_mask=np.zeros(F, dtype=np.uint64), uv=np.zeros((F, C, 4)),
-                  dof=np.zeros(F, dtype=np.int32), stereo=1, R_cl2cr=self.R_cl2cr, t_cl2cr=self.t_cl2cr, noise=self.noise)
+                  dof=np.zeros(F, dtype=np.int32), stereo=1 if self.stereo else 0, R_cl2cr=self.R_cl2cr, t_cl2cr=self.t_cl2cr, noise=self.noise)
         max_dof = 1
         for j, fid in enumerate(ids):
             fi = self.map[fid]
@@ -387,7 +389,7 @@ class Filter:
         for fid in sorted(self.map):
             fi = self.map[fid]
             if fi.is_to_marg:
-                if self.triangulate(fi) and len(fi.obs) >= 3:
+                if self.triangulate(fi) and len(fi.obs) >= (3 if self.stereo else 4):        # RemoveLostUpdate.cpp:287 / :51
                     update_ids.append(fid)
                 else:
                     direct.append(fid)
@@ -510,8 +512,9 @@ class Filter:
         tr["invalid_erased"] = gone
 
     # ---- the camera callback ----------------------------------------------------------------------------------------------
-    def callback_stereo(self, stamp, feats):                             # IngvioFilter.cpp:252-379
-        """feats: iterable of (id, u0, v0, u1, v1).  Returns the frame's trace dict, or None when the callback returned early."""
+    def callback_frame(self, stamp, feats):                              # IngvioFilter.cpp:252-379 (stereo) / :124-250 (mono): the same sequence
+        """feats: iterable of (id, u0, v0, u1, v1) or, mono, (id, u0, v0).  Returns the frame's trace dict, or None when the callback
+        returned early."""
         if not self.has_image_come:
             self.has_image_come = True
             return None
@@ -523,7 +526,7 @@ class Filter:
         if self.timestamp < stamp:
             return None
         tr = dict(stamp=stamp)
-        self.collect_stereo(feats)
+        self.collect_meas(feats)
         self.remove_lost_update(tr)
         tr["marg_stamps"] = []
         tr["clean_erased"] = []
@@ -636,10 +639,11 @@ def play_recording(path, overrides="", max_frames=None):
             elif typ == 1:
                 v = struct.unpack("<6d", payload)
                 flt.callback_imu(to_sec(ns), v[0:3], v[3:6])
-            elif typ == 3:
+            elif typ in (2, 3):
                 cnt = struct.unpack_from("<I", payload)[0]
-                feats = [struct.unpack_from("<Q4d", payload, 4 + 40 * i) for i in range(cnt)]
-                tr = flt.callback_stereo(to_sec(ns), feats)
+                feats = [struct.unpack_from("<Q4d", payload, 4 + 40 * i) for i in range(cnt)] if typ == 3 else \
+                        [struct.unpack_from("<Q2d", payload, 4 + 24 * i) for i in range(cnt)]
+                tr = flt.callback_frame(to_sec(ns), feats)
                 if tr is not None:
                     traces.append(tr)
                     if max_frames and len(traces) >= max_frames:

@@ -324,6 +324,37 @@ def test_config3_in_frame_gnss_vs_oracle(orc, strong_reject, window):
     ctx.close()
 
 
+def test_strip_restore_survives_a_separate_gnss_pass(orc):
+    """after a fused frame step the prior survives in the untouched ping-pong half up to the propagation strips, and a
+    following frame_run(restore_prior) only rewrites those strips - also when a SEPARATE GNSS pass (k_downdate, in place in the live
+    half) ran in between.  frame_run(restore) -> gnss_run -> frame_run(restore) must give exactly what a frame step from a full
+    restore gives."""
+    from ingvio_amd import capi, host, synth
+    nb = 3
+    ctx = capi.Context(batch=nb, n_max=256, c_max=11, f_max=150, m_max=64)
+    cases = []
+    for b in range(nb):
+        flt, step, frame, info = synth.build_case(lambda P, b=b: capi.DeviceCov(ctx, b, P), host.imu_transition, seed=360 + b)
+        cases.append((flt, step, frame, info, synth.make_gnss(np.random.default_rng(960 + b), flt)))
+    table = cases[0][2]["chi2_table"]
+    blocks = [host.gnss_rows(c[4]) for c in cases]
+    ctx.snapshot()
+    ctx.frame_stage(0, [c[1] for c in cases], [c[2] for c in cases], cases[0][1]["sigma"], 1, 0.2, 0.2)
+    ctx.frame_run(restore_prior=True)
+    ref = [ctx.cov_get(b) for b in range(nb)]                     # the frame step from the full restore
+    ctx.gnss_stage(0, blocks, table, gate_rows=True)
+    ctx.gnss_run()                                                # separate pass: changes the live half only
+    assert not np.array_equal(ctx.cov_get(0), ref[0])
+    ctx.frame_run(restore_prior=True)                             # strips only (the shortcut under test)
+    for b in range(nb):
+        assert np.array_equal(ctx.cov_get(b), ref[b]), b
+    ctx.restore()                                                 # and against a FULL restore followed by the same step
+    ctx.frame_run(restore_prior=True)
+    for b in range(nb):
+        assert np.array_equal(ctx.cov_get(b), ref[b]), b
+    ctx.close()
+
+
 def test_in_frame_gnss_stage_is_consumed_by_one_frame(orc):
     """an in-frame GNSS stage belongs to ONE frame.  A non-restoring ingvio_frame_run applies it and consumes it: the
     results stay fetchable, a second frame run (new frame staged, no new GNSS stage) must NOT apply the old rows again, and a fetch

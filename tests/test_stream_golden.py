@@ -1,7 +1,7 @@
 """Stream-level parity of the drop-in path: the C++ shim's callbacks on the device against the golden streams.
 
-tests/golden/stream_*.npz hold, for every processed camera frame of five synthetic streams (key-frame and sliding-window mode, 11
-and 21 clones, the RemoveLost cap as written and lifted), what an INDEPENDENT Python transcription of the reference's policy layer
+tests/golden/stream_*.npz hold, for every processed camera frame of seven synthetic streams (key-frame and sliding-window mode, 11
+and 21 clones, the RemoveLost cap as written and lifted, stereo and mono), what an INDEPENDENT Python transcription of the reference's policy layer
 (oracle/stream_filter.py: IngvioFilter::callbackStereoFrame, RemoveLost / SwMarg / Keyframe selection, anchor change, observation
 cleaning, eraseInvalidFeatures, marginalisation) decided while driving the CPU oracle, and the state it ended the frame with.
 `ingvio_replay --synth <spec> --trace` plays the same SplitMix64 stream through IngvioFilter on the device.  Compared per frame:
@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 TOOL = os.path.join(ROOT, "ingvio_amd", "lib", "ingvio_replay")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-STREAMS = ["kf11", "kf11_lifted", "sw11", "kf21", "sw21"]
+STREAMS = ["kf11", "kf11_lifted", "sw11", "kf21", "sw21", "kf11_mono", "sw11_mono"]      # the last two: the MONO callback (BASELINE configs[0])
 POSE_TOL = 1e-9
 COV_TOL = 1e-6
 
