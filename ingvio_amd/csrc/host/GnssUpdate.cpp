@@ -72,6 +72,7 @@ int GnssUpdate::updateTrackedSys(std::shared_ptr<State> state, const GnssResidua
 {
     if (!state->_state_params._enable_gnss) return 0;
     const int nsat = (int)g.sys.size();
+    _last_keep.clear();
     if (nsat <= 0) return 0;
     if (state->_gnss.find(State::YOF) == state->_gnss.end() || state->_gnss.find(State::FS) == state->_gnss.end()) return 0;   // checkGnssStates
     int idx_cb[4] = { -1, -1, -1, -1 };
@@ -96,7 +97,9 @@ int GnssUpdate::updateTrackedSys(std::shared_ptr<State> state, const GnssResidua
     const int b = StateManager::filterIndex(state);
     VecXd dx(ingvio_ldp(ctx), 0.0);
     int used = 0, status = 0;
-    const int rc = ingvio_gnss_update_batch(ctx, b, 1, &blk, &o, dx.data(), &used, nullptr, &status);      // gates + ekfUpdate, one round trip
+    std::vector<int> keep((size_t)ingvio_mld(ctx), 0);
+    const int rc = ingvio_gnss_update_batch(ctx, b, 1, &blk, &o, dx.data(), &used, keep.data(), &status);      // gates + ekfUpdate, one round trip
+    _last_keep.assign(keep.begin(), keep.begin() + rows);                                              // per candidate row: survived its gate (trace)
     if (rc < 0) {
         std::cout << "[GnssUpdate]: device update failed (" << rc << "): " << ingvio_last_error(ctx) << std::endl;
         std::exit(EXIT_FAILURE);

@@ -160,7 +160,11 @@ public:
     GnssResiduals residualsAt(std::shared_ptr<State> state, const GnssMeas& gnss_meas, const GvioAlignment& aligner,
                               const double* cb_override = nullptr, const double* fs_override = nullptr);
 
+    const std::vector<int>& lastKeep() const { return _last_keep; }
+    void clearLastKeep() { _last_keep.clear(); }      // candidate rows of the last updateTrackedSys that passed their per-row gate
+
 protected:
+    std::vector<int> _last_keep;
     double _psr_noise_amp, _dopp_noise_amp;
     bool _is_gnss_chi2_test, _is_gnss_strong_reject, _is_adjust_yof;
 };

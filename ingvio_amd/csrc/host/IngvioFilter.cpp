@@ -27,6 +27,7 @@ IngvioFilter::IngvioFilter(const IngvioParams& params, std::shared_ptr<Triangula
 void IngvioFilter::gnssBlock(double stamp)
 {
     _last_gnss_rows = 0;
+    _gnss_update->clearLastKeep();
     if (!_filter_params._enable_gnss) return;
     GnssMeas gnss_meas;
     SppMeas spp_meas;

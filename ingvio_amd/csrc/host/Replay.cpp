@@ -313,6 +313,9 @@ struct FileSink : SynthSink {
     void stereo(const msg::StereoFrame& m) override { w.stereo(m); }
     void mono(const msg::MonoFrame& m) override { w.mono(m); }
     void truth(double stamp, const double p[3], const double q[4]) override { w.truth(stamp, p, q); }
+    void gnss(const GnssMeas& m) override { w.gnss(m); }
+    void spp(const SppMeas& m) override { w.spp(m); }
+    void alignment(const GvioAlignment& a, double stamp) override { w.alignment(a, stamp); }
 };
 
 struct FilterSink : SynthSink {
@@ -332,6 +335,9 @@ struct FilterSink : SynthSink {
         if (fp._enable_gnss) filter->gnssSync()->setSync();
     }
     void imu(const msg::Imu& m) override { if (filter) filter->callbackIMU(m); }
+    void gnss(const GnssMeas& m) override { if (filter) filter->callbackGnssMeas(m); }
+    void spp(const SppMeas& m) override { if (filter) filter->callbackSppMeas(m); }
+    void alignment(const GvioAlignment& a, double) override { if (filter) filter->setGnssAlignment(a); }
     template <class F> void frame(const F& m, uint32_t k, bool is_mono)
     {
         if (!filter) return;

@@ -92,6 +92,66 @@ void worldPoint(const SynthConfig& cfg, const Track& t, int slot, double* pw)
 
 }  // namespace
 
+namespace {
+
+// ---- GNSS side (enable_gnss): local ENU at (31 N, 121.4 E, 30 m); the filter's world frame is the truth frame shifted to the starting
+// point (the gravity initialisation of a level start reproduces the truth attitude up to the IMU noise in its average), rotated
+// against ENU by the true yaw offset.  Formulas = what psr_res / dopp_res invert (gnss_spp.cpp:100-146, :256-282). ----
+const double YO_TRUE = 0.3;
+const int GN_NS = 8;
+const int GN_SYS[GN_NS] = { 0, 0, 0, 0, 3, 3, 2, 2 };
+const double GN_CB0[4] = { 150.0, 0.0, 165.0, 180.0 }, GN_FS = 5.0;
+
+GvioAlignment synthAlignment()
+{
+    GvioAlignment al;
+    const Vec3d lla(31.0, 121.4, 30.0);
+    al.aligned = true; al.yaw_offset = YO_TRUE + 0.01; al.R_enu2ecef = gnss::geo2rotation(lla); al.anchor_ecef = gnss::geo2ecef(lla);
+    return al;
+}
+
+void synthGnssEpoch(const SynthConfig& cfg, int k, double t, GnssMeas& gm, SppMeas& spp)
+{
+    const GvioAlignment al = synthAlignment();
+    Mat3d Rz = Mat3d::Identity();
+    Rz(0, 0) = std::cos(YO_TRUE); Rz(0, 1) = -std::sin(YO_TRUE); Rz(1, 0) = std::sin(YO_TRUE); Rz(1, 1) = std::cos(YO_TRUE);
+    const Mat3d Rw2ecef = al.R_enu2ecef * Rz;
+    const Truth tr = truthAt(t - T_STATIC), tr0 = truthAt(0.0);
+    const Vec3d pw(tr.p[0] - tr0.p[0], tr.p[1] - tr0.p[1], tr.p[2] - tr0.p[2]), vw(tr.v[0], tr.v[1], tr.v[2]);
+    const Vec3d rcv = Rw2ecef * pw + al.anchor_ecef, vel = Rw2ecef * vw;
+    gm = GnssMeas(); gm.stamp = t;
+    for (int i = 0; i < GN_NS; ++i) {
+        SplitMix64 r = sub(cfg, k, 4, i);
+        const double el = (25 + 50.0 * i / GN_NS) * M_PI / 180, az = 2 * M_PI * (i * 0.37 + 0.1);
+        const Vec3d dir(std::cos(el) * std::sin(az), std::cos(el) * std::cos(az), std::sin(el));
+        gnss::SatObs o;
+        o.sys = GN_SYS[i]; o.freq = o.sys == 3 ? gnss::FREQ1_BDS : gnss::FREQ1; o.psr_std = 1.0; o.dopp_std = 0.5; o.ura = 2.0;
+        o.sv_vel = al.R_enu2ecef * Vec3d(2500.0 * std::cos(az), -2500.0 * std::sin(az), 300.0 * (i % 3 - 1));
+        o.sv_pos = al.anchor_ecef + al.R_enu2ecef * (dir * 2.2e7) + o.sv_vel * t;
+        o.sv_dt = 1e-5 * (i + 1); o.sv_ddt = 1e-11 * i; o.tgd = 2e-9 * i; o.ion_delay = 2.0 + 0.3 * i; o.tro_delay = 2.5 + 0.2 * i;
+        const Vec3d d = o.sv_pos - rcv;
+        const double range = d.norm();
+        const Vec3d u = d * (1.0 / range);
+        const double cb = GN_CB0[o.sys] + GN_FS * t;
+        const double sag = gnss::EARTH_OMG_GPS * (o.sv_pos[0] * rcv[1] - o.sv_pos[1] * rcv[0]) / gnss::LIGHT_SPEED;
+        o.psr = range + sag + cb - o.sv_dt * gnss::LIGHT_SPEED + o.tro_delay + o.ion_delay + o.tgd * gnss::LIGHT_SPEED + 0.8 * r.normal();
+        if (i == 5 && k >= 8) o.psr += 80.0;
+        const double sagd = gnss::EARTH_OMG_GPS / gnss::LIGHT_SPEED * (o.sv_vel[0] * rcv[1] + o.sv_pos[0] * vel[1] - o.sv_vel[1] * rcv[0] - o.sv_pos[1] * vel[0]);
+        const Vec3d dv = o.sv_vel - vel;
+        const double est = dv[0] * u[0] + dv[1] * u[1] + dv[2] * u[2] + GN_FS + sagd - o.sv_ddt * gnss::LIGHT_SPEED;
+        o.dopp = -(est + 0.05 * r.normal()) * o.freq / gnss::LIGHT_SPEED;
+        gm.sats.push_back(o);
+    }
+    SplitMix64 r = sub(cfg, k, 5, 0);
+    spp = SppMeas(); spp.stamp = t;
+    for (int c = 0; c < 3; ++c) spp.posSpp[c] = rcv[c] + 2.0 * r.normal();
+    for (int s4 = 0; s4 < 4; ++s4) { const double n = 3.0 * r.normal(); spp.posSpp[3 + s4] = GN_CB0[s4] == 0.0 ? 0.0 : GN_CB0[s4] + GN_FS * t + n; }
+    for (int c = 0; c < 3; ++c) spp.velSpp[c] = vel[c];
+    spp.velSpp[3] = GN_FS + 0.2 * r.normal();
+}
+
+}  // namespace
+
 std::string synthParamsText(const SynthConfig& cfg)
 {
     char buf[4096];
@@ -159,6 +219,7 @@ int synthStream(const SynthConfig& cfg, SynthSink& sink)
         f0.header.seq = 0; f0.header.stamp = msg::Time::fromNSec(0); f0.header.frame_id = "cam0";
         if (cfg.stereo) sink.stereo(f0);
         else { msg::MonoFrame m0; m0.header = f0.header; sink.mono(m0); }
+        if (cfg.enable_gnss) sink.alignment(synthAlignment(), 0.0);
     }
     for (int n = 1; n <= n_imu; ++n) {
         const double t = n * DT_IMU;
@@ -177,6 +238,11 @@ int synthStream(const SynthConfig& cfg, SynthSink& sink)
         sink.imu(m);
         if (n > n_static && (n - n_static) % IMU_PER_FRAME == 0) {
             const int kf = (n - n_static) / IMU_PER_FRAME;
+            if (cfg.enable_gnss) {                        // the epoch of this frame time arrives before the frame (GnssSync buffers it)
+                GnssMeas gm; SppMeas sp;
+                synthGnssEpoch(cfg, kf, t, gm, sp);
+                sink.gnss(gm); sink.spp(sp);
+            }
             msg::StereoFrame f;
             synthFrame(cfg, kf, f);
             if (cfg.stereo) sink.stereo(f);

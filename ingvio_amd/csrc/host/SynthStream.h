@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <string>
 
+#include "GnssUpdate.h"
 #include "Messages.h"
 
 namespace ingvio {
@@ -54,7 +55,10 @@ struct SynthConfig {
     double pixel_noise = 1e-3;    // normalised image coordinates
     double visual_noise = 0.08;
     uint64_t seed = 0x1A6F10ULL;
-    int enable_gnss = 0;
+    int enable_gnss = 0;          // 1: every camera frame k >= 1 is preceded by a GNSS epoch (8 satellites: GPS x4, BDS x2, GAL x2; pseudo-range and
+                                  // Doppler with the satellite states and atmosphere delays already evaluated, as the replay format carries them) and
+                                  // its SPP fix; the stream opens with the ENU alignment (yaw offset 0.31 against a true 0.30).  Satellite 5 carries an
+                                  // 80 m pseudo-range outlier from frame 8 on (the per-row gate of gnss_chi2_test has work)
     std::string extra_params;     // appended "key: value" lines
 };
 
@@ -65,6 +69,9 @@ struct SynthSink {
     virtual void stereo(const msg::StereoFrame& m) = 0;
     virtual void mono(const msg::MonoFrame& m) = 0;
     virtual void truth(double stamp, const double p[3], const double q_xyzw[4]) = 0;
+    virtual void gnss(const GnssMeas&) {}
+    virtual void spp(const SppMeas&) {}
+    virtual void alignment(const GvioAlignment&, double /*stamp*/) {}
 };
 
 // The PARAMS text of a config (key names of config/*/ingvio_stereo.yaml; extrinsics of config/sportsfield/stereo_*_config.yaml).

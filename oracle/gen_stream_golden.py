@@ -40,6 +40,12 @@ STREAMS = {
     # observations per RemoveLost feature (RemoveLostUpdate.cpp:51), 2 rows per observation; longer tracks (a mono point needs parallax)
     "kf11_mono": ("feats=150,clones=11,life=10,cohort=0,frames=70,key=1,stereo=0,outlier_every=6", ""),
     "sw11_mono": ("feats=150,clones=11,life=13,cohort=0,frames=70,key=0,stereo=0,outlier_every=6", "frame_select_interval: 5\n"),
+    # BASELINE configs[2]: stereo + raw GNSS.  Every frame carries an epoch of 8 satellites (GPS x4, BDS x2, GAL x2: pseudo-range +
+    # Doppler, satellite 5 with an 80 m outlier from frame 8 on) and its SPP fix; the alignment is given.  Pins the GNSS block of the
+    # callback (IngvioFilter.cpp:329-362): epoch matching, checkYofStatus, updateTrackedSys with gnss_chi2_test, addNewTrackedSys'
+    # delayed initialisations - i.e. where the GNSS scalars sit in the (idx, size) table
+    "sw11_gnss": ("feats=150,clones=11,life=13,cohort=0,frames=60,key=0,gnss=1", "frame_select_interval: 5\ngnss_chi2_test: 1\ngnss_strong_reject: 1\n"),
+    "kf11_gnss": ("feats=150,clones=11,life=10,cohort=0,frames=60,key=1,gnss=1", "gnss_chi2_test: 1\ngnss_strong_reject: 0\n"),
     "sw21": ("feats=100,clones=21,life=25,cohort=0,frames=70,key=0,outlier_every=7", "frame_select_interval: 6\n"),
 }
 

@@ -18,10 +18,17 @@ clones are selected, when anchors change and what is erased:
     KeyframeUpdate::getMargKfs / updateStateStereo / changeMSCKFAnchor / cleanStereoObsAtMargTime / margSwPose
                                                    KeyframeUpdate.cpp:43-129, 587-735, 280-328, 737-760, 119-129
 
+    GNSS block of the callback                     IngvioFilter.cpp:329-362; GnssSync.cpp:27-68, 136-194 (buffers, 0.13 s window)
+    GnssUpdate::checkYofStatus / updateTrackedSys / addNewTrackedSys / getResJacobianOfSys    GnssUpdate.cpp:33-43, 84-293, 295-523
+    GnssManager helpers, gnss_comm psr_res / dopp_res / sat_azel / ecef2geo     GnssManager.cpp:63-133; gnss_spp.cpp:99-146, 256-282;
+                                                                                gnss_utility.cpp:347-388, 733-772
+
 The numerical kernels behind it are the oracle's (oracle/ingvio_oracle.c): orc_imu_transition, orc_propagate_cov,
 orc_augment_clone, orc_triangulate, orc_msckf_update (per-feature Jacobian, nullspace, chi^2 gate, stacking, compression, EKF
-update), orc_marginalize, the retractions.  Scope: mono and stereo, MSCKF features only (max_landmark_features = 0, enable_gnss = 0 — the
-shipped configurations of the visual part).  Every processed camera frame yields a trace record (see `Trace`)."""
+update), orc_marginalize, the retractions; for GNSS orc_gnss_rows (the rows of updateTrackedSys with their per-row gates),
+orc_whiten_residual, orc_ekf_update, orc_add_variable_delayed.  Scope: mono and stereo, MSCKF features only (max_landmark_features
+= 0); GNSS epochs with the satellite states and atmosphere delays already evaluated (what the INGVIOR1 format carries), the alignment
+given (no batchAlign), is_adjust_yof = 0.  Every processed camera frame yields a trace record (see `Trace`)."""
 import math
 
 import numpy as np
@@ -80,16 +87,105 @@ def quat_to_rot(q):
                      [txz - twy, tyz + twx, 1 - (txx + tyy)]])
 
 
+# ---- gnss_comm pieces (gnss_constant.hpp:203-214; gnss_utility.cpp; gnss_spp.cpp) ------------------------------------------------------
+LIGHT_SPEED = 2.99792458e8
+EARTH_OMG_GPS = 7.2921151467e-5
+EARTH_SEMI_MAJOR = 6378137.0
+EARTH_ECCE_2 = 6.69437999014e-3
+D2R = math.pi / 180.0
+R2D = 180.0 / math.pi
+
+
+def ecef2geo(xyz):                                                       # gnss_utility.cpp:347-388
+    if xyz[0] == 0 and xyz[1] == 0:
+        return np.zeros(3)
+    e2, a = EARTH_ECCE_2, EARTH_SEMI_MAJOR
+    a2 = a * a
+    b2 = a2 * (1 - e2)
+    b = math.sqrt(b2)
+    ep2 = (a2 - b2) / b2
+    p = math.sqrt(xyz[0] * xyz[0] + xyz[1] * xyz[1])
+    s1, s2 = xyz[2] * a, p * b
+    h = math.sqrt(s1 * s1 + s2 * s2)
+    sin_theta, cos_theta = s1 / h, s2 / h
+    s1 = xyz[2] + ep2 * b * sin_theta ** 3
+    s2 = p - a * e2 * cos_theta ** 3
+    h = math.sqrt(s1 * s1 + s2 * s2)
+    tan_lat, sin_lat, cos_lat = s1 / s2, s1 / h, s2 / h
+    lat = math.atan(tan_lat)
+    N = a2 * (a2 * cos_lat * cos_lat + b2 * sin_lat * sin_lat) ** -0.5
+    return np.array([lat * R2D, math.atan2(xyz[1], xyz[0]) * R2D, p / cos_lat - N])
+
+
+def ecef2enu(ref_lla, v):                                                # :733-743
+    lat, lon = ref_lla[0] * D2R, ref_lla[1] * D2R
+    sl, cl, so, co = math.sin(lat), math.cos(lat), math.sin(lon), math.cos(lon)
+    R = np.array([[-so, co, 0.0], [-sl * co, -sl * so, cl], [cl * co, cl * so, sl]])
+    return R @ v
+
+
+def sat_azel(rcv, sat):                                                  # :762-772
+    lla = ecef2geo(rcv)
+    d = sat - rcv
+    d = d / np.linalg.norm(d)
+    e = ecef2enu(lla, d)
+    az = 0.0 if math.hypot(d[0], d[1]) < 1e-12 else math.atan2(e[0], e[1])
+    if az < 0:
+        az += 2 * math.pi
+    return az, math.asin(e[2])
+
+
+def psr_res(rcv7, sats):
+    """gnss_spp.cpp:99-146 with the observation's own atmosphere delays (the INGVIOR1 record carries calculate_ion_delay /
+    calculate_trop_delay's outputs).  -> res [n], unit_rv2sv [n, 3] (= -J.row.head<3>), elevation [n]."""
+    n = len(sats)
+    res = np.zeros(n); los = np.zeros((n, 3)); el = np.full(n, math.pi / 2.0)
+    r = np.asarray(rcv7[:3], dtype=float)
+    for i, o in enumerate(sats):
+        if np.linalg.norm(r) > 0:
+            _, el[i] = sat_azel(r, o["sv_pos"])
+        rv2sv = o["sv_pos"] - r
+        rng = float(np.linalg.norm(rv2sv))
+        sagnac = EARTH_OMG_GPS * (o["sv_pos"][0] * rcv7[1] - o["sv_pos"][1] * rcv7[0]) / LIGHT_SPEED
+        est = rng + sagnac + rcv7[3 + o["sys"]] - o["sv_dt"] * LIGHT_SPEED + o["tro"] + o["ion"] + o["tgd"] * LIGHT_SPEED
+        los[i] = rv2sv / rng
+        res[i] = est - o["psr"]
+    return res, los, el
+
+
+def dopp_res(rcv4, rcv_ecef, sats):                                      # gnss_spp.cpp:256-282
+    res = np.zeros(len(sats))
+    for i, o in enumerate(sats):
+        u = o["sv_pos"] - rcv_ecef
+        u = u / np.linalg.norm(u)
+        sagnac = EARTH_OMG_GPS / LIGHT_SPEED * (o["sv_vel"][0] * rcv_ecef[1] + o["sv_pos"][0] * rcv4[1]
+                                                - o["sv_vel"][1] * rcv_ecef[0] - o["sv_pos"][1] * rcv4[0])
+        est = float((o["sv_vel"] - np.asarray(rcv4[:3])) @ u) + rcv4[3] + sagnac - o["sv_ddt"] * LIGHT_SPEED
+        if o["freq"] < 0:
+            continue
+        res[i] = est + o["dopp"] * (LIGHT_SPEED / o["freq"])
+    return res
+
+
+def rot_z(yaw):                                                          # GnssManager::calcRw2enu (GnssManager.cpp:63-66): AngleAxis(yo, UnitZ)
+    c, s = math.cos(yaw), math.sin(yaw)
+    return np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+
+
+GPS, GLO, GAL, BDS, FS, YOF = range(6)                                   # State::GNSSType (State.h:75)
+
+
 class Var:
     """One error-state variable (Type: idx, size) with its nominal value."""
 
     def __init__(self, kind, size):
-        self.kind = kind            # 'se23' | 'vec3' | 'se3'
+        self.kind = kind            # 'se23' | 'vec3' | 'se3' | 'scalar'
         self.size = size
         self.idx = -1
         self.R = np.eye(3)
         self.p = np.zeros(3)        # SE23: trans1 (position); SE3: translation; Vec3: the value
         self.v = np.zeros(3)        # SE23: trans2 (velocity)
+        self.s = 0.0                # Scalar: the value
 
     def update(self, dx):
         i = self.idx
@@ -97,6 +193,8 @@ class Var:
             self.R, self.p, self.v = orc.se23_update(self.R, self.p, self.v, dx[i:i + 9])
         elif self.kind == "se3":                                         # PoseState.cpp:79-88
             self.R, self.p = orc.se3_update(self.R, self.p, dx[i:i + 6])
+        elif self.kind == "scalar":                                      # VecState.cpp:40-44
+            self.s = self.s + dx[i]
         else:                                                            # VecState.cpp:25-29
             self.p = self.p + dx[i:i + 3]
 
@@ -120,7 +218,23 @@ class Filter:
         p.update(parse_params(overrides))
         g = lambda k, d: float(p.get(k, d))
         gi = lambda k, d: int(float(p.get(k, d)))
-        assert gi("enable_gnss", 1) == 0 and gi("max_landmark_features", 0) == 0, "scope: visual only, MSCKF features"
+        assert gi("max_landmark_features", 0) == 0, "scope: MSCKF features"
+        self.enable_gnss = gi("enable_gnss", 1)
+        if self.enable_gnss:
+            assert gi("is_adjust_yof", 0) == 0, "scope: is_adjust_yof = 0"
+            # State.cpp:49-57 incl. quirk Q1: BOTH clock noises are assigned to _noise_clockbias, _noise_cb_rw keeps its default 0.2
+            self.sigma_cb = g("noise_rcv_clockbias_randomwalk", 0.2)
+            self.sigma_rw = 0.2
+            self.init_cov_cb = g("init_cov_rcv_clockbias", 2.0)
+            self.init_cov_yof = g("init_cov_yof", 0.015)
+            self.gnss_chi2_test = gi("gnss_chi2_test", 0)
+            self.gnss_strong_reject = gi("gnss_strong_reject", 1)
+            self.psr_amp = g("psr_noise_amp", 1.0)
+            self.dopp_amp = g("dopp_noise_amp", 1.0)
+        self.gnss = {}               # GNSSType -> scalar Var (State::_gnss)
+        self.gnss_buf, self.spp_buf = [], []                              # GnssSync's queues (the replay marks the synchronisation as done)
+        self.unsync_thres = 0.13                                          # GnssSync.h:61
+        self.align = None            # dict(yaw_offset, R_enu2ecef, anchor_ecef) once aligned
         self.stereo = gi("cam_nums", 2) == 2                             # IngvioFilter.cpp:100-112: cam_nums 1 -> the mono callback
         self.max_sw = gi("max_sliding_window_poses", 27)
         self.is_key_frame = gi("is_key_frame", 1)
@@ -157,7 +271,7 @@ class Filter:
         for v in self.err_vars:
             v.idx = idx
             idx += v.size
-        self.cov = orc.Cov(1e-3 ** 2 * np.eye(idx), ld=((idx + 6 * (self.max_sw + 3) + 15) // 16) * 16)
+        self.cov = orc.Cov(1e-3 ** 2 * np.eye(idx), ld=((idx + 6 + 6 * (self.max_sw + 3) + 15) // 16) * 16)
         self.timestamp = -1.0
         self.sw = {}                 # stamp -> clone Var
         self.map = {}                # id -> Feature
@@ -254,6 +368,14 @@ class Filter:
         e = self.ext_pose
         self.timestamp += dt
         e.R, e.p, e.v, Phi, G = orc.imu_transition(e.R, e.p, e.v, self.bg.p, self.ba.p, gyro, accel, self.gravity, dt)
+        if self.enable_gnss:
+            if FS in self.gnss:                                           # ImuPropagator.cpp:139-148: cb += dt * fs
+                for t4 in (GPS, GLO, GAL, BDS):
+                    if t4 in self.gnss:
+                        self.gnss[t4].s = self.gnss[t4].s + dt * self.gnss[FS].s
+            gi5 = [self.gnss[t5].idx if t5 in self.gnss else -1 for t5 in (GPS, GLO, GAL, BDS, FS)]
+            self.cov.propagate(Phi, G, dt, self.sigma, 1, gi5, self.sigma_cb, self.sigma_rw)
+            return
         self.cov.propagate(Phi, G, dt, self.sigma)
 
     def propagate_until(self, t_end):                                    # ImuPropagator.cpp:232-292
@@ -511,6 +633,162 @@ class Filter:
             del self.map[fid]
         tr["invalid_erased"] = gone
 
+    # ---- GNSS ---------------------------------------------------------------------------------------------------------------
+    def callback_gnss_meas(self, stamp, sats):                           # GnssSync::bufferGnssMeas (GnssSync.cpp:27-46)
+        if len(self.gnss_buf) > 100:
+            del self.gnss_buf[:len(self.gnss_buf) - 100]
+        self.gnss_buf.append((stamp, sats))
+
+    def callback_spp_meas(self, stamp, pos7, vel4):                      # GnssSync::bufferSppMeas (:48-68)
+        if len(self.spp_buf) > 100:
+            del self.spp_buf[:len(self.spp_buf) - 100]
+        self.spp_buf.append((stamp, np.asarray(pos7, dtype=float), np.asarray(vel4, dtype=float)))
+
+    def _pick(self, buf, target):                                        # getGnssMeasAt / getSppAt (:136-194)
+        while buf:
+            t = buf[0][0]
+            if t < target - self.unsync_thres:
+                buf.pop(0)
+                continue
+            if t >= target + self.unsync_thres:
+                break
+            return buf.pop(0)
+        return None
+
+    def add_gnss_variable(self, gtype, value, cov):                      # StateManager::addGNSSVariable (StateManager.cpp:216-231)
+        v = Var("scalar", 1)
+        v.s = float(value)
+        v.idx = self.cov.append_independent(np.array([[cov]]))
+        self.gnss[gtype] = v
+        self.err_vars.append(v)
+
+    def _rcv_state(self, cb_over=None, fs_over=None):
+        """xyzt / dopp of updateTrackedSys (GnssUpdate.cpp:101-113) and addNewTrackedSys (:343-372)."""
+        al, e = self.align, self.ext_pose
+        Rw2enu = rot_z(self.gnss[YOF].s)
+        xyzt = np.zeros(7)
+        xyzt[:3] = al["R_enu2ecef"] @ (Rw2enu @ e.p) + al["anchor_ecef"]                      # getTenu2ecef() * calcTw2enu(yof) * p
+        for t4 in (GPS, GLO, GAL, BDS):                                  # GnssManager::getClockbiasVec
+            if t4 in self.gnss:
+                xyzt[3 + t4] = self.gnss[t4].s
+        if cb_over:
+            for t4, val in cb_over.items():
+                xyzt[3 + t4] = val
+        dopp = np.zeros(4)
+        dopp[:3] = al["R_enu2ecef"] @ (Rw2enu @ e.v)
+        if fs_over is not None:
+            dopp[3] = fs_over
+        elif FS in self.gnss:
+            dopp[3] = self.gnss[FS].s
+        return xyzt, dopp, al["R_enu2ecef"] @ Rw2enu
+
+    def update_tracked_sys(self, sats, tr):                              # GnssUpdate.cpp:84-293
+        tr["gnss_rows"] = 0
+        tr["gnss_keep"] = []
+        if not sats:
+            return
+        if YOF not in self.gnss or FS not in self.gnss or not any(t4 in self.gnss for t4 in (GPS, GLO, GAL, BDS)):      # checkGnssStates
+            return
+        xyzt, dopp, Rw2ecef = self._rcv_state()
+        res_pos, los, el = psr_res(xyzt, sats)
+        res_vel = dopp_res(dopp, xyzt[:3], sats)
+        e = self.ext_pose
+        g = dict(los=los, sys=[o["sys"] for o in sats], res_pos=res_pos, res_vel=res_vel, sin_el=np.sin(el),
+                 ura=[o["ura"] for o in sats], psr_std=[o["psr_std"] for o in sats],
+                 dopp_std_mps=[o["dopp_std"] * LIGHT_SPEED / o["freq"] for o in sats], R_w2ecef=Rw2ecef, p_w=e.p, v_w=e.v,
+                 idx_se23=e.idx, idx_yof=self.gnss[YOF].idx, idx_fs=self.gnss[FS].idx,
+                 idx_cb=[self.gnss[t4].idx if t4 in self.gnss else -1 for t4 in (GPS, GLO, GAL, BDS)],
+                 psr_amp=self.psr_amp, dopp_amp=self.dopp_amp, chi2_test=self.gnss_chi2_test,
+                 chi2_table=np.array([0.0] + [self.chi2(d) for d in range(1, 41)]))
+        H, res, Rd, vidx, vsize = orc.gnss_rows(self.cov, g)             # rows with their per-row gates (:148-272), var_order as built there
+        m = len(res)
+        # which candidate rows survived: the ungated row set, matched by (residual, variance)
+        g0 = dict(g); g0["chi2_test"] = 0
+        H0, res0, Rd0, _, _ = orc.gnss_rows(self.cov, g0)
+        keep, j = [], 0
+        for i in range(len(res0)):
+            if j < m and res0[i] == res[j] and Rd0[i] == Rd[j]:
+                keep.append(1); j += 1
+            else:
+                keep.append(0)
+        assert j == m
+        tr["gnss_keep"] = keep
+        if m <= 14 and self.gnss_strong_reject:                          # :286: the block gate, dof = rows (0 rows: dof <= 0 -> refused)
+            if m <= 0 or not (self.cov.whiten(vidx, vsize, H, res, Rd) < self.chi2(m)):
+                return
+        dx, _ = self.cov.ekf_update(vidx, vsize, H, res, Rd)             # :289 (zero rows: K has no columns, nothing changes)
+        self.box_plus(dx)
+        tr["gnss_rows"] = m
+
+    def add_new_tracked_sys(self, sats, pos7, vel4, tr):                 # GnssUpdate.cpp:295-470
+        tr["gnss_added"] = []
+        if not sats or YOF not in self.gnss:
+            return
+        spp_sys = ([FS] if abs(vel4[3]) > 1e-3 else []) + [t4 for t4 in (GPS, GLO, GAL, BDS) if abs(pos7[3 + t4]) > 1e-3]      # getSysInSppMeas
+        # calcSysToAdd + the loop at :375 iterate std::unordered_set<GNSSType>: with libstdc++ (the reference's toolchain; checked with
+        # g++ for all 32 subsets) the two reversals cancel and the order is the insertion order FS, GPS, GLO, GAL, BDS
+        to_add = [t for t in spp_sys if t not in self.gnss]
+        if not to_add:
+            return
+        cb_over = {t4: pos7[3 + t4] for t4 in to_add if t4 != FS}
+        fs_over = vel4[3] if FS in to_add else None
+        xyzt, dopp, Rw2ecef = self._rcv_state(cb_over, fs_over)
+        res_pos, los, el = psr_res(xyzt, sats)
+        res_vel = dopp_res(dopp, xyzt[:3], sats)
+        sin_el = np.sin(el)
+        sin_el = np.where(np.abs(sin_el) < 1e-6, 1e-6, sin_el)
+        e = self.ext_pose
+        x_vidx, x_vsize = [e.idx, self.gnss[YOF].idx], [9, 1]
+        for gtype in to_add:
+            fs = gtype == FS
+            rows = list(range(len(sats))) if fs else [i for i, o in enumerate(sats) if o["sys"] == gtype]      # getResJacobianOfSys :472-521
+            if not rows:
+                continue
+            m = len(rows)
+            Hx = np.zeros((m, 10)); Hf = np.ones((m, 1)); res = np.zeros(m)
+            x = e.v if fs else e.p                                       # read INSIDE the loop (:389 / :440): an earlier addition's update moved it
+            RS = Rw2ecef @ np.array([[0.0, -x[2], x[1]], [x[2], 0.0, -x[0]], [-x[1], x[0], 0.0]])
+            avg = 0.0
+            for r, i in enumerate(rows):
+                u = los[i]
+                Hx[r, 0:3] = u @ RS
+                Hx[r, (6 if fs else 3):(9 if fs else 6)] = -(u @ Rw2ecef)
+                res[r] = -(res_vel[i] if fs else res_pos[i])
+                std = sats[i]["dopp_std"] * LIGHT_SPEED / sats[i]["freq"] if fs else sats[i]["psr_std"]
+                avg += sats[i]["ura"] * std / (sin_el[i] * sin_el[i])
+            noise = (self.dopp_amp if fs else self.psr_amp) * math.sqrt(avg / m)
+            if m <= 1:                                                   # addVariableDelayed: H_new.rows() <= H_new.cols() (StateManager.cpp:571-575)
+                continue
+            added, dx, _ = self.cov.add_variable_delayed(x_vidx, x_vsize, Hx, Hf, res, noise, chi2_mult=0.95, do_chi2=True,
+                                                         chi2_check=float(_chi2.ppf(0.95, m)))
+            if not added:
+                continue
+            v = Var("scalar", 1)
+            v.s = float(vel4[3] if fs else pos7[3 + gtype])
+            v.idx = self.cov.n - 1
+            self.err_vars.append(v)
+            if m > 1:                                                    # Hup.rows() > 0: the EKF update with the remaining rows (:631-632)
+                self.box_plus(dx)
+            self.gnss[gtype] = v
+            tr["gnss_added"].append(gtype)
+
+    def gnss_block(self, stamp, tr):                                     # IngvioFilter.cpp:329-362
+        tr["gnss_rows"], tr["gnss_keep"], tr["gnss_added"], tr["gnss_epoch"] = 0, [], [], -1.0
+        if not self.enable_gnss:
+            return
+        spp = self._pick(self.spp_buf, stamp)
+        gm = self._pick(self.gnss_buf, stamp)
+        if gm is None:
+            return
+        tr["gnss_epoch"] = gm[0]
+        if self.align is None:
+            return                                                       # batchAlign is out of this transcription's scope: the alignment is given
+        if YOF not in self.gnss:                                         # checkYofStatus :33-43
+            self.add_gnss_variable(YOF, self.align["yaw_offset"], self.init_cov_yof)
+        self.update_tracked_sys(gm[1], tr)
+        if spp is not None:
+            self.add_new_tracked_sys(gm[1], spp[1], spp[2], tr)
+
     # ---- the camera callback ----------------------------------------------------------------------------------------------
     def callback_frame(self, stamp, feats):                              # IngvioFilter.cpp:252-379 (stereo) / :124-250 (mono): the same sequence
         """feats: iterable of (id, u0, v0, u1, v1) or, mono, (id, u0, v0).  Returns the frame's trace dict, or None when the callback
@@ -565,6 +843,7 @@ class Filter:
                 self.marg_sw_pose(marg_time)
                 tr["marg_stamps"] = [marg_time]
         self.erase_invalid(tr)
+        self.gnss_block(stamp, tr)
         self.frames += 1
         # the state after the frame
         tr["table"] = [(v.idx, v.size) for v in self.err_vars]
@@ -572,6 +851,7 @@ class Filter:
         tr["map_ids"] = sorted(self.map)
         e = self.ext_pose
         tr["pose"] = np.concatenate([e.R.reshape(-1), e.p, e.v, self.bg.p, self.ba.p, self.extr.R.reshape(-1), self.extr.p])
+        tr["gnss_vals"] = np.array([self.gnss[t6].s if t6 in self.gnss else np.nan for t6 in range(6)])      # GPS GLO GAL BDS FS YOF
         P = self.cov.P
         tr["n"] = int(P.shape[0])
         tr["diag"] = np.diag(P).copy()
@@ -581,9 +861,9 @@ class Filter:
 
 
 LIST_KEYS_INT = ["lost_ids", "lost_direct", "lost_acc", "sel_ids", "sel_acc", "clean_erased", "anchor_erased", "anchor_moved",
-                 "invalid_erased", "map_ids"]
-LIST_KEYS_F64 = ["sel_stamps", "marg_stamps", "sw_stamps", "diag"]
-SCALAR_KEYS = ["stamp", "lost_rows", "sel_rows", "n", "norm"]
+                 "invalid_erased", "map_ids", "gnss_keep", "gnss_added"]
+LIST_KEYS_F64 = ["sel_stamps", "marg_stamps", "sw_stamps", "diag", "gnss_vals"]
+SCALAR_KEYS = ["stamp", "lost_rows", "sel_rows", "n", "norm", "gnss_rows", "gnss_epoch"]
 
 
 def pack_traces(traces):
@@ -621,6 +901,11 @@ def unpack_traces(z):
     return out
 
 
+def _stamp_from_ns(ns):
+    """decodeGnss / decodeSpp (Replay.cpp): m.stamp = 1e-9 * (double)stamp_ns - NOT ros::Time::toSec()."""
+    return 1e-9 * float(ns)
+
+
 def play_recording(path, overrides="", max_frames=None):
     """Plays an INGVIOR1 recording (IMU + STEREO_FRAME records) into a Filter; returns the list of trace dicts."""
     import struct
@@ -639,6 +924,21 @@ def play_recording(path, overrides="", max_frames=None):
             elif typ == 1:
                 v = struct.unpack("<6d", payload)
                 flt.callback_imu(to_sec(ns), v[0:3], v[3:6])
+            elif typ == 4:                                               # GNSS_MEAS: u32 n, n x { i32 sys, f64 x 17 } (Replay.h)
+                cnt = struct.unpack_from("<I", payload)[0]
+                sats = []
+                for i in range(cnt):
+                    v = struct.unpack_from("<i17d", payload, 4 + 140 * i)
+                    sats.append(dict(sys=v[0], psr=v[1], dopp=v[2], psr_std=v[3], dopp_std=v[4], freq=v[5], sv_pos=np.array(v[6:9]),
+                                     sv_vel=np.array(v[9:12]), sv_dt=v[12], sv_ddt=v[13], tgd=v[14], ura=v[15], ion=v[16], tro=v[17]))
+                flt.callback_gnss_meas(_stamp_from_ns(ns), sats)
+            elif typ == 5:                                               # SPP_MEAS: posSpp 7, velSpp 4
+                v = struct.unpack("<11d", payload)
+                flt.callback_spp_meas(_stamp_from_ns(ns), v[:7], v[7:])
+            elif typ == 6:                                               # ALIGNMENT: aligned, yaw_offset, R_enu2ecef 9 (row-major), anchor_ecef 3
+                v = struct.unpack("<14d", payload)
+                if v[0] != 0.0:
+                    flt.align = dict(yaw_offset=v[1], R_enu2ecef=np.array(v[2:11]).reshape(3, 3), anchor_ecef=np.array(v[11:14]))
             elif typ in (2, 3):
                 cnt = struct.unpack_from("<I", payload)[0]
                 feats = [struct.unpack_from("<Q4d", payload, 4 + 40 * i) for i in range(cnt)] if typ == 3 else \

@@ -18,15 +18,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 TOOL = os.path.join(ROOT, "ingvio_amd", "lib", "ingvio_replay")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-STREAMS = ["kf11", "kf11_lifted", "sw11", "kf21", "sw21", "kf11_mono", "sw11_mono"]      # the last two: the MONO callback (BASELINE configs[0])
+STREAMS = ["kf11", "kf11_lifted", "sw11", "kf21", "sw21", "kf11_mono", "sw11_mono",      # mono: the MONO callback (BASELINE configs[0])
+           "sw11_gnss", "kf11_gnss"]                                                       # raw GNSS epochs in the callback (BASELINE configs[2])
 POSE_TOL = 1e-9
 COV_TOL = 1e-6
 
 INT_TAGS = {"LOST_IDS": "lost_ids", "LOST_ACC": "lost_acc", "LOST_DIRECT": "lost_direct", "SEL_IDS": "sel_ids", "SEL_ACC": "sel_acc",
             "CLEAN_ERASED": "clean_erased", "ANCHOR_ERASED": "anchor_erased", "ANCHOR_MOVED": "anchor_moved", "INVALID_ERASED": "invalid_erased",
-            "MAP_IDS": "map_ids", "TABLE": "table"}
-F64_TAGS = {"SEL_STAMPS": "sel_stamps", "MARG_STAMPS": "marg_stamps", "SW_STAMPS": "sw_stamps", "POSE": "pose", "DIAG": "diag"}
-SCALAR_TAGS = {"LOST_ROWS": "lost_rows", "SEL_ROWS": "sel_rows", "NORM": "norm"}
+            "MAP_IDS": "map_ids", "TABLE": "table", "GNSS_KEEP": "gnss_keep"}
+F64_TAGS = {"SEL_STAMPS": "sel_stamps", "MARG_STAMPS": "marg_stamps", "SW_STAMPS": "sw_stamps", "POSE": "pose", "DIAG": "diag",
+            "GNSS_VALS": "gnss_vals"}
+SCALAR_TAGS = {"LOST_ROWS": "lost_rows", "SEL_ROWS": "sel_rows", "NORM": "norm", "GNSS_ROWS": "gnss_rows", "GNSS_ADDED_TOTAL": "gnss_added_total"}
 
 
 def parse_trace(text):
@@ -57,7 +59,8 @@ def parse_trace(text):
 def compare(gold, got, pose_tol=POSE_TOL, cov_tol=COV_TOL):
     """-> (list of mismatch strings, dict of the largest deviations seen)."""
     bad = []
-    worst = dict(pose=0.0, diag=0.0, norm=0.0)
+    worst = dict(pose=0.0, diag=0.0, norm=0.0, gnss=0.0)
+    added_total = 0
     if len(gold) != len(got):
         bad.append("frames: golden %d, shim %d" % (len(gold), len(got)))
     for f, (g, s) in enumerate(zip(gold, got)):
@@ -76,6 +79,16 @@ def compare(gold, got, pose_tol=POSE_TOL, cov_tol=COV_TOL):
                 bad.append("%s: %s differs: golden %s shim %s" % (tag, k, np.asarray(g[k]).tolist(), s[k].tolist()))
         if not np.array_equal(np.asarray(g["table"], dtype=np.int64).reshape(-1, 2), s["table"]):
             bad.append("%s: (idx, size) table differs" % tag)
+        # the GNSS block: rows handed to ekfUpdate, which candidate rows passed their gates, how many variables the delayed
+        # initialisations have added so far, which GNSS scalars exist
+        added_total += len(g["gnss_added"])
+        if "gnss_rows" in s:
+            if int(g["gnss_rows"]) != int(s["gnss_rows"]) or not np.array_equal(np.asarray(g["gnss_keep"], dtype=np.int64), s["gnss_keep"]):
+                bad.append("%s: GNSS rows %d vs %d, keep %s vs %s" % (tag, int(g["gnss_rows"]), int(s["gnss_rows"]), np.asarray(g["gnss_keep"]).tolist(), s["gnss_keep"].tolist()))
+            if added_total != int(s["gnss_added_total"]):
+                bad.append("%s: GNSS variables added so far %d vs %d" % (tag, added_total, int(s["gnss_added_total"])))
+            if not np.array_equal(np.isnan(np.asarray(g["gnss_vals"])), np.isnan(s["gnss_vals"])):
+                bad.append("%s: GNSS scalars in the state differ" % tag)
         # rows handed to the Kalman update: the reference (and the oracle) count the stacked rows it keeps, the device works in
         # information form and always reports n = 6 x window clones (include/ingvio_hip.h, ingvio_msckf_opts::compress_rule) - the
         # same posterior; what must agree is WHETHER an update took place
@@ -88,6 +101,13 @@ def compare(gold, got, pose_tol=POSE_TOL, cov_tol=COV_TOL):
         dd = float(np.max(np.abs(np.asarray(g["diag"]) - s["diag"]) / np.maximum(np.abs(np.asarray(g["diag"])), 1e-300)))
         dn = abs(float(g["norm"]) - s["norm"]) / float(g["norm"])
         worst["pose"] = max(worst["pose"], dp); worst["diag"] = max(worst["diag"], dd); worst["norm"] = max(worst["norm"], dn)
+        if "gnss_vals" in s and np.any(~np.isnan(s["gnss_vals"])):
+            gv, sv = np.asarray(g["gnss_vals"]), s["gnss_vals"]
+            ok = ~np.isnan(gv)
+            dg = float(np.max(np.abs(gv[ok] - sv[ok]) / np.maximum(np.abs(gv[ok]), 1.0)))
+            worst["gnss"] = max(worst["gnss"], dg)
+            if dg > pose_tol:
+                bad.append("%s: GNSS scalars off by %.3e" % (tag, dg))
         if dp > pose_tol:
             bad.append("%s: nominal state off by %.3e" % (tag, dp))
         if dd > cov_tol or dn > cov_tol:
@@ -136,10 +156,17 @@ def test_golden_streams_cover_the_policies():
         assert per_frame == ({0, 2} if key else {0, 1}), (name, per_frame)
         n = np.array([t["n"] for t in tr])
         clones = int(spec.split("clones=")[1].split(",")[0])
-        assert n.max() == 21 + 6 * (clones - (1 if key else 0)), (name, n.max())       # state size after the frame's marginalisation
+        n_gnss = 5 if "gnss=1" in spec else 0                              # YOF, FS and three clock biases
+        assert n.max() == 21 + n_gnss + 6 * (clones - (1 if key else 0)), (name, n.max())       # state size after the frame's marginalisation
     assert max(int(np.sum(t["lost_acc"])) for t in load_golden("kf11")[0]) == 20          # RemoveLostUpdate.h:38
     assert max(int(np.sum(t["lost_acc"])) for t in load_golden("kf11_lifted")[0]) > 60
     assert seen["kf11"]["moved"] > 0 and seen["kf21"]["erased"] > 0 and seen["sw11"]["moved"] > 0
+    for name in ("sw11_gnss", "kf11_gnss"):                               # the GNSS block did its three things
+        tr = load_golden(name)[0]
+        assert tr[0]["gnss_added"].tolist() == [4, 0, 2, 3]              # FS, GPS, GAL, BDS by delayed initialisation at the first aligned epoch
+        assert max(t["gnss_rows"] for t in tr) == 16 and any(0 in t["gnss_keep"].tolist() for t in tr)      # the outlier's row refused by its gate
+        assert [v[0] for v in tr[-1]["table"].tolist()[4:9]] == [21, 22, 23, 24, 25]      # YOF, FS, GPS, GAL, BDS right after the extrinsics
+        assert not np.isnan(tr[-1]["gnss_vals"][[0, 2, 3, 4, 5]]).any() and np.isnan(tr[-1]["gnss_vals"][1])
 
 
 @needs_tool
@@ -147,7 +174,7 @@ def test_python_policy_replays_its_own_golden(tmp_path):
     """oracle/stream_filter.py on a freshly written recording reproduces the committed file (first 30 frames of two streams): the
     fixture is what the generator says it is, and the C oracle underneath is deterministic."""
     from oracle import gen_stream_golden as gen, stream_filter as sf
-    for name in ("kf11", "sw11"):
+    for name in ("kf11", "sw11", "sw11_gnss"):
         gold, spec, ov = load_golden(name)
         rec = str(tmp_path / (name + ".ingvior"))
         gen.write_recording(spec, rec)
@@ -157,6 +184,7 @@ def test_python_policy_replays_its_own_golden(tmp_path):
                 assert np.array_equal(np.asarray(g[k]), np.asarray(t[k], dtype=np.int64)), (name, k)
             assert g["stamp"] == t["stamp"] and np.array_equal(g["sel_stamps"], np.asarray(t["sel_stamps"], dtype=float))
             assert np.array_equal(g["pose"], t["pose"]) and np.array_equal(g["diag"], t["diag"])
+            assert np.array_equal(g["gnss_vals"], t["gnss_vals"], equal_nan=True) and g["gnss_rows"] == t["gnss_rows"]
 
 
 @needs_tool
@@ -187,8 +215,8 @@ def test_shim_stream_matches_golden(name):
     gold, spec, ov = load_golden(name)
     got = run_shim(spec, ov)
     bad, worst = compare(gold, got)
-    print("stream %s: %d frames, largest deviation: nominal state %.2e, diag(P) %.2e rel, |P|_F %.2e rel" % (name, len(got), worst["pose"], worst["diag"],
-                                                                                                             worst["norm"]))
+    print("stream %s: %d frames, largest deviation: nominal state %.2e, diag(P) %.2e rel, |P|_F %.2e rel, GNSS scalars %.2e rel"
+          % (name, len(got), worst["pose"], worst["diag"], worst["norm"], worst["gnss"]))
     assert not bad, "\n".join(bad[:10])
 
 
@@ -200,3 +228,14 @@ def test_shim_with_a_wrong_frame_select_interval_goes_red():
     got = run_shim(spec, ov, extra=["frame_select_interval: 4"])
     bad, _ = compare(gold, got)
     assert bad and "sel_stamps" in " ".join(bad), bad[:3]
+
+
+@needs_tool
+@pytest.mark.gpu
+def test_shim_without_the_gnss_row_gate_goes_red():
+    """The shim with gnss_chi2_test off against the golden stream made with it on: the outlier pseudo-range (from frame 8 on) is
+    fused instead of refused, and the comparison must say so at the GNSS rows."""
+    gold, spec, ov = load_golden("sw11_gnss")
+    got = run_shim(spec, ov, extra=["gnss_chi2_test: 0"])
+    bad, _ = compare(gold, got)
+    assert bad and "GNSS rows" in " ".join(bad), bad[:3]

@@ -42,6 +42,7 @@ static bool parseSynth(const std::string& spec, ingvio::SynthConfig& c)
         else if (k == "pixel_noise") c.pixel_noise = std::atof(v.c_str());
         else if (k == "visual_noise") c.visual_noise = std::atof(v.c_str());
         else if (k == "seed") c.seed = std::strtoull(v.c_str(), nullptr, 0);
+        else if (k == "gnss") c.enable_gnss = std::atoi(v.c_str());
         else return false;
     }
     return c.feats > 0 && c.clones >= 3 && c.life >= 1 && c.frames >= 1;
@@ -75,6 +76,15 @@ static void printTrace(int k, ingvio::IngvioFilter& f, bool keyframe)
     std::printf("SEL_ROWS %d\n", se.rows);
     printDoubles("MARG_STAMPS", mt.marg_stamps); printInts("CLEAN_ERASED", mt.clean_erased); printInts("ANCHOR_ERASED", mt.anchor_erased);
     printInts("ANCHOR_MOVED", mt.anchor_moved); printInts("INVALID_ERASED", f.lastInvalidErased());
+    // the GNSS block of the callback (IngvioFilter.cpp:329-362): rows handed to ekfUpdate, which candidate rows passed their gate, variables
+    // added so far (delayed initialisation), the GNSS scalars GPS GLO GAL BDS FS YOF (nan: not in the state)
+    std::printf("GNSS_ROWS %d\nGNSS_ADDED_TOTAL %d\n", f.lastGnssRows(), f.gnssVarsAdded());
+    printInts("GNSS_KEEP", f.gnssUpdate()->lastKeep());
+    {
+        std::vector<double> gv;
+        for (int t = 0; t < 6; ++t) { auto it = state->_gnss.find(t); gv.push_back(it != state->_gnss.end() ? it->second->value() : std::nan("")); }
+        printDoubles("GNSS_VALS", gv);
+    }
     std::vector<int> table;
     for (const auto& v : StateManager::errVariables(state)) { table.push_back(v->idx()); table.push_back(v->size()); }
     printInts("TABLE", table);
