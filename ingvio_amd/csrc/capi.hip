@@ -76,6 +76,9 @@ struct ingvio_ctx {
     int method;                    // 0 dense TSQR path, 1 factored (information-form) path
     int *d_accept, *d_used, *d_chunk_used, *d_colmap, *d_m, *d_nc, *d_status, *d_pcbase;
     double *d_big_sg, *d_big_wk;        // large-window workspaces (c_max > 16)
+    double* d_Asum = nullptr;           // [B][rstride]: the chunk partials of a filter summed (k_chunk_sum), windows up to 16 clones with G > 1
+    int* d_used_sum = nullptr;          // [B]
+    double* d_Tflat = nullptr;          // [min(B, APPLY_FLAT_NB)][ldp * 100]: T of the few-filter apply (k_apply_T_flat), windows up to 16 clones
 
     int* d_tri_ok;                      // [B][f_max] triangulation flags
     // ingvio_qr_compress, general path: device buffers and the captured launch sequence (~300 kernels) of the last shape
@@ -569,6 +572,12 @@ int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int s
     L.gamma = c->d_gamma; L.accept = c->d_accept; L.used = c->d_used; L.rec = c->d_rec;
     L.Apart = c->d_Rpart + (size_t)b0 * c->G * c->rstride; L.chunk_used = c->d_chunk_used + (size_t)b0 * c->G;
     L.G = c->G; L.rstride = c->rstride; L.noise = c->d_noise + b0;
+    L.Tflat = c->d_Tflat; L.tfstride = (size_t)c->ldp * 100; L.flat_nb = std::min(c->d.batch, APPLY_FLAT_NB);
+    L.Asum = c->d_Asum ? c->d_Asum + (size_t)b0 * c->rstride : nullptr; L.used_sum = c->d_used_sum ? c->d_used_sum + b0 : nullptr;
+#ifdef INGVIO_ALT_KERNELS      // INGVIO_FEW=off: few filters take the same kernels as a full batch (chunk partials added inside the solve, k_info_apply)
+    static const bool few_off = [] { const char* e = getenv("INGVIO_FEW"); return e && !strcmp(e, "off"); }();
+    if (few_off) { L.Tflat = nullptr; L.Asum = nullptr; }
+#endif
     L.T = c->d_Y + (size_t)b0 * c->ystride; L.Pc = c->d_Yc + (size_t)b0 * c->ystride; L.ystride = c->ystride;
     L.dx = c->d_dx; L.m_out = c->d_m + b0; L.nc_out = c->d_nc + b0; L.status = c->d_status;
     L.big_sg = c->d_big_sg ? c->d_big_sg + (size_t)b0 * bigwin_sg_doubles(c->G) : nullptr;
@@ -746,6 +755,8 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     rc |= dalloc(c, &c->d_H, (size_t)B * c->hstride); rc |= dalloc(c, &c->d_res, (size_t)B * c->mld);
     rc |= dalloc(c, &c->d_colmap, (size_t)B * c->cstride); rc |= dalloc(c, &c->d_nc, B); rc |= dalloc(c, &c->d_pcbase, B);
     rc |= dalloc(c, &c->d_tri_ok, (size_t)B * fm);
+    if (desc->c_max <= 16) rc |= dalloc(c, &c->d_Tflat, (size_t)std::min(B, APPLY_FLAT_NB) * c->ldp * 100);
+    if (desc->c_max <= 16 && c->G > 1) { rc |= dalloc(c, &c->d_Asum, (size_t)B * c->rstride); rc |= dalloc(c, &c->d_used_sum, B); }
     c->d_big_sg = nullptr; c->d_big_wk = nullptr;
     if (desc->c_max > 16) {
         rc |= dalloc(c, &c->d_big_sg, (size_t)B * bigwin_sg_doubles(c->G)); rc |= dalloc(c, &c->d_big_wk, (size_t)B * bigwin_wk_doubles());
@@ -770,7 +781,8 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
                      c->gn.H, c->gn.res, c->gn.noise, c->gn.gamma, c->gn.chi2, c->gn.m, c->gn.nc, c->gn.colmap, c->gn.keep,
                      c->gn.feph, c->gn.fobs, c->gn.frcv, c->gn.front,
                      c->dw.Hd, c->dw.X, c->dw.Y, c->dw.Tb, c->dw.noise, c->dw.noiseB, c->dw.m, c->dw.cidx, c->lm.pose, c->lm.pf, c->lm.uv, c->lm.gamma, c->lm.idx, c->lm.n_lm,
-                     c->lm.lm_idx, c->lm.anchor_idx, c->lm.tracked, c->lm.accept, c->lm.dx, c->d_xchg, c->dw.U, c->dw.rowmap, c->d_zero_idx };
+                     c->lm.lm_idx, c->lm.anchor_idx, c->lm.tracked, c->lm.accept, c->lm.dx, c->d_xchg, c->dw.U, c->dw.rowmap, c->d_zero_idx,
+                     c->d_Asum, c->d_used_sum, c->d_Tflat };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& sl : c->pin) { if (sl.p) hipHostFree(sl.p); if (sl.ev) hipEventDestroy(sl.ev); }
     if (c->h_result) hipHostFree(c->h_result);

@@ -2,6 +2,8 @@
 #pragma once
 #include "dev_common.h"
 
+constexpr int APPLY_FLAT_NB = 32;      // up to this many filters per launch take the one-wave-per-tile apply (kernels_factored.hip)
+
 struct FactoredLaunch {
     int stage;            // 0 gate, 1 gram, 2 info solve, 3 info apply (+ downdate); large windows also 5: the part of the solve that needs
                           // the prior only (gauge reference, [Pdd; I] -> [L; L^-T], Pc) - must have run before stage 2, may overlap 0 and 1
@@ -15,6 +17,11 @@ struct FactoredLaunch {
     int* used;
     double* rec;          // [B][fmax][rec_size] per-feature records (gate -> gram)
     double* Apart;
+    double* Asum;         // windows up to 16 clones, G > 1: [nb][rstride] the chunk partials summed before the solve (k_chunk_sum), or nullptr
+    int* used_sum;        // [nb]
+    double* Tflat;        // windows up to 16 clones, at most flat_nb filters: T = Pc M of the two-launch apply (k_apply_T_flat), [flat_nb][tfstride]
+    size_t tfstride;
+    int flat_nb;
     int* chunk_used;
     int G, rstride;
     const double* noise;

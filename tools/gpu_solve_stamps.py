@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, os.getcwd())
 import bench
 from ingvio_amd import capi, synth
-B = 512
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 ctx = capi.Context(batch=B, n_max=256, c_max=11, f_max=150, m_max=64)
 filters, steps, frames, infos = bench.build_batch(ctx, B, 0, 150, 11, 6, 52)
 ctx.snapshot(); pr = synth.PARAMS
