@@ -1026,8 +1026,9 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
 // (every tile re-reads its 2 x 16 x MP operands) - for batches that fill the chip k_info_apply stays.
 template <int NC>
 __global__ __launch_bounds__(256) void k_apply_T_flat(CovView cv, int b0, const double* __restrict__ Mall, int mstride, const double* __restrict__ Pcall,
-                                                      int ystride, const int* __restrict__ m_all, const int* __restrict__ pc_base,
-                                                      double* __restrict__ Tall, size_t tstride, double* __restrict__ dx_all)
+                                                      int ystride, const int* __restrict__ m_all, const int* __restrict__ marg_idx, int msize,
+                                                      const int* __restrict__ pc_base, double* __restrict__ Tall, size_t tstride,
+                                                      double* __restrict__ dx_all)
 {
     constexpr int MP = (NC + 3) & ~3, K4 = MP / 4, JT = (MP + 15) / 16;
     const int bl = blockIdx.y, b = b0 + bl;
@@ -1048,13 +1049,22 @@ __global__ __launch_bounds__(256) void k_apply_T_flat(CovView cv, int b0, const 
     for (int k4 = 0; k4 < K4; ++k4) pf[k4] = (Pc + (size_t)(4 * k4) * ld)[ra + kq * ld];             // Pc[row][k]
 #pragma unroll
     for (int k4 = 0; k4 < K4; ++k4) mf[k4] = (M + (size_t)(4 * k4) * MP)[kq * MP + jc];              // M[k][col]
-    if (tj == 0) {                                             // dx = Pc t, in the prior's index space (all n rows: the marginalised ones too)
+    const int midx = marg_idx ? marg_idx[bl] : -1;
+    if (tj == 0) {                                             // dx = Pc t, in the prior's index space
         double d = 0.0;
 #pragma unroll
         for (int k4 = 0; k4 < K4; ++k4) d += pf[k4] * tvec[4 * k4 + kq];
         d += __shfl_xor(d, 16, WAVE);
         d += __shfl_xor(d, 32, WAVE);
-        if (kq == 0 && 16 * ti + l15 < n) dx_all[(size_t)b * ld + ra] = d;
+        const bool marg_row = midx >= 0 && ra >= midx && ra < midx + msize;
+        if (kq == 0 && 16 * ti + l15 < n && !marg_row) dx_all[(size_t)b * ld + ra] = d;
+    }
+    if (midx >= 0 && t == 0) {      // the states about to be marginalised: summed the way k_info_apply sums them (one lane per row, k ascending)
+        for (int q = lane; q < msize; q += WAVE) {
+            double d = 0.0;
+            for (int k = 0; k < MP; ++k) d += Pc[midx + q + (size_t)k * ld] * tvec[k];
+            dx_all[(size_t)b * ld + midx + q] = d;
+        }
     }
     double4_f acc = { 0.0, 0.0, 0.0, 0.0 };                    // acc[r] = T[row 16 ti + l15][col 16 tj + kq + 4 r]
 #pragma unroll
@@ -1312,7 +1322,7 @@ int launch_factored(const FactoredLaunch& L, hipStream_t st)
             const int JTx = ncm <= 36 ? 3 : (ncm <= 66 ? 5 : 6);
 #define FLAT_DISPATCH(NC)                                                                                             \
             hipLaunchKernelGGL((k_apply_T_flat<NC>), dim3((nt * JTx + 3) / 4, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride, \
-                               L.m_out, L.pc_base, L.Tflat, L.tfstride, L.dx);                                          \
+                               L.m_out, L.marg_idx, L.marg_size, L.pc_base, L.Tflat, L.tfstride, L.dx);                 \
             hipLaunchKernelGGL((k_apply_sym_flat<NC>), dim3((nt * (nt + 1) / 2 + 3) / 4, L.nb), dim3(256), 0, st, L.cv, L.b0, L.Pc, L.ystride, \
                                L.m_out, L.marg_idx, L.marg_size, L.pc_base, L.Tflat, L.tfstride, L.status);
             if (ncm <= 36) { FLAT_DISPATCH(36) } else if (ncm <= 66) { FLAT_DISPATCH(66) } else { FLAT_DISPATCH(96) }

@@ -2,7 +2,10 @@
 #pragma once
 #include "dev_common.h"
 
-constexpr int APPLY_FLAT_NB = 32;      // up to this many filters per launch take the one-wave-per-tile apply (kernels_factored.hip)
+#ifndef INGVIO_APPLY_FLAT_NB
+#define INGVIO_APPLY_FLAT_NB 64
+#endif
+constexpr int APPLY_FLAT_NB = INGVIO_APPLY_FLAT_NB;      // up to this many filters per launch take the one-wave-per-tile apply (kernels_factored.hip)
 
 struct FactoredLaunch {
     int stage;            // 0 gate, 1 gram, 2 info solve, 3 info apply (+ downdate); large windows also 5: the part of the solve that needs

@@ -11,6 +11,8 @@ process) that runs the parity tests covering it.  One toggle per case:
   INGVIO_APPLY_TW=2        k_info_apply with two tile columns per step
   INGVIO_LM_FRONT=split    landmark update with k_lm_build + k_lm_products (compacting) instead of the fused front
   INGVIO_LM_SOLVE=sweep    landmark / dense-H update on the Cholesky sweep out of L2 instead of the register-resident solve
+  INGVIO_FEW=off           few filters (B <= 32) on the kernels of a full batch: chunk partials added inside the solve, k_info_apply
+                           (the product sums them with k_chunk_sum first and applies with one wave per tile, k_apply_*_flat)
 """
 import os
 import subprocess
@@ -30,6 +32,8 @@ CASES = [
     ("INGVIO_INFO_GAUGE", "off", ["tests/test_gpu_parity.py", "-k", "test_full_n249_batch_vs_oracle or test_large_window_vs_oracle or test_window_size_classes"]),
     ("INGVIO_INFO_SOLVE", "gj", ["tests/test_gpu_parity.py", "-k", "test_full_n249_batch_vs_oracle or test_window_size_classes"]),
     ("INGVIO_APPLY_TW", "2", ["tests/test_gpu_parity.py", "-k", "test_full_n249_batch_vs_oracle or test_window_size_classes or test_consecutive_frames"]),
+    ("INGVIO_FEW", "off", ["tests/test_gpu_parity.py", "tests/test_gpu_pinning.py", "-k",
+                           "test_msckf_small or test_window_size_classes or test_ragged or test_consecutive_frames or test_sigma_and_prior_scale_sweep"]),
     ("INGVIO_LM_FRONT", "split", ["tests/test_landmark_batch.py"]),
     ("INGVIO_LM_SOLVE", "sweep", ["tests/test_landmark_batch.py"]),
 ]
@@ -48,3 +52,40 @@ def test_alternative_path_stays_correct(var, value, args):
     tail = "\n".join(r.stdout.strip().splitlines()[-15:])
     assert r.returncode == 0, "%s=%s:\n%s\n%s" % (var, value, tail, r.stderr[-2000:])
     assert " passed" in tail and " failed" not in tail, tail
+
+
+FEW_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import bench
+from ingvio_amd import capi, synth
+B = int(sys.argv[2])
+ctx = capi.Context(batch=B, n_max=256, c_max=11, f_max=150, m_max=64)
+filters, steps, frames, infos = bench.build_batch(ctx, B, 0, 150, 11, 6, 52)
+ctx.snapshot(); pr = synth.PARAMS
+ctx.frame_stage(0, steps, frames, filters[0].sigma(), 1, pr["sigma_cb"], pr["sigma_rw"])
+ctx.frame_run(restore_prior=True)
+dx, acc, rows = ctx.frame_fetch()
+np.savez(sys.argv[1], P=np.stack([np.asarray(ctx.cov_get(b)) for b in range(B)]), dx=dx, acc=acc, rows=rows)
+"""
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_few_filter_path_is_bit_identical_to_the_full_batch_kernels(tmp_path, B):
+    """k_chunk_sum + k_apply_T_flat / k_apply_sym_flat (what B <= 32 filters take) form the same sums and products in the same order as
+    the chunk loop of k_info_solve and k_info_apply: posterior, dx and accept masks of a whole frame (N = 249, 150 features, fused
+    marginalisation) are equal to the last bit."""
+    if not os.path.exists(ALT_LIB):
+        pytest.skip("build_var/alt/libingvio_hip.so not built")
+    import numpy as np
+    outs = []
+    for tag, extra in (("few", {}), ("full", {"INGVIO_HIP_LIB": ALT_LIB, "INGVIO_FEW": "off"})):
+        env = dict(os.environ); env.update(extra)
+        out = str(tmp_path / ("%s.npz" % tag))
+        r = subprocess.run([sys.executable, "-c", FEW_CHILD % ROOT, out, str(B)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert np.array_equal(a["acc"], b["acc"]) and np.array_equal(a["rows"], b["rows"]) and a["acc"].sum() > 50 * B
+    assert np.array_equal(a["dx"], b["dx"]), float(np.max(np.abs(a["dx"] - b["dx"])))
+    assert np.array_equal(a["P"], b["P"]), float(np.max(np.abs(a["P"] - b["P"])))
