@@ -390,6 +390,16 @@ typedef struct {
 } ingvio_tri_opts;
 int ingvio_triangulate(ingvio_ctx* ctx, int b0, int nb, const ingvio_msckf_frame* frames, const ingvio_tri_opts* opts,
                        double* pf_out, int* ok_out);
+/* RemoveLostUpdate::updateStateStereo / Mono in ONE device round trip (RemoveLostUpdate.cpp:276-405, :41-170): the reference
+ * triangulates every lost feature (MapServerManager.cpp:274-341), drops the ones that fail and updates with the rest.  Here the
+ * staged features' points are triangulated on the device from the frame's own observations (frames[].pf is ignored), a feature whose
+ * triangulation fails - including a point behind its anchor camera, MapServerManager.cpp:290,325 - drops out of the update on the
+ * device (tri_ok[i] = 0, accepted[i] = 0), and the rest is ingvio_msckf_update.  pf_out [nb][f_max][3], tri_ok [nb][f_max] (may be
+ * NULL).  One upload, one download, one synchronisation: ingvio_triangulate + ingvio_msckf_update cost a single real-time filter
+ * two of each and the host a second packing of the same observations (round 5). */
+int ingvio_msckf_update_tri(ingvio_ctx* ctx, int b0, int nb, const ingvio_msckf_frame* frames, const ingvio_msckf_opts* opts,
+                            const ingvio_tri_opts* tri, double* dx_out, int* accepted, double* gamma, int* rows_out,
+                            double* pf_out, int* tri_ok);
 
 /* ---- one benchmark "update" for the whole batch ------------------------------
  * k-step propagation + clone + MSCKF update + marginalise one clone, all filters, no host

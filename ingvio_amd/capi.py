@@ -24,7 +24,7 @@ EXPORTS = [
     "ingvio_build_id",
     "ingvio_cov_set", "ingvio_cov_get", "ingvio_get_n", "ingvio_cov_get_marginal", "ingvio_cov_snapshot",
     "ingvio_cov_restore", "ingvio_propagate", "ingvio_propagate_fused", "ingvio_augment_clone", "ingvio_marginalize",
-    "ingvio_append_independent", "ingvio_ekf_update", "ingvio_chi2_gamma", "ingvio_msckf_update", "ingvio_qr_compress",
+    "ingvio_append_independent", "ingvio_ekf_update", "ingvio_chi2_gamma", "ingvio_msckf_update", "ingvio_msckf_update_tri", "ingvio_qr_compress",
     "ingvio_frame_stage", "ingvio_frame_stage_async", "ingvio_frame_run", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_select",
     "ingvio_profile_reset",
     "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_set_qr_method", "ingvio_landmark_stage", "ingvio_landmark_run",
@@ -554,6 +554,36 @@ class Context:
         rc = self.L.ingvio_msckf_update(self.h, b0, nb, arr, C.byref(o), _d(dx), _i(acc), _d(gam), _i(rows))
         self._chk(rc)
         return dx, acc, gam, rows
+
+    def msckf_update_tri(self, b0, frames, max_accept=0, compress_rule=1, selected_variant=0, stereo=True, **params):
+        """ingvio_msckf_update_tri: the frames' points are triangulated on the device from their own observations (pf of the frame
+        dicts is ignored), failed features drop out.  Returns (dx, accepted, gamma, rows, pf[nb, f_max, 3], tri_ok[nb, f_max])."""
+        if isinstance(frames, dict):
+            frames = [frames]
+        nb = len(frames)
+        arr = (MsckfFrame * nb)()
+        keeps = []
+        for i, fr in enumerate(frames):
+            f, k = make_frame(fr)
+            arr[i] = f; keeps.append(k)
+        o, chi2 = make_opts(frames[0], max_accept, compress_rule, selected_variant)
+        pr = dict(trans_thres=0.1, huber_epsilon=0.01, conv_precision=5e-7, init_damping=1e-3, outer_loop_max_iter=10,
+                  inner_loop_max_iter=10, max_depth=60.0, min_depth=0.2)
+        pr.update(params)
+        t = TriOpts()
+        t.stereo = 1 if stereo else 0
+        Rl = f64(frames[0]["R_cl2cr"]).reshape(-1); tl = f64(frames[0]["t_cl2cr"])
+        for i in range(9):
+            t.R_cl2cr[i] = float(Rl[i])
+        for i in range(3):
+            t.t_cl2cr[i] = float(tl[i])
+        for k, v in pr.items():
+            setattr(t, k, v)
+        dx = np.zeros((nb, self.ldp)); acc = np.zeros((nb, self.f_max), dtype=np.int32)
+        gam = np.zeros((nb, self.f_max)); rows = np.zeros(nb, dtype=np.int32)
+        pf = np.zeros((nb, self.f_max, 3)); ok = np.zeros((nb, self.f_max), dtype=np.int32)
+        self._chk(self.L.ingvio_msckf_update_tri(self.h, b0, nb, arr, C.byref(o), C.byref(t), _d(dx), _i(acc), _d(gam), _i(rows), _d(pf), _i(ok)))
+        return dx, acc, gam, rows, pf, ok
 
     def qr_compress(self, H, res):
         H = np.asfortranarray(H, dtype=np.float64)

@@ -66,7 +66,7 @@ struct ingvio_ctx {
     // frame staging
     char* d_result_slab = nullptr;                     // d_dx | d_gamma | d_used | d_m | d_status are views into it; h_result: pinned mirror
     char* h_result = nullptr;
-    size_t result_bytes = 0, ro_gam = 0, ro_used = 0, ro_m = 0, ro_st = 0;
+    size_t result_bytes = 0, ro_gam = 0, ro_used = 0, ro_m = 0, ro_st = 0, ro_tok = 0, ro_tpf = 0;      // ro_tok / ro_tpf: triangulation flags and points (ingvio_msckf_update_tri)
     char* d_frame_slab[2] = { nullptr, nullptr };      // the frame arrays below are views into these (frame_slab_carve); [1]: the async set
     int *d_clone_idx, *d_nclones, *d_nfeat, *d_anchor, *d_dof;
     double *d_clone_R, *d_clone_p, *d_pf, *d_uv, *d_chi2;
@@ -742,10 +742,11 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
         // the results an update call hands back - dx, gamma, used flags, row count, status - sit in ONE device slab (and a pinned
         // mirror): a whole-batch fetch is one device-to-host copy instead of five (~18 us each for a single filter)
         const size_t o_dx = 0, o_gam = pad64(8 * (size_t)B * c->ldp), o_used = o_gam + pad64(8 * (size_t)B * fm), o_m = o_used + pad64(4 * (size_t)B * fm),
-                     o_st = o_m + pad64(4 * (size_t)B), tot = o_st + pad64(4 * (size_t)B);
+                     o_st = o_m + pad64(4 * (size_t)B), o_tok = o_st + pad64(4 * (size_t)B), o_tpf = o_tok + pad64(4 * (size_t)B * fm),
+                     tot = o_tpf + pad64(8 * (size_t)B * fm * 3);
         if (dalloc(c, &c->d_result_slab, tot) || hipHostMalloc((void**)&c->h_result, tot, hipHostMallocDefault) != hipSuccess) rc |= 1;
         else {
-            c->result_bytes = tot; c->ro_gam = o_gam; c->ro_used = o_used; c->ro_m = o_m; c->ro_st = o_st;
+            c->result_bytes = tot; c->ro_gam = o_gam; c->ro_used = o_used; c->ro_m = o_m; c->ro_st = o_st; c->ro_tok = o_tok; c->ro_tpf = o_tpf;
             c->d_dx = (double*)(c->d_result_slab + o_dx); c->d_gamma = (double*)(c->d_result_slab + o_gam);
             c->d_used = (int*)(c->d_result_slab + o_used); c->d_m = (int*)(c->d_result_slab + o_m); c->d_status = (int*)(c->d_result_slab + o_st);
         }
@@ -1588,11 +1589,13 @@ int ingvio_chi2_gamma_multi(ingvio_ctx* c, int b, int nblk, const ingvio_gate_bl
     return last_launch(c);
 }
 
-int ingvio_msckf_update(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* frames, const ingvio_msckf_opts* opts,
-                        double* dx_out, int* accepted, double* gamma, int* rows_out)
+// tri != nullptr: the points of the staged features are triangulated on the device first (ingvio_msckf_update_tri)
+static int msckf_update_impl(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* frames, const ingvio_msckf_opts* opts, const ingvio_tri_opts* tri,
+                             double* dx_out, int* accepted, double* gamma, int* rows_out, double* pf_out, int* tri_ok)
 {
     if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || !frames || !opts) return INGVIO_E_ARG;
+    if (tri && (tri->outer_loop_max_iter < 0 || tri->inner_loop_max_iter < 0)) return INGVIO_E_ARG;
     MsckfOpts op;
     int rc = make_opts(c, opts, &op);
     if (rc) return rc;
@@ -1602,19 +1605,35 @@ int ingvio_msckf_update(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame*
     rc = fill_noise_scalar(c, b0, nb, op.var);
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_status + b0, 0, sizeof(int) * (size_t)nb, c->st));
+    const int fm = c->d.f_max;
+    if (tri) {
+        TriLaunch T;
+        memset(&T, 0, sizeof T);
+        T.fv = fview(c); T.b0 = b0;
+        memcpy(T.R_lr, tri->R_cl2cr, 72); memcpy(T.t_lr, tri->t_cl2cr, 24);
+        T.trans_thres = tri->trans_thres; T.huber_epsilon = tri->huber_epsilon; T.conv_precision = tri->conv_precision;
+        T.init_damping = tri->init_damping; T.max_depth = tri->max_depth; T.min_depth = tri->min_depth;
+        T.outer_loop_max_iter = tri->outer_loop_max_iter; T.inner_loop_max_iter = tri->inner_loop_max_iter;
+        T.pf = c->d_pf; T.ok = c->d_tri_ok; T.mask_failed = 1; T.mask_rw = c->d_mask; T.check_anchor = 1;
+        T.ok2 = (int*)(c->d_result_slab + c->ro_tok); T.pf2 = (double*)(c->d_result_slab + c->ro_tpf);
+        if (launch_triangulate(T, nb, fmx > 0 ? fmx : 1, tri->stereo, c->st)) return INGVIO_E_UNSUPPORTED;
+    }
     rc = run_msckf(c, b0, nb, op, opts->stereo, fmx);
     if (rc) return rc;
-    const int fm = c->d.f_max;
     std::vector<int> rows(nb), status(nb);
     if (b0 == 0 && nb == c->d.batch && c->result_bytes <= (1u << 20)) {      // the whole batch, small: one copy of the result slab
-        HIPCHK(c, hipMemcpyAsync(c->h_result, c->d_result_slab, c->result_bytes, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipMemcpyAsync(c->h_result, c->d_result_slab, tri ? c->result_bytes : c->ro_tok, hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipStreamSynchronize(c->st));
         if (dx_out) memcpy(dx_out, c->h_result, 8 * (size_t)nb * c->ldp);
         if (gamma) memcpy(gamma, c->h_result + c->ro_gam, 8 * (size_t)nb * fm);
         if (accepted) memcpy(accepted, c->h_result + c->ro_used, sizeof(int) * (size_t)nb * fm);
         memcpy(rows.data(), c->h_result + c->ro_m, sizeof(int) * (size_t)nb);
         memcpy(status.data(), c->h_result + c->ro_st, sizeof(int) * (size_t)nb);
+        if (tri && tri_ok) memcpy(tri_ok, c->h_result + c->ro_tok, sizeof(int) * (size_t)nb * fm);
+        if (tri && pf_out) memcpy(pf_out, c->h_result + c->ro_tpf, 8 * (size_t)nb * fm * 3);
     } else {
+        if (tri && tri_ok) HIPCHK(c, hipMemcpyAsync(tri_ok, c->d_result_slab + c->ro_tok + sizeof(int) * (size_t)b0 * fm, sizeof(int) * (size_t)nb * fm, hipMemcpyDeviceToHost, c->st));
+        if (tri && pf_out) HIPCHK(c, hipMemcpyAsync(pf_out, c->d_result_slab + c->ro_tpf + 8 * (size_t)b0 * fm * 3, 8 * (size_t)nb * fm * 3, hipMemcpyDeviceToHost, c->st));
         if (dx_out) HIPCHK(c, hipMemcpyAsync(dx_out, c->d_dx + (size_t)b0 * c->ldp, 8 * (size_t)nb * c->ldp, hipMemcpyDeviceToHost, c->st));
         if (accepted) HIPCHK(c, hipMemcpyAsync(accepted, c->d_used + (size_t)b0 * fm, sizeof(int) * (size_t)nb * fm, hipMemcpyDeviceToHost, c->st));
         if (gamma) HIPCHK(c, hipMemcpyAsync(gamma, c->d_gamma + (size_t)b0 * fm, 8 * (size_t)nb * fm, hipMemcpyDeviceToHost, c->st));
@@ -1631,6 +1650,19 @@ int ingvio_msckf_update(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame*
         if (status[i] & 2) soft = INGVIO_NEG_DIAG;
     }
     return nb == 1 ? soft : (soft == INGVIO_NEG_DIAG ? soft : INGVIO_OK);
+}
+
+int ingvio_msckf_update(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* frames, const ingvio_msckf_opts* opts,
+                        double* dx_out, int* accepted, double* gamma, int* rows_out)
+{
+    return msckf_update_impl(c, b0, nb, frames, opts, nullptr, dx_out, accepted, gamma, rows_out, nullptr, nullptr);
+}
+
+int ingvio_msckf_update_tri(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* frames, const ingvio_msckf_opts* opts,
+                            const ingvio_tri_opts* tri, double* dx_out, int* accepted, double* gamma, int* rows_out, double* pf_out, int* tri_ok)
+{
+    if (!tri) return INGVIO_E_ARG;
+    return msckf_update_impl(c, b0, nb, frames, opts, tri, dx_out, accepted, gamma, rows_out, pf_out, tri_ok);
 }
 
 // ---- SLAM-landmark covariance operations -------------------------------------------------------

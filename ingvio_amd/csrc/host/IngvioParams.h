@@ -51,6 +51,7 @@ public:
     // (RemoveLostUpdate.h:38: 20; 0 = no cap) and its compression rule (0 = keep all rows after the rotation, RemoveLostUpdate.cpp:390;
     // 1 = keep the top n rows like the other two update classes)
     int _hip_max_valid_ids = 20, _hip_compress_rule = 0;
+    int _hip_fuse_triangulation = 1;      // RemoveLost: triangulation + update in one device round trip (ingvio_msckf_update_tri); 0: two calls
 };
 
 }  // namespace ingvio

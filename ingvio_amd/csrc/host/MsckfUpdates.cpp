@@ -1,4 +1,5 @@
 #include <chrono>
+#include <typeinfo>
 #include <cstdio>
 #include <cstdlib>
 #include "MsckfUpdates.h"
@@ -98,6 +99,17 @@ bool Triangulator::triangulate(std::shared_ptr<FeatureInfo> fi, const std::share
     return accept(fi, flag, pf);
 }
 
+void Triangulator::fillOpts(const std::shared_ptr<State>& state, bool stereo, ingvio_tri_opts& o) const
+{
+    std::memset(&o, 0, sizeof o);
+    o.stereo = stereo ? 1 : 0;
+    std::memcpy(o.R_cl2cr, state->_state_params._T_cl2cr.R.m, sizeof o.R_cl2cr);
+    std::memcpy(o.t_cl2cr, state->_state_params._T_cl2cr.t.v, sizeof o.t_cl2cr);
+    o.trans_thres = _trans_thres; o.huber_epsilon = _huber_epsilon; o.conv_precision = _conv_precision;
+    o.init_damping = _init_damping; o.outer_loop_max_iter = _outer_loop_max_iter; o.inner_loop_max_iter = _inner_loop_max_iter;
+    o.max_depth = _max_depth; o.min_depth = _min_depth;
+}
+
 void Triangulator::triangulateMany(const std::vector<std::shared_ptr<FeatureInfo>>& feats, const std::shared_ptr<State> state, bool stereo,
                                    std::vector<char>& ok)
 {
@@ -121,13 +133,7 @@ void Triangulator::triangulateMany(const std::vector<std::shared_ptr<FeatureInfo
         cp.insert(cp.end(), p.v, p.v + 3);
     }
     ingvio_tri_opts o;
-    std::memset(&o, 0, sizeof o);
-    o.stereo = stereo ? 1 : 0;
-    std::memcpy(o.R_cl2cr, state->_state_params._T_cl2cr.R.m, sizeof o.R_cl2cr);
-    std::memcpy(o.t_cl2cr, state->_state_params._T_cl2cr.t.v, sizeof o.t_cl2cr);
-    o.trans_thres = _trans_thres; o.huber_epsilon = _huber_epsilon; o.conv_precision = _conv_precision;
-    o.init_damping = _init_damping; o.outer_loop_max_iter = _outer_loop_max_iter; o.inner_loop_max_iter = _inner_loop_max_iter;
-    o.max_depth = _max_depth; o.min_depth = _min_depth;
+    fillOpts(state, stereo, o);
     for (size_t f0 = 0; f0 < feats.size(); f0 += (size_t)fcap) {    // the device frame holds f_max features
         const int nf = (int)std::min((size_t)fcap, feats.size() - f0);
         std::vector<unsigned long long> mask((size_t)nf, 0ULL);
@@ -241,7 +247,8 @@ ingvio_msckf_opts makeOpts(const std::shared_ptr<State>& state, bool stereo, dou
 
 // ---------------------------------------------------------------------------------------------
 RemoveLostUpdate::RemoveLostUpdate(const IngvioParams& fp)
-    : UpdateBase(fp._chi2_max_dof, fp._chi2_thres), _max_valid_ids(fp._hip_max_valid_ids), _compress_rule(fp._hip_compress_rule), _noise(fp._visual_noise) {}
+    : UpdateBase(fp._chi2_max_dof, fp._chi2_thres), _max_valid_ids(fp._hip_max_valid_ids), _compress_rule(fp._hip_compress_rule), _fuse_tri(fp._hip_fuse_triangulation != 0),
+      _noise(fp._visual_noise) {}
 
 void RemoveLostUpdate::updateStateMono(std::shared_ptr<State> s, std::shared_ptr<MapServer> m, std::shared_ptr<Triangulator> t) { update(s, m, t, false); }
 void RemoveLostUpdate::updateStateStereo(std::shared_ptr<State> s, std::shared_ptr<MapServer> m, std::shared_ptr<Triangulator> t) { update(s, m, t, true); }
@@ -250,16 +257,57 @@ void RemoveLostUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapS
 {
     _last_rows = 0; _last_accepted = 0;
     _rec.clear();
+    static const bool timing = std::getenv("INGVIO_SHIM_TIMING") != nullptr;      // host wall time of the update's phases on stderr (debugging aid)
+    using clk = std::chrono::steady_clock;
+    auto us = [](clk::time_point x, clk::time_point y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
+    clk::time_point qm, q0, q1, q2, q3;
+    if (timing) qm = clk::now();
     markMargFeatures(map_server, state, stereo);                                       // RemoveLostUpdate.cpp:43 / :279
     std::vector<int> update_ids, direct_marg_ids, cand_ids;
     std::vector<std::shared_ptr<FeatureInfo>> cand;
     for (auto& item : *map_server)
         if (item.second->_ftype == FeatureInfo::MSCKF && item.second->_isToMarg) { cand_ids.push_back(item.first); cand.push_back(item.second); }
-    static const bool timing = std::getenv("INGVIO_SHIM_TIMING") != nullptr;      // host wall time of the update's phases on stderr (debugging aid)
-    using clk = std::chrono::steady_clock;
-    auto us = [](clk::time_point x, clk::time_point y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
-    clk::time_point q0, q1, q2, q3;
     if (timing) q0 = clk::now();
+    // Triangulation and update in ONE device round trip (ingvio_msckf_update_tri, round 5): every candidate with enough observations is
+    // staged, the device triangulates, drops what fails (MapServerManager.cpp:283-305 / :318-340 incl. the depth in the anchor camera)
+    // and updates with the rest - the same features, points and order the two calls below produce, minus a synchronisation, a download,
+    // an upload and a second packing of the observations (0.11 of the 0.5 ms a lost cohort of 150 tracks costs a single filter).  Every
+    // candidate is erased below either way, so nothing of the triangulation has to return to the map server.  Only for the stock
+    // Triangulator (a subclass may triangulate differently) and windows / feature counts one device frame holds.
+    const int n_sw = (int)state->_sw_camleft_poses.size();
+    if (_fuse_tri && typeid(*tri) == typeid(Triangulator) && !cand.empty() && n_sw > 0 && n_sw <= 64 && n_sw <= ingvio_c_max(StateManager::ctx(state)) &&
+        (int)cand.size() <= ingvio_f_max(StateManager::ctx(state))) {
+        FlatFrame ff(state);
+        std::vector<int> slot(cand.size(), -1);                // -1: not enough observations (dropped), -2: updated outside the frame, >= 0: slot in the frame
+        int max_dof = 1;
+        for (size_t i = 0; i < cand.size(); ++i) {
+            const bool enough = stereo ? cand[i]->numOfStereoFrames() >= 3 : cand[i]->numOfMonoFrames() >= 4;           // :287 / :51
+            if (!enough) continue;
+            const int dof = (stereo ? (int)cand[i]->_stereo_obs.size() : (int)cand[i]->_mono_obs.size()) - 1;           // :332-333 (Q4)
+            if (ff.add(cand[i], stereo, nullptr, dof)) { slot[i] = ff.F - 1; if (dof > max_dof) max_dof = dof; }
+            else if (tri->triangulate(cand[i], state, stereo)) slot[i] = -2;      // anchor outside the window / nothing observed in it: as before
+        }
+        if (timing) q1 = q2 = clk::now();
+        std::vector<int> acc, tok;
+        if (ff.F > 0) {
+            const std::vector<double> table = chi2TableDense(max_dof + 1);
+            const ingvio_msckf_frame fr = ff.view();
+            const ingvio_msckf_opts op = makeOpts(state, stereo, _noise, table, _max_valid_ids, _compress_rule /* 0 = as written, Q2 */, 0);
+            ingvio_tri_opts to;
+            tri->fillOpts(state, stereo, to);
+            _last_rows = StateManager::msckfUpdateTri(state, fr, op, to, &acc, &tok);
+        }
+        if (timing) q3 = clk::now();
+        for (size_t i = 0; i < cand.size(); ++i) {
+            if (slot[i] >= 0 && tok[slot[i]]) { _rec.ids.push_back(cand_ids[i]); _rec.accepted.push_back(acc[slot[i]]); _last_accepted += acc[slot[i]]; }
+            else if (slot[i] != -2) _rec.direct.push_back(cand_ids[i]);
+        }
+        _rec.rows = _last_rows;
+        for (int id : cand_ids) map_server->erase(id);                                                // :301-302, :402-403
+        if (timing) std::fprintf(stderr, "SHIM remove_lost us (one call): mark + candidates %.1f, frame of %d features %.1f, triangulate + msckfUpdate %.1f, erase %.1f\n",
+                                 us(qm, q0), ff.F, us(q0, q1), us(q2, q3), us(q3, clk::now()));
+        return;
+    }
     std::vector<char> tri_ok;
     tri->triangulateMany(cand, state, stereo, tri_ok);                 // one device call for the frame's lost features
     if (timing) q1 = clk::now();
@@ -291,8 +339,8 @@ void RemoveLostUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapS
     }
     if (timing) q3 = clk::now();
     for (const auto& id : update_ids) map_server->erase(id);                                          // :402-403
-    if (timing) std::fprintf(stderr, "SHIM remove_lost us: triangulate %zu features %.1f, frame of %d features %.1f, msckfUpdate %.1f, erase %.1f\n",
-                             cand.size(), us(q0, q1), ff.F, us(q1, q2), us(q2, q3), us(q3, clk::now()));
+    if (timing) std::fprintf(stderr, "SHIM remove_lost us: mark + candidates %.1f, triangulate %zu features %.1f, frame of %d features %.1f, msckfUpdate %.1f, erase %.1f\n",
+                             us(qm, q0), cand.size(), us(q0, q1), ff.F, us(q1, q2), us(q2, q3), us(q3, clk::now()));
 }
 
 // ---------------------------------------------------------------------------------------------

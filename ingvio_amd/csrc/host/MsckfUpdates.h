@@ -12,6 +12,7 @@
 
 #include <map>
 
+#include "ingvio_hip.h"
 #include "IngvioParams.h"
 #include "MapServer.h"
 #include "Update.h"
@@ -43,6 +44,8 @@ public:
     // names its observations by a mask over the window slots.
     virtual void triangulateMany(const std::vector<std::shared_ptr<FeatureInfo>>& features, const std::shared_ptr<State> state, bool stereo,
                                  std::vector<char>& ok);
+    // this object's parameters as the device call takes them (RemoveLostUpdate hands them to ingvio_msckf_update_tri)
+    void fillOpts(const std::shared_ptr<State>& state, bool stereo, ingvio_tri_opts& o) const;
 
 protected:
     bool accept(std::shared_ptr<FeatureInfo> fi, bool flag, const Vec3d& pf) const;      // MapServerManager.cpp:283-305 / :318-340
@@ -84,6 +87,7 @@ protected:
     void update(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri, bool stereo);
     int _max_valid_ids;
     int _compress_rule = 0;
+    bool _fuse_tri = true;      // IngvioParams::_hip_fuse_triangulation
     double _noise;
     int _last_rows = 0, _last_accepted = 0;
     UpdateRecord _rec;

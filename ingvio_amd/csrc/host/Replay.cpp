@@ -239,6 +239,7 @@ bool applyParamsText(const std::string& text, IngvioParams& p)
         else if (key == "hip_device") inum(p._hip_device);
         else if (key == "hip_max_valid_ids") inum(p._hip_max_valid_ids);
         else if (key == "hip_compress_rule") inum(p._hip_compress_rule);
+        else if (key == "hip_fuse_triangulation") inum(p._hip_fuse_triangulation);
         else continue;                             // topics, tracker and aligner keys: not read by this path
         if (vs.fail()) ok = false;
     }

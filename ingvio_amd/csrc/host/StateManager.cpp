@@ -407,6 +407,24 @@ void StateManager::triangulateFrame(std::shared_ptr<State> state, const ingvio_m
     for (int j = 0; j < frame.n_feat; ++j) { pf[j] = Vec3d(pfo[3 * j], pfo[3 * j + 1], pfo[3 * j + 2]); ok[j] = oko[j] != 0; }
 }
 
+int StateManager::msckfUpdateTri(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_msckf_opts& opts,
+                                 const ingvio_tri_opts& tri, std::vector<int>* accepted, std::vector<int>* tri_ok)
+{
+    const int ldp = ingvio_ldp(state->_ctx), fm = std::max(ingvio_f_max(state->_ctx), frame.n_feat);
+    VecXd dx(ldp, 0.0);
+    std::vector<int> acc(fm, 0), tok(fm, 0);
+    int rows = 0;
+    const int rc = ingvio_msckf_update_tri(state->_ctx, state->_b, 1, &frame, &opts, &tri, dx.data(), acc.data(), nullptr, &rows, nullptr, tok.data());
+    if (rc < 0) fatal(state, "msckfUpdateTri", rc);
+    if (accepted) accepted->assign(acc.begin(), acc.begin() + frame.n_feat);
+    if (tri_ok) tri_ok->assign(tok.begin(), tok.begin() + frame.n_feat);
+    if (rows > 0) {
+        dx.resize(state->curr_cov_size());
+        boxPlus(state, dx);
+    }
+    return rows;
+}
+
 int StateManager::msckfUpdate(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_msckf_opts& opts,
                               std::vector<int>* accepted)
 {

@@ -73,6 +73,9 @@ public:
                                  std::vector<Vec3d>& pf, std::vector<char>& ok);
     static int msckfUpdate(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_msckf_opts& opts,
                            std::vector<int>* accepted = nullptr);
+    // the same with the frame's points triangulated on the device first (ingvio_msckf_update_tri): tri_ok[j] for j < frame.n_feat
+    static int msckfUpdateTri(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_msckf_opts& opts,
+                              const ingvio_tri_opts& tri, std::vector<int>* accepted, std::vector<int>* tri_ok);
 
     static ingvio_ctx* ctx(const std::shared_ptr<State>& state) { return state->_ctx; }
     static int filterIndex(const std::shared_ptr<State>& state) { return state->_b; }

@@ -161,6 +161,7 @@ __global__ __launch_bounds__(TRI_NT) void k_triangulate(TriLaunch L)
             pf_out[0] = pf_out[1] = pf_out[2] = 0.0;
             L.ok[oidx] = 0;
             if (L.mask_failed) L.mask_rw[oidx] = 0ULL;
+            if (L.ok2) { L.ok2[oidx] = 0; L.pf2[oidx * 3] = L.pf2[oidx * 3 + 1] = L.pf2[oidx * 3 + 2] = 0.0; }
         }
     };
     const int n = EYES * __popcll(mask);
@@ -330,9 +331,18 @@ __global__ __launch_bounds__(TRI_NT) void k_triangulate(TriLaunch L)
     m3mulv(Rl, plast, w3);
     w3[0] += pl[0]; w3[1] += pl[1]; w3[2] += pl[2];
     if (w3[0] != w3[0] || w3[1] != w3[1] || w3[2] != w3[2]) { fail(); return; }
+    if (L.check_anchor) {                                                           // MapServerManager.cpp:290,325: depth in the anchor's (left) camera
+        const int a = fv.anchor[oidx];
+        if (a < 0 || a >= C) { fail(); return; }
+        const double* Ra = sR[0][a];
+        const double* pa = sP[0][a];
+        const double z = Ra[2] * (w3[0] - pa[0]) + Ra[5] * (w3[1] - pa[1]) + Ra[8] * (w3[2] - pa[2]);      // (R_a^T (p_f - p_a)).z
+        if (z <= 0.0) { fail(); return; }
+    }
     if (q == 0) {
         pf_out[0] = w3[0]; pf_out[1] = w3[1]; pf_out[2] = w3[2];
         L.ok[oidx] = 1;
+        if (L.ok2) { L.ok2[oidx] = 1; L.pf2[oidx * 3] = w3[0]; L.pf2[oidx * 3 + 1] = w3[1]; L.pf2[oidx * 3 + 2] = w3[2]; }
     }
 }
 

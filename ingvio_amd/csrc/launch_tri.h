@@ -12,6 +12,12 @@ struct TriLaunch {
     int* ok;                      // [B][fmax]
     int mask_failed;              // also clear the observation mask of failed features (they then drop out of the update)
     unsigned long long* mask_rw;  // [B][fmax]
+    // update-with-triangulation call (ingvio_msckf_update_tri): the staged frame carries anchors - a point behind its anchor camera
+    // fails as well (FeatureInfoManager::triangulateFeatureInfoStereo, MapServerManager.cpp:325) - and the flags / points are
+    // mirrored into the result slab the update's fetch copies (nullptr: not mirrored)
+    int check_anchor;
+    int* ok2;                     // [B][fmax] or nullptr
+    double* pf2;                  // [B][fmax][3] or nullptr
 };
 
 int launch_triangulate(const TriLaunch& L, int nb, int fmax_used, int stereo, hipStream_t st);

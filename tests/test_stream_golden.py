@@ -239,3 +239,15 @@ def test_shim_without_the_gnss_row_gate_goes_red():
     got = run_shim(spec, ov, extra=["gnss_chi2_test: 0"])
     bad, _ = compare(gold, got)
     assert bad and "GNSS rows" in " ".join(bad), bad[:3]
+
+
+@needs_tool
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["kf11", "sw11_mono"])
+def test_shim_stream_with_two_call_remove_lost_matches_golden(name):
+    """The golden streams run with RemoveLost's triangulation and update in one device call (hip_fuse_triangulation, the default);
+    the two-call form (ingvio_triangulate, host selection, ingvio_msckf_update) stays correct as well."""
+    gold, spec, ov = load_golden(name)
+    got = run_shim(spec, ov, extra=["hip_fuse_triangulation: 0"])
+    bad, _ = compare(gold, got)
+    assert not bad, "\n".join(bad[:10])

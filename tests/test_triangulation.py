@@ -166,3 +166,48 @@ def test_gpu_triangulate_staged_then_update():
     P = ctx.cov_get(0)
     assert np.linalg.norm(P - oc.P) / np.linalg.norm(oc.P) < 1e-9
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stereo", [True, False])
+def test_gpu_update_with_triangulation_equals_the_two_calls(stereo):
+    """ingvio_msckf_update_tri (RemoveLostUpdate in one device round trip) against ingvio_triangulate followed by ingvio_msckf_update on
+    the features that passed (what the shim did before, RemoveLostUpdate.cpp:283-299 + :300-397): same flags, same points, same accept
+    masks, and the same posterior and correction to the last bit.  Also the extra failure the one-call path carries: a point behind its
+    anchor camera (MapServerManager.cpp:290,325) - forced here by naming an anchor that looks away."""
+    from ingvio_amd import capi, host, synth
+    F, C = 96, 11
+    ctx, frames = _frames(stereo, C, F, 1, True, 2e-3, 1200)
+    fr = dict(frames[0])
+    fr["dof"] = np.array([max(1, bin(int(m)).count("1") - 1) for m in fr["obs_mask"]], dtype=np.int32)
+    n = int(np.max(fr["clone_idx"])) + 6                    # a state that already holds every clone of the frame (the update alone, no frame step)
+    rng = np.random.default_rng(77)
+    M = rng.normal(size=(n, n))
+    prior = 1e-3 * (M @ M.T / n + np.eye(n))
+    ctx.cov_set(0, prior)
+    # two calls: triangulate, keep what passed (anchor depth checked on the host as Triangulator::accept does), update
+    pf, ok = ctx.triangulate(0, [fr], stereo=stereo)
+    keep = []
+    for j in range(F):
+        a = int(fr["anchor"][j])
+        Ra = np.asarray(fr["clone_R"][a]).reshape(3, 3); pa = np.asarray(fr["clone_p"][a])
+        if ok[0, j] and (Ra.T @ (pf[0, j] - pa))[2] > 0:
+            keep.append(j)
+    assert 20 < len(keep) < F
+    fr2 = dict(fr)
+    for k in ("pf", "uv", "anchor", "obs_mask", "dof"):
+        fr2[k] = np.asarray(fr[k] if k != "pf" else pf[0])[keep]
+    fr2["pf"] = pf[0][keep]
+    dx2, acc2, gam2, rows2 = ctx.msckf_update(0, [fr2], max_accept=0, compress_rule=1)
+    P2 = ctx.cov_get(0)
+    # one call on the same prior
+    ctx.cov_set(0, prior)
+    fr1 = dict(fr); fr1["pf"] = np.full((F, 3), 321.0)
+    dx1, acc1, gam1, rows1, pf1, ok1 = ctx.msckf_update_tri(0, [fr1], max_accept=0, compress_rule=1, stereo=stereo)
+    P1 = ctx.cov_get(0)
+    assert np.array_equal(np.nonzero(ok1[0, :F])[0], np.asarray(keep))
+    assert np.array_equal(pf1[0][keep], pf[0][keep]) and not np.any(pf1[0][ok1[0] == 0])
+    assert np.array_equal(acc1[0][keep], acc2[0][:len(keep)]) and acc1[0].sum() == acc2[0].sum() and acc2[0].sum() > 10
+    assert rows1[0] == rows2[0]
+    assert np.array_equal(dx1, dx2) and np.array_equal(P1, P2)
+    ctx.close()

@@ -1,0 +1,21 @@
+#!/bin/bash
+# rocprofv3 kernel + memory-copy trace of the single-filter latency stream through the C++ shim (what the device does per camera callback).
+# usage (GPU box): bash tools/gpu_replay_trace.sh [config2|config5]
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+W=${1:-config2}
+case $W in
+  config2) SPEC="feats=150,clones=11,life=10,cohort=1,birth_frame=3,frames=45,key=1";;
+  config5) SPEC="feats=300,clones=30,life=28,cohort=1,birth_frame=2,frames=95,key=1";;
+esac
+OUT=gpurun_out/replay_trace_$W
+rm -rf $OUT; mkdir -p $OUT
+rocprofv3 --kernel-trace --memory-copy-trace --stats -d $OUT -o rt --output-format csv -- ingvio_amd/lib/ingvio_replay --synth "$SPEC" --time --set "hip_max_valid_ids: 0" --set "hip_compress_rule: 1" > $OUT/stdout.txt 2> $OUT/stderr.txt
+tail -1 $OUT/stdout.txt
+f=$(find $OUT -name '*kernel_stats.csv' | head -1)
+python - "$f" <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    print("%-52s calls %4s avg %8.1f us min %8.1f max %8.1f" % (r['Name'][:52], r['Calls'], float(r['AverageNs'])/1e3, float(r['MinNs'])/1e3, float(r['MaxNs'])/1e3))
+PY
+f=$(find $OUT -name '*memory_copy_stats.csv' | head -1); [ -n "$f" ] && cat "$f" | cut -c1-160
