@@ -22,6 +22,7 @@
 #include <vector>
 
 #define KMAX 64            // IMU steps per fused propagation call
+#define IMU_SLAB_NB 4      // ingvio_propagate(_fused) for up to this many filters: inputs travel as one copy (ingvio_ctx::d_imu)
 #define CHI2_CAP 1024
 
 namespace {
@@ -78,6 +79,10 @@ struct ingvio_ctx {
     double *d_big_sg, *d_big_wk;        // large-window workspaces (c_max > 16)
     double* d_Asum = nullptr;           // [B][rstride]: the chunk partials of a filter summed (k_chunk_sum), windows up to 16 clones with G > 1
     int* d_used_sum = nullptr;          // [B]
+    // what d_chi2 and d_noise hold (single-filter latency: an update re-sent the same gate table and the same noise variance with every
+    // call, two host-to-device copies of ~7 us each in front of the kernels); invalidated by every other writer of those buffers
+    struct { std::vector<double> chi2; bool chi2_ok = false; double var = 0.0; int b0 = -1, nb = 0; bool noise_ok = false; } upc;
+    char* d_imu = nullptr;              // [IMU_SLAB_NB filters] Phi | G | dt | gnss_idx of ingvio_propagate(_fused) in one piece (few filters per call)
     double* d_Tflat = nullptr;          // [min(B, APPLY_FLAT_NB)][ldp * 100]: T of the few-filter apply (k_apply_T_flat), windows up to 16 clones
 
     int* d_tri_ok;                      // [B][f_max] triangulation flags
@@ -405,6 +410,7 @@ void swap_input_sets(ingvio_ctx* c)
     std::swap(c->d_nclones, a.nclones); std::swap(c->d_nfeat, a.nfeat); std::swap(c->d_anchor, a.anchor); std::swap(c->d_dof, a.dof);
     std::swap(c->d_clone_R, a.clone_R); std::swap(c->d_clone_p, a.clone_p); std::swap(c->d_pf, a.pf); std::swap(c->d_uv, a.uv);
     std::swap(c->d_chi2, a.chi2); std::swap(c->d_mask, a.mask); std::swap(c->d_noise, a.noise);
+    c->upc.chi2_ok = false; c->upc.noise_ok = false;
     c->set_id ^= 1;
 }
 
@@ -519,8 +525,11 @@ int make_opts(ingvio_ctx* c, const ingvio_msckf_opts* o, MsckfOpts* op)
     op->chi2 = c->d_chi2;
     op->chi2_len = o->chi2_len;
     if (wait_inputs(c)) return INGVIO_E_HIP;
+    auto& u = c->upc;
+    if (u.chi2_ok && (int)u.chi2.size() >= o->chi2_len && !memcmp(u.chi2.data(), o->chi2_table, 8 * (size_t)o->chi2_len)) return 0;      // already there
     const UpItem item = { c->d_chi2, o->chi2_table, 8 * (size_t)o->chi2_len };      // through the pinned ring: no stream synchronisation
     if (stage_small(c, &item, 1)) return INGVIO_E_HIP;
+    u.chi2.assign(o->chi2_table, o->chi2_table + o->chi2_len); u.chi2_ok = true;
     return 0;
 }
 
@@ -642,9 +651,12 @@ int run_msckf(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int stereo, in
 
 int fill_noise_scalar(ingvio_ctx* c, int b0, int nb, double var)
 {
+    auto& u = c->upc;
+    if (u.noise_ok && u.b0 == b0 && u.nb == nb && u.var == var) return 0;                           // already there
     std::vector<double> v(nb, var);
     const UpItem item = { c->d_noise + b0, v.data(), 8 * (size_t)nb };
     if (stage_small(c, &item, 1)) return INGVIO_E_HIP;
+    u.noise_ok = true; u.b0 = b0; u.nb = nb; u.var = var;
     return 0;
 }
 
@@ -756,6 +768,7 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     rc |= dalloc(c, &c->d_H, (size_t)B * c->hstride); rc |= dalloc(c, &c->d_res, (size_t)B * c->mld);
     rc |= dalloc(c, &c->d_colmap, (size_t)B * c->cstride); rc |= dalloc(c, &c->d_nc, B); rc |= dalloc(c, &c->d_pcbase, B);
     rc |= dalloc(c, &c->d_tri_ok, (size_t)B * fm);
+    rc |= dalloc(c, &c->d_imu, (size_t)IMU_SLAB_NB * (8 * (size_t)KMAX * (225 + 180 + 1) + 64) + 256);
     if (desc->c_max <= 16) rc |= dalloc(c, &c->d_Tflat, (size_t)std::min(B, APPLY_FLAT_NB) * c->ldp * 100);
     if (desc->c_max <= 16 && c->G > 1) { rc |= dalloc(c, &c->d_Asum, (size_t)B * c->rstride); rc |= dalloc(c, &c->d_used_sum, B); }
     c->d_big_sg = nullptr; c->d_big_wk = nullptr;
@@ -783,7 +796,7 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
                      c->gn.feph, c->gn.fobs, c->gn.frcv, c->gn.front,
                      c->dw.Hd, c->dw.X, c->dw.Y, c->dw.Tb, c->dw.noise, c->dw.noiseB, c->dw.m, c->dw.cidx, c->lm.pose, c->lm.pf, c->lm.uv, c->lm.gamma, c->lm.idx, c->lm.n_lm,
                      c->lm.lm_idx, c->lm.anchor_idx, c->lm.tracked, c->lm.accept, c->lm.dx, c->d_xchg, c->dw.U, c->dw.rowmap, c->d_zero_idx,
-                     c->d_Asum, c->d_used_sum, c->d_Tflat };
+                     c->d_Asum, c->d_used_sum, c->d_Tflat, c->d_imu };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& sl : c->pin) { if (sl.p) hipHostFree(sl.p); if (sl.ev) hipEventDestroy(sl.ev); }
     if (c->h_result) hipHostFree(c->h_result);
@@ -900,12 +913,31 @@ int ingvio_propagate_fused(ingvio_ctx* c, int b0, int nb, int k, const double* P
     if (check_range(c, b0, nb) || k < 1 || k > KMAX || !Phi || !G || !dt || !sigma) return INGVIO_E_ARG;
     for (int i = 0; i < nb; ++i) if (c->h_n[b0 + i] < 15) return INGVIO_E_ARG;
     if (wait_inputs(c)) return INGVIO_E_HIP;
+    const bool with_gnss = enable_gnss && gnss_idx;
+    if (c->d_imu && nb <= IMU_SLAB_NB) {
+        // few filters: Phi | G | dt | gnss_idx packed into ONE pinned image and ONE copy into a device slab of the same layout (the four
+        // arrays are four allocations, i.e. four copies of ~7 us each on the stream in front of the kernel - a third of what a single
+        // filter's propagation costs its host)
+        const size_t nPhi = (size_t)nb * k * 225, nG = (size_t)nb * k * 180, ndt = (size_t)nb * k;
+        const size_t oG = 8 * nPhi, odt = oG + 8 * nG, ogn = pad64(odt + 8 * ndt), tot = ogn + (with_gnss ? sizeof(int) * (size_t)nb * 5 : 0);
+        Uploader up{ c };
+        if (up.begin(tot + 64)) return INGVIO_E_HIP;
+        char* img = up.take<char>(tot);
+        memcpy(img, Phi, 8 * nPhi); memcpy(img + oG, G, 8 * nG); memcpy(img + odt, dt, 8 * ndt);
+        if (with_gnss) memcpy(img + ogn, gnss_idx, sizeof(int) * (size_t)nb * 5);
+        up.copy(c->d_imu, img, tot);
+        if (up.end()) return INGVIO_E_HIP;
+        ProfScope p(c, PF_PROPAGATE);
+        launch_propagate(view(c), b0, nb, c->d.n_max, (const double*)c->d_imu, (const double*)(c->d_imu + oG), (const double*)(c->d_imu + odt), k,
+                         with_gnss ? (const int*)(c->d_imu + ogn) : nullptr, sigma, enable_gnss, scb, srw, c->st);
+        return last_launch(c);
+    }
     const UpItem items[4] = { { c->d_Phi, Phi, 8 * (size_t)nb * k * 225 }, { c->d_G, G, 8 * (size_t)nb * k * 180 }, { c->d_dt, dt, 8 * (size_t)nb * k },
-                              { c->d_gnss, gnss_idx, (enable_gnss && gnss_idx) ? sizeof(int) * (size_t)nb * 5 : 0 } };
+                              { c->d_gnss, gnss_idx, with_gnss ? sizeof(int) * (size_t)nb * 5 : 0 } };
     if (stage_small(c, items, 4)) return INGVIO_E_HIP;
     {
         ProfScope p(c, PF_PROPAGATE);
-        launch_propagate(view(c), b0, nb, c->d.n_max, c->d_Phi, c->d_G, c->d_dt, k, (enable_gnss && gnss_idx) ? c->d_gnss : nullptr,
+        launch_propagate(view(c), b0, nb, c->d.n_max, c->d_Phi, c->d_G, c->d_dt, k, with_gnss ? c->d_gnss : nullptr,
                          sigma, enable_gnss, scb, srw, c->st);
     }
     return last_launch(c);                      // no stream synchronisation: the inputs were staged through the pinned ring (stage_small)
@@ -926,9 +958,12 @@ int ingvio_augment_clone(ingvio_ctx* c, int b0, int nb, const double* R, int* ne
         if (c->h_n[b0 + i] + 6 > c->d.n_max) return INGVIO_E_CAPACITY;
     }
     if (wait_inputs(c)) return INGVIO_E_HIP;
-    const UpItem item = { c->d_R, R, 8 * (size_t)nb * 9 };
-    if (stage_small(c, &item, 1)) return INGVIO_E_HIP;
-    { ProfScope p(c, PF_AUGMENT); launch_augment(view(c), b0, nb, c->d_R, c->st); }
+    if (nb == 1) { ProfScope p(c, PF_AUGMENT); launch_augment_one(view(c), b0, R, c->st); }      // R as a kernel argument
+    else {
+        const UpItem item = { c->d_R, R, 8 * (size_t)nb * 9 };
+        if (stage_small(c, &item, 1)) return INGVIO_E_HIP;
+        ProfScope p(c, PF_AUGMENT); launch_augment(view(c), b0, nb, c->d_R, c->st);
+    }
     for (int i = 0; i < nb; ++i) { if (new_idx) new_idx[i] = c->h_n[b0 + i]; c->h_n[b0 + i] += 6; }
     return last_launch(c);
 }
@@ -940,9 +975,12 @@ int ingvio_marginalize(ingvio_ctx* c, int b0, int nb, const int* idx, int size)
     for (int i = 0; i < nb; ++i)
         if (idx[i] >= 0 && idx[i] + size > c->h_n[b0 + i]) return INGVIO_E_NOT_IN_STATE;
     if (wait_inputs(c)) return INGVIO_E_HIP;
-    const UpItem item = { c->d_idx, idx, sizeof(int) * (size_t)nb };
-    if (stage_small(c, &item, 1)) return INGVIO_E_HIP;
-    { ProfScope p(c, PF_MARG); launch_marginalize(view(c), b0, nb, c->d.n_max, c->d_idx, size, c->st); }
+    if (nb == 1) { ProfScope p(c, PF_MARG); launch_marginalize(view(c), b0, 1, c->d.n_max, nullptr, size, c->st, idx[0]); }      // the index as a kernel argument
+    else {
+        const UpItem item = { c->d_idx, idx, sizeof(int) * (size_t)nb };
+        if (stage_small(c, &item, 1)) return INGVIO_E_HIP;
+        ProfScope p(c, PF_MARG); launch_marginalize(view(c), b0, nb, c->d.n_max, c->d_idx, size, c->st);
+    }
     for (int i = 0; i < nb; ++i) if (idx[i] >= 0) { c->h_n[b0 + i] -= size; c->h_cur[b0 + i] ^= 1; }
     return last_launch(c);
 }
@@ -2154,6 +2192,7 @@ static int frame_stage_impl(ingvio_ctx* c, int b0, int nb, const ingvio_frame_st
     upl.copy(c->d_idx + b0, mi, n);
     upl.copy(c->d_chi2, chi2, (size_t)opts->chi2_len);
     upl.copy(c->d_noise + b0, nz, n);
+    c->upc.chi2_ok = false; c->upc.noise_ok = false;
     MsckfOpts& op = c->st_op;
     memcpy(op.R_lr, opts->R_cl2cr, 72);
     memcpy(op.t_lr, opts->t_cl2cr, 24);

@@ -156,19 +156,28 @@ void IngvioFilter::callbackStereoFrame(const StereoFrameMsg& frame)
         }
     } report{ timing, t0, t1, t2, t3, _frames };
     if (_filter_params._is_key_frame) {
+        clk::time_point k0, k1, k2, k3;
+        if (timing) k0 = clk::now();
         _keyframe_update->updateStateStereo(_state, _map_server, _tri);
+        if (timing) k1 = clk::now();
         if (_filter_params._max_lm_feats > 0) {                                         // :283-289
             _landmark_update->updateLandmarkStereo(_state, _map_server);
             _landmark_update->initNewLandmarkStereo(_state, _map_server, _tri, _filter_params._max_sw_clones);
         }
         _keyframe_update->cleanStereoObsAtMargTime(_state, _map_server);
+        if (timing) k2 = clk::now();
         _keyframe_update->changeMSCKFAnchor(_state, _map_server);
+        if (timing) k3 = clk::now();
         if (_filter_params._max_lm_feats > 0) {                                         // :295-301
             std::vector<double> marg_kfs;
             _keyframe_update->getMargKfs(_state, marg_kfs);
             _landmark_update->changeLandmarkAnchor(_state, _map_server, marg_kfs);
         }
         _keyframe_update->margSwPose(_state);
+        if (timing) {
+            auto us = [](clk::time_point x, clk::time_point y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
+            std::fprintf(stderr, "SHIM key frame us: update %.1f clean %.1f anchor change %.1f marginalise %.1f\n", us(k0, k1), us(k1, k2), us(k2, k3), us(k3, clk::now()));
+        }
     } else {
         _sw_marg_update->updateStateStereo(_state, _map_server, _tri);
         if (_filter_params._max_lm_feats > 0) {                                         // :309-315

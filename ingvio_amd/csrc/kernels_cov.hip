@@ -397,10 +397,20 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
 // One workgroup per filter; the 6 new rows/cols are J*P[0:21,:], read through the symmetric
 // counterpart P[c, 0:21] so consecutive lanes read consecutive addresses.
 // ---------------------------------------------------------------------------------------------
+struct Mat9Arg { double m[9]; };
 __global__ __launch_bounds__(256) void k_augment(CovView cv, int b0, const double* __restrict__ Rs)
 {
     __shared__ double sJP[6][21];
     augment_filter<256>(cv, b0 + blockIdx.x, Rs + blockIdx.x * 9, sJP);
+}
+// ONE filter: the rotation rides as a kernel argument (no 72-byte host-to-device copy in front of the kernel)
+__global__ __launch_bounds__(256) void k_augment_imm(CovView cv, int b, Mat9Arg R)
+{
+    __shared__ double sJP[6][21];
+    __shared__ double sR[9];
+    if (threadIdx.x < 9) sR[threadIdx.x] = R.m[threadIdx.x];
+    __syncthreads();
+    augment_filter<256>(cv, b, sR, sJP);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -408,10 +418,12 @@ __global__ __launch_bounds__(256) void k_augment(CovView cv, int b0, const doubl
 // the filter's other ping-pong buffer; k_post then flips `cur` and shrinks n.  grid = (col tiles, nb)
 // ---------------------------------------------------------------------------------------------
 #define MARG_COLS 8
-__global__ __launch_bounds__(256) void k_marginalize(CovView cv, int b0, const int* __restrict__ idxs, int size)
+// idxs == nullptr: ONE filter, its index rides as a kernel argument (idx_imm) - a single real-time filter then marginalises without
+// the 7 us host-to-device copy of four bytes in front of the kernel
+__global__ __launch_bounds__(256) void k_marginalize(CovView cv, int b0, const int* __restrict__ idxs, int size, int idx_imm)
 {
     const int bl = blockIdx.y, b = b0 + bl, tid = threadIdx.x;
-    const int idx = idxs[bl];
+    const int idx = idxs ? idxs[bl] : idx_imm;
     if (idx < 0) return;
     const int n = cv.n[b], ld = cv.ldp, nn = n - size;
     const double* src = cov_ptr(cv, b);
@@ -427,11 +439,11 @@ __global__ __launch_bounds__(256) void k_marginalize(CovView cv, int b0, const i
     }
 }
 
-__global__ void k_post_marg(CovView cv, int b0, int nb, const int* __restrict__ idxs, int size)
+__global__ void k_post_marg(CovView cv, int b0, int nb, const int* __restrict__ idxs, int size, int idx_imm)
 {
     const int bl = blockIdx.x * blockDim.x + threadIdx.x;
     if (bl >= nb) return;
-    if (idxs[bl] < 0) return;
+    if ((idxs ? idxs[bl] : idx_imm) < 0) return;
     const int b = b0 + bl;
     cv.cur[b] ^= 1;
     cv.n[b] -= size;
@@ -538,14 +550,20 @@ void launch_augment(CovView cv, int b0, int nb, const double* R, hipStream_t st)
 {
     hipLaunchKernelGGL(k_augment, dim3(nb), dim3(256), 0, st, cv, b0, R);
 }
-void launch_marginalize(CovView cv, int b0, int nb, int n_cap, const int* idx, int size, hipStream_t st)
+void launch_augment_one(CovView cv, int b, const double* R_host, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_marginalize, dim3((n_cap + MARG_COLS - 1) / MARG_COLS, nb), dim3(256), 0, st, cv, b0, idx, size);
-    hipLaunchKernelGGL(k_post_marg, dim3((nb + 255) / 256), dim3(256), 0, st, cv, b0, nb, idx, size);
+    Mat9Arg R;
+    for (int i = 0; i < 9; ++i) R.m[i] = R_host[i];
+    hipLaunchKernelGGL(k_augment_imm, dim3(1), dim3(256), 0, st, cv, b, R);
+}
+void launch_marginalize(CovView cv, int b0, int nb, int n_cap, const int* idx, int size, hipStream_t st, int idx_imm)
+{
+    hipLaunchKernelGGL(k_marginalize, dim3((n_cap + MARG_COLS - 1) / MARG_COLS, nb), dim3(256), 0, st, cv, b0, idx, size, idx_imm);
+    hipLaunchKernelGGL(k_post_marg, dim3((nb + 255) / 256), dim3(256), 0, st, cv, b0, nb, idx, size, idx_imm);
 }
 void launch_post_marg(CovView cv, int b0, int nb, const int* idx, int size, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_post_marg, dim3((nb + 255) / 256), dim3(256), 0, st, cv, b0, nb, idx, size);
+    hipLaunchKernelGGL(k_post_marg, dim3((nb + 255) / 256), dim3(256), 0, st, cv, b0, nb, idx, size, -1);
 }
 void launch_append(CovView cv, int b0, int nb, int size, const double* blk, hipStream_t st)
 {

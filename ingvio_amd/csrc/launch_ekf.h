@@ -52,7 +52,8 @@ void launch_propagate(CovView cv, int b0, int nb, int n_cap, const double* Phi, 
                       const int* gnss_idx, const double sigma[4], int enable_gnss, double scb, double srw, hipStream_t st,
                       const double* augR = nullptr, int* status_clear = nullptr);      // optional fused K2 / status reset
 void launch_augment(CovView cv, int b0, int nb, const double* R, hipStream_t st);
-void launch_marginalize(CovView cv, int b0, int nb, int n_cap, const int* idx, int size, hipStream_t st);
+void launch_augment_one(CovView cv, int b, const double* R_host, hipStream_t st);      // one filter, R (host memory) as a kernel argument
+void launch_marginalize(CovView cv, int b0, int nb, int n_cap, const int* idx, int size, hipStream_t st, int idx_imm = -1);      // idx == nullptr: nb = 1, index idx_imm
 void launch_post_marg(CovView cv, int b0, int nb, const int* idx, int size, hipStream_t st);
 void launch_append(CovView cv, int b0, int nb, int size, const double* blk, hipStream_t st);
 void launch_copy_ints(int* dst, const int* src, int count, hipStream_t st);
