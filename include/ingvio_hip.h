@@ -394,12 +394,17 @@ int ingvio_triangulate(ingvio_ctx* ctx, int b0, int nb, const ingvio_msckf_frame
  * triangulates every lost feature (MapServerManager.cpp:274-341), drops the ones that fail and updates with the rest.  Here the
  * staged features' points are triangulated on the device from the frame's own observations (frames[].pf is ignored), a feature whose
  * triangulation fails - including a point behind its anchor camera, MapServerManager.cpp:290,325 - drops out of the update on the
- * device (tri_ok[i] = 0, accepted[i] = 0), and the rest is ingvio_msckf_update.  pf_out [nb][f_max][3], tri_ok [nb][f_max] (may be
- * NULL).  One upload, one download, one synchronisation: ingvio_triangulate + ingvio_msckf_update cost a single real-time filter
- * two of each and the host a second packing of the same observations (round 5). */
+ * device (accepted[i] = 0), and the rest is ingvio_msckf_update.  tri_ok[i]: 1 triangulated, 0 failed, 2 triangulated but behind its
+ * anchor camera (the reference counts that attempt, MapServerManager.cpp:287 / :322).  pf_out [nb][f_max][3], tri_ok [nb][f_max]
+ * (may be NULL).  One upload, one download, one synchronisation: ingvio_triangulate + ingvio_msckf_update cost a single real-time
+ * filter two of each and the host a second packing of the same observations (round 5).
+ * tri_masks (NULL, or nb pointers of which any may be NULL): the observations the TRIANGULATION of filter i's features uses, one
+ * mask per feature over the window slots, when they differ from the update's obs_mask - the selected-stamp updates
+ * (SwMargUpdate.cpp:236-257, KeyframeUpdate.cpp:607-628) triangulate from every observation and update with the selected stamps
+ * only; frames[i].uv must then carry the measurements of every slot of the triangulation mask. */
 int ingvio_msckf_update_tri(ingvio_ctx* ctx, int b0, int nb, const ingvio_msckf_frame* frames, const ingvio_msckf_opts* opts,
-                            const ingvio_tri_opts* tri, double* dx_out, int* accepted, double* gamma, int* rows_out,
-                            double* pf_out, int* tri_ok);
+                            const ingvio_tri_opts* tri, const unsigned long long* const* tri_masks, double* dx_out, int* accepted,
+                            double* gamma, int* rows_out, double* pf_out, int* tri_ok);
 
 /* ---- one benchmark "update" for the whole batch ------------------------------
  * k-step propagation + clone + MSCKF update + marginalise one clone, all filters, no host

@@ -555,7 +555,7 @@ class Context:
         self._chk(rc)
         return dx, acc, gam, rows
 
-    def msckf_update_tri(self, b0, frames, max_accept=0, compress_rule=1, selected_variant=0, stereo=True, **params):
+    def msckf_update_tri(self, b0, frames, max_accept=0, compress_rule=1, selected_variant=0, stereo=True, tri_masks=None, **params):
         """ingvio_msckf_update_tri: the frames' points are triangulated on the device from their own observations (pf of the frame
         dicts is ignored), failed features drop out.  Returns (dx, accepted, gamma, rows, pf[nb, f_max, 3], tri_ok[nb, f_max])."""
         if isinstance(frames, dict):
@@ -582,7 +582,11 @@ class Context:
         dx = np.zeros((nb, self.ldp)); acc = np.zeros((nb, self.f_max), dtype=np.int32)
         gam = np.zeros((nb, self.f_max)); rows = np.zeros(nb, dtype=np.int32)
         pf = np.zeros((nb, self.f_max, 3)); ok = np.zeros((nb, self.f_max), dtype=np.int32)
-        self._chk(self.L.ingvio_msckf_update_tri(self.h, b0, nb, arr, C.byref(o), C.byref(t), _d(dx), _i(acc), _d(gam), _i(rows), _d(pf), _i(ok)))
+        tm = None
+        if tri_masks is not None:                              # one mask array per filter (None: the frame's obs_mask)
+            tm_keep = [None if m is None else np.ascontiguousarray(m, dtype=np.uint64) for m in tri_masks]
+            tm = (c_up * nb)(*[C.cast(None, c_up) if m is None else m.ctypes.data_as(c_up) for m in tm_keep])
+        self._chk(self.L.ingvio_msckf_update_tri(self.h, b0, nb, arr, C.byref(o), C.byref(t), tm, _d(dx), _i(acc), _d(gam), _i(rows), _d(pf), _i(ok)))
         return dx, acc, gam, rows, pf, ok
 
     def qr_compress(self, H, res):

@@ -82,6 +82,7 @@ struct ingvio_ctx {
     // what d_chi2 and d_noise hold (single-filter latency: an update re-sent the same gate table and the same noise variance with every
     // call, two host-to-device copies of ~7 us each in front of the kernels); invalidated by every other writer of those buffers
     struct { std::vector<double> chi2; bool chi2_ok = false; double var = 0.0; int b0 = -1, nb = 0; bool noise_ok = false; } upc;
+    unsigned long long* d_tri_mask = nullptr;      // [B][f_max], allocated on first use: triangulation masks of ingvio_msckf_update_tri
     char* d_imu = nullptr;              // [IMU_SLAB_NB filters] Phi | G | dt | gnss_idx of ingvio_propagate(_fused) in one piece (few filters per call)
     double* d_Tflat = nullptr;          // [min(B, APPLY_FLAT_NB)][ldp * 100]: T of the few-filter apply (k_apply_T_flat), windows up to 16 clones
 
@@ -796,7 +797,7 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
                      c->gn.feph, c->gn.fobs, c->gn.frcv, c->gn.front,
                      c->dw.Hd, c->dw.X, c->dw.Y, c->dw.Tb, c->dw.noise, c->dw.noiseB, c->dw.m, c->dw.cidx, c->lm.pose, c->lm.pf, c->lm.uv, c->lm.gamma, c->lm.idx, c->lm.n_lm,
                      c->lm.lm_idx, c->lm.anchor_idx, c->lm.tracked, c->lm.accept, c->lm.dx, c->d_xchg, c->dw.U, c->dw.rowmap, c->d_zero_idx,
-                     c->d_Asum, c->d_used_sum, c->d_Tflat, c->d_imu };
+                     c->d_Asum, c->d_used_sum, c->d_Tflat, c->d_imu, c->d_tri_mask };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& sl : c->pin) { if (sl.p) hipHostFree(sl.p); if (sl.ev) hipEventDestroy(sl.ev); }
     if (c->h_result) hipHostFree(c->h_result);
@@ -1629,7 +1630,8 @@ int ingvio_chi2_gamma_multi(ingvio_ctx* c, int b, int nblk, const ingvio_gate_bl
 
 // tri != nullptr: the points of the staged features are triangulated on the device first (ingvio_msckf_update_tri)
 static int msckf_update_impl(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* frames, const ingvio_msckf_opts* opts, const ingvio_tri_opts* tri,
-                             double* dx_out, int* accepted, double* gamma, int* rows_out, double* pf_out, int* tri_ok)
+                             const unsigned long long* const* tri_masks, double* dx_out, int* accepted, double* gamma, int* rows_out, double* pf_out,
+                             int* tri_ok)
 {
     if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || !frames || !opts) return INGVIO_E_ARG;
@@ -1654,6 +1656,19 @@ static int msckf_update_impl(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_f
         T.outer_loop_max_iter = tri->outer_loop_max_iter; T.inner_loop_max_iter = tri->inner_loop_max_iter;
         T.pf = c->d_pf; T.ok = c->d_tri_ok; T.mask_failed = 1; T.mask_rw = c->d_mask; T.check_anchor = 1;
         T.ok2 = (int*)(c->d_result_slab + c->ro_tok); T.pf2 = (double*)(c->d_result_slab + c->ro_tpf);
+        if (tri_masks) {                                       // triangulation masks that differ from the update's: their own device array
+            if (!c->d_tri_mask && dalloc(c, &c->d_tri_mask, (size_t)c->d.batch * fm)) return INGVIO_E_HIP;
+            std::vector<unsigned long long> tm((size_t)nb * fm, 0ULL);
+            for (int i = 0; i < nb; ++i) {
+                const unsigned long long* src = tri_masks[i] ? tri_masks[i] : frames[i].obs_mask;
+                const int C = frames[i].n_clones;
+                const unsigned long long cmask = C >= 64 ? ~0ULL : ((1ULL << C) - 1ULL);
+                for (int j = 0; j < frames[i].n_feat; ++j) tm[(size_t)i * fm + j] = src[j] & cmask;
+            }
+            const UpItem item = { c->d_tri_mask + (size_t)b0 * fm, tm.data(), 8 * tm.size() };
+            if (stage_small(c, &item, 1)) return INGVIO_E_HIP;
+            T.tri_mask = c->d_tri_mask;
+        }
         if (launch_triangulate(T, nb, fmx > 0 ? fmx : 1, tri->stereo, c->st)) return INGVIO_E_UNSUPPORTED;
     }
     rc = run_msckf(c, b0, nb, op, opts->stereo, fmx);
@@ -1693,14 +1708,15 @@ static int msckf_update_impl(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_f
 int ingvio_msckf_update(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* frames, const ingvio_msckf_opts* opts,
                         double* dx_out, int* accepted, double* gamma, int* rows_out)
 {
-    return msckf_update_impl(c, b0, nb, frames, opts, nullptr, dx_out, accepted, gamma, rows_out, nullptr, nullptr);
+    return msckf_update_impl(c, b0, nb, frames, opts, nullptr, nullptr, dx_out, accepted, gamma, rows_out, nullptr, nullptr);
 }
 
 int ingvio_msckf_update_tri(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* frames, const ingvio_msckf_opts* opts,
-                            const ingvio_tri_opts* tri, double* dx_out, int* accepted, double* gamma, int* rows_out, double* pf_out, int* tri_ok)
+                            const ingvio_tri_opts* tri, const unsigned long long* const* tri_masks, double* dx_out, int* accepted,
+                            double* gamma, int* rows_out, double* pf_out, int* tri_ok)
 {
     if (!tri) return INGVIO_E_ARG;
-    return msckf_update_impl(c, b0, nb, frames, opts, tri, dx_out, accepted, gamma, rows_out, pf_out, tri_ok);
+    return msckf_update_impl(c, b0, nb, frames, opts, tri, tri_masks, dx_out, accepted, gamma, rows_out, pf_out, tri_ok);
 }
 
 // ---- SLAM-landmark covariance operations -------------------------------------------------------

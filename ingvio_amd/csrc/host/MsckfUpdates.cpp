@@ -194,15 +194,19 @@ struct FlatFrame {
         for (int s = 0; s < C; ++s) if (poses[s] == p) return s;
         return -1;
     }
-    // `sel`: nullptr = every observation inside the window (RemoveLost), else only these stamps
-    bool add(const std::shared_ptr<FeatureInfo>& fi, bool stereo, const std::vector<double>* sel, int dof_value)
+    std::vector<unsigned long long> all_mask;      // with_all: every observation inside the window (what the triangulation uses)
+    // `sel`: nullptr = every observation inside the window (RemoveLost), else only these stamps.  with_all: the measurements of EVERY
+    // observed slot are kept (and named in all_mask) while `mask` still names the selected ones - the one-call selected update
+    // triangulates from all of them on the device
+    bool add(const std::shared_ptr<FeatureInfo>& fi, bool stereo, const std::vector<double>* sel, int dof_value, bool with_all = false)
     {
         const int a = slotOfPose(fi->_landmark->getAnchoredPose());
         if (a < 0) return false;
-        unsigned long long m = 0ULL;
+        unsigned long long m = 0ULL, ma = 0ULL;
         std::vector<double> row((size_t)C * 4, 0.0);
         for (int s = 0; s < C; ++s) {
-            if (sel) { bool in = false; for (double t : *sel) if (t == times[s]) in = true; if (!in) continue; }
+            bool in = true;
+            if (sel) { in = false; for (double t : *sel) if (t == times[s]) in = true; if (!in && !with_all) continue; }
             if (stereo) {
                 auto it = fi->_stereo_obs.find(times[s]);
                 if (it == fi->_stereo_obs.end()) continue;
@@ -212,9 +216,11 @@ struct FlatFrame {
                 if (it == fi->_mono_obs.end()) continue;
                 row[4 * s] = it->second->_u0; row[4 * s + 1] = it->second->_v0;
             }
-            m |= 1ULL << s;
+            ma |= 1ULL << s;
+            if (in) m |= 1ULL << s;
         }
         if (!m) return false;
+        if (with_all) all_mask.push_back(ma);
         const Vec3d& p = fi->_landmark->valuePosXyz();
         pf.insert(pf.end(), p.v, p.v + 3);
         uv.insert(uv.end(), row.begin(), row.end());
@@ -299,7 +305,7 @@ void RemoveLostUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapS
         }
         if (timing) q3 = clk::now();
         for (size_t i = 0; i < cand.size(); ++i) {
-            if (slot[i] >= 0 && tok[slot[i]]) { _rec.ids.push_back(cand_ids[i]); _rec.accepted.push_back(acc[slot[i]]); _last_accepted += acc[slot[i]]; }
+            if (slot[i] >= 0 && tok[slot[i]] == 1) { _rec.ids.push_back(cand_ids[i]); _rec.accepted.push_back(acc[slot[i]]); _last_accepted += acc[slot[i]]; }
             else if (slot[i] != -2) _rec.direct.push_back(cand_ids[i]);
         }
         _rec.rows = _last_rows;
@@ -345,7 +351,8 @@ void RemoveLostUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapS
 
 // ---------------------------------------------------------------------------------------------
 SwMargUpdate::SwMargUpdate(const IngvioParams& fp)
-    : UpdateBase(fp._chi2_max_dof, fp._chi2_thres), _noise(fp._visual_noise), _frame_select_interval(fp._frame_select_interval) {}
+    : UpdateBase(fp._chi2_max_dof, fp._chi2_thres), _noise(fp._visual_noise), _frame_select_interval(fp._frame_select_interval),
+      _fuse_tri(fp._hip_fuse_triangulation != 0) {}
 
 void SwMargUpdate::selectSwTimestamps(const std::map<double, std::shared_ptr<SE3>>& sw_poses, const double& marg_time,
                                       std::vector<double>& selected_timestamps)
@@ -365,7 +372,8 @@ void SwMargUpdate::updateStateMono(std::shared_ptr<State> s, std::shared_ptr<Map
 void SwMargUpdate::updateStateStereo(std::shared_ptr<State> s, std::shared_ptr<MapServer> m, std::shared_ptr<Triangulator> t) { update(s, m, t, true); }
 
 static int selectedUpdate(UpdateBase& base, std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server,
-                          std::shared_ptr<Triangulator> tri, bool stereo, const std::vector<double>& sel, int dof, double noise, UpdateRecord& rec)
+                          std::shared_ptr<Triangulator> tri, bool stereo, const std::vector<double>& sel, int dof, double noise, UpdateRecord& rec,
+                          bool fuse_tri)
 {
     rec.clear();
     rec.stamps = sel;
@@ -379,6 +387,38 @@ static int selectedUpdate(UpdateBase& base, std::shared_ptr<State> state, std::s
         for (double ts : sel)
             if (stereo ? fi->_stereo_obs.find(ts) == fi->_stereo_obs.end() : fi->_mono_obs.find(ts) == fi->_mono_obs.end()) { miss = true; break; }
         if (!miss) cand.push_back(fi);
+    }
+    const int n_sw = (int)state->_sw_camleft_poses.size();
+    if (fuse_tri && typeid(*tri) == typeid(Triangulator) && !cand.empty() && n_sw > 0 && n_sw <= 64 && n_sw <= ingvio_c_max(StateManager::ctx(state)) &&
+        (int)cand.size() <= ingvio_f_max(StateManager::ctx(state))) {
+        // triangulation (from EVERY observation in the window) and update (at the selected stamps) in one device round trip, see
+        // RemoveLostUpdate::update.  These features live on: value / FEJ position and the attempt counter are set from the call's results
+        // exactly as Triangulator::accept sets them.
+        std::vector<int> slot(cand.size(), -1);
+        for (size_t i = 0; i < cand.size(); ++i) {
+            if (ff.add(cand[i], stereo, &sel, dof, true)) slot[i] = ff.F - 1;
+            else tri->triangulate(cand[i], state, stereo);         // not stageable (anchor outside the window): triangulated as before, never updated
+        }
+        if (ff.F == 0) return 0;
+        const std::vector<double> table = base.chi2TableDense(dof + 1);
+        const ingvio_msckf_frame fr = ff.view();
+        const ingvio_msckf_opts op = makeOpts(state, stereo, noise, table, 0, 1 /* top_n, SwMargUpdate.cpp:350-351 */, 1 /* Q10 */);
+        ingvio_tri_opts to;
+        tri->fillOpts(state, stereo, to);
+        std::vector<int> acc, tok;
+        std::vector<Vec3d> pf;
+        rec.rows = StateManager::msckfUpdateTri(state, fr, op, to, &acc, &tok, ff.all_mask.data(), &pf);
+        for (size_t i = 0; i < cand.size(); ++i) {
+            if (slot[i] < 0) continue;
+            const auto& fi = cand[i];
+            if (tok[slot[i]] == 0) continue;                       // MapServerManager.cpp:283-286: nothing counted, nothing set
+            ++fi->_numOfTri;
+            if (tok[slot[i]] != 1) continue;                       // behind its anchor camera (:290 / :325)
+            if (!fi->_isTri) { fi->_landmark->setFejPosXyz(pf[slot[i]]); fi->_isTri = true; }
+            fi->_landmark->setValuePosXyz(pf[slot[i]]);
+            rec.ids.push_back(fi->_id); rec.accepted.push_back(acc[slot[i]]);
+        }
+        return rec.rows;
     }
     std::vector<char> tri_ok;
     tri->triangulateMany(cand, state, stereo, tri_ok);
@@ -405,7 +445,7 @@ void SwMargUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapServe
             std::cout << "[SwMargUpdate]: selected timestamp not in sw!" << std::endl;                // :462-466
             std::exit(EXIT_FAILURE);
         }
-    _last_rows = selectedUpdate(*this, state, map_server, tri, stereo, selected_timestamps, (int)selected_timestamps.size() - 1, _noise, _rec);
+    _last_rows = selectedUpdate(*this, state, map_server, tri, stereo, selected_timestamps, (int)selected_timestamps.size() - 1, _noise, _rec, _fuse_tri);
 }
 
 template <bool STEREO>
@@ -473,7 +513,8 @@ void SwMargUpdate::margSwPose(std::shared_ptr<State> state)
 
 // ---------------------------------------------------------------------------------------------
 KeyframeUpdate::KeyframeUpdate(const IngvioParams& fp)
-    : UpdateBase(fp._chi2_max_dof, fp._chi2_thres), _noise(fp._visual_noise), _max_sw_poses(fp._max_sw_clones) {}
+    : UpdateBase(fp._chi2_max_dof, fp._chi2_thres), _noise(fp._visual_noise), _max_sw_poses(fp._max_sw_clones),
+      _fuse_tri(fp._hip_fuse_triangulation != 0) {}
 
 void KeyframeUpdate::getMargKfs(const std::shared_ptr<State> state, std::vector<double>& marg_kfs)
 {
@@ -508,7 +549,7 @@ void KeyframeUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapSer
     std::vector<double> selected_timestamps;
     this->getMargKfs(state, selected_timestamps);
     if (selected_timestamps.size() == 0) return;
-    _last_rows = selectedUpdate(*this, state, map_server, tri, stereo, selected_timestamps, 2 /* KeyframeUpdate.cpp:675-676 */, _noise, _rec);
+    _last_rows = selectedUpdate(*this, state, map_server, tri, stereo, selected_timestamps, 2 /* KeyframeUpdate.cpp:675-676 */, _noise, _rec, _fuse_tri);
 }
 
 void KeyframeUpdate::cleanMonoObsAtMargTime(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server)

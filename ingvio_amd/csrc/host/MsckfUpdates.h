@@ -112,6 +112,7 @@ protected:
     void update(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, std::shared_ptr<Triangulator> tri, bool stereo);
     double _noise;
     int _frame_select_interval;
+    bool _fuse_tri = true;      // IngvioParams::_hip_fuse_triangulation
     int _last_rows = 0;
     UpdateRecord _rec;
     MaintenanceRecord _maint;
@@ -137,6 +138,7 @@ protected:
     MaintenanceRecord _maint;
     double _noise;
     int _max_sw_poses;
+    bool _fuse_tri = true;      // IngvioParams::_hip_fuse_triangulation
     // the reference keeps this counter as a process-global static (KeyframeUpdate.cpp:41); per filter here
     int _select_cnt = 0;
     double _timestamp = -1;

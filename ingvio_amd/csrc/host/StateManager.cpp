@@ -408,16 +408,21 @@ void StateManager::triangulateFrame(std::shared_ptr<State> state, const ingvio_m
 }
 
 int StateManager::msckfUpdateTri(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_msckf_opts& opts,
-                                 const ingvio_tri_opts& tri, std::vector<int>* accepted, std::vector<int>* tri_ok)
+                                 const ingvio_tri_opts& tri, std::vector<int>* accepted, std::vector<int>* tri_ok,
+                                 const unsigned long long* tri_mask, std::vector<Vec3d>* pf)
 {
     const int ldp = ingvio_ldp(state->_ctx), fm = std::max(ingvio_f_max(state->_ctx), frame.n_feat);
     VecXd dx(ldp, 0.0);
     std::vector<int> acc(fm, 0), tok(fm, 0);
+    std::vector<double> pfo(pf ? 3 * (size_t)fm : 0, 0.0);
     int rows = 0;
-    const int rc = ingvio_msckf_update_tri(state->_ctx, state->_b, 1, &frame, &opts, &tri, dx.data(), acc.data(), nullptr, &rows, nullptr, tok.data());
+    const unsigned long long* masks[1] = { tri_mask };
+    const int rc = ingvio_msckf_update_tri(state->_ctx, state->_b, 1, &frame, &opts, &tri, tri_mask ? masks : nullptr, dx.data(), acc.data(), nullptr,
+                                           &rows, pf ? pfo.data() : nullptr, tok.data());
     if (rc < 0) fatal(state, "msckfUpdateTri", rc);
     if (accepted) accepted->assign(acc.begin(), acc.begin() + frame.n_feat);
     if (tri_ok) tri_ok->assign(tok.begin(), tok.begin() + frame.n_feat);
+    if (pf) { pf->resize((size_t)frame.n_feat); for (int j = 0; j < frame.n_feat; ++j) (*pf)[j] = Vec3d(pfo[3 * j], pfo[3 * j + 1], pfo[3 * j + 2]); }
     if (rows > 0) {
         dx.resize(state->curr_cov_size());
         boxPlus(state, dx);

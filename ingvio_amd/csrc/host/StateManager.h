@@ -74,8 +74,11 @@ public:
     static int msckfUpdate(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_msckf_opts& opts,
                            std::vector<int>* accepted = nullptr);
     // the same with the frame's points triangulated on the device first (ingvio_msckf_update_tri): tri_ok[j] for j < frame.n_feat
+    // (1 triangulated, 0 failed, 2 behind its anchor camera); tri_mask: the observations the triangulation uses when they differ from
+    // frame.obs_mask (nullptr: the same); pf: the triangulated points
     static int msckfUpdateTri(std::shared_ptr<State> state, const ingvio_msckf_frame& frame, const ingvio_msckf_opts& opts,
-                              const ingvio_tri_opts& tri, std::vector<int>* accepted, std::vector<int>* tri_ok);
+                              const ingvio_tri_opts& tri, std::vector<int>* accepted, std::vector<int>* tri_ok,
+                              const unsigned long long* tri_mask = nullptr, std::vector<Vec3d>* pf = nullptr);
 
     static ingvio_ctx* ctx(const std::shared_ptr<State>& state) { return state->_ctx; }
     static int filterIndex(const std::shared_ptr<State>& state) { return state->_b; }

@@ -153,15 +153,15 @@ __global__ __launch_bounds__(TRI_NT) void k_triangulate(TriLaunch L)
     const int j = blockIdx.x * (TRI_NT / TRI_LPF) + (tid >> 2);
     if (j >= F) return;                                                             // whole quads leave together
     const size_t oidx = (size_t)b * fv.fmax + j;
-    const unsigned long long mask = fv.obs_mask[oidx] & (C >= 64 ? ~0ULL : ((1ULL << C) - 1ULL));
+    const unsigned long long mask = (L.tri_mask ? L.tri_mask : fv.obs_mask)[oidx] & (C >= 64 ? ~0ULL : ((1ULL << C) - 1ULL));
     const double* uv = fv.uv + oidx * fv.cmax * 4;
     double* pf_out = L.pf + oidx * 3;
-    auto fail = [&]() {
+    auto fail = [&](int code = 0) {
         if (q == 0) {
             pf_out[0] = pf_out[1] = pf_out[2] = 0.0;
-            L.ok[oidx] = 0;
+            L.ok[oidx] = code;
             if (L.mask_failed) L.mask_rw[oidx] = 0ULL;
-            if (L.ok2) { L.ok2[oidx] = 0; L.pf2[oidx * 3] = L.pf2[oidx * 3 + 1] = L.pf2[oidx * 3 + 2] = 0.0; }
+            if (L.ok2) { L.ok2[oidx] = code; L.pf2[oidx * 3] = L.pf2[oidx * 3 + 1] = L.pf2[oidx * 3 + 2] = 0.0; }
         }
     };
     const int n = EYES * __popcll(mask);
@@ -333,11 +333,11 @@ __global__ __launch_bounds__(TRI_NT) void k_triangulate(TriLaunch L)
     if (w3[0] != w3[0] || w3[1] != w3[1] || w3[2] != w3[2]) { fail(); return; }
     if (L.check_anchor) {                                                           // MapServerManager.cpp:290,325: depth in the anchor's (left) camera
         const int a = fv.anchor[oidx];
-        if (a < 0 || a >= C) { fail(); return; }
+        if (a < 0 || a >= C) { fail(2); return; }
         const double* Ra = sR[0][a];
         const double* pa = sP[0][a];
         const double z = Ra[2] * (w3[0] - pa[0]) + Ra[5] * (w3[1] - pa[1]) + Ra[8] * (w3[2] - pa[2]);      // (R_a^T (p_f - p_a)).z
-        if (z <= 0.0) { fail(); return; }
+        if (z <= 0.0) { fail(2); return; }
     }
     if (q == 0) {
         pf_out[0] = w3[0]; pf_out[1] = w3[1]; pf_out[2] = w3[2];

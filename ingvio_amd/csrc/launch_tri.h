@@ -15,7 +15,8 @@ struct TriLaunch {
     // update-with-triangulation call (ingvio_msckf_update_tri): the staged frame carries anchors - a point behind its anchor camera
     // fails as well (FeatureInfoManager::triangulateFeatureInfoStereo, MapServerManager.cpp:325) - and the flags / points are
     // mirrored into the result slab the update's fetch copies (nullptr: not mirrored)
-    int check_anchor;
+    int check_anchor;             // a point behind its anchor camera: ok = 2 (attempt counted, MapServerManager.cpp:287), feature dropped
+    const unsigned long long* tri_mask;      // [B][fmax] observations the triangulation uses, or nullptr: fv.obs_mask
     int* ok2;                     // [B][fmax] or nullptr
     double* pf2;                  // [B][fmax][3] or nullptr
 };

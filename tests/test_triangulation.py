@@ -169,12 +169,13 @@ def test_gpu_triangulate_staged_then_update():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("stereo", [True, False])
-def test_gpu_update_with_triangulation_equals_the_two_calls(stereo):
+@pytest.mark.parametrize("stereo,selected", [(True, False), (False, False), (True, True)])
+def test_gpu_update_with_triangulation_equals_the_two_calls(stereo, selected):
     """ingvio_msckf_update_tri (RemoveLostUpdate in one device round trip) against ingvio_triangulate followed by ingvio_msckf_update on
     the features that passed (what the shim did before, RemoveLostUpdate.cpp:283-299 + :300-397): same flags, same points, same accept
     masks, and the same posterior and correction to the last bit.  Also the extra failure the one-call path carries: a point behind its
-    anchor camera (MapServerManager.cpp:290,325) - forced here by naming an anchor that looks away."""
+    anchor camera (MapServerManager.cpp:290,325), reported as tri_ok = 2.  selected: the selected-stamp form (SwMargUpdate.cpp:236-257) -
+    triangulation from every observation, update with three stamps only (tri_masks)."""
     from ingvio_amd import capi, host, synth
     F, C = 96, 11
     ctx, frames = _frames(stereo, C, F, 1, True, 2e-3, 1200)
@@ -185,28 +186,34 @@ def test_gpu_update_with_triangulation_equals_the_two_calls(stereo):
     M = rng.normal(size=(n, n))
     prior = 1e-3 * (M @ M.T / n + np.eye(n))
     ctx.cov_set(0, prior)
+    full = np.asarray(fr["obs_mask"], dtype=np.uint64)
+    upd = full & np.uint64((1 << 0) | (1 << 5) | (1 << 10)) if selected else full      # the observations the UPDATE uses
+    sv = 1 if selected else 0
     # two calls: triangulate, keep what passed (anchor depth checked on the host as Triangulator::accept does), update
     pf, ok = ctx.triangulate(0, [fr], stereo=stereo)
-    keep = []
+    keep, behind = [], []
     for j in range(F):
         a = int(fr["anchor"][j])
         Ra = np.asarray(fr["clone_R"][a]).reshape(3, 3); pa = np.asarray(fr["clone_p"][a])
         if ok[0, j] and (Ra.T @ (pf[0, j] - pa))[2] > 0:
             keep.append(j)
+        elif ok[0, j]:
+            behind.append(j)
     assert 20 < len(keep) < F
     fr2 = dict(fr)
-    for k in ("pf", "uv", "anchor", "obs_mask", "dof"):
-        fr2[k] = np.asarray(fr[k] if k != "pf" else pf[0])[keep]
-    fr2["pf"] = pf[0][keep]
-    dx2, acc2, gam2, rows2 = ctx.msckf_update(0, [fr2], max_accept=0, compress_rule=1)
+    for k in ("uv", "anchor", "dof"):
+        fr2[k] = np.asarray(fr[k])[keep]
+    fr2["pf"] = pf[0][keep]; fr2["obs_mask"] = upd[keep]
+    dx2, acc2, gam2, rows2 = ctx.msckf_update(0, [fr2], max_accept=0, compress_rule=1, selected_variant=sv)
     P2 = ctx.cov_get(0)
     # one call on the same prior
     ctx.cov_set(0, prior)
-    fr1 = dict(fr); fr1["pf"] = np.full((F, 3), 321.0)
-    dx1, acc1, gam1, rows1, pf1, ok1 = ctx.msckf_update_tri(0, [fr1], max_accept=0, compress_rule=1, stereo=stereo)
+    fr1 = dict(fr); fr1["pf"] = np.full((F, 3), 321.0); fr1["obs_mask"] = upd
+    dx1, acc1, gam1, rows1, pf1, ok1 = ctx.msckf_update_tri(0, [fr1], max_accept=0, compress_rule=1, selected_variant=sv, stereo=stereo,
+                                                            tri_masks=[full] if selected else None)
     P1 = ctx.cov_get(0)
-    assert np.array_equal(np.nonzero(ok1[0, :F])[0], np.asarray(keep))
-    assert np.array_equal(pf1[0][keep], pf[0][keep]) and not np.any(pf1[0][ok1[0] == 0])
+    assert np.array_equal(np.nonzero(ok1[0, :F] == 1)[0], np.asarray(keep)) and np.array_equal(np.nonzero(ok1[0, :F] == 2)[0], np.asarray(behind, dtype=np.int64))
+    assert np.array_equal(pf1[0][keep], pf[0][keep]) and not np.any(pf1[0][ok1[0] != 1])
     assert np.array_equal(acc1[0][keep], acc2[0][:len(keep)]) and acc1[0].sum() == acc2[0].sum() and acc2[0].sum() > 10
     assert rows1[0] == rows2[0]
     assert np.array_equal(dx1, dx2) and np.array_equal(P1, P2)

@@ -7,10 +7,14 @@ W=${1:-config2}
 case $W in
   config2) SPEC="feats=150,clones=11,life=10,cohort=1,birth_frame=3,frames=45,key=1";;
   config5) SPEC="feats=300,clones=30,life=28,cohort=1,birth_frame=2,frames=95,key=1";;
+  kf27) SPEC="feats=150,clones=27,life=25,cohort=0,frames=110,key=1";;      # the sports-field stereo window, staggered track deaths (6 lost features per frame)
+  kf21) SPEC="feats=100,clones=21,life=19,cohort=0,frames=90,key=1";;
 esac
+EXTRA=()
+case $W in config2|config5) EXTRA=(--set "hip_max_valid_ids: 0" --set "hip_compress_rule: 1");; esac
 OUT=gpurun_out/replay_trace_$W
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --memory-copy-trace --stats -d $OUT -o rt --output-format csv -- ingvio_amd/lib/ingvio_replay --synth "$SPEC" --time --set "hip_max_valid_ids: 0" --set "hip_compress_rule: 1" > $OUT/stdout.txt 2> $OUT/stderr.txt
+rocprofv3 --kernel-trace --memory-copy-trace --stats -d $OUT -o rt --output-format csv -- ingvio_amd/lib/ingvio_replay --synth "$SPEC" --time "${EXTRA[@]}" > $OUT/stdout.txt 2> $OUT/stderr.txt
 tail -1 $OUT/stdout.txt
 f=$(find $OUT -name '*kernel_stats.csv' | head -1)
 python - "$f" <<'PY'
