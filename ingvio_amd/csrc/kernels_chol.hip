@@ -540,13 +540,19 @@ __global__ __launch_bounds__(256) void k_chol_carried(CholArgs a, int per)
 
 int dbg_read_chol(long long* out, int n) { return dbg_read_local(out, n); }
 
+#ifndef GEMM64_MIN_BATCH
+#define GEMM64_MIN_BATCH 8
+#endif
 void launch_gemm(const GemmArgs& g, hipStream_t st)
 {
     const int nbi = (g.M + 31) / 32, nbj = (g.N + 31) / 32;
     const int blocks = g.lower ? nbi * (nbi + 1) / 2 : nbi * nbj;
     GemmArgs h = g;
     if (h.ksplit < 1) h.ksplit = 1;
-    if (h.ksplit == 1 && g.K >= 96 && g.M >= 96 && g.N >= 64) {          // a K loop worth pipelining: 64 x 64 blocks (k_gemm64)
+    // a K loop worth pipelining: 64 x 64 blocks (k_gemm64) - when there are enough filters to fill the chip with them.  A handful of
+    // filters is latency-bound: k_gemm's workgroup is three memory round trips deep (its four waves split K), k_gemm64's ten staged
+    // chunks (16 against 6 us per product for one filter at 27 clones)
+    if (h.ksplit == 1 && g.K >= 96 && g.M >= 96 && g.N >= 64 && g.batch > GEMM64_MIN_BATCH) {
         const int n64i = (g.M + 63) / 64, n64j = (g.N + 63) / 64;
         const dim3 grid64(xcd_grid(g.lower ? n64i * (n64i + 1) / 2 : n64i * n64j, g.batch));
         if (g.modeA == 0 && g.modeB == 0) hipLaunchKernelGGL((k_gemm64<0, 0>), grid64, dim3(256), 0, st, h);

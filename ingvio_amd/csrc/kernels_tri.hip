@@ -1,11 +1,12 @@
 // kernels_tri.hip — SURVEY.md §8(f) row f-1: batched feature triangulation on the device.
 // Triangulator::triangulateMonoObs (Triangulator.cpp:173-318) and its stereo wrapper (:320-359): Levenberg-Marquardt on
 // (x/z, y/z, 1/z) in the frame of the LAST mono-equivalent observation, Huber-weighted normal equations, accept test
-// on the unweighted cost, depth / parallax / convergence gates.  One DPP QUAD per feature: the iteration is sequential,
-// but each cost / normal-equation pass is a sum over observations, dealt round-robin to the four lanes and reduced
-// with two quad_perm exchanges; 16 features per wave, 32 per workgroup.  The window's camera poses (left, and right = left * T_cl2cr^-1) are
-// staged once per workgroup in LDS.  Per-observation arithmetic follows the restatement in oracle/ingvio_oracle.c; only the order of
-// the sums over observations differs (4 partial sums), which the parity tolerance (5e-7 relative) covers.  gfx950 only.
+// on the unweighted cost, depth / parallax / convergence gates.  One DPP QUAD per feature (one DPP ROW of 16 lanes when the call
+// holds few features, round 5): the iteration is sequential, but each cost / normal-equation pass is a sum over observations, dealt
+// round-robin to the lanes of the group and reduced with lane exchanges; 16 (4) features per wave, 32 (8) per workgroup.  The window's
+// camera poses (left, and right = left * T_cl2cr^-1) are staged once per workgroup in LDS.  Per-observation arithmetic follows the
+// restatement in oracle/ingvio_oracle.c; only the order of the sums over observations differs (4 or 16 partial sums), which the parity
+// tolerance (5e-7 relative) covers.  gfx950 only.
 #include "dev_common.h"
 #include "launch_tri.h"
 
@@ -64,9 +65,10 @@ __device__ __forceinline__ void solve3(const double A[9], double lambda, const d
 }
 
 #define TRI_CMAX 64
-#define TRI_LPF 4                      // lanes per feature (one DPP quad)
-#define TRI_NT 128                     // 32 features per workgroup
-#define TRI_NOBS 6                     // register path: up to 24 mono-equivalent observations per feature
+#define TRI_NT 128                     // 32 features per workgroup at 4 lanes per feature, 8 at 16
+#define TRI_NOBS 6                     // register path at 4 lanes per feature: up to 24 mono-equivalent observations per feature
+#define TRI_NOBS16 4                   // ... at 16 lanes per feature: up to 64
+#define TRI_FEW 2048                   // up to this many features in a call: 16 lanes per feature
 
 // quad_perm DPP: full-rate lane exchange inside a quad (0xB1 = lanes ^1, 0x4E = lanes ^2)
 template <int CTRL>
@@ -78,24 +80,45 @@ __device__ __forceinline__ double dpp_quad(double x)
 }
 template <int CTRL>
 __device__ __forceinline__ int dpp_quad_i(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xf, 0xf, true); }
-// butterfly: a+b is commutative, so all four lanes end with the SAME bits and the quad's control flow stays uniform
-__device__ __forceinline__ double quad_sum(double x)
+// Reductions over the LPF lanes of a feature (4: a DPP quad, 16: a DPP row).  Every step is an EXCHANGE between two lanes (quad_perm
+// lanes ^1 / ^2, then the mirror images inside the half row and the row: lane i with 7 - i, lane i with 15 - i), a + b is commutative,
+// so all lanes of the group end with the SAME bits and the group's control flow stays uniform - a rotation (row_ror) would leave the
+// four quads of a row with differently associated sums, i.e. with different last bits and, once in a while, different branches.
+template <int LPF>
+__device__ __forceinline__ double grp_sum(double x)
 {
     x += dpp_quad<0xB1>(x);
     x += dpp_quad<0x4E>(x);
+    if (LPF == 16) {
+        x += dpp_quad<0x141>(x);                                         // row_half_mirror
+        x += dpp_quad<0x140>(x);                                         // row_mirror
+    }
     return x;
 }
-__device__ __forceinline__ int quad_or(int x)
+template <int LPF>
+__device__ __forceinline__ int grp_or(int x)
 {
     x |= dpp_quad_i<0xB1>(x);
     x |= dpp_quad_i<0x4E>(x);
+    if (LPF == 16) {
+        x |= dpp_quad_i<0x141>(x);
+        x |= dpp_quad_i<0x140>(x);
+    }
     return x;
+}
+// the larger value wins, the lower key among equal values: a symmetric rule, both lanes of an exchange pick the same winner
+template <int CTRL>
+__device__ __forceinline__ void max_exchange(double& v, int& key)
+{
+    const double ov = dpp_quad<CTRL>(v); const int ok_ = dpp_quad_i<CTRL>(key);
+    if (ov > v || (ov == v && ok_ < key)) { v = ov; key = ok_; }
 }
 
 // The mono-equivalent observations of a feature in the reference's order (clone ascending, left eye before right) are
 // dealt round-robin to the four lanes of a quad: lane q owns observations q, q+4, q+8, ...  Stereo: that is every second
-// observing clone starting at the (q>>1)-th, always eye q&1; mono: every fourth starting at the q-th.
-template <bool STEREO>
+// observing clone starting at the (q>>1)-th, always eye q&1; mono: every fourth starting at the q-th.  (LPF lanes per feature: every
+// LPF / eyes-th observing clone.)
+template <bool STEREO, int LPF>
 struct ObsCursor {
     unsigned long long m;
     __device__ __forceinline__ ObsCursor(unsigned long long mask, int q)
@@ -103,7 +126,7 @@ struct ObsCursor {
         m = mask;
         const int skip = STEREO ? (q >> 1) : q;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < (STEREO ? LPF / 2 : LPF) - 1; ++i)
             if (i < skip) m &= m - 1ULL;
     }
     __device__ __forceinline__ bool valid() const { return m != 0ULL; }
@@ -111,14 +134,18 @@ struct ObsCursor {
     __device__ __forceinline__ void next()
     {
 #pragma unroll
-        for (int i = 0; i < (STEREO ? 2 : 4); ++i) m &= m - 1ULL;
+        for (int i = 0; i < (STEREO ? LPF / 2 : LPF); ++i) m &= m - 1ULL;
     }
 };
 
 // NOBS > 0: a lane keeps its (at most NOBS) observations - clone slot and measurement - in registers and every pass is a
 // fully unrolled, branch-free loop over them (independent observations interleave, nothing is re-read from global
 // memory).  NOBS == 0: any number of observations, walked with the cursor and read from global memory in every pass.
-template <bool STEREO, int NOBS>
+// LPF lanes per feature: 4 for throughput (16 features per wave; every lane of a group repeats the scalar part of the iteration - the
+// 3 x 3 solves, the acceptance tests), 16 when there are few features and the LATENCY of one feature's iteration is what the caller
+// waits for (a single real-time filter: 22-54 observations dealt to 16 lanes instead of 4 - a pass over them is 2-4 observations
+// per lane instead of 6-14).
+template <bool STEREO, int NOBS, int LPF>
 __global__ __launch_bounds__(TRI_NT) void k_triangulate(TriLaunch L)
 {
     constexpr int EYES = STEREO ? 2 : 1;
@@ -149,8 +176,8 @@ __global__ __launch_bounds__(TRI_NT) void k_triangulate(TriLaunch L)
         }
     }
     __syncthreads();
-    const int q = tid & (TRI_LPF - 1), eq = STEREO ? (q & 1) : 0;
-    const int j = blockIdx.x * (TRI_NT / TRI_LPF) + (tid >> 2);
+    const int q = tid & (LPF - 1), eq = STEREO ? (q & 1) : 0;
+    const int j = blockIdx.x * (TRI_NT / LPF) + tid / LPF;
     if (j >= F) return;                                                             // whole quads leave together
     const size_t oidx = (size_t)b * fv.fmax + j;
     const unsigned long long mask = (L.tri_mask ? L.tri_mask : fv.obs_mask)[oidx] & (C >= 64 ? ~0ULL : ((1ULL << C) - 1ULL));
@@ -173,7 +200,7 @@ __global__ __launch_bounds__(TRI_NT) void k_triangulate(TriLaunch L)
     int sl[NREG], cnt = 0;
     double mu[NREG], mv[NREG];
     if (NOBS > 0) {
-        ObsCursor<STEREO> oc(mask, q);
+        ObsCursor<STEREO, LPF> oc(mask, q);
 #pragma unroll
         for (int t = 0; t < NREG; ++t) {
             const bool v = oc.valid();
@@ -194,7 +221,7 @@ __global__ __launch_bounds__(TRI_NT) void k_triangulate(TriLaunch L)
             }
         } else {
             int t = 0;
-            for (ObsCursor<STEREO> oc(mask, q); oc.valid(); oc.next(), ++t) {
+            for (ObsCursor<STEREO, LPF> oc(mask, q); oc.valid(); oc.next(), ++t) {
                 const int s = oc.slot();
                 body(s, uv[4 * s + 2 * eq], uv[4 * s + 2 * eq + 1], t, true);
             }
@@ -215,7 +242,7 @@ __global__ __launch_bounds__(TRI_NT) void k_triangulate(TriLaunch L)
         double max_trans = -__builtin_inf();
         int kmax = 0x7fffffff;
         each_obs([&](int s, double, double, int t, bool live) {
-            const int k = q + TRI_LPF * t;
+            const int k = q + LPF * t;
             const double* pi = sP[eq][s];
             const double d[3] = { pi[0] - pl[0], pi[1] - pl[1], pi[2] - pl[2] };
             const double dot = fw[0] * d[0] + fw[1] * d[1] + fw[2] * d[2];
@@ -224,10 +251,9 @@ __global__ __launch_bounds__(TRI_NT) void k_triangulate(TriLaunch L)
             if (live && !(s == s_last && eq == EYES - 1) && tr > max_trans) { max_trans = tr; kmax = (k << 8) | (s << 1) | eq; }
         });
         {
-            double ot = dpp_quad<0xB1>(max_trans); int ok_ = dpp_quad_i<0xB1>(kmax);
-            if (ot > max_trans || (ot == max_trans && ok_ < kmax)) { max_trans = ot; kmax = ok_; }
-            ot = dpp_quad<0x4E>(max_trans); ok_ = dpp_quad_i<0x4E>(kmax);
-            if (ot > max_trans || (ot == max_trans && ok_ < kmax)) { max_trans = ot; kmax = ok_; }
+            max_exchange<0xB1>(max_trans, kmax);
+            max_exchange<0x4E>(max_trans, kmax);
+            if (LPF == 16) { max_exchange<0x141>(max_trans, kmax); max_exchange<0x140>(max_trans, kmax); }
         }
         if (max_trans < L.trans_thres) { fail(); return; }                          // :192
         smax = (kmax >> 1) & 127; emax = kmax & 1;
@@ -256,7 +282,7 @@ __global__ __launch_bounds__(TRI_NT) void k_triangulate(TriLaunch L)
             const double uc = unit_cost(u, v, Rr, tr, pf0);
             c += live ? uc : 0.0;
         });
-        return quad_sum(c);
+        return grp_sum<LPF>(c);
     };
     const double eps2 = L.huber_epsilon * L.huber_epsilon, two_eps = 2.0 * L.huber_epsilon;
     double total_cost = total_cost_of(sol);
@@ -295,9 +321,9 @@ __global__ __launch_bounds__(TRI_NT) void k_triangulate(TriLaunch L)
             }
         });
 #pragma unroll
-        for (int t = 0; t < 6; ++t) A[t] = quad_sum(A[t]);
+        for (int t = 0; t < 6; ++t) A[t] = grp_sum<LPF>(A[t]);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) bv[t] = quad_sum(bv[t]);
+        for (int t = 0; t < 3; ++t) bv[t] = grp_sum<LPF>(bv[t]);
         const double Af[9] = { A[0], A[1], A[2], A[1], A[3], A[4], A[2], A[4], A[5] };
         do {
             double delta[3], ns[3];
@@ -325,7 +351,7 @@ __global__ __launch_bounds__(TRI_NT) void k_triangulate(TriLaunch L)
         m3mulv(Rr, plast, t3);
         behind |= (live && t3[2] + tr[2] <= L.min_depth) ? 1 : 0;
     });
-    if (quad_or(behind)) { fail(); return; }
+    if (grp_or<LPF>(behind)) { fail(); return; }
     if (plast[2] < L.min_depth || plast[2] > L.max_depth) { fail(); return; }        // :296-297
     double w3[3];
     m3mulv(Rl, plast, w3);
@@ -351,15 +377,29 @@ __global__ __launch_bounds__(TRI_NT) void k_triangulate(TriLaunch L)
 int launch_triangulate(const TriLaunch& L, int nb, int fmax_used, int stereo, hipStream_t st)
 {
     if (L.fv.cmax > TRI_CMAX) return -1;
-    const int fpb = TRI_NT / TRI_LPF;
+    const int eyes = stereo ? 2 : 1;
+    if ((long long)nb * fmax_used <= TRI_FEW) {                                       // few features: 16 lanes each (latency)
+        const int fpb = TRI_NT / 16;
+        const dim3 grid((fmax_used + fpb - 1) / fpb, nb);
+        const bool regs = eyes * L.fv.cmax <= 16 * TRI_NOBS16;
+        if (stereo) {
+            if (regs) hipLaunchKernelGGL((k_triangulate<true, TRI_NOBS16, 16>), grid, dim3(TRI_NT), 0, st, L);
+            else hipLaunchKernelGGL((k_triangulate<true, 0, 16>), grid, dim3(TRI_NT), 0, st, L);
+        } else {
+            if (regs) hipLaunchKernelGGL((k_triangulate<false, TRI_NOBS16, 16>), grid, dim3(TRI_NT), 0, st, L);
+            else hipLaunchKernelGGL((k_triangulate<false, 0, 16>), grid, dim3(TRI_NT), 0, st, L);
+        }
+        return 0;
+    }
+    const int fpb = TRI_NT / 4;
     const dim3 grid((fmax_used + fpb - 1) / fpb, nb);
-    const bool regs = (stereo ? 2 : 1) * L.fv.cmax <= TRI_LPF * TRI_NOBS;          // every lane's share fits the register path
+    const bool regs = eyes * L.fv.cmax <= 4 * TRI_NOBS;                               // every lane's share fits the register path
     if (stereo) {
-        if (regs) hipLaunchKernelGGL((k_triangulate<true, TRI_NOBS>), grid, dim3(TRI_NT), 0, st, L);
-        else hipLaunchKernelGGL((k_triangulate<true, 0>), grid, dim3(TRI_NT), 0, st, L);
+        if (regs) hipLaunchKernelGGL((k_triangulate<true, TRI_NOBS, 4>), grid, dim3(TRI_NT), 0, st, L);
+        else hipLaunchKernelGGL((k_triangulate<true, 0, 4>), grid, dim3(TRI_NT), 0, st, L);
     } else {
-        if (regs) hipLaunchKernelGGL((k_triangulate<false, TRI_NOBS>), grid, dim3(TRI_NT), 0, st, L);
-        else hipLaunchKernelGGL((k_triangulate<false, 0>), grid, dim3(TRI_NT), 0, st, L);
+        if (regs) hipLaunchKernelGGL((k_triangulate<false, TRI_NOBS, 4>), grid, dim3(TRI_NT), 0, st, L);
+        else hipLaunchKernelGGL((k_triangulate<false, 0, 4>), grid, dim3(TRI_NT), 0, st, L);
     }
     return 0;
 }

@@ -108,10 +108,12 @@ def _frames(stereo, C, F, nb, ragged, noise_px, seed0):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("stereo,C,ragged,noise", [(True, 11, False, 0.0), (True, 11, True, 2e-3), (False, 11, True, 2e-3),
-                                                     (True, 30, True, 5e-3), (False, 6, False, 0.03)])
-def test_gpu_triangulation_vs_oracle(stereo, C, ragged, noise):
-    F, nb = 96, 2
+@pytest.mark.parametrize("stereo,C,ragged,noise,nb", [(True, 11, False, 0.0, 2), (True, 11, True, 2e-3, 2), (False, 11, True, 2e-3, 2),
+                                                        (True, 30, True, 5e-3, 2), (False, 6, False, 0.03, 2),
+                                                        # more than 2048 features in the call: four lanes per feature instead of sixteen
+                                                        (True, 11, True, 2e-3, 24), (False, 30, True, 5e-3, 24)])
+def test_gpu_triangulation_vs_oracle(stereo, C, ragged, noise, nb):
+    F = 96
     ctx, frames = _frames(stereo, C, F, nb, ragged, noise, 900)
     pf, ok = ctx.triangulate(0, frames, stereo=stereo)
     n_ok = 0
