@@ -827,6 +827,13 @@ LATENCY_STREAMS = {      # SynthStream.h specs: every `life` frames a whole coho
 }
 
 
+STAGGERED_STREAMS = {
+    "kf11": "feats=150,clones=11,life=10,cohort=0,frames=90,key=1",
+    "kf21": "feats=100,clones=21,life=19,cohort=0,frames=90,key=1",
+    "kf27": "feats=150,clones=27,life=25,cohort=0,frames=110,key=1",
+}
+
+
 def latency_b1(args):
     """Single-filter latency: ONE filter driven through the C++ shim's callback surface
     (IngvioFilter::callbackIMU / callbackStereoFrame, IngvioFilter.cpp:252-379: propagate + clone, RemoveLost update, key-frame
@@ -854,6 +861,20 @@ def latency_b1(args):
                             all_ms=float(kv["median_ms"]), frames=int(kv["timed"]), final_pos_err_m=float(kv["final_pos_err_m"]))
         e["stream"] = spec
         out[name] = e
+    # every frame loses a few tracks (staggered deaths) - what a running tracker delivers: median over ALL camera callbacks, as written,
+    # at the window sizes of the reference's shipped stereo configurations (config/fw_zed2i_f9p: 21 poses, config/sportsfield: 27)
+    st = {}
+    for name, spec in STAGGERED_STREAMS.items():
+        try:
+            r = subprocess.run([REPLAY_TOOL, "--synth", spec, "--time"], capture_output=True, text=True, timeout=300)
+        except subprocess.TimeoutExpired:
+            st[name] = dict(error="timeout"); continue
+        line = [l for l in r.stdout.splitlines() if l.startswith("LATENCY")]
+        if r.returncode != 0 or not line:
+            st[name] = dict(error=(r.stderr or r.stdout)[-200:]); continue
+        kv = dict(x.split("=") for x in line[0].split()[1:])
+        st[name] = dict(median_ms=float(kv["median_ms"]), frames=int(kv["timed"]), stream=spec)
+    out["staggered"] = st
     return out
 
 
@@ -912,7 +933,7 @@ def compact_line(full):
         # as written: cap 20, all rows kept), other = the frames in between; the oracle's single-thread update time beside it
         cl = {}
         for k, e in lat.items():
-            if not isinstance(e, dict):
+            if not isinstance(e, dict) or k == "staggered":
                 continue
             c = {}
             for label in ("lifted", "as_written"):
@@ -920,6 +941,8 @@ def compact_line(full):
                 c[label] = _pick(v, ("heavy_ms", "heavy_accepted", "other_ms", "error"))
             c["oracle_1thread_update_ms"] = e.get("oracle_1thread_update_ms")
             cl[k] = c
+        if isinstance(lat.get("staggered"), dict):      # a few lost tracks per frame, median over all callbacks, key-frame mode at 11 / 21 / 27 poses
+            cl["staggered_median_ms"] = {k: (v.get("median_ms") if "median_ms" in v else v.get("error")) for k, v in lat["staggered"].items()}
         out["latency_b1_ms"] = cl
     if full.get("aux_configs"):
         out["aux_configs"] = {

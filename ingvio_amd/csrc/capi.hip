@@ -22,6 +22,7 @@
 #include <vector>
 
 #define KMAX 64            // IMU steps per fused propagation call
+#define UPLOAD_KERNEL_MAX (256u << 10)      // host-to-device uploads up to this size travel as a kernel reading the pinned slab (Uploader::copy)
 #define IMU_SLAB_NB 4      // ingvio_propagate(_fused) for up to this many filters: inputs travel as one copy (ingvio_ctx::d_imu)
 #define CHI2_CAP 1024
 
@@ -82,6 +83,7 @@ struct ingvio_ctx {
     // what d_chi2 and d_noise hold (single-filter latency: an update re-sent the same gate table and the same noise variance with every
     // call, two host-to-device copies of ~7 us each in front of the kernels); invalidated by every other writer of those buffers
     struct { std::vector<double> chi2; bool chi2_ok = false; double var = 0.0; int b0 = -1, nb = 0; bool noise_ok = false; } upc;
+    bool fork_recorded = false;         // large windows: ev_fork already recorded on the main stream by the caller of run_msckf_factored
     unsigned long long* d_tri_mask = nullptr;      // [B][f_max], allocated on first use: triangulation masks of ingvio_msckf_update_tri
     char* d_imu = nullptr;              // [IMU_SLAB_NB filters] Phi | G | dt | gnss_idx of ingvio_propagate(_fused) in one piece (few filters per call)
     double* d_Tflat = nullptr;          // [min(B, APPLY_FLAT_NB)][ldp * 100]: T of the few-filter apply (k_apply_T_flat), windows up to 16 clones
@@ -287,7 +289,14 @@ struct Uploader {
     template <class T>
     void copy(T* dst, const T* src, size_t count)
     {
-        if (count && hipMemcpyAsync(dst, src, sizeof(T) * count, hipMemcpyHostToDevice, stream ? stream : c->st) != hipSuccess) rc = INGVIO_E_HIP;
+        const size_t bytes = sizeof(T) * count;
+        if (!count) return;
+        // small uploads on the compute stream: a kernel that reads the pinned slab (k_upload_words) - no copy-engine hand-over
+        if (!stream && bytes <= UPLOAD_KERNEL_MAX && (bytes & 3) == 0 && (((uintptr_t)dst | (uintptr_t)src) & 3) == 0) {
+            launch_upload_words(dst, src, bytes, c->st);
+            return;
+        }
+        if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream ? stream : c->st) != hipSuccess) rc = INGVIO_E_HIP;
     }
     int end()
     {
@@ -602,17 +611,24 @@ int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int s
     const bool big = c->d.c_max > 16;
     L.mstride = c->ystride; L.n_cap = c->d.n_max;
     L.marg_idx = marg_idx; L.marg_size = marg_size; L.pc_base = c->d_pcbase + b0;
+    // Order of ISSUE (round 5, single-filter latency): the fork point is recorded first (by the caller already when it has something to
+    // run between the fork and the gate - the triangulation of ingvio_msckf_update_tri), then the main stream's gate and Gram launches,
+    // and only then the eight launches of the side stream - issued first they kept the host busy for 24 us during which the gate could
+    // not start (one filter, 27 clones: gate at +53 us after the frame's upload instead of +30).
     bool forked = false;
     if (big && phase == 0 && c->st2) {
-        HIPCHK(c, hipEventRecord(c->ev_fork, c->st));                  // after everything that wrote P on the main stream
-        HIPCHK(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
-        L.stage = 5; launch_factored(L, c->st2);
-        HIPCHK(c, hipEventRecord(c->ev_join, c->st2));
+        if (!c->fork_recorded) HIPCHK(c, hipEventRecord(c->ev_fork, c->st));      // after everything that wrote P on the main stream
+        c->fork_recorded = false;
         forked = true;
     }
     if (phase != 2) {
         { ProfScope p(c, PF_GATE2); L.stage = 0; if (launch_factored(L, c->st)) return INGVIO_E_UNSUPPORTED; }
         { ProfScope p(c, PF_GRAM); L.stage = 1; launch_factored(L, c->st); }
+    }
+    if (forked) {
+        HIPCHK(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
+        L.stage = 5; launch_factored(L, c->st2);
+        HIPCHK(c, hipEventRecord(c->ev_join, c->st2));
     }
     if (phase == 1) return last_launch(c);
     if (forked) HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_join, 0));
@@ -1637,6 +1653,8 @@ static int msckf_update_impl(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_f
     if (check_range(c, b0, nb) || !frames || !opts) return INGVIO_E_ARG;
     if (tri && (tri->outer_loop_max_iter < 0 || tri->inner_loop_max_iter < 0)) return INGVIO_E_ARG;
     MsckfOpts op;
+    c->fork_recorded = false;
+    HIPCHK(c, hipMemsetAsync(c->d_status + b0, 0, sizeof(int) * (size_t)nb, c->st));      // first: it runs while the host packs the frame
     int rc = make_opts(c, opts, &op);
     if (rc) return rc;
     int fmx = 0;
@@ -1644,8 +1662,11 @@ static int msckf_update_impl(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_f
     if (rc) return rc;
     rc = fill_noise_scalar(c, b0, nb, op.var);
     if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->d_status + b0, 0, sizeof(int) * (size_t)nb, c->st));
     const int fm = c->d.f_max;
+    if (tri && c->d.c_max > 16 && c->st2 && c->method == 1) {      // the prior-only half of the large-window solve may start now, beside the triangulation
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->st));
+        c->fork_recorded = true;
+    }
     if (tri) {
         TriLaunch T;
         memset(&T, 0, sizeof T);

@@ -476,6 +476,24 @@ __global__ void k_copy_ints(int* dst, const int* src, int count)
     if (i < count) dst[i] = src[i];
 }
 
+// Small host-to-device uploads as a KERNEL that reads the pinned staging slab over the bus (hipHostMalloc memory is mapped into the
+// device's address space) instead of hipMemcpyAsync: the copy engine's completion reaches the compute queue 10-17 us after the copy
+// itself ended (rocprofv3: 11 us copy, the first kernel behind it 17 us later) - for a single real-time filter a third of what the
+// kernels in front of the Kalman solve take.  Words of 4 bytes (every upload of this library is a multiple), 16 where both sides allow.
+__global__ __launch_bounds__(256) void k_upload_words(unsigned* __restrict__ dst, const unsigned* __restrict__ src, size_t nwords, int vec4)
+{
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    if (vec4) {
+        const size_t n4 = nwords >> 2;
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        for (size_t i = i0; i < n4; i += stride) d4[i] = s4[i];
+        for (size_t i = (n4 << 2) + i0; i < nwords; i += stride) dst[i] = src[i];
+    } else {
+        for (size_t i = i0; i < nwords; i += stride) dst[i] = src[i];
+    }
+}
+
 // snapshot / restore of every filter's live covariance (benchmark hygiene: each timed step starts
 // from the same prior).  grid = (col tiles, B).
 __global__ __launch_bounds__(256) void k_snapshot(CovView cv, double* __restrict__ snap, int* __restrict__ n_snap)
@@ -568,6 +586,16 @@ void launch_post_marg(CovView cv, int b0, int nb, const int* idx, int size, hipS
 void launch_append(CovView cv, int b0, int nb, int size, const double* blk, hipStream_t st)
 {
     hipLaunchKernelGGL(k_append, dim3(nb), dim3(256), 0, st, cv, b0, size, blk);
+}
+void launch_upload_words(void* dst, const void* src_pinned, size_t bytes, hipStream_t st)
+{
+    const size_t nwords = bytes >> 2;
+    const int vec4 = (((uintptr_t)dst | (uintptr_t)src_pinned) & 15) == 0 ? 1 : 0;
+    const size_t items = vec4 ? (nwords >> 2) + 3 : nwords;
+    int blocks = (int)((items + 255) / 256);
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_upload_words, dim3(blocks), dim3(256), 0, st, (unsigned*)dst, (const unsigned*)src_pinned, nwords, vec4);
 }
 void launch_copy_ints(int* dst, const int* src, int count, hipStream_t st)
 {
