@@ -22,7 +22,9 @@
 #include <vector>
 
 #define KMAX 64            // IMU steps per fused propagation call
-#define UPLOAD_KERNEL_MAX (256u << 10)      // host-to-device uploads up to this size travel as a kernel reading the pinned slab (Uploader::copy)
+#ifndef UPLOAD_KERNEL_MAX      // host-to-device uploads up to this size travel as a kernel reading the pinned slab (Uploader::copy)
+#define UPLOAD_KERNEL_MAX (256u << 10)
+#endif
 #define IMU_SLAB_NB 4      // ingvio_propagate(_fused) for up to this many filters: inputs travel as one copy (ingvio_ctx::d_imu)
 #define CHI2_CAP 1024
 
@@ -362,8 +364,10 @@ size_t frame_slab_carve(const ingvio_ctx* c, char* base, FrameSlabPtrs* out)
     q.clone_idx = (int*)take(4 * B * cm); q.nclones = (int*)take(4 * B); q.nfeat = (int*)take(4 * B);
     q.anchor = (int*)take(4 * B * fm); q.dof = (int*)take(4 * B * fm);
     q.clone_R = (double*)take(8 * B * cm * 9); q.clone_p = (double*)take(8 * B * cm * 3);
-    q.pf = (double*)take(8 * B * fm * 3); q.uv = (double*)take(8 * B * fm * cm * 4);
-    q.mask = (unsigned long long*)take(8 * B * fm);
+    // uv last: a whole-batch upload then ends with the measurements of the last filter's LAST USED feature (pack_frames) - a single
+    // filter that lost 6 tracks uploads 14 KB instead of the 360 KB its f_max x c_max measurement array takes
+    q.pf = (double*)take(8 * B * fm * 3); q.mask = (unsigned long long*)take(8 * B * fm);
+    q.uv = (double*)take(8 * B * fm * cm * 4);
     if (out) *out = q;
     return (off + 63) & ~(size_t)63;
 }
@@ -471,8 +475,9 @@ int pack_frames(ingvio_ctx* c, Uploader& up, int b0, int nb, const ingvio_msckf_
     int* cidx = up.take<int>((size_t)nb * cm); int* ncl = up.take<int>(nb); int* nft = up.take<int>(nb);
     int* anc = up.take<int>((size_t)nb * fm); int* dof = up.take<int>((size_t)nb * fm);
     double* cR = up.take<double>((size_t)nb * cm * 9); double* cp = up.take<double>((size_t)nb * cm * 3);
-    double* pf = up.take<double>((size_t)nb * fm * 3); double* uv = up.take<double>((size_t)nb * fm * cm * 4);
+    double* pf = up.take<double>((size_t)nb * fm * 3);
     unsigned long long* mk = up.take<unsigned long long>((size_t)nb * fm);
+    double* uv = up.take<double>((size_t)nb * fm * cm * 4);      // same order as frame_slab_carve: uv last
     parallel_for(nb, [=](int i) {
         const ingvio_msckf_frame& f = fr[i];
         const int C = f.n_clones, F = f.n_feat;
@@ -493,7 +498,9 @@ int pack_frames(ingvio_ctx* c, Uploader& up, int b0, int nb, const ingvio_msckf_
     });
     for (int i = 0; i < nb; ++i) c->h_nclones[b0 + i] = fr[i].n_clones;
     if (whole) {
-        up.copy(reinterpret_cast<char*>(c->d_clone_idx), up.slab->p + slab0, up.off - slab0);
+        // the image up to the measurements of the last filter's last feature (what lies behind is not read by any kernel)
+        const size_t used = (size_t)(reinterpret_cast<char*>(uv) - (up.slab->p + slab0)) + 8 * ((size_t)(nb - 1) * fm + (size_t)fr[nb - 1].n_feat) * cm * 4;
+        up.copy(reinterpret_cast<char*>(c->d_clone_idx), up.slab->p + slab0, std::max(used, (size_t)64));
         *fmax_used = fmx;
         return 0;
     }
