@@ -101,6 +101,7 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
     int* sUse = reinterpret_cast<int*>(smem_raw + ((sizeof(GBBatch) + 15) / 16) * 16);
     int* sList = sUse + fv.fmax;
     __shared__ int sNu;
+    __shared__ unsigned long long sAmask;
     const int bl = blockIdx.y, b = b0 + bl, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int F = fv.n_feat[b], C = fv.n_clones[b], ncol = 6 * C;
     double* Sg = Sg_all + ((size_t)bl * G + g) * (size_t)CMAX * CMAX * GB_SW;
@@ -117,10 +118,6 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
         if (g == 0) used_out[(size_t)b * fv.fmax + j] = use;
     }
     for (int e = tid; e < KR * LDW; e += GB_NT) { (&sb.Bm[0][0])[e] = 0.0; (&sb.Ym[0][0])[e] = 0.0; }
-    for (int e = tid; e < C * C * GB_SW; e += GB_NT) {          // only the (slot, anchor) pairs of this window
-        const int q = e / GB_SW, v = e - q * GB_SW, c = q / C, a2 = q - c * C;
-        Sg[((size_t)c * CMAX + a2) * GB_SW + v] = 0.0;
-    }
     __syncthreads();
     if (wave == 0) {                                            // ordered list of the used features
         int cnt = 0;
@@ -136,6 +133,23 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
     __syncthreads();
     const int nu = sNu, per = (nu + G - 1) / G;
     const int q0 = g * per, q1 = min(nu, q0 + per);
+    // The anchors of THIS chunk's features (round 5): the sparse sums Sg[slot][anchor] are touched for those anchor columns only.  A
+    // single real-time filter loses a handful of tracks per frame - one feature per chunk - and used to zero all C x C pairs here
+    // (198 KB of stores at 27 clones) and to walk all of them again in the epilogue: 25 k + 53 k of the kernel's 120 k cycles.
+    if (wave == 0) {
+        unsigned long long m = 0ULL;
+        for (int q = q0 + lane; q < q1; q += WAVE) m |= 1ULL << (int)rec_in[((size_t)b * fv.fmax + sList[q]) * REC + 1];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m |= __shfl_xor(m, off, WAVE);
+        if (lane == 0) sAmask = m;
+    }
+    __syncthreads();
+    const unsigned long long amask = sAmask;
+    for (int e = tid; e < C * C * GB_SW; e += GB_NT) {          // only the (slot, anchor) pairs of this window whose anchor occurs
+        const int q = e / GB_SW, v = e - q * GB_SW, c = q / C, a2 = q - c * C;
+        if ((amask >> a2) & 1ULL) Sg[((size_t)c * CMAX + a2) * GB_SW + v] = 0.0;
+    }
+    __syncthreads();
 
     int tiA[TPW], tjA[TPW];
 #pragma unroll
@@ -335,13 +349,14 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
         }
         double sum = 0.0;
         const int iaq = ia >= 0 ? ia : 0;
-        for (int a0 = 0; a0 < C; a0 += 12) {                                               // 24 independent loads per pass, added in order
+        const bool c_anchor = (amask >> c) & 1ULL;                                          // Sg[.][c] exists only then
+        for (int a0 = 0; a0 < C; a0 += 12) {                                               // up to 24 independent loads per pass, added in order
             double x[12], y[12];
 #pragma unroll
             for (int u = 0; u < 12; ++u) {
                 const int a = min(a0 + u, C - 1);
-                x[u] = Sg[((size_t)c * CMAX + a) * GB_SW + is];                            // obs at slot c, anchor a
-                y[u] = Sg[((size_t)a * CMAX + c) * GB_SW + iaq];                           // obs at slot a, anchor c
+                x[u] = ((amask >> a) & 1ULL) ? Sg[((size_t)c * CMAX + a) * GB_SW + is] : 0.0;      // obs at slot c, anchor a
+                y[u] = c_anchor ? Sg[((size_t)a * CMAX + c) * GB_SW + iaq] : 0.0;                   // obs at slot a, anchor c
             }
 #pragma unroll
             for (int u = 0; u < 12; ++u) if (a0 + u < C) sum += ss * x[u] + sa * y[u];
@@ -352,6 +367,8 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
     for (int q = tid; q < C * C; q += GB_NT) {
         const int c = q / C, c2 = q - c * C;
         if (c == c2) continue;
+        const bool hasS = (amask >> c2) & 1ULL, hasSt = (amask >> c) & 1ULL;      // obs at slot c with anchor c2 / at slot c2 with anchor c
+        if (!hasS && !hasSt) continue;                                      // neither exists: the block keeps its rank-3 part
         double blk[36];                                                     // the rank-3 part already in `out`: all loads in flight together
 #pragma unroll
         for (int m = 0; m < 6; ++m)
@@ -361,7 +378,10 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
         const double* St = Sg + ((size_t)c2 * CMAX + c) * GB_SW;            // obs at slot c2, anchor c
         double s1[9], st1[9], s2[9], st2[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) { s1[i] = S[i]; st1[i] = St[i]; s2[i] = S[9 + i]; st2[i] = St[9 + i]; }
+        for (int i = 0; i < 9; ++i) {
+            s1[i] = hasS ? S[i] : 0.0; s2[i] = hasS ? S[9 + i] : 0.0;
+            st1[i] = hasSt ? St[i] : 0.0; st2[i] = hasSt ? St[9 + i] : 0.0;
+        }
 #pragma unroll
         for (int m = 0; m < 3; ++m)
 #pragma unroll

@@ -4,9 +4,10 @@ sys.path.insert(0, "/root/repo")
 import bench
 from ingvio_amd import capi, synth
 B, F, C = int(sys.argv[1]) if len(sys.argv) > 1 else 1, 300, 30
+FF = int(sys.argv[2]) if len(sys.argv) > 2 else F            # features per frame (the context keeps f_max = 300)
 N = 21 + 6 + 600 + 180
 ctx = capi.Context(batch=B, n_max=((N + 15) // 16) * 16, c_max=C, f_max=F, m_max=64)
-filters, steps, frames, infos = bench.build_batch(ctx, B, 0, F, C, 6, 200)
+filters, steps, frames, infos = bench.build_batch(ctx, B, 0, FF, C, 6, 200)
 ctx.snapshot(); pr = synth.PARAMS
 ctx.frame_stage(0, steps, frames, filters[0].sigma(), 1, pr["sigma_cb"], pr["sigma_rw"])
 for _ in range(3):
