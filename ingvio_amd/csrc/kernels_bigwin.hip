@@ -129,27 +129,36 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
             cnt += __popcll(m);
         }
         if (lane == 0) sNu = cnt;
-    }
-    __syncthreads();
-    const int nu = sNu, per = (nu + G - 1) / G;
-    const int q0 = g * per, q1 = min(nu, q0 + per);
-    // The anchors of THIS chunk's features (round 5): the sparse sums Sg[slot][anchor] are touched for those anchor columns only.  A
-    // single real-time filter loses a handful of tracks per frame - one feature per chunk - and used to zero all C x C pairs here
-    // (198 KB of stores at 27 clones) and to walk all of them again in the epilogue: 25 k + 53 k of the kernel's 120 k cycles.
-    if (wave == 0) {
+        // The anchors of THIS chunk's features (round 5): the sparse sums Sg[slot][anchor] are touched for those anchor columns only.
+        // A single real-time filter loses a handful of tracks per frame - one feature per chunk - and used to zero all C x C pairs here
+        // (198 KB of stores at 27 clones) and to walk all of them again in the epilogue: 25 k + 53 k of the kernel's 120 k cycles.
+        __builtin_amdgcn_wave_barrier();                        // this wave's own sList entries
+        const int per0 = (cnt + G - 1) / G, qa = g * per0, qb = min(cnt, qa + per0);
         unsigned long long m = 0ULL;
-        for (int q = q0 + lane; q < q1; q += WAVE) m |= 1ULL << (int)rec_in[((size_t)b * fv.fmax + sList[q]) * REC + 1];
+        for (int q = qa + lane; q < qb; q += WAVE) m |= 1ULL << (int)rec_in[((size_t)b * fv.fmax + sList[q]) * REC + 1];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) m |= __shfl_xor(m, off, WAVE);
         if (lane == 0) sAmask = m;
     }
     __syncthreads();
+    const int nu = sNu, per = (nu + G - 1) / G;
+    const int q0 = g * per, q1 = min(nu, q0 + per);
     const unsigned long long amask = sAmask;
-    for (int e = tid; e < C * C * GB_SW; e += GB_NT) {          // only the (slot, anchor) pairs of this window whose anchor occurs
-        const int q = e / GB_SW, v = e - q * GB_SW, c = q / C, a2 = q - c * C;
-        if ((amask >> a2) & 1ULL) Sg[((size_t)c * CMAX + a2) * GB_SW + v] = 0.0;
+    // zeroed by the thread that later adds into the same addresses (slot c, values part + 8 j: the read-modify-write of the batch loop):
+    // a thread sees its own stores in order, so no workgroup barrier has to wait for them here; every other reader of Sg sits behind
+    // the __syncthreads at the end of the batch loop
+    if (tid < CMAX * 8) {
+        const int c = tid >> 3, part = tid & 7;
+        if (c < C) {
+            for (unsigned long long rest = amask; rest; rest &= rest - 1ULL) {
+                const int a2 = __ffsll((long long)rest) - 1;
+                if (a2 >= C) break;
+                double* S = Sg + ((size_t)c * CMAX + a2) * GB_SW;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) { const int v = part + 8 * j; if (v < GB_SW) S[v] = 0.0; }
+            }
+        }
     }
-    __syncthreads();
 
     int tiA[TPW], tjA[TPW];
 #pragma unroll
