@@ -102,7 +102,10 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
     int* sList = sUse + fv.fmax;
     __shared__ int sNu;
     __shared__ unsigned long long sAmask;
-    const int bl = blockIdx.y, b = b0 + bl, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // wave as a SCALAR (round 5): the tile coordinates (tiA, tjA) of a wave's 14 accumulators are wave-uniform; as vector values their
+    // 28 LDS offsets were spilled and every MFMA of the batch loop waited for a scratch reload (s_waitcnt vmcnt(0), i.e. also for the
+    // record prefetch issued just before): 18.5 k of a batch's 31 k cycles for 2.7 k cycles of matrix work
+    const int bl = blockIdx.y, b = b0 + bl, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int F = fv.n_feat[b], C = fv.n_clones[b], ncol = 6 * C;
     double* Sg = Sg_all + ((size_t)bl * G + g) * (size_t)CMAX * CMAX * GB_SW;
 
@@ -173,12 +176,17 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
     const int kq = lane >> 4, l15 = lane & 15;
 
     double pre[PRE];
+    // The next batch's records.  UNCONDITIONAL loads from clamped indices (round 5): as `cond ? rec_in[..] : 0.0` every one of the five
+    // loads sat in its own exec-masked block behind an s_waitcnt vmcnt(0) - five dependent memory trips per batch, and the MFMA loop
+    // behind them (its accumulators' scratch reloads wait on the same counter): 18.5 k of a batch's 31 k cycles.  Entries past the
+    // batch's features are never read (the staging store and the operand phase are bounded by nbf).
     auto fetch = [&](int qb) {
-        const int nbf = min(GB_NB, q1 - qb);
+        if (nu == 0) return;                                    // uniform: nothing listed, nothing to address
 #pragma unroll
         for (int u = 0; u < PRE; ++u) {
-            const int e = tid + u * GB_NT, f = e / REC, w = e - f * REC;
-            pre[u] = (qb < q1 && e < nbf * REC) ? rec_in[((size_t)b * fv.fmax + sList[qb + f]) * REC + w] : 0.0;
+            const int e = tid + u * GB_NT, f = min(e / REC, GB_NB - 1), w = e - (e / REC) * REC;
+            const int qi = min(qb + f, nu - 1);
+            pre[u] = rec_in[((size_t)b * fv.fmax + sList[qi]) * REC + w];
         }
     };
     fetch(q0);
@@ -191,6 +199,7 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
             for (int e = tid; e < (KR - 3 * nbf) * LDW; e += GB_NT) { (&sb.Bm[3 * nbf][0])[e] = 0.0; (&sb.Ym[3 * nbf][0])[e] = 0.0; }
         }
         lds_barrier();
+        if (qb == q0 + 2 * GB_NB) dbg_stamp(53);
         // operand rows B, Y = Ns^-1 B and the sparse scratch, lane = (feature, window slot)
         if (tid < nbf * WAVE) {
             const int f = tid >> 6, c = tid & 63;
@@ -246,22 +255,25 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
             }
         }
         lds_barrier();
+        if (qb == q0 + 2 * GB_NB) dbg_stamp(54);
         fetch(qb + GB_NB);
         const int nst = (3 * nbf + 3) >> 2;
 #pragma unroll
         for (int st = 0; st < KR / 4; ++st) {
             if (st < nst) {
+                // (all 28 operand fragments of a step read first and the products after them: 144 against 131 us per launch - the
+                // fragments' 56 registers push the accumulators into scratch; padding the panels' row stride against bank conflicts: no change)
 #pragma unroll
                 for (int u = 0; u < TPW; ++u) {
                     if (wave + NW * u < NUP) {
-                        const int ti = tiA[u], tj = tjA[u];
-                        const double af = sb.Ym[4 * st + kq][16 * ti + l15];
-                        const double bf = sb.Bm[4 * st + kq][16 * tj + l15];
+                        const double af = sb.Ym[4 * st + kq][16 * tiA[u] + l15];
+                        const double bf = sb.Bm[4 * st + kq][16 * tjA[u] + l15];
                         acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[u], 0, 0, 0);
                     }
                 }
             }
         }
+        if (qb == q0 + 2 * GB_NB) dbg_stamp(55);
         // sparse sums: slot c is always handled by the same 8 threads (part = which of the 33 values), features in order
         // The batch's contributions are first merged by anchor (later features into the earlier one with the same key, in feature
         // order), then ALL read-modify-writes of the batch are issued together: one memory trip per batch instead of a dependent

@@ -122,7 +122,8 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
     int* sList = sUse + fv.fmax;
     __shared__ int sNu;
     __shared__ double sPose[16][12];                              // the window's clone poses: R (9, row-major), p (3)
-    const int bl = blockIdx.y, b = b0 + bl, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // wave as a scalar: the tile coordinates of a wave's accumulators are wave-uniform (see k_feat_gram_big)
+    const int bl = blockIdx.y, b = b0 + bl, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int F = fv.n_feat[b], C = fv.n_clones[b], ncol = 6 * C;
     for (int e = tid; e < 12 * C; e += GRAM_NT) {
         const int c = e / 12, q = e - 12 * c;
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     // of rows at that offset run at 2.6 TB/s against 4.9 TB/s aligned (tools/micro/hbm_mix.hip).  The READS are the misaligned side now.
     const int n = cv.n[b], ld = cv.ldp;
     const int no = fused ? n - msize : n, nt = (no + 15) >> 4;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;      // (wave as a scalar, readfirstlane: 130 -> 141 us per launch - left a vector value)
     if (2 * part * 4 >= nt) return;                           // whole workgroup idle (uniform)
     const int pw = part * 4 + wave;                           // this wave owns tile rows pw and nt-1-pw: nt+1 tiles, balanced
     const bool wave_on = 2 * pw < nt;

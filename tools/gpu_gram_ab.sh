@@ -1,0 +1,10 @@
+cd /root/repo
+for rep in 1 2; do for v in g1 g2 g3 g4; do
+INGVIO_HIP_LIB=/root/repo/build_var/$v/libingvio_hip.so python bench.py --config 5 --no-cpu --no-aux --no-latency --detail gpurun_out/gab_$v.json 2>/dev/null | tail -1 > gpurun_out/gab_line_$v.json
+python - $v <<'PY'
+import json, sys
+v = sys.argv[1]
+d = json.load(open("gpurun_out/gab_line_%s.json" % v)); k = json.load(open("gpurun_out/gab_%s.json" % v))["kernels"]
+print(v, "ms/step", round(d["ms_per_step"], 4), "gram us", round(1e3 * k["k_feat_gram2"]["avg_ms"], 1), "gate us", round(1e3 * k["k_feat_gate3"]["avg_ms"], 1))
+PY
+done; done

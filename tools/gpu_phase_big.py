@@ -14,6 +14,8 @@ for _ in range(3):
     ctx.frame_run(restore_prior=True)
 d = ctx.debug_read(56)
 print("gram_big [prologue, batch loop, rank-3 epilogue, sparse epilogue]", [d[i + 1] - d[i] for i in range(48, 52)], "total", d[52] - d[48])
+d2 = ctx.debug_read(64)
+print("gram_big batch 2 [operand phase (P2) + barrier, MFMA, sparse read-modify-write + barrier -> end of the loop is stamp 50]", [d2[54] - d2[53], d2[55] - d2[54]])
 import os
 if os.environ.get("INGVIO_DBG_TU") == "b":
     print("gate4_big [front, barrier, pair blocks, tile fill, LDL + gate]", [d[i + 1] - d[i] for i in range(5, 10)], "total", d[10] - d[5])
