@@ -262,7 +262,8 @@ __global__ __launch_bounds__(GB_NT, 1) void k_feat_gram_big(
         for (int st = 0; st < KR / 4; ++st) {
             if (st < nst) {
                 // (all 28 operand fragments of a step read first and the products after them: 144 against 131 us per launch - the
-                // fragments' 56 registers push the accumulators into scratch; padding the panels' row stride against bank conflicts: no change)
+                // fragments' 56 registers push the accumulators into scratch; in groups of 2 or 4 tiles: 146; padding the panels' row
+                // stride against bank conflicts: no change)
 #pragma unroll
                 for (int u = 0; u < TPW; ++u) {
                     if (wave + NW * u < NUP) {

@@ -1,5 +1,5 @@
 cd /root/repo
-for rep in 1 2; do for v in g1 g2 g3 g4; do
+for rep in 1 2; do for v in gg0 gg2 gg4; do
 INGVIO_HIP_LIB=/root/repo/build_var/$v/libingvio_hip.so python bench.py --config 5 --no-cpu --no-aux --no-latency --detail gpurun_out/gab_$v.json 2>/dev/null | tail -1 > gpurun_out/gab_line_$v.json
 python - $v <<'PY'
 import json, sys
