@@ -11,7 +11,7 @@ process) that runs the parity tests covering it.  One toggle per case:
   INGVIO_APPLY_TW=2        k_info_apply with two tile columns per step
   INGVIO_LM_FRONT=split    landmark update with k_lm_build + k_lm_products (compacting) instead of the fused front
   INGVIO_LM_SOLVE=sweep    landmark / dense-H update on the Cholesky sweep out of L2 instead of the register-resident solve
-  INGVIO_FEW=off           few filters (B <= 32) on the kernels of a full batch: chunk partials added inside the solve, k_info_apply
+  INGVIO_FEW=off           few filters (up to 64 per launch) on the kernels of a full batch: chunk partials added inside the solve, k_info_apply
                            (the product sums them with k_chunk_sum first and applies with one wave per tile, k_apply_*_flat)
 """
 import os
@@ -72,7 +72,7 @@ np.savez(sys.argv[1], P=np.stack([np.asarray(ctx.cov_get(b)) for b in range(B)])
 
 @pytest.mark.parametrize("B", [1, 3])
 def test_few_filter_path_is_bit_identical_to_the_full_batch_kernels(tmp_path, B):
-    """k_chunk_sum + k_apply_T_flat / k_apply_sym_flat (what B <= 32 filters take) form the same sums and products in the same order as
+    """k_chunk_sum + k_apply_T_flat / k_apply_sym_flat (what launches of up to 64 filters take) form the same sums and products in the same order as
     the chunk loop of k_info_solve and k_info_apply: posterior, dx and accept masks of a whole frame (N = 249, 150 features, fused
     marginalisation) are equal to the last bit."""
     if not os.path.exists(ALT_LIB):

@@ -1,3 +1,7 @@
+#!/bin/bash
+# Where the one-wave-per-tile apply stops paying: config-2 bench at 64 / 128 / 256 filters with the product library (threshold 64) and
+# with a variant whose threshold is 256.  Build the variant first:  bash tools/build_variant.sh flat256 -DINGVIO_APPLY_FLAT_NB=256
+# usage (GPU box): bash tools/gpu_flat_sweep.sh
 cd /root/repo
 python -m pytest tests/test_gpu_alternatives.py -x -q -m gpu -k "few or FEW" 2>&1 | tail -3
 for B in 64 128 256; do
