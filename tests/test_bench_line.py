@@ -21,7 +21,8 @@ def canned():
                as_written=dict(heavy_ms=0.9, heavy_min_ms=0.8, heavy_frames=5, heavy_accepted=20, heavy_rows=740, other_ms=0.31, all_ms=0.32,
                                frames=50, final_pos_err_m=0.015), stream="feats=150,clones=11,life=10,cohort=1,frames=75,key=1",
                oracle_1thread_update_ms=13.8)
-    full["latency_b1_ms"] = dict(config2=lat, config5=copy.deepcopy(lat))
+    full["latency_b1_ms"] = dict(config2=lat, config5=copy.deepcopy(lat),
+                                 staggered=dict(kf21=dict(median_ms=0.3, frames=50, stream="feats=100,clones=21"), kf27=dict(error="timeout")))
     return full
 
 
@@ -45,6 +46,7 @@ def test_compact_line_fits_and_has_the_contract_keys():
     for v in d["aux_configs"].values():
         assert set(v) == {"value", "ms_per_step", "workload", "roofline_kernel", "roofline_frac", "max_rel_cov_err", "accept_mask_equal"}
     assert d["latency_b1_ms"]["config2"]["lifted"]["heavy_ms"] == 1.234
+    assert d["latency_b1_ms"]["staggered_median_ms"] == dict(kf21=0.3, kf27="timeout") and "staggered" not in d["latency_b1_ms"]
     assert "kernels" not in d and "as_written_cap20" not in d
     # round 5: the hand-over figures ride on the line as four numbers, the notes stay in the detail file
     assert set(d["host_handover"]) == {"serial_updates_per_s", "pipelined_updates_per_s", "stagers8_aggregate_updates_per_s", "stagers8_host_threads"}
