@@ -25,7 +25,7 @@ EXPORTS = [
     "ingvio_cov_set", "ingvio_cov_get", "ingvio_get_n", "ingvio_cov_get_marginal", "ingvio_cov_snapshot",
     "ingvio_cov_restore", "ingvio_propagate", "ingvio_propagate_fused", "ingvio_augment_clone", "ingvio_marginalize",
     "ingvio_append_independent", "ingvio_ekf_update", "ingvio_chi2_gamma", "ingvio_msckf_update", "ingvio_msckf_update_tri", "ingvio_qr_compress",
-    "ingvio_frame_stage", "ingvio_frame_stage_async", "ingvio_frame_run", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_select",
+    "ingvio_frame_stage", "ingvio_frame_stage_async", "ingvio_frame_run", "ingvio_set_frame_parts", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_select",
     "ingvio_profile_reset",
     "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_set_qr_method", "ingvio_landmark_stage", "ingvio_landmark_run",
     "ingvio_landmark_fetch", "ingvio_frame_run_phase", "ingvio_info_set", "ingvio_debug_read", "ingvio_triangulate",
@@ -630,6 +630,10 @@ class Context:
 
     def frame_run(self, restore_prior=False):
         self._chk(self.L.ingvio_frame_run(self.h, 1 if restore_prior else 0))
+
+    def set_frame_parts(self, parts):
+        """-1 automatic, 1 off, 2..4: slices of the batch that ingvio_frame_run runs on their own streams (ingvio_set_frame_parts)"""
+        self._chk(self.L.ingvio_set_frame_parts(self.h, int(parts)))
 
     def frame_fetch(self, b0=0, nb=None):
         nb = self.batch if nb is None else nb

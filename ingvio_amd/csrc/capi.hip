@@ -164,6 +164,21 @@ struct ingvio_ctx {
     struct PinSlab { char* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; };
     PinSlab pin[4];
     int pin_next = 0;
+    // Split frame step (round 6): ingvio_frame_run deals the batch to `parts` slices, each with its own stream and
+    // its own chain restore -> propagate -> gate -> Gram -> solve -> apply.  The gates are chained by events (slice p's gate starts
+    // when slice p - 1's has ended; slice 0's when the LAST slice's of the previous step has), so the slices run half a step apart:
+    // the HBM-bound kernels of one slice (apply, propagate, restore) sit under the FP64-bound ones of the other (gate, Gram).
+    // The slices' streams are NOT joined at the end of the call - consecutive steps pipeline; every other entry point that touches
+    // the context joins them first (join_parts, called through enter()).
+    struct PartStream { hipStream_t st = nullptr; hipEvent_t ev_gate = nullptr, ev_apply = nullptr, ev_done = nullptr; };
+    PartStream part[4];
+    int parts_alloc = 0;
+    int parts_req = -1;                 // ingvio_set_frame_parts: -1 automatic, 1 off, 2..4 forced
+    bool split_pending = false;         // slices of the last split step may still be running on their own streams
+    hipEvent_t tok_last = nullptr;      // end of the throughput segment issued last (nullptr: none yet / chain broken)
+    hipEvent_t ev_split_fork = nullptr;
+    hipStream_t run_st = nullptr;       // the stream run_msckf_factored and ProfScope issue on (c->st except inside a split step)
+    hipEvent_t tok_wait = nullptr, tok_rec = nullptr;      // run_msckf_factored: wait before / record after its throughput segment (phase 1: gate + Gram, phase 2: apply)
     // profiling
     bool prof;
     std::vector<ProfRec> recs;
@@ -211,11 +226,11 @@ struct ProfScope {
     ingvio_ctx* c; int id; hipEvent_t a, b; bool on;
     ProfScope(ingvio_ctx* c_, int id_) : c(c_), id(id_), on(c_->prof && (c_->prof_only < 0 || c_->prof_only == id_))
     {
-        if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->st); }
+        if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->run_st); }
     }
     ~ProfScope()
     {
-        if (on) { hipEventRecord(b, c->st); c->recs.push_back({ id, a, b }); }
+        if (on) { hipEventRecord(b, c->run_st); c->recs.push_back({ id, a, b }); }
     }
 };
 
@@ -253,6 +268,35 @@ int down_sync(ingvio_ctx* c, void* dst, const void* src, size_t bytes)
 int last_launch(ingvio_ctx* c)
 {
     HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// Split frame step: the compute stream waits for the slices' streams (a device-side wait, the host does not block).  Called by every
+// entry point other than ingvio_frame_run itself before it touches the context.
+int join_parts(ingvio_ctx* c)
+{
+    if (!c->split_pending) return 0;
+    for (int p = 0; p < c->parts_alloc; ++p) HIPCHK(c, hipStreamWaitEvent(c->st, c->part[p].ev_done, 0));
+    c->split_pending = false;
+    if (c->alt_ready) {                            // the input set the slices read may be refilled once they are done with it
+        HIPCHK(c, hipEventRecord(c->ev_free[c->set_id], c->st));
+        c->free_valid[c->set_id] = true;
+    }
+    return 0;
+}
+#define ENTER(c) do { if ((c) && (c)->split_pending && join_parts(c)) return INGVIO_E_HIP; } while (0)
+
+int parts_prepare(ingvio_ctx* c, int P)
+{
+    while (c->parts_alloc < P) {
+        auto& q = c->part[c->parts_alloc];
+        HIPCHK(c, hipStreamCreateWithFlags(&q.st, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&q.ev_gate, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&q.ev_apply, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&q.ev_done, hipEventDisableTiming));
+        ++c->parts_alloc;
+    }
+    if (!c->ev_split_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_split_fork, hipEventDisableTiming));
     return 0;
 }
 
@@ -563,7 +607,7 @@ static int gnss_in_frame_launch(ingvio_ctx* c, int b0, int nb, FactoredLaunch& L
     const size_t mld = c->mld, hs = mld * GNSS_NCW, ws = (size_t)c->ldp * 16;
     L.gcolmap = g.colmap + (size_t)b0 * GNSS_NCW; L.gnc = g.nc + b0; L.gcstride = GNSS_NCW;
     L.gW = g.W + (size_t)b0 * ws; L.gWstride = ws;
-    { ProfScope p(c, PF_POSTCOLS); L.stage = 4; launch_factored(L, c->st); }
+    { ProfScope p(c, PF_POSTCOLS); L.stage = 4; launch_factored(L, c->run_st); }
     EkfLaunch E;
     memset(&E, 0, sizeof E);
     E.cv = L.cv; E.b0 = b0; E.nb = nb; E.H = c->d_H + (size_t)b0 * hs; E.res = c->d_res + (size_t)b0 * mld;
@@ -577,9 +621,9 @@ static int gnss_in_frame_launch(ingvio_ctx* c, int b0, int nb, FactoredLaunch& L
                    g.nc + b0, (int)hs, GNSS_NCW };
     {
         ProfScope p(c, PF_ROWGATE);
-        if (launch_rows_gate(E, in, g.thr1, g.gamma + (size_t)b0 * mld, g.keep + (size_t)b0 * mld, c->st)) return INGVIO_E_CAPACITY;
+        if (launch_rows_gate(E, in, g.thr1, g.gamma + (size_t)b0 * mld, g.keep + (size_t)b0 * mld, c->run_st)) return INGVIO_E_CAPACITY;
     }
-    { ProfScope p(c, PF_EKF_CORE); launch_ekf_core(E, c->st); }
+    { ProfScope p(c, PF_EKF_CORE); launch_ekf_core(E, c->run_st); }
     L.gY = E.Y; L.gYstride = ws; L.gm = g.mf + b0;
     g.fused_last = true;
     g.results = true;
@@ -624,13 +668,15 @@ int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int s
     // not start (one filter, 27 clones: gate at +53 us after the frame's upload instead of +30).
     bool forked = false;
     if (big && phase == 0 && c->st2) {
-        if (!c->fork_recorded) HIPCHK(c, hipEventRecord(c->ev_fork, c->st));      // after everything that wrote P on the main stream
+        if (!c->fork_recorded) HIPCHK(c, hipEventRecord(c->ev_fork, c->run_st));      // after everything that wrote P on the main stream
         c->fork_recorded = false;
         forked = true;
     }
     if (phase != 2) {
-        { ProfScope p(c, PF_GATE2); L.stage = 0; if (launch_factored(L, c->st)) return INGVIO_E_UNSUPPORTED; }
-        { ProfScope p(c, PF_GRAM); L.stage = 1; launch_factored(L, c->st); }
+        if (c->tok_wait) HIPCHK(c, hipStreamWaitEvent(c->run_st, c->tok_wait, 0));      // split frame step: one throughput segment at a time
+        { ProfScope p(c, PF_GATE2); L.stage = 0; if (launch_factored(L, c->run_st)) return INGVIO_E_UNSUPPORTED; }
+        { ProfScope p(c, PF_GRAM); L.stage = 1; launch_factored(L, c->run_st); }
+        if (c->tok_rec) HIPCHK(c, hipEventRecord(c->tok_rec, c->run_st));
     }
     if (forked) {
         HIPCHK(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
@@ -638,11 +684,13 @@ int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int s
         HIPCHK(c, hipEventRecord(c->ev_join, c->st2));
     }
     if (phase == 1) return last_launch(c);
-    if (forked) HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_join, 0));
-    else if (big) { ProfScope p(c, PF_INFO); L.stage = 5; launch_factored(L, c->st); }      // split step / no side stream: in line
-    { ProfScope p(c, PF_INFO); L.stage = 2; launch_factored(L, c->st); }
+    if (forked) HIPCHK(c, hipStreamWaitEvent(c->run_st, c->ev_join, 0));
+    else if (big) { ProfScope p(c, PF_INFO); L.stage = 5; launch_factored(L, c->run_st); }      // split step / no side stream: in line
+    { ProfScope p(c, PF_INFO); L.stage = 2; launch_factored(L, c->run_st); }
     if (gnss_fuse) { if (int rc = gnss_in_frame_launch(c, b0, nb, L)) return rc; }
-    { ProfScope p(c, PF_APPLY); L.stage = 3; launch_factored(L, c->st); }
+    if (phase == 2 && c->tok_wait) HIPCHK(c, hipStreamWaitEvent(c->run_st, c->tok_wait, 0));
+    { ProfScope p(c, PF_APPLY); L.stage = 3; launch_factored(L, c->run_st); }
+    if (phase == 2 && c->tok_rec) HIPCHK(c, hipEventRecord(c->tok_rec, c->run_st));
     return last_launch(c);
 }
 
@@ -704,6 +752,8 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     if (c->own_stream) {
         if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) { delete c; return INGVIO_E_HIP; }
     } else c->st = (hipStream_t)desc->stream;
+    c->run_st = c->st;
+    if (const char* e = getenv("INGVIO_FRAME_PARTS")) c->parts_req = atoi(e);
     if (desc->c_max > 16) {
         // a higher priority than the compute stream's default: its short dependent launches take the slots the gate's workgroups free
         int lo = 0, hi = 0;
@@ -811,6 +861,7 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
 int ingvio_ctx_destroy(ingvio_ctx* c)
 {
     if (!c) return INGVIO_E_ARG;
+    for (int p = 0; p < c->parts_alloc; ++p) hipStreamSynchronize(c->part[p].st);
     hipStreamSynchronize(c->st);
     void* ptrs[] = { c->Pbase, c->Psnap, c->d_cur, c->d_n, c->d_n_snap, c->d_Phi, c->d_G, c->d_dt, c->d_R, c->d_blk, c->d_gnss,
                      c->d_idx, c->d_frame_slab[0], c->d_frame_slab[1],
@@ -836,6 +887,8 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
         for (auto e : c->ev_free) if (e) hipEventDestroy(e);
     }
     for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (int p = 0; p < c->parts_alloc; ++p) { hipStreamDestroy(c->part[p].st); hipEventDestroy(c->part[p].ev_gate); hipEventDestroy(c->part[p].ev_apply); hipEventDestroy(c->part[p].ev_done); }
+    if (c->ev_split_fork) hipEventDestroy(c->ev_split_fork);
     if (c->st2) hipStreamDestroy(c->st2);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
@@ -846,12 +899,17 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
 
 int ingvio_sync(ingvio_ctx* c)
 {
+    ENTER(c);
     if (!c) return INGVIO_E_ARG;
     HIPCHK(c, hipStreamSynchronize(c->st));
     HIPCHK(c, hipGetLastError());
     return INGVIO_OK;
 }
-void* ingvio_ctx_stream(ingvio_ctx* c) { return c ? (void*)c->st : nullptr; }
+void* ingvio_ctx_stream(ingvio_ctx* c)
+{
+    if (c && c->split_pending) join_parts(c);      // the caller orders its own work behind this stream
+    return c ? (void*)c->st : nullptr;
+}
 const char* ingvio_last_error(ingvio_ctx* c) { return c ? c->err.c_str() : "null context"; }
 int ingvio_ldp(ingvio_ctx* c) { return c ? c->ldp : 0; }
 int ingvio_f_max(ingvio_ctx* c) { return c ? c->d.f_max : 0; }
@@ -859,6 +917,7 @@ int ingvio_c_max(ingvio_ctx* c) { return c ? c->d.c_max : 0; }
 
 int ingvio_cov_set(ingvio_ctx* c, int b, const double* P, int ld, int n)
 {
+    ENTER(c);
     if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b, 1) || !P || n < 0 || n > c->d.n_max || ld < n) return INGVIO_E_ARG;
     double* dst = c->Pbase + ((size_t)c->h_cur[b] * c->d.batch + b) * c->pp;
@@ -871,6 +930,7 @@ int ingvio_cov_set(ingvio_ctx* c, int b, const double* P, int ld, int n)
 
 int ingvio_cov_get(ingvio_ctx* c, int b, double* P, int ld)
 {
+    ENTER(c);
     if (check_range(c, b, 1) || !P) return INGVIO_E_ARG;
     const int n = c->h_n[b];
     if (ld < n) return INGVIO_E_ARG;
@@ -883,6 +943,7 @@ int ingvio_cov_get(ingvio_ctx* c, int b, double* P, int ld)
 
 int ingvio_get_n(ingvio_ctx* c, int b, int* n)
 {
+    ENTER(c);
     if (check_range(c, b, 1) || !n) return INGVIO_E_ARG;
     *n = c->h_n[b];
     return INGVIO_OK;
@@ -890,6 +951,7 @@ int ingvio_get_n(ingvio_ctx* c, int b, int* n)
 
 int ingvio_cov_get_marginal(ingvio_ctx* c, int b, const int* vidx, const int* vsize, int k, double* out)
 {
+    ENTER(c);
     if (check_range(c, b, 1) || !vidx || !vsize || !out || k < 1) return INGVIO_E_ARG;
     const int n = c->h_n[b];
     std::vector<double> P((size_t)n * n);
@@ -912,6 +974,7 @@ int ingvio_cov_get_marginal(ingvio_ctx* c, int b, const int* vidx, const int* vs
 
 int ingvio_cov_snapshot(ingvio_ctx* c)
 {
+    ENTER(c);
     if (phase_busy(c)) return INGVIO_E_ARG;
     if (!c) return INGVIO_E_ARG;
     launch_snapshot(view(c), c->d.n_max, c->Psnap, c->d_n_snap, c->st);
@@ -922,9 +985,10 @@ int ingvio_cov_snapshot(ingvio_ctx* c)
 
 int ingvio_cov_restore(ingvio_ctx* c)
 {
+    ENTER(c);
     if (!c || !c->has_snap) return INGVIO_E_ARG;
     c->phase_pending = false;                      // the way out of an abandoned split step: every filter returns to the snapshot
-    launch_restore(view(c), c->d.n_max, c->Psnap, c->d_n_snap, c->st);
+    launch_restore(view(c), 0, c->d.batch, c->d.n_max, c->Psnap, c->d_n_snap, c->st);
     c->h_n = c->h_n_snap;
     std::fill(c->h_cur.begin(), c->h_cur.end(), 0);
     return last_launch(c);
@@ -933,6 +997,7 @@ int ingvio_cov_restore(ingvio_ctx* c)
 int ingvio_propagate_fused(ingvio_ctx* c, int b0, int nb, int k, const double* Phi, const double* G, const double* dt,
                            const double sigma[4], int enable_gnss, const int* gnss_idx, double scb, double srw)
 {
+    ENTER(c);
     if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || k < 1 || k > KMAX || !Phi || !G || !dt || !sigma) return INGVIO_E_ARG;
     for (int i = 0; i < nb; ++i) if (c->h_n[b0 + i] < 15) return INGVIO_E_ARG;
@@ -970,11 +1035,13 @@ int ingvio_propagate_fused(ingvio_ctx* c, int b0, int nb, int k, const double* P
 int ingvio_propagate(ingvio_ctx* c, int b0, int nb, const double* Phi, const double* G, const double* dt,
                      const double sigma[4], int enable_gnss, const int* gnss_idx, double scb, double srw)
 {
+    ENTER(c);
     return ingvio_propagate_fused(c, b0, nb, 1, Phi, G, dt, sigma, enable_gnss, gnss_idx, scb, srw);
 }
 
 int ingvio_augment_clone(ingvio_ctx* c, int b0, int nb, const double* R, int* new_idx)
 {
+    ENTER(c);
     if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || !R) return INGVIO_E_ARG;
     for (int i = 0; i < nb; ++i) {
@@ -994,6 +1061,7 @@ int ingvio_augment_clone(ingvio_ctx* c, int b0, int nb, const double* R, int* ne
 
 int ingvio_marginalize(ingvio_ctx* c, int b0, int nb, const int* idx, int size)
 {
+    ENTER(c);
     if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || !idx || size < 1) return INGVIO_E_ARG;
     for (int i = 0; i < nb; ++i)
@@ -1011,6 +1079,7 @@ int ingvio_marginalize(ingvio_ctx* c, int b0, int nb, const int* idx, int size)
 
 int ingvio_append_independent(ingvio_ctx* c, int b0, int nb, int size, const double* blk, int* new_idx)
 {
+    ENTER(c);
     if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || !blk || size < 1 || size > 6) return INGVIO_E_ARG;
     for (int i = 0; i < nb; ++i) if (c->h_n[b0 + i] + size > c->d.n_max) return INGVIO_E_CAPACITY;
@@ -1095,6 +1164,7 @@ static int stage_generic(ingvio_ctx* c, int b, const int* vidx, const int* vsize
 int ingvio_ekf_update(ingvio_ctx* c, int b, const int* vidx, const int* vsize, int k, const double* H, int ldh, int m,
                       const double* res, const double* R, int r_kind, double* dx_out)
 {
+    ENTER(c);
     if (phase_busy(c)) return INGVIO_E_ARG;
     int nc = 0;
     if (c && vsize && k >= 1) {                                     // S beyond LDS / rows beyond m_max: the dense route
@@ -1130,6 +1200,7 @@ int ingvio_ekf_update(ingvio_ctx* c, int b, const int* vidx, const int* vsize, i
 // (INGVIO_OK / INGVIO_NEG_DIAG per filter, may be NULL).
 int ingvio_ekf_update_batch(ingvio_ctx* c, int b0, int nb, const ingvio_update_block* blk, int r_kind, double* dx_out, int* status_out)
 {
+    ENTER(c);
     if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || !blk) return INGVIO_E_ARG;
     if (r_kind != INGVIO_R_SCALAR && r_kind != INGVIO_R_DIAG) return INGVIO_E_UNSUPPORTED;
@@ -1268,6 +1339,7 @@ static int gnss_alloc(ingvio_ctx* c)
 
 int ingvio_gnss_stage(ingvio_ctx* c, int b0, int nb, const ingvio_update_block* blk, const ingvio_gnss_opts* o)
 {
+    ENTER(c);
     if (check_range(c, b0, nb) || !blk || !o) return INGVIO_E_ARG;
     if ((o->gate_rows || o->strong_reject) && (!o->chi2_table || o->chi2_len < 2 || o->chi2_len > CHI2_CAP)) return INGVIO_E_ARG;
     auto& g = c->gn;
@@ -1351,6 +1423,7 @@ static int gnss_run_separate(ingvio_ctx* c, int b0, int nb, bool own_slots = fal
 // raw GNSS epochs -> candidate rows, on the device (kernels_gnss.hip)
 int ingvio_gnss_front_stage(ingvio_ctx* c, int b0, int nb, const ingvio_gnss_epoch* ep, const ingvio_gnss_opts* o)
 {
+    ENTER(c);
     static_assert(GNSS_FRONT_NCW == GNSS_NCW, "column stride of the staged rows");
     if (check_range(c, b0, nb) || !ep || !o) return INGVIO_E_ARG;
     if ((o->gate_rows || o->strong_reject) && (!o->chi2_table || o->chi2_len < 2 || o->chi2_len > CHI2_CAP)) return INGVIO_E_ARG;
@@ -1433,6 +1506,7 @@ int ingvio_gnss_front_stage(ingvio_ctx* c, int b0, int nb, const ingvio_gnss_epo
 // iterate on.  One launch for all epochs, temporary device buffers, nothing of the context's state is touched.
 int ingvio_gnss_sat_eval(ingvio_ctx* c, int n_epochs, const ingvio_gnss_epoch* ep, double* out)
 {
+    ENTER(c);
     if (!c || n_epochs < 1 || !ep || !out) return INGVIO_E_ARG;
     const size_t S = INGVIO_GNSS_MAX_SAT;
     for (int i = 0; i < n_epochs; ++i) {
@@ -1485,6 +1559,7 @@ int ingvio_gnss_sat_eval(ingvio_ctx* c, int n_epochs, const ingvio_gnss_epoch* e
 
 int ingvio_gnss_front_fetch(ingvio_ctx* c, int b0, int nb, double* out)
 {
+    ENTER(c);
     if (check_range(c, b0, nb) || !out || !c->gn.front) return INGVIO_E_ARG;
     if (down_sync(c, out, c->gn.front + (size_t)b0 * 64 * GF_N, 8 * (size_t)nb * 64 * GF_N)) return INGVIO_E_HIP;
     return last_launch(c);
@@ -1492,6 +1567,7 @@ int ingvio_gnss_front_fetch(ingvio_ctx* c, int b0, int nb, double* out)
 
 int ingvio_gnss_run(ingvio_ctx* c, int b0, int nb)
 {
+    ENTER(c);
     if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || !c->gn.staged) return INGVIO_E_ARG;
     if (c->gn.in_frame) { c->err = "the staged GNSS update is in-frame: ingvio_frame_run applies it"; return INGVIO_E_ARG; }
@@ -1542,6 +1618,7 @@ static int gnss_run_separate(ingvio_ctx* c, int b0, int nb, bool own_slots)
 
 int ingvio_gnss_fetch(ingvio_ctx* c, int b0, int nb, double* dx_out, int* rows_out, int* keep_out, double* gamma_out, int* status_out)
 {
+    ENTER(c);
     if (check_range(c, b0, nb)) return INGVIO_E_ARG;
     if (!c->gn.results) { c->err = "ingvio_gnss_fetch: no GNSS update has run on the staged rows (an in-frame stage is applied by ingvio_frame_run)"; return INGVIO_E_ARG; }
     const size_t mld = c->mld;
@@ -1566,6 +1643,7 @@ int ingvio_gnss_fetch(ingvio_ctx* c, int b0, int nb, double* dx_out, int* rows_o
 int ingvio_gnss_update_batch(ingvio_ctx* c, int b0, int nb, const ingvio_update_block* blk, const ingvio_gnss_opts* o, double* dx_out,
                              int* rows_out, int* keep_out, int* status_out)
 {
+    ENTER(c);
     if (phase_busy(c)) return INGVIO_E_ARG;
     int rc = ingvio_gnss_stage(c, b0, nb, blk, o);
     if (rc) return rc;
@@ -1579,6 +1657,7 @@ int ingvio_mld(ingvio_ctx* c) { return c ? c->mld : 0; }
 int ingvio_chi2_gamma(ingvio_ctx* c, int b, const int* vidx, const int* vsize, int k, const double* H, int ldh, int m,
                       const double* res, const double* R, int r_kind, double* gamma)
 {
+    ENTER(c);
     if (!gamma) return INGVIO_E_ARG;
     int nc = 0;
     int rc = stage_generic(c, b, vidx, vsize, k, H, ldh, m, res, R, r_kind, &nc);
@@ -1594,6 +1673,7 @@ int ingvio_chi2_gamma(ingvio_ctx* c, int b, const int* vidx, const int* vsize, i
 // LandmarkUpdate.cpp:98-99; the per-row GNSS gates, GnssUpdate.cpp:190,259): gamma_out[g] for block g, R = noise_var * I.
 int ingvio_chi2_gamma_multi(ingvio_ctx* c, int b, int nblk, const ingvio_gate_block* blk, double noise_var, double* gamma_out)
 {
+    ENTER(c);
     if (check_range(c, b, 1) || nblk < 0 || (nblk && (!blk || !gamma_out))) return INGVIO_E_ARG;
     if (nblk == 0) return INGVIO_OK;
     size_t nd = 1, ni = 0, lds = 0;                         // doubles (slot 0 = noise), ints
@@ -1736,6 +1816,7 @@ static int msckf_update_impl(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_f
 int ingvio_msckf_update(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* frames, const ingvio_msckf_opts* opts,
                         double* dx_out, int* accepted, double* gamma, int* rows_out)
 {
+    ENTER(c);
     return msckf_update_impl(c, b0, nb, frames, opts, nullptr, nullptr, dx_out, accepted, gamma, rows_out, nullptr, nullptr);
 }
 
@@ -1743,6 +1824,7 @@ int ingvio_msckf_update_tri(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_fr
                             const ingvio_tri_opts* tri, const unsigned long long* const* tri_masks, double* dx_out, int* accepted,
                             double* gamma, int* rows_out, double* pf_out, int* tri_ok)
 {
+    ENTER(c);
     if (!tri) return INGVIO_E_ARG;
     return msckf_update_impl(c, b0, nb, frames, opts, tri, tri_masks, dx_out, accepted, gamma, rows_out, pf_out, tri_ok);
 }
@@ -1761,6 +1843,7 @@ static int stage_hnew(ingvio_ctx* c, const double* H_new, int ldn, int m, int s)
 int ingvio_add_variable_delayed_invertible(ingvio_ctx* c, int b, const int* vidx, const int* vsize, int k, const double* H_old, int ldh,
                                            const double* H_new, int ldn, int s, double noise, int* new_idx)
 {
+    ENTER(c);
     if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b, 1)) return INGVIO_E_ARG;
     if (c->h_n[b] + s > c->d.n_max) return INGVIO_E_CAPACITY;
@@ -1783,6 +1866,7 @@ int ingvio_add_variable_delayed(ingvio_ctx* c, int b, const int* vidx, const int
                                 const double* H_new, int ldn, int m, int s, const double* res, double noise, double chi2_mult,
                                 int do_chi2, double chi2_check, double* dx_out, int* added, int* new_idx, double* chi2_out)
 {
+    ENTER(c);
     if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b, 1) || !added) return INGVIO_E_ARG;
     *added = 0;
@@ -1832,6 +1916,7 @@ int ingvio_add_variable_delayed(ingvio_ctx* c, int b, const int* vidx, const int
 
 int ingvio_replace_var_linear(ingvio_ctx* c, int b, int tidx, int tsize, const int* vidx, const int* vsize, int k, const double* H, int ldh)
 {
+    ENTER(c);
     if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b, 1) || tsize < 1 || tsize > 6) return INGVIO_E_ARG;
     if (tidx < 0 || tidx + tsize > c->h_n[b]) return INGVIO_E_NOT_IN_STATE;       // "Target var not in state" (:653-657)
@@ -1850,6 +1935,7 @@ int ingvio_replace_var_linear(ingvio_ctx* c, int b, int tidx, int tsize, const i
 int ingvio_triangulate(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_frame* frames, const ingvio_tri_opts* o,
                        double* pf_out, int* ok_out)
 {
+    ENTER(c);
     if (check_range(c, b0, nb) || !o) return INGVIO_E_ARG;
     if (o->outer_loop_max_iter < 0 || o->inner_loop_max_iter < 0) return INGVIO_E_ARG;
     int fmx = c->d.f_max;
@@ -2000,6 +2086,7 @@ static int landmark_update_launch(ingvio_ctx* c, int b0, int nb, const int* marg
 
 int ingvio_landmark_stage(ingvio_ctx* c, int b0, int nb, const ingvio_landmark_frame* fr, const ingvio_landmark_opts* o)
 {
+    ENTER(c);
     if (check_range(c, b0, nb) || !fr || !o || !(o->noise > 0.0)) return INGVIO_E_ARG;
     auto& s = c->lm;
     int l_hi = 0;
@@ -2081,6 +2168,7 @@ static int landmark_in_state(ingvio_ctx* c, int b0, int nb, const std::vector<in
 
 int ingvio_landmark_run(ingvio_ctx* c, int b0, int nb)
 {
+    ENTER(c);
     if (phase_busy(c)) return INGVIO_E_ARG;
     if (check_range(c, b0, nb) || !c->lm.staged) return INGVIO_E_ARG;
     if (int rc = landmark_in_state(c, b0, nb, c->h_n, 0)) return rc;
@@ -2090,6 +2178,7 @@ int ingvio_landmark_run(ingvio_ctx* c, int b0, int nb)
 
 int ingvio_landmark_fetch(ingvio_ctx* c, int b0, int nb, double* dx, int* rows, int* accept, double* gamma, int* status)
 {
+    ENTER(c);
     if (check_range(c, b0, nb) || !c->lm.alloc) return INGVIO_E_ARG;
     if (dx) HIPCHK(c, hipMemcpyAsync(dx, c->lm.dx + (size_t)b0 * c->ldp, 8 * (size_t)nb * c->ldp, hipMemcpyDeviceToHost, c->st));
     if (rows) HIPCHK(c, hipMemcpyAsync(rows, c->dw.m + b0, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, c->st));
@@ -2103,6 +2192,7 @@ int ingvio_landmark_fetch(ingvio_ctx* c, int b0, int nb, double* dx, int* rows, 
 
 int ingvio_set_qr_method(ingvio_ctx* c, int method)
 {
+    ENTER(c);
     if (!c || method < 0 || method > 2) return INGVIO_E_ARG;
     c->qr_method = method;
     return INGVIO_OK;
@@ -2110,6 +2200,7 @@ int ingvio_set_qr_method(ingvio_ctx* c, int method)
 
 int ingvio_qr_compress(ingvio_ctx* c, const double* H, int ldh, int m, int n, const double* res, double* Ht, int ldt, double* rt)
 {
+    ENTER(c);
     if (!c || !H || !res || !Ht || !rt || m < 1 || n < 1 || ldh < m || ldt < n) return INGVIO_E_ARG;
     // Every shape takes the blocked Householder QR of kernels_qr.hip (device buffers and the launch graph cached per shape): no
     // per-call allocation and no use of any filter's staging buffers - a drop-in for six SPQR call sites must not touch batch state.
@@ -2259,13 +2350,92 @@ static int frame_stage_impl(ingvio_ctx* c, int b0, int nb, const ingvio_frame_st
 int ingvio_frame_stage(ingvio_ctx* c, int b0, int nb, const ingvio_frame_step* steps, const ingvio_msckf_frame* frames,
                        const ingvio_msckf_opts* opts, const double sigma[4], int enable_gnss, double scb, double srw)
 {
+    ENTER(c);
     return frame_stage_impl(c, b0, nb, steps, frames, opts, sigma, enable_gnss, scb, srw, false);
 }
 
 int ingvio_frame_stage_async(ingvio_ctx* c, int b0, int nb, const ingvio_frame_step* steps, const ingvio_msckf_frame* frames,
                              const ingvio_msckf_opts* opts, const double sigma[4], int enable_gnss, double scb, double srw)
 {
+    ENTER(c);
     return frame_stage_impl(c, b0, nb, steps, frames, opts, sigma, enable_gnss, scb, srw, true);
+}
+
+// The fused frame step of windows up to 16 clones with the batch dealt to P slices.  Slice p = filters [p B / P, (p + 1) B / P) rounded
+// to multiples of 8 (the kernels' XCD-aware block order works on groups of 8 filters), on stream part[p].st:
+//     restore -> propagate + clone -> [wait: gate of slice p - 1] gate [record] -> Gram -> solve -> (GNSS in-frame) -> apply + marginalise
+// Same kernels, same arguments per filter as the unsplit step: results are bit-identical (tests/test_gpu_parity.py runs both).
+#ifndef SPLIT_AUTO_MIN_BATCH
+#define SPLIT_AUTO_MIN_BATCH 128
+#endif
+static int frame_run_split(ingvio_ctx* c, int restore_prior, int P, bool gnss_fuse)
+{
+    const int B = c->d.batch;
+    if (parts_prepare(c, P)) return INGVIO_E_HIP;
+    if (c->split_pending && c->copy_pending) ENTER(c);                     // fresh inputs on the copy stream: order them through c->st
+    if (wait_inputs(c)) return INGVIO_E_HIP;
+    if (!c->split_pending) {                                                // work on c->st since the last split step: the slices start behind it
+        HIPCHK(c, hipEventRecord(c->ev_split_fork, c->st));
+        for (int p = 0; p < P; ++p) HIPCHK(c, hipStreamWaitEvent(c->part[p].st, c->ev_split_fork, 0));
+        c->tok_last = nullptr;
+    }
+    const bool strips = restore_prior && c->strip_ok && c->mut_seq == c->strip_seq;
+    if (restore_prior) { c->h_n = c->h_n_snap; std::fill(c->h_cur.begin(), c->h_cur.end(), 0); }
+    for (int b = 0; b < B; ++b) c->h_n[b] += 6;
+    const int k = c->st_k;
+    int rc = 0;
+    auto range = [&](int p, int& b0, int& nb) {
+        b0 = (int)((long long)B * p / P) & ~7;
+        const int b1 = p + 1 == P ? B : ((int)((long long)B * (p + 1) / P) & ~7);
+        nb = b1 - b0;
+    };
+    // Issue order = order of the throughput segments on the device: gate + Gram of every slice, then the apply of every slice; a
+    // segment waits for the one issued before it (whatever stream that was on) - the slices' latency-bound kernels (restore, propagate,
+    // solve, the flips) run freely in between, under the other slices' segments
+    for (int p = 0; p < P && !rc; ++p) {
+        int b0, nb; range(p, b0, nb);
+        if (nb <= 0) continue;
+        auto& q = c->part[p];
+        c->run_st = q.st;
+        if (restore_prior) {
+            ProfScope pr(c, PF_RESTORE);
+            if (strips) launch_restore_strips(view(c), b0, nb, c->d.n_max, c->Psnap, c->d_n_snap, c->st_enable_gnss ? c->d_gnss : nullptr, q.st);
+            else launch_restore(view(c), b0, nb, c->d.n_max, c->Psnap, c->d_n_snap, q.st);
+        }
+        {
+            ProfScope pr(c, PF_PROPAGATE);
+            launch_propagate(view(c), b0, nb, c->d.n_max, c->d_Phi + (size_t)b0 * k * 225, c->d_G + (size_t)b0 * k * 180, c->d_dt + (size_t)b0 * k, k,
+                             c->st_enable_gnss ? c->d_gnss + (size_t)b0 * 5 : nullptr, c->st_sigma, c->st_enable_gnss, c->st_scb, c->st_srw, q.st,
+                             c->d_R + (size_t)b0 * 9, c->d_status);
+        }
+        c->tok_wait = c->tok_last; c->tok_rec = q.ev_gate;
+        rc = run_msckf_factored(c, b0, nb, c->st_op, c->st_stereo, c->st_fmax_used, c->d_idx + b0, 6, 1, gnss_fuse);
+        c->tok_last = rc ? nullptr : q.ev_gate;
+    }
+    for (int p = 0; p < P && !rc; ++p) {
+        int b0, nb; range(p, b0, nb);
+        if (nb <= 0) continue;
+        auto& q = c->part[p];
+        c->run_st = q.st;
+        c->tok_wait = c->tok_last; c->tok_rec = q.ev_apply;
+        rc = run_msckf_factored(c, b0, nb, c->st_op, c->st_stereo, c->st_fmax_used, c->d_idx + b0, 6, 2, gnss_fuse);
+        c->tok_last = rc ? nullptr : q.ev_apply;
+        if (!rc) {
+            ProfScope pr(c, PF_MARG);
+            launch_post_marg(view(c), b0, nb, c->d_idx + b0, 6, q.st);
+        }
+    }
+    for (int p = 0; p < P; ++p) hipEventRecord(c->part[p].ev_done, c->part[p].st);
+    c->tok_wait = nullptr; c->tok_rec = nullptr;
+    c->run_st = c->st;
+    c->split_pending = true;
+    if (rc) { c->tok_last = nullptr; ENTER(c); return rc; }
+    bool all_marg = true;
+    for (int b = 0; b < B; ++b) { if (c->st_marg[b] >= 0) { c->h_n[b] -= 6; c->h_cur[b] ^= 1; } else all_marg = false; }
+    c->strip_ok = all_marg && restore_prior;
+    c->strip_seq = c->mut_seq;
+    if (c->gn.staged && c->gn.in_frame && !restore_prior) c->gn.staged = false;
+    return INGVIO_OK;
 }
 
 static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
@@ -2318,12 +2488,24 @@ static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
         }
         if (c->lm.staged && c->lm.in_frame) { if (int rc = landmark_in_state(c, 0, B, n0, 6)) return rc; }
     }
+    // ---- split step (round 6): the batch as `parts` slices on their own streams, gates chained, nothing joined at the end ----
+    {
+        const bool with_lm0 = c->lm.staged && c->lm.in_frame;
+        const bool gnss0 = c->gn.staged && c->gn.in_frame && c->gn.m_cap > 0;
+        bool gfuse0 = gnss0 && c->d.c_max <= 16 && c->gn.m_cap <= 16 && c->gn.nc_max <= 16;
+        for (int b = 0; b < B && gfuse0; ++b) if (c->st_marg[b] < 0 || c->gn.hi[b] > c->st_marg[b]) gfuse0 = false;
+        int P = c->parts_req >= 0 ? c->parts_req : (B >= SPLIT_AUTO_MIN_BATCH ? 2 : 1);
+        if (P > 4) P = 4;
+        if (phase == 0 && P > 1 && c->method == 1 && !with_lm0 && c->d.c_max <= 16 && (!gnss0 || gfuse0) && B >= 16 * P)
+            return frame_run_split(c, restore_prior, P, gfuse0);
+    }
+    ENTER(c);
     if (wait_inputs(c)) return INGVIO_E_HIP;
     if (restore_prior) {
         ProfScope p(c, PF_RESTORE);
         const bool strips = c->strip_ok && c->mut_seq == c->strip_seq;
-        if (strips) launch_restore_strips(view(c), c->d.n_max, c->Psnap, c->d_n_snap, c->st_enable_gnss ? c->d_gnss : nullptr, c->st);
-        else launch_restore(view(c), c->d.n_max, c->Psnap, c->d_n_snap, c->st);
+        if (strips) launch_restore_strips(view(c), 0, B, c->d.n_max, c->Psnap, c->d_n_snap, c->st_enable_gnss ? c->d_gnss : nullptr, c->st);
+        else launch_restore(view(c), 0, B, c->d.n_max, c->Psnap, c->d_n_snap, c->st);
         c->h_n = c->h_n_snap;
         std::fill(c->h_cur.begin(), c->h_cur.end(), 0);
     }
@@ -2398,6 +2580,13 @@ static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
 }
 
 int ingvio_frame_run(ingvio_ctx* c, int restore_prior) { return frame_run_impl(c, restore_prior, 0); }
+int ingvio_set_frame_parts(ingvio_ctx* c, int parts)
+{
+    if (!c || parts < -1 || parts > 4) return INGVIO_E_ARG;
+    ENTER(c);
+    c->parts_req = parts == 0 ? 1 : parts;
+    return INGVIO_OK;
+}
 int ingvio_frame_run_phase(ingvio_ctx* c, int restore_prior, int phase)
 {
     if (phase < 0 || phase > 2) return INGVIO_E_ARG;
@@ -2408,6 +2597,7 @@ int ingvio_frame_run_phase(ingvio_ctx* c, int restore_prior, int phase)
 // single filter: every rank sums the ranks' partials and continues with ingvio_frame_run_phase(.., 2))
 int ingvio_info_set(ingvio_ctx* c, int b, const double* A, int ncol, int n_accepted)
 {
+    ENTER(c);
     if (check_range(c, b, 1) || !A || ncol < 6 || (size_t)ncol * (ncol + 1) > (size_t)c->rstride || n_accepted < 0) return INGVIO_E_ARG;
     std::vector<int> used(c->G, 0);
     used[0] = n_accepted;
@@ -2445,6 +2635,7 @@ __global__ __launch_bounds__(256) void k_info_commit(const double* __restrict__ 
 
 int ingvio_info_reduce(ingvio_ctx* c, int b, double** dev_ptr, int* count, int* ncol_out)
 {
+    ENTER(c);
     if (check_range(c, b, 1) || !dev_ptr || !count || c->method != 1) return INGVIO_E_ARG;
     int C = 0;
     if (down_sync(c, &C, c->d_nclones + b, sizeof(int))) return INGVIO_E_HIP;
@@ -2462,6 +2653,7 @@ int ingvio_info_reduce(ingvio_ctx* c, int b, double** dev_ptr, int* count, int* 
 
 int ingvio_info_commit(ingvio_ctx* c, int b)
 {
+    ENTER(c);
     if (check_range(c, b, 1) || !c->d_xchg || c->method != 1) return INGVIO_E_ARG;
     int C = 0;
     if (down_sync(c, &C, c->d_nclones + b, sizeof(int))) return INGVIO_E_HIP;
@@ -2474,6 +2666,7 @@ int ingvio_info_commit(ingvio_ctx* c, int b)
 
 int ingvio_frame_fetch(ingvio_ctx* c, int b0, int nb, double* dx_out, int* accepted, int* rows_out)
 {
+    ENTER(c);
     if (check_range(c, b0, nb)) return INGVIO_E_ARG;
     const int fm = c->d.f_max;
     if (dx_out) HIPCHK(c, hipMemcpyAsync(dx_out, c->d_dx + (size_t)b0 * c->ldp, 8 * (size_t)nb * c->ldp, hipMemcpyDeviceToHost, c->st));
@@ -2485,6 +2678,7 @@ int ingvio_frame_fetch(ingvio_ctx* c, int b0, int nb, double* dx_out, int* accep
 
 int ingvio_set_msckf_method(ingvio_ctx* c, int method)
 {
+    ENTER(c);
     if (!c || method < 0 || method > 1) return INGVIO_E_ARG;
     c->method = method;
     return INGVIO_OK;
@@ -2493,6 +2687,7 @@ int ingvio_set_msckf_method(ingvio_ctx* c, int method)
 // parity hook: [A | b] = [sum_j H_j^T H_j | sum_j H_j^T r_j] of the last MSCKF update of filter b, ncol x (ncol + 1) row-major
 int ingvio_debug_msckf_info(ingvio_ctx* c, int b, double* A_out, int* ncol_out)
 {
+    ENTER(c);
     if (check_range(c, b, 1) || !A_out || !ncol_out) return INGVIO_E_ARG;
     int C = 0;
     if (down_sync(c, &C, c->d_nclones + b, sizeof(int))) return INGVIO_E_HIP;
@@ -2534,6 +2729,7 @@ int ingvio_debug_msckf_info(ingvio_ctx* c, int b, double* A_out, int* ncol_out)
 // parity hook: [M | t] handed from the information solve to the apply kernel (MP x MP row-major, then MP entries), filter b
 int ingvio_debug_info_solution(ingvio_ctx* c, int b, double* out, int count)
 {
+    ENTER(c);
     if (check_range(c, b, 1) || !out || count < 1 || count > c->ystride) return INGVIO_E_ARG;
     if (down_sync(c, out, c->d_Y + (size_t)b * c->ystride, 8 * (size_t)count)) return INGVIO_E_HIP;
     return INGVIO_OK;
@@ -2541,6 +2737,7 @@ int ingvio_debug_info_solution(ingvio_ctx* c, int b, double* out, int count)
 
 int ingvio_debug_read(ingvio_ctx* c, long long* out, int n)
 {
+    ENTER(c);
     if (!c || !out || n < 1 || n > 64) return INGVIO_E_ARG;
     HIPCHK(c, hipStreamSynchronize(c->st));
     long long a[64], bq[64], cq[64], sq[64];
@@ -2561,6 +2758,7 @@ int ingvio_debug_read(ingvio_ctx* c, long long* out, int n)
 
 int ingvio_profile_select(ingvio_ctx* c, const char* kernel_name)
 {
+    ENTER(c);
     if (!c) return INGVIO_E_ARG;
     c->prof_only = -1;
     if (!kernel_name || !*kernel_name) return INGVIO_OK;
@@ -2570,6 +2768,7 @@ int ingvio_profile_select(ingvio_ctx* c, const char* kernel_name)
 
 int ingvio_profile_enable(ingvio_ctx* c, int enable)
 {
+    ENTER(c);
     if (!c) return INGVIO_E_ARG;
     c->prof = enable != 0;
     return INGVIO_OK;
@@ -2588,6 +2787,7 @@ static void prof_collect(ingvio_ctx* c)
 
 int ingvio_profile_reset(ingvio_ctx* c)
 {
+    ENTER(c);
     if (!c) return INGVIO_E_ARG;
     prof_collect(c);
     memset(c->prof_ms, 0, sizeof c->prof_ms); memset(c->prof_calls, 0, sizeof c->prof_calls);
@@ -2596,6 +2796,7 @@ int ingvio_profile_reset(ingvio_ctx* c)
 
 int ingvio_profile_get(ingvio_ctx* c, const char** names, double* ms, int* calls, int cap)
 {
+    ENTER(c);
     if (!c || !names || !ms || !calls) return INGVIO_E_ARG;
     prof_collect(c);
     int k = 0;

@@ -508,9 +508,9 @@ __global__ __launch_bounds__(256) void k_snapshot(CovView cv, double* __restrict
     }
     if (blockIdx.x == 0 && tid == 0) n_snap[b] = n;
 }
-__global__ __launch_bounds__(256) void k_restore(CovView cv, const double* __restrict__ snap, const int* __restrict__ n_snap)
+__global__ __launch_bounds__(256) void k_restore(CovView cv, int b0, const double* __restrict__ snap, const int* __restrict__ n_snap)
 {
-    const int b = blockIdx.y, tid = threadIdx.x, n = n_snap[b], ld = cv.ldp;
+    const int b = b0 + blockIdx.y, tid = threadIdx.x, n = n_snap[b], ld = cv.ldp;
     const double* src = snap + (size_t)b * cv.pstride;
     double* dst = cv.Pbase + (size_t)b * cv.pstride;          // half 0
     for (int jj = 0; jj < MARG_COLS; ++jj) {
@@ -522,10 +522,10 @@ __global__ __launch_bounds__(256) void k_restore(CovView cv, const double* __res
 // Partial restore after a fused frame step (propagate + clone + out-of-place update/marginalise): half 0 still holds
 // the snapshot except for the rows/columns of the propagation's active set A = {0..14} + clock states (the six clone
 // rows/cols lie beyond n_snap).  grid = (ceil(n_cap/256), B), thread = row/column index.
-__global__ __launch_bounds__(256) void k_restore_strips(CovView cv, const double* __restrict__ snap, const int* __restrict__ n_snap,
+__global__ __launch_bounds__(256) void k_restore_strips(CovView cv, int b0, const double* __restrict__ snap, const int* __restrict__ n_snap,
                                                         const int* __restrict__ gnss_idx)
 {
-    const int b = blockIdx.y, n = n_snap[b], ld = cv.ldp;
+    const int b = b0 + blockIdx.y, n = n_snap[b], ld = cv.ldp;
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r == 0) { cv.cur[b] = 0; cv.n[b] = n; }           // nothing in this kernel reads cur / n
     if (r >= n) return;
@@ -546,10 +546,10 @@ __global__ __launch_bounds__(256) void k_restore_strips(CovView cv, const double
 #pragma unroll
     for (int a = 0; a < NA_MAX; ++a) if (a < na) dst[A[a] + (size_t)r * ld] = w[a];
 }
-__global__ void k_post_restore(CovView cv, const int* __restrict__ n_snap)
+__global__ void k_post_restore(CovView cv, int b0, int nb, const int* __restrict__ n_snap)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < cv.B) { cv.cur[b] = 0; cv.n[b] = n_snap[b]; }
+    const int bl = blockIdx.x * blockDim.x + threadIdx.x, b = b0 + bl;
+    if (bl < nb) { cv.cur[b] = 0; cv.n[b] = n_snap[b]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -605,14 +605,14 @@ void launch_snapshot(CovView cv, int n_cap, double* snap, int* n_snap, hipStream
 {
     hipLaunchKernelGGL(k_snapshot, dim3((n_cap + MARG_COLS - 1) / MARG_COLS, cv.B), dim3(256), 0, st, cv, snap, n_snap);
 }
-void launch_restore_strips(CovView cv, int n_cap, const double* snap, const int* n_snap, const int* gnss_idx, hipStream_t st)
+void launch_restore_strips(CovView cv, int b0, int nb, int n_cap, const double* snap, const int* n_snap, const int* gnss_idx, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_restore_strips, dim3((n_cap + 255) / 256, cv.B), dim3(256), 0, st, cv, snap, n_snap, gnss_idx);
+    hipLaunchKernelGGL(k_restore_strips, dim3((n_cap + 255) / 256, nb), dim3(256), 0, st, cv, b0, snap, n_snap, gnss_idx);
 }
-void launch_restore(CovView cv, int n_cap, const double* snap, const int* n_snap, hipStream_t st)
+void launch_restore(CovView cv, int b0, int nb, int n_cap, const double* snap, const int* n_snap, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_restore, dim3((n_cap + MARG_COLS - 1) / MARG_COLS, cv.B), dim3(256), 0, st, cv, snap, n_snap);
-    hipLaunchKernelGGL(k_post_restore, dim3((cv.B + 255) / 256), dim3(256), 0, st, cv, n_snap);
+    hipLaunchKernelGGL(k_restore, dim3((n_cap + MARG_COLS - 1) / MARG_COLS, nb), dim3(256), 0, st, cv, b0, snap, n_snap);
+    hipLaunchKernelGGL(k_post_restore, dim3((nb + 255) / 256), dim3(256), 0, st, cv, b0, nb, n_snap);
 }
 
 int dbg_read_cov(long long* out, int n) { return dbg_read_local(out, n); }

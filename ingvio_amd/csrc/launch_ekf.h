@@ -59,6 +59,6 @@ void launch_append(CovView cv, int b0, int nb, int size, const double* blk, hipS
 void launch_copy_ints(int* dst, const int* src, int count, hipStream_t st);
 void launch_upload_words(void* dst, const void* src_pinned, size_t bytes, hipStream_t st);      // bytes % 4 == 0; src: hipHostMalloc memory
 void launch_snapshot(CovView cv, int n_cap, double* snap, int* n_snap, hipStream_t st);
-void launch_restore_strips(CovView cv, int n_cap, const double* snap, const int* n_snap, const int* gnss_idx, hipStream_t st);
-void launch_restore(CovView cv, int n_cap, const double* snap, const int* n_snap, hipStream_t st);
+void launch_restore_strips(CovView cv, int b0, int nb, int n_cap, const double* snap, const int* n_snap, const int* gnss_idx, hipStream_t st);      // filters [b0, b0 + nb)
+void launch_restore(CovView cv, int b0, int nb, int n_cap, const double* snap, const int* n_snap, hipStream_t st);
 int dbg_read_cov(long long* out, int n);

@@ -19,7 +19,9 @@ sys.path.insert(0, ROOT)
 TOOL = os.path.join(ROOT, "ingvio_amd", "lib", "ingvio_replay")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 STREAMS = ["kf11", "kf11_lifted", "sw11", "kf21", "sw21", "kf11_mono", "sw11_mono",      # mono: the MONO callback (BASELINE configs[0])
-           "sw11_gnss", "kf11_gnss"]                                                       # raw GNSS epochs in the callback (BASELINE configs[2])
+           "sw11_gnss", "kf11_gnss",                                                       # raw GNSS epochs in the callback (BASELINE configs[2])
+           "kf27", "kf35_mono"]      # the windows and parameter values the reference SHIPS (config/sportsfield/ingvio_stereo.yaml / ingvio_mono.yaml)
+SHIPPED = ("kf27", "kf35_mono")      # visual_noise 0.18: the synthetic +0.5 outliers mostly pass the gate there - pinned as they come
 POSE_TOL = 1e-9
 COV_TOL = 1e-6
 
@@ -144,13 +146,15 @@ def test_golden_streams_cover_the_policies():
     for name in STREAMS:
         tr, spec, ov = load_golden(name)
         assert len(tr) >= 60
+        if name in SHIPPED:
+            assert ("frame_select_interval: %d" % (18 if name == "kf27" else 28)) in ov and "visual_noise: 0.18" in ov
         lost = sum(len(t["lost_ids"]) for t in tr); lost_acc = sum(int(np.sum(t["lost_acc"])) for t in tr)
         sel = sum(len(t["sel_ids"]) for t in tr); sel_acc = sum(int(np.sum(t["sel_acc"])) for t in tr)
         seen[name] = dict(lost=lost, lost_acc=lost_acc, sel=sel, sel_acc=sel_acc, moved=sum(len(t["anchor_moved"]) for t in tr),
                           erased=sum(len(t["anchor_erased"]) for t in tr), direct=sum(len(t["lost_direct"]) for t in tr),
                           margs=sum(len(t["marg_stamps"]) for t in tr))
         assert lost > 0 and sel > 0 and sel_acc > 0 and seen[name]["margs"] > 0 and seen[name]["direct"] > 0, (name, seen[name])
-        assert lost_acc < lost or sel_acc < sel, name                     # the chi^2 gate (or the cap) refused something
+        assert lost_acc < lost or sel_acc < sel or name in SHIPPED, name  # the chi^2 gate (or the cap) refused something
         key = "key=1" in spec
         per_frame = {len(t["marg_stamps"]) for t in tr}
         assert per_frame == ({0, 2} if key else {0, 1}), (name, per_frame)
@@ -228,6 +232,28 @@ def test_shim_with_a_wrong_frame_select_interval_goes_red():
     got = run_shim(spec, ov, extra=["frame_select_interval: 4"])
     bad, _ = compare(gold, got)
     assert bad and "sel_stamps" in " ".join(bad), bad[:3]
+
+
+@needs_tool
+@pytest.mark.gpu
+def test_shim_with_another_visual_noise_goes_red_on_the_shipped_stereo_stream():
+    """kf27 (sportsfield stereo values) played with the synthetic default visual_noise 0.08 instead of the shipped 0.18: same policy
+    decisions at first, another posterior - the comparison must fail on the state or the covariance."""
+    gold, spec, ov = load_golden("kf27")
+    got = run_shim(spec, ov, extra=["visual_noise: 0.08"])
+    bad, _ = compare(gold, got)
+    assert bad, "the comparison did not notice a different measurement noise"
+
+
+@needs_tool
+@pytest.mark.gpu
+def test_shim_in_sliding_window_mode_goes_red_on_the_shipped_mono_stream():
+    """kf35_mono is key-frame mode as shipped (is_key_frame: 1, two clones chosen by KeyframeUpdate::getMargKfs every other frame); the
+    shim switched to sliding-window mode marginalises the oldest clone every frame instead: red at the marginalised stamps."""
+    gold, spec, ov = load_golden("kf35_mono")
+    got = run_shim(spec, ov, extra=["is_key_frame: 0"])
+    bad, _ = compare(gold, got)
+    assert bad and any(k in " ".join(bad) for k in ("marg_stamps", "sel_stamps", "sel_ids", "table")), bad[:3]
 
 
 @needs_tool
