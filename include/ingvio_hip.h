@@ -431,14 +431,15 @@ int ingvio_frame_stage_async(ingvio_ctx* ctx, int b0, int nb, const ingvio_frame
                              const ingvio_msckf_frame* frames, const ingvio_msckf_opts* opts,
                              const double sigma[4], int enable_gnss, double sigma_cb, double sigma_rw);
 int ingvio_frame_run(ingvio_ctx* ctx, int restore_prior);
-/* Throughput batches (round 6): ingvio_frame_run deals the batch to `parts` slices of filters, each on its own HIP stream, the slices'
- * chi^2 gates chained by events so that the slices run half a step apart - the HBM-bound kernels of one slice (apply + marginalise,
- * propagate) execute under the FP64-bound ones of the other (gate, Gram).  Consecutive ingvio_frame_run calls pipeline (the slices are
- * not joined at the end of the call); every other entry point, ingvio_sync and ingvio_ctx_stream included, first makes the context's
- * stream wait for them.  Per filter the same kernels with the same arguments: results are bit-identical to parts = 1.
- * parts: -1 automatic (2 for batches of 128 filters and more, windows up to 16 clones, no in-frame landmark stage), 1 off, 2..4.
- * The reference has no counterpart (one filter, one thread: IngvioNode.cpp:36); this is SURVEY 8(e)'s independent-filters mode
- * inside one GPU.  Environment override at context creation: INGVIO_FRAME_PARTS. */
+/* Throughput batches (round 6, an experiment kept selectable): ingvio_frame_run deals the batch to `parts` slices of filters, each
+ * on its own HIP stream; the slices' throughput-bound segments (gate + Gram, apply) are chained by events so that only ONE runs at a
+ * time while the other slices' latency-bound kernels (restore, propagate, solve) execute beside it.  Consecutive ingvio_frame_run
+ * calls pipeline (the slices are not joined at the end of the call); every other entry point, ingvio_sync and ingvio_ctx_stream
+ * included, first makes the context's stream wait for them.  Per filter the same kernels with the same arguments: results are
+ * bit-identical to parts = 1 (tests/test_gpu_alternatives.py).  parts: -1 / 0 / 1 off (the default: on MI355X the kernels are each
+ * sized to fill a CU's LDS and registers alone, co-resident kernels halve each other's occupancy and the split loses),
+ * 2..4 slices.  Windows up to 16 clones, factored method, no in-frame landmark stage.  The reference has no counterpart (one filter,
+ * one thread: IngvioNode.cpp:36).  Environment override at context creation: INGVIO_FRAME_PARTS. */
 int ingvio_set_frame_parts(ingvio_ctx* ctx, int parts);
 int ingvio_frame_fetch(ingvio_ctx* ctx, int b0, int nb, double* dx_out, int* accepted, int* rows_out);
 

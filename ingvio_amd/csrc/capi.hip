@@ -300,6 +300,13 @@ int parts_prepare(ingvio_ctx* c, int P)
     return 0;
 }
 
+// INGVIO_RESTORE=pass: ingvio_frame_run(restore_prior) keeps the separate restore pass in front of the propagation (comparison runs)
+static bool no_snap_propagate()
+{
+    static const bool v = [] { const char* e = getenv("INGVIO_RESTORE"); return e && !strcmp(e, "pass"); }();
+    return v;
+}
+
 // ---- pinned staging ------------------------------------------------------------------------------------------------
 struct Uploader {
     ingvio_ctx* c;
@@ -2365,9 +2372,6 @@ int ingvio_frame_stage_async(ingvio_ctx* c, int b0, int nb, const ingvio_frame_s
 // to multiples of 8 (the kernels' XCD-aware block order works on groups of 8 filters), on stream part[p].st:
 //     restore -> propagate + clone -> [wait: gate of slice p - 1] gate [record] -> Gram -> solve -> (GNSS in-frame) -> apply + marginalise
 // Same kernels, same arguments per filter as the unsplit step: results are bit-identical (tests/test_gpu_parity.py runs both).
-#ifndef SPLIT_AUTO_MIN_BATCH
-#define SPLIT_AUTO_MIN_BATCH 128
-#endif
 static int frame_run_split(ingvio_ctx* c, int restore_prior, int P, bool gnss_fuse)
 {
     const int B = c->d.batch;
@@ -2397,7 +2401,8 @@ static int frame_run_split(ingvio_ctx* c, int restore_prior, int P, bool gnss_fu
         if (nb <= 0) continue;
         auto& q = c->part[p];
         c->run_st = q.st;
-        if (restore_prior) {
+        const bool from_snap = strips && propagate_can_restore(c->d.n_max) && !no_snap_propagate();
+        if (restore_prior && !from_snap) {
             ProfScope pr(c, PF_RESTORE);
             if (strips) launch_restore_strips(view(c), b0, nb, c->d.n_max, c->Psnap, c->d_n_snap, c->st_enable_gnss ? c->d_gnss : nullptr, q.st);
             else launch_restore(view(c), b0, nb, c->d.n_max, c->Psnap, c->d_n_snap, q.st);
@@ -2406,7 +2411,7 @@ static int frame_run_split(ingvio_ctx* c, int restore_prior, int P, bool gnss_fu
             ProfScope pr(c, PF_PROPAGATE);
             launch_propagate(view(c), b0, nb, c->d.n_max, c->d_Phi + (size_t)b0 * k * 225, c->d_G + (size_t)b0 * k * 180, c->d_dt + (size_t)b0 * k, k,
                              c->st_enable_gnss ? c->d_gnss + (size_t)b0 * 5 : nullptr, c->st_sigma, c->st_enable_gnss, c->st_scb, c->st_srw, q.st,
-                             c->d_R + (size_t)b0 * 9, c->d_status);
+                             c->d_R + (size_t)b0 * 9, c->d_status, from_snap ? c->Psnap : nullptr, c->d_n_snap);
         }
         c->tok_wait = c->tok_last; c->tok_rec = q.ev_gate;
         rc = run_msckf_factored(c, b0, nb, c->st_op, c->st_stereo, c->st_fmax_used, c->d_idx + b0, 6, 1, gnss_fuse);
@@ -2494,18 +2499,27 @@ static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
         const bool gnss0 = c->gn.staged && c->gn.in_frame && c->gn.m_cap > 0;
         bool gfuse0 = gnss0 && c->d.c_max <= 16 && c->gn.m_cap <= 16 && c->gn.nc_max <= 16;
         for (int b = 0; b < B && gfuse0; ++b) if (c->st_marg[b] < 0 || c->gn.hi[b] > c->st_marg[b]) gfuse0 = false;
-        int P = c->parts_req >= 0 ? c->parts_req : (B >= SPLIT_AUTO_MIN_BATCH ? 2 : 1);
+        // automatic = off: measured on MI355X at 512 filters x (150 features, 11 clones, N = 249) the split LOSES - 0.535 ms unsplit, 0.58
+        // (gates chained) / 0.65 (throughput segments chained) with two slices, 0.73-0.97 with three and four
+        int P = c->parts_req > 0 ? c->parts_req : 1;
         if (P > 4) P = 4;
         if (phase == 0 && P > 1 && c->method == 1 && !with_lm0 && c->d.c_max <= 16 && (!gnss0 || gfuse0) && B >= 16 * P)
             return frame_run_split(c, restore_prior, P, gfuse0);
     }
     ENTER(c);
     if (wait_inputs(c)) return INGVIO_E_HIP;
+    // restore_prior right after a fused frame step that itself began with a restore: half 0 still equals the snapshot outside the
+    // propagation's strips - the propagation then READS the snapshot and writes half 0, no restore pass at all (round 6; before:
+    // k_restore_strips, 23 us and 94 MB per 512 filters)
+    bool from_snap = false;
     if (restore_prior) {
-        ProfScope p(c, PF_RESTORE);
         const bool strips = c->strip_ok && c->mut_seq == c->strip_seq;
-        if (strips) launch_restore_strips(view(c), 0, B, c->d.n_max, c->Psnap, c->d_n_snap, c->st_enable_gnss ? c->d_gnss : nullptr, c->st);
-        else launch_restore(view(c), 0, B, c->d.n_max, c->Psnap, c->d_n_snap, c->st);
+        from_snap = strips && propagate_can_restore(c->d.n_max) && !no_snap_propagate();
+        if (!from_snap) {
+            ProfScope p(c, PF_RESTORE);
+            if (strips) launch_restore_strips(view(c), 0, B, c->d.n_max, c->Psnap, c->d_n_snap, c->st_enable_gnss ? c->d_gnss : nullptr, c->st);
+            else launch_restore(view(c), 0, B, c->d.n_max, c->Psnap, c->d_n_snap, c->st);
+        }
         c->h_n = c->h_n_snap;
         std::fill(c->h_cur.begin(), c->h_cur.end(), 0);
     }
@@ -2513,7 +2527,8 @@ static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
         // one launch: status reset + K1 (k composed IMU steps) + K2 (clone) when a workgroup owns a whole filter
         ProfScope p(c, PF_PROPAGATE);
         launch_propagate(view(c), 0, B, c->d.n_max, c->d_Phi, c->d_G, c->d_dt, c->st_k, c->st_enable_gnss ? c->d_gnss : nullptr,
-                         c->st_sigma, c->st_enable_gnss, c->st_scb, c->st_srw, c->st, c->d_R, c->d_status);
+                         c->st_sigma, c->st_enable_gnss, c->st_scb, c->st_srw, c->st, c->d_R, c->d_status,
+                         from_snap ? c->Psnap : nullptr, c->d_n_snap);
     }
     for (int b = 0; b < B; ++b) c->h_n[b] += 6;
     // factored path: the marginalisation of the oldest clone rides on the update's write-back (k_info_apply

@@ -60,12 +60,19 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
     CovView cv, int b0, const double* __restrict__ Phi, const double* __restrict__ G,
     const double* __restrict__ dts, int k, const int* __restrict__ gnss_idx,
     double sg0, double sg1, double sg2, double sg3, int enable_gnss, double scb, double srw,
-    const double* __restrict__ augR, int* __restrict__ status_clear)
+    const double* __restrict__ augR, int* __restrict__ status_clear, const double* __restrict__ snap, const int* __restrict__ n_snap)
 {
     const int bl = blockIdx.y, b = b0 + bl, tid = threadIdx.x;
     if (status_clear && blockIdx.x == 0 && tid == 0) status_clear[b] = 0;
-    const int n = cv.n[b], ld = cv.ldp;
-    double* P = cov_ptr(cv, b);
+    // snap != nullptr (single-tile launches with the fused clone only): the step starts from the SNAPSHOT of the prior
+    // (ingvio_frame_run(restore_prior) right after a fused frame step: half 0 still equals the snapshot outside the propagation's rows
+    // and columns A, which this kernel rewrites anyway) - everything the propagation reads comes from the snapshot, everything it
+    // writes goes to half 0: the restore pass (k_restore_strips, 23 us per 512 filters) and its traffic are gone (round 6)
+    const int ld = cv.ldp;
+    const int n = snap ? n_snap[b] : cv.n[b];
+    double* P = snap ? cv.Pbase + (size_t)b * cv.pstride : cov_ptr(cv, b);
+    const double* Ps = snap ? snap + (size_t)b * cv.pstride : P;
+    if (snap && tid == 0) cv.cur[b] = 0;
 
     __shared__ double sT1[225];                                  // the fused clone's 6 x 21 scratch
     // a chunk of steps' (Phi, G~) fetched at once (one memory latency per chunk); after the composition the
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
     double qpre[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
     if (augR && tid < n) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) qpre[j] = P[tid + (size_t)(15 + j) * ld];
+        for (int j = 0; j < 6; ++j) qpre[j] = Ps[tid + (size_t)(15 + j) * ld];
     }
     dbg_stamp(16);
     const double* PhiB = Phi + (size_t)bl * k * 225;
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
                 const int row = blockIdx.x * PROP_THREADS + 64 * wv + 16 * rt + l15;
-                pvf[rt][t4] = row < n ? P[row + (size_t)cc * ld] : 0.0;
+                pvf[rt][t4] = row < n ? Ps[row + (size_t)cc * ld] : 0.0;
             }
         }
         if (blockIdx.x == 0) {
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int e = tid + u * PROP_THREADS;
-                if (e < naq * naq) { const int a = e / naq, c = e - a * naq; aap[u] = P[acol(a) + (size_t)acol(c) * ld]; }
+                if (e < naq * naq) { const int a = e / naq, c = e - a * naq; aap[u] = Ps[acol(a) + (size_t)acol(c) * ld]; }
             }
         }
     }
@@ -556,14 +563,16 @@ __global__ void k_post_restore(CovView cv, int b0, int nb, const int* __restrict
 #include "launch_ekf.h"
 void launch_propagate(CovView cv, int b0, int nb, int n_cap, const double* Phi, const double* G, const double* dt, int k,
                       const int* gnss_idx, const double sigma[4], int enable_gnss, double scb, double srw, hipStream_t st,
-                      const double* augR, int* status_clear)
+                      const double* augR, int* status_clear, const double* snap, const int* n_snap)
 {
     const int tiles = (n_cap + PROP_THREADS - 1) / PROP_THREADS;
     const bool fuse = augR && tiles == 1;
     hipLaunchKernelGGL(k_propagate, dim3(tiles, nb), dim3(PROP_THREADS), 0, st, cv, b0, Phi, G, dt, k, gnss_idx,
-                       sigma[0], sigma[1], sigma[2], sigma[3], enable_gnss, scb, srw, fuse ? augR : nullptr, status_clear);
+                       sigma[0], sigma[1], sigma[2], sigma[3], enable_gnss, scb, srw, fuse ? augR : nullptr, status_clear,
+                       fuse ? snap : nullptr, n_snap);
     if (augR && !fuse) hipLaunchKernelGGL(k_augment, dim3(nb), dim3(256), 0, st, cv, b0, augR);
 }
+bool propagate_can_restore(int n_cap) { return (n_cap + PROP_THREADS - 1) / PROP_THREADS == 1; }
 void launch_augment(CovView cv, int b0, int nb, const double* R, hipStream_t st)
 {
     hipLaunchKernelGGL(k_augment, dim3(nb), dim3(256), 0, st, cv, b0, R);

@@ -50,7 +50,9 @@ void launch_gamma(CovView cv, int b, const double* H, const double* res, const i
 // kernels_cov.hip
 void launch_propagate(CovView cv, int b0, int nb, int n_cap, const double* Phi, const double* G, const double* dt, int k,
                       const int* gnss_idx, const double sigma[4], int enable_gnss, double scb, double srw, hipStream_t st,
-                      const double* augR = nullptr, int* status_clear = nullptr);      // optional fused K2 / status reset
+                      const double* augR = nullptr, int* status_clear = nullptr,      // optional fused K2 / status reset
+                      const double* snap = nullptr, const int* n_snap = nullptr);      // optional: start from the snapshot (when propagate_can_restore and augR)
+bool propagate_can_restore(int n_cap);
 void launch_augment(CovView cv, int b0, int nb, const double* R, hipStream_t st);
 void launch_augment_one(CovView cv, int b, const double* R_host, hipStream_t st);      // one filter, R (host memory) as a kernel argument
 void launch_marginalize(CovView cv, int b0, int nb, int n_cap, const int* idx, int size, hipStream_t st, int idx_imm = -1);      // idx == nullptr: nb = 1, index idx_imm
