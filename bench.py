@@ -831,6 +831,11 @@ STAGGERED_STREAMS = {
     "kf11": "feats=150,clones=11,life=10,cohort=0,frames=90,key=1",
     "kf21": "feats=100,clones=21,life=19,cohort=0,frames=90,key=1",
     "kf27": "feats=150,clones=27,life=25,cohort=0,frames=110,key=1",
+    # sliding-window mode (is_key_frame 0) at BASELINE's 11 poses: 12 clones at update time, the oldest marginalised every frame, three
+    # selected stamps (frame_select_interval 5) - window class 72 of the solve since round 6
+    "sw11": ("feats=150,clones=11,life=13,cohort=0,frames=90,key=0", ["--set", "frame_select_interval: 5"]),
+    # the reference's shipped MONO configuration (config/sportsfield/ingvio_mono.yaml: 35 poses)
+    "kf35_mono": "feats=150,clones=35,life=33,cohort=0,frames=120,key=1,stereo=0",
 }
 
 
@@ -865,8 +870,11 @@ def latency_b1(args):
     # at the window sizes of the reference's shipped stereo configurations (config/fw_zed2i_f9p: 21 poses, config/sportsfield: 27)
     st = {}
     for name, spec in STAGGERED_STREAMS.items():
+        sets = []
+        if isinstance(spec, tuple):
+            spec, sets = spec
         try:
-            r = subprocess.run([REPLAY_TOOL, "--synth", spec, "--time"], capture_output=True, text=True, timeout=300)
+            r = subprocess.run([REPLAY_TOOL, "--synth", spec, "--time"] + sets, capture_output=True, text=True, timeout=300)
         except subprocess.TimeoutExpired:
             st[name] = dict(error="timeout"); continue
         line = [l for l in r.stdout.splitlines() if l.startswith("LATENCY")]

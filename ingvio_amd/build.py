@@ -34,7 +34,7 @@ def _all_deps(dirs):
 EXTRA_FLAGS = {"kernels_bigwin.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
-def source_build_id():
+def source_build_id(variant_flags=()):
     """Identity of the DEVICE code a libingvio_hip.so is built from: {"tu": {file: sha1 of the translation unit's own text + the
     headers it includes (transitively, csrc/ and include/ingvio_hip.h) + its extra flags}, "kernels": {__global__ name: file}}.  build_hip() embeds it in the
     library (ingvio_build_id()); tools/pmc_summary.py stores it beside the counters it folds, and bench.py refuses to price a
@@ -57,7 +57,7 @@ def source_build_id():
         h = hashlib.sha1(texts[src])
         for hd in sorted(closure(src, set())):
             h.update(hd.encode()); h.update(texts[hd])
-        h.update(" ".join(EXTRA_FLAGS.get(src, [])).encode())
+        h.update(" ".join(EXTRA_FLAGS.get(src, []) + list(variant_flags)).encode())
         tu[src] = h.hexdigest()[:16]
     # kernels defined in a header belong to every translation unit that instantiates them: attributed to the first .hip that
     # includes the header (good enough: a header change flips every hash anyway)
@@ -70,14 +70,19 @@ def source_build_id():
             else:
                 owner = next((s for s in HIP_SOURCES if ('#include "%s"' % f).encode() in texts[s]), None)
                 kernels.setdefault(name, owner or HIP_SOURCES[0])
-    return {"tu": tu, "kernels": kernels}
+    out = {"tu": tu, "kernels": kernels}
+    if variant_flags:
+        out["variant"] = " ".join(variant_flags)      # bench.py prices kernels with the product library's counters only
+    return out
 
 
-def _write_build_id():
-    """lib/build_id.cpp: the JSON of source_build_id() as a string the loaded library returns (ingvio_build_id)."""
+def _write_build_id(out_dir=None, variant_flags=()):
+    """<out_dir or lib>/build_id.cpp: the JSON of source_build_id() as a string the loaded library returns (ingvio_build_id).  A
+    variant build (build_alt: -DINGVIO_ALT_KERNELS) hashes its extra flags into every translation unit's id and carries a `variant`
+    field, so counters collected on it are never taken for the product library's."""
     import json
-    txt = json.dumps(source_build_id(), sort_keys=True)
-    src = os.path.join(LIB, "build_id.cpp")
+    txt = json.dumps(source_build_id(variant_flags), sort_keys=True)
+    src = os.path.join(out_dir or LIB, "build_id.cpp")
     body = 'extern "C" const char* ingvio_build_id(void) { return R"BID(%s)BID"; }\n' % txt
     if not os.path.exists(src) or open(src).read() != body:
         with open(src, "w") as f:
@@ -136,7 +141,10 @@ def build_alt(force=False, verbose=False):
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(cmds), os.cpu_count() or 4)) as ex:
             list(ex.map(subprocess.check_call, cmds))
-    bid_obj = os.path.join(LIB, "build_id.o")
+    bid_src = _write_build_id(out, ("-DINGVIO_ALT_KERNELS",))
+    bid_obj = os.path.join(out, "build_id.o")
+    if force or _newer(bid_obj, [bid_src]):
+        subprocess.check_call(["g++", "-O1", "-fPIC", "-c", bid_src, "-o", bid_obj])
     if force or _newer(lib, objs + [bid_obj]):
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + [bid_obj])
     return lib

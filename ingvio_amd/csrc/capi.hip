@@ -347,13 +347,14 @@ struct Uploader {
         // small uploads on the compute stream: a kernel that reads the pinned slab (k_upload_words) - no copy-engine hand-over
         if (!stream && bytes <= UPLOAD_KERNEL_MAX && (bytes & 3) == 0 && (((uintptr_t)dst | (uintptr_t)src) & 3) == 0) {
             launch_upload_words(dst, src, bytes, c->st);
+            if (hipGetLastError() != hipSuccess) rc = INGVIO_E_HIP;
             return;
         }
         if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream ? stream : c->st) != hipSuccess) rc = INGVIO_E_HIP;
     }
     int end()
     {
-        if (rc) { c->err = "hipMemcpyAsync from the pinned staging slab failed"; return rc; }
+        if (rc) { c->err = "upload from the pinned staging slab failed (hipMemcpyAsync / k_upload_words launch)"; return rc; }
         HIPCHK(c, hipEventRecord(slab->ev, stream ? stream : c->st));
         slab->busy = true;
         return 0;
@@ -1757,6 +1758,10 @@ static int msckf_update_impl(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_f
     rc = fill_noise_scalar(c, b0, nb, op.var);
     if (rc) return rc;
     const int fm = c->d.f_max;
+    //  fork_recorded must not outlive this call: an early error return between here and run_msckf_factored - the only
+    // place that consumes the flag - would make the NEXT large-window step skip recording ev_fork and start its side stream
+    // against a stale event
+    struct ForkGuard { ingvio_ctx* c; ~ForkGuard() { c->fork_recorded = false; } } fork_guard{ c };
     if (tri && c->d.c_max > 16 && c->st2 && c->method == 1) {      // the prior-only half of the large-window solve may start now, beside the triangulation
         HIPCHK(c, hipEventRecord(c->ev_fork, c->st));
         c->fork_recorded = true;
@@ -1789,7 +1794,7 @@ static int msckf_update_impl(ingvio_ctx* c, int b0, int nb, const ingvio_msckf_f
     rc = run_msckf(c, b0, nb, op, opts->stereo, fmx);
     if (rc) return rc;
     std::vector<int> rows(nb), status(nb);
-    if (b0 == 0 && nb == c->d.batch && c->result_bytes <= (1u << 20)) {      // the whole batch, small: one copy of the result slab
+    if (b0 == 0 && nb == c->d.batch && (tri ? c->result_bytes : c->ro_tok) <= (1u << 20)) {      // the whole batch, small: one copy of the result slab (gated on the bytes this call copies)
         HIPCHK(c, hipMemcpyAsync(c->h_result, c->d_result_slab, tri ? c->result_bytes : c->ro_tok, hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipStreamSynchronize(c->st));
         if (dx_out) memcpy(dx_out, c->h_result, 8 * (size_t)nb * c->ldp);

@@ -1,4 +1,5 @@
 #include "GnssUpdate.h"
+#include <algorithm>
 #include <cstring>
 
 #include <cmath>
@@ -99,11 +100,13 @@ int GnssUpdate::updateTrackedSys(std::shared_ptr<State> state, const GnssResidua
     int used = 0, status = 0;
     std::vector<int> keep((size_t)ingvio_mld(ctx), 0);
     const int rc = ingvio_gnss_update_batch(ctx, b, 1, &blk, &o, dx.data(), &used, keep.data(), &status);      // gates + ekfUpdate, one round trip
-    _last_keep.assign(keep.begin(), keep.begin() + rows);                                              // per candidate row: survived its gate (trace)
     if (rc < 0) {
         std::cout << "[GnssUpdate]: device update failed (" << rc << "): " << ingvio_last_error(ctx) << std::endl;
         std::exit(EXIT_FAILURE);
     }
+    // per candidate row: survived its gate (trace).  After the status check and clamped (more rows than the context's row
+    // capacity is exactly the case the device call refuses - the range must not be formed before that is known)
+    _last_keep.assign(keep.begin(), keep.begin() + std::min<size_t>((size_t)rows, keep.size()));
     if (status == INGVIO_NEG_DIAG)
         std::cout << "[StateManager]: EKF Update and found negative diag cov elements! " << std::endl;   // StateManager.cpp:418
     if (used == 0 || status == INGVIO_REJECTED) return 0;

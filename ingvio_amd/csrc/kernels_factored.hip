@@ -1272,15 +1272,15 @@ __global__ __launch_bounds__(256) void k_chunk_sum(const double* __restrict__ Ap
     const int bl = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
     const int* cu = chunk_used + (size_t)bl * G;
     const double* A = Apart + (size_t)bl * G * rstride;
-    unsigned mask = 0;
+    unsigned long long mask = 0;                              // G <= 64 (a 32-bit mask aliased chunks 32.. of the variant build)
     int total = 0;
-    for (int g = 0; g < G; ++g) { mask |= (cu[g] != 0 ? 1u : 0u) << g; total += cu[g]; }
+    for (int g = 0; g < G; ++g) { mask |= (cu[g] != 0 ? 1ull : 0ull) << g; total += cu[g]; }
     if (e < rstride) {
         double s = 0.0;
 #pragma unroll 8
         for (int g = 0; g < G; ++g) {
             const double x = A[(size_t)g * rstride + e];
-            s += ((mask >> g) & 1u) ? x : 0.0;
+            s += ((mask >> g) & 1ull) ? x : 0.0;
         }
         out[(size_t)bl * rstride + e] = s;
     }
@@ -1304,7 +1304,7 @@ int launch_factored(const FactoredLaunch& L, hipStream_t st)
 #define POSTCOLS_DISPATCH(NC)                                                                                           \
         hipLaunchKernelGGL((k_post_cols<NC>), dim3((nt + 3) / 4, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride, L.m_out, \
                            L.pc_base, L.gcolmap, L.gnc, L.gcstride, L.gW, L.gWstride);
-        if (ncm <= 36) { POSTCOLS_DISPATCH(36) } else if (ncm <= 66) { POSTCOLS_DISPATCH(66) } else { POSTCOLS_DISPATCH(96) }
+        if (ncm <= 36) { POSTCOLS_DISPATCH(36) } else if (ncm <= 66) { POSTCOLS_DISPATCH(66) } else if (ncm <= 72) { POSTCOLS_DISPATCH(72) } else { POSTCOLS_DISPATCH(96) }
 #undef POSTCOLS_DISPATCH
         return 0;
     }
@@ -1320,13 +1320,13 @@ int launch_factored(const FactoredLaunch& L, hipStream_t st)
 #endif
         // few filters: one wave per tile, two flat launches (k_apply_T_flat / k_apply_sym_flat)
         if (!L.gY && L.Tflat && L.nb <= L.flat_nb) {
-            const int JTx = ncm <= 36 ? 3 : (ncm <= 66 ? 5 : 6);
+            const int JTx = ncm <= 36 ? 3 : (ncm <= 72 ? 5 : 6);
 #define FLAT_DISPATCH(NC)                                                                                             \
             hipLaunchKernelGGL((k_apply_T_flat<NC>), dim3((nt * JTx + 3) / 4, L.nb), dim3(256), 0, st, L.cv, L.b0, L.T, L.mstride, L.Pc, L.ystride, \
                                L.m_out, L.marg_idx, L.marg_size, L.pc_base, L.Tflat, L.tfstride, L.dx);                 \
             hipLaunchKernelGGL((k_apply_sym_flat<NC>), dim3((nt * (nt + 1) / 2 + 3) / 4, L.nb), dim3(256), 0, st, L.cv, L.b0, L.Pc, L.ystride, \
                                L.m_out, L.marg_idx, L.marg_size, L.pc_base, L.Tflat, L.tfstride, L.status);
-            if (ncm <= 36) { FLAT_DISPATCH(36) } else if (ncm <= 66) { FLAT_DISPATCH(66) } else { FLAT_DISPATCH(96) }
+            if (ncm <= 36) { FLAT_DISPATCH(36) } else if (ncm <= 66) { FLAT_DISPATCH(66) } else if (ncm <= 72) { FLAT_DISPATCH(72) } else { FLAT_DISPATCH(96) }
 #undef FLAT_DISPATCH
             return 0;
         }
@@ -1336,7 +1336,8 @@ int launch_factored(const FactoredLaunch& L, hipStream_t st)
         APPLY_TW2(NC)                                                                                                 \
         else hipLaunchKernelGGL((k_info_apply<NC, 1>), dim3(nb8 * wgpf), dim3(256), 0, st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride, L.Pc, \
                            L.ystride, L.m_out, L.dx, L.status, L.marg_idx, L.marg_size, L.pc_base);
-        if (ncm <= 36) { APPLY_DISPATCH(36) } else if (ncm <= 66) { APPLY_DISPATCH(66) } else { APPLY_DISPATCH(96) }
+        // class 72 = a 12-clone window: an 11-pose window in sliding-window mode holds 12 clones at update time (SwMargUpdate.cpp:412-419)
+        if (ncm <= 36) { APPLY_DISPATCH(36) } else if (ncm <= 66) { APPLY_DISPATCH(66) } else if (ncm <= 72) { APPLY_DISPATCH(72) } else { APPLY_DISPATCH(96) }
 #undef APPLY_DISPATCH
 #undef APPLY_TW2
         return 0;
@@ -1367,7 +1368,7 @@ int launch_factored(const FactoredLaunch& L, hipStream_t st)
                                L.G, L.rstride, L.noise, L.T, L.mstride, L.Pc, L.ystride, L.dx, L.m_out, L.nc_out, L.status,  \
                                L.marg_idx, L.pc_base);                                                                      \
         }
-        if (ncm <= 36) { INFO_DISPATCH(36) } else if (ncm <= 66) { INFO_DISPATCH(66) } else { INFO_DISPATCH(96) }
+        if (ncm <= 36) { INFO_DISPATCH(36) } else if (ncm <= 66) { INFO_DISPATCH(66) } else if (ncm <= 72) { INFO_DISPATCH(72) } else { INFO_DISPATCH(96) }
 #undef INFO_DISPATCH
         return 0;
     }

@@ -224,6 +224,8 @@ __device__ __forceinline__ void solve_wave(const SolveArgs<NC>& a, int* bad)
     // complete under factorisation 1.  A is exactly symmetric (k_feat_gram2 builds both halves from the same sums): element
     // (row, col) is read at (col, row), which runs along the 16 lanes of a fragment (coalesced); the b row is column ncol.
     double af[RW][NT][4];
+    unsigned long long used_mask = 0;                          // G <= 16 chunks (ingvio_ctx_create; INGVIO_GRAM_CHUNKS of the variant build: <= 64)
+    for (int g = 0; g < a.G; ++g) used_mask |= (a.chunk_used[a.bl * a.G + g] != 0 ? 1ull : 0ull) << g;
 #pragma unroll
     for (int w = 0; w < RW; ++w) {
         if (D2.rows[W][w].valid && D2.rows[W][w].kind == 1) {
@@ -237,7 +239,12 @@ __device__ __forceinline__ void solve_wave(const SolveArgs<NC>& a, int* bad)
                     if (col < ncol && (row < ncol || row == NC)) {      // row NC = b^T
                         const int colF = RED ? col + (col >= a.ref6 ? 6 : 0) : col, rowF = RED ? row + (row >= a.ref6 ? 6 : 0) : row;
                         const size_t e = (size_t)colF * (a.ncolF + 1) + (row == NC ? a.ncolF : rowF);
-                        for (int g = 0; g < a.G; ++g) if (a.chunk_used[a.bl * a.G + g]) v += a.Apart[((size_t)a.bl * a.G + g) * a.rstride + e];
+                        // every load is issued whether its chunk is used or not (the value is selected away): under the condition each
+                        // element was a dependent round trip of its own (round 6: 19.5 k -> see DESIGN 4.3 cycles for this phase)
+                        for (int g = 0; g < a.G; ++g) {
+                            const double x = a.Apart[((size_t)a.bl * a.G + g) * a.rstride + e];
+                            v += ((used_mask >> g) & 1ull) ? x : 0.0;
+                        }
                     }
                     af[w][kt][s] = v;
                 }
@@ -430,7 +437,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     const double* P = cov_ptr(cv, b);
     for (int c = tid; c < NPF; c += NTH) { const int cc = c < ncolF ? c : 0; sColF[c] = fv.clone_idx[(size_t)b * fv.cmax + cc / 6] + cc % 6; }
-    if (RED && tid < 256) {                                  // translation information of every clone: trace of its (p, p) block
+#ifndef SOLVE_REF_BY_INFO
+#define SOLVE_REF_BY_INFO 0      // 1: the reference clone of the gauge reduction = the one with the largest translation information (rounds 3-5)
+#endif
+    if (SOLVE_REF_BY_INFO && RED && tid < 256) {             // translation information of every clone: trace of its (p, p) block
         // lane (clone c, chunk g): three loads; the per-clone sums over the chunks are taken in chunk order below, so the choice
         // of the reference clone - and with it every bit of the result - does not depend on the order the lanes ran in
         const int c = tid >> 4, g0 = tid & 15;
@@ -453,7 +463,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int i = e / ncolF, j = e - i * ncolF;
         X[i * Cfg::LDSS + j] = P[sColF[j] + (size_t)sColF[i] * ld];
     }
-    if (RED && tid == 0) {
+    // Round 6: the reference clone is the NEWEST one (the clone of this frame).  Any reference is exact algebra (the differences
+    // d_c = u_c - u_ref span the same space); the largest-information rule of rounds 3-5 cost three dependent loads per lane, a
+    // barrier and a 176-term serial loop of one thread in front of every solve (~6 k of the set-up's 35 k cycles) for no measurable
+    // change of the result (tests/test_gpu_pinning.py::test_sigma_and_prior_scale_sweep passes with either).
+    if (!SOLVE_REF_BY_INFO && RED && tid == 0) sRefSlot = C - 1;
+    if (SOLVE_REF_BY_INFO && RED && tid == 0) {
         int best = 0; double tb = -1.0;
         for (int c = 0; c < C; ++c) {
             double t = 0.0;
@@ -599,7 +614,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 }  // namespace
 
-// returns 0 when the window class is handled here (6 C <= 66), non-zero otherwise (caller falls back to k_info_update)
+// returns 0 when the window class is handled here (6 C <= 72), non-zero otherwise (caller falls back to k_info_update)
 int launch_info_solve(const FactoredLaunch& L, hipStream_t st)
 {
     const int ncm = 6 * ((L.c_used > 0 && L.c_used <= L.fv.cmax) ? L.c_used : L.fv.cmax);      // window class by the frames (launch_factored.h)
@@ -623,6 +638,10 @@ int launch_info_solve(const FactoredLaunch& L, hipStream_t st)
     const bool red = !L.op.selected_variant && !no_gauge;
     if (ncm <= 36) { if (red) SOLVE_DISPATCH(36, true) else SOLVE_DISPATCH(36, false) }
     if (ncm <= 66) { if (red) SOLVE_DISPATCH(66, true) else SOLVE_DISPATCH(66, false) }
+    // 12 clones (round 6): the same five tile rows as the 66 class - 66 reduced / 72 unreduced columns; 121 KB of LDS unreduced: one
+    // workgroup per CU, which is what a single real-time filter in sliding-window mode needs (it used to take the Gauss-Jordan
+    // route of the 16-clone class: 0.4 ms per update)
+    if (ncm <= 72) { if (red) SOLVE_DISPATCH(72, true) else SOLVE_DISPATCH(72, false) }
 #undef SOLVE_DISPATCH
     return 1;
 }

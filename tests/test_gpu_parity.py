@@ -329,6 +329,7 @@ def test_gate_mixed_groups_of_four_vs_oracle(orc, selected, F, C):
 
 @pytest.mark.parametrize("C,stereo,method", [(16, True, "factored"), (16, False, "factored"), (6, True, "factored"),
                                              (6, False, "factored"), (13, True, "factored"), (4, True, "factored"),
+                                             (12, True, "factored"), (12, False, "factored"),      # 12 clones: the symmetric solve's 72 class (round 6)
                                              (13, True, "dense"), (16, False, "dense"), (4, False, "dense")])
 def test_window_size_classes_vs_oracle(orc, C, stereo, method):
     """The kernels are instantiated for window classes 6 / 11 / 16 clones: run whole frames at the class maxima and
@@ -533,6 +534,44 @@ def test_config5_stress_vs_oracle(orc, n_lm):
     P = ctx2.cov_get(0)
     assert np.array_equal(acc[0, :F], acco) and rows[0] == 6 * C and ctx2.n(0) == N - 6
     assert rel_err(P, oc.P) < 1e-10 and rel_err(dx[0, :N], dxo) < 1e-7 and np.array_equal(P, P.T)
+    ctx2.close()
+
+
+@pytest.mark.parametrize("selected,stereo,nb", [(1, True, 1), (0, True, 1), (1, False, 1), (1, True, 3)])
+def test_twelve_clone_window_vs_oracle(orc, selected, stereo, nb):
+    """An 11-pose window in SLIDING-WINDOW mode (is_key_frame 0) holds 12 clones at update time (SwMargUpdate.cpp:412-419, State.h:83-92):
+    window class 72 of k_info_solve (66 columns gauge-reduced for the RemoveLost form, 72 unreduced for the Selected-timestamp form
+    with quirk Q10) and of the apply kernels - one filter (the flat few-filter kernels) and a small batch, two consecutive updates on
+    the same covariance, posterior and dx against the oracle."""
+    from ingvio_amd import capi, host, synth
+    C, F, n_gnss, n_lm = 12, 60, 6, 4
+    N = 21 + n_gnss + 3 * n_lm + 6 * C
+    ctx2 = capi.Context(batch=nb, n_max=((N + 15) // 16) * 16, c_max=C, f_max=F, m_max=64)
+    cases = []
+    for b in range(nb):
+        flt, step, frame, info = synth.build_case(lambda P, b=b: capi.DeviceCov(ctx2, b, P), host.imu_transition, seed=170 + b, F=F, C=C,
+                                                  n_gnss=n_gnss, n_landmarks=n_lm, stereo=stereo)
+        rng = np.random.default_rng(3000 + b)
+        mask = np.zeros(F, dtype=np.uint64); dof = np.zeros(F, dtype=np.int32)
+        for j in range(F):
+            # the Selected-timestamp updates see 3 stamps of the window (frame_select_interval 5 at 11 poses), RemoveLost whole tracks
+            k = int(rng.integers(3 if stereo else 5, 5 if (selected and stereo) else C + 1))
+            obs = np.sort(rng.choice(C, size=k, replace=False))
+            mask[j] = np.uint64(sum(1 << int(o) for o in obs)); dof[j] = k - 1
+        frame = dict(frame); frame["obs_mask"] = mask; frame["dof"] = dof
+        frame["anchor"] = np.array([int([o for o in range(C) if (int(mask[j]) >> o) & 1][0]) if j % 2 else int(rng.integers(0, C)) for j in range(F)],
+                                   dtype=np.int32)                       # half the anchors observe the feature themselves (Q10 bites there)
+        cases.append((step, frame))
+    ocs = [orc.Cov(ctx2.cov_get(b), ld=ctx2.ldp) for b in range(nb)]
+    ctx2.frame_stage(0, [c[0] for c in cases], [c[1] for c in cases], cases[0][0]["sigma"], 1, 0.2, 0.2, max_accept=0, compress_rule=1,
+                     selected_variant=selected)
+    for it in range(2):
+        ctx2.frame_run(restore_prior=False)
+        dx, acc, rows = ctx2.frame_fetch()
+        for b in range(nb):
+            dxo, acco, gamo, m = orc.frame_update(ocs[b], cases[b][0], cases[b][1], max_accept=0, compress_rule=1, selected_variant=selected)
+            assert np.array_equal(acc[b, :F], acco) and acco.sum() > 10
+            assert rel_err(ctx2.cov_get(b), ocs[b].P) < 1e-10 and rel_err(dx[b, :N], dxo) < 1e-7, (it, b)
     ctx2.close()
 
 

@@ -9,8 +9,11 @@ case $W in
   config5) SPEC="feats=300,clones=30,life=28,cohort=1,birth_frame=2,frames=95,key=1";;
   kf27) SPEC="feats=150,clones=27,life=25,cohort=0,frames=110,key=1";;      # the sports-field stereo window, staggered track deaths (6 lost features per frame)
   kf21) SPEC="feats=100,clones=21,life=19,cohort=0,frames=90,key=1";;
+  sw11) SPEC="feats=150,clones=11,life=13,cohort=0,frames=90,key=0";;      # sliding-window mode at 11 poses: 12 clones at update time
+  kf35_mono) SPEC="feats=150,clones=35,life=33,cohort=0,frames=120,key=1,stereo=0";;
 esac
 EXTRA=()
+case $W in sw11) EXTRA=(--set "frame_select_interval: 5");; esac
 case $W in config2|config5) EXTRA=(--set "hip_max_valid_ids: 0" --set "hip_compress_rule: 1");; esac
 OUT=gpurun_out/replay_trace_$W
 rm -rf $OUT; mkdir -p $OUT
