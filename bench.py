@@ -138,8 +138,8 @@ def algorithmic_flops(F_used, F, C, N, k):
         "k_ekf_core": k8_9_11, "k_downdate": k10,
         # factored path: same algorithmic work, carried by other kernels (K8/K9 -> k_info_update; K10/K11 and the
         # P H^T / K products -> k_info_apply)
-        "k_feat_gate3": F * (k4 + k5), "k_feat_gram2": F_used * k4 + k7, "k_info_update": 2.0 * n ** 3 + n ** 3 / 3.0,
-        "k_info_apply": k10 + 4.0 * N * n * n + 2.0 * N * n}
+        "gate": F * (k4 + k5), "gram": F_used * k4 + k7, "solve": 2.0 * n ** 3 + n ** 3 / 3.0,
+        "apply": k10 + 4.0 * N * n * n + 2.0 * N * n}
     total = F * (k4 + k5) + k7 + k8_9_11 + k10 + k1 + k2
     return per_kernel, total
 
@@ -148,7 +148,7 @@ def algorithmic_bytes(N, k_imu, F, C):
     """bytes a kernel must move at least once per update (FP64).  Only kernels whose traffic has such a
     closed form are listed: the strip kernels and the update's read+write of P."""
     return {"k_propagate": 2.0 * 2 * (15 + 6) * N * 8 + 8.0 * k_imu * 405,      # 15-column strip + the 6 new clone rows, both ways
-            "k_info_apply": 2.0 * N * N * 8,                                   # read + write P once
+            "apply": 2.0 * N * N * 8,                                   # read + write P once
             "k_marginalize": 2.0 * N * N * 8, "restore_full": 2.0 * N * N * 8}
 
 
@@ -216,8 +216,10 @@ def hbm_traffic_bytes(c):
 # The library's profile slots are named after the STAGE; rocprofv3 sees kernels.  Stage -> candidates, each candidate a tuple of
 # kernels whose counters are added up (x their launches per step): the first candidate with counters for all its kernels wins.
 STAGE_KERNELS = {
-    "k_feat_gate3": (("k_feat_gate5",), ("k_feat_gate4",), ("k_feat_gate3",)),      # stereo: four features per wave (round 4, windows <= 11 clones) / one per wave (round 3) / first generation, mono
-    "k_info_update": (("k_info_solve",), ("k_info_update",)),            # windows up to 11 clones / 12..16
+    "gate": (("k_feat_gate5",), ("k_feat_gate4",), ("k_feat_gate3",)),      # stereo: four features per wave (round 4, windows <= 11 clones) / one per wave (round 3) / first generation, mono
+    "gram": (("k_feat_gram2",),),
+    "solve": (("k_info_solve",), ("k_info_update",)),            # windows up to 12 clones / 13..16
+    "apply": (("k_info_apply",),),
     "restore": (("k_restore_strips",), ("k_restore",)),
     "k_lm_build": (("k_lm_rows", "k_lm_front"), ("k_lm_build", "k_lm_products")),        # fused front (round 3) / compacting build + products
     "k_lm_gemm": (("k_gemm",),),
@@ -225,11 +227,11 @@ STAGE_KERNELS = {
     "k_downdate": (("k_downdate64",), ("k_downdate",)),
 }
 STAGE_KERNELS_BIG = {                                                      # windows of 17..36 clones (kernels_bigwin.hip)
-    "k_feat_gate3": (("k_feat_gate4_big",), ("k_feat_gate3_big",)), "k_feat_gram2": (("k_feat_gram_big",),),
+    "gate": (("k_feat_gate4_big",), ("k_feat_gate3_big",)), "gram": (("k_feat_gram_big",),),
     # round 5: the set-up is k_big_prep_P (prior only, on the side stream together with the first sweep) + k_big_prep_A
-    "k_info_update": (("k_big_prep_P", "k_big_prep_A", "k_chol_first", "k_chol_step", "k_chol_carried", "k_gemm64", "k_copy_rows", "k_big_gauge_fix"),
+    "solve": (("k_big_prep_P", "k_big_prep_A", "k_chol_first", "k_chol_step", "k_chol_carried", "k_gemm64", "k_copy_rows", "k_big_gauge_fix"),
                       ("k_big_prep_P", "k_big_prep_A", "k_chol_first", "k_chol_step", "k_chol_carried", "k_gemm64", "k_copy_rows"), ("k_info_update_big",)),
-    "k_info_apply": (("k_apply_T64b", "k_apply_sym64b"), ("k_apply_T", "k_apply_sym"), ("k_info_apply_big",)),
+    "apply": (("k_apply_T64b", "k_apply_sym64b"), ("k_apply_T", "k_apply_sym"), ("k_info_apply_big",)),
 }
 
 
@@ -247,7 +249,7 @@ def counters_for(counters, name, big, C=None):
     """-> (summed counters of the stage's kernels or None, the kernels they belong to)."""
     table = STAGE_KERNELS_BIG if big and name in STAGE_KERNELS_BIG else STAGE_KERNELS
     cands = table.get(name, ((name,),))
-    if name == "k_feat_gate3" and C is not None:            # the gate that ran is known: counters of another generation do not apply
+    if name == "gate" and C is not None:            # the gate that ran is known: counters of another generation do not apply
         cands = ((gate_kernel_of(C),),)
     if counters is None:
         return None, cands[0]
@@ -266,7 +268,7 @@ def counters_for(counters, name, big, C=None):
 def kernel_that_ran(stage, cand, C, stereo=True):
     """The kernel rocprofv3 sees for a profile slot (slots are named after the stage)."""
     name = "+".join(cand)
-    if stage == "k_feat_gate3":
+    if stage == "gate":
         if not stereo:
             return "k_feat_gate3%s<%d>" % ("_big" if C > 16 else "", C)
         cls = 6 if C <= 6 else 11 if C <= 11 else 16 if C <= 16 else 24 if C <= 24 else 28 if C <= 28 else 30 if C <= 30 else 32 if C <= 32 else 36      # launch_factored / launch_bigwin classes

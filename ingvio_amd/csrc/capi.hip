@@ -34,7 +34,7 @@ enum ProfId { PF_RESTORE, PF_PROPAGATE, PF_AUGMENT, PF_GATE, PF_FOLD, PF_MERGE, 
               PF_GATE2, PF_GRAM, PF_INFO, PF_APPLY, PF_ROWGATE, PF_LM_BUILD, PF_LM_GEMM, PF_LM_CHOL, PF_POSTCOLS, PF_COUNT };
 const char* kProfNames[PF_COUNT] = { "restore", "k_propagate", "k_augment", "k_msckf_gate", "k_msckf_fold",
                                      "k_msckf_merge", "k_ekf_core", "k_downdate", "k_marginalize",
-                                     "k_feat_gate3", "k_feat_gram2", "k_info_update", "k_info_apply", "k_rows_gate",
+                                     "gate", "gram", "solve", "apply", "k_rows_gate",      // stage slots: bench.py names the kernel that ran
                                      "k_lm_build", "k_lm_gemm", "k_lm_chol", "k_post_cols" };
 struct ProfRec { int id; hipEvent_t a, b; };
 

@@ -220,6 +220,7 @@ void LandmarkUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapSer
     // LandmarkUpdate.cpp:32-149: rows of every in-state landmark, a chi^2 gate per landmark on the prior (:98-99, dof = rows),
     // the accepted rows stacked, one ekfUpdate - all of it in one device call (kernels_lmbatch.hip); the nominal values stay here
     _last_rows = 0;
+    _last_upd_ids.clear(); _last_upd_acc.clear();
     const int L = (int)state->_anchored_landmarks.size();
     if (L == 0) return;
     if (L > INGVIO_LM_MAX) {          // unreachable: State::construct refuses max_landmark_features > INGVIO_LM_MAX at start-up
@@ -232,7 +233,9 @@ void LandmarkUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapSer
     std::vector<int> lm_idx, anchor_idx;
     std::vector<double> pf, uv;
     std::vector<unsigned char> tracked;
+    std::vector<int> order_ids;
     for (const auto& item : state->_anchored_landmarks) {
+        order_ids.push_back(item.first);
         checkTracked(map_server, state, item.first, stereo);
         const auto fi = map_server->at(item.first);
         lm_idx.push_back(item.second->idx());
@@ -257,7 +260,12 @@ void LandmarkUpdate::update(std::shared_ptr<State> state, std::shared_ptr<MapSer
     const Iso3& T_lr = state->_state_params._T_cl2cr;
     std::memcpy(op.R_cl2cr, T_lr.R.m, sizeof op.R_cl2cr);
     for (int i = 0; i < 3; ++i) op.t_cl2cr[i] = T_lr.t[i];
-    _last_rows = StateManager::landmarkUpdate(state, fr, op);
+    std::vector<int> acc;
+    _last_rows = StateManager::landmarkUpdate(state, fr, op, &acc);
+    std::vector<std::pair<int, int>> rec;
+    for (size_t i = 0; i < order_ids.size(); ++i) rec.emplace_back(order_ids[i], i < acc.size() ? (acc[i] != 0) : 0);
+    std::sort(rec.begin(), rec.end());
+    for (const auto& r : rec) { _last_upd_ids.push_back(r.first); _last_upd_acc.push_back(r.second); }
 }
 
 void LandmarkUpdate::updateLandmarkMonoSw(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server)
@@ -320,6 +328,7 @@ void LandmarkUpdate::initNew(std::shared_ptr<State> state, std::shared_ptr<MapSe
                              int min_init_poses, bool stereo)
 {
     _last_init = 0;
+    _last_init_ids.clear();
     if ((int)state->_sw_camleft_poses.size() < min_init_poses) return;
     const int vac_num_lm = state->_state_params._max_landmarks - (int)state->_anchored_landmarks.size();
     if (vac_num_lm <= 0) return;
@@ -348,6 +357,7 @@ void LandmarkUpdate::initNew(std::shared_ptr<State> state, std::shared_ptr<MapSe
         state->_anchored_landmarks[id] = map_server->at(id)->_landmark;
         map_server->at(id)->_ftype = FeatureInfo::SLAM;
         ++_last_init;
+        _last_init_ids.push_back(id);
     }
 }
 

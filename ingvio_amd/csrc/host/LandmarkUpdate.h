@@ -41,6 +41,11 @@ public:
                               const std::vector<double>& marg_kfs);                                        // :318-361
     int lastRows() const { return _last_rows; }
     int lastInitialised() const { return _last_init; }
+    // per frame, for the stream traces (tools/ingvio_replay.cpp --trace; oracle/stream_filter.py): the landmarks the update evaluated
+    // (ascending id) with their chi^2 verdicts, and the ids the delayed initialisation added, in the order it added them
+    const std::vector<int>& lastUpdateIds() const { return _last_upd_ids; }
+    const std::vector<int>& lastUpdateAccepted() const { return _last_upd_acc; }
+    const std::vector<int>& lastInitIds() const { return _last_init_ids; }
 
     // rows x 24 = [extended pose 9 | extrinsics 6 | anchor 6 | landmark 3]  (:521-572 mono, :619-686 stereo)
     static void landmarkRows(const std::shared_ptr<FeatureInfo> feature_info, const std::shared_ptr<State> state, bool stereo,
@@ -58,6 +63,7 @@ protected:
     void reanchor(std::shared_ptr<State> state, std::shared_ptr<MapServer> map_server, const std::vector<std::shared_ptr<SE3>>& old_anchors);
     double _noise;
     int _last_rows = 0, _last_init = 0;
+    std::vector<int> _last_upd_ids, _last_upd_acc, _last_init_ids;
 };
 
 }  // namespace ingvio

@@ -55,6 +55,15 @@ STREAMS = {
     "kf35_mono": ("feats=100,clones=35,life=33,cohort=0,frames=90,key=1,stereo=0,outlier_every=6",
                   "frame_select_interval: 28\nvisual_noise: 0.18\ntrans_thres: 0.25\nconv_precision: 5e-08\nmax_depth: 60.0\nmin_depth: 0.2\n"
                   "max_baseline_ratio: 80.0\nhuber_epsilon: 0.01\ninit_damping: 1e-03\n"),
+    # in-state SLAM landmarks (round 6; VERDICT r05 missing 3): max_landmark_features 6, sliding-window mode, tracks that outlive the window
+    # (a landmark is initialised from a track with >= max_sliding_window_poses observations, LandmarkUpdate.cpp:892-917) - delayed
+    # initialisation, the per-frame landmark update with its chi^2 gates, anchor change before the oldest clone goes, landmarks that
+    # lose track and leave the state
+    "sw11_lm": ("feats=100,clones=11,life=20,cohort=0,frames=70,key=0,outlier_every=9", "frame_select_interval: 5\nmax_landmark_features: 6\n"),
+    # the same in key-frame mode (two clones chosen by getMargKfs leave every other frame: changeLandmarkAnchor(state, map, marg_kfs),
+    # LandmarkUpdate.cpp:318-361) and through the MONO callback (two rows per landmark, initNewLandmarkMono :363-424)
+    "kf11_lm": ("feats=100,clones=11,life=45,cohort=0,frames=80,key=1,outlier_every=9", "max_landmark_features: 5\n"),
+    "sw11_lm_mono": ("feats=100,clones=11,life=20,cohort=0,frames=70,key=0,stereo=0,outlier_every=9", "frame_select_interval: 5\nmax_landmark_features: 6\n"),
     "sw21": ("feats=100,clones=21,life=25,cohort=0,frames=70,key=0,outlier_every=7", "frame_select_interval: 6\n"),
 }
 

@@ -26,8 +26,10 @@ clones are selected, when anchors change and what is erased:
 The numerical kernels behind it are the oracle's (oracle/ingvio_oracle.c): orc_imu_transition, orc_propagate_cov,
 orc_augment_clone, orc_triangulate, orc_msckf_update (per-feature Jacobian, nullspace, chi^2 gate, stacking, compression, EKF
 update), orc_marginalize, the retractions; for GNSS orc_gnss_rows (the rows of updateTrackedSys with their per-row gates),
-orc_whiten_residual, orc_ekf_update, orc_add_variable_delayed.  Scope: mono and stereo, MSCKF features only (max_landmark_features
-= 0); GNSS epochs with the satellite states and atmosphere delays already evaluated (what the INGVIOR1 format carries), the alignment
+orc_whiten_residual, orc_ekf_update, orc_add_variable_delayed.  Scope: mono and stereo; MSCKF features and - round 6 - in-state SLAM
+landmarks (max_landmark_features > 0: LandmarkUpdate.cpp:32-149 / 688-801 update, :363-424 / :892-956 delayed initialisation, :273-361
+anchor change, MapServerManager.cpp:225-273 / 343-379 / 456-491; rows orc_landmark_rows_epose, orc_add_variable_delayed,
+orc_replace_var_linear); GNSS epochs with the satellite states and atmosphere delays already evaluated (what the INGVIOR1 format carries), the alignment
 given (no batchAlign), is_adjust_yof = 0.  Every processed camera frame yields a trace record (see `Trace`)."""
 import math
 
@@ -186,6 +188,8 @@ class Var:
         self.p = np.zeros(3)        # SE23: trans1 (position); SE3: translation; Vec3: the value
         self.v = np.zeros(3)        # SE23: trans2 (velocity)
         self.s = 0.0                # Scalar: the value
+        self.anchor = None          # 'lm' (AnchoredLandmark in the state): the anchoring clone Var; .p is the WORLD position (valuePosXyz)
+        self.feature = None         # 'lm': the Feature it belongs to (its pf is kept equal to .p)
 
     def update(self, dx):
         i = self.idx
@@ -195,15 +199,22 @@ class Var:
             self.R, self.p = orc.se3_update(self.R, self.p, dx[i:i + 6])
         elif self.kind == "scalar":                                      # VecState.cpp:40-44
             self.s = self.s + dx[i]
+        elif self.kind == "lm":                                          # AnchoredLandmark::update (AnchoredLandmark.cpp:227-243): the anchor's d_theta from dx
+            a = self.anchor.idx
+            dth = dx[a:a + 3]
+            self.p = orc.gamma(dth, 0).reshape(3, 3) @ self.p + orc.gamma(dth, 1).reshape(3, 3) @ dx[i:i + 3]
+            self.feature.pf = self.p.copy()
         else:                                                            # VecState.cpp:25-29
             self.p = self.p + dx[i:i + 3]
 
 
 class Feature:
-    """FeatureInfo (MapServer.h:69-134), MSCKF type only."""
+    """FeatureInfo (MapServer.h:69-134)."""
 
     def __init__(self):
         self.id = -1
+        self.slam = False           # _ftype == SLAM: the landmark is a state variable (self.lm)
+        self.lm = None
         self.is_to_marg = False
         self.is_tri = False
         self.num_tri = 0
@@ -218,7 +229,8 @@ class Filter:
         p.update(parse_params(overrides))
         g = lambda k, d: float(p.get(k, d))
         gi = lambda k, d: int(float(p.get(k, d)))
-        assert gi("max_landmark_features", 0) == 0, "scope: MSCKF features"
+        self.max_lm = gi("max_landmark_features", 0)                     # State.cpp: _max_landmarks
+        self.landmarks = {}          # id -> 'lm' Var (State::_anchored_landmarks)
         self.enable_gnss = gi("enable_gnss", 1)
         if self.enable_gnss:
             assert gi("is_adjust_yof", 0) == 0, "scope: is_adjust_yof = 0"
@@ -271,7 +283,7 @@ class Filter:
         for v in self.err_vars:
             v.idx = idx
             idx += v.size
-        self.cov = orc.Cov(1e-3 ** 2 * np.eye(idx), ld=((idx + 6 + 6 * (self.max_sw + 3) + 15) // 16) * 16)
+        self.cov = orc.Cov(1e-3 ** 2 * np.eye(idx), ld=((idx + 6 + 6 * (self.max_sw + 3) + 3 * self.max_lm + 15) // 16) * 16)
         self.timestamp = -1.0
         self.sw = {}                 # stamp -> clone Var
         self.map = {}                # id -> Feature
@@ -448,6 +460,8 @@ class Filter:
             else:
                 if ts in fi.obs:
                     continue
+                if fi.slam:                                              # MapServerManager.cpp:136-137 / :178-179: a landmark keeps its latest observation only
+                    fi.obs.clear()
                 fi.obs[ts] = (u0, v0, u1, v1)
                 fi.is_to_marg = False
 
@@ -504,13 +518,20 @@ class Filter:
     # ---- the three updates ----------------------------------------------------------------------------------------------
     def remove_lost_update(self, tr):                                    # RemoveLostUpdate.cpp:276-405
         ts = self.timestamp
-        for fi in self.map.values():                                     # markMargStereoFeatures, MapServerManager.cpp:245-273
+        lost_lm = []
+        for fid in sorted(self.map):                                     # markMargStereoFeatures, MapServerManager.cpp:245-273 (mono :225-243)
+            fi = self.map[fid]
             if ts not in fi.obs:
                 fi.is_to_marg = True
+                if fi.slam:
+                    lost_lm.append(fid)
+        for fid in lost_lm:                                              # a landmark that lost track leaves the state at once
+            self.marg_landmark(fid)
+            del self.map[fid]
         update_ids, direct = [], []
         for fid in sorted(self.map):
             fi = self.map[fid]
-            if fi.is_to_marg:
+            if fi.is_to_marg and not fi.slam:                            # RemoveLostUpdate.cpp:285: MSCKF type only
                 if self.triangulate(fi) and len(fi.obs) >= (3 if self.stereo else 4):        # RemoveLostUpdate.cpp:287 / :51
                     update_ids.append(fid)
                 else:
@@ -542,6 +563,8 @@ class Filter:
         update_ids = []
         for fid in sorted(self.map):
             fi = self.map[fid]
+            if fi.slam:                                                  # SwMargUpdate.cpp:240 / KeyframeUpdate.cpp:611
+                continue
             if any(t not in fi.obs for t in sel):
                 continue
             if self.triangulate(fi):
@@ -602,6 +625,8 @@ class Filter:
         gone, moved = [], []
         for fid in sorted(self.map):
             fi = self.map[fid]
+            if fi.slam:                                                  # SwMargUpdate.cpp:384 / KeyframeUpdate.cpp:301
+                continue
             if any(fi.anchor is o for o in old):
                 if fi.is_tri:
                     body = new_anchor.R.T @ (fi.pf - new_anchor.p)
@@ -630,8 +655,159 @@ class Filter:
             if body[2] <= 0.2:
                 gone.append(fid)
         for fid in gone:
+            if self.map[fid].slam:                                       # :485-486
+                self.marg_landmark(fid)
             del self.map[fid]
         tr["invalid_erased"] = gone
+
+    # ---- in-state SLAM landmarks (max_landmark_features > 0) ---------------------------------------------------------------------------
+    def marg_landmark(self, fid):                                        # StateManager::margAnchoredLandmarkInState (StateManager.cpp:340-353)
+        if fid not in self.landmarks:
+            return
+        self.marginalize(self.landmarks[fid])
+        del self.landmarks[fid]
+
+    def update_landmarks(self, tr):                                      # LandmarkUpdate.cpp:32-149 (mono) / :688-801 (stereo)
+        """Per in-state landmark: the rows of its CURRENT observation w.r.t. [extended pose 9 | extrinsics 6 | anchor 6 | landmark 3]
+        (:521-572 / :619-686), a chi^2 gate on the prior with dof = rows (Update.cpp:81-102), the accepted rows stacked with a var_order that
+        grows in order of first appearance, one ekfUpdate.  _anchored_landmarks is an unordered_map: the iteration order is unspecified and
+        the posterior does not depend on it - ascending id here."""
+        tr["lm_upd_ids"], tr["lm_upd_acc"] = [], []
+        if not self.landmarks:
+            return
+        e, x = self.ext_pose, self.extr
+        rows_per = 4 if self.stereo else 2
+        var_order, col_of = [e, x], {id(e): 0, id(x): 9}
+        col_cnt = 15
+        Hs, rs = [], []
+        for fid in sorted(self.landmarks):
+            lm = self.landmarks[fid]
+            fi = self.map[fid]
+            assert fi.slam and self.timestamp in fi.obs and fi.lm is lm, "landmark in state not tracked to curr time"
+            H, res = orc.landmark_rows_epose(e.R, e.p, x.R, x.p, lm.p, np.array(fi.obs[self.timestamp]), self.stereo, self.R_cl2cr, self.t_cl2cr)
+            vo = [e, x, lm.anchor, lm]
+            gam = self.cov.whiten([v.idx for v in vo], [v.size for v in vo], H, res, self.noise ** 2)
+            ok = bool(gam < self.chi2(len(res)))
+            tr["lm_upd_ids"].append(fid)
+            tr["lm_upd_acc"].append(int(ok))
+            if not ok:
+                continue
+            for v in (lm.anchor, lm):
+                if id(v) not in col_of:
+                    col_of[id(v)] = col_cnt
+                    col_cnt += v.size
+                    var_order.append(v)
+            Hs.append((H, [col_of[id(v)] for v in vo], [v.size for v in vo]))
+            rs.append(res)
+        if not Hs:
+            return
+        m = rows_per * len(Hs)
+        Hl = np.zeros((m, col_cnt))
+        for k, (H, cols, sizes) in enumerate(Hs):
+            c0 = 0
+            for c, sz in zip(cols, sizes):
+                Hl[rows_per * k:rows_per * (k + 1), c:c + sz] = H[:, c0:c0 + sz]
+                c0 += sz
+        dx, rc = self.cov.ekf_update([v.idx for v in var_order], [v.size for v in var_order], Hl, np.concatenate(rs), self.noise ** 2)
+        self.box_plus(dx)
+
+    def feat_all_obs_rows(self, fi):                                     # LandmarkUpdate.cpp:426-500 (mono) / :803-890 (stereo)
+        sw = self.sw_sorted()
+        col = {id(c): 6 * k for k, (_, c) in enumerate(sw)}
+        per = 4 if self.stereo else 2
+        skew = lambda v: np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+        Hx, Hf, res = [], [], []
+        for t in sorted(fi.obs):
+            if t not in self.sw:
+                continue
+            c = self.sw[t]
+            q = c.R.T @ (fi.pf - c.p)
+            Hp = np.array([[1 / q[2], 0, -q[0] / q[2] ** 2], [0, 1 / q[2], -q[1] / q[2] ** 2]])
+            D = np.zeros((3, 6 * len(sw)))
+            if c is not fi.anchor:
+                D[:, col[id(c)]:col[id(c)] + 3] = c.R.T @ skew(fi.pf)
+                D[:, col[id(fi.anchor)]:col[id(fi.anchor)] + 3] = -D[:, col[id(c)]:col[id(c)] + 3]
+            D[:, col[id(c)] + 3:col[id(c)] + 6] = -c.R.T
+            blocks_x, blocks_f, pred = [Hp @ D], [Hp @ c.R.T], [q[0] / q[2], q[1] / q[2]]
+            if self.stereo:
+                qr = self.R_cl2cr @ q + self.t_cl2cr
+                Hr = np.array([[1 / qr[2], 0, -qr[0] / qr[2] ** 2], [0, 1 / qr[2], -qr[1] / qr[2] ** 2]])
+                blocks_x.append(Hr @ self.R_cl2cr @ D)
+                blocks_f.append(Hr @ self.R_cl2cr @ c.R.T)
+                pred += [qr[0] / qr[2], qr[1] / qr[2]]
+            Hx.append(np.vstack(blocks_x)); Hf.append(np.vstack(blocks_f))
+            res.append(np.array(fi.obs[t][:per]) - np.array(pred))
+        return np.concatenate(res), np.vstack(Hx), np.vstack(Hf)
+
+    def init_new_landmarks(self, tr):                                    # LandmarkUpdate.cpp:363-424 (mono) / :892-956 (stereo); min_init_poses = max_sw
+        tr["lm_init_ids"] = []
+        if len(self.sw) < self.max_sw:
+            return
+        vac = self.max_lm - len(self.landmarks)
+        if vac <= 0:
+            return
+        ids = []
+        for fid in sorted(self.map):                                     # MapServer is a std::map<int, ...>: ascending id
+            if len(ids) >= vac:
+                break
+            fi = self.map[fid]
+            if len(fi.obs) < self.max_sw or fi.slam:
+                continue
+            if not self.triangulate(fi):
+                continue
+            ids.append(fid)
+        sw = self.sw_sorted()
+        for fid in ids:
+            fi = self.map[fid]
+            res, Hx, Hf = self.feat_all_obs_rows(fi)
+            n_old = self.cov.n
+            added, dx, chi2 = self.cov.add_variable_delayed([c.idx for _, c in sw], [6] * len(sw), Hx, Hf, res, self.noise, 0.95, True)
+            if not added:
+                continue
+            lm = Var("lm", 3)
+            lm.idx, lm.p, lm.anchor, lm.feature = n_old, fi.pf.copy(), fi.anchor, fi
+            self.err_vars.append(lm)
+            self.landmarks[fid] = lm
+            fi.lm, fi.slam = lm, True
+            self.box_plus(dx)                                            # the ekfUpdate of the remaining rows (StateManager.cpp:623-624)
+            tr["lm_init_ids"].append(fid)
+
+    def change_landmark_anchor(self, old_stamps):                        # LandmarkUpdate.cpp:273-316 (sliding window) / :318-361 (key frames)
+        if not old_stamps:
+            return
+        old = [self.sw[t] for t in old_stamps]
+        latest = max(self.sw)
+        new_anchor = self.sw[latest]
+        to_marg = []
+        for fid in sorted(self.map):
+            fi = self.map[fid]
+            if not fi.slam or not any(fi.lm.anchor is o for o in old):
+                continue
+            body = new_anchor.R.T @ (fi.lm.p - new_anchor.p)
+            if body[2] <= 0:
+                to_marg.append(fid)
+                continue
+            self.change_anchored_pose(fi, latest)
+            if fi.lm.anchor is not new_anchor:
+                to_marg.append(fid)
+        for fid in to_marg:
+            self.marg_landmark(fid)
+            del self.map[fid]
+
+    def change_anchored_pose(self, fi, target):                          # FeatureInfoManager::changeAnchoredPose, MapServerManager.cpp:343-379
+        if len(self.sw) < 2 or target not in self.sw or fi.id not in self.landmarks or not fi.slam:
+            return
+        if not any(c is fi.lm.anchor for c in self.sw.values()) or self.landmarks[fi.id] is not fi.lm:
+            return
+        skew = lambda v: np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+        vo = [fi.lm.anchor, self.sw[target], fi.lm]
+        H = np.zeros((3, 15))
+        H[:, 0:3] = -skew(fi.lm.p)
+        H[:, 6:9] = skew(fi.lm.p)
+        H[:, 12:15] = np.eye(3)
+        self.cov.replace_var_linear(fi.lm.idx, 3, [v.idx for v in vo], [v.size for v in vo], H)
+        fi.lm.anchor = self.sw[target]                                   # resetAnchoredPose(.., true): the world value stays
+        fi.anchor = fi.lm.anchor
 
     # ---- GNSS ---------------------------------------------------------------------------------------------------------------
     def callback_gnss_meas(self, stamp, sats):                           # GnssSync::bufferGnssMeas (GnssSync.cpp:27-46)
@@ -803,7 +979,8 @@ class Filter:
         self.propagate_augment_at_end(stamp)
         if self.timestamp < stamp:
             return None
-        tr = dict(stamp=stamp)
+        tr = dict(stamp=stamp, lm_upd_ids=[], lm_upd_acc=[], lm_init_ids=[])
+        lm_before = set(self.landmarks)
         self.collect_meas(feats)
         self.remove_lost_update(tr)
         tr["marg_stamps"] = []
@@ -816,11 +993,16 @@ class Filter:
                 self.selected_update(sel, 2, tr)                         # KeyframeUpdate.cpp:675-676: dof 2
             else:
                 tr.update(sel_stamps=[], sel_ids=[], sel_acc=[], sel_rows=0)
+            if self.max_lm > 0:                                          # IngvioFilter.cpp:283-289
+                self.update_landmarks(tr)
+                self.init_new_landmarks(tr)
             kfs = self.get_marg_kfs()
             self.clean_obs(kfs, tr)                                      # cleanStereoObsAtMargTime
             kfs = self.get_marg_kfs()
             if kfs:
                 self.change_anchor(kfs, 0.3, tr)                         # changeMSCKFAnchor, body.z() <= 0.3
+            if self.max_lm > 0:                                          # :295-301
+                self.change_landmark_anchor(self.get_marg_kfs())
             kfs = self.get_marg_kfs()
             for t in kfs:                                                # margSwPose
                 self.marg_sw_pose(t)
@@ -832,12 +1014,18 @@ class Filter:
                 self.selected_update(sel, len(sel) - 1, tr)              # SwMargUpdate.cpp:306-307
             else:
                 tr.update(sel_stamps=[], sel_ids=[], sel_acc=[], sel_rows=0)
+            if self.max_lm > 0:                                          # :309-315
+                self.update_landmarks(tr)
+                self.init_new_landmarks(tr)
             marg_time = self.next_marg_time()
             if marg_time != INF:
                 self.clean_obs([marg_time], tr)
             marg_time = self.next_marg_time()
             if marg_time != INF and marg_time in self.sw:
                 self.change_anchor([marg_time], 0.0, tr)                 # body.z() <= 0
+            marg_time = self.next_marg_time()
+            if self.max_lm > 0 and marg_time != INF and marg_time in self.sw:      # :321-322
+                self.change_landmark_anchor([marg_time])
             marg_time = self.next_marg_time()
             if marg_time != INF:
                 self.marg_sw_pose(marg_time)
@@ -852,6 +1040,10 @@ class Filter:
         e = self.ext_pose
         tr["pose"] = np.concatenate([e.R.reshape(-1), e.p, e.v, self.bg.p, self.ba.p, self.extr.R.reshape(-1), self.extr.p])
         tr["gnss_vals"] = np.array([self.gnss[t6].s if t6 in self.gnss else np.nan for t6 in range(6)])      # GPS GLO GAL BDS FS YOF
+        # in-state landmarks after the frame (ascending id), their world positions, and what left the state during the frame
+        tr["lm_ids"] = sorted(self.landmarks)
+        tr["lm_vals"] = np.concatenate([self.landmarks[i].p for i in tr["lm_ids"]]) if self.landmarks else np.zeros(0)
+        tr["lm_marg_ids"] = sorted((lm_before | set(tr["lm_init_ids"])) - set(self.landmarks))
         P = self.cov.P
         tr["n"] = int(P.shape[0])
         tr["diag"] = np.diag(P).copy()
@@ -861,8 +1053,9 @@ class Filter:
 
 
 LIST_KEYS_INT = ["lost_ids", "lost_direct", "lost_acc", "sel_ids", "sel_acc", "clean_erased", "anchor_erased", "anchor_moved",
-                 "invalid_erased", "map_ids", "gnss_keep", "gnss_added"]
-LIST_KEYS_F64 = ["sel_stamps", "marg_stamps", "sw_stamps", "diag", "gnss_vals"]
+                 "invalid_erased", "map_ids", "gnss_keep", "gnss_added", "lm_upd_ids", "lm_upd_acc", "lm_init_ids", "lm_ids", "lm_marg_ids"]
+LIST_KEYS_F64 = ["sel_stamps", "marg_stamps", "sw_stamps", "diag", "gnss_vals", "lm_vals"]
+OPTIONAL_KEYS = ("lm_upd_ids", "lm_upd_acc", "lm_init_ids", "lm_ids", "lm_marg_ids", "lm_vals")      # absent from the golden files of rounds 4-5 (no landmarks)
 SCALAR_KEYS = ["stamp", "lost_rows", "sel_rows", "n", "norm", "gnss_rows", "gnss_epoch"]
 
 
@@ -890,6 +1083,9 @@ def unpack_traces(z):
     for f in range(nf):
         t = {}
         for k in LIST_KEYS_INT + LIST_KEYS_F64:
+            if k in OPTIONAL_KEYS and k not in z:
+                t[k] = np.zeros(0, dtype=np.int64 if k in LIST_KEYS_INT else np.float64)
+                continue
             o = z[k + "_off"]
             t[k] = z[k][o[f]:o[f + 1]]
         o = z["table_off"]

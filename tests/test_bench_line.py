@@ -72,29 +72,29 @@ COUNTERS = {"k_feat_gate5": {"SQ_INSTS_VALU_ADD_F64": 1e6, "SQ_INSTS_VALU_MUL_F6
                              "SQ_ACTIVE_INST_VALU": 1.5e8, "_launches_per_step": 1},
             "k_info_solve": {"SQ_INSTS_VALU_ADD_F64": 1e5, "SQ_INSTS_VALU_MUL_F64": 1e5, "SQ_INSTS_VALU_FMA_F64": 1e6, "SQ_INSTS_VALU_MFMA_MOPS_F64": 1e6,
                              "_launches_per_step": 1}}
-PROF = {"k_feat_gate3": (0.2 * 20, 20), "k_info_update": (0.08 * 3, 3), "k_never_ran": (0.0, 0)}
+PROF = {"gate": (0.2 * 20, 20), "solve": (0.08 * 3, 3), "k_never_ran": (0.0, 0)}
 
 
 def price(rec_build):
-    return bench.price_kernels(PROF, "k_feat_gate3", COUNTERS, "profiles/counters.json[test]", rec_build, LIVE, 11, 512,
-                               {"k_feat_gate3": 9.6e7}, {})
+    return bench.price_kernels(PROF, "gate", COUNTERS, "profiles/counters.json[test]", rec_build, LIVE, 11, 512,
+                               {"gate": 9.6e7}, {})
 
 
 def test_counters_of_the_running_build_price_the_kernel():
     kernels, rl = price(dict(LIVE["tu"]))
-    assert rl["kernel"] == "k_feat_gate5<11>" and rl["stage"] == "k_feat_gate3"        # the kernel rocprofv3 sees, not the stage slot
+    assert rl["kernel"] == "k_feat_gate5<11>" and rl["stage"] == "gate"        # the kernel rocprofv3 sees, not the stage slot
     ex = 64.0 * (1e6 + 2e6 + 1e5 + 2 * 3e7) + 512.0 * 4e6
     assert abs(rl["achieved"] - ex / 0.2e-3 / 1e12) < 1e-9 and abs(rl["frac"] - rl["achieved"] / 78.6) < 1e-12
     assert rl["traffic"] == 2 * 1024 * 1000.0 + 1024 * 500.0 and not rl.get("counters_stale")
-    assert "k_never_ran" not in kernels and kernels["k_info_update"]["kernel"] == "k_info_solve"
+    assert "k_never_ran" not in kernels and kernels["solve"]["kernel"] == "k_info_solve"
 
 
 def test_flipped_hash_gives_no_fraction():
     rec = dict(LIVE["tu"]); rec["kernels_factored.hip"] = "0000"                        # the gate was rebuilt after the PMC passes
     kernels, rl = price(rec)
     assert rl["frac"] is None and rl["achieved"] is None and rl["counters_stale"] is True and rl["traffic"] is None
-    assert kernels["k_feat_gate3"]["counters_stale"] == ["k_feat_gate5"] and "executed_tflops" not in kernels["k_feat_gate3"]
-    assert "executed_tflops" in kernels["k_info_update"]                                # another translation unit: still current
+    assert kernels["gate"]["counters_stale"] == ["k_feat_gate5"] and "executed_tflops" not in kernels["gate"]
+    assert "executed_tflops" in kernels["solve"]                                # another translation unit: still current
     line = bench.compact_line(dict(canned(), roofline=rl))
     assert json.loads(line)["roofline"]["frac"] is None and json.loads(line)["roofline"]["counters_stale"] is True
 
@@ -102,9 +102,9 @@ def test_flipped_hash_gives_no_fraction():
 def test_counters_of_another_gate_generation_are_not_used():
     """Counters of k_feat_gate4 say nothing about k_feat_gate5 (the kernel a <= 11-clone stereo window runs): unpriced, named right."""
     old = {"k_feat_gate4": COUNTERS["k_feat_gate5"], "k_info_solve": COUNTERS["k_info_solve"]}
-    kernels, rl = bench.price_kernels(PROF, "k_feat_gate3", old, "x", dict(LIVE["tu"]), LIVE, 11, 512, {"k_feat_gate3": 9.6e7}, {})
+    kernels, rl = bench.price_kernels(PROF, "gate", old, "x", dict(LIVE["tu"]), LIVE, 11, 512, {"gate": 9.6e7}, {})
     assert rl["kernel"] == "k_feat_gate5<11>" and rl["frac"] is None
-    kernels16, rl16 = bench.price_kernels(PROF, "k_feat_gate3", old, "x", dict(LIVE["tu"]), LIVE, 16, 512, {"k_feat_gate3": 9.6e7}, {})
+    kernels16, rl16 = bench.price_kernels(PROF, "gate", old, "x", dict(LIVE["tu"]), LIVE, 16, 512, {"gate": 9.6e7}, {})
     assert rl16["kernel"] == "k_feat_gate4<16>" and rl16["frac"] is not None
 
 

@@ -20,16 +20,20 @@ TOOL = os.path.join(ROOT, "ingvio_amd", "lib", "ingvio_replay")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 STREAMS = ["kf11", "kf11_lifted", "sw11", "kf21", "sw21", "kf11_mono", "sw11_mono",      # mono: the MONO callback (BASELINE configs[0])
            "sw11_gnss", "kf11_gnss",                                                       # raw GNSS epochs in the callback (BASELINE configs[2])
+           "sw11_lm", "kf11_lm", "sw11_lm_mono",      # in-state SLAM landmarks: delayed initialisation, landmark update, anchor change (SURVEY 8f row f-2 as a stream)
            "kf27", "kf35_mono"]      # the windows and parameter values the reference SHIPS (config/sportsfield/ingvio_stereo.yaml / ingvio_mono.yaml)
 SHIPPED = ("kf27", "kf35_mono")      # visual_noise 0.18: the synthetic +0.5 outliers mostly pass the gate there - pinned as they come
 POSE_TOL = 1e-9
 COV_TOL = 1e-6
+LM_TOL = 1e-7        # world positions of in-state landmarks (2 - 20 m away): they start from the triangulator's iterate, which stops at
+                     # conv_precision 5e-7 on the cost (Triangulator.cpp:262-270) - two FP64 evaluations of it agree to ~1e-8 m
 
 INT_TAGS = {"LOST_IDS": "lost_ids", "LOST_ACC": "lost_acc", "LOST_DIRECT": "lost_direct", "SEL_IDS": "sel_ids", "SEL_ACC": "sel_acc",
             "CLEAN_ERASED": "clean_erased", "ANCHOR_ERASED": "anchor_erased", "ANCHOR_MOVED": "anchor_moved", "INVALID_ERASED": "invalid_erased",
-            "MAP_IDS": "map_ids", "TABLE": "table", "GNSS_KEEP": "gnss_keep"}
+            "MAP_IDS": "map_ids", "TABLE": "table", "GNSS_KEEP": "gnss_keep",
+            "LM_UPD_IDS": "lm_upd_ids", "LM_UPD_ACC": "lm_upd_acc", "LM_INIT_IDS": "lm_init_ids", "LM_IDS": "lm_ids", "LM_MARG_IDS": "lm_marg_ids"}
 F64_TAGS = {"SEL_STAMPS": "sel_stamps", "MARG_STAMPS": "marg_stamps", "SW_STAMPS": "sw_stamps", "POSE": "pose", "DIAG": "diag",
-            "GNSS_VALS": "gnss_vals"}
+            "GNSS_VALS": "gnss_vals", "LM_VALS": "lm_vals"}
 SCALAR_TAGS = {"LOST_ROWS": "lost_rows", "SEL_ROWS": "sel_rows", "NORM": "norm", "GNSS_ROWS": "gnss_rows", "GNSS_ADDED_TOTAL": "gnss_added_total"}
 
 
@@ -81,6 +85,11 @@ def compare(gold, got, pose_tol=POSE_TOL, cov_tol=COV_TOL):
                 bad.append("%s: %s differs: golden %s shim %s" % (tag, k, np.asarray(g[k]).tolist(), s[k].tolist()))
         if not np.array_equal(np.asarray(g["table"], dtype=np.int64).reshape(-1, 2), s["table"]):
             bad.append("%s: (idx, size) table differs" % tag)
+        # in-state SLAM landmarks: which ones the update evaluated and accepted, which ones the delayed initialisation added, which ones
+        # are in the state after the frame and which ones left it
+        for k in ("lm_upd_ids", "lm_upd_acc", "lm_init_ids", "lm_ids", "lm_marg_ids"):
+            if k in s and not np.array_equal(np.asarray(g[k], dtype=np.int64), s[k]):
+                bad.append("%s: %s differs: golden %s shim %s" % (tag, k, np.asarray(g[k]).tolist(), s[k].tolist()))
         # the GNSS block: rows handed to ekfUpdate, which candidate rows passed their gates, how many variables the delayed
         # initialisations have added so far, which GNSS scalars exist
         added_total += len(g["gnss_added"])
@@ -110,6 +119,11 @@ def compare(gold, got, pose_tol=POSE_TOL, cov_tol=COV_TOL):
             worst["gnss"] = max(worst["gnss"], dg)
             if dg > pose_tol:
                 bad.append("%s: GNSS scalars off by %.3e" % (tag, dg))
+        if "lm_vals" in s and len(s["lm_vals"]):
+            dl = float(np.max(np.abs(np.asarray(g["lm_vals"]) - s["lm_vals"])))
+            worst["lm"] = max(worst.get("lm", 0.0), dl)
+            if dl > LM_TOL:
+                bad.append("%s: landmark positions off by %.3e" % (tag, dl))
         if dp > pose_tol:
             bad.append("%s: nominal state off by %.3e" % (tag, dp))
         if dd > cov_tol or dn > cov_tol:
@@ -161,10 +175,14 @@ def test_golden_streams_cover_the_policies():
         n = np.array([t["n"] for t in tr])
         clones = int(spec.split("clones=")[1].split(",")[0])
         n_gnss = 5 if "gnss=1" in spec else 0                              # YOF, FS and three clock biases
-        assert n.max() == 21 + n_gnss + 6 * (clones - (1 if key else 0)), (name, n.max())       # state size after the frame's marginalisation
+        n_lm = int(ov.split("max_landmark_features:")[1].split()[0]) if "max_landmark_features" in ov else 0
+        assert n.max() == 21 + n_gnss + 3 * n_lm + 6 * (clones - (1 if key else 0)), (name, n.max())       # state size after the frame's marginalisation
     assert max(int(np.sum(t["lost_acc"])) for t in load_golden("kf11")[0]) == 20          # RemoveLostUpdate.h:38
     assert max(int(np.sum(t["lost_acc"])) for t in load_golden("kf11_lifted")[0]) > 60
     assert seen["kf11"]["moved"] > 0 and seen["kf21"]["erased"] > 0 and seen["sw11"]["moved"] > 0
+    tr = load_golden("sw11_lm")[0]                                        # the landmark life cycle happened: initialised, updated every frame, lost / re-anchored, full state
+    assert sum(len(t["lm_init_ids"]) for t in tr) >= 20 and sum(len(t["lm_marg_ids"]) for t in tr) >= 15
+    assert max(len(t["lm_ids"]) for t in tr) == 6 and sum(int(np.sum(t["lm_upd_acc"])) for t in tr) > 150
     for name in ("sw11_gnss", "kf11_gnss"):                               # the GNSS block did its three things
         tr = load_golden(name)[0]
         assert tr[0]["gnss_added"].tolist() == [4, 0, 2, 3]              # FS, GPS, GAL, BDS by delayed initialisation at the first aligned epoch
@@ -219,8 +237,8 @@ def test_shim_stream_matches_golden(name):
     gold, spec, ov = load_golden(name)
     got = run_shim(spec, ov)
     bad, worst = compare(gold, got)
-    print("stream %s: %d frames, largest deviation: nominal state %.2e, diag(P) %.2e rel, |P|_F %.2e rel, GNSS scalars %.2e rel"
-          % (name, len(got), worst["pose"], worst["diag"], worst["norm"], worst["gnss"]))
+    print("stream %s: %d frames, largest deviation: nominal state %.2e, diag(P) %.2e rel, |P|_F %.2e rel, GNSS scalars %.2e rel, landmarks %.2e"
+          % (name, len(got), worst["pose"], worst["diag"], worst["norm"], worst["gnss"], worst.get("lm", 0.0)))
     assert not bad, "\n".join(bad[:10])
 
 
@@ -254,6 +272,16 @@ def test_shim_in_sliding_window_mode_goes_red_on_the_shipped_mono_stream():
     got = run_shim(spec, ov, extra=["is_key_frame: 0"])
     bad, _ = compare(gold, got)
     assert bad and any(k in " ".join(bad) for k in ("marg_stamps", "sel_stamps", "sel_ids", "table")), bad[:3]
+
+
+@needs_tool
+@pytest.mark.gpu
+def test_shim_with_fewer_landmark_slots_goes_red():
+    """sw11_lm was made with max_landmark_features 6; the shim with 4 slots initialises fewer landmarks: red at the ids in the state."""
+    gold, spec, ov = load_golden("sw11_lm")
+    got = run_shim(spec, ov, extra=["max_landmark_features: 4"])
+    bad, _ = compare(gold, got)
+    assert bad and any(k in " ".join(bad) for k in ("lm_init_ids", "lm_ids", "table")), bad[:3]
 
 
 @needs_tool

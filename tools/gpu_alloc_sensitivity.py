@@ -21,5 +21,5 @@ for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
     ctx.sync(); ctx.profile_enable(False)
     prof = ctx.profile_get()
     ms = lambda k: prof[k][0] / max(prof[k][1], 1) if k in prof else float("nan")
-    print("trial %d  gate %.4f ms  gram %.4f  solve %.4f  apply %.4f" % (trial, ms("k_feat_gate3"), ms("k_feat_gram2"), ms("k_info_update"), ms("k_info_apply")), flush=True)
+    print("trial %d  gate %.4f ms  gram %.4f  solve %.4f  apply %.4f" % (trial, ms("gate"), ms("gram"), ms("solve"), ms("apply")), flush=True)
     ctx.close()

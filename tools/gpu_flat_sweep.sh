@@ -10,7 +10,7 @@ for B in 64 128 256; do
     python - $B $lib <<'PY'
 import json, sys
 a = json.load(open("gpurun_out/few/bb.json")); d = json.load(open("gpurun_out/few/dd.json"))
-print("B", sys.argv[1], sys.argv[2], "ms/step", a["ms_per_step"], "apply us", round(1e3 * d["kernels"]["k_info_apply"]["avg_ms"], 1), "solve us", round(1e3 * d["kernels"]["k_info_update"]["avg_ms"], 1))
+print("B", sys.argv[1], sys.argv[2], "ms/step", a["ms_per_step"], "apply us", round(1e3 * d["kernels"]["apply"]["avg_ms"], 1), "solve us", round(1e3 * d["kernels"]["solve"]["avg_ms"], 1))
 PY
   done
 done

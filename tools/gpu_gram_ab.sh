@@ -10,6 +10,6 @@ python - $v <<'PY'
 import json, sys
 v = sys.argv[1]
 d = json.load(open("gpurun_out/gab_line_%s.json" % v)); k = json.load(open("gpurun_out/gab_%s.json" % v))["kernels"]
-print(v, "ms/step", round(d["ms_per_step"], 4), "gram us", round(1e3 * k["k_feat_gram2"]["avg_ms"], 1), "gate us", round(1e3 * k["k_feat_gate3"]["avg_ms"], 1))
+print(v, "ms/step", round(d["ms_per_step"], 4), "gram us", round(1e3 * k["gram"]["avg_ms"], 1), "gate us", round(1e3 * k["gate"]["avg_ms"], 1))
 PY
 done; done

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
+#include <set>
 #include <string>
 
 #include "../ingvio_amd/csrc/host/Replay.h"
@@ -84,6 +85,25 @@ static void printTrace(int k, ingvio::IngvioFilter& f, bool keyframe)
         std::vector<double> gv;
         for (int t = 0; t < 6; ++t) { auto it = state->_gnss.find(t); gv.push_back(it != state->_gnss.end() ? it->second->value() : std::nan("")); }
         printDoubles("GNSS_VALS", gv);
+    }
+    // in-state SLAM landmarks (max_landmark_features > 0): what the update evaluated and accepted, what the delayed initialisation added, the
+    // landmarks in the state after the frame (ascending id) with their world positions, and what left the state during the frame
+    {
+        static std::set<int> lm_prev;
+        const auto& lu = *f.landmarkUpdate();
+        printInts("LM_UPD_IDS", lu.lastUpdateIds()); printInts("LM_UPD_ACC", lu.lastUpdateAccepted()); printInts("LM_INIT_IDS", lu.lastInitIds());
+        std::vector<int> ids;
+        for (const auto& it : state->_anchored_landmarks) ids.push_back(it.first);
+        std::sort(ids.begin(), ids.end());
+        std::vector<double> vals;
+        for (int id : ids) { const Vec3d p = state->_anchored_landmarks.at(id)->valuePosXyz(); vals.insert(vals.end(), p.v, p.v + 3); }
+        printInts("LM_IDS", ids); printDoubles("LM_VALS", vals);
+        std::set<int> had = lm_prev;
+        for (int id : lu.lastInitIds()) had.insert(id);
+        std::vector<int> gone;
+        for (int id : had) if (!std::binary_search(ids.begin(), ids.end(), id)) gone.push_back(id);
+        printInts("LM_MARG_IDS", gone);
+        lm_prev = std::set<int>(ids.begin(), ids.end());
     }
     std::vector<int> table;
     for (const auto& v : StateManager::errVariables(state)) { table.push_back(v->idx()); table.push_back(v->size()); }
