@@ -651,13 +651,18 @@ def run_workload(args, grp, aux=False):
             for _ in range(5):
                 st_sync(); ctx.frame_run(restore_prior=True); ctx.frame_fetch()
             t_serial = (time.perf_counter() - t0) / 5
-            st_async()
-            for _ in range(3):
-                ctx.frame_run(restore_prior=True); st_async(); ctx.frame_fetch()
+            def pipelined(stage_call, n):
+                """run(i); fetch_begin(i); stage_async(i + 1); run(i + 1); fetch_end(i): the result copies of frame i sit in front of frame
+                i + 1's kernels, the host packs and unpacks while the device computes (round 6: fetch in two halves)"""
+                stage_call(); ctx.frame_run(restore_prior=True)
+                for _ in range(n):
+                    ctx.frame_fetch_begin(); stage_call(); ctx.frame_run(restore_prior=True); res = ctx.frame_fetch_end()
+                ctx.frame_fetch()
+                return res
+            pipelined(st_async, 3)
             t0 = time.perf_counter()
-            for _ in range(10):
-                ctx.frame_run(restore_prior=True); st_async(); ctx.frame_fetch()
-            t_pipe = (time.perf_counter() - t0) / 10
+            pipelined(st_async, 10)
+            t_pipe = (time.perf_counter() - t0) / 11
             ctx.sync()
             in_bytes = sum(np.asarray(v).nbytes for v in frames[0].values() if hasattr(v, "nbytes")) + \
                 sum(np.asarray(v).nbytes for v in steps[0].values() if hasattr(v, "nbytes"))
@@ -666,11 +671,37 @@ def run_workload(args, grp, aux=False):
                 try:                                      # one PROCESS per stager, as ranks are (the threaded variant: tests/test_gpu_stagers.py)
                     stg = stagers_rate_processes(8, 64, reps=20)
                     stg["host_threads"] = os.cpu_count()
+                    stg["tracks"] = stagers_rate_processes(8, 64, reps=20, mode="tracks")["aggregate_updates_per_s"]
                 except Exception as e:                    # auxiliary figure: never takes the bench line down
                     stg = dict(error=str(e)[-200:])
-            handover = dict(serial_updates_per_s=B / t_serial, pipelined_updates_per_s=B / t_pipe, input_bytes_per_update=in_bytes, stagers8=stg,
+            # the same hand-over as a DELTA on the device-resident track store (round 6): one new column per frame + the track list + raw IMU
+            trk = None
+            try:
+                ref_dx, ref_acc, _ = (ctx.frame_run(restore_prior=True), ctx.frame_fetch())[1]
+                tk_sync, tk_bytes = tracks_handover_prepare(ctx, steps, frames, sg, False, kw)
+                for _ in range(3):
+                    tk_sync(); ctx.frame_run(restore_prior=True); dxt, acct, _r = ctx.frame_fetch()
+                same = bool(np.array_equal(acct, ref_acc) and np.linalg.norm(dxt - ref_dx) <= 1e-9 * np.linalg.norm(ref_dx))
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    tk_sync(); ctx.frame_run(restore_prior=True); ctx.frame_fetch()
+                t_tser = (time.perf_counter() - t0) / 5
+                tk_async, _ = tracks_handover_prepare(ctx, steps, frames, sg, True, kw)
+                pipelined(tk_async, 3)
+                t0 = time.perf_counter()
+                dxp, accp, _r = pipelined(tk_async, 10)
+                t_tpipe = (time.perf_counter() - t0) / 11
+                same = same and bool(np.array_equal(accp, ref_acc) and np.linalg.norm(dxp - ref_dx) <= 1e-9 * np.linalg.norm(ref_dx))
+                ctx.sync()
+                trk = dict(serial_updates_per_s=B / t_tser, pipelined_updates_per_s=B / t_tpipe, input_bytes_per_update=tk_bytes,
+                           same_result_as_staged_frame=same,
+                           note="ingvio_frame_stage_tracks: observations stay on the device, a frame = the new clone's column + window / track "
+                                "bookkeeping + the track list of the update + raw IMU samples (Phi / G formed on the device)")
+            except Exception as e:
+                trk = dict(error=str(e)[-300:])
+            handover = dict(serial_updates_per_s=B / t_serial, pipelined_updates_per_s=B / t_pipe, input_bytes_per_update=in_bytes, stagers8=stg, tracks=trk,
                             note="host buffers -> pinned slab (8 host threads) -> PCIe -> run -> dx/accept back; pipelined = copy "
-                                 "stream + second device input set (ingvio_frame_stage_async); auxiliary, `value` is device-resident")
+                                 "stream + second device input set (ingvio_frame_stage_async) + the fetch in two halves (ingvio_frame_fetch_begin / _end); auxiliary, `value` is device-resident")
         updates = B * world * args.steps
         step_desc = ("propagate(k=10)+clone+MSCKF update" + ("+landmark update (%d in-state landmarks, per-landmark chi2 gates)" % n_lm_real if real_lm else "")
                      + "+marginalise" + (("+GNSS update (8 sats, per-row chi2 gates, %s)" % ("separate pass" if args.gnss_separate else "in-frame: one sweep over P"))
@@ -765,6 +796,32 @@ def stagers_rate(n_stagers=8, filters_each=64, F=150, C=11, n_gnss=6, n_lm=52, r
                 concurrent_equals_alone=same, results_finite=finite, host_threads=os.cpu_count())
 
 
+def tracks_handover_prepare(ctx, steps, frames, sigma_args, use_async, kw):
+    """Device-resident track store (ingvio_tracks_create / ingvio_frame_stage_tracks): fills the store with the batch's frames column by
+    column (one delta per window slot, the points with the last one), then returns (steady-state call, input bytes per update).  The
+    steady-state frame is what a running filter sends: the newest window slot leaves and arrives again with its column (one measurement
+    per track), the clone table, the list of tracks the update uses, the raw IMU samples - the store and therefore the staged frame are
+    the same after every call, so the step computes what the fully staged frame computes (checked by the caller).  The points are NOT
+    re-sent: in a running filter they are the device's own triangulation results (ingvio_msckf_update_tri)."""
+    B = len(steps)
+    F, C = np.asarray(frames[0]["uv"]).shape[:2]
+    ctx.tracks_create(F)
+    base = [dict(clone_idx=fr["clone_idx"], clone_R=fr["clone_R"], clone_p=fr["clone_p"], feat_track=[], feat_anchor=[], feat_dof=[]) for fr in frames]
+    tracks = np.arange(F, dtype=np.int32)
+
+    def col(fr, s, **extra):
+        return dict(append=s, obs_track=tracks, obs_uv=np.ascontiguousarray(np.asarray(fr["uv"])[:, s, :]), **extra)
+    for s in range(C):
+        last = s == C - 1
+        tfs = [dict(base[b], **col(frames[b], s, **(dict(pf_track=tracks, pf=frames[b]["pf"]) if last else {}))) for b in range(B)]
+        ctx.frame_stage_tracks_prepare(0, steps, tfs, frames[0], *sigma_args, **kw)()
+    tfs = [dict(base[b], drop=[C - 1], feat_track=tracks, feat_anchor=frames[b]["anchor"], feat_dof=frames[b]["dof"], **col(frames[b], C - 1)) for b in range(B)]
+    call = ctx.frame_stage_tracks_prepare(0, steps, tfs, frames[0], *sigma_args, use_async=use_async, **kw)
+    k = len(steps[0]["dt"])
+    nbytes = 4 * (32 + 1 + F + C + F + 5) + 8 * (4 * F + 12 * C + 7 * k + 24)      # header + ints + doubles of one filter's delta (capi.hip: ingvio_frame_stage_tracks)
+    return call, nbytes
+
+
 def _stager_child():
     """One stager PROCESS of stagers_rate_processes(): builds its own 64-filter context, reports READY, waits for the common start
     time on stdin, runs the pipelined hand-over loop and prints its own start / end wall-clock times."""
@@ -776,8 +833,12 @@ def _stager_child():
     ctx = capi.Context(batch=n_f, n_max=((N + 15) // 16) * 16, c_max=C, f_max=F, m_max=64, device=int(os.environ.get("INGVIO_DEVICE", "0")))
     filters, steps, frames, infos = build_batch(ctx, n_f, 4000 + 97 * i, F, C, n_gnss, n_lm)
     ctx.snapshot()
-    st = ctx.frame_stage_prepare(0, steps, frames, filters[0].sigma(), filters[0].enable_gnss, pr["sigma_cb"], pr["sigma_rw"], max_accept=0,
-                                 compress_rule=1, use_async=True)
+    if len(sys.argv) > 5 and sys.argv[5] == "tracks":      # the hand-over as a delta on the device-resident track store
+        st, _ = tracks_handover_prepare(ctx, steps, frames, (filters[0].sigma(), filters[0].enable_gnss, pr["sigma_cb"], pr["sigma_rw"]), True,
+                                        dict(max_accept=0, compress_rule=1))
+    else:
+        st = ctx.frame_stage_prepare(0, steps, frames, filters[0].sigma(), filters[0].enable_gnss, pr["sigma_cb"], pr["sigma_rw"], max_accept=0,
+                                     compress_rule=1, use_async=True)
     st()
     for _ in range(3):
         ctx.frame_run(restore_prior=True); st(); ctx.frame_fetch()
@@ -787,20 +848,22 @@ def _stager_child():
     while time.time() < t_start:
         pass
     t0 = time.time()
-    for _ in range(reps):
-        ctx.frame_run(restore_prior=True); st(); dx, acc, rows = ctx.frame_fetch()
+    ctx.frame_run(restore_prior=True)
+    for _ in range(reps - 1):
+        ctx.frame_fetch_begin(); st(); ctx.frame_run(restore_prior=True); dx, acc, rows = ctx.frame_fetch_end()
+    dx, acc, rows = ctx.frame_fetch()
     ctx.sync()
     t1 = time.time()
     print(json.dumps(dict(t0=t0, t1=t1, finite=bool(np.isfinite(dx).all()), accepted=float(acc.sum()) / n_f)), flush=True)
     ctx.close()
 
 
-def stagers_rate_processes(n_stagers=8, filters_each=64, reps=20):
+def stagers_rate_processes(n_stagers=8, filters_each=64, reps=20, mode="frames"):
     """The same hand-over loop as stagers_rate() with one PROCESS per stager - what `torchrun --nproc-per-node 8` ranks of one host
     are: own interpreter, own HIP runtime, own copy queues - all on GPU 0 here (a one-GPU box), started together.  Aggregate =
     all staged updates / (last end - first start)."""
     import subprocess
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--stager-child", str(i), str(filters_each), str(reps)], stdin=subprocess.PIPE,
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--stager-child", str(i), str(filters_each), str(reps), mode], stdin=subprocess.PIPE,
                               stdout=subprocess.PIPE, text=True, cwd=ROOT) for i in range(n_stagers)]
     try:
         for p in procs:
@@ -968,6 +1031,10 @@ def compact_line(full):
         s8 = hh.get("stagers8") or {}
         h["stagers8_aggregate_updates_per_s"] = s8.get("aggregate_updates_per_s")
         h["stagers8_host_threads"] = s8.get("host_threads")
+        tk = hh.get("tracks") or {}      # the hand-over as a delta on the device-resident track store (round 6)
+        h["tracks"] = dict(serial=tk.get("serial_updates_per_s"), pipelined=tk.get("pipelined_updates_per_s"), bytes_per_update=tk.get("input_bytes_per_update"),
+                           same_result=tk.get("same_result_as_staged_frame"), stagers8_aggregate=s8.get("tracks"), error=tk.get("error"))
+        h["bytes_per_update"] = hh.get("input_bytes_per_update")
         out["host_handover"] = h
     out["detail"] = "bench_detail.json (per-kernel table, notes, host hand-over, as-written cap-20 figures)"
     line = json.dumps(_rnd(out))

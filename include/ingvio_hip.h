@@ -430,6 +430,43 @@ int ingvio_frame_stage(ingvio_ctx* ctx, int b0, int nb, const ingvio_frame_step*
 int ingvio_frame_stage_async(ingvio_ctx* ctx, int b0, int nb, const ingvio_frame_step* steps,
                              const ingvio_msckf_frame* frames, const ingvio_msckf_opts* opts,
                              const double sigma[4], int enable_gnss, double sigma_cb, double sigma_rw);
+/* ---- device-resident track store: the frame hand-over as a DELTA (round 6) -------------------------------------------------
+ * The reference's MapServer gains ONE observation per live feature per camera frame (MapServerManager::collectStereoMeas,
+ * MapServerManager.cpp:146-217) and forgets the observations of the clones that leave the window (KeyframeUpdate::
+ * cleanStereoObsAtMargTime, KeyframeUpdate.cpp:737-761; SwMargUpdate.cpp:425-446); ingvio_frame_stage re-sends every filter's whole
+ * [F][C][4] measurement array and its k transition matrices with every frame (61 KB per update at 150 features x 11 clones, k = 10).
+ * With a track store the observations of every live track stay on the device (uv [t_max][c_max][4], a 64-bit observation mask and
+ * the triangulated point per track and filter), and a frame travels as
+ *   - the delta on the store, applied in this order: window slots that leave (the tracks' rows close up), tracks that were erased,
+ *     the new clone's column (one measurement per observed track), points that changed;
+ *   - the frame the update uses: the clone table and, per feature, its track, anchor slot, dof and - for the Selected-timestamp
+ *     updates (SwMargUpdate.cpp:236-257) - a mask ANDed onto the stored one;
+ *   - the raw IMU samples of the frame and the nominal state at its start: ImuPropagator::stateAndCovTransition
+ *     (ImuPropagator.cpp:98-162, analytic branch) runs on the device (Phi, G, dt and the clone rotation never cross the bus);
+ * about 7.6 KB per update for the same frame.  ingvio_frame_stage_tracks leaves the context exactly as ingvio_frame_stage(_async) does:
+ * ingvio_frame_run / ingvio_frame_fetch follow.  Slot and track numbers are the CALLER's bookkeeping (the shim's MapServer); tracks
+ * are numbered 0 .. t_max - 1 (t_max <= 65536), anchor slots and dof fit a byte. */
+typedef struct {
+    int n_drop; const int* drop_slots;            /* window slots leaving the window, ascending (before the append)              */
+    int n_free; const int* free_tracks;           /* erased features: the track's observations are forgotten                     */
+    int append_slot;                              /* window slot of the frame's new clone, -1: no new column                     */
+    int n_obs; const int* obs_track; const double* obs_uv;      /* [n_obs], [n_obs][4] (mono: first two)                            */
+    int n_pf; const int* pf_track; const double* pf;            /* [n_pf], [n_pf][3] points that changed                            */
+    int n_clones; const int* clone_idx; const double* clone_R; const double* clone_p;      /* as ingvio_msckf_frame                */
+    int n_feat; const int* feat_track; const int* feat_anchor; const int* feat_dof;
+    const unsigned long long* feat_sel;           /* [n_feat] or NULL: every stored observation of the track takes part          */
+} ingvio_track_frame;
+typedef struct {
+    int k;                        /* IMU steps (the same for every filter of a call)                                              */
+    const double* imu;            /* [k][7] gyro (3), accel (3), dt of each step, as ImuPropagator::propagateUntil forms them     */
+    double R[9], p[3], v[3], bg[3], ba[3], gravity[3];      /* State::_extended_pose (row-major R), biases, gravity at the frame's start */
+    int gnss_idx[5];
+    int marg_idx;                 /* idx of the clone to marginalise afterwards, -1: none                                        */
+} ingvio_frame_step_raw;
+int ingvio_tracks_create(ingvio_ctx* ctx, int t_max);             /* allocates (or clears) the store: every track empty            */
+int ingvio_frame_stage_tracks(ingvio_ctx* ctx, int b0, int nb, const ingvio_frame_step_raw* steps, const ingvio_track_frame* frames,
+                              const ingvio_msckf_opts* opts, const double sigma[4], int enable_gnss, double sigma_cb, double sigma_rw,
+                              int async /* != 0: whole batch, on the copy stream into the second input set, as ingvio_frame_stage_async */);
 int ingvio_frame_run(ingvio_ctx* ctx, int restore_prior);
 /* Throughput batches (round 6, an experiment kept selectable): ingvio_frame_run deals the batch to `parts` slices of filters, each
  * on its own HIP stream; the slices' throughput-bound segments (gate + Gram, apply) are chained by events so that only ONE runs at a
@@ -442,6 +479,11 @@ int ingvio_frame_run(ingvio_ctx* ctx, int restore_prior);
  * one thread: IngvioNode.cpp:36).  Environment override at context creation: INGVIO_FRAME_PARTS. */
 int ingvio_set_frame_parts(ingvio_ctx* ctx, int parts);
 int ingvio_frame_fetch(ingvio_ctx* ctx, int b0, int nb, double* dx_out, int* accepted, int* rows_out);
+/* The fetch in two halves (round 6): _begin enqueues the result copies (into pinned memory) behind the frame's kernels and returns;
+ * _end waits for them and fills the caller's arrays.  In between the host may stage and LAUNCH the next frame - its kernels queue up
+ * behind the copies, the device does not idle while the host unpacks:   run(i); fetch_begin(i); stage_async(i+1); run(i+1); fetch_end(i). */
+int ingvio_frame_fetch_begin(ingvio_ctx* ctx, int b0, int nb);
+int ingvio_frame_fetch_end(ingvio_ctx* ctx, double* dx_out, int* accepted, int* rows_out);
 
 /* parity hook (tests): the stacked measurement information of filter b's LAST MSCKF update, A_out [ncol][ncol+1] row-major =
  * [sum_j H_j^T H_j | sum_j H_j^T r_j] over the used features in window-slot column order, ncol = 6 * n_clones (caller provides

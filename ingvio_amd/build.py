@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib")
-HIP_SOURCES = ["kernels_cov.hip", "kernels_msckf.hip", "kernels_ekf.hip", "kernels_factored.hip", "kernels_solve.hip", "kernels_bigwin.hip", "kernels_tri.hip", "kernels_lm.hip", "kernels_qr.hip", "kernels_chol.hip", "kernels_lmbatch.hip", "kernels_lmchol.hip", "kernels_gnss.hip", "capi.hip"]
+HIP_SOURCES = ["kernels_cov.hip", "kernels_msckf.hip", "kernels_ekf.hip", "kernels_factored.hip", "kernels_solve.hip", "kernels_bigwin.hip", "kernels_tri.hip", "kernels_lm.hip", "kernels_qr.hip", "kernels_chol.hip", "kernels_lmbatch.hip", "kernels_lmchol.hip", "kernels_gnss.hip", "kernels_tracks.hip", "capi.hip"]
 HIP_LIB = os.path.join(LIB, "libingvio_hip.so")
 HOST_LIB = os.path.join(LIB, "libingvio_host.so")
 

@@ -25,7 +25,7 @@ EXPORTS = [
     "ingvio_cov_set", "ingvio_cov_get", "ingvio_get_n", "ingvio_cov_get_marginal", "ingvio_cov_snapshot",
     "ingvio_cov_restore", "ingvio_propagate", "ingvio_propagate_fused", "ingvio_augment_clone", "ingvio_marginalize",
     "ingvio_append_independent", "ingvio_ekf_update", "ingvio_chi2_gamma", "ingvio_msckf_update", "ingvio_msckf_update_tri", "ingvio_qr_compress",
-    "ingvio_frame_stage", "ingvio_frame_stage_async", "ingvio_frame_run", "ingvio_set_frame_parts", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_select",
+    "ingvio_frame_stage", "ingvio_frame_stage_async", "ingvio_frame_fetch_begin", "ingvio_frame_fetch_end", "ingvio_tracks_create", "ingvio_frame_stage_tracks", "ingvio_frame_run", "ingvio_set_frame_parts", "ingvio_frame_fetch", "ingvio_profile_enable", "ingvio_profile_select",
     "ingvio_profile_reset",
     "ingvio_profile_get", "ingvio_set_msckf_method", "ingvio_set_qr_method", "ingvio_landmark_stage", "ingvio_landmark_run",
     "ingvio_landmark_fetch", "ingvio_frame_run_phase", "ingvio_info_set", "ingvio_debug_read", "ingvio_triangulate",
@@ -92,6 +92,18 @@ class MsckfOpts(C.Structure):
 class FrameStep(C.Structure):
     _fields_ = [("k", C.c_int), ("Phi", c_dp), ("G", c_dp), ("dt", c_dp), ("gnss_idx", C.c_int * 5),
                 ("R_i2w", C.c_double * 9), ("marg_idx", C.c_int)]
+
+
+class TrackFrame(C.Structure):
+    _fields_ = [("n_drop", C.c_int), ("drop_slots", c_ip), ("n_free", C.c_int), ("free_tracks", c_ip), ("append_slot", C.c_int),
+                ("n_obs", C.c_int), ("obs_track", c_ip), ("obs_uv", c_dp), ("n_pf", C.c_int), ("pf_track", c_ip), ("pf", c_dp),
+                ("n_clones", C.c_int), ("clone_idx", c_ip), ("clone_R", c_dp), ("clone_p", c_dp),
+                ("n_feat", C.c_int), ("feat_track", c_ip), ("feat_anchor", c_ip), ("feat_dof", c_ip), ("feat_sel", c_up)]
+
+
+class FrameStepRaw(C.Structure):
+    _fields_ = [("k", C.c_int), ("imu", c_dp), ("R", C.c_double * 9), ("p", C.c_double * 3), ("v", C.c_double * 3), ("bg", C.c_double * 3),
+                ("ba", C.c_double * 3), ("gravity", C.c_double * 3), ("gnss_idx", C.c_int * 5), ("marg_idx", C.c_int)]
 
 
 _lib = None
@@ -169,6 +181,37 @@ def make_step(step):
     s.k = k; s.Phi = _d(keep["Phi"]); s.G = _d(keep["G"]); s.dt = _d(keep["dt"])
     s.gnss_idx = (C.c_int * 5)(*[int(x) for x in step.get("gnss_idx", (-1,) * 5)])
     s.R_i2w = (C.c_double * 9)(*np.asarray(step["R_i2w"], dtype=np.float64).reshape(9))
+    s.marg_idx = int(step.get("marg_idx", -1))
+    return s, keep
+
+
+def make_track_frame(d):
+    """d: dict(drop=[...], free=[...], append=slot or -1, obs_track, obs_uv [n,4], pf_track, pf [n,3], clone_idx, clone_R, clone_p,
+    feat_track, feat_anchor, feat_dof, feat_sel (optional))"""
+    keep = dict(drop=i32(d.get("drop", [])), free=i32(d.get("free", [])), obs_track=i32(d.get("obs_track", [])), obs_uv=f64(d.get("obs_uv", np.zeros((0, 4)))),
+                pf_track=i32(d.get("pf_track", [])), pf=f64(d.get("pf", np.zeros((0, 3)))), clone_idx=i32(d["clone_idx"]), clone_R=f64(d["clone_R"]),
+                clone_p=f64(d["clone_p"]), feat_track=i32(d["feat_track"]), feat_anchor=i32(d["feat_anchor"]), feat_dof=i32(d["feat_dof"]))
+    f = TrackFrame()
+    f.n_drop = len(keep["drop"]); f.drop_slots = _i(keep["drop"]); f.n_free = len(keep["free"]); f.free_tracks = _i(keep["free"])
+    f.append_slot = int(d.get("append", -1)); f.n_obs = len(keep["obs_track"]); f.obs_track = _i(keep["obs_track"]); f.obs_uv = _d(keep["obs_uv"])
+    f.n_pf = len(keep["pf_track"]); f.pf_track = _i(keep["pf_track"]); f.pf = _d(keep["pf"])
+    f.n_clones = len(keep["clone_idx"]); f.clone_idx = _i(keep["clone_idx"]); f.clone_R = _d(keep["clone_R"]); f.clone_p = _d(keep["clone_p"])
+    f.n_feat = len(keep["feat_track"]); f.feat_track = _i(keep["feat_track"]); f.feat_anchor = _i(keep["feat_anchor"]); f.feat_dof = _i(keep["feat_dof"])
+    if d.get("feat_sel") is not None:
+        keep["feat_sel"] = np.ascontiguousarray(d["feat_sel"], dtype=np.uint64)
+        f.feat_sel = keep["feat_sel"].ctypes.data_as(c_up)
+    return f, keep
+
+
+def make_step_raw(step):
+    raw = step["raw"]
+    keep = dict(imu=f64(raw["imu"]))
+    s = FrameStepRaw()
+    s.k = keep["imu"].shape[0]; s.imu = _d(keep["imu"])
+    s.R = (C.c_double * 9)(*np.asarray(raw["R"], dtype=np.float64).reshape(9))
+    for name in ("p", "v", "bg", "ba", "gravity"):
+        setattr(s, name, (C.c_double * 3)(*np.asarray(raw[name], dtype=np.float64).reshape(3)))
+    s.gnss_idx = (C.c_int * 5)(*[int(x) for x in step.get("gnss_idx", (-1,) * 5)])
     s.marg_idx = int(step.get("marg_idx", -1))
     return s, keep
 
@@ -609,6 +652,30 @@ class Context:
         self._chk(self.L.ingvio_frame_stage(self.h, b0, nb, sa, fa, C.byref(o), _d(f64(sigma)), int(enable_gnss),
                                             C.c_double(sigma_cb), C.c_double(sigma_rw)))
 
+    def tracks_create(self, t_max):
+        """allocates / clears the device-resident track store (ingvio_tracks_create)"""
+        self._chk(self.L.ingvio_tracks_create(self.h, int(t_max)))
+
+    def frame_stage_tracks_prepare(self, b0, steps, track_frames, opts_frame, sigma, enable_gnss=0, sigma_cb=0.0, sigma_rw=0.0, max_accept=0,
+                                   compress_rule=1, selected_variant=0, use_async=False):
+        """Builds the C argument arrays once and returns a callable that issues ingvio_frame_stage_tracks on them: the frame hand-over
+        as a delta on the device-resident track store + raw IMU samples.  steps: step dicts with a "raw" entry (synth.Filter.step_dict);
+        track_frames: dicts as make_track_frame takes them; opts_frame: a dict with stereo / R_cl2cr / t_cl2cr / noise / chi2_table."""
+        nb = len(steps)
+        sa = (FrameStepRaw * nb)(); fa = (TrackFrame * nb)()
+        keeps = []
+        for i in range(nb):
+            s, k1 = make_step_raw(steps[i]); f, k2 = make_track_frame(track_frames[i])
+            sa[i] = s; fa[i] = f; keeps.append((k1, k2))
+        o, chi2 = make_opts(opts_frame, max_accept, compress_rule, selected_variant)
+        sg = f64(sigma)
+
+        def call():
+            _keep = (keeps, chi2, sg)
+            self._chk(self.L.ingvio_frame_stage_tracks(self.h, b0, nb, sa, fa, C.byref(o), _d(sg), int(enable_gnss), C.c_double(sigma_cb),
+                                                       C.c_double(sigma_rw), 1 if use_async else 0))
+        return call
+
     def frame_stage_prepare(self, b0, steps, frames, sigma, enable_gnss=0, sigma_cb=0.0, sigma_rw=0.0, max_accept=0,
                             compress_rule=1, selected_variant=0, use_async=False):
         """Builds the C argument arrays once and returns a callable that re-issues ingvio_frame_stage on them (for timing
@@ -639,6 +706,18 @@ class Context:
         nb = self.batch if nb is None else nb
         dx = np.zeros((nb, self.ldp)); acc = np.zeros((nb, self.f_max), dtype=np.int32); rows = np.zeros(nb, dtype=np.int32)
         self._chk(self.L.ingvio_frame_fetch(self.h, b0, nb, _d(dx), _i(acc), _i(rows)))
+        return dx, acc, rows
+
+    def frame_fetch_begin(self, b0=0, nb=None):
+        """enqueues the result copies behind the frame's kernels (ingvio_frame_fetch_begin); frame_fetch_end() returns them"""
+        nb = self.batch if nb is None else nb
+        self._fetch_nb = nb
+        self._chk(self.L.ingvio_frame_fetch_begin(self.h, b0, nb))
+
+    def frame_fetch_end(self):
+        nb = self._fetch_nb
+        dx = np.empty((nb, self.ldp)); acc = np.empty((nb, self.f_max), dtype=np.int32); rows = np.empty(nb, dtype=np.int32)
+        self._chk(self.L.ingvio_frame_fetch_end(self.h, _d(dx), _i(acc), _i(rows)))
         return dx, acc, rows
 
     # ---- triangulation (f-1) ------------------------------------------------------------------

@@ -229,10 +229,14 @@ class Filter:
         the nominal state (ImuPropagator.cpp:232-292 with one sample per step)."""
         pr = PARAMS
         steps = []
-        for _ in range(k):
+        # the same samples in raw form (ingvio_frame_step_raw: the transition matrices are then formed on the device)
+        self.last_raw = dict(imu=np.zeros((k, 7)), R=np.array(self.R, dtype=float), p=np.array(self.p, dtype=float), v=np.array(self.v, dtype=float),
+                             bg=np.array(self.bg, dtype=float), ba=np.array(self.ba, dtype=float), gravity=np.array(self.gravity, dtype=float))
+        for q in range(k):
             gyro, acc = true_imu(self.t + dt)
             gyro = gyro + rng.normal(0.0, pr["noise_g"], 3)
             acc = acc + rng.normal(0.0, pr["noise_a"], 3)
+            self.last_raw["imu"][q, 0:3] = gyro; self.last_raw["imu"][q, 3:6] = acc; self.last_raw["imu"][q, 6] = dt
             self.R, self.p, self.v, Phi, G = self.transition(self.R, self.p, self.v, self.bg, self.ba,
                                                              gyro, acc, self.gravity, dt)
             self.t += dt
@@ -262,7 +266,7 @@ class Filter:
         return dict(Phi=[s[0] for s in steps], G=[s[1] for s in steps], dt=[s[2] for s in steps],
                     sigma=self.sigma(), enable_gnss=self.enable_gnss, gnss_idx=list(self.gnss_idx),
                     sigma_cb=pr["sigma_cb"], sigma_rw=pr["sigma_rw"], R_i2w=self.R.copy(),
-                    marg_idx=-1 if marg_name is None else self.idx_of(marg_name))
+                    marg_idx=-1 if marg_name is None else self.idx_of(marg_name), raw=getattr(self, "last_raw", None))
 
 
 def true_cam_pose(t):

@@ -49,7 +49,10 @@ def test_compact_line_fits_and_has_the_contract_keys():
     assert d["latency_b1_ms"]["staggered_median_ms"] == dict(kf21=0.3, kf27="timeout") and "staggered" not in d["latency_b1_ms"]
     assert "kernels" not in d and "as_written_cap20" not in d
     # round 5: the hand-over figures ride on the line as four numbers, the notes stay in the detail file
-    assert set(d["host_handover"]) == {"serial_updates_per_s", "pipelined_updates_per_s", "stagers8_aggregate_updates_per_s", "stagers8_host_threads"}
+    # round 6: + the same hand-over as a delta on the device-resident track store, and the bytes either form sends per update
+    assert set(d["host_handover"]) == {"serial_updates_per_s", "pipelined_updates_per_s", "stagers8_aggregate_updates_per_s", "stagers8_host_threads",
+                                       "tracks", "bytes_per_update"}
+    assert set(d["host_handover"]["tracks"]) == {"serial", "pipelined", "bytes_per_update", "same_result", "stagers8_aggregate", "error"}
     assert abs(d["value"] - full["value"]) / full["value"] < 1e-5
 
 

@@ -7,7 +7,7 @@ OUT=$ROOT/build_var/$NAME
 mkdir -p "$OUT"
 cd "$ROOT/ingvio_amd/csrc"
 OBJS=""
-for f in kernels_cov kernels_msckf kernels_ekf kernels_factored kernels_solve kernels_bigwin kernels_tri kernels_lm kernels_qr kernels_chol kernels_lmbatch kernels_lmchol kernels_gnss capi; do
+for f in kernels_cov kernels_msckf kernels_ekf kernels_factored kernels_solve kernels_bigwin kernels_tri kernels_lm kernels_qr kernels_chol kernels_lmbatch kernels_lmchol kernels_gnss kernels_tracks capi; do
   EXTRA=""
   if [ $f = kernels_bigwin ]; then EXTRA="-mllvm -amdgpu-sched-strategy=max-ilp"; fi
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $EXTRA "$@" -c $f.hip -o "$OUT/$f.o" &
