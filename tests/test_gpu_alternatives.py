@@ -89,3 +89,39 @@ def test_few_filter_path_is_bit_identical_to_the_full_batch_kernels(tmp_path, B)
     assert np.array_equal(a["acc"], b["acc"]) and np.array_equal(a["rows"], b["rows"]) and a["acc"].sum() > 50 * B
     assert np.array_equal(a["dx"], b["dx"]), float(np.max(np.abs(a["dx"] - b["dx"])))
     assert np.array_equal(a["P"], b["P"]), float(np.max(np.abs(a["P"] - b["P"])))
+
+
+@pytest.mark.parametrize("parts", [2, 3])
+def test_split_frame_step_is_bit_identical(parts):
+    """ingvio_set_frame_parts (round 6): the batch dealt to slices on their own streams, throughput segments chained by events, the slices
+    NOT joined at the end of ingvio_frame_run - consecutive steps, a fetch in between, a stage, ingvio_sync: every result equal to the
+    unsplit step's to the last bit (same kernels, same arguments per filter)."""
+    import numpy as np
+    from ingvio_amd import capi, host, synth
+    B, C, F = 48, 11, 30
+    N = 21 + 6 * C
+    ctx = capi.Context(batch=B, n_max=((N + 15) // 16) * 16, c_max=C, f_max=F, m_max=32)
+    cases = [synth.build_case(lambda P, b=b: capi.DeviceCov(ctx, b, P), host.imu_transition, seed=300 + b, F=F, C=C, n_gnss=0, n_landmarks=0) for b in range(B)]
+    ctx.snapshot()
+    stage = lambda: ctx.frame_stage(0, [c[1] for c in cases], [c[2] for c in cases], cases[0][1]["sigma"])
+    stage()
+    outs = []
+    for p in (1, parts):
+        ctx.set_frame_parts(p)
+        for _ in range(3):                                              # pipelined steps, nothing joined in between
+            ctx.frame_run(restore_prior=True)
+        dx, acc, rows = ctx.frame_fetch()
+        stage()                                                         # an entry point other than frame_run joins the slices first
+        ctx.frame_run(restore_prior=True)
+        ctx.frame_run(restore_prior=False)                              # and a step that continues from the posterior
+        ctx.sync()
+        dx2, acc2, rows2 = ctx.frame_fetch()
+        outs.append((dx, acc, rows, dx2, acc2, [ctx.cov_get(b) for b in (0, B // 2 - 1, B // 2, B - 1)]))
+        ctx.restore()
+    a, b = outs
+    assert a[1].sum() > 10 * B
+    for x, y in zip(a[:5], b[:5]):
+        assert np.array_equal(x, y)
+    for x, y in zip(a[5], b[5]):
+        assert np.array_equal(x, y)
+    ctx.close()
