@@ -71,7 +71,7 @@ class LazyCov:
         return self.n - 6
 
 
-def build_batch(ctx, B, seed0, F, C, n_gnss, n_landmarks, lm_sigma=1.0):
+def build_batch(ctx, B, seed0, F, C, n_gnss, n_landmarks, lm_sigma=1.0, stereo=True):
     """Creates B config-2 style cases; priors are produced by the HIP path itself (batched propagate+clone)."""
     from ingvio_amd import host, synth
     pr = synth.PARAMS
@@ -110,13 +110,13 @@ def build_batch(ctx, B, seed0, F, C, n_gnss, n_landmarks, lm_sigma=1.0):
         clone_times = [c["t"] for c in flt.clones] + [t_new]
         step = flt.step_dict(st, marg_name=flt.clones[0]["name"])
         new_idx = flt.cov.n
-        pf, uv, outlier = synth.make_features(rng, clone_times, F)
+        pf, uv, outlier = synth.make_features(rng, clone_times, F, stereo=stereo)
         clones = flt.clones + [dict(R=flt.R @ synth.R_CL2I, p=flt.p + flt.R @ synth.T_CL2I)]
         frames.append(dict(
             clone_idx=np.array([flt.idx_of(c["name"]) for c in flt.clones] + [new_idx], dtype=np.int32),
             clone_R=np.stack([c["R"] for c in clones]), clone_p=np.stack([c["p"] for c in clones]), pf=pf,
             anchor=np.zeros(F, dtype=np.int32), obs_mask=np.full(F, (1 << C) - 1, dtype=np.uint64), uv=uv,
-            dof=np.full(F, C - 1, dtype=np.int32), stereo=1, R_cl2cr=Rlr, t_cl2cr=tlr, noise=pr["visual_noise"],
+            dof=np.full(F, C - 1, dtype=np.int32), stereo=1 if stereo else 0, R_cl2cr=Rlr, t_cl2cr=tlr, noise=pr["visual_noise"],
             chi2_table=table))
         steps.append(step)
         infos.append(dict(outlier=outlier, n_prior=flt.cov.n, rng=rng))
@@ -245,12 +245,12 @@ def gate_kernel_of(C):
     return "k_feat_gate4" if (g == "4" or C > 11) else "k_feat_gate5"
 
 
-def counters_for(counters, name, big, C=None):
+def counters_for(counters, name, big, C=None, stereo=True):
     """-> (summed counters of the stage's kernels or None, the kernels they belong to)."""
     table = STAGE_KERNELS_BIG if big and name in STAGE_KERNELS_BIG else STAGE_KERNELS
     cands = table.get(name, ((name,),))
     if name == "gate" and C is not None:            # the gate that ran is known: counters of another generation do not apply
-        cands = ((gate_kernel_of(C),),)
+        cands = ((gate_kernel_of(C) if stereo else ("k_feat_gate3_big" if C > 16 else "k_feat_gate3"),),)      # mono: the first-generation gate
     if counters is None:
         return None, cands[0]
     for cand in cands:
@@ -276,7 +276,7 @@ def kernel_that_ran(stage, cand, C, stereo=True):
     return name
 
 
-def price_kernels(prof, dom_name, counters, csrc, rec_build, live_build, C, B, per_kernel, bytes_k):
+def price_kernels(prof, dom_name, counters, csrc, rec_build, live_build, C, B, per_kernel, bytes_k, stereo=True):
     """Per-kernel table (time from HIP events, executed operations / HBM bytes from the committed counters - only when they belong
     to the running build of the kernel's translation unit) and the roofline of the dominant kernel.  Pure function of its
     inputs: tests/test_bench_line.py flips a hash and sees frac = None."""
@@ -285,8 +285,8 @@ def price_kernels(prof, dom_name, counters, csrc, rec_build, live_build, C, B, p
         if calls == 0:
             continue
         avg = ms / calls
-        c, cand = counters_for(counters, name, C > 16, C)
-        e = dict(avg_ms=avg, calls=calls, kernel=kernel_that_ran(name, cand, C))
+        c, cand = counters_for(counters, name, C > 16, C, stereo)
+        e = dict(avg_ms=avg, calls=calls, kernel=kernel_that_ran(name, cand, C, stereo))
         if c is not None:
             st = stale_kernels(cand, rec_build, live_build)
             if st:                                  # counters of another build of this kernel: no price, say so
@@ -471,6 +471,8 @@ def parse_args():
                          "the marginalisation)")
     ap.add_argument("--gnss-separate", action="store_true", help="config 3: the GNSS update as its own pass over P after the frame (round 3) "
                     "instead of in-frame on the MSCKF write-back")
+    ap.add_argument("--mono", action="store_true", help="the MONO form of the workload (BASELINE configs[0]: RemoveLostUpdate.cpp:169-273, two rows per "
+                    "observation, rho = 2C - 3 rows per feature); auxiliary workload, never the default line")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary config-3 / config-5 passes of the default run")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-filter latency figures (C++ shim stream) of the default run")
     ap.add_argument("--detail", default=DETAIL_JSON, help="where the full result (per-kernel tables, notes) is written")
@@ -500,7 +502,8 @@ def run_workload(args, grp, aux=False):
     t_build = time.perf_counter()
     real_lm = args.landmarks == "real" and n_lm > 0
     n_lm_real = min(n_lm, capi.LM_MAX) if real_lm else 0
-    filters, steps, frames, infos = build_batch(ctx, B, rank * B, F, C, n_gnss, n_lm, lm_sigma=0.05 if real_lm else 1.0)
+    stereo = not getattr(args, "mono", False)
+    filters, steps, frames, infos = build_batch(ctx, B, rank * B, F, C, n_gnss, n_lm, lm_sigma=0.05 if real_lm else 1.0, stereo=stereo)
     ctx.snapshot()
     pr = synth.PARAMS
     ctx.frame_stage(0, steps, frames, filters[0].sigma(), filters[0].enable_gnss, pr["sigma_cb"], pr["sigma_rw"],
@@ -591,10 +594,10 @@ def run_workload(args, grp, aux=False):
         F_used = float(n_acc.mean())
         per_kernel, total_flops = algorithmic_flops(F_used, F, C, N, synth.IMU_PER_FRAME)
         bytes_k = algorithmic_bytes(N, synth.IMU_PER_FRAME, F, C)
-        wkey = "c%d_B%d_F%d_C%d_N%d" % (args.config, B, F, C, N) + ("_lmreal" if real_lm else "")
+        wkey = "c%d_B%d_F%d_C%d_N%d" % (args.config, B, F, C, N) + ("_lmreal" if real_lm else "") + ("" if stereo else "_mono")
         counters, csrc, rec_build = load_counters(args.counters, wkey)
         live_build = capi.build_id()
-        kernels, roofline = price_kernels(prof, dom_name, counters, csrc, rec_build, live_build, C, B, per_kernel, bytes_k)
+        kernels, roofline = price_kernels(prof, dom_name, counters, csrc, rec_build, live_build, C, B, per_kernel, bytes_k, stereo=stereo)
         cpu, parity = None, None
         if world > 1 and not real_lm:
             parity = dict(sample=world, filters="filter 0 of every rank", max_rel_cov_err=float(summ[:, 3].max()),
@@ -723,8 +726,8 @@ def run_workload(args, grp, aux=False):
             metric="ekf_updates_per_sec", value=updates / elapsed, unit="updates/s", n_gpus=world, steps=args.steps,
             warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak",
             vs_baseline=None, dtype="f64", data="synthetic",
-            config=dict(workload="BASELINE configs[%d]: synthetic stereo MSCKF, %d feats x %d clones, state dim N=%d (update at N), "
-                                 "%d independent filters per GPU; step = %s" % (args.config - 1, F, C, N, B, step_desc),
+            config=dict(workload="BASELINE configs[%d]: synthetic %s MSCKF, %d feats x %d clones, state dim N=%d (update at N), "
+                                 "%d independent filters per GPU; step = %s" % (args.config - 1, "stereo" if stereo else "MONO", F, C, N, B, step_desc),
                         baseline_config=args.config, filters_per_gpu=B, feats=F, clones=C, state_dim=N, imu_steps=synth.IMU_PER_FRAME,
                         gnss_rows_used_per_filter=None if gn_used is None else float(np.mean(gn_used)),
                         landmarks=args.landmarks if n_lm else None, landmarks_in_state=n_lm_real if real_lm else 0,

@@ -9,11 +9,11 @@ W="${*:-c2 c3 c5}"
 args() { case $1 in
   c2) echo "--config 2";; c3) echo "--config 3";; c5) echo "--config 5";;
   c2n87) echo "--config 2 --state literal";; c2n93) echo "--config 2 --state gnss";; c5lit) echo "--config 5 --state literal";;
-  c2lm) echo "--config 2 --landmarks real";; esac; }
+  c2lm) echo "--config 2 --landmarks real";; c2mono) echo "--config 2 --mono";; c2c12) echo "--config 2 --clones 12";; esac; }
 key() { case $1 in
   c2) echo c2_B512_F150_C11_N249;; c3) echo c3_B512_F150_C11_N249;; c5) echo c5_B32_F300_C30_N807;;
   c2n87) echo c2_B512_F150_C11_N87;; c2n93) echo c2_B512_F150_C11_N93;; c5lit) echo c5_B32_F300_C30_N201;;
-  c2lm) echo c2_B512_F150_C11_N249_lmreal;; esac; }
+  c2lm) echo c2_B512_F150_C11_N249_lmreal;; c2mono) echo c2_B512_F150_C11_N249_mono;; c2c12) echo c2_B512_F150_C12_N255;; esac; }
 for w in $W; do
   PS=""
   case $w in c5|c5lit) PS="k_chol_step=11,k_chol_first=2,k_gemm64=3";; esac

@@ -15,7 +15,7 @@ PY
 done
 bash tools/gpu_b1_profile.sh > gpurun_out/final_b1/b1_profile.txt 2>&1
 cp gpurun_out/b1/kernel_stats_c2.csv gpurun_out/final_b1/kernel_stats_c2_b1.csv; cp gpurun_out/b1/kernel_stats_c5.csv gpurun_out/final_b1/kernel_stats_c5_b1.csv
-for w in config2 kf21 kf27; do
+for w in config2 kf21 kf27 sw11 kf35_mono; do
   bash tools/gpu_replay_trace.sh $w > gpurun_out/final_b1/replay_$w.txt 2>&1
   cp gpurun_out/replay_trace_$w/rt_kernel_stats.csv gpurun_out/final_b1/replay_kernel_stats_$w.csv
   head -1 gpurun_out/final_b1/replay_$w.txt | cut -c1-200
