@@ -43,6 +43,8 @@ public:
     void callbackGnssMeas(const GnssMeas& gnss_meas) { _gnss_sync->bufferGnssMeas(gnss_meas); }       // GnssProcessor.cpp:119-220 -> GnssSync
     void callbackSppMeas(const SppMeas& spp_meas) { _gnss_sync->bufferSppMeas(spp_meas); }
     void setGnssAlignment(const GvioAlignment& a) { _gvio_aligner = a; }
+    const GvioAlignment& gnssAlignment() const { return _gvio_aligner; }               // given (setGnssAlignment) or found by batchAlign
+    const IngvioParams& params() const { return _filter_params; }
     std::shared_ptr<GvioAligner> gvioAligner() { return _aligner; }                     // batchAlign on the raw epochs (IngvioFilter.cpp:344-345)
     std::shared_ptr<GnssSync> gnssSync() { return _gnss_sync; }
     std::shared_ptr<GnssUpdate> gnssUpdate() { return _gnss_update; }

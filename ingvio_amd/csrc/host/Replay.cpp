@@ -101,6 +101,19 @@ void ReplayWriter::alignment(const GvioAlignment& a, double stamp)
     for (int i = 0; i < 3; ++i) app(b, a.anchor_ecef[i]);
     put(RP_ALIGNMENT, (uint64_t)std::llround(stamp * 1e9), b);
 }
+void ReplayWriter::gnssRaw(double stamp, double doy, const double iono[8], const std::vector<double>& eph, const std::vector<double>& obs)
+{
+    std::vector<uint8_t> b;
+    app(b, doy);
+    for (int i = 0; i < 8; ++i) app(b, iono[i]);
+    const uint32_t n = (uint32_t)(obs.size() / INGVIO_OBS_N);
+    app(b, n);
+    for (uint32_t i = 0; i < n; ++i) {
+        for (int q = 0; q < INGVIO_EPH_N; ++q) app(b, eph[(size_t)i * INGVIO_EPH_N + q]);
+        for (int q = 0; q < INGVIO_OBS_N; ++q) app(b, obs[(size_t)i * INGVIO_OBS_N + q]);
+    }
+    put(RP_GNSS_RAW, (uint64_t)std::llround(stamp * 1e9), b);
+}
 void ReplayWriter::truth(double stamp, const double p[3], const double q[4])
 {
     std::vector<uint8_t> b;
@@ -109,6 +122,21 @@ void ReplayWriter::truth(double stamp, const double p[3], const double q[4])
     put(RP_GROUND_TRUTH, (uint64_t)std::llround(stamp * 1e9), b);
 }
 
+bool decodeGnssRaw(const ReplayRecord& r, GnssMeas& m)
+{
+    Cur c{ r.payload };
+    m.doy = c.get<double>();
+    m.iono.assign(8, 0.0);
+    for (int i = 0; i < 8; ++i) m.iono[i] = c.get<double>();
+    const uint32_t n = c.get<uint32_t>();
+    if (!c.ok || (size_t)n * 8 * (INGVIO_EPH_N + INGVIO_OBS_N) + 76 != r.payload.size() || n > INGVIO_GNSS_MAX_SAT) return false;
+    m.raw_eph.assign((size_t)n * INGVIO_EPH_N, 0.0); m.raw_obs.assign((size_t)n * INGVIO_OBS_N, 0.0);
+    for (uint32_t i = 0; i < n; ++i) {
+        for (int q = 0; q < INGVIO_EPH_N; ++q) m.raw_eph[(size_t)i * INGVIO_EPH_N + q] = c.get<double>();
+        for (int q = 0; q < INGVIO_OBS_N; ++q) m.raw_obs[(size_t)i * INGVIO_OBS_N + q] = c.get<double>();
+    }
+    return c.ok && c.o == r.payload.size();
+}
 bool decodeImu(const ReplayRecord& r, msg::Imu& m)
 {
     Cur c{ r.payload };
@@ -255,6 +283,9 @@ bool replayFile(const std::string& path, const std::string& overrides, bool dump
     std::unique_ptr<IngvioFilter> filter;
     ReplayRecord rec;
     bool first = true;
+    GnssMeas raw_pending;                         // a GNSS_RAW record waits for the GNSS_MEAS record of the same stamp
+    uint64_t raw_stamp = 0;
+    bool have_raw = false;
     auto make_filter = [&]() {
         if (filter || dump_only) return;
         applyParamsText(overrides, fp);
@@ -295,7 +326,16 @@ bool replayFile(const std::string& path, const std::string& overrides, bool dump
             }
             break;
         }
-        case RP_GNSS_MEAS: { GnssMeas g; if (!decodeGnss(rec, g)) { err = "bad GNSS record"; return false; } make_filter(); if (filter) filter->callbackGnssMeas(g); break; }
+        case RP_GNSS_RAW: { if (!decodeGnssRaw(rec, raw_pending)) { err = "bad GNSS_RAW record"; return false; } raw_stamp = rec.stamp_ns; have_raw = true; break; }
+        case RP_GNSS_MEAS: {
+            GnssMeas g;
+            if (!decodeGnss(rec, g)) { err = "bad GNSS record"; return false; }
+            if (have_raw && raw_stamp == rec.stamp_ns) { g.raw_eph = raw_pending.raw_eph; g.raw_obs = raw_pending.raw_obs; g.iono = raw_pending.iono; g.doy = raw_pending.doy; }
+            have_raw = false;
+            make_filter();
+            if (filter) filter->callbackGnssMeas(g);
+            break;
+        }
         case RP_SPP_MEAS: { SppMeas s; if (!decodeSpp(rec, s)) { err = "bad SPP record"; return false; } make_filter(); if (filter) filter->callbackSppMeas(s); break; }
         case RP_ALIGNMENT: { GvioAlignment a; if (!decodeAlignment(rec, a)) { err = "bad ALIGNMENT record"; return false; } make_filter(); if (filter) filter->setGnssAlignment(a); break; }
         default: break;

@@ -12,6 +12,10 @@
 //   5 SPP_MEAS      f64 x 11: posSpp 7, velSpp 4
 //   6 ALIGNMENT     f64 x 14: aligned, yaw_offset, R_enu2ecef 9, anchor_ecef 3                          (GvioAligner result)
 //   7 GROUND_TRUTH  f64 x 7: position 3, orientation xyzw                                               (evaluation only)
+//   8 GNSS_RAW      f64 doy, f64 x 8 Klobuchar parameters, u32 n, n x { f64 x 25 ephemeris, f64 x 6 observation } in the layout of
+//                   ingvio_gnss_epoch (include/ingvio_hip.h): the raw content of the GNSS_MEAS record that FOLLOWS with the same stamp
+//                   (GnssData.h GnssMeas = (obs, ephems) + latest_gnss_iono_params) - what GvioAligner::batchAlign reads; a recording
+//                   without an ALIGNMENT record and with these lets the filter align itself (IngvioFilter.cpp:344-345)
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -25,7 +29,7 @@
 
 namespace ingvio {
 
-enum ReplayType : uint8_t { RP_PARAMS = 0, RP_IMU, RP_MONO_FRAME, RP_STEREO_FRAME, RP_GNSS_MEAS, RP_SPP_MEAS, RP_ALIGNMENT, RP_GROUND_TRUTH, RP_COUNT };
+enum ReplayType : uint8_t { RP_PARAMS = 0, RP_IMU, RP_MONO_FRAME, RP_STEREO_FRAME, RP_GNSS_MEAS, RP_SPP_MEAS, RP_ALIGNMENT, RP_GROUND_TRUTH, RP_GNSS_RAW, RP_COUNT };
 
 struct ReplayRecord { uint8_t type = 0; uint64_t stamp_ns = 0; std::vector<uint8_t> payload; };
 
@@ -51,6 +55,7 @@ public:
     void spp(const SppMeas& m);
     void alignment(const GvioAlignment& a, double stamp);
     void truth(double stamp, const double p[3], const double q_xyzw[4]);
+    void gnssRaw(double stamp, double doy, const double iono[8], const std::vector<double>& eph, const std::vector<double>& obs);
     void close() { if (_f) std::fclose(_f); _f = nullptr; }
     ~ReplayWriter() { close(); }
 private:
@@ -68,6 +73,7 @@ bool decodeStereo(const ReplayRecord& r, msg::StereoFrame& m);
 bool decodeGnss(const ReplayRecord& r, GnssMeas& m);
 bool decodeSpp(const ReplayRecord& r, SppMeas& m);
 bool decodeAlignment(const ReplayRecord& r, GvioAlignment& a);
+bool decodeGnssRaw(const ReplayRecord& r, GnssMeas& m);      // fills m.raw_eph / raw_obs / iono / doy
 
 struct ReplayStats { uint64_t counts[RP_COUNT] = { 0 }; uint64_t features = 0; double t_first = 0, t_last = 0; int frames_processed = 0; };
 

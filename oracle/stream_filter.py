@@ -246,7 +246,10 @@ class Filter:
         self.gnss = {}               # GNSSType -> scalar Var (State::_gnss)
         self.gnss_buf, self.spp_buf = [], []                              # GnssSync's queues (the replay marks the synchronisation as done)
         self.unsync_thres = 0.13                                          # GnssSync.h:61
-        self.align = None            # dict(yaw_offset, R_enu2ecef, anchor_ecef) once aligned
+        self.align = None            # dict(yaw_offset, R_enu2ecef, anchor_ecef) once aligned: given with the recording, or found by batchAlign
+        self.aligner = None          # GvioAligner (oracle/gvio_align.py), created with the first raw epoch
+        self.gv_batch, self.gv_max_iter = gi("gv_align_batch_size", 25), gi("gv_align_max_iter", 10)
+        self.gv_eps, self.gv_vel_thres = g("gv_align_conv_epsilon", 1e-5), g("gv_align_vel_thres", 0.4)
         self.stereo = gi("cam_nums", 2) == 2                             # IngvioFilter.cpp:100-112: cam_nums 1 -> the mono callback
         self.max_sw = gi("max_sliding_window_poses", 27)
         self.is_key_frame = gi("is_key_frame", 1)
@@ -810,10 +813,12 @@ class Filter:
         fi.anchor = fi.lm.anchor
 
     # ---- GNSS ---------------------------------------------------------------------------------------------------------------
-    def callback_gnss_meas(self, stamp, sats):                           # GnssSync::bufferGnssMeas (GnssSync.cpp:27-46)
+    def callback_gnss_meas(self, stamp, sats, raw=None):                 # GnssSync::bufferGnssMeas (GnssSync.cpp:27-46)
+        """raw: None or dict(eph [n, 25], obs [n, 6], ion [8], doy) - the epoch's ephemerides and observations as GnssProcessor hands them
+        on (GnssData.h GnssMeas = (obs, ephems)); only GvioAligner::batchAlign reads them"""
         if len(self.gnss_buf) > 100:
             del self.gnss_buf[:len(self.gnss_buf) - 100]
-        self.gnss_buf.append((stamp, sats))
+        self.gnss_buf.append((stamp, sats, raw))
 
     def callback_spp_meas(self, stamp, pos7, vel4):                      # GnssSync::bufferSppMeas (:48-68)
         if len(self.spp_buf) > 100:
@@ -957,8 +962,16 @@ class Filter:
         if gm is None:
             return
         tr["gnss_epoch"] = gm[0]
+        if spp is not None and self.align is None and gm[2] is not None:  # :344-345: flag && !isAlign() -> batchAlign on the raw epoch
+            if self.aligner is None:
+                from . import gvio_align
+                self.aligner = gvio_align.Aligner(orc, self.gv_batch, self.gv_max_iter, self.gv_eps, self.gv_vel_thres)
+            raw = gm[2]
+            self.aligner.batch_align(dict(eph=raw["eph"], obs=raw["obs"], doy=raw["doy"]), self.ext_pose.p, self.ext_pose.v, raw["ion"])
+            if self.aligner.aligned:
+                self.align = dict(yaw_offset=self.aligner.yaw_offset, R_enu2ecef=self.aligner.R_enu2ecef, anchor_ecef=self.aligner.anchor_ecef)
         if self.align is None:
-            return                                                       # batchAlign is out of this transcription's scope: the alignment is given
+            return                                                       # not aligned (yet): no GNSS update (:347)
         if YOF not in self.gnss:                                         # checkYofStatus :33-43
             self.add_gnss_variable(YOF, self.align["yaw_offset"], self.init_cov_yof)
         self.update_tracked_sys(gm[1], tr)
@@ -1040,6 +1053,7 @@ class Filter:
         e = self.ext_pose
         tr["pose"] = np.concatenate([e.R.reshape(-1), e.p, e.v, self.bg.p, self.ba.p, self.extr.R.reshape(-1), self.extr.p])
         tr["gnss_vals"] = np.array([self.gnss[t6].s if t6 in self.gnss else np.nan for t6 in range(6)])      # GPS GLO GAL BDS FS YOF
+        tr["align"] = np.array([0.0, 0.0, 0.0, 0.0, 0.0]) if self.align is None else np.r_[1.0, self.align["yaw_offset"], self.align["anchor_ecef"]]
         # in-state landmarks after the frame (ascending id), their world positions, and what left the state during the frame
         tr["lm_ids"] = sorted(self.landmarks)
         tr["lm_vals"] = np.concatenate([self.landmarks[i].p for i in tr["lm_ids"]]) if self.landmarks else np.zeros(0)
@@ -1054,8 +1068,8 @@ class Filter:
 
 LIST_KEYS_INT = ["lost_ids", "lost_direct", "lost_acc", "sel_ids", "sel_acc", "clean_erased", "anchor_erased", "anchor_moved",
                  "invalid_erased", "map_ids", "gnss_keep", "gnss_added", "lm_upd_ids", "lm_upd_acc", "lm_init_ids", "lm_ids", "lm_marg_ids"]
-LIST_KEYS_F64 = ["sel_stamps", "marg_stamps", "sw_stamps", "diag", "gnss_vals", "lm_vals"]
-OPTIONAL_KEYS = ("lm_upd_ids", "lm_upd_acc", "lm_init_ids", "lm_ids", "lm_marg_ids", "lm_vals")      # absent from the golden files of rounds 4-5 (no landmarks)
+LIST_KEYS_F64 = ["sel_stamps", "marg_stamps", "sw_stamps", "diag", "gnss_vals", "lm_vals", "align"]
+OPTIONAL_KEYS = ("lm_upd_ids", "lm_upd_acc", "lm_init_ids", "lm_ids", "lm_marg_ids", "lm_vals", "align")      # absent from the golden files of rounds 4-5 (no landmarks)
 SCALAR_KEYS = ["stamp", "lost_rows", "sel_rows", "n", "norm", "gnss_rows", "gnss_epoch"]
 
 
@@ -1107,6 +1121,7 @@ def play_recording(path, overrides="", max_frames=None):
     import struct
     flt = None
     traces = []
+    raw_pending = None
     with open(path, "rb") as f:
         assert f.read(8) == b"INGVIOR1"
         while True:
@@ -1120,6 +1135,12 @@ def play_recording(path, overrides="", max_frames=None):
             elif typ == 1:
                 v = struct.unpack("<6d", payload)
                 flt.callback_imu(to_sec(ns), v[0:3], v[3:6])
+            elif typ == 8:                                               # GNSS_RAW: doy, ion 8, u32 n, n x { eph 25, obs 6 }: belongs to the GNSS_MEAS that follows
+                doy = struct.unpack_from("<d", payload)[0]
+                ion = np.array(struct.unpack_from("<8d", payload, 8))
+                cnt = struct.unpack_from("<I", payload, 72)[0]
+                rec31 = np.array(struct.unpack_from("<%dd" % (31 * cnt), payload, 76)).reshape(cnt, 31)
+                raw_pending = (ns, dict(eph=rec31[:, :25].copy(), obs=rec31[:, 25:].copy(), ion=ion, doy=doy))
             elif typ == 4:                                               # GNSS_MEAS: u32 n, n x { i32 sys, f64 x 17 } (Replay.h)
                 cnt = struct.unpack_from("<I", payload)[0]
                 sats = []
@@ -1127,7 +1148,9 @@ def play_recording(path, overrides="", max_frames=None):
                     v = struct.unpack_from("<i17d", payload, 4 + 140 * i)
                     sats.append(dict(sys=v[0], psr=v[1], dopp=v[2], psr_std=v[3], dopp_std=v[4], freq=v[5], sv_pos=np.array(v[6:9]),
                                      sv_vel=np.array(v[9:12]), sv_dt=v[12], sv_ddt=v[13], tgd=v[14], ura=v[15], ion=v[16], tro=v[17]))
-                flt.callback_gnss_meas(_stamp_from_ns(ns), sats)
+                raw = raw_pending[1] if raw_pending is not None and raw_pending[0] == ns else None
+                raw_pending = None
+                flt.callback_gnss_meas(_stamp_from_ns(ns), sats, raw)
             elif typ == 5:                                               # SPP_MEAS: posSpp 7, velSpp 4
                 v = struct.unpack("<11d", payload)
                 flt.callback_spp_meas(_stamp_from_ns(ns), v[:7], v[7:])

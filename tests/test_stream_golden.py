@@ -33,7 +33,7 @@ INT_TAGS = {"LOST_IDS": "lost_ids", "LOST_ACC": "lost_acc", "LOST_DIRECT": "lost
             "MAP_IDS": "map_ids", "TABLE": "table", "GNSS_KEEP": "gnss_keep",
             "LM_UPD_IDS": "lm_upd_ids", "LM_UPD_ACC": "lm_upd_acc", "LM_INIT_IDS": "lm_init_ids", "LM_IDS": "lm_ids", "LM_MARG_IDS": "lm_marg_ids"}
 F64_TAGS = {"SEL_STAMPS": "sel_stamps", "MARG_STAMPS": "marg_stamps", "SW_STAMPS": "sw_stamps", "POSE": "pose", "DIAG": "diag",
-            "GNSS_VALS": "gnss_vals", "LM_VALS": "lm_vals"}
+            "GNSS_VALS": "gnss_vals", "LM_VALS": "lm_vals", "ALIGN": "align"}
 SCALAR_TAGS = {"LOST_ROWS": "lost_rows", "SEL_ROWS": "sel_rows", "NORM": "norm", "GNSS_ROWS": "gnss_rows", "GNSS_ADDED_TOTAL": "gnss_added_total"}
 
 
@@ -85,6 +85,16 @@ def compare(gold, got, pose_tol=POSE_TOL, cov_tol=COV_TOL):
                 bad.append("%s: %s differs: golden %s shim %s" % (tag, k, np.asarray(g[k]).tolist(), s[k].tolist()))
         if not np.array_equal(np.asarray(g["table"], dtype=np.int64).reshape(-1, 2), s["table"]):
             bad.append("%s: (idx, size) table differs" % tag)
+        # the alignment the GNSS block works with (given, or found by GvioAligner::batchAlign on the stream's raw epochs): found in the
+        # same frame, yaw to 1e-8 rad, anchor to 1e-4 m (the Gauss-Newton iterations stop at gv_align_conv_epsilon = 1e-5)
+        if "align" in s and len(g.get("align", [])) == 5:
+            ga, sa = np.asarray(g["align"]), s["align"]
+            if ga[0] != sa[0]:
+                bad.append("%s: aligned %s vs %s" % (tag, ga[0], sa[0]))
+            elif ga[0]:
+                worst["yaw"] = max(worst.get("yaw", 0.0), abs(ga[1] - sa[1])); worst["anchor"] = max(worst.get("anchor", 0.0), float(np.linalg.norm(ga[2:] - sa[2:])))
+                if abs(ga[1] - sa[1]) > 1e-8 or np.linalg.norm(ga[2:] - sa[2:]) > 1e-4:
+                    bad.append("%s: alignment differs: yaw %.3e rad, anchor %.3e m" % (tag, abs(ga[1] - sa[1]), np.linalg.norm(ga[2:] - sa[2:])))
         # in-state SLAM landmarks: which ones the update evaluated and accepted, which ones the delayed initialisation added, which ones
         # are in the state after the frame and which ones left it
         for k in ("lm_upd_ids", "lm_upd_acc", "lm_init_ids", "lm_ids", "lm_marg_ids"):
@@ -139,12 +149,18 @@ def load_golden(name):
     return sf.unpack_traces(z), str(z["spec"]), str(z["overrides"])
 
 
-def run_shim(spec, overrides, extra=()):
+def run_shim(spec, overrides, extra=(), raw_gnss=False, tmp=None):
     sets = []
     for line in list(overrides.splitlines()) + list(extra):
         if line.strip():
             sets += ["--set", line]
-    r = subprocess.run([TOOL, "--synth", spec, "--trace"] + sets, capture_output=True, text=True, timeout=900)
+    src = ["--synth", spec]
+    if raw_gnss:                                                           # the recording with raw GNSS epochs, rebuilt here (deterministic), played as a FILE
+        from oracle import gen_stream_golden as gen
+        rec = os.path.join(tmp, "raw_gnss.ingvior")
+        gen.write_recording(spec, rec, raw_gnss=True)
+        src = [rec]
+    r = subprocess.run([TOOL] + src + ["--trace"] + sets, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     return parse_trace(r.stdout)
 
@@ -230,6 +246,35 @@ def test_a_wrong_selection_rule_is_caught_by_the_comparison(tmp_path):
 
 
 # ---- GPU: the shim against the golden streams ---------------------------------------------------------------------------------
+@needs_tool
+@pytest.mark.gpu
+def test_shim_aligns_itself_as_the_golden_stream_does(tmp_path):
+    """sw11_gnss_align: no ALIGNMENT record, a raw GNSS epoch (ephemerides + observations) in front of every GNSS_MEAS record.  The filter
+    buffers gv_align_batch_size epochs, drops the first batch (the camera is still accelerating: horizontal velocity excitation below
+    gv_align_vel_thres, GvioAligner.cpp:104-124), aligns on the second - GvioAligner::batchAlign on the device's satellite geodesy
+    (host/GvioAligner.cpp over ingvio_gnss_sat_eval) against oracle/gvio_align.py over the C oracle's: aligned in the same frame, then
+    checkYofStatus, the delayed initialisations of the clock states and the GNSS updates with the alignment each side FOUND (measured:
+    yaw 4e-13 rad, anchor 7e-9 m apart; nominal state 7e-10 - inside the tolerance of every other stream)."""
+    gold, spec, ov = load_golden("sw11_gnss_align")
+    got = run_shim(spec, ov, raw_gnss=True, tmp=str(tmp_path))
+    bad, worst = compare(gold, got)
+    print("self-aligning stream: %d frames, yaw %.2e rad, anchor %.2e m, nominal state %.2e, diag(P) %.2e, GNSS scalars %.2e"
+          % (len(got), worst.get("yaw", -1), worst.get("anchor", -1), worst["pose"], worst["diag"], worst["gnss"]))
+    assert not bad, "\n".join(bad[:10])
+    first = min(f for f, t in enumerate(gold) if t["align"][0])
+    assert 20 < first < 40 and abs(gold[first]["align"][1] - 0.3) < 0.02                       # the generating yaw offset (SynthStream.cpp:100)
+    assert sum(int(t["gnss_rows"]) for t in gold[first + 1:]) > 300                            # and GNSS updates from then on
+
+
+@needs_tool
+@pytest.mark.gpu
+def test_self_aligning_stream_with_another_batch_size_goes_red(tmp_path):
+    gold, spec, ov = load_golden("sw11_gnss_align")
+    got = run_shim(spec, ov, extra=["gv_align_batch_size: 10"], raw_gnss=True, tmp=str(tmp_path))
+    bad, _ = compare(gold, got)
+    assert bad and "align" in " ".join(bad), bad[:3]
+
+
 @needs_tool
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", STREAMS)

@@ -105,6 +105,12 @@ static void printTrace(int k, ingvio::IngvioFilter& f, bool keyframe)
         printInts("LM_MARG_IDS", gone);
         lm_prev = std::set<int>(ids.begin(), ids.end());
     }
+    // the world <-> ENU / ECEF alignment the GNSS updates use: given with the recording, or found by GvioAligner::batchAlign on the raw epochs
+    {
+        const GvioAlignment& al = f.gnssAlignment();
+        std::vector<double> a = { al.aligned ? 1.0 : 0.0, al.yaw_offset, al.anchor_ecef[0], al.anchor_ecef[1], al.anchor_ecef[2] };
+        printDoubles("ALIGN", a);
+    }
     std::vector<int> table;
     for (const auto& v : StateManager::errVariables(state)) { table.push_back(v->idx()); table.push_back(v->size()); }
     printInts("TABLE", table);
@@ -194,9 +200,11 @@ int main(int argc, char** argv)
     }
     ingvio::ReplayStats st;
     std::string err;
+    int trace_k = 0;
     const bool ok = ingvio::replayFile(file, overrides, dump,
-        [](const ingvio::msg::Odometry& od, const ingvio::IngvioFilter& f) {
+        [&](const ingvio::msg::Odometry& od, const ingvio::IngvioFilter& f) {
             auto& flt = const_cast<ingvio::IngvioFilter&>(f);
+            if (trace) { printTrace(++trace_k, flt, flt.params()._is_key_frame != 0); return; }      // ingvio_replay <file> --trace: as --synth ... --trace
             std::printf("ODOM %.9f %.9f %.9f %.9f %.9f %.9f %.9f %.9f %.6f %.6f %.6f %d %zu\n", od.header.stamp.toSec(), od.position.x, od.position.y,
                         od.position.z, od.orientation.x, od.orientation.y, od.orientation.z, od.orientation.w, od.linear_velocity.x,
                         od.linear_velocity.y, od.linear_velocity.z, flt.state()->curr_cov_size(), flt.state()->_sw_camleft_poses.size());
