@@ -271,7 +271,7 @@ def kernel_that_ran(stage, cand, C, stereo=True):
     if stage == "gate":
         if not stereo:
             return "k_feat_gate3%s<%d>" % ("_big" if C > 16 else "", C)
-        cls = 6 if C <= 6 else 11 if C <= 11 else 16 if C <= 16 else 24 if C <= 24 else 28 if C <= 28 else 30 if C <= 30 else 32 if C <= 32 else 36      # launch_factored / launch_bigwin classes
+        cls = 6 if C <= 6 else 11 if C <= 11 else 12 if C <= 12 else 16 if C <= 16 else 24 if C <= 24 else 28 if C <= 28 else 30 if C <= 30 else 32 if C <= 32 else 36      # launch_factored / launch_bigwin classes
         return "%s<%d>" % (cand[0], cls)
     return name
 

@@ -1290,7 +1290,7 @@ __global__ __launch_bounds__(256) void k_chunk_sum(const double* __restrict__ Ap
 int factored_rec_size(int cmax)
 {
     if (cmax > 16) return cmax <= bigwin_cmax() ? bigwin_rec_size() : 0;
-    const int cls = cmax <= 6 ? 6 : (cmax <= 11 ? 11 : 16);
+    const int cls = cmax <= 6 ? 6 : (cmax <= 11 ? 11 : (cmax <= 12 ? 12 : 16));
     return rec_size(cls);
 }
 
@@ -1373,12 +1373,15 @@ int launch_factored(const FactoredLaunch& L, hipStream_t st)
         return 0;
     }
     const int cm = cm_sel;
-    const int cls = cm <= 6 ? 6 : (cm <= 11 ? 11 : (cm <= 16 ? 16 : -1));
+    // class 12 (round 6): an 11-pose window in sliding-window mode holds 12 clones at update time; on the 16-clone instantiations the
+    // Gram kernel spills (132 B of scratch per lane) and both kernels loop over four slots that do not exist
+    const int cls = cm <= 6 ? 6 : (cm <= 11 ? 11 : (cm <= 12 ? 12 : (cm <= 16 ? 16 : -1)));
     if (cls < 0) return -1;
 #define DISPATCH(CM)                                                         \
     if (cls == CM) { if (L.stereo) launch_ft<CM, true>(L, st); else launch_ft<CM, false>(L, st); return 0; }
     DISPATCH(6)
     DISPATCH(11)
+    DISPATCH(12)
     DISPATCH(16)
 #undef DISPATCH
     return -1;
