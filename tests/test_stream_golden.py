@@ -1,7 +1,8 @@
 """Stream-level parity of the drop-in path: the C++ shim's callbacks on the device against the golden streams.
 
-tests/golden/stream_*.npz hold, for every processed camera frame of seven synthetic streams (key-frame and sliding-window mode, 11
-and 21 clones, the RemoveLost cap as written and lifted, stereo and mono), what an INDEPENDENT Python transcription of the reference's policy layer
+tests/golden/stream_*.npz hold, for every processed camera frame of fifteen synthetic streams (key-frame and sliding-window mode, 11
+and 21 clones, the RemoveLost cap as written and lifted, stereo and mono, raw GNSS epochs; round 6: the 27- / 35-pose windows and
+parameter values the reference ships, in-state SLAM landmarks, a stream in which the filter aligns itself), what an INDEPENDENT Python transcription of the reference's policy layer
 (oracle/stream_filter.py: IngvioFilter::callbackStereoFrame, RemoveLost / SwMarg / Keyframe selection, anchor change, observation
 cleaning, eraseInvalidFeatures, marginalisation) decided while driving the CPU oracle, and the state it ended the frame with.
 `ingvio_replay --synth <spec> --trace` plays the same SplitMix64 stream through IngvioFilter on the device.  Compared per frame:
