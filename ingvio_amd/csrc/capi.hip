@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <string>
 #include <atomic>
 #include <condition_variable>
@@ -403,6 +404,7 @@ public:
     // runs job(t) for t = 1 .. T - 1 on the workers and job(0) on the caller; false: the pool is busy (caller falls back)
     bool run(int T, const std::function<void(int)>& job)
     {
+        if (getpid() != owner_) return false;                             // a fork()ed child has the object but not its threads
         std::unique_lock<std::mutex> user(user_m_, std::try_to_lock);
         if (!user.owns_lock()) return false;
         ensure(T - 1);
@@ -419,9 +421,10 @@ public:
         return true;
     }
 private:
-    HostPool() {}
+    HostPool() : owner_(getpid()) {}
     ~HostPool()
     {
+        if (getpid() != owner_) { for (auto& t : th_) t.detach(); return; }
         { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++gen_; }
         cv_start_.notify_all();
         for (auto& t : th_) t.join();
@@ -452,6 +455,7 @@ private:
             }
         }
     }
+    const pid_t owner_;
     std::mutex user_m_, m_;
     std::condition_variable cv_start_, cv_done_;
     std::vector<std::thread> th_;
