@@ -66,27 +66,40 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// value of lane (i - N) mod 16 of the same 16-lane row (DPP row_ror:N on both halves of the double): no LDS traffic, unlike __shfl
+// value of lane (i - N) mod 16 of the same 16-lane row (DPP row_ror:N on both halves of the double): no LDS traffic, unlike __shfl.
+// bound_ctrl with full row / bank masks: every lane is written, so the compiler may leave `old` undefined - with bound_ctrl off
+// (rounds 4-6) every half was preceded by a v_mov_b32 0 of its destination: four VALU instructions per rotated double instead of two.
 template <int N>
 __device__ __forceinline__ double row_ror_f64(double v)
 {
     static_assert(N >= 1 && N <= 15, "row_ror");
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + N, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N, 0xf, 0xf, false);
+#ifdef INGVIO_DPP32      // A/B switch (tools/build_tu_variant.sh dpp32 kernels_factored -DINGVIO_DPP32): the forms of rounds 4-6
+    constexpr bool BC = false;
+#else
+    constexpr bool BC = true;
+#endif
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + N, 0xf, 0xf, BC);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N, 0xf, 0xf, BC);
     return __hiloint2double(hi, lo);
 }
 
-// value of lane `src` (0..15, a run-time constant after unrolling) of the same 16-lane row: DPP row_newbcast on both halves
+// value of lane `src` (0..15, a run-time constant after unrolling) of the same 16-lane row.  row_newbcast is the one DPP control
+// gfx90a+ executes on 64-bit operands: ONE v_mov_b64_dpp per double (the 32-bit pair with `old` = 0 was four instructions - 270 +
+// 270 of the 2900 VALU instructions of a k_feat_gate5<11> wave, all in the register finish of the eliminations)
 __device__ __forceinline__ double row_bcast_f64(double v, int src)
 {
-    int lo = __double2loint(v), hi = __double2hiint(v);
     switch (src & 15) {
-#define INGVIO_BC(N) case N: lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + N, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + N, 0xf, 0xf, false); break;
+#ifdef INGVIO_DPP32
+#define INGVIO_BC(N) case N: return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + N, 0xf, 0xf, false), \
+                                                     __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + N, 0xf, 0xf, false));
+#else
+#define INGVIO_BC(N) case N: return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + N, 0xf, 0xf, true);
+#endif
         INGVIO_BC(0) INGVIO_BC(1) INGVIO_BC(2) INGVIO_BC(3) INGVIO_BC(4) INGVIO_BC(5) INGVIO_BC(6) INGVIO_BC(7)
         INGVIO_BC(8) INGVIO_BC(9) INGVIO_BC(10) INGVIO_BC(11) INGVIO_BC(12) INGVIO_BC(13) INGVIO_BC(14) INGVIO_BC(15)
 #undef INGVIO_BC
     }
-    return __hiloint2double(hi, lo);
+    return v;
 }
 
 // 1/x to full FP64 precision: v_rcp_f64 + two Newton steps (the IEEE division expands to ~3x the latency).  Measured on MI355X
