@@ -91,6 +91,7 @@ struct ingvio_ctx {
     // what d_chi2 and d_noise hold (single-filter latency: an update re-sent the same gate table and the same noise variance with every
     // call, two host-to-device copies of ~7 us each in front of the kernels); invalidated by every other writer of those buffers
     struct { std::vector<double> chi2; bool chi2_ok = false; double var = 0.0; int b0 = -1, nb = 0; bool noise_ok = false; } upc;
+    int apply_flipped = 0;              // set by run_msckf_factored: the fused marginalisation's flip (cur, n) was done by the write-back kernel itself (k_info_apply)
     bool fork_recorded = false;         // large windows: ev_fork already recorded on the main stream by the caller of run_msckf_factored
     unsigned long long* d_tri_mask = nullptr;      // [B][f_max], allocated on first use: triangulation masks of ingvio_msckf_update_tri
     char* d_imu = nullptr;              // [IMU_SLAB_NB filters] Phi | G | dt | gnss_idx of ingvio_propagate(_fused) in one piece (few filters per call)
@@ -315,6 +316,13 @@ int parts_prepare(ingvio_ctx* c, int P)
 static bool no_snap_propagate()
 {
     static const bool v = [] { const char* e = getenv("INGVIO_RESTORE"); return e && !strcmp(e, "pass"); }();
+    return v;
+}
+
+// INGVIO_FLIP=launch: the fused marginalisation's flip of the halves stays a launch of its own (k_post_marg; comparison runs)
+static bool no_apply_flip()
+{
+    static const bool v = [] { const char* e = getenv("INGVIO_FLIP"); return e && !strcmp(e, "launch"); }();
     return v;
 }
 
@@ -753,6 +761,9 @@ int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int s
     const bool big = c->d.c_max > 16;
     L.mstride = c->ystride; L.n_cap = c->d.n_max;
     L.marg_idx = marg_idx; L.marg_size = marg_size; L.pc_base = c->d_pcbase + b0;
+    // the write-back flips the halves itself where its kernel can (k_info_apply); the caller asks c->apply_flipped before launch_post_marg
+    c->apply_flipped = 0;
+    L.flip_cnt = c->d_pcbase + c->d.batch + b0; L.did_flip = no_apply_flip() ? nullptr : &c->apply_flipped;
     // Order of ISSUE (round 5, single-filter latency): the fork point is recorded first (by the caller already when it has something to
     // run between the fork and the gate - the triangulation of ingvio_msckf_update_tri), then the main stream's gate and Gram launches,
     // and only then the eight launches of the side stream - issued first they kept the host busy for 24 us during which the gate could
@@ -931,7 +942,7 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
     rc |= dalloc(c, &c->d_accept, (size_t)B * fm);
     rc |= dalloc(c, &c->d_Rpart, (size_t)B * c->G * c->rstride); rc |= dalloc(c, &c->d_chunk_used, (size_t)B * c->G);
     rc |= dalloc(c, &c->d_H, (size_t)B * c->hstride); rc |= dalloc(c, &c->d_res, (size_t)B * c->mld);
-    rc |= dalloc(c, &c->d_colmap, (size_t)B * c->cstride); rc |= dalloc(c, &c->d_nc, B); rc |= dalloc(c, &c->d_pcbase, B);
+    rc |= dalloc(c, &c->d_colmap, (size_t)B * c->cstride); rc |= dalloc(c, &c->d_nc, B); rc |= dalloc(c, &c->d_pcbase, 2 * (size_t)B);      // [B] pc_base | [B] arrival counters of the fused flip (k_info_apply)
     rc |= dalloc(c, &c->d_tri_ok, (size_t)B * fm);
     rc |= dalloc(c, &c->d_imu, (size_t)IMU_SLAB_NB * (8 * (size_t)KMAX * (225 + 180 + 1) + 64) + 256);
     if (desc->c_max <= 16) rc |= dalloc(c, &c->d_Tflat, (size_t)std::min(B, APPLY_FLAT_NB) * c->ldp * 100);
@@ -2713,7 +2724,7 @@ static int frame_run_split(ingvio_ctx* c, int restore_prior, int P, bool gnss_fu
         c->tok_wait = c->tok_last; c->tok_rec = q.ev_apply;
         rc = run_msckf_factored(c, b0, nb, c->st_op, c->st_stereo, c->st_fmax_used, c->d_idx + b0, 6, 2, gnss_fuse);
         c->tok_last = rc ? nullptr : q.ev_apply;
-        if (!rc) {
+        if (!rc && !c->apply_flipped) {
             ProfScope pr(c, PF_MARG);
             launch_post_marg(view(c), b0, nb, c->d_idx + b0, 6, q.st);
         }
@@ -2749,7 +2760,7 @@ static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
         if (with_lm2) { rc2 = landmark_update_launch(c, 0, B2); if (rc2) return rc2; }
         {
             ProfScope p(c, PF_MARG);
-            if (!with_lm2) launch_post_marg(view(c), 0, B2, c->d_idx, 6, c->st);
+            if (!with_lm2) { if (!c->apply_flipped) launch_post_marg(view(c), 0, B2, c->d_idx, 6, c->st); }
             else launch_marginalize(view(c), 0, B2, c->d.n_max, c->d_idx, 6, c->st);
         }
         for (int b = 0; b < B2; ++b) if (c->st_marg[b] >= 0) { c->h_n[b] -= 6; c->h_cur[b] ^= 1; }
@@ -2851,14 +2862,17 @@ static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
                                     : run_msckf(c, 0, B, c->st_op, c->st_stereo, c->st_fmax_used));
     if (rc) return rc;
     if (lm_oop) {
-        launch_post_marg(view(c), 0, B, c->d_zero_idx, 0, c->st);
+        if (!c->apply_flipped) launch_post_marg(view(c), 0, B, c->d_zero_idx, 0, c->st);
         for (int b = 0; b < B; ++b) c->h_cur[b] ^= 1;
     }
     bool lm_fused = false;
     if (with_lm) { rc = landmark_update_launch(c, 0, B, c->d_idx, 6, &lm_fused); if (rc) return rc; }
     {
         ProfScope p(c, PF_MARG);
-        if (fuse || lm_fused) launch_post_marg(view(c), 0, B, c->d_idx, 6, c->st);
+        if (fuse) {
+            if (!c->apply_flipped) launch_post_marg(view(c), 0, B, c->d_idx, 6, c->st);
+        }
+        else if (lm_fused) launch_post_marg(view(c), 0, B, c->d_idx, 6, c->st);
         else launch_marginalize(view(c), 0, B, c->d.n_max, c->d_idx, 6, c->st);
     }
     // a landmark stage belongs to ONE frame: unless the caller replays the same prior (restore_prior, the bench and the parity tests)

@@ -691,7 +691,8 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
                                                        const double* __restrict__ Pcall, int ystride, const int* __restrict__ m_all,
                                                        double* __restrict__ dx_all, int* __restrict__ status,
                                                        const int* __restrict__ marg_idx, int msize, const int* __restrict__ pc_base,
-                                                       const double* __restrict__ Ygall = nullptr, size_t ygstride = 0, const int* __restrict__ gm_all = nullptr)
+                                                       const double* __restrict__ Ygall = nullptr, size_t ygstride = 0, const int* __restrict__ gm_all = nullptr,
+                                                       int* __restrict__ flip_cnt = nullptr)
 {
     constexpr int MP = (NC + 3) & ~3, K4 = MP / 4, JT = (MP + 15) / 16, KY = YW / 4, MPY = MP + YW;
     // sT (layout change of T, first phase) and sB (B-operand tile Pc[16 tj .. +16][0..MP), staged once per workgroup
@@ -733,6 +734,17 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
     const int no = fused ? n - msize : n, nt = (no + 15) >> 4;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;      // (wave as a scalar, readfirstlane: 130 -> 141 us per launch - left a vector value)
     if (2 * part * 4 >= nt) return;                           // whole workgroup idle (uniform)
+    // Fused marginalisation (round 6): the halves flip and n shrinks inside this kernel - what k_post_marg did in a dependent launch of
+    // its own behind it (5 us per step whatever the batch).  Every workgroup that works on the filter (8 part < nt) has read cur / n
+    // above and arrives here; the last ARRIVAL flips (the others hold their pointers in registers; an idle workgroup that starts later
+    // reads the smaller n and stays idle).  The arrival is issued first thing and looked at after the first memory round trip of the
+    // set-up (flip_check below): nothing of it lives into the sweep - as an epilogue it kept n, nt and b alive through the kernel,
+    // which runs at the SGPR limit (106, 18 spilled): 28 spilled, +13 us; the flip moved into the solve cost the write-back 11 us as well.
+    int flip_old = -2;
+    if (flip_cnt && fused && tid == 0) flip_old = atomicAdd(&flip_cnt[bl], 1);
+    auto flip_check = [&]() __attribute__((always_inline)) {
+        if (flip_old == ((nt + 7) >> 3) - 1) { flip_cnt[bl] = 0; cv.cur[b] ^= 1; cv.n[b] = n - msize; }
+    };
     const int pw = part * 4 + wave;                           // this wave owns tile rows pw and nt-1-pw: nt+1 tiles, balanced
     const bool wave_on = 2 * pw < nt;
     const int tiR[2] = { pw, nt - 1 - pw };
@@ -859,6 +871,7 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
         for (int u = 0; u < MST; ++u) { const int e = tid + 256 * u; if (e < MP * MP) sM[e] = mreg[u]; }
         lds_barrier();
     }
+    flip_check();
     dbg_stamp(11);
     // ---- T rows of this wave's (up to) two tile rows, kept as A-operand fragments ------------------------------
     double tfrag[TLDS ? 1 : 2][K4];                            // TLDS: row tiR[1] only
@@ -1331,11 +1344,12 @@ int launch_factored(const FactoredLaunch& L, hipStream_t st)
             return 0;
         }
 #define APPLY_DISPATCH(NC)                                                                                            \
-        if (L.gY) hipLaunchKernelGGL((k_info_apply<NC, 1, 16>), dim3(nb8 * wgpf), dim3(256), 0, st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride, L.Pc, \
-                           L.ystride, L.m_out, L.dx, L.status, L.marg_idx, L.marg_size, L.pc_base, L.gY, L.gYstride, L.gm); \
+        if (L.gY) { hipLaunchKernelGGL((k_info_apply<NC, 1, 16>), dim3(nb8 * wgpf), dim3(256), 0, st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride, L.Pc, \
+                           L.ystride, L.m_out, L.dx, L.status, L.marg_idx, L.marg_size, L.pc_base, L.gY, L.gYstride, L.gm, flip); if (flip) *L.did_flip = 1; } \
         APPLY_TW2(NC)                                                                                                 \
-        else hipLaunchKernelGGL((k_info_apply<NC, 1>), dim3(nb8 * wgpf), dim3(256), 0, st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride, L.Pc, \
-                           L.ystride, L.m_out, L.dx, L.status, L.marg_idx, L.marg_size, L.pc_base);
+        else { hipLaunchKernelGGL((k_info_apply<NC, 1>), dim3(nb8 * wgpf), dim3(256), 0, st, L.cv, L.b0, L.nb, wgpf, L.T, L.mstride, L.Pc, \
+                           L.ystride, L.m_out, L.dx, L.status, L.marg_idx, L.marg_size, L.pc_base, (const double*)nullptr, (size_t)0, (const int*)nullptr, flip); if (flip) *L.did_flip = 1; }
+        int* const flip = (L.marg_idx && L.did_flip) ? L.flip_cnt : nullptr;
         // class 72 = a 12-clone window: an 11-pose window in sliding-window mode holds 12 clones at update time (SwMargUpdate.cpp:412-419)
         if (ncm <= 36) { APPLY_DISPATCH(36) } else if (ncm <= 66) { APPLY_DISPATCH(66) } else if (ncm <= 72) { APPLY_DISPATCH(72) } else { APPLY_DISPATCH(96) }
 #undef APPLY_DISPATCH

@@ -39,6 +39,9 @@ struct FactoredLaunch {
     const int* marg_idx;  // stage 3: fused StateManager::marginalize, per filter state index or -1 (nullptr: none)
     int marg_size;
     int* pc_base;         // [nb] stage 2 -> 3: first clone column when Pc is read straight from P, else -1
+    int* flip_cnt;        // stage 3 with a fused marginalisation: [nb] arrival counters (zero between launches) - the LAST workgroup of a
+                          // filter to START flips the ping-pong halves and shrinks n (what k_post_marg did in a launch of its own), or nullptr
+    int* did_flip;        // host flag, set by launch_factored when the stage-3 kernel it chose does that flip
     double* big_sg;       // large-window path: [nb][G][36][36][34] sparse sums (kernels_bigwin.hip)
     double* big_wk;       // large-window path: per-filter solve workspace (bigwin_wk_doubles)
     int ncol_cap;         // 6 * (context c_max): size class of the large-window solve
