@@ -216,7 +216,7 @@ def hbm_traffic_bytes(c):
 # The library's profile slots are named after the STAGE; rocprofv3 sees kernels.  Stage -> candidates, each candidate a tuple of
 # kernels whose counters are added up (x their launches per step): the first candidate with counters for all its kernels wins.
 STAGE_KERNELS = {
-    "gate": (("k_feat_gate5",), ("k_feat_gate4",), ("k_feat_gate3",)),      # stereo: four features per wave (round 4, windows <= 11 clones) / one per wave (round 3) / first generation, mono
+    "gate": (("k_feat_gate5",), ("k_feat_gate4",), ("k_feat_gate5m",), ("k_feat_gate3",)),      # stereo: four features per wave (round 4, windows <= 11 clones) / one per wave (round 3); mono: four per wave (round 6, 7..11 clones) / first generation
     "gram": (("k_feat_gram2",),),
     "solve": (("k_info_solve",), ("k_info_update",)),            # windows up to 12 clones / 13..16
     "apply": (("k_info_apply",),),
@@ -235,6 +235,14 @@ STAGE_KERNELS_BIG = {                                                      # win
 }
 
 
+def mono_gate_kernel_of(C):
+    """The mono gate kernel launch_factored / launch_bigwin pick: four features per wave for the 11-clone class (round 6, gate5m_kernel.h),
+    the first-generation gate elsewhere (and with INGVIO_GATE=3)."""
+    if C > 16:
+        return "k_feat_gate3_big"
+    return "k_feat_gate5m" if (6 < C <= 11 and os.environ.get("INGVIO_GATE", "")[:1] != "3") else "k_feat_gate3"
+
+
 def gate_kernel_of(C):
     """The stereo gate kernel launch_factored / launch_bigwin pick for a window of C clones (INGVIO_GATE selects the older ones)."""
     g = os.environ.get("INGVIO_GATE", "")[:1]
@@ -250,7 +258,7 @@ def counters_for(counters, name, big, C=None, stereo=True):
     table = STAGE_KERNELS_BIG if big and name in STAGE_KERNELS_BIG else STAGE_KERNELS
     cands = table.get(name, ((name,),))
     if name == "gate" and C is not None:            # the gate that ran is known: counters of another generation do not apply
-        cands = ((gate_kernel_of(C) if stereo else ("k_feat_gate3_big" if C > 16 else "k_feat_gate3"),),)      # mono: the first-generation gate
+        cands = ((gate_kernel_of(C) if stereo else mono_gate_kernel_of(C),),)
     if counters is None:
         return None, cands[0]
     for cand in cands:
@@ -269,7 +277,7 @@ def kernel_that_ran(stage, cand, C, stereo=True):
     """The kernel rocprofv3 sees for a profile slot (slots are named after the stage)."""
     name = "+".join(cand)
     if stage == "gate":
-        if not stereo:
+        if not stereo and cand[0] != "k_feat_gate5m":
             return "k_feat_gate3%s<%d>" % ("_big" if C > 16 else "", C)
         cls = 6 if C <= 6 else 11 if C <= 11 else 12 if C <= 12 else 16 if C <= 16 else 24 if C <= 24 else 28 if C <= 28 else 30 if C <= 30 else 32 if C <= 32 else 36      # launch_factored / launch_bigwin classes
         return "%s<%d>" % (cand[0], cls)

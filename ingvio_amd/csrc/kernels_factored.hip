@@ -20,6 +20,7 @@
 
 #include "gate_kernel.h"
 #include "gate5_kernel.h"
+#include "gate5m_kernel.h"
 
 // K3 + K5 for the window classes 6 / 11 / 16, see gate_kernel.h: workgroups of GATE_FPW waves = GATE_FPW features of one
 // filter; with GATE_FPW > 1 wave 0 runs the per-observation front for all of them (64 / GATE_FPW lanes each), then one
@@ -60,6 +61,15 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(GATE5_WPE,
     CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out, int* __restrict__ accept_out)
 {
     gate5_body<CMAX>(cv, fv, op, b0, nb, fmax_used, gamma_out, accept_out);
+}
+
+// Mono windows up to 11 clones (round 6): the measurement-space gate as a quasi-definite bordered system on the same machinery
+// (gate5m_kernel.h) - four features per wave, two tile rows instead of gate3's three.
+template <int CMAX>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(GATE5_WPE, GATE5_WPE))) void k_feat_gate5m(
+    CovView cv, FrameView fv, MsckfOpts op, int b0, int nb, int fmax_used, double* __restrict__ gamma_out, int* __restrict__ accept_out)
+{
+    gate5m_body<CMAX>(cv, fv, op, b0, nb, fmax_used, gamma_out, accept_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1247,6 +1257,14 @@ static void launch_ft(const FactoredLaunch& L, hipStream_t st)
         if constexpr (STEREO && CMAX <= 11) {
             if (!gate3 && !gate4) {
                 hipLaunchKernelGGL((k_feat_gate5<CMAX>), dim3(nb8 * ((L.fmax_used + 3) / 4)), dim3(WAVE), 0, st, L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used,
+                                   L.gamma, L.accept);
+                return;
+            }
+        }
+        if constexpr (!STEREO && CMAX == 11) {                        // mono, 7..11 clones: four features per wave (INGVIO_GATE=3: the first-generation gate)
+            static const bool gate3m = [] { const char* e = getenv("INGVIO_GATE"); return e && e[0] == '3'; }();
+            if (!gate3m) {
+                hipLaunchKernelGGL((k_feat_gate5m<CMAX>), dim3(nb8 * ((L.fmax_used + 3) / 4)), dim3(WAVE), 0, st, L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used,
                                    L.gamma, L.accept);
                 return;
             }
