@@ -327,6 +327,51 @@ def test_gate_mixed_groups_of_four_vs_oracle(orc, selected, F, C):
     ctx2.close()
 
 
+@pytest.mark.parametrize("selected,F,C", [(0, 150, 11), (1, 149, 11), (0, 7, 9), (1, 13, 7), (0, 30, 8)])
+def test_mono_gate_groups_of_four_vs_oracle(orc, selected, F, C):
+    """k_feat_gate5m (round 6): the MONO gate of 7..11-clone windows, four features per wave - the measurement-space gate value as the
+    last corner of a quasi-definite bordered LDL^T (2 nobs rows of S, the three columns of Hf as negative pivots, r as the border).
+    Groups whose members have different observation sets, features with no / one observation (2 nobs - 3 <= 0: NaN, rejected, as the
+    reference's size check), with two (one degree of freedom), an anchor that is or is not among the observing clones, feature counts
+    that are not multiples of four, the Q10 (selected-timestamp) variant: gamma and the accept mask of every feature against the
+    oracle's dense nullspace evaluation, then the posterior."""
+    from ingvio_amd import capi, host, synth
+    n_lm = 10
+    n_max = ((21 + 6 + 3 * n_lm + 6 * C + 15) // 16) * 16
+    ctx2 = capi.Context(batch=1, n_max=n_max, c_max=C, f_max=max(F, 4), m_max=64)
+    flt, step, frame, info = synth.build_case(lambda P: capi.DeviceCov(ctx2, 0, P), host.imu_transition, seed=170 + F, F=F, C=C, n_landmarks=n_lm,
+                                              stereo=False)
+    for Phi, G, dt in zip(step["Phi"], step["G"], step["dt"]):
+        flt.cov.propagate(Phi, G, dt, step["sigma"], step["enable_gnss"], step["gnss_idx"], step["sigma_cb"], step["sigma_rw"])
+    flt.cov.augment(step["R_i2w"])
+    P0 = ctx2.cov_get(0)
+    rng = np.random.default_rng(6000 + F)
+    mask = np.zeros(F, dtype=np.uint64); dof = np.zeros(F, dtype=np.int32)
+    for j in range(F):
+        kind = j % 8
+        if kind == 0: obs = []                                                     # no observation at all
+        elif kind == 1: obs = [int(rng.integers(0, C))]                            # one: 2 rows, nothing left after the projection
+        elif kind == 2: obs = sorted(rng.choice(C, size=2, replace=False).tolist())  # two: one degree of freedom
+        elif kind == 3: obs = list(range(C))                                       # the full window
+        else: obs = sorted(rng.choice(C, size=int(rng.integers(2, C + 1)), replace=False).tolist())
+        mask[j] = np.uint64(sum(1 << int(o) for o in obs)); dof[j] = max(2 * len(obs) - 3, 1)
+    frame = dict(frame); frame["obs_mask"] = mask; frame["dof"] = dof
+    frame["anchor"] = rng.integers(0, C, size=F).astype(np.int32)
+    assert not frame["stereo"]
+    dx, acc, gam, rows = ctx2.msckf_update(0, frame, selected_variant=selected)
+    oc = orc.Cov(P0, ld=n_max)
+    dxo, acco, gamo, m = oc.msckf_update(frame, max_accept=0, compress_rule=1, selected_variant=selected)
+    assert np.array_equal(acc[0, :F], acco), np.flatnonzero(acc[0, :F] != acco)
+    g = gam[0, :F]
+    few = np.array([bin(int(mk)).count("1") < 2 for mk in mask])
+    assert np.isnan(g[few]).all() and not acc[0, :F][few].any()
+    ok = ~few & np.isfinite(gamo)
+    assert ok.sum() >= F // 2 and np.allclose(g[ok], gamo[ok], rtol=1e-8, atol=1e-10), np.abs(g[ok] - gamo[ok]).max()
+    P = ctx2.cov_get(0)
+    assert rel_err(P, oc.P) < TIGHT and np.linalg.norm(dx[0, :P0.shape[0]] - dxo) < 1e-8 * max(np.linalg.norm(dxo), 1e-6)
+    ctx2.close()
+
+
 @pytest.mark.parametrize("C,stereo,method", [(16, True, "factored"), (16, False, "factored"), (6, True, "factored"),
                                              (6, False, "factored"), (13, True, "factored"), (4, True, "factored"),
                                              (12, True, "factored"), (12, False, "factored"),      # 12 clones: the symmetric solve's 72 class (round 6)
