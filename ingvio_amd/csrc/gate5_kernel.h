@@ -266,6 +266,34 @@ __device__ __forceinline__ void gate5_body(CovView cv, FrameView fv, MsckfOpts o
         bool jreal[NTL];
 #pragma unroll
         for (int tj = 0; tj < NTL; ++tj) jreal[tj] = 16 * tj + l15 < np;
+#ifndef GATE5_FILL_PIN1      // round 6: ALL reads of the feature's tiles are issued before the first select (one PIN4 per tile keeps them out
+                             // of the selects' branches); -DGATE5_FILL_PIN1: pinned one by one (rounds 4-5) - a wait for LDS per element
+#pragma unroll
+        for (int t = 0; t < NLT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[fq][t][r] = kp[fidx[t][r]];
+        double wvv[NTL];
+#pragma unroll
+        for (int tj = 0; tj < NTL; ++tj) wvv[tj] = wq[wcol[tj]];
+#pragma unroll
+        for (int ti = 0; ti < NTL; ++ti) {
+#pragma unroll
+            for (int tj = 0; tj <= ti; ++tj) {
+                const int t = ti * (ti + 1) / 2 + tj;
+                double b0 = T[fq][t][0], b1 = T[fq][t][1], b2 = T[fq][t][2], b3 = T[fq][t][3];
+                PIN4(b0, b1, b2, b3);
+                const double bvs[4] = { b0, b1, b2, b3 };
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ireal = 16 * ti + kq + 4 * r < np;
+                    const double padv = (fdiag[t][r] && !ireal) ? 1.0 : 0.0;          // unit pivots on the padding rows
+                    double v = (ireal && jreal[tj]) ? bvs[r] : padv;
+                    if (ti == NTL - 1 && r == 3) v = kq == 3 ? (jreal[tj] ? wvv[tj] : 0.0) : v;      // row BR for kq == 3: the border row w^T, corner 0
+                    T[fq][t][r] = v;
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int ti = 0; ti < NTL; ++ti) {
 #pragma unroll
@@ -287,6 +315,7 @@ __device__ __forceinline__ void gate5_body(CovView cv, FrameView fv, MsckfOpts o
                 }
             }
         }
+#endif
         wave_sync();                          // triangle fq & 1 is free again; triangle (fq + 1) & 1 is complete
     }
     dbg_stamp(8);

@@ -282,32 +282,36 @@ __device__ __forceinline__ void gate5m_body(CovView cv, FrameView fv, MsckfOpts 
         bool jreal[NTL];
 #pragma unroll
         for (int tj = 0; tj < NTL; ++tj) jreal[tj] = 16 * tj + l15 < np;
+        // all reads of the feature's tiles first (unconditional, clamped indices), one PIN4 per tile in front of the selects (gate5_body)
+#pragma unroll
+        for (int t2 = 0; t2 < NLT; ++t2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[fq][t2][r] = kp[fidx[t2][r]];
+        double hrow[NTL], hcol[3];            // border ROW elements of rows HR + kq (r == 3 of the last tile row); border COLUMN elements of rows 16 + kq + 4 r
+#pragma unroll
+        for (int tj = 0; tj < NTL; ++tj) { const int col = 16 * tj + l15; hrow[tj] = fg.hb[kq][col < NPMAX ? col : 0]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { const int row = 16 * (NTL - 1) + kq + 4 * r, col = 16 * (NTL - 1) + l15; hcol[r] = fg.hb[col >= HR ? col - HR : 0][row < NPMAX ? row : 0]; }
 #pragma unroll
         for (int ti = 0; ti < NTL; ++ti) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * ti + kq + 4 * r;
-                const bool ireal = row < np;
+            for (int tj = 0; tj <= ti; ++tj) {
+                const int t2 = ti * (ti + 1) / 2 + tj;
+                double b0 = T[fq][t2][0], b1 = T[fq][t2][1], b2 = T[fq][t2][2], b3 = T[fq][t2][3];
+                PIN4(b0, b1, b2, b3);
+                const double bvs[4] = { b0, b1, b2, b3 };
+                const int col = 16 * tj + l15;
+                const bool bcol = col >= HR;                                          // border columns (Hf, r)
 #pragma unroll
-                for (int tj = 0; tj <= ti; ++tj) {
-                    const int t2 = ti * (ti + 1) / 2 + tj;
-                    const int col = 16 * tj + l15;
-                    double bv = kp[fidx[t2][r]];
-                    asm volatile("" : "+v"(bv));                                      // keep the read out of the selects' branches
-                    const bool brow = row >= HR, bcol = col >= HR;                    // border rows / columns (Hf, r): zero pivots, no padding
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + kq + 4 * r;
+                    const bool ireal = row < np, brow = row >= HR;                    // border rows: zero pivots, no padding
                     const double padv = (fdiag[t2][r] && !ireal && !brow) ? 1.0 : 0.0; // unit pivots on the padding rows np..HR-1
-                    double v = (ireal && jreal[tj]) ? bv : padv;
+                    double v = (ireal && jreal[tj]) ? bvs[r] : padv;
                     if (ti == NTL - 1) {
                         // the border, filled symmetrically (the diagonal tile keeps both triangles: the register finish reads whole rows)
-                        if (r == 3) {                                                 // rows HR + kq: column col of [Hf | r]^T
-                            double hv = fg.hb[kq][col < NPMAX ? col : 0];
-                            asm volatile("" : "+v"(hv));
-                            v = jreal[tj] ? hv : 0.0;
-                        } else if (tj == NTL - 1) {                                   // columns HR..HR+3 of the rows above the border
-                            double hv = fg.hb[bcol ? col - HR : 0][row < NPMAX ? row : 0];
-                            asm volatile("" : "+v"(hv));
-                            v = bcol ? (ireal ? hv : 0.0) : v;
-                        }
+                        if (r == 3) v = jreal[tj] ? hrow[tj] : 0.0;                   // rows HR + kq: column col of [Hf | r]^T
+                        else if (tj == NTL - 1) v = bcol ? (ireal ? hcol[r] : 0.0) : v;   // columns HR..HR+3 of the rows above the border
                     }
                     T[fq][t2][r] = v;
                 }

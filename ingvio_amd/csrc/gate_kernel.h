@@ -995,27 +995,40 @@ __device__ __forceinline__ void gate4_big_back(Gate4BigShared<CMAX>& sh, const M
 #pragma unroll
     for (int ti = 0; ti < NTL; ++ti) {
         if (gate4_row_owner<NTL>(ti) != W) continue;
+        // Round 6: every read of the tile row is UNCONDITIONAL, from an index clamped into the buffer (padding elements read something
+        // valid and are overridden), ALL of them are issued before the first select (one PIN4 per tile keeps them out of the selects'
+        // branches without a wait per element).  As `ireal ? kp[..] : ..` every element was an exec-masked branch with its own LDS
+        // round trip behind s_waitcnt lgkmcnt(0): ~100 serial round trips per wave, 10.8 k of the kernel's 73 k cycles (shader-clock
+        // stamps, 32 filters x 300 features x 30 clones).
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = 16 * ti + kq + 4 * r;
-            const bool ireal = i < np;
-            const int ii = ireal ? i : 0, tri_i = ii * (ii + 1) / 2;
+        for (int tj = 0; tj <= ti; ++tj)
 #pragma unroll
-            for (int tj = 0; tj <= ti; ++tj) {
-                const int jcol = 16 * tj + l15;
-                double bv;
-                if (tj < ti) bv = sh.kp[tri_i + jcol];
-                else {
-                    const int jj = jreal[tj] ? jcol : 0;
-                    bv = sh.kp[ii >= jj ? tri_i + jj : jj * (jj + 1) / 2 + ii];
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ti + kq + 4 * r, jcol = 16 * tj + l15;
+                const int hi = tj < ti ? i : (i > jcol ? i : jcol), lo = tj < ti ? jcol : (i > jcol ? jcol : i);
+                const int e = hi * (hi + 1) / 2 + lo;
+                T[ti * (ti + 1) / 2 + tj][r] = sh.kp[e < SH::KPK + 16 ? e : SH::KPK + 15];
+            }
+        double wv[NTL];
+        if (ti == NTL - 1) {
+#pragma unroll
+            for (int tj = 0; tj < NTL; ++tj) wv[tj] = sh.w[jreal[tj] ? 16 * tj + l15 : 0];
+        }
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj) {
+            double4_f& t4 = T[ti * (ti + 1) / 2 + tj];
+            double b0 = t4[0], b1 = t4[1], b2 = t4[2], b3 = t4[3];
+            PIN4(b0, b1, b2, b3);
+            const double bvs[4] = { b0, b1, b2, b3 };
+            const int jcol = 16 * tj + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ti + kq + 4 * r;
+                const bool ireal = i < np;
                 const double idv = (i == jcol) ? 1.0 : 0.0;
-                double v = (ireal && jreal[tj]) ? bv : ((!ireal && !jreal[tj]) ? idv : 0.0);
-                if (ti == NTL - 1 && r == 3) {
-                    const double wv = sh.w[jreal[tj] ? jcol : 0];
-                    v = kq == 3 ? (jreal[tj] ? wv : 0.0) : v;
-                }
-                T[ti * (ti + 1) / 2 + tj][r] = v;
+                double v = (ireal && jreal[tj]) ? bvs[r] : ((!ireal && !jreal[tj]) ? idv : 0.0);
+                if (ti == NTL - 1 && r == 3) v = kq == 3 ? (jreal[tj] ? wv[tj] : 0.0) : v;
+                t4[r] = v;
             }
         }
     }
