@@ -1218,9 +1218,18 @@ __device__ __forceinline__ void gate4_big_body(CovView cv, FrameView fv, MsckfOp
                 // the record's sums: Ns = sum N_o (-> Ns^-1), hs = sum h_o, Nsa = sum over the observations whose clone is not the anchor
                 double* const sums = Nh + CMAX * 12;
                 if (lane < 21) {
+                    // Round 6: all CMAX reads are issued together and selected afterwards, added in the same order - as a loop over nobs
+                    // with the read under its condition this was a chain of up to 36 dependent LDS round trips on 21 lanes
                     const int anch = lane >= 12, comp = anch ? lane - 12 : lane;
+                    double xs[CMAX];
+                    int cs[CMAX];
+#pragma unroll
+                    for (int o = 0; o < CMAX; ++o) { xs[o] = Nh[o * 12 + comp]; cs[o] = sh.cna[o]; }
+#pragma unroll
+                    for (int o = 0; o + 3 < CMAX; o += 4) PIN4(xs[o], xs[o + 1], xs[o + 2], xs[o + 3]);
                     double sacc = 0.0;
-                    for (int o = 0; o < nobs; ++o) sacc += (!anch || sh.cna[o]) ? Nh[o * 12 + comp] : 0.0;
+#pragma unroll
+                    for (int o = 0; o < CMAX; ++o) sacc += (o < nobs && (!anch || cs[o])) ? xs[o] : 0.0;
                     sums[lane] = sacc;
                 }
                 wave_sync();
