@@ -274,16 +274,28 @@ __device__ __forceinline__ void solve_wave(const SolveArgs<NC>& a, int* bad)
 #pragma unroll
             for (int c = 0; c < NT; ++c) {
                 const int col = 16 * c + l15;
+                if (D1.rows[W][w].valid && D1.rows[W][w].kind == 0 && c <= D1.rows[W][w].c1) {      // (compile-time: the tile exists)
+                    // Round 6: the tile's reads are unconditional - the indices are clamped into the window - and issued together, the
+                    // padding is selected afterwards: under `row < ncol && col < ncol` every element was an exec-masked branch with its
+                    // own LDS round trip (32 in a row per lane).  One pin per tile: all 128 reads at once spill (128 VGPRs at 4 waves).
+                    double x[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * D1.rows[W][w].rt + kq + 4 * r;
-                    double v = row == col ? 1.0 : 0.0;
-                    if (D1.rows[W][w].valid && D1.rows[W][w].kind == 0 && c <= D1.rows[W][w].c1 && row < ncol && col < ncol) {
-                        v = S[scol_r[w][r] * LDS + scol_c[c]];
-                        if (RED)                                                 // covariance of the DIFFERENCES to the reference clone
-                            v = (v - S[scol_r[w][r] * LDS + sref_c[c]]) - (S[sref_r[w][r] * LDS + scol_c[c]] - S[sref_r[w][r] * LDS + sref_c[c]]);
+                    for (int r = 0; r < 4; ++r) {
+                        x[r] = S[scol_r[w][r] * LDS + scol_c[c]];
+                        if (RED) {                                               // covariance of the DIFFERENCES to the reference clone
+                            const double x1 = S[scol_r[w][r] * LDS + sref_c[c]], x2 = S[sref_r[w][r] * LDS + scol_c[c]], x3 = S[sref_r[w][r] * LDS + sref_c[c]];
+                            x[r] = (x[r] - x1) - (x2 - x3);
+                        }
                     }
-                    T[w][c][r] = v;
+                    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * D1.rows[W][w].rt + kq + 4 * r;
+                        T[w][c][r] = (row < ncol && col < ncol) ? x[r] : (row == col ? 1.0 : 0.0);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[w][c][r] = (16 * D1.rows[W][w].rt + kq + 4 * r == col) ? 1.0 : 0.0;
                 }
             }
         __syncthreads();                                      // every wave holds its tiles of Pdd: the staging area becomes X and Y
@@ -459,9 +471,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __syncthreads();
     dbg_stamp(61);
     static_assert((NC + 6) * Cfg::LDSS <= 2 * MROWS * LDM, "the staged window block exceeds the X / Y area");
-    for (int e = tid; e < ncolF * ncolF; e += NTH) {          // S[i][j] = P(window column j, window column i): j runs along the coalesced direction
-        const int i = e / ncolF, j = e - i * ncolF;
-        X[i * Cfg::LDSS + j] = P[sColF[j] + (size_t)sColF[i] * ld];
+    {
+        // S[i][j] = P(window column j, window column i): j runs along the coalesced direction.  Round 6: a thread's loads are ALL issued
+        // before its first LDS store (as a loop `X[..] = P[..]` the stores to X - LDS, like the index table the addresses come from - kept
+        // every iteration's loads behind the previous store: 9 dependent global round trips per thread in front of everything else)
+        constexpr int SPT = (NCF * NCF + NTH - 1) / NTH;
+        const int nn = ncolF * ncolF;
+        const float inv = 1.0f / (float)ncolF;
+        double sv[SPT];
+        int so[SPT];
+#pragma unroll
+        for (int u = 0; u < SPT; ++u) {
+            const int e = min(tid + NTH * u, nn - 1);
+            const int i = (int)(((float)e + 0.5f) * inv), j = e - i * ncolF;      // e / ncolF (exact: e < 2^13, the quotient's fraction is >= 0.5 / 72 off an integer)
+            sv[u] = P[sColF[j] + (size_t)sColF[i] * ld];
+            so[u] = i * Cfg::LDSS + j;
+        }
+#pragma unroll
+        for (int u = 0; u < SPT; ++u) if (tid + NTH * u < nn) X[so[u]] = sv[u];
     }
     // Round 6: the reference clone is the NEWEST one (the clone of this frame).  Any reference is exact algebra (the differences
     // d_c = u_c - u_ref span the same space); the largest-information rule of rounds 3-5 cost three dependent loads per lane, a
