@@ -763,9 +763,13 @@ __global__ __launch_bounds__(256) void k_copy_rows(const double* __restrict__ S,
 {
     const int bl = blockIdx.y;
     if (active && !active[bl]) return;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < nrows * ncols; e += gridDim.x * 256) {
-        const int i = e % nrows, j = e / nrows;
-        D[(size_t)bl * sd + dst_row + i + (size_t)j * ldd] = S[(size_t)bl * ss + src_row + i + (size_t)j * lds];
+    const int tot = nrows * ncols, gn = gridDim.x * 256;
+    for (int e0 = blockIdx.x * 256 + threadIdx.x; e0 < tot; e0 += 4 * gn) {      // four elements in flight per thread
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int e = min(e0 + u * gn, tot - 1), i = e % nrows, j = e / nrows; v[u] = S[(size_t)bl * ss + src_row + i + (size_t)j * lds]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int e = e0 + u * gn, i = e % nrows, j = e / nrows; if (e < tot) D[(size_t)bl * sd + dst_row + i + (size_t)j * ldd] = v[u]; }
     }
 }
 
