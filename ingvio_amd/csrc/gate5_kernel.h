@@ -35,6 +35,7 @@ struct Gate5Shared {
         double Q[9];                 // F_b P(b, b) F_b^T + s^2 N_b^-1
         double w[3 * CMAX];          // w_o = u_o - u_b at 3 (rank(o) - 1)
         double rpsum;                // sum_o |r_perp,o|^2
+        double thr;                  // the feature's chi^2 threshold (-inf: no valid degrees of freedom), fetched by the front
     } f[NF];
     static constexpr int KPS = (KPK + 16 + 1) & ~1;
 #ifndef GATE5_DB
@@ -77,6 +78,33 @@ __device__ __forceinline__ void gate5_body(CovView cv, FrameView fv, MsckfOpts o
     const double px = pf[0], py = pf[1], pz = pf[2];
     const unsigned long long mask = jok ? fv.obs_mask[oidx] : 0ULL;
     const int cidx = sl < C ? fv.clone_idx[(size_t)b * fv.cmax + sl] : 0;
+    // ================= pair lane = window-slot pair (c, c2), 1 <= c2 <= c < C: its block of P, loaded once.  Round 6: requested HERE,
+    // before the front's projections, for every slot pair of the window (whether any of the four features needs the pair is only known
+    // after the front): the block's 36 loads used to start after the front - a full memory round trip in front of the first pair block =====
+    const int npair = C * (C - 1) / 2;
+    const bool pact = lane < npair;
+    int pi = 0, pi2 = 0;
+    {
+        const int q = pact ? lane : 0;
+        pi = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
+        while ((pi + 1) * (pi + 2) / 2 <= q) ++pi;
+        while (pi * (pi + 1) / 2 > q) --pi;
+        pi2 = q - pi * (pi + 1) / 2;
+    }
+    const int pc = pi + 1, pc2 = pi2 + 1;                                   // window slots of the pair
+    const int gc = __shfl(cidx, pc, WAVE), gc2 = __shfl(cidx, pc2, WAVE);   // lanes 0..15 hold clone_idx of slots 0..15 (feature 0's group)
+    double Att[9], Atp[9], Apt[9], App[9];
+    if (pact) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                Att[3 * m + q] = P[(gc + m) + (size_t)(gc2 + q) * ld];
+                Atp[3 * m + q] = P[(gc + m) + (size_t)(gc2 + 3 + q) * ld];
+                Apt[3 * m + q] = P[(gc + 3 + m) + (size_t)(gc2 + q) * ld];
+                App[3 * m + q] = P[(gc + 3 + m) + (size_t)(gc2 + 3 + q) * ld];
+            }
+    }
     bool valid = false;
     double Gm[4][3], rs[4];
     if (sl < C && ((mask >> sl) & 1ULL)) {
@@ -127,7 +155,13 @@ __device__ __forceinline__ void gate5_body(CovView cv, FrameView fv, MsckfOpts o
     double ub[3];
 #pragma unroll
     for (int m = 0; m < 3; ++m) ub[m] = __shfl(u[m], gbase + bslot, WAVE);
-    if (sl == 0) sh.f[g].rpsum = rr;
+    if (sl == 0) {
+        sh.f[g].rpsum = rr;
+        // the gate's threshold, fetched HERE (round 6): read at the very end - dof, then chi2[dof], two dependent global round trips of the
+        // one lane that writes the results - it was 3.2 k of a group's 37 k cycles (shader-clock stamps of a contended workgroup)
+        const int dof = fv.dof[oidx];
+        sh.f[g].thr = (dof >= 1 && dof < op.chi2_len) ? op.chi2[dof] : -__builtin_inf();      // Update.cpp:120
+    }
     if (valid) {
         typename SH::Feat& fg = sh.f[g];
 #pragma unroll
@@ -164,35 +198,11 @@ __device__ __forceinline__ void gate5_body(CovView cv, FrameView fv, MsckfOpts o
     if (lane < NF && j0 + lane < F) { gamma_out[(size_t)b * fv.fmax + j0 + lane] = sh.f[lane].Q[0] + sh.f[lane].w[0] + sh.f[lane].rpsum; accept_out[(size_t)b * fv.fmax + j0 + lane] = 0; }
     return;
 #endif
-    // ================= pair lane = window-slot pair (c, c2), 1 <= c2 <= c < C: its block of P, loaded once =================
-    const int npair = C * (C - 1) / 2;
-    const bool pact = lane < npair;
-    int pi = 0, pi2 = 0;
-    {
-        const int q = pact ? lane : 0;
-        pi = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
-        while ((pi + 1) * (pi + 2) / 2 <= q) ++pi;
-        while (pi * (pi + 1) / 2 > q) --pi;
-        pi2 = q - pi * (pi + 1) / 2;
-    }
-    const int pc = pi + 1, pc2 = pi2 + 1;                                   // window slots of the pair
-    const int gc = __shfl(cidx, pc, WAVE), gc2 = __shfl(cidx, pc2, WAVE);   // lanes 0..15 hold clone_idx of slots 0..15 (feature 0's group)
+    // ================= pair lanes: which of the blocks requested above are needed at all =================
     bool need = false;
 #pragma unroll
     for (int q = 0; q < NF; ++q) need |= ((vmg[q] >> pc) & 1u) && ((vmg[q] >> pc2) & 1u) && pc2 != bs_g[q];
     need = need && pact;
-    double Att[9], Atp[9], Apt[9], App[9];
-    if (need) {
-#pragma unroll
-        for (int m = 0; m < 3; ++m)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                Att[3 * m + q] = P[(gc + m) + (size_t)(gc2 + q) * ld];
-                Atp[3 * m + q] = P[(gc + m) + (size_t)(gc2 + 3 + q) * ld];
-                Apt[3 * m + q] = P[(gc + 3 + m) + (size_t)(gc2 + q) * ld];
-                App[3 * m + q] = P[(gc + 3 + m) + (size_t)(gc2 + 3 + q) * ld];
-            }
-    }
     const int kq = lane >> 4, l15 = lane & 15;
     const double mk0 = kq == 0 ? 1.0 : 0.0, mk1 = kq == 1 ? 1.0 : 0.0, mk2 = kq == 2 ? 1.0 : 0.0, mk3 = kq == 3 ? 1.0 : 0.0;      // row selectors of the 4 x 4 block (see PIN4)
     // per-feature inputs of the pair stage (wave-uniform: scalar loads, all requested up front)
@@ -458,8 +468,7 @@ __device__ __forceinline__ void gate5_body(CovView cv, FrameView fv, MsckfOpts o
                 if (!fok_g[fq]) { gamma_out[oq] = __builtin_nan(""); accept_out[oq] = 0; }
                 else {
                     const double gval = -T[fq][NLT - 1][3] + sh.f[fq].rpsum / op.var;
-                    const int dof = fv.dof[oq];
-                    const bool ok = dof >= 1 && dof < op.chi2_len && gval < op.chi2[dof];      // Update.cpp:120
+                    const bool ok = gval < sh.f[fq].thr;                                        // Update.cpp:120 (threshold staged by the front)
                     gamma_out[oq] = gval;
                     accept_out[oq] = ok ? 1 : 0;
                 }

@@ -38,6 +38,7 @@ struct Gate5mShared {
         double Sd[CMAX][3];          // diagonal block of S by window slot: (0,0), (1,0), (1,1)
         double Q[9];                 // X P(th_a, th_a) X^T
         double hb[4][NPMAX + 2];     // border rows by packed row index 2 rank(c) + t: the three columns of Hf, then r
+        double thr;                  // the feature's chi^2 threshold (-inf: no valid degrees of freedom), fetched by the front
     } f[NF];
     static constexpr int KPS = (KPK + 16 + 1) & ~1;
     union alignas(16) {
@@ -97,6 +98,32 @@ __device__ __forceinline__ void gate5m_body(CovView cv, FrameView fv, MsckfOpts 
     const double px = pf[0], py = pf[1], pz = pf[2];
     const unsigned long long mask = jok ? fv.obs_mask[oidx] : 0ULL;
     const int cidx = sl < C ? fv.clone_idx[(size_t)b * fv.cmax + sl] : 0;
+    // ================= pair lane = window-slot pair (c, c2), 0 <= c2 < c < C: its block of P, loaded once - requested here, before the
+    // front's projections, for every slot pair of the window (see gate5_body) =================
+    const int npair = C * (C - 1) / 2;
+    const bool pact = lane < npair;
+    int pi = 0, pi2 = 0;
+    {
+        const int q = pact ? lane : 0;
+        pi = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
+        while ((pi + 1) * (pi + 2) / 2 <= q) ++pi;
+        while (pi * (pi + 1) / 2 > q) --pi;
+        pi2 = q - pi * (pi + 1) / 2;
+    }
+    const int pc = pi + 1, pc2 = pi2;                                       // window slots of the pair, pc > pc2
+    const int gc = __shfl(cidx, pc, WAVE), gc2 = __shfl(cidx, pc2, WAVE);   // lanes 0..15 hold clone_idx of slots 0..15 (feature 0's group)
+    double Att[9], Atp[9], Apt[9], App[9];
+    if (pact) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                Att[3 * m + q] = P[(gc + m) + (size_t)(gc2 + q) * ld];
+                Atp[3 * m + q] = P[(gc + m) + (size_t)(gc2 + 3 + q) * ld];
+                Apt[3 * m + q] = P[(gc + 3 + m) + (size_t)(gc2 + q) * ld];
+                App[3 * m + q] = P[(gc + 3 + m) + (size_t)(gc2 + 3 + q) * ld];
+            }
+    }
     bool valid = false;
     double Gm[2][3], rs[2];
     if (sl < C && ((mask >> sl) & 1ULL)) {
@@ -110,6 +137,10 @@ __device__ __forceinline__ void gate5m_body(CovView cv, FrameView fv, MsckfOpts 
     const unsigned gm = (unsigned)(vm >> gbase) & 0xFFFFu;                    // the valid slots of this lane's feature
     const int od = __popc(gm & ((1u << sl) - 1u));                            // rank of this slot among the feature's observations
     const int ga = __shfl(cidx, gbase + (a >= 0 && a < 16 ? a : 0), WAVE);    // first state column of the anchor clone
+    if (sl == 0) {                                                            // the gate's threshold, staged now (see gate5_body)
+        const int dof = fv.dof[oidx];
+        sh.f[g].thr = (dof >= 1 && dof < op.chi2_len) ? op.chi2[dof] : -__builtin_inf();      // Update.cpp:120
+    }
     if (valid) {
         typename SH::Feat& fg = sh.f[g];
         const double cn = sl != a ? 1.0 : 0.0, pl = !(op.selected_variant && sl == a) ? 1.0 : 0.0;
@@ -180,35 +211,11 @@ __device__ __forceinline__ void gate5m_body(CovView cv, FrameView fv, MsckfOpts 
         np_g[q] = 2 * nobs;
     }
     wave_sync();
-    // ================= pair lane = window-slot pair (c, c2), 0 <= c2 < c < C: its block of P, loaded once =================
-    const int npair = C * (C - 1) / 2;
-    const bool pact = lane < npair;
-    int pi = 0, pi2 = 0;
-    {
-        const int q = pact ? lane : 0;
-        pi = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
-        while ((pi + 1) * (pi + 2) / 2 <= q) ++pi;
-        while (pi * (pi + 1) / 2 > q) --pi;
-        pi2 = q - pi * (pi + 1) / 2;
-    }
-    const int pc = pi + 1, pc2 = pi2;                                       // window slots of the pair, pc > pc2
-    const int gc = __shfl(cidx, pc, WAVE), gc2 = __shfl(cidx, pc2, WAVE);   // lanes 0..15 hold clone_idx of slots 0..15 (feature 0's group)
+    // ================= pair lanes: which of the blocks requested before the front are needed at all =================
     bool need = false;
 #pragma unroll
     for (int q = 0; q < NF; ++q) need |= ((vmg[q] >> pc) & 1u) && ((vmg[q] >> pc2) & 1u);
     need = need && pact;
-    double Att[9], Atp[9], Apt[9], App[9];
-    if (need) {
-#pragma unroll
-        for (int m = 0; m < 3; ++m)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                Att[3 * m + q] = P[(gc + m) + (size_t)(gc2 + q) * ld];
-                Atp[3 * m + q] = P[(gc + m) + (size_t)(gc2 + 3 + q) * ld];
-                Apt[3 * m + q] = P[(gc + 3 + m) + (size_t)(gc2 + q) * ld];
-                App[3 * m + q] = P[(gc + 3 + m) + (size_t)(gc2 + 3 + q) * ld];
-            }
-    }
     const int kq = lane >> 4, l15 = lane & 15;
     double qx[NF], qy[NF], qz[NF];
     int aq[NF];
@@ -423,8 +430,7 @@ __device__ __forceinline__ void gate5m_body(CovView cv, FrameView fv, MsckfOpts 
                 if (!fok_g[fq]) { gamma_out[oq] = __builtin_nan(""); accept_out[oq] = 0; }
                 else {
                     const double gval = -T[fq][NLT - 1][3];
-                    const int dof = fv.dof[oq];
-                    const bool ok = dof >= 1 && dof < op.chi2_len && gval < op.chi2[dof];      // Update.cpp:120
+                    const bool ok = gval < sh.f[fq].thr;                                        // Update.cpp:120 (threshold staged by the front)
                     gamma_out[oq] = gval;
                     accept_out[oq] = ok ? 1 : 0;
                 }
