@@ -201,14 +201,26 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
     double in_uv[4], in_pf[3];
     unsigned long long in_mask = 0ULL;
     int in_anchor = 0;
+    // Round 6, measured and left OFF (-DGRAM_SPLIT=1): waves 2-3 take the SPARSE scratch of the next batch off waves 0-1 - they project
+    // the same (feature, slot) lanes again (~120 FP64 operations) and write sp[..] themselves, after their own P3b.  Shader-clock
+    // stamps of a batch: P3a 2.5 k cycles (all waves), then P2 9.2 k on waves 0-1 beside P3b 3.5 k on waves 2-3 - half of the workgroup
+    // idle for 5.7 k of a batch's 11.7 k cycles.  But the kernel sits AT its register budget (256 VGPRs at two workgroups per CU): with
+    // the projection's temporaries live beside the 33 sparse accumulators the allocator spills the LDS offsets of the MFMA loop (88 B
+    // of scratch, reloaded in front of every product): 106 -> 158 us per 512 filters.  Handing N_o, h_o over through LDS instead needs
+    // a second pair of buffers the 80 KB of a workgroup do not have.
+#ifndef GRAM_SPLIT
+#define GRAM_SPLIT 0
+#endif
+    constexpr bool SPLIT = GRAM_SPLIT && CMAX * CMAX <= 128;
+    const int ft = SPLIT ? (tid & 127) : tid;                 // (feature, slot) lane of the operand-row phase
     auto fetch = [&](int qb) {
-        const int f = tid >> 4, c = tid & 15;
+        const int f = ft >> 4, c = ft & 15;
         in_mask = 0ULL; in_anchor = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) in_uv[i] = 0.0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) in_pf[i] = 0.0;
-        if (tid < GRAM_NB * 16 && qb + f < q1) {
+        if (ft < GRAM_NB * 16 && qb + f < q1) {
             const size_t oidx = (size_t)b * fv.fmax + sList[qb + f];
             in_mask = fv.obs_mask[oidx]; in_anchor = fv.anchor[oidx];
 #pragma unroll
@@ -235,16 +247,17 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
     // P2 (operand rows + sparse scratch of one batch, lanes (feature, slot) of waves 0-1), P3a (rank-3 part, all waves), P3b (sparse
     // sums, pair lanes).  Window classes with at most 128 (slot, anchor) pairs put the pair lanes on waves 2-3 and double-buffer the
     // sparse scratch, so that P3b of batch i runs BESIDE P2 of batch i+1 instead of after it (P2 6.3 k, P3b 3.5 k of a batch's 14.8 k cycles).
-    auto do_p2 = [&](int qb, int buf, int nthr) {              // nthr: threads that make the call (256, or the 128 of waves 0-1)
+    // rows / sparse: which half of P2 the caller wants (both: the first batch and the window classes without the split)
+    auto do_p2 = [&](int qb, int buf, int nthr, bool rows, bool sparse) {      // nthr: threads that make the call (256, or the 128 of waves 0-1)
         const int nbf = min(GRAM_NB, q1 - qb);
         dbg_stamp(34);
-        if (nbf < GRAM_NB) {                                   // short last batch: clear the unused stacked rows
+        if (rows && nbf < GRAM_NB) {                           // short last batch: clear the unused stacked rows
             for (int e = tid; e < (KR - 3 * nbf) * LDW; e += nthr) { (&sb.Bm[3 * nbf][0])[e] = 0.0; (&sb.Ym[3 * nbf][0])[e] = 0.0; }
         }
         dbg_stamp(35);
         // ---- P2: operand rows B, Y = Ns^-1 B and the sparse scratch, lane = (feature, window slot) -----
-        if (tid < nbf * 16) {
-            const int f = tid >> 4, c = tid & 15;
+        if (ft < nbf * 16) {
+            const int f = ft >> 4, c = ft & 15;
             const int a = in_anchor;
             const double px = in_pf[0], py = in_pf[1], pz = in_pf[2];
             bool obs = c < C && ((in_mask >> c) & 1ULL);
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
             const double cn = (obs && c != a) ? 1.0 : 0.0, pl = (obs && !(op.selected_variant && c == a)) ? 1.0 : 0.0;
             // Ns = sum_o N_o (= Hf^T Hf), hs = sum_o h_o, Nsa = sum over the observations whose clone is not the anchor
             double Ns[9], hs[3], Nsa[9];
-            {
+            if (rows) {
                 const double n0 = sum16(N[0]), n1 = sum16(N[1]), n2 = sum16(N[2]), n4 = sum16(N[4]), n5 = sum16(N[5]), n8 = sum16(N[8]);
                 Ns[0] = n0; Ns[1] = n1; Ns[2] = n2; Ns[3] = n1; Ns[4] = n4; Ns[5] = n5; Ns[6] = n2; Ns[7] = n5; Ns[8] = n8;
 #ifdef GRAM_NSA_SUMS
@@ -294,10 +307,12 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
                 for (int i = 0; i < 3; ++i) hs[i] = sum16(h[i]);
             }
             if (c < C) {
+                double NX[9];
+                mulX(N, px, py, pz, NX);                            // N_o X
+              if (rows) {
                 double Nsi[9];
                 inv3sym(Ns, Nsi);
-                double Bt[9], Bp[9], NX[9];
-                mulX(N, px, py, pz, NX);                            // N_o X
+                double Bt[9], Bp[9];
 #pragma unroll
                 for (int i = 0; i < 9; ++i) { Bt[i] = cn * NX[i]; Bp[i] = -pl * N[i]; }
                 if (c == a) {                                       // theta_anchor block: -Nsa X   (the anchor's own cn is 0)
@@ -322,6 +337,8 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
 #pragma unroll
                     for (int k = 0; k < 3; ++k) sb.Bm[3 * f + k][NC] = hs[k];      // extra column: hs
                 }
+              }
+              if (sparse) {
                 // sparse scratch
                 double* sp = sb.sp[buf][f][c < CMAX ? c : 0];
                 double S1[9];
@@ -336,6 +353,7 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
 #pragma unroll
                 for (int i = 0; i < 3; ++i) sp[30 + i] = pl * h[i];                      // pl h_o
                 sp[33] = obs ? (double)a : -1.0;                       // key: the anchor slot this contribution belongs to
+              }
             }
         }
     };
@@ -376,7 +394,7 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
         }
     };
     if (OVL) {
-        if (q0 < q1) { do_p2(q0, 0, GRAM_NT); fetch(q0 + GRAM_NB); }
+        if (q0 < q1) { if (!SPLIT || wave < 2) do_p2(q0, 0, SPLIT ? 128 : GRAM_NT, true, true); fetch(q0 + GRAM_NB); }
         lds_barrier();
         int it = 0;
         for (int qb = q0; qb < q1; qb += GRAM_NB, ++it) {
@@ -385,15 +403,18 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
             if (it == 3) dbg_stamp(37);
             lds_barrier();                                      // every wave is done with this batch's operand rows
             if (it == 3) dbg_stamp(38);
-            if (wave < 2) { if (qb + GRAM_NB < q1) { do_p2(qb + GRAM_NB, (it + 1) & 1, 128); fetch(qb + 2 * GRAM_NB); } }
-            else do_p3b(qb, it & 1);
+            if (wave < 2) { if (qb + GRAM_NB < q1) { do_p2(qb + GRAM_NB, (it + 1) & 1, 128, true, !SPLIT); fetch(qb + 2 * GRAM_NB); } }
+            else {
+                do_p3b(qb, it & 1);
+                if (SPLIT && qb + GRAM_NB < q1) { do_p2(qb + GRAM_NB, (it + 1) & 1, 128, false, true); fetch(qb + 2 * GRAM_NB); }
+            }
             if (it == 3) dbg_stamp(41);
             lds_barrier();
             if (it == 3) dbg_stamp(42);
         }
     } else {
         for (int qb = q0; qb < q1; qb += GRAM_NB) {
-            do_p2(qb, 0, GRAM_NT);
+            do_p2(qb, 0, GRAM_NT, true, true);
             lds_barrier();                                      // LDS hand-over only: the next batch's input loads stay in flight
             fetch(qb + GRAM_NB);
             do_p3a(qb);
