@@ -497,6 +497,10 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
     dbg_stamp(40);
 }
 
+#ifdef INGVIO_ALT_KERNELS      // k_feat_gram3 (round 6, measured and rejected: 115 against 107 us per 512 filters): one operand panel (Z^T Z),
+#include "gram3_kernel.h"      // double-buffered, one barrier per batch - variant build only, INGVIO_GRAM=3
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // K8/K9/K11 in information form, one workgroup per filter:
 //   [M | t] = (A Pcc + s^2 I)^-1 [A | b]  by Gauss-Jordan with partial pivoting in LDS,
@@ -1303,6 +1307,23 @@ static void launch_ft(const FactoredLaunch& L, hipStream_t st)
         hipLaunchKernelGGL((k_feat_gate3<CMAX, STEREO>), dim3(nb8 * ((L.fmax_used + GATE_FPW - 1) / GATE_FPW)), dim3(GATE_FPW * WAVE), 0, st,
                            L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
     } else {
+#ifdef INGVIO_ALT_KERNELS
+        if constexpr (CMAX * CMAX <= 128) {                          // window classes 6 and 11, INGVIO_GRAM=3: the third generation (gram3_kernel.h)
+            static const bool gram3 = [] { const char* e = getenv("INGVIO_GRAM"); return e && e[0] == '3'; }();
+            if (gram3) {
+                constexpr size_t uni3 = sizeof(Gram3Batch<CMAX>) > sizeof(Gram2Out<CMAX>) ? sizeof(Gram3Batch<CMAX>) : sizeof(Gram2Out<CMAX>);
+                const size_t sm3 = ((uni3 + 15) / 16) * 16 + 2 * sizeof(int) * (size_t)L.fv.fmax;
+                static size_t attr_sm3 = 0;
+                if (sm3 > attr_sm3) {
+                    hipFuncSetAttribute((const void*)k_feat_gram3<CMAX, STEREO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm3);
+                    attr_sm3 = sm3;
+                }
+                hipLaunchKernelGGL((k_feat_gram3<CMAX, STEREO>), dim3(L.G, L.nb), dim3(GRAM_NT), sm3, st,
+                                   L.fv, L.op, L.b0, L.accept, L.used, L.Apart, L.chunk_used, L.G, L.rstride);
+                return;
+            }
+        }
+#endif
         constexpr size_t uni = sizeof(Gram2Batch<CMAX>) > sizeof(Gram2Out<CMAX>) ? sizeof(Gram2Batch<CMAX>) : sizeof(Gram2Out<CMAX>);
         const size_t sm = ((uni + 15) / 16) * 16 + 2 * sizeof(int) * (size_t)L.fv.fmax;
         static size_t attr_sm = 0;

@@ -11,6 +11,7 @@ process) that runs the parity tests covering it.  One toggle per case:
   INGVIO_APPLY_TW=2        k_info_apply with two tile columns per step
   INGVIO_LM_FRONT=split    landmark update with k_lm_build + k_lm_products (compacting) instead of the fused front
   INGVIO_LM_SOLVE=sweep    landmark / dense-H update on the Cholesky sweep out of L2 instead of the register-resident solve
+  INGVIO_GRAM=3            k_feat_gram3 (round 6): one operand panel Z = D^-1/2 L^-1 B (B^T Ns^-1 B = Z^T Z), double-buffered, one barrier per batch
   INGVIO_FEW=off           few filters (up to 64 per launch) on the kernels of a full batch: chunk partials added inside the solve, k_info_apply
                            (the product sums them with k_chunk_sum first and applies with one wave per tile, k_apply_*_flat)
 """
@@ -34,6 +35,8 @@ CASES = [
     ("INGVIO_APPLY_TW", "2", ["tests/test_gpu_parity.py", "-k", "test_full_n249_batch_vs_oracle or test_window_size_classes or test_consecutive_frames"]),
     ("INGVIO_FEW", "off", ["tests/test_gpu_parity.py", "tests/test_gpu_pinning.py", "-k",
                            "test_msckf_small or test_window_size_classes or test_ragged or test_consecutive_frames or test_sigma_and_prior_scale_sweep"]),
+    ("INGVIO_GRAM", "3", ["tests/test_gpu_parity.py", "tests/test_gpu_pinning.py", "-k",
+                          "test_full_n249_batch_vs_oracle or test_msckf_small or test_window_size_classes or test_ragged or test_mono_gate or test_sigma_and_prior_scale_sweep"]),
     ("INGVIO_LM_FRONT", "split", ["tests/test_landmark_batch.py"]),
     ("INGVIO_LM_SOLVE", "sweep", ["tests/test_landmark_batch.py"]),
 ]
