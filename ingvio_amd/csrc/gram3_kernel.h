@@ -20,16 +20,6 @@
 // (slot, anchor) accumulator needs the accumulators in LDS (33 KB) or the features ordered by anchor.
 #pragma once
 
-// 1 / sqrt(x) to full precision: v_rsq_f64 + two Newton steps (as kernels_chol.hip's)
-__device__ __forceinline__ double g3_rsqrt(double x)
-{
-    double y = __builtin_amdgcn_rsq(x);
-    double e = fma(-x * y, y, 1.0);
-    y = fma(y * e, fma(e, 0.375, 0.5), y);
-    e = fma(-x * y, y, 1.0);
-    return fma(y * e, 0.5, y);
-}
-
 template <int CMAX>
 struct Gram3Batch {
     using Cfg = Gram2Cfg<CMAX>;
@@ -216,11 +206,11 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram3(
                 }
                 // Z = D^-1/2 L^-1 B with Ns = L D L^T (3 x 3, SPD for a used feature): B^T Ns^-1 B = Z^T Z - ONE operand panel
                 // (k_feat_gram2 stages B and Y = Ns^-1 B), which is what lets the panel be double-buffered in the same LDS
-                const double s0 = Ns[0] > 0.0 ? g3_rsqrt(Ns[0]) : 0.0, r0 = s0 * s0;          // s_k = d_k^-1/2 (0: a pivot that is not positive -
+                const double s0 = Ns[0] > 0.0 ? gram_rsqrt(Ns[0]) : 0.0, r0 = s0 * s0;          // s_k = d_k^-1/2 (0: a pivot that is not positive -
                 const double l10 = Ns[1] * r0, l20 = Ns[2] * r0;                              // the feature then contributes nothing through that row)
-                const double d1 = Ns[4] - l10 * Ns[1], s1 = d1 > 0.0 ? g3_rsqrt(d1) : 0.0, r1 = s1 * s1;
+                const double d1 = Ns[4] - l10 * Ns[1], s1 = d1 > 0.0 ? gram_rsqrt(d1) : 0.0, r1 = s1 * s1;
                 const double t21 = Ns[5] - l20 * Ns[1], l21 = t21 * r1;
-                const double d2 = (Ns[8] - l20 * Ns[2]) - l21 * t21, s2 = d2 > 0.0 ? g3_rsqrt(d2) : 0.0;
+                const double d2 = (Ns[8] - l20 * Ns[2]) - l21 * t21, s2 = d2 > 0.0 ? gram_rsqrt(d2) : 0.0;
                 double (*Z)[LDW] = sb.Zm[buf];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {

@@ -90,6 +90,18 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(GATE5_WPE,
 // ---------------------------------------------------------------------------------------------
 #define GRAM_NB 8
 #define GRAM_NT 256
+#ifndef GRAM2_ZFORM
+#define GRAM2_ZFORM 1      // the rank-3 term as Z^T Z (one operand panel); 0: Y^T B with Y = Ns^-1 B (rounds 2-5)
+#endif
+// 1 / sqrt(x) to full precision: v_rsq_f64 + two Newton steps (as kernels_chol.hip's)
+__device__ __forceinline__ double gram_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(y * e, fma(e, 0.375, 0.5), y);
+    e = fma(-x * y, y, 1.0);
+    return fma(y * e, 0.5, y);
+}
 template <int CMAX>
 struct Gram2Cfg {
     static constexpr int NC = 6 * CMAX;
@@ -310,8 +322,6 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
                 double NX[9];
                 mulX(N, px, py, pz, NX);                            // N_o X
               if (rows) {
-                double Nsi[9];
-                inv3sym(Ns, Nsi);
                 double Bt[9], Bp[9];
 #pragma unroll
                 for (int i = 0; i < 9; ++i) { Bt[i] = cn * NX[i]; Bp[i] = -pl * N[i]; }
@@ -321,6 +331,34 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
 #pragma unroll
                     for (int i = 0; i < 9; ++i) Bt[i] = -T[i];
                 }
+#if GRAM2_ZFORM
+                // Round 6: the rank-3 term as a SYMMETRIC product.  With Ns = L D L^T (3 x 3, SPD for a used feature)
+                //     B^T Ns^-1 B = Z^T Z,   Z = D^-1/2 L^-1 B      (the hs column rides as D^-1/2 L^-1 hs)
+                // - ONE operand panel (Bm holds Z, Ym is not used): the forward substitution replaces inv3sym and two 3 x 3 products and
+                // halves the panel stores (P2: 9.2 k -> 6.3 k cycles per batch, shader-clock stamps of k_feat_gram3, gram3_kernel.h)
+                const double s0 = Ns[0] > 0.0 ? gram_rsqrt(Ns[0]) : 0.0, r0 = s0 * s0;          // s_k = d_k^-1/2 (0: a pivot that is not positive)
+                const double l10 = Ns[1] * r0, l20 = Ns[2] * r0;
+                const double d1 = Ns[4] - l10 * Ns[1], s1 = d1 > 0.0 ? gram_rsqrt(d1) : 0.0, r1 = s1 * s1;
+                const double t21 = Ns[5] - l20 * Ns[1], l21 = t21 * r1;
+                const double d2 = (Ns[8] - l20 * Ns[2]) - l21 * t21, s2 = d2 > 0.0 ? gram_rsqrt(d2) : 0.0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    {
+                        const double y0 = Bt[q], y1 = Bt[3 + q] - l10 * y0, y2 = (Bt[6 + q] - l20 * y0) - l21 * y1;
+                        sb.Bm[3 * f + 0][6 * c + q] = s0 * y0; sb.Bm[3 * f + 1][6 * c + q] = s1 * y1; sb.Bm[3 * f + 2][6 * c + q] = s2 * y2;
+                    }
+                    {
+                        const double y0 = Bp[q], y1 = Bp[3 + q] - l10 * y0, y2 = (Bp[6 + q] - l20 * y0) - l21 * y1;
+                        sb.Bm[3 * f + 0][6 * c + 3 + q] = s0 * y0; sb.Bm[3 * f + 1][6 * c + 3 + q] = s1 * y1; sb.Bm[3 * f + 2][6 * c + 3 + q] = s2 * y2;
+                    }
+                }
+                if (c == 0) {
+                    const double y0 = hs[0], y1 = hs[1] - l10 * y0, y2 = (hs[2] - l20 * y0) - l21 * y1;
+                    sb.Bm[3 * f + 0][NC] = s0 * y0; sb.Bm[3 * f + 1][NC] = s1 * y1; sb.Bm[3 * f + 2][NC] = s2 * y2;
+                }
+#else
+                double Nsi[9];
+                inv3sym(Ns, Nsi);
                 double Yt[9], Yp[9];
                 mul33(Nsi, Bt, Yt);
                 mul33(Nsi, Bp, Yp);
@@ -337,6 +375,7 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
 #pragma unroll
                     for (int k = 0; k < 3; ++k) sb.Bm[3 * f + k][NC] = hs[k];      // extra column: hs
                 }
+#endif
               }
               if (sparse) {
                 // sparse scratch
@@ -368,7 +407,7 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
                 for (int u = 0; u < TPW; ++u) {
                     if (wave + 4 * u < NUP) {
                         const int ti = tiA[u], tj = tjA[u];
-                        const double af = sb.Ym[4 * st + kq][16 * ti + l15];      // A[i][k] = Y[k][i]
+                        const double af = (GRAM2_ZFORM ? sb.Bm : sb.Ym)[4 * st + kq][16 * ti + l15];      // A[i][k] = Y[k][i]  (Z-form: Z[k][i])
                         const double bf = sb.Bm[4 * st + kq][16 * tj + l15];      // B[k][j]
                         acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[u], 0, 0, 0);
                     }
