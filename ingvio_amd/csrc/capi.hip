@@ -2867,12 +2867,9 @@ static int frame_run_impl(ingvio_ctx* c, int restore_prior, int phase)
     }
     bool lm_fused = false;
     if (with_lm) { rc = landmark_update_launch(c, 0, B, c->d_idx, 6, &lm_fused); if (rc) return rc; }
-    {
+    if (!(fuse && c->apply_flipped)) {             // (the write-back of the fused step has flipped the halves itself: no launch, no profile slot)
         ProfScope p(c, PF_MARG);
-        if (fuse) {
-            if (!c->apply_flipped) launch_post_marg(view(c), 0, B, c->d_idx, 6, c->st);
-        }
-        else if (lm_fused) launch_post_marg(view(c), 0, B, c->d_idx, 6, c->st);
+        if (fuse || lm_fused) launch_post_marg(view(c), 0, B, c->d_idx, 6, c->st);
         else launch_marginalize(view(c), 0, B, c->d.n_max, c->d_idx, 6, c->st);
     }
     // a landmark stage belongs to ONE frame: unless the caller replays the same prior (restore_prior, the bench and the parity tests)
