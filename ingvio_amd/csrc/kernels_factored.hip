@@ -203,6 +203,21 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
     for (int i = 0; i < 9; ++i) { sS1[i] = 0.0; sNX[i] = 0.0; sS3[i] = 0.0; }
 #pragma unroll
     for (int i = 0; i < 3; ++i) { s4[i] = 0.0; s5[i] = 0.0; }
+    // Round 6 (P3U, window classes whose pair lanes sit on waves 2-3): the sparse sums by lane (slot c, CHUNK j of the 33 values) with
+    // one accumulator triple per ANCHOR, instead of lane (slot c, anchor a) with all 33 values.  A feature has ONE anchor - wave-uniform
+    // while the wave walks the batch feature by feature - so a lane adds its three values into the triple of that anchor behind a
+    // scalar branch: 3 additions per feature.  Lane (c, a) multiplied ten of its eleven lanes' 33 values by zero (the key selected the
+    // one anchor): 33 FMAs + 34 LDS values per feature and lane - by the stamps of k_feat_gram3 the sparse sums were the longest
+    // issue stream of a batch (3.9 k of ~10 k cycles per SIMD).  Same additions in the same order: bit-identical sums.
+#ifndef GRAM2_P3B_UNIFORM
+#define GRAM2_P3B_UNIFORM 1
+#endif
+    constexpr bool P3U = GRAM2_P3B_UNIFORM && CMAX * CMAX <= 128 && 11 * CMAX <= 128;      // 11 chunks of 3 = the 33 values of a slot, on waves 2-3
+    double sacc[3 * CMAX];
+#pragma unroll
+    for (int i = 0; i < 3 * CMAX; ++i) sacc[i] = 0.0;
+    const int uc = ptid >= 0 ? ptid / 11 : 0, uj = ptid >= 0 ? ptid - 11 * uc : 0;      // P3U lane: (slot, chunk of three values), 11 chunks per slot
+    const bool ulane = P3U && ptid >= 0 && ptid < 11 * CMAX;
     const int kq = lane >> 4, l15 = lane & 15;
 
     // The per-observation quantities (N_o = G_o^T G_o, h_o = G_o^T r_o) are recomputed here from the frame inputs (one projection
@@ -391,7 +406,7 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
                 for (int i = 0; i < 9; ++i) sp[21 + i] = pl * N[i];                      // pl N_o
 #pragma unroll
                 for (int i = 0; i < 3; ++i) sp[30 + i] = pl * h[i];                      // pl h_o
-                sp[33] = obs ? (double)a : -1.0;                       // key: the anchor slot this contribution belongs to
+                sp[33] = (obs || c == 0) ? (double)a : -1.0;          // key: the anchor slot this contribution belongs to (slot 0 always carries it: P3U reads the feature's anchor there; its values are zero when it does not observe)
               }
             }
         }
@@ -418,7 +433,24 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
     auto do_p3b = [&](int qb, int buf) {
         const int nbf = min(GRAM_NB, q1 - qb);
         // ---- P3b: sparse part, lane (c, a): branch-free, one level of LDS reads (the key says whose anchor it is) ----
-        if (pairlane) {
+        if (P3U) {
+            if (ulane) {                                        // lane (slot uc, chunk uj): values 3 uj .. 3 uj + 2 of the slot's 33
+#pragma unroll
+                for (int f = 0; f < GRAM_NB; ++f) {
+                    if (f < nbf) {
+                        const double* sp = sb.sp[buf][f][uc];
+                        const int af = __builtin_amdgcn_readfirstlane((int)sb.sp[buf][f][0][33]);      // the feature's anchor slot (slot 0's key always carries it)
+                        const double x0 = sp[3 * uj], x1 = sp[3 * uj + 1], x2 = sp[3 * uj + 2];       // zero for a slot that does not observe the feature
+                        switch (af) {                                   // wave-uniform: a scalar branch, then three additions
+#define P3U_CASE(A) case A: if (A < CMAX) { sacc[3 * (A < CMAX ? A : 0)] += x0; sacc[3 * (A < CMAX ? A : 0) + 1] += x1; sacc[3 * (A < CMAX ? A : 0) + 2] += x2; } break;
+                            P3U_CASE(0) P3U_CASE(1) P3U_CASE(2) P3U_CASE(3) P3U_CASE(4) P3U_CASE(5) P3U_CASE(6) P3U_CASE(7) P3U_CASE(8) P3U_CASE(9) P3U_CASE(10)
+#undef P3U_CASE
+                            default: break;
+                        }
+                    }
+                }
+            }
+        } else if (pairlane) {
 #pragma unroll
             for (int f = 0; f < GRAM_NB; ++f) {
                 if (f < nbf) {
@@ -476,7 +508,17 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
             }
         }
     }
-    if (pairlane) {
+    if (P3U) {
+        if (ulane) {                                            // scratch order (S1, NX, X^T h, pl N, pl h) -> the epilogue's (S1, NX, pl N, X^T h, pl h)
+#pragma unroll
+            for (int a2 = 0; a2 < CMAX; ++a2)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int v = 3 * uj + i;
+                    so.S[uc][a2][v < 18 ? v : (v < 21 ? v + 9 : (v < 30 ? v - 3 : v))] = sacc[3 * a2 + i];
+                }
+        }
+    } else if (pairlane) {
         double* S = so.S[pc][pa];
 #pragma unroll
         for (int i = 0; i < 9; ++i) { S[i] = sS1[i]; S[9 + i] = sNX[i]; S[18 + i] = sS3[i]; }
