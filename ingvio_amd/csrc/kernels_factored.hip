@@ -441,11 +441,12 @@ __global__ __launch_bounds__(GRAM_NT, 2) void k_feat_gram2(
                         const double* sp = sb.sp[buf][f][uc];
                         const int af = __builtin_amdgcn_readfirstlane((int)sb.sp[buf][f][0][33]);      // the feature's anchor slot (slot 0's key always carries it)
                         const double x0 = sp[3 * uj], x1 = sp[3 * uj + 1], x2 = sp[3 * uj + 2];       // zero for a slot that does not observe the feature
-                        switch (af) {                                   // wave-uniform: a scalar branch, then three additions
-#define P3U_CASE(A) case A: if (A < CMAX) { sacc[3 * (A < CMAX ? A : 0)] += x0; sacc[3 * (A < CMAX ? A : 0) + 1] += x1; sacc[3 * (A < CMAX ? A : 0) + 2] += x2; } break;
-                            P3U_CASE(0) P3U_CASE(1) P3U_CASE(2) P3U_CASE(3) P3U_CASE(4) P3U_CASE(5) P3U_CASE(6) P3U_CASE(7) P3U_CASE(8) P3U_CASE(9) P3U_CASE(10)
-#undef P3U_CASE
-                            default: break;
+#pragma unroll
+                        for (int a2 = 0; a2 < CMAX; ++a2) {             // wave-uniform selector per anchor (a scalar), three multiply-adds: no branch
+                            const double m = af == a2 ? 1.0 : 0.0;     // (as a switch on the scalar the compiler copied the other thirty
+                            sacc[3 * a2] = fma(m, x0, sacc[3 * a2]);    //  accumulators around every case block: 66 v_mov_b64 per feature)
+                            sacc[3 * a2 + 1] = fma(m, x1, sacc[3 * a2 + 1]);
+                            sacc[3 * a2 + 2] = fma(m, x2, sacc[3 * a2 + 2]);
                         }
                     }
                 }
