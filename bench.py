@@ -229,8 +229,8 @@ STAGE_KERNELS = {
 STAGE_KERNELS_BIG = {                                                      # windows of 17..36 clones (kernels_bigwin.hip)
     "gate": (("k_feat_gate4_big",), ("k_feat_gate3_big",)), "gram": (("k_feat_gram_big",),),
     # round 5: the set-up is k_big_prep_P (prior only, on the side stream together with the first sweep) + k_big_prep_A
-    "solve": (("k_big_prep_P", "k_big_prep_A", "k_chol_first", "k_chol_step", "k_chol_carried", "k_gemm64", "k_copy_rows", "k_big_gauge_fix"),
-                      ("k_big_prep_P", "k_big_prep_A", "k_chol_first", "k_chol_step", "k_chol_carried", "k_gemm64", "k_copy_rows"), ("k_info_update_big",)),
+    "solve": (("k_big_prep_P", "k_big_prep_A", "k_chol_first", "k_chol_step", "k_chol_carried", "k_gemm64", "k_big_gauge_fix"),
+                      ("k_big_prep_P", "k_big_prep_A", "k_chol_first", "k_chol_step", "k_chol_carried", "k_gemm64"), ("k_info_update_big",)),
     "apply": (("k_apply_T64b", "k_apply_sym64b"), ("k_apply_T", "k_apply_sym"), ("k_info_apply_big",)),
 }
 

@@ -162,7 +162,7 @@ struct ingvio_ctx {
     bool alt_ready = false;
     // large windows: the measurement-independent front of the Kalman solve runs here, under the gate and the Gram kernel (run_msckf_factored)
     hipStream_t st2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_ref = nullptr;
     hipEvent_t ev_fetch = nullptr;      // ingvio_frame_fetch_begin / _end
     int fetch_b0 = 0, fetch_nb = 0;
     hipStream_t st_copy = nullptr;
@@ -781,14 +781,25 @@ int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int s
         if (c->tok_rec) HIPCHK(c, hipEventRecord(c->tok_rec, c->run_st));
     }
     if (forked) {
+        // the side stream in two pieces: [A; b^T] of the main stream (stage 8) needs the gauge reference the set-up kernel picks, not the
+        // sweep behind it - it runs while the sweep's last panels are still on their way (round 6)
         HIPCHK(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
-        L.stage = 5; launch_factored(L, c->st2);
+        L.stage = 6; launch_factored(L, c->st2);
+        HIPCHK(c, hipEventRecord(c->ev_ref, c->st2));
+        L.stage = 7; launch_factored(L, c->st2);
         HIPCHK(c, hipEventRecord(c->ev_join, c->st2));
     }
     if (phase == 1) return last_launch(c);
-    if (forked) HIPCHK(c, hipStreamWaitEvent(c->run_st, c->ev_join, 0));
-    else if (big) { ProfScope p(c, PF_INFO); L.stage = 5; launch_factored(L, c->run_st); }      // split step / no side stream: in line
-    { ProfScope p(c, PF_INFO); L.stage = 2; launch_factored(L, c->run_st); }
+    if (forked) {
+        ProfScope p(c, PF_INFO);
+        HIPCHK(c, hipStreamWaitEvent(c->run_st, c->ev_ref, 0));
+        L.stage = 8; launch_factored(L, c->run_st);
+        HIPCHK(c, hipStreamWaitEvent(c->run_st, c->ev_join, 0));
+        L.stage = 9; launch_factored(L, c->run_st);
+    } else {
+        if (big) { ProfScope p(c, PF_INFO); L.stage = 5; launch_factored(L, c->run_st); }      // split step / no side stream: in line
+        { ProfScope p(c, PF_INFO); L.stage = 2; launch_factored(L, c->run_st); }
+    }
     if (gnss_fuse) { if (int rc = gnss_in_frame_launch(c, b0, nb, L)) return rc; }
     if (phase == 2 && c->tok_wait) HIPCHK(c, hipStreamWaitEvent(c->run_st, c->tok_wait, 0));
     { ProfScope p(c, PF_APPLY); L.stage = 3; launch_factored(L, c->run_st); }
@@ -862,6 +873,7 @@ int ingvio_ctx_create(const ingvio_ctx_desc* desc, ingvio_ctx** out)
         hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (hipStreamCreateWithPriority(&c->st2, hipStreamNonBlocking, hi) != hipSuccess) c->st2 = nullptr;
         if (c->st2 && (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                       hipEventCreateWithFlags(&c->ev_ref, hipEventDisableTiming) != hipSuccess ||
                        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)) { hipStreamDestroy(c->st2); c->st2 = nullptr; }
     }
     const int B = desc->batch;
@@ -996,6 +1008,7 @@ int ingvio_ctx_destroy(ingvio_ctx* c)
     if (c->st2) hipStreamDestroy(c->st2);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->ev_ref) hipEventDestroy(c->ev_ref);
     if (c->own_stream) hipStreamDestroy(c->st);
     delete c;
     return INGVIO_OK;

@@ -757,81 +757,67 @@ __global__ __launch_bounds__(256) void k_big_prep_A(
     if (wg == 0 && tid == 0) { m_out[bl] = ncol; nc_out[bl] = ncol; }
 }
 
-// rows [src_row, +nrows) of S (ld lds) -> rows [dst_row, +nrows) of D (ld ldd), ncols columns, per batch element
-__global__ __launch_bounds__(256) void k_copy_rows(const double* __restrict__ S, size_t ss, int lds, int src_row, double* __restrict__ D,
-                                                   size_t sd, int ldd, int dst_row, int nrows, int ncols, const int* __restrict__ active)
-{
-    const int bl = blockIdx.y;
-    if (active && !active[bl]) return;
-    const int tot = nrows * ncols, gn = gridDim.x * 256;
-    for (int e0 = blockIdx.x * 256 + threadIdx.x; e0 < tot; e0 += 4 * gn) {      // four elements in flight per thread
-        double v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const int e = min(e0 + u * gn, tot - 1), i = e % nrows, j = e / nrows; v[u] = S[(size_t)bl * ss + src_row + i + (size_t)j * lds]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const int e = e0 + u * gn, i = e % nrows, j = e / nrows; if (e < tot) D[(size_t)bl * sd + dst_row + i + (size_t)j * ldd] = v[u]; }
-    }
-}
-
 // The reference clone's block row / column of [M | t]: minus the sums over the other clones' blocks (every block row and column
-// of the n x n solution sums to zero: M = T^-T diag(0, Mr) T^-1, see k_info_solve).  Workgroups 0 .. gridDim.x - 2 fill the block
-// row and the block column, the last one the 6 x 6 corner = + the sum of ALL other blocks (the double sum, straight from M, so that
-// it does not have to wait for the block row: one launch instead of two).
+// of the n x n solution sums to zero: M = T^-T diag(0, Mr) T^-1, see k_info_solve), the 6 x 6 corner = + the sum of ALL other blocks.
+// ONE launch, every load coalesced along a row of M (round 6; before: a thread per output walked its 30 blocks at a stride of six
+// doubles or six rows - 64 different lines per load instruction, 45 k line requests from the corner's one workgroup alone: 27-31 us
+// per 32 filters for 2.6 k sums):
+//   workgroups 0..5 (k): thread J sums column J over the rows 6 c + k, c != ref  ->  block row (ref, k) = - that sum; the same column
+//     sums, added over the columns 6 c + l through LDS, are the corner's row k (the double sum, without waiting for anybody);
+//     thread MP does the same for t;
+//   workgroups 6.. : GF_ROWS rows of M each, staged whole in LDS (coalesced), thread (row, k) sums its 30 entries  ->  block column.
+// Rows / columns of the reference block itself are read by nobody who uses them (masked), so the writers race with no reader.
+#define GF_ROWS 18
 __global__ __launch_bounds__(256) void k_big_gauge_fix(FrameView fv, int b0, double* __restrict__ Mall, int mstride, const double* __restrict__ ws_all,
                                                        size_t ws_stride, size_t oref, const int* __restrict__ active)
 {
     constexpr int MP = BIG_NC;
-    __shared__ double sPart[36][7];
+    __shared__ double sRow[GF_ROWS][MP + 1];
     const int bl = blockIdx.y, tid = threadIdx.x;
     if (active && !active[bl]) return;
     const int ref = (int)ws_all[(size_t)bl * ws_stride + oref];
     if (ref < 0) return;
     const int C = fv.n_clones[b0 + bl], ref6 = 6 * ref;
     double* Mg = Mall + (size_t)bl * mstride;
-    if (blockIdx.x == gridDim.x - 1) {                        // corner (k, l): 7 threads each, partial sums over the block rows c' = q, q + 7, ...
-        const int o = tid / 7, q = tid - 7 * o;
-        if (o < 36) {
-            const int k = o / 6, l = o - 6 * k;
-            double s = 0.0;
-            for (int c2 = q; c2 < C; c2 += 7) {
-                if (c2 == ref) continue;
-                const double* row = Mg + (size_t)(6 * c2 + k) * MP + l;
-                double v[BIG_CMAX];
+    if (blockIdx.x < 6) {
+        const int k = blockIdx.x, J = tid;
+        double* sCS = &sRow[0][0];
+        double s = 0.0;
+        if (J <= MP) {
+            const double* col = J < MP ? Mg + (size_t)k * MP + J : Mg + (size_t)MP * MP + k;      // element of row 6 c + k: + c * step
+            const size_t step = J < MP ? (size_t)6 * MP : 6;
+            double v[BIG_CMAX];
 #pragma unroll
-                for (int c = 0; c < BIG_CMAX; ++c) v[c] = row[6 * min(c, C - 1)];             // one row of blocks: all loads in flight together
-                double r = 0.0;
+            for (int c = 0; c < BIG_CMAX; ++c) v[c] = col[min(c, C - 1) * step];                   // all loads in flight, masked by a factor
 #pragma unroll
-                for (int c = 0; c < BIG_CMAX; ++c) r += (c < C && c != ref ? 1.0 : 0.0) * v[c];
-                s += r;
-            }
-            sPart[o][q] = s;
+            for (int c = 0; c < BIG_CMAX; ++c) s += (c < C && c != ref ? 1.0 : 0.0) * v[c];
+            const bool inref = J >= ref6 && J < ref6 + 6;
+            if (J == MP) Mg[(size_t)MP * MP + ref6 + k] = -s;
+            else if (!inref) Mg[(size_t)(ref6 + k) * MP + J] = -s;
+            if (J < MP) sCS[J] = inref ? 0.0 : s;
         }
         __syncthreads();
-        if (tid < 36) {
-            const int k = tid / 6, l = tid - 6 * k;
-            double s = 0.0;
-#pragma unroll
-            for (int q2 = 0; q2 < 7; ++q2) s += sPart[tid][q2];
-            Mg[(size_t)(ref6 + k) * MP + ref6 + l] = s;
+        if (tid < 6) {
+            double r = 0.0;
+            for (int c = 0; c < C; ++c) r += (c != ref ? 1.0 : 0.0) * sCS[6 * c + tid];
+            Mg[(size_t)(ref6 + k) * MP + ref6 + tid] = r;
         }
         return;
     }
-    const int nwg = gridDim.x - 1;
-    for (int e = blockIdx.x * 256 + tid; e < 2 * 6 * (MP + 1); e += nwg * 256) {
-        const int side = e / (6 * (MP + 1)), q = e - side * 6 * (MP + 1), k = q / (MP + 1), J = q - k * (MP + 1);
-        if (J == MP) {
-            if (side == 0) {
-                double s = 0.0;
-#pragma unroll 6
-                for (int c = 0; c < C; ++c) s += (c != ref ? 1.0 : 0.0) * Mg[(size_t)MP * MP + 6 * c + k];
-                Mg[(size_t)MP * MP + ref6 + k] = -s;
-            }
-        } else if (J < ref6 || J >= ref6 + 6) {
-            double s = 0.0;
-            const size_t base = side == 0 ? (size_t)k * MP + J : (size_t)J * MP + k, step = side == 0 ? (size_t)6 * MP : 6;
-#pragma unroll 6
-            for (int c = 0; c < C; ++c) s += (c != ref ? 1.0 : 0.0) * Mg[base + c * step];      // loads independent of the mask: all in flight
-            if (side == 0) Mg[(size_t)(ref6 + k) * MP + J] = -s; else Mg[(size_t)J * MP + ref6 + k] = -s;
+    const int J0 = (blockIdx.x - 6) * GF_ROWS;
+    constexpr int PER = (GF_ROWS * MP + 255) / 256;
+    double v[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { const int e = min(tid + 256 * u, GF_ROWS * MP - 1); v[u] = Mg[(size_t)(J0 + e / MP) * MP + e % MP]; }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { const int e = tid + 256 * u; if (e < GF_ROWS * MP) sRow[e / MP][e % MP] = v[u]; }
+    __syncthreads();
+    if (tid < 6 * GF_ROWS) {
+        const int r = tid / 6, k = tid - 6 * r, J = J0 + r;
+        if (J < ref6 || J >= ref6 + 6) {
+            double sum = 0.0;
+            for (int c = 0; c < C; ++c) sum += (c != ref ? 1.0 : 0.0) * sRow[r][6 * c + k];
+            Mg[(size_t)J * MP + ref6 + k] = -sum;
         }
     }
 }
@@ -840,7 +826,8 @@ static int big_n32(int ncol_cap) { const int n = ncol_cap > 0 ? ncol_cap : BIG_N
 
 // the measurement-independent front of the solve (stage 5): gauge reference, [Pdd; I] and its Cholesky sweep -> [L; L^-T], the Pc copy.
 // No activity flags yet (m_out is written by k_big_prep_A): every filter of the range runs.
-static void launch_big_solve_front(const FactoredLaunch& L, hipStream_t st)
+// part 0: both; 1: the set-up kernel only (gauge reference, [Pdd; I], Pc - stage 6); 2: the sweep only (stage 7)
+static void launch_big_solve_front(const FactoredLaunch& L, hipStream_t st, int part = 0)
 {
     const int n32 = big_n32(L.ncol_cap);
     const BigWs w(n32);
@@ -852,14 +839,20 @@ static void launch_big_solve_front(const FactoredLaunch& L, hipStream_t st)
     constexpr bool no_gauge = false;
 #endif
     const int gauge = (!L.op.selected_variant && !no_gauge) ? 1 : 0;
-    hipLaunchKernelGGL(k_big_prep_P, dim3(32, L.nb), dim3(256), 0, st, L.cv, L.fv, L.b0, L.Pc, L.ystride, L.marg_idx, L.pc_base, ws, wss, n32, gauge);
+    if (part != 2)
+        hipLaunchKernelGGL(k_big_prep_P, dim3(32, L.nb), dim3(256), 0, st, L.cv, L.fv, L.b0, L.Pc, L.ystride, L.marg_idx, L.pc_base, ws, wss, n32, gauge);
+    if (part == 1) return;
     CholArgs c1 = {};
     c1.W = ws + w.oX1; c1.Y = ws + w.oY1; c1.xs = wss; c1.ld = w.ld1; c1.rows = 2 * n32; c1.ncols = n32;
     c1.status = L.status + L.b0; c1.fail_bit = 4; c1.active = nullptr; c1.batch = L.nb; c1.Tb = ws + w.oT; c1.ts = wss; c1.t_slots = n32 / 32;
+    // L^-T (the carried rows) goes straight into the second sweep's working copy as well: no k_copy_rows launch on the critical path
+    c1.Y2 = ws + w.oX2; c1.y2s = wss; c1.ld_y2 = w.ld2; c1.y2_row0 = 2 * n32 + 32;
     launch_chol_sweep(c1, st);
 }
 
-static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
+// part 0: all of it; 1: [A; b^T] from the chunk partials only (stage 8: needs the Gram kernel and the gauge reference of stage 6, not the
+// sweep of stage 7); 2: the rest (stage 9)
+static void launch_big_solve(const FactoredLaunch& L, hipStream_t st, int part = 0)
 {
     const int n32 = big_n32(L.ncol_cap), MP = BIG_NC;
     const BigWs w(n32);
@@ -871,8 +864,10 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
     constexpr bool no_gauge = false;
 #endif
     const int gauge = (!L.op.selected_variant && !no_gauge) ? 1 : 0;
-    hipLaunchKernelGGL(k_big_prep_A, dim3(32, L.nb), dim3(256), 0, st, L.cv, L.fv, L.b0, L.Apart, L.chunk_used, L.G, L.rstride, L.dx, L.m_out,
-                       L.nc_out, ws, wss, n32);
+    if (part != 2)
+        hipLaunchKernelGGL(k_big_prep_A, dim3(32, L.nb), dim3(256), 0, st, L.cv, L.fv, L.b0, L.Apart, L.chunk_used, L.G, L.rstride, L.dx, L.m_out,
+                           L.nc_out, ws, wss, n32);
+    if (part == 1) return;
     const int* act = L.m_out;                                            // 0 = nothing accepted: every later launch skips the filter
     CholArgs c1 = {};
     c1.W = ws + w.oX1; c1.Y = ws + w.oY1; c1.xs = wss; c1.ld = w.ld1; c1.rows = 2 * n32; c1.ncols = n32;
@@ -892,9 +887,7 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
     g.M = n32; g.N = n32; g.K = n32; g.m_lim = n32; g.n_lim = n32; g.ksplit = 1; g.lower = 1; g.diag_add_vec = L.noise;
     g.active = act; g.batch = L.nb;
     launch_gemm(g, st);
-    hipLaunchKernelGGL(k_copy_rows, dim3(16, L.nb), dim3(256), 0, st, ws + w.oY1, wss, w.ld1, n32, ws + w.oX2, wss, w.ld2, 2 * n32 + 32,
-                       n32, n32, act);
-    CholArgs c2 = c1;
+    CholArgs c2 = c1;                                                   // (rows 2 n32 + 32 .. of X2 = L^-T: written by the first sweep itself, CholArgs::Y2)
     c2.W = ws + w.oX2; c2.Y = ws + w.oY2; c2.ld = w.ld2; c2.rows = 3 * n32 + 32;
     launch_chol_sweep(c2, st);
     // M = R2 R1^T (row-major, MP wide), t = R2 r1b^T
@@ -907,7 +900,7 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st)
     g.Cx = L.T + (size_t)MP * MP; g.scx = L.mstride; g.cx_col = n32;
     launch_gemm(g, st);
     // one launch for the reference clone's block row / column AND its 6 x 6 corner (the corner from M itself: a double sum)
-    if (gauge) hipLaunchKernelGGL(k_big_gauge_fix, dim3(12, L.nb), dim3(256), 0, st, L.fv, L.b0, L.T, L.mstride, ws, wss, w.oRef, act);
+    if (gauge) hipLaunchKernelGGL(k_big_gauge_fix, dim3(6 + BIG_NC / GF_ROWS, L.nb), dim3(256), 0, st, L.fv, L.b0, L.T, L.mstride, ws, wss, w.oRef, act);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1441,6 +1434,8 @@ int launch_bigwin(const FactoredLaunch& L, hipStream_t st)
         return 0;
     }
     if (L.stage == 5) { launch_big_solve_front(L, st); return 0; }      // the measurement-independent front of stage 2 (may run on a side stream)
+    if (L.stage == 6 || L.stage == 7) { launch_big_solve_front(L, st, L.stage - 5); return 0; }      // ... in two pieces: set-up kernel, sweep
+    if (L.stage == 8 || L.stage == 9) { launch_big_solve(L, st, L.stage - 7); return 0; }           // stage 2 in two pieces: [A; b^T], the rest
     if (L.stage == 1) {
         const size_t sm = ((sizeof(GBBatch) + 15) / 16) * 16 + 2 * sizeof(int) * (size_t)L.fv.fmax;
         static size_t attr_sm = 0;

@@ -327,10 +327,19 @@ __device__ __forceinline__ void store_factor(const double (&d)[32], int lane, do
     }
 }
 
+// Resources (round 6).  On the side stream of the large-window solve these kernels run UNDER the gate (k_feat_gate4_big: 2-wave workgroups of
+// 232 VGPRs and 40.1 KB, four per CU = the whole register file and LDS).  Tried: [Y_i; Y_j] in the panel blocks' LDS (25.9 instead of 42.7 KB,
+// one more barrier) and a cap of 128 VGPRs, so that a step's workgroup fits what ONE retiring gate workgroup leaves behind - the first step
+// (2016 workgroups) still ends with the gate, 220 us after it was issued (rocprofv3 timeline), and the cap spills 26 registers in factor32
+// (config 5: 1.011 -> 1.032 ms per step).  Whatever arbitrates between the two queues, it is not the workgroup's footprint.  The smaller
+// LDS stays (it costs nothing), the register cap does not (CHOL_STEP_WPE 4 rebuilds it).
+#ifndef CHOL_STEP_WPE
+#define CHOL_STEP_WPE 3
+#endif
 // ---------------------------------------------------------------------------------------------
 // First diagonal block + the original diagonal (the reference of the pivot floor).  grid = batch, 256 threads.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chol_first(CholArgs a)
+__global__ __launch_bounds__(256, CHOL_STEP_WPE) void k_chol_first(CholArgs a)
 {
     __shared__ double sDI[64][33];
     __shared__ __attribute__((aligned(16))) double sC[2][32];
@@ -363,12 +372,13 @@ __global__ __launch_bounds__(256) void k_chol_first(CholArgs a)
 // factorises it on the spot (one wave, factor32) and leaves T_k+1 for the next launch.  The last panel has no trailing blocks:
 // its launch only scales the rows below.  grid = (blocks, batch), 256 threads.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chol_step(CholArgs a, int k, int per)
+__global__ __launch_bounds__(256, CHOL_STEP_WPE) void k_chol_step(CholArgs a, int k, int per)
 {
     __shared__ double sT[32][33];
-    __shared__ double sUi[32][33];
-    __shared__ double sUj[32][33];
-    __shared__ double sDI[64][33];                                       // Y_i (rows 0..31), Y_j (rows 32..63); later [D; I]
+    __shared__ double sUD[64][33];                                       // the panel blocks U_i (rows 0..31), U_j (32..63); then Y_i, Y_j; later [D; I]
+    double (*sUi)[33] = sUD;
+    double (*sUj)[33] = sUD + 32;
+    double (*sDI)[33] = sUD;
     __shared__ __attribute__((aligned(16))) double sC[2][32];
     int batch, blk;
     if (!xcd_decode(per, a.batch, batch, blk)) return;
@@ -415,6 +425,7 @@ __global__ __launch_bounds__(256) void k_chol_step(CholArgs a, int k, int per)
             yi = __builtin_amdgcn_mfma_f64_16x16x4f64(sUi[16 * ti + l15][4 * k4 + kq], tb, yi, 0, 0, 0);
             if (!diag && !tail_only) yj = __builtin_amdgcn_mfma_f64_16x16x4f64(sUj[16 * ti + l15][4 * k4 + kq], tb, yj, 0, 0, 0);
         }
+        lds_barrier();                                                   // every wave has read its U fragments: Y takes their place
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             sDI[16 * ti + kq + 4 * r][16 * tj + l15] = yi[r];
@@ -425,6 +436,10 @@ __global__ __launch_bounds__(256) void k_chol_step(CholArgs a, int k, int per)
     if (tail_only || j == k + 1) {                                       // this workgroup owns the output of block row i
         double* Yo = Y + (size_t)32 * i + (size_t)(32 * k) * ld;
         for (int e = tid; e < 1024; e += 256) { const int r = e & 31, c = e >> 5; Yo[(size_t)r + (size_t)c * ld] = sDI[r][c]; }
+        if (a.Y2 && i >= ncb) {
+            double* Y2o = a.Y2 + (size_t)batch * a.y2s + (size_t)(a.y2_row0 + 32 * (i - ncb)) + (size_t)(32 * k) * a.ld_y2;
+            for (int e = tid; e < 1024; e += 256) { const int r = e & 31, c = e >> 5; Y2o[(size_t)r + (size_t)c * a.ld_y2] = sDI[r][c]; }
+        }
     }
     if (tail_only) return;
 #pragma unroll
@@ -533,6 +548,7 @@ __global__ __launch_bounds__(256) void k_chol_carried(CholArgs a, int per)
     for (int e = tid; e < 32 * a.ncols; e += 256) {
         const int r = e & 31, c = e >> 5;
         Y[(size_t)(32 * i + r) + (size_t)c * ld] = sRow[r * lds + c];
+        if (a.Y2) a.Y2[(size_t)batch * a.y2s + (size_t)(a.y2_row0 + 32 * blk + r) + (size_t)c * a.ld_y2] = sRow[r * lds + c];
     }
 }
 

@@ -52,6 +52,8 @@ struct CholArgs {
     int* status; int fail_bit;
     const int* active;
     int batch;
+    double* Y2; size_t y2s; int ld_y2, y2_row0;  // optional: the CARRIED rows of the result (rows ncols.. of Y) are also written to rows y2_row0.. of Y2 (ld ld_y2,
+                                                 // batch stride y2s) - the next sweep's working copy takes them without a copy launch in between
 };
 void launch_chol_sweep(const CholArgs& a, hipStream_t st);
 
