@@ -1262,6 +1262,9 @@ __device__ __forceinline__ void gate4_big_body(CovView cv, FrameView fv, MsckfOp
         };
         double Att[9], Atp[9], Apt[9], App[9];
         auto load4 = [&](int g, int g2) {
+#ifdef GATE4_ABL_SAMEBLK      // ablation probe (results invalid): every lane reads the same block - what the pair stage costs without its gathers
+            g = sh.gidx[1]; g2 = sh.gidx[1];
+#endif
 #pragma unroll
             for (int m = 0; m < 3; ++m)
 #pragma unroll
