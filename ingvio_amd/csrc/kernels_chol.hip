@@ -73,8 +73,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g)
     const double* B = g.B + (size_t)batch * g.sb;
     // K range of this workgroup, then of this wave (multiples of 16)
     const int kchunks = (g.K + 15) / 16;
-    const int per_wg = (kchunks + g.ksplit - 1) / g.ksplit;
-    const int c_lo = ky * per_wg, c_hi = min(kchunks, c_lo + per_wg);
+    const int c_first = min(kchunks, g.k_from == 1 ? 2 * bi : (g.k_from == 2 ? 2 * bj : 0));      // triangular operand: the chunks before the block's first row / column are zeros
+    const int per_wg = (kchunks - c_first + g.ksplit - 1) / g.ksplit;
+    const int c_lo = c_first + ky * per_wg, c_hi = min(kchunks, c_lo + per_wg);
     const int per_wave = (max(0, c_hi - c_lo) + 3) / 4;
     const int w_lo = c_lo + wave * per_wave, w_hi = min(c_hi, w_lo + per_wave);
     const int i0 = bi * 32 + l15, i1 = i0 + 16, j0 = bj * 32 + l15, j1 = j0 + 16;
@@ -153,9 +154,11 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmArgs g)
     const double* A = g.A + (size_t)batch * g.sa + (g.a_sel ? (size_t)g.a_sel[batch] * g.a_sel_stride : 0);
     const double* B = g.B + (size_t)batch * g.sb;
     b64_d4 c[4];
-    block64_mma2<MA == 1, MB == 1>(sh.ab, (g.K + 15) & ~15,
-                                   [&](int r, int k) { return ld_op<MA>(A, g.lda, 64 * bi + r, k, g.M, g.K, g.Ax, g.ax); },
-                                   [&](int r, int k) { return ld_op<MB>(B, g.ldb, 64 * bj + r, k, g.N, g.K, g.Bx, g.bx); }, true, c);
+    const int k16 = (g.K + 15) & ~15;
+    const int ks = min(k16, g.k_from == 1 ? 64 * bi : (g.k_from == 2 ? 64 * bj : 0));                // triangular operand (GemmArgs::k_from): K starts at the block
+    block64_mma2<MA == 1, MB == 1>(sh.ab, k16 - ks,
+                                   [&](int r, int k) { return ld_op<MA>(A, g.lda, 64 * bi + r, ks + k, g.M, g.K, g.Ax, g.ax); },
+                                   [&](int r, int k) { return ld_op<MB>(B, g.ldb, 64 * bj + r, ks + k, g.N, g.K, g.Bx, g.bx); }, true, c);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, wi = wave >> 1, wj = wave & 1;
     block64_to_lds(c, sh.sV[wave]);                                     // the wave's 32 x 32 quadrant, then stores along the contiguous dimension
     double* C = g.C + (size_t)batch * g.sc;

@@ -26,6 +26,8 @@ struct GemmArgs {
     double diag_add; const double* diag_add_vec;    // diag_add_vec[batch] (e.g. the per-filter measurement variance) overrides diag_add
     const int* active;
     int batch;
+    int k_from;                                     // triangular operands (round 6): 1: opA(i, k) = 0 for k < i (K starts at the block's first row), 2: opB(k, j) = 0 for k < j
+                                                    // (at its first column), 0: full K.  The skipped products are exact zeros: same result
     double* Cx; size_t scx; int cx_col;             // optional: column cx_col of the product goes to the VECTOR Cx[batch scx + i] instead of C (a
                                                     // matrix-vector product riding on the GEMM as one more column of opB); Cx == nullptr: off
 };
