@@ -776,7 +776,20 @@ int run_msckf_factored(ingvio_ctx* c, int b0, int nb, const MsckfOpts& op, int s
     }
     if (phase != 2) {
         if (c->tok_wait) HIPCHK(c, hipStreamWaitEvent(c->run_st, c->tok_wait, 0));      // split frame step: one throughput segment at a time
-        { ProfScope p(c, PF_GATE2); L.stage = 0; if (launch_factored(L, c->run_st)) return INGVIO_E_UNSUPPORTED; }
+        {
+            // the gate's events ride on its dispatch packet (FactoredLaunch::prof_a / prof_b) instead of bracketing it
+            const bool pon = c->prof && (c->prof_only < 0 || c->prof_only == PF_GATE2);
+            int used = 0;
+            if (pon) { hipEventCreate(&L.prof_a); hipEventCreate(&L.prof_b); L.prof_used = &used; }
+            L.stage = 0;
+            const int grc = launch_factored(L, c->run_st);
+            if (pon) {
+                if (used) c->recs.push_back({ PF_GATE2, L.prof_a, L.prof_b });
+                else { hipEventDestroy(L.prof_a); hipEventDestroy(L.prof_b); }
+                L.prof_a = nullptr; L.prof_b = nullptr; L.prof_used = nullptr;
+            }
+            if (grc) return INGVIO_E_UNSUPPORTED;
+        }
         { ProfScope p(c, PF_GRAM); L.stage = 1; launch_factored(L, c->run_st); }
         if (c->tok_rec) HIPCHK(c, hipEventRecord(c->tok_rec, c->run_st));
     }

@@ -54,7 +54,7 @@ static void launch_gate_big(const FactoredLaunch& L, hipStream_t st)
             const size_t sm = sizeof(Gate4BigShared<CM>);
             static bool attr_set = false;
             if (!attr_set) { hipFuncSetAttribute((const void*)k_feat_gate4_big<CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
-            hipLaunchKernelGGL((k_feat_gate4_big<CM>), dim3(nb8 * L.fmax_used), dim3(2 * WAVE), sm, st, L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used,
+            LAUNCH_GATE(L, (k_feat_gate4_big<CM>), dim3(nb8 * L.fmax_used), dim3(2 * WAVE), sm, st, L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used,
                                L.gamma, L.accept, L.rec);
             return;
         }
@@ -62,7 +62,7 @@ static void launch_gate_big(const FactoredLaunch& L, hipStream_t st)
 #ifndef INGVIO_ALT_KERNELS
     if constexpr (!STEREO)
 #endif
-    hipLaunchKernelGGL((k_feat_gate3_big<STEREO, CM>), dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st,
+    LAUNCH_GATE(L, (k_feat_gate3_big<STEREO, CM>), dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st,
                        L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
 }
 

@@ -1363,7 +1363,7 @@ static void launch_ft(const FactoredLaunch& L, hipStream_t st)
         static const bool gate4 = [] { const char* e = getenv("INGVIO_GATE"); return e && e[0] == '4'; }();      // one feature per wave (round 3)
         if constexpr (STEREO && CMAX <= 11) {
             if (!gate3 && !gate4) {
-                hipLaunchKernelGGL((k_feat_gate5<CMAX>), dim3(nb8 * ((L.fmax_used + 3) / 4)), dim3(WAVE), 0, st, L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used,
+                LAUNCH_GATE(L, (k_feat_gate5<CMAX>), dim3(nb8 * ((L.fmax_used + 3) / 4)), dim3(WAVE), 0, st, L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used,
                                    L.gamma, L.accept);
                 return;
             }
@@ -1371,14 +1371,14 @@ static void launch_ft(const FactoredLaunch& L, hipStream_t st)
         if constexpr (!STEREO && CMAX == 11) {                        // mono, 7..11 clones: four features per wave (INGVIO_GATE=3: the first-generation gate)
             static const bool gate3m = [] { const char* e = getenv("INGVIO_GATE"); return e && e[0] == '3'; }();
             if (!gate3m) {
-                hipLaunchKernelGGL((k_feat_gate5m<CMAX>), dim3(nb8 * ((L.fmax_used + 3) / 4)), dim3(WAVE), 0, st, L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used,
+                LAUNCH_GATE(L, (k_feat_gate5m<CMAX>), dim3(nb8 * ((L.fmax_used + 3) / 4)), dim3(WAVE), 0, st, L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used,
                                    L.gamma, L.accept);
                 return;
             }
         }
         if constexpr (STEREO) {
             if (!gate3) {
-                hipLaunchKernelGGL((k_feat_gate4<CMAX>), dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st, L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used,
+                LAUNCH_GATE(L, (k_feat_gate4<CMAX>), dim3(nb8 * L.fmax_used), dim3(WAVE), 0, st, L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used,
                                    L.gamma, L.accept);
                 return;
             }
@@ -1386,7 +1386,7 @@ static void launch_ft(const FactoredLaunch& L, hipStream_t st)
 #ifndef INGVIO_ALT_KERNELS
         if constexpr (!STEREO)                                         // k_feat_gate3<CMAX, true> is not instantiated in the product library
 #endif
-        hipLaunchKernelGGL((k_feat_gate3<CMAX, STEREO>), dim3(nb8 * ((L.fmax_used + GATE_FPW - 1) / GATE_FPW)), dim3(GATE_FPW * WAVE), 0, st,
+        LAUNCH_GATE(L, (k_feat_gate3<CMAX, STEREO>), dim3(nb8 * ((L.fmax_used + GATE_FPW - 1) / GATE_FPW)), dim3(GATE_FPW * WAVE), 0, st,
                            L.cv, L.fv, L.op, L.b0, L.nb, L.fmax_used, L.gamma, L.accept, L.rec);
     } else {
 #ifdef INGVIO_ALT_KERNELS

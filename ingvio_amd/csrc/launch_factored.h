@@ -59,7 +59,18 @@ struct FactoredLaunch {
     const double* gY;
     size_t gYstride;
     const int* gm;
+    // profiling of the gate (stage 0, one kernel whatever the class): when set, the kernel is launched with these events ATTACHED to its
+    // dispatch (hipExtLaunchKernelGGL: the kernel's own start / stop timestamps) instead of an event record in front of and behind it -
+    // two barrier packets of 2-3 us each per step inside bench.py's timed region (round 6)
+    hipEvent_t prof_a, prof_b;
+    int* prof_used;       // set to 1 by the launch site that took the events
 };
+#include <hip/hip_ext.h>
+#define LAUNCH_GATE(L, kernel, grid, block, shmem, st, ...)                                                             \
+    do {                                                                                                                \
+        if ((L).prof_a) { hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, (L).prof_a, (L).prof_b, 0, __VA_ARGS__); if ((L).prof_used) *(L).prof_used = 1; } \
+        else hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                                           \
+    } while (0)
 
 int launch_factored(const FactoredLaunch& L, hipStream_t st);
 // kernels_solve.hip: stage 2 in symmetric (LDL^T) form on the matrix cores; non-zero when the window class is not covered
