@@ -150,7 +150,7 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
                 pvf[rt][t4] = row < n ? Ps[row + (size_t)cc * ld] : 0.0;
             }
         }
-        if (blockIdx.x == 0) {
+        if (blockIdx.x == 0 && gridDim.x > 1) {                 // (a single tile takes Phi_A P_AA from its strip product, see the A x A block below)
             auto acol = [&](int i) { return i < 15 ? i : (i == 15 ? cg[0] : i == 16 ? cg[1] : i == 17 ? cg[2] : i == 18 ? cg[3] : cg[4]); };
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -171,6 +171,13 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
     //     Q      += dt_s X_s^T X_s               A = B = the registers of X_s                                            (3 MFMA)
     // (the first version ran two barrier-separated phases of 15-term LDS dot products per step: 3.7 k cycles per step, 37 k of the
     // kernel's 145 k; the steps of a chunk now take 11 MFMAs each).
+    // Phi_A / Q_A zeroed and the active set written NOW, by everybody, under the loads above (round 6: this used to follow the
+    // composition as zero fill - barrier - thread 0's serial bookkeeping - barrier: 5 k of the kernel's 75 k cycles); every thread has
+    // computed naq and the clock columns cg[] from the indices itself
+    auto acol_of = [&](int i) { return i < 15 ? i : (i == 15 ? cg[0] : i == 16 ? cg[1] : i == 17 ? cg[2] : i == 18 ? cg[3] : cg[4]); };
+    for (int a = tid; a < NA_MAX * NA_MAX; a += PROP_THREADS) { sPhiA[a] = 0.0; sQA[a] = 0.0; }
+    if (tid < NA_MAX) sA[tid] = tid < naq ? acol_of(tid) : 0;      // padding: loads stay unconditional, Phi_A rows/cols there are zero
+    if (tid == 0) sNA = naq;
     typedef double d4 __attribute__((ext_vector_type(4)));
     d4 PsiT = { 0.0, 0.0, 0.0, 0.0 }, Qacc = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
@@ -235,28 +242,8 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
         lds_barrier();                                        // the chunk's LDS may be overwritten
     }
     dbg_stamp(17);
-    for (int a = tid; a < NA_MAX * NA_MAX; a += PROP_THREADS) { sPhiA[a] = 0.0; sQA[a] = 0.0; }
-    lds_barrier();
-    // active set + GNSS clock block (thread 0, bookkeeping only)
-    if (tid == 0) {
-        int gi[5], na = 15;
-        for (int g = 0; g < 5; ++g) gi[g] = (enable_gnss && gnss_idx) ? gnss_idx[bl * 5 + g] : -1;
-        for (int a = 0; a < 15; ++a) sA[a] = a;
-        int loc[5];
-        for (int g = 0; g < 5; ++g) { loc[g] = -1; if (gi[g] >= 0) { loc[g] = na; sA[na++] = gi[g]; } }
-        sNA = na;
-        for (int a = na; a < NA_MAX; ++a) sA[a] = 0;      // padding: loads stay unconditional, Phi_A rows/cols there are zero
-        const bool has_fs = gi[4] >= 0;
-        const double T = sQg[25];
-        const double (*qg)[5] = reinterpret_cast<const double (*)[5]>(sQg);
-        for (int a = 0; a < 5; ++a) {
-            if (loc[a] < 0) continue;
-            sPhiA[loc[a] * NA_MAX + loc[a]] = 1.0;
-            if (a < 4 && has_fs) sPhiA[loc[a] * NA_MAX + loc[4]] = T;
-            for (int c = 0; c < 5; ++c) if (loc[c] >= 0) sQA[loc[a] * NA_MAX + loc[c]] = qg[a][c];
-        }
-    }
-    lds_barrier();                                            // the zero fill and thread 0's clock entries before wave 0's block
+    // the composed step into Phi_A / Q_A: wave 0 its 15 x 15 blocks, 25 lanes of wave 1 the GNSS clock block (position of clock state g
+    // in the active set: 15 + the number of present clock states before it) - disjoint entries, one barrier
     if (tid < 64) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -265,6 +252,16 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
                 sPhiA[l15 * NA_MAX + c] = PsiT[r];              // Psi^T[c][l15] = Phi_tot(l15, c)
                 sQA[c * NA_MAX + l15] = Qacc[r];                // Q(c, l15)
             }
+        }
+    } else if (wv == 1 && lane < 25) {
+        const int ga = lane / 5, gc = lane - 5 * ga;
+        auto gidx = [&](int q) { return q == 0 ? giq[0] : q == 1 ? giq[1] : q == 2 ? giq[2] : q == 3 ? giq[3] : giq[4]; };
+        auto locof = [&](int q) { int l = 15; for (int u = 0; u < 5; ++u) l += (u < q && gidx(u) >= 0) ? 1 : 0; return l; };
+        if (gidx(ga) >= 0 && gidx(gc) >= 0) {
+            const int la = locof(ga), lc = locof(gc);
+            sQA[la * NA_MAX + lc] = sQg[lane];
+            if (ga == gc) sPhiA[la * NA_MAX + la] = 1.0;
+            if (gc == 4 && ga < 4) sPhiA[la * NA_MAX + lc] = sQg[25];      // clock bias <- clock drift over the total time (has_fs: gidx(4) >= 0 here)
         }
     }
     lds_barrier();
@@ -320,23 +317,29 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
     dbg_stamp(19);
     // A x A block, tile 0 only
     if (blockIdx.x == 0) {
+        if (gridDim.x > 1) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {                          // requested at the top of the kernel (behind the strip's stores a load
-            const int e = tid + u * PROP_THREADS;              // issued here would wait for their acknowledgements: one vmcnt queue)
-            if (e < na * na) { const int a = e / na, c = e - a * na; sX[a * NA_MAX + c] = aap[u]; }
+            for (int u = 0; u < 2; ++u) {                      // requested at the top of the kernel (behind the strip's stores a load
+                const int e = tid + u * PROP_THREADS;          // issued here would wait for their acknowledgements: one vmcnt queue)
+                if (e < na * na) { const int a = e / na, c = e - a * na; sX[a * NA_MAX + c] = aap[u]; }
+            }
+            lds_barrier();
+            for (int e = tid; e < na * na; e += PROP_THREADS) {
+                const int a = e / na, c = e % na;
+                double acc = 0.0;
+                for (int l = 0; l < na; ++l) acc += sPhiA[a * NA_MAX + l] * sX[l * NA_MAX + c];
+                sY[a * NA_MAX + c] = acc;
+            }
+            lds_barrier();
         }
-        lds_barrier();
+        // Single tile (round 6): Y = Phi_A P[A, A] is already there - the strip product above ran for EVERY row of the tile, the rows of
+        // the active set included (computed, not stored): sStrip[i][A_c] = sum_k Phi_A[i][k] P[A_c][A_k] = (Phi_A P_AA)[i][c], P symmetric
+        // bit for bit.  The block's loads, its staging and the first of the two dot-product passes (two barriers) are gone.
+        const bool ytile = gridDim.x == 1;
         for (int e = tid; e < na * na; e += PROP_THREADS) {
             const int a = e / na, c = e % na;
             double acc = 0.0;
-            for (int l = 0; l < na; ++l) acc += sPhiA[a * NA_MAX + l] * sX[l * NA_MAX + c];
-            sY[a * NA_MAX + c] = acc;
-        }
-        lds_barrier();
-        for (int e = tid; e < na * na; e += PROP_THREADS) {
-            const int a = e / na, c = e % na;
-            double acc = 0.0;
-            for (int l = 0; l < na; ++l) acc += sY[a * NA_MAX + l] * sPhiA[c * NA_MAX + l];
+            for (int l = 0; l < na; ++l) acc += (ytile ? sStrip[a * (PROP_THREADS + 1) + sA[l]] : sY[a * NA_MAX + l]) * sPhiA[c * NA_MAX + l];
             sX[a * NA_MAX + c] = acc + sQA[a * NA_MAX + c];
         }
         lds_barrier();

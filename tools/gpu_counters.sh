@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $ROOT/bench.py --no-cpu --no-profile --no-aux --no-latency --steps 3 --warmup 1 $*"
+BENCH="python $ROOT/bench.py --no-cpu --no-profile --no-aux --no-latency --no-condition --steps 3 --warmup 1 $*"      # counters are per launch: no conditioning steps (they only grow the csv)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python $ROOT/bench.py --no-cpu --no-profile --no-aux --no-latency --steps 20 --warmup 5 "$@" > "$OUT/stats.log" 2>&1
 PASSES=(
  "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES"
@@ -31,4 +31,5 @@ cd "$ROOT"
 python tools/pmc_summary.py --key "$KEY" --last 3 --per-step "${PER_STEP:-}" --out gpurun_out/counters.json --csv "gpurun_out/counters_$TAG.csv" \
   --source "rocprofv3 --pmc (5 passes) -- python bench.py --no-cpu --no-profile --steps 3 --warmup 1 $*; last 3 dispatches per kernel" $DIRS
 find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "gpurun_out/kernel_stats_$TAG.csv" \;
+rm -rf $DIRS      # the raw per-dispatch counter files: folded above (gpurun copies at most 64 MiB back)
 tail -2 "$OUT/stats.log"
