@@ -54,6 +54,10 @@ def test_compact_line_fits_and_has_the_contract_keys():
                                        "tracks", "bytes_per_update"}
     assert set(d["host_handover"]["tracks"]) == {"serial", "pipelined", "bytes_per_update", "same_result", "stagers8_aggregate", "error"}
     assert abs(d["value"] - full["value"]) / full["value"] < 1e-5
+    # round 6: the untimed conditioning steps in front of the timed region are DISCLOSED on the line (absent with --no-condition)
+    assert "device_conditioning" not in d
+    cond = dict(steps=520, seconds=0.2523, first_block_ms_per_step=0.5035, last_block_ms_per_step=0.4813)
+    assert json.loads(bench.compact_line(dict(full, device_conditioning=cond)))["device_conditioning"] == cond
 
 
 def test_line_limit_is_enforced():
