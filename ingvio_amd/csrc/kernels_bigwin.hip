@@ -869,6 +869,12 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st, int part =
     constexpr bool no_gauge = false;
 #endif
     const int gauge = (!L.op.selected_variant && !no_gauge) ? 1 : 0;
+#ifdef INGVIO_ALT_KERNELS
+    static const bool tri_off = [] { const char* e = getenv("INGVIO_BIG_GEMM"); return e && !strcmp(e, "full"); }();      // the products over all of K, for comparison
+#else
+    constexpr bool tri_off = false;
+#endif
+    const bool tri = BIG_GEMM_TRI && !tri_off;
     if (part != 2)
         hipLaunchKernelGGL(k_big_prep_A, dim3(32, L.nb), dim3(256), 0, st, L.cv, L.fv, L.b0, L.Apart, L.chunk_used, L.G, L.rstride, L.dx, L.m_out,
                            L.nc_out, ws, wss, n32);
@@ -883,7 +889,7 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st, int part =
     g.B = ws + w.oY1; g.sb = wss; g.ldb = w.ld1; g.modeB = 1;
     g.C = ws + w.oX2 + n32; g.sc = wss; g.rs = 1; g.cs = w.ld2;
     g.M = n32 + 32; g.N = n32; g.K = n32; g.m_lim = n32 + 32; g.n_lim = n32; g.ksplit = 1; g.active = act; g.batch = L.nb;
-    g.k_from = BIG_GEMM_TRI ? 2 : 0;                                     // L[k][j] = 0 for k < j
+    g.k_from = tri ? 2 : 0;                                     // L[k][j] = 0 for k < j
     launch_gemm(g, st);
     // W = L^T (A L) + s^2 I -> X2 rows 0 .. (lower blocks)
     g = GemmArgs{};
@@ -892,7 +898,7 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st, int part =
     g.C = ws + w.oX2; g.sc = wss; g.rs = 1; g.cs = w.ld2;
     g.M = n32; g.N = n32; g.K = n32; g.m_lim = n32; g.n_lim = n32; g.ksplit = 1; g.lower = 1; g.diag_add_vec = L.noise;
     g.active = act; g.batch = L.nb;
-    g.k_from = BIG_GEMM_TRI ? 1 : 0;                                     // (L^T)[i][k] = L[k][i] = 0 for k < i
+    g.k_from = tri ? 1 : 0;                                     // (L^T)[i][k] = L[k][i] = 0 for k < i
     launch_gemm(g, st);
     CholArgs c2 = c1;                                                   // (rows 2 n32 + 32 .. of X2 = L^-T: written by the first sweep itself, CholArgs::Y2)
     c2.W = ws + w.oX2; c2.Y = ws + w.oY2; c2.ld = w.ld2; c2.rows = 3 * n32 + 32;
@@ -905,7 +911,7 @@ static void launch_big_solve(const FactoredLaunch& L, hipStream_t st, int part =
     // t rides on the same launch: r1b is the row of Y2 right below R1, i.e. column n32 of the product, stored as the vector after M
     g.M = n32; g.N = n32 + 1; g.K = n32; g.m_lim = MP; g.n_lim = n32 < MP ? n32 : MP; g.ksplit = 1; g.active = act; g.batch = L.nb;
     g.Cx = L.T + (size_t)MP * MP; g.scx = L.mstride; g.cx_col = n32;
-    g.k_from = BIG_GEMM_TRI ? 1 : 0;                                     // R2 = L^-T L2^-T is upper triangular: R2[i][k] = 0 for k < i
+    g.k_from = tri ? 1 : 0;                                     // R2 = L^-T L2^-T is upper triangular: R2[i][k] = 0 for k < i
     launch_gemm(g, st);
     // one launch for the reference clone's block row / column AND its 6 x 6 corner (the corner from M itself: a double sum)
     if (gauge) hipLaunchKernelGGL(k_big_gauge_fix, dim3(6 + BIG_NC / GF_ROWS, L.nb), dim3(256), 0, st, L.fv, L.b0, L.T, L.mstride, ws, wss, w.oRef, act);

@@ -12,6 +12,8 @@ process) that runs the parity tests covering it.  One toggle per case:
   INGVIO_LM_FRONT=split    landmark update with k_lm_build + k_lm_products (compacting) instead of the fused front
   INGVIO_LM_SOLVE=sweep    landmark / dense-H update on the Cholesky sweep out of L2 instead of the register-resident solve
   INGVIO_GRAM=3            k_feat_gram3 (round 6): one operand panel Z = D^-1/2 L^-1 B (B^T Ns^-1 B = Z^T Z), double-buffered, one barrier per batch
+  INGVIO_BIG_GEMM=full     the three products of the large-window solve over all of K (the product skips the chunks in front of a block's first
+                           row / column: triangular operands, GemmArgs::k_from, round 6)
   INGVIO_FEW=off           few filters (up to 64 per launch) on the kernels of a full batch: chunk partials added inside the solve, k_info_apply
                            (the product sums them with k_chunk_sum first and applies with one wave per tile, k_apply_*_flat)
 """
@@ -37,6 +39,7 @@ CASES = [
                            "test_msckf_small or test_window_size_classes or test_ragged or test_consecutive_frames or test_sigma_and_prior_scale_sweep"]),
     ("INGVIO_GRAM", "3", ["tests/test_gpu_parity.py", "tests/test_gpu_pinning.py", "-k",
                           "test_full_n249_batch_vs_oracle or test_msckf_small or test_window_size_classes or test_ragged or test_mono_gate or test_sigma_and_prior_scale_sweep"]),
+    ("INGVIO_BIG_GEMM", "full", ["tests/test_gpu_parity.py", "tests/test_gpu_pinning.py", "-k", "large_window or config5 or big"]),
     ("INGVIO_LM_FRONT", "split", ["tests/test_landmark_batch.py"]),
     ("INGVIO_LM_SOLVE", "sweep", ["tests/test_landmark_batch.py"]),
 ]
