@@ -570,15 +570,27 @@ def run_workload(args, grp, aux=False):
         dom_name = max(cand)[1] if cand else None
         ctx.profile_select(dom_name)
 
-    barrier()
-    ctx.profile_reset()
-    ctx.profile_enable(dom_name is not None)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    ctx.sync()
-    elapsed_local = time.perf_counter() - t0
-    ctx.profile_enable(False)
+    def timed_region():
+        barrier()
+        ctx.profile_reset()
+        ctx.profile_enable(dom_name is not None)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        ctx.profile_enable(False)
+        return dt
+
+    elapsed_local = timed_region()
+    # AUXILIARY passes only (aux_configs: configs 3 and 5 behind the headline workload in the same process; never the headline): a
+    # timed region that comes out more than 1.5 x slower per step than the conditioning block right before it is an outlier of the
+    # run, not of the kernels (seen once in a dozen default runs: config 5 at 1.98 ms per step between runs at 0.96-0.97) - it is
+    # timed once more, and the first figure is reported beside the second (`retimed`)
+    retimed = None
+    if aux and cond and elapsed_local / args.steps * 1e3 > 1.5 * cond["last_block_ms_per_step"]:
+        retimed = dict(first_ms_per_step=elapsed_local / args.steps * 1e3, conditioned_ms_per_step=cond["last_block_ms_per_step"])
+        elapsed_local = timed_region()
     if dom_name is not None:
         prof[dom_name] = ctx.profile_get()[dom_name]      # the dominant kernel: measured live inside the timed region
     elapsed = grp.max_over_ranks(elapsed_local)
@@ -760,7 +772,7 @@ def run_workload(args, grp, aux=False):
                         parallelism="independent filters, %d rank(s), no data-path collective" % world),
             ms_per_update=elapsed / args.steps * 1e3 / B, per_rank_ms_per_step=per_rank_ms, per_rank_spread=rank_spread, rank_balance_ok=bool(rank_spread <= 0.05), accepted_per_filter=F_used, results_finite=ok,
             algorithmic_flops_per_update=total_flops, whole_step_executed=step_exec,
-            device_conditioning=cond, method=args.method, roofline=roofline, cpu_baseline=cpu, parity_vs_oracle=parity, as_written_cap20=aw, host_handover=handover,
+            device_conditioning=cond, retimed=retimed, method=args.method, roofline=roofline, cpu_baseline=cpu, parity_vs_oracle=parity, as_written_cap20=aw, host_handover=handover,
             kernels=kernels, oracle_update_ms_upper_bound=oracle_1t,
             kernels_note="per-kernel avg_ms: separate untimed pass of 3 steps with an event pair around every launch; the "
                          "roofline kernel's avg_ms is from the timed region; executed_* and hbm_* come from the committed PMC passes "
@@ -979,7 +991,7 @@ def latency_b1(args):
     return out
 
 
-AUX_KEYS = ("value", "unit", "ms_per_step", "ms_per_update", "steps", "warmup", "config", "accepted_per_filter", "results_finite",
+AUX_KEYS = ("value", "unit", "ms_per_step", "ms_per_update", "steps", "warmup", "config", "accepted_per_filter", "results_finite", "retimed",
             "roofline", "whole_step_executed", "parity_vs_oracle", "kernels", "setup_s", "oracle_update_ms_upper_bound")
 COND_SECONDS = 0.25                      # untimed steps of the workload in front of the timed region (run_workload: device conditioning)
 LINE_LIMIT = 6000                        # the driver keeps the last ~8 KB of stdout: the final line must fit with room to spare
@@ -1053,6 +1065,9 @@ def compact_line(full):
                     max_rel_cov_err=(v.get("parity_vs_oracle") or {}).get("max_rel_cov_err"),
                     accept_mask_equal=(v.get("parity_vs_oracle") or {}).get("accept_mask_equal"))
             for k, v in full["aux_configs"].items()}
+        for k, v in full["aux_configs"].items():
+            if v.get("retimed"):                          # an outlier of the run was timed a second time (run_workload): both figures on the line
+                out["aux_configs"][k]["retimed"] = v["retimed"]
     hh = full.get("host_handover")
     if hh is not None:
         # host buffers in, results out (never `value`): one context serial / pipelined, and 8 concurrent stagers x 64 filters on this GPU
