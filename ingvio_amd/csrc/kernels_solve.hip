@@ -226,28 +226,52 @@ __device__ __forceinline__ void solve_wave(const SolveArgs<NC>& a, int* bad)
     double af[RW][NT][4];
     unsigned long long used_mask = 0;                          // G <= 16 chunks (ingvio_ctx_create; INGVIO_GRAM_CHUNKS of the variant build: <= 64)
     for (int g = 0; g < a.G; ++g) used_mask |= (a.chunk_used[a.bl * a.G + g] != 0 ? 1ull : 0ull) << g;
+    // Round 6 (last day): with the chunk loop INSIDE the element loop and a run-time trip count every element was a load -> wait ->
+    // select -> add of its own - 16 to 32 dependent round trips per lane, 17.6 k of the kernel's 129 k cycles (shader-clock stamps),
+    // nothing of it under the factorisation.  ONE partial (what a full batch and, behind k_chunk_sum, a few filters have): every load is
+    // issued here from a clamped address and NOT looked at - the padding is selected away right before the product, after factorisation
+    // 1 (the barriers in between are LDS-only: __syncthreads would drain the loads).  Several partials: the chunk loop outermost, a
+    // chunk's loads in flight together (G round trips), added in chunk order as before.
+    unsigned okm[RW];
+    const bool one_partial = a.G == 1;
 #pragma unroll
     for (int w = 0; w < RW; ++w) {
+        okm[w] = 0u;
         if (D2.rows[W][w].valid && D2.rows[W][w].kind == 1) {
             const int row = 16 * D2.rows[W][w].rt + l15;
+            int eoff[NT][4];
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int col = 16 * kt + 4 * s + kq;
-                    double v = 0.0;
-                    if (col < ncol && (row < ncol || row == NC)) {      // row NC = b^T
-                        const int colF = RED ? col + (col >= a.ref6 ? 6 : 0) : col, rowF = RED ? row + (row >= a.ref6 ? 6 : 0) : row;
-                        const size_t e = (size_t)colF * (a.ncolF + 1) + (row == NC ? a.ncolF : rowF);
-                        // every load is issued whether its chunk is used or not (the value is selected away): under the condition each
-                        // element was a dependent round trip of its own (round 6: 19.5 k -> see DESIGN 4.3 cycles for this phase)
-                        for (int g = 0; g < a.G; ++g) {
-                            const double x = a.Apart[((size_t)a.bl * a.G + g) * a.rstride + e];
-                            v += ((used_mask >> g) & 1ull) ? x : 0.0;
-                        }
-                    }
-                    af[w][kt][s] = v;
+                    const bool ok = col < ncol && (row < ncol || row == NC);      // row NC = b^T
+                    const int colF = RED ? col + (col >= a.ref6 ? 6 : 0) : col, rowF = RED ? row + (row >= a.ref6 ? 6 : 0) : row;
+                    eoff[kt][s] = ok ? colF * (a.ncolF + 1) + (row == NC ? a.ncolF : rowF) : 0;
+                    okm[w] |= (ok ? 1u : 0u) << (4 * kt + s);
+                    af[w][kt][s] = 0.0;
                 }
+            if (one_partial) {
+                const double* Ap = a.Apart + (size_t)a.bl * a.rstride;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) af[w][kt][s] = Ap[eoff[kt][s]];
+            } else {
+                for (int g = 0; g < a.G; ++g) {
+                    const double* Ap = a.Apart + ((size_t)a.bl * a.G + g) * a.rstride;
+                    const bool used = (used_mask >> g) & 1ull;
+                    double x[NT][4];
+#pragma unroll
+                    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) x[kt][s] = Ap[eoff[kt][s]];
+#pragma unroll
+                    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) af[w][kt][s] += (used && ((okm[w] >> (4 * kt + s)) & 1u)) ? x[kt][s] : 0.0;
+                }
+            }
         }
     }
     // ================= factorisation 1: Pcc = L D L^T, identity carried =================
@@ -298,9 +322,9 @@ __device__ __forceinline__ void solve_wave(const SolveArgs<NC>& a, int* bad)
                     for (int r = 0; r < 4; ++r) T[w][c][r] = (16 * D1.rows[W][w].rt + kq + 4 * r == col) ? 1.0 : 0.0;
                 }
             }
-        __syncthreads();                                      // every wave holds its tiles of Pdd: the staging area becomes X and Y
+        lds_barrier();                                        // every wave holds its tiles of Pdd: the staging area becomes X and Y (LDS only: the A fragments stay in flight)
         for (int e = W * 64 + lane; e < 2 * MROWS * LDM; e += NTH) X[e] = 0.0;
-        __syncthreads();
+        lds_barrier();
         auto emit = [&](int w, int row, int col, int k, double x, double xs) {
             if (D1.rows[W][w].kind == 0) X[row * LDM + col] = row > 4 * k + 3 ? xs : (row == col ? 1.0 : 0.0);   // L: identity pivot blocks
             else Y[(row - NP) * LDM + col] = xs;                                                             // L^-T D^-1 (upper)
@@ -320,13 +344,19 @@ __device__ __forceinline__ void solve_wave(const SolveArgs<NC>& a, int* bad)
                 for (int r = 0; r < 4; ++r) T[w][c][r] = Y[(16 * D2.rows[W][w].rt + kq + 4 * r) * LDM + 16 * c + l15];
             }
         }
-    __syncthreads();                                          // every wave has its R2 tiles: Y may be overwritten
+    lds_barrier();                                            // every wave has its R2 tiles: Y may be overwritten
     // ---- R1 = [A ; b^T ; 0] L  (A symmetric, from the gram partials in global memory; L in X) ----
 #pragma unroll
     for (int w = 0; w < RW; ++w) {
         if (D2.rows[W][w].valid && D2.rows[W][w].kind == 1) {
             constexpr int dummy = 0; (void)dummy;
             const int i = D2.rows[W][w].rt;
+            if (one_partial) {                                  // the fragments requested before factorisation 1: padding selected away now
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) af[w][kt][s] = ((okm[w] >> (4 * kt + s)) & 1u) ? af[w][kt][s] : 0.0;
+            }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 double4_f acc = { 0.0, 0.0, 0.0, 0.0 };
