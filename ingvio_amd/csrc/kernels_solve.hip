@@ -634,6 +634,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     for (int cr = 0; cr < CF - 1; ++cr) s += side == 0 ? X[(6 * cr + k) * LDM + Jr] : X[Jr * LDM + 6 * cr + k];
                 }
                 if (side == 0) Mg[(size_t)(ref6 + k) * MPF + J] = -s; else Mg[(size_t)J * MPF + ref6 + k] = -s;
+                if (side == 0 && J < NCF) Y[k * LDM + (J < ref6 ? J : J - 6)] = s;      // the column sums of block row k, for the corner below (Y is dead)
             }
         }
         if (MPF > NCF) {                                      // zero padding of the other rows / columns
@@ -645,11 +646,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 Mg[(size_t)(NCF + e / (MPF - NCF)) * MPF + NCF + e % (MPF - NCF)] = 0.0;
             if (tid < MPF - NCF) Mg[(size_t)MPF * MPF + NCF + tid] = 0.0;
         }
-        if (tid < 36) {                                       // corner: + the sum over all the other clones' blocks
-            const int k = tid / 6, l = tid - 6 * k;
+        lds_barrier();
+        if (tid < 36) {                                       // corner: + the sum over all the other clones' blocks = the block row's column sums added over
+            const int k = tid / 6, l = tid - 6 * k;           // the clones (round 6: as a double sum 36 lanes walked 100 LDS reads each at the very end of the kernel)
             double s = 0.0;
-            for (int cr = 0; cr < CF - 1; ++cr)
-                for (int c2 = 0; c2 < CF - 1; ++c2) s += X[(6 * cr + k) * LDM + 6 * c2 + l];
+            for (int c2 = 0; c2 < CF - 1; ++c2) s += Y[k * LDM + 6 * c2 + l];
             Mg[(size_t)(ref6 + k) * MPF + ref6 + l] = s;
         }
     }
