@@ -1003,23 +1003,10 @@ __global__ __launch_bounds__(256, 2) void k_info_apply(CovView cv, int b0, int n
             }
     }
     if (upd && fused && part == 0 && wave == 0) {      // the correction of the states about to be marginalised: no tile covers them
-        if (msize <= 8) {
-            // lane (q = state, kc = one of eight slices of k): nine loads per lane in flight, three exchanges - as `for q = lane` six lanes
-            // walked MP = 68 products each in front of this wave's T phase, with the other three waves waiting at the barrier behind it
-            const int q = lane & 7, kc = lane >> 3;
+        for (int q = lane; q < msize; q += WAVE) {
             double d = 0.0;
-            if (q < msize) {
-#pragma unroll
-                for (int k0 = 0; k0 < MP; k0 += 8) { const int k = k0 + kc; if (k < MP) d = fma(Pc[midx + q + (size_t)k * ld], tvec[k], d); }
-            }
-            d += __shfl_xor(d, 8, WAVE); d += __shfl_xor(d, 16, WAVE); d += __shfl_xor(d, 32, WAVE);
-            if (kc == 0 && q < msize) dx_all[(size_t)b * ld + midx + q] = d;
-        } else {
-            for (int q = lane; q < msize; q += WAVE) {
-                double d = 0.0;
-                for (int k = 0; k < MP; ++k) d += Pc[midx + q + (size_t)k * ld] * tvec[k];
-                dx_all[(size_t)b * ld + midx + q] = d;
-            }
+            for (int k = 0; k < MP; ++k) d += Pc[midx + q + (size_t)k * ld] * tvec[k];
+            dx_all[(size_t)b * ld + midx + q] = d;
         }
     }
     if (upd) {
