@@ -56,6 +56,7 @@ __device__ __forceinline__ void augment_filter(CovView cv, int b, const double* 
     if (tid == 0) cv.n[b] = n + 6;
 }
 
+template <bool SPLIT>      // SPLIT: the composition's steps on two waves (few filters: the launch site picks it for up to 64)
 __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
     CovView cv, int b0, const double* __restrict__ Phi, const double* __restrict__ G,
     const double* __restrict__ dts, int k, const int* __restrict__ gnss_idx,
@@ -188,8 +189,14 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
         chunk_store(ci);
         lds_barrier();                                          // LDS only: the strip fragments requested above stay in flight under the composition (__syncthreads would drain them: 22 k cycles of "fetch" at 512 filters)
         if (ci == nchunk - 1) dbg_stamp(21);
-        if (tid < 64) {
-            for (int s = s0 + cnt - 1; s >= s0; --s) {
+        // Round 6 (last day): the chunk's steps in two halves on two waves - wave 0 carries the chain through the upper half while wave 1
+        // composes the lower half from the identity, Psi_L^T and Q_L = sum dt (Psi_L,s G~)(..)^T; then, on wave 0,
+        //     Psi^T <- Psi_L^T Psi_U^T   and   Q <- Q_U + Psi_U Q_L Psi_U^T = Q_U + (Psi_U^T)^T (Q_L Psi_U^T)
+        // (12 MFMAs; Psi_L^T and Q_L reach wave 0 as A fragments through LDS, everything else is the C/D = B = transposed-A identity of
+        // the layouts above).  A chunk of ten steps was 110 dependent MFMAs on one wave - 12.4 k of the kernel's 75 k cycles, and 5 of
+        // the 18 us a single filter's propagation takes; now 55 + 12.
+        auto run_steps = [&](int s_hi, int s_lo, d4& Pt, d4& Qa) __attribute__((always_inline)) {
+            for (int s = s_hi; s >= s_lo; --s) {
                 const double* sStep = sAll + (s - s0) * 405;
                 const double dt = sDt[s];
                 const bool rowok = l15 < 15;
@@ -203,16 +210,57 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
                 }
                 d4 nw = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) nw = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t4], PsiT[t4], nw, 0, 0, 0);
-                PsiT = nw;
+                for (int t4 = 0; t4 < 4; ++t4) nw = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t4], Pt[t4], nw, 0, 0, 0);
+                Pt = nw;
                 d4 X = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) X = __builtin_amdgcn_mfma_f64_16x16x4f64(gf[t4], PsiT[t4], X, 0, 0, 0);
+                for (int t4 = 0; t4 < 4; ++t4) X = __builtin_amdgcn_mfma_f64_16x16x4f64(gf[t4], Pt[t4], X, 0, 0, 0);
 #pragma unroll
-                for (int t4 = 0; t4 < 3; ++t4) Qacc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[t4], dt * X[t4], Qacc, 0, 0, 0);
+                for (int t4 = 0; t4 < 3; ++t4) Qa = __builtin_amdgcn_mfma_f64_16x16x4f64(X[t4], dt * X[t4], Qa, 0, 0, 0);
+            }
+        };
+        // (a template flag, not a run-time one: with every CU busy the second wave's products are not free - 512 filters: 40 -> 55 us -
+        // and the two-wave form behind a run-time condition still cost the full batch 19 us through its code generation alone)
+        const bool split = SPLIT && cnt >= 4;
+        const int sm = split ? s0 + cnt / 2 : s0;                // lower half [s0, sm), upper half [sm, s0 + cnt)
+        double* const sPL = sX;                                   // Psi_L^T and Q_L, 16 x 16 row-major (sX / sY are free until the A x A block)
+        double* const sQL = sY;
+        if (!SPLIT) {
+            if (tid < 64) {
+                for (int s = s0 + cnt - 1; s >= s0; --s) {
+                    const double* sStep = sAll + (s - s0) * 405;
+                    const double dt = sDt[s];
+                    const bool rowok = l15 < 15;
+                    double af[4], gf[4];
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4) {
+                        const int kk = 4 * t4 + kq;
+                        const bool ok = rowok && kk < 15;
+                        af[t4] = ok ? sStep[kk + 15 * l15] : 0.0;                               // Phi_s^T [i = l15][k = kk]
+                        gf[t4] = (ok && l15 < 12) ? sStep[225 + kk + 15 * l15] : 0.0;           // G~_s^T  [i = l15][k = kk]
+                    }
+                    d4 nw = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4) nw = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t4], PsiT[t4], nw, 0, 0, 0);
+                    PsiT = nw;
+                    d4 X = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4) X = __builtin_amdgcn_mfma_f64_16x16x4f64(gf[t4], PsiT[t4], X, 0, 0, 0);
+#pragma unroll
+                    for (int t4 = 0; t4 < 3; ++t4) Qacc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[t4], dt * X[t4], Qacc, 0, 0, 0);
+                }
             }
         }
-        else if (wv == 3 && ci == nchunk - 1) {
+        else if (tid < 64) run_steps(s0 + cnt - 1, sm, PsiT, Qacc);
+        else if (wv == 1 && split) {
+            d4 Pl = { 0.0, 0.0, 0.0, 0.0 }, Ql = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Pl[r] = (kq + 4 * r == l15) ? 1.0 : 0.0;
+            run_steps(sm - 1, s0, Pl, Ql);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sPL[(kq + 4 * r) * 16 + l15] = Pl[r]; sQL[(kq + 4 * r) * 16 + l15] = Ql[r]; }      // C/D: element (kq + 4 r, l15)
+        }
+        if (wv == 3 && ci == nchunk - 1) {
             // beside wave 0's first chunk: the 5 x 5 clock block's recursion over ALL steps (sequential in the steps, :56-86 and
             // :99-116 composed), one element per lane of wave 3: lane e = 5 a + c holds qg[a][c]; a step is two lane exchanges
             // (row 4 into the present rows, then the updated column 4 into the present columns) and the noise terms.
@@ -239,7 +287,23 @@ __global__ __launch_bounds__(PROP_THREADS) void k_propagate(
             if (el) sQg[lane] = v;
             if (lane == 0) sQg[25] = Tg;
         }
-        lds_barrier();                                        // the chunk's LDS may be overwritten
+        lds_barrier();                                        // the chunk's LDS may be overwritten; wave 1's half is in LDS
+        if (split) {
+            if (tid < 64) {
+                double al[4], aq[4];
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) { al[t4] = sPL[l15 * 16 + 4 * t4 + kq]; aq[t4] = sQL[l15 * 16 + 4 * t4 + kq]; }      // A[i = l15][k = 4 t4 + kq]
+                d4 Z = { 0.0, 0.0, 0.0, 0.0 }, Pn = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) Z = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[t4], PsiT[t4], Z, 0, 0, 0);            // Q_L Psi_U^T
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) Qacc = __builtin_amdgcn_mfma_f64_16x16x4f64(PsiT[t4], Z[t4], Qacc, 0, 0, 0);      // + (Psi_U^T)^T (Q_L Psi_U^T)
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(al[t4], PsiT[t4], Pn, 0, 0, 0);          // Psi_L^T Psi_U^T
+                PsiT = Pn;
+            }
+            lds_barrier();                                    // sPL / sQL may be rewritten by the next chunk
+        }
     }
     dbg_stamp(17);
     // the composed step into Phi_A / Q_A: wave 0 its 15 x 15 blocks, 25 lanes of wave 1 the GNSS clock block (position of clock state g
@@ -570,9 +634,12 @@ void launch_propagate(CovView cv, int b0, int nb, int n_cap, const double* Phi, 
 {
     const int tiles = (n_cap + PROP_THREADS - 1) / PROP_THREADS;
     const bool fuse = augR && tiles == 1;
-    hipLaunchKernelGGL(k_propagate, dim3(tiles, nb), dim3(PROP_THREADS), 0, st, cv, b0, Phi, G, dt, k, gnss_idx,
+if (nb <= 64) {     hipLaunchKernelGGL(k_propagate<true>, dim3(tiles, nb), dim3(PROP_THREADS), 0, st, cv, b0, Phi, G, dt, k, gnss_idx,
                        sigma[0], sigma[1], sigma[2], sigma[3], enable_gnss, scb, srw, fuse ? augR : nullptr, status_clear,
-                       fuse ? snap : nullptr, n_snap);
+                       fuse ? snap : nullptr, n_snap); }
+    else {     hipLaunchKernelGGL(k_propagate<false>, dim3(tiles, nb), dim3(PROP_THREADS), 0, st, cv, b0, Phi, G, dt, k, gnss_idx,
+                       sigma[0], sigma[1], sigma[2], sigma[3], enable_gnss, scb, srw, fuse ? augR : nullptr, status_clear,
+                       fuse ? snap : nullptr, n_snap); }
     if (augR && !fuse) hipLaunchKernelGGL(k_augment, dim3(nb), dim3(256), 0, st, cv, b0, augR);
 }
 bool propagate_can_restore(int n_cap) { return (n_cap + PROP_THREADS - 1) / PROP_THREADS == 1; }

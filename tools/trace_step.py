@@ -3,7 +3,7 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('k_propagate')]
+idx = [i for i, r in enumerate(rows) if 'k_propagate' in r['Kernel_Name']]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 i0, i1 = idx[-k - 1], idx[-k]
 t0 = int(rows[i0]['Start_Timestamp'])
