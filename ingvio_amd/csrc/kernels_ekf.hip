@@ -49,11 +49,32 @@ __global__ __launch_bounds__(EKF_THREADS) void k_ekf_core(
     for (int c = tid; c < nc; c += EKF_THREADS) sCol[c] = cm[c];
     __syncthreads();
     // ---- K8: PH^T -> Y (n x m, column-major, ld) ------------------------------------------
+    // Small updates (the in-frame GNSS update: 16 rows, 15 columns) used to walk these loops one dependent global round trip at a time -
+    // a load of P (or W) and IB of H per column here, two loads per column for S, and in the substitution at the end every x_k read
+    // back from the Y it had just been stored to (m^2 / 2 serialized loads per state row): 42 us per 512 filters for 0.1 MFLOP each.
+    // With nc <= 16 / m <= 16 a thread's operands are requested together and kept in registers; the sums run in the same order
+    // (bit-identical results).  Larger updates take the loops as they were.
+    const bool small_c = nc <= 16, small_m = m <= 16;
     for (int r = tid; r < n; r += EKF_THREADS) {
+        double pr[16];
+        if (small_c) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { const int cc = c < nc ? c : 0; pr[c] = W ? W[r + (size_t)cc * ld] : P[r + (size_t)sCol[cc] * ld]; }
+        }
         for (int ib = 0; ib < m; ib += IB) {
             double acc[IB];
 #pragma unroll
             for (int ii = 0; ii < IB; ++ii) acc[ii] = 0.0;
+            if (small_c) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    if (c < nc) {
+                        const double* hc = H + (size_t)c * mld + ib;
+#pragma unroll
+                        for (int ii = 0; ii < IB; ++ii) acc[ii] += pr[c] * hc[ii];
+                    }
+                }
+            } else
             for (int c = 0; c < nc; ++c) {
                 const double p = W ? W[r + (size_t)c * ld] : P[r + (size_t)sCol[c] * ld];
                 const double* hc = H + (size_t)c * mld + ib;      // rows ib.. of column c (zero padded to mld)
@@ -70,6 +91,13 @@ __global__ __launch_bounds__(EKF_THREADS) void k_ekf_core(
         const int i = e % m, i2 = e / m;
         if (i < i2) continue;
         double acc = 0.0;
+        if (small_c) {
+            double hv[16], yv[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { const int cc = c < nc ? c : 0; hv[c] = H[i + (size_t)cc * mld]; yv[c] = Y[sCol[cc] + (size_t)i2 * ld]; }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) if (c < nc) acc += hv[c] * yv[c];
+        } else
         for (int c = 0; c < nc; ++c) acc += H[i + (size_t)c * mld] * Y[sCol[c] + (size_t)i2 * ld];
         if (r_kind == 0) { if (i == i2) acc += noise[0]; }
         else if (r_kind == 1) { if (i == i2) acc += noise[i]; }
@@ -121,6 +149,23 @@ __global__ __launch_bounds__(EKF_THREADS) void k_ekf_core(
     // ---- Y = PHT L^-T (row-wise forward substitution), dx = Y z -----------------------------
     for (int r = tid; r < n; r += EKF_THREADS) {
         double d = 0.0;
+        if (small_m) {
+            double y[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) y[j] = Y[r + (size_t)(j < m ? j : 0) * ld];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j < m) {
+                    double x = y[j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) x -= sS[j * LS + k] * y[k];
+                    x /= sS[j * LS + j];
+                    y[j] = x;
+                    Y[r + (size_t)j * ld] = x;
+                    d += x * sS[m * LS + j];
+                }
+            }
+        } else
         for (int j = 0; j < m; ++j) {
             double x = Y[r + (size_t)j * ld];
             for (int k = 0; k < j; ++k) x -= sS[j * LS + k] * Y[r + (size_t)k * ld];
